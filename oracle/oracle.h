@@ -1,0 +1,149 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain scalar C++17, one sample per loop iteration, OpenMP over samples) of the
+ * psdr-jit PathTracer.renderC / renderD hot path, used ONLY as the checker in tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg.  The shipped product
+ * (psdr_jit_amd/, include/psdr_hip.h) never includes, links or calls anything in oracle/.
+ *
+ * PARITY UNPINNED: the reference cannot be compiled or imported in this environment (its drjit
+ * submodule is empty and un-pinned, it needs CUDA+OptiX, and it ships no tests, golden images or
+ * known-answer vectors).  This restatement follows the reference sources cited next to every
+ * function and is pinned only by analytic known-answer tests (tests/test_oracle_kat.py).
+ *
+ * C ABI so that tests can drive it through ctypes.  All matrices are row-major float[16].
+ * "d_*" members are the forward-mode tangent of the member they shadow with respect to ONE scalar
+ * scene parameter (the reference obtains the same quantity with drjit.forward_to, README.md:87-104).
+ */
+#ifndef ORC_ORACLE_H
+#define ORC_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_mesh {            /* reference Mesh, include/psdr/shape/mesh.h:13-146 */
+    int n_vertices, n_faces, n_uvs;
+    const float *vertices;           /* [n_vertices*3] object space (m_vertex_positions_raw) */
+    const float *d_vertices;         /* optional tangent, may be NULL */
+    const int *faces;                /* [n_faces*3] */
+    const float *uvs;                /* [n_uvs*2] or NULL */
+    const int *face_uvs;             /* [n_faces*3] or NULL */
+    float to_world_left[16], to_world_raw[16], to_world_right[16];
+    float d_to_world_left[16], d_to_world_raw[16], d_to_world_right[16];
+    int bsdf_id;
+    int emitter_id;                  /* index into orc_scene_desc.emitters, -1 = not a light */
+    int use_face_normals;            /* m_use_face_normals (default 0) */
+    int enable_edges;                /* m_enable_edges (default 1) */
+} orc_mesh;
+
+typedef struct orc_bsdf {            /* Diffuse, include/psdr/bsdf/diffuse.h */
+    int type;                        /* 0 = diffuse */
+    float reflectance[3], d_reflectance[3];
+    int two_sided;
+} orc_bsdf;
+
+typedef struct orc_emitter {         /* AreaLight, include/psdr/emitter/area.h */
+    float radiance[3], d_radiance[3];
+} orc_emitter;
+
+typedef struct orc_camera {          /* PerspectiveCamera(fov_x, near, far) */
+    float fov_x, near_clip, far_clip;
+    float to_world_left[16], to_world_raw[16], to_world_right[16];
+    float d_to_world_left[16], d_to_world_raw[16], d_to_world_right[16];
+} orc_camera;
+
+typedef struct orc_scene_desc {
+    int n_meshes;   const orc_mesh *meshes;
+    int n_bsdfs;    const orc_bsdf *bsdfs;
+    int n_emitters; const orc_emitter *emitters;
+    int n_cameras;  const orc_camera *cameras;
+    int width, height, spp, sppe, sppse;   /* RenderOption, include/psdr/types.h:217-228 */
+} orc_scene_desc;
+
+/* One of the reference's three N-lane samplers (Scene::m_samplers[0..2]) in closed form:
+ * lane i was seeded with seed_value = seed + (pix_ids ? pix_ids[i / spp] : i)   (integrator.cpp:24-28)
+ * and has already produced `skip` numbers since then (m_samplers is mutable state that every
+ * render call advances, scene.h:76). */
+typedef struct orc_sampler {
+    uint64_t seed;
+    uint64_t skip;
+} orc_sampler;
+
+typedef struct orc_scene orc_scene;
+
+/* = Scene::configure(active_sensor) (scene.cpp:311-601).  Primary-edge lists are kept only for the
+ * sensors listed in active_sensors (scene.cpp:381-405).  Returns NULL on error. */
+orc_scene *orc_scene_create(const orc_scene_desc *desc, const int *active_sensors, int n_active);
+void orc_scene_destroy(orc_scene *s);
+const char *orc_last_error(void);
+void orc_set_num_threads(int n);     /* 0 = OpenMP default */
+int orc_get_num_threads(void);
+
+/* --- introspection used by the parity tests on the configured snapshot --- */
+int orc_num_triangles(const orc_scene *s);
+int orc_num_sec_edges(const orc_scene *s);
+int orc_num_primary_edges(const orc_scene *s, int sensor_id);
+/* 25 floats per triangle: p0 e1 e2 n0 n1 n2 face_normal (3 each), face_area, then 3 ints bit-cast
+ * (face_indices); `tangent` selects the d/dparam of the float fields. */
+void orc_get_triangle_info(const orc_scene *s, int tangent, float *out);
+/* 16 floats per edge: p0 e1 n0 n1 p2 (3 each), is_boundary */
+void orc_get_sec_edges(const orc_scene *s, int tangent, float *out);
+/* 7 floats per edge: p0.xy p1.xy normal.xy length */
+void orc_get_primary_edges(const orc_scene *s, int sensor_id, int tangent, float *out);
+/* mesh-local edge list of mesh m: 5 ints per edge (v0 v1 f0 f1 opp); returns count */
+int orc_get_mesh_edges(const orc_scene *s, int mesh, int *out, int cap);
+float orc_emitter_sampling_weight(const orc_scene *s, int emitter);
+
+/* closest-hit query (Scene_OptiX::ray_intersect restated, scene_optix.cpp:343-410):
+ * out_tri = global triangle id or -1, out_uv barycentrics, out_t distance. use_bvh: 0 = brute force. */
+void orc_trace(const orc_scene *s, int n, const float *o, const float *d, int use_bvh,
+               int *out_tri, float *out_uv, float *out_t);
+
+/* which terms of renderD to evaluate (bit mask) */
+#define ORC_TERM_INTERIOR 1
+#define ORC_TERM_PRIMARY  2
+#define ORC_TERM_SECONDARY 4
+
+/* = Integrator::renderC (integrator.cpp:12-48).  pix_ids == NULL renders the full frame
+ * (out_rgb is [H*W*3], pixel-interleaved, pixel = y*W + x); otherwise the batch path
+ * (__render_batch, integrator.cpp:139-176) with out_rgb [n_pix*3].
+ * Only lanes in [lane_begin, lane_end) are evaluated (lane_end < 0 = all) so that a partition of
+ * the lane range can be checked to sum to the full image (multi-GPU sharding). */
+int orc_render_c(const orc_scene *s, int sensor_id, int max_depth, int hide_emitters,
+                 orc_sampler sampler, const int *pix_ids, int n_pix,
+                 int64_t lane_begin, int64_t lane_end, float *out_rgb);
+
+/* = Integrator::renderD (integrator.cpp:51-100) followed by drjit.forward_to(img):
+ * out_rgb = image, out_drgb = d image / d parameter.  samplers[0..2] = interior / primary edge /
+ * secondary edge.  guiding: handle from orc_guiding_build or NULL. */
+typedef struct orc_guiding orc_guiding;
+int orc_render_d(const orc_scene *s, int sensor_id, int max_depth, int hide_emitters,
+                 const orc_sampler samplers[3], const int *pix_ids, int n_pix,
+                 const orc_guiding *guiding, int terms,
+                 int shard_rank, int shard_count,   /* lanes [N*r/c, N*(r+1)/c) of each sampler; c<=1 = all */
+                 float *out_rgb, float *out_drgb);
+
+/* per-lane radiance of the interior term (debug/parity aid): out [n_lanes*3] */
+int orc_li_lanes(const orc_scene *s, int sensor_id, int max_depth, int hide_emitters,
+                 orc_sampler sampler, int64_t lane_begin, int64_t lane_end, float *out);
+
+/* = PathTracer::preprocess_secondary_edges (path.cpp:130-168) */
+orc_guiding *orc_guiding_build(const orc_scene *s, int sensor_id, int max_depth,
+                               const int reso[4], int nrounds, int seed);
+int orc_guiding_num_cells(const orc_guiding *g);
+void orc_guiding_get_mass(const orc_guiding *g, float *out);
+void orc_guiding_destroy(orc_guiding *g);
+
+/* building blocks exposed for known-answer tests */
+uint64_t orc_tea64(uint64_t v0, uint64_t v1);
+void orc_pcg32_raw(uint64_t initstate, uint64_t initseq, int n, uint32_t *out);
+void orc_sampler_floats(uint64_t seed_value, uint64_t lane, uint64_t skip, int n, float *out);
+void orc_square_to_cosine_hemisphere(int n, const float *uv, float *out_xyz);
+void orc_square_to_uniform_triangle(int n, const float *uv, float *out_ab);
+void orc_coordinate_system(const float n[3], float s[3], float t[3]);
+int orc_distrb_sample_reuse(int size, const float *pmf, float *sample_inout, float *pdf_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

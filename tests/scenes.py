@@ -1,0 +1,132 @@
+"""Scene descriptions shared by the tests: the README Cornell box (reference README.md:54-85,
+8 meshes / 36 triangles / 66 mesh edges) and the tutorial sphere box (tutorials/Forward_AD.ipynb
+cells 2-5, 652 triangles).  Geometry comes from the OBJ data files under psdr_jit_amd/data/cbox.
+
+The OBJ reader here is the tests' own (fan triangulation = what an ear-clipping triangulator
+yields for convex polygons, which is what the reference gets from tinyobj)."""
+import os
+
+import numpy as np
+
+from oracle.oracle import BsdfSpec, CameraSpec, EmitterSpec, MeshSpec, SceneSpec
+
+DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "psdr_jit_amd", "data", "cbox")
+
+
+def load_obj(path):
+    v, vt, f, fuv = [], [], [], []
+    with open(path) as fh:
+        for line in fh:
+            p = line.split()
+            if not p:
+                continue
+            if p[0] == "v":
+                v.append([float(x) for x in p[1:4]])
+            elif p[0] == "vt":
+                vt.append([float(x) for x in p[1:3]])
+            elif p[0] == "f":
+                idx = [q.split("/") for q in p[1:]]
+                vi = [int(q[0]) - 1 for q in idx]
+                ti = [int(q[1]) - 1 if len(q) > 1 and q[1] != "" else -1 for q in idx]
+                for k in range(1, len(vi) - 1):
+                    f.append([vi[0], vi[k], vi[k + 1]])
+                    fuv.append([ti[0], ti[k], ti[k + 1]])
+    v = np.asarray(v, dtype=np.float32)
+    f = np.asarray(f, dtype=np.int32)
+    if vt:
+        return v, f, np.asarray(vt, dtype=np.float32), np.asarray(fuv, dtype=np.int32)
+    return v, f, None, None
+
+
+def translate(x, y, z):
+    m = np.eye(4, dtype=np.float32)
+    m[:3, 3] = [x, y, z]
+    return m
+
+
+def _mesh(name, bsdf, emitter=-1, raw=None):
+    path = os.path.join(DATA, name)
+    v, f, uv, fuv = load_obj(path)
+    m = MeshSpec(vertices=v, faces=f, uvs=uv, face_uvs=fuv, bsdf=bsdf, emitter=emitter, path=path)
+    if raw is not None:
+        m.to_world_raw = raw
+    return m
+
+
+def cbox_scene(width=128, height=128, spp=4, sppe=0, sppse=0, param="light_x"):
+    """README scene.  param selects the scalar the tangent data refers to:
+       'light_x'  : Mesh[0].to_world_left = T(100*P, 0, 0), P = 0   (README.md:87-90)
+       'box_x'    : same for Mesh[1] (small box)
+       'albedo'   : d red-wall reflectance / dP = (1,1,1)
+       'radiance' : d light radiance / dP = (1,1,1)
+       'camera_x' : camera to_world_left = T(100*P, 0, 0)
+       None       : no tangent."""
+    bsdfs = [BsdfSpec((0.0, 0.0, 0.0), name="light"), BsdfSpec((0.5, 0.5, 0.5), name="cat"),
+             BsdfSpec((0.95, 0.95, 0.95), name="white"), BsdfSpec((0.20, 0.90, 0.20), name="green"),
+             BsdfSpec((0.90, 0.20, 0.20), name="red")]
+    emitters = [EmitterSpec((20.0, 20.0, 8.0))]
+    meshes = [
+        _mesh("cbox_luminaire.obj", 0, emitter=0, raw=translate(0.0, -0.5, 0.0)),
+        _mesh("cbox_smallbox.obj", 1), _mesh("cbox_largebox.obj", 1),
+        _mesh("cbox_floor.obj", 2), _mesh("cbox_ceiling.obj", 2), _mesh("cbox_back.obj", 2),
+        _mesh("cbox_greenwall.obj", 3), _mesh("cbox_redwall.obj", 4),
+    ]
+    cam = CameraSpec(60.0, 0.000001, 10000000.0, to_world_raw=translate(208.0, 273.0, -800.0))
+    dT = np.zeros((4, 4), dtype=np.float32)
+    dT[0, 3] = 100.0
+    if param == "light_x":
+        meshes[0].d_to_world_left = dT
+    elif param == "box_x":
+        meshes[1].d_to_world_left = dT
+    elif param == "albedo":
+        bsdfs[4].d_reflectance = (1.0, 1.0, 1.0)
+    elif param == "radiance":
+        emitters[0].d_radiance = (1.0, 1.0, 1.0)
+    elif param == "camera_x":
+        cam.d_to_world_left = dT
+    elif param is not None:
+        raise ValueError(param)
+    return SceneSpec(meshes, bsdfs, emitters, [cam], width, height, spp, sppe, sppse)
+
+
+def set_param_value(spec, param, P):
+    """Return the spec with the scalar parameter moved to value P (for finite differences)."""
+    import copy
+    s = copy.deepcopy(spec)
+    if param == "light_x":
+        s.meshes[0].to_world_left = translate(100.0 * P, 0, 0)
+    elif param == "box_x":
+        s.meshes[1].to_world_left = translate(100.0 * P, 0, 0)
+    elif param == "albedo":
+        r = s.bsdfs[4].reflectance
+        s.bsdfs[4].reflectance = (r[0] + P, r[1] + P, r[2] + P)
+    elif param == "radiance":
+        r = s.emitters[0].radiance
+        s.emitters[0].radiance = (r[0] + P, r[1] + P, r[2] + P)
+    elif param == "camera_x":
+        s.cameras[0].to_world_left = translate(100.0 * P, 0, 0)
+    else:
+        raise ValueError(param)
+    return s
+
+
+def sphere_scene(width=512, height=512, spp=32, sppe=32, sppse=32):
+    """tutorials/Forward_AD.ipynb cells 2-5: 8 meshes, 652 triangles; the notebook logs
+    '(79) primary edges initialized' and '990 secondary edges initialized'."""
+    bsdfs = [BsdfSpec((0.2, 0.9, 0.9), name="sphere_large"), BsdfSpec((0.5, 0.5, 0.5), name="back"),
+             BsdfSpec((0.5, 0.5, 0.5), name="light"), BsdfSpec((0.9, 0.6, 0.1), name="sphere_small"),
+             BsdfSpec((0.95, 0.95, 0.95), name="white"), BsdfSpec((0.2, 0.9, 0.2), name="green"),
+             BsdfSpec((0.9, 0.2, 0.2), name="red")]
+    emitters = [EmitterSpec((20.0, 20.0, 8.0))]
+    meshes = [
+        _mesh("cbox_luminaire.obj", 2, emitter=0, raw=translate(0.0, -0.5, 0.0)),
+        _mesh("cbox_smallball.obj", 3), _mesh("cbox_largeball.obj", 0),
+        _mesh("cbox_floor.obj", 4), _mesh("cbox_ceiling.obj", 4), _mesh("cbox_back.obj", 1),
+        _mesh("cbox_greenwall.obj", 5), _mesh("cbox_redwall.obj", 6),
+    ]
+    dT = np.zeros((4, 4), dtype=np.float32)
+    dT[0, 3] = 100.0
+    meshes[0].d_to_world_left = dT
+    meshes[1].d_to_world_left = dT
+    cam = CameraSpec(60.0, 0.000001, 10000000.0, to_world_raw=translate(278.0, 273.0, -500.0))
+    return SceneSpec(meshes, bsdfs, emitters, [cam], width, height, spp, sppe, sppse)
