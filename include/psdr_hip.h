@@ -1,0 +1,187 @@
+/* psdr_hip.h — C ABI of libpsdr_hip.so: the MI355X (gfx950) implementation of psdr-jit's
+ * PathTracer.renderC / renderD hot path.
+ *
+ * The reference has no FFI seam for this path (Python -> pybind11 -> C++ virtuals -> drjit/OptiX,
+ * reference src/psdr.cpp:100-441); the seam below is the one SURVEY.md §8(b) specifies: a POD
+ * "configured-scene snapshot" (= what Scene::configure leaves in Scene's public SoA members,
+ * reference include/psdr/scene/scene.h:56-90) plus render entry points that replace
+ *   Integrator::renderC / renderD            reference src/integrator/integrator.cpp:12-100
+ *   Integrator::__render / __render_batch    reference src/integrator/integrator.cpp:103-176
+ *   Integrator::render_primary_edges         reference src/integrator/integrator.cpp:179-198
+ *   PathTracer::__Li                         reference src/integrator/path.cpp:35-127
+ *   PathTracer::render_secondary_edges       reference src/integrator/path.cpp:171-294
+ *   PathTracer::preprocess_secondary_edges   reference src/integrator/path.cpp:130-168
+ *   Scene::ray_intersect + Scene_OptiX       reference src/scene/scene.cpp:612-806, scene_optix.cpp:265-410
+ *
+ * Conventions: every function returns 0 on success, non-zero on error (message via
+ * psdr_hip_last_error(), which mirrors psdr_jit::Exception's text, reference include/misc/Exception.h).
+ * All pointers inside psdr_scene_snapshot are HOST pointers owned by the caller and are copied
+ * during psdr_hip_scene_create.  Image buffers passed to the render calls are DEVICE pointers
+ * owned by the caller (e.g. a torch tensor's data_ptr); `stream` is a hipStream_t (NULL = default
+ * stream).  No call synchronises the device.  Float data is IEEE float32, indices int32, RNG state uint64.
+ * Matrices are row-major float[16].  Tangent ("d_") arrays hold d(value)/d(theta) for ONE scalar scene
+ * parameter theta (forward mode; the reference gets the same from drjit.forward_to) and may be NULL.
+ */
+#ifndef PSDR_HIP_H
+#define PSDR_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSDR_HIP_ABI_VERSION 1
+
+/* TriangleInfo SoA, reference include/psdr/types.h:162-175 (+ Scene::m_triangle_uv,
+ * m_triangle_face_normals, scene.cpp:528-542).  Arrays of n_triangles rows. */
+typedef struct psdr_triangles {
+    int32_t n_triangles;
+    const float *p0, *e1, *e2, *n0, *n1, *n2, *face_normal;   /* [n*3] each */
+    const float *face_area;                                   /* [n]   */
+    const float *uv;                                          /* [n*6] uv0 uv1 uv2, zeros if no uv */
+    const int32_t *mesh_id;                                   /* [n]   */
+    const uint8_t *use_face_normal;                           /* [n]   */
+    /* forward tangents (NULL = none) */
+    const float *d_p0, *d_e1, *d_e2, *d_n0, *d_n1, *d_n2, *d_face_normal, *d_face_area;
+} psdr_triangles;
+
+typedef struct psdr_mesh_rec {       /* what the kernels need of reference Mesh (mesh.h:82-141) */
+    int32_t bsdf_id;                 /* -1 = none */
+    int32_t emitter_id;              /* -1 = not an emitter */
+    int32_t face_offset, n_faces;    /* rows of psdr_triangles */
+    float inv_total_area;            /* Mesh::m_inv_total_area */
+    /* Mesh::m_face_distrb (DiscreteDistribution over faces ~ area); used when emitter_id >= 0 */
+    int32_t distrb_offset;           /* into psdr_scene_snapshot.face_pmf / face_cmf */
+    float distrb_sum;
+} psdr_mesh_rec;
+
+typedef struct psdr_bsdf_rec {       /* Diffuse, reference src/bsdf/diffuse.cpp */
+    int32_t type;                    /* 0 = diffuse */
+    int32_t two_sided;
+    float reflectance[3], d_reflectance[3];
+} psdr_bsdf_rec;
+
+typedef struct psdr_emitter_rec {    /* AreaLight, reference src/emitter/area.cpp */
+    int32_t mesh_id;
+    float sampling_weight;           /* normalised, scene.cpp:511-514 */
+    float radiance[3], d_radiance[3];
+} psdr_emitter_rec;
+
+/* SecondaryEdgeInfo SoA, reference include/psdr/edge/edge.h:49-68 */
+typedef struct psdr_sec_edges {
+    int32_t n_edges;
+    const float *p0, *e1, *n0, *n1, *p2;      /* [n*3] */
+    const uint8_t *is_boundary;               /* [n] */
+    const float *d_p0, *d_e1;                 /* tangents used by the estimator */
+    const float *pmf, *cmf;                   /* Scene::m_sec_edge_distrb, [n] */
+    float sum;
+} psdr_sec_edges;
+
+/* PerspectiveCamera after configure(), reference src/sensor/perspective.cpp:10-152 */
+typedef struct psdr_sensor_rec {
+    float sample_to_camera[16];
+    float to_world[16], d_to_world[16];
+    float world_to_sample[16], d_world_to_sample[16];
+    float cam_pos[3], cam_dir[3];
+    float inv_area;
+    /* PrimaryEdgeInfo (edge.h:27-40) + Sensor::m_edge_distrb; n_edges == 0 disables the term */
+    int32_t n_edges;
+    const float *edge_p0, *edge_p1;           /* [n*2] sample-space end points */
+    const float *d_edge_p0, *d_edge_p1;       /* [n*2] tangents */
+    const float *edge_normal;                 /* [n*2] */
+    const float *edge_length;                 /* [n] */
+    const float *edge_pmf, *edge_cmf;         /* [n] */
+    float edge_sum;
+} psdr_sensor_rec;
+
+typedef struct psdr_scene_snapshot {
+    int32_t abi_version;                      /* PSDR_HIP_ABI_VERSION */
+    int32_t width, height, spp, sppe, sppse;  /* RenderOption, reference include/psdr/types.h:217-228 */
+    psdr_triangles tris;
+    int32_t n_meshes;   const psdr_mesh_rec *meshes;
+    int32_t n_bsdfs;    const psdr_bsdf_rec *bsdfs;
+    int32_t n_emitters; const psdr_emitter_rec *emitters;
+    const float *emitter_pmf, *emitter_cmf;   /* Scene::m_emitters_distrb, [n_emitters] */
+    float emitter_sum;
+    int32_t n_face_distrb;                    /* total length of the concatenated face CDFs */
+    const float *face_pmf, *face_cmf;
+    psdr_sec_edges sec_edges;
+    int32_t n_sensors;  const psdr_sensor_rec *sensors;
+} psdr_scene_snapshot;
+
+/* One of Scene::m_samplers[0..2] in closed form: lane i was seeded with
+ * seed_value = seed + (pix_ids ? pix_ids[i / spp] : i) (integrator.cpp:24-28, scene.cpp:330-344)
+ * and has already produced `skip` numbers.  The kernels never store per-lane RNG state. */
+typedef struct psdr_sampler {
+    uint64_t seed;
+    uint64_t skip;
+} psdr_sampler;
+
+#define PSDR_TERM_INTERIOR  1
+#define PSDR_TERM_PRIMARY   2
+#define PSDR_TERM_SECONDARY 4
+
+typedef struct psdr_hip_scene psdr_hip_scene;      /* device-resident scene + BVH */
+typedef struct psdr_hip_guiding psdr_hip_guiding;  /* device-resident HyperCubeDistribution3f */
+
+typedef struct psdr_render_args {
+    int32_t sensor_id;
+    int32_t max_depth;            /* PathTracer(max_depth) */
+    int32_t hide_emitters;        /* PathTracer::m_hide_emitters */
+    psdr_sampler samplers[3];     /* interior / primary edge / secondary edge */
+    const int32_t *pix_ids;       /* DEVICE pointer, batch_pix (integrator.cpp:139-176); NULL = full frame */
+    int32_t n_pix;
+    int32_t terms;                /* PSDR_TERM_* mask (renderD only) */
+    int32_t shard_rank, shard_count;  /* evaluate lanes [N*r/c, N*(r+1)/c) of each sampler; count<=1 = all */
+    const psdr_hip_guiding *guiding;  /* NULL = unguided secondary edges */
+    int32_t zero_output;          /* 1: the call clears out buffers first (hipMemsetAsync on `stream`) */
+} psdr_render_args;
+
+/* counters of the instrumented build: filled by psdr_hip_render_*_counted */
+typedef struct psdr_counters {
+    uint64_t rays, nodes_visited, tris_tested, shaded_hits;
+} psdr_counters;
+
+const char *psdr_hip_last_error(void);
+int psdr_hip_abi_version(void);
+int psdr_hip_device_count(void);
+int psdr_hip_set_device(int device);
+
+/* replaces Scene_OptiX::configure (GAS build) + the jit uploads of Scene::configure */
+int psdr_hip_scene_create(const psdr_scene_snapshot *snapshot, psdr_hip_scene **out);
+int psdr_hip_scene_destroy(psdr_hip_scene *scene);
+/* BVH statistics for DESIGN/bench: nodes, leaves, max depth, bytes resident in LDS per workgroup */
+int psdr_hip_scene_stats(const psdr_hip_scene *scene, int32_t *n_nodes, int32_t *n_leaves, int32_t *max_depth, int32_t *lds_bytes);
+
+/* closest hit for a batch of rays (device arrays o[n*3], d[n*3] -> tri[n], uv[n*2], t[n]); parity aid */
+int psdr_hip_trace(const psdr_hip_scene *scene, int32_t n, const float *o, const float *d,
+                   int32_t *out_tri, float *out_uv, float *out_t, void *stream);
+
+/* Integrator::renderC: out_rgb is [n_pixels*3] float32, pixel-interleaved, pixel = y*W + x */
+int psdr_hip_render_c(const psdr_hip_scene *scene, const psdr_render_args *args, float *out_rgb, void *stream);
+/* Integrator::renderD + forward derivative: out_rgb = image, out_drgb = d image / d theta */
+int psdr_hip_render_d_fwd(const psdr_hip_scene *scene, const psdr_render_args *args,
+                          float *out_rgb, float *out_drgb, void *stream);
+/* same kernels with traversal counters enabled (slower; counters is a HOST struct, call synchronises) */
+int psdr_hip_render_c_counted(const psdr_hip_scene *scene, const psdr_render_args *args, float *out_rgb,
+                              psdr_counters *counters, void *stream);
+int psdr_hip_render_d_fwd_counted(const psdr_hip_scene *scene, const psdr_render_args *args, float *out_rgb,
+                                  float *out_drgb, psdr_counters *counters, void *stream);
+/* per-lane radiance of the interior term, out [n_lanes*3] (device); parity aid */
+int psdr_hip_li_lanes(const psdr_hip_scene *scene, const psdr_render_args *args, int64_t lane_begin, int64_t lane_end,
+                      float *out, void *stream);
+
+/* PathTracer::preprocess_secondary_edges: reso = {rx, ry, rz, samples per cell} */
+int psdr_hip_guiding_build(const psdr_hip_scene *scene, int32_t sensor_id, int32_t max_depth, const int32_t reso[4],
+                           int32_t nrounds, int32_t seed, psdr_hip_guiding **out, void *stream);
+int psdr_hip_guiding_mass(const psdr_hip_guiding *g, float *out_host, int32_t cap);   /* returns n_cells via cap check */
+int psdr_hip_guiding_num_cells(const psdr_hip_guiding *g);
+int psdr_hip_guiding_destroy(psdr_hip_guiding *g);
+
+/* sampler building blocks (host side, bit-exact with the kernels): known-answer tests */
+uint64_t psdr_hip_tea64(uint64_t v0, uint64_t v1);
+int psdr_hip_sampler_floats(uint64_t seed_value, uint64_t lane, uint64_t skip, int32_t n, float *out_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSDR_HIP_H */

@@ -267,9 +267,12 @@ class OracleScene:
             raise RuntimeError(L.orc_last_error().decode())
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_scene_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().orc_scene_destroy(self._h)
+                self._h = None
+        except Exception:      # interpreter shutdown
+            pass
 
     # ---- snapshot introspection
     @property
@@ -369,9 +372,12 @@ class OracleGuiding:
         return out
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_guiding_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().orc_guiding_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
 
 
 # ------------------------------------------------------------------ KAT helpers

@@ -238,6 +238,7 @@ int orc_render_d(const orc_scene *s, int sensor_id, int max_depth, int hide, con
                     float dv = v[c].d;
                     if (pdf0 > Epsilon) dv /= pdf0;
                     if (sc.sppse > 1) dv /= (float) sc.sppse;
+                    if (!std::isfinite(dv)) dv = 0.f;
                     val[3 * o + c] = dv;
                 }
             }

@@ -33,6 +33,30 @@ template <typename T> static void coordinate_system(const V3<T> &n, V3<T> &s, V3
 template <bool ad> static V3<Real<ad>> to_local(const Frame<ad> &f, const V3<Real<ad>> &v) { return {dot(v, f.s), dot(v, f.t), dot(v, f.n)}; }
 template <bool ad> static V3<Real<ad>> to_world(const Frame<ad> &f, const V3<Real<ad>> &v) { return f.s * v.x + f.t * v.y + f.n * v.z; }
 
+// drjit::sincos is not libm: drjit evaluates the Cephes single-precision kernels (S. Moshier, sinf.c /
+// cosf.c: octant reduction with the 3-term extended-precision pi/4 split, degree-3 polynomials in z=x^2).
+// drjit is absent from /root/reference, so the published Cephes algorithm is restated here with every
+// multiply-add written as an explicit fma; the HIP path states the same algorithm, which makes the two
+// agree bit-for-bit on this step.
+static void sincos_cephes(float xx, float &s_out, float &c_out) {
+    const float FOPI = 1.27323954473516f, DP1 = 0.78515625f, DP2 = 2.4187564849853515625e-4f, DP3 = 3.77489497744594108e-8f;
+    float x = fabs(xx);
+    int j = (int) (FOPI * x);
+    float y = (float) j;
+    if (j & 1) { j += 1; y += 1.0f; }
+    j &= 7;
+    float sign_s = xx < 0.f ? -1.f : 1.f, sign_c = 1.f;
+    if (j > 3) { sign_s = -sign_s; sign_c = -sign_c; j -= 4; }
+    if (j > 1) sign_c = -sign_c;
+    x = fma_(-y, DP1, x); x = fma_(-y, DP2, x); x = fma_(-y, DP3, x);
+    const float z = x * x;
+    const float ps = fma_(fma_(fma_(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, x, x);
+    const float pc = fma_(fma_(fma_(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fma_(-0.5f, z, 1.0f));
+    const bool swap = (j == 1) || (j == 2);
+    s_out = sign_s * (swap ? pc : ps);
+    c_out = sign_c * (swap ? ps : pc);
+}
+
 // warp.h:16-63
 static V3f square_to_cosine_hemisphere(float sx, float sy) {
     float x = fma_(2.f, sx, -1.f), y = fma_(2.f, sy, -1.f);
@@ -41,7 +65,8 @@ static V3f square_to_cosine_hemisphere(float sx, float sy) {
     float phi = .25f * Pi * rp / r;
     if (q13) phi = .5f * Pi - phi;
     if (is_zero) phi = 0.f;
-    float s = std::sin(phi), c = std::cos(phi);
+    float s, c;
+    sincos_cephes(phi, s, c);
     float px = r * c, py = r * s;
     float z = safe_sqrt(1.f - fma_(py, py, px * px));
     return {px, py, z};

@@ -1,0 +1,414 @@
+"""psdr_jit_amd — MI355X-native drop-in for the psdr_jit PathTracer hot path.
+
+Keeps the reference's Python surface (reference src/psdr.cpp:120-439) for the in-scope subset:
+    Scene, RenderOption, Mesh, DiffuseBSDF, AreaLight, PerspectiveCamera, PathTracer
+    scene.opts.{width,height,spp,sppe,sppse,log_level}, scene.seed, scene.param_map[...],
+    scene.add_Sensor / add_BSDF / add_Mesh / configure, PathTracer.renderC / renderD /
+    preprocess_secondary_edges / hide_emitters.
+drjit arrays are replaced by torch tensors (device memory, streams, autograd = plumbing):
+    Matrix4fD / Matrix4fC / FloatD build tensors, images come back as float32 [n_pixels, 3]
+    CUDA(ROCm) tensors, `forward_grad(img, P)` stands in for drjit.set_grad/forward_to/grad and
+    `loss.backward()` for drjit.backward.
+
+All rendering happens in libpsdr_hip.so (hand-written gfx950 kernels) behind the C ABI of
+include/psdr_hip.h.  There is NO CPU fallback: importing this package fails if the native
+libraries are missing, and rendering raises if no GPU is visible.
+"""
+import os as _os
+
+import numpy as _np
+import torch as _torch
+
+from . import build as _build
+
+_HERE = _os.path.dirname(_os.path.abspath(__file__))
+if not (_os.path.exists(_build.HIP_LIB) and _os.path.exists(_build.CORE_LIB)):
+    raise ImportError(
+        "psdr_jit_amd: native libraries not built (expected %s and %s). Run `python -m psdr_jit_amd.build` "
+        "or __graft_entry__.build(); there is no CPU fallback." % (_build.HIP_LIB, _build.CORE_LIB))
+
+from . import _psdr_core as _core  # noqa: E402
+
+Object = _core.Object
+RenderOption = _core.RenderOption
+BSDF = _core.BSDF
+DiffuseBSDF = _core.DiffuseBSDF
+Emitter = _core.Emitter
+AreaLight = _core.AreaLight
+Sensor = _core.Sensor
+PerspectiveCamera = _core.PerspectiveCamera
+Mesh = _core.Mesh
+Scene = _core.Scene
+Integrator = _core.Integrator
+PathTracer = _core.PathTracer
+PsdrException = _core.PsdrException
+
+TERM_INTERIOR, TERM_PRIMARY, TERM_SECONDARY, TERM_ALL = 1, 2, 4, 7
+
+
+# ------------------------------------------------------------------ drjit type stand-ins
+def FloatD(x=0.0):
+    """drjit.cuda.ad.Float stand-in: a float32 scalar tensor (set requires_grad_() to differentiate)."""
+    return x.to(_torch.float32) if isinstance(x, _torch.Tensor) else _torch.tensor(float(x), dtype=_torch.float32)
+
+
+FloatC = FloatD
+
+
+def Matrix4fD(rows):
+    """drjit Matrix4f stand-in: 4x4 float32 tensor; entries may be tensors (keeps the autograd graph)."""
+    if isinstance(rows, _torch.Tensor):
+        return rows.to(_torch.float32).reshape(4, 4)
+    flat = [e for r in rows for e in r]
+    if any(isinstance(e, _torch.Tensor) for e in flat):
+        ref = next(e for e in flat if isinstance(e, _torch.Tensor))
+        flat = [e.to(_torch.float32).reshape(()) if isinstance(e, _torch.Tensor) else _torch.tensor(float(e), dtype=_torch.float32, device=ref.device) for e in flat]
+        return _torch.stack(flat).reshape(4, 4)
+    return _torch.tensor(_np.asarray(rows, dtype=_np.float32).reshape(4, 4))
+
+
+Matrix4fC = Matrix4fD
+
+
+def _split(x, shape):
+    """tensor/array -> (float32 numpy value, tensor-or-None kept for autograd)."""
+    if isinstance(x, _torch.Tensor):
+        return x.detach().to("cpu", _torch.float32).numpy().reshape(shape), x
+    return _np.asarray(x, dtype=_np.float32).reshape(shape), None
+
+
+def _zeros_like(v):
+    return _np.zeros_like(v, dtype=_np.float32)
+
+
+def _params(obj):
+    d = obj.__dict__.get("_psdr_params")
+    if d is None:
+        d = {}
+        obj.__dict__["_psdr_params"] = d
+    return d
+
+
+def _make_param_property(name, shape_of):
+    def getter(self):
+        t = _params(self).get(name)
+        if t is not None:
+            return t
+        return _torch.from_numpy(_np.array(self._get(name, False)))
+
+    def setter(self, value):
+        v, t = _split(value, shape_of(self, value))
+        self._set(name, v, _zeros_like(v))
+        if t is not None:
+            _params(self)[name] = t
+        else:
+            _params(self).pop(name, None)
+
+    return property(getter, setter)
+
+
+def _m44(self, value):
+    return (4, 4)
+
+
+def _v3(self, value):
+    return (3,) if _np.size(value.detach().cpu().numpy() if isinstance(value, _torch.Tensor) else value) == 3 else (1,)
+
+
+def _vtx(self, value):
+    return (self.num_vertices, 3)
+
+
+for _cls in (Mesh, Sensor, PerspectiveCamera):
+    for _n in ("to_world", "to_world_left", "to_world_right"):
+        setattr(_cls, _n, _make_param_property(_n, _m44))
+Mesh.vertex_positions = _make_param_property("vertex_positions", _vtx)
+DiffuseBSDF.reflectance = _make_param_property("reflectance", _v3)
+AreaLight.radiance = _make_param_property("radiance", _v3)
+
+
+def _set_transform(self, mat, set_left=True):
+    """Mesh/Sensor.set_transform (reference mesh.h:26-33, sensor.h:34-40)."""
+    name = "to_world_left" if set_left else "to_world_right"
+    setattr(self, name, mat)
+
+
+def _append_transform(self, mat, append_left=True):
+    name = "to_world_left" if append_left else "to_world_right"
+    cur = getattr(self, name)
+    m = Matrix4fD(mat)
+    cur = cur.to(m.device) if isinstance(cur, _torch.Tensor) else cur
+    setattr(self, name, (m @ cur) if append_left else (cur @ m))
+
+
+for _cls in (Mesh, Sensor, PerspectiveCamera):
+    _cls.set_transform = _set_transform
+    _cls.append_transform = _append_transform
+
+_DiffuseBSDF_init = DiffuseBSDF.__init__
+
+
+def _diffuse_init(self, reflectance=None):
+    if reflectance is None:
+        _DiffuseBSDF_init(self)
+    else:
+        v, t = _split(reflectance, (-1,))
+        _DiffuseBSDF_init(self, v)
+        if t is not None:
+            _params(self)["reflectance"] = t
+
+
+DiffuseBSDF.__init__ = _diffuse_init
+_AreaLight_init = AreaLight.__init__
+
+
+def _arealight_init(self, radiance):
+    v, t = _split(radiance, (-1,))
+    _AreaLight_init(self, v)
+    if t is not None:
+        _params(self)["radiance"] = t
+
+
+AreaLight.__init__ = _arealight_init
+
+
+# ------------------------------------------------------------------ Scene
+def _keep(scene, key, src):
+    """The scene works on its own copies (reference scene.cpp:107-126,148-309): carry the torch leaves over."""
+    obj = scene.param_map[key]
+    scene.__dict__.setdefault("_psdr_objs", {})[key] = obj
+    if src is not None and "_psdr_params" in src.__dict__:
+        obj.__dict__["_psdr_params"] = dict(src.__dict__["_psdr_params"])
+    return obj
+
+
+_Scene_add_Sensor = Scene.add_Sensor
+_Scene_add_BSDF = Scene.add_BSDF
+
+
+def _add_Sensor(self, sensor):
+    _Scene_add_Sensor(self, sensor)
+    _keep(self, "Sensor[%d]" % (self.num_sensors - 1), sensor)
+
+
+def _add_BSDF(self, bsdf, name, twoSide=False):
+    _Scene_add_BSDF(self, bsdf, name, twoSide)
+    _keep(self, "BSDF[id=%s]" % name, bsdf)
+
+
+def _add_Mesh(self, mesh_or_path, *args):
+    """add_Mesh(path, Matrix4, bsdf_id, emitter|None) or add_Mesh(mesh, bsdf_id, emitter=None)."""
+    n_em = self.get_num_emitters()
+    if isinstance(mesh_or_path, (str, bytes, _os.PathLike)):
+        transform, bsdf_id, emitter = args[0], args[1], (args[2] if len(args) > 2 else None)
+        v, t = _split(transform, (4, 4))
+        self._add_Mesh_file(_os.fspath(mesh_or_path), v, bsdf_id, emitter)
+        obj = _keep(self, "Mesh[%d]" % (self.num_meshes - 1), None)
+        if t is not None:
+            _params(obj)["to_world"] = t
+    else:
+        bsdf_id, emitter = args[0], (args[1] if len(args) > 1 else None)
+        self._add_Mesh_obj(mesh_or_path, bsdf_id, emitter)
+        _keep(self, "Mesh[%d]" % (self.num_meshes - 1), mesh_or_path)
+    if emitter is not None:
+        _keep(self, "Emitter[%d]" % n_em, emitter)
+
+
+def _configure(self, active_sensor=()):
+    _sync_params(self)
+    self._configure(list(active_sensor))
+    self.__dict__["_psdr_active"] = list(active_sensor)
+
+
+Scene.add_Sensor = _add_Sensor
+Scene.add_BSDF = _add_BSDF
+Scene.add_Mesh = _add_Mesh
+Scene.configure = _configure
+
+
+def _leaves(scene):
+    """[(object, name, tensor)] for every torch-valued scene parameter."""
+    out = []
+    for key in sorted(scene.__dict__.get("_psdr_objs", {})):
+        obj = scene.__dict__["_psdr_objs"][key]
+        for name, t in sorted(obj.__dict__.get("_psdr_params", {}).items()):
+            out.append((obj, name, t))
+    return out
+
+
+def _sync_params(scene, tangents=None):
+    """Push current tensor values (and optional tangents {id(tensor): array}) into the host objects."""
+    for obj, name, t in _leaves(scene):
+        v = t.detach().to("cpu", _torch.float32).numpy()
+        shape = (4, 4) if name.startswith("to_world") else ((obj.num_vertices, 3) if name == "vertex_positions" else (-1,))
+        v = v.reshape(shape)
+        d = _zeros_like(v)
+        if tangents is not None and id(t) in tangents:
+            d = _np.asarray(tangents[id(t)], dtype=_np.float32).reshape(v.shape)
+        obj._set(name, v, d)
+
+
+# ------------------------------------------------------------------ distributed sharding
+def _shard():
+    """(rank, world) when torch.distributed is initialised, else (0, 1)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def _device():
+    if not _torch.cuda.is_available():
+        raise RuntimeError("psdr_jit_amd: no ROCm GPU visible — the renderer has no CPU fallback")
+    return _torch.device("cuda", _torch.cuda.current_device())
+
+
+def _stream_ptr():
+    return int(_torch.cuda.current_stream().cuda_stream)
+
+
+def _pix(batch_pix, dev):
+    if batch_pix is None or (isinstance(batch_pix, int) and batch_pix == -1):
+        return None
+    return _torch.as_tensor(batch_pix, dtype=_torch.int32).to(dev).contiguous()
+
+
+def _all_reduce(t, distributed):
+    if distributed:
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)     # RCCL over xGMI ("nccl" backend on ROCm)
+    return t
+
+
+# ------------------------------------------------------------------ Integrator.renderC / renderD
+def _renderC(self, scene, sensor_id=0, seed=-1, batch_pix=-1, distributed=None):
+    """Integrator.renderC (reference integrator.cpp:12-48): float32 [n_pixels, 3], pixel = y*W + x."""
+    dev = _device()
+    pix = _pix(batch_pix, dev)
+    n = int(pix.numel()) if pix is not None else scene.opts.width * scene.opts.height
+    rank, world = _shard() if distributed in (None, True) else (0, 1)
+    out = _torch.empty((n, 3), dtype=_torch.float32, device=dev)
+    self._renderC(scene, sensor_id, seed, pix.data_ptr() if pix is not None else 0, n, out.data_ptr(), _stream_ptr(), rank, world)
+    return _all_reduce(out, world > 1)
+
+
+def _render_d_raw(self, scene, sensor_id, seed, batch_pix, terms, distributed=None):
+    dev = _device()
+    pix = _pix(batch_pix, dev)
+    n = int(pix.numel()) if pix is not None else scene.opts.width * scene.opts.height
+    rank, world = _shard() if distributed in (None, True) else (0, 1)
+    buf = _torch.empty((2, n, 3), dtype=_torch.float32, device=dev)
+    self._renderD(scene, sensor_id, seed, pix.data_ptr() if pix is not None else 0, n, buf[0].data_ptr(), buf[1].data_ptr(), _stream_ptr(), rank, world, terms)
+    _all_reduce(buf, world > 1)      # one collective for image + derivative
+    return buf[0], buf[1]
+
+
+class _RenderDFn(_torch.autograd.Function):
+    """Autograd node of renderD.  forward = primal image; backward replays forward-mode renders
+    (one per scalar degree of freedom of the 4x4 / rgb leaves) until the adjoint kernel of
+    psdr_render_d_bwd lands — exact, but O(#dof) renders."""
+
+    @staticmethod
+    def forward(ctx, state, *leaf_tensors):
+        ctx.state = state
+        return state["img"]
+
+    @staticmethod
+    def backward(ctx, grad_img):
+        st = ctx.state
+        integ, scene = st["integrator"], st["scene"]
+        grads = []
+        for (obj, name, t), needs in zip(st["leaves"], ctx.needs_input_grad[1:]):
+            if not needs:
+                grads.append(None)
+                continue
+            if name == "vertex_positions":
+                raise NotImplementedError("reverse-mode w.r.t. vertex_positions needs the adjoint kernel (psdr_render_d_bwd)")
+            g = _torch.zeros(t.numel(), dtype=_torch.float32)
+            ndof = 12 if name.startswith("to_world") else t.numel()
+            for k in range(ndof):
+                e = _np.zeros(t.numel(), dtype=_np.float32)
+                e[k] = 1.0
+                dimg = _replay_forward(integ, scene, st, {id(t): e})
+                g[k] = float((dimg * grad_img).sum())
+            grads.append(g.reshape(t.shape).to(t.device, t.dtype))
+        _sync_params(scene)
+        scene._configure(st["active"])
+        return (None,) + tuple(grads)
+
+
+def _replay_forward(integ, scene, st, tangents):
+    """Re-render with the sampler state of the recorded call and the given leaf tangents."""
+    _sync_params(scene, tangents)
+    scene._configure(st["active"])
+    saved = [scene._sampler_state(k) for k in range(3)]
+    _, dimg = _render_d_raw(integ, scene, st["sensor_id"], st["replay_seed"], st["batch_pix"], st["terms"])
+    return dimg
+
+
+def _renderD(self, scene, sensor_id=0, seed=-1, batch_pix=-1, terms=TERM_ALL):
+    """Integrator.renderD (reference integrator.cpp:51-100).  Returns the image as a tensor attached
+    to the autograd graph of the scene's torch parameters."""
+    if seed == -1:
+        # make the call replayable: fix the seeds it would have used
+        seed_used = None
+    leaves = _leaves(scene)
+    state = {"integrator": self, "scene": scene, "sensor_id": sensor_id, "batch_pix": batch_pix, "terms": terms,
+             "active": scene.__dict__.get("_psdr_active", []), "leaves": leaves, "seed": seed}
+    # replay needs a deterministic sampler: remember the seed if given, else derive one from the scene seed + skip
+    if seed == -1:
+        _, _, s0, k0 = scene._sampler_state(0)
+        state["replay_seed"] = int((s0 * 1000003 + k0 + 12345) % (2 ** 31 - 1))
+        seed = state["replay_seed"]
+    else:
+        state["replay_seed"] = seed
+    img, dimg = _render_d_raw(self, scene, sensor_id, seed, batch_pix, terms)
+    state["img"] = img
+    state["dimg0"] = dimg
+    tens = [t for (_, _, t) in leaves]
+    if any(t.requires_grad for t in tens):
+        return _RenderDFn.apply(state, *tens)
+    return img
+
+
+def forward_grad(img, param, direction=None):
+    """d img / d param along `direction` (default: ones) — the torch spelling of
+    drjit.set_grad(P, 1); drjit.forward_to(img); drjit.grad(img) (reference README.md:102-104)."""
+    fn = img.grad_fn
+    if fn is None or not hasattr(fn, "state"):
+        raise RuntimeError("forward_grad: img does not come from renderD with differentiable scene parameters")
+    st = fn.state
+    tangents = {}
+    v = _torch.ones_like(param) if direction is None else direction
+    for (obj, name, t) in st["leaves"]:
+        if not t.requires_grad:
+            continue
+        if t is param:
+            tangents[id(t)] = v.detach().cpu().numpy()
+            continue
+        w = _torch.zeros_like(t, requires_grad=True)
+        (g,) = _torch.autograd.grad(t, param, w, create_graph=True, allow_unused=True)
+        if g is None:
+            continue
+        (jv,) = _torch.autograd.grad(g, w, v, allow_unused=True)
+        if jv is not None:
+            tangents[id(t)] = jv.detach().cpu().numpy()
+    dimg = _replay_forward(st["integrator"], st["scene"], st, tangents)
+    _sync_params(st["scene"])
+    st["scene"]._configure(st["active"])
+    return dimg
+
+
+Integrator.renderC = _renderC
+Integrator.renderD = _renderD
+PathTracer.renderC = _renderC
+PathTracer.renderD = _renderD
+
+
+def render_d_fwd(integrator, scene, sensor_id=0, seed=-1, batch_pix=-1, terms=TERM_ALL, tangents=None):
+    """One-shot renderD + forward derivative: returns (img, d_img).  `tangents` maps scene leaf tensors
+    (by identity) to their tangent arrays; host objects whose tangents were set through `_set` keep them."""
+    if tangents is not None:
+        _sync_params(scene, {id(k): v for k, v in tangents.items()})
+        scene._configure(scene.__dict__.get("_psdr_active", []))
+    return _render_d_raw(integrator, scene, sensor_id, seed, batch_pix, terms)

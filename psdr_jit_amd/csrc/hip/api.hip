@@ -1,0 +1,643 @@
+// api.hip — gfx950 kernels and the C ABI of libpsdr_hip.so (include/psdr_hip.h).
+//
+// Kernel structure (one thread = one sample lane of the reference's wavefront arrays):
+//   * persistent workgroups of 256 threads (4 wave64) stride over 256-lane chunks of the lane range;
+//   * at start each workgroup stages the scene blob into LDS (small scenes) with 16-byte loads;
+//   * each lane re-derives its RNG state (sampler.h), traces/shades its whole path in registers with
+//     an LDS traversal stack (scene_dev.h, shade.h), then lanes of one pixel are combined with a
+//     wave-level segmented scan so that ONE lane per pixel issues the float atomics
+//     (the reference issues 3 atomics per lane: scatter_reduce, integrator.cpp:127-129).
+// There is no host synchronisation inside a render call (the reference syncs before each of its 7+
+// OptiX launches, scene_optix.cpp:345).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../../include/psdr_hip.h"
+#include "bvh.h"
+#include "edges.h"
+
+using namespace psdr;
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+static thread_local std::string g_err;
+static int fail(const std::string &msg) { g_err = msg; return 1; }
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// device helpers shared by the kernels
+struct LaneRange { long long begin, end; };
+
+struct RenderParams {
+    int max_depth, hide_emitters;
+    unsigned long long seed, skip;
+    const int *pix_ids;
+    int n_pix;
+    LaneRange range;
+};
+
+template <bool LDS>
+PSDR_DEV SceneView<LDS> make_view(const float4 *blob, const SceneTables &T, float4 *smem) {
+    const float4 *B = blob;
+    if (LDS) {
+        for (int i = threadIdx.x; i < T.blob_words; i += kBlock) smem[i] = blob[i];
+        __syncthreads();
+        B = smem;
+    }
+    SceneView<LDS> S;
+    S.B = B; S.T = &T;
+    S.stack = reinterpret_cast<int *>(smem + (LDS ? T.blob_words : 0)) + threadIdx.x;
+    S.c_nodes = S.c_tris = S.c_rays = S.c_hits = 0u;
+    return S;
+}
+
+template <bool LDS> PSDR_DEV void flush_counters(const SceneView<LDS> &S, Counters *ctr) {
+    unsigned long long v[4] = {S.c_rays, S.c_nodes, S.c_tris, S.c_hits};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        unsigned long long x = v[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+        if ((threadIdx.x & 63) == 0) atomicAdd(reinterpret_cast<unsigned long long *>(ctr) + k, x);
+    }
+}
+
+// inclusive segmented scan over the wave: lanes with equal key are contiguous
+PSDR_DEV float seg_scan(float v, int key, int lane_id) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float vu = __shfl_up(v, off);
+        const int ku = __shfl_up(key, off);
+        if (lane_id >= off && ku == key) v += vu;
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// interior term: Integrator::__render / __render_batch, reference integrator.cpp:103-176
+template <bool AD, bool LDS, bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_interior(const float4 *__restrict__ blob, const SceneTables T, const SensorDev cam,
+                                                     const RenderParams P, float *__restrict__ out, float *__restrict__ dout,
+                                                     float *__restrict__ lanes_out, Counters *ctr) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    SceneView<LDS> S = make_view<LDS>(blob, T, smem);
+    const int lane_id = threadIdx.x & 63;
+    const long long n = P.range.end - P.range.begin;
+    const long long n_chunks = (n + kBlock - 1) / kBlock;
+    const float inv_spp = T.spp > 1 ? 1.f / (float) T.spp : 1.f;
+    for (long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const long long lane = P.range.begin + chunk * kBlock + threadIdx.x;
+        const bool in_range = lane < P.range.end;
+        int pix_slot = -1;                 // row of the output image this lane adds to
+        float val[3] = {0.f, 0.f, 0.f}, dval[3] = {0.f, 0.f, 0.f};
+        if (in_range) {
+            const long long k = T.spp > 1 ? lane / T.spp : lane;
+            const int pix = P.pix_ids ? P.pix_ids[k] : (int) k;
+            pix_slot = (int) k;
+            LaneRng rng;
+            rng.seed(P.seed + (P.pix_ids ? (unsigned long long) (long long) pix : (unsigned long long) lane), (unsigned long long) lane, P.skip);
+            const float bx = (float) (pix % T.width), by = (float) (pix / T.width);
+            const float jx = rng.next_1d(), jy = rng.next_1d();
+            const float sx = (bx + jx) / (float) T.width, sy = (by + jy) / (float) T.height;
+            const RayT<AD> ray = sample_primary_ray<AD>(cam, sx, sy);
+            const VecN<AD> L = Li<AD, LDS, COUNT>(S, rng, ray, true, P.max_depth, P.hide_emitters != 0);
+            const float pv[3] = {detach(L.x), detach(L.y), detach(L.z)};
+            const float tv[3] = {tangent(L.x), tangent(L.y), tangent(L.z)};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {                 // NaN/Inf scrub, integrator.cpp:126
+                const bool okp = finite_(pv[c]);
+                val[c] = okp ? pv[c] : 0.f;
+                dval[c] = (okp && finite_(tv[c])) ? tv[c] : 0.f;
+            }
+            if (lanes_out) {
+                const long long o = 3 * (lane - P.range.begin);
+                lanes_out[o] = pv[0]; lanes_out[o + 1] = pv[1]; lanes_out[o + 2] = pv[2];
+            }
+        }
+        if (out) {
+            const int next_key = __shfl_down(pix_slot, 1);
+            const bool seg_end = (lane_id == 63) || (next_key != pix_slot);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float s = seg_scan(val[c], pix_slot, lane_id);
+                if (seg_end && pix_slot >= 0) atomicAdd(&out[3 * (long long) pix_slot + c], s * inv_spp);
+                if (AD) {
+                    const float ds = seg_scan(dval[c], pix_slot, lane_id);
+                    if (seg_end && pix_slot >= 0) atomicAdd(&dout[3 * (long long) pix_slot + c], ds * inv_spp);
+                }
+            }
+        }
+    }
+    if (COUNT) flush_counters(S, ctr);
+}
+
+// primary-edge term, reference integrator.cpp:179-198
+template <bool LDS, bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_primary_edges(const float4 *__restrict__ blob, const SceneTables T, const SensorDev cam,
+                                                          const RenderParams P, float *__restrict__ dout, Counters *ctr) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    SceneView<LDS> S = make_view<LDS>(blob, T, smem);
+    const long long n = P.range.end - P.range.begin;
+    const long long n_chunks = (n + kBlock - 1) / kBlock;
+    for (long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const long long lane = P.range.begin + chunk * kBlock + threadIdx.x;
+        if (lane < P.range.end) {
+            LaneRng rng;
+            rng.seed(P.seed + (unsigned long long) lane, (unsigned long long) lane, P.skip);
+            Vec3f dv;
+            const int idx = primary_edge_lane<LDS, COUNT>(S, cam, rng, P.max_depth, P.hide_emitters != 0, T.sppe, dv);
+            if (idx >= 0) {
+                if (dv.x != 0.f) atomicAdd(&dout[3 * (long long) idx], dv.x);
+                if (dv.y != 0.f) atomicAdd(&dout[3 * (long long) idx + 1], dv.y);
+                if (dv.z != 0.f) atomicAdd(&dout[3 * (long long) idx + 2], dv.z);
+            }
+        }
+    }
+    if (COUNT) flush_counters(S, ctr);
+}
+
+struct GuidingDev {          // HyperCubeDistribution<3>, reference src/core/cube_distrb.cpp:10-64
+    const float *pmf, *cmf;
+    float sum;
+    int reso[3], num_cells;
+    float unit[3];
+};
+
+PSDR_DEV float guiding_sample_reuse(const GuidingDev &G, Vec3f &s) {
+    float pdf;
+    const int idx = sample_reuse(G.num_cells, G.sum, [&](int i) { return G.pmf[i]; }, [&](int i) { return G.cmf[i]; }, s.z, pdf);
+    const int c0 = idx / (G.reso[1] * G.reso[2]);
+    const int rem = idx - c0 * (G.reso[1] * G.reso[2]);
+    const int c1 = rem / G.reso[2], c2 = rem - c1 * G.reso[2];
+    s.x = (s.x + (float) c0) * G.unit[0];
+    s.y = (s.y + (float) c1) * G.unit[1];
+    s.z = (s.z + (float) c2) * G.unit[2];
+    return pdf * (float) G.num_cells;
+}
+
+// secondary-edge term, reference path.cpp:274-294
+template <bool LDS, bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_secondary_edges(const float4 *__restrict__ blob, const SceneTables T, const SecEdgeTables E,
+                                                            const SensorDev cam, const RenderParams P, const GuidingDev G, const int use_guiding,
+                                                            float *__restrict__ dout, Counters *ctr) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    SceneView<LDS> S = make_view<LDS>(blob, T, smem);
+    const long long n = P.range.end - P.range.begin;
+    const long long n_chunks = (n + kBlock - 1) / kBlock;
+    for (long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const long long lane = P.range.begin + chunk * kBlock + threadIdx.x;
+        if (lane < P.range.end) {
+            LaneRng rng;
+            rng.seed(P.seed + (unsigned long long) lane, (unsigned long long) lane, P.skip);
+            Vec3f s3;
+            s3.x = rng.next_1d(); s3.y = rng.next_1d(); s3.z = rng.next_1d();
+            const float pdf0 = use_guiding ? guiding_sample_reuse(G, s3) : 1.f;
+            Vec3f v;
+            const int idx = eval_secondary_edge<true, LDS, COUNT>(S, E, cam, s3, v);
+            if (idx >= 0) {
+                float o[3] = {v.x, v.y, v.z};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (pdf0 > kEpsilon) o[c] /= pdf0;
+                    if (T.sppse > 1) o[c] /= (float) T.sppse;
+                    if (finite_(o[c]) && o[c] != 0.f) atomicAdd(&dout[3 * (long long) idx + c], o[c]);
+                }
+            }
+        }
+    }
+    if (COUNT) flush_counters(S, ctr);
+}
+
+// guiding grid: PathTracer::preprocess_secondary_edges, reference path.cpp:130-168 (one round per launch)
+template <bool LDS>
+__global__ __launch_bounds__(kBlock) void k_guiding_round(const float4 *__restrict__ blob, const SceneTables T, const SecEdgeTables E,
+                                                          const SensorDev cam, const GuidingDev G, const int per_cell, const int seed,
+                                                          const int round, float *__restrict__ mass) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    SceneView<LDS> S = make_view<LDS>(blob, T, smem);
+    const long long n = (long long) G.num_cells * per_cell;
+    const long long n_chunks = (n + kBlock - 1) / kBlock;
+    for (long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const long long lane = chunk * kBlock + threadIdx.x;
+        if (lane < n) {
+            const int cell = (int) (lane / per_cell);
+            const int c0 = cell / (G.reso[1] * G.reso[2]);
+            const int rem = cell - c0 * (G.reso[1] * G.reso[2]);
+            const int c1 = rem / G.reso[2], c2 = rem - c1 * G.reso[2];
+            LaneRng rng;
+            rng.seed((unsigned long long) lane + (unsigned long long) (long long) seed, (unsigned long long) lane, (unsigned long long) (3 * round));
+            Vec3f s3;
+            s3.x = rng.next_1d(); s3.y = rng.next_1d(); s3.z = rng.next_1d();
+            s3 = Vec3f((s3.x + (float) c0) * G.unit[0], (s3.y + (float) c1) * G.unit[1], (s3.z + (float) c2) * G.unit[2]);
+            Vec3f v;
+            eval_secondary_edge<false, LDS, false>(S, E, cam, s3, v);
+            float o[3] = {v.x, v.y, v.z};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { if (!finite_(o[c])) o[c] = 0.f; if (per_cell > 1) o[c] /= (float) per_cell; }
+            const float m = fmaxf(o[0], fmaxf(o[1], o[2]));
+            if (m != 0.f) atomicAdd(&mass[cell], m);
+        }
+    }
+}
+
+// batch closest-hit query (parity aid for the traversal alone)
+template <bool LDS>
+__global__ __launch_bounds__(kBlock) void k_trace(const float4 *__restrict__ blob, const SceneTables T, int n, const float *__restrict__ o,
+                                                  const float *__restrict__ d, int *__restrict__ out_tri, float *__restrict__ out_uv, float *__restrict__ out_t) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    SceneView<LDS> S = make_view<LDS>(blob, T, smem);
+    for (long long i = (long long) blockIdx.x * kBlock + threadIdx.x; i < (long long) ((n + kBlock - 1) / kBlock) * kBlock; i += (long long) gridDim.x * kBlock) {
+        if (i < n) {
+            const Hit h = trace<LDS, false>(S, Vec3f(o[3 * i], o[3 * i + 1], o[3 * i + 2]), Vec3f(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
+            int id = -1;
+            if (h.slot >= 0) id = __float_as_int(S.ld(T.trav_off + 3 * h.slot + 2).y);
+            out_tri[i] = id; out_uv[2 * i] = h.u; out_uv[2 * i + 1] = h.v; out_t[i] = h.t;
+        }
+    }
+}
+
+__global__ void k_sampler_floats(unsigned long long seed_value, unsigned long long lane, unsigned long long skip, int n, float *out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        LaneRng r; r.seed(seed_value, lane, skip);
+        for (int i = 0; i < n; ++i) out[i] = r.next_1d();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void) hipFree(p); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    int upload(const void *src, size_t bytes) {
+        if (bytes == 0) bytes = 16;
+        HIPCHK(hipMalloc(&p, bytes));
+        if (src) HIPCHK(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice)); else HIPCHK(hipMemset(p, 0, bytes));
+        return 0;
+    }
+    template <typename T> const T *as() const { return reinterpret_cast<const T *>(p); }
+};
+
+struct psdr_hip_scene {
+    SceneTables T{};
+    DevBuf blob;
+    bool lds = false;
+    size_t smem_bytes = 0;
+    SecEdgeTables E{};
+    std::vector<std::unique_ptr<DevBuf>> bufs;
+    std::vector<SensorDev> sensors;
+    DevBuf counters;
+    int n_leaves = 0, max_depth = 0, grid = 0;
+    const float *up(const float *src, size_t n, int &rc) {
+        if (!src) return nullptr;
+        bufs.emplace_back(new DevBuf());
+        rc |= bufs.back()->upload(src, n * sizeof(float));
+        return bufs.back()->as<float>();
+    }
+    const uint8_t *up8(const uint8_t *src, size_t n, int &rc) {
+        if (!src) return nullptr;
+        bufs.emplace_back(new DevBuf());
+        rc |= bufs.back()->upload(src, n);
+        return bufs.back()->as<uint8_t>();
+    }
+};
+
+struct psdr_hip_guiding {
+    GuidingDev G{};
+    DevBuf pmf, cmf;
+    std::vector<float> mass;
+};
+
+static inline void put4(std::vector<float> &b, size_t word, float x, float y, float z, float w) { float *q = &b[4 * word]; q[0] = x; q[1] = y; q[2] = z; q[3] = w; }
+static inline float ibits(int32_t v) { float f; std::memcpy(&f, &v, 4); return f; }
+static inline size_t words_for_floats(size_t n) { return (n + 3) / 4; }
+
+extern "C" {
+
+const char *psdr_hip_last_error(void) { return g_err.c_str(); }
+int psdr_hip_abi_version(void) { return PSDR_HIP_ABI_VERSION; }
+int psdr_hip_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+int psdr_hip_set_device(int device) { HIPCHK(hipSetDevice(device)); return 0; }
+
+int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
+    if (!s || !out) return fail("psdr_hip_scene_create: null argument");
+    if (s->abi_version != PSDR_HIP_ABI_VERSION) return fail("psdr_hip_scene_create: ABI version mismatch");
+    const psdr_triangles &tr = s->tris;
+    const int n = tr.n_triangles;
+    if (n <= 0) return fail("Missing meshes!");
+    if (s->n_sensors <= 0) return fail("Missing sensor!");
+    auto sc = std::make_unique<psdr_hip_scene>();
+
+    BvhResult bvh;
+    build_bvh(tr.p0, tr.e1, tr.e2, n, bvh);
+    std::vector<int32_t> orig2slot(n);
+    for (int slot = 0; slot < n; ++slot) orig2slot[bvh.order[slot]] = slot;
+
+    const bool has_tan = tr.d_p0 != nullptr;
+    SceneTables &T = sc->T;
+    size_t w = 0;
+    T.nodes_off = (int) w; w += 4 * (size_t) bvh.n_nodes;
+    T.trav_off = (int) w;  w += 3 * (size_t) n;
+    T.shade_off = (int) w; w += 6 * (size_t) n;
+    T.tan_off = (int) w;   w += has_tan ? 6 * (size_t) n : 0;
+    T.map_off = (int) w;   w += words_for_floats(n);
+    T.mesh_off = (int) w;  w += 2 * (size_t) s->n_meshes;
+    T.bsdf_off = (int) w;  w += 2 * (size_t) std::max(1, s->n_bsdfs);
+    T.emit_off = (int) w;  w += 2 * (size_t) std::max(1, s->n_emitters);
+    T.ecdf_off = (int) w;  w += words_for_floats(2 * (size_t) std::max(1, s->n_emitters));
+    T.fcdf_off = (int) w;  w += words_for_floats(2 * (size_t) std::max(1, s->n_face_distrb));
+    T.blob_words = (int) w;
+    T.n_nodes = bvh.n_nodes; T.n_tris = n; T.n_meshes = s->n_meshes; T.n_bsdfs = s->n_bsdfs; T.n_emitters = s->n_emitters;
+    T.n_fcdf = s->n_face_distrb; T.has_tangent = has_tan ? 1 : 0; T.stack_depth = bvh.max_depth + 1;
+    T.emitter_sum = s->emitter_sum;
+    T.width = s->width; T.height = s->height; T.spp = s->spp; T.sppe = s->sppe; T.sppse = s->sppse;
+
+    std::vector<float> blob(4 * w, 0.f);
+    std::memcpy(&blob[4 * (size_t) T.nodes_off], bvh.nodes.data(), sizeof(float) * bvh.nodes.size());
+    for (int slot = 0; slot < n; ++slot) {
+        const int o = bvh.order[slot];
+        const float *p0 = tr.p0 + 3 * o, *e1 = tr.e1 + 3 * o, *e2 = tr.e2 + 3 * o;
+        put4(blob, T.trav_off + 3 * (size_t) slot, p0[0], p0[1], p0[2], e1[0]);
+        put4(blob, T.trav_off + 3 * (size_t) slot + 1, e1[1], e1[2], e2[0], e2[1]);
+        put4(blob, T.trav_off + 3 * (size_t) slot + 2, e2[2], ibits(o), 0.f, 0.f);
+        const float *n0 = tr.n0 + 3 * o, *n1 = tr.n1 + 3 * o, *n2 = tr.n2 + 3 * o, *fn = tr.face_normal + 3 * o;
+        const size_t sw = T.shade_off + 6 * (size_t) slot;
+        put4(blob, sw, n0[0], n0[1], n0[2], tr.face_area[o]);
+        put4(blob, sw + 1, n1[0], n1[1], n1[2], ibits(tr.mesh_id[o]));
+        put4(blob, sw + 2, n2[0], n2[1], n2[2], ibits(tr.use_face_normal && tr.use_face_normal[o] ? 1 : 0));
+        put4(blob, sw + 3, fn[0], fn[1], fn[2], ibits(o));
+        if (tr.uv) {
+            const float *uv = tr.uv + 6 * o;
+            put4(blob, sw + 4, uv[0], uv[1], uv[2], uv[3]);
+            put4(blob, sw + 5, uv[4], uv[5], 0.f, 0.f);
+        }
+        if (has_tan) {
+            const float *a = tr.d_p0 + 3 * o, *b = tr.d_e1 + 3 * o, *c = tr.d_e2 + 3 * o, *d0 = tr.d_n0 + 3 * o, *d1 = tr.d_n1 + 3 * o,
+                        *d2 = tr.d_n2 + 3 * o, *df = tr.d_face_normal + 3 * o;
+            const size_t tw = T.tan_off + 6 * (size_t) slot;
+            put4(blob, tw, a[0], a[1], a[2], b[0]);
+            put4(blob, tw + 1, b[1], b[2], c[0], c[1]);
+            put4(blob, tw + 2, c[2], d0[0], d0[1], d0[2]);
+            put4(blob, tw + 3, d1[0], d1[1], d1[2], d2[0]);
+            put4(blob, tw + 4, d2[1], d2[2], df[0], df[1]);
+            put4(blob, tw + 5, df[2], tr.d_face_area[o], 0.f, 0.f);
+        }
+    }
+    for (int i = 0; i < n; ++i) blob[4 * (size_t) T.map_off + i] = ibits(orig2slot[i]);
+    for (int i = 0; i < s->n_meshes; ++i) {
+        const psdr_mesh_rec &m = s->meshes[i];
+        put4(blob, T.mesh_off + 2 * (size_t) i, ibits(m.bsdf_id), ibits(m.emitter_id), ibits(m.face_offset), ibits(m.n_faces));
+        put4(blob, T.mesh_off + 2 * (size_t) i + 1, m.inv_total_area, ibits(m.distrb_offset), m.distrb_sum, 0.f);
+    }
+    for (int i = 0; i < s->n_bsdfs; ++i) {
+        const psdr_bsdf_rec &b = s->bsdfs[i];
+        if (b.type != 0) return fail("Unknown BSDF type!");
+        put4(blob, T.bsdf_off + 2 * (size_t) i, b.reflectance[0], b.reflectance[1], b.reflectance[2], ibits((b.two_sided ? 1 : 0)));
+        put4(blob, T.bsdf_off + 2 * (size_t) i + 1, b.d_reflectance[0], b.d_reflectance[1], b.d_reflectance[2], 0.f);
+    }
+    for (int i = 0; i < s->n_emitters; ++i) {
+        const psdr_emitter_rec &e = s->emitters[i];
+        put4(blob, T.emit_off + 2 * (size_t) i, e.radiance[0], e.radiance[1], e.radiance[2], e.sampling_weight);
+        put4(blob, T.emit_off + 2 * (size_t) i + 1, e.d_radiance[0], e.d_radiance[1], e.d_radiance[2], ibits(e.mesh_id));
+        blob[4 * (size_t) T.ecdf_off + i] = s->emitter_pmf ? s->emitter_pmf[i] : 1.f;
+        blob[4 * (size_t) T.ecdf_off + s->n_emitters + i] = s->emitter_cmf ? s->emitter_cmf[i] : 1.f;
+    }
+    for (int i = 0; i < s->n_face_distrb; ++i) {
+        blob[4 * (size_t) T.fcdf_off + i] = s->face_pmf[i];
+        blob[4 * (size_t) T.fcdf_off + s->n_face_distrb + i] = s->face_cmf[i];
+    }
+    if (sc->blob.upload(blob.data(), blob.size() * sizeof(float))) return 1;
+
+    const size_t stack_bytes = (size_t) T.stack_depth * kBlock * sizeof(int);
+    const size_t blob_bytes = (size_t) T.blob_words * 16;
+    sc->lds = blob_bytes + stack_bytes <= 40 * 1024;      // keeps >= 4 workgroups per CU (160 KiB LDS)
+    sc->smem_bytes = (sc->lds ? blob_bytes : 0) + stack_bytes;
+    if (sc->smem_bytes > 64 * 1024) return fail("BVH too deep for the LDS traversal stack");
+    sc->n_leaves = bvh.n_leaves; sc->max_depth = bvh.max_depth;
+
+    int rc = 0;
+    const psdr_sec_edges &se = s->sec_edges;
+    SecEdgeTables &E = sc->E;
+    E.n = se.n_edges; E.sum = se.sum;
+    if (se.n_edges > 0) {
+        const size_t m = (size_t) se.n_edges;
+        E.p0 = sc->up(se.p0, 3 * m, rc); E.e1 = sc->up(se.e1, 3 * m, rc); E.n0 = sc->up(se.n0, 3 * m, rc); E.n1 = sc->up(se.n1, 3 * m, rc);
+        E.p2 = sc->up(se.p2, 3 * m, rc); E.d_p0 = sc->up(se.d_p0, 3 * m, rc); E.d_e1 = sc->up(se.d_e1, 3 * m, rc);
+        E.pmf = sc->up(se.pmf, m, rc); E.cmf = sc->up(se.cmf, m, rc); E.is_boundary = sc->up8(se.is_boundary, m, rc);
+        if (E.d_p0 == nullptr || E.d_e1 == nullptr) { E.d_p0 = nullptr; E.d_e1 = nullptr; }
+    }
+    for (int i = 0; i < s->n_sensors; ++i) {
+        const psdr_sensor_rec &r = s->sensors[i];
+        SensorDev d{};
+        std::memcpy(d.sample_to_camera.m, r.sample_to_camera, 64); std::memcpy(d.to_world.m, r.to_world, 64);
+        std::memcpy(d.d_to_world.m, r.d_to_world, 64); std::memcpy(d.world_to_sample.m, r.world_to_sample, 64);
+        std::memcpy(d.d_world_to_sample.m, r.d_world_to_sample, 64);
+        for (int k = 0; k < 3; ++k) { d.cam_pos[k] = r.cam_pos[k]; d.cam_dir[k] = r.cam_dir[k]; }
+        d.inv_area = r.inv_area; d.n_edges = r.n_edges; d.edge_sum = r.edge_sum;
+        if (r.n_edges > 0) {
+            const size_t m = (size_t) r.n_edges;
+            std::vector<float> zeros(2 * m, 0.f);
+            d.edge_p0 = sc->up(r.edge_p0, 2 * m, rc); d.edge_p1 = sc->up(r.edge_p1, 2 * m, rc);
+            d.d_edge_p0 = sc->up(r.d_edge_p0 ? r.d_edge_p0 : zeros.data(), 2 * m, rc);
+            d.d_edge_p1 = sc->up(r.d_edge_p1 ? r.d_edge_p1 : zeros.data(), 2 * m, rc);
+            d.edge_normal = sc->up(r.edge_normal, 2 * m, rc); d.edge_length = sc->up(r.edge_length, m, rc);
+            d.edge_pmf = sc->up(r.edge_pmf, m, rc); d.edge_cmf = sc->up(r.edge_cmf, m, rc);
+        }
+        sc->sensors.push_back(d);
+    }
+    if (rc) return 1;
+    if (sc->counters.upload(nullptr, sizeof(Counters))) return 1;
+
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount; }
+    sc->grid = cus * 8;
+    *out = sc.release();
+    return 0;
+}
+
+int psdr_hip_scene_destroy(psdr_hip_scene *scene) { delete scene; return 0; }
+
+int psdr_hip_scene_stats(const psdr_hip_scene *sc, int32_t *n_nodes, int32_t *n_leaves, int32_t *max_depth, int32_t *lds_bytes) {
+    if (!sc) return fail("null scene");
+    if (n_nodes) *n_nodes = sc->T.n_nodes;
+    if (n_leaves) *n_leaves = sc->n_leaves;
+    if (max_depth) *max_depth = sc->max_depth;
+    if (lds_bytes) *lds_bytes = (int32_t) sc->smem_bytes * (sc->lds ? 1 : -1);
+    return 0;
+}
+
+} // extern "C"
+
+static inline LaneRange shard(long long N, int rank, int count) {
+    if (count <= 1) return {0, N};
+    return {N * rank / count, N * (rank + 1) / count};
+}
+static inline int grid_for(const psdr_hip_scene *sc, long long n) {
+    long long chunks = (n + kBlock - 1) / kBlock;
+    if (chunks < 1) chunks = 1;
+    return (int) std::min<long long>(chunks, sc->grid);
+}
+
+#define LAUNCH(kernel, sc, n_lanes, stream, ...) \
+    hipLaunchKernelGGL(kernel, dim3(grid_for(sc, n_lanes)), dim3(kBlock), (sc)->smem_bytes, (hipStream_t) (stream), __VA_ARGS__)
+
+static int check_args(const psdr_hip_scene *sc, const psdr_render_args *a) {
+    if (!sc || !a) return fail("null argument");
+    if (a->sensor_id < 0 || a->sensor_id >= (int) sc->sensors.size()) return fail("Invalid sensor id!");
+    if (a->max_depth < 0) return fail("max_depth >= 0");
+    if (a->pix_ids && a->n_pix <= 0) return fail("batch rendering needs n_pix > 0");
+    return 0;
+}
+
+template <bool COUNT>
+static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool ad, float *out, float *dout, float *lanes_out,
+                       long long lane_b, long long lane_e, psdr_counters *counters, void *stream) {
+    if (check_args(sc, a)) return 1;
+    const SceneTables &T = sc->T;
+    hipStream_t st = (hipStream_t) stream;
+    const long long npx = a->pix_ids ? a->n_pix : (long long) T.width * T.height;
+    if (a->zero_output) {
+        if (out) HIPCHK(hipMemsetAsync(out, 0, sizeof(float) * 3 * npx, st));
+        if (dout) HIPCHK(hipMemsetAsync(dout, 0, sizeof(float) * 3 * npx, st));
+    }
+    Counters *ctr = (Counters *) sc->counters.p;
+    if (COUNT) HIPCHK(hipMemsetAsync(ctr, 0, sizeof(Counters), st));
+    const SensorDev &cam = sc->sensors[a->sensor_id];
+    const int terms = ad ? (a->terms ? a->terms : 7) : PSDR_TERM_INTERIOR;
+
+    if ((terms & PSDR_TERM_INTERIOR) && T.spp > 0) {
+        RenderParams P{a->max_depth, a->hide_emitters, a->samplers[0].seed, a->samplers[0].skip, a->pix_ids, a->n_pix, {0, 0}};
+        P.range = lanes_out ? LaneRange{lane_b, lane_e} : shard(npx * T.spp, a->shard_rank, a->shard_count);
+        const long long nl = P.range.end - P.range.begin;
+        if (nl > 0) {
+            if (ad) {
+                if (sc->lds) LAUNCH((k_interior<true, true, COUNT>), sc, nl, st, sc->blob.as<float4>(), T, cam, P, out, dout, lanes_out, ctr);
+                else LAUNCH((k_interior<true, false, COUNT>), sc, nl, st, sc->blob.as<float4>(), T, cam, P, out, dout, lanes_out, ctr);
+            } else {
+                if (sc->lds) LAUNCH((k_interior<false, true, COUNT>), sc, nl, st, sc->blob.as<float4>(), T, cam, P, out, dout, lanes_out, ctr);
+                else LAUNCH((k_interior<false, false, COUNT>), sc, nl, st, sc->blob.as<float4>(), T, cam, P, out, dout, lanes_out, ctr);
+            }
+        }
+    }
+    if (ad && !a->pix_ids && !lanes_out) {
+        if ((terms & PSDR_TERM_PRIMARY) && T.sppe > 0 && cam.n_edges > 0) {
+            RenderParams P{a->max_depth, a->hide_emitters, a->samplers[1].seed, a->samplers[1].skip, nullptr, 0, shard(npx * T.sppe, a->shard_rank, a->shard_count)};
+            const long long nl = P.range.end - P.range.begin;
+            if (nl > 0) {
+                if (sc->lds) LAUNCH((k_primary_edges<true, COUNT>), sc, nl, st, sc->blob.as<float4>(), T, cam, P, dout, ctr);
+                else LAUNCH((k_primary_edges<false, COUNT>), sc, nl, st, sc->blob.as<float4>(), T, cam, P, dout, ctr);
+            }
+        }
+        if ((terms & PSDR_TERM_SECONDARY) && T.sppse > 0 && sc->E.n > 0) {
+            RenderParams P{a->max_depth, a->hide_emitters, a->samplers[2].seed, a->samplers[2].skip, nullptr, 0, shard(npx * T.sppse, a->shard_rank, a->shard_count)};
+            const long long nl = P.range.end - P.range.begin;
+            GuidingDev G{};
+            const int use_g = a->guiding ? 1 : 0;
+            if (a->guiding) G = a->guiding->G;
+            if (nl > 0) {
+                if (sc->lds) LAUNCH((k_secondary_edges<true, COUNT>), sc, nl, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, dout, ctr);
+                else LAUNCH((k_secondary_edges<false, COUNT>), sc, nl, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, dout, ctr);
+            }
+        }
+    }
+    HIPCHK(hipGetLastError());
+    if (COUNT && counters) {
+        Counters h;
+        HIPCHK(hipMemcpyAsync(&h, ctr, sizeof(h), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        counters->rays = h.rays; counters->nodes_visited = h.nodes; counters->tris_tested = h.tris; counters->shaded_hits = h.hits;
+    }
+    return 0;
+}
+
+extern "C" {
+
+int psdr_hip_render_c(const psdr_hip_scene *sc, const psdr_render_args *a, float *out, void *stream) {
+    if (!out) return fail("null output");
+    return render_impl<false>(sc, a, false, out, nullptr, nullptr, 0, 0, nullptr, stream);
+}
+int psdr_hip_render_d_fwd(const psdr_hip_scene *sc, const psdr_render_args *a, float *out, float *dout, void *stream) {
+    if (!out || !dout) return fail("null output");
+    return render_impl<false>(sc, a, true, out, dout, nullptr, 0, 0, nullptr, stream);
+}
+int psdr_hip_render_c_counted(const psdr_hip_scene *sc, const psdr_render_args *a, float *out, psdr_counters *c, void *stream) {
+    if (!out) return fail("null output");
+    return render_impl<true>(sc, a, false, out, nullptr, nullptr, 0, 0, c, stream);
+}
+int psdr_hip_render_d_fwd_counted(const psdr_hip_scene *sc, const psdr_render_args *a, float *out, float *dout, psdr_counters *c, void *stream) {
+    if (!out || !dout) return fail("null output");
+    return render_impl<true>(sc, a, true, out, dout, nullptr, 0, 0, c, stream);
+}
+int psdr_hip_li_lanes(const psdr_hip_scene *sc, const psdr_render_args *a, int64_t lane_begin, int64_t lane_end, float *out, void *stream) {
+    if (!out || lane_end <= lane_begin) return fail("bad lane range");
+    return render_impl<false>(sc, a, false, nullptr, nullptr, out, lane_begin, lane_end, nullptr, stream);
+}
+
+int psdr_hip_trace(const psdr_hip_scene *sc, int32_t n, const float *o, const float *d, int32_t *out_tri, float *out_uv, float *out_t, void *stream) {
+    if (!sc) return fail("null scene");
+    if (n <= 0) return 0;
+    if (sc->lds) LAUNCH((k_trace<true>), sc, (long long) n, stream, sc->blob.as<float4>(), sc->T, n, o, d, out_tri, out_uv, out_t);
+    else LAUNCH((k_trace<false>), sc, (long long) n, stream, sc->blob.as<float4>(), sc->T, n, o, d, out_tri, out_uv, out_t);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int psdr_hip_guiding_build(const psdr_hip_scene *sc, int32_t sensor_id, int32_t max_depth, const int32_t reso[4], int32_t nrounds, int32_t seed,
+                           psdr_hip_guiding **out, void *stream) {
+    (void) max_depth;
+    if (!sc || !out || !reso) return fail("null argument");
+    if (nrounds <= 0) return fail("nrounds > 0");
+    if (sensor_id < 0 || sensor_id >= (int) sc->sensors.size()) return fail("Invalid sensor id!");
+    if (sc->E.n <= 0) return fail("Scene needs to be configured with sppse > 0!");
+    const long long cells = (long long) reso[0] * reso[1] * reso[2];
+    if (cells <= 0 || reso[3] <= 0 || cells * reso[3] > 2147483647LL) return fail("bad guiding resolution");
+    auto g = std::make_unique<psdr_hip_guiding>();
+    GuidingDev &G = g->G;
+    for (int k = 0; k < 3; ++k) { G.reso[k] = reso[k]; G.unit[k] = 1.f / (float) reso[k]; }
+    G.num_cells = (int) cells;
+    hipStream_t st = (hipStream_t) stream;
+    DevBuf mass;
+    if (mass.upload(nullptr, sizeof(float) * cells)) return 1;
+    const long long nl = cells * reso[3];
+    for (int r = 0; r < nrounds; ++r) {
+        if (sc->lds) LAUNCH((k_guiding_round<true>), sc, nl, st, sc->blob.as<float4>(), sc->T, sc->E, sc->sensors[sensor_id], G, reso[3], seed, r, (float *) mass.p);
+        else LAUNCH((k_guiding_round<false>), sc, nl, st, sc->blob.as<float4>(), sc->T, sc->E, sc->sensors[sensor_id], G, reso[3], seed, r, (float *) mass.p);
+    }
+    HIPCHK(hipGetLastError());
+    g->mass.resize(cells);
+    HIPCHK(hipMemcpyAsync(g->mass.data(), mass.p, sizeof(float) * cells, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    // DiscreteDistribution::init on the host (double-precision CDF, reference pmf.h:12-38)
+    std::vector<float> cmf(cells);
+    float sum = 0.f; double acc = 0.0;
+    for (long long i = 0; i < cells; ++i) {
+        if (nrounds > 1) g->mass[i] /= (float) nrounds;
+        sum += g->mass[i]; acc += (double) g->mass[i]; cmf[i] = (float) acc;
+    }
+    G.sum = sum;
+    if (g->pmf.upload(g->mass.data(), sizeof(float) * cells) || g->cmf.upload(cmf.data(), sizeof(float) * cells)) return 1;
+    G.pmf = g->pmf.as<float>(); G.cmf = g->cmf.as<float>();
+    *out = g.release();
+    return 0;
+}
+int psdr_hip_guiding_num_cells(const psdr_hip_guiding *g) { return g ? g->G.num_cells : 0; }
+int psdr_hip_guiding_mass(const psdr_hip_guiding *g, float *out_host, int32_t cap) {
+    if (!g || !out_host) return fail("null argument");
+    if (cap < g->G.num_cells) return fail("buffer too small");
+    std::memcpy(out_host, g->mass.data(), sizeof(float) * g->G.num_cells);
+    return 0;
+}
+int psdr_hip_guiding_destroy(psdr_hip_guiding *g) { delete g; return 0; }
+
+uint64_t psdr_hip_tea64(uint64_t v0, uint64_t v1) { return tea64(v0, v1); }
+int psdr_hip_sampler_floats(uint64_t seed_value, uint64_t lane, uint64_t skip, int32_t n, float *out_dev, void *stream) {
+    hipLaunchKernelGGL(k_sampler_floats, dim3(1), dim3(64), 0, (hipStream_t) stream, seed_value, lane, skip, n, out_dev);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+} // extern "C"

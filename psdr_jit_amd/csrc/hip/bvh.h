@@ -1,0 +1,146 @@
+// bvh.h — host-side builder of the software BVH that replaces the OptiX GAS
+// (reference src/scene/scene_optix.cpp:265-332 builds a geometry acceleration structure with
+// optixAccelBuild; MI355X has no ray-tracing unit, so traversal is a HIP loop over this tree).
+//
+// Layout (one 64-byte node = 4 x float4, fetched with four ds_read_b128 / one 64 B global line):
+//   q0 = left.lo.xyz , bits(left_ref)      q1 = left.hi.xyz , bits(right_ref)
+//   q2 = right.lo.xyz, 0                   q3 = right.hi.xyz, 0
+// ref >= 0 : index of an inner node;  ref < 0 : leaf, ~ref = (first_triangle << 2) | (count - 1),
+// 1..4 triangles, triangles re-ordered so that a leaf's triangles are contiguous.
+// Binned SAH (16 bins); boxes are padded so the slab test can never reject a ray that the
+// triangle test accepts (hit selection must not depend on the traversal order).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+namespace psdr {
+
+struct BvhResult {
+    std::vector<float> nodes;      // 16 floats per node
+    std::vector<int32_t> order;    // device triangle slot -> original triangle id
+    int32_t n_nodes = 0, n_leaves = 0, max_depth = 0;
+};
+
+namespace bvh_detail {
+struct Box {
+    float lo[3], hi[3];
+    Box() { for (int k = 0; k < 3; ++k) { lo[k] = std::numeric_limits<float>::max(); hi[k] = -std::numeric_limits<float>::max(); } }
+    void grow(const Box &b) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); } }
+    void grow(const float *p) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); } }
+    float half_area() const {
+        float d[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+        if (d[0] < 0.f) return 0.f;
+        return d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
+    }
+};
+struct TmpNode { Box box; int left = -1, right = -1, first = 0, count = 0; };
+inline int32_t float_bits(int32_t v) { return v; }
+} // namespace bvh_detail
+
+inline void build_bvh(const float *p0, const float *e1, const float *e2, int n, BvhResult &out) {
+    using namespace bvh_detail;
+    constexpr int kBins = 16, kLeafMax = 4;
+    std::vector<Box> tb(n);
+    std::vector<float> ctr(3 * (size_t) n);
+    out.order.resize(n);
+    for (int i = 0; i < n; ++i) {
+        out.order[i] = i;
+        float a[3], b[3], c[3];
+        for (int k = 0; k < 3; ++k) { a[k] = p0[3 * i + k]; b[k] = a[k] + e1[3 * i + k]; c[k] = a[k] + e2[3 * i + k]; }
+        tb[i].grow(a); tb[i].grow(b); tb[i].grow(c);
+        for (int k = 0; k < 3; ++k) {
+            ctr[3 * (size_t) i + k] = 0.5f * (tb[i].lo[k] + tb[i].hi[k]);
+            float pad = 1e-4f * std::max(1.f, std::max(std::fabs(tb[i].lo[k]), std::fabs(tb[i].hi[k])));
+            tb[i].lo[k] -= pad; tb[i].hi[k] += pad;
+        }
+    }
+    std::vector<TmpNode> tmp;
+    tmp.reserve(2 * (size_t) n + 2);
+    struct Job { int node, first, count, depth; };
+    std::vector<Job> stack;
+    tmp.emplace_back();
+    stack.push_back({0, 0, n, 1});
+    int max_depth = 1;
+    while (!stack.empty()) {
+        Job j = stack.back(); stack.pop_back();
+        max_depth = std::max(max_depth, j.depth);
+        Box box, cb;
+        for (int i = j.first; i < j.first + j.count; ++i) { box.grow(tb[out.order[i]]); cb.grow(&ctr[3 * (size_t) out.order[i]]); }
+        TmpNode nd; nd.box = box; nd.first = j.first; nd.count = j.count;
+        if (j.count > kLeafMax || (j.node == 0 && j.count > 1)) {
+            int axis = 0;
+            for (int k = 1; k < 3; ++k) if (cb.hi[k] - cb.lo[k] > cb.hi[axis] - cb.lo[axis]) axis = k;
+            int mid = -1;
+            float ext = cb.hi[axis] - cb.lo[axis];
+            if (ext > 0.f) {
+                Box bb[kBins]; int bc[kBins] = {0};
+                float scale = kBins / ext;
+                auto bin_of = [&](int t) { int b = (int) ((ctr[3 * (size_t) t + axis] - cb.lo[axis]) * scale); return std::min(std::max(b, 0), kBins - 1); };
+                for (int i = j.first; i < j.first + j.count; ++i) { int t = out.order[i]; int b = bin_of(t); bb[b].grow(tb[t]); bc[b]++; }
+                float best = std::numeric_limits<float>::max(); int best_split = -1;
+                Box r[kBins]; int rc[kBins];
+                Box acc; int cnt = 0;
+                for (int b = kBins - 1; b > 0; --b) { acc.grow(bb[b]); cnt += bc[b]; r[b] = acc; rc[b] = cnt; }
+                acc = Box(); cnt = 0;
+                for (int b = 0; b < kBins - 1; ++b) {
+                    acc.grow(bb[b]); cnt += bc[b];
+                    if (cnt == 0 || rc[b + 1] == 0) continue;
+                    float cost = acc.half_area() * cnt + r[b + 1].half_area() * rc[b + 1];
+                    if (cost < best) { best = cost; best_split = b; }
+                }
+                if (best_split >= 0) {
+                    auto it = std::stable_partition(out.order.begin() + j.first, out.order.begin() + j.first + j.count,
+                                                    [&](int t) { return bin_of(t) <= best_split; });
+                    mid = (int) (it - out.order.begin());
+                }
+            }
+            if (mid <= j.first || mid >= j.first + j.count) {   // degenerate: split by index
+                mid = j.first + j.count / 2;
+            }
+            nd.left = (int) tmp.size(); tmp.emplace_back();
+            nd.right = (int) tmp.size(); tmp.emplace_back();
+            nd.count = 0;
+            stack.push_back({nd.left, j.first, mid - j.first, j.depth + 1});
+            stack.push_back({nd.right, mid, j.first + j.count - mid, j.depth + 1});
+        }
+        tmp[j.node] = nd;
+    }
+    // emit two-box nodes; inner tmp nodes get device indices in DFS order
+    std::vector<int> dev_index(tmp.size(), -1);
+    int n_inner = 0, n_leaves = 0;
+    for (size_t i = 0; i < tmp.size(); ++i) { if (tmp[i].left >= 0) dev_index[i] = n_inner++; else n_leaves++; }
+    bool single_leaf_root = (tmp[0].left < 0);
+    if (single_leaf_root) n_inner = 1;
+    out.nodes.assign(16 * (size_t) n_inner, 0.f);
+    auto ref_of = [&](int ti) -> int32_t {
+        const TmpNode &t = tmp[ti];
+        if (t.left >= 0) return dev_index[ti];
+        return ~((t.first << 2) | (t.count - 1));
+    };
+    auto put = [&](float *q, const Box &b, int32_t ref_lo_slot, int32_t ref_hi_slot, bool with_refs) {
+        q[0] = b.lo[0]; q[1] = b.lo[1]; q[2] = b.lo[2];
+        q[4] = b.hi[0]; q[5] = b.hi[1]; q[6] = b.hi[2];
+        if (with_refs) { std::memcpy(&q[3], &ref_lo_slot, 4); std::memcpy(&q[7], &ref_hi_slot, 4); }
+    };
+    if (single_leaf_root) {
+        float *q = &out.nodes[0];
+        Box empty;   // lo > hi: never hit
+        int32_t lref = n > 0 ? ref_of(0) : ~0, rref = lref;
+        put(q, n > 0 ? tmp[0].box : empty, lref, rref, true);
+        put(q + 8, empty, 0, 0, false);
+    } else {
+        for (size_t i = 0; i < tmp.size(); ++i) {
+            if (tmp[i].left < 0) continue;
+            float *q = &out.nodes[16 * (size_t) dev_index[i]];
+            put(q, tmp[tmp[i].left].box, ref_of(tmp[i].left), ref_of(tmp[i].right), true);
+            put(q + 8, tmp[tmp[i].right].box, 0, 0, false);
+        }
+    }
+    out.n_nodes = n_inner; out.n_leaves = n_leaves; out.max_depth = max_depth;
+}
+
+} // namespace psdr

@@ -1,0 +1,178 @@
+// edges.h — camera sampling and the two boundary-integral estimators of renderD.
+//   primary edges   : Integrator::render_primary_edges, reference src/integrator/integrator.cpp:179-198
+//                     + PerspectiveCamera::sample_primary_edge, src/sensor/perspective.cpp:200-226
+//   secondary edges : PathTracer::eval_secondary_edge / render_secondary_edges, src/integrator/path.cpp:171-294
+//                     + Scene::sample_boundary_segment_direct, src/scene/scene.cpp:1027-1068
+// Both have zero primal (value - detach(value)); only the tangent is accumulated.
+#pragma once
+#include "shade.h"
+
+namespace psdr {
+
+// PerspectiveCamera::sample_primary_ray, reference perspective.cpp:160-178 (direction detached in D mode)
+template <bool AD> PSDR_DEV RayT<AD> sample_primary_ray(const SensorDev &cam, float sx, float sy) {
+    const Vec3f d = normalize(xform_pos(cam.sample_to_camera, Vec3f(sx, sy, 0.f)));
+    RayT<AD> r;
+    if constexpr (AD) {
+        Mat4<Dual> M;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) M.m[i] = Dual(cam.to_world.m[i], cam.d_to_world.m[i]);
+        r.o = xform_pos(M, Vec3d(Dual(0.f)));
+        r.d = xform_dir(M, promote(d));
+    } else {
+        r.o = xform_pos(cam.to_world, Vec3f(0.f));
+        r.d = xform_dir(cam.to_world, d);
+    }
+    return r;
+}
+
+struct SensorDirectSample { float qx, qy; int pixel_idx; float sensor_val; bool valid; };
+// PerspectiveCamera::sample_direct, reference perspective.cpp:181-197
+PSDR_DEV SensorDirectSample sample_direct(const SceneTables &T, const SensorDev &cam, const Vec3f &p) {
+    SensorDirectSample r;
+    const Vec3f q = xform_pos(cam.world_to_sample, p);
+    r.qx = q.x; r.qy = q.y;
+    const int ix = (int) floorf(q.x * (float) T.width), iy = (int) floorf(q.y * (float) T.height);
+    r.valid = ix >= 0 && ix < T.width && iy >= 0 && iy < T.height;
+    r.pixel_idx = r.valid ? iy * T.width + ix : -1;
+    Vec3f dir = p - Vec3f(cam.cam_pos[0], cam.cam_pos[1], cam.cam_pos[2]);
+    const float dist2 = squared_norm(dir);
+    dir = dir / safe_sqrt(dist2);
+    const float cosTheta = dot(Vec3f(cam.cam_dir[0], cam.cam_dir[1], cam.cam_dir[2]), dir);
+    const float rc = 1.f / cosTheta;
+    r.sensor_val = (1.f / dist2) * (rc * rc * rc) * cam.inv_area;
+    return r;
+}
+
+// one lane of render_primary_edges: returns pixel index (or -1) and d(value)/d(theta)
+template <bool LDS, bool COUNT>
+PSDR_DEV int primary_edge_lane(SceneView<LDS> &S, const SensorDev &cam, LaneRng &rng, int max_depth, bool hide, int sppe, Vec3f &dval) {
+    const SceneTables &T = *S.T;
+    float s = rng.next_1d(), pdf;
+    const int ei = sample_reuse(cam.n_edges, cam.edge_sum, [&](int i) { return cam.edge_pmf[i]; }, [&](int i) { return cam.edge_cmf[i]; }, s, pdf);
+    pdf /= cam.edge_length[ei];
+    const float nx = cam.edge_normal[2 * ei], ny = cam.edge_normal[2 * ei + 1];
+    const float oms = 1.0f - s;
+    const Dual p0x(cam.edge_p0[2 * ei], cam.d_edge_p0[2 * ei]), p0y(cam.edge_p0[2 * ei + 1], cam.d_edge_p0[2 * ei + 1]);
+    const Dual p1x(cam.edge_p1[2 * ei], cam.d_edge_p1[2 * ei]), p1y(cam.edge_p1[2 * ei + 1], cam.d_edge_p1[2 * ei + 1]);
+    const Dual px = fma_(p0x, oms, p1x * s), py = fma_(p0y, oms, p1y * s);
+    const Dual x_dot_n = fma_(py, ny, px * nx);
+    const int ix = (int) floorf(px.v * (float) T.width), iy = (int) floorf(py.v * (float) T.height);
+    const bool valid = ix >= 0 && ix < T.width && iy >= 0 && iy < T.height;
+    const int idx = valid ? iy * T.width + ix : -1;
+    const RayT<false> ray_p = sample_primary_ray<false>(cam, px.v + kEdgeEpsilon * nx, py.v + kEdgeEpsilon * ny);
+    const RayT<false> ray_n = sample_primary_ray<false>(cam, px.v - kEdgeEpsilon * nx, py.v - kEdgeEpsilon * ny);
+    // Li(ray_n) first, then Li(ray_p): both advance sampler 1 (integrator.cpp:185-186)
+    const Vec3f Ln = Li<false, LDS, COUNT>(S, rng, ray_n, valid, max_depth, hide);
+    const Vec3f Lp = Li<false, LDS, COUNT>(S, rng, ray_p, valid, max_depth, hide);
+    const Vec3f dL = (Ln - Lp) / pdf;
+    float out[3] = {dL.x, dL.y, dL.z};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float pv = x_dot_n.v * out[c];
+        float dv = x_dot_n.d * out[c];
+        if (!finite_(pv) || !finite_(dv)) dv = 0.f;          // integrator.cpp:188
+        if (sppe > 1) dv /= (float) sppe;
+        out[c] = dv;
+    }
+    dval = Vec3f(out[0], out[1], out[2]);
+    return idx;
+}
+
+struct BoundarySegSampleDirect { bool valid; float pdf; Vec3d p0; Vec3f edge, edge2, p2, n; int emitter_slot; };
+
+PSDR_DEV int sign_eps(float x, float eps) { return x > eps ? 1 : (x < -eps ? -1 : 0); }     // reference utils.h:47-53
+PSDR_DEV float sign1(float x) { return signbit_(x) ? -1.f : 1.f; }                          // drjit::sign
+PSDR_DEV Vec3f ld3(const float *p, int i) { return Vec3f(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
+
+// Scene::sample_boundary_segment_direct, reference scene.cpp:1027-1068
+template <bool LDS> PSDR_DEV BoundarySegSampleDirect sample_boundary_segment_direct(const SceneView<LDS> &S, const SecEdgeTables &E, Vec3f s3) {
+    BoundarySegSampleDirect r;
+    float sample1 = s3.x, pdf0;
+    const int ei = sample_reuse(E.n, E.sum, [&](int i) { return E.pmf[i]; }, [&](int i) { return E.cmf[i]; }, sample1, pdf0);
+    const Vec3f e1 = ld3(E.e1, ei), p0 = ld3(E.p0, ei);
+    Vec3f de1(0.f), dp0(0.f);
+    if (E.d_e1) { de1 = ld3(E.d_e1, ei); dp0 = ld3(E.d_p0, ei); }
+    const Dual s1(sample1);
+    r.p0 = Vec3d(fma_(Dual(e1.x, de1.x), s1, Dual(p0.x, dp0.x)), fma_(Dual(e1.y, de1.y), s1, Dual(p0.y, dp0.y)), fma_(Dual(e1.z, de1.z), s1, Dual(p0.z, dp0.z)));
+    r.edge = normalize(e1);
+    r.edge2 = ld3(E.p2, ei) - p0;
+    const Vec3f p0v = detach(r.p0);
+    pdf0 /= norm(e1);
+    const PositionSample<false> ps2 = sample_emitter_position<false, LDS>(S, s3.y, s3.z);
+    r.p2 = ps2.p; r.n = ps2.n; r.emitter_slot = ps2.slot;
+    Vec3f e = r.p2 - p0v;
+    const float distSqr = squared_norm(e);
+    e = e / safe_sqrt(distSqr);
+    const float cosTheta = dot(r.n, -e);
+    const bool is_boundary = E.is_boundary[ei] != 0;
+    const int sgn0 = sign_eps(dot(ld3(E.n0, ei), e), kEdgeEpsilon), sgn1 = sign_eps(dot(ld3(E.n1, ei), e), kEdgeEpsilon);
+    r.valid = (cosTheta > kEpsilon) && ((is_boundary && sgn0 != 0) || (!is_boundary && sgn0 * sgn1 < 0));
+    r.pdf = r.valid ? pdf0 * ps2.pdf * (distSqr / cosTheta) : 0.f;
+    return r;
+}
+
+// PathTracer::eval_secondary_edge<ad>, reference path.cpp:171-270.
+// AD=true : returns the pixel index (or -1) and the tangent of the estimator in `value`.
+// AD=false: guiding pass, `value` = value0 without the normal velocity (path.cpp:267-268), returns -1.
+template <bool AD, bool LDS, bool COUNT>
+PSDR_DEV int eval_secondary_edge(SceneView<LDS> &S, const SecEdgeTables &E, const SensorDev &cam, const Vec3f &s3, Vec3f &value) {
+    value = Vec3f(0.f);
+    const SceneTables &T = *S.T;
+    const BoundarySegSampleDirect bss = sample_boundary_segment_direct<LDS>(S, E, s3);
+    if (!bss.valid) return -1;
+    const Vec3f _p0 = detach(bss.p0), _p2 = bss.p2, _dir = normalize(_p2 - _p0);
+
+    RayT<false> r2; r2.o = _p0; r2.d = _dir;
+    const Its<false> its2 = ray_intersect<false, false, LDS, COUNT>(S, r2, true);
+    if (!(its2.valid && mesh_emitter(S, its2.mesh) >= 0 && norm(its2.p - _p2) < kShadowEpsilon)) return -1;
+
+    RayT<false> r1; r1.o = _p0; r1.d = -_dir;
+    const Its<false> its1c = ray_intersect<false, false, LDS, COUNT>(S, r1, true);
+    if (!its1c.valid) return -1;
+    const Vec3f _p1 = its1c.p;
+
+    const SensorDirectSample sds = sample_direct(T, cam, _p1);
+    if (!sds.valid) return -1;
+
+    const RayT<AD> camera_ray = sample_primary_ray<AD>(cam, sds.qx, sds.qy);
+    const Its<AD> its1 = ray_intersect<AD, false, LDS, COUNT>(S, camera_ray, true);
+    if (!(its1.valid && norm(detach(its1.p) - _p1) < kShadowEpsilon)) return -1;
+    if (mesh_bsdf(S, its1.mesh) < 0) return -1;
+
+    const float dist = norm(_p2 - _p1), cos2 = fabsf(dot(bss.n, -_dir));
+    const Vec3f e = cross(bss.edge, _dir);
+    const float sinphi = norm(e);
+    const Vec3f proj = normalize(cross(e, bss.n));
+    const float sinphi2 = norm(cross(_dir, proj));
+    const float base_v = (its1c.t / dist) * (sinphi / sinphi2) * cos2;
+    if (!((sinphi > kEpsilon) && (sinphi2 > kEpsilon))) return -1;
+
+    const Vec3f d0 = -detach(camera_ray.d);
+    const Vec3f d0_local = to_local<false>(its1c, d0);
+    Vec3f bsdf_val = bsdf_eval<false, LDS>(S, its1c, d0_local, true);
+    const float correction = fabsf((its1c.wi.z * dot(d0, its1c.n)) / (d0_local.z * dot(_dir, its1c.n)));
+    bsdf_val = bsdf_val * correction;
+    Vec3f value0 = bsdf_val * eval_Le<false, LDS>(S, its2, true) * (base_v * sds.sensor_val / bss.pdf);
+
+    if constexpr (AD) {
+        const Vec3f n = normalize(cross(bss.n, proj));
+        value0 = value0 * (sign1(dot(e, bss.edge2)) * sign1(dot(e, n)));
+        Vec3d v0, e1, e2;
+        load_geom<true, LDS>(S, its2.slot, v0, e1, e2);
+        const Vec3d sd = normalize(bss.p0 - its1.p);
+        Dual u, v, t;
+        ray_tri_uvt<Dual>(v0, e1, e2, its1.p, sd, u, v, t);
+        // u2 = bilinear(detach(v0), detach(e1), detach(e2), uv): only the barycentrics carry a tangent
+        const Vec3f v0f = detach(v0), e1f = detach(e1), e2f = detach(e2);
+        const Vec3f du2(e1f.x * u.d + e2f.x * v.d, e1f.y * u.d + e2f.y * v.d, e1f.z * u.d + e2f.z * v.d);
+        const float dn = dot(n, du2);
+        value = value0 * dn;                                  // result - detach(result)
+        return sds.pixel_idx;
+    } else {
+        value = value0;
+        return -1;
+    }
+}
+
+} // namespace psdr

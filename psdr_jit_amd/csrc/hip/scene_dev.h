@@ -1,0 +1,132 @@
+// scene_dev.h — device view of the configured scene and the closest-hit traversal.
+//
+// All read-only scene tables live in ONE contiguous "blob" of float4 words
+//   [ BVH nodes | traversal triangles | shading triangles | triangle tangents | orig->slot map |
+//     mesh / bsdf / emitter records | emitter CDF | emitter-mesh face CDFs ]
+// which psdr_hip_scene_create uploads once.  When the blob is small (Cornell box: ~11 KB) every
+// workgroup copies it into LDS with coalesced 16-byte loads at kernel start and all later scene
+// reads are ds_read_b128 (wave-uniform addresses broadcast); large scenes read it through L2.
+// The kernels are templated on the memory space so that both forms compile to their own ISA.
+#pragma once
+#include "dmath.h"
+
+namespace psdr {
+
+constexpr float kEpsilon = 1e-5f, kRayEpsilon = 1e-3f, kShadowEpsilon = 1e-3f, kEdgeEpsilon = 1e-5f;   // reference constants.h:12-17
+constexpr float kPi = 3.14159265358979323846f, kInvPi = 0.31830988618379067154f;
+constexpr float kTraceTMax = 100000000.f;   // reference scene_optix.cpp:376
+constexpr int kBlock = 256;
+
+struct SceneTables {
+    // float4-word offsets into the blob
+    int nodes_off, trav_off, shade_off, tan_off, map_off, mesh_off, bsdf_off, emit_off, ecdf_off, fcdf_off;
+    int n_nodes, n_tris, n_meshes, n_bsdfs, n_emitters, n_fcdf;
+    int has_tangent, stack_depth;
+    float emitter_sum;
+    int blob_words;            // float4 count
+    int width, height, spp, sppe, sppse;
+};
+
+struct SecEdgeTables {         // global memory (one random edge per lane: no reuse worth staging)
+    const float *p0, *e1, *n0, *n1, *p2, *d_p0, *d_e1, *pmf, *cmf;
+    const uint8_t *is_boundary;
+    int n;
+    float sum;
+};
+
+struct SensorDev {
+    Mat4<float> sample_to_camera, to_world, d_to_world, world_to_sample, d_world_to_sample;
+    float cam_pos[3], cam_dir[3];
+    float inv_area;
+    int n_edges;
+    const float *edge_p0, *edge_p1, *d_edge_p0, *d_edge_p1, *edge_normal, *edge_length, *edge_pmf, *edge_cmf;
+    float edge_sum;
+};
+
+struct Counters { unsigned long long rays, nodes, tris, hits; };
+
+// per-lane view used by every device function
+template <bool LDS> struct SceneView {
+    const float4 *B;           // blob base (LDS or global)
+    const SceneTables *T;      // kernel-argument copy
+    int *stack;                // this lane's LDS traversal stack, stride kBlock
+    unsigned int c_nodes, c_tris, c_rays, c_hits;   // instrumented build only
+
+    PSDR_DEV float4 ld(int word) const { return B[word]; }
+    PSDR_DEV float ldf(int word_off, int idx) const { return reinterpret_cast<const float *>(B + word_off)[idx]; }
+    PSDR_DEV int ldi(int word_off, int idx) const { return reinterpret_cast<const int *>(B + word_off)[idx]; }
+};
+
+struct Hit { int slot; float u, v, t; };   // slot = device triangle slot (BVH leaf order), -1 = miss
+
+// Möller–Trumbore exactly as the reference's own ray_intersect_triangle (include/psdr/utils.h:82-93)
+PSDR_DEV bool tri_test(const float4 &a, const float4 &b, const float4 &c, const Vec3f &o, const Vec3f &d, float &u, float &v, float &t) {
+    Vec3f p0(a.x, a.y, a.z), e1(a.w, b.x, b.y), e2(b.z, b.w, c.x);
+    Vec3f h = cross(d, e2);
+    float det = dot(e1, h);
+    float f = 1.f / det;
+    Vec3f s = o - p0;
+    u = f * dot(s, h);
+    Vec3f q = cross(s, e1);
+    v = f * dot(d, q);
+    t = f * dot(e2, q);
+    return (u >= 0.f) && (v >= 0.f) && (u + v <= 1.f) && (t > kRayEpsilon) && (t < kTraceTMax);
+}
+
+// Closest hit in (RayEpsilon, 1e8), ties -> smallest original triangle id
+// (replaces jit_optix_ray_trace, reference scene_optix.cpp:343-410; NaN rays miss, :348-353).
+template <bool LDS, bool COUNT>
+PSDR_DEV Hit trace(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
+    Hit best; best.slot = -1; best.u = best.v = 0.f; best.t = 0.f;
+    if (!(o.x == o.x && o.y == o.y && o.z == o.z && d.x == d.x && d.y == d.y && d.z == d.z)) return best;
+    const SceneTables &T = *S.T;
+    float best_t = __builtin_inff();
+    int best_id = 0x7fffffff;
+    const float ix = 1.f / d.x, iy = 1.f / d.y, iz = 1.f / d.z;
+    int sp = 0;
+    int ref = 0;
+    if (COUNT) S.c_rays++;
+    while (true) {
+        if (ref >= 0) {
+            const int w = T.nodes_off + 4 * ref;
+            const float4 q0 = S.ld(w), q1 = S.ld(w + 1), q2 = S.ld(w + 2), q3 = S.ld(w + 3);
+            if (COUNT) S.c_nodes++;
+            // slab tests; fminf/fmaxf drop NaNs (0 * inf), which keeps the test conservative
+            float t0, t1, tnL = 0.f, tfL = best_t, tnR = 0.f, tfR = best_t;
+            t0 = (q0.x - o.x) * ix; t1 = (q1.x - o.x) * ix; tnL = fmaxf(tnL, fminf(t0, t1)); tfL = fminf(tfL, fmaxf(t0, t1) * 1.0000004f);
+            t0 = (q0.y - o.y) * iy; t1 = (q1.y - o.y) * iy; tnL = fmaxf(tnL, fminf(t0, t1)); tfL = fminf(tfL, fmaxf(t0, t1) * 1.0000004f);
+            t0 = (q0.z - o.z) * iz; t1 = (q1.z - o.z) * iz; tnL = fmaxf(tnL, fminf(t0, t1)); tfL = fminf(tfL, fmaxf(t0, t1) * 1.0000004f);
+            t0 = (q2.x - o.x) * ix; t1 = (q3.x - o.x) * ix; tnR = fmaxf(tnR, fminf(t0, t1)); tfR = fminf(tfR, fmaxf(t0, t1) * 1.0000004f);
+            t0 = (q2.y - o.y) * iy; t1 = (q3.y - o.y) * iy; tnR = fmaxf(tnR, fminf(t0, t1)); tfR = fminf(tfR, fmaxf(t0, t1) * 1.0000004f);
+            t0 = (q2.z - o.z) * iz; t1 = (q3.z - o.z) * iz; tnR = fmaxf(tnR, fminf(t0, t1)); tfR = fminf(tfR, fmaxf(t0, t1) * 1.0000004f);
+            const bool hL = tnL <= tfL, hR = tnR <= tfR;
+            const int rL = __float_as_int(q0.w), rR = __float_as_int(q1.w);
+            if (hL && hR) {
+                const bool left_first = tnL <= tnR;
+                S.stack[sp * kBlock] = left_first ? rR : rL;
+                ++sp;
+                ref = left_first ? rL : rR;
+                continue;
+            } else if (hL) { ref = rL; continue; }
+            else if (hR) { ref = rR; continue; }
+        } else {
+            const int code = ~ref, first = code >> 2, cnt = (code & 3) + 1;
+            for (int k = 0; k < cnt; ++k) {
+                const int w = T.trav_off + 3 * (first + k);
+                const float4 a = S.ld(w), b = S.ld(w + 1), c = S.ld(w + 2);
+                float u, v, t;
+                if (COUNT) S.c_tris++;
+                if (tri_test(a, b, c, o, d, u, v, t)) {
+                    const int id = __float_as_int(c.y);
+                    if (t < best_t || (t == best_t && id < best_id)) { best_t = t; best_id = id; best.slot = first + k; best.u = u; best.v = v; best.t = t; }
+                }
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        ref = S.stack[sp * kBlock];
+    }
+    return best;
+}
+
+} // namespace psdr

@@ -1,0 +1,366 @@
+// shade.h — per-lane shading code of the path tracer: Scene::ray_intersect post-processing,
+// area-light sampling, the diffuse BSDF and PathTracer::__Li, all in registers.
+// The reference materialises every quantity below as an N-lane device array between OptiX launches
+// (SURVEY.md §2 kernel table); here one lane = one thread and nothing leaves the register file.
+// AD=false is the reference's C instantiation, AD=true its D instantiation (one forward tangent).
+#pragma once
+#include "scene_dev.h"
+#include "sampler.h"
+
+namespace psdr {
+
+template <bool AD> struct RayT { VecN<AD> o, d; };
+
+// reference include/psdr/core/intersection.h:24-60 — only the members the diffuse path reads
+template <bool AD> struct Its {
+    bool valid;
+    int slot, mesh;
+    VecN<AD> p, n, wi, fs, ft, fn;     // position, geometric normal, local incident dir, shading frame
+    Num<AD> t, J;
+};
+
+template <bool AD> PSDR_DEV VecN<AD> to_local(const Its<AD> &its, const VecN<AD> &v) { return VecN<AD>(dot(v, its.fs), dot(v, its.ft), dot(v, its.fn)); }
+template <bool AD> PSDR_DEV VecN<AD> to_world(const Its<AD> &its, const Vec3f &v) {
+    return its.fs * Num<AD>(v.x) + its.ft * Num<AD>(v.y) + its.fn * Num<AD>(v.z);
+}
+
+// reference include/psdr/core/frame.h:9-28 (Duff et al. 2017)
+template <typename T> PSDR_DEV void coordinate_system(const Vec3<T> &n, Vec3<T> &s, Vec3<T> &t) {
+    const float nz = detach(n.z);
+    const float sg = signbit_(nz) ? -1.f : 1.f;
+    T a = -rcp_(T(sg) + n.z);
+    T b = n.x * n.y * a;
+    s = Vec3<T>(mulsign(sqr(n.x) * a, nz) + T(1.f), mulsign(b, nz), -mulsign(n.x, nz));
+    t = Vec3<T>(b, T(sg) + sqr(n.y) * a, -n.y);
+}
+
+template <bool AD, bool LDS> struct TriData { VecN<AD> p0, e1, e2; };
+
+template <bool AD, bool LDS> PSDR_DEV VecN<AD> pick3(const Vec3f &v, const Vec3f &d) {
+    if constexpr (AD) return make_dual(v, d); else return v;
+}
+
+// load p0,e1,e2 (+tangents) of a triangle slot
+template <bool AD, bool LDS> PSDR_DEV void load_geom(const SceneView<LDS> &S, int slot, VecN<AD> &p0, VecN<AD> &e1, VecN<AD> &e2) {
+    const SceneTables &T = *S.T;
+    const int w = T.trav_off + 3 * slot;
+    const float4 a = S.ld(w), b = S.ld(w + 1), c = S.ld(w + 2);
+    Vec3f vp0(a.x, a.y, a.z), ve1(a.w, b.x, b.y), ve2(b.z, b.w, c.x);
+    if constexpr (AD) {
+        if (T.has_tangent) {
+            const int g = T.tan_off + 6 * slot;
+            const float4 ta = S.ld(g), tb = S.ld(g + 1), tc = S.ld(g + 2);
+            p0 = make_dual(vp0, Vec3f(ta.x, ta.y, ta.z)); e1 = make_dual(ve1, Vec3f(ta.w, tb.x, tb.y)); e2 = make_dual(ve2, Vec3f(tb.z, tb.w, tc.x));
+        } else { p0 = promote(vp0); e1 = promote(ve1); e2 = promote(ve2); }
+    } else { p0 = vp0; e1 = ve1; e2 = ve2; }
+}
+
+template <typename T> PSDR_DEV void ray_tri_uvt(const Vec3<T> &p0, const Vec3<T> &e1, const Vec3<T> &e2, const Vec3<T> &o, const Vec3<T> &d, T &u, T &v, T &t) {
+    Vec3<T> h = cross(d, e2);
+    T a = dot(e1, h);
+    T f = rcp_(a);
+    Vec3<T> s = o - p0;
+    u = f * dot(s, h);
+    Vec3<T> q = cross(s, e1);
+    v = f * dot(d, q);
+    t = f * dot(e2, q);
+}
+
+// Scene::ray_intersect<ad, path_space>, reference src/scene/scene.cpp:612-806
+template <bool AD, bool PATH_SPACE, bool LDS, bool COUNT>
+PSDR_DEV Its<AD> ray_intersect(SceneView<LDS> &S, const RayT<AD> &ray, bool active) {
+    static_assert(AD || !PATH_SPACE, "path-space needs AD");
+    using R = Num<AD>; using V = VecN<AD>;
+    Its<AD> its;
+    its.valid = false; its.slot = -1; its.mesh = -1; its.t = R(0.f); its.J = R(1.f);
+    if (!active) return its;
+    const Hit h = trace<LDS, COUNT>(S, detach(ray.o), detach(ray.d));
+    if (h.slot < 0) return its;
+    if (COUNT) S.c_hits++;
+    const SceneTables &T = *S.T;
+    its.valid = true; its.slot = h.slot;
+    V p0, e1, e2;
+    load_geom<AD, LDS>(S, h.slot, p0, e1, e2);
+    const int w = T.shade_off + 6 * h.slot;
+    const float4 s0 = S.ld(w), s1 = S.ld(w + 1), s2 = S.ld(w + 2), s3 = S.ld(w + 3), s4 = S.ld(w + 4), s5 = S.ld(w + 5);
+    its.mesh = __float_as_int(s1.w);
+    const bool flat = (__float_as_int(s2.w) & 1) != 0;
+    V n0, n1, n2;
+    if constexpr (AD) {
+        if (T.has_tangent) {
+            const int g = T.tan_off + 6 * h.slot;
+            const float4 tc = S.ld(g + 2), td = S.ld(g + 3), te = S.ld(g + 4), tf = S.ld(g + 5);
+            n0 = make_dual(Vec3f(s0.x, s0.y, s0.z), Vec3f(tc.y, tc.z, tc.w));
+            n1 = make_dual(Vec3f(s1.x, s1.y, s1.z), Vec3f(td.x, td.y, td.z));
+            n2 = make_dual(Vec3f(s2.x, s2.y, s2.z), Vec3f(td.w, te.x, te.y));
+            its.n = make_dual(Vec3f(s3.x, s3.y, s3.z), Vec3f(te.z, te.w, tf.x));
+            if constexpr (PATH_SPACE) its.J = Dual(s0.w, tf.y) / Dual(s0.w);      // area / detach(area), scene.cpp:680
+        } else {
+            n0 = promote(Vec3f(s0.x, s0.y, s0.z)); n1 = promote(Vec3f(s1.x, s1.y, s1.z)); n2 = promote(Vec3f(s2.x, s2.y, s2.z));
+            its.n = promote(Vec3f(s3.x, s3.y, s3.z));
+        }
+    } else {
+        n0 = Vec3f(s0.x, s0.y, s0.z); n1 = Vec3f(s1.x, s1.y, s1.z); n2 = Vec3f(s2.x, s2.y, s2.z);
+        its.n = Vec3f(s3.x, s3.y, s3.z);
+    }
+    R u, v;
+    V dir_in;
+    if constexpr (!AD || PATH_SPACE) {
+        u = R(h.u); v = R(h.v);                         // detached barycentrics from the tracer
+        its.p = madd3(e1, u, e2, v, p0);
+        V dir = its.p - ray.o;
+        its.t = norm(dir);
+        dir_in = dir / its.t;
+    } else {
+        R t;
+        ray_tri_uvt<R>(p0, e1, e2, ray.o, ray.d, u, v, t);     // differentiable re-intersection, scene.cpp:774
+        its.p = V(fma_(ray.d.x, t, ray.o.x), fma_(ray.d.y, t, ray.o.y), fma_(ray.d.z, t, ray.o.z));
+        its.t = t;
+        dir_in = ray.d;
+    }
+    V sh_n = normalize(madd3(n1 - n0, u, n2 - n0, v, n0));
+    if (flat) sh_n = its.n;
+    its.fn = sh_n;
+    coordinate_system(sh_n, its.fs, its.ft);
+    // tangent frame from the uv parameterisation when it is non-degenerate (scene.cpp:724-766)
+    const float du0x = s4.z - s4.x, du0y = s4.w - s4.y, du1x = s5.x - s4.x, du1y = s5.y - s4.y;
+    const float det = fma_(du0x, du1y, -(du0y * du1x));
+    if (det != 0.f) {
+        const float inv_det = 1.f / det;
+        V dp_du = (e1 * R(du1y) - e2 * R(du0y)) * R(inv_det);
+        its.fs = normalize(dp_du - sh_n * dot(sh_n, dp_du));
+        its.ft = cross(sh_n, its.fs);
+    }
+    its.wi = to_local<AD>(its, -dir_in);
+    return its;
+}
+
+// ---------------------------------------------------------------- records from the blob
+struct MeshRec { int bsdf, emitter, face_offset, n_faces; float inv_total_area; int distrb_offset; float distrb_sum; };
+template <bool LDS> PSDR_DEV MeshRec load_mesh(const SceneView<LDS> &S, int mesh) {
+    const int w = S.T->mesh_off + 2 * mesh;
+    const float4 a = S.ld(w), b = S.ld(w + 1);
+    MeshRec m;
+    m.bsdf = __float_as_int(a.x); m.emitter = __float_as_int(a.y); m.face_offset = __float_as_int(a.z); m.n_faces = __float_as_int(a.w);
+    m.inv_total_area = b.x; m.distrb_offset = __float_as_int(b.y); m.distrb_sum = b.z;
+    return m;
+}
+template <bool LDS> PSDR_DEV int mesh_emitter(const SceneView<LDS> &S, int mesh) { return __float_as_int(S.ld(S.T->mesh_off + 2 * mesh).y); }
+template <bool LDS> PSDR_DEV int mesh_bsdf(const SceneView<LDS> &S, int mesh) { return __float_as_int(S.ld(S.T->mesh_off + 2 * mesh).x); }
+
+// DiscreteDistribution::sample_reuse, reference src/core/pmf.cpp:26-45 (size 1 leaves the sample untouched)
+template <typename PmfFn, typename CmfFn>
+PSDR_DEV int sample_reuse(int size, float sum, PmfFn pmf, CmfFn cmf, float &s, float &pdf) {
+    if (size == 1) { pdf = 1.f; return 0; }
+    s *= sum;
+    int lo = 0, hi = size - 1;               // first i in [0, size-1) with !(cmf[i] < s), else size-1
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (cmf(mid) < s) lo = mid + 1; else hi = mid; }
+    const int idx = lo;
+    if (idx > 0) s -= cmf(idx - 1);
+    const float p = pmf(idx);
+    if (p > 0.f) s /= p;
+    s = fminf(fmaxf(s, 0.f), 1.f);
+    pdf = p / sum;
+    return idx;
+}
+
+// ---------------------------------------------------------------- emitters (area lights)
+// Intersection::Le -> AreaLight::eval, reference intersection.h:35-42, area.cpp:17-26
+template <bool AD, bool LDS> PSDR_DEV VecN<AD> eval_Le(const SceneView<LDS> &S, const Its<AD> &its, bool active) {
+    using V = VecN<AD>;
+    if (!active || !its.valid) return V(Num<AD>(0.f));
+    const int e = mesh_emitter(S, its.mesh);
+    if (e < 0 || !(detach(its.wi.z) > 0.f)) return V(Num<AD>(0.f));
+    const int w = S.T->emit_off + 2 * e;
+    const float4 a = S.ld(w);
+    if constexpr (AD) { const float4 b = S.ld(w + 1); return make_dual(Vec3f(a.x, a.y, a.z), Vec3f(b.x, b.y, b.z)); }
+    else return Vec3f(a.x, a.y, a.z);
+}
+
+template <bool AD> struct PositionSample { VecN<AD> p, n; Num<AD> J; float pdf; int slot; };
+
+// Scene::sample_emitter_position -> AreaLight::sample_position -> Mesh::__sample_position
+// reference scene.cpp:987-1013, mesh.cpp:413-454, warp.h:79-82
+template <bool AD, bool LDS> PSDR_DEV PositionSample<AD> sample_emitter_position(const SceneView<LDS> &S, float sx, float sy) {
+    const SceneTables &T = *S.T;
+    float epdf = 1.f;
+    int ei = 0;
+    if (T.n_emitters > 1) {
+        ei = sample_reuse(T.n_emitters, T.emitter_sum,
+                          [&](int i) { return S.ldf(T.ecdf_off, i); },
+                          [&](int i) { return S.ldf(T.ecdf_off, T.n_emitters + i); }, sy, epdf);
+    }
+    const int mesh = __float_as_int(S.ld(T.emit_off + 2 * ei + 1).w);
+    const MeshRec m = load_mesh(S, mesh);
+    float fpdf;
+    const int fi = sample_reuse(m.n_faces, m.distrb_sum,
+                                [&](int i) { return S.ldf(T.fcdf_off, m.distrb_offset + i); },
+                                [&](int i) { return S.ldf(T.fcdf_off, T.n_fcdf + m.distrb_offset + i); }, sx, fpdf);
+    const float tt = safe_sqrt(1.f - sx);
+    const float a = 1.f - tt, b = tt * sy;
+    const int slot = S.ldi(T.map_off, m.face_offset + fi);
+    PositionSample<AD> r;
+    VecN<AD> p0, e1, e2;
+    load_geom<AD, LDS>(S, slot, p0, e1, e2);
+    r.p = madd3(e1, Num<AD>(a), e2, Num<AD>(b), p0);
+    const float4 s0 = S.ld(T.shade_off + 6 * slot), s3 = S.ld(T.shade_off + 6 * slot + 3);
+    r.J = Num<AD>(1.f);
+    if constexpr (AD) {
+        if (T.has_tangent) {
+            const float4 te = S.ld(T.tan_off + 6 * slot + 4), tf = S.ld(T.tan_off + 6 * slot + 5);
+            r.n = make_dual(Vec3f(s3.x, s3.y, s3.z), Vec3f(te.z, te.w, tf.x));
+            r.J = Dual(s0.w, tf.y) / Dual(s0.w);
+        } else r.n = promote(Vec3f(s3.x, s3.y, s3.z));
+    } else r.n = Vec3f(s3.x, s3.y, s3.z);
+    r.pdf = m.inv_total_area * epdf;
+    r.slot = slot;
+    return r;
+}
+
+// Scene::emitter_position_pdf, reference scene.cpp:1016-1024 -> area.cpp:48-59 -> mesh.cpp:457-466
+template <bool AD, bool LDS> PSDR_DEV float emitter_position_pdf(const SceneView<LDS> &S, const Its<AD> &its) {
+    if (!its.valid) return 0.f;
+    const MeshRec m = load_mesh(S, its.mesh);
+    if (m.emitter < 0) return 0.f;
+    return S.ld(S.T->emit_off + 2 * m.emitter).w * m.inv_total_area;
+}
+
+// ---------------------------------------------------------------- Diffuse BSDF, reference src/bsdf/diffuse.cpp:24-108
+template <bool AD, bool LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S, const Its<AD> &its, VecN<AD> wo, bool active) {
+    using R = Num<AD>; using V = VecN<AD>;
+    const int w = S.T->bsdf_off + 2 * mesh_bsdf(S, its.mesh);
+    const float4 a = S.ld(w);
+    R wiz = its.wi.z;
+    if (__float_as_int(a.w) & 1) { wo.z = mulsign(wo.z, detach(wiz)); wiz = abs_(wiz); }
+    if (!(active && detach(wiz) > 0.f && detach(wo.z) > 0.f)) return V(R(0.f));
+    V refl;
+    if constexpr (AD) { const float4 b = S.ld(w + 1); refl = make_dual(Vec3f(a.x, a.y, a.z), Vec3f(b.x, b.y, b.z)); }
+    else refl = Vec3f(a.x, a.y, a.z);
+    return refl * R(kInvPi) * wo.z;
+}
+template <bool AD, bool LDS> PSDR_DEV float bsdf_pdf(const SceneView<LDS> &S, const Its<AD> &its, const VecN<AD> &wo, bool active) {
+    const float4 a = S.ld(S.T->bsdf_off + 2 * mesh_bsdf(S, its.mesh));
+    float wiz = detach(its.wi.z), woz = detach(wo.z);
+    if (__float_as_int(a.w) & 1) { woz = mulsign(woz, wiz); wiz = fabsf(wiz); }
+    return (active && wiz > 0.f && woz > 0.f) ? kInvPi * woz : 0.f;
+}
+// sin/cos as drjit computes them: the Cephes single-precision kernels (octant reduction with the three-term
+// pi/4 split, cubic polynomials in x^2), every multiply-add an explicit fma.  ~20 VALU ops, no libm call,
+// and bit-reproducible on any IEEE target.
+PSDR_DEV void sincos_cephes(float xx, float &s_out, float &c_out) {
+    float x = fabsf(xx);
+    int j = (int) (1.27323954473516f * x);
+    float y = (float) j;
+    if (j & 1) { j += 1; y += 1.0f; }
+    j &= 7;
+    float sign_s = xx < 0.f ? -1.f : 1.f, sign_c = 1.f;
+    if (j > 3) { sign_s = -sign_s; sign_c = -sign_c; j -= 4; }
+    if (j > 1) sign_c = -sign_c;
+    x = fma_(-y, 0.78515625f, x); x = fma_(-y, 2.4187564849853515625e-4f, x); x = fma_(-y, 3.77489497744594108e-8f, x);
+    const float z = x * x;
+    const float ps = fma_(fma_(fma_(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, x, x);
+    const float pc = fma_(fma_(fma_(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fma_(-0.5f, z, 1.0f));
+    const bool swap = (j == 1) || (j == 2);
+    s_out = sign_s * (swap ? pc : ps);
+    c_out = sign_c * (swap ? ps : pc);
+}
+
+// reference include/psdr/core/warp.h:16-63
+PSDR_DEV Vec3f square_to_cosine_hemisphere(float sx, float sy) {
+    const float x = fma_(2.f, sx, -1.f), y = fma_(2.f, sy, -1.f);
+    const bool is_zero = (x == 0.f) && (y == 0.f), q13 = fabsf(x) < fabsf(y);
+    const float r = q13 ? y : x, rp = q13 ? x : y;
+    float phi = .25f * kPi * rp / r;
+    if (q13) phi = .5f * kPi - phi;
+    if (is_zero) phi = 0.f;
+    float s, c;
+    sincos_cephes(phi, s, c);
+    const float px = r * c, py = r * s;
+    return Vec3f(px, py, safe_sqrt(1.f - fma_(py, py, px * px)));
+}
+struct BSDFSample { Vec3f wo; float pdf; bool valid; };
+template <bool AD, bool LDS> PSDR_DEV BSDFSample bsdf_sample(const SceneView<LDS> &S, const Its<AD> &its, float s1, float s2, bool active) {
+    const float4 a = S.ld(S.T->bsdf_off + 2 * mesh_bsdf(S, its.mesh));
+    float wiz = detach(its.wi.z);
+    if (__float_as_int(a.w) & 1) wiz = fabsf(wiz);
+    BSDFSample bs;
+    bs.wo = square_to_cosine_hemisphere(s1, s2);
+    bs.pdf = kInvPi * bs.wo.z;
+    bs.valid = active && (wiz > 0.f);
+    return bs;
+}
+
+PSDR_DEV float mis_weight(float p1, float p2) { const float w1 = p1 * p1, w2 = p2 * p2; return w1 / (w1 + w2); }   // reference utils.h:277-281
+
+// ---------------------------------------------------------------- PathTracer::__Li, reference src/integrator/path.cpp:35-127
+// Consumes exactly 5*max_depth draws of `rng` whatever the path does (the reference draws for masked lanes too).
+template <bool AD, bool LDS, bool COUNT>
+PSDR_DEV VecN<AD> Li(SceneView<LDS> &S, LaneRng &rng, const RayT<AD> &ray_in, bool active, int max_depth, bool hide_emitters) {
+    using R = Num<AD>; using V = VecN<AD>;
+    Its<AD> its = ray_intersect<AD, false, LDS, COUNT>(S, ray_in, active);
+    active = active && its.valid;
+    V throughput(R(1.f));
+    V result = hide_emitters ? V(R(0.f)) : eval_Le<AD, LDS>(S, its, active);
+    for (int depth = 0; depth < max_depth; ++depth) {
+        if (!active) { rng.advance((uint64_t) (5 * (max_depth - depth))); break; }
+        {   // next-event estimation (path.cpp:47-83)
+            const float sx = rng.next_1d(), sy = rng.next_1d();
+            const bool its_is_emitter = mesh_emitter(S, its.mesh) >= 0;
+            if (!its_is_emitter) {
+                PositionSample<AD> ps = sample_emitter_position<AD, LDS>(S, sx, sy);
+                V wod = ps.p - its.p;
+                const R dist_sqr = squared_norm(wod);
+                const R dist = safe_sqrt(dist_sqr);
+                wod = wod / dist;
+                RayT<AD> ray1; ray1.o = its.p; ray1.d = wod;
+                Its<AD> its1 = ray_intersect<AD, AD, LDS, COUNT>(S, ray1, true);
+                bool active_direct = its1.valid && (detach(its1.t) > detach(dist) - kShadowEpsilon) && (mesh_emitter(S, its1.mesh) >= 0);
+                if (active_direct) {
+                    const R cos_val = dot(its1.n, -wod);
+                    const R G_val = abs_(cos_val) / dist_sqr;
+                    const V emitter_val = eval_Le<AD, LDS>(S, its1, true);
+                    const V wo_local = to_local<AD>(its, wod);
+                    V bsdf_val2 = bsdf_eval<AD, LDS>(S, its, wo_local, true);
+                    bsdf_val2 = bsdf_val2 * (G_val * ps.J / R(ps.pdf));
+                    const float pdf1 = bsdf_pdf<AD, LDS>(S, its, wo_local, true) * detach(G_val);
+                    if (pdf1 != 0.f) {
+                        const float weight1 = mis_weight(ps.pdf, pdf1);
+                        result = result + throughput * emitter_val * bsdf_val2 * R(weight1);
+                    }
+                }
+            }
+        }
+        {   // BSDF sampling (path.cpp:86-123)
+            const float s0 = rng.next_1d(), s1 = rng.next_1d(), s2 = rng.next_1d();
+            (void) s0;
+            const BSDFSample bs = bsdf_sample<AD, LDS>(S, its, s1, s2, true);
+            RayT<AD> curr; curr.o = its.p; curr.d = to_world<AD>(its, bs.wo);
+            Its<AD> its1 = ray_intersect<AD, AD, LDS, COUNT>(S, curr, true);
+            active = bs.valid && its1.valid;
+            if (!active) continue;
+            V bsdf_val;
+            float pdf0;
+            if constexpr (AD) {
+                V wo = (its1.p - its.p) / its1.t;
+                const R cos_val = dot(its1.n, -wo);
+                const R G_val = abs_(cos_val) / sqr(its1.t);
+                pdf0 = bs.pdf * G_val.v;
+                if (its1.t.v < kEpsilon) bsdf_val = V(R(0.f));
+                else bsdf_val = bsdf_eval<AD, LDS>(S, its, to_local<AD>(its, wo), true) * G_val * its1.J / R(pdf0);
+            } else {
+                const float cos_val = dot(its1.n, -curr.d);
+                const float G_val = fabsf(cos_val) / sqr(its1.t);
+                pdf0 = bs.pdf * G_val;
+                if (its1.t < kEpsilon) bsdf_val = V(0.f);
+                else bsdf_val = bsdf_eval<AD, LDS>(S, its, bs.wo, true) / bs.pdf;
+            }
+            const float weight2 = mis_weight(pdf0, emitter_position_pdf<AD, LDS>(S, its1));
+            throughput = throughput * bsdf_val;
+            result = result + eval_Le<AD, LDS>(S, its1, true) * throughput * R(weight2);
+            its = its1;
+        }
+    }
+    return result;
+}
+
+} // namespace psdr

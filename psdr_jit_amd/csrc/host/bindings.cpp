@@ -1,0 +1,218 @@
+// bindings.cpp — pybind11 surface `_psdr_core` with the reference's class / method names for the
+// in-scope subset (reference src/psdr.cpp:120-439).  drjit arrays are replaced by numpy arrays for
+// host data and by raw device pointers (ints) for images; the torch-facing conveniences (Matrix4fD
+// stand-ins, autograd) live in psdr_jit_amd/__init__.py on top of this module.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include "scene_host.h"
+
+namespace py = pybind11;
+using namespace py::literals;
+using namespace psdr_host;
+
+using farr = py::array_t<float, py::array::c_style | py::array::forcecast>;
+using iarr = py::array_t<int, py::array::c_style | py::array::forcecast>;
+
+static M16 to_m16(const farr &a) {
+    if (a.size() != 16) throw Exception("expected a 4x4 matrix");
+    M16 m; std::memcpy(m.data(), a.data(), 64); return m;
+}
+static farr from_m16(const M16 &m) { farr a({4, 4}); std::memcpy(a.mutable_data(), m.data(), 64); return a; }
+static std::array<float, 3> to_a3(const farr &a) {
+    if (a.size() == 1) return {a.data()[0], a.data()[0], a.data()[0]};
+    if (a.size() != 3) throw Exception("expected 3 floats");
+    return {a.data()[0], a.data()[1], a.data()[2]};
+}
+static farr from_vec(const std::vector<float> &v, ssize_t cols) {
+    farr a({(ssize_t) v.size() / cols, cols});
+    if (!v.empty()) std::memcpy(a.mutable_data(), v.data(), v.size() * sizeof(float));
+    return a;
+}
+static iarr from_ivec(const std::vector<int> &v, ssize_t cols) {
+    iarr a({(ssize_t) v.size() / cols, cols});
+    if (!v.empty()) std::memcpy(a.mutable_data(), v.data(), v.size() * sizeof(int));
+    return a;
+}
+static std::vector<float> to_fvec(const farr &a) { return std::vector<float>(a.data(), a.data() + a.size()); }
+static std::vector<int> to_ivec(const iarr &a) { return std::vector<int>(a.data(), a.data() + a.size()); }
+
+PYBIND11_MODULE(_psdr_core, m) {
+    m.doc() = "Path-space differentiable renderer — MI355X host core";
+    py::register_exception<Exception>(m, "PsdrException", PyExc_RuntimeError);
+
+    m.def("hip_abi_version", []() { return psdr_hip_abi_version(); });
+    m.def("hip_device_count", []() { return psdr_hip_device_count(); });
+    m.def("hip_set_device", [](int d) { if (psdr_hip_set_device(d)) throw Exception(psdr_hip_last_error()); });
+
+    py::class_<Object>(m, "Object", py::dynamic_attr())
+        .def("type_name", &Object::type_name)
+        .def_readonly("id", &Object::m_id)
+        .def("__repr__", &Object::to_string);
+
+    py::class_<RenderOption>(m, "RenderOption")
+        .def(py::init<>())
+        .def(py::init<int, int, int>(), "width"_a, "height"_a, "spp/sppe"_a)
+        .def(py::init<int, int, int, int>(), "width"_a, "height"_a, "spp"_a, "sppe"_a)
+        .def(py::init<int, int, int, int, int>(), "width"_a, "height"_a, "spp"_a, "sppe"_a, "sppse"_a)
+        .def_readwrite("width", &RenderOption::width).def_readwrite("height", &RenderOption::height)
+        .def_readwrite("spp", &RenderOption::spp).def_readwrite("sppe", &RenderOption::sppe).def_readwrite("sppse", &RenderOption::sppse)
+        .def_readwrite("log_level", &RenderOption::log_level)
+        .def("__repr__", [](const RenderOption &ro) {
+            std::ostringstream oss;
+            oss << "[width: " << ro.width << ", height: " << ro.height << ", spp: " << ro.spp << ", sppe: " << ro.sppe << ", sppse: " << ro.sppse
+                << ", log_level: " << ro.log_level << "]";
+            return oss.str();
+        });
+
+    py::class_<BSDF, Object>(m, "BSDF", py::dynamic_attr()).def_readwrite("twoSide", &BSDF::m_twoSide).def("anisotropic", &BSDF::anisotropic);
+    py::class_<Diffuse, BSDF>(m, "DiffuseBSDF", py::dynamic_attr())
+        .def(py::init<>())
+        .def(py::init([](const farr &r) { return new Diffuse(to_a3(r)); }))
+        .def("_get", [](const Diffuse &d, const std::string &, bool tangent) { auto &r = tangent ? d.d_reflectance : d.reflectance; farr a(3); std::memcpy(a.mutable_data(), r.data(), 12); return a; })
+        .def("_set", [](Diffuse &d, const std::string &, const farr &v, const farr &t) { d.reflectance = to_a3(v); d.d_reflectance = to_a3(t); });
+
+    py::class_<Emitter, Object>(m, "Emitter", py::dynamic_attr());
+    py::class_<AreaLight, Emitter>(m, "AreaLight", py::dynamic_attr())
+        .def(py::init([](const farr &r) { return new AreaLight(to_a3(r)); }))
+        .def_readonly("sampling_weight", &AreaLight::m_sampling_weight)
+        .def("_get", [](const AreaLight &d, const std::string &, bool tangent) { auto &r = tangent ? d.d_radiance : d.radiance; farr a(3); std::memcpy(a.mutable_data(), r.data(), 12); return a; })
+        .def("_set", [](AreaLight &d, const std::string &, const farr &v, const farr &t) { d.radiance = to_a3(v); d.d_radiance = to_a3(t); });
+
+    auto get_xf = [](const Transformable &t, const std::string &name, bool tangent) -> farr {
+        if (name == "to_world") return from_m16(tangent ? t.d_to_world_raw : t.to_world_raw);
+        if (name == "to_world_left") return from_m16(tangent ? t.d_to_world_left : t.to_world_left);
+        if (name == "to_world_right") return from_m16(tangent ? t.d_to_world_right : t.to_world_right);
+        throw Exception("unknown parameter: " + name);
+    };
+    auto set_xf = [](Transformable &t, const std::string &name, const farr &v, const farr &d) {
+        if (name == "to_world") { t.to_world_raw = to_m16(v); t.d_to_world_raw = to_m16(d); }
+        else if (name == "to_world_left") { t.to_world_left = to_m16(v); t.d_to_world_left = to_m16(d); }
+        else if (name == "to_world_right") { t.to_world_right = to_m16(v); t.d_to_world_right = to_m16(d); }
+        else throw Exception("unknown parameter: " + name);
+    };
+
+    py::class_<Sensor, Object>(m, "Sensor", py::dynamic_attr())
+        .def("_get", [get_xf](const Sensor &s, const std::string &n, bool tg) { return get_xf(s, n, tg); })
+        .def("_set", [set_xf](Sensor &s, const std::string &n, const farr &v, const farr &d) { set_xf(s, n, v, d); })
+        .def("_set_transform", [](Sensor &s, const farr &v, const farr &d, bool left) { s.set_transform(to_m16(v), to_m16(d), left); })
+        .def("_append_transform", [](Sensor &s, const farr &v, const farr &d, bool left) { s.append_transform(to_m16(v), to_m16(d), left); })
+        .def_readonly("enable_edges", &Sensor::m_enable_edges);
+    py::class_<PerspectiveCamera, Sensor>(m, "PerspectiveCamera", py::dynamic_attr())
+        .def(py::init<float, float, float>())
+        .def_property_readonly("world_to_sample", [](const PerspectiveCamera &c) { farr a({4, 4}); std::memcpy(a.mutable_data(), c.rec.world_to_sample, 64); return a; })
+        .def("_primary_edges", [](const PerspectiveCamera &c, bool tangent) {
+            const PrimaryEdges &e = c.m_edges;
+            const size_t n = e.length.size();
+            farr a({(ssize_t) n, (ssize_t) 7});
+            float *o = a.mutable_data();
+            for (size_t i = 0; i < n; ++i) {
+                const std::vector<float> &p0 = tangent ? e.d_p0 : e.p0, &p1 = tangent ? e.d_p1 : e.p1;
+                o[7 * i] = p0[2 * i]; o[7 * i + 1] = p0[2 * i + 1]; o[7 * i + 2] = p1[2 * i]; o[7 * i + 3] = p1[2 * i + 1];
+                o[7 * i + 4] = tangent ? 0.f : e.normal[2 * i]; o[7 * i + 5] = tangent ? 0.f : e.normal[2 * i + 1]; o[7 * i + 6] = tangent ? 0.f : e.length[i];
+            }
+            return a;
+        });
+
+    py::class_<Mesh, Object>(m, "Mesh", py::dynamic_attr())
+        .def(py::init<>())
+        .def("load", &Mesh::load, "filename"_a, "verbose"_a = false)
+        .def("load_raw", [](Mesh &me, const farr &v, const iarr &f, const farr &uv, const iarr &fuv, bool verbose) {
+            me.load_raw(to_fvec(v), to_ivec(f), to_fvec(uv), to_ivec(fuv), verbose); }, "v"_a, "f"_a, "uv"_a = farr(0), "f_uv"_a = iarr(0), "verbose"_a = false)
+        .def("configure", &Mesh::configure)
+        .def("dump", &Mesh::dump)
+        .def("_get", [get_xf](const Mesh &me, const std::string &n, bool tg) -> farr {
+            if (n == "vertex_positions") return from_vec(tg ? me.d_vertex_positions_raw : me.vertex_positions_raw, 3);
+            return get_xf(me, n, tg); })
+        .def("_set", [set_xf](Mesh &me, const std::string &n, const farr &v, const farr &d) {
+            if (n == "vertex_positions") {
+                if ((ssize_t) v.size() != 3 * (ssize_t) me.m_num_vertices || d.size() != v.size()) throw Exception("vertex_positions: size mismatch");
+                me.vertex_positions_raw = to_fvec(v); me.d_vertex_positions_raw = to_fvec(d); me.m_ready = false; return;
+            }
+            set_xf(me, n, v, d); me.m_ready = false; })
+        .def("_set_transform", [](Mesh &me, const farr &v, const farr &d, bool left) { me.set_transform(to_m16(v), to_m16(d), left); me.m_ready = false; })
+        .def("_append_transform", [](Mesh &me, const farr &v, const farr &d, bool left) { me.append_transform(to_m16(v), to_m16(d), left); me.m_ready = false; })
+        .def_readonly("num_vertices", &Mesh::m_num_vertices)
+        .def_readonly("num_faces", &Mesh::m_num_faces)
+        .def_readonly("bsdf", &Mesh::m_bsdf)
+        .def_property_readonly("vertex_positions_T", [](const Mesh &me) { return from_vec(me.vertex_positions, 3); })
+        .def_property_readonly("vertex_normals", [](const Mesh &me) { return from_vec(me.vertex_normals_raw, 3); })
+        .def_property_readonly("vertex_uv", [](const Mesh &me) { return from_vec(me.vertex_uv, 2); })
+        .def_property_readonly("face_indices", [](const Mesh &me) { return from_ivec(me.face_indices, 3); })
+        .def_property_readonly("face_uv_indices", [](const Mesh &me) { return from_ivec(me.face_uv_indices, 3); })
+        .def_readwrite("use_face_normal", &Mesh::m_use_face_normals)
+        .def_readwrite("enable_edges", &Mesh::m_enable_edges)
+        .def("edge_indices", [](const Mesh &me) {
+            iarr a({(ssize_t) me.edges.size(), (ssize_t) 5});
+            int *o = a.mutable_data();
+            for (size_t i = 0; i < me.edges.size(); ++i) { const MeshEdge &e = me.edges[i]; o[5 * i] = e.v0; o[5 * i + 1] = e.v1; o[5 * i + 2] = e.f0; o[5 * i + 3] = e.f1; o[5 * i + 4] = e.opp; }
+            return a; });
+
+    py::class_<Scene, Object>(m, "Scene", py::dynamic_attr())
+        .def(py::init<>())
+        .def("add_Sensor", &Scene::add_Sensor, "Add Sensor")
+        .def("_add_Mesh_file", [](Scene &s, const std::string &f, const farr &t, const std::string &b, const Emitter *e) { s.add_Mesh(f, to_m16(t), b, e); })
+        .def("_add_Mesh_obj", [](Scene &s, const Mesh *mesh, const std::string &b, const Emitter *e) { s.add_Mesh(mesh, b, e); })
+        .def("add_BSDF", &Scene::add_BSDF, "Add BSDF", "bsdf"_a, "name"_a, "twoSide"_a = false)
+        .def("_configure", &Scene::configure, "active_sensor"_a = std::vector<int>(), py::call_guard<py::gil_scoped_release>())
+        .def("_configure_host", &Scene::configure_host, "active_sensor"_a = std::vector<int>())
+        .def("is_ready", &Scene::is_ready)
+        .def_readwrite("opts", &Scene::m_opts, "Render options")
+        .def_readwrite("seed", &Scene::seed, "Sample seed")
+        .def_readonly("num_sensors", &Scene::m_num_sensors)
+        .def_readonly("num_meshes", &Scene::m_num_meshes)
+        .def("get_num_emitters", &Scene::get_num_emitters)
+        .def_property_readonly("param_map", [](Scene &s) {
+            py::dict d;
+            py::object self = py::cast(&s, py::return_value_policy::reference);
+            for (auto &kv : s.m_param_map) d[py::str(kv.first)] = py::cast(kv.second, py::return_value_policy::reference_internal, self);
+            return d; }, "Parameter map")
+        .def("_sampler_state", [](const Scene &s, int k) { return py::make_tuple(s.m_samplers[k].ready, s.m_samplers[k].sample_count, s.m_samplers[k].seed, s.m_samplers[k].skip); })
+        .def("_bvh_stats", [](const Scene &s) {
+            int32_t n = 0, l = 0, d = 0, b = 0;
+            if (!s.m_hip || psdr_hip_scene_stats(s.m_hip, &n, &l, &d, &b)) throw Exception("scene not configured");
+            return py::make_tuple(n, l, d, b); })
+        .def("_hip_handle", [](const Scene &s) { return (uintptr_t) s.m_hip; })
+        .def("_snapshot", [](const Scene &s) {
+            // configured host arrays in the oracle's row formats (tests compare them with the CPU restatement)
+            const Scene::Snapshot &S = s.snap;
+            const size_t n = S.area.size();
+            farr tri({(ssize_t) n, (ssize_t) 22}), dtri({(ssize_t) n, (ssize_t) 22});
+            const std::vector<float> *src[7] = {&S.p0, &S.e1, &S.e2, &S.n0, &S.n1, &S.n2, &S.fn};
+            const std::vector<float> *dsrc[7] = {&S.d_p0, &S.d_e1, &S.d_e2, &S.d_n0, &S.d_n1, &S.d_n2, &S.d_fn};
+            for (size_t i = 0; i < n; ++i) {
+                for (int k = 0; k < 7; ++k) for (int c = 0; c < 3; ++c) { tri.mutable_data()[22 * i + 3 * k + c] = (*src[k])[3 * i + c]; dtri.mutable_data()[22 * i + 3 * k + c] = (*dsrc[k])[3 * i + c]; }
+                tri.mutable_data()[22 * i + 21] = S.area[i]; dtri.mutable_data()[22 * i + 21] = S.d_area[i];
+            }
+            const size_t ne = (size_t) S.n_sec_edges;
+            farr se({(ssize_t) ne, (ssize_t) 16}), dse({(ssize_t) ne, (ssize_t) 16});
+            for (size_t i = 0; i < ne; ++i) {
+                float *o = se.mutable_data() + 16 * i, *d = dse.mutable_data() + 16 * i;
+                for (int c = 0; c < 3; ++c) {
+                    o[c] = S.se_p0[3 * i + c]; o[3 + c] = S.se_e1[3 * i + c]; o[6 + c] = S.se_n0[3 * i + c]; o[9 + c] = S.se_n1[3 * i + c]; o[12 + c] = S.se_p2[3 * i + c];
+                    d[c] = S.se_d_p0[3 * i + c]; d[3 + c] = S.se_d_e1[3 * i + c]; d[6 + c] = d[9 + c] = d[12 + c] = 0.f;
+                }
+                o[15] = S.se_boundary[i] ? 1.f : 0.f; d[15] = 0.f;
+            }
+            py::dict out;
+            out["triangles"] = tri; out["d_triangles"] = dtri; out["sec_edges"] = se; out["d_sec_edges"] = dse;
+            out["mesh_id"] = py::array_t<int32_t>(S.mesh_id.size(), S.mesh_id.data());
+            out["uv"] = from_vec(S.uv, 6);
+            out["sec_edge_cmf"] = from_vec(S.sec_edge_distrb.cmf, 1);
+            out["face_cmf"] = from_vec(S.face_cmf, 1);
+            return out; });
+
+    py::class_<Integrator, Object>(m, "Integrator", py::dynamic_attr())
+        .def("_renderC", &Integrator::renderC, "scene"_a, "sensor_id"_a, "seed"_a, "pix_ids"_a, "n_pix"_a, "out"_a, "stream"_a, "shard_rank"_a, "shard_count"_a,
+             py::call_guard<py::gil_scoped_release>())
+        .def("_renderD", &Integrator::renderD, "scene"_a, "sensor_id"_a, "seed"_a, "pix_ids"_a, "n_pix"_a, "out"_a, "dout"_a, "stream"_a, "shard_rank"_a,
+             "shard_count"_a, "terms"_a, py::call_guard<py::gil_scoped_release>());
+
+    py::class_<PathTracer, Integrator>(m, "PathTracer", py::dynamic_attr())
+        .def(py::init<int>(), "max_depth"_a = 1)
+        .def("preprocess_secondary_edges", &PathTracer::preprocess_secondary_edges, "scene"_a, "sensor_id"_a, "resolution"_a, "nrounds"_a = 1, "seed"_a = 0)
+        .def("_guiding_mass", [](const PathTracer &p, int sid) { auto v = p.guiding_mass(sid); return from_vec(v, 1); })
+        .def_readwrite("hide_emitters", &PathTracer::m_hide_emitters)
+        .def_readonly("max_depth", &PathTracer::m_max_depth);
+}

@@ -1,0 +1,714 @@
+// scene_host.cpp — host scene model: OBJ loading, Mesh/Camera/Scene::configure, snapshot assembly and
+// the render drivers that call libpsdr_hip.so.  Reference sites are cited per function.
+#include "scene_host.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <limits>
+#include <sstream>
+
+namespace psdr_host {
+
+static constexpr float Epsilon = 1e-5f;      // reference include/psdr/constants.h:12
+static constexpr float kPi = 3.14159265358979323846f;
+
+void throw_assert(const char *cond, const char *file, int line, const std::string &msg) {
+    std::ostringstream oss;
+    oss << "Assertion failed in " << file << ":" << line << " : " << cond;
+    if (!msg.empty()) oss << " (" << msg << ")";
+    throw Exception(oss.str());
+}
+
+void Object::log(const std::string &msg) const { std::cout << "[" << type_name() << "] " << msg << std::endl; }
+
+static void hip_check(int rc) { if (rc) throw Exception(std::string("libpsdr_hip: ") + psdr_hip_last_error()); }
+
+static float sum_f32(const std::vector<float> &v) { float s = 0.f; for (float x : v) s += x; return s; }
+
+// reference include/psdr/core/pmf.h:12-38 + src/core/pmf.cpp:6-15
+void Distrb::init(const std::vector<float> &p) {
+    PSDR_ASSERT_MSG(!p.empty(), "DiscreteDistribution: empty distribution!");
+    size = (int) p.size();
+    pmf = p;
+    sum = sum_f32(p);
+    cmf.resize(p.size());
+    double acc = 0.0;
+    for (size_t i = 0; i < p.size(); ++i) {
+        PSDR_ASSERT_MSG(!(p[i] < 0.f), "DiscreteDistribution: entries must be non-negative!");
+        acc += (double) p[i];
+        cmf[i] = (float) acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+static DM4 mul3(const M16 &l, const M16 &dl, const M16 &r, const M16 &dr, const M16 &rt, const M16 &drt) {
+    return DM4::from(l, dl) * DM4::from(r, dr) * DM4::from(rt, drt);
+}
+DM4 Transformable::to_world() const { return mul3(to_world_left, d_to_world_left, to_world_raw, d_to_world_raw, to_world_right, d_to_world_right); }
+
+void Transformable::set_transform(const M16 &mat, const M16 &dmat, bool set_left) {
+    if (set_left) { to_world_left = mat; d_to_world_left = dmat; } else { to_world_right = mat; d_to_world_right = dmat; }
+}
+void Transformable::append_transform(const M16 &mat, const M16 &dmat, bool append_left) {
+    DM4 m = DM4::from(mat, dmat);
+    if (append_left) { DM4 r = m * DM4::from(to_world_left, d_to_world_left); r.split(to_world_left.data(), d_to_world_left.data()); }
+    else { DM4 r = DM4::from(to_world_right, d_to_world_right) * m; r.split(to_world_right.data(), d_to_world_right.data()); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// OBJ reader.  Polygons are triangulated by ear clipping in the plane of the dominant normal axis
+// (the published tinyobjloader algorithm the reference relies on, include/tiny_obj_loader; a convex
+// n-gon becomes the fan (v0,v1,v2), (v0,v2,v3), ...).
+namespace {
+struct Corner { int v, vt; };
+
+bool point_in_tri(const float *x, const float *y, float tx, float ty) {
+    bool c = false;
+    for (int i = 0, j = 2; i < 3; j = i++)
+        if (((y[i] > ty) != (y[j] > ty)) && (tx < (x[j] - x[i]) * (ty - y[i]) / (y[j] - y[i]) + x[i])) c = !c;
+    return c;
+}
+
+void triangulate(const std::vector<Corner> &poly, const std::vector<float> &V, std::vector<Corner> &out) {
+    const size_t n = poly.size();
+    if (n < 3) return;
+    if (n == 3) { out.insert(out.end(), poly.begin(), poly.end()); return; }
+    int ax0 = 1, ax1 = 2;
+    for (size_t k = 0; k < n; ++k) {
+        const float *a = &V[3 * poly[k].v], *b = &V[3 * poly[(k + 1) % n].v], *c = &V[3 * poly[(k + 2) % n].v];
+        float e0[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e1[3] = {c[0] - b[0], c[1] - b[1], c[2] - b[2]};
+        float cx = std::fabs(e0[1] * e1[2] - e0[2] * e1[1]), cy = std::fabs(e0[2] * e1[0] - e0[0] * e1[2]), cz = std::fabs(e0[0] * e1[1] - e0[1] * e1[0]);
+        const float eps = std::numeric_limits<float>::epsilon();
+        if (cx > eps || cy > eps || cz > eps) {
+            if (!(cx > cy && cx > cz)) { ax0 = 0; if (cz > cx && cz > cy) ax1 = 1; }
+            break;
+        }
+    }
+    float area = 0.f;
+    for (size_t k = 0; k < n; ++k) {
+        const float *a = &V[3 * poly[k].v], *b = &V[3 * poly[(k + 1) % n].v];
+        area += (a[ax0] * b[ax1] - a[ax1] * b[ax0]) * 0.5f;
+    }
+    std::vector<Corner> rem = poly;
+    size_t guess = 0, budget = n, prev = n;
+    while (rem.size() > 3 && budget > 0) {
+        const size_t m = rem.size();
+        if (guess >= m) guess -= m;
+        if (prev != m) { prev = m; budget = m; } else --budget;
+        Corner tri[3]; float x[3], y[3];
+        for (int k = 0; k < 3; ++k) { tri[k] = rem[(guess + k) % m]; x[k] = V[3 * tri[k].v + ax0]; y[k] = V[3 * tri[k].v + ax1]; }
+        const float cr = (x[1] - x[0]) * (y[2] - y[1]) - (y[1] - y[0]) * (x[2] - x[1]);
+        if (cr * area < 0.f) { ++guess; continue; }
+        bool overlap = false;
+        for (size_t o = 3; o < m && !overlap; ++o) {
+            const Corner &c = rem[(guess + o) % m];
+            overlap = point_in_tri(x, y, V[3 * c.v + ax0], V[3 * c.v + ax1]);
+        }
+        if (overlap) { ++guess; continue; }
+        out.push_back(tri[0]); out.push_back(tri[1]); out.push_back(tri[2]);
+        rem.erase(rem.begin() + (guess + 1) % m);
+    }
+    if (rem.size() == 3) out.insert(out.end(), rem.begin(), rem.end());
+}
+} // namespace
+
+void Mesh::load(const std::string &fname, bool verbose) {
+    std::ifstream in(fname);
+    PSDR_ASSERT_MSG(in.good(), std::string("Failed to load OBJ from: ") + fname);
+    std::vector<float> V, VT;
+    std::vector<Corner> corners;
+    std::string line;
+    while (std::getline(in, line)) {
+        std::istringstream ss(line);
+        std::string tag;
+        if (!(ss >> tag)) continue;
+        if (tag == "v") { float x, y, z; ss >> x >> y >> z; V.push_back(x); V.push_back(y); V.push_back(z); }
+        else if (tag == "vt") { float u = 0.f, v = 0.f; ss >> u >> v; VT.push_back(u); VT.push_back(v); }
+        else if (tag == "f") {
+            std::vector<Corner> poly;
+            std::string tok;
+            while (ss >> tok) {
+                Corner c{0, -1};
+                int vi = 0, ti = 0;
+                size_t s1 = tok.find('/');
+                vi = std::stoi(tok.substr(0, s1));
+                if (s1 != std::string::npos) {
+                    size_t s2 = tok.find('/', s1 + 1);
+                    std::string t = tok.substr(s1 + 1, s2 == std::string::npos ? std::string::npos : s2 - s1 - 1);
+                    if (!t.empty()) ti = std::stoi(t);
+                }
+                c.v = vi > 0 ? vi - 1 : (int) V.size() / 3 + vi;
+                c.vt = ti > 0 ? ti - 1 : (ti < 0 ? (int) VT.size() / 2 + ti : -1);
+                poly.push_back(c);
+            }
+            for (const Corner &c : poly) PSDR_ASSERT_MSG(c.v >= 0 && 3 * c.v + 2 < (int) V.size(), std::string("Bad vertex index in: ") + fname);
+            triangulate(poly, V, corners);
+        }
+    }
+    std::vector<int> f(corners.size()), fuv;
+    for (size_t i = 0; i < corners.size(); ++i) f[i] = corners[i].v;
+    if (!VT.empty()) { fuv.resize(corners.size()); for (size_t i = 0; i < corners.size(); ++i) fuv[i] = corners[i].vt; }
+    load_raw(V, f, VT, fuv, verbose);
+}
+
+void Mesh::load_raw(const std::vector<float> &v, const std::vector<int> &f, const std::vector<float> &uv, const std::vector<int> &fuv, bool verbose) {
+    PSDR_ASSERT(v.size() % 3 == 0 && f.size() % 3 == 0);
+    m_num_vertices = (int) v.size() / 3;
+    m_num_faces = (int) f.size() / 3;
+    vertex_positions_raw = v;
+    d_vertex_positions_raw.assign(v.size(), 0.f);
+    m_has_uv = !uv.empty();
+    vertex_uv = uv;
+    face_uv_indices = m_has_uv ? fuv : std::vector<int>();
+    if (m_has_uv) PSDR_ASSERT(fuv.size() == f.size());
+    face_indices = f;
+    for (int idx : f) PSDR_ASSERT(idx >= 0 && idx < m_num_vertices);
+    edges.clear();
+    if (m_enable_edges) build_edges();
+    if (verbose) std::cout << "Loaded " << m_num_vertices << " vertices, " << m_num_faces << " faces, " << edges.size() << " edges. " << std::endl;
+    m_ready = false;
+}
+
+// reference src/shape/mesh.cpp:102-150: std::map over (min,max) vertex ids; first entry of the value is the
+// vertex opposite to the edge in the first face seen, then the face ids; emitted in key order.
+void Mesh::build_edges() {
+    std::map<std::pair<int, int>, std::vector<int>> em;
+    for (int f = 0; f < m_num_faces; ++f)
+        for (int i = 0; i < 3; ++i) {
+            const int a = face_indices[3 * f + i], b = face_indices[3 * f + (i + 1) % 3], c = face_indices[3 * f + (i + 2) % 3];
+            const auto key = a < b ? std::make_pair(a, b) : std::make_pair(b, a);
+            auto it = em.find(key);
+            if (it == em.end()) it = em.emplace(key, std::vector<int>{c}).first;
+            it->second.push_back(f);
+        }
+    edges.clear();
+    edges.reserve(em.size());
+    for (const auto &kv : em) edges.push_back({kv.first.first, kv.first.second, kv.second[1], kv.second.size() >= 3 ? kv.second[2] : -1, kv.second[0]});
+}
+
+// process_mesh<true>, reference src/shape/mesh.cpp:23-62; rows of 22 floats: p0 e1 e2 n0 n1 n2 fn area
+static void process_mesh(const std::vector<D3> &V, const std::vector<int> &F, int nf, std::vector<float> &tri, std::vector<float> &d_tri,
+                         std::vector<float> *vertex_normals_out) {
+    const size_t nv = V.size();
+    std::vector<D3> vn(nv), fnrm(nf);
+    std::vector<DF> vw(nv), farea(nf);
+    for (int f = 0; f < nf; ++f) {
+        const D3 p0 = V[F[3 * f]], e1 = V[F[3 * f + 1]] - p0, e2 = V[F[3 * f + 2]] - p0;
+        fnrm[f] = dcross(e1, e2);
+        farea[f] = dnorm(fnrm[f]);
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int f = 0; f < nf; ++f) { const int v = F[3 * f + i]; vn[v] = vn[v] + fnrm[f]; vw[v] = vw[v] + farea[f]; }
+    for (size_t v = 0; v < nv; ++v) vn[v] = dnormalize(vn[v] / vw[v]);
+    if (vertex_normals_out) {
+        vertex_normals_out->resize(3 * nv);
+        for (size_t v = 0; v < nv; ++v) { (*vertex_normals_out)[3 * v] = vn[v].x.v; (*vertex_normals_out)[3 * v + 1] = vn[v].y.v; (*vertex_normals_out)[3 * v + 2] = vn[v].z.v; }
+        return;
+    }
+    tri.resize(22 * (size_t) nf); d_tri.resize(22 * (size_t) nf);
+    auto put = [&](size_t row, int col, const D3 &a) {
+        tri[22 * row + col] = a.x.v; tri[22 * row + col + 1] = a.y.v; tri[22 * row + col + 2] = a.z.v;
+        d_tri[22 * row + col] = a.x.d; d_tri[22 * row + col + 1] = a.y.d; d_tri[22 * row + col + 2] = a.z.d;
+    };
+    for (int f = 0; f < nf; ++f) {
+        const D3 p0 = V[F[3 * f]], e1 = V[F[3 * f + 1]] - p0, e2 = V[F[3 * f + 2]] - p0;
+        put(f, 0, p0); put(f, 3, e1); put(f, 6, e2);
+        put(f, 9, vn[F[3 * f]]); put(f, 12, vn[F[3 * f + 1]]); put(f, 15, vn[F[3 * f + 2]]);
+        put(f, 18, fnrm[f] / farea[f]);
+        const DF a = farea[f] * DF(0.5f);
+        tri[22 * (size_t) f + 21] = a.v; d_tri[22 * (size_t) f + 21] = a.d;
+    }
+}
+
+// Mesh::configure, reference src/shape/mesh.cpp:317-382
+void Mesh::configure() {
+    if (m_bsdf != nullptr) PSDR_ASSERT(!m_bsdf->anisotropic() || !m_use_face_normals);
+    PSDR_ASSERT_MSG(m_num_faces > 0, "Mesh has no faces!");
+    if (d_vertex_positions_raw.size() != vertex_positions_raw.size()) d_vertex_positions_raw.assign(vertex_positions_raw.size(), 0.f);
+    std::vector<D3> raw(m_num_vertices), world(m_num_vertices);
+    for (int v = 0; v < m_num_vertices; ++v)
+        raw[v] = {DF(vertex_positions_raw[3 * v], d_vertex_positions_raw[3 * v]), DF(vertex_positions_raw[3 * v + 1], d_vertex_positions_raw[3 * v + 1]),
+                  DF(vertex_positions_raw[3 * v + 2], d_vertex_positions_raw[3 * v + 2])};
+    std::vector<float> dummy1, dummy2;
+    process_mesh(raw, face_indices, m_num_faces, dummy1, dummy2, &vertex_normals_raw);
+    const DM4 tw = to_world();
+    vertex_positions.resize(3 * (size_t) m_num_vertices); d_vertex_positions.resize(3 * (size_t) m_num_vertices);
+    for (int v = 0; v < m_num_vertices; ++v) {
+        world[v] = xform_pos(tw, raw[v]);
+        vertex_positions[3 * v] = world[v].x.v; vertex_positions[3 * v + 1] = world[v].y.v; vertex_positions[3 * v + 2] = world[v].z.v;
+        d_vertex_positions[3 * v] = world[v].x.d; d_vertex_positions[3 * v + 1] = world[v].y.d; d_vertex_positions[3 * v + 2] = world[v].z.d;
+    }
+    process_mesh(world, face_indices, m_num_faces, tri, d_tri, nullptr);
+    std::vector<float> areas(m_num_faces);
+    for (int f = 0; f < m_num_faces; ++f) areas[f] = tri[22 * (size_t) f + 21];
+    m_total_area = sum_f32(areas);
+    m_inv_total_area = 1.f / m_total_area;
+    face_distrb.init(areas);
+    if (m_enable_edges && edges.empty()) build_edges();
+    m_ready = true;
+}
+
+std::string Mesh::to_string() const {
+    std::ostringstream oss;
+    oss << "Mesh[nv=" << m_num_vertices << ", nf=" << m_num_faces;
+    if (!m_id.empty()) oss << ", id=" << m_id;
+    if (m_bsdf) oss << ", bsdf=" << m_bsdf->to_string();
+    oss << "]";
+    return oss.str();
+}
+
+// Mesh::dump, reference src/shape/mesh.cpp:469-541 (raw=true writes the world-space positions there)
+void Mesh::dump(const std::string &fname, bool raw) const {
+    const std::vector<float> &P = raw ? vertex_positions : vertex_positions_raw;
+    FILE *fout = std::fopen(fname.c_str(), "wt");
+    PSDR_ASSERT_MSG(fout != nullptr, std::string("Cannot write: ") + fname);
+    for (int i = 0; i < m_num_vertices; ++i) std::fprintf(fout, "v %.6e %.6e %.6e\n", P[3 * i], P[3 * i + 1], P[3 * i + 2]);
+    if (m_has_uv) for (size_t i = 0; i + 1 < vertex_uv.size(); i += 2) std::fprintf(fout, "vt %.6e %.6e\n", vertex_uv[i], vertex_uv[i + 1]);
+    for (int f = 0; f < m_num_faces; ++f) {
+        const int *v = &face_indices[3 * f];
+        if (m_has_uv) { const int *t = &face_uv_indices[3 * f]; std::fprintf(fout, "f %d/%d %d/%d %d/%d\n", v[0] + 1, t[0] + 1, v[1] + 1, t[1] + 1, v[2] + 1, t[2] + 1); }
+        else std::fprintf(fout, "f %d %d %d\n", v[0] + 1, v[1] + 1, v[2] + 1);
+    }
+    std::fclose(fout);
+}
+
+// ------------------------------------------------------------------------------------------------
+// PerspectiveCamera::configure, reference src/sensor/perspective.cpp:10-152 + sensor.cpp:7-14
+static DM4 persp_matrix(float fov, float near_, float far_) {       // reference include/psdr/core/transform.h:48-61
+    const float recip = 1.f / (far_ - near_);
+    const float cot = 1.f / std::tan((fov * .5f) * (kPi / 180.f));
+    DM4 m;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) m.m[i][j] = DF(0.f);
+    m.m[0][0] = DF(cot); m.m[1][1] = DF(cot); m.m[2][2] = DF(far_ * recip); m.m[2][3] = DF(-near_ * far_ * recip); m.m[3][2] = DF(1.f);
+    return m;
+}
+static DM4 scale_matrix(float x, float y, float z) { DM4 m = DM4::identity(); m.m[0][0] = DF(x); m.m[1][1] = DF(y); m.m[2][2] = DF(z); return m; }
+static DM4 translate_matrix(float x, float y, float z) { DM4 m = DM4::identity(); m.m[0][3] = DF(x); m.m[1][3] = DF(y); m.m[2][3] = DF(z); return m; }
+static D3 fvec(const float *p) { return {DF(p[0]), DF(p[1]), DF(p[2])}; }
+static D3 dvec(const float *p, const float *d) { return {DF(p[0], d[0]), DF(p[1], d[1]), DF(p[2], d[2])}; }
+static float fdot(D3 a, D3 b) { return ddot(a, b).v; }
+
+void PerspectiveCamera::configure(const Scene &scene, bool keep_edges) {
+    const RenderOption &o = scene.m_opts;
+    const float aspect = (float) o.width / (float) o.height;
+    const DM4 tw = to_world();
+    PSDR_ASSERT_MSG(std::fabs(det3(tw) - 1.f) < Epsilon, "Sensor transformation should not involve scaling!");
+    const DM4 c2s = scale_matrix(-0.5f, -0.5f * aspect, 1.f) * translate_matrix(-1.f, -1.f / aspect, 0.f) * persp_matrix(m_fov_x, m_near_clip, m_far_clip);
+    const DM4 s2c = inverse(c2s);
+    const DM4 w2s = c2s * inverse(tw);
+    float dummy[16];
+    s2c.split(rec.sample_to_camera, dummy);
+    tw.split(rec.to_world, rec.d_to_world);
+    w2s.split(rec.world_to_sample, rec.d_world_to_sample);
+    const D3 pos = xform_pos(tw, {DF(0.f), DF(0.f), DF(0.f)}), dir = xform_dir(tw, {DF(0.f), DF(0.f), DF(1.f)});
+    rec.cam_pos[0] = pos.x.v; rec.cam_pos[1] = pos.y.v; rec.cam_pos[2] = pos.z.v;
+    rec.cam_dir[0] = dir.x.v; rec.cam_dir[1] = dir.y.v; rec.cam_dir[2] = dir.z.v;
+    const D3 v00 = xform_pos(s2c, {DF(0.f), DF(0.f), DF(0.f)}), v10 = xform_pos(s2c, {DF(1.f), DF(0.f), DF(0.f)}),
+             v11 = xform_pos(s2c, {DF(1.f), DF(1.f), DF(0.f)}), vc = xform_pos(s2c, {DF(.5f), DF(.5f), DF(0.f)});
+    rec.inv_area = (1.f / (dnorm(v00 - v10).v * dnorm(v11 - v10).v)) * ddot(vc, vc).v;
+
+    m_edges = PrimaryEdges();
+    m_enable_edges = false;
+    if (o.sppe <= 0) return;
+    PrimaryEdges pe;
+    const D3 cpos = {DF(pos.x.v), DF(pos.y.v), DF(pos.z.v)};
+    for (const Mesh *mesh : scene.m_meshes) {
+        if (!mesh->m_enable_edges) continue;
+        int kept = 0;
+        for (const MeshEdge &e : mesh->edges) {
+            const bool valid = e.f1 >= 0;
+            const float *t0 = &mesh->tri[22 * (size_t) e.f0];
+            const D3 e0 = dnormalize(cpos - fvec(t0)), n0 = fvec(t0 + 18);
+            D3 e1 = dnormalize(cpos), n1 = {DF(0.f), DF(0.f), DF(0.f)};        // masked gathers return zeros
+            if (valid) { const float *t1 = &mesh->tri[22 * (size_t) e.f1]; e1 = dnormalize(cpos - fvec(t1)); n1 = fvec(t1 + 18); }
+            bool uv_mask = false;
+            if (mesh->m_has_uv) {
+                int b[3] = {0, 0, 0}, cut = 0;
+                if (valid) for (int k = 0; k < 3; ++k) b[k] = mesh->face_uv_indices[3 * e.f1 + k];
+                for (int k = 0; k < 3; ++k) { const int a = mesh->face_uv_indices[3 * e.f0 + k]; if (a == b[0] || a == b[1] || a == b[2]) ++cut; }
+                uv_mask = cut != 2;
+            }
+            bool keep;
+            if (mesh->m_use_face_normals) keep = !(valid && ((fdot(e0, n0) < Epsilon && fdot(e1, n1) < Epsilon) || fdot(n0, n1) > 1.f - Epsilon));
+            else keep = !valid || ((fdot(e0, n0) > Epsilon) != (fdot(e1, n1) > Epsilon));
+            if (mesh->m_has_uv) keep = keep || uv_mask;
+            if (!keep) continue;
+            ++kept;
+            const D3 q0 = xform_pos(w2s, dvec(&mesh->vertex_positions[3 * e.v0], &mesh->d_vertex_positions[3 * e.v0])),
+                     q1 = xform_pos(w2s, dvec(&mesh->vertex_positions[3 * e.v1], &mesh->d_vertex_positions[3 * e.v1]));
+            float ex = q1.x.v - q0.x.v, ey = q1.y.v - q0.y.v;
+            const float len = std::sqrt(std::fmaf(ey, ey, ex * ex));
+            ex /= len; ey /= len;
+            pe.p0.push_back(q0.x.v); pe.p0.push_back(q0.y.v); pe.p1.push_back(q1.x.v); pe.p1.push_back(q1.y.v);
+            pe.d_p0.push_back(q0.x.d); pe.d_p0.push_back(q0.y.d); pe.d_p1.push_back(q1.x.d); pe.d_p1.push_back(q1.y.d);
+            pe.normal.push_back(-ey); pe.normal.push_back(ex);
+            pe.length.push_back(len);
+        }
+        PSDR_ASSERT_MSG(kept > 0, "slices(info) > 0");
+    }
+    if (!pe.length.empty() && keep_edges) {
+        pe.distrb.init(pe.length);
+        m_edges = std::move(pe);
+        m_enable_edges = true;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+Scene::Scene() { for (int k = 0; k < 3; ++k) { m_lower[k] = 0.f; m_upper[k] = 0.f; } }
+Scene::~Scene() {
+    release_device();
+    for (Sensor *s : m_sensors) delete s;
+    for (Emitter *e : m_emitters) delete e;
+    for (BSDF *b : m_bsdfs) delete b;
+    for (Mesh *m : m_meshes) delete m;
+}
+void Scene::release_device() { if (m_hip) { psdr_hip_scene_destroy(m_hip); m_hip = nullptr; } }
+
+// build_param_map, reference src/scene/scene.cpp:29-47
+template <typename T> static void add_params(std::unordered_map<std::string, Object *> &pm, const std::vector<T *> &arr, const char *name) {
+    for (size_t i = 0; i < arr.size(); ++i) {
+        std::ostringstream k1; k1 << name << "[" << i << "]";
+        pm[k1.str()] = arr[i];
+        if (!arr[i]->m_id.empty()) { std::ostringstream k2; k2 << name << "[id=" << arr[i]->m_id << "]"; pm[k2.str()] = arr[i]; }
+    }
+}
+void Scene::rebuild_param_map() {
+    m_param_map.clear();
+    add_params(m_param_map, m_meshes, "Mesh"); add_params(m_param_map, m_bsdfs, "BSDF");
+    add_params(m_param_map, m_emitters, "Emitter"); add_params(m_param_map, m_sensors, "Sensor");
+}
+
+void Scene::add_Sensor(const Sensor *sensor) {       // scene.cpp:107-126 (the scene keeps its own copy)
+    if (m_opts.log_level > 0) std::cout << "add_Sensor: " << sensor->to_string() << std::endl;
+    const PerspectiveCamera *pc = dynamic_cast<const PerspectiveCamera *>(sensor);
+    PSDR_ASSERT_MSG(pc != nullptr, "Unknown sensor type!");
+    m_sensors.push_back(new PerspectiveCamera(*pc));
+    m_num_sensors = (int) m_sensors.size();
+    rebuild_param_map();
+}
+void Scene::add_BSDF(const BSDF *bsdf, const std::string &bsdf_id, bool twoSide) {      // scene.cpp:148-247
+    const Diffuse *d = dynamic_cast<const Diffuse *>(bsdf);
+    PSDR_ASSERT_MSG(d != nullptr, "Unknown BSDF type!");
+    if (m_opts.log_level > 0) std::cout << "add_BSDF: Diffuse " << bsdf_id << std::endl;
+    PSDR_ASSERT_MSG(m_param_map.find("BSDF[id=" + bsdf_id + "]") == m_param_map.end(), std::string("Duplicate BSDF id: ") + bsdf_id);
+    Diffuse *c = new Diffuse(*d);
+    c->m_twoSide = twoSide; c->m_id = bsdf_id;
+    m_bsdfs.push_back(c);
+    rebuild_param_map();
+}
+static int find_bsdf(const Scene &s, const std::string &id) {
+    for (size_t i = 0; i < s.m_bsdfs.size(); ++i) if (s.m_bsdfs[i]->m_id == id) return (int) i;
+    return -1;
+}
+void Scene::add_Mesh(const std::string &fname, const M16 &transform, const std::string &bsdf_id, const Emitter *emitter) {   // scene.cpp:249-279
+    Mesh m;
+    m.load(fname, false);
+    m.to_world_raw = transform;
+    add_Mesh(&m, bsdf_id, emitter);
+}
+void Scene::add_Mesh(const Mesh *mesh_, const std::string &bsdf_id, const Emitter *emitter) {                              // scene.cpp:281-309
+    if (m_opts.log_level > 0) std::cout << "add_Mesh: " << m_meshes.size() << std::endl;
+    const int b = find_bsdf(*this, bsdf_id);
+    PSDR_ASSERT_MSG(b >= 0, std::string("Unknown BSDF id: ") + bsdf_id);
+    Mesh *mesh = new Mesh(*mesh_);
+    mesh->m_mesh_id = (int) m_meshes.size();
+    mesh->m_bsdf_id = b; mesh->m_bsdf = m_bsdfs[b];
+    mesh->m_emitter = nullptr; mesh->m_emitter_id = -1;
+    if (emitter) {
+        const AreaLight *al = dynamic_cast<const AreaLight *>(emitter);
+        PSDR_ASSERT_MSG(al != nullptr, "Unknown emitter type!");
+        if (m_opts.log_level > 0) std::cout << "add Area light" << std::endl;
+        AreaLight *c = new AreaLight(*al);
+        c->m_mesh = mesh;
+        mesh->m_emitter = c; mesh->m_emitter_id = (int) m_emitters.size();
+        m_emitters.push_back(c);
+    }
+    m_meshes.push_back(mesh);
+    m_num_meshes = (int) m_meshes.size();
+    rebuild_param_map();
+}
+
+bool Scene::is_ready() const {
+    return m_configured && m_hip != nullptr && (m_opts.spp == 0 || m_samplers[0].ready) && (m_opts.sppe == 0 || m_samplers[1].ready) &&
+           (m_opts.sppse == 0 || m_samplers[2].ready);
+}
+
+// Scene::configure, reference src/scene/scene.cpp:311-601
+void Scene::configure(const std::vector<int> &active_sensor) {
+    using namespace std::chrono;
+    const auto start_time = high_resolution_clock::now();
+    configure_host(active_sensor);
+    upload();
+    if (m_opts.log_level > 0) {
+        std::ostringstream oss;
+        oss << "Configured in " << duration_cast<duration<double>>(high_resolution_clock::now() - start_time).count() << " seconds.";
+        log(oss.str());
+    }
+}
+
+// host half of configure: everything except the device upload / BVH build
+void Scene::configure_host(const std::vector<int> &active_sensor) {
+    m_configured = false;
+    if (m_opts.log_level > 0) std::cout << "[Scene] resolution: " << m_opts.height << " " << m_opts.width << std::endl;
+    PSDR_ASSERT(m_num_sensors == (int) m_sensors.size());
+    PSDR_ASSERT(m_num_meshes == (int) m_meshes.size());
+
+    // seed samplers when the lane count changed (scene.cpp:329-344)
+    const int spps[3] = {m_opts.spp, m_opts.sppe, m_opts.sppse};
+    for (int k = 0; k < 3; ++k)
+        if (spps[k] > 0) {
+            const int64_t count = (int64_t) m_opts.height * m_opts.width * spps[k];
+            if (!m_samplers[k].ready || m_samplers[k].sample_count != count) m_samplers[k] = SamplerState{true, count, (uint64_t) (int64_t) seed, 0};
+        }
+
+    PSDR_ASSERT_MSG(!m_meshes.empty(), "Missing meshes!");
+    PSDR_ASSERT_MSG(!m_sensors.empty(), "Missing sensor!");
+    for (int id : active_sensor) PSDR_ASSERT_MSG(id >= 0 && id < m_num_sensors, "Invalid sensor id!");
+
+    Snapshot &S = snap;
+    S = Snapshot();
+    for (int k = 0; k < 3; ++k) { m_lower[k] = std::numeric_limits<float>::max(); m_upper[k] = -std::numeric_limits<float>::max(); }
+    int face_offset = 0;
+    for (Mesh *mesh : m_meshes) {
+        mesh->configure();
+        psdr_mesh_rec r{};
+        r.bsdf_id = mesh->m_bsdf_id; r.emitter_id = mesh->m_emitter_id; r.face_offset = face_offset; r.n_faces = mesh->m_num_faces;
+        r.inv_total_area = mesh->m_inv_total_area; r.distrb_offset = 0; r.distrb_sum = mesh->face_distrb.sum;
+        if (mesh->m_emitter_id >= 0) {
+            r.distrb_offset = (int) S.face_pmf.size();
+            S.face_pmf.insert(S.face_pmf.end(), mesh->face_distrb.pmf.begin(), mesh->face_distrb.pmf.end());
+            S.face_cmf.insert(S.face_cmf.end(), mesh->face_distrb.cmf.begin(), mesh->face_distrb.cmf.end());
+        }
+        S.meshes.push_back(r);
+        for (int f = 0; f < mesh->m_num_faces; ++f) {
+            const float *t = &mesh->tri[22 * (size_t) f], *d = &mesh->d_tri[22 * (size_t) f];
+            auto app = [](std::vector<float> &dst, const float *src) { dst.push_back(src[0]); dst.push_back(src[1]); dst.push_back(src[2]); };
+            app(S.p0, t); app(S.e1, t + 3); app(S.e2, t + 6); app(S.n0, t + 9); app(S.n1, t + 12); app(S.n2, t + 15); app(S.fn, t + 18); S.area.push_back(t[21]);
+            app(S.d_p0, d); app(S.d_e1, d + 3); app(S.d_e2, d + 6); app(S.d_n0, d + 9); app(S.d_n1, d + 12); app(S.d_n2, d + 15); app(S.d_fn, d + 18); S.d_area.push_back(d[21]);
+            for (int k = 0; k < 3; ++k) {
+                if (mesh->m_has_uv) { const int ui = mesh->face_uv_indices[3 * f + k]; S.uv.push_back(mesh->vertex_uv[2 * ui]); S.uv.push_back(mesh->vertex_uv[2 * ui + 1]); }
+                else { S.uv.push_back(0.f); S.uv.push_back(0.f); }
+            }
+            S.mesh_id.push_back(mesh->m_mesh_id);
+            S.flat.push_back(mesh->m_use_face_normals ? 1 : 0);
+        }
+        face_offset += mesh->m_num_faces;
+        for (int v = 0; v < mesh->m_num_vertices; ++v)
+            for (int k = 0; k < 3; ++k) { m_lower[k] = std::min(m_lower[k], mesh->vertex_positions[3 * v + k]); m_upper[k] = std::max(m_upper[k], mesh->vertex_positions[3 * v + k]); }
+    }
+
+    // sensors: only the active ones keep their primary-edge list (scene.cpp:381-416)
+    std::vector<size_t> num_edges;
+    for (int sid = 0; sid < m_num_sensors; ++sid) {
+        const bool active = std::find(active_sensor.begin(), active_sensor.end(), sid) != active_sensor.end();
+        PerspectiveCamera *cam = static_cast<PerspectiveCamera *>(m_sensors[sid]);
+        cam->configure(*this, active);
+        for (int k = 0; k < 3; ++k) { m_lower[k] = std::min(m_lower[k], cam->rec.cam_pos[k]); m_upper[k] = std::max(m_upper[k], cam->rec.cam_pos[k]); }
+        if (m_opts.sppe > 0 && (active || active_sensor.empty())) num_edges.push_back(cam->m_enable_edges ? cam->m_edges.length.size() : 1);
+    }
+    if (m_opts.log_level > 0) {
+        std::ostringstream oss;
+        oss << "AABB: [lower = [[" << m_lower[0] << ", " << m_lower[1] << ", " << m_lower[2] << "]], upper = [[" << m_upper[0] << ", " << m_upper[1] << ", " << m_upper[2] << "]]]";
+        log(oss.str());
+        if (m_opts.sppe > 0 && !num_edges.empty()) {
+            std::ostringstream o2; o2 << "(" << num_edges[0];
+            for (size_t i = 1; i < num_edges.size(); ++i) o2 << ", " << num_edges[i];
+            o2 << ") primary edges initialized.";
+            log(o2.str());
+        }
+    }
+
+    // emitters (area.cpp:9-14, scene.cpp:488-515)
+    if (!m_emitters.empty()) {
+        std::vector<float> weights;
+        for (Emitter *e : m_emitters) {
+            AreaLight *al = static_cast<AreaLight *>(e);
+            PSDR_ASSERT(al->m_mesh != nullptr && al->m_mesh->m_ready);
+            al->m_sampling_weight = al->m_mesh->m_total_area * (al->radiance[0] * .2126f + al->radiance[1] * .7152f + al->radiance[2] * .0722f);
+            al->m_ready = true;
+            weights.push_back(al->m_sampling_weight);
+        }
+        S.emitters_distrb.init(weights);
+        const float inv_total = 1.f / S.emitters_distrb.sum;
+        for (Emitter *e : m_emitters) {
+            AreaLight *al = static_cast<AreaLight *>(e);
+            al->m_sampling_weight *= inv_total;
+            psdr_emitter_rec r{};
+            r.mesh_id = al->m_mesh->m_mesh_id; r.sampling_weight = al->m_sampling_weight;
+            for (int k = 0; k < 3; ++k) { r.radiance[k] = al->radiance[k]; r.d_radiance[k] = al->d_radiance[k]; }
+            S.emitters.push_back(r);
+        }
+    }
+    for (BSDF *b : m_bsdfs) {
+        const Diffuse *d = static_cast<const Diffuse *>(b);
+        psdr_bsdf_rec r{};
+        r.type = 0; r.two_sided = d->m_twoSide ? 1 : 0;
+        for (int k = 0; k < 3; ++k) { r.reflectance[k] = d->reflectance[k]; r.d_reflectance[k] = d->d_reflectance[k]; }
+        S.bsdfs.push_back(r);
+    }
+
+    // secondary edges (mesh.cpp:355-369, scene.cpp:546-571): every mesh edge is kept
+    if (m_opts.sppse > 0) {
+        std::vector<float> pmf;
+        int fo = 0;
+        for (const Mesh *mesh : m_meshes) {
+            if (mesh->m_enable_edges) {
+                for (const MeshEdge &e : mesh->edges) {
+                    const float *P = mesh->vertex_positions.data(), *dP = mesh->d_vertex_positions.data();
+                    float e1[3], de1[3];
+                    for (int k = 0; k < 3; ++k) {
+                        e1[k] = P[3 * e.v1 + k] - P[3 * e.v0 + k]; de1[k] = dP[3 * e.v1 + k] - dP[3 * e.v0 + k];
+                        S.se_p0.push_back(P[3 * e.v0 + k]); S.se_d_p0.push_back(dP[3 * e.v0 + k]);
+                        S.se_p2.push_back(P[3 * e.opp + k]);
+                        S.se_n0.push_back(mesh->tri[22 * (size_t) e.f0 + 18 + k]);
+                        S.se_n1.push_back(e.f1 >= 0 ? mesh->tri[22 * (size_t) e.f1 + 18 + k] : 0.f);
+                    }
+                    for (int k = 0; k < 3; ++k) { S.se_e1.push_back(e1[k]); S.se_d_e1.push_back(de1[k]); }
+                    S.se_boundary.push_back(e.f1 < 0 ? 1 : 0);
+                    pmf.push_back(std::sqrt(std::fmaf(e1[2], e1[2], std::fmaf(e1[1], e1[1], e1[0] * e1[0]))));
+                }
+            }
+            fo += mesh->m_num_faces;
+        }
+        S.n_sec_edges = (int) pmf.size();
+        if (!pmf.empty()) S.sec_edge_distrb.init(pmf);
+        if (m_opts.log_level > 0) { std::ostringstream oss; oss << S.n_sec_edges << " secondary edges initialized."; log(oss.str()); }
+    }
+
+    m_host_ready = true;
+}
+
+// assemble the C-ABI snapshot and hand it to the HIP library (replaces Scene_OptiX::configure)
+void Scene::upload() {
+    PSDR_ASSERT_MSG(m_host_ready, "configure_host() first");
+    Snapshot &S = snap;
+    S.sensors.clear();
+    psdr_scene_snapshot sn{};
+    sn.abi_version = PSDR_HIP_ABI_VERSION;
+    sn.width = m_opts.width; sn.height = m_opts.height; sn.spp = m_opts.spp; sn.sppe = m_opts.sppe; sn.sppse = m_opts.sppse;
+    psdr_triangles &t = sn.tris;
+    t.n_triangles = (int) S.area.size();
+    t.p0 = S.p0.data(); t.e1 = S.e1.data(); t.e2 = S.e2.data(); t.n0 = S.n0.data(); t.n1 = S.n1.data(); t.n2 = S.n2.data();
+    t.face_normal = S.fn.data(); t.face_area = S.area.data(); t.uv = S.uv.data(); t.mesh_id = S.mesh_id.data(); t.use_face_normal = S.flat.data();
+    t.d_p0 = S.d_p0.data(); t.d_e1 = S.d_e1.data(); t.d_e2 = S.d_e2.data(); t.d_n0 = S.d_n0.data(); t.d_n1 = S.d_n1.data(); t.d_n2 = S.d_n2.data();
+    t.d_face_normal = S.d_fn.data(); t.d_face_area = S.d_area.data();
+    sn.n_meshes = (int) S.meshes.size(); sn.meshes = S.meshes.data();
+    sn.n_bsdfs = (int) S.bsdfs.size(); sn.bsdfs = S.bsdfs.data();
+    sn.n_emitters = (int) S.emitters.size(); sn.emitters = S.emitters.data();
+    sn.emitter_pmf = S.emitters_distrb.pmf.data(); sn.emitter_cmf = S.emitters_distrb.cmf.data(); sn.emitter_sum = S.emitters_distrb.sum;
+    sn.n_face_distrb = (int) S.face_pmf.size(); sn.face_pmf = S.face_pmf.data(); sn.face_cmf = S.face_cmf.data();
+    psdr_sec_edges &se = sn.sec_edges;
+    se.n_edges = S.n_sec_edges;
+    if (S.n_sec_edges > 0) {
+        se.p0 = S.se_p0.data(); se.e1 = S.se_e1.data(); se.n0 = S.se_n0.data(); se.n1 = S.se_n1.data(); se.p2 = S.se_p2.data();
+        se.is_boundary = S.se_boundary.data(); se.d_p0 = S.se_d_p0.data(); se.d_e1 = S.se_d_e1.data();
+        se.pmf = S.sec_edge_distrb.pmf.data(); se.cmf = S.sec_edge_distrb.cmf.data(); se.sum = S.sec_edge_distrb.sum;
+    }
+    for (Sensor *s : m_sensors) {
+        PerspectiveCamera *cam = static_cast<PerspectiveCamera *>(s);
+        psdr_sensor_rec r = cam->rec;
+        r.n_edges = cam->m_enable_edges ? (int) cam->m_edges.length.size() : 0;
+        if (r.n_edges > 0) {
+            const PrimaryEdges &pe = cam->m_edges;
+            r.edge_p0 = pe.p0.data(); r.edge_p1 = pe.p1.data(); r.d_edge_p0 = pe.d_p0.data(); r.d_edge_p1 = pe.d_p1.data();
+            r.edge_normal = pe.normal.data(); r.edge_length = pe.length.data(); r.edge_pmf = pe.distrb.pmf.data(); r.edge_cmf = pe.distrb.cmf.data();
+            r.edge_sum = pe.distrb.sum;
+        }
+        S.sensors.push_back(r);
+    }
+    sn.n_sensors = (int) S.sensors.size(); sn.sensors = S.sensors.data();
+    release_device();
+    hip_check(psdr_hip_scene_create(&sn, &m_hip));
+    m_configured = true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Integrator::renderC / renderD, reference src/integrator/integrator.cpp:12-100
+static void fill_args(psdr_render_args &a, const Scene &scene, const Integrator &it, int sensor_id, uintptr_t pix_ids, int n_pix, int rank, int count) {
+    std::memset(&a, 0, sizeof(a));
+    a.sensor_id = sensor_id; a.max_depth = it.max_depth(); a.hide_emitters = it.hide_emitters() ? 1 : 0;
+    for (int k = 0; k < 3; ++k) { a.samplers[k].seed = scene.m_samplers[k].seed; a.samplers[k].skip = scene.m_samplers[k].skip; }
+    a.pix_ids = reinterpret_cast<const int32_t *>(pix_ids); a.n_pix = n_pix;
+    a.shard_rank = rank; a.shard_count = count; a.zero_output = 1;
+    a.guiding = it.guiding(sensor_id);
+}
+
+void Integrator::renderC(const Scene &scene, int sensor_id, int seed, uintptr_t pix_ids, int n_pix, uintptr_t out, uintptr_t stream, int rank, int count) const {
+    using namespace std::chrono;
+    const auto start_time = high_resolution_clock::now();
+    const RenderOption &opts = scene.m_opts;
+    PSDR_ASSERT_MSG(!(pix_ids != 0 && seed == -1), "While using batch rendering, seed must be set!");
+    PSDR_ASSERT_MSG(scene.is_ready(), "Input scene must be configured!");
+    PSDR_ASSERT_MSG(sensor_id >= 0 && sensor_id < scene.m_num_sensors, "Invalid sensor id!");
+    const int64_t npx = pix_ids ? n_pix : (int64_t) opts.width * opts.height;
+    PSDR_ASSERT(npx * opts.spp <= std::numeric_limits<int>::max());
+    if (seed != -1) scene.m_samplers[0] = SamplerState{true, npx * opts.spp, (uint64_t) (int64_t) seed, 0};
+    psdr_render_args a;
+    fill_args(a, scene, *this, sensor_id, pix_ids, n_pix, rank, count);
+    hip_check(psdr_hip_render_c(scene.m_hip, &a, reinterpret_cast<float *>(out), reinterpret_cast<void *>(stream)));
+    if (opts.spp > 0) scene.m_samplers[0].skip += 2 + 5 * (uint64_t) max_depth();
+    if (opts.log_level) {
+        std::ostringstream oss;
+        oss << "Rendered in " << duration_cast<duration<double>>(high_resolution_clock::now() - start_time).count() << " seconds.";
+        log(oss.str());
+    }
+}
+
+void Integrator::renderD(const Scene &scene, int sensor_id, int seed, uintptr_t pix_ids, int n_pix, uintptr_t out, uintptr_t dout, uintptr_t stream,
+                         int rank, int count, int terms) const {
+    using namespace std::chrono;
+    const auto start_time = high_resolution_clock::now();
+    const RenderOption &opts = scene.m_opts;
+    PSDR_ASSERT_MSG(!(pix_ids != 0 && seed == -1), "While using batch rendering, seed must be set!");
+    PSDR_ASSERT_MSG(scene.is_ready(), "Input scene must be configured!");
+    PSDR_ASSERT_MSG(sensor_id >= 0 && sensor_id < scene.m_num_sensors, "Invalid sensor id!");
+    const int64_t num_pixels = (int64_t) opts.height * opts.width;
+    const int64_t npx = pix_ids ? n_pix : num_pixels;
+    if (seed != -1) {
+        if (opts.spp > 0) scene.m_samplers[0] = SamplerState{true, npx * opts.spp, (uint64_t) (int64_t) seed, 0};
+        if (opts.sppe > 0) scene.m_samplers[1] = SamplerState{true, num_pixels * opts.sppe, (uint64_t) (int64_t) seed, 0};
+        if (opts.sppse > 0) scene.m_samplers[2] = SamplerState{true, num_pixels * opts.sppse, (uint64_t) (int64_t) seed, 0};
+    }
+    psdr_render_args a;
+    fill_args(a, scene, *this, sensor_id, pix_ids, n_pix, rank, count);
+    a.terms = terms;
+    hip_check(psdr_hip_render_d_fwd(scene.m_hip, &a, reinterpret_cast<float *>(out), reinterpret_cast<float *>(dout), reinterpret_cast<void *>(stream)));
+    const PerspectiveCamera *cam = static_cast<const PerspectiveCamera *>(scene.m_sensors[sensor_id]);
+    if (opts.spp > 0 && (terms & PSDR_TERM_INTERIOR)) scene.m_samplers[0].skip += 2 + 5 * (uint64_t) max_depth();
+    if (opts.sppe > 0 && cam->m_enable_edges && (terms & PSDR_TERM_PRIMARY) && !pix_ids) scene.m_samplers[1].skip += 1 + 10 * (uint64_t) max_depth();
+    if (opts.sppse > 0 && (terms & PSDR_TERM_SECONDARY) && !pix_ids) scene.m_samplers[2].skip += 3;
+    if (opts.log_level) {
+        std::ostringstream oss;
+        oss << "Rendered in " << duration_cast<duration<double>>(high_resolution_clock::now() - start_time).count() << " seconds.";
+        log(oss.str());
+    }
+}
+
+PathTracer::PathTracer(int max_depth) : m_max_depth(max_depth) { PSDR_ASSERT(max_depth >= 0); }
+PathTracer::~PathTracer() { for (psdr_hip_guiding *g : m_warpper) if (g) psdr_hip_guiding_destroy(g); }
+const psdr_hip_guiding *PathTracer::guiding(int sensor_id) const {
+    return (sensor_id >= 0 && sensor_id < (int) m_warpper.size()) ? m_warpper[sensor_id] : nullptr;
+}
+// PathTracer::preprocess_secondary_edges, reference src/integrator/path.cpp:130-168
+void PathTracer::preprocess_secondary_edges(const Scene &scene, int sensor_id, const std::array<int, 4> &reso, int nrounds, int seed) {
+    PSDR_ASSERT(nrounds > 0);
+    PSDR_ASSERT_MSG(scene.is_ready(), "Scene needs to be configured!");
+    PSDR_ASSERT_MSG(sensor_id >= 0 && sensor_id < scene.m_num_sensors, "Invalid sensor id!");
+    if ((int) m_warpper.size() != scene.m_num_sensors) m_warpper.resize(scene.m_num_sensors, nullptr);
+    if (m_warpper[sensor_id]) { psdr_hip_guiding_destroy(m_warpper[sensor_id]); m_warpper[sensor_id] = nullptr; }
+    hip_check(psdr_hip_guiding_build(scene.m_hip, sensor_id, m_max_depth, reso.data(), nrounds, seed, &m_warpper[sensor_id], nullptr));
+}
+std::vector<float> PathTracer::guiding_mass(int sensor_id) const {
+    const psdr_hip_guiding *g = guiding(sensor_id);
+    PSDR_ASSERT_MSG(g != nullptr, "no guiding distribution for this sensor");
+    std::vector<float> out(psdr_hip_guiding_num_cells(g));
+    hip_check(psdr_hip_guiding_mass(g, out.data(), (int) out.size()));
+    return out;
+}
+
+} // namespace psdr_host

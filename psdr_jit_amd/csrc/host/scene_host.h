@@ -1,0 +1,220 @@
+// scene_host.h — host-side scene model behind the psdr_jit Python surface.
+//
+// Mirrors the reference classes that the hot path needs (same member names / semantics):
+//   RenderOption (include/psdr/types.h:217-228), Object (include/psdr/object.h), Mesh (shape/mesh.h),
+//   Diffuse (bsdf/diffuse.h), AreaLight (emitter/area.h), PerspectiveCamera (sensor/perspective.h),
+//   Scene (scene/scene.h), Integrator / PathTracer (integrator/integrator.h, path.h).
+// drjit arrays become plain host vectors; every differentiable member carries one forward tangent.
+// Scene::configure() produces the psdr_scene_snapshot of include/psdr_hip.h and hands it to
+// libpsdr_hip.so; rendering is entirely behind that C ABI.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../../include/psdr_hip.h"
+#include "hnum.h"
+
+namespace psdr_host {
+
+using M16 = std::array<float, 16>;
+inline M16 identity16() { return {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}; }
+inline M16 zeros16() { M16 z{}; return z; }
+
+// reference include/misc/Exception.h:7-40 (text carries file/line); surfaces as RuntimeError in Python
+struct Exception : std::runtime_error { using std::runtime_error::runtime_error; };
+[[noreturn]] void throw_assert(const char *cond, const char *file, int line, const std::string &msg);
+#define PSDR_ASSERT_MSG(cond, msg) do { if (!(cond)) ::psdr_host::throw_assert(#cond, __FILE__, __LINE__, (msg)); } while (0)
+#define PSDR_ASSERT(cond) PSDR_ASSERT_MSG(cond, "")
+
+struct Object {
+    virtual ~Object() {}
+    virtual std::string type_name() const = 0;
+    virtual std::string to_string() const { return type_name(); }
+    void log(const std::string &msg) const;
+    std::string m_id;
+};
+
+struct RenderOption {
+    RenderOption() : width(128), height(128), spp(1), sppe(0), sppse(0), log_level(1) {}
+    RenderOption(int w, int h, int s) : width(w), height(h), spp(s), sppe(s), sppse(s), log_level(1) {}
+    RenderOption(int w, int h, int s1, int s2) : width(w), height(h), spp(s1), sppe(s2), sppse(s2), log_level(1) {}
+    RenderOption(int w, int h, int s1, int s2, int s3) : width(w), height(h), spp(s1), sppe(s2), sppse(s3), log_level(1) {}
+    int width, height, spp, sppe, sppse, log_level;
+};
+
+// DiscreteDistribution (host part), reference include/psdr/core/pmf.h:12-38, src/core/pmf.cpp:6-15
+struct Distrb {
+    int size = 0;
+    float sum = 0.f;
+    std::vector<float> pmf, cmf;
+    void init(const std::vector<float> &p);
+};
+
+struct BSDF : Object {
+    bool m_twoSide = false;
+    virtual bool anisotropic() const = 0;
+};
+struct Diffuse : BSDF {
+    Diffuse() : reflectance{0.5f, 0.5f, 0.5f}, d_reflectance{0, 0, 0} {}
+    explicit Diffuse(const std::array<float, 3> &r) : reflectance(r), d_reflectance{0, 0, 0} {}
+    std::string type_name() const override { return "Diffuse"; }
+    std::string to_string() const override { return std::string("Diffuse[id=") + m_id + "]"; }
+    bool anisotropic() const override { return false; }
+    std::array<float, 3> reflectance, d_reflectance;   // Bitmap3fD with 1x1 resolution (bitmap.cpp:54-59)
+};
+
+struct Mesh;
+struct Emitter : Object { float m_sampling_weight = 1.f; bool m_ready = false; };
+struct AreaLight : Emitter {
+    explicit AreaLight(const std::array<float, 3> &r) : radiance(r), d_radiance{0, 0, 0} {}
+    std::string type_name() const override { return "AreaLight"; }
+    std::array<float, 3> radiance, d_radiance;
+    const Mesh *m_mesh = nullptr;
+};
+
+struct Transformable {
+    M16 to_world_raw = identity16(), to_world_left = identity16(), to_world_right = identity16();
+    M16 d_to_world_raw = zeros16(), d_to_world_left = zeros16(), d_to_world_right = zeros16();
+    // Mesh::set_transform / append_transform, reference mesh.h:26-42 (same on Sensor, sensor.h:34-48)
+    void set_transform(const M16 &mat, const M16 &dmat, bool set_left);
+    void append_transform(const M16 &mat, const M16 &dmat, bool append_left);
+    DM4 to_world() const;      // left * raw * right
+};
+
+struct MeshEdge { int v0, v1, f0, f1, opp; };
+
+struct Mesh : Object, Transformable {
+    std::string type_name() const override { return "Mesh"; }
+    std::string to_string() const override;
+    void load(const std::string &fname, bool verbose = false);     // OBJ (triangulates polygons)
+    void load_raw(const std::vector<float> &v, const std::vector<int> &f, const std::vector<float> &uv, const std::vector<int> &fuv, bool verbose = false);
+    void configure();
+    void dump(const std::string &fname, bool raw) const;
+
+    int m_mesh_id = -1;
+    bool m_ready = false, m_use_face_normals = false, m_has_uv = false, m_enable_edges = true;
+    int m_bsdf_id = -1, m_emitter_id = -1;
+    const BSDF *m_bsdf = nullptr;
+    const Emitter *m_emitter = nullptr;
+    int m_num_vertices = 0, m_num_faces = 0;
+    std::vector<float> vertex_positions_raw, d_vertex_positions_raw;   // [nv*3]
+    std::vector<float> vertex_uv;                                       // [nuv*2]
+    std::vector<int> face_indices, face_uv_indices;                     // [nf*3]
+    std::vector<MeshEdge> edges;
+    // results of configure()
+    std::vector<float> vertex_positions, d_vertex_positions;            // world space
+    std::vector<float> vertex_normals_raw;
+    float m_total_area = 0.f, m_inv_total_area = 0.f;
+    Distrb face_distrb;
+    // per-face TriangleInfo rows (value, tangent), 22 floats each: p0 e1 e2 n0 n1 n2 fn area
+    std::vector<float> tri, d_tri;
+private:
+    void build_edges();
+};
+
+struct PrimaryEdges {
+    std::vector<float> p0, p1, d_p0, d_p1, normal, length;
+    Distrb distrb;
+};
+
+struct Scene;
+struct Sensor : Object, Transformable {
+    virtual void configure(const Scene &scene, bool keep_edges) = 0;
+    bool m_enable_edges = false;
+    PrimaryEdges m_edges;
+};
+struct PerspectiveCamera : Sensor {
+    PerspectiveCamera(float fov_x, float near_, float far_) : m_fov_x(fov_x), m_near_clip(near_), m_far_clip(far_) {}
+    std::string type_name() const override { return "PerspectiveCamera"; }
+    void configure(const Scene &scene, bool keep_edges) override;
+    float m_fov_x, m_near_clip, m_far_clip;
+    psdr_sensor_rec rec{};     // filled by configure (edge pointers are patched when the snapshot is assembled)
+};
+
+// closed form of one of Scene::m_samplers[3] (reference scene.h:76, sampler.h:8-40)
+struct SamplerState {
+    bool ready = false;
+    int64_t sample_count = 0;
+    uint64_t seed = 0, skip = 0;
+};
+
+struct Scene : Object {
+    Scene();
+    ~Scene() override;
+    std::string type_name() const override { return "Scene"; }
+
+    void add_Sensor(const Sensor *sensor);
+    void add_BSDF(const BSDF *bsdf, const std::string &bsdf_id, bool twoSide = false);
+    void add_Mesh(const std::string &fname, const M16 &transform, const std::string &bsdf_id, const Emitter *emitter);
+    void add_Mesh(const Mesh *mesh, const std::string &bsdf_id, const Emitter *emitter);
+    void configure(const std::vector<int> &active_sensor = {});
+    void configure_host(const std::vector<int> &active_sensor = {});   // host half (no device needed)
+    void upload();                                                      // BVH build + device upload
+    bool is_ready() const;
+    size_t get_num_emitters() const { return m_emitters.size(); }
+
+    int seed = 0;
+    RenderOption m_opts;
+    int m_num_sensors = 0, m_num_meshes = 0;
+    std::vector<Sensor *> m_sensors;
+    std::vector<Emitter *> m_emitters;
+    std::vector<BSDF *> m_bsdfs;
+    std::vector<Mesh *> m_meshes;
+    std::unordered_map<std::string, Object *> m_param_map;
+    mutable SamplerState m_samplers[3];
+    float m_lower[3], m_upper[3];
+
+    // configured snapshot (host arrays the psdr_scene_snapshot points into)
+    struct Snapshot {
+        std::vector<float> p0, e1, e2, n0, n1, n2, fn, area, uv, d_p0, d_e1, d_e2, d_n0, d_n1, d_n2, d_fn, d_area;
+        std::vector<int32_t> mesh_id;
+        std::vector<uint8_t> flat;
+        std::vector<psdr_mesh_rec> meshes;
+        std::vector<psdr_bsdf_rec> bsdfs;
+        std::vector<psdr_emitter_rec> emitters;
+        Distrb emitters_distrb, sec_edge_distrb;
+        std::vector<float> face_pmf, face_cmf;
+        std::vector<float> se_p0, se_e1, se_n0, se_n1, se_p2, se_d_p0, se_d_e1;
+        std::vector<uint8_t> se_boundary;
+        std::vector<psdr_sensor_rec> sensors;
+        int n_sec_edges = 0;
+    } snap;
+    psdr_hip_scene *m_hip = nullptr;
+    bool m_configured = false, m_host_ready = false;
+private:
+    void rebuild_param_map();
+    void release_device();
+};
+
+struct Integrator : Object {
+    // out / dout / pix_ids are DEVICE pointers (uintptr_t from the caller's tensors), stream a hipStream_t
+    void renderC(const Scene &scene, int sensor_id, int seed, uintptr_t pix_ids, int n_pix, uintptr_t out, uintptr_t stream,
+                 int shard_rank, int shard_count) const;
+    void renderD(const Scene &scene, int sensor_id, int seed, uintptr_t pix_ids, int n_pix, uintptr_t out, uintptr_t dout, uintptr_t stream,
+                 int shard_rank, int shard_count, int terms) const;
+    virtual int max_depth() const = 0;
+    virtual bool hide_emitters() const = 0;
+    virtual const psdr_hip_guiding *guiding(int sensor_id) const { (void) sensor_id; return nullptr; }
+};
+
+struct PathTracer : Integrator {
+    explicit PathTracer(int max_depth = 1);
+    ~PathTracer() override;
+    std::string type_name() const override { return "PathTracer"; }
+    int max_depth() const override { return m_max_depth; }
+    bool hide_emitters() const override { return m_hide_emitters; }
+    const psdr_hip_guiding *guiding(int sensor_id) const override;
+    void preprocess_secondary_edges(const Scene &scene, int sensor_id, const std::array<int, 4> &reso, int nrounds = 1, int seed = 0);
+    std::vector<float> guiding_mass(int sensor_id) const;
+    bool m_hide_emitters = false;
+    int m_max_depth;
+    std::vector<psdr_hip_guiding *> m_warpper;
+};
+
+} // namespace psdr_host

@@ -1,0 +1,54 @@
+"""Builds the PRODUCT scene (psdr_jit_amd, host C++ + HIP) from the same neutral SceneSpec the
+oracle consumes, through the reference-style Python surface."""
+import numpy as np
+
+
+def build_scene(spec, configure=True, active=(0,), host_only=False, log_level=0):
+    import psdr_jit_amd as psdr
+    sc = psdr.Scene()
+    sc.opts.width, sc.opts.height = spec.width, spec.height
+    sc.opts.spp, sc.opts.sppe, sc.opts.sppse = spec.spp, spec.sppe, spec.sppse
+    sc.opts.log_level = log_level
+    for c in spec.cameras:
+        cam = psdr.PerspectiveCamera(c.fov_x, c.near, c.far)
+        cam._set("to_world", c.to_world_raw, c.d_to_world_raw)
+        cam._set("to_world_left", c.to_world_left, c.d_to_world_left)
+        cam._set("to_world_right", c.to_world_right, c.d_to_world_right)
+        sc.add_Sensor(cam)
+    for i, b in enumerate(spec.bsdfs):
+        bs = psdr.DiffuseBSDF(list(b.reflectance))
+        bs._set("reflectance", np.asarray(b.reflectance, np.float32), np.asarray(b.d_reflectance, np.float32))
+        sc.add_BSDF(bs, b.name or ("bsdf%d" % i), b.two_sided)
+    for m in spec.meshes:
+        mesh = psdr.Mesh()
+        mesh.enable_edges = m.enable_edges
+        if m.path is not None:
+            mesh.load(m.path)
+        else:
+            mesh.load_raw(m.vertices, m.faces, m.uvs if m.uvs is not None else np.zeros((0, 2), np.float32),
+                          m.face_uvs if m.face_uvs is not None else np.zeros((0, 3), np.int32))
+        mesh.use_face_normal = m.use_face_normals
+        mesh._set("to_world", m.to_world_raw, m.d_to_world_raw)
+        mesh._set("to_world_left", m.to_world_left, m.d_to_world_left)
+        mesh._set("to_world_right", m.to_world_right, m.d_to_world_right)
+        if m.d_vertices is not None:
+            mesh._set("vertex_positions", m.vertices, m.d_vertices)
+        em = None
+        if m.emitter >= 0:
+            e = spec.emitters[m.emitter]
+            em = psdr.AreaLight(list(e.radiance))
+            em._set("radiance", np.asarray(e.radiance, np.float32), np.asarray(e.d_radiance, np.float32))
+        b = spec.bsdfs[m.bsdf]
+        sc.add_Mesh(mesh, b.name or ("bsdf%d" % m.bsdf), em)
+    if configure:
+        if host_only:
+            sc._configure_host(list(active))
+        else:
+            sc._configure(list(active))
+            sc.__dict__["_psdr_active"] = list(active)
+    return sc
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
