@@ -116,6 +116,8 @@ typedef struct psdr_sampler {
     uint64_t skip;
 } psdr_sampler;
 
+#define PSDR_SHARD_CHUNK 256
+
 #define PSDR_TERM_INTERIOR  1
 #define PSDR_TERM_PRIMARY   2
 #define PSDR_TERM_SECONDARY 4
@@ -131,7 +133,8 @@ typedef struct psdr_render_args {
     const int32_t *pix_ids;       /* DEVICE pointer, batch_pix (integrator.cpp:139-176); NULL = full frame */
     int32_t n_pix;
     int32_t terms;                /* PSDR_TERM_* mask (renderD only) */
-    int32_t shard_rank, shard_count;  /* evaluate lanes [N*r/c, N*(r+1)/c) of each sampler; count<=1 = all */
+    int32_t shard_rank, shard_count;  /* multi-GPU: rank r of c evaluates the PSDR_SHARD_CHUNK-lane chunks k of each
+                                       * sampler's lane range with k % c == r (interleaved for load balance); c<=1 = all */
     const psdr_hip_guiding *guiding;  /* NULL = unguided secondary edges */
     int32_t zero_output;          /* 1: the call clears out buffers first (hipMemsetAsync on `stream`) */
 } psdr_render_args;

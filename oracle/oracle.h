@@ -120,7 +120,7 @@ typedef struct orc_guiding orc_guiding;
 int orc_render_d(const orc_scene *s, int sensor_id, int max_depth, int hide_emitters,
                  const orc_sampler samplers[3], const int *pix_ids, int n_pix,
                  const orc_guiding *guiding, int terms,
-                 int shard_rank, int shard_count,   /* lanes [N*r/c, N*(r+1)/c) of each sampler; c<=1 = all */
+                 int shard_rank, int shard_count,   /* 256-lane chunks k with k % c == r of each sampler; c<=1 = all */
                  float *out_rgb, float *out_drgb);
 
 /* per-lane radiance of the interior term (debug/parity aid): out [n_lanes*3] */

@@ -141,10 +141,8 @@ int orc_li_lanes(const orc_scene *s, int sensor_id, int max_depth, int hide, orc
 }
 
 // ---------------------------------------------------------------- renderD
-static inline void shard(int64_t N, int rank, int count, int64_t &b, int64_t &e) {
-    if (count <= 1) { b = 0; e = N; return; }
-    b = N * rank / count; e = N * (rank + 1) / count;
-}
+// multi-GPU sharding of the product: rank r of c owns the 256-lane chunks k with k % c == r
+static inline bool in_shard(int64_t lane, int rank, int count) { return count <= 1 || ((lane / 256) % count) == rank; }
 
 int orc_render_d(const orc_scene *s, int sensor_id, int max_depth, int hide, const orc_sampler samplers[3], const int *pix_ids, int n_pix,
                  const orc_guiding *guiding, int terms, int shard_rank, int shard_count, float *out, float *dout) {
@@ -158,13 +156,13 @@ int orc_render_d(const orc_scene *s, int sensor_id, int max_depth, int hide, con
 
     // interior integral (integrator.cpp:75-81)
     if ((terms & ORC_TERM_INTERIOR) && sc.spp > 0) {
-        int64_t lb, le;
-        shard(npx * sc.spp, shard_rank, shard_count, lb, le);
-        const int64_t px0 = lb / sc.spp, px1 = (le + sc.spp - 1) / sc.spp;
+        const int64_t lb = 0, le = npx * sc.spp;
+        const int64_t px0 = 0, px1 = npx;
 #pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads)
         for (int64_t px = px0; px < px1; ++px) {
             float acc[3] = {0, 0, 0}, dacc[3] = {0, 0, 0};
             for (int64_t lane = std::max(px * sc.spp, lb); lane < std::min((px + 1) * sc.spp, le); ++lane) {
+                if (!in_shard(lane, shard_rank, shard_count)) continue;
                 V3d v = interior_lane<true>(sc, cam, max_depth, hide != 0, samplers[0], pix_ids, lane);
                 for (int c = 0; c < 3; ++c) {
                     // the reference masks value where the primal is non-finite (integrator.cpp:126)
@@ -189,12 +187,13 @@ int orc_render_d(const orc_scene *s, int sensor_id, int max_depth, int hide, con
 
     // primary edges (integrator.cpp:179-198)
     if ((terms & ORC_TERM_PRIMARY) && sc.sppe > 0 && cam.enable_edges) {
-        int64_t lb, le;
-        shard(npx * sc.sppe, shard_rank, shard_count, lb, le);
+        const int64_t lb = 0, le = npx * sc.sppe;
         for (int64_t c0 = lb; c0 < le; c0 += CH) {
             int64_t c1 = std::min(c0 + CH, le);
 #pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads)
             for (int64_t lane = c0; lane < c1; ++lane) {
+                idx[lane - c0] = -1;
+                if (!in_shard(lane, shard_rank, shard_count)) continue;
                 LaneSampler sm;
                 seed_lane(sm, samplers[1], nullptr, 1, lane);
                 PrimaryEdgeSample es = sample_primary_edge(sc, cam, sm.next_1d());
@@ -219,12 +218,13 @@ int orc_render_d(const orc_scene *s, int sensor_id, int max_depth, int hide, con
 
     // secondary edges (path.cpp:274-294)
     if ((terms & ORC_TERM_SECONDARY) && sc.sppse > 0 && !sc.sec_edges.empty()) {
-        int64_t lb, le;
-        shard(npx * sc.sppse, shard_rank, shard_count, lb, le);
+        const int64_t lb = 0, le = npx * sc.sppse;
         for (int64_t c0 = lb; c0 < le; c0 += CH) {
             int64_t c1 = std::min(c0 + CH, le);
 #pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads)
             for (int64_t lane = c0; lane < c1; ++lane) {
+                idx[lane - c0] = -1;
+                if (!in_shard(lane, shard_rank, shard_count)) continue;
                 LaneSampler sm;
                 seed_lane(sm, samplers[2], nullptr, 1, lane);
                 V3f s3;

@@ -38,6 +38,7 @@ struct RenderParams {
     const int *pix_ids;
     int n_pix;
     LaneRange range;
+    int shard_rank, shard_count;   // rank r of c evaluates the 256-lane chunks k with k % c == r
 };
 
 template <bool LDS>
@@ -88,7 +89,9 @@ __global__ __launch_bounds__(kBlock) void k_interior(const float4 *__restrict__ 
     const long long n = P.range.end - P.range.begin;
     const long long n_chunks = (n + kBlock - 1) / kBlock;
     const float inv_spp = T.spp > 1 ? 1.f / (float) T.spp : 1.f;
-    for (long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    for (long long lc = blockIdx.x;; lc += gridDim.x) {
+        const long long chunk = lc * P.shard_count + P.shard_rank;
+        if (chunk >= n_chunks) break;
         const long long lane = P.range.begin + chunk * kBlock + threadIdx.x;
         const bool in_range = lane < P.range.end;
         int pix_slot = -1;                 // row of the output image this lane adds to
@@ -142,7 +145,9 @@ __global__ __launch_bounds__(kBlock) void k_primary_edges(const float4 *__restri
     SceneView<LDS> S = make_view<LDS>(blob, T, smem);
     const long long n = P.range.end - P.range.begin;
     const long long n_chunks = (n + kBlock - 1) / kBlock;
-    for (long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    for (long long lc = blockIdx.x;; lc += gridDim.x) {
+        const long long chunk = lc * P.shard_count + P.shard_rank;
+        if (chunk >= n_chunks) break;
         const long long lane = P.range.begin + chunk * kBlock + threadIdx.x;
         if (lane < P.range.end) {
             LaneRng rng;
@@ -187,7 +192,9 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edges(const float4 *__rest
     SceneView<LDS> S = make_view<LDS>(blob, T, smem);
     const long long n = P.range.end - P.range.begin;
     const long long n_chunks = (n + kBlock - 1) / kBlock;
-    for (long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    for (long long lc = blockIdx.x;; lc += gridDim.x) {
+        const long long chunk = lc * P.shard_count + P.shard_rank;
+        if (chunk >= n_chunks) break;
         const long long lane = P.range.begin + chunk * kBlock + threadIdx.x;
         if (lane < P.range.end) {
             LaneRng rng;
@@ -472,9 +479,11 @@ int psdr_hip_scene_stats(const psdr_hip_scene *sc, int32_t *n_nodes, int32_t *n_
 
 } // extern "C"
 
-static inline LaneRange shard(long long N, int rank, int count) {
-    if (count <= 1) return {0, N};
-    return {N * rank / count, N * (rank + 1) / count};
+// number of 256-lane chunks of [0, n) that belong to shard `rank` of `count` (chunk k -> rank k % count)
+static inline long long local_lanes(long long n, int rank, int count) {
+    const long long chunks = (n + kBlock - 1) / kBlock;
+    const long long mine = chunks > rank ? (chunks - rank + count - 1) / count : 0;
+    return mine * kBlock;
 }
 static inline int grid_for(const psdr_hip_scene *sc, long long n) {
     long long chunks = (n + kBlock - 1) / kBlock;
@@ -508,11 +517,14 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
     if (COUNT) HIPCHK(hipMemsetAsync(ctr, 0, sizeof(Counters), st));
     const SensorDev &cam = sc->sensors[a->sensor_id];
     const int terms = ad ? (a->terms ? a->terms : 7) : PSDR_TERM_INTERIOR;
+    const int count = a->shard_count > 1 ? a->shard_count : 1;
+    const int rank = count > 1 ? a->shard_rank : 0;
+    if (rank < 0 || rank >= count) return fail("bad shard rank");
 
     if ((terms & PSDR_TERM_INTERIOR) && T.spp > 0) {
-        RenderParams P{a->max_depth, a->hide_emitters, a->samplers[0].seed, a->samplers[0].skip, a->pix_ids, a->n_pix, {0, 0}};
-        P.range = lanes_out ? LaneRange{lane_b, lane_e} : shard(npx * T.spp, a->shard_rank, a->shard_count);
-        const long long nl = P.range.end - P.range.begin;
+        RenderParams P{a->max_depth, a->hide_emitters, a->samplers[0].seed, a->samplers[0].skip, a->pix_ids, a->n_pix, {0, npx * T.spp}, rank, count};
+        if (lanes_out) { P.range = LaneRange{lane_b, lane_e}; P.shard_rank = 0; P.shard_count = 1; }
+        const long long nl = local_lanes(P.range.end - P.range.begin, P.shard_rank, P.shard_count);
         if (nl > 0) {
             if (ad) {
                 if (sc->lds) LAUNCH((k_interior<true, true, COUNT>), sc, nl, st, sc->blob.as<float4>(), T, cam, P, out, dout, lanes_out, ctr);
@@ -525,16 +537,16 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
     }
     if (ad && !a->pix_ids && !lanes_out) {
         if ((terms & PSDR_TERM_PRIMARY) && T.sppe > 0 && cam.n_edges > 0) {
-            RenderParams P{a->max_depth, a->hide_emitters, a->samplers[1].seed, a->samplers[1].skip, nullptr, 0, shard(npx * T.sppe, a->shard_rank, a->shard_count)};
-            const long long nl = P.range.end - P.range.begin;
+            RenderParams P{a->max_depth, a->hide_emitters, a->samplers[1].seed, a->samplers[1].skip, nullptr, 0, {0, npx * T.sppe}, rank, count};
+            const long long nl = local_lanes(P.range.end, rank, count);
             if (nl > 0) {
                 if (sc->lds) LAUNCH((k_primary_edges<true, COUNT>), sc, nl, st, sc->blob.as<float4>(), T, cam, P, dout, ctr);
                 else LAUNCH((k_primary_edges<false, COUNT>), sc, nl, st, sc->blob.as<float4>(), T, cam, P, dout, ctr);
             }
         }
         if ((terms & PSDR_TERM_SECONDARY) && T.sppse > 0 && sc->E.n > 0) {
-            RenderParams P{a->max_depth, a->hide_emitters, a->samplers[2].seed, a->samplers[2].skip, nullptr, 0, shard(npx * T.sppse, a->shard_rank, a->shard_count)};
-            const long long nl = P.range.end - P.range.begin;
+            RenderParams P{a->max_depth, a->hide_emitters, a->samplers[2].seed, a->samplers[2].skip, nullptr, 0, {0, npx * T.sppse}, rank, count};
+            const long long nl = local_lanes(P.range.end, rank, count);
             GuidingDev G{};
             const int use_g = a->guiding ? 1 : 0;
             if (a->guiding) G = a->guiding->G;
