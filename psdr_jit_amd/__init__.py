@@ -341,30 +341,24 @@ def _replay_forward(integ, scene, st, tangents):
     """Re-render with the sampler state of the recorded call and the given leaf tangents."""
     _sync_params(scene, tangents)
     scene._configure(st["active"])
-    saved = [scene._sampler_state(k) for k in range(3)]
-    _, dimg = _render_d_raw(integ, scene, st["sensor_id"], st["replay_seed"], st["batch_pix"], st["terms"])
+    after = [scene._sampler_state(k) for k in range(3)]
+    for k, s in enumerate(st["samplers"]):
+        scene._set_sampler_state(k, *s)
+    _, dimg = _render_d_raw(integ, scene, st["sensor_id"], st["seed"], st["batch_pix"], st["terms"])
+    for k, s in enumerate(after):
+        scene._set_sampler_state(k, *s)
     return dimg
 
 
 def _renderD(self, scene, sensor_id=0, seed=-1, batch_pix=-1, terms=TERM_ALL):
     """Integrator.renderD (reference integrator.cpp:51-100).  Returns the image as a tensor attached
     to the autograd graph of the scene's torch parameters."""
-    if seed == -1:
-        # make the call replayable: fix the seeds it would have used
-        seed_used = None
     leaves = _leaves(scene)
     state = {"integrator": self, "scene": scene, "sensor_id": sensor_id, "batch_pix": batch_pix, "terms": terms,
-             "active": scene.__dict__.get("_psdr_active", []), "leaves": leaves, "seed": seed}
-    # replay needs a deterministic sampler: remember the seed if given, else derive one from the scene seed + skip
-    if seed == -1:
-        _, _, s0, k0 = scene._sampler_state(0)
-        state["replay_seed"] = int((s0 * 1000003 + k0 + 12345) % (2 ** 31 - 1))
-        seed = state["replay_seed"]
-    else:
-        state["replay_seed"] = seed
+             "active": scene.__dict__.get("_psdr_active", []), "leaves": leaves, "seed": seed,
+             "samplers": [scene._sampler_state(k) for k in range(3)]}      # the streams this call starts from
     img, dimg = _render_d_raw(self, scene, sensor_id, seed, batch_pix, terms)
     state["img"] = img
-    state["dimg0"] = dimg
     tens = [t for (_, _, t) in leaves]
     if any(t.requires_grad for t in tens):
         return _RenderDFn.apply(state, *tens)

@@ -169,6 +169,9 @@ PYBIND11_MODULE(_psdr_core, m) {
             for (auto &kv : s.m_param_map) d[py::str(kv.first)] = py::cast(kv.second, py::return_value_policy::reference_internal, self);
             return d; }, "Parameter map")
         .def("_sampler_state", [](const Scene &s, int k) { return py::make_tuple(s.m_samplers[k].ready, s.m_samplers[k].sample_count, s.m_samplers[k].seed, s.m_samplers[k].skip); })
+        .def("_set_sampler_state", [](Scene &s, int k, bool ready, int64_t count, uint64_t seed, uint64_t skip) {
+            if (k < 0 || k > 2) throw Exception("sampler index");
+            s.m_samplers[k] = SamplerState{ready, count, seed, skip}; })
         .def("_bvh_stats", [](const Scene &s) {
             int32_t n = 0, l = 0, d = 0, b = 0;
             if (!s.m_hip || psdr_hip_scene_stats(s.m_hip, &n, &l, &d, &b)) throw Exception("scene not configured");
