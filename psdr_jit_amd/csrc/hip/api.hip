@@ -19,6 +19,7 @@
 #include "../../../include/psdr_hip.h"
 #include "bvh.h"
 #include "edges.h"
+#include "paths.h"
 
 using namespace psdr;
 
@@ -50,7 +51,7 @@ PSDR_DEV SceneView<LDS> make_view(const float4 *blob, const SceneTables &T, floa
         B = smem;
     }
     SceneView<LDS> S;
-    S.B = B; S.T = &T;
+    S.B = B; S.G = blob; S.T = &T;
     S.stack = reinterpret_cast<int *>(smem + (LDS ? T.blob_words : 0)) + threadIdx.x;
     S.c_nodes = S.c_tris = S.c_rays = S.c_hits = 0u;
     return S;
@@ -78,89 +79,13 @@ PSDR_DEV float seg_scan(float v, int key, int lane_id) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// interior term: Integrator::__render / __render_batch, reference integrator.cpp:103-176
-template <bool AD, bool LDS, bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_interior(const float4 *__restrict__ blob, const SceneTables T, const SensorDev cam,
-                                                     const RenderParams P, float *__restrict__ out, float *__restrict__ dout,
-                                                     float *__restrict__ lanes_out, Counters *ctr) {
+// interior term (MODE 0) and primary-edge term (MODE 1): persistent lanes with path regeneration, paths.h
+template <bool AD, bool LDS, bool COUNT, int MODE>
+__global__ __launch_bounds__(kBlock) void k_paths(const float4 *__restrict__ blob, const SceneTables T, const SensorDev cam,
+                                                  const PathParams P, Counters *ctr) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     SceneView<LDS> S = make_view<LDS>(blob, T, smem);
-    const int lane_id = threadIdx.x & 63;
-    const long long n = P.range.end - P.range.begin;
-    const long long n_chunks = (n + kBlock - 1) / kBlock;
-    const float inv_spp = T.spp > 1 ? 1.f / (float) T.spp : 1.f;
-    for (long long lc = blockIdx.x;; lc += gridDim.x) {
-        const long long chunk = lc * P.shard_count + P.shard_rank;
-        if (chunk >= n_chunks) break;
-        const long long lane = P.range.begin + chunk * kBlock + threadIdx.x;
-        const bool in_range = lane < P.range.end;
-        int pix_slot = -1;                 // row of the output image this lane adds to
-        float val[3] = {0.f, 0.f, 0.f}, dval[3] = {0.f, 0.f, 0.f};
-        if (in_range) {
-            const long long k = T.spp > 1 ? lane / T.spp : lane;
-            const int pix = P.pix_ids ? P.pix_ids[k] : (int) k;
-            pix_slot = (int) k;
-            LaneRng rng;
-            rng.seed(P.seed + (P.pix_ids ? (unsigned long long) (long long) pix : (unsigned long long) lane), (unsigned long long) lane, P.skip);
-            const float bx = (float) (pix % T.width), by = (float) (pix / T.width);
-            const float jx = rng.next_1d(), jy = rng.next_1d();
-            const float sx = (bx + jx) / (float) T.width, sy = (by + jy) / (float) T.height;
-            const RayT<AD> ray = sample_primary_ray<AD>(cam, sx, sy);
-            const VecN<AD> L = Li<AD, LDS, COUNT>(S, rng, ray, true, P.max_depth, P.hide_emitters != 0);
-            const float pv[3] = {detach(L.x), detach(L.y), detach(L.z)};
-            const float tv[3] = {tangent(L.x), tangent(L.y), tangent(L.z)};
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {                 // NaN/Inf scrub, integrator.cpp:126
-                const bool okp = finite_(pv[c]);
-                val[c] = okp ? pv[c] : 0.f;
-                dval[c] = (okp && finite_(tv[c])) ? tv[c] : 0.f;
-            }
-            if (lanes_out) {
-                const long long o = 3 * (lane - P.range.begin);
-                lanes_out[o] = pv[0]; lanes_out[o + 1] = pv[1]; lanes_out[o + 2] = pv[2];
-            }
-        }
-        if (out) {
-            const int next_key = __shfl_down(pix_slot, 1);
-            const bool seg_end = (lane_id == 63) || (next_key != pix_slot);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float s = seg_scan(val[c], pix_slot, lane_id);
-                if (seg_end && pix_slot >= 0) atomicAdd(&out[3 * (long long) pix_slot + c], s * inv_spp);
-                if (AD) {
-                    const float ds = seg_scan(dval[c], pix_slot, lane_id);
-                    if (seg_end && pix_slot >= 0) atomicAdd(&dout[3 * (long long) pix_slot + c], ds * inv_spp);
-                }
-            }
-        }
-    }
-    if (COUNT) flush_counters(S, ctr);
-}
-
-// primary-edge term, reference integrator.cpp:179-198
-template <bool LDS, bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_primary_edges(const float4 *__restrict__ blob, const SceneTables T, const SensorDev cam,
-                                                          const RenderParams P, float *__restrict__ dout, Counters *ctr) {
-    extern __shared__ __attribute__((aligned(16))) float4 smem[];
-    SceneView<LDS> S = make_view<LDS>(blob, T, smem);
-    const long long n = P.range.end - P.range.begin;
-    const long long n_chunks = (n + kBlock - 1) / kBlock;
-    for (long long lc = blockIdx.x;; lc += gridDim.x) {
-        const long long chunk = lc * P.shard_count + P.shard_rank;
-        if (chunk >= n_chunks) break;
-        const long long lane = P.range.begin + chunk * kBlock + threadIdx.x;
-        if (lane < P.range.end) {
-            LaneRng rng;
-            rng.seed(P.seed + (unsigned long long) lane, (unsigned long long) lane, P.skip);
-            Vec3f dv;
-            const int idx = primary_edge_lane<LDS, COUNT>(S, cam, rng, P.max_depth, P.hide_emitters != 0, T.sppe, dv);
-            if (idx >= 0) {
-                if (dv.x != 0.f) atomicAdd(&dout[3 * (long long) idx], dv.x);
-                if (dv.y != 0.f) atomicAdd(&dout[3 * (long long) idx + 1], dv.y);
-                if (dv.z != 0.f) atomicAdd(&dout[3 * (long long) idx + 2], dv.z);
-            }
-        }
-    }
+    run_paths<AD, LDS, COUNT, MODE>(S, cam, P);
     if (COUNT) flush_counters(S, ctr);
 }
 
@@ -183,36 +108,69 @@ PSDR_DEV float guiding_sample_reuse(const GuidingDev &G, Vec3f &s) {
     return pdf * (float) G.num_cells;
 }
 
-// secondary-edge term, reference path.cpp:274-294
+// secondary-edge term, reference path.cpp:274-294.
+// Only ~1 in 6 boundary-segment samples of the README scene passes the cheap validity test of
+// sample_boundary_segment_direct (silhouette condition + light facing), and only those trace rays.  Each lane
+// therefore keeps drawing candidates (RNG seed + three draws + the validity test, no ray) until the wave holds
+// enough valid ones, and the traced part (3 rays) runs with nearly all lanes active (stage r01a: 17 %).
 template <bool LDS, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_secondary_edges(const float4 *__restrict__ blob, const SceneTables T, const SecEdgeTables E,
-                                                            const SensorDev cam, const RenderParams P, const GuidingDev G, const int use_guiding,
-                                                            float *__restrict__ dout, Counters *ctr) {
+                                                            const SensorDev cam, const PathParams P, const GuidingDev G, const int use_guiding,
+                                                            Counters *ctr) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     SceneView<LDS> S = make_view<LDS>(blob, T, smem);
-    const long long n = P.range.end - P.range.begin;
-    const long long n_chunks = (n + kBlock - 1) / kBlock;
-    for (long long lc = blockIdx.x;; lc += gridDim.x) {
-        const long long chunk = lc * P.shard_count + P.shard_rank;
-        if (chunk >= n_chunks) break;
-        const long long lane = P.range.begin + chunk * kBlock + threadIdx.x;
-        if (lane < P.range.end) {
-            LaneRng rng;
-            rng.seed(P.seed + (unsigned long long) lane, (unsigned long long) lane, P.skip);
-            Vec3f s3;
-            s3.x = rng.next_1d(); s3.y = rng.next_1d(); s3.z = rng.next_1d();
-            const float pdf0 = use_guiding ? guiding_sample_reuse(G, s3) : 1.f;
+    const int lane_id = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane_id) - 1ull;
+    long long q_next = 0, q_end = 0;
+    bool exhausted = false;
+    bool have = false;
+    BoundarySegSampleDirect bss;
+    bss.valid = false;
+    float pdf0 = 1.f;
+    for (;;) {
+        for (int round = 0; round < 16; ++round) {
+            const unsigned long long need = __ballot(!have);
+            if (__popcll(need) <= 6) break;
+            if (q_next >= q_end && !exhausted) {
+                unsigned long long base = 0;
+                if (lane_id == 0) base = atomicAdd(P.counter, (unsigned long long) kFetchBatch);
+                base = __shfl(base, 0);
+                if ((long long) base >= P.n_local) exhausted = true;
+                else { q_next = (long long) base; q_end = q_next + kFetchBatch < P.n_local ? q_next + kFetchBatch : P.n_local; }
+            }
+            if (q_next >= q_end) break;
+            const int rank = __popcll(need & lt_mask);
+            const long long item = q_next + rank;
+            if (!have && item < q_end) {
+                const long long chunk = (item >> 8) * P.shard_count + P.shard_rank;
+                const long long lane = P.begin + (chunk << 8) + (item & 255);
+                if (lane < P.end) {
+                    LaneRng rng;
+                    rng.seed(P.seed + (unsigned long long) lane, (unsigned long long) lane, P.skip);
+                    Vec3f s3;
+                    s3.x = rng.next_1d(); s3.y = rng.next_1d(); s3.z = rng.next_1d();
+                    pdf0 = use_guiding ? guiding_sample_reuse(G, s3) : 1.f;
+                    bss = sample_boundary_segment_direct<LDS>(S, E, s3);
+                    have = bss.valid;
+                }
+            }
+            const int n_need = __popcll(need);
+            q_next += n_need < (int) (q_end - q_next) ? n_need : (q_end - q_next);
+        }
+        if (__ballot(have) == 0ull) { if (exhausted && q_next >= q_end) break; continue; }
+        if (have) {
             Vec3f v;
-            const int idx = eval_secondary_edge<true, LDS, COUNT>(S, E, cam, s3, v);
+            const int idx = eval_boundary_segment<true, LDS, COUNT>(S, cam, bss, v);
             if (idx >= 0) {
                 float o[3] = {v.x, v.y, v.z};
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     if (pdf0 > kEpsilon) o[c] /= pdf0;
                     if (T.sppse > 1) o[c] /= (float) T.sppse;
-                    if (finite_(o[c]) && o[c] != 0.f) atomicAdd(&dout[3 * (long long) idx + c], o[c]);
+                    if (finite_(o[c]) && o[c] != 0.f) atomicAdd(&P.dout[3 * (long long) idx + c], o[c]);
                 }
             }
+            have = false;
         }
     }
     if (COUNT) flush_counters(S, ctr);
@@ -289,6 +247,8 @@ struct DevBuf {
     template <typename T> const T *as() const { return reinterpret_cast<const T *>(p); }
 };
 
+constexpr unsigned kQueueRing = 1024;
+
 struct psdr_hip_scene {
     SceneTables T{};
     DevBuf blob;
@@ -298,6 +258,8 @@ struct psdr_hip_scene {
     std::vector<std::unique_ptr<DevBuf>> bufs;
     std::vector<SensorDev> sensors;
     DevBuf counters;
+    DevBuf queues;                       // ring of work-queue heads, one per path-kernel launch
+    mutable unsigned queue_slot = 0;
     int n_leaves = 0, max_depth = 0, grid = 0;
     const float *up(const float *src, size_t n, int &rc) {
         if (!src) return nullptr;
@@ -458,6 +420,7 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     }
     if (rc) return 1;
     if (sc->counters.upload(nullptr, sizeof(Counters))) return 1;
+    if (sc->queues.upload(nullptr, sizeof(unsigned long long) * kQueueRing)) return 1;
 
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount; }
@@ -521,38 +484,53 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
     const int rank = count > 1 ? a->shard_rank : 0;
     if (rank < 0 || rank >= count) return fail("bad shard rank");
 
+    auto next_queue = [&](unsigned long long *&q) -> int {
+        q = (unsigned long long *) sc->queues.p + (sc->queue_slot++ % kQueueRing);
+        HIPCHK(hipMemsetAsync(q, 0, sizeof(unsigned long long), st));
+        return 0;
+    };
     if ((terms & PSDR_TERM_INTERIOR) && T.spp > 0) {
-        RenderParams P{a->max_depth, a->hide_emitters, a->samplers[0].seed, a->samplers[0].skip, a->pix_ids, a->n_pix, {0, npx * T.spp}, rank, count};
-        if (lanes_out) { P.range = LaneRange{lane_b, lane_e}; P.shard_rank = 0; P.shard_count = 1; }
-        const long long nl = local_lanes(P.range.end - P.range.begin, P.shard_rank, P.shard_count);
-        if (nl > 0) {
+        PathParams P{};
+        P.max_depth = a->max_depth; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[0].seed; P.skip = a->samplers[0].skip;
+        P.pix_ids = a->pix_ids; P.begin = 0; P.end = npx * T.spp; P.shard_rank = rank; P.shard_count = count;
+        P.out = out; P.dout = dout; P.lanes_out = lanes_out;
+        if (lanes_out) { P.begin = lane_b; P.end = lane_e; P.shard_rank = 0; P.shard_count = 1; }
+        P.n_local = local_lanes(P.end - P.begin, P.shard_rank, P.shard_count);
+        if (P.n_local > 0) {
+            if (next_queue(P.counter)) return 1;
             if (ad) {
-                if (sc->lds) LAUNCH((k_interior<true, true, COUNT>), sc, nl, st, sc->blob.as<float4>(), T, cam, P, out, dout, lanes_out, ctr);
-                else LAUNCH((k_interior<true, false, COUNT>), sc, nl, st, sc->blob.as<float4>(), T, cam, P, out, dout, lanes_out, ctr);
+                if (sc->lds) LAUNCH((k_paths<true, true, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
+                else LAUNCH((k_paths<true, false, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
             } else {
-                if (sc->lds) LAUNCH((k_interior<false, true, COUNT>), sc, nl, st, sc->blob.as<float4>(), T, cam, P, out, dout, lanes_out, ctr);
-                else LAUNCH((k_interior<false, false, COUNT>), sc, nl, st, sc->blob.as<float4>(), T, cam, P, out, dout, lanes_out, ctr);
+                if (sc->lds) LAUNCH((k_paths<false, true, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
+                else LAUNCH((k_paths<false, false, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
             }
         }
     }
     if (ad && !a->pix_ids && !lanes_out) {
         if ((terms & PSDR_TERM_PRIMARY) && T.sppe > 0 && cam.n_edges > 0) {
-            RenderParams P{a->max_depth, a->hide_emitters, a->samplers[1].seed, a->samplers[1].skip, nullptr, 0, {0, npx * T.sppe}, rank, count};
-            const long long nl = local_lanes(P.range.end, rank, count);
-            if (nl > 0) {
-                if (sc->lds) LAUNCH((k_primary_edges<true, COUNT>), sc, nl, st, sc->blob.as<float4>(), T, cam, P, dout, ctr);
-                else LAUNCH((k_primary_edges<false, COUNT>), sc, nl, st, sc->blob.as<float4>(), T, cam, P, dout, ctr);
+            PathParams P{};
+            P.max_depth = a->max_depth; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[1].seed; P.skip = a->samplers[1].skip;
+            P.begin = 0; P.end = npx * T.sppe; P.shard_rank = rank; P.shard_count = count; P.dout = dout;
+            P.n_local = local_lanes(P.end, rank, count);
+            if (P.n_local > 0) {
+                if (next_queue(P.counter)) return 1;
+                if (sc->lds) LAUNCH((k_paths<false, true, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
+                else LAUNCH((k_paths<false, false, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
             }
         }
         if ((terms & PSDR_TERM_SECONDARY) && T.sppse > 0 && sc->E.n > 0) {
-            RenderParams P{a->max_depth, a->hide_emitters, a->samplers[2].seed, a->samplers[2].skip, nullptr, 0, {0, npx * T.sppse}, rank, count};
-            const long long nl = local_lanes(P.range.end, rank, count);
+            PathParams P{};
+            P.max_depth = a->max_depth; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[2].seed; P.skip = a->samplers[2].skip;
+            P.begin = 0; P.end = npx * T.sppse; P.shard_rank = rank; P.shard_count = count; P.dout = dout;
+            P.n_local = local_lanes(P.end, rank, count);
             GuidingDev G{};
             const int use_g = a->guiding ? 1 : 0;
             if (a->guiding) G = a->guiding->G;
-            if (nl > 0) {
-                if (sc->lds) LAUNCH((k_secondary_edges<true, COUNT>), sc, nl, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, dout, ctr);
-                else LAUNCH((k_secondary_edges<false, COUNT>), sc, nl, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, dout, ctr);
+            if (P.n_local > 0) {
+                if (next_queue(P.counter)) return 1;
+                if (sc->lds) LAUNCH((k_secondary_edges<true, COUNT>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr);
+                else LAUNCH((k_secondary_edges<false, COUNT>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr);
             }
         }
     }

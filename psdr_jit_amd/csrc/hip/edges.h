@@ -116,11 +116,21 @@ template <bool LDS> PSDR_DEV BoundarySegSampleDirect sample_boundary_segment_dir
 // AD=true : returns the pixel index (or -1) and the tangent of the estimator in `value`.
 // AD=false: guiding pass, `value` = value0 without the normal velocity (path.cpp:267-268), returns -1.
 template <bool AD, bool LDS, bool COUNT>
+PSDR_DEV int eval_boundary_segment(SceneView<LDS> &S, const SensorDev &cam, const BoundarySegSampleDirect &bss, Vec3f &value);
+
+template <bool AD, bool LDS, bool COUNT>
 PSDR_DEV int eval_secondary_edge(SceneView<LDS> &S, const SecEdgeTables &E, const SensorDev &cam, const Vec3f &s3, Vec3f &value) {
     value = Vec3f(0.f);
-    const SceneTables &T = *S.T;
     const BoundarySegSampleDirect bss = sample_boundary_segment_direct<LDS>(S, E, s3);
     if (!bss.valid) return -1;
+    return eval_boundary_segment<AD, LDS, COUNT>(S, cam, bss, value);
+}
+
+// the traced part of eval_secondary_edge (path.cpp:176-270) for an already sampled, valid boundary segment
+template <bool AD, bool LDS, bool COUNT>
+PSDR_DEV int eval_boundary_segment(SceneView<LDS> &S, const SensorDev &cam, const BoundarySegSampleDirect &bss, Vec3f &value) {
+    value = Vec3f(0.f);
+    const SceneTables &T = *S.T;
     const Vec3f _p0 = detach(bss.p0), _p2 = bss.p2, _dir = normalize(_p2 - _p0);
 
     RayT<false> r2; r2.o = _p0; r2.d = _dir;

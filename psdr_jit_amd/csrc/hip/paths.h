@@ -1,0 +1,258 @@
+// paths.h — persistent-lane path tracer with wave-level path regeneration.
+//
+// Stage r01a ran one lane = one sample from start to finish; the PMC pass showed only 33-50 % of the
+// lanes active per VALU instruction because paths end at different depths (70 % of the camera rays of
+// the README scene miss the box) and BVH walks differ in length.  Here every lane of a wave64 is a
+// persistent worker: each loop iteration performs, for all lanes together,
+//     [A] one shadow-ray trace (next-event estimation of the lane's current vertex) and
+//     [B] one extension-ray trace (the camera ray of a freshly fetched sample, or the BSDF-sampled ray),
+// and a lane whose path has ended fetches the next sample index before the next iteration
+// (wave-aggregated: one atomicAdd per 256 samples, handed out with ballot/popcount prefix ranks).
+// The per-lane arithmetic is exactly PathTracer::__Li (reference src/integrator/path.cpp:35-127) as in
+// shade.h::Li — only the order in which samples are executed changes, so results are unchanged.
+//
+// MODE 0: interior term (Integrator::__render / __render_batch, reference integrator.cpp:103-176)
+// MODE 1: primary-edge term (Integrator::render_primary_edges, integrator.cpp:179-198): one work item =
+//         one edge sample = two consecutive paths (ray_n then ray_p) sharing the lane's RNG stream.
+#pragma once
+#include "edges.h"
+
+namespace psdr {
+
+struct PathParams {
+    int max_depth, hide_emitters;
+    unsigned long long seed, skip;
+    const int *pix_ids;
+    long long begin, end;            // lane range of the sampler
+    int shard_rank, shard_count;     // 256-lane chunks k with k % count == rank
+    long long n_local;               // number of local work items (multiple of 256)
+    unsigned long long *counter;     // work queue head (zeroed before launch)
+    float *out, *dout, *lanes_out;
+};
+
+constexpr int kFetchBatch = 256;
+
+template <bool AD, bool LDS, bool COUNT, int MODE>
+PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParams &P) {
+    using R = Num<AD>; using V = VecN<AD>;
+    const SceneTables &T = *S.T;
+    const int lane_id = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane_id) - 1ull;
+    const float inv_spp = T.spp > 1 ? 1.f / (float) T.spp : 1.f;
+
+    // wave-uniform local queue
+    long long q_next = 0, q_end = 0;
+    bool exhausted = false;
+
+    // per-lane path state
+    bool busy = false;
+    int depth = -1;                       // -1: the extension ray is a camera ray
+    LaneRng rng; rng.state = 0; rng.inc = 1;
+    Its<AD> its;                          // current vertex (valid when depth >= 0)
+    its.valid = false; its.slot = -1; its.mesh = -1;
+    V thr(R(1.f)), res(R(0.f));
+    RayT<AD> ext;                         // pending extension ray
+    long long lane = 0;                   // sample index of the current work item
+    int pix_slot = -1;
+    // MODE 1 extras
+    int side = 0;
+    Vec3f Ln(0.f), dir_p(0.f);
+    float edge_xdn_v = 0.f, edge_xdn_d = 0.f, edge_pdf = 1.f;
+    bool edge_valid = false;
+    static_assert(MODE == 0 || !AD, "the primary-edge paths are traced in C mode");
+
+    for (;;) {
+        // ------------------------------------------------------------------ fetch work for idle lanes
+        if (q_next >= q_end && !exhausted) {
+            unsigned long long base = 0;
+            if (lane_id == 0) base = atomicAdd(P.counter, (unsigned long long) kFetchBatch);
+            base = __shfl(base, 0);
+            if ((long long) base >= P.n_local) exhausted = true;
+            else { q_next = (long long) base; q_end = q_next + kFetchBatch < P.n_local ? q_next + kFetchBatch : P.n_local; }
+        }
+        const unsigned long long need = __ballot(!busy);
+        if (need != 0ull && q_next < q_end) {
+            const int rank = __popcll(need & lt_mask);
+            const long long item = q_next + rank;
+            const int n_need = __popcll(need);
+            if (!busy && item < q_end) {
+                const long long chunk = (item >> 8) * P.shard_count + P.shard_rank;
+                lane = P.begin + (chunk << 8) + (item & 255);
+                if (lane < P.end) {
+                    busy = true; depth = -1; thr = V(R(1.f)); res = V(R(0.f));
+                    if (MODE == 0) {
+                        const long long k = T.spp > 1 ? lane / T.spp : lane;
+                        const int pix = P.pix_ids ? P.pix_ids[k] : (int) k;
+                        pix_slot = (int) k;
+                        rng.seed(P.seed + (P.pix_ids ? (unsigned long long) (long long) pix : (unsigned long long) lane), (unsigned long long) lane, P.skip);
+                        const float bx = (float) (pix % T.width), by = (float) (pix / T.width);
+                        const float jx = rng.next_1d(), jy = rng.next_1d();
+                        ext = sample_primary_ray<AD>(cam, (bx + jx) / (float) T.width, (by + jy) / (float) T.height);
+                    } else {
+                        // PerspectiveCamera::sample_primary_edge, reference perspective.cpp:200-226
+                        rng.seed(P.seed + (unsigned long long) lane, (unsigned long long) lane, P.skip);
+                        float s = rng.next_1d(), pdf;
+                        const int ei = sample_reuse(cam.n_edges, cam.edge_sum, [&](int i) { return cam.edge_pmf[i]; }, [&](int i) { return cam.edge_cmf[i]; }, s, pdf);
+                        pdf /= cam.edge_length[ei];
+                        const float nx = cam.edge_normal[2 * ei], ny = cam.edge_normal[2 * ei + 1];
+                        const float oms = 1.0f - s;
+                        const Dual p0x(cam.edge_p0[2 * ei], cam.d_edge_p0[2 * ei]), p0y(cam.edge_p0[2 * ei + 1], cam.d_edge_p0[2 * ei + 1]);
+                        const Dual p1x(cam.edge_p1[2 * ei], cam.d_edge_p1[2 * ei]), p1y(cam.edge_p1[2 * ei + 1], cam.d_edge_p1[2 * ei + 1]);
+                        const Dual px = fma_(p0x, oms, p1x * s), py = fma_(p0y, oms, p1y * s);
+                        const Dual x_dot_n = fma_(py, ny, px * nx);
+                        const int ix = (int) floorf(px.v * (float) T.width), iy = (int) floorf(py.v * (float) T.height);
+                        edge_valid = ix >= 0 && ix < T.width && iy >= 0 && iy < T.height;
+                        pix_slot = edge_valid ? iy * T.width + ix : -1;
+                        const RayT<false> ray_p = sample_primary_ray<false>(cam, px.v + kEdgeEpsilon * nx, py.v + kEdgeEpsilon * ny);
+                        const RayT<false> ray_n = sample_primary_ray<false>(cam, px.v - kEdgeEpsilon * nx, py.v - kEdgeEpsilon * ny);
+                        dir_p = ray_p.d;
+                        if constexpr (!AD) ext = ray_n;
+                        side = 0;
+                        edge_xdn_v = x_dot_n.v; edge_xdn_d = x_dot_n.d; edge_pdf = pdf;
+                        if (!edge_valid) busy = false;       // Li(..., valid=false) contributes nothing
+                    }
+                }
+            }
+            q_next += n_need < (int) (q_end - q_next) ? n_need : (q_end - q_next);
+        }
+        if (__ballot(busy) == 0ull) { if (exhausted && q_next >= q_end) break; continue; }
+
+        // ------------------------------------------------------------------ [A] next-event estimation (path.cpp:47-83)
+        const bool at_vertex = busy && depth >= 0;
+        bool do_nee = false;
+        PositionSample<AD> ps;
+        V wod(R(0.f)); R dist_sqr(0.f), dist(0.f);
+        RayT<AD> ray1; ray1.o = V(R(0.f)); ray1.d = V(R(0.f));
+        if (at_vertex) {
+            const float sx = rng.next_1d(), sy = rng.next_1d();
+            do_nee = mesh_emitter(S, its.mesh) < 0;
+            if (do_nee) {
+                ps = sample_emitter_position<AD, LDS>(S, sx, sy);
+                wod = ps.p - its.p;
+                dist_sqr = squared_norm(wod);
+                dist = safe_sqrt(dist_sqr);
+                wod = wod / dist;
+                ray1.o = its.p; ray1.d = wod;
+            }
+        }
+        {
+            Hit h; h.slot = -1; h.u = h.v = h.t = 0.f;
+            if (do_nee) h = trace<LDS, COUNT>(S, detach(ray1.o), detach(ray1.d));
+            if (do_nee && h.slot >= 0) {
+                if (COUNT) S.c_hits++;
+                const Its<AD> its1 = make_its<AD, LDS, false>(S, h, ray1, true);
+                if ((detach(its1.t) > detach(dist) - kShadowEpsilon) && (mesh_emitter(S, its1.mesh) >= 0)) {
+                    const R cos_val = dot(its1.n, -wod);
+                    const R G_val = abs_(cos_val) / dist_sqr;
+                    const V emitter_val = eval_Le<AD, LDS>(S, its1, true);
+                    const V wo_local = to_local<AD>(its, wod);
+                    V bsdf_val2 = bsdf_eval<AD, LDS>(S, its, wo_local, true);
+                    bsdf_val2 = bsdf_val2 * (G_val * ps.J / R(ps.pdf));
+                    const float pdf1 = bsdf_pdf<AD, LDS>(S, its, wo_local, true) * detach(G_val);
+                    if (pdf1 != 0.f) res = res + thr * emitter_val * bsdf_val2 * R(mis_weight(ps.pdf, pdf1));
+                }
+            }
+        }
+
+        // ------------------------------------------------------------------ [B] extension ray
+        BSDFSample bs; bs.wo = Vec3f(0.f, 0.f, 1.f); bs.pdf = 1.f; bs.valid = true;
+        if (at_vertex) {
+            const float s0 = rng.next_1d(), s1 = rng.next_1d(), s2 = rng.next_1d();
+            (void) s0;
+            bs = bsdf_sample<AD, LDS>(S, its, s1, s2, true);
+            ext.o = its.p; ext.d = to_world<AD>(its, bs.wo);
+        }
+        Hit hx; hx.slot = -1; hx.u = hx.v = hx.t = 0.f;
+        if (busy) hx = trace<LDS, COUNT>(S, detach(ext.o), detach(ext.d));
+        bool finished = false;
+        if (busy) {
+            if (COUNT) { if (hx.slot >= 0) S.c_hits++; }
+            const Its<AD> itx = make_its<AD, LDS, true>(S, hx, ext, depth >= 0);
+            if (depth < 0) {
+                // first hit: result = Le (path.cpp:38-43)
+                its = itx;
+                if (!P.hide_emitters) res = eval_Le<AD, LDS>(S, itx, itx.valid);
+                depth = 0;
+                finished = !itx.valid || P.max_depth == 0;
+            } else {
+                // BSDF-sampled vertex (path.cpp:86-123)
+                if (bs.valid && itx.valid) {
+                    V bsdf_val;
+                    float pdf0;
+                    if constexpr (AD) {
+                        V wo = (itx.p - its.p) / itx.t;
+                        const R cos_val = dot(itx.n, -wo);
+                        const R G_val = abs_(cos_val) / sqr(itx.t);
+                        pdf0 = bs.pdf * G_val.v;
+                        if (itx.t.v < kEpsilon) bsdf_val = V(R(0.f));
+                        else bsdf_val = bsdf_eval<AD, LDS>(S, its, to_local<AD>(its, wo), true) * G_val * itx.J / R(pdf0);
+                    } else {
+                        const float cos_val = dot(itx.n, -ext.d);
+                        const float G_val = fabsf(cos_val) / sqr(itx.t);
+                        pdf0 = bs.pdf * G_val;
+                        if (itx.t < kEpsilon) bsdf_val = V(0.f);
+                        else bsdf_val = bsdf_eval<AD, LDS>(S, its, bs.wo, true) / bs.pdf;
+                    }
+                    const float weight2 = mis_weight(pdf0, emitter_position_pdf<AD, LDS>(S, itx));
+                    thr = thr * bsdf_val;
+                    res = res + eval_Le<AD, LDS>(S, itx, true) * thr * R(weight2);
+                    its = itx;
+                    depth += 1;
+                    finished = depth >= P.max_depth;
+                } else {
+                    depth += 1;
+                    finished = true;
+                }
+            }
+        }
+
+        // ------------------------------------------------------------------ path end: accumulate, or start the second edge path
+        if (busy && finished) {
+            if (MODE == 0) {
+                const float pv[3] = {detach(res.x), detach(res.y), detach(res.z)};
+                const float tv[3] = {tangent(res.x), tangent(res.y), tangent(res.z)};
+                if (P.lanes_out) {
+                    const long long o = 3 * (lane - P.begin);
+                    P.lanes_out[o] = pv[0]; P.lanes_out[o + 1] = pv[1]; P.lanes_out[o + 2] = pv[2];
+                }
+                if (P.out) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {             // NaN/Inf scrub, integrator.cpp:126
+                        const bool okp = finite_(pv[c]);
+                        const float v = okp ? pv[c] : 0.f;
+                        if (v != 0.f) atomicAdd(&P.out[3 * (long long) pix_slot + c], v * inv_spp);
+                        if (AD) {
+                            const float d = (okp && finite_(tv[c])) ? tv[c] : 0.f;
+                            if (d != 0.f) atomicAdd(&P.dout[3 * (long long) pix_slot + c], d * inv_spp);
+                        }
+                    }
+                }
+                busy = false;
+            } else {
+                if (side == 0) {
+                    Ln = detach(res);
+                    // the reference's Li always draws 5 numbers per depth level; skip what this path left
+                    if (depth < P.max_depth) rng.advance((unsigned long long) (5 * (P.max_depth - depth)));
+                    side = 1; depth = -1; thr = V(R(1.f)); res = V(R(0.f));
+                    if constexpr (!AD) { ext.o = xform_pos(cam.to_world, Vec3f(0.f)); ext.d = dir_p; }
+                } else {
+                    // value = x_dot_n * (Ln - Lp) / pdf, scrub, / sppe; only the tangent survives (integrator.cpp:187-192)
+                    const Vec3f Lp = detach(res);
+                    const Vec3f dL = (Ln - Lp) / edge_pdf;
+                    const float o3[3] = {dL.x, dL.y, dL.z};
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float pv = edge_xdn_v * o3[c];
+                        float dv = edge_xdn_d * o3[c];
+                        if (!finite_(pv) || !finite_(dv)) dv = 0.f;
+                        if (T.sppe > 1) dv /= (float) T.sppe;
+                        if (dv != 0.f) atomicAdd(&P.dout[3 * (long long) pix_slot + c], dv);
+                    }
+                    busy = false;
+                }
+            }
+        }
+    }
+}
+
+} // namespace psdr

@@ -16,6 +16,7 @@ constexpr float kEpsilon = 1e-5f, kRayEpsilon = 1e-3f, kShadowEpsilon = 1e-3f, k
 constexpr float kPi = 3.14159265358979323846f, kInvPi = 0.31830988618379067154f;
 constexpr float kTraceTMax = 100000000.f;   // reference scene_optix.cpp:376
 constexpr int kBlock = 256;
+constexpr int kBruteForceMax = 64;          // scenes with at most this many triangles skip the BVH
 
 struct SceneTables {
     // float4-word offsets into the blob
@@ -48,6 +49,7 @@ struct Counters { unsigned long long rays, nodes, tris, hits; };
 // per-lane view used by every device function
 template <bool LDS> struct SceneView {
     const float4 *B;           // blob base (LDS or global)
+    const float4 *G;           // blob base in global memory (wave-uniform reads become scalar loads)
     const SceneTables *T;      // kernel-argument copy
     int *stack;                // this lane's LDS traversal stack, stride kBlock
     unsigned int c_nodes, c_tris, c_rays, c_hits;   // instrumented build only
@@ -82,12 +84,38 @@ PSDR_DEV Hit trace(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
     const SceneTables &T = *S.T;
     float best_t = __builtin_inff();
     int best_id = 0x7fffffff;
+    if (T.n_tris <= kBruteForceMax) {
+        // Tiny scenes (README Cornell box: 36 triangles): test every triangle.  The loop is wave-uniform, the
+        // triangle words are read with scalar loads into SGPRs, there is no stack, no LDS traffic and no
+        // divergence - for incoherent rays this beats any per-lane tree walk on a 64-wide SIMD machine.
+        // Same tri_test, same (t, id) order => same hit as the BVH path.
+        if (COUNT) { S.c_rays++; S.c_tris += (unsigned) T.n_tris; }
+        const float4 *tri = S.G + T.trav_off;
+        // software-pipelined: the scalar loads of triangle k+1 are issued before triangle k is tested
+        float4 a = tri[0], b = tri[1], c = tri[2];
+        for (int k = 0; k < T.n_tris; ++k) {
+            const int kn = (k + 1 < T.n_tris) ? k + 1 : k;
+            const float4 na = tri[3 * kn], nb = tri[3 * kn + 1], nc = tri[3 * kn + 2];
+            float u, v, t;
+            if (tri_test(a, b, c, o, d, u, v, t)) {
+                const int id = __float_as_int(c.y);
+                if (t < best_t || (t == best_t && id < best_id)) { best_t = t; best_id = id; best.slot = k; best.u = u; best.v = v; best.t = t; }
+            }
+            a = na; b = nb; c = nc;
+        }
+        return best;
+    }
     const float ix = 1.f / d.x, iy = 1.f / d.y, iz = 1.f / d.z;
     int sp = 0;
     int ref = 0;
+    constexpr int kDone = (int) 0x80000000;
     if (COUNT) S.c_rays++;
+    // "while-while" traversal: all lanes of the wave first walk inner nodes until each holds a leaf (or is
+    // done), then all leaves are intersected together.  Mixing both in one loop body made every iteration
+    // pay for up to four triangle tests even when a single lane was at a leaf (stage r01a: ~3900 lane
+    // instructions per ray against ~900 of useful work).
     while (true) {
-        if (ref >= 0) {
+        while (ref >= 0) {
             const int w = T.nodes_off + 4 * ref;
             const float4 q0 = S.ld(w), q1 = S.ld(w + 1), q2 = S.ld(w + 2), q3 = S.ld(w + 3);
             if (COUNT) S.c_nodes++;
@@ -106,10 +134,13 @@ PSDR_DEV Hit trace(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
                 S.stack[sp * kBlock] = left_first ? rR : rL;
                 ++sp;
                 ref = left_first ? rL : rR;
-                continue;
-            } else if (hL) { ref = rL; continue; }
-            else if (hR) { ref = rR; continue; }
-        } else {
+            } else if (hL) ref = rL;
+            else if (hR) ref = rR;
+            else if (sp == 0) ref = kDone;
+            else { --sp; ref = S.stack[sp * kBlock]; }
+        }
+        if (ref == kDone) break;
+        {
             const int code = ~ref, first = code >> 2, cnt = (code & 3) + 1;
             for (int k = 0; k < cnt; ++k) {
                 const int w = T.trav_off + 3 * (first + k);

@@ -66,23 +66,22 @@ template <typename T> PSDR_DEV void ray_tri_uvt(const Vec3<T> &p0, const Vec3<T>
     t = f * dot(e2, q);
 }
 
-// Scene::ray_intersect<ad, path_space>, reference src/scene/scene.cpp:612-806
-template <bool AD, bool PATH_SPACE, bool LDS, bool COUNT>
-PSDR_DEV Its<AD> ray_intersect(SceneView<LDS> &S, const RayT<AD> &ray, bool active) {
-    static_assert(AD || !PATH_SPACE, "path-space needs AD");
+// Scene::ray_intersect<ad, path_space> after the trace, reference src/scene/scene.cpp:621-806.
+// `path_space` is a run-time flag so that lanes at different path depths can share one instruction stream
+// (it only matters in AD mode: first camera hit = solid-angle form, later hits = material form).
+// FRAME=false skips the tangent frame (shadow rays only need n, wi.z, t, J).
+template <bool AD, bool LDS, bool FRAME>
+PSDR_DEV Its<AD> make_its(const SceneView<LDS> &S, const Hit &h, const RayT<AD> &ray, bool path_space) {
     using R = Num<AD>; using V = VecN<AD>;
     Its<AD> its;
     its.valid = false; its.slot = -1; its.mesh = -1; its.t = R(0.f); its.J = R(1.f);
-    if (!active) return its;
-    const Hit h = trace<LDS, COUNT>(S, detach(ray.o), detach(ray.d));
     if (h.slot < 0) return its;
-    if (COUNT) S.c_hits++;
     const SceneTables &T = *S.T;
     its.valid = true; its.slot = h.slot;
     V p0, e1, e2;
     load_geom<AD, LDS>(S, h.slot, p0, e1, e2);
     const int w = T.shade_off + 6 * h.slot;
-    const float4 s0 = S.ld(w), s1 = S.ld(w + 1), s2 = S.ld(w + 2), s3 = S.ld(w + 3), s4 = S.ld(w + 4), s5 = S.ld(w + 5);
+    const float4 s0 = S.ld(w), s1 = S.ld(w + 1), s2 = S.ld(w + 2), s3 = S.ld(w + 3);
     its.mesh = __float_as_int(s1.w);
     const bool flat = (__float_as_int(s2.w) & 1) != 0;
     V n0, n1, n2;
@@ -94,7 +93,7 @@ PSDR_DEV Its<AD> ray_intersect(SceneView<LDS> &S, const RayT<AD> &ray, bool acti
             n1 = make_dual(Vec3f(s1.x, s1.y, s1.z), Vec3f(td.x, td.y, td.z));
             n2 = make_dual(Vec3f(s2.x, s2.y, s2.z), Vec3f(td.w, te.x, te.y));
             its.n = make_dual(Vec3f(s3.x, s3.y, s3.z), Vec3f(te.z, te.w, tf.x));
-            if constexpr (PATH_SPACE) its.J = Dual(s0.w, tf.y) / Dual(s0.w);      // area / detach(area), scene.cpp:680
+            if (path_space) its.J = Dual(s0.w, tf.y) / Dual(s0.w);      // area / detach(area), scene.cpp:680
         } else {
             n0 = promote(Vec3f(s0.x, s0.y, s0.z)); n1 = promote(Vec3f(s1.x, s1.y, s1.z)); n2 = promote(Vec3f(s2.x, s2.y, s2.z));
             its.n = promote(Vec3f(s3.x, s3.y, s3.z));
@@ -105,34 +104,51 @@ PSDR_DEV Its<AD> ray_intersect(SceneView<LDS> &S, const RayT<AD> &ray, bool acti
     }
     R u, v;
     V dir_in;
-    if constexpr (!AD || PATH_SPACE) {
+    if (!AD || path_space) {
         u = R(h.u); v = R(h.v);                         // detached barycentrics from the tracer
         its.p = madd3(e1, u, e2, v, p0);
         V dir = its.p - ray.o;
         its.t = norm(dir);
         dir_in = dir / its.t;
     } else {
-        R t;
-        ray_tri_uvt<R>(p0, e1, e2, ray.o, ray.d, u, v, t);     // differentiable re-intersection, scene.cpp:774
-        its.p = V(fma_(ray.d.x, t, ray.o.x), fma_(ray.d.y, t, ray.o.y), fma_(ray.d.z, t, ray.o.z));
-        its.t = t;
-        dir_in = ray.d;
+        if constexpr (AD) {
+            R t;
+            ray_tri_uvt<R>(p0, e1, e2, ray.o, ray.d, u, v, t);     // differentiable re-intersection, scene.cpp:774
+            its.p = V(fma_(ray.d.x, t, ray.o.x), fma_(ray.d.y, t, ray.o.y), fma_(ray.d.z, t, ray.o.z));
+            its.t = t;
+            dir_in = ray.d;
+        }
     }
     V sh_n = normalize(madd3(n1 - n0, u, n2 - n0, v, n0));
     if (flat) sh_n = its.n;
     its.fn = sh_n;
-    coordinate_system(sh_n, its.fs, its.ft);
-    // tangent frame from the uv parameterisation when it is non-degenerate (scene.cpp:724-766)
-    const float du0x = s4.z - s4.x, du0y = s4.w - s4.y, du1x = s5.x - s4.x, du1y = s5.y - s4.y;
-    const float det = fma_(du0x, du1y, -(du0y * du1x));
-    if (det != 0.f) {
-        const float inv_det = 1.f / det;
-        V dp_du = (e1 * R(du1y) - e2 * R(du0y)) * R(inv_det);
-        its.fs = normalize(dp_du - sh_n * dot(sh_n, dp_du));
-        its.ft = cross(sh_n, its.fs);
+    if constexpr (FRAME) {
+        coordinate_system(sh_n, its.fs, its.ft);
+        // tangent frame from the uv parameterisation when it is non-degenerate (scene.cpp:724-766)
+        const float4 s4 = S.ld(w + 4), s5 = S.ld(w + 5);
+        const float du0x = s4.z - s4.x, du0y = s4.w - s4.y, du1x = s5.x - s4.x, du1y = s5.y - s4.y;
+        const float det = fma_(du0x, du1y, -(du0y * du1x));
+        if (det != 0.f) {
+            const float inv_det = 1.f / det;
+            V dp_du = (e1 * R(du1y) - e2 * R(du0y)) * R(inv_det);
+            its.fs = normalize(dp_du - sh_n * dot(sh_n, dp_du));
+            its.ft = cross(sh_n, its.fs);
+        }
+        its.wi = to_local<AD>(its, -dir_in);
+    } else {
+        its.wi = V(R(0.f), R(0.f), dot(-dir_in, sh_n));
     }
-    its.wi = to_local<AD>(its, -dir_in);
     return its;
+}
+
+// Scene::ray_intersect<ad, path_space>, reference src/scene/scene.cpp:612-806
+template <bool AD, bool PATH_SPACE, bool LDS, bool COUNT, bool FRAME = true>
+PSDR_DEV Its<AD> ray_intersect(SceneView<LDS> &S, const RayT<AD> &ray, bool active) {
+    static_assert(AD || !PATH_SPACE, "path-space needs AD");
+    Hit h; h.slot = -1; h.u = h.v = h.t = 0.f;
+    if (active) h = trace<LDS, COUNT>(S, detach(ray.o), detach(ray.d));
+    if (COUNT) { if (h.slot >= 0) S.c_hits++; }
+    return make_its<AD, LDS, FRAME>(S, h, ray, PATH_SPACE);
 }
 
 // ---------------------------------------------------------------- records from the blob

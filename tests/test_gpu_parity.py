@@ -217,7 +217,8 @@ def test_counters_match_oracle_scale(torch_cuda, psdr):
     cabi.check(cabi.lib().psdr_hip_render_c_counted(sc._hip_handle(), C.byref(a), out.data_ptr(), C.byref(c), None))
     n = 64 * 64 * 8
     assert n <= c.rays <= 7 * n                      # 1 + 2*depth rays per lane at most
-    assert c.nodes_visited >= c.rays and c.tris_tested >= c.shaded_hits
+    # 36 triangles <= kBruteForceMax: every ray tests every triangle and visits no BVH node
+    assert c.nodes_visited == 0 and c.tris_tested == 36 * c.rays and c.tris_tested >= c.shaded_hits
     plain = torch_cuda.empty_like(out)
     cabi.check(cabi.lib().psdr_hip_render_c(sc._hip_handle(), C.byref(a), plain.data_ptr(), None))
     assert torch_cuda.allclose(out, plain, rtol=1e-5, atol=1e-6)
