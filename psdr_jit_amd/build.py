@@ -18,14 +18,14 @@ HIP_LIB = os.path.join(LIBDIR, "libpsdr_hip.so")
 CORE_LIB = os.path.join(HERE, "_psdr_core" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
 
 HIP_SRCS = [os.path.join(CSRC, "hip", f) for f in ("api.hip",)]
-HIP_DEPS = [os.path.join(CSRC, "hip", f) for f in ("dmath.h", "sampler.h", "scene_dev.h", "shade.h", "edges.h", "bvh.h")] + \
+HIP_DEPS = [os.path.join(CSRC, "hip", f) for f in ("dmath.h", "sampler.h", "scene_dev.h", "shade.h", "edges.h", "paths.h", "bvh.h")] + \
            [os.path.join(ROOT, "include", "psdr_hip.h")]
 HOST_SRCS = [os.path.join(CSRC, "host", f) for f in ("scene_host.cpp", "bindings.cpp")]
 HOST_DEPS = [os.path.join(CSRC, "host", f) for f in ("scene_host.h", "hnum.h")] + [os.path.join(ROOT, "include", "psdr_hip.h")]
 
 # -ffp-contract=off: every fused multiply-add in the kernels is an explicit fma so that the
 # arithmetic matches the scalar CPU restatement the parity tests compare against.
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-slp-vectorize"]
 
 
 def _stale(target, deps):

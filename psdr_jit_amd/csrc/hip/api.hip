@@ -81,7 +81,7 @@ PSDR_DEV float seg_scan(float v, int key, int lane_id) {
 // ------------------------------------------------------------------------------------------------
 // interior term (MODE 0) and primary-edge term (MODE 1): persistent lanes with path regeneration, paths.h
 template <bool AD, bool LDS, bool COUNT, int MODE>
-__global__ __launch_bounds__(kBlock) void k_paths(const float4 *__restrict__ blob, const SceneTables T, const SensorDev cam,
+__global__ __launch_bounds__(kBlock, (AD ? 3 : 1)) void k_paths(const float4 *__restrict__ blob, const SceneTables T, const SensorDev cam,
                                                   const PathParams P, Counters *ctr) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     SceneView<LDS> S = make_view<LDS>(blob, T, smem);
@@ -319,6 +319,18 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     T.emit_off = (int) w;  w += 2 * (size_t) std::max(1, s->n_emitters);
     T.ecdf_off = (int) w;  w += words_for_floats(2 * (size_t) std::max(1, s->n_emitters));
     T.fcdf_off = (int) w;  w += words_for_floats(2 * (size_t) std::max(1, s->n_face_distrb));
+    const psdr_sec_edges &se = s->sec_edges;
+    SecEdgeTables &E = sc->E;
+    E.n = se.n_edges; E.sum = se.sum;
+    E.off = (int) w;       w += 6 * (size_t) std::max(0, se.n_edges);
+    E.cdf_off = (int) w;   w += words_for_floats(2 * (size_t) std::max(1, se.n_edges));
+    std::vector<std::pair<int, int>> pe_offs;
+    for (int i = 0; i < s->n_sensors; ++i) {
+        const int ne = std::max(0, s->sensors[i].n_edges);
+        const int o1 = (int) w; w += 3 * (size_t) ne;
+        const int o2 = (int) w; w += words_for_floats(2 * (size_t) std::max(1, ne));
+        pe_offs.emplace_back(o1, o2);
+    }
     T.blob_words = (int) w;
     T.n_nodes = bvh.n_nodes; T.n_tris = n; T.n_meshes = s->n_meshes; T.n_bsdfs = s->n_bsdfs; T.n_emitters = s->n_emitters;
     T.n_fcdf = s->n_face_distrb; T.has_tangent = has_tan ? 1 : 0; T.stack_depth = bvh.max_depth + 1;
@@ -379,6 +391,32 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
         blob[4 * (size_t) T.fcdf_off + i] = s->face_pmf[i];
         blob[4 * (size_t) T.fcdf_off + s->n_face_distrb + i] = s->face_cmf[i];
     }
+    for (int i = 0; i < se.n_edges; ++i) {
+        const float *p0 = se.p0 + 3 * i, *e1 = se.e1 + 3 * i, *n0 = se.n0 + 3 * i, *n1 = se.n1 + 3 * i, *p2 = se.p2 + 3 * i;
+        const float z3[3] = {0.f, 0.f, 0.f};
+        const float *dp0 = se.d_p0 ? se.d_p0 + 3 * i : z3, *de1 = se.d_e1 ? se.d_e1 + 3 * i : z3;
+        const size_t ew = E.off + 6 * (size_t) i;
+        put4(blob, ew, p0[0], p0[1], p0[2], e1[0]);
+        put4(blob, ew + 1, e1[1], e1[2], n0[0], n0[1]);
+        put4(blob, ew + 2, n0[2], n1[0], n1[1], n1[2]);
+        put4(blob, ew + 3, p2[0], p2[1], p2[2], ibits(se.is_boundary[i] ? 1 : 0));
+        put4(blob, ew + 4, dp0[0], dp0[1], dp0[2], de1[0]);
+        put4(blob, ew + 5, de1[1], de1[2], 0.f, 0.f);
+        blob[4 * (size_t) E.cdf_off + i] = se.pmf[i];
+        blob[4 * (size_t) E.cdf_off + se.n_edges + i] = se.cmf[i];
+    }
+    for (int k = 0; k < s->n_sensors; ++k) {
+        const psdr_sensor_rec &r = s->sensors[k];
+        for (int i = 0; i < r.n_edges; ++i) {
+            const size_t pw = pe_offs[k].first + 3 * (size_t) i;
+            put4(blob, pw, r.edge_p0[2 * i], r.edge_p0[2 * i + 1], r.edge_p1[2 * i], r.edge_p1[2 * i + 1]);
+            put4(blob, pw + 1, r.d_edge_p0 ? r.d_edge_p0[2 * i] : 0.f, r.d_edge_p0 ? r.d_edge_p0[2 * i + 1] : 0.f,
+                 r.d_edge_p1 ? r.d_edge_p1[2 * i] : 0.f, r.d_edge_p1 ? r.d_edge_p1[2 * i + 1] : 0.f);
+            put4(blob, pw + 2, r.edge_normal[2 * i], r.edge_normal[2 * i + 1], r.edge_length[i], 0.f);
+            blob[4 * (size_t) pe_offs[k].second + i] = r.edge_pmf[i];
+            blob[4 * (size_t) pe_offs[k].second + r.n_edges + i] = r.edge_cmf[i];
+        }
+    }
     if (sc->blob.upload(blob.data(), blob.size() * sizeof(float))) return 1;
 
     const size_t stack_bytes = (size_t) T.stack_depth * kBlock * sizeof(int);
@@ -388,17 +426,6 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     if (sc->smem_bytes > 64 * 1024) return fail("BVH too deep for the LDS traversal stack");
     sc->n_leaves = bvh.n_leaves; sc->max_depth = bvh.max_depth;
 
-    int rc = 0;
-    const psdr_sec_edges &se = s->sec_edges;
-    SecEdgeTables &E = sc->E;
-    E.n = se.n_edges; E.sum = se.sum;
-    if (se.n_edges > 0) {
-        const size_t m = (size_t) se.n_edges;
-        E.p0 = sc->up(se.p0, 3 * m, rc); E.e1 = sc->up(se.e1, 3 * m, rc); E.n0 = sc->up(se.n0, 3 * m, rc); E.n1 = sc->up(se.n1, 3 * m, rc);
-        E.p2 = sc->up(se.p2, 3 * m, rc); E.d_p0 = sc->up(se.d_p0, 3 * m, rc); E.d_e1 = sc->up(se.d_e1, 3 * m, rc);
-        E.pmf = sc->up(se.pmf, m, rc); E.cmf = sc->up(se.cmf, m, rc); E.is_boundary = sc->up8(se.is_boundary, m, rc);
-        if (E.d_p0 == nullptr || E.d_e1 == nullptr) { E.d_p0 = nullptr; E.d_e1 = nullptr; }
-    }
     for (int i = 0; i < s->n_sensors; ++i) {
         const psdr_sensor_rec &r = s->sensors[i];
         SensorDev d{};
@@ -407,18 +434,9 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
         std::memcpy(d.d_world_to_sample.m, r.d_world_to_sample, 64);
         for (int k = 0; k < 3; ++k) { d.cam_pos[k] = r.cam_pos[k]; d.cam_dir[k] = r.cam_dir[k]; }
         d.inv_area = r.inv_area; d.n_edges = r.n_edges; d.edge_sum = r.edge_sum;
-        if (r.n_edges > 0) {
-            const size_t m = (size_t) r.n_edges;
-            std::vector<float> zeros(2 * m, 0.f);
-            d.edge_p0 = sc->up(r.edge_p0, 2 * m, rc); d.edge_p1 = sc->up(r.edge_p1, 2 * m, rc);
-            d.d_edge_p0 = sc->up(r.d_edge_p0 ? r.d_edge_p0 : zeros.data(), 2 * m, rc);
-            d.d_edge_p1 = sc->up(r.d_edge_p1 ? r.d_edge_p1 : zeros.data(), 2 * m, rc);
-            d.edge_normal = sc->up(r.edge_normal, 2 * m, rc); d.edge_length = sc->up(r.edge_length, m, rc);
-            d.edge_pmf = sc->up(r.edge_pmf, m, rc); d.edge_cmf = sc->up(r.edge_cmf, m, rc);
-        }
+        d.pe_off = pe_offs[i].first; d.pecdf_off = pe_offs[i].second;
         sc->sensors.push_back(d);
     }
-    if (rc) return 1;
     if (sc->counters.upload(nullptr, sizeof(Counters))) return 1;
     if (sc->queues.upload(nullptr, sizeof(unsigned long long) * kQueueRing)) return 1;
 

@@ -44,59 +44,24 @@ PSDR_DEV SensorDirectSample sample_direct(const SceneTables &T, const SensorDev 
     return r;
 }
 
-// one lane of render_primary_edges: returns pixel index (or -1) and d(value)/d(theta)
-template <bool LDS, bool COUNT>
-PSDR_DEV int primary_edge_lane(SceneView<LDS> &S, const SensorDev &cam, LaneRng &rng, int max_depth, bool hide, int sppe, Vec3f &dval) {
-    const SceneTables &T = *S.T;
-    float s = rng.next_1d(), pdf;
-    const int ei = sample_reuse(cam.n_edges, cam.edge_sum, [&](int i) { return cam.edge_pmf[i]; }, [&](int i) { return cam.edge_cmf[i]; }, s, pdf);
-    pdf /= cam.edge_length[ei];
-    const float nx = cam.edge_normal[2 * ei], ny = cam.edge_normal[2 * ei + 1];
-    const float oms = 1.0f - s;
-    const Dual p0x(cam.edge_p0[2 * ei], cam.d_edge_p0[2 * ei]), p0y(cam.edge_p0[2 * ei + 1], cam.d_edge_p0[2 * ei + 1]);
-    const Dual p1x(cam.edge_p1[2 * ei], cam.d_edge_p1[2 * ei]), p1y(cam.edge_p1[2 * ei + 1], cam.d_edge_p1[2 * ei + 1]);
-    const Dual px = fma_(p0x, oms, p1x * s), py = fma_(p0y, oms, p1y * s);
-    const Dual x_dot_n = fma_(py, ny, px * nx);
-    const int ix = (int) floorf(px.v * (float) T.width), iy = (int) floorf(py.v * (float) T.height);
-    const bool valid = ix >= 0 && ix < T.width && iy >= 0 && iy < T.height;
-    const int idx = valid ? iy * T.width + ix : -1;
-    const RayT<false> ray_p = sample_primary_ray<false>(cam, px.v + kEdgeEpsilon * nx, py.v + kEdgeEpsilon * ny);
-    const RayT<false> ray_n = sample_primary_ray<false>(cam, px.v - kEdgeEpsilon * nx, py.v - kEdgeEpsilon * ny);
-    // Li(ray_n) first, then Li(ray_p): both advance sampler 1 (integrator.cpp:185-186)
-    const Vec3f Ln = Li<false, LDS, COUNT>(S, rng, ray_n, valid, max_depth, hide);
-    const Vec3f Lp = Li<false, LDS, COUNT>(S, rng, ray_p, valid, max_depth, hide);
-    const Vec3f dL = (Ln - Lp) / pdf;
-    float out[3] = {dL.x, dL.y, dL.z};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float pv = x_dot_n.v * out[c];
-        float dv = x_dot_n.d * out[c];
-        if (!finite_(pv) || !finite_(dv)) dv = 0.f;          // integrator.cpp:188
-        if (sppe > 1) dv /= (float) sppe;
-        out[c] = dv;
-    }
-    dval = Vec3f(out[0], out[1], out[2]);
-    return idx;
-}
-
 struct BoundarySegSampleDirect { bool valid; float pdf; Vec3d p0; Vec3f edge, edge2, p2, n; int emitter_slot; };
 
 PSDR_DEV int sign_eps(float x, float eps) { return x > eps ? 1 : (x < -eps ? -1 : 0); }     // reference utils.h:47-53
 PSDR_DEV float sign1(float x) { return signbit_(x) ? -1.f : 1.f; }                          // drjit::sign
-PSDR_DEV Vec3f ld3(const float *p, int i) { return Vec3f(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
 
 // Scene::sample_boundary_segment_direct, reference scene.cpp:1027-1068
 template <bool LDS> PSDR_DEV BoundarySegSampleDirect sample_boundary_segment_direct(const SceneView<LDS> &S, const SecEdgeTables &E, Vec3f s3) {
     BoundarySegSampleDirect r;
     float sample1 = s3.x, pdf0;
-    const int ei = sample_reuse(E.n, E.sum, [&](int i) { return E.pmf[i]; }, [&](int i) { return E.cmf[i]; }, sample1, pdf0);
-    const Vec3f e1 = ld3(E.e1, ei), p0 = ld3(E.p0, ei);
-    Vec3f de1(0.f), dp0(0.f);
-    if (E.d_e1) { de1 = ld3(E.d_e1, ei); dp0 = ld3(E.d_p0, ei); }
+    const int ei = sample_reuse(E.n, E.sum, [&](int i) { return S.ldf(E.cdf_off, i); }, [&](int i) { return S.ldf(E.cdf_off, E.n + i); }, sample1, pdf0);
+    const int w = E.off + 6 * ei;
+    const float4 q0 = S.ld(w), q1 = S.ld(w + 1), q2 = S.ld(w + 2), q3 = S.ld(w + 3), q4 = S.ld(w + 4), q5 = S.ld(w + 5);
+    const Vec3f p0(q0.x, q0.y, q0.z), e1(q0.w, q1.x, q1.y), n0(q1.z, q1.w, q2.x), n1(q2.y, q2.z, q2.w), p2(q3.x, q3.y, q3.z);
+    const Vec3f dp0(q4.x, q4.y, q4.z), de1(q4.w, q5.x, q5.y);
     const Dual s1(sample1);
     r.p0 = Vec3d(fma_(Dual(e1.x, de1.x), s1, Dual(p0.x, dp0.x)), fma_(Dual(e1.y, de1.y), s1, Dual(p0.y, dp0.y)), fma_(Dual(e1.z, de1.z), s1, Dual(p0.z, dp0.z)));
     r.edge = normalize(e1);
-    r.edge2 = ld3(E.p2, ei) - p0;
+    r.edge2 = p2 - p0;
     const Vec3f p0v = detach(r.p0);
     pdf0 /= norm(e1);
     const PositionSample<false> ps2 = sample_emitter_position<false, LDS>(S, s3.y, s3.z);
@@ -105,8 +70,8 @@ template <bool LDS> PSDR_DEV BoundarySegSampleDirect sample_boundary_segment_dir
     const float distSqr = squared_norm(e);
     e = e / safe_sqrt(distSqr);
     const float cosTheta = dot(r.n, -e);
-    const bool is_boundary = E.is_boundary[ei] != 0;
-    const int sgn0 = sign_eps(dot(ld3(E.n0, ei), e), kEdgeEpsilon), sgn1 = sign_eps(dot(ld3(E.n1, ei), e), kEdgeEpsilon);
+    const bool is_boundary = __float_as_int(q3.w) != 0;
+    const int sgn0 = sign_eps(dot(n0, e), kEdgeEpsilon), sgn1 = sign_eps(dot(n1, e), kEdgeEpsilon);
     r.valid = (cosTheta > kEpsilon) && ((is_boundary && sgn0 != 0) || (!is_boundary && sgn0 * sgn1 < 0));
     r.pdf = r.valid ? pdf0 * ps2.pdf * (distSqr / cosTheta) : 0.f;
     return r;

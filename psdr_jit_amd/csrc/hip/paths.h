@@ -92,12 +92,13 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
                         // PerspectiveCamera::sample_primary_edge, reference perspective.cpp:200-226
                         rng.seed(P.seed + (unsigned long long) lane, (unsigned long long) lane, P.skip);
                         float s = rng.next_1d(), pdf;
-                        const int ei = sample_reuse(cam.n_edges, cam.edge_sum, [&](int i) { return cam.edge_pmf[i]; }, [&](int i) { return cam.edge_cmf[i]; }, s, pdf);
-                        pdf /= cam.edge_length[ei];
-                        const float nx = cam.edge_normal[2 * ei], ny = cam.edge_normal[2 * ei + 1];
+                        const int ei = sample_reuse(cam.n_edges, cam.edge_sum, [&](int i) { return S.ldf(cam.pecdf_off, i); },
+                                                    [&](int i) { return S.ldf(cam.pecdf_off, cam.n_edges + i); }, s, pdf);
+                        const float4 r0 = S.ld(cam.pe_off + 3 * ei), r1 = S.ld(cam.pe_off + 3 * ei + 1), r2 = S.ld(cam.pe_off + 3 * ei + 2);
+                        pdf /= r2.z;
+                        const float nx = r2.x, ny = r2.y;
                         const float oms = 1.0f - s;
-                        const Dual p0x(cam.edge_p0[2 * ei], cam.d_edge_p0[2 * ei]), p0y(cam.edge_p0[2 * ei + 1], cam.d_edge_p0[2 * ei + 1]);
-                        const Dual p1x(cam.edge_p1[2 * ei], cam.d_edge_p1[2 * ei]), p1y(cam.edge_p1[2 * ei + 1], cam.d_edge_p1[2 * ei + 1]);
+                        const Dual p0x(r0.x, r1.x), p0y(r0.y, r1.y), p1x(r0.z, r1.z), p1y(r0.w, r1.w);
                         const Dual px = fma_(p0x, oms, p1x * s), py = fma_(p0y, oms, p1y * s);
                         const Dual x_dot_n = fma_(py, ny, px * nx);
                         const int ix = (int) floorf(px.v * (float) T.width), iy = (int) floorf(py.v * (float) T.height);

@@ -28,19 +28,22 @@ struct SceneTables {
     int width, height, spp, sppe, sppse;
 };
 
-struct SecEdgeTables {         // global memory (one random edge per lane: no reuse worth staging)
-    const float *p0, *e1, *n0, *n1, *p2, *d_p0, *d_e1, *pmf, *cmf;
-    const uint8_t *is_boundary;
-    int n;
+// Secondary-edge table inside the blob: 6 words per edge
+//   {p0.xyz, e1.x} {e1.yz, n0.xy} {n0.z, n1.xyz} {p2.xyz, bits(is_boundary)} {d_p0.xyz, d_e1.x} {d_e1.yz, 0, 0}
+// followed (at cdf_off) by pmf[n], cmf[n].  (Stage r01a kept these in global arrays: the CDF binary search was a
+// chain of 7 dependent global loads per candidate and dominated the secondary-edge kernel.)
+struct SecEdgeTables {
+    int off, cdf_off, n;
     float sum;
 };
 
+// Primary-edge table of one sensor inside the blob: 3 words per edge {p0.xy, p1.xy} {d_p0.xy, d_p1.xy} {n.xy, length, 0},
+// then pmf[n], cmf[n] at pecdf_off.
 struct SensorDev {
     Mat4<float> sample_to_camera, to_world, d_to_world, world_to_sample, d_world_to_sample;
     float cam_pos[3], cam_dir[3];
     float inv_area;
-    int n_edges;
-    const float *edge_p0, *edge_p1, *d_edge_p0, *d_edge_p1, *edge_normal, *edge_length, *edge_pmf, *edge_cmf;
+    int n_edges, pe_off, pecdf_off;
     float edge_sum;
 };
 
@@ -90,17 +93,29 @@ PSDR_DEV Hit trace(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
         // divergence - for incoherent rays this beats any per-lane tree walk on a 64-wide SIMD machine.
         // Same tri_test, same (t, id) order => same hit as the BVH path.
         if (COUNT) { S.c_rays++; S.c_tris += (unsigned) T.n_tris; }
-        const float4 *tri = S.G + T.trav_off;
+        const float4 *tri = S.G + T.trav_off;       // (LDS broadcast reads measured 3 % slower than scalar loads)
         // software-pipelined: the scalar loads of triangle k+1 are issued before triangle k is tested
         float4 a = tri[0], b = tri[1], c = tri[2];
         for (int k = 0; k < T.n_tris; ++k) {
             const int kn = (k + 1 < T.n_tris) ? k + 1 : k;
             const float4 na = tri[3 * kn], nb = tri[3 * kn + 1], nc = tri[3 * kn + 2];
+            // all of u, v, t unconditionally, ONE exec-masked region for the (rare) accept: the short-circuit form cost
+            // three s_and_saveexec / s_cbranch_execz pairs per triangle (SALU was 50 % of the VALU count)
             float u, v, t;
-            if (tri_test(a, b, c, o, d, u, v, t)) {
-                const int id = __float_as_int(c.y);
-                if (t < best_t || (t == best_t && id < best_id)) { best_t = t; best_id = id; best.slot = k; best.u = u; best.v = v; best.t = t; }
+            {
+                const Vec3f p0(a.x, a.y, a.z), e1(a.w, b.x, b.y), e2(b.z, b.w, c.x);
+                const Vec3f h = cross(d, e2);
+                const float f = 1.f / dot(e1, h);
+                const Vec3f s = o - p0;
+                u = f * dot(s, h);
+                const Vec3f q = cross(s, e1);
+                v = f * dot(d, q);
+                t = f * dot(e2, q);
             }
+            const int id = __float_as_int(c.y);
+            const bool ok = (u >= 0.f) & (v >= 0.f) & (u + v <= 1.f) & (t > kRayEpsilon) & (t < kTraceTMax);
+            const bool better = ok & ((t < best_t) | ((t == best_t) & (id < best_id)));
+            if (better) { best_t = t; best_id = id; best.slot = k; best.u = u; best.v = v; best.t = t; }
             a = na; b = nb; c = nc;
         }
         return best;

@@ -72,6 +72,7 @@ def pmc(tag):
                 t = 2.0 * f * 1024 + w * 1024
                 fh.write("    %-28s %18.0f   bytes/launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024\n" % ("HBM traffic", t))
                 key = {"k_interior<true, true, false>": "k_interior<AD>", "k_primary_edges<true, false>": "k_primary_edges",
+                       "k_paths<true, true, false, 0>": "k_interior<AD>", "k_paths<false, true, false, 1>": "k_primary_edges",
                        "k_secondary_edges<true, false>": "k_secondary_edges"}.get(k, k)
                 traffic[key] = t
             h, m = cs.get("TCC_HIT_sum", (None, 0))[0], cs.get("TCC_MISS_sum", (None, 0))[0]
