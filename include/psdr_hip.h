@@ -164,6 +164,19 @@ int psdr_hip_render_c(const psdr_hip_scene *scene, const psdr_render_args *args,
 /* Integrator::renderD + forward derivative: out_rgb = image, out_drgb = d image / d theta */
 int psdr_hip_render_d_fwd(const psdr_hip_scene *scene, const psdr_render_args *args,
                           float *out_rgb, float *out_drgb, void *stream);
+/* Reverse mode of renderD (the reference's drjit.backward through Integrator::renderD, README.md:102-106):
+ * given d_rgb = d loss / d image ([n_pixels*3], device), accumulate the adjoints of the snapshot quantities
+ * the image depends on.  All buffers are DEVICE pointers owned by the caller; rows follow the snapshot order.
+ * The host chains them to vertices / transforms / colours.  (d loss / d camera pose is forward-mode only.) */
+typedef struct psdr_grads {
+    float *g_triangles;    /* [n_triangles*22] rows [p0 e1 e2 n0 n1 n2 face_normal face_area] */
+    float *g_bsdf;         /* [n_bsdfs*3] reflectance */
+    float *g_emitter;      /* [n_emitters*3] radiance */
+    float *g_sec_edges;    /* [n_sec_edges*6] (p0, e1); required when sppse > 0 and the term is requested */
+    float *g_prim_edges;   /* [n_primary_edges(sensor)*4] sample-space (p0.xy, p1.xy); required when sppe > 0 */
+} psdr_grads;
+int psdr_hip_render_d_bwd(const psdr_hip_scene *scene, const psdr_render_args *args, const float *d_rgb,
+                          const psdr_grads *grads, void *stream);
 /* same kernels with traversal counters enabled (slower; counters is a HOST struct, call synchronises) */
 int psdr_hip_render_c_counted(const psdr_hip_scene *scene, const psdr_render_args *args, float *out_rgb,
                               psdr_counters *counters, void *stream);

@@ -304,9 +304,9 @@ def _render_d_raw(self, scene, sensor_id, seed, batch_pix, terms, distributed=No
 
 
 class _RenderDFn(_torch.autograd.Function):
-    """Autograd node of renderD.  forward = primal image; backward replays forward-mode renders
-    (one per scalar degree of freedom of the 4x4 / rgb leaves) until the adjoint kernel of
-    psdr_render_d_bwd lands — exact, but O(#dof) renders."""
+    """Autograd node of renderD.  forward = primal image; backward = the reverse-mode kernels
+    (psdr_hip_render_d_bwd: adjoints of the configured snapshot) followed by the host chain rule of
+    chain.py down to the leaf tensors (mesh transforms, vertex positions, reflectances, radiances)."""
 
     @staticmethod
     def forward(ctx, state, *leaf_tensors):
@@ -315,25 +315,68 @@ class _RenderDFn(_torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_img):
+        from . import chain
         st = ctx.state
         integ, scene = st["integrator"], st["scene"]
-        grads = []
-        for (obj, name, t), needs in zip(st["leaves"], ctx.needs_input_grad[1:]):
-            if not needs:
-                grads.append(None)
-                continue
-            if name == "vertex_positions":
-                raise NotImplementedError("reverse-mode w.r.t. vertex_positions needs the adjoint kernel (psdr_render_d_bwd)")
-            g = _torch.zeros(t.numel(), dtype=_torch.float32)
-            ndof = 12 if name.startswith("to_world") else t.numel()
-            for k in range(ndof):
-                e = _np.zeros(t.numel(), dtype=_np.float32)
-                e[k] = 1.0
-                dimg = _replay_forward(integ, scene, st, {id(t): e})
-                g[k] = float((dimg * grad_img).sum())
-            grads.append(g.reshape(t.shape).to(t.device, t.dtype))
-        _sync_params(scene)
-        scene._configure(st["active"])
+        leaves = st["leaves"]
+        needs = ctx.needs_input_grad[1:]
+        for (obj, name, t), need in zip(leaves, needs):
+            if need and isinstance(obj, Sensor):
+                raise NotImplementedError("reverse mode w.r.t. the camera pose is not implemented; use forward_grad()")
+        dev = grad_img.device
+        g_img = grad_img.contiguous().to(_torch.float32)
+        snap = scene._snapshot()
+        n_tris = int(snap["triangles"].shape[0])
+        n_sec = int(snap["sec_edges"].shape[0])
+        cam = scene.param_map["Sensor[%d]" % st["sensor_id"]]
+        n_prim = int(_np.asarray(cam._primary_edge_ids()).reshape(-1, 3).shape[0])
+        pm = scene.param_map
+        nb = sum(1 for k in pm if k.startswith("BSDF[") and not k.startswith("BSDF[id="))
+        ne = sum(1 for k in pm if k.startswith("Emitter[") and not k.startswith("Emitter[id="))
+        sizes = [n_tris * 22, max(1, nb) * 3, max(1, ne) * 3, max(1, n_sec) * 6, max(1, n_prim) * 4]
+        flat = _torch.zeros(sum(sizes), dtype=_torch.float32, device=dev)
+        offs = [0]
+        for z in sizes:
+            offs.append(offs[-1] + z)
+        ptr = [flat.data_ptr() + 4 * o for o in offs[:-1]]
+        if st["seed"] != -1:
+            seeds, skips = [st["seed"]] * 3, [0, 0, 0]
+        else:
+            seeds, skips = [s[2] for s in st["samplers"]], [s[3] for s in st["samplers"]]
+        rank, world = _shard()
+        _core._render_d_bwd(integ, scene, st["sensor_id"], seeds, skips, g_img.data_ptr(), ptr[0], ptr[1], ptr[2], ptr[3], ptr[4],
+                            _stream_ptr(), rank, world, st["terms"])
+        _all_reduce(flat, world > 1)
+        g = flat.to("cpu", _torch.float64)
+        g_tri, g_bsdf, g_em = g[offs[0]:offs[1]].reshape(n_tris, 22), g[offs[1]:offs[2]].reshape(-1, 3)[:nb], g[offs[2]:offs[3]].reshape(-1, 3)[:ne]
+        g_sec, g_prim = g[offs[3]:offs[4]].reshape(-1, 6)[:n_sec], g[offs[4]:offs[5]].reshape(-1, 4)[:n_prim]
+
+        fresh = {}
+
+        def leaf_of(obj, name):
+            t = obj.__dict__.get("_psdr_params", {}).get(name)
+            key = (id(obj), name)
+            if t is not None and t.requires_grad:
+                if key not in fresh:
+                    fresh[key] = t.detach().to("cpu", _torch.float64).clone().requires_grad_(True)
+                return fresh[key]
+            return _torch.as_tensor(_np.asarray(obj._get(name, False), dtype=_np.float64))
+
+        with _torch.enable_grad():          # autograd runs backward() with grad mode off
+            tri, sec, prim, refl, rad = chain.snapshot_tensors(scene, st["sensor_id"], leaf_of)
+        outs, gos = [], []
+        for o, go in ((tri, g_tri), (sec, g_sec), (prim, g_prim), (refl, g_bsdf), (rad, g_em)):
+            if o.requires_grad and o.numel() > 0:
+                outs.append(o)
+                gos.append(go.reshape(o.shape))
+        grads = [None] * len(leaves)
+        wanted = [(i, fresh.get((id(obj), name))) for i, ((obj, name, t), need) in enumerate(zip(leaves, needs)) if need]
+        wanted = [(i, f) for i, f in wanted if f is not None]
+        if outs and wanted:
+            res = _torch.autograd.grad(outs, [f for _, f in wanted], gos, allow_unused=True)
+            for (i, f), r in zip(wanted, res):
+                t = leaves[i][2]
+                grads[i] = _torch.zeros_like(t) if r is None else r.reshape(t.shape).to(t.device, t.dtype)
         return (None,) + tuple(grads)
 
 

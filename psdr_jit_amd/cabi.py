@@ -8,7 +8,7 @@ from . import build as _build
 SYMBOLS = [
     "psdr_hip_last_error", "psdr_hip_abi_version", "psdr_hip_device_count", "psdr_hip_set_device",
     "psdr_hip_scene_create", "psdr_hip_scene_destroy", "psdr_hip_scene_stats", "psdr_hip_trace",
-    "psdr_hip_render_c", "psdr_hip_render_d_fwd", "psdr_hip_render_c_counted", "psdr_hip_render_d_fwd_counted",
+    "psdr_hip_render_c", "psdr_hip_render_d_fwd", "psdr_hip_render_d_bwd", "psdr_hip_render_c_counted", "psdr_hip_render_d_fwd_counted",
     "psdr_hip_li_lanes", "psdr_hip_guiding_build", "psdr_hip_guiding_mass", "psdr_hip_guiding_num_cells",
     "psdr_hip_guiding_destroy", "psdr_hip_tea64", "psdr_hip_sampler_floats",
 ]
@@ -22,6 +22,11 @@ class RenderArgs(C.Structure):
     _fields_ = [("sensor_id", C.c_int32), ("max_depth", C.c_int32), ("hide_emitters", C.c_int32),
                 ("samplers", Sampler * 3), ("pix_ids", C.c_void_p), ("n_pix", C.c_int32), ("terms", C.c_int32),
                 ("shard_rank", C.c_int32), ("shard_count", C.c_int32), ("guiding", C.c_void_p), ("zero_output", C.c_int32)]
+
+
+class Grads(C.Structure):
+    _fields_ = [("g_triangles", C.c_void_p), ("g_bsdf", C.c_void_p), ("g_emitter", C.c_void_p), ("g_sec_edges", C.c_void_p),
+                ("g_prim_edges", C.c_void_p)]
 
 
 class Counters(C.Structure):
@@ -44,6 +49,7 @@ def lib():
         L.psdr_hip_trace.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.psdr_hip_render_c.argtypes = [C.c_void_p, C.POINTER(RenderArgs), C.c_void_p, C.c_void_p]
         L.psdr_hip_render_d_fwd.argtypes = [C.c_void_p, C.POINTER(RenderArgs), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.psdr_hip_render_d_bwd.argtypes = [C.c_void_p, C.POINTER(RenderArgs), C.c_void_p, C.POINTER(Grads), C.c_void_p]
         L.psdr_hip_render_c_counted.argtypes = [C.c_void_p, C.POINTER(RenderArgs), C.c_void_p, C.POINTER(Counters), C.c_void_p]
         L.psdr_hip_render_d_fwd_counted.argtypes = [C.c_void_p, C.POINTER(RenderArgs), C.c_void_p, C.c_void_p, C.POINTER(Counters), C.c_void_p]
         L.psdr_hip_li_lanes.argtypes = [C.c_void_p, C.POINTER(RenderArgs), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]

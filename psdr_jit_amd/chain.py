@@ -1,0 +1,101 @@
+"""Host-side chain rule of reverse mode: from the adjoints of the configured snapshot (what
+psdr_hip_render_d_bwd returns: TriangleInfo rows, edge tables, colours) to the user's leaf tensors
+(mesh transforms, raw vertex positions, reflectances, radiances).
+
+The differentiable part of Scene::configure (reference src/shape/mesh.cpp:23-62,317-369 process_mesh +
+SecondaryEdgeInfo, src/sensor/perspective.cpp:130-143 primary-edge projection) is restated with torch
+ops in float64 and differentiated by torch.autograd — O(#triangles) glue; the per-sample work is all
+in the HIP kernels.  (Camera-pose leaves are forward-mode only.)
+"""
+import math
+
+import numpy as np
+import torch
+
+F64 = torch.float64
+
+
+def _t(x):
+    return torch.as_tensor(np.asarray(x, dtype=np.float64), dtype=F64)
+
+
+def _xform_pos(M, V):
+    h = V @ M[:3, :3].T + M[:3, 3]
+    w = V @ M[3, :3] + M[3, 3]
+    return h / w[:, None]
+
+
+def _process_mesh(Vw, F):
+    """rows [p0 e1 e2 n0 n1 n2 face_normal area] (22 floats) of process_mesh, reference mesh.cpp:23-62."""
+    i0, i1, i2 = F[:, 0], F[:, 1], F[:, 2]
+    p0 = Vw[i0]
+    e1 = Vw[i1] - p0
+    e2 = Vw[i2] - p0
+    N = torch.cross(e1, e2, dim=1)
+    a = N.norm(dim=1)
+    vn = torch.zeros_like(Vw)
+    for idx in (i0, i1, i2):
+        vn = vn.index_add(0, idx, N)
+    used = torch.zeros(Vw.shape[0], dtype=torch.bool)
+    used[F.reshape(-1)] = True
+    nrm = vn.norm(dim=1, keepdim=True)
+    n_v = torch.where(used[:, None], vn / torch.where(used[:, None], nrm, torch.ones_like(nrm)), torch.zeros_like(vn))
+    return torch.cat([p0, e1, e2, n_v[i0], n_v[i1], n_v[i2], N / a[:, None], (0.5 * a)[:, None]], dim=1)
+
+
+def _camera_to_sample(fov_x, near, far, aspect):
+    recip = 1.0 / (far - near)
+    cot = 1.0 / math.tan(math.radians(fov_x * 0.5))
+    P = torch.zeros((4, 4), dtype=F64)
+    P[0, 0] = cot
+    P[1, 1] = cot
+    P[2, 2] = far * recip
+    P[2, 3] = -near * far * recip
+    P[3, 2] = 1.0
+    S = torch.diag(torch.tensor([-0.5, -0.5 * aspect, 1.0, 1.0], dtype=F64))
+    T = torch.eye(4, dtype=F64)
+    T[0, 3] = -1.0
+    T[1, 3] = -1.0 / aspect
+    return S @ T @ P
+
+
+def snapshot_tensors(scene, sensor_id, leaf_of):
+    """leaf_of(obj, name) -> float64 tensor (a fresh leaf for differentiable parameters, a constant otherwise).
+    Returns (tri_rows, sec_rows, prim_rows, refl_rows, rad_rows) in the snapshot's row order."""
+    pm = scene.param_map
+    Vws, tri_rows, sec_rows = [], [], []
+    for i in range(scene.num_meshes):
+        m = pm["Mesh[%d]" % i]
+        V = leaf_of(m, "vertex_positions").reshape(-1, 3)
+        M = leaf_of(m, "to_world_left").reshape(4, 4) @ leaf_of(m, "to_world").reshape(4, 4) @ leaf_of(m, "to_world_right").reshape(4, 4)
+        Vw = _xform_pos(M, V)
+        Vws.append(Vw)
+        F = torch.as_tensor(np.asarray(m.face_indices, dtype=np.int64))
+        tri_rows.append(_process_mesh(Vw, F))
+        if scene.opts.sppse > 0 and m.enable_edges:
+            E = torch.as_tensor(np.asarray(m.edge_indices(), dtype=np.int64))
+            if E.numel():
+                sec_rows.append(torch.cat([Vw[E[:, 0]], Vw[E[:, 1]] - Vw[E[:, 0]]], dim=1))
+    tri = torch.cat(tri_rows, dim=0)
+    sec = torch.cat(sec_rows, dim=0) if sec_rows else torch.zeros((0, 6), dtype=F64)
+    cam = pm["Sensor[%d]" % sensor_id]
+    ids = torch.as_tensor(np.asarray(cam._primary_edge_ids(), dtype=np.int64)).reshape(-1, 3)
+    if ids.shape[0] > 0:
+        fov, near, far = cam._camera_params()
+        aspect = float(scene.opts.width) / float(scene.opts.height)
+        tw = leaf_of(cam, "to_world_left").reshape(4, 4) @ leaf_of(cam, "to_world").reshape(4, 4) @ leaf_of(cam, "to_world_right").reshape(4, 4)
+        w2s = _camera_to_sample(fov, near, far, aspect) @ torch.linalg.inv(tw)
+        q0, q1 = [], []
+        for mid, v0, v1 in ids.tolist():
+            q0.append(Vws[mid][v0])
+            q1.append(Vws[mid][v1])
+        q0 = _xform_pos(w2s, torch.stack(q0))
+        q1 = _xform_pos(w2s, torch.stack(q1))
+        prim = torch.cat([q0[:, :2], q1[:, :2]], dim=1)
+    else:
+        prim = torch.zeros((0, 4), dtype=F64)
+    nb = sum(1 for k in pm if k.startswith("BSDF[") and not k.startswith("BSDF[id="))
+    ne = sum(1 for k in pm if k.startswith("Emitter[") and not k.startswith("Emitter[id="))
+    refl = torch.stack([leaf_of(pm["BSDF[%d]" % i], "reflectance").reshape(-1).expand(3) for i in range(nb)]) if nb else torch.zeros((0, 3), dtype=F64)
+    rad = torch.stack([leaf_of(pm["Emitter[%d]" % i], "radiance").reshape(-1).expand(3) for i in range(ne)]) if ne else torch.zeros((0, 3), dtype=F64)
+    return tri, sec, prim, refl, rad

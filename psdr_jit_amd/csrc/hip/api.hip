@@ -20,6 +20,7 @@
 #include "bvh.h"
 #include "edges.h"
 #include "paths.h"
+#include "adjoint.h"
 
 using namespace psdr;
 
@@ -54,6 +55,7 @@ PSDR_DEV SceneView<LDS> make_view(const float4 *blob, const SceneTables &T, floa
     S.B = B; S.G = blob; S.T = &T;
     S.stack = reinterpret_cast<int *>(smem + (LDS ? T.blob_words : 0)) + threadIdx.x;
     S.c_nodes = S.c_tris = S.c_rays = S.c_hits = 0u;
+    S.mode = 0; S.rec = nullptr; S.rec_i = 0; S.rec_n = 0; S.ext = nullptr; S.ext_n = 0; S.probe_kind = 0; S.probe_id = 0; S.probe_comp = 0;
     return S;
 }
 
@@ -89,6 +91,19 @@ __global__ __launch_bounds__(kBlock, (AD ? 3 : 1)) void k_paths(const float4 *__
     if (COUNT) flush_counters(S, ctr);
 }
 
+template <bool LDS> PSDR_DEV float *scratch_base(float4 *smem, const SceneTables &T) {
+    return reinterpret_cast<float *>(smem + (LDS ? T.blob_words : 0)) + T.stack_depth * kBlock;
+}
+
+// reverse mode of the interior term (adjoint.h)
+template <bool LDS>
+__global__ __launch_bounds__(kBlock) void k_interior_adjoint(const float4 *__restrict__ blob, const SceneTables T, const SensorDev cam,
+                                                             const AdjointParams P) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    SceneView<LDS> S = make_view<LDS>(blob, T, smem);
+    run_interior_adjoint<LDS>(S, cam, P, scratch_base<LDS>(smem, T));
+}
+
 struct GuidingDev {          // HyperCubeDistribution<3>, reference src/core/cube_distrb.cpp:10-64
     const float *pmf, *cmf;
     float sum;
@@ -113,7 +128,7 @@ PSDR_DEV float guiding_sample_reuse(const GuidingDev &G, Vec3f &s) {
 // sample_boundary_segment_direct (silhouette condition + light facing), and only those trace rays.  Each lane
 // therefore keeps drawing candidates (RNG seed + three draws + the validity test, no ray) until the wave holds
 // enough valid ones, and the traced part (3 rays) runs with nearly all lanes active (stage r01a: 17 %).
-template <bool LDS, bool COUNT>
+template <bool LDS, bool COUNT, bool ADJ>
 __global__ __launch_bounds__(kBlock) void k_secondary_edges(const float4 *__restrict__ blob, const SceneTables T, const SecEdgeTables E,
                                                             const SensorDev cam, const PathParams P, const GuidingDev G, const int use_guiding,
                                                             Counters *ctr) {
@@ -158,6 +173,57 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edges(const float4 *__rest
             q_next += n_need < (int) (q_end - q_next) ? n_need : (q_end - q_next);
         }
         if (__ballot(have) == 0ull) { if (exhausted && q_next >= q_end) break; continue; }
+        if constexpr (ADJ) if (have) {
+            // reverse mode: record the three rays once, then probe the quantities the tangent is linear in
+            float *rec = scratch_base<LDS>(smem, T) + threadIdx.x;
+            S.rec = rec; S.mode = 1; S.rec_n = 0; S.rec_i = 0; S.probe_kind = 0;
+            BoundarySegSampleDirect b0 = bss;
+            b0.p0 = promote(detach(bss.p0));
+            Vec3f v;
+            const int idx = eval_boundary_segment<true, LDS, false>(S, cam, b0, v);
+            if (idx >= 0) {
+                float w3[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float k = P.adj_w[3 * (long long) idx + c];
+                    if (pdf0 > kEpsilon) k /= pdf0;
+                    if (T.sppse > 1) k /= (float) T.sppse;
+                    w3[c] = k;
+                }
+                S.mode = 2;
+                auto probe = [&](const BoundarySegSampleDirect &b) -> float {
+                    S.rec_i = 0;
+                    Vec3f t;
+                    const int id = eval_boundary_segment<true, LDS, false>(S, cam, b, t);
+                    if (id < 0) return 0.f;
+                    float g = 0.f;
+                    if (finite_(t.x)) g += w3[0] * t.x;
+                    if (finite_(t.y)) g += w3[1] * t.y;
+                    if (finite_(t.z)) g += w3[2] * t.z;
+                    return g;
+                };
+                for (int c = 0; c < 3; ++c) {
+                    BoundarySegSampleDirect bp = b0;
+                    if (c == 0) bp.p0.x.d = 1.f; else if (c == 1) bp.p0.y.d = 1.f; else bp.p0.z.d = 1.f;
+                    const float g = probe(bp);
+                    if (g != 0.f) { atomicAdd(&P.g_sec[6 * bss.edge_id + c], g); atomicAdd(&P.g_sec[6 * bss.edge_id + 3 + c], bss.s1 * g); }
+                }
+                for (int which = 0; which < 3; which += 2) {       // hit 0: emitter triangle, hit 2: camera-ray triangle
+                    const int slot = __float_as_int(rec[4 * which * kBlock]);
+                    if (slot < 0) continue;
+                    const int orig = __float_as_int(S.ld(T.shade_off + 6 * slot + 3).w);
+                    S.probe_kind = 1; S.probe_id = slot;
+                    for (int comp = 0; comp < 9; ++comp) {
+                        S.probe_comp = comp;
+                        const float g = probe(b0);
+                        if (g != 0.f) atomicAdd(&P.g_tri[22 * orig + comp], g);
+                    }
+                    S.probe_kind = 0;
+                }
+            }
+            S.mode = 0;
+            have = false;
+        }
         if (have) {
             Vec3f v;
             const int idx = eval_boundary_segment<true, LDS, COUNT>(S, cam, bss, v);
@@ -547,8 +613,8 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
             if (a->guiding) G = a->guiding->G;
             if (P.n_local > 0) {
                 if (next_queue(P.counter)) return 1;
-                if (sc->lds) LAUNCH((k_secondary_edges<true, COUNT>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr);
-                else LAUNCH((k_secondary_edges<false, COUNT>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr);
+                if (sc->lds) LAUNCH((k_secondary_edges<true, COUNT, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr);
+                else LAUNCH((k_secondary_edges<false, COUNT, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr);
             }
         }
     }
@@ -583,6 +649,89 @@ int psdr_hip_render_d_fwd_counted(const psdr_hip_scene *sc, const psdr_render_ar
 int psdr_hip_li_lanes(const psdr_hip_scene *sc, const psdr_render_args *a, int64_t lane_begin, int64_t lane_end, float *out, void *stream) {
     if (!out || lane_end <= lane_begin) return fail("bad lane range");
     return render_impl<false>(sc, a, false, nullptr, nullptr, out, lane_begin, lane_end, nullptr, stream);
+}
+
+int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, const float *d_rgb, const psdr_grads *g, void *stream) {
+    if (check_args(sc, a)) return 1;
+    if (!d_rgb || !g || !g->g_triangles || !g->g_bsdf || !g->g_emitter) return fail("null gradient buffer");
+    if (a->pix_ids) return fail("reverse mode of batch rendering is not supported");
+    if (a->max_depth > kAdjMaxDepth) return fail("reverse mode supports max_depth <= 4");
+    const SceneTables &T = sc->T;
+    hipStream_t st = (hipStream_t) stream;
+    const long long npx = (long long) T.width * T.height;
+    const int count = a->shard_count > 1 ? a->shard_count : 1;
+    const int rank = count > 1 ? a->shard_rank : 0;
+    if (rank < 0 || rank >= count) return fail("bad shard rank");
+    SensorDev cam = sc->sensors[a->sensor_id];
+    for (int i = 0; i < 16; ++i) { cam.d_to_world.m[i] = 0.f; cam.d_world_to_sample.m[i] = 0.f; }     // probes only
+    const int terms = a->terms ? a->terms : 7;
+    if (a->zero_output) {
+        HIPCHK(hipMemsetAsync(g->g_triangles, 0, sizeof(float) * 22 * (size_t) T.n_tris, st));
+        HIPCHK(hipMemsetAsync(g->g_bsdf, 0, sizeof(float) * 3 * (size_t) std::max(1, T.n_bsdfs), st));
+        HIPCHK(hipMemsetAsync(g->g_emitter, 0, sizeof(float) * 3 * (size_t) std::max(1, T.n_emitters), st));
+        if (g->g_sec_edges && sc->E.n > 0) HIPCHK(hipMemsetAsync(g->g_sec_edges, 0, sizeof(float) * 6 * (size_t) sc->E.n, st));
+        if (g->g_prim_edges && cam.n_edges > 0) HIPCHK(hipMemsetAsync(g->g_prim_edges, 0, sizeof(float) * 4 * (size_t) cam.n_edges, st));
+    }
+    auto next_queue = [&](unsigned long long *&q) -> int {
+        q = (unsigned long long *) sc->queues.p + (sc->queue_slot++ % kQueueRing);
+        HIPCHK(hipMemsetAsync(q, 0, sizeof(unsigned long long), st));
+        return 0;
+    };
+    const size_t n_acc = (size_t) T.n_tris * 22 + (size_t) T.n_bsdfs * 3 + (size_t) T.n_emitters * 3;
+    const bool lds_acc = n_acc * sizeof(float) <= 32 * 1024;
+    const size_t adj_bytes = sizeof(float) * ((size_t) (kAdjHitWords + kAdjExtWords) * kBlock + (lds_acc ? n_acc : 0));
+    const size_t smem = sc->smem_bytes + adj_bytes;
+    if (smem > 160 * 1024) return fail("scene too large for the adjoint kernel's LDS records");
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void *) k_interior_adjoint<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *) k_interior_adjoint<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *) k_secondary_edges<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *) k_secondary_edges<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    if ((terms & PSDR_TERM_INTERIOR) && T.spp > 0) {
+        AdjointParams P{};
+        P.max_depth = a->max_depth; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[0].seed; P.skip = a->samplers[0].skip;
+        P.begin = 0; P.end = npx * T.spp; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
+        P.w = d_rgb; P.g_tri = g->g_triangles; P.g_bsdf = g->g_bsdf; P.g_emitter = g->g_emitter; P.lds_accum = lds_acc ? 1 : 0;
+        if (P.n_local > 0) {
+            if (next_queue(P.counter)) return 1;
+            const int grid = grid_for(sc, P.n_local);
+            if (sc->lds) hipLaunchKernelGGL((k_interior_adjoint<true>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, cam, P);
+            else hipLaunchKernelGGL((k_interior_adjoint<false>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, cam, P);
+        }
+    }
+    if ((terms & PSDR_TERM_PRIMARY) && T.sppe > 0 && cam.n_edges > 0) {
+        if (!g->g_prim_edges) return fail("g_prim_edges is required when the primary-edge term is requested");
+        PathParams P{};
+        P.max_depth = a->max_depth; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[1].seed; P.skip = a->samplers[1].skip;
+        P.begin = 0; P.end = npx * T.sppe; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
+        P.adj_w = d_rgb; P.g_prim = g->g_prim_edges;
+        if (P.n_local > 0) {
+            if (next_queue(P.counter)) return 1;
+            if (sc->lds) LAUNCH((k_paths<false, true, false, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, (Counters *) nullptr);
+            else LAUNCH((k_paths<false, false, false, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, (Counters *) nullptr);
+        }
+    }
+    if ((terms & PSDR_TERM_SECONDARY) && T.sppse > 0 && sc->E.n > 0) {
+        if (!g->g_sec_edges) return fail("g_sec_edges is required when the secondary-edge term is requested");
+        PathParams P{};
+        P.max_depth = a->max_depth; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[2].seed; P.skip = a->samplers[2].skip;
+        P.begin = 0; P.end = npx * T.sppse; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
+        P.adj_w = d_rgb; P.g_sec = g->g_sec_edges; P.g_tri = g->g_triangles;
+        GuidingDev G{};
+        const int use_g = a->guiding ? 1 : 0;
+        if (a->guiding) G = a->guiding->G;
+        if (P.n_local > 0) {
+            if (next_queue(P.counter)) return 1;
+            const int grid = grid_for(sc, P.n_local);
+            if (sc->lds) hipLaunchKernelGGL((k_secondary_edges<true, false, true>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, (Counters *) nullptr);
+            else hipLaunchKernelGGL((k_secondary_edges<false, false, true>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, (Counters *) nullptr);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 int psdr_hip_trace(const psdr_hip_scene *sc, int32_t n, const float *o, const float *d, int32_t *out_tri, float *out_uv, float *out_t, void *stream) {

@@ -44,7 +44,7 @@ PSDR_DEV SensorDirectSample sample_direct(const SceneTables &T, const SensorDev 
     return r;
 }
 
-struct BoundarySegSampleDirect { bool valid; float pdf; Vec3d p0; Vec3f edge, edge2, p2, n; int emitter_slot; };
+struct BoundarySegSampleDirect { bool valid; float pdf; Vec3d p0; Vec3f edge, edge2, p2, n; int emitter_slot; int edge_id; float s1; };
 
 PSDR_DEV int sign_eps(float x, float eps) { return x > eps ? 1 : (x < -eps ? -1 : 0); }     // reference utils.h:47-53
 PSDR_DEV float sign1(float x) { return signbit_(x) ? -1.f : 1.f; }                          // drjit::sign
@@ -62,6 +62,7 @@ template <bool LDS> PSDR_DEV BoundarySegSampleDirect sample_boundary_segment_dir
     r.p0 = Vec3d(fma_(Dual(e1.x, de1.x), s1, Dual(p0.x, dp0.x)), fma_(Dual(e1.y, de1.y), s1, Dual(p0.y, dp0.y)), fma_(Dual(e1.z, de1.z), s1, Dual(p0.z, dp0.z)));
     r.edge = normalize(e1);
     r.edge2 = p2 - p0;
+    r.edge_id = ei; r.s1 = sample1;
     const Vec3f p0v = detach(r.p0);
     pdf0 /= norm(e1);
     const PositionSample<false> ps2 = sample_emitter_position<false, LDS>(S, s3.y, s3.z);

@@ -28,6 +28,11 @@ struct PathParams {
     long long n_local;               // number of local work items (multiple of 256)
     unsigned long long *counter;     // work queue head (zeroed before launch)
     float *out, *dout, *lanes_out;
+    // reverse mode of the edge terms (NULL = forward): w = d loss / d image; outputs are adjoints of the edge tables
+    const float *adj_w;
+    float *g_prim;                   // [n_primary_edges * 4]  (p0.xy, p1.xy in sample space)
+    float *g_sec;                    // [n_sec_edges * 6]      (p0, e1)
+    float *g_tri;                    // [n_tris * 22]
 };
 
 constexpr int kFetchBatch = 256;
@@ -57,7 +62,8 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
     // MODE 1 extras
     int side = 0;
     Vec3f Ln(0.f), dir_p(0.f);
-    float edge_xdn_v = 0.f, edge_xdn_d = 0.f, edge_pdf = 1.f;
+    float edge_xdn_v = 0.f, edge_xdn_d = 0.f, edge_pdf = 1.f, edge_s = 0.f, edge_nx = 0.f, edge_ny = 0.f;
+    int edge_i = 0;
     bool edge_valid = false;
     static_assert(MODE == 0 || !AD, "the primary-edge paths are traced in C mode");
 
@@ -109,7 +115,7 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
                         dir_p = ray_p.d;
                         if constexpr (!AD) ext = ray_n;
                         side = 0;
-                        edge_xdn_v = x_dot_n.v; edge_xdn_d = x_dot_n.d; edge_pdf = pdf;
+                        edge_xdn_v = x_dot_n.v; edge_xdn_d = x_dot_n.d; edge_pdf = pdf; edge_s = s; edge_nx = nx; edge_ny = ny; edge_i = ei;
                         if (!edge_valid) busy = false;       // Li(..., valid=false) contributes nothing
                     }
                 }
@@ -241,13 +247,30 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
                     const Vec3f Lp = detach(res);
                     const Vec3f dL = (Ln - Lp) / edge_pdf;
                     const float o3[3] = {dL.x, dL.y, dL.z};
+                    if (P.adj_w == nullptr) {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const float pv = edge_xdn_v * o3[c];
-                        float dv = edge_xdn_d * o3[c];
-                        if (!finite_(pv) || !finite_(dv)) dv = 0.f;
-                        if (T.sppe > 1) dv /= (float) T.sppe;
-                        if (dv != 0.f) atomicAdd(&P.dout[3 * (long long) pix_slot + c], dv);
+                        for (int c = 0; c < 3; ++c) {
+                            const float pv = edge_xdn_v * o3[c];
+                            float dv = edge_xdn_d * o3[c];
+                            if (!finite_(pv) || !finite_(dv)) dv = 0.f;
+                            if (T.sppe > 1) dv /= (float) T.sppe;
+                            if (dv != 0.f) atomicAdd(&P.dout[3 * (long long) pix_slot + c], dv);
+                        }
+                    } else {
+                        // adjoint: the tangent is d(x_dot_n) * o3 / sppe with d(x_dot_n) = n . ((1-s) d p0 + s d p1)
+                        float kw = 0.f;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            float k = o3[c];
+                            if (!finite_(edge_xdn_v * k) || !finite_(k)) k = 0.f;
+                            if (T.sppe > 1) k /= (float) T.sppe;
+                            kw += P.adj_w[3 * (long long) pix_slot + c] * k;
+                        }
+                        if (kw != 0.f) {
+                            const float a = (1.0f - edge_s) * kw, b = edge_s * kw;
+                            atomicAdd(&P.g_prim[4 * edge_i], edge_nx * a); atomicAdd(&P.g_prim[4 * edge_i + 1], edge_ny * a);
+                            atomicAdd(&P.g_prim[4 * edge_i + 2], edge_nx * b); atomicAdd(&P.g_prim[4 * edge_i + 3], edge_ny * b);
+                        }
                     }
                     busy = false;
                 }

@@ -57,6 +57,33 @@ template <bool LDS> struct SceneView {
     int *stack;                // this lane's LDS traversal stack, stride kBlock
     unsigned int c_nodes, c_tris, c_rays, c_hits;   // instrumented build only
 
+    // ---- reverse mode (k_adjoint only; constant 0 everywhere else, so the compiler folds it away)
+    // The adjoint of a path is obtained by re-running its D-mode shading with ONE-HOT tangents ("probes")
+    // on the scene quantities the path touched.  The hits found by the first (recording) run are replayed
+    // instead of traversing again, so a probe costs shading only.
+    int mode;                  // 0 = trace, 1 = trace + record hits, 2 = replay recorded hits
+    float *rec;                // this lane's LDS record, stride kBlock: 4 words per hit (slot, u, v, t)
+    int rec_i, rec_n;          // replay cursor / number of recorded hits
+    int *ext;                  // extra triangle slots read without a trace (light samples), stride kBlock
+    int ext_n;
+    int probe_kind;            // 0 none, 1 triangle field, 2 bsdf reflectance, 3 emitter radiance, 4 camera to_world
+    int probe_id, probe_comp;
+
+    PSDR_DEV bool tan_on() const { return probe_kind != 0 || T->has_tangent != 0; }
+    // word k (0..5) of the 22-float tangent row [p0 e1 e2 n0 n1 n2 fn area] of triangle slot `slot`
+    PSDR_DEV float4 tanw(int slot, int k) const {
+        if (probe_kind == 0) return B[T->tan_off + 6 * slot + k];
+        const bool on = probe_kind == 1 && slot == probe_id && (probe_comp >> 2) == k;
+        const int l = probe_comp & 3;
+        return make_float4(on && l == 0 ? 1.f : 0.f, on && l == 1 ? 1.f : 0.f, on && l == 2 ? 1.f : 0.f, on && l == 3 ? 1.f : 0.f);
+    }
+    PSDR_DEV float4 rgb_tan(int word, int kind, int id) const {      // tangent of a bsdf / emitter colour record
+        if (probe_kind == 0) return B[word];
+        const bool on = probe_kind == kind && id == probe_id;
+        return make_float4(on && probe_comp == 0 ? 1.f : 0.f, on && probe_comp == 1 ? 1.f : 0.f, on && probe_comp == 2 ? 1.f : 0.f, 0.f);
+    }
+    PSDR_DEV void note_slot(int slot) { if (mode == 1 && ext_n < 8) { ext[ext_n * kBlock] = slot; ++ext_n; } }
+
     PSDR_DEV float4 ld(int word) const { return B[word]; }
     PSDR_DEV float ldf(int word_off, int idx) const { return reinterpret_cast<const float *>(B + word_off)[idx]; }
     PSDR_DEV int ldi(int word_off, int idx) const { return reinterpret_cast<const int *>(B + word_off)[idx]; }
@@ -80,8 +107,30 @@ PSDR_DEV bool tri_test(const float4 &a, const float4 &b, const float4 &c, const 
 
 // Closest hit in (RayEpsilon, 1e8), ties -> smallest original triangle id
 // (replaces jit_optix_ray_trace, reference scene_optix.cpp:343-410; NaN rays miss, :348-353).
+template <bool LDS, bool COUNT> PSDR_DEV Hit trace_scene(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d);
+
 template <bool LDS, bool COUNT>
 PSDR_DEV Hit trace(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
+    if (S.mode == 2) {                       // replay: pop the hit the recording run found for this ray
+        Hit h; h.slot = -1; h.u = h.v = h.t = 0.f;
+        if (S.rec_i < S.rec_n) {
+            const float *r = S.rec + 4 * S.rec_i * kBlock;
+            h.slot = __float_as_int(r[0]); h.u = r[kBlock]; h.v = r[2 * kBlock]; h.t = r[3 * kBlock];
+        }
+        ++S.rec_i;
+        return h;
+    }
+    const Hit h = trace_scene<LDS, COUNT>(S, o, d);
+    if (S.mode == 1) {
+        float *r = S.rec + 4 * S.rec_n * kBlock;
+        r[0] = __int_as_float(h.slot); r[kBlock] = h.u; r[2 * kBlock] = h.v; r[3 * kBlock] = h.t;
+        ++S.rec_n;
+    }
+    return h;
+}
+
+template <bool LDS, bool COUNT>
+PSDR_DEV Hit trace_scene(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
     Hit best; best.slot = -1; best.u = best.v = 0.f; best.t = 0.f;
     if (!(o.x == o.x && o.y == o.y && o.z == o.z && d.x == d.x && d.y == d.y && d.z == d.z)) return best;
     const SceneTables &T = *S.T;

@@ -47,9 +47,8 @@ template <bool AD, bool LDS> PSDR_DEV void load_geom(const SceneView<LDS> &S, in
     const float4 a = S.ld(w), b = S.ld(w + 1), c = S.ld(w + 2);
     Vec3f vp0(a.x, a.y, a.z), ve1(a.w, b.x, b.y), ve2(b.z, b.w, c.x);
     if constexpr (AD) {
-        if (T.has_tangent) {
-            const int g = T.tan_off + 6 * slot;
-            const float4 ta = S.ld(g), tb = S.ld(g + 1), tc = S.ld(g + 2);
+        if (S.tan_on()) {
+            const float4 ta = S.tanw(slot, 0), tb = S.tanw(slot, 1), tc = S.tanw(slot, 2);
             p0 = make_dual(vp0, Vec3f(ta.x, ta.y, ta.z)); e1 = make_dual(ve1, Vec3f(ta.w, tb.x, tb.y)); e2 = make_dual(ve2, Vec3f(tb.z, tb.w, tc.x));
         } else { p0 = promote(vp0); e1 = promote(ve1); e2 = promote(ve2); }
     } else { p0 = vp0; e1 = ve1; e2 = ve2; }
@@ -86,9 +85,8 @@ PSDR_DEV Its<AD> make_its(const SceneView<LDS> &S, const Hit &h, const RayT<AD> 
     const bool flat = (__float_as_int(s2.w) & 1) != 0;
     V n0, n1, n2;
     if constexpr (AD) {
-        if (T.has_tangent) {
-            const int g = T.tan_off + 6 * h.slot;
-            const float4 tc = S.ld(g + 2), td = S.ld(g + 3), te = S.ld(g + 4), tf = S.ld(g + 5);
+        if (S.tan_on()) {
+            const float4 tc = S.tanw(h.slot, 2), td = S.tanw(h.slot, 3), te = S.tanw(h.slot, 4), tf = S.tanw(h.slot, 5);
             n0 = make_dual(Vec3f(s0.x, s0.y, s0.z), Vec3f(tc.y, tc.z, tc.w));
             n1 = make_dual(Vec3f(s1.x, s1.y, s1.z), Vec3f(td.x, td.y, td.z));
             n2 = make_dual(Vec3f(s2.x, s2.y, s2.z), Vec3f(td.w, te.x, te.y));
@@ -189,7 +187,7 @@ template <bool AD, bool LDS> PSDR_DEV VecN<AD> eval_Le(const SceneView<LDS> &S, 
     if (e < 0 || !(detach(its.wi.z) > 0.f)) return V(Num<AD>(0.f));
     const int w = S.T->emit_off + 2 * e;
     const float4 a = S.ld(w);
-    if constexpr (AD) { const float4 b = S.ld(w + 1); return make_dual(Vec3f(a.x, a.y, a.z), Vec3f(b.x, b.y, b.z)); }
+    if constexpr (AD) { const float4 b = S.rgb_tan(w + 1, 3, e); return make_dual(Vec3f(a.x, a.y, a.z), Vec3f(b.x, b.y, b.z)); }
     else return Vec3f(a.x, a.y, a.z);
 }
 
@@ -222,8 +220,8 @@ template <bool AD, bool LDS> PSDR_DEV PositionSample<AD> sample_emitter_position
     const float4 s0 = S.ld(T.shade_off + 6 * slot), s3 = S.ld(T.shade_off + 6 * slot + 3);
     r.J = Num<AD>(1.f);
     if constexpr (AD) {
-        if (T.has_tangent) {
-            const float4 te = S.ld(T.tan_off + 6 * slot + 4), tf = S.ld(T.tan_off + 6 * slot + 5);
+        if (S.tan_on()) {
+            const float4 te = S.tanw(slot, 4), tf = S.tanw(slot, 5);
             r.n = make_dual(Vec3f(s3.x, s3.y, s3.z), Vec3f(te.z, te.w, tf.x));
             r.J = Dual(s0.w, tf.y) / Dual(s0.w);
         } else r.n = promote(Vec3f(s3.x, s3.y, s3.z));
@@ -250,7 +248,7 @@ template <bool AD, bool LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S
     if (__float_as_int(a.w) & 1) { wo.z = mulsign(wo.z, detach(wiz)); wiz = abs_(wiz); }
     if (!(active && detach(wiz) > 0.f && detach(wo.z) > 0.f)) return V(R(0.f));
     V refl;
-    if constexpr (AD) { const float4 b = S.ld(w + 1); refl = make_dual(Vec3f(a.x, a.y, a.z), Vec3f(b.x, b.y, b.z)); }
+    if constexpr (AD) { const float4 b = S.rgb_tan(w + 1, 2, mesh_bsdf(S, its.mesh)); refl = make_dual(Vec3f(a.x, a.y, a.z), Vec3f(b.x, b.y, b.z)); }
     else refl = Vec3f(a.x, a.y, a.z);
     return refl * R(kInvPi) * wo.z;
 }
@@ -324,6 +322,7 @@ PSDR_DEV VecN<AD> Li(SceneView<LDS> &S, LaneRng &rng, const RayT<AD> &ray_in, bo
             const bool its_is_emitter = mesh_emitter(S, its.mesh) >= 0;
             if (!its_is_emitter) {
                 PositionSample<AD> ps = sample_emitter_position<AD, LDS>(S, sx, sy);
+                S.note_slot(ps.slot);
                 V wod = ps.p - its.p;
                 const R dist_sqr = squared_norm(wod);
                 const R dist = safe_sqrt(dist_sqr);

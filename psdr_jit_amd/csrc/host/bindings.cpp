@@ -102,6 +102,8 @@ PYBIND11_MODULE(_psdr_core, m) {
     py::class_<PerspectiveCamera, Sensor>(m, "PerspectiveCamera", py::dynamic_attr())
         .def(py::init<float, float, float>())
         .def_property_readonly("world_to_sample", [](const PerspectiveCamera &c) { farr a({4, 4}); std::memcpy(a.mutable_data(), c.rec.world_to_sample, 64); return a; })
+        .def("_primary_edge_ids", [](const PerspectiveCamera &c) { return from_ivec(c.m_edges.ids, 3); })
+        .def("_camera_params", [](const PerspectiveCamera &c) { return py::make_tuple(c.m_fov_x, c.m_near_clip, c.m_far_clip); })
         .def("_primary_edges", [](const PerspectiveCamera &c, bool tangent) {
             const PrimaryEdges &e = c.m_edges;
             const size_t n = e.length.size();
@@ -211,6 +213,21 @@ PYBIND11_MODULE(_psdr_core, m) {
              py::call_guard<py::gil_scoped_release>())
         .def("_renderD", &Integrator::renderD, "scene"_a, "sensor_id"_a, "seed"_a, "pix_ids"_a, "n_pix"_a, "out"_a, "dout"_a, "stream"_a, "shard_rank"_a,
              "shard_count"_a, "terms"_a, py::call_guard<py::gil_scoped_release>());
+
+    m.def("_render_d_bwd", [](const Integrator &it, const Scene &scene, int sensor_id, const std::vector<uint64_t> &seeds, const std::vector<uint64_t> &skips,
+                              uintptr_t d_rgb, uintptr_t g_tri, uintptr_t g_bsdf, uintptr_t g_emitter, uintptr_t g_sec, uintptr_t g_prim, uintptr_t stream,
+                              int rank, int count, int terms) {
+        if (!scene.is_ready()) throw Exception("Input scene must be configured!");
+        psdr_render_args a;
+        std::memset(&a, 0, sizeof(a));
+        a.sensor_id = sensor_id; a.max_depth = it.max_depth(); a.hide_emitters = it.hide_emitters() ? 1 : 0;
+        for (int k = 0; k < 3; ++k) { a.samplers[k].seed = seeds[k]; a.samplers[k].skip = skips[k]; }
+        a.shard_rank = rank; a.shard_count = count; a.zero_output = 1; a.terms = terms; a.guiding = it.guiding(sensor_id);
+        psdr_grads g{reinterpret_cast<float *>(g_tri), reinterpret_cast<float *>(g_bsdf), reinterpret_cast<float *>(g_emitter),
+                     reinterpret_cast<float *>(g_sec), reinterpret_cast<float *>(g_prim)};
+        if (psdr_hip_render_d_bwd(scene.m_hip, &a, reinterpret_cast<const float *>(d_rgb), &g, reinterpret_cast<void *>(stream)))
+            throw Exception(std::string("libpsdr_hip: ") + psdr_hip_last_error());
+    });
 
     py::class_<PathTracer, Integrator>(m, "PathTracer", py::dynamic_attr())
         .def(py::init<int>(), "max_depth"_a = 1)

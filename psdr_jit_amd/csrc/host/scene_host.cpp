@@ -348,6 +348,7 @@ void PerspectiveCamera::configure(const Scene &scene, bool keep_edges) {
             pe.d_p0.push_back(q0.x.d); pe.d_p0.push_back(q0.y.d); pe.d_p1.push_back(q1.x.d); pe.d_p1.push_back(q1.y.d);
             pe.normal.push_back(-ey); pe.normal.push_back(ex);
             pe.length.push_back(len);
+            pe.ids.push_back(mesh->m_mesh_id); pe.ids.push_back(e.v0); pe.ids.push_back(e.v1);
         }
         PSDR_ASSERT_MSG(kept > 0, "slices(info) > 0");
     }

@@ -120,6 +120,7 @@ private:
 
 struct PrimaryEdges {
     std::vector<float> p0, p1, d_p0, d_p1, normal, length;
+    std::vector<int> ids;          // (mesh id, v0, v1) per kept edge: lets the host chain gradients back to vertices
     Distrb distrb;
 };
 
