@@ -80,6 +80,10 @@ PSDR_DEV float seg_scan(float v, int key, int lane_id) {
     return v;
 }
 
+template <bool LDS> PSDR_DEV float *scratch_base(float4 *smem, const SceneTables &T) {
+    return reinterpret_cast<float *>(smem + (LDS ? T.blob_words : 0)) + T.stack_depth * kBlock;
+}
+
 // ------------------------------------------------------------------------------------------------
 // interior term (MODE 0) and primary-edge term (MODE 1): persistent lanes with path regeneration, paths.h
 template <bool AD, bool LDS, bool COUNT, int MODE>
@@ -87,12 +91,20 @@ __global__ __launch_bounds__(kBlock, (AD ? 3 : 1)) void k_paths(const float4 *__
                                                   const PathParams P, Counters *ctr) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     SceneView<LDS> S = make_view<LDS>(blob, T, smem);
-    run_paths<AD, LDS, COUNT, MODE>(S, cam, P);
+    if (MODE == 1 && P.adj_w != nullptr && P.lds_acc) {
+        // reverse mode of the primary-edge term: 8.4 M samples add into a 42 x 4 table - accumulate per workgroup in LDS
+        float *acc = scratch_base<LDS>(smem, T);
+        for (int i = threadIdx.x; i < 4 * P.n_prim; i += kBlock) acc[i] = 0.f;
+        __syncthreads();
+        PathParams Q = P;
+        Q.g_prim = acc;
+        run_paths<AD, LDS, COUNT, MODE>(S, cam, Q);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 4 * P.n_prim; i += kBlock) if (acc[i] != 0.f) atomicAdd(&P.g_prim[i], acc[i]);
+    } else {
+        run_paths<AD, LDS, COUNT, MODE>(S, cam, P);
+    }
     if (COUNT) flush_counters(S, ctr);
-}
-
-template <bool LDS> PSDR_DEV float *scratch_base(float4 *smem, const SceneTables &T) {
-    return reinterpret_cast<float *>(smem + (LDS ? T.blob_words : 0)) + T.stack_depth * kBlock;
 }
 
 // reverse mode of the interior term (adjoint.h)
@@ -142,6 +154,11 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edges(const float4 *__rest
     BoundarySegSampleDirect bss;
     bss.valid = false;
     float pdf0 = 1.f;
+    if constexpr (ADJ) if (P.lds_acc) {
+        float *acc = scratch_base<LDS>(smem, T) + (kAdjHitWords + kAdjExtWords) * kBlock;
+        for (int i = threadIdx.x; i < 6 * P.n_sec + 22 * T.n_tris; i += kBlock) acc[i] = 0.f;
+        __syncthreads();
+    }
     for (;;) {
         for (int round = 0; round < 16; ++round) {
             const unsigned long long need = __ballot(!have);
@@ -176,6 +193,8 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edges(const float4 *__rest
         if constexpr (ADJ) if (have) {
             // reverse mode: record the three rays once, then probe the quantities the tangent is linear in
             float *rec = scratch_base<LDS>(smem, T) + threadIdx.x;
+            float *g_sec = P.lds_acc ? scratch_base<LDS>(smem, T) + (kAdjHitWords + kAdjExtWords) * kBlock : P.g_sec;
+            float *g_tri = P.lds_acc ? g_sec + 6 * P.n_sec : P.g_tri;
             S.rec = rec; S.mode = 1; S.rec_n = 0; S.rec_i = 0; S.probe_kind = 0;
             BoundarySegSampleDirect b0 = bss;
             b0.p0 = promote(detach(bss.p0));
@@ -206,7 +225,7 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edges(const float4 *__rest
                     BoundarySegSampleDirect bp = b0;
                     if (c == 0) bp.p0.x.d = 1.f; else if (c == 1) bp.p0.y.d = 1.f; else bp.p0.z.d = 1.f;
                     const float g = probe(bp);
-                    if (g != 0.f) { atomicAdd(&P.g_sec[6 * bss.edge_id + c], g); atomicAdd(&P.g_sec[6 * bss.edge_id + 3 + c], bss.s1 * g); }
+                    if (g != 0.f) { atomicAdd(&g_sec[6 * bss.edge_id + c], g); atomicAdd(&g_sec[6 * bss.edge_id + 3 + c], bss.s1 * g); }
                 }
                 for (int which = 0; which < 3; which += 2) {       // hit 0: emitter triangle, hit 2: camera-ray triangle
                     const int slot = __float_as_int(rec[4 * which * kBlock]);
@@ -216,7 +235,7 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edges(const float4 *__rest
                     for (int comp = 0; comp < 9; ++comp) {
                         S.probe_comp = comp;
                         const float g = probe(b0);
-                        if (g != 0.f) atomicAdd(&P.g_tri[22 * orig + comp], g);
+                        if (g != 0.f) atomicAdd(&g_tri[22 * orig + comp], g);
                     }
                     S.probe_kind = 0;
                 }
@@ -238,6 +257,12 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edges(const float4 *__rest
             }
             have = false;
         }
+    }
+    if constexpr (ADJ) if (P.lds_acc) {
+        float *acc = scratch_base<LDS>(smem, T) + (kAdjHitWords + kAdjExtWords) * kBlock;
+        __syncthreads();
+        for (int i = threadIdx.x; i < 6 * P.n_sec; i += kBlock) if (acc[i] != 0.f) atomicAdd(&P.g_sec[i], acc[i]);
+        for (int i = threadIdx.x; i < 22 * T.n_tris; i += kBlock) if (acc[6 * P.n_sec + i] != 0.f) atomicAdd(&P.g_tri[i], acc[6 * P.n_sec + i]);
     }
     if (COUNT) flush_counters(S, ctr);
 }
@@ -707,11 +732,13 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         PathParams P{};
         P.max_depth = a->max_depth; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[1].seed; P.skip = a->samplers[1].skip;
         P.begin = 0; P.end = npx * T.sppe; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
-        P.adj_w = d_rgb; P.g_prim = g->g_prim_edges;
+        P.adj_w = d_rgb; P.g_prim = g->g_prim_edges; P.n_prim = cam.n_edges; P.lds_acc = (cam.n_edges <= 2048) ? 1 : 0;
         if (P.n_local > 0) {
             if (next_queue(P.counter)) return 1;
-            if (sc->lds) LAUNCH((k_paths<false, true, false, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, (Counters *) nullptr);
-            else LAUNCH((k_paths<false, false, false, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, (Counters *) nullptr);
+            const int grid = grid_for(sc, P.n_local);
+            const size_t sm = sc->smem_bytes + (P.lds_acc ? sizeof(float) * 4 * (size_t) cam.n_edges : 0);
+            if (sc->lds) hipLaunchKernelGGL((k_paths<false, true, false, 1>), dim3(grid), dim3(kBlock), sm, st, sc->blob.as<float4>(), T, cam, P, (Counters *) nullptr);
+            else hipLaunchKernelGGL((k_paths<false, false, false, 1>), dim3(grid), dim3(kBlock), sm, st, sc->blob.as<float4>(), T, cam, P, (Counters *) nullptr);
         }
     }
     if ((terms & PSDR_TERM_SECONDARY) && T.sppse > 0 && sc->E.n > 0) {
@@ -719,15 +746,18 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         PathParams P{};
         P.max_depth = a->max_depth; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[2].seed; P.skip = a->samplers[2].skip;
         P.begin = 0; P.end = npx * T.sppse; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
-        P.adj_w = d_rgb; P.g_sec = g->g_sec_edges; P.g_tri = g->g_triangles;
+        P.adj_w = d_rgb; P.g_sec = g->g_sec_edges; P.g_tri = g->g_triangles; P.n_sec = sc->E.n;
+        const size_t sec_acc = sizeof(float) * (6 * (size_t) sc->E.n + 22 * (size_t) T.n_tris);
+        P.lds_acc = (sec_acc <= 48 * 1024) ? 1 : 0;
+        const size_t smem_sec = sc->smem_bytes + sizeof(float) * (size_t) (kAdjHitWords + kAdjExtWords) * kBlock + (P.lds_acc ? sec_acc : 0);
         GuidingDev G{};
         const int use_g = a->guiding ? 1 : 0;
         if (a->guiding) G = a->guiding->G;
         if (P.n_local > 0) {
             if (next_queue(P.counter)) return 1;
             const int grid = grid_for(sc, P.n_local);
-            if (sc->lds) hipLaunchKernelGGL((k_secondary_edges<true, false, true>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, (Counters *) nullptr);
-            else hipLaunchKernelGGL((k_secondary_edges<false, false, true>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, (Counters *) nullptr);
+            if (sc->lds) hipLaunchKernelGGL((k_secondary_edges<true, false, true>), dim3(grid), dim3(kBlock), smem_sec, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, (Counters *) nullptr);
+            else hipLaunchKernelGGL((k_secondary_edges<false, false, true>), dim3(grid), dim3(kBlock), smem_sec, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, (Counters *) nullptr);
         }
     }
     HIPCHK(hipGetLastError());

@@ -33,6 +33,7 @@ struct PathParams {
     float *g_prim;                   // [n_primary_edges * 4]  (p0.xy, p1.xy in sample space)
     float *g_sec;                    // [n_sec_edges * 6]      (p0, e1)
     float *g_tri;                    // [n_tris * 22]
+    int lds_acc, n_prim, n_sec;      // 1: the kernel accumulates the adjoint tables in LDS first (same-address atomics)
 };
 
 constexpr int kFetchBatch = 256;
