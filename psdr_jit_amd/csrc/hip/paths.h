@@ -37,6 +37,10 @@ struct PathParams {
 };
 
 constexpr int kFetchBatch = 256;
+#ifndef PSDR_REGEN_MIN
+#define PSDR_REGEN_MIN 1
+#endif
+constexpr int kRegenMin = PSDR_REGEN_MIN;
 
 template <bool AD, bool LDS, bool COUNT, int MODE>
 PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParams &P) {
@@ -78,7 +82,10 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
             else { q_next = (long long) base; q_end = q_next + kFetchBatch < P.n_local ? q_next + kFetchBatch : P.n_local; }
         }
         const unsigned long long need = __ballot(!busy);
-        if (need != 0ull && q_next < q_end) {
+        // regenerate only when enough lanes are idle: seeding a lane (two 64-bit TEA hashes + pcg32 seed, ~600
+        // instructions) runs under the mask of the fetching lanes, so doing it every iteration for a handful of
+        // lanes costs as much as doing it for a quarter of the wave
+        if (need != 0ull && q_next < q_end && (__popcll(need) >= kRegenMin || __ballot(busy) == 0ull)) {
             const int rank = __popcll(need & lt_mask);
             const long long item = q_next + rank;
             const int n_need = __popcll(need);
