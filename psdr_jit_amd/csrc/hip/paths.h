@@ -150,9 +150,18 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
                 ray1.o = its.p; ray1.d = wod;
             }
         }
+        // ------------------------------------------------------------------ [B] extension ray (drawn before the traces
+        // so that both rays of this vertex share one pass over the triangles; the draw order is unchanged)
+        BSDFSample bs; bs.wo = Vec3f(0.f, 0.f, 1.f); bs.pdf = 1.f; bs.valid = true;
+        if (at_vertex) {
+            const float s0 = rng.next_1d(), s1 = rng.next_1d(), s2 = rng.next_1d();
+            (void) s0;
+            bs = bsdf_sample<AD, LDS>(S, its, s1, s2, true);
+            ext.o = its.p; ext.d = to_world<AD>(its, bs.wo);
+        }
+        Hit h, hx;
+        trace2<LDS, COUNT>(S, detach(ray1.o), detach(ray1.d), do_nee, detach(ext.o), detach(ext.d), busy, h, hx);
         {
-            Hit h; h.slot = -1; h.u = h.v = h.t = 0.f;
-            if (do_nee) h = trace<LDS, COUNT>(S, detach(ray1.o), detach(ray1.d));
             if (do_nee && h.slot >= 0) {
                 if (COUNT) S.c_hits++;
                 const Its<AD> its1 = make_its<AD, LDS, false>(S, h, ray1, true);
@@ -169,16 +178,6 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
             }
         }
 
-        // ------------------------------------------------------------------ [B] extension ray
-        BSDFSample bs; bs.wo = Vec3f(0.f, 0.f, 1.f); bs.pdf = 1.f; bs.valid = true;
-        if (at_vertex) {
-            const float s0 = rng.next_1d(), s1 = rng.next_1d(), s2 = rng.next_1d();
-            (void) s0;
-            bs = bsdf_sample<AD, LDS>(S, its, s1, s2, true);
-            ext.o = its.p; ext.d = to_world<AD>(its, bs.wo);
-        }
-        Hit hx; hx.slot = -1; hx.u = hx.v = hx.t = 0.f;
-        if (busy) hx = trace<LDS, COUNT>(S, detach(ext.o), detach(ext.d));
         bool finished = false;
         if (busy) {
             if (COUNT) { if (hx.slot >= 0) S.c_hits++; }

@@ -89,6 +89,9 @@ template <bool LDS> struct SceneView {
     PSDR_DEV int ldi(int word_off, int idx) const { return reinterpret_cast<const int *>(B + word_off)[idx]; }
 };
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+PSDR_DEV f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 struct Hit { int slot; float u, v, t; };   // slot = device triangle slot (BVH leaf order), -1 = miss
 
 // Möller–Trumbore exactly as the reference's own ray_intersect_triangle (include/psdr/utils.h:82-93)
@@ -222,6 +225,60 @@ PSDR_DEV Hit trace_scene(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
         ref = S.stack[sp * kBlock];
     }
     return best;
+}
+
+// Two rays per lane through ONE pass over the triangles (the NEE shadow ray and the BSDF extension ray of the same
+// path vertex).  The scalar triangle loads, the loop control and the exec bookkeeping are shared and the two
+// independent dependency chains fill each other's latency slots; every ray still sees exactly tri_test's
+// arithmetic and the (t, id) order, so the hits equal two trace() calls.  Inactive rays are given a NaN origin,
+// which fails every comparison.  BVH scenes and the record/replay modes trace the rays one after the other.
+template <bool LDS, bool COUNT>
+PSDR_DEV void trace2(SceneView<LDS> &S, const Vec3f &oA_, const Vec3f &dA, bool actA, const Vec3f &oB_, const Vec3f &dB, bool actB,
+                     Hit &hA, Hit &hB) {
+    hA.slot = -1; hA.u = hA.v = hA.t = 0.f;
+    hB.slot = -1; hB.u = hB.v = hB.t = 0.f;
+    const SceneTables &T = *S.T;
+    if (S.mode != 0 || T.n_tris > kBruteForceMax) {
+        if (actA) hA = trace<LDS, COUNT>(S, oA_, dA);
+        if (actB) hB = trace<LDS, COUNT>(S, oB_, dB);
+        return;
+    }
+    const float qnan = __builtin_nanf("");
+    const Vec3f oA = actA ? oA_ : Vec3f(qnan), oB = actB ? oB_ : Vec3f(qnan);
+    if (COUNT) { const unsigned n = (actA ? 1u : 0u) + (actB ? 1u : 0u); S.c_rays += n; S.c_tris += n * (unsigned) T.n_tris; }
+    // Both rays ride in the two halves of packed-f32 registers: v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 do two
+    // IEEE f32 operations per lane per issue slot (the 157 TF VALU peak is the packed rate), element-wise identical
+    // to the scalar instructions, so the hits stay bit-equal to tri_test.
+    const f2 ox = {oA.x, oB.x}, oy = {oA.y, oB.y}, oz = {oA.z, oB.z};
+    const f2 dx = {dA.x, dB.x}, dy = {dA.y, dB.y}, dz = {dA.z, dB.z};
+    float btA = __builtin_inff(), btB = __builtin_inff();
+    int bidA = 0x7fffffff, bidB = 0x7fffffff;
+    const float4 *tri = S.G + T.trav_off;
+    float4 a = tri[0], b = tri[1], c = tri[2];
+    for (int k = 0; k < T.n_tris; ++k) {
+        const int kn = (k + 1 < T.n_tris) ? k + 1 : k;
+        const float4 na = tri[3 * kn], nb = tri[3 * kn + 1], nc = tri[3 * kn + 2];
+        const int id = __float_as_int(c.y);
+        const f2 e1x = a.w, e1y = b.x, e1z = b.y, e2x = b.z, e2y = b.w, e2z = c.x;
+        // h = cross(d, e2); det = dot(e1, h)
+        const f2 hx = pk_fma(dy, e2z, -(dz * e2y)), hy = pk_fma(dz, e2x, -(dx * e2z)), hz = pk_fma(dx, e2y, -(dy * e2x));
+        const f2 det = pk_fma(e1z, hz, pk_fma(e1y, hy, e1x * hx));
+        f2 f; f.x = 1.f / det.x; f.y = 1.f / det.y;
+        const f2 sx = ox - (f2) a.x, sy = oy - (f2) a.y, sz = oz - (f2) a.z;
+        const f2 u = f * pk_fma(sz, hz, pk_fma(sy, hy, sx * hx));
+        // q = cross(s, e1)
+        const f2 qx = pk_fma(sy, e1z, -(sz * e1y)), qy = pk_fma(sz, e1x, -(sx * e1z)), qz = pk_fma(sx, e1y, -(sy * e1x));
+        const f2 v = f * pk_fma(dz, qz, pk_fma(dy, qy, dx * qx));
+        const f2 t = f * pk_fma(e2z, qz, pk_fma(e2y, qy, e2x * qx));
+        const f2 uv = u + v;
+        const bool okA = (u.x >= 0.f) & (v.x >= 0.f) & (uv.x <= 1.f) & (t.x > kRayEpsilon) & (t.x < kTraceTMax);
+        const bool okB = (u.y >= 0.f) & (v.y >= 0.f) & (uv.y <= 1.f) & (t.y > kRayEpsilon) & (t.y < kTraceTMax);
+        const bool betA = okA & ((t.x < btA) | ((t.x == btA) & (id < bidA)));
+        const bool betB = okB & ((t.y < btB) | ((t.y == btB) & (id < bidB)));
+        if (betA) { btA = t.x; bidA = id; hA.slot = k; hA.u = u.x; hA.v = v.x; hA.t = t.x; }
+        if (betB) { btB = t.y; bidB = id; hB.slot = k; hB.u = u.y; hB.v = v.y; hB.t = t.y; }
+        a = na; b = nb; c = nc;
+    }
 }
 
 } // namespace psdr
