@@ -246,38 +246,77 @@ PSDR_DEV void trace2(SceneView<LDS> &S, const Vec3f &oA_, const Vec3f &dA, bool 
     const float qnan = __builtin_nanf("");
     const Vec3f oA = actA ? oA_ : Vec3f(qnan), oB = actB ? oB_ : Vec3f(qnan);
     if (COUNT) { const unsigned n = (actA ? 1u : 0u) + (actB ? 1u : 0u); S.c_rays += n; S.c_tris += n * (unsigned) T.n_tris; }
-    // Both rays ride in the two halves of packed-f32 registers: v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 do two
-    // IEEE f32 operations per lane per issue slot (the 157 TF VALU peak is the packed rate), element-wise identical
-    // to the scalar instructions, so the hits stay bit-equal to tri_test.
+    // Both rays ride in the two halves of packed-f32 registers (element-wise identical to the scalar instructions).
+    //
+    // Two phases.  The exact test spends more than half of its issue cycles on the IEEE division and on eight
+    // compares (measured on gfx950: v_mul/v_add/v_fmac 2 cycles per wave64, v_fma 3, v_cmp 4.3, v_rcp 8.2, the
+    // division sequence 44).  Phase 1 therefore only FILTERS: the Moeller-Trumbore numerators and the determinant,
+    // then one sign-folded min3 test that is conservative (it accepts everything tri_test accepts, with a 2^-18
+    // relative margin that covers the rounding of 1/det and of the three products) and a per-lane bit mask of the
+    // survivors.  Phase 2 runs the exact tri_test - same arithmetic, same (t, id) order as ever - on the 1-5
+    // surviving triangles of each lane.  The hits are bit-equal to the single-phase loop.
     const f2 ox = {oA.x, oB.x}, oy = {oA.y, oB.y}, oz = {oA.z, oB.z};
     const f2 dx = {dA.x, dB.x}, dy = {dA.y, dB.y}, dz = {dA.z, dB.z};
+    unsigned mA0 = 0u, mA1 = 0u, mB0 = 0u, mB1 = 0u;
+    {
+        const float4 *tri = S.G + T.trav_off;
+        float4 a = tri[0], b = tri[1], c = tri[2];
+        for (int k = 0; k < T.n_tris; ++k) {
+            const int kn = (k + 1 < T.n_tris) ? k + 1 : k;
+            const float4 na = tri[3 * kn], nb = tri[3 * kn + 1], nc = tri[3 * kn + 2];
+            const f2 e1x = a.w, e1y = b.x, e1z = b.y, e2x = b.z, e2y = b.w, e2z = c.x;
+            const f2 hx = pk_fma(dy, e2z, -(dz * e2y)), hy = pk_fma(dz, e2x, -(dx * e2z)), hz = pk_fma(dx, e2y, -(dy * e2x));
+            const f2 det = pk_fma(e1z, hz, pk_fma(e1y, hy, e1x * hx));
+            const f2 sx = ox - (f2) a.x, sy = oy - (f2) a.y, sz = oz - (f2) a.z;
+            const f2 un = pk_fma(sz, hz, pk_fma(sy, hy, sx * hx));
+            const f2 qx = pk_fma(sy, e1z, -(sz * e1y)), qy = pk_fma(sz, e1x, -(sx * e1z)), qz = pk_fma(sx, e1y, -(sy * e1x));
+            const f2 vn = pk_fma(dz, qz, pk_fma(dy, qy, dx * qx));
+            const f2 tn = pk_fma(e2z, qz, pk_fma(e2y, qy, e2x * qx));
+            const unsigned bit = 1u << (k & 31);
+            bool pass[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const unsigned db = __float_as_uint(det[r]), sg = db & 0x80000000u;
+                const float ad = __uint_as_float(db & 0x7fffffffu);
+                const float ua = __uint_as_float(__float_as_uint(un[r]) ^ sg), va = __uint_as_float(__float_as_uint(vn[r]) ^ sg);
+                const float ta = __uint_as_float(__float_as_uint(tn[r]) ^ sg);
+                const float m = __builtin_fminf(__builtin_fminf(ua, va), ad - (ua + va));       // v_min3_f32
+                pass[r] = __builtin_fminf(__builtin_fmaf(ad, 3.8146973e-06f, m), ta) >= 0.f;
+            }
+            if (k < 32) { mA0 |= pass[0] ? bit : 0u; mB0 |= pass[1] ? bit : 0u; }
+            else        { mA1 |= pass[0] ? bit : 0u; mB1 |= pass[1] ? bit : 0u; }
+            a = na; b = nb; c = nc;
+        }
+    }
     float btA = __builtin_inff(), btB = __builtin_inff();
     int bidA = 0x7fffffff, bidB = 0x7fffffff;
-    const float4 *tri = S.G + T.trav_off;
-    float4 a = tri[0], b = tri[1], c = tri[2];
-    for (int k = 0; k < T.n_tris; ++k) {
-        const int kn = (k + 1 < T.n_tris) ? k + 1 : k;
-        const float4 na = tri[3 * kn], nb = tri[3 * kn + 1], nc = tri[3 * kn + 2];
-        const int id = __float_as_int(c.y);
-        const f2 e1x = a.w, e1y = b.x, e1z = b.y, e2x = b.z, e2y = b.w, e2z = c.x;
-        // h = cross(d, e2); det = dot(e1, h)
+    for (;;) {
+        const bool moreA = (mA0 | mA1) != 0u, moreB = (mB0 | mB1) != 0u;
+        if (__ballot(moreA || moreB) == 0ull) break;
+        int kA = 0, kB = 0;
+        if (mA0 != 0u) { kA = __builtin_ctz(mA0); mA0 &= mA0 - 1u; } else if (mA1 != 0u) { kA = 32 + __builtin_ctz(mA1); mA1 &= mA1 - 1u; }
+        if (mB0 != 0u) { kB = __builtin_ctz(mB0); mB0 &= mB0 - 1u; } else if (mB1 != 0u) { kB = 32 + __builtin_ctz(mB1); mB1 &= mB1 - 1u; }
+        const float4 aA = S.ld(T.trav_off + 3 * kA), bA = S.ld(T.trav_off + 3 * kA + 1), cA = S.ld(T.trav_off + 3 * kA + 2);
+        const float4 aB = S.ld(T.trav_off + 3 * kB), bB = S.ld(T.trav_off + 3 * kB + 1), cB = S.ld(T.trav_off + 3 * kB + 2);
+        const f2 p0x = {aA.x, aB.x}, p0y = {aA.y, aB.y}, p0z = {aA.z, aB.z};
+        const f2 e1x = {aA.w, aB.w}, e1y = {bA.x, bB.x}, e1z = {bA.y, bB.y};
+        const f2 e2x = {bA.z, bB.z}, e2y = {bA.w, bB.w}, e2z = {cA.x, cB.x};
         const f2 hx = pk_fma(dy, e2z, -(dz * e2y)), hy = pk_fma(dz, e2x, -(dx * e2z)), hz = pk_fma(dx, e2y, -(dy * e2x));
         const f2 det = pk_fma(e1z, hz, pk_fma(e1y, hy, e1x * hx));
         f2 f; f.x = 1.f / det.x; f.y = 1.f / det.y;
-        const f2 sx = ox - (f2) a.x, sy = oy - (f2) a.y, sz = oz - (f2) a.z;
+        const f2 sx = ox - p0x, sy = oy - p0y, sz = oz - p0z;
         const f2 u = f * pk_fma(sz, hz, pk_fma(sy, hy, sx * hx));
-        // q = cross(s, e1)
         const f2 qx = pk_fma(sy, e1z, -(sz * e1y)), qy = pk_fma(sz, e1x, -(sx * e1z)), qz = pk_fma(sx, e1y, -(sy * e1x));
         const f2 v = f * pk_fma(dz, qz, pk_fma(dy, qy, dx * qx));
         const f2 t = f * pk_fma(e2z, qz, pk_fma(e2y, qy, e2x * qx));
         const f2 uv = u + v;
-        const bool okA = (u.x >= 0.f) & (v.x >= 0.f) & (uv.x <= 1.f) & (t.x > kRayEpsilon) & (t.x < kTraceTMax);
-        const bool okB = (u.y >= 0.f) & (v.y >= 0.f) & (uv.y <= 1.f) & (t.y > kRayEpsilon) & (t.y < kTraceTMax);
-        const bool betA = okA & ((t.x < btA) | ((t.x == btA) & (id < bidA)));
-        const bool betB = okB & ((t.y < btB) | ((t.y == btB) & (id < bidB)));
-        if (betA) { btA = t.x; bidA = id; hA.slot = k; hA.u = u.x; hA.v = v.x; hA.t = t.x; }
-        if (betB) { btB = t.y; bidB = id; hB.slot = k; hB.u = u.y; hB.v = v.y; hB.t = t.y; }
-        a = na; b = nb; c = nc;
+        const int idA = __float_as_int(cA.y), idB = __float_as_int(cB.y);
+        const bool okA = moreA & (u.x >= 0.f) & (v.x >= 0.f) & (uv.x <= 1.f) & (t.x > kRayEpsilon) & (t.x < kTraceTMax);
+        const bool okB = moreB & (u.y >= 0.f) & (v.y >= 0.f) & (uv.y <= 1.f) & (t.y > kRayEpsilon) & (t.y < kTraceTMax);
+        const bool betA = okA & ((t.x < btA) | ((t.x == btA) & (idA < bidA)));
+        const bool betB = okB & ((t.y < btB) | ((t.y == btB) & (idB < bidB)));
+        if (betA) { btA = t.x; bidA = idA; hA.slot = kA; hA.u = u.x; hA.v = v.x; hA.t = t.x; }
+        if (betB) { btB = t.y; bidB = idB; hB.slot = kB; hB.u = u.y; hB.v = v.y; hB.t = t.y; }
     }
 }
 

@@ -26,8 +26,9 @@ def short(name):
 
 
 def db_of(d):
-    f = glob.glob(os.path.join(OUT, d, "*_results.db"))
-    return sqlite3.connect(f[0]) if f else None
+    f = glob.glob(os.path.join(OUT, d, "**", "*_results.db"), recursive=True)
+    f.sort(key=os.path.getmtime)
+    return sqlite3.connect(f[-1]) if f else None
 
 
 def kernel_stats(tag):
@@ -50,7 +51,7 @@ def kernel_stats(tag):
 
 def pmc(tag):
     per = {}
-    for d in ("prof_fetch", "prof_write", "prof_l2", "prof_sq"):
+    for d in ("prof_fetch", "prof_write", "prof_l2", "prof_sq", "prof_sq2"):
         db = db_of(d)
         if db is None:
             continue
@@ -73,8 +74,11 @@ def pmc(tag):
                 fh.write("    %-28s %18.0f   bytes/launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024\n" % ("HBM traffic", t))
                 key = {"k_interior<true, true, false>": "k_interior<AD>", "k_primary_edges<true, false>": "k_primary_edges",
                        "k_paths<true, true, false, 0>": "k_interior<AD>", "k_paths<false, true, false, 1>": "k_primary_edges",
-                       "k_secondary_edges<true, false>": "k_secondary_edges"}.get(k, k)
+                       "k_secondary_edges<true, false>": "k_secondary_edges", "k_secondary_edges<true, false, false>": "k_secondary_edges"}.get(k, k)
                 traffic[key] = t
+            tc, ai = cs.get("SQ_THREAD_CYCLES_VALU", (None, 0))[0], cs.get("SQ_ACTIVE_INST_VALU", (None, 0))[0]
+            if tc is not None and ai:
+                fh.write("    %-28s %18.4f   SQ_THREAD_CYCLES_VALU / (64*SQ_ACTIVE_INST_VALU)\n" % ("VALU lane utilisation", tc / (64.0 * ai)))
             h, m = cs.get("TCC_HIT_sum", (None, 0))[0], cs.get("TCC_MISS_sum", (None, 0))[0]
             if h is not None and m is not None and h + m > 0:
                 fh.write("    %-28s %18.4f   TCC_HIT/(TCC_HIT+TCC_MISS)\n" % ("L2 hit rate", h / (h + m)))
