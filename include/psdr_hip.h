@@ -158,6 +158,9 @@ int psdr_hip_scene_stats(const psdr_hip_scene *scene, int32_t *n_nodes, int32_t 
 /* closest hit for a batch of rays (device arrays o[n*3], d[n*3] -> tri[n], uv[n*2], t[n]); parity aid */
 int psdr_hip_trace(const psdr_hip_scene *scene, int32_t n, const float *o, const float *d,
                    int32_t *out_tri, float *out_uv, float *out_t, void *stream);
+/* same query, two rays per lane through the two-ray tracer the path kernels use (rays 2i, 2i+1 share a lane) */
+int psdr_hip_trace_pairs(const psdr_hip_scene *scene, int32_t n, const float *o, const float *d,
+                         int32_t *out_tri, float *out_uv, float *out_t, void *stream);
 
 /* Integrator::renderC: out_rgb is [n_pixels*3] float32, pixel-interleaved, pixel = y*W + x */
 int psdr_hip_render_c(const psdr_hip_scene *scene, const psdr_render_args *args, float *out_rgb, void *stream);

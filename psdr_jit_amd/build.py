@@ -18,7 +18,7 @@ HIP_LIB = os.path.join(LIBDIR, "libpsdr_hip.so")
 CORE_LIB = os.path.join(HERE, "_psdr_core" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
 
 HIP_SRCS = [os.path.join(CSRC, "hip", f) for f in ("api.hip",)]
-HIP_DEPS = [os.path.join(CSRC, "hip", f) for f in ("dmath.h", "sampler.h", "scene_dev.h", "shade.h", "edges.h", "paths.h", "adjoint.h", "bvh.h")] + \
+HIP_DEPS = [os.path.join(CSRC, "hip", f) for f in ("dmath.h", "sampler.h", "scene_dev.h", "shade.h", "edges.h", "paths.h", "adjoint.h", "bvh.h", "filter.h")] + \
            [os.path.join(ROOT, "include", "psdr_hip.h")]
 HOST_SRCS = [os.path.join(CSRC, "host", f) for f in ("scene_host.cpp", "bindings.cpp")]
 HOST_DEPS = [os.path.join(CSRC, "host", f) for f in ("scene_host.h", "hnum.h")] + [os.path.join(ROOT, "include", "psdr_hip.h")]

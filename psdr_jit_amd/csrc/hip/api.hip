@@ -18,6 +18,7 @@
 
 #include "../../../include/psdr_hip.h"
 #include "bvh.h"
+#include "filter.h"
 #include "edges.h"
 #include "paths.h"
 #include "adjoint.h"
@@ -302,9 +303,25 @@ __global__ __launch_bounds__(kBlock) void k_guiding_round(const float4 *__restri
 // batch closest-hit query (parity aid for the traversal alone)
 template <bool LDS>
 __global__ __launch_bounds__(kBlock) void k_trace(const float4 *__restrict__ blob, const SceneTables T, int n, const float *__restrict__ o,
-                                                  const float *__restrict__ d, int *__restrict__ out_tri, float *__restrict__ out_uv, float *__restrict__ out_t) {
+                                                  const float *__restrict__ d, int *__restrict__ out_tri, float *__restrict__ out_uv, float *__restrict__ out_t,
+                                                  int pairs) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     SceneView<LDS> S = make_view<LDS>(blob, T, smem);
+    if (pairs) {
+        // lane i carries rays 2i and 2i+1 through the two-ray path (trace2) that the path kernels use
+        const long long np = ((long long) n + 1) / 2;
+        for (long long i = (long long) blockIdx.x * kBlock + threadIdx.x; i < ((np + kBlock - 1) / kBlock) * kBlock; i += (long long) gridDim.x * kBlock) {
+            const long long ia = 2 * i, ib = 2 * i + 1;
+            const bool actA = ia < n, actB = ib < n;
+            const long long ja = actA ? ia : 0, jb = actB ? ib : 0;
+            Hit hA, hB;
+            trace2<LDS, false>(S, Vec3f(o[3 * ja], o[3 * ja + 1], o[3 * ja + 2]), Vec3f(d[3 * ja], d[3 * ja + 1], d[3 * ja + 2]), actA,
+                               Vec3f(o[3 * jb], o[3 * jb + 1], o[3 * jb + 2]), Vec3f(d[3 * jb], d[3 * jb + 1], d[3 * jb + 2]), actB, hA, hB);
+            if (actA) { out_tri[ia] = hA.slot >= 0 ? __float_as_int(S.ld(T.trav_off + 3 * hA.slot + 2).y) : -1; out_uv[2 * ia] = hA.u; out_uv[2 * ia + 1] = hA.v; out_t[ia] = hA.t; }
+            if (actB) { out_tri[ib] = hB.slot >= 0 ? __float_as_int(S.ld(T.trav_off + 3 * hB.slot + 2).y) : -1; out_uv[2 * ib] = hB.u; out_uv[2 * ib + 1] = hB.v; out_t[ib] = hB.t; }
+        }
+        return;
+    }
     for (long long i = (long long) blockIdx.x * kBlock + threadIdx.x; i < (long long) ((n + kBlock - 1) / kBlock) * kBlock; i += (long long) gridDim.x * kBlock) {
         if (i < n) {
             const Hit h = trace<LDS, false>(S, Vec3f(o[3 * i], o[3 * i + 1], o[3 * i + 2]), Vec3f(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
@@ -410,6 +427,22 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     T.emit_off = (int) w;  w += 2 * (size_t) std::max(1, s->n_emitters);
     T.ecdf_off = (int) w;  w += words_for_floats(2 * (size_t) std::max(1, s->n_emitters));
     T.fcdf_off = (int) w;  w += words_for_floats(2 * (size_t) std::max(1, s->n_face_distrb));
+    std::vector<FilterPrim> filt;
+    build_filter_prims(tr.p0, tr.e1, tr.e2, bvh.order.data(), n, filt);
+    T.filt_off = (int) w;  w += 4 * filt.size();
+    T.n_filt = (int) filt.size();
+    {   // bounding sphere of the scene (for the absolute slack of the quad filter)
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (int i = 0; i < n; ++i)
+            for (int v = 0; v < 3; ++v)
+                for (int k = 0; k < 3; ++k) {
+                    const double x = (double) tr.p0[3 * i + k] + (v == 1 ? (double) tr.e1[3 * i + k] : v == 2 ? (double) tr.e2[3 * i + k] : 0.0);
+                    lo[k] = std::min(lo[k], x); hi[k] = std::max(hi[k], x);
+                }
+        double r2 = 0.0;
+        for (int k = 0; k < 3; ++k) { T.center[k] = n > 0 ? (float) (0.5 * (lo[k] + hi[k])) : 0.f; r2 += n > 0 ? 0.25 * (hi[k] - lo[k]) * (hi[k] - lo[k]) : 0.0; }
+        T.radius = (float) (std::sqrt(r2) * 1.0001);
+    }
     const psdr_sec_edges &se = s->sec_edges;
     SecEdgeTables &E = sc->E;
     E.n = se.n_edges; E.sum = se.sum;
@@ -460,6 +493,14 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
         }
     }
     for (int i = 0; i < n; ++i) blob[4 * (size_t) T.map_off + i] = ibits(orig2slot[i]);
+    for (size_t i = 0; i < filt.size(); ++i) {
+        const FilterPrim &f = filt[i];
+        const size_t fw = T.filt_off + 4 * i;
+        put4(blob, fw, f.p0[0], f.p0[1], f.p0[2], f.e1[0]);
+        put4(blob, fw + 1, f.e1[1], f.e1[2], f.e2[0], f.e2[1]);
+        put4(blob, fw + 2, f.e2[2], f.umax, f.vmax, f.smax);
+        put4(blob, fw + 3, f.da, f.db, ibits(f.slot_a | ((f.slot_b < 0 ? 0xff : f.slot_b) << 8)), f.k16);
+    }
     for (int i = 0; i < s->n_meshes; ++i) {
         const psdr_mesh_rec &m = s->meshes[i];
         put4(blob, T.mesh_off + 2 * (size_t) i, ibits(m.bsdf_id), ibits(m.emitter_id), ibits(m.face_offset), ibits(m.n_faces));
@@ -764,13 +805,19 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     return 0;
 }
 
-int psdr_hip_trace(const psdr_hip_scene *sc, int32_t n, const float *o, const float *d, int32_t *out_tri, float *out_uv, float *out_t, void *stream) {
+static int trace_impl(const psdr_hip_scene *sc, int32_t n, const float *o, const float *d, int32_t *out_tri, float *out_uv, float *out_t, void *stream, int pairs) {
     if (!sc) return fail("null scene");
     if (n <= 0) return 0;
-    if (sc->lds) LAUNCH((k_trace<true>), sc, (long long) n, stream, sc->blob.as<float4>(), sc->T, n, o, d, out_tri, out_uv, out_t);
-    else LAUNCH((k_trace<false>), sc, (long long) n, stream, sc->blob.as<float4>(), sc->T, n, o, d, out_tri, out_uv, out_t);
+    if (sc->lds) LAUNCH((k_trace<true>), sc, (long long) n, stream, sc->blob.as<float4>(), sc->T, n, o, d, out_tri, out_uv, out_t, pairs);
+    else LAUNCH((k_trace<false>), sc, (long long) n, stream, sc->blob.as<float4>(), sc->T, n, o, d, out_tri, out_uv, out_t, pairs);
     HIPCHK(hipGetLastError());
     return 0;
+}
+int psdr_hip_trace(const psdr_hip_scene *sc, int32_t n, const float *o, const float *d, int32_t *out_tri, float *out_uv, float *out_t, void *stream) {
+    return trace_impl(sc, n, o, d, out_tri, out_uv, out_t, stream, 0);
+}
+int psdr_hip_trace_pairs(const psdr_hip_scene *sc, int32_t n, const float *o, const float *d, int32_t *out_tri, float *out_uv, float *out_t, void *stream) {
+    return trace_impl(sc, n, o, d, out_tri, out_uv, out_t, stream, 1);
 }
 
 int psdr_hip_guiding_build(const psdr_hip_scene *sc, int32_t sensor_id, int32_t max_depth, const int32_t reso[4], int32_t nrounds, int32_t seed,

@@ -23,6 +23,8 @@ struct SceneTables {
     int nodes_off, trav_off, shade_off, tan_off, map_off, mesh_off, bsdf_off, emit_off, ecdf_off, fcdf_off;
     int n_nodes, n_tris, n_meshes, n_bsdfs, n_emitters, n_fcdf;
     int has_tangent, stack_depth;
+    int filt_off, n_filt;      // filter primitives of the brute-force tracer (4 words each, see filter.h)
+    float center[3], radius;   // bounding sphere of all vertices
     float emitter_sum;
     int blob_words;            // float4 count
     int width, height, spp, sppe, sppse;
@@ -140,35 +142,55 @@ PSDR_DEV Hit trace_scene(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
     float best_t = __builtin_inff();
     int best_id = 0x7fffffff;
     if (T.n_tris <= kBruteForceMax) {
-        // Tiny scenes (README Cornell box: 36 triangles): test every triangle.  The loop is wave-uniform, the
-        // triangle words are read with scalar loads into SGPRs, there is no stack, no LDS traffic and no
-        // divergence - for incoherent rays this beats any per-lane tree walk on a 64-wide SIMD machine.
-        // Same tri_test, same (t, id) order => same hit as the BVH path.
+        // Tiny scenes (README Cornell box: 36 triangles): no tree.  Every ray is tested against every filter
+        // primitive in a wave-uniform loop (primitive words arrive by scalar loads in SGPRs, no stack, no LDS traffic,
+        // no divergence - for incoherent rays this beats any per-lane tree walk on a 64-wide SIMD machine), and the
+        // exact tri_test then runs on the few surviving triangles of each lane.  See trace2 below for the two phases;
+        // this is its one-ray form.  Same tri_test, same (t, id) order => same hit as the BVH path.
         if (COUNT) { S.c_rays++; S.c_tris += (unsigned) T.n_tris; }
-        const float4 *tri = S.G + T.trav_off;       // (LDS broadcast reads measured 3 % slower than scalar loads)
-        // software-pipelined: the scalar loads of triangle k+1 are issued before triangle k is tested
-        float4 a = tri[0], b = tri[1], c = tri[2];
-        for (int k = 0; k < T.n_tris; ++k) {
-            const int kn = (k + 1 < T.n_tris) ? k + 1 : k;
-            const float4 na = tri[3 * kn], nb = tri[3 * kn + 1], nc = tri[3 * kn + 2];
-            // all of u, v, t unconditionally, ONE exec-masked region for the (rare) accept: the short-circuit form cost
-            // three s_and_saveexec / s_cbranch_execz pairs per triangle (SALU was 50 % of the VALU count)
-            float u, v, t;
-            {
+        unsigned m0 = 0u, m1 = 0u;
+        const float s_ray = norm(o - Vec3f(T.center[0], T.center[1], T.center[2])) + T.radius;
+        {
+            const float4 *prim = S.G + T.filt_off;
+            float4 a = prim[0], b = prim[1], c = prim[2], g = prim[3];
+            for (int k = 0; k < T.n_filt; ++k) {
+                const int kn = (k + 1 < T.n_filt) ? k + 1 : k;
+                const float4 na = prim[4 * kn], nb = prim[4 * kn + 1], nc = prim[4 * kn + 2], ng = prim[4 * kn + 3];
                 const Vec3f p0(a.x, a.y, a.z), e1(a.w, b.x, b.y), e2(b.z, b.w, c.x);
                 const Vec3f h = cross(d, e2);
-                const float f = 1.f / dot(e1, h);
+                const float det = dot(e1, h);
                 const Vec3f s = o - p0;
-                u = f * dot(s, h);
+                const float un = dot(s, h);
                 const Vec3f q = cross(s, e1);
-                v = f * dot(d, q);
-                t = f * dot(e2, q);
+                const float vn = dot(d, q), tn = dot(e2, q);
+                const unsigned db = __float_as_uint(det), sg = db & 0x80000000u;
+                const float ad = __uint_as_float(db & 0x7fffffffu);
+                const float ua = __uint_as_float(__float_as_uint(un) ^ sg), va = __uint_as_float(__float_as_uint(vn) ^ sg);
+                const float ta = __uint_as_float(__float_as_uint(tn) ^ sg);
+                const float hi_u = fmaf(c.y, ad, -ua), hi_v = fmaf(c.z, ad, -va), hi_s = fmaf(c.w, ad, -(ua + va));
+                const float m = __builtin_fminf(__builtin_fminf(__builtin_fminf(ua, va), __builtin_fminf(hi_u, hi_v)), hi_s);
+                const float kq = g.w * 32768.f, slack = g.w * (s_ray + kq);          // absolute slack of a quad (filter.h)
+                const bool pass = __builtin_fminf(fmaf(ad, 3.8146973e-06f, m) + slack, fmaf(slack, kq, ta)) >= 0.f;
+                const float sel = fmaf(g.y, ua, -(g.x * va)), band = fmaf(ad, 1e-3f, slack) * (g.x + g.y);
+                const int sab = __float_as_int(g.z), sa = sab & 0xff, sb = (sab >> 8) & 0xff;
+                const unsigned a_lo = sa < 32 ? 1u << sa : 0u, a_hi = sa >= 32 ? 1u << (sa - 32) : 0u;
+                const unsigned b_lo = sb < 32 ? 1u << sb : 0u, b_hi = (sb >= 32 && sb < 64) ? 1u << (sb - 32) : 0u;
+                const bool in_a = pass & (sel >= -band), in_b = pass & (sel <= band);
+                m0 |= (in_a ? a_lo : 0u) | (in_b ? b_lo : 0u);
+                m1 |= (in_a ? a_hi : 0u) | (in_b ? b_hi : 0u);
+                a = na; b = nb; c = nc; g = ng;
             }
+        }
+        for (;;) {
+            const bool more = (m0 | m1) != 0u;
+            if (__ballot(more) == 0ull) break;
+            int k = 0;
+            if (m0 != 0u) { k = __builtin_ctz(m0); m0 &= m0 - 1u; } else if (m1 != 0u) { k = 32 + __builtin_ctz(m1); m1 &= m1 - 1u; }
+            const float4 a = S.ld(T.trav_off + 3 * k), b = S.ld(T.trav_off + 3 * k + 1), c = S.ld(T.trav_off + 3 * k + 2);
+            float u, v, t;
+            const bool ok = more & tri_test(a, b, c, o, d, u, v, t);
             const int id = __float_as_int(c.y);
-            const bool ok = (u >= 0.f) & (v >= 0.f) & (u + v <= 1.f) & (t > kRayEpsilon) & (t < kTraceTMax);
-            const bool better = ok & ((t < best_t) | ((t == best_t) & (id < best_id)));
-            if (better) { best_t = t; best_id = id; best.slot = k; best.u = u; best.v = v; best.t = t; }
-            a = na; b = nb; c = nc;
+            if (ok & ((t < best_t) | ((t == best_t) & (id < best_id)))) { best_t = t; best_id = id; best.slot = k; best.u = u; best.v = v; best.t = t; }
         }
         return best;
     }
@@ -258,12 +280,15 @@ PSDR_DEV void trace2(SceneView<LDS> &S, const Vec3f &oA_, const Vec3f &dA, bool 
     const f2 ox = {oA.x, oB.x}, oy = {oA.y, oB.y}, oz = {oA.z, oB.z};
     const f2 dx = {dA.x, dB.x}, dy = {dA.y, dB.y}, dz = {dA.z, dB.z};
     unsigned mA0 = 0u, mA1 = 0u, mB0 = 0u, mB1 = 0u;
+    const Vec3f ctr(T.center[0], T.center[1], T.center[2]);
+    const f2 s_ray = {norm(oA - ctr) + T.radius, norm(oB - ctr) + T.radius};
     {
-        const float4 *tri = S.G + T.trav_off;
-        float4 a = tri[0], b = tri[1], c = tri[2];
-        for (int k = 0; k < T.n_tris; ++k) {
-            const int kn = (k + 1 < T.n_tris) ? k + 1 : k;
-            const float4 na = tri[3 * kn], nb = tri[3 * kn + 1], nc = tri[3 * kn + 2];
+        // filter primitives (filter.h): {p0.xyz, e1.x} {e1.yz, e2.xy} {e2.z, umax, vmax, smax} {da, db, slot_a, slot_b}
+        const float4 *prim = S.G + T.filt_off;
+        float4 a = prim[0], b = prim[1], c = prim[2], g = prim[3];
+        for (int k = 0; k < T.n_filt; ++k) {
+            const int kn = (k + 1 < T.n_filt) ? k + 1 : k;
+            const float4 na = prim[4 * kn], nb = prim[4 * kn + 1], nc = prim[4 * kn + 2], ng = prim[4 * kn + 3];
             const f2 e1x = a.w, e1y = b.x, e1z = b.y, e2x = b.z, e2y = b.w, e2z = c.x;
             const f2 hx = pk_fma(dy, e2z, -(dz * e2y)), hy = pk_fma(dz, e2x, -(dx * e2z)), hz = pk_fma(dx, e2y, -(dy * e2x));
             const f2 det = pk_fma(e1z, hz, pk_fma(e1y, hy, e1x * hx));
@@ -272,20 +297,35 @@ PSDR_DEV void trace2(SceneView<LDS> &S, const Vec3f &oA_, const Vec3f &dA, bool 
             const f2 qx = pk_fma(sy, e1z, -(sz * e1y)), qy = pk_fma(sz, e1x, -(sx * e1z)), qz = pk_fma(sx, e1y, -(sy * e1x));
             const f2 vn = pk_fma(dz, qz, pk_fma(dy, qy, dx * qx));
             const f2 tn = pk_fma(e2z, qz, pk_fma(e2y, qy, e2x * qx));
-            const unsigned bit = 1u << (k & 31);
-            bool pass[2];
+            // fold the sign of det into the numerators: u = ua/ad, v = va/ad, t = ta/ad with ad = |det|
+            f2 ua, va, ta, ad;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const unsigned db = __float_as_uint(det[r]), sg = db & 0x80000000u;
-                const float ad = __uint_as_float(db & 0x7fffffffu);
-                const float ua = __uint_as_float(__float_as_uint(un[r]) ^ sg), va = __uint_as_float(__float_as_uint(vn[r]) ^ sg);
-                const float ta = __uint_as_float(__float_as_uint(tn[r]) ^ sg);
-                const float m = __builtin_fminf(__builtin_fminf(ua, va), ad - (ua + va));       // v_min3_f32
-                pass[r] = __builtin_fminf(__builtin_fmaf(ad, 3.8146973e-06f, m), ta) >= 0.f;
+                ad[r] = __uint_as_float(db & 0x7fffffffu);
+                ua[r] = __uint_as_float(__float_as_uint(un[r]) ^ sg);
+                va[r] = __uint_as_float(__float_as_uint(vn[r]) ^ sg);
+                ta[r] = __uint_as_float(__float_as_uint(tn[r]) ^ sg);
             }
-            if (k < 32) { mA0 |= pass[0] ? bit : 0u; mB0 |= pass[1] ? bit : 0u; }
-            else        { mA1 |= pass[0] ? bit : 0u; mB1 |= pass[1] ? bit : 0u; }
-            a = na; b = nb; c = nc;
+            const f2 hi_u = pk_fma((f2) c.y, ad, -ua), hi_v = pk_fma((f2) c.z, ad, -va), hi_s = pk_fma((f2) c.w, ad, -(ua + va));
+            const float kq = g.w * 32768.f;
+            const f2 slack = (f2) g.w * (s_ray + (f2) kq);                    // absolute slack of a quad (filter.h)
+            const f2 margin = pk_fma(ad, (f2) 3.8146973e-06f, slack);         // 2^-18 |det| + slack
+            const f2 tlo = pk_fma(slack, (f2) kq, ta);
+            const f2 sel = pk_fma((f2) g.y, ua, -((f2) g.x * va));            // side of the quad's diagonal
+            const f2 band = pk_fma(ad, (f2) 1e-3f, slack) * (f2) (g.x + g.y);
+            const int sab = __float_as_int(g.z), sa = sab & 0xff, sb = (sab >> 8) & 0xff;
+            const unsigned a_lo = sa < 32 ? 1u << sa : 0u, a_hi = sa >= 32 ? 1u << (sa - 32) : 0u;
+            const unsigned b_lo = sb < 32 ? 1u << sb : 0u, b_hi = (sb >= 32 && sb < 64) ? 1u << (sb - 32) : 0u;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float m = __builtin_fminf(__builtin_fminf(__builtin_fminf(ua[r], va[r]), __builtin_fminf(hi_u[r], hi_v[r])), hi_s[r]);
+                const bool pass = __builtin_fminf(m + margin[r], tlo[r]) >= 0.f;
+                const bool in_a = pass & (sel[r] >= -band[r]), in_b = pass & (sel[r] <= band[r]);
+                const unsigned lo = (in_a ? a_lo : 0u) | (in_b ? b_lo : 0u), hi = (in_a ? a_hi : 0u) | (in_b ? b_hi : 0u);
+                if (r == 0) { mA0 |= lo; mA1 |= hi; } else { mB0 |= lo; mB1 |= hi; }
+            }
+            a = na; b = nb; c = nc; g = ng;
         }
     }
     float btA = __builtin_inff(), btB = __builtin_inff();

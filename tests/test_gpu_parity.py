@@ -74,6 +74,24 @@ def test_trace_matches_oracle(torch_cuda, psdr, orc, scene_name):
     o[:1000] = [208.0, 273.0, -800.0]
     d[1000:1010] = [0.0, 0.0, 1.0]
     d[1010] = [np.nan, 0.0, 1.0]
+    # boundary-segment-like rays: from a point on a triangle edge (or a vertex) towards a point on another triangle's
+    # edge / vertex - grazing, edge-on and in-plane rays, which is what the secondary-edge sampler produces and what
+    # stresses the conservative candidate filter of the brute-force tracer
+    ti = np.asarray(ref.triangle_info())[:, :9].astype(np.float64)
+    m = 100000
+    def edge_points(k):
+        tr = ti[rng.integers(0, len(ti), size=k)]
+        p0, e1, e2 = tr[:, 0:3], tr[:, 3:6], tr[:, 6:9]
+        s = rng.random(k)[:, None]
+        s[rng.random(k) < 0.2] = 0.0                     # vertices
+        which = rng.integers(0, 3, size=k)[:, None]
+        return np.where(which == 0, p0 + s * e1, np.where(which == 1, p0 + s * e2, p0 + e1 + s * (e2 - e1)))
+    so, st = edge_points(m), edge_points(m)
+    sd = st - so
+    ln = np.linalg.norm(sd, axis=1, keepdims=True)
+    keep = ln[:, 0] > 1e-3
+    o[2000:2000 + m][keep] = so[keep].astype(np.float32)
+    d[2000:2000 + m][keep] = (sd[keep] / ln[keep]).astype(np.float32)
     to, td = torch_cuda.from_numpy(o).cuda(), torch_cuda.from_numpy(d).cuda()
     tri = torch_cuda.empty(n, dtype=torch_cuda.int32, device="cuda")
     uv = torch_cuda.empty((n, 2), dtype=torch_cuda.float32, device="cuda")
@@ -83,6 +101,13 @@ def test_trace_matches_oracle(torch_cuda, psdr, orc, scene_name):
     assert np.array_equal(tri.cpu().numpy(), wtri)           # indices: bit exact
     hit = wtri >= 0
     assert np.array_equal(uv.cpu().numpy()[hit], wuv[hit]) and np.array_equal(t.cpu().numpy()[hit], wt[hit])
+    # the two-rays-per-lane tracer of the path kernels (odd count: the last lane carries one ray)
+    n2 = n - 1
+    tri.fill_(-7); uv.zero_(); t.zero_()
+    cabi.check(cabi.lib().psdr_hip_trace_pairs(sc._hip_handle(), n2, to.data_ptr(), td.data_ptr(), tri.data_ptr(), uv.data_ptr(), t.data_ptr(), None))
+    assert np.array_equal(tri.cpu().numpy()[:n2], wtri[:n2]) and int(tri[n2]) == -7
+    hit = wtri[:n2] >= 0
+    assert np.array_equal(uv.cpu().numpy()[:n2][hit], wuv[:n2][hit]) and np.array_equal(t.cpu().numpy()[:n2][hit], wt[:n2][hit])
 
 
 def _li_lanes(torch, sc, n, max_depth, seed, skip=0):
