@@ -42,8 +42,13 @@ typedef struct orc_bsdf {            /* Diffuse, include/psdr/bsdf/diffuse.h */
     int two_sided;
 } orc_bsdf;
 
-typedef struct orc_emitter {         /* AreaLight, include/psdr/emitter/area.h */
+typedef struct orc_emitter {         /* AreaLight (include/psdr/emitter/area.h) or EnvironmentMap (emitter/envmap.h) */
     float radiance[3], d_radiance[3];
+    int type;                        /* 0 = AreaLight, 1 = EnvironmentMap (at most one, Scene::add_EnvironmentMap) */
+    int env_width, env_height;       /* m_radiance.m_resolution */
+    const float *env_data;           /* [env_height*env_width*3] row-major rgb, lat-long */
+    float env_scale;                 /* m_scale */
+    float env_to_world_left[16], env_to_world_raw[16];
 } orc_emitter;
 
 typedef struct orc_camera {          /* PerspectiveCamera(fov_x, near, far) */

@@ -69,8 +69,15 @@ class BsdfSpec:
 
 @dataclass
 class EmitterSpec:
+    """AreaLight (type 0, attached to a mesh through MeshSpec.emitter_id) or EnvironmentMap (type 1: env_data is the
+    lat-long radiance image [H, W, 3]; the bounding cube is added by configure, as in the reference)."""
     radiance: tuple = (1.0, 1.0, 1.0)
     d_radiance: tuple = (0.0, 0.0, 0.0)
+    type: int = 0
+    env_data: Optional[np.ndarray] = None
+    env_scale: float = 1.0
+    env_to_world_left: np.ndarray = field(default_factory=_eye)
+    env_to_world_raw: np.ndarray = field(default_factory=_eye)
 
 
 @dataclass
@@ -118,7 +125,8 @@ class _Bsdf(C.Structure):
 
 
 class _Emitter(C.Structure):
-    _fields_ = [("radiance", _F3), ("d_radiance", _F3)]
+    _fields_ = [("radiance", _F3), ("d_radiance", _F3), ("type", C.c_int), ("env_width", C.c_int), ("env_height", C.c_int),
+                ("env_data", C.POINTER(C.c_float)), ("env_scale", C.c_float), ("env_to_world_left", _F16), ("env_to_world_raw", _F16)]
 
 
 class _Camera(C.Structure):
@@ -254,6 +262,15 @@ class OracleScene:
         for i, e in enumerate(spec.emitters):
             emitters[i].radiance = _F3(*e.radiance)
             emitters[i].d_radiance = _F3(*e.d_radiance)
+            emitters[i].type = int(e.type)
+            emitters[i].env_to_world_left, emitters[i].env_to_world_raw = _m16(e.env_to_world_left), _m16(e.env_to_world_raw)
+            emitters[i].env_scale = float(e.env_scale)
+            if e.type == 1:
+                img = np.ascontiguousarray(np.asarray(e.env_data, dtype=np.float32))
+                assert img.ndim == 3 and img.shape[2] == 3
+                self._keep.append(img)
+                emitters[i].env_height, emitters[i].env_width = img.shape[0], img.shape[1]
+                emitters[i].env_data = img.ctypes.data_as(C.POINTER(C.c_float))
         cams = (_Camera * len(spec.cameras))()
         for i, c in enumerate(spec.cameras):
             cams[i].fov_x, cams[i].near_clip, cams[i].far_clip = c.fov_x, c.near, c.far

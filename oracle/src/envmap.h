@@ -1,0 +1,185 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see num.h header).  PARITY UNPINNED.
+//
+// envmap.h — EnvironmentMap emitter (reference src/emitter/envmap.cpp:17-173), the lat-long Bitmap lookup it uses
+// (src/core/bitmap.cpp:47-128, envmap_mode), HyperCubeDistribution<2> (src/core/cube_distrb.cpp:9-64) and
+// ray_intersect_scene_aabb (include/psdr/utils.h:145-164).
+//
+// drjit's atan2 / acos / sincos are its own polynomial kernels and are not in /root/reference; the published Cephes
+// single-precision algorithms are restated here with explicit fma (the HIP path states the same), derivatives are the
+// analytic ones.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <vector>
+#include "scene.h"
+
+namespace orc {
+
+void sincos_cephes(float xx, float &s_out, float &c_out);     // integrator.cpp
+
+// ---------------------------------------------------------------- Cephes atanf / atan2f / asinf / acosf
+inline float atan_cephes(float xx) {
+    float x = std::fabs(xx), y;
+    if (x > 2.414213562373095f) { y = 1.5707963267948966f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
+    else y = 0.f;
+    const float z = x * x;
+    const float p = fma_(fma_(fma_(8.05374449538e-2f, z, -1.38776856032e-1f), z, 1.99777106478e-1f), z, -3.33329491539e-1f);
+    y += fma_(p * z, x, x);
+    return xx < 0.f ? -y : y;
+}
+inline float atan2_cephes(float y, float x) {
+    const float PIF = 3.141592653589793f, PIO2F = 1.5707963267948966f;
+    int code = 0;
+    if (x < 0.f) code = 2;
+    if (y < 0.f) code |= 1;
+    if (x == 0.f) {
+        if (code & 1) return -PIO2F;
+        if (y == 0.f) return 0.f;
+        return PIO2F;
+    }
+    if (y == 0.f) return (code & 2) ? PIF : 0.f;
+    const float w = code == 2 ? PIF : (code == 3 ? -PIF : 0.f);
+    return w + atan_cephes(y / x);
+}
+inline float asin_cephes(float xx) {
+    float a = std::fabs(xx), x, z;
+    bool flag = false;
+    if (a > 1.0f) return 0.f;
+    if (a < 1.0e-4f) return xx;
+    if (a > 0.5f) { z = 0.5f * (1.0f - a); x = std::sqrt(z); flag = true; }
+    else { x = a; z = x * x; }
+    const float p = fma_(fma_(fma_(fma_(4.2163199048e-2f, z, 2.4181311049e-2f), z, 4.5470025998e-2f), z, 7.4953002686e-2f), z, 1.6666752422e-1f);
+    z = fma_(p * z, x, x);
+    if (flag) { z = z + z; z = 1.5707963267948966f - z; }
+    return xx < 0.f ? -z : z;
+}
+inline float acos_cephes(float x) {
+    if (x < -0.5f) return 3.141592653589793f - 2.0f * asin_cephes(std::sqrt(0.5f * (1.0f + x)));
+    if (x > 0.5f) return 2.0f * asin_cephes(std::sqrt(0.5f * (1.0f - x)));
+    return 1.5707963267948966f - asin_cephes(x);
+}
+// drjit::safe_acos = acos(clamp(x, -1, 1)); d/dx = -1/sqrt(1 - x^2)
+inline float safe_acos_(float x) { return acos_cephes(std::min(std::max(x, -1.f), 1.f)); }
+inline Dual safe_acos_(const Dual &x) {
+    const float c = std::min(std::max(x.v, -1.f), 1.f);
+    return Dual(acos_cephes(c), -x.d / std::sqrt(fma_(-c, c, 1.f)));
+}
+inline float atan2_(float y, float x) { return atan2_cephes(y, x); }
+inline Dual atan2_(const Dual &y, const Dual &x) {
+    return Dual(atan2_cephes(y.v, x.v), fma_(x.v, y.d, -(y.v * x.d)) / fma_(x.v, x.v, y.v * y.v));
+}
+inline float floor_(float x) { return std::floor(x); }
+inline Dual floor_(const Dual &x) { return Dual(std::floor(x.v), 0.f); }
+
+// ---------------------------------------------------------------- Bitmap3fD (lat-long, envmap_mode) and the cell grid
+
+// Bitmap<3>::eval<ad>(uv, flip_v = false, envmap_mode = true) with the default m_rot = 0, m_scale = 1, m_trans = 0
+// (bitmap.cpp:47-128); the texel values carry no tangent (the lookup position does).
+template <typename R> V3<R> envmap_bitmap_eval(const EnvmapC &E, R u, R v) {
+    const int W = E.width, H = E.height;
+    float sr, cr;
+    sincos_cephes(0.f, sr, cr);                                                   // cos(m_rot), sin(m_rot)
+    R x = (u - R(0.5f)) * R(cr) + (v - R(0.5f)) * R(sr);
+    R y = -(u - R(0.5f)) * R(sr) + (v - R(0.5f)) * R(cr);
+    x = x + R(0.5f); y = y + R(0.5f);
+    x = x * R(1.f); y = y * R(1.f);                                               // uv *= m_scale
+    x = x - R(-.5f + 1.f / 2); y = y + R(-.5f + 1.f / 2);
+    x = x + R(0.f); y = y + R(0.f);                                               // uv += m_trans
+    x = x - R((float) (0.5 / W));                                                 // :83
+    x = x - floor_(x); y = y - floor_(y);
+    x = x * R((float) W); y = y * R((float) (H - 1));
+    int px = (int) std::floor(detach(x)), py = (int) std::floor(detach(y));
+    const R w1x = x - R((float) px), w1y = y - R((float) py), w0x = R(1.0f) - w1x, w0y = R(1.0f) - w1y;
+    const int yw = std::min(py, H - 2) * W;
+    const int xp1 = (px + 1) % W;
+    const int last = W * H - 1;
+    auto texel = [&](int i) { i = std::min(std::max(i, 0), last); return V3f(E.data[3 * i], E.data[3 * i + 1], E.data[3 * i + 2]); };
+    const V3f v00 = texel(yw + px), v10 = texel(yw + xp1), v01 = texel(yw + px + W), v11 = texel(yw + xp1 + W);
+    auto lerp3 = [](const R &a, const V3<R> &p, const R &b, const V3<R> &q) {
+        return V3<R>(fma_(a, p.x, b * q.x), fma_(a, p.y, b * q.y), fma_(a, p.z, b * q.z));
+    };
+    const V3<R> v0 = lerp3(w0x, V3<R>(v00), w1x, V3<R>(v10)), v1 = lerp3(w0x, V3<R>(v01), w1x, V3<R>(v11));
+    return lerp3(w0y, v0, w1y, v1);
+}
+
+// EnvironmentMap::configure (envmap.cpp:17-44)
+inline void envmap_configure(EnvmapC &E) {
+    if (!(E.width > 1 && E.height > 1)) throw std::runtime_error("EnvironmentMap: width > 1 && height > 1");
+    const int w2 = (E.width - 1) << 1, h2 = (E.height - 1) << 1;
+    E.reso[0] = w2; E.reso[1] = h2;
+    E.num_cells = w2 * h2;
+    E.unit[0] = 1.f / (float) w2; E.unit[1] = 1.f / (float) h2;
+    std::vector<float> mass((size_t) E.num_cells);
+    const float dtheta = Pi / (float) h2;
+    for (int idx = 0; idx < E.num_cells; ++idx) {
+        const int cx = idx / h2, cy = idx - cx * h2;                              // cube_distrb.cpp:22-29
+        const float u = ((float) cx + .5f) * E.unit[0], v = ((float) cy + .5f) * E.unit[1];
+        const V3f val = envmap_bitmap_eval<float>(E, u, v);
+        const float theta = ((float) (idx % h2) + .5f) * dtheta;
+        float s, c;
+        sincos_cephes(theta, s, c);
+        mass[idx] = (val.x * .2126f + val.y * .7152f + val.z * .0722f) * s;
+    }
+    E.cell_distrb.init(mass);
+    E.from_world = inverse(E.to_world);
+}
+
+// EnvironmentMap::eval_direction (envmap.cpp:59-77)
+template <bool ad> V3<Real<ad>> envmap_eval_direction(const EnvmapC &E, const V3<Real<ad>> &wi) {
+    using R = Real<ad>;
+    V3<R> v;
+    if constexpr (ad) v = transform_dir(E.from_world, wi); else v = transform_dir(detach(E.from_world), wi);
+    R u = atan2_(v.x, -v.z) * R(InvTwoPi), w = safe_acos_(v.y) * R(InvPi);
+    u = u - floor_(u); w = w - floor_(w);
+    return envmap_bitmap_eval<R>(E, u, w) * R(E.scale);
+}
+
+// HyperCubeDistribution<2>::sample_reuse / pdf (cube_distrb.cpp:42-64)
+inline float envmap_cell_sample_reuse(const EnvmapC &E, float &sx, float &sy) {
+    float pdf;
+    const int idx = E.cell_distrb.sample_reuse(sy, pdf);
+    const int cx = idx / E.reso[1], cy = idx - cx * E.reso[1];
+    sx = (sx + (float) cx) * E.unit[0];
+    sy = (sy + (float) cy) * E.unit[1];
+    return pdf * (float) E.num_cells;
+}
+inline float envmap_cell_pdf(const EnvmapC &E, float u, float v) {
+    const int ix = (int) std::floor(u * (float) E.reso[0]), iy = (int) std::floor(v * (float) E.reso[1]);
+    if (!(ix >= 0 && ix < E.reso[0] && iy >= 0 && iy < E.reso[1])) return 0.f;
+    const int idx = ix * E.reso[1] + iy;
+    return (E.cell_distrb.pmf[idx] / E.cell_distrb.sum) * (float) E.num_cells;
+}
+
+// EnvironmentMap::sample_direction (envmap.cpp:118-132)
+inline V3f envmap_sample_direction(const EnvmapC &E, float &sx, float &sy, float &pdf) {
+    pdf = envmap_cell_sample_reuse(E, sx, sy);
+    const float theta = sy * Pi, phi = sx * TwoPi;
+    float st, ct, sp, cp;
+    sincos_cephes(theta, st, ct);
+    sincos_cephes(phi, sp, cp);
+    const V3f d0(cp * st, sp * st, ct);                                           // sphdir, utils.h:56-61
+    V3f d(d0.y, d0.z, -d0.x);
+    const float inv_sin_theta = 1.f / std::sqrt(std::max(fma_(d.x, d.x, d.z * d.z), Epsilon * Epsilon));   // safe_rsqrt
+    if (pdf > Epsilon) pdf *= inv_sin_theta * (.5f / (Pi * Pi));
+    return transform_dir(detach(E.to_world), d);
+}
+
+// ray_intersect_scene_aabb<false> (utils.h:145-164)
+inline void ray_intersect_scene_aabb(const V3f &o, const V3f &d, const V3f &lower, const V3f &upper, float &t, V3f &n, float &G) {
+    const float t1[3] = {(lower.x - o.x) / d.x, (lower.y - o.y) / d.y, (lower.z - o.z) / d.z};
+    const float t2[3] = {(upper.x - o.x) / d.x, (upper.y - o.y) / d.y, (upper.z - o.z) / d.z};
+    const float dd[3] = {d.x, d.y, d.z};
+    float t2p[3];
+    for (int i = 0; i < 3; ++i) t2p[i] = std::fmax(t1[i], t2[i]);                 // drjit::maximum
+    t = t2p[0];
+    int idx = 0;
+    for (int i = 1; i < 3; ++i) if (t2p[i] < t) { t = t2p[i]; idx = i; }          // argmin, utils.h:95-105
+    float nn[3] = {0.f, 0.f, 0.f};
+    const float sg = dd[idx] > 0.f ? 1.f : (dd[idx] < 0.f ? -1.f : dd[idx]);      // drjit::sign (copysign(1, x); +-0 irrelevant here)
+    nn[idx] = -sg;
+    n = V3f(nn[0], nn[1], nn[2]);
+    G = dot(n, -d) * (1.f / (t * t));
+}
+
+} // namespace orc

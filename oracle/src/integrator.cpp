@@ -4,6 +4,7 @@
 // reference file:line it follows.  `ad=false` is the reference's C instantiation, `ad=true` the
 // D instantiation with drjit's tape replaced by one forward tangent (num.h).
 #include "integrator.h"
+#include "envmap.h"
 #include <cmath>
 
 namespace orc {
@@ -38,7 +39,7 @@ template <bool ad> static V3<Real<ad>> to_world(const Frame<ad> &f, const V3<Rea
 // drjit is absent from /root/reference, so the published Cephes algorithm is restated here with every
 // multiply-add written as an explicit fma; the HIP path states the same algorithm, which makes the two
 // agree bit-for-bit on this step.
-static void sincos_cephes(float xx, float &s_out, float &c_out) {
+void sincos_cephes(float xx, float &s_out, float &c_out) {
     const float FOPI = 1.27323954473516f, DP1 = 0.78515625f, DP2 = 2.4187564849853515625e-4f, DP3 = 3.77489497744594108e-8f;
     float x = fabs(xx);
     int j = (int) (FOPI * x);
@@ -214,12 +215,17 @@ template Its<true> ray_intersect<true, true>(const Scene &, const RayD &, bool, 
 // ---------------------------------------------------------------- emitters
 template <bool ad> static bool is_emitter(const Scene &sc, const Its<ad> &its) { return its.valid && sc.meshes[its.mesh].emitter >= 0; }
 
-// intersection.h:35-42 -> area.cpp:17-26: one-sided, zero when the shape has no emitter
+// intersection.h:35-42 -> area.cpp:17-26 (one-sided, zero when the shape has no emitter) / envmap.cpp:47-56
 template <bool ad> static V3<Real<ad>> Le(const Scene &sc, const Its<ad> &its, bool active) {
     using V = V3<Real<ad>>;
     if (!its.valid || !active) return V(Real<ad>(0.f));
     int e = sc.meshes[its.mesh].emitter;
-    if (e < 0 || !(detach(its.wi.z) > 0.f)) return V(Real<ad>(0.f));
+    if (e < 0) return V(Real<ad>(0.f));
+    if (sc.emitters[e].type == 1) {
+        const V wi_world = to_world<ad>(its.sh, its.wi);
+        return envmap_eval_direction<ad>(sc.env, -wi_world);
+    }
+    if (!(detach(its.wi.z) > 0.f)) return V(Real<ad>(0.f));
     return pick<ad>(sc.emitters[e].radiance);
 }
 
@@ -242,27 +248,64 @@ template <bool ad> static PositionSample<ad> mesh_sample_position(const Scene &s
     return r;
 }
 
+// EnvironmentMap::__sample_position (envmap.cpp:91-116): a direction from the cell grid, carried to the scene's
+// bounding box; everything detached
+template <bool ad> static PositionSample<ad> envmap_sample_position(const Scene &sc, const V3f &ref_p, float sx, float sy) {
+    using R = Real<ad>;
+    PositionSample<ad> r;
+    float pdf, t, G;
+    const V3f d = envmap_sample_direction(sc.env, sx, sy, pdf);
+    V3f n;
+    ray_intersect_scene_aabb(ref_p, d, sc.env.lower, sc.env.upper, t, n, G);
+    const V3f p(fma_(d.x, t, ref_p.x), fma_(d.y, t, ref_p.y), fma_(d.z, t, ref_p.z));
+    r.p = V3<R>(R(p.x), R(p.y), R(p.z));
+    r.n = V3<R>(R(n.x), R(n.y), R(n.z));
+    r.pdf = pdf * G;
+    r.J = R(1.f);
+    r.valid = true;
+    return r;
+}
+
+template <bool ad> static PositionSample<ad> emitter_sample_position(const Scene &sc, int ei, const V3f &ref_p, float sx, float sy) {
+    if (sc.emitters[ei].type == 1) return envmap_sample_position<ad>(sc, ref_p, sx, sy);
+    return mesh_sample_position<ad>(sc, sc.meshes[sc.emitters[ei].mesh], sx, sy);
+}
+
 // scene.cpp:987-1013
-template <bool ad> static PositionSample<ad> sample_emitter_position(const Scene &sc, float sx, float sy) {
-    if (sc.emitters.size() == 1) return mesh_sample_position<ad>(sc, sc.meshes[sc.emitters[0].mesh], sx, sy);
+template <bool ad> static PositionSample<ad> sample_emitter_position(const Scene &sc, const V3f &ref_p, float sx, float sy) {
+    if (sc.emitters.size() == 1) return emitter_sample_position<ad>(sc, 0, ref_p, sx, sy);
     float epdf;
     int ei = sc.emitters_distrb.sample_reuse(sy, epdf);
-    PositionSample<ad> r = mesh_sample_position<ad>(sc, sc.meshes[sc.emitters[ei].mesh], sx, sy);
+    PositionSample<ad> r = emitter_sample_position<ad>(sc, ei, ref_p, sx, sy);
     r.pdf *= epdf;
     return r;
 }
 
-// scene.cpp:1016-1024 -> area.cpp:48-59 -> mesh.cpp:457-466
-template <bool ad> static float emitter_position_pdf(const Scene &sc, const Its<ad> &its) {
+// scene.cpp:1016-1024 -> area.cpp:48-59 -> mesh.cpp:457-466, or envmap.cpp:146-166
+template <bool ad> static float emitter_position_pdf(const Scene &sc, const V3f &ref_p, const Its<ad> &its) {
     if (!its.valid) return 0.f;
     const MeshC &m = sc.meshes[its.mesh];
     if (m.emitter < 0) return 0.f;
+    if (sc.emitters[m.emitter].type == 1) {
+        V3f d = detach(its.p) - ref_p;
+        const float dist2 = squared_norm(d);
+        d = d / safe_sqrt(dist2);
+        const float G = std::fabs(dot(d, detach(its.n))) / dist2;
+        d = transform_dir(detach(sc.env.from_world), d);
+        const float factor = G * (1.f / std::sqrt(std::max(fma_(d.x, d.x, d.z * d.z), Epsilon * Epsilon))) * (.5f / (Pi * Pi));
+        float u = atan2_cephes(d.x, -d.z) * InvTwoPi;
+        float v = safe_acos_(d.y) * InvPi;
+        u -= std::floor(u); v -= std::floor(v);
+        return envmap_cell_pdf(sc.env, u, v) * factor;
+    }
     return sc.emitters[m.emitter].sampling_weight * m.inv_total_area;
 }
 
 // ---------------------------------------------------------------- Diffuse BSDF (diffuse.cpp:24-108)
+// a mesh without BSDF (the envmap's bounding cube): drjit's vcall on a null pointer returns zeros
 template <bool ad> static V3<Real<ad>> bsdf_eval(const Scene &sc, const Its<ad> &its, V3<Real<ad>> wo, bool active) {
     using R = Real<ad>; using V = V3<R>;
+    if (sc.meshes[its.mesh].bsdf < 0) return V(R(0.f));
     const BsdfC &b = sc.bsdfs[sc.meshes[its.mesh].bsdf];
     R wiz = its.wi.z;
     if (b.two_sided) { wo.z = mulsign(wo.z, detach(wiz)); wiz = abs_(wiz); }
@@ -271,6 +314,7 @@ template <bool ad> static V3<Real<ad>> bsdf_eval(const Scene &sc, const Its<ad> 
     return pick<ad>(b.reflectance) * R(InvPi) * wo.z;
 }
 template <bool ad> static float bsdf_pdf(const Scene &sc, const Its<ad> &its, const V3<Real<ad>> &wo_, bool active) {
+    if (sc.meshes[its.mesh].bsdf < 0) return 0.f;
     const BsdfC &b = sc.bsdfs[sc.meshes[its.mesh].bsdf];
     float wiz = detach(its.wi.z), woz = detach(wo_.z);
     if (b.two_sided) { woz = mulsign(woz, wiz); wiz = fabs(wiz); }
@@ -279,6 +323,7 @@ template <bool ad> static float bsdf_pdf(const Scene &sc, const Its<ad> &its, co
 }
 struct BSDFSample { V3f wo; float pdf; bool valid; };
 template <bool ad> static BSDFSample bsdf_sample(const Scene &sc, const Its<ad> &its, const float s3[3], bool active) {
+    if (sc.meshes[its.mesh].bsdf < 0) { BSDFSample z; z.wo = V3f(0.f, 0.f, 0.f); z.pdf = 0.f; z.valid = false; return z; }
     const BsdfC &b = sc.bsdfs[sc.meshes[its.mesh].bsdf];
     float wiz = detach(its.wi.z);
     if (b.two_sided) wiz = fabs(wiz);
@@ -303,7 +348,7 @@ V3<Real<ad>> Li(const Scene &sc, LaneSampler &sampler, const Ray<ad> &ray_, bool
         if (!active) { sampler.rng.advance((uint64_t) 5 * (max_depth - depth)); break; }
         {   // next-event estimation
             float sx = sampler.next_1d(), sy = sampler.next_1d();
-            PositionSample<ad> ps = sample_emitter_position<ad>(sc, sx, sy);
+            PositionSample<ad> ps = sample_emitter_position<ad>(sc, detach(its.p), sx, sy);
             bool active_direct = active && ps.valid && !is_emitter<ad>(sc, its);
             V wod = ps.p - its.p;
             R dist_sqr = squared_norm(wod);
@@ -351,7 +396,7 @@ V3<Real<ad>> Li(const Scene &sc, LaneSampler &sampler, const Ray<ad> &ray_, bool
                 if (its1.t < Epsilon) bsdf_val = V(0.f);
                 else bsdf_val = bsdf_eval<ad>(sc, its, V(bs.wo.x, bs.wo.y, bs.wo.z), active) / bs.pdf;
             }
-            float weight2 = mis_weight(pdf0, emitter_position_pdf<ad>(sc, its1));
+            float weight2 = mis_weight(pdf0, emitter_position_pdf<ad>(sc, detach(its.p), its1));
             throughput *= bsdf_val;
             result += Le<ad>(sc, its1, active) * throughput * R(weight2);
             its = its1;
@@ -376,7 +421,7 @@ BoundarySegSampleDirect sample_boundary_segment_direct(const Scene &sc, V3f samp
     r.edge2 = detach(info.p2) - detach(info.p0);
     V3f p0 = detach(r.p0);
     pdf0 /= norm(e1);
-    PositionSample<false> ps2 = sample_emitter_position<false>(sc, sample3.y, sample3.z);
+    PositionSample<false> ps2 = sample_emitter_position<false>(sc, p0, sample3.y, sample3.z);
     r.p2 = ps2.p; r.n = ps2.n;
     V3f e = r.p2 - p0;
     float distSqr = squared_norm(e);

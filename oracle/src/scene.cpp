@@ -5,6 +5,8 @@
 // src/emitter/area.cpp:9-14) plus a closest-hit query that stands in for OptiX
 // (src/scene/scene_optix.cpp:343-410).
 #include "scene.h"
+#include "envmap.h"
+#include <limits>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -187,6 +189,18 @@ Scene *configure_scene(const orc_scene_desc &d, const int *active, int n_active)
         EmitterC ec;
         ec.radiance = V3d(Dual(e.radiance[0], e.d_radiance[0]), Dual(e.radiance[1], e.d_radiance[1]),
                           Dual(e.radiance[2], e.d_radiance[2]));
+        ec.type = e.type;
+        if (e.type == 1) {
+            if (sc->env_emitter >= 0) throw std::runtime_error("A scene is only allowed to have one envmap!");
+            sc->env_emitter = i;
+            EnvmapC &E = sc->env;
+            E.width = e.env_width; E.height = e.env_height;
+            if (!e.env_data || E.width < 1 || E.height < 1) throw std::runtime_error("EnvironmentMap: missing radiance data");
+            E.data.assign(e.env_data, e.env_data + (size_t) 3 * E.width * E.height);
+            E.scale = e.env_scale;
+            const float zero16[16] = {0};
+            E.to_world = make_m4d(e.env_to_world_left, zero16) * make_m4d(e.env_to_world_raw, zero16);      // envmap.cpp:41
+        }
         sc->emitters.push_back(ec);
     }
 
@@ -262,16 +276,74 @@ Scene *configure_scene(const orc_scene_desc &d, const int *active, int n_active)
         configure_camera(*sc, sc->cameras[ci], d.cameras[ci], keep);
     }
 
-    // --- emitters (area.cpp:9-14, scene.cpp:488-515)
+    // --- scene bounds (scene.cpp:357-371, 379-416): all mesh vertices and all camera positions.
+    // m_upper starts at numeric_limits<float>::min() (the smallest positive float, not the lowest), as in the reference.
+    {
+        float lo[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
+        float hi[3] = {std::numeric_limits<float>::min(), std::numeric_limits<float>::min(), std::numeric_limits<float>::min()};
+        auto grow = [&](const V3f &p) {
+            const float c[3] = {p.x, p.y, p.z};
+            for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], c[k]); hi[k] = std::max(hi[k], c[k]); }
+        };
+        for (const MeshC &m : sc->meshes) for (const V3d &v : m.verts) grow(detach(v));
+        for (const CameraC &c : sc->cameras) grow(detach(c.pos));
+        sc->lower = V3f(lo[0], lo[1], lo[2]); sc->upper = V3f(hi[0], hi[1], hi[2]);
+    }
+
+    // --- environment lighting: margin + bounding cube mesh (scene.cpp:434-485)
+    if (sc->env_emitter >= 0) {
+        const float ex[3] = {sc->upper.x - sc->lower.x, sc->upper.y - sc->lower.y, sc->upper.z - sc->lower.z};
+        const float margin = std::min(ex[0], std::min(ex[1], ex[2])) * 0.05f;
+        sc->lower = V3f(sc->lower.x - margin, sc->lower.y - margin, sc->lower.z - margin);
+        sc->upper = V3f(sc->upper.x + margin, sc->upper.y + margin, sc->upper.z + margin);
+        sc->env.lower = sc->lower; sc->env.upper = sc->upper;
+        const float lo[3] = {sc->lower.x, sc->lower.y, sc->lower.z}, hi[3] = {sc->upper.x, sc->upper.y, sc->upper.z};
+        static const int face_data[3][12] = {{0, 0, 1, 1, 2, 2, 0, 0, 0, 0, 4, 4}, {1, 3, 5, 7, 3, 7, 5, 4, 2, 6, 7, 6}, {3, 2, 7, 3, 7, 6, 1, 5, 6, 4, 5, 7}};
+        MeshC mc;
+        const int mi = (int) sc->meshes.size();
+        mc.face_offset = (int) sc->tris.size(); mc.n_faces = 12; mc.n_vertices = 8;
+        mc.bsdf = -1; mc.emitter = sc->env_emitter;
+        mc.use_face_normals = true; mc.enable_edges = false; mc.has_uv = false;
+        mc.verts.resize(8);
+        for (int i = 0; i < 8; ++i)
+            mc.verts[i] = V3d(Dual((i & 1) ? hi[0] : lo[0]), Dual((i & 2) ? hi[1] : lo[1]), Dual((i & 4) ? hi[2] : lo[2]));
+        mc.faces.resize(36);
+        for (int f = 0; f < 12; ++f) for (int k = 0; k < 3; ++k) mc.faces[3 * f + k] = face_data[k][f];
+        std::vector<Tri> tris;
+        process_mesh(mc.verts, mc.faces, 12, tris);
+        std::vector<float> areas(12);
+        for (int f = 0; f < 12; ++f) {
+            Tri &t = tris[f];
+            t.flat = true; t.mesh = mi;
+            for (int k = 0; k < 3; ++k) t.uv[k] = V2f(0.f, 0.f);
+            areas[f] = t.area.v;
+        }
+        mc.total_area = sum_f32(areas);
+        mc.inv_total_area = 1.f / mc.total_area;
+        mc.face_distrb.init(areas);
+        sc->tris.insert(sc->tris.end(), tris.begin(), tris.end());
+        sc->emitters[sc->env_emitter].mesh = mi;
+        sc->meshes.push_back(std::move(mc));
+    }
+
+    // --- emitters (area.cpp:9-14, envmap.cpp:17-44, scene.cpp:488-515)
     if (!sc->emitters.empty()) {
         std::vector<float> w;
+        double total_weight = 0.0;
         for (EmitterC &e : sc->emitters) {
             if (e.mesh < 0) throw std::runtime_error("emitter without mesh");
-            V3f r = detach(e.radiance);
-            float lum = r.x * .2126f + r.y * .7152f + r.z * .0722f;                  // utils.h:76-79
-            e.sampling_weight = sc->meshes[e.mesh].total_area * lum;
-            w.push_back(e.sampling_weight);
+            if (e.type == 1) {
+                envmap_configure(sc->env);
+                e.sampling_weight = 0.f;
+            } else {
+                V3f r = detach(e.radiance);
+                float lum = r.x * .2126f + r.y * .7152f + r.z * .0722f;              // utils.h:76-79
+                e.sampling_weight = sc->meshes[e.mesh].total_area * lum;
+            }
+            total_weight += e.sampling_weight;
         }
+        for (EmitterC &e : sc->emitters) if (e.type == 1) e.sampling_weight = (float) total_weight;   // scene.cpp:500-504
+        for (EmitterC &e : sc->emitters) w.push_back(e.sampling_weight);
         sc->emitters_distrb.init(w);
         float inv_total = 1.f / sc->emitters_distrb.sum;
         for (EmitterC &e : sc->emitters) e.sampling_weight *= inv_total;

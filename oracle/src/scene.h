@@ -16,6 +16,7 @@ namespace orc {
 // reference include/psdr/constants.h:12-17
 constexpr float Epsilon = 1e-5f, RayEpsilon = 1e-3f, ShadowEpsilon = 1e-3f, EdgeEpsilon = 1e-5f;
 constexpr float Pi = 3.14159265358979323846f, InvPi = 0.31830988618379067154f;
+constexpr float TwoPi = 6.28318530717958647692f, InvTwoPi = 0.15915494309189533577f;   // constants.h:21-23
 constexpr float TraceTMax = 100000000.f;   // scene_optix.cpp:376
 
 // sequential fp32 sum (drjit::sum is an fp32 device reduction whose order is unspecified)
@@ -44,8 +45,8 @@ struct Distrb {
     int sample_reuse(float &s, float &pdf) const {
         if (size == 1) { pdf = 1.f; return 0; }
         s *= sum;
-        int idx = size - 1;                     // binary_search over [0, size-1): first i with !(cmf[i] < s)
-        for (int i = 0; i < size - 1; ++i) if (!(cmf[i] < s)) { idx = i; break; }
+        // binary_search over [0, size-1): first i with !(cmf[i] < s), else size-1
+        int idx = (int) (std::lower_bound(cmf.begin(), cmf.begin() + (size - 1), s) - cmf.begin());
         if (idx > 0) s -= cmf[idx - 1];
         float p = pmf[idx];
         if (p > 0.f) s /= p;
@@ -79,7 +80,22 @@ struct MeshC {
     Distrb face_distrb;
 };
 struct BsdfC { int type; V3d reflectance; bool two_sided; };
-struct EmitterC { V3d radiance; int mesh = -1; float sampling_weight = 1.f; };
+// type 0 = AreaLight (area.h), 1 = EnvironmentMap (envmap.h); an envmap's mesh is the bounding cube scene.cpp:442-480 adds
+struct EmitterC { V3d radiance; int mesh = -1; float sampling_weight = 1.f; int type = 0; };
+
+struct EnvmapC {
+    int width = 0, height = 0;               // m_radiance.m_resolution
+    std::vector<float> data;                 // [height*width*3], row-major rgb
+    float scale = 1.f;                       // m_scale
+    M4d to_world, from_world;                // envmap.cpp:41-42
+    V3f lower, upper;                        // scene AABB + margin (scene.cpp:436-440)
+    // HyperCubeDistribution2f m_cell_distrb
+    int reso[2] = {0, 0};
+    int num_cells = 0;
+    float unit[2] = {0.f, 0.f};
+    Distrb cell_distrb;
+};
+
 
 struct CameraC {                   // PerspectiveCamera, src/sensor/perspective.cpp:10-152
     M4d to_world, world_to_sample, sample_to_world;
@@ -98,6 +114,9 @@ struct Scene {
     std::vector<MeshC> meshes;
     std::vector<BsdfC> bsdfs;
     std::vector<EmitterC> emitters;
+    int env_emitter = -1;              // index of the EnvironmentMap in emitters (Scene::m_emitter_env), -1 = none
+    EnvmapC env;
+    V3f lower, upper;                  // Scene::m_lower / m_upper
     std::vector<CameraC> cameras;
     std::vector<Tri> tris;
     std::vector<SecEdge> sec_edges;

@@ -130,3 +130,48 @@ def sphere_scene(width=512, height=512, spp=32, sppe=32, sppse=32):
     meshes[1].d_to_world_left = dT
     cam = CameraSpec(60.0, 0.000001, 10000000.0, to_world_raw=translate(278.0, 273.0, -500.0))
     return SceneSpec(meshes, bsdfs, emitters, [cam], width, height, spp, sppe, sppse)
+
+
+def synthetic_envmap(width=64, height=32, sun=True):
+    """Lat-long radiance image [H, W, 3] by a fixed formula (BASELINE config 5 / SURVEY §8d): a constant sky
+    (0.6, 0.7, 0.9) plus, when `sun`, one Gaussian sun of peak (40, 36, 30) at (u, v) = (0.30, 0.25), sigma 0.04."""
+    u = (np.arange(width, dtype=np.float64) + 0.5) / width
+    v = (np.arange(height, dtype=np.float64) + 0.5) / height
+    uu, vv = np.meshgrid(u, v)
+    img = np.empty((height, width, 3), dtype=np.float64)
+    img[...] = (0.6, 0.7, 0.9)
+    if sun:
+        du = np.minimum(np.abs(uu - 0.30), 1.0 - np.abs(uu - 0.30))
+        g = np.exp(-(du * du + (vv - 0.25) ** 2) / (2 * 0.04 ** 2))
+        img += g[..., None] * np.array([40.0, 36.0, 30.0])
+    return img.astype(np.float32)
+
+
+def envmap_scene(width=64, height=64, spp=4, sppe=0, sppse=0, param="albedo", env=None, area_light=False, floor_only=False):
+    """Cornell-box furniture (floor + the two boxes) under an environment map - the Forward_AD_envmap layout in
+    small.  param: 'albedo' (d box reflectance / dP = (1,1,1)), 'box_x' (small box translated by 100*P in x), None."""
+    bsdfs = [BsdfSpec((0.5, 0.5, 0.5), name="cat"), BsdfSpec((0.8, 0.8, 0.8), name="white"), BsdfSpec((0.0, 0.0, 0.0), name="light")]
+    emitters = [EmitterSpec(type=1, env_data=env if env is not None else synthetic_envmap(), env_scale=1.0)]
+    meshes = [_mesh("cbox_floor.obj", 1)]
+    if not floor_only:
+        meshes = [_mesh("cbox_smallbox.obj", 0), _mesh("cbox_largebox.obj", 0)] + meshes
+    if area_light:
+        emitters.append(EmitterSpec((20.0, 20.0, 8.0)))
+        meshes.append(_mesh("cbox_luminaire.obj", 2, emitter=1, raw=translate(0.0, -100.0, 0.0)))
+    cam = CameraSpec(60.0, 0.000001, 10000000.0, to_world_raw=translate(278.0, 400.0, -700.0) @ _rot_x(np.radians(25.0)))
+    if param == "albedo":
+        bsdfs[0].d_reflectance = (1.0, 1.0, 1.0)
+    elif param == "box_x" and not floor_only:
+        dT = np.zeros((4, 4), dtype=np.float32)
+        dT[0, 3] = 100.0
+        meshes[0].d_to_world_left = dT
+    elif param is not None:
+        raise ValueError(param)
+    return SceneSpec(meshes, bsdfs, emitters, [cam], width, height, spp, sppe, sppse)
+
+
+def _rot_x(a):
+    m = np.eye(4, dtype=np.float32)
+    c, s = np.cos(a), np.sin(a)
+    m[1, 1], m[1, 2], m[2, 1], m[2, 2] = c, -s, s, c
+    return m

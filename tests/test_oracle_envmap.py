@@ -1,0 +1,83 @@
+"""Known-answer tests of the oracle's EnvironmentMap emitter (reference src/emitter/envmap.cpp, scene.cpp:434-515):
+the oracle is unpinned against the reference (it cannot be built here), so its envmap path is pinned analytically."""
+import numpy as np
+import pytest
+
+import scenes
+
+
+def _latlong_lookup(img, d):
+    """independent float64 restatement of EnvironmentMap::eval_direction + Bitmap::eval(envmap_mode) for unit vectors d [n,3]"""
+    H, W, _ = img.shape
+    u = np.arctan2(d[:, 0], -d[:, 2]) / (2 * np.pi)
+    v = np.arccos(np.clip(d[:, 1], -1, 1)) / np.pi
+    u -= np.floor(u); v -= np.floor(v)
+    u -= 0.5 / W
+    u -= np.floor(u)
+    x, y = u * W, v * (H - 1)
+    px, py = np.floor(x).astype(int), np.floor(y).astype(int)
+    wx, wy = x - px, y - py
+    yw = np.minimum(py, H - 2)
+    x0, x1 = np.clip(px, 0, W - 1), (px + 1) % W
+    v00, v10, v01, v11 = img[yw, x0], img[yw, x1], img[yw + 1, x0], img[yw + 1, x1]
+    return ((1 - wx)[:, None] * v00 + wx[:, None] * v10) * (1 - wy)[:, None] + ((1 - wx)[:, None] * v01 + wx[:, None] * v11) * wy[:, None]
+
+
+def test_constant_envmap_furnace(orc):
+    L = np.array([0.6, 0.7, 0.9])
+    spec = scenes.envmap_scene(32, 32, 256, 0, 0, param=None, env=scenes.synthetic_envmap(64, 32, sun=False), floor_only=True)
+    sc = orc.OracleScene(spec, [0])
+    img = sc.render_c(max_depth=1, seed=1).reshape(32, 32, 3)
+    assert np.allclose(img[1, 16], L, rtol=1e-5)                      # camera ray that leaves the scene sees the map
+    floor = img[14:17, 12:20].reshape(-1, 3).mean(axis=0)             # unoccluded diffuse floor: rho * L
+    assert np.allclose(floor, 0.8 * L, rtol=0.02), floor
+    # deeper paths add nothing on a lone floor (every bounce leaves the scene)
+    img3 = sc.render_c(max_depth=3, seed=1).reshape(32, 32, 3)
+    assert np.allclose(img3[14:17, 12:20].reshape(-1, 3).mean(axis=0), 0.8 * L, rtol=0.02)
+
+
+def test_sun_envmap_irradiance_matches_quadrature(orc):
+    env = scenes.synthetic_envmap(128, 64, sun=True)
+    spec = scenes.envmap_scene(16, 16, 4096, 0, 0, param=None, env=env, floor_only=True)
+    sc = orc.OracleScene(spec, [0])
+    img = sc.render_c(max_depth=1, seed=3).reshape(16, 16, 3)
+    # E = int L(w) cos(theta) dw over the upper hemisphere (floor normal +y), midpoint rule on a fine grid
+    n_t, n_p = 1024, 2048
+    th = (np.arange(n_t) + 0.5) * (0.5 * np.pi / n_t)
+    ph = (np.arange(n_p) + 0.5) * (2 * np.pi / n_p)
+    T, P = np.meshgrid(th, ph, indexing="ij")
+    d = np.stack([np.sin(T) * np.cos(P), np.cos(T), np.sin(T) * np.sin(P)], axis=-1).reshape(-1, 3)
+    Lw = _latlong_lookup(env.astype(np.float64), d).reshape(n_t, n_p, 3)
+    E = (Lw * (np.cos(T) * np.sin(T))[..., None]).sum(axis=(0, 1)) * (0.5 * np.pi / n_t) * (2 * np.pi / n_p)
+    want = 0.8 / np.pi * E
+    got = img[7:9, 6:10].reshape(-1, 3).mean(axis=0)
+    assert np.allclose(got, want, rtol=0.03), (got, want)
+
+
+def test_envmap_albedo_derivative_and_sampler_budget(orc):
+    spec = scenes.envmap_scene(32, 32, 64, 0, 0, param="albedo")
+    sc = orc.OracleScene(spec, [0])
+    img, dimg = sc.render_d(max_depth=1, seeds=(2, 2, 2))
+    # the image is exactly linear in the box albedo at depth 1 (same seeds = same paths): FD == derivative
+    spec2 = scenes.envmap_scene(32, 32, 64, 0, 0, param="albedo")
+    spec2.bsdfs[0].reflectance = (0.75, 0.75, 0.75)
+    img2, _ = orc.OracleScene(spec2, [0]).render_d(max_depth=1, seeds=(2, 2, 2))
+    fd = (img2 - img) / 0.25
+    assert np.abs(dimg).sum() > 1.0
+    assert np.allclose(dimg, fd, rtol=1e-4, atol=1e-5)
+    assert np.all(np.isfinite(img)) and np.all(np.isfinite(dimg))
+    # at depth 2 the floor picks up light from the boxes: the derivative spreads to floor pixels, still matches FD to O(h)
+    img_a, d_a = sc.render_d(max_depth=2, seeds=(2, 2, 2))
+    spec3 = scenes.envmap_scene(32, 32, 64, 0, 0, param="albedo")
+    spec3.bsdfs[0].reflectance = (0.5 + 1e-2,) * 3
+    img_b, _ = orc.OracleScene(spec3, [0]).render_d(max_depth=2, seeds=(2, 2, 2))
+    assert np.allclose(d_a, (img_b - img_a) / 1e-2, rtol=2e-2, atol=2e-3)
+
+
+def test_envmap_plus_area_light_runs_and_is_deterministic(orc):
+    spec = scenes.envmap_scene(24, 24, 16, 8, 8, param="box_x", area_light=True)
+    sc = orc.OracleScene(spec, [0])
+    a, da = sc.render_d(max_depth=2, seeds=(4, 5, 6))
+    b, db = sc.render_d(max_depth=2, seeds=(4, 5, 6))
+    assert np.array_equal(a, b) and np.array_equal(da, db)
+    assert np.all(np.isfinite(a)) and np.all(np.isfinite(da)) and np.abs(da).sum() > 0
