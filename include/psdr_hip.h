@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PSDR_HIP_ABI_VERSION 1
+#define PSDR_HIP_ABI_VERSION 2
 
 /* TriangleInfo SoA, reference include/psdr/types.h:162-175 (+ Scene::m_triangle_uv,
  * m_triangle_face_normals, scene.cpp:528-542).  Arrays of n_triangles rows. */
@@ -60,11 +60,25 @@ typedef struct psdr_bsdf_rec {       /* Diffuse, reference src/bsdf/diffuse.cpp 
     float reflectance[3], d_reflectance[3];
 } psdr_bsdf_rec;
 
-typedef struct psdr_emitter_rec {    /* AreaLight, reference src/emitter/area.cpp */
-    int32_t mesh_id;
+typedef struct psdr_emitter_rec {    /* AreaLight (src/emitter/area.cpp) or EnvironmentMap (src/emitter/envmap.cpp) */
+    int32_t mesh_id;                 /* the light's mesh; for the envmap the bounding cube scene.cpp:442-480 adds */
     float sampling_weight;           /* normalised, scene.cpp:511-514 */
     float radiance[3], d_radiance[3];
+    int32_t type;                    /* 0 = AreaLight, 1 = EnvironmentMap (psdr_scene_snapshot.envmap) */
 } psdr_emitter_rec;
+
+/* EnvironmentMap after configure() (envmap.cpp:17-44): lat-long radiance, transform, the scene box it is carried to
+ * (scene.cpp:436-440) and its HyperCubeDistribution2f over (2(W-1)) x (2(H-1)) cells, cell index = cx*reso[1] + cy */
+typedef struct psdr_envmap_rec {
+    int32_t width, height;
+    const float *radiance;           /* [height*width*3] row-major rgb (Bitmap3fD m_radiance) */
+    float scale;                     /* m_scale */
+    float to_world[16], from_world[16];
+    float lower[3], upper[3];
+    int32_t reso[2];
+    const float *cell_pmf, *cell_cmf; /* unnormalised masses and their running sums, [reso[0]*reso[1]] */
+    float cell_sum;
+} psdr_envmap_rec;
 
 /* SecondaryEdgeInfo SoA, reference include/psdr/edge/edge.h:49-68 */
 typedef struct psdr_sec_edges {
@@ -106,6 +120,7 @@ typedef struct psdr_scene_snapshot {
     const float *face_pmf, *face_cmf;
     psdr_sec_edges sec_edges;
     int32_t n_sensors;  const psdr_sensor_rec *sensors;
+    const psdr_envmap_rec *envmap;            /* Scene::m_emitter_env, NULL = none */
 } psdr_scene_snapshot;
 
 /* One of Scene::m_samplers[0..2] in closed form: lane i was seeded with
@@ -161,6 +176,13 @@ int psdr_hip_trace(const psdr_hip_scene *scene, int32_t n, const float *o, const
 /* same query, two rays per lane through the two-ray tracer the path kernels use (rays 2i, 2i+1 share a lane) */
 int psdr_hip_trace_pairs(const psdr_hip_scene *scene, int32_t n, const float *o, const float *d,
                          int32_t *out_tri, float *out_uv, float *out_t, void *stream);
+
+/* EnvironmentMap::sample_position / sample_position_pdf alone (envmap.cpp:91-166; device arrays; parity aids):
+ * ref_p[n*3], s2[n*2] -> p[n*3] on the scene box, its normal n[n*3], pdf[n];  ref_p, p, nrm -> pdf[n] */
+int psdr_hip_env_sample(const psdr_hip_scene *scene, int32_t n, const float *ref_p, const float *s2,
+                        float *out_p, float *out_n, float *out_pdf, void *stream);
+int psdr_hip_env_pdf(const psdr_hip_scene *scene, int32_t n, const float *ref_p, const float *p, const float *nrm,
+                     float *out_pdf, void *stream);
 
 /* Integrator::renderC: out_rgb is [n_pixels*3] float32, pixel-interleaved, pixel = y*W + x */
 int psdr_hip_render_c(const psdr_hip_scene *scene, const psdr_render_args *args, float *out_rgb, void *stream);

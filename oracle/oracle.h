@@ -98,6 +98,12 @@ void orc_get_primary_edges(const orc_scene *s, int sensor_id, int tangent, float
 /* mesh-local edge list of mesh m: 5 ints per edge (v0 v1 f0 f1 opp); returns count */
 int orc_get_mesh_edges(const orc_scene *s, int mesh, int *out, int cap);
 float orc_emitter_sampling_weight(const orc_scene *s, int emitter);
+/* configured EnvironmentMap (0 if the scene has none): bounds = lower xyz, upper xyz; reso = cell grid; cell arrays have reso[0]*reso[1] entries */
+int orc_envmap_info(const orc_scene *s, float bounds[6], int reso[2], float *cell_sum);
+void orc_envmap_cells(const orc_scene *s, float *pmf, float *cmf);
+/* EnvironmentMap::sample_position / sample_position_pdf alone (host arrays, same layout as psdr_hip_env_sample / _pdf) */
+void orc_env_sample(const orc_scene *s, int n, const float *ref_p, const float *s2, float *out_p, float *out_n, float *out_pdf);
+void orc_env_pdf(const orc_scene *s, int n, const float *ref_p, const float *p, const float *nrm, float *out_pdf);
 
 /* closest-hit query (Scene_OptiX::ray_intersect restated, scene_optix.cpp:343-410):
  * out_tri = global triangle id or -1, out_uv barycentrics, out_t distance. use_bvh: 0 = brute force. */

@@ -303,6 +303,47 @@ class OracleScene:
     def num_primary_edges(self, sensor=0):
         return lib().orc_num_primary_edges(self._h, sensor)
 
+    def envmap_info(self):
+        """(bounds[6], reso[2], cell_sum, pmf, cmf) of the configured EnvironmentMap, or None"""
+        b = (C.c_float * 6)(); r = (C.c_int * 2)(); cs = C.c_float()
+        L = lib()
+        L.orc_envmap_info.restype = C.c_int
+        L.orc_envmap_info.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_float)]
+        L.orc_envmap_cells.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orc_envmap_cells.restype = None
+        if not L.orc_envmap_info(self._h, b, r, C.byref(cs)):
+            return None
+        n = r[0] * r[1]
+        pmf, cmf = np.empty(n, np.float32), np.empty(n, np.float32)
+        lib().orc_envmap_cells(self._h, pmf.ctypes.data_as(C.POINTER(C.c_float)), cmf.ctypes.data_as(C.POINTER(C.c_float)))
+        return np.array(list(b), np.float32), (r[0], r[1]), float(cs.value), pmf, cmf
+
+    def env_sample(self, ref_p, s2):
+        L = lib()
+        ref_p = np.ascontiguousarray(ref_p, np.float32); s2 = np.ascontiguousarray(s2, np.float32)
+        n = len(ref_p)
+        p, nn, pdf = np.empty((n, 3), np.float32), np.empty((n, 3), np.float32), np.empty(n, np.float32)
+        fp = C.POINTER(C.c_float)
+        L.orc_env_sample.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, fp, fp]; L.orc_env_sample.restype = None
+        L.orc_env_sample(self._h, n, ref_p.ctypes.data_as(fp), s2.ctypes.data_as(fp), p.ctypes.data_as(fp), nn.ctypes.data_as(fp), pdf.ctypes.data_as(fp))
+        return p, nn, pdf
+
+    def env_pdf(self, ref_p, p, nrm):
+        L = lib()
+        ref_p = np.ascontiguousarray(ref_p, np.float32); p = np.ascontiguousarray(p, np.float32); nrm = np.ascontiguousarray(nrm, np.float32)
+        n = len(ref_p)
+        pdf = np.empty(n, np.float32)
+        fp = C.POINTER(C.c_float)
+        L.orc_env_pdf.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, fp]; L.orc_env_pdf.restype = None
+        L.orc_env_pdf(self._h, n, ref_p.ctypes.data_as(fp), p.ctypes.data_as(fp), nrm.ctypes.data_as(fp), pdf.ctypes.data_as(fp))
+        return pdf
+
+    def emitter_weight(self, i):
+        L = lib()
+        L.orc_emitter_sampling_weight.restype = C.c_float
+        L.orc_emitter_sampling_weight.argtypes = [C.c_void_p, C.c_int]
+        return float(L.orc_emitter_sampling_weight(self._h, int(i)))
+
     def triangle_info(self, tangent=False):
         out = np.zeros((self.num_triangles, 25), dtype=np.float32)
         lib().orc_get_triangle_info(self._h, int(tangent), out.ctypes.data)

@@ -66,6 +66,30 @@ int orc_get_mesh_edges(const orc_scene *s, int mesh, int *out, int cap) {
     return n;
 }
 float orc_emitter_sampling_weight(const orc_scene *s, int e) { return s->sc->emitters[e].sampling_weight; }
+int orc_envmap_info(const orc_scene *s, float bounds[6], int reso[2], float *cell_sum) {
+    if (s->sc->env_emitter < 0) return 0;
+    const orc::EnvmapC &E = s->sc->env;
+    bounds[0] = E.lower.x; bounds[1] = E.lower.y; bounds[2] = E.lower.z; bounds[3] = E.upper.x; bounds[4] = E.upper.y; bounds[5] = E.upper.z;
+    reso[0] = E.reso[0]; reso[1] = E.reso[1];
+    *cell_sum = E.cell_distrb.sum;
+    return 1;
+}
+void orc_env_sample(const orc_scene *s, int n, const float *ref_p, const float *s2, float *out_p, float *out_n, float *out_pdf) {
+    for (int i = 0; i < n; ++i) {
+        orc::V3f p, nn; float pdf;
+        orc::kat_env_sample(*s->sc, orc::V3f(ref_p[3 * i], ref_p[3 * i + 1], ref_p[3 * i + 2]), s2[2 * i], s2[2 * i + 1], p, nn, pdf);
+        out_p[3 * i] = p.x; out_p[3 * i + 1] = p.y; out_p[3 * i + 2] = p.z; out_n[3 * i] = nn.x; out_n[3 * i + 1] = nn.y; out_n[3 * i + 2] = nn.z; out_pdf[i] = pdf;
+    }
+}
+void orc_env_pdf(const orc_scene *s, int n, const float *ref_p, const float *p, const float *nrm, float *out_pdf) {
+    for (int i = 0; i < n; ++i)
+        out_pdf[i] = orc::kat_env_pdf(*s->sc, orc::V3f(ref_p[3 * i], ref_p[3 * i + 1], ref_p[3 * i + 2]), orc::V3f(p[3 * i], p[3 * i + 1], p[3 * i + 2]),
+                                      orc::V3f(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]));
+}
+void orc_envmap_cells(const orc_scene *s, float *pmf, float *cmf) {
+    const orc::EnvmapC &E = s->sc->env;
+    for (int i = 0; i < E.num_cells; ++i) { pmf[i] = E.cell_distrb.pmf[i]; cmf[i] = E.cell_distrb.cmf[i]; }
+}
 
 void orc_trace(const orc_scene *s, int n, const float *o, const float *d, int use_bvh, int *out_tri, float *out_uv, float *out_t) {
 #pragma omp parallel for schedule(static) num_threads(orc_get_num_threads())

@@ -266,6 +266,11 @@ template <bool ad> static PositionSample<ad> envmap_sample_position(const Scene 
     return r;
 }
 
+void kat_env_sample(const Scene &sc, const V3f &ref_p, float sx, float sy, V3f &p, V3f &n, float &pdf) {
+    const PositionSample<false> r = envmap_sample_position<false>(sc, ref_p, sx, sy);
+    p = r.p; n = r.n; pdf = r.pdf;
+}
+
 template <bool ad> static PositionSample<ad> emitter_sample_position(const Scene &sc, int ei, const V3f &ref_p, float sx, float sy) {
     if (sc.emitters[ei].type == 1) return envmap_sample_position<ad>(sc, ref_p, sx, sy);
     return mesh_sample_position<ad>(sc, sc.meshes[sc.emitters[ei].mesh], sx, sy);
@@ -281,16 +286,21 @@ template <bool ad> static PositionSample<ad> sample_emitter_position(const Scene
     return r;
 }
 
+float kat_env_pdf(const Scene &sc, const V3f &ref_p, const V3f &p, const V3f &n);
 // scene.cpp:1016-1024 -> area.cpp:48-59 -> mesh.cpp:457-466, or envmap.cpp:146-166
 template <bool ad> static float emitter_position_pdf(const Scene &sc, const V3f &ref_p, const Its<ad> &its) {
     if (!its.valid) return 0.f;
     const MeshC &m = sc.meshes[its.mesh];
     if (m.emitter < 0) return 0.f;
-    if (sc.emitters[m.emitter].type == 1) {
-        V3f d = detach(its.p) - ref_p;
+    if (sc.emitters[m.emitter].type == 1) return kat_env_pdf(sc, ref_p, detach(its.p), detach(its.n));
+    return sc.emitters[m.emitter].sampling_weight * m.inv_total_area;
+}
+float kat_env_pdf(const Scene &sc, const V3f &ref_p, const V3f &p, const V3f &n) {
+    {
+        V3f d = p - ref_p;
         const float dist2 = squared_norm(d);
         d = d / safe_sqrt(dist2);
-        const float G = std::fabs(dot(d, detach(its.n))) / dist2;
+        const float G = std::fabs(dot(d, n)) / dist2;
         d = transform_dir(detach(sc.env.from_world), d);
         const float factor = G * (1.f / std::sqrt(std::max(fma_(d.x, d.x, d.z * d.z), Epsilon * Epsilon))) * (.5f / (Pi * Pi));
         float u = atan2_cephes(d.x, -d.z) * InvTwoPi;
@@ -298,7 +308,6 @@ template <bool ad> static float emitter_position_pdf(const Scene &sc, const V3f 
         u -= std::floor(u); v -= std::floor(v);
         return envmap_cell_pdf(sc.env, u, v) * factor;
     }
-    return sc.emitters[m.emitter].sampling_weight * m.inv_total_area;
 }
 
 // ---------------------------------------------------------------- Diffuse BSDF (diffuse.cpp:24-108)

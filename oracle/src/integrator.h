@@ -55,6 +55,8 @@ BoundarySegSampleDirect sample_boundary_segment_direct(const Scene &sc, V3f samp
 template <bool ad>
 int eval_secondary_edge(const Scene &sc, const CameraC &cam, const V3f &sample3, V3<Real<ad>> &value);
 
+void kat_env_sample(const Scene &sc, const V3f &ref_p, float sx, float sy, V3f &p, V3f &n, float &pdf);
+float kat_env_pdf(const Scene &sc, const V3f &ref_p, const V3f &p, const V3f &n);
 void kat_cosine_hemisphere(float sx, float sy, float *o);
 void kat_uniform_triangle(float sx, float sy, float *o);
 void kat_coordinate_system(const float *n, float *s, float *t);

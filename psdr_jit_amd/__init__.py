@@ -35,6 +35,7 @@ BSDF = _core.BSDF
 DiffuseBSDF = _core.DiffuseBSDF
 Emitter = _core.Emitter
 AreaLight = _core.AreaLight
+EnvironmentMap = _core.EnvironmentMap
 Sensor = _core.Sensor
 PerspectiveCamera = _core.PerspectiveCamera
 Mesh = _core.Mesh
@@ -196,6 +197,56 @@ def _add_BSDF(self, bsdf, name, twoSide=False):
     _keep(self, "BSDF[id=%s]" % name, bsdf)
 
 
+def load_radiance_image(path):
+    """Lat-long radiance image [H, W, 3] float32 from a .npy file or an OpenEXR file (the reference reads EXR through
+    tinyexr, bitmap_loader.cpp; here: psdr_jit_amd.exr, a small reader for scanline float/half images)."""
+    path = _os.fspath(path)
+    if path.lower().endswith(".npy"):
+        img = _np.load(path)
+    else:
+        from . import exr as _exr
+        img = _exr.read_rgb(path)
+    img = _np.ascontiguousarray(_np.asarray(img, dtype=_np.float32))
+    if img.ndim != 3 or img.shape[2] < 3:
+        raise RuntimeError("EnvironmentMap: expected an [H, W, 3] image")
+    return img[:, :, :3].copy()
+
+
+_EnvironmentMap_init = EnvironmentMap.__init__
+
+
+def _envmap_init(self, radiance=None):
+    """EnvironmentMap(file_name) as in the reference (envmap.h:13-15), or EnvironmentMap(array[H, W, 3])."""
+    if radiance is None:
+        _EnvironmentMap_init(self)
+    elif isinstance(radiance, (str, bytes, _os.PathLike)):
+        _EnvironmentMap_init(self, load_radiance_image(radiance))
+    else:
+        r = radiance.detach().cpu().numpy() if isinstance(radiance, _torch.Tensor) else radiance
+        _EnvironmentMap_init(self, _np.ascontiguousarray(_np.asarray(r, dtype=_np.float32)))
+
+
+EnvironmentMap.__init__ = _envmap_init
+EnvironmentMap.radiance = property(lambda self: self._get("radiance", False), lambda self, v: self._set("radiance", _np.ascontiguousarray(_np.asarray(v, dtype=_np.float32)), _np.zeros((1, 1, 3), _np.float32)))
+EnvironmentMap.to_world = property(lambda self: self._get("to_world_raw", False), lambda self, v: self._set("to_world_raw", _np.ascontiguousarray(_np.asarray(_split(v, (4, 4))[0], dtype=_np.float32)), _np.zeros((4, 4), _np.float32)))
+EnvironmentMap.to_world_left = property(lambda self: self._get("to_world_left", False), lambda self, v: self._set("to_world_left", _np.ascontiguousarray(_np.asarray(_split(v, (4, 4))[0], dtype=_np.float32)), _np.zeros((4, 4), _np.float32)))
+EnvironmentMap.set_transform = lambda self, mat: setattr(self, "to_world_left", mat)
+
+
+def _add_EnvironmentMap(self, emitter_or_path, to_world=None, scale=1.0):
+    """add_EnvironmentMap(fname, to_world, scale) or add_EnvironmentMap(emitter), reference scene.cpp:85-105."""
+    n_em = self.get_num_emitters()
+    if isinstance(emitter_or_path, EnvironmentMap):
+        self._add_EnvironmentMap(emitter_or_path)
+    else:
+        e = EnvironmentMap(emitter_or_path)
+        e.scale = float(scale)
+        if to_world is not None:
+            e.to_world = to_world
+        self._add_EnvironmentMap(e)
+    _keep(self, "Emitter[%d]" % n_em, None)
+
+
 def _add_Mesh(self, mesh_or_path, *args):
     """add_Mesh(path, Matrix4, bsdf_id, emitter|None) or add_Mesh(mesh, bsdf_id, emitter=None)."""
     n_em = self.get_num_emitters()
@@ -223,6 +274,7 @@ def _configure(self, active_sensor=()):
 Scene.add_Sensor = _add_Sensor
 Scene.add_BSDF = _add_BSDF
 Scene.add_Mesh = _add_Mesh
+Scene.add_EnvironmentMap = _add_EnvironmentMap
 Scene.configure = _configure
 
 

@@ -7,7 +7,7 @@ from . import build as _build
 
 SYMBOLS = [
     "psdr_hip_last_error", "psdr_hip_abi_version", "psdr_hip_device_count", "psdr_hip_set_device",
-    "psdr_hip_scene_create", "psdr_hip_scene_destroy", "psdr_hip_scene_stats", "psdr_hip_trace", "psdr_hip_trace_pairs",
+    "psdr_hip_scene_create", "psdr_hip_scene_destroy", "psdr_hip_scene_stats", "psdr_hip_trace", "psdr_hip_trace_pairs", "psdr_hip_env_sample", "psdr_hip_env_pdf",
     "psdr_hip_render_c", "psdr_hip_render_d_fwd", "psdr_hip_render_d_bwd", "psdr_hip_render_c_counted", "psdr_hip_render_d_fwd_counted",
     "psdr_hip_li_lanes", "psdr_hip_guiding_build", "psdr_hip_guiding_mass", "psdr_hip_guiding_num_cells",
     "psdr_hip_guiding_destroy", "psdr_hip_tea64", "psdr_hip_sampler_floats",
@@ -48,6 +48,8 @@ def lib():
         L.psdr_hip_sampler_floats.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]
         L.psdr_hip_trace.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.psdr_hip_trace_pairs.argtypes = L.psdr_hip_trace.argtypes
+        L.psdr_hip_env_sample.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 6
+        L.psdr_hip_env_pdf.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 5
         L.psdr_hip_render_c.argtypes = [C.c_void_p, C.POINTER(RenderArgs), C.c_void_p, C.c_void_p]
         L.psdr_hip_render_d_fwd.argtypes = [C.c_void_p, C.POINTER(RenderArgs), C.c_void_p, C.c_void_p, C.c_void_p]
         L.psdr_hip_render_d_bwd.argtypes = [C.c_void_p, C.POINTER(RenderArgs), C.c_void_p, C.POINTER(Grads), C.c_void_p]

@@ -65,6 +65,11 @@ def snapshot_tensors(scene, sensor_id, leaf_of):
     pm = scene.param_map
     Vws, tri_rows, sec_rows = [], [], []
     for i in range(scene.num_meshes):
+        if "Mesh[%d]" % i not in pm:
+            # the environment map's bounding cube (scene.cpp:442-480): 12 constant faces, not a parameter
+            Vws.append(None)
+            tri_rows.append(torch.zeros((12, 22), dtype=F64))
+            continue
         m = pm["Mesh[%d]" % i]
         V = leaf_of(m, "vertex_positions").reshape(-1, 3)
         M = leaf_of(m, "to_world_left").reshape(4, 4) @ leaf_of(m, "to_world").reshape(4, 4) @ leaf_of(m, "to_world_right").reshape(4, 4)
@@ -97,5 +102,7 @@ def snapshot_tensors(scene, sensor_id, leaf_of):
     nb = sum(1 for k in pm if k.startswith("BSDF[") and not k.startswith("BSDF[id="))
     ne = sum(1 for k in pm if k.startswith("Emitter[") and not k.startswith("Emitter[id="))
     refl = torch.stack([leaf_of(pm["BSDF[%d]" % i], "reflectance").reshape(-1).expand(3) for i in range(nb)]) if nb else torch.zeros((0, 3), dtype=F64)
-    rad = torch.stack([leaf_of(pm["Emitter[%d]" % i], "radiance").reshape(-1).expand(3) for i in range(ne)]) if ne else torch.zeros((0, 3), dtype=F64)
+    def _rad(e):      # the environment map's texels are not differentiated (its row of g_emitter stays zero)
+        return torch.zeros(3, dtype=F64) if type(e).__name__ == "EnvironmentMap" else leaf_of(e, "radiance").reshape(-1).expand(3)
+    rad = torch.stack([_rad(pm["Emitter[%d]" % i]) for i in range(ne)]) if ne else torch.zeros((0, 3), dtype=F64)
     return tri, sec, prim, refl, rad

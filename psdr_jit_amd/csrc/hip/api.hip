@@ -332,6 +332,25 @@ __global__ __launch_bounds__(kBlock) void k_trace(const float4 *__restrict__ blo
     }
 }
 
+// EnvironmentMap::sample_position / sample_position_pdf alone (parity aids)
+__global__ void k_env_sample(const SceneTables T, int n, const float *__restrict__ ref_p, const float *__restrict__ s2,
+                             float *__restrict__ out_p, float *__restrict__ out_n, float *__restrict__ out_pdf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Vec3f p, nn; float pdf;
+    env_sample_position(T.env, Vec3f(ref_p[3 * i], ref_p[3 * i + 1], ref_p[3 * i + 2]), s2[2 * i], s2[2 * i + 1], p, nn, pdf);
+    out_p[3 * i] = p.x; out_p[3 * i + 1] = p.y; out_p[3 * i + 2] = p.z;
+    out_n[3 * i] = nn.x; out_n[3 * i + 1] = nn.y; out_n[3 * i + 2] = nn.z;
+    out_pdf[i] = pdf;
+}
+__global__ void k_env_pdf(const SceneTables T, int n, const float *__restrict__ ref_p, const float *__restrict__ p, const float *__restrict__ nrm,
+                          float *__restrict__ out_pdf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out_pdf[i] = env_position_pdf(T.env, Vec3f(ref_p[3 * i], ref_p[3 * i + 1], ref_p[3 * i + 2]), Vec3f(p[3 * i], p[3 * i + 1], p[3 * i + 2]),
+                                  Vec3f(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]));
+}
+
 __global__ void k_sampler_floats(unsigned long long seed_value, unsigned long long lane, unsigned long long skip, int n, float *out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         LaneRng r; r.seed(seed_value, lane, skip);
@@ -427,6 +446,23 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     T.emit_off = (int) w;  w += 2 * (size_t) std::max(1, s->n_emitters);
     T.ecdf_off = (int) w;  w += words_for_floats(2 * (size_t) std::max(1, s->n_emitters));
     T.fcdf_off = (int) w;  w += words_for_floats(2 * (size_t) std::max(1, s->n_face_distrb));
+    T.env_emitter = -1;
+    for (int i = 0; i < s->n_emitters; ++i) if (s->emitters[i].type == 1) T.env_emitter = i;
+    if (T.env_emitter >= 0) {
+        const psdr_envmap_rec *er = s->envmap;
+        if (!er || !er->radiance || !er->cell_pmf || !er->cell_cmf || er->width < 2 || er->height < 2) return fail("EnvironmentMap emitter without a configured psdr_envmap_rec");
+        EnvDev &ED = T.env;
+        int rc = 0;
+        const size_t cells = (size_t) er->reso[0] * er->reso[1];
+        ED.radiance = sc->up(er->radiance, (size_t) 3 * er->width * er->height, rc);
+        ED.cell_pmf = sc->up(er->cell_pmf, cells, rc);
+        ED.cell_cmf = sc->up(er->cell_cmf, cells, rc);
+        if (rc) return 1;
+        ED.width = er->width; ED.height = er->height; ED.reso0 = er->reso[0]; ED.reso1 = er->reso[1]; ED.num_cells = (int) cells;
+        ED.scale = er->scale; ED.cell_sum = er->cell_sum;
+        std::memcpy(ED.to_world.m, er->to_world, 64); std::memcpy(ED.from_world.m, er->from_world, 64);
+        for (int k = 0; k < 3; ++k) { ED.lower[k] = er->lower[k]; ED.upper[k] = er->upper[k]; }
+    }
     std::vector<FilterPrim> filt;
     build_filter_prims(tr.p0, tr.e1, tr.e2, bvh.order.data(), n, filt);
     T.filt_off = (int) w;  w += 4 * filt.size();
@@ -810,6 +846,22 @@ static int trace_impl(const psdr_hip_scene *sc, int32_t n, const float *o, const
     if (n <= 0) return 0;
     if (sc->lds) LAUNCH((k_trace<true>), sc, (long long) n, stream, sc->blob.as<float4>(), sc->T, n, o, d, out_tri, out_uv, out_t, pairs);
     else LAUNCH((k_trace<false>), sc, (long long) n, stream, sc->blob.as<float4>(), sc->T, n, o, d, out_tri, out_uv, out_t, pairs);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int psdr_hip_env_sample(const psdr_hip_scene *sc, int32_t n, const float *ref_p, const float *s2, float *out_p, float *out_n, float *out_pdf, void *stream) {
+    if (!sc) return fail("null scene");
+    if (sc->T.env_emitter < 0) return fail("the scene has no EnvironmentMap");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_env_sample, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t) stream, sc->T, n, ref_p, s2, out_p, out_n, out_pdf);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int psdr_hip_env_pdf(const psdr_hip_scene *sc, int32_t n, const float *ref_p, const float *p, const float *nrm, float *out_pdf, void *stream) {
+    if (!sc) return fail("null scene");
+    if (sc->T.env_emitter < 0) return fail("the scene has no EnvironmentMap");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_env_pdf, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t) stream, sc->T, n, ref_p, p, nrm, out_pdf);
     HIPCHK(hipGetLastError());
     return 0;
 }

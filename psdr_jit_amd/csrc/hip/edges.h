@@ -65,7 +65,7 @@ template <bool LDS> PSDR_DEV BoundarySegSampleDirect sample_boundary_segment_dir
     r.edge_id = ei; r.s1 = sample1;
     const Vec3f p0v = detach(r.p0);
     pdf0 /= norm(e1);
-    const PositionSample<false> ps2 = sample_emitter_position<false, LDS>(S, s3.y, s3.z);
+    const PositionSample<false> ps2 = sample_emitter_position<false, LDS>(S, p0v, s3.y, s3.z);
     r.p2 = ps2.p; r.n = ps2.n; r.emitter_slot = ps2.slot;
     Vec3f e = r.p2 - p0v;
     const float distSqr = squared_norm(e);

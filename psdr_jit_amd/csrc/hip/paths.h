@@ -142,7 +142,7 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
             const float sx = rng.next_1d(), sy = rng.next_1d();
             do_nee = mesh_emitter(S, its.mesh) < 0;
             if (do_nee) {
-                ps = sample_emitter_position<AD, LDS>(S, sx, sy);
+                ps = sample_emitter_position<AD, LDS>(S, detach(its.p), sx, sy);
                 wod = ps.p - its.p;
                 dist_sqr = squared_norm(wod);
                 dist = safe_sqrt(dist_sqr);
@@ -164,7 +164,10 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
         {
             if (do_nee && h.slot >= 0) {
                 if (COUNT) S.c_hits++;
-                const Its<AD> its1 = make_its<AD, LDS, false>(S, h, ray1, true);
+                // shadow hits only need n, wi.z, t, J - except on the environment map, whose radiance is looked up along
+                // the direction rebuilt from the shading frame (envmap.cpp:47-56)
+                Its<AD> its1 = make_its<AD, LDS, false>(S, h, ray1, true);
+                if (T.env_emitter >= 0 && mesh_emitter(S, its1.mesh) == T.env_emitter) its1 = make_its<AD, LDS, true>(S, h, ray1, true);
                 if ((detach(its1.t) > detach(dist) - kShadowEpsilon) && (mesh_emitter(S, its1.mesh) >= 0)) {
                     const R cos_val = dot(its1.n, -wod);
                     const R G_val = abs_(cos_val) / dist_sqr;
@@ -207,7 +210,7 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
                         if (itx.t < kEpsilon) bsdf_val = V(0.f);
                         else bsdf_val = bsdf_eval<AD, LDS>(S, its, bs.wo, true) / bs.pdf;
                     }
-                    const float weight2 = mis_weight(pdf0, emitter_position_pdf<AD, LDS>(S, itx));
+                    const float weight2 = mis_weight(pdf0, emitter_position_pdf<AD, LDS>(S, detach(its.p), itx));
                     thr = thr * bsdf_val;
                     res = res + eval_Le<AD, LDS>(S, itx, true) * thr * R(weight2);
                     its = itx;

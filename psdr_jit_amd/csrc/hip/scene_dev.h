@@ -18,6 +18,16 @@ constexpr float kTraceTMax = 100000000.f;   // reference scene_optix.cpp:376
 constexpr int kBlock = 256;
 constexpr int kBruteForceMax = 64;          // scenes with at most this many triangles skip the BVH
 
+// EnvironmentMap after configure() (psdr_envmap_rec): too large for the LDS blob, read from global memory
+struct EnvDev {
+    const float *radiance;          // [height*width*3]
+    const float *cell_pmf, *cell_cmf;
+    int width, height, reso0, reso1, num_cells;
+    float scale, cell_sum;
+    Mat4<float> to_world, from_world;
+    float lower[3], upper[3];
+};
+
 struct SceneTables {
     // float4-word offsets into the blob
     int nodes_off, trav_off, shade_off, tan_off, map_off, mesh_off, bsdf_off, emit_off, ecdf_off, fcdf_off;
@@ -25,6 +35,8 @@ struct SceneTables {
     int has_tangent, stack_depth;
     int filt_off, n_filt;      // filter primitives of the brute-force tracer (4 words each, see filter.h)
     float center[3], radius;   // bounding sphere of all vertices
+    int env_emitter;           // index of the EnvironmentMap among the emitters, -1 = none
+    EnvDev env;
     float emitter_sum;
     int blob_words;            // float4 count
     int width, height, spp, sppe, sppse;
@@ -84,7 +96,7 @@ template <bool LDS> struct SceneView {
         const bool on = probe_kind == kind && id == probe_id;
         return make_float4(on && probe_comp == 0 ? 1.f : 0.f, on && probe_comp == 1 ? 1.f : 0.f, on && probe_comp == 2 ? 1.f : 0.f, 0.f);
     }
-    PSDR_DEV void note_slot(int slot) { if (mode == 1 && ext_n < 8) { ext[ext_n * kBlock] = slot; ++ext_n; } }
+    PSDR_DEV void note_slot(int slot) { if (mode == 1 && slot >= 0 && ext_n < 8) { ext[ext_n * kBlock] = slot; ++ext_n; } }
 
     PSDR_DEV float4 ld(int word) const { return B[word]; }
     PSDR_DEV float ldf(int word_off, int idx) const { return reinterpret_cast<const float *>(B + word_off)[idx]; }

@@ -6,6 +6,7 @@
 #pragma once
 #include "scene_dev.h"
 #include "sampler.h"
+#include "../common/envmath.h"
 
 namespace psdr {
 
@@ -23,6 +24,7 @@ template <bool AD> PSDR_DEV VecN<AD> to_local(const Its<AD> &its, const VecN<AD>
 template <bool AD> PSDR_DEV VecN<AD> to_world(const Its<AD> &its, const Vec3f &v) {
     return its.fs * Num<AD>(v.x) + its.ft * Num<AD>(v.y) + its.fn * Num<AD>(v.z);
 }
+PSDR_DEV Vec3d to_world_d(const Its<true> &its, const Vec3d &v) { return its.fs * v.x + its.ft * v.y + its.fn * v.z; }
 
 // reference include/psdr/core/frame.h:9-28 (Duff et al. 2017)
 template <typename T> PSDR_DEV void coordinate_system(const Vec3<T> &n, Vec3<T> &s, Vec3<T> &t) {
@@ -178,13 +180,89 @@ PSDR_DEV int sample_reuse(int size, float sum, PmfFn pmf, CmfFn cmf, float &s, f
     return idx;
 }
 
-// ---------------------------------------------------------------- emitters (area lights)
+// ---------------------------------------------------------------- EnvironmentMap (reference src/emitter/envmap.cpp)
+// hooks of csrc/common/envmath.h for the (value, tangent) type; derivatives of atan2 / acos are the analytic ones
+PSDR_DEV Dual e_fma(const Dual &a, const Dual &b, const Dual &c) { return fma_(a, b, c); }
+PSDR_DEV Dual e_floor(const Dual &a) { return Dual(floorf(a.v), 0.f); }
+PSDR_DEV float e_value(const Dual &a) { return a.v; }
+PSDR_DEV float env_atan2(float y, float x) { return env::atan2_f(y, x); }
+PSDR_DEV Dual env_atan2(const Dual &y, const Dual &x) { return Dual(env::atan2_f(y.v, x.v), fmaf(x.v, y.d, -(y.v * x.d)) / fmaf(x.v, x.v, y.v * y.v)); }
+PSDR_DEV float env_safe_acos(float x) { return env::safe_acos_f(x); }
+PSDR_DEV Dual env_safe_acos(const Dual &x) {
+    const float c = fminf(fmaxf(x.v, -1.f), 1.f);
+    return Dual(env::acos_f(c), -x.d / sqrtf(fmaf(-c, c, 1.f)));
+}
+PSDR_DEV Mat4<Dual> promote(const Mat4<float> &M) { Mat4<Dual> r; for (int i = 0; i < 16; ++i) r.m[i] = Dual(M.m[i]); return r; }
+PSDR_DEV float env_floor(float a) { return floorf(a); }
+PSDR_DEV Dual env_floor(const Dual &a) { return Dual(floorf(a.v), 0.f); }
+
+// EnvironmentMap::eval_direction, envmap.cpp:59-77 (the map's own transform and texels carry no tangent)
+template <bool AD> PSDR_DEV VecN<AD> env_eval_direction(const EnvDev &E, const VecN<AD> &wi) {
+    using R = Num<AD>;
+    VecN<AD> v;
+    if constexpr (AD) v = xform_dir(promote(E.from_world), wi); else v = xform_dir(E.from_world, wi);
+    R u = env_atan2(v.x, -v.z) * R(env::kInvTwoPi), w = env_safe_acos(v.y) * R(env::kInvPi);
+    u = u - env_floor(u); w = w - env_floor(w);
+    R rgb[3];
+    env::bitmap_eval<R>(E.radiance, E.width, E.height, u, w, rgb);
+    return VecN<AD>(rgb[0], rgb[1], rgb[2]) * R(E.scale);
+}
+
+// EnvironmentMap::__sample_position_pdf, envmap.cpp:146-166
+PSDR_DEV float env_position_pdf(const EnvDev &E, const Vec3f &ref_p, const Vec3f &p, const Vec3f &n) {
+    Vec3f d = p - ref_p;
+    const float dist2 = squared_norm(d);
+    d = d / safe_sqrt(dist2);
+    const float G = fabsf(dot(d, n)) / dist2;
+    d = xform_dir(E.from_world, d);
+    const float factor = G * (1.f / sqrtf(fmaxf(fma_(d.x, d.x, d.z * d.z), kEpsilon * kEpsilon))) * (.5f / (kPi * kPi));
+    float u = env::atan2_f(d.x, -d.z) * env::kInvTwoPi;
+    float v = env::safe_acos_f(d.y) * env::kInvPi;
+    u -= floorf(u); v -= floorf(v);
+    const int ix = (int) floorf(u * (float) E.reso0), iy = (int) floorf(v * (float) E.reso1);
+    if (!(ix >= 0 && ix < E.reso0 && iy >= 0 && iy < E.reso1)) return 0.f;
+    return (E.cell_pmf[ix * E.reso1 + iy] / E.cell_sum) * (float) E.num_cells * factor;
+}
+
+// EnvironmentMap::__sample_position (envmap.cpp:91-132): a direction from the cell grid (HyperCubeDistribution2f,
+// cube_distrb.cpp:42-49), carried to the scene box (utils.h:145-164); everything detached
+PSDR_DEV void env_sample_position(const EnvDev &E, const Vec3f &ref_p, float sx, float sy, Vec3f &p_out, Vec3f &n_out, float &pdf_out) {
+    float pdf;
+    const int idx = sample_reuse(E.num_cells, E.cell_sum, [&](int i) { return E.cell_pmf[i]; }, [&](int i) { return E.cell_cmf[i]; }, sy, pdf);
+    const int cx = idx / E.reso1, cy = idx - cx * E.reso1;
+    sx = (sx + (float) cx) * (1.f / (float) E.reso0);
+    sy = (sy + (float) cy) * (1.f / (float) E.reso1);
+    pdf *= (float) E.num_cells;
+    const float theta = sy * kPi, phi = sx * env::kTwoPi;
+    float st, ct, sp, cp;
+    env::sincos_f(theta, st, ct);
+    env::sincos_f(phi, sp, cp);
+    const Vec3f d0(cp * st, sp * st, ct);                                      // sphdir, utils.h:56-61
+    Vec3f d(d0.y, d0.z, -d0.x);
+    const float inv_sin_theta = 1.f / sqrtf(fmaxf(fma_(d.x, d.x, d.z * d.z), kEpsilon * kEpsilon));
+    if (pdf > kEpsilon) pdf *= inv_sin_theta * (.5f / (kPi * kPi));
+    d = xform_dir(E.to_world, d);
+    const float o3[3] = {ref_p.x, ref_p.y, ref_p.z}, d3[3] = {d.x, d.y, d.z};
+    float t, G, n3[3];
+    env::scene_aabb_exit(o3, d3, E.lower, E.upper, t, n3, G);
+    p_out = Vec3f(fma_(d.x, t, ref_p.x), fma_(d.y, t, ref_p.y), fma_(d.z, t, ref_p.z));
+    n_out = Vec3f(n3[0], n3[1], n3[2]);
+    pdf_out = pdf * G;
+}
+
+// ---------------------------------------------------------------- emitters
 // Intersection::Le -> AreaLight::eval, reference intersection.h:35-42, area.cpp:17-26
 template <bool AD, bool LDS> PSDR_DEV VecN<AD> eval_Le(const SceneView<LDS> &S, const Its<AD> &its, bool active) {
     using V = VecN<AD>;
     if (!active || !its.valid) return V(Num<AD>(0.f));
     const int e = mesh_emitter(S, its.mesh);
-    if (e < 0 || !(detach(its.wi.z) > 0.f)) return V(Num<AD>(0.f));
+    if (e < 0) return V(Num<AD>(0.f));
+    if (e == S.T->env_emitter) {               // EnvironmentMap::eval, envmap.cpp:47-56
+        V wi_world;
+        if constexpr (AD) wi_world = to_world_d(its, its.wi); else wi_world = to_world<false>(its, its.wi);
+        return env_eval_direction<AD>(S.T->env, -wi_world);
+    }
+    if (!(detach(its.wi.z) > 0.f)) return V(Num<AD>(0.f));
     const int w = S.T->emit_off + 2 * e;
     const float4 a = S.ld(w);
     if constexpr (AD) { const float4 b = S.rgb_tan(w + 1, 3, e); return make_dual(Vec3f(a.x, a.y, a.z), Vec3f(b.x, b.y, b.z)); }
@@ -195,7 +273,7 @@ template <bool AD> struct PositionSample { VecN<AD> p, n; Num<AD> J; float pdf; 
 
 // Scene::sample_emitter_position -> AreaLight::sample_position -> Mesh::__sample_position
 // reference scene.cpp:987-1013, mesh.cpp:413-454, warp.h:79-82
-template <bool AD, bool LDS> PSDR_DEV PositionSample<AD> sample_emitter_position(const SceneView<LDS> &S, float sx, float sy) {
+template <bool AD, bool LDS> PSDR_DEV PositionSample<AD> sample_emitter_position(const SceneView<LDS> &S, const Vec3f &ref_p, float sx, float sy) {
     const SceneTables &T = *S.T;
     float epdf = 1.f;
     int ei = 0;
@@ -203,6 +281,18 @@ template <bool AD, bool LDS> PSDR_DEV PositionSample<AD> sample_emitter_position
         ei = sample_reuse(T.n_emitters, T.emitter_sum,
                           [&](int i) { return S.ldf(T.ecdf_off, i); },
                           [&](int i) { return S.ldf(T.ecdf_off, T.n_emitters + i); }, sy, epdf);
+    }
+    if (ei == T.env_emitter) {
+        Vec3f p, nn;
+        float pdf_env;
+        env_sample_position(T.env, ref_p, sx, sy, p, nn, pdf_env);
+        PositionSample<AD> r;
+        if constexpr (AD) { r.p = promote(p); r.n = promote(nn); }
+        else { r.p = p; r.n = nn; }
+        r.J = Num<AD>(1.f);
+        r.pdf = pdf_env * epdf;
+        r.slot = -1;
+        return r;
     }
     const int mesh = __float_as_int(S.ld(T.emit_off + 2 * ei + 1).w);
     const MeshRec m = load_mesh(S, mesh);
@@ -232,16 +322,18 @@ template <bool AD, bool LDS> PSDR_DEV PositionSample<AD> sample_emitter_position
 }
 
 // Scene::emitter_position_pdf, reference scene.cpp:1016-1024 -> area.cpp:48-59 -> mesh.cpp:457-466
-template <bool AD, bool LDS> PSDR_DEV float emitter_position_pdf(const SceneView<LDS> &S, const Its<AD> &its) {
+template <bool AD, bool LDS> PSDR_DEV float emitter_position_pdf(const SceneView<LDS> &S, const Vec3f &ref_p, const Its<AD> &its) {
     if (!its.valid) return 0.f;
     const MeshRec m = load_mesh(S, its.mesh);
     if (m.emitter < 0) return 0.f;
+    if (m.emitter == S.T->env_emitter) return env_position_pdf(S.T->env, ref_p, detach(its.p), detach(its.n));
     return S.ld(S.T->emit_off + 2 * m.emitter).w * m.inv_total_area;
 }
 
 // ---------------------------------------------------------------- Diffuse BSDF, reference src/bsdf/diffuse.cpp:24-108
 template <bool AD, bool LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S, const Its<AD> &its, VecN<AD> wo, bool active) {
     using R = Num<AD>; using V = VecN<AD>;
+    if (mesh_bsdf(S, its.mesh) < 0) return V(R(0.f));          // the envmap's bounding cube has no BSDF (null vcall = zeros)
     const int w = S.T->bsdf_off + 2 * mesh_bsdf(S, its.mesh);
     const float4 a = S.ld(w);
     R wiz = its.wi.z;
@@ -253,6 +345,7 @@ template <bool AD, bool LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S
     return refl * R(kInvPi) * wo.z;
 }
 template <bool AD, bool LDS> PSDR_DEV float bsdf_pdf(const SceneView<LDS> &S, const Its<AD> &its, const VecN<AD> &wo, bool active) {
+    if (mesh_bsdf(S, its.mesh) < 0) return 0.f;
     const float4 a = S.ld(S.T->bsdf_off + 2 * mesh_bsdf(S, its.mesh));
     float wiz = detach(its.wi.z), woz = detach(wo.z);
     if (__float_as_int(a.w) & 1) { woz = mulsign(woz, wiz); wiz = fabsf(wiz); }
@@ -294,6 +387,7 @@ PSDR_DEV Vec3f square_to_cosine_hemisphere(float sx, float sy) {
 }
 struct BSDFSample { Vec3f wo; float pdf; bool valid; };
 template <bool AD, bool LDS> PSDR_DEV BSDFSample bsdf_sample(const SceneView<LDS> &S, const Its<AD> &its, float s1, float s2, bool active) {
+    if (mesh_bsdf(S, its.mesh) < 0) { BSDFSample z; z.wo = Vec3f(0.f, 0.f, 0.f); z.pdf = 0.f; z.valid = false; return z; }
     const float4 a = S.ld(S.T->bsdf_off + 2 * mesh_bsdf(S, its.mesh));
     float wiz = detach(its.wi.z);
     if (__float_as_int(a.w) & 1) wiz = fabsf(wiz);
@@ -321,7 +415,7 @@ PSDR_DEV VecN<AD> Li(SceneView<LDS> &S, LaneRng &rng, const RayT<AD> &ray_in, bo
             const float sx = rng.next_1d(), sy = rng.next_1d();
             const bool its_is_emitter = mesh_emitter(S, its.mesh) >= 0;
             if (!its_is_emitter) {
-                PositionSample<AD> ps = sample_emitter_position<AD, LDS>(S, sx, sy);
+                PositionSample<AD> ps = sample_emitter_position<AD, LDS>(S, detach(its.p), sx, sy);
                 S.note_slot(ps.slot);
                 V wod = ps.p - its.p;
                 const R dist_sqr = squared_norm(wod);
@@ -369,7 +463,7 @@ PSDR_DEV VecN<AD> Li(SceneView<LDS> &S, LaneRng &rng, const RayT<AD> &ray_in, bo
                 if (its1.t < kEpsilon) bsdf_val = V(0.f);
                 else bsdf_val = bsdf_eval<AD, LDS>(S, its, bs.wo, true) / bs.pdf;
             }
-            const float weight2 = mis_weight(pdf0, emitter_position_pdf<AD, LDS>(S, its1));
+            const float weight2 = mis_weight(pdf0, emitter_position_pdf<AD, LDS>(S, detach(its.p), its1));
             throughput = throughput * bsdf_val;
             result = result + eval_Le<AD, LDS>(S, its1, true) * throughput * R(weight2);
             its = its1;

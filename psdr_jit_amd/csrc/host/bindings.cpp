@@ -151,8 +151,36 @@ PYBIND11_MODULE(_psdr_core, m) {
             for (size_t i = 0; i < me.edges.size(); ++i) { const MeshEdge &e = me.edges[i]; o[5 * i] = e.v0; o[5 * i + 1] = e.v1; o[5 * i + 2] = e.f0; o[5 * i + 3] = e.f1; o[5 * i + 4] = e.opp; }
             return a; });
 
+    py::class_<EnvironmentMap, Emitter>(m, "EnvironmentMap", py::dynamic_attr())
+        .def(py::init<>())
+        .def(py::init([](const farr &rgb) {
+            if (rgb.ndim() != 3 || rgb.shape(2) != 3) throw Exception("EnvironmentMap: radiance must be a [height, width, 3] array");
+            std::vector<float> d(rgb.data(), rgb.data() + rgb.size());
+            return new EnvironmentMap((int) rgb.shape(1), (int) rgb.shape(0), d); }))
+        .def_readonly("sampling_weight", &EnvironmentMap::m_sampling_weight)
+        .def_readwrite("scale", &EnvironmentMap::scale)
+        .def_readonly("width", &EnvironmentMap::width).def_readonly("height", &EnvironmentMap::height)
+        .def("_get", [](const EnvironmentMap &e, const std::string &name, bool tangent) {
+            if (name == "radiance") {
+                farr a({(py::ssize_t) e.height, (py::ssize_t) e.width, (py::ssize_t) 3});
+                if (tangent) std::memset(a.mutable_data(), 0, sizeof(float) * a.size()); else std::memcpy(a.mutable_data(), e.data.data(), sizeof(float) * e.data.size());
+                return a;
+            }
+            const M16 &mm = name == "to_world_left" ? e.to_world_left : e.to_world_raw;
+            farr a({4, 4});
+            if (tangent) std::memset(a.mutable_data(), 0, 64); else std::memcpy(a.mutable_data(), mm.data(), 64);
+            return a; })
+        .def("_set", [](EnvironmentMap &e, const std::string &name, const farr &v, const farr &) {
+            if (name == "radiance") {
+                if (v.ndim() != 3 || v.shape(2) != 3) throw Exception("EnvironmentMap: radiance must be a [height, width, 3] array");
+                e.height = (int) v.shape(0); e.width = (int) v.shape(1); e.data.assign(v.data(), v.data() + v.size());
+            } else if (name == "to_world_left") e.to_world_left = to_m16(v);
+            else e.to_world_raw = to_m16(v);
+            e.m_ready = false; });
+
     py::class_<Scene, Object>(m, "Scene", py::dynamic_attr())
         .def(py::init<>())
+        .def("_add_EnvironmentMap", &Scene::add_EnvironmentMap)
         .def("add_Sensor", &Scene::add_Sensor, "Add Sensor")
         .def("_add_Mesh_file", [](Scene &s, const std::string &f, const farr &t, const std::string &b, const Emitter *e) { s.add_Mesh(f, to_m16(t), b, e); })
         .def("_add_Mesh_obj", [](Scene &s, const Mesh *mesh, const std::string &b, const Emitter *e) { s.add_Mesh(mesh, b, e); })
@@ -206,6 +234,17 @@ PYBIND11_MODULE(_psdr_core, m) {
             out["uv"] = from_vec(S.uv, 6);
             out["sec_edge_cmf"] = from_vec(S.sec_edge_distrb.cmf, 1);
             out["face_cmf"] = from_vec(S.face_cmf, 1);
+            std::vector<float> ew;
+            for (const psdr_emitter_rec &e : S.emitters) ew.push_back(e.sampling_weight);
+            out["emitter_weights"] = from_vec(ew, 1);
+            if (S.has_envmap && s.m_emitter_env) {
+                const EnvironmentMap &E = *s.m_emitter_env;
+                out["env_cell_pmf"] = from_vec(E.cell_distrb.pmf, 1); out["env_cell_cmf"] = from_vec(E.cell_distrb.cmf, 1);
+                out["env_cell_sum"] = E.cell_distrb.sum;
+                std::vector<float> b = {E.lower[0], E.lower[1], E.lower[2], E.upper[0], E.upper[1], E.upper[2]};
+                out["env_bounds"] = from_vec(b, 1);
+                out["env_reso"] = py::make_tuple(E.reso[0], E.reso[1]);
+            }
             return out; });
 
     py::class_<Integrator, Object>(m, "Integrator", py::dynamic_attr())

@@ -1,6 +1,7 @@
 // scene_host.cpp — host scene model: OBJ loading, Mesh/Camera/Scene::configure, snapshot assembly and
 // the render drivers that call libpsdr_hip.so.  Reference sites are cited per function.
 #include "scene_host.h"
+#include "../common/envmath.h"
 
 #include <algorithm>
 #include <chrono>
@@ -46,6 +47,28 @@ void Distrb::init(const std::vector<float> &p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// EnvironmentMap::configure, reference src/emitter/envmap.cpp:17-44
+void EnvironmentMap::configure() {
+    m_sampling_weight = 0.0f;
+    PSDR_ASSERT(width > 1 && height > 1);
+    PSDR_ASSERT_MSG(data.size() == (size_t) 3 * width * height, "Bitmap: invalid data size!");
+    const int w2 = (width - 1) << 1, h2 = (height - 1) << 1;
+    reso[0] = w2; reso[1] = h2;
+    std::vector<float> mass((size_t) w2 * h2);
+    for (int idx = 0; idx < w2 * h2; ++idx) mass[idx] = psdr::env::cell_mass(data.data(), width, height, w2, h2, idx);
+    cell_distrb.init(mass);
+    const M16 z = zeros16();
+    const DM4 tw = DM4::from(to_world_left, z) * DM4::from(to_world_raw, z);
+    const DM4 fw = inverse(tw);
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { to_world[4 * i + j] = tw.m[i][j].v; from_world[4 * i + j] = fw.m[i][j].v; }
+    m_ready = true;
+}
+std::string EnvironmentMap::to_string() const {
+    std::ostringstream oss;
+    oss << "EnvironmentMap[sampling_weight = " << m_sampling_weight << "]";
+    return oss.str();
+}
+
 static DM4 mul3(const M16 &l, const M16 &dl, const M16 &r, const M16 &dr, const M16 &rt, const M16 &drt) {
     return DM4::from(l, dl) * DM4::from(r, dr) * DM4::from(rt, drt);
 }
@@ -434,6 +457,15 @@ void Scene::add_Mesh(const Mesh *mesh_, const std::string &bsdf_id, const Emitte
     rebuild_param_map();
 }
 
+void Scene::add_EnvironmentMap(const EnvironmentMap *emitter_) {                                                           // scene.cpp:97-105
+    PSDR_ASSERT_MSG(m_emitter_env == nullptr, "A scene is only allowed to have one envmap!");
+    PSDR_ASSERT_MSG(emitter_ != nullptr, "Unknown emitter type!");
+    EnvironmentMap *emitter = new EnvironmentMap(*emitter_);
+    m_emitters.push_back(emitter);
+    m_emitter_env = emitter;
+    rebuild_param_map();
+}
+
 bool Scene::is_ready() const {
     return m_configured && m_hip != nullptr && (m_opts.spp == 0 || m_samplers[0].ready) && (m_opts.sppe == 0 || m_samplers[1].ready) &&
            (m_opts.sppse == 0 || m_samplers[2].ready);
@@ -473,9 +505,10 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
 
     Snapshot &S = snap;
     S = Snapshot();
-    for (int k = 0; k < 3; ++k) { m_lower[k] = std::numeric_limits<float>::max(); m_upper[k] = -std::numeric_limits<float>::max(); }
+    // m_upper starts at numeric_limits<float>::min(), the smallest positive float, as in the reference (scene.cpp:357-358)
+    for (int k = 0; k < 3; ++k) { m_lower[k] = std::numeric_limits<float>::max(); m_upper[k] = std::numeric_limits<float>::min(); }
     int face_offset = 0;
-    for (Mesh *mesh : m_meshes) {
+    auto append_mesh = [&](Mesh *mesh) {
         mesh->configure();
         psdr_mesh_rec r{};
         r.bsdf_id = mesh->m_bsdf_id; r.emitter_id = mesh->m_emitter_id; r.face_offset = face_offset; r.n_faces = mesh->m_num_faces;
@@ -501,7 +534,8 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
         face_offset += mesh->m_num_faces;
         for (int v = 0; v < mesh->m_num_vertices; ++v)
             for (int k = 0; k < 3; ++k) { m_lower[k] = std::min(m_lower[k], mesh->vertex_positions[3 * v + k]); m_upper[k] = std::max(m_upper[k], mesh->vertex_positions[3 * v + k]); }
-    }
+    };
+    for (Mesh *mesh : m_meshes) append_mesh(mesh);
 
     // sensors: only the active ones keep their primary-edge list (scene.cpp:381-416)
     std::vector<size_t> num_edges;
@@ -524,24 +558,67 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
         }
     }
 
-    // emitters (area.cpp:9-14, scene.cpp:488-515)
+    // environment lighting: margin + bounding cube, added once (scene.cpp:434-485)
+    if (m_emitter_env != nullptr && !m_has_bound_mesh) {
+        const float margin = std::min(m_upper[0] - m_lower[0], std::min(m_upper[1] - m_lower[1], m_upper[2] - m_lower[2])) * 0.05f;
+        for (int k = 0; k < 3; ++k) { m_lower[k] -= margin; m_upper[k] += margin; m_emitter_env->lower[k] = m_lower[k]; m_emitter_env->upper[k] = m_upper[k]; }
+        static const int face_data[3][12] = {{0, 0, 1, 1, 2, 2, 0, 0, 0, 0, 4, 4}, {1, 3, 5, 7, 3, 7, 5, 4, 2, 6, 7, 6}, {3, 2, 7, 3, 7, 6, 1, 5, 6, 4, 5, 7}};
+        Mesh *bound = new Mesh();
+        bound->m_num_vertices = 8; bound->m_num_faces = 12;
+        bound->m_use_face_normals = true; bound->m_enable_edges = false;
+        bound->m_bsdf = nullptr; bound->m_bsdf_id = -1;
+        bound->m_emitter = m_emitter_env;
+        bound->m_emitter_id = (int) (std::find(m_emitters.begin(), m_emitters.end(), (Emitter *) m_emitter_env) - m_emitters.begin());
+        bound->m_mesh_id = (int) m_meshes.size();
+        bound->vertex_positions_raw.resize(24);
+        for (int i = 0; i < 8; ++i) for (int j = 0; j < 3; ++j) bound->vertex_positions_raw[3 * i + j] = (i & (1 << j)) ? m_upper[j] : m_lower[j];
+        bound->face_indices.resize(36);
+        for (int f = 0; f < 12; ++f) for (int k = 0; k < 3; ++k) bound->face_indices[3 * f + k] = face_data[k][f];
+        m_emitter_env->m_bound_mesh_id = bound->m_mesh_id;
+        m_meshes.push_back(bound);
+        ++m_num_meshes;
+        m_has_bound_mesh = true;
+        append_mesh(bound);
+        if (m_opts.log_level > 0) log("Bounding mesh added for environmental lighting.");
+    }
+
+    // emitters (area.cpp:9-14, envmap.cpp:17-44, scene.cpp:488-515)
     if (!m_emitters.empty()) {
         std::vector<float> weights;
+        double total_weight = 0.0;
         for (Emitter *e : m_emitters) {
-            AreaLight *al = static_cast<AreaLight *>(e);
-            PSDR_ASSERT(al->m_mesh != nullptr && al->m_mesh->m_ready);
-            al->m_sampling_weight = al->m_mesh->m_total_area * (al->radiance[0] * .2126f + al->radiance[1] * .7152f + al->radiance[2] * .0722f);
-            al->m_ready = true;
-            weights.push_back(al->m_sampling_weight);
+            if (EnvironmentMap *env = dynamic_cast<EnvironmentMap *>(e)) {
+                env->configure();
+            } else {
+                AreaLight *al = static_cast<AreaLight *>(e);
+                PSDR_ASSERT(al->m_mesh != nullptr && al->m_mesh->m_ready);
+                al->m_sampling_weight = al->m_mesh->m_total_area * (al->radiance[0] * .2126f + al->radiance[1] * .7152f + al->radiance[2] * .0722f);
+                al->m_ready = true;
+            }
+            total_weight += e->m_sampling_weight;
         }
+        for (Emitter *e : m_emitters) if (dynamic_cast<EnvironmentMap *>(e)) e->m_sampling_weight = (float) total_weight;
+        for (Emitter *e : m_emitters) weights.push_back(e->m_sampling_weight);
         S.emitters_distrb.init(weights);
         const float inv_total = 1.f / S.emitters_distrb.sum;
         for (Emitter *e : m_emitters) {
-            AreaLight *al = static_cast<AreaLight *>(e);
-            al->m_sampling_weight *= inv_total;
+            e->m_sampling_weight *= inv_total;
             psdr_emitter_rec r{};
-            r.mesh_id = al->m_mesh->m_mesh_id; r.sampling_weight = al->m_sampling_weight;
-            for (int k = 0; k < 3; ++k) { r.radiance[k] = al->radiance[k]; r.d_radiance[k] = al->d_radiance[k]; }
+            r.sampling_weight = e->m_sampling_weight;
+            if (EnvironmentMap *env = dynamic_cast<EnvironmentMap *>(e)) {
+                r.type = 1; r.mesh_id = env->m_bound_mesh_id;
+                psdr_envmap_rec &er = S.envmap;
+                er.width = env->width; er.height = env->height; er.radiance = env->data.data(); er.scale = env->scale;
+                std::memcpy(er.to_world, env->to_world, 64); std::memcpy(er.from_world, env->from_world, 64);
+                for (int k = 0; k < 3; ++k) { er.lower[k] = env->lower[k]; er.upper[k] = env->upper[k]; }
+                er.reso[0] = env->reso[0]; er.reso[1] = env->reso[1];
+                er.cell_pmf = env->cell_distrb.pmf.data(); er.cell_cmf = env->cell_distrb.cmf.data(); er.cell_sum = env->cell_distrb.sum;
+                S.has_envmap = true;
+            } else {
+                AreaLight *al = static_cast<AreaLight *>(e);
+                r.type = 0; r.mesh_id = al->m_mesh->m_mesh_id;
+                for (int k = 0; k < 3; ++k) { r.radiance[k] = al->radiance[k]; r.d_radiance[k] = al->d_radiance[k]; }
+            }
             S.emitters.push_back(r);
         }
     }
@@ -601,6 +678,7 @@ void Scene::upload() {
     sn.n_meshes = (int) S.meshes.size(); sn.meshes = S.meshes.data();
     sn.n_bsdfs = (int) S.bsdfs.size(); sn.bsdfs = S.bsdfs.data();
     sn.n_emitters = (int) S.emitters.size(); sn.emitters = S.emitters.data();
+    sn.envmap = S.has_envmap ? &S.envmap : nullptr;
     sn.emitter_pmf = S.emitters_distrb.pmf.data(); sn.emitter_cmf = S.emitters_distrb.cmf.data(); sn.emitter_sum = S.emitters_distrb.sum;
     sn.n_face_distrb = (int) S.face_pmf.size(); sn.face_pmf = S.face_pmf.data(); sn.face_cmf = S.face_cmf.data();
     psdr_sec_edges &se = sn.sec_edges;

@@ -78,6 +78,27 @@ struct AreaLight : Emitter {
     const Mesh *m_mesh = nullptr;
 };
 
+// EnvironmentMap, reference include/psdr/emitter/envmap.h + src/emitter/envmap.cpp.  The radiance is a lat-long
+// Bitmap3fD given as an array (the reference's constructor reads an OpenEXR file; the Python layer does the file I/O).
+struct EnvironmentMap : Emitter {
+    EnvironmentMap() {}
+    EnvironmentMap(int w, int h, const std::vector<float> &rgb) : width(w), height(h), data(rgb) {}
+    std::string type_name() const override { return "EnvironmentMap"; }
+    std::string to_string() const override;
+    void set_transform(const M16 &mat) { to_world_left = mat; m_ready = false; }      // envmap.h:19-22
+    void configure();                                                                  // envmap.cpp:17-44
+    int width = 0, height = 0;
+    std::vector<float> data;                                                           // [height*width*3] row-major rgb
+    float scale = 1.f;
+    M16 to_world_raw = identity16(), to_world_left = identity16();
+    // configured state
+    float to_world[16], from_world[16];
+    float lower[3] = {0, 0, 0}, upper[3] = {0, 0, 0};
+    int reso[2] = {0, 0};
+    Distrb cell_distrb;
+    int m_bound_mesh_id = -1;
+};
+
 struct Transformable {
     M16 to_world_raw = identity16(), to_world_left = identity16(), to_world_right = identity16();
     M16 d_to_world_raw = zeros16(), d_to_world_left = zeros16(), d_to_world_right = zeros16();
@@ -154,6 +175,7 @@ struct Scene : Object {
     void add_BSDF(const BSDF *bsdf, const std::string &bsdf_id, bool twoSide = false);
     void add_Mesh(const std::string &fname, const M16 &transform, const std::string &bsdf_id, const Emitter *emitter);
     void add_Mesh(const Mesh *mesh, const std::string &bsdf_id, const Emitter *emitter);
+    void add_EnvironmentMap(const EnvironmentMap *emitter);             // scene.cpp:85-105 (one per scene)
     void configure(const std::vector<int> &active_sensor = {});
     void configure_host(const std::vector<int> &active_sensor = {});   // host half (no device needed)
     void upload();                                                      // BVH build + device upload
@@ -170,6 +192,8 @@ struct Scene : Object {
     std::unordered_map<std::string, Object *> m_param_map;
     mutable SamplerState m_samplers[3];
     float m_lower[3], m_upper[3];
+    EnvironmentMap *m_emitter_env = nullptr;
+    bool m_has_bound_mesh = false;
 
     // configured snapshot (host arrays the psdr_scene_snapshot points into)
     struct Snapshot {
@@ -185,6 +209,8 @@ struct Scene : Object {
         std::vector<uint8_t> se_boundary;
         std::vector<psdr_sensor_rec> sensors;
         int n_sec_edges = 0;
+        psdr_envmap_rec envmap{};
+        bool has_envmap = false;
     } snap;
     psdr_hip_scene *m_hip = nullptr;
     bool m_configured = false, m_host_ready = false;

@@ -19,7 +19,21 @@ def build_scene(spec, configure=True, active=(0,), host_only=False, log_level=0)
         bs = psdr.DiffuseBSDF(list(b.reflectance))
         bs._set("reflectance", np.asarray(b.reflectance, np.float32), np.asarray(b.d_reflectance, np.float32))
         sc.add_BSDF(bs, b.name or ("bsdf%d" % i), b.two_sided)
+    def add_envs_before(k):
+        # emitters are numbered in the order they are added: keep the spec's numbering
+        for i, e in enumerate(spec.emitters):
+            if getattr(e, "type", 0) == 1 and i < k and i not in added_env:
+                env = psdr.EnvironmentMap(np.asarray(e.env_data, np.float32))
+                env.scale = float(e.env_scale)
+                env.to_world = np.asarray(e.env_to_world_raw, np.float32)
+                env.to_world_left = np.asarray(e.env_to_world_left, np.float32)
+                sc.add_EnvironmentMap(env)
+                added_env.add(i)
+
+    added_env = set()
     for m in spec.meshes:
+        if m.emitter >= 0:
+            add_envs_before(m.emitter)
         mesh = psdr.Mesh()
         mesh.enable_edges = m.enable_edges
         if m.path is not None:
@@ -40,6 +54,7 @@ def build_scene(spec, configure=True, active=(0,), host_only=False, log_level=0)
             em._set("radiance", np.asarray(e.radiance, np.float32), np.asarray(e.d_radiance, np.float32))
         b = spec.bsdfs[m.bsdf]
         sc.add_Mesh(mesh, b.name or ("bsdf%d" % m.bsdf), em)
+    add_envs_before(len(spec.emitters))
     if configure:
         if host_only:
             sc._configure_host(list(active))

@@ -33,7 +33,7 @@ def test_cabi_exports_every_declared_symbol(psdr):
     for name in declared:
         assert hasattr(L, name), "libpsdr_hip.so does not export %s" % name
     assert sorted(cabi.SYMBOLS) == declared
-    assert L.psdr_hip_abi_version() == 1
+    assert L.psdr_hip_abi_version() == 2
     # host-side sampler building block is bit-exact with the oracle / golden table
     import json
     with open(os.path.join(ROOT, "tests", "golden", "tea64.json")) as fh:
@@ -65,6 +65,39 @@ def test_host_snapshot_matches_oracle(psdr, orc, name, param):
     assert abs(sc.param_map["Emitter[0]"].sampling_weight - ref.emitter_sampling_weight(0)) == 0.0
     if name == "sphere":
         assert snap["sec_edges"].shape[0] == 990 and cam._primary_edges(False).shape[0] == 79   # Forward_AD.ipynb:139-140
+
+
+def test_host_envmap_configure_matches_oracle(psdr, orc):
+    """EnvironmentMap::configure, the bounding cube and the emitter weights (scene.cpp:434-515) on the host"""
+    spec = scenes.envmap_scene(32, 32, 4, 4, 4, param="box_x", area_light=True)
+    ref = orc.OracleScene(spec, [0])
+    sc = product.build_scene(spec, host_only=True)
+    snap = sc._snapshot()
+    assert sc.num_meshes == len(spec.meshes) + 1                       # + bounding cube
+    assert np.array_equal(snap["triangles"], ref.triangle_info(False)[:, :22])
+    assert np.array_equal(snap["d_triangles"], ref.triangle_info(True)[:, :22])
+    bounds, reso, cell_sum, pmf, cmf = ref.envmap_info()
+    assert tuple(snap["env_reso"]) == reso == (126, 62)
+    assert np.array_equal(np.asarray(snap["env_bounds"]).ravel(), bounds)
+    assert np.array_equal(np.asarray(snap["env_cell_pmf"]).ravel(), pmf) and np.array_equal(np.asarray(snap["env_cell_cmf"]).ravel(), cmf)
+    assert float(snap["env_cell_sum"]) == cell_sum
+    w = np.asarray(snap["emitter_weights"]).ravel()
+    assert w[0] == np.float32(ref.emitter_weight(0)) and w[1] == np.float32(ref.emitter_weight(1))
+    assert abs(w[0] - 0.5) < 1e-6 and abs(w[1] - 0.5) < 1e-6          # the envmap takes the summed weight of the others
+    # a second envmap is refused (scene.cpp:86)
+    with pytest.raises(RuntimeError, match="only allowed to have one envmap"):
+        sc.add_EnvironmentMap(psdr.EnvironmentMap(scenes.synthetic_envmap(8, 4)))
+
+
+def test_exr_round_trip(psdr, tmp_path):
+    from psdr_jit_amd import exr
+    img = (np.random.default_rng(0).random((19, 31, 3)) * 7).astype(np.float32)
+    for comp in ("none", "zip"):
+        f = str(tmp_path / ("a_%s.exr" % comp))
+        exr.write_rgb(f, img, comp)
+        assert np.array_equal(exr.read_rgb(f), img)
+    e = psdr.EnvironmentMap(str(tmp_path / "a_zip.exr"))
+    assert (e.width, e.height) == (31, 19) and np.array_equal(np.asarray(e.radiance), img)
 
 
 def test_obj_loader_matches_test_loader(psdr):
