@@ -167,7 +167,7 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
                 // shadow hits only need n, wi.z, t, J - except on the environment map, whose radiance is looked up along
                 // the direction rebuilt from the shading frame (envmap.cpp:47-56)
                 Its<AD> its1 = make_its<AD, LDS, false>(S, h, ray1, true);
-                if (T.env_emitter >= 0 && mesh_emitter(S, its1.mesh) == T.env_emitter) its1 = make_its<AD, LDS, true>(S, h, ray1, true);
+                if constexpr (!LDS) { if (T.env_emitter >= 0 && mesh_emitter(S, its1.mesh) == T.env_emitter) its1 = make_its<AD, LDS, true>(S, h, ray1, true); }
                 if ((detach(its1.t) > detach(dist) - kShadowEpsilon) && (mesh_emitter(S, its1.mesh) >= 0)) {
                     const R cos_val = dot(its1.n, -wod);
                     const R G_val = abs_(cos_val) / dist_sqr;

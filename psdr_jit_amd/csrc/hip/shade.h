@@ -197,6 +197,8 @@ PSDR_DEV float env_floor(float a) { return floorf(a); }
 PSDR_DEV Dual env_floor(const Dual &a) { return Dual(floorf(a.v), 0.f); }
 
 // EnvironmentMap::eval_direction, envmap.cpp:59-77 (the map's own transform and texels carry no tangent)
+// The environment-map branches exist only in the LDS=false instantiations: a scene with an environment map is never
+// staged into LDS (api.hip), so the small-scene kernels (all Cornell boxes) carry none of this code or its registers.
 template <bool AD> PSDR_DEV VecN<AD> env_eval_direction(const EnvDev &E, const VecN<AD> &wi) {
     using R = Num<AD>;
     VecN<AD> v;
@@ -257,10 +259,12 @@ template <bool AD, bool LDS> PSDR_DEV VecN<AD> eval_Le(const SceneView<LDS> &S, 
     if (!active || !its.valid) return V(Num<AD>(0.f));
     const int e = mesh_emitter(S, its.mesh);
     if (e < 0) return V(Num<AD>(0.f));
-    if (e == S.T->env_emitter) {               // EnvironmentMap::eval, envmap.cpp:47-56
-        V wi_world;
-        if constexpr (AD) wi_world = to_world_d(its, its.wi); else wi_world = to_world<false>(its, its.wi);
-        return env_eval_direction<AD>(S.T->env, -wi_world);
+    if constexpr (!LDS) {
+        if (e == S.T->env_emitter) {           // EnvironmentMap::eval, envmap.cpp:47-56
+            V wi_world;
+            if constexpr (AD) wi_world = to_world_d(its, its.wi); else wi_world = to_world<false>(its, its.wi);
+            return env_eval_direction<AD>(S.T->env, -wi_world);
+        }
     }
     if (!(detach(its.wi.z) > 0.f)) return V(Num<AD>(0.f));
     const int w = S.T->emit_off + 2 * e;
@@ -282,7 +286,7 @@ template <bool AD, bool LDS> PSDR_DEV PositionSample<AD> sample_emitter_position
                           [&](int i) { return S.ldf(T.ecdf_off, i); },
                           [&](int i) { return S.ldf(T.ecdf_off, T.n_emitters + i); }, sy, epdf);
     }
-    if (ei == T.env_emitter) {
+    if (!LDS && ei == T.env_emitter) {
         Vec3f p, nn;
         float pdf_env;
         env_sample_position(T.env, ref_p, sx, sy, p, nn, pdf_env);
@@ -326,7 +330,7 @@ template <bool AD, bool LDS> PSDR_DEV float emitter_position_pdf(const SceneView
     if (!its.valid) return 0.f;
     const MeshRec m = load_mesh(S, its.mesh);
     if (m.emitter < 0) return 0.f;
-    if (m.emitter == S.T->env_emitter) return env_position_pdf(S.T->env, ref_p, detach(its.p), detach(its.n));
+    if (!LDS && m.emitter == S.T->env_emitter) return env_position_pdf(S.T->env, ref_p, detach(its.p), detach(its.n));
     return S.ld(S.T->emit_off + 2 * m.emitter).w * m.inv_total_area;
 }
 

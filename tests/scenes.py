@@ -147,13 +147,15 @@ def synthetic_envmap(width=64, height=32, sun=True):
     return img.astype(np.float32)
 
 
-def envmap_scene(width=64, height=64, spp=4, sppe=0, sppse=0, param="albedo", env=None, area_light=False, floor_only=False):
+def envmap_scene(width=64, height=64, spp=4, sppe=0, sppse=0, param="albedo", env=None, area_light=False, floor_only=False, balls=False):
     """Cornell-box furniture (floor + the two boxes) under an environment map - the Forward_AD_envmap layout in
     small.  param: 'albedo' (d box reflectance / dP = (1,1,1)), 'box_x' (small box translated by 100*P in x), None."""
     bsdfs = [BsdfSpec((0.5, 0.5, 0.5), name="cat"), BsdfSpec((0.8, 0.8, 0.8), name="white"), BsdfSpec((0.0, 0.0, 0.0), name="light")]
     emitters = [EmitterSpec(type=1, env_data=env if env is not None else synthetic_envmap(), env_scale=1.0)]
     meshes = [_mesh("cbox_floor.obj", 1)]
-    if not floor_only:
+    if balls:      # the tutorial spheres (304 + 304 triangles): more than 64 triangles, so the BVH path is taken
+        meshes = [_mesh("cbox_smallball.obj", 0), _mesh("cbox_largeball.obj", 0)] + meshes
+    elif not floor_only:
         meshes = [_mesh("cbox_smallbox.obj", 0), _mesh("cbox_largebox.obj", 0)] + meshes
     if area_light:
         emitters.append(EmitterSpec((20.0, 20.0, 8.0)))
