@@ -160,7 +160,9 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
             ext.o = its.p; ext.d = to_world<AD>(its, bs.wo);
         }
         Hit h, hx;
-        trace2<LDS, COUNT>(S, detach(ray1.o), detach(ray1.d), do_nee, detach(ext.o), detach(ext.d), busy, h, hx);
+        // an invalid BSDF sample (e.g. on the BSDF-less bounding cube of the environment map: wo = 0) ends the path whatever
+        // its ray hits; a zero-direction ray would wander through every BVH node that contains its origin
+        trace2<LDS, COUNT>(S, detach(ray1.o), detach(ray1.d), do_nee, detach(ext.o), detach(ext.d), busy && bs.valid, h, hx);
         {
             if (do_nee && h.slot >= 0) {
                 if (COUNT) S.c_hits++;

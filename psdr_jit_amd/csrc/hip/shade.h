@@ -448,7 +448,7 @@ PSDR_DEV VecN<AD> Li(SceneView<LDS> &S, LaneRng &rng, const RayT<AD> &ray_in, bo
             (void) s0;
             const BSDFSample bs = bsdf_sample<AD, LDS>(S, its, s1, s2, true);
             RayT<AD> curr; curr.o = its.p; curr.d = to_world<AD>(its, bs.wo);
-            Its<AD> its1 = ray_intersect<AD, AD, LDS, COUNT>(S, curr, true);
+            Its<AD> its1 = ray_intersect<AD, AD, LDS, COUNT>(S, curr, bs.valid);     // (an invalid sample ends the path)
             active = bs.valid && its1.valid;
             if (!active) continue;
             V bsdf_val;

@@ -177,3 +177,47 @@ def _rot_x(a):
     c, s = np.cos(a), np.sin(a)
     m[1, 1], m[1, 2], m[2, 1], m[2, 2] = c, -s, s, c
     return m
+
+
+def icosphere(level=3, radius=1.0, noise=0.0, seed=0):
+    """Icosphere with 20*4^level triangles; `noise` scales a seeded radial perturbation (BASELINE config 5's
+    ~100k-triangle mesh: level 6 = 81920 triangles, numpy.random.default_rng(0))."""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = [[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t], [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]]
+    f = [[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2], [10, 7, 6], [7, 1, 8],
+         [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5], [2, 4, 11], [6, 2, 10], [8, 6, 7], [9, 8, 1]]
+    v = [np.asarray(p, np.float64) / np.linalg.norm(p) for p in v]
+    for _ in range(level):
+        cache, nf = {}, []
+        def mid(a, b):
+            key = (a, b) if a < b else (b, a)
+            if key not in cache:
+                m = v[a] + v[b]
+                v.append(m / np.linalg.norm(m))
+                cache[key] = len(v) - 1
+            return cache[key]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [[a, ab, ca], [b, bc, ab], [c, ca, bc], [ab, bc, ca]]
+        f = nf
+    v = np.asarray(v)
+    if noise > 0:
+        v = v * (1.0 + noise * np.random.default_rng(seed).standard_normal(len(v)))[:, None]
+    return (v * radius).astype(np.float32), np.asarray(f, dtype=np.int32)
+
+
+def config5_scene(width=128, height=128, spp=4, sppe=4, sppse=4, level=6, env_res=(1024, 512), param="albedo"):
+    """BASELINE config 5: a ~100k-triangle mesh on a floor under a synthetic 1024x512 lat-long map
+    (constant sky + one Gaussian sun), DiffuseBSDF albedo of the mesh as the parameter."""
+    v, f = icosphere(level, radius=150.0, noise=0.01, seed=0)
+    bsdfs = [BsdfSpec((0.5, 0.5, 0.5), name="blob"), BsdfSpec((0.8, 0.8, 0.8), name="white")]
+    emitters = [EmitterSpec(type=1, env_data=synthetic_envmap(env_res[0], env_res[1]), env_scale=1.0)]
+    blob = MeshSpec(vertices=v, faces=f, uvs=None, face_uvs=None, bsdf=0, emitter=-1)
+    blob.to_world_raw = translate(278.0, 160.0, 280.0)
+    meshes = [blob, _mesh("cbox_floor.obj", 1)]
+    cam = CameraSpec(60.0, 0.000001, 10000000.0, to_world_raw=translate(278.0, 400.0, -700.0) @ _rot_x(np.radians(25.0)))
+    if param == "albedo":
+        bsdfs[0].d_reflectance = (1.0, 1.0, 1.0)
+    elif param is not None:
+        raise ValueError(param)
+    return SceneSpec(meshes, bsdfs, emitters, [cam], width, height, spp, sppe, sppse)
