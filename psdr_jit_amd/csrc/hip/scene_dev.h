@@ -146,6 +146,86 @@ PSDR_DEV Hit trace(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
     return h;
 }
 
+// BVH traversal of up to two rays per lane (scenes with more than kBruteForceMax triangles).
+// "while-while" (all lanes of the wave first walk inner nodes until each holds a leaf or is done, then all leaves are
+// intersected together; mixing both in one loop body made every iteration pay for up to four triangle tests even when a
+// single lane was at a leaf) with a per-lane ray queue: a lane that finishes its first ray starts its second one in the
+// next round instead of idling until the whole wave has finished the first pass (config 5 measured 13 % of the lanes
+// active per VALU instruction with one pass per ray).  Each ray sees the same nodes, tests and (t, id) order as alone.
+template <bool LDS, bool COUNT>
+PSDR_DEV void bvh_trace2(SceneView<LDS> &S, const Vec3f &oA, const Vec3f &dA, bool actA, const Vec3f &oB, const Vec3f &dB, bool actB,
+                         Hit &hA, Hit &hB) {
+    const SceneTables &T = *S.T;
+    constexpr int kDone = (int) 0x80000000;
+    hA.slot = -1; hA.u = hA.v = hA.t = 0.f;
+    hB.slot = -1; hB.u = hB.v = hB.t = 0.f;
+    int pending = (actA ? 1 : 0) | (actB ? 2 : 0);
+    int cur = -1, sp = 0, ref = kDone;
+    Vec3f o(0.f), d(0.f);
+    float ix = 0.f, iy = 0.f, iz = 0.f, best_t = 0.f;
+    int best_id = 0;
+    Hit best; best.slot = -1; best.u = best.v = best.t = 0.f;
+    for (;;) {
+        if (ref == kDone) {                                   // retire the finished ray, take the next one
+            if (cur == 0) hA = best; else if (cur == 1) hB = best;
+            cur = -1;
+            if (pending != 0) {
+                cur = (pending & 1) ? 0 : 1;
+                pending &= ~(1 << cur);
+                o = cur == 0 ? oA : oB; d = cur == 0 ? dA : dB;
+                best.slot = -1; best.u = best.v = best.t = 0.f;
+                best_t = __builtin_inff(); best_id = 0x7fffffff;
+                sp = 0;
+                // NaN rays miss (reference scene_optix.cpp:348-353)
+                const bool ok = (o.x == o.x && o.y == o.y && o.z == o.z && d.x == d.x && d.y == d.y && d.z == d.z);
+                ref = ok ? 0 : kDone;
+                ix = 1.f / d.x; iy = 1.f / d.y; iz = 1.f / d.z;
+                if (COUNT) { if (ok) S.c_rays++; }
+            }
+        }
+        if (__ballot(ref != kDone || cur >= 0) == 0ull) break;
+        while (ref >= 0) {
+            const int w = T.nodes_off + 4 * ref;
+            const float4 q0 = S.ld(w), q1 = S.ld(w + 1), q2 = S.ld(w + 2), q3 = S.ld(w + 3);
+            if (COUNT) S.c_nodes++;
+            // slab tests; fminf/fmaxf drop NaNs (0 * inf), which keeps the test conservative
+            float t0, t1, tnL = 0.f, tfL = best_t, tnR = 0.f, tfR = best_t;
+            t0 = (q0.x - o.x) * ix; t1 = (q1.x - o.x) * ix; tnL = fmaxf(tnL, fminf(t0, t1)); tfL = fminf(tfL, fmaxf(t0, t1) * 1.0000004f);
+            t0 = (q0.y - o.y) * iy; t1 = (q1.y - o.y) * iy; tnL = fmaxf(tnL, fminf(t0, t1)); tfL = fminf(tfL, fmaxf(t0, t1) * 1.0000004f);
+            t0 = (q0.z - o.z) * iz; t1 = (q1.z - o.z) * iz; tnL = fmaxf(tnL, fminf(t0, t1)); tfL = fminf(tfL, fmaxf(t0, t1) * 1.0000004f);
+            t0 = (q2.x - o.x) * ix; t1 = (q3.x - o.x) * ix; tnR = fmaxf(tnR, fminf(t0, t1)); tfR = fminf(tfR, fmaxf(t0, t1) * 1.0000004f);
+            t0 = (q2.y - o.y) * iy; t1 = (q3.y - o.y) * iy; tnR = fmaxf(tnR, fminf(t0, t1)); tfR = fminf(tfR, fmaxf(t0, t1) * 1.0000004f);
+            t0 = (q2.z - o.z) * iz; t1 = (q3.z - o.z) * iz; tnR = fmaxf(tnR, fminf(t0, t1)); tfR = fminf(tfR, fmaxf(t0, t1) * 1.0000004f);
+            const bool hL = tnL <= tfL, hR = tnR <= tfR;
+            const int rL = __float_as_int(q0.w), rR = __float_as_int(q1.w);
+            if (hL && hR) {
+                const bool left_first = tnL <= tnR;
+                S.stack[sp * kBlock] = left_first ? rR : rL;
+                ++sp;
+                ref = left_first ? rL : rR;
+            } else if (hL) ref = rL;
+            else if (hR) ref = rR;
+            else if (sp == 0) ref = kDone;
+            else { --sp; ref = S.stack[sp * kBlock]; }
+        }
+        if (ref != kDone) {
+            const int code = ~ref, first = code >> 2, cnt = (code & 3) + 1;
+            for (int k = 0; k < cnt; ++k) {
+                const int w = T.trav_off + 3 * (first + k);
+                const float4 a = S.ld(w), b = S.ld(w + 1), c = S.ld(w + 2);
+                float u, v, t;
+                if (COUNT) S.c_tris++;
+                if (tri_test(a, b, c, o, d, u, v, t)) {
+                    const int id = __float_as_int(c.y);
+                    if (t < best_t || (t == best_t && id < best_id)) { best_t = t; best_id = id; best.slot = first + k; best.u = u; best.v = v; best.t = t; }
+                }
+            }
+            if (sp == 0) ref = kDone;
+            else { --sp; ref = S.stack[sp * kBlock]; }
+        }
+    }
+}
+
 template <bool LDS, bool COUNT>
 PSDR_DEV Hit trace_scene(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
     Hit best; best.slot = -1; best.u = best.v = 0.f; best.t = 0.f;
@@ -206,58 +286,8 @@ PSDR_DEV Hit trace_scene(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
         }
         return best;
     }
-    const float ix = 1.f / d.x, iy = 1.f / d.y, iz = 1.f / d.z;
-    int sp = 0;
-    int ref = 0;
-    constexpr int kDone = (int) 0x80000000;
-    if (COUNT) S.c_rays++;
-    // "while-while" traversal: all lanes of the wave first walk inner nodes until each holds a leaf (or is
-    // done), then all leaves are intersected together.  Mixing both in one loop body made every iteration
-    // pay for up to four triangle tests even when a single lane was at a leaf (stage r01a: ~3900 lane
-    // instructions per ray against ~900 of useful work).
-    while (true) {
-        while (ref >= 0) {
-            const int w = T.nodes_off + 4 * ref;
-            const float4 q0 = S.ld(w), q1 = S.ld(w + 1), q2 = S.ld(w + 2), q3 = S.ld(w + 3);
-            if (COUNT) S.c_nodes++;
-            // slab tests; fminf/fmaxf drop NaNs (0 * inf), which keeps the test conservative
-            float t0, t1, tnL = 0.f, tfL = best_t, tnR = 0.f, tfR = best_t;
-            t0 = (q0.x - o.x) * ix; t1 = (q1.x - o.x) * ix; tnL = fmaxf(tnL, fminf(t0, t1)); tfL = fminf(tfL, fmaxf(t0, t1) * 1.0000004f);
-            t0 = (q0.y - o.y) * iy; t1 = (q1.y - o.y) * iy; tnL = fmaxf(tnL, fminf(t0, t1)); tfL = fminf(tfL, fmaxf(t0, t1) * 1.0000004f);
-            t0 = (q0.z - o.z) * iz; t1 = (q1.z - o.z) * iz; tnL = fmaxf(tnL, fminf(t0, t1)); tfL = fminf(tfL, fmaxf(t0, t1) * 1.0000004f);
-            t0 = (q2.x - o.x) * ix; t1 = (q3.x - o.x) * ix; tnR = fmaxf(tnR, fminf(t0, t1)); tfR = fminf(tfR, fmaxf(t0, t1) * 1.0000004f);
-            t0 = (q2.y - o.y) * iy; t1 = (q3.y - o.y) * iy; tnR = fmaxf(tnR, fminf(t0, t1)); tfR = fminf(tfR, fmaxf(t0, t1) * 1.0000004f);
-            t0 = (q2.z - o.z) * iz; t1 = (q3.z - o.z) * iz; tnR = fmaxf(tnR, fminf(t0, t1)); tfR = fminf(tfR, fmaxf(t0, t1) * 1.0000004f);
-            const bool hL = tnL <= tfL, hR = tnR <= tfR;
-            const int rL = __float_as_int(q0.w), rR = __float_as_int(q1.w);
-            if (hL && hR) {
-                const bool left_first = tnL <= tnR;
-                S.stack[sp * kBlock] = left_first ? rR : rL;
-                ++sp;
-                ref = left_first ? rL : rR;
-            } else if (hL) ref = rL;
-            else if (hR) ref = rR;
-            else if (sp == 0) ref = kDone;
-            else { --sp; ref = S.stack[sp * kBlock]; }
-        }
-        if (ref == kDone) break;
-        {
-            const int code = ~ref, first = code >> 2, cnt = (code & 3) + 1;
-            for (int k = 0; k < cnt; ++k) {
-                const int w = T.trav_off + 3 * (first + k);
-                const float4 a = S.ld(w), b = S.ld(w + 1), c = S.ld(w + 2);
-                float u, v, t;
-                if (COUNT) S.c_tris++;
-                if (tri_test(a, b, c, o, d, u, v, t)) {
-                    const int id = __float_as_int(c.y);
-                    if (t < best_t || (t == best_t && id < best_id)) { best_t = t; best_id = id; best.slot = first + k; best.u = u; best.v = v; best.t = t; }
-                }
-            }
-        }
-        if (sp == 0) break;
-        --sp;
-        ref = S.stack[sp * kBlock];
-    }
+    Hit other;
+    bvh_trace2<LDS, COUNT>(S, o, d, true, o, d, false, best, other);
     return best;
 }
 
@@ -272,11 +302,12 @@ PSDR_DEV void trace2(SceneView<LDS> &S, const Vec3f &oA_, const Vec3f &dA, bool 
     hA.slot = -1; hA.u = hA.v = hA.t = 0.f;
     hB.slot = -1; hB.u = hB.v = hB.t = 0.f;
     const SceneTables &T = *S.T;
-    if (S.mode != 0 || T.n_tris > kBruteForceMax) {
+    if (S.mode != 0) {
         if (actA) hA = trace<LDS, COUNT>(S, oA_, dA);
         if (actB) hB = trace<LDS, COUNT>(S, oB_, dB);
         return;
     }
+    if (T.n_tris > kBruteForceMax) { bvh_trace2<LDS, COUNT>(S, oA_, dA, actA, oB_, dB, actB, hA, hB); return; }
     const float qnan = __builtin_nanf("");
     const Vec3f oA = actA ? oA_ : Vec3f(qnan), oB = actB ? oB_ : Vec3f(qnan);
     if (COUNT) { const unsigned n = (actA ? 1u : 0u) + (actB ? 1u : 0u); S.c_rays += n; S.c_tris += n * (unsigned) T.n_tris; }

@@ -25,7 +25,11 @@ def short(name):
     return n.split("(")[0]
 
 
+PREFIX = ""
+
+
 def db_of(d):
+    d = PREFIX + d.replace("prof_", "") if PREFIX else d
     f = glob.glob(os.path.join(OUT, d, "**", "*_results.db"), recursive=True)
     f.sort(key=os.path.getmtime)
     return sqlite3.connect(f[-1]) if f else None
@@ -88,6 +92,8 @@ def pmc(tag):
 
 if __name__ == "__main__":
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    if len(sys.argv) > 2:
+        PREFIX = sys.argv[2]
     os.makedirs(PROF, exist_ok=True)
     kernel_stats(tag)
     pmc(tag)
