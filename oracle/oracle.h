@@ -40,6 +40,10 @@ typedef struct orc_bsdf {            /* Diffuse, include/psdr/bsdf/diffuse.h */
     int type;                        /* 0 = diffuse */
     float reflectance[3], d_reflectance[3];
     int two_sided;
+    /* textured reflectance (Bitmap3fD with resolution > 1x1, bitmap.cpp:47-128): tex_data != NULL overrides `reflectance` */
+    int tex_width, tex_height;
+    const float *tex_data;           /* [tex_height*tex_width*3] row-major rgb */
+    const float *d_tex_data;         /* optional tangent of the texels */
 } orc_bsdf;
 
 typedef struct orc_emitter {         /* AreaLight (include/psdr/emitter/area.h) or EnvironmentMap (emitter/envmap.h) */

@@ -65,6 +65,8 @@ class BsdfSpec:
     d_reflectance: tuple = (0.0, 0.0, 0.0)
     two_sided: bool = False
     name: str = ""
+    texture: Optional[np.ndarray] = None      # [H, W, 3] reflectance texture (Bitmap3fD), overrides `reflectance`
+    d_texture: Optional[np.ndarray] = None    # tangent of the texels
 
 
 @dataclass
@@ -121,7 +123,8 @@ class _Mesh(C.Structure):
 
 
 class _Bsdf(C.Structure):
-    _fields_ = [("type", C.c_int), ("reflectance", _F3), ("d_reflectance", _F3), ("two_sided", C.c_int)]
+    _fields_ = [("type", C.c_int), ("reflectance", _F3), ("d_reflectance", _F3), ("two_sided", C.c_int),
+                ("tex_width", C.c_int), ("tex_height", C.c_int), ("tex_data", C.POINTER(C.c_float)), ("d_tex_data", C.POINTER(C.c_float))]
 
 
 class _Emitter(C.Structure):
@@ -258,6 +261,17 @@ class OracleScene:
             bsdfs[i].reflectance = _F3(*b.reflectance)
             bsdfs[i].d_reflectance = _F3(*b.d_reflectance)
             bsdfs[i].two_sided = int(b.two_sided)
+            if getattr(b, "texture", None) is not None:
+                tex = np.ascontiguousarray(np.asarray(b.texture, dtype=np.float32))
+                assert tex.ndim == 3 and tex.shape[2] == 3
+                self._keep.append(tex)
+                bsdfs[i].tex_height, bsdfs[i].tex_width = tex.shape[0], tex.shape[1]
+                bsdfs[i].tex_data = tex.ctypes.data_as(C.POINTER(C.c_float))
+                if getattr(b, "d_texture", None) is not None:
+                    dt = np.ascontiguousarray(np.asarray(b.d_texture, dtype=np.float32))
+                    assert dt.shape == tex.shape
+                    self._keep.append(dt)
+                    bsdfs[i].d_tex_data = dt.ctypes.data_as(C.POINTER(C.c_float))
         emitters = (_Emitter * max(1, len(spec.emitters)))()
         for i, e in enumerate(spec.emitters):
             emitters[i].radiance = _F3(*e.radiance)

@@ -103,6 +103,41 @@ template <typename R> V3<R> envmap_bitmap_eval(const EnvmapC &E, R u, R v) {
     return lerp3(w0y, v0, w1y, v1);
 }
 
+// Bitmap<3>::eval<ad>(uv, flip_v = true, envmap_mode = false): the reflectance texture of Diffuse (diffuse.cpp:38);
+// 1x1 bitmaps return their value (bitmap.cpp:54-59).  Texels carry the tangent d_tex.
+template <bool ad> V3<Real<ad>> bsdf_reflectance(const BsdfC &b, const V2<Real<ad>> &uv) {
+    using R = Real<ad>;
+    if (b.tex_w == 0) {
+        if constexpr (ad) return b.reflectance; else return detach(b.reflectance);
+    }
+    const int W = b.tex_w, H = b.tex_h;
+    float sr, cr;
+    sincos_cephes(0.f, sr, cr);
+    R x = (uv.x - R(0.5f)) * R(cr) + (uv.y - R(0.5f)) * R(sr);
+    R y = -(uv.x - R(0.5f)) * R(sr) + (uv.y - R(0.5f)) * R(cr);
+    x = x + R(0.5f); y = y + R(0.5f);
+    y = -y;                                                                       // flip_v
+    x = x * R(1.f); y = y * R(1.f);
+    x = x - R(-.5f + 1.f / 2); y = y + R(-.5f + 1.f / 2);
+    x = x + R(0.f); y = y + R(0.f);
+    x = x - floor_(x); y = y - floor_(y);
+    x = x * R((float) (W - 1)); y = y * R((float) (H - 1));
+    int px = (int) std::floor(detach(x)), py = (int) std::floor(detach(y));
+    const R w1x = x - R((float) px), w1y = y - R((float) py), w0x = R(1.0f) - w1x, w0y = R(1.0f) - w1y;
+    px = std::max(std::min(px, W - 2), 0); py = std::max(std::min(py, H - 2), 0);
+    const int i00 = py * W + px, i10 = i00 + 1, i01 = i00 + W, i11 = i01 + 1;
+    auto texel = [&](int i, int c) -> R {
+        if constexpr (ad) return Dual(b.tex[3 * i + c], b.d_tex[3 * i + c]); else return b.tex[3 * i + c];
+    };
+    R out[3];
+    for (int c = 0; c < 3; ++c) {
+        const R v0 = fma_(w0x, texel(i00, c), w1x * texel(i10, c));
+        const R v1 = fma_(w0x, texel(i01, c), w1x * texel(i11, c));
+        out[c] = fma_(w0y, v0, w1y * v1);
+    }
+    return V3<R>(out[0], out[1], out[2]);
+}
+
 // EnvironmentMap::configure (envmap.cpp:17-44)
 inline void envmap_configure(EnvmapC &E) {
     if (!(E.width > 1 && E.height > 1)) throw std::runtime_error("EnvironmentMap: width > 1 && height > 1");

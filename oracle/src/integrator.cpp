@@ -320,7 +320,7 @@ template <bool ad> static V3<Real<ad>> bsdf_eval(const Scene &sc, const Its<ad> 
     if (b.two_sided) { wo.z = mulsign(wo.z, detach(wiz)); wiz = abs_(wiz); }
     active = active && (detach(wiz) > 0.f && detach(wo.z) > 0.f);
     if (!active) return V(R(0.f));
-    return pick<ad>(b.reflectance) * R(InvPi) * wo.z;
+    return bsdf_reflectance<ad>(b, its.uv) * R(InvPi) * wo.z;
 }
 template <bool ad> static float bsdf_pdf(const Scene &sc, const Its<ad> &its, const V3<Real<ad>> &wo_, bool active) {
     if (sc.meshes[its.mesh].bsdf < 0) return 0.f;

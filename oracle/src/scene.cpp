@@ -182,6 +182,13 @@ Scene *configure_scene(const orc_scene_desc &d, const int *active, int n_active)
         bc.type = b.type; bc.two_sided = b.two_sided != 0;
         bc.reflectance = V3d(Dual(b.reflectance[0], b.d_reflectance[0]), Dual(b.reflectance[1], b.d_reflectance[1]),
                              Dual(b.reflectance[2], b.d_reflectance[2]));
+        if (b.tex_data != nullptr) {
+            if (b.tex_width < 2 || b.tex_height < 2) throw std::runtime_error("Bitmap: invalid resolution!");
+            bc.tex_w = b.tex_width; bc.tex_h = b.tex_height;
+            const size_t n = (size_t) 3 * b.tex_width * b.tex_height;
+            bc.tex.assign(b.tex_data, b.tex_data + n);
+            if (b.d_tex_data) bc.d_tex.assign(b.d_tex_data, b.d_tex_data + n); else bc.d_tex.assign(n, 0.f);
+        }
         sc->bsdfs.push_back(bc);
     }
     for (int i = 0; i < d.n_emitters; ++i) {

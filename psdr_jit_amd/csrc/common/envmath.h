@@ -118,6 +118,34 @@ PSDR_HD void bitmap_eval(const float *data, int W, int H, R u, R v, R out[3]) {
     }
 }
 
+// Bitmap<3>::eval<ad>(uv, flip_v, envmap_mode = false) with m_rot = 0, m_scale = 1, m_trans = 0 (bitmap.cpp:47-128):
+// the texture lookup of Diffuse::m_reflectance (diffuse.cpp:38, flip_v = true).  texel(i, c) returns channel c of
+// texel i as an R (so that a (value, tangent) texel can be supplied).
+template <typename R, typename TexelFn>
+PSDR_HD void bitmap_eval_tex(TexelFn texel, int W, int H, R u, R v, bool flip_v, R out[3]) {
+    float sr, cr;
+    sincos_f(0.f, sr, cr);
+    R x = (u - R(0.5f)) * R(cr) + (v - R(0.5f)) * R(sr);
+    R y = -(u - R(0.5f)) * R(sr) + (v - R(0.5f)) * R(cr);
+    x = x + R(0.5f); y = y + R(0.5f);
+    if (flip_v) y = -y;
+    x = x * R(1.f); y = y * R(1.f);
+    x = x - R(-.5f + 1.f / 2); y = y + R(-.5f + 1.f / 2);
+    x = x + R(0.f); y = y + R(0.f);
+    x = x - e_floor(x); y = y - e_floor(y);
+    x = x * R((float) (W - 1)); y = y * R((float) (H - 1));
+    int px = (int) floorf(e_value(x)), py = (int) floorf(e_value(y));
+    const R w1x = x - R((float) px), w1y = y - R((float) py), w0x = R(1.0f) - w1x, w0y = R(1.0f) - w1y;
+    px = px < W - 2 ? px : W - 2; py = py < H - 2 ? py : H - 2;
+    px = px < 0 ? 0 : px; py = py < 0 ? 0 : py;
+    const int i00 = py * W + px, i10 = i00 + 1, i01 = i00 + W, i11 = i01 + 1;
+    for (int c = 0; c < 3; ++c) {
+        const R v0 = e_fma(w0x, texel(i00, c), w1x * texel(i10, c));
+        const R v1 = e_fma(w0x, texel(i01, c), w1x * texel(i11, c));
+        out[c] = e_fma(w0y, v0, w1y * v1);
+    }
+}
+
 // mass of cell idx of HyperCubeDistribution2f (envmap.cpp:28-31, cube_distrb.cpp:22-29): luminance * sin(theta)
 PSDR_HD float cell_mass(const float *data, int W, int H, int w2, int h2, int idx) {
     const int cx = idx / h2, cy = idx - cx * h2;

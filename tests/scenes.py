@@ -221,3 +221,46 @@ def config5_scene(width=128, height=128, spp=4, sppe=4, sppse=4, level=6, env_re
     elif param is not None:
         raise ValueError(param)
     return SceneSpec(meshes, bsdfs, emitters, [cam], width, height, spp, sppe, sppse)
+
+
+def ramp_texture(width=16, height=8):
+    """reflectance texture that is linear in (u, v): bilinear interpolation reproduces it exactly"""
+    u = np.arange(width, dtype=np.float64) / (width - 1)
+    v = np.arange(height, dtype=np.float64) / (height - 1)
+    uu, vv = np.meshgrid(u, v)
+    return np.stack([0.2 + 0.6 * uu, 0.8 - 0.5 * vv, 0.3 + 0.2 * uu + 0.3 * vv], axis=-1).astype(np.float32)
+
+
+def checker_texture(width=32, height=32, cells=4):
+    yy, xx = np.meshgrid(np.arange(height), np.arange(width), indexing="ij")
+    c = ((xx * cells // width) + (yy * cells // height)) % 2
+    return np.where(c[..., None] == 1, np.array([0.85, 0.8, 0.2]), np.array([0.15, 0.25, 0.7])).astype(np.float32)
+
+
+def textured_scene(width=48, height=48, spp=4, sppe=0, sppse=0, texture=None, param=None, env=True, box=True):
+    """A uv-mapped floor quad (uv = (x, z)/560) with a textured DiffuseBSDF, the small box on it, under a constant
+    environment map (env=True) or the Cornell luminaire.  param: 'texture' (d texel / dP = 1), 'box_x', None."""
+    tex = texture if texture is not None else ramp_texture()
+    v = np.array([[0, 0, 0], [560, 0, 0], [560, 0, 560], [0, 0, 560]], dtype=np.float32)
+    f = np.array([[0, 2, 1], [0, 3, 2]], dtype=np.int32)             # normal +y
+    uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], dtype=np.float32)
+    floor = MeshSpec(vertices=v, faces=f, uvs=uv, face_uvs=f.copy(), bsdf=0, emitter=-1)
+    bsdfs = [BsdfSpec((0.5, 0.5, 0.5), name="tex", texture=tex), BsdfSpec((0.5, 0.5, 0.5), name="cat"), BsdfSpec((0.0, 0.0, 0.0), name="light")]
+    meshes = [floor]
+    if box:
+        meshes.append(_mesh("cbox_smallbox.obj", 1))
+    if env:
+        emitters = [EmitterSpec(type=1, env_data=synthetic_envmap(64, 32, sun=False), env_scale=1.0)]
+    else:
+        emitters = [EmitterSpec((20.0, 20.0, 8.0))]
+        meshes.append(_mesh("cbox_luminaire.obj", 2, emitter=0, raw=translate(0.0, -100.0, 0.0)))
+    cam = CameraSpec(60.0, 0.000001, 10000000.0, to_world_raw=translate(278.0, 400.0, -700.0) @ _rot_x(np.radians(25.0)))
+    if param == "texture":
+        bsdfs[0].d_texture = np.ones_like(tex)
+    elif param == "box_x" and box:
+        dT = np.zeros((4, 4), dtype=np.float32)
+        dT[0, 3] = 100.0
+        meshes[1].d_to_world_left = dT
+    elif param is not None:
+        raise ValueError(param)
+    return SceneSpec(meshes, bsdfs, emitters, [cam], width, height, spp, sppe, sppse)
