@@ -116,6 +116,40 @@ def _v3(self, value):
     return (3,) if _np.size(value.detach().cpu().numpy() if isinstance(value, _torch.Tensor) else value) == 3 else (1,)
 
 
+def _refl_shape(self, value):
+    """a colour (1 or 3 numbers) or a reflectance texture [H, W, 3] (the reference's Bitmap3fD)"""
+    shp = tuple(value.shape) if hasattr(value, "shape") else _np.shape(value)
+    if len(shp) == 3:
+        return shp
+    return _v3(self, value)
+
+
+class Bitmap3fD:
+    """Stand-in for the reference's Bitmap3fD (bitmap.h): an [H, W, 3] array.  Bitmap3fD(), Bitmap3fD(file_name),
+    Bitmap3fD(value) or Bitmap3fD(width, height, data[H*W, 3])."""
+
+    def __init__(self, *args):
+        if len(args) == 0:
+            self.data = _np.zeros((1, 1, 3), _np.float32)
+        elif len(args) == 1 and isinstance(args[0], (str, bytes, _os.PathLike)):
+            self.data = None
+            self.load_openexr(args[0])
+        elif len(args) == 1:
+            a = args[0].detach().cpu().numpy() if isinstance(args[0], _torch.Tensor) else _np.asarray(args[0], _np.float32)
+            self.data = a.reshape(1, 1, 3) if a.size == 3 else _np.ascontiguousarray(a, _np.float32)
+        else:
+            w, h, d = args
+            d = d.detach().cpu().numpy() if isinstance(d, _torch.Tensor) else _np.asarray(d, _np.float32)
+            self.data = _np.ascontiguousarray(d, _np.float32).reshape(int(h), int(w), 3)
+
+    def load_openexr(self, file_name):
+        self.data = load_radiance_image(file_name)
+
+    @property
+    def resolution(self):
+        return (self.data.shape[1], self.data.shape[0])
+
+
 def _vtx(self, value):
     return (self.num_vertices, 3)
 
@@ -124,7 +158,7 @@ for _cls in (Mesh, Sensor, PerspectiveCamera):
     for _n in ("to_world", "to_world_left", "to_world_right"):
         setattr(_cls, _n, _make_param_property(_n, _m44))
 Mesh.vertex_positions = _make_param_property("vertex_positions", _vtx)
-DiffuseBSDF.reflectance = _make_param_property("reflectance", _v3)
+DiffuseBSDF.reflectance = _make_param_property("reflectance", _refl_shape)
 AreaLight.radiance = _make_param_property("radiance", _v3)
 
 
@@ -152,11 +186,18 @@ _DiffuseBSDF_init = DiffuseBSDF.__init__
 def _diffuse_init(self, reflectance=None):
     if reflectance is None:
         _DiffuseBSDF_init(self)
-    else:
-        v, t = _split(reflectance, (-1,))
-        _DiffuseBSDF_init(self, v)
-        if t is not None:
-            _params(self)["reflectance"] = t
+        return
+    if isinstance(reflectance, Bitmap3fD):
+        reflectance = reflectance.data.reshape(3) if reflectance.data.size == 3 else reflectance.data
+    shp = tuple(reflectance.shape) if hasattr(reflectance, "shape") else _np.shape(reflectance)
+    if len(shp) == 3:                       # a reflectance texture
+        _DiffuseBSDF_init(self)
+        self.reflectance = reflectance
+        return
+    v, t = _split(reflectance, (-1,))
+    _DiffuseBSDF_init(self, v)
+    if t is not None:
+        _params(self)["reflectance"] = t
 
 
 DiffuseBSDF.__init__ = _diffuse_init

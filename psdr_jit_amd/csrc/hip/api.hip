@@ -463,6 +463,28 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
         std::memcpy(ED.to_world.m, er->to_world, 64); std::memcpy(ED.from_world.m, er->from_world, 64);
         for (int k = 0; k < 3; ++k) { ED.lower[k] = er->lower[k]; ED.upper[k] = er->upper[k]; }
     }
+    T.tex = nullptr;
+    {
+        bool any_tex = false;
+        for (int i = 0; i < s->n_bsdfs; ++i) any_tex |= s->bsdfs[i].tex_data != nullptr;
+        if (any_tex) {
+            std::vector<TexDev> td((size_t) s->n_bsdfs, TexDev{nullptr, nullptr, 0, 0});
+            int rc = 0;
+            for (int i = 0; i < s->n_bsdfs; ++i) {
+                const psdr_bsdf_rec &b = s->bsdfs[i];
+                if (!b.tex_data) continue;
+                if (b.tex_width < 2 || b.tex_height < 2) return fail("Bitmap: invalid resolution!");
+                const size_t nt = (size_t) 3 * b.tex_width * b.tex_height;
+                td[i].data = sc->up(b.tex_data, nt, rc);
+                td[i].d_data = sc->up(b.d_tex_data, nt, rc);
+                td[i].w = b.tex_width; td[i].h = b.tex_height;
+            }
+            sc->bufs.emplace_back(new DevBuf());
+            rc |= sc->bufs.back()->upload(td.data(), td.size() * sizeof(TexDev));
+            if (rc) return 1;
+            T.tex = sc->bufs.back()->as<TexDev>();
+        }
+    }
     std::vector<FilterPrim> filt;
     build_filter_prims(tr.p0, tr.e1, tr.e2, bvh.order.data(), n, filt);
     T.filt_off = (int) w;  w += 4 * filt.size();
@@ -545,7 +567,7 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     for (int i = 0; i < s->n_bsdfs; ++i) {
         const psdr_bsdf_rec &b = s->bsdfs[i];
         if (b.type != 0) return fail("Unknown BSDF type!");
-        put4(blob, T.bsdf_off + 2 * (size_t) i, b.reflectance[0], b.reflectance[1], b.reflectance[2], ibits((b.two_sided ? 1 : 0)));
+        put4(blob, T.bsdf_off + 2 * (size_t) i, b.reflectance[0], b.reflectance[1], b.reflectance[2], ibits((b.two_sided ? 1 : 0) | (b.tex_data ? 2 : 0)));
         put4(blob, T.bsdf_off + 2 * (size_t) i + 1, b.d_reflectance[0], b.d_reflectance[1], b.d_reflectance[2], 0.f);
     }
     for (int i = 0; i < s->n_emitters; ++i) {
@@ -589,8 +611,8 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
 
     const size_t stack_bytes = (size_t) T.stack_depth * kBlock * sizeof(int);
     const size_t blob_bytes = (size_t) T.blob_words * 16;
-    // keeps >= 4 workgroups per CU (160 KiB LDS); the environment-map code lives in the LDS=false kernels only (shade.h)
-    sc->lds = blob_bytes + stack_bytes <= 40 * 1024 && T.env_emitter < 0;
+    // keeps >= 4 workgroups per CU (160 KiB LDS); the environment-map and texture code lives in the LDS=false kernels only (shade.h)
+    sc->lds = blob_bytes + stack_bytes <= 40 * 1024 && T.env_emitter < 0 && T.tex == nullptr;
     sc->smem_bytes = (sc->lds ? blob_bytes : 0) + stack_bytes;
     if (sc->smem_bytes > 64 * 1024) return fail("BVH too deep for the LDS traversal stack");
     sc->n_leaves = bvh.n_leaves; sc->max_depth = bvh.max_depth;

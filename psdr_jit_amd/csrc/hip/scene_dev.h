@@ -28,6 +28,9 @@ struct EnvDev {
     float lower[3], upper[3];
 };
 
+// reflectance texture of one BSDF (global memory; w == 0: constant colour)
+struct TexDev { const float *data, *d_data; int w, h; };
+
 struct SceneTables {
     // float4-word offsets into the blob
     int nodes_off, trav_off, shade_off, tan_off, map_off, mesh_off, bsdf_off, emit_off, ecdf_off, fcdf_off;
@@ -36,6 +39,7 @@ struct SceneTables {
     int filt_off, n_filt;      // filter primitives of the brute-force tracer (4 words each, see filter.h)
     float center[3], radius;   // bounding sphere of all vertices
     int env_emitter;           // index of the EnvironmentMap among the emitters, -1 = none
+    const TexDev *tex;         // [n_bsdfs] or NULL when no BSDF is textured
     EnvDev env;
     float emitter_sum;
     int blob_words;            // float4 count

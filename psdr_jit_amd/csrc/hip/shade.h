@@ -18,6 +18,7 @@ template <bool AD> struct Its {
     int slot, mesh;
     VecN<AD> p, n, wi, fs, ft, fn;     // position, geometric normal, local incident dir, shading frame
     Num<AD> t, J;
+    Num<AD> tu, tv;                    // texture coordinates (Intersection::uv); only kept by the LDS=false kernels of textured scenes
 };
 
 template <bool AD> PSDR_DEV VecN<AD> to_local(const Its<AD> &its, const VecN<AD> &v) { return VecN<AD>(dot(v, its.fs), dot(v, its.ft), dot(v, its.fn)); }
@@ -127,6 +128,12 @@ PSDR_DEV Its<AD> make_its(const SceneView<LDS> &S, const Hit &h, const RayT<AD> 
         // tangent frame from the uv parameterisation when it is non-degenerate (scene.cpp:724-766)
         const float4 s4 = S.ld(w + 4), s5 = S.ld(w + 5);
         const float du0x = s4.z - s4.x, du0y = s4.w - s4.y, du1x = s5.x - s4.x, du1y = s5.y - s4.y;
+        if constexpr (!LDS) {              // its.uv = bilinear2(uv0, uv1 - uv0, uv2 - uv0, barycentrics), scene.cpp:715/779
+            if (T.tex != nullptr) {
+                its.tu = fma_(R(du0x), u, fma_(R(du1x), v, R(s4.x)));
+                its.tv = fma_(R(du0y), u, fma_(R(du1y), v, R(s4.y)));
+            }
+        }
         const float det = fma_(du0x, du1y, -(du0y * du1x));
         if (det != 0.f) {
             const float inv_det = 1.f / det;
@@ -344,8 +351,26 @@ template <bool AD, bool LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S
     if (__float_as_int(a.w) & 1) { wo.z = mulsign(wo.z, detach(wiz)); wiz = abs_(wiz); }
     if (!(active && detach(wiz) > 0.f && detach(wo.z) > 0.f)) return V(R(0.f));
     V refl;
-    if constexpr (AD) { const float4 b = S.rgb_tan(w + 1, 2, mesh_bsdf(S, its.mesh)); refl = make_dual(Vec3f(a.x, a.y, a.z), Vec3f(b.x, b.y, b.z)); }
-    else refl = Vec3f(a.x, a.y, a.z);
+    bool textured = false;
+    if constexpr (!LDS) {
+        if (__float_as_int(a.w) & 2) {         // Bitmap3fD reflectance, diffuse.cpp:38 -> bitmap.cpp:47-128 (flip_v)
+            textured = true;
+            const TexDev td = S.T->tex[mesh_bsdf(S, its.mesh)];
+            R rgb[3];
+            if constexpr (AD) {
+                const bool tan = td.d_data != nullptr && S.mode == 0;      // (texel adjoints are not returned by reverse mode)
+                env::bitmap_eval_tex<Dual>([&](int i, int c) { return Dual(td.data[3 * i + c], tan ? td.d_data[3 * i + c] : 0.f); },
+                                           td.w, td.h, its.tu, its.tv, true, rgb);
+            } else {
+                env::bitmap_eval_tex<float>([&](int i, int c) { return td.data[3 * i + c]; }, td.w, td.h, its.tu, its.tv, true, rgb);
+            }
+            refl = V(rgb[0], rgb[1], rgb[2]);
+        }
+    }
+    if (!textured) {
+        if constexpr (AD) { const float4 b = S.rgb_tan(w + 1, 2, mesh_bsdf(S, its.mesh)); refl = make_dual(Vec3f(a.x, a.y, a.z), Vec3f(b.x, b.y, b.z)); }
+        else refl = Vec3f(a.x, a.y, a.z);
+    }
     return refl * R(kInvPi) * wo.z;
 }
 template <bool AD, bool LDS> PSDR_DEV float bsdf_pdf(const SceneView<LDS> &S, const Its<AD> &its, const VecN<AD> &wo, bool active) {

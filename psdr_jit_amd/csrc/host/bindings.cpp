@@ -70,8 +70,25 @@ PYBIND11_MODULE(_psdr_core, m) {
     py::class_<Diffuse, BSDF>(m, "DiffuseBSDF", py::dynamic_attr())
         .def(py::init<>())
         .def(py::init([](const farr &r) { return new Diffuse(to_a3(r)); }))
-        .def("_get", [](const Diffuse &d, const std::string &, bool tangent) { auto &r = tangent ? d.d_reflectance : d.reflectance; farr a(3); std::memcpy(a.mutable_data(), r.data(), 12); return a; })
-        .def("_set", [](Diffuse &d, const std::string &, const farr &v, const farr &t) { d.reflectance = to_a3(v); d.d_reflectance = to_a3(t); });
+        .def("_get", [](const Diffuse &d, const std::string &, bool tangent) {
+            if (d.tex_w > 0) {          // textured: [H, W, 3]
+                farr a({(py::ssize_t) d.tex_h, (py::ssize_t) d.tex_w, (py::ssize_t) 3});
+                const std::vector<float> &src = tangent ? d.d_tex : d.tex;
+                if (src.size() == (size_t) a.size()) std::memcpy(a.mutable_data(), src.data(), sizeof(float) * src.size()); else std::memset(a.mutable_data(), 0, sizeof(float) * a.size());
+                return a;
+            }
+            auto &r = tangent ? d.d_reflectance : d.reflectance; farr a(3); std::memcpy(a.mutable_data(), r.data(), 12); return a; })
+        .def("_set", [](Diffuse &d, const std::string &, const farr &v, const farr &t) {
+            if (v.ndim() == 3) {        // Bitmap3fD(width, height, data): a reflectance texture
+                if (v.shape(2) != 3 || v.shape(0) < 2 || v.shape(1) < 2) throw Exception("Bitmap: invalid resolution!");
+                d.tex_h = (int) v.shape(0); d.tex_w = (int) v.shape(1);
+                d.tex.assign(v.data(), v.data() + v.size());
+                if (t.size() == v.size()) d.d_tex.assign(t.data(), t.data() + t.size()); else d.d_tex.assign((size_t) v.size(), 0.f);
+                return;
+            }
+            d.tex_w = d.tex_h = 0; d.tex.clear(); d.d_tex.clear();
+            d.reflectance = to_a3(v); d.d_reflectance = to_a3(t); })
+        .def_readonly("_tex_width", &Diffuse::tex_w).def_readonly("_tex_height", &Diffuse::tex_h);
 
     py::class_<Emitter, Object>(m, "Emitter", py::dynamic_attr());
     py::class_<AreaLight, Emitter>(m, "AreaLight", py::dynamic_attr())

@@ -627,6 +627,12 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
         psdr_bsdf_rec r{};
         r.type = 0; r.two_sided = d->m_twoSide ? 1 : 0;
         for (int k = 0; k < 3; ++k) { r.reflectance[k] = d->reflectance[k]; r.d_reflectance[k] = d->d_reflectance[k]; }
+        if (d->tex_w > 0) {
+            PSDR_ASSERT_MSG(d->tex_w >= 2 && d->tex_h >= 2, "Bitmap: invalid resolution!");
+            PSDR_ASSERT_MSG(d->tex.size() == (size_t) 3 * d->tex_w * d->tex_h, "Bitmap: invalid data size!");
+            r.tex_width = d->tex_w; r.tex_height = d->tex_h; r.tex_data = d->tex.data();
+            r.d_tex_data = d->d_tex.size() == d->tex.size() ? d->d_tex.data() : nullptr;
+        }
         S.bsdfs.push_back(r);
     }
 

@@ -67,6 +67,9 @@ struct Diffuse : BSDF {
     std::string to_string() const override { return std::string("Diffuse[id=") + m_id + "]"; }
     bool anisotropic() const override { return false; }
     std::array<float, 3> reflectance, d_reflectance;   // Bitmap3fD with 1x1 resolution (bitmap.cpp:54-59)
+    // Bitmap3fD with a larger resolution: [tex_h*tex_w*3] row-major rgb texels (+ their forward tangent); tex_w == 0: none
+    int tex_w = 0, tex_h = 0;
+    std::vector<float> tex, d_tex;
 };
 
 struct Mesh;

@@ -18,6 +18,10 @@ def build_scene(spec, configure=True, active=(0,), host_only=False, log_level=0)
     for i, b in enumerate(spec.bsdfs):
         bs = psdr.DiffuseBSDF(list(b.reflectance))
         bs._set("reflectance", np.asarray(b.reflectance, np.float32), np.asarray(b.d_reflectance, np.float32))
+        if getattr(b, "texture", None) is not None:
+            tex = np.ascontiguousarray(np.asarray(b.texture, np.float32))
+            dtex = np.ascontiguousarray(np.asarray(b.d_texture, np.float32)) if getattr(b, "d_texture", None) is not None else np.zeros_like(tex)
+            bs._set("reflectance", tex, dtex)
         sc.add_BSDF(bs, b.name or ("bsdf%d" % i), b.two_sided)
     def add_envs_before(k):
         # emitters are numbered in the order they are added: keep the spec's numbering

@@ -130,3 +130,55 @@ def test_envmap_api_and_reverse_mode(psdr, orc):
     assert product.rel_l2(img.detach().cpu().numpy(), wimg) < TOL
     img.sum().backward()
     assert abs(float(refl.grad.sum()) - float(wd.sum())) < 2e-3 * abs(float(wd.sum()))
+
+
+@pytest.mark.parametrize("env", [True, False])
+def test_textured_reflectance_render_c_and_d(psdr, orc, env):
+    """Bitmap3fD reflectance (bitmap.cpp:47-128): image, texel tangent and geometry tangent against the oracle"""
+    for param, tex in (("texture", scenes.ramp_texture()), ("box_x", scenes.checker_texture()), (None, scenes.checker_texture(33, 17, 5))):
+        spec = scenes.textured_scene(48, 48, 8, 8, 8, texture=tex, param=param, env=env)
+        sc = product.build_scene(spec)
+        ref = orc.OracleScene(spec, [0])
+        integ = psdr.PathTracer(2)
+        img, dimg = psdr.render_d_fwd(integ, sc, 0, seed=4)
+        wimg, wd = ref.render_d(max_depth=2, seeds=(4, 4, 4))
+        assert product.rel_l2(img.cpu().numpy(), wimg) < TOL, (param, env)
+        if np.abs(wd).max() > 0:
+            assert product.rel_l2(dimg.cpu().numpy(), wd) < TOL, (param, env)
+        c = psdr.PathTracer(3).renderC(sc, 0, seed=2).cpu().numpy()
+        assert product.rel_l2(c, ref.render_c(max_depth=3, seed=2)) < TOL
+
+
+def test_textured_api(psdr, orc):
+    """DiffuseBSDF(Bitmap3fD) / bsdf.reflectance = array through the reference-style API"""
+    import os
+    tex = scenes.checker_texture()
+    spec = scenes.textured_scene(32, 32, 4, 0, 0, texture=tex, env=False)
+    sc = psdr.Scene()
+    sc.opts.spp, sc.opts.sppe, sc.opts.sppse = 4, 0, 0
+    sc.opts.width = sc.opts.height = 32
+    sc.opts.log_level = 0
+    cam = psdr.PerspectiveCamera(60, 0.000001, 10000000.)
+    cam.to_world = psdr.Matrix4fD(np.asarray(spec.cameras[0].to_world_raw).tolist())
+    sc.add_Sensor(cam)
+    sc.add_BSDF(psdr.DiffuseBSDF(psdr.Bitmap3fD(tex.shape[1], tex.shape[0], tex.reshape(-1, 3))), "tex")
+    sc.add_BSDF(psdr.DiffuseBSDF([0.5, 0.5, 0.5]), "cat")
+    sc.add_BSDF(psdr.DiffuseBSDF([0.0, 0.0, 0.0]), "light")
+    floor = psdr.Mesh()
+    m = spec.meshes[0]
+    floor.load_raw(m.vertices, m.faces, m.uvs, m.face_uvs)
+    sc.add_Mesh(floor, "tex", None)
+    I = np.eye(4, dtype=np.float32)
+    sc.add_Mesh(os.path.join(scenes.DATA, "cbox_smallbox.obj"), psdr.Matrix4fC(I.tolist()), "cat", None)
+    sc.add_Mesh(os.path.join(scenes.DATA, "cbox_luminaire.obj"), psdr.Matrix4fC(scenes.translate(0.0, -100.0, 0.0).tolist()), "light", psdr.AreaLight([20.0, 20.0, 8.0]))
+    sc.configure()
+    sc.configure([0])
+    img = psdr.PathTracer(2).renderC(sc, 0, seed=6).cpu().numpy()
+    want = orc.OracleScene(spec, [0]).render_c(max_depth=2, seed=6)
+    assert product.rel_l2(img, want) < TOL
+    # switching back to a constant colour
+    sc.param_map["BSDF[id=tex]"].reflectance = [0.5, 0.5, 0.5]
+    sc.configure([0])
+    spec.bsdfs[0].texture = None
+    img = psdr.PathTracer(2).renderC(sc, 0, seed=6).cpu().numpy()
+    assert product.rel_l2(img, orc.OracleScene(spec, [0]).render_c(max_depth=2, seed=6)) < TOL
