@@ -316,6 +316,24 @@ Scene.add_Sensor = _add_Sensor
 Scene.add_BSDF = _add_BSDF
 Scene.add_Mesh = _add_Mesh
 Scene.add_EnvironmentMap = _add_EnvironmentMap
+
+
+def _load_file(self, file_name, auto_configure=True):
+    """Scene::load_file (reference scene.cpp:75-78, scene_loader.cpp)"""
+    import sys as _sys
+    from . import scene_loader as _sl
+    _sl.load_file(self, _os.fspath(file_name), _sys.modules[__name__], auto_configure)
+
+
+def _load_string(self, scene_xml, auto_configure=True):
+    """Scene::load_string (reference scene.cpp:80-83)"""
+    import sys as _sys
+    from . import scene_loader as _sl
+    _sl.load_string(self, scene_xml, _sys.modules[__name__], auto_configure)
+
+
+Scene.load_file = _load_file
+Scene.load_string = _load_string
 Scene.configure = _configure
 
 

@@ -48,7 +48,7 @@ PYBIND11_MODULE(_psdr_core, m) {
 
     py::class_<Object>(m, "Object", py::dynamic_attr())
         .def("type_name", &Object::type_name)
-        .def_readonly("id", &Object::m_id)
+        .def_readwrite("id", &Object::m_id)
         .def("__repr__", &Object::to_string);
 
     py::class_<RenderOption>(m, "RenderOption")

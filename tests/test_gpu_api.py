@@ -124,3 +124,33 @@ def test_vertex_and_transform_gradients_reverse_matches_forward(psdr):
     assert abs(lhs_V - rhs_V) < 2e-3 * max(1.0, abs(rhs_V)), (lhs_V, rhs_V)
     assert abs(lhs_P - rhs_P) < 2e-3 * max(1.0, abs(rhs_P)), (lhs_P, rhs_P)
     assert abs(rhs_V) > 1e-3 and abs(rhs_P) > 1e-3
+
+
+def test_xml_scene_renders_like_the_scripted_scene(psdr, orc):
+    """Scene.load_string (reference scene_loader.cpp) of the README Cornell box == the add_* version, against the oracle"""
+    D = scenes.DATA
+    shapes = "".join(
+        '<shape type="obj"><string name="filename" value="%s/%s.obj"/><ref id="%s"/></shape>' % (D, f, b)
+        for f, b in (("cbox_smallbox", "cat"), ("cbox_largebox", "cat"), ("cbox_floor", "white"), ("cbox_ceiling", "white"),
+                     ("cbox_back", "white"), ("cbox_greenwall", "green"), ("cbox_redwall", "red")))
+    xml = """<scene version="0.6.0">
+  <sensor type="perspective"><float name="fov" value="60"/><float name="near_clip" value="0.000001"/><float name="far_clip" value="10000000"/>
+    <transform name="to_world"><translate x="208" y="273" z="-800"/></transform>
+    <sampler type="independent"><integer name="sample_count" value="8"/></sampler>
+    <film type="hdrfilm"><integer name="width" value="48"/><integer name="height" value="48"/></film></sensor>
+  <bsdf type="diffuse" id="light"><rgb name="reflectance" value="0, 0, 0"/></bsdf>
+  <bsdf type="diffuse" id="cat"><rgb name="reflectance" value="0.5"/></bsdf>
+  <bsdf type="diffuse" id="white"><rgb name="reflectance" value="0.95, 0.95, 0.95"/></bsdf>
+  <bsdf type="diffuse" id="green"><rgb name="reflectance" value="0.20, 0.90, 0.20"/></bsdf>
+  <bsdf type="diffuse" id="red"><rgb name="reflectance" value="0.90, 0.20, 0.20"/></bsdf>
+  <shape type="obj"><string name="filename" value="%s/cbox_luminaire.obj"/><ref id="light"/>
+    <transform name="to_world"><translate y="-0.5"/></transform><emitter type="area"><rgb name="radiance" value="20, 20, 8"/></emitter></shape>
+  %s
+</scene>""" % (D, shapes)
+    sc = psdr.Scene()
+    sc.opts.log_level = 0
+    sc.load_string(xml)                       # auto_configure
+    assert (sc.opts.spp, sc.opts.sppe, sc.opts.sppse) == (8, 0, 0)
+    img = psdr.PathTracer(2).renderC(sc, 0, seed=4).cpu().numpy()
+    ref = orc.OracleScene(scenes.cbox_scene(48, 48, 8, 0, 0, param=None), [0])
+    assert product.rel_l2(img, ref.render_c(max_depth=2, seed=4)) < 1e-3

@@ -89,6 +89,76 @@ def test_host_envmap_configure_matches_oracle(psdr, orc):
         sc.add_EnvironmentMap(psdr.EnvironmentMap(scenes.synthetic_envmap(8, 4)))
 
 
+def _cbox_xml(data_dir, tex_file=None, env_file=None):
+    refl = '<texture type="bitmap" name="reflectance"><string name="filename" value="%s"/></texture>' % tex_file if tex_file else '<rgb name="reflectance" value="0.95, 0.95, 0.95"/>'
+    env = '<emitter type="envmap"><string name="filename" value="%s"/><float name="scale" value="2.0"/><transform name="to_world"><rotate y="1" angle="30"/></transform></emitter>' % env_file if env_file else ""
+    return """<?xml version="1.0"?>
+<scene version="0.6.0">
+  <sensor type="perspective">
+    <float name="fov" value="60"/><string name="fov_axis" value="x"/>
+    <float name="near_clip" value="0.000001"/><float name="far_clip" value="10000000"/>
+    <transform name="to_world"><look_at origin="208, 273, -800" target="208, 273, 0" up="0, 1, 0"/></transform>
+    <sampler type="independent"><integer name="sample_count" value="4"/></sampler>
+    <film type="hdrfilm"><integer name="width" value="40"/><integer name="height" value="30"/></film>
+  </sensor>
+  <bsdf type="diffuse" id="light"><rgb name="reflectance" value="0"/></bsdf>
+  <bsdf type="diffuse" id="white">%s</bsdf>
+  <bsdf type="diffuse" id="cat"><float name="reflectance" value="0.5"/></bsdf>
+  %s
+  <shape type="obj" id="lum"><string name="filename" value="%s/cbox_luminaire.obj"/><ref id="light"/>
+    <transform name="to_world"><translate y="-0.5"/></transform>
+    <emitter type="area"><rgb name="radiance" value="20, 20, 8"/></emitter></shape>
+  <shape type="obj"><string name="filename" value="%s/cbox_floor.obj"/><ref id="white"/></shape>
+  <shape type="obj"><string name="filename" value="%s/cbox_largebox.obj"/><ref id="cat"/><boolean name="face_normals" value="true"/>
+    <transform name="to_world"><scale x="1.0" y="0.5" z="1.0"/><translate x="10"/></transform></shape>
+</scene>""" % (refl, env, data_dir, data_dir, data_dir)
+
+
+def test_xml_scene_loader(psdr, tmp_path):
+    """Scene.load_string / load_file (scene_loader.cpp:174-510): same scene as the equivalent add_* calls"""
+    from psdr_jit_amd import exr
+    tex = scenes.checker_texture(8, 8, 2)
+    exr.write_rgb(str(tmp_path / "tex.exr"), tex)
+    envimg = scenes.synthetic_envmap(16, 8)
+    exr.write_rgb(str(tmp_path / "env.exr"), envimg)
+    xml = _cbox_xml(scenes.DATA, str(tmp_path / "tex.exr"), str(tmp_path / "env.exr"))
+    sc = psdr.Scene()
+    sc.opts.log_level = 0
+    sc.load_string(xml, False)
+    f = tmp_path / "scene.xml"
+    f.write_text(xml)
+    sc2 = psdr.Scene()
+    sc2.opts.log_level = 0
+    sc2.load_file(str(f), False)
+    for s in (sc, sc2):
+        assert (s.opts.width, s.opts.height, s.opts.spp, s.opts.sppe, s.opts.sppse) == (40, 30, 4, 0, 0)
+        assert s.num_sensors == 1 and s.num_meshes == 3 and s.get_num_emitters() == 2
+        assert np.array_equal(np.asarray(s.param_map["BSDF[id=white]"]._get("reflectance", False)), tex)
+        assert np.allclose(np.asarray(s.param_map["BSDF[id=cat]"]._get("reflectance", False)), 0.5)
+        env = s.param_map["Emitter[0]"]
+        assert env.scale == 2.0 and np.array_equal(np.asarray(env.radiance), envimg)
+        c, sn = np.cos(np.radians(30.0)), np.sin(np.radians(30.0))
+        assert np.allclose(np.asarray(env.to_world), [[c, 0, sn, 0], [0, 1, 0, 0], [-sn, 0, c, 0], [0, 0, 0, 1]], atol=1e-6)
+        assert np.allclose(np.asarray(s.param_map["Emitter[1]"]._get("radiance", False)), [20, 20, 8])
+        assert "Mesh[id=lum]" in s.param_map
+        cam = np.asarray(s.param_map["Sensor[0]"]._get("to_world", False))
+        # look_at(origin, target=+z, up=+y): columns left = up x dir = +x, up, dir, origin (transform.h:83-104)
+        assert np.allclose(cam, [[1, 0, 0, 208], [0, 1, 0, 273], [0, 0, 1, -800], [0, 0, 0, 1]], atol=1e-5)
+        box = s.param_map["Mesh[2]"]
+        assert box.use_face_normal is True
+        assert np.allclose(np.asarray(box._get("to_world", False)), [[1, 0, 0, 10], [0, 0.5, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])   # scale, then translate
+        s._configure_host([0])
+        assert s.num_meshes == 4                            # + the environment map's bounding cube
+    with pytest.raises(RuntimeError, match="Unknown BSDF type"):
+        psdr.Scene().load_string('<scene><bsdf type="roughconductor" id="a"/></scene>', False)
+    with pytest.raises(RuntimeError, match="BSDF must have an id"):
+        psdr.Scene().load_string('<scene><bsdf type="diffuse"><rgb name="reflectance" value="1"/></bsdf></scene>', False)
+    with pytest.raises(RuntimeError, match="XML parsing failed"):
+        psdr.Scene().load_string("<scene>", False)
+    with pytest.raises(RuntimeError, match="Unsupported sensor"):
+        psdr.Scene().load_string('<scene><sensor type="orthographic"><film><integer name="width" value="1"/><integer name="height" value="1"/></film><sampler><integer name="n" value="1"/></sampler></sensor></scene>', False)
+
+
 def test_exr_round_trip(psdr, tmp_path):
     from psdr_jit_amd import exr
     img = (np.random.default_rng(0).random((19, 31, 3)) * 7).astype(np.float32)
