@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PSDR_HIP_ABI_VERSION 3
+#define PSDR_HIP_ABI_VERSION 4
 
 /* TriangleInfo SoA, reference include/psdr/types.h:162-175 (+ Scene::m_triangle_uv,
  * m_triangle_face_normals, scene.cpp:528-542).  Arrays of n_triangles rows. */
@@ -157,6 +157,8 @@ typedef struct psdr_render_args {
                                        * sampler's lane range with k % c == r (interleaved for load balance); c<=1 = all */
     const psdr_hip_guiding *guiding;  /* NULL = unguided secondary edges */
     int32_t zero_output;          /* 1: the call clears out buffers first (hipMemsetAsync on `stream`) */
+    int32_t direct_mode;          /* 0: PathTracer(max_depth); 1 + mis: DirectIntegrator(mis), mis = 0/1/2 (reference
+                                     src/integrator/direct.cpp:34-132: emitter sample only / BSDF sample only / both with MIS) */
 } psdr_render_args;
 
 /* counters of the instrumented build: filled by psdr_hip_render_*_counted */

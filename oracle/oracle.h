@@ -85,6 +85,9 @@ typedef struct orc_scene orc_scene;
 orc_scene *orc_scene_create(const orc_scene_desc *desc, const int *active_sensors, int n_active);
 void orc_scene_destroy(orc_scene *s);
 const char *orc_last_error(void);
+/* integrator used by the render calls that follow: -1 = PathTracer(max_depth) (default), 0/1/2 = DirectIntegrator(mis)
+ * (reference src/integrator/direct.cpp: emitter sampling only / BSDF sampling only / both with MIS; max_depth is ignored) */
+void orc_set_direct_mis(orc_scene *s, int mis);
 void orc_set_num_threads(int n);     /* 0 = OpenMP default */
 int orc_get_num_threads(void);
 

@@ -352,6 +352,12 @@ class OracleScene:
         L.orc_env_pdf(self._h, n, ref_p.ctypes.data_as(fp), p.ctypes.data_as(fp), nrm.ctypes.data_as(fp), pdf.ctypes.data_as(fp))
         return pdf
 
+    def set_direct_mis(self, mis):
+        """-1: PathTracer (default); 0/1/2: DirectIntegrator(mis) for the render calls that follow"""
+        L = lib()
+        L.orc_set_direct_mis.argtypes = [C.c_void_p, C.c_int]; L.orc_set_direct_mis.restype = None
+        L.orc_set_direct_mis(self._h, int(mis))
+
     def emitter_weight(self, i):
         L = lib()
         L.orc_emitter_sampling_weight.restype = C.c_float

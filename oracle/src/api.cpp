@@ -65,6 +65,7 @@ int orc_get_mesh_edges(const orc_scene *s, int mesh, int *out, int cap) {
     for (int i = 0; i < n && i < cap; ++i) { out[5 * i] = E[i].v0; out[5 * i + 1] = E[i].v1; out[5 * i + 2] = E[i].f0; out[5 * i + 3] = E[i].f1; out[5 * i + 4] = E[i].opp; }
     return n;
 }
+void orc_set_direct_mis(orc_scene *s, int mis) { s->sc->direct_mis = mis; }
 float orc_emitter_sampling_weight(const orc_scene *s, int e) { return s->sc->emitters[e].sampling_weight; }
 int orc_envmap_info(const orc_scene *s, float bounds[6], int reso[2], float *cell_sum) {
     if (s->sc->env_emitter < 0) return 0;

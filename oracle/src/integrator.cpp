@@ -353,9 +353,14 @@ V3<Real<ad>> Li(const Scene &sc, LaneSampler &sampler, const Ray<ad> &ray_, bool
     active = active && its.valid;
     V throughput(R(1.f));
     V result = hide_emitters ? V(R(0.f)) : Le<ad>(sc, its, active);
+    // DirectIntegrator(mis) (reference src/integrator/direct.cpp:34-132) is the same body run once: mis = 0 draws and uses
+    // only the emitter sample (weight 1), mis = 1 only the BSDF sample (weight 1), mis = 2 both with MIS; -1 = PathTracer
+    const int mis = sc.direct_mis;
+    const int nd = mis == 0 ? 2 : (mis == 1 ? 3 : 5);
+    if (mis >= 0) max_depth = 1;
     for (int depth = 0; depth < max_depth; ++depth) {
-        if (!active) { sampler.rng.advance((uint64_t) 5 * (max_depth - depth)); break; }
-        {   // next-event estimation
+        if (!active) { sampler.rng.advance((uint64_t) nd * (max_depth - depth)); break; }
+        if (mis != 1) {   // next-event estimation
             float sx = sampler.next_1d(), sy = sampler.next_1d();
             PositionSample<ad> ps = sample_emitter_position<ad>(sc, detach(its.p), sx, sy);
             bool active_direct = active && ps.valid && !is_emitter<ad>(sc, its);
@@ -376,11 +381,11 @@ V3<Real<ad>> Li(const Scene &sc, LaneSampler &sampler, const Ray<ad> &ray_, bool
                 bsdf_val2 *= G_val * ps.J / R(ps.pdf);
                 float pdf1 = bsdf_pdf<ad>(sc, its, wo_local, active_direct) * detach(G_val);
                 active_direct = active_direct && (pdf1 != 0.f);
-                float weight1 = mis_weight(ps.pdf, pdf1);
+                float weight1 = mis == 0 ? 1.f : mis_weight(ps.pdf, pdf1);
                 if (active_direct) result += throughput * emitter_val * bsdf_val2 * R(weight1);
             }
         }
-        {   // BSDF sampling
+        if (mis != 0) {   // BSDF sampling
             float s3[3];
             s3[0] = sampler.next_1d(); s3[1] = sampler.next_1d(); s3[2] = sampler.next_1d();
             BSDFSample bs = bsdf_sample<ad>(sc, its, s3, active);
@@ -405,7 +410,7 @@ V3<Real<ad>> Li(const Scene &sc, LaneSampler &sampler, const Ray<ad> &ray_, bool
                 if (its1.t < Epsilon) bsdf_val = V(0.f);
                 else bsdf_val = bsdf_eval<ad>(sc, its, V(bs.wo.x, bs.wo.y, bs.wo.z), active) / bs.pdf;
             }
-            float weight2 = mis_weight(pdf0, emitter_position_pdf<ad>(sc, detach(its.p), its1));
+            float weight2 = mis == 1 ? 1.f : mis_weight(pdf0, emitter_position_pdf<ad>(sc, detach(its.p), its1));
             throughput *= bsdf_val;
             result += Le<ad>(sc, its1, active) * throughput * R(weight2);
             its = its1;

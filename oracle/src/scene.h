@@ -124,6 +124,7 @@ struct Scene {
     std::vector<BvhNode> bvh;
     std::vector<int> bvh_tris;
     bool use_bvh = false;
+    int direct_mis = -1;               // >= 0: Li is DirectIntegrator(mis) (direct.cpp), -1: PathTracer
 };
 
 Scene *configure_scene(const orc_scene_desc &d, const int *active, int n_active);

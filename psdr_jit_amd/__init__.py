@@ -42,6 +42,7 @@ Mesh = _core.Mesh
 Scene = _core.Scene
 Integrator = _core.Integrator
 PathTracer = _core.PathTracer
+Direct = _core.Direct          # DirectIntegrator(mis), reference psdr.cpp:436-439
 PsdrException = _core.PsdrException
 
 TERM_INTERIOR, TERM_PRIMARY, TERM_SECONDARY, TERM_ALL = 1, 2, 4, 7
@@ -551,6 +552,8 @@ Integrator.renderC = _renderC
 Integrator.renderD = _renderD
 PathTracer.renderC = _renderC
 PathTracer.renderD = _renderD
+Direct.renderC = _renderC
+Direct.renderD = _renderD
 
 
 def render_d_fwd(integrator, scene, sensor_id=0, seed=-1, batch_pix=-1, terms=TERM_ALL, tangents=None):

@@ -21,7 +21,7 @@ class Sampler(C.Structure):
 class RenderArgs(C.Structure):
     _fields_ = [("sensor_id", C.c_int32), ("max_depth", C.c_int32), ("hide_emitters", C.c_int32),
                 ("samplers", Sampler * 3), ("pix_ids", C.c_void_p), ("n_pix", C.c_int32), ("terms", C.c_int32),
-                ("shard_rank", C.c_int32), ("shard_count", C.c_int32), ("guiding", C.c_void_p), ("zero_output", C.c_int32)]
+                ("shard_rank", C.c_int32), ("shard_count", C.c_int32), ("guiding", C.c_void_p), ("zero_output", C.c_int32), ("direct_mode", C.c_int32)]
 
 
 class Grads(C.Structure):
@@ -67,11 +67,12 @@ def check(rc):
 
 
 def make_args(sensor_id=0, max_depth=1, hide_emitters=False, seeds=(0, 0, 0), skips=(0, 0, 0), pix_ids_ptr=0, n_pix=0,
-              terms=7, shard_rank=0, shard_count=1, guiding=None, zero_output=True):
+              terms=7, shard_rank=0, shard_count=1, guiding=None, zero_output=True, direct_mis=-1):
     a = RenderArgs()
     a.sensor_id, a.max_depth, a.hide_emitters = sensor_id, max_depth, int(hide_emitters)
     for k in range(3):
         a.samplers[k].seed, a.samplers[k].skip = int(seeds[k]), int(skips[k])
     a.pix_ids, a.n_pix, a.terms = pix_ids_ptr or None, n_pix, terms
     a.shard_rank, a.shard_count, a.guiding, a.zero_output = shard_rank, shard_count, guiding, int(zero_output)
+    a.direct_mode = int(direct_mis) + 1
     return a

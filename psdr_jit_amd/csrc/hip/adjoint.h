@@ -33,6 +33,7 @@ struct AdjointParams {
     float *g_tri;                   // [n_tris * 22], ORIGINAL triangle order
     float *g_bsdf, *g_emitter;      // [n_bsdfs * 3], [n_emitters * 3]
     int lds_accum;                  // 1: accumulate in LDS first (small scenes), 0: global atomics
+    int mis;                        // -1: PathTracer; 0/1/2: DirectIntegrator(mis)
 };
 
 template <bool LDS>

@@ -56,7 +56,7 @@ PSDR_DEV SceneView<LDS> make_view(const float4 *blob, const SceneTables &T, floa
     S.B = B; S.G = blob; S.T = &T;
     S.stack = reinterpret_cast<int *>(smem + (LDS ? T.blob_words : 0)) + threadIdx.x;
     S.c_nodes = S.c_tris = S.c_rays = S.c_hits = 0u;
-    S.mode = 0; S.rec = nullptr; S.rec_i = 0; S.rec_n = 0; S.ext = nullptr; S.ext_n = 0; S.probe_kind = 0; S.probe_id = 0; S.probe_comp = 0;
+    S.mis = -1; S.mode = 0; S.rec = nullptr; S.rec_i = 0; S.rec_n = 0; S.ext = nullptr; S.ext_n = 0; S.probe_kind = 0; S.probe_id = 0; S.probe_comp = 0;
     return S;
 }
 
@@ -92,6 +92,7 @@ __global__ __launch_bounds__(kBlock, (AD ? 3 : 4)) void k_paths(const float4 *__
                                                   const PathParams P, Counters *ctr) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     SceneView<LDS> S = make_view<LDS>(blob, T, smem);
+    S.mis = P.mis;
     if (MODE == 1 && P.adj_w != nullptr && P.lds_acc) {
         // reverse mode of the primary-edge term: 8.4 M samples add into a 42 x 4 table - accumulate per workgroup in LDS
         float *acc = scratch_base<LDS>(smem, T);
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(kBlock) void k_interior_adjoint(const float4 *__res
                                                              const AdjointParams P) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     SceneView<LDS> S = make_view<LDS>(blob, T, smem);
+    S.mis = P.mis;
     run_interior_adjoint<LDS>(S, cam, P, scratch_base<LDS>(smem, T));
 }
 
@@ -700,7 +702,7 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
     };
     if ((terms & PSDR_TERM_INTERIOR) && T.spp > 0) {
         PathParams P{};
-        P.max_depth = a->max_depth; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[0].seed; P.skip = a->samplers[0].skip;
+        P.max_depth = (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[0].seed; P.skip = a->samplers[0].skip;
         P.pix_ids = a->pix_ids; P.begin = 0; P.end = npx * T.spp; P.shard_rank = rank; P.shard_count = count;
         P.out = out; P.dout = dout; P.lanes_out = lanes_out;
         if (lanes_out) { P.begin = lane_b; P.end = lane_e; P.shard_rank = 0; P.shard_count = 1; }
@@ -719,7 +721,7 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
     if (ad && !a->pix_ids && !lanes_out) {
         if ((terms & PSDR_TERM_PRIMARY) && T.sppe > 0 && cam.n_edges > 0) {
             PathParams P{};
-            P.max_depth = a->max_depth; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[1].seed; P.skip = a->samplers[1].skip;
+            P.max_depth = (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[1].seed; P.skip = a->samplers[1].skip;
             P.begin = 0; P.end = npx * T.sppe; P.shard_rank = rank; P.shard_count = count; P.dout = dout;
             P.n_local = local_lanes(P.end, rank, count);
             if (P.n_local > 0) {
@@ -730,7 +732,7 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
         }
         if ((terms & PSDR_TERM_SECONDARY) && T.sppse > 0 && sc->E.n > 0) {
             PathParams P{};
-            P.max_depth = a->max_depth; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[2].seed; P.skip = a->samplers[2].skip;
+            P.max_depth = (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[2].seed; P.skip = a->samplers[2].skip;
             P.begin = 0; P.end = npx * T.sppse; P.shard_rank = rank; P.shard_count = count; P.dout = dout;
             P.n_local = local_lanes(P.end, rank, count);
             GuidingDev G{};
@@ -817,7 +819,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     }
     if ((terms & PSDR_TERM_INTERIOR) && T.spp > 0) {
         AdjointParams P{};
-        P.max_depth = a->max_depth; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[0].seed; P.skip = a->samplers[0].skip;
+        P.max_depth = (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[0].seed; P.skip = a->samplers[0].skip;
         P.begin = 0; P.end = npx * T.spp; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
         P.w = d_rgb; P.g_tri = g->g_triangles; P.g_bsdf = g->g_bsdf; P.g_emitter = g->g_emitter; P.lds_accum = lds_acc ? 1 : 0;
         if (P.n_local > 0) {
@@ -830,7 +832,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     if ((terms & PSDR_TERM_PRIMARY) && T.sppe > 0 && cam.n_edges > 0) {
         if (!g->g_prim_edges) return fail("g_prim_edges is required when the primary-edge term is requested");
         PathParams P{};
-        P.max_depth = a->max_depth; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[1].seed; P.skip = a->samplers[1].skip;
+        P.max_depth = (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[1].seed; P.skip = a->samplers[1].skip;
         P.begin = 0; P.end = npx * T.sppe; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
         P.adj_w = d_rgb; P.g_prim = g->g_prim_edges; P.n_prim = cam.n_edges; P.lds_acc = (cam.n_edges <= 2048) ? 1 : 0;
         if (P.n_local > 0) {
@@ -844,7 +846,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     if ((terms & PSDR_TERM_SECONDARY) && T.sppse > 0 && sc->E.n > 0) {
         if (!g->g_sec_edges) return fail("g_sec_edges is required when the secondary-edge term is requested");
         PathParams P{};
-        P.max_depth = a->max_depth; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[2].seed; P.skip = a->samplers[2].skip;
+        P.max_depth = (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[2].seed; P.skip = a->samplers[2].skip;
         P.begin = 0; P.end = npx * T.sppse; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
         P.adj_w = d_rgb; P.g_sec = g->g_sec_edges; P.g_tri = g->g_triangles; P.n_sec = sc->E.n;
         const size_t sec_acc = sizeof(float) * (6 * (size_t) sc->E.n + 22 * (size_t) T.n_tris);

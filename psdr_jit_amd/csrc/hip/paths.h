@@ -34,6 +34,7 @@ struct PathParams {
     float *g_sec;                    // [n_sec_edges * 6]      (p0, e1)
     float *g_tri;                    // [n_tris * 22]
     int lds_acc, n_prim, n_sec;      // 1: the kernel accumulates the adjoint tables in LDS first (same-address atomics)
+    int mis;                         // -1: PathTracer; 0/1/2: DirectIntegrator(mis), reference direct.cpp:34-132 (max_depth = 1)
 };
 
 constexpr int kFetchBatch = 256;
@@ -138,7 +139,7 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
         PositionSample<AD> ps;
         V wod(R(0.f)); R dist_sqr(0.f), dist(0.f);
         RayT<AD> ray1; ray1.o = V(R(0.f)); ray1.d = V(R(0.f));
-        if (at_vertex) {
+        if (at_vertex && P.mis != 1) {           // (DirectIntegrator(1) neither draws nor uses the emitter sample)
             const float sx = rng.next_1d(), sy = rng.next_1d();
             do_nee = mesh_emitter(S, its.mesh) < 0;
             if (do_nee) {
@@ -153,7 +154,9 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
         // ------------------------------------------------------------------ [B] extension ray (drawn before the traces
         // so that both rays of this vertex share one pass over the triangles; the draw order is unchanged)
         BSDFSample bs; bs.wo = Vec3f(0.f, 0.f, 1.f); bs.pdf = 1.f; bs.valid = true;
-        if (at_vertex) {
+        const bool do_bsdf = at_vertex && P.mis != 0;      // (DirectIntegrator(0) stops after the emitter sample)
+        if (at_vertex && !do_bsdf) bs.valid = false;
+        if (do_bsdf) {
             const float s0 = rng.next_1d(), s1 = rng.next_1d(), s2 = rng.next_1d();
             (void) s0;
             bs = bsdf_sample<AD, LDS>(S, its, s1, s2, true);
@@ -178,7 +181,7 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
                     V bsdf_val2 = bsdf_eval<AD, LDS>(S, its, wo_local, true);
                     bsdf_val2 = bsdf_val2 * (G_val * ps.J / R(ps.pdf));
                     const float pdf1 = bsdf_pdf<AD, LDS>(S, its, wo_local, true) * detach(G_val);
-                    if (pdf1 != 0.f) res = res + thr * emitter_val * bsdf_val2 * R(mis_weight(ps.pdf, pdf1));
+                    if (pdf1 != 0.f) res = res + thr * emitter_val * bsdf_val2 * R(P.mis == 0 ? 1.f : mis_weight(ps.pdf, pdf1));
                 }
             }
         }
@@ -212,7 +215,7 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
                         if (itx.t < kEpsilon) bsdf_val = V(0.f);
                         else bsdf_val = bsdf_eval<AD, LDS>(S, its, bs.wo, true) / bs.pdf;
                     }
-                    const float weight2 = mis_weight(pdf0, emitter_position_pdf<AD, LDS>(S, detach(its.p), itx));
+                    const float weight2 = P.mis == 1 ? 1.f : mis_weight(pdf0, emitter_position_pdf<AD, LDS>(S, detach(its.p), itx));
                     thr = thr * bsdf_val;
                     res = res + eval_Le<AD, LDS>(S, itx, true) * thr * R(weight2);
                     its = itx;
@@ -251,7 +254,7 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
                 if (side == 0) {
                     Ln = detach(res);
                     // the reference's Li always draws 5 numbers per depth level; skip what this path left
-                    if (depth < P.max_depth) rng.advance((unsigned long long) (5 * (P.max_depth - depth)));
+                    if (depth < P.max_depth) rng.advance((unsigned long long) ((P.mis == 0 ? 2 : (P.mis == 1 ? 3 : 5)) * (P.max_depth - depth)));
                     side = 1; depth = -1; thr = V(R(1.f)); res = V(R(0.f));
                     if constexpr (!AD) { ext.o = xform_pos(cam.to_world, Vec3f(0.f)); ext.d = dir_p; }
                 } else {

@@ -79,6 +79,7 @@ template <bool LDS> struct SceneView {
     // The adjoint of a path is obtained by re-running its D-mode shading with ONE-HOT tangents ("probes")
     // on the scene quantities the path touched.  The hits found by the first (recording) run are replayed
     // instead of traversing again, so a probe costs shading only.
+    int mis;                   // Li variant: -1 PathTracer, 0/1/2 DirectIntegrator(mis) (set by the kernels from their parameters)
     int mode;                  // 0 = trace, 1 = trace + record hits, 2 = replay recorded hits
     float *rec;                // this lane's LDS record, stride kBlock: 4 words per hit (slot, u, v, t)
     int rec_i, rec_n;          // replay cursor / number of recorded hits

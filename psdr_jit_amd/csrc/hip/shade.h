@@ -438,9 +438,14 @@ PSDR_DEV VecN<AD> Li(SceneView<LDS> &S, LaneRng &rng, const RayT<AD> &ray_in, bo
     active = active && its.valid;
     V throughput(R(1.f));
     V result = hide_emitters ? V(R(0.f)) : eval_Le<AD, LDS>(S, its, active);
+    // DirectIntegrator(mis) (reference direct.cpp:34-132) is one pass of the same body: mis = 0 draws and uses only the emitter
+    // sample (weight 1), mis = 1 only the BSDF sample (weight 1), mis = 2 both with MIS
+    const int mis = S.mis;
+    const int nd = mis == 0 ? 2 : (mis == 1 ? 3 : 5);
+    if (mis >= 0) max_depth = 1;
     for (int depth = 0; depth < max_depth; ++depth) {
-        if (!active) { rng.advance((uint64_t) (5 * (max_depth - depth))); break; }
-        {   // next-event estimation (path.cpp:47-83)
+        if (!active) { rng.advance((uint64_t) (nd * (max_depth - depth))); break; }
+        if (mis != 1) {   // next-event estimation (path.cpp:47-83)
             const float sx = rng.next_1d(), sy = rng.next_1d();
             const bool its_is_emitter = mesh_emitter(S, its.mesh) >= 0;
             if (!its_is_emitter) {
@@ -462,13 +467,13 @@ PSDR_DEV VecN<AD> Li(SceneView<LDS> &S, LaneRng &rng, const RayT<AD> &ray_in, bo
                     bsdf_val2 = bsdf_val2 * (G_val * ps.J / R(ps.pdf));
                     const float pdf1 = bsdf_pdf<AD, LDS>(S, its, wo_local, true) * detach(G_val);
                     if (pdf1 != 0.f) {
-                        const float weight1 = mis_weight(ps.pdf, pdf1);
+                        const float weight1 = mis == 0 ? 1.f : mis_weight(ps.pdf, pdf1);
                         result = result + throughput * emitter_val * bsdf_val2 * R(weight1);
                     }
                 }
             }
         }
-        {   // BSDF sampling (path.cpp:86-123)
+        if (mis != 0) {   // BSDF sampling (path.cpp:86-123)
             const float s0 = rng.next_1d(), s1 = rng.next_1d(), s2 = rng.next_1d();
             (void) s0;
             const BSDFSample bs = bsdf_sample<AD, LDS>(S, its, s1, s2, true);
@@ -492,7 +497,7 @@ PSDR_DEV VecN<AD> Li(SceneView<LDS> &S, LaneRng &rng, const RayT<AD> &ray_in, bo
                 if (its1.t < kEpsilon) bsdf_val = V(0.f);
                 else bsdf_val = bsdf_eval<AD, LDS>(S, its, bs.wo, true) / bs.pdf;
             }
-            const float weight2 = mis_weight(pdf0, emitter_position_pdf<AD, LDS>(S, detach(its.p), its1));
+            const float weight2 = mis == 1 ? 1.f : mis_weight(pdf0, emitter_position_pdf<AD, LDS>(S, detach(its.p), its1));
             throughput = throughput * bsdf_val;
             result = result + eval_Le<AD, LDS>(S, its1, true) * throughput * R(weight2);
             its = its1;

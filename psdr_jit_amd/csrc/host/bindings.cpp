@@ -279,6 +279,7 @@ PYBIND11_MODULE(_psdr_core, m) {
         a.sensor_id = sensor_id; a.max_depth = it.max_depth(); a.hide_emitters = it.hide_emitters() ? 1 : 0;
         for (int k = 0; k < 3; ++k) { a.samplers[k].seed = seeds[k]; a.samplers[k].skip = skips[k]; }
         a.shard_rank = rank; a.shard_count = count; a.zero_output = 1; a.terms = terms; a.guiding = it.guiding(sensor_id);
+        a.direct_mode = it.direct_mis() + 1;
         psdr_grads g{reinterpret_cast<float *>(g_tri), reinterpret_cast<float *>(g_bsdf), reinterpret_cast<float *>(g_emitter),
                      reinterpret_cast<float *>(g_sec), reinterpret_cast<float *>(g_prim)};
         if (psdr_hip_render_d_bwd(scene.m_hip, &a, reinterpret_cast<const float *>(d_rgb), &g, reinterpret_cast<void *>(stream)))
@@ -291,4 +292,7 @@ PYBIND11_MODULE(_psdr_core, m) {
         .def("_guiding_mass", [](const PathTracer &p, int sid) { auto v = p.guiding_mass(sid); return from_vec(v, 1); })
         .def_readwrite("hide_emitters", &PathTracer::m_hide_emitters)
         .def_readonly("max_depth", &PathTracer::m_max_depth);
+    py::class_<DirectIntegrator, PathTracer>(m, "Direct", py::dynamic_attr())
+        .def(py::init<int>(), "mis"_a = 2)
+        .def_readonly("mis", &DirectIntegrator::m_mis);
 }

@@ -721,6 +721,7 @@ static void fill_args(psdr_render_args &a, const Scene &scene, const Integrator 
     a.pix_ids = reinterpret_cast<const int32_t *>(pix_ids); a.n_pix = n_pix;
     a.shard_rank = rank; a.shard_count = count; a.zero_output = 1;
     a.guiding = it.guiding(sensor_id);
+    a.direct_mode = it.direct_mis() + 1;
 }
 
 void Integrator::renderC(const Scene &scene, int sensor_id, int seed, uintptr_t pix_ids, int n_pix, uintptr_t out, uintptr_t stream, int rank, int count) const {
@@ -736,7 +737,7 @@ void Integrator::renderC(const Scene &scene, int sensor_id, int seed, uintptr_t 
     psdr_render_args a;
     fill_args(a, scene, *this, sensor_id, pix_ids, n_pix, rank, count);
     hip_check(psdr_hip_render_c(scene.m_hip, &a, reinterpret_cast<float *>(out), reinterpret_cast<void *>(stream)));
-    if (opts.spp > 0) scene.m_samplers[0].skip += 2 + 5 * (uint64_t) max_depth();
+    if (opts.spp > 0) scene.m_samplers[0].skip += 2 + (uint64_t) draws_per_level() * (uint64_t) max_depth();
     if (opts.log_level) {
         std::ostringstream oss;
         oss << "Rendered in " << duration_cast<duration<double>>(high_resolution_clock::now() - start_time).count() << " seconds.";
@@ -764,8 +765,8 @@ void Integrator::renderD(const Scene &scene, int sensor_id, int seed, uintptr_t 
     a.terms = terms;
     hip_check(psdr_hip_render_d_fwd(scene.m_hip, &a, reinterpret_cast<float *>(out), reinterpret_cast<float *>(dout), reinterpret_cast<void *>(stream)));
     const PerspectiveCamera *cam = static_cast<const PerspectiveCamera *>(scene.m_sensors[sensor_id]);
-    if (opts.spp > 0 && (terms & PSDR_TERM_INTERIOR)) scene.m_samplers[0].skip += 2 + 5 * (uint64_t) max_depth();
-    if (opts.sppe > 0 && cam->m_enable_edges && (terms & PSDR_TERM_PRIMARY) && !pix_ids) scene.m_samplers[1].skip += 1 + 10 * (uint64_t) max_depth();
+    if (opts.spp > 0 && (terms & PSDR_TERM_INTERIOR)) scene.m_samplers[0].skip += 2 + (uint64_t) draws_per_level() * (uint64_t) max_depth();
+    if (opts.sppe > 0 && cam->m_enable_edges && (terms & PSDR_TERM_PRIMARY) && !pix_ids) scene.m_samplers[1].skip += 1 + 2 * (uint64_t) draws_per_level() * (uint64_t) max_depth();
     if (opts.sppse > 0 && (terms & PSDR_TERM_SECONDARY) && !pix_ids) scene.m_samplers[2].skip += 3;
     if (opts.log_level) {
         std::ostringstream oss;

@@ -231,6 +231,8 @@ struct Integrator : Object {
     virtual int max_depth() const = 0;
     virtual bool hide_emitters() const = 0;
     virtual const psdr_hip_guiding *guiding(int sensor_id) const { (void) sensor_id; return nullptr; }
+    virtual int direct_mis() const { return -1; }                 // >= 0: DirectIntegrator(mis)
+    int draws_per_level() const { const int m = direct_mis(); return m == 0 ? 2 : (m == 1 ? 3 : 5); }
 };
 
 struct PathTracer : Integrator {
@@ -245,6 +247,15 @@ struct PathTracer : Integrator {
     bool m_hide_emitters = false;
     int m_max_depth;
     std::vector<psdr_hip_guiding *> m_warpper;
+};
+
+// DirectIntegrator(mis), reference src/integrator/direct.cpp: one bounce; mis = 0 emitter sampling only, 1 BSDF sampling
+// only, 2 both with MIS (= PathTracer(1)).  The edge terms and the guiding pass are those of PathTracer (direct.cpp:135-277).
+struct DirectIntegrator : PathTracer {
+    explicit DirectIntegrator(int mis = 1) : PathTracer(1), m_mis(mis) { PSDR_ASSERT(mis >= 0 && mis <= 2); }
+    std::string type_name() const override { return "DirectIntegrator"; }
+    int direct_mis() const override { return m_mis; }
+    int m_mis;
 };
 
 } // namespace psdr_host

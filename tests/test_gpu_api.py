@@ -154,3 +154,35 @@ def test_xml_scene_renders_like_the_scripted_scene(psdr, orc):
     img = psdr.PathTracer(2).renderC(sc, 0, seed=4).cpu().numpy()
     ref = orc.OracleScene(scenes.cbox_scene(48, 48, 8, 0, 0, param=None), [0])
     assert product.rel_l2(img, ref.render_c(max_depth=2, seed=4)) < 1e-3
+
+
+@pytest.mark.parametrize("mis", [0, 1, 2])
+def test_direct_integrator(psdr, orc, mis):
+    """psdr.Direct(mis) (reference direct.cpp:34-132): renderC, all three renderD terms, sampler continuation, reverse mode"""
+    import torch
+    spec = scenes.cbox_scene(48, 48, 8, 8, 8, param="light_x")
+    sc = product.build_scene(spec)
+    ref = orc.OracleScene(spec, [0])
+    ref.set_direct_mis(mis)
+    integ = psdr.Direct(mis)
+    assert integ.mis == mis and integ.max_depth == 1
+    a = integ.renderC(sc, 0, seed=5).cpu().numpy()
+    assert product.rel_l2(a, ref.render_c(max_depth=1, seed=5)) < 1e-3
+    nd = {0: 2, 1: 3, 2: 5}[mis]
+    b = integ.renderC(sc, 0).cpu().numpy()                       # continues the stream: 2 + nd draws were used
+    assert product.rel_l2(b, ref.render_c(max_depth=1, seed=5, skip=2 + nd)) < 1e-3
+    img, dimg = psdr.render_d_fwd(integ, sc, 0, seed=9)
+    wimg, wd = ref.render_d(max_depth=1, seeds=(9, 9, 9))
+    assert product.rel_l2(img.cpu().numpy(), wimg) < 1e-3 and product.rel_l2(dimg.cpu().numpy(), wd) < 1e-3
+    if mis == 2:
+        pt = psdr.PathTracer(1).renderC(sc, 0, seed=5).cpu().numpy()
+        assert np.array_equal(a, pt)
+    # reverse mode == forward mode
+    P = psdr.FloatD(0.).requires_grad_()
+    sc2 = _readme_scene(psdr, P)
+    im = integ.renderD(sc2, 0, seed=2)
+    w = torch.linspace(0.5, 1.5, im.numel(), device=im.device).reshape(im.shape)
+    d = psdr.forward_grad(im, P)
+    (im * w).sum().backward()
+    want = float((d * w).sum())
+    assert abs(float(P.grad) - want) < 2e-3 * max(1.0, abs(want))
