@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PSDR_HIP_ABI_VERSION 4
+#define PSDR_HIP_ABI_VERSION 5
 
 /* TriangleInfo SoA, reference include/psdr/types.h:162-175 (+ Scene::m_triangle_uv,
  * m_triangle_face_normals, scene.cpp:528-542).  Arrays of n_triangles rows. */
@@ -102,6 +102,7 @@ typedef struct psdr_sensor_rec {
     float world_to_sample[16], d_world_to_sample[16];
     float cam_pos[3], cam_dir[3];
     float inv_area;
+    int32_t orthographic;            /* 1: OrthographicCamera (src/sensor/orthographic.cpp): rays start on the near plane along cam_dir */
     /* PrimaryEdgeInfo (edge.h:27-40) + Sensor::m_edge_distrb; n_edges == 0 disables the term */
     int32_t n_edges;
     const float *edge_p0, *edge_p1;           /* [n*2] sample-space end points */

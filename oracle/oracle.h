@@ -59,6 +59,7 @@ typedef struct orc_camera {          /* PerspectiveCamera(fov_x, near, far) */
     float fov_x, near_clip, far_clip;
     float to_world_left[16], to_world_raw[16], to_world_right[16];
     float d_to_world_left[16], d_to_world_raw[16], d_to_world_right[16];
+    int orthographic;                /* 1: OrthographicCamera(near, far) (src/sensor/orthographic.cpp), fov_x unused */
 } orc_camera;
 
 typedef struct orc_scene_desc {

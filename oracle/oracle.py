@@ -93,6 +93,7 @@ class CameraSpec:
     d_to_world_left: np.ndarray = field(default_factory=_zero4)
     d_to_world_raw: np.ndarray = field(default_factory=_zero4)
     d_to_world_right: np.ndarray = field(default_factory=_zero4)
+    orthographic: bool = False            # OrthographicCamera(near, far): fov_x unused
 
 
 @dataclass
@@ -135,7 +136,7 @@ class _Emitter(C.Structure):
 class _Camera(C.Structure):
     _fields_ = [("fov_x", C.c_float), ("near_clip", C.c_float), ("far_clip", C.c_float),
                 ("to_world_left", _F16), ("to_world_raw", _F16), ("to_world_right", _F16),
-                ("d_to_world_left", _F16), ("d_to_world_raw", _F16), ("d_to_world_right", _F16)]
+                ("d_to_world_left", _F16), ("d_to_world_raw", _F16), ("d_to_world_right", _F16), ("orthographic", C.c_int)]
 
 
 class _Desc(C.Structure):
@@ -288,6 +289,7 @@ class OracleScene:
         cams = (_Camera * len(spec.cameras))()
         for i, c in enumerate(spec.cameras):
             cams[i].fov_x, cams[i].near_clip, cams[i].far_clip = c.fov_x, c.near, c.far
+            cams[i].orthographic = int(getattr(c, "orthographic", False))
             cams[i].to_world_left, cams[i].to_world_raw, cams[i].to_world_right = _m16(c.to_world_left), _m16(c.to_world_raw), _m16(c.to_world_right)
             cams[i].d_to_world_left, cams[i].d_to_world_raw, cams[i].d_to_world_right = _m16(c.d_to_world_left), _m16(c.d_to_world_raw), _m16(c.d_to_world_right)
         desc = _Desc(len(spec.meshes), meshes, len(spec.bsdfs), bsdfs, len(spec.emitters), emitters, len(spec.cameras), cams,

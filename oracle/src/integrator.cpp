@@ -81,6 +81,19 @@ static void square_to_uniform_triangle(float sx, float sy, float &a, float &b) {
 // ---------------------------------------------------------------- camera
 // perspective.cpp:160-178
 template <bool ad> Ray<ad> sample_primary_ray(const CameraC &cam, const V2<Real<ad>> &s) {
+    if (cam.orthographic) {          // orthographic.cpp:161-181: origin on the near plane, direction = the camera axis
+        Ray<ad> r;
+        const V3f near_p = transform_pos(cam.sample_to_camera, V3f(detach(s.x), detach(s.y), 0.f));
+        if constexpr (ad) {
+            r.o = transform_pos(cam.to_world, V3d(near_p));
+            r.d = transform_dir(cam.to_world, V3d(Dual(0.f), Dual(0.f), Dual(1.f)));
+        } else {
+            M4f tw = detach(cam.to_world);
+            r.o = transform_pos(tw, near_p);
+            r.d = transform_dir(tw, V3f(0.f, 0.f, 1.f));
+        }
+        return r;
+    }
     V3f d = normalize(transform_pos(cam.sample_to_camera, V3f(detach(s.x), detach(s.y), 0.f)));   // detached in D mode (:172)
     Ray<ad> r;
     if constexpr (ad) {

@@ -94,8 +94,11 @@ static void configure_camera(Scene &sc, CameraC &cam, const orc_camera &d, bool 
     if (!(std::fabs(det3(detach(cam.to_world)) - 1.f) < Epsilon))
         throw std::runtime_error("Sensor transformation should not involve scaling!");
     // perspective.cpp:22-46
-    cam.camera_to_sample = scale_m(-0.5f, -0.5f * aspect, 1.f) * translate_m(-1.f, -1.f / aspect, 0.f)
-                           * perspective(d.fov_x, d.near_clip, d.far_clip);
+    cam.orthographic = d.orthographic != 0;
+    // orthographic.cpp:12-16 / transform.h:75-78: orthographic(near, far) = scale(1, 1, 1/(far-near)) * translate(0, 0, -near)
+    const M4f proj = cam.orthographic ? scale_m(1.f, 1.f, 1.f / (d.far_clip - d.near_clip)) * translate_m(0.f, 0.f, -d.near_clip)
+                                      : perspective(d.fov_x, d.near_clip, d.far_clip);
+    cam.camera_to_sample = scale_m(-0.5f, -0.5f * aspect, 1.f) * translate_m(-1.f, -1.f / aspect, 0.f) * proj;
     cam.sample_to_camera = inverse(cam.camera_to_sample);
     cam.world_to_sample = promote(cam.camera_to_sample) * inverse(cam.to_world);
     cam.sample_to_world = cam.to_world * promote(cam.sample_to_camera);
@@ -293,7 +296,7 @@ Scene *configure_scene(const orc_scene_desc &d, const int *active, int n_active)
             for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], c[k]); hi[k] = std::max(hi[k], c[k]); }
         };
         for (const MeshC &m : sc->meshes) for (const V3d &v : m.verts) grow(detach(v));
-        for (const CameraC &c : sc->cameras) grow(detach(c.pos));
+        for (const CameraC &c : sc->cameras) if (!c.orthographic) grow(detach(c.pos));      // only PerspectiveCamera (scene.cpp:383-387)
         sc->lower = V3f(lo[0], lo[1], lo[2]); sc->upper = V3f(hi[0], hi[1], hi[2]);
     }
 

@@ -103,6 +103,7 @@ struct CameraC {                   // PerspectiveCamera, src/sensor/perspective.
     V3d pos, dir;
     float inv_area = 0.f;
     bool enable_edges = false;
+    bool orthographic = false;     // OrthographicCamera (orthographic.cpp): parallel rays from the near plane
     std::vector<PrimEdge> edges;
     Distrb edge_distrb;
 };

@@ -41,6 +41,14 @@ PerspectiveCamera = _core.PerspectiveCamera
 Mesh = _core.Mesh
 Scene = _core.Scene
 Integrator = _core.Integrator
+
+
+def OrthographicCamera(near, far):
+    """OrthographicCamera(near, far) (reference psdr.cpp:375-383, src/sensor/orthographic.cpp): the view volume is
+    [-1, 1] x [-1/aspect, 1/aspect] camera units wide; returns a camera object with .orthographic == True."""
+    return _core._make_orthographic(float(near), float(far))
+
+
 PathTracer = _core.PathTracer
 Direct = _core.Direct          # DirectIntegrator(mis), reference psdr.cpp:436-439
 PsdrException = _core.PsdrException

@@ -626,7 +626,7 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
         std::memcpy(d.d_to_world.m, r.d_to_world, 64); std::memcpy(d.world_to_sample.m, r.world_to_sample, 64);
         std::memcpy(d.d_world_to_sample.m, r.d_world_to_sample, 64);
         for (int k = 0; k < 3; ++k) { d.cam_pos[k] = r.cam_pos[k]; d.cam_dir[k] = r.cam_dir[k]; }
-        d.inv_area = r.inv_area; d.n_edges = r.n_edges; d.edge_sum = r.edge_sum;
+        d.inv_area = r.inv_area; d.n_edges = r.n_edges; d.edge_sum = r.edge_sum; d.ortho = r.orthographic;
         d.pe_off = pe_offs[i].first; d.pecdf_off = pe_offs[i].second;
         sc->sensors.push_back(d);
     }

@@ -11,6 +11,21 @@ namespace psdr {
 
 // PerspectiveCamera::sample_primary_ray, reference perspective.cpp:160-178 (direction detached in D mode)
 template <bool AD> PSDR_DEV RayT<AD> sample_primary_ray(const SensorDev &cam, float sx, float sy) {
+    if (cam.ortho) {      // OrthographicCamera::sample_primary_ray, orthographic.cpp:161-181
+        const Vec3f near_p = xform_pos(cam.sample_to_camera, Vec3f(sx, sy, 0.f));
+        RayT<AD> r;
+        if constexpr (AD) {
+            Mat4<Dual> M;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) M.m[i] = Dual(cam.to_world.m[i], cam.d_to_world.m[i]);
+            r.o = xform_pos(M, promote(near_p));
+            r.d = xform_dir(M, Vec3d(Dual(0.f), Dual(0.f), Dual(1.f)));
+        } else {
+            r.o = xform_pos(cam.to_world, near_p);
+            r.d = xform_dir(cam.to_world, Vec3f(0.f, 0.f, 1.f));
+        }
+        return r;
+    }
     const Vec3f d = normalize(xform_pos(cam.sample_to_camera, Vec3f(sx, sy, 0.f)));
     RayT<AD> r;
     if constexpr (AD) {

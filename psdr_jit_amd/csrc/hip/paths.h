@@ -67,7 +67,7 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
     int pix_slot = -1;
     // MODE 1 extras
     int side = 0;
-    Vec3f Ln(0.f), dir_p(0.f);
+    Vec3f Ln(0.f);
     float edge_xdn_v = 0.f, edge_xdn_d = 0.f, edge_pdf = 1.f, edge_s = 0.f, edge_nx = 0.f, edge_ny = 0.f;
     int edge_i = 0;
     bool edge_valid = false;
@@ -121,7 +121,7 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
                         pix_slot = edge_valid ? iy * T.width + ix : -1;
                         const RayT<false> ray_p = sample_primary_ray<false>(cam, px.v + kEdgeEpsilon * nx, py.v + kEdgeEpsilon * ny);
                         const RayT<false> ray_n = sample_primary_ray<false>(cam, px.v - kEdgeEpsilon * nx, py.v - kEdgeEpsilon * ny);
-                        dir_p = ray_p.d;
+                        (void) ray_p;      // rebuilt from (edge_i, edge_s) when the first path has ended
                         if constexpr (!AD) ext = ray_n;
                         side = 0;
                         edge_xdn_v = x_dot_n.v; edge_xdn_d = x_dot_n.d; edge_pdf = pdf; edge_s = s; edge_nx = nx; edge_ny = ny; edge_i = ei;
@@ -256,7 +256,13 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
                     // the reference's Li always draws 5 numbers per depth level; skip what this path left
                     if (depth < P.max_depth) rng.advance((unsigned long long) ((P.mis == 0 ? 2 : (P.mis == 1 ? 3 : 5)) * (P.max_depth - depth)));
                     side = 1; depth = -1; thr = V(R(1.f)); res = V(R(0.f));
-                    if constexpr (!AD) { ext.o = xform_pos(cam.to_world, Vec3f(0.f)); ext.d = dir_p; }
+                    if constexpr (!AD) {
+                        // ray_p = sample_primary_ray(p + EdgeEpsilon * n): the same arithmetic as at the start of the work item
+                        const float4 r0 = S.ld(cam.pe_off + 3 * edge_i);
+                        const float oms = 1.0f - edge_s;
+                        const float pxv = fmaf(r0.x, oms, r0.z * edge_s), pyv = fmaf(r0.y, oms, r0.w * edge_s);
+                        ext = sample_primary_ray<false>(cam, pxv + kEdgeEpsilon * edge_nx, pyv + kEdgeEpsilon * edge_ny);
+                    }
                 } else {
                     // value = x_dot_n * (Ln - Lp) / pdf, scrub, / sppe; only the tangent survives (integrator.cpp:187-192)
                     const Vec3f Lp = detach(res);

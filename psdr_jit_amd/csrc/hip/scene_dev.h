@@ -63,6 +63,7 @@ struct SensorDev {
     float inv_area;
     int n_edges, pe_off, pecdf_off;
     float edge_sum;
+    int ortho;                 // OrthographicCamera
 };
 
 struct Counters { unsigned long long rays, nodes, tris, hits; };

@@ -116,7 +116,10 @@ PYBIND11_MODULE(_psdr_core, m) {
         .def("_set_transform", [](Sensor &s, const farr &v, const farr &d, bool left) { s.set_transform(to_m16(v), to_m16(d), left); })
         .def("_append_transform", [](Sensor &s, const farr &v, const farr &d, bool left) { s.append_transform(to_m16(v), to_m16(d), left); })
         .def_readonly("enable_edges", &Sensor::m_enable_edges);
+    m.def("_make_orthographic", [](float near_, float far_) { auto *c = new PerspectiveCamera(0.f, near_, far_); c->m_orthographic = true; return c; },
+          py::return_value_policy::take_ownership);
     py::class_<PerspectiveCamera, Sensor>(m, "PerspectiveCamera", py::dynamic_attr())
+        .def_readonly("orthographic", &PerspectiveCamera::m_orthographic)
         .def(py::init<float, float, float>())
         .def_property_readonly("world_to_sample", [](const PerspectiveCamera &c) { farr a({4, 4}); std::memcpy(a.mutable_data(), c.rec.world_to_sample, 64); return a; })
         .def("_primary_edge_ids", [](const PerspectiveCamera &c) { return from_ivec(c.m_edges.ids, 3); })

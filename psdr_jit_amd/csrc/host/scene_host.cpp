@@ -321,7 +321,10 @@ void PerspectiveCamera::configure(const Scene &scene, bool keep_edges) {
     const float aspect = (float) o.width / (float) o.height;
     const DM4 tw = to_world();
     PSDR_ASSERT_MSG(std::fabs(det3(tw) - 1.f) < Epsilon, "Sensor transformation should not involve scaling!");
-    const DM4 c2s = scale_matrix(-0.5f, -0.5f * aspect, 1.f) * translate_matrix(-1.f, -1.f / aspect, 0.f) * persp_matrix(m_fov_x, m_near_clip, m_far_clip);
+    const DM4 proj = m_orthographic ? scale_matrix(1.f, 1.f, 1.f / (m_far_clip - m_near_clip)) * translate_matrix(0.f, 0.f, -m_near_clip)   // transform.h:75-78
+                                    : persp_matrix(m_fov_x, m_near_clip, m_far_clip);
+    const DM4 c2s = scale_matrix(-0.5f, -0.5f * aspect, 1.f) * translate_matrix(-1.f, -1.f / aspect, 0.f) * proj;
+    rec.orthographic = m_orthographic ? 1 : 0;
     const DM4 s2c = inverse(c2s);
     const DM4 w2s = c2s * inverse(tw);
     float dummy[16];
@@ -543,7 +546,8 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
         const bool active = std::find(active_sensor.begin(), active_sensor.end(), sid) != active_sensor.end();
         PerspectiveCamera *cam = static_cast<PerspectiveCamera *>(m_sensors[sid]);
         cam->configure(*this, active);
-        for (int k = 0; k < 3; ++k) { m_lower[k] = std::min(m_lower[k], cam->rec.cam_pos[k]); m_upper[k] = std::max(m_upper[k], cam->rec.cam_pos[k]); }
+        if (!cam->m_orthographic)      // only PerspectiveCamera positions extend the scene box (scene.cpp:383-387, 410-414)
+            for (int k = 0; k < 3; ++k) { m_lower[k] = std::min(m_lower[k], cam->rec.cam_pos[k]); m_upper[k] = std::max(m_upper[k], cam->rec.cam_pos[k]); }
         if (m_opts.sppe > 0 && (active || active_sensor.empty())) num_edges.push_back(cam->m_enable_edges ? cam->m_edges.length.size() : 1);
     }
     if (m_opts.log_level > 0) {

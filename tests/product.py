@@ -10,7 +10,7 @@ def build_scene(spec, configure=True, active=(0,), host_only=False, log_level=0)
     sc.opts.spp, sc.opts.sppe, sc.opts.sppse = spec.spp, spec.sppe, spec.sppse
     sc.opts.log_level = log_level
     for c in spec.cameras:
-        cam = psdr.PerspectiveCamera(c.fov_x, c.near, c.far)
+        cam = psdr.OrthographicCamera(c.near, c.far) if getattr(c, "orthographic", False) else psdr.PerspectiveCamera(c.fov_x, c.near, c.far)
         cam._set("to_world", c.to_world_raw, c.d_to_world_raw)
         cam._set("to_world_left", c.to_world_left, c.d_to_world_left)
         cam._set("to_world_right", c.to_world_right, c.d_to_world_right)

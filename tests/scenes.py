@@ -264,3 +264,30 @@ def textured_scene(width=48, height=48, spp=4, sppe=0, sppse=0, texture=None, pa
     elif param is not None:
         raise ValueError(param)
     return SceneSpec(meshes, bsdfs, emitters, [cam], width, height, spp, sppe, sppse)
+
+
+def _scale_m(s):
+    m = np.eye(4, dtype=np.float32)
+    m[0, 0] = m[1, 1] = m[2, 2] = s
+    return m
+
+
+def ortho_cbox_scene(width=48, height=48, spp=4, sppe=0, sppse=0, param="box_x"):
+    """The README Cornell box shrunk into the orthographic view volume ([-1, 1] x [-1/aspect, 1/aspect] camera units:
+    sensor transforms may not scale, reference sensor.cpp:7-14) and seen through OrthographicCamera(near, far)."""
+    spec = cbox_scene(width, height, spp, sppe, sppse, param=None)
+    S = _scale_m(1.0 / 300.0) @ translate(-278.0, -273.0, -280.0)
+    for m in spec.meshes:
+        m.to_world_raw = (S @ np.asarray(m.to_world_raw, np.float32)).astype(np.float32)
+    spec.cameras[0] = CameraSpec(0.0, 0.1, 100.0, to_world_raw=translate(0.0, 0.0, -5.0), orthographic=True)
+    dT = np.zeros((4, 4), dtype=np.float32)
+    dT[0, 3] = 0.3
+    if param == "box_x":
+        spec.meshes[1].d_to_world_left = dT
+    elif param == "light_x":
+        spec.meshes[0].d_to_world_left = dT
+    elif param == "camera_x":
+        spec.cameras[0].d_to_world_left = dT
+    elif param is not None:
+        raise ValueError(param)
+    return spec

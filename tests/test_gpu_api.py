@@ -186,3 +186,22 @@ def test_direct_integrator(psdr, orc, mis):
     (im * w).sum().backward()
     want = float((d * w).sum())
     assert abs(float(P.grad) - want) < 2e-3 * max(1.0, abs(want))
+
+
+@pytest.mark.parametrize("param", ["box_x", "camera_x"])
+def test_orthographic_camera(psdr, orc, param):
+    """psdr.OrthographicCamera(near, far) (reference orthographic.cpp): renderC and all terms of renderD against the oracle"""
+    spec = scenes.ortho_cbox_scene(48, 48, 8, 8, 8, param=param)
+    sc = product.build_scene(spec)
+    assert sc.param_map["Sensor[0]"].orthographic
+    ref = orc.OracleScene(spec, [0])
+    integ = psdr.PathTracer(2)
+    c = integ.renderC(sc, 0, seed=3).cpu().numpy()
+    assert c.max() > 0 and product.rel_l2(c, ref.render_c(max_depth=2, seed=3)) < 1e-3
+    for terms in (1, 2, 4, 7):
+        img, dimg = psdr.render_d_fwd(integ, sc, 0, seed=6, terms=terms)
+        wimg, wd = ref.render_d(max_depth=2, seeds=(6, 6, 6), terms=terms)
+        if terms & 1:
+            assert product.rel_l2(img.cpu().numpy(), wimg) < 1e-3
+        if np.abs(wd).max() > 0:
+            assert product.rel_l2(dimg.cpu().numpy(), wd) < 1e-3, (param, terms)

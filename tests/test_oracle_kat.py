@@ -224,3 +224,23 @@ def test_direct_integrator_variants(orc):
     m = pt.mean()
     assert abs(nee.mean() / m - 1.0) < 0.02 and abs(bsdf.mean() / m - 1.0) < 0.06
     assert nee.reshape(-1, 3).std() < bsdf.reshape(-1, 3).std()            # a small light: emitter sampling has less noise
+
+
+def test_orthographic_camera_projection(orc):
+    """OrthographicCamera (orthographic.cpp): a unit square light facing the camera covers (res/2)^2 pixels whatever its
+    distance, and a pixel's radiance is the light's radiance."""
+    import scenes
+    from oracle.oracle import BsdfSpec, CameraSpec, EmitterSpec, MeshSpec, SceneSpec
+    counts = []
+    for z in (2.0, 7.0):
+        v = np.array([[-0.5, -0.5, z], [0.5, -0.5, z], [0.5, 0.5, z], [-0.5, 0.5, z]], dtype=np.float32)
+        f = np.array([[0, 2, 1], [0, 3, 2]], dtype=np.int32)          # normal -z: faces the camera at the origin looking +z
+        light = MeshSpec(vertices=v, faces=f, uvs=None, face_uvs=None, bsdf=0, emitter=0)
+        cam = CameraSpec(0.0, 0.1, 100.0, orthographic=True)
+        spec = SceneSpec([light], [BsdfSpec((0.0, 0.0, 0.0))], [EmitterSpec((3.0, 2.0, 1.0))], [cam], 32, 32, 16, 0, 0)
+        img = orc.OracleScene(spec, [0]).render_c(max_depth=0, seed=1).reshape(32, 32, 3)
+        lit = img[..., 0] > 1.5
+        counts.append(int(lit.sum()))
+        assert np.allclose(img[16, 16], [3.0, 2.0, 1.0])
+        assert np.allclose(img[0, 0], 0.0)
+    assert counts[0] == counts[1] == 16 * 16
