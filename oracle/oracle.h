@@ -37,13 +37,16 @@ typedef struct orc_mesh {            /* reference Mesh, include/psdr/shape/mesh.
 } orc_mesh;
 
 typedef struct orc_bsdf {            /* Diffuse, include/psdr/bsdf/diffuse.h */
-    int type;                        /* 0 = diffuse */
+    int type;                        /* 0 = Diffuse, 1 = Microfacet */
     float reflectance[3], d_reflectance[3];
     int two_sided;
     /* textured reflectance (Bitmap3fD with resolution > 1x1, bitmap.cpp:47-128): tex_data != NULL overrides `reflectance` */
     int tex_width, tex_height;
     const float *tex_data;           /* [tex_height*tex_width*3] row-major rgb */
     const float *d_tex_data;         /* optional tangent of the texels */
+    /* type 1 = Microfacet (src/bsdf/microfacet.cpp): reflectance = diffuse reflectance, plus */
+    float specular[3], d_specular[3];
+    float roughness, d_roughness;
 } orc_bsdf;
 
 typedef struct orc_emitter {         /* AreaLight (include/psdr/emitter/area.h) or EnvironmentMap (emitter/envmap.h) */
@@ -161,6 +164,12 @@ void orc_square_to_cosine_hemisphere(int n, const float *uv, float *out_xyz);
 void orc_square_to_uniform_triangle(int n, const float *uv, float *out_ab);
 void orc_coordinate_system(const float n[3], float s[3], float t[3]);
 int orc_distrb_sample_reuse(int size, const float *pmf, float *sample_inout, float *pdf_out);
+/* Microfacet BSDF building blocks in the local shading frame (microfacet.cpp / ggx.cpp): params = specular rgb, diffuse rgb,
+ * roughness, then their tangents in the same order (14 floats); eval returns value rgb then tangent rgb (6 floats) */
+void orc_microfacet_eval(const float params[14], int two_sided, const float wi[3], const float wo[3], float out[6]);
+float orc_microfacet_pdf(float roughness, int two_sided, const float wi[3], const float wo[3]);
+int orc_microfacet_sample(float roughness, int two_sided, const float wi[3], const float s3[3], float wo_out[3], float *pdf_out);
+float orc_ggx_eval(float alpha, const float m[3]);
 
 #ifdef __cplusplus
 }

@@ -67,6 +67,11 @@ class BsdfSpec:
     name: str = ""
     texture: Optional[np.ndarray] = None      # [H, W, 3] reflectance texture (Bitmap3fD), overrides `reflectance`
     d_texture: Optional[np.ndarray] = None    # tangent of the texels
+    type: int = 0                             # 0 = DiffuseBSDF, 1 = MicrofacetBSDF(specular, diffuse = reflectance, roughness)
+    specular: tuple = (0.04, 0.04, 0.04)
+    d_specular: tuple = (0.0, 0.0, 0.0)
+    roughness: float = 0.5
+    d_roughness: float = 0.0
 
 
 @dataclass
@@ -125,7 +130,8 @@ class _Mesh(C.Structure):
 
 class _Bsdf(C.Structure):
     _fields_ = [("type", C.c_int), ("reflectance", _F3), ("d_reflectance", _F3), ("two_sided", C.c_int),
-                ("tex_width", C.c_int), ("tex_height", C.c_int), ("tex_data", C.POINTER(C.c_float)), ("d_tex_data", C.POINTER(C.c_float))]
+                ("tex_width", C.c_int), ("tex_height", C.c_int), ("tex_data", C.POINTER(C.c_float)), ("d_tex_data", C.POINTER(C.c_float)),
+                ("specular", _F3), ("d_specular", _F3), ("roughness", C.c_float), ("d_roughness", C.c_float)]
 
 
 class _Emitter(C.Structure):
@@ -258,7 +264,11 @@ class OracleScene:
             mm.use_face_normals, mm.enable_edges = int(m.use_face_normals), int(m.enable_edges)
         bsdfs = (_Bsdf * max(1, len(spec.bsdfs)))()
         for i, b in enumerate(spec.bsdfs):
-            bsdfs[i].type = 0
+            bsdfs[i].type = int(getattr(b, "type", 0))
+            bsdfs[i].specular = _F3(*getattr(b, "specular", (0.04, 0.04, 0.04)))
+            bsdfs[i].d_specular = _F3(*getattr(b, "d_specular", (0.0, 0.0, 0.0)))
+            bsdfs[i].roughness = float(getattr(b, "roughness", 0.5))
+            bsdfs[i].d_roughness = float(getattr(b, "d_roughness", 0.0))
             bsdfs[i].reflectance = _F3(*b.reflectance)
             bsdfs[i].d_reflectance = _F3(*b.d_reflectance)
             bsdfs[i].two_sided = int(b.two_sided)

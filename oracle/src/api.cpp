@@ -65,6 +65,10 @@ int orc_get_mesh_edges(const orc_scene *s, int mesh, int *out, int cap) {
     for (int i = 0; i < n && i < cap; ++i) { out[5 * i] = E[i].v0; out[5 * i + 1] = E[i].v1; out[5 * i + 2] = E[i].f0; out[5 * i + 3] = E[i].f1; out[5 * i + 4] = E[i].opp; }
     return n;
 }
+void orc_microfacet_eval(const float params[14], int two_sided, const float wi[3], const float wo[3], float out[6]) { orc::kat_microfacet_eval(params, two_sided, wi, wo, out); }
+float orc_microfacet_pdf(float roughness, int two_sided, const float wi[3], const float wo[3]) { return orc::kat_microfacet_pdf(roughness, two_sided, wi, wo); }
+int orc_microfacet_sample(float roughness, int two_sided, const float wi[3], const float s3[3], float wo_out[3], float *pdf_out) { return orc::kat_microfacet_sample(roughness, two_sided, wi, s3, wo_out, pdf_out); }
+float orc_ggx_eval(float alpha, const float m[3]) { return orc::kat_ggx_eval(alpha, m); }
 void orc_set_direct_mis(orc_scene *s, int mis) { s->sc->direct_mis = mis; }
 float orc_emitter_sampling_weight(const orc_scene *s, int e) { return s->sc->emitters[e].sampling_weight; }
 int orc_envmap_info(const orc_scene *s, float bounds[6], int reso[2], float *cell_sum) {

@@ -163,6 +163,9 @@ template <typename T> static void ray_intersect_triangle(const V3<T> &p0, const 
 
 template <bool ad> static V3<Real<ad>> pick(const V3d &a) { if constexpr (ad) return a; else return detach(a); }
 template <bool ad> static Real<ad> pick(const Dual &a) { if constexpr (ad) return a; else return a.v; }
+} // namespace orc
+#include "microfacet.h"
+namespace orc {
 
 // scene.cpp:612-806
 template <bool ad, bool path_space>
@@ -329,6 +332,10 @@ template <bool ad> static V3<Real<ad>> bsdf_eval(const Scene &sc, const Its<ad> 
     using R = Real<ad>; using V = V3<R>;
     if (sc.meshes[its.mesh].bsdf < 0) return V(R(0.f));
     const BsdfC &b = sc.bsdfs[sc.meshes[its.mesh].bsdf];
+    if (b.type == 1) {          // Microfacet (microfacet.cpp); its diffuse reflectance is b.reflectance
+        MicrofacetParams P{b.specular, b.reflectance, b.roughness, b.two_sided};
+        return microfacet_eval<ad>(P, its.wi, wo, active);
+    }
     R wiz = its.wi.z;
     if (b.two_sided) { wo.z = mulsign(wo.z, detach(wiz)); wiz = abs_(wiz); }
     active = active && (detach(wiz) > 0.f && detach(wo.z) > 0.f);
@@ -338,6 +345,10 @@ template <bool ad> static V3<Real<ad>> bsdf_eval(const Scene &sc, const Its<ad> 
 template <bool ad> static float bsdf_pdf(const Scene &sc, const Its<ad> &its, const V3<Real<ad>> &wo_, bool active) {
     if (sc.meshes[its.mesh].bsdf < 0) return 0.f;
     const BsdfC &b = sc.bsdfs[sc.meshes[its.mesh].bsdf];
+    if (b.type == 1) {
+        MicrofacetParams P{b.specular, b.reflectance, b.roughness, b.two_sided};
+        return microfacet_pdf(P, detach(its.wi), detach(wo_), active);
+    }
     float wiz = detach(its.wi.z), woz = detach(wo_.z);
     if (b.two_sided) { woz = mulsign(woz, wiz); wiz = fabs(wiz); }
     active = active && (wiz > 0.f && woz > 0.f);
@@ -347,6 +358,12 @@ struct BSDFSample { V3f wo; float pdf; bool valid; };
 template <bool ad> static BSDFSample bsdf_sample(const Scene &sc, const Its<ad> &its, const float s3[3], bool active) {
     if (sc.meshes[its.mesh].bsdf < 0) { BSDFSample z; z.wo = V3f(0.f, 0.f, 0.f); z.pdf = 0.f; z.valid = false; return z; }
     const BsdfC &b = sc.bsdfs[sc.meshes[its.mesh].bsdf];
+    if (b.type == 1) {
+        MicrofacetParams P{b.specular, b.reflectance, b.roughness, b.two_sided};
+        const MicrofacetSample m = microfacet_sample(P, detach(its.wi), s3, active);
+        BSDFSample r; r.wo = m.wo; r.pdf = m.pdf; r.valid = m.valid;
+        return r;
+    }
     float wiz = detach(its.wi.z);
     if (b.two_sided) wiz = fabs(wiz);
     BSDFSample bs;
@@ -539,6 +556,29 @@ float Guiding::sample_reuse(V3f &s) const {
 }
 
 // exported for the known-answer tests
+static MicrofacetParams kat_params(const float *p, int two_sided) {
+    MicrofacetParams P;
+    P.specular = V3d(Dual(p[0], p[7]), Dual(p[1], p[8]), Dual(p[2], p[9]));
+    P.diffuse = V3d(Dual(p[3], p[10]), Dual(p[4], p[11]), Dual(p[5], p[12]));
+    P.roughness = Dual(p[6], p[13]);
+    P.two_sided = two_sided != 0;
+    return P;
+}
+void kat_microfacet_eval(const float *params, int two_sided, const float *wi, const float *wo, float *out) {
+    const V3d r = microfacet_eval<true>(kat_params(params, two_sided), V3d(V3f(wi[0], wi[1], wi[2])), V3d(V3f(wo[0], wo[1], wo[2])), true);
+    out[0] = r.x.v; out[1] = r.y.v; out[2] = r.z.v; out[3] = r.x.d; out[4] = r.y.d; out[5] = r.z.d;
+}
+float kat_microfacet_pdf(float roughness, int two_sided, const float *wi, const float *wo) {
+    MicrofacetParams P; P.roughness = Dual(roughness); P.two_sided = two_sided != 0;
+    return microfacet_pdf(P, V3f(wi[0], wi[1], wi[2]), V3f(wo[0], wo[1], wo[2]), true);
+}
+int kat_microfacet_sample(float roughness, int two_sided, const float *wi, const float *s3, float *wo_out, float *pdf_out) {
+    MicrofacetParams P; P.roughness = Dual(roughness); P.two_sided = two_sided != 0;
+    const MicrofacetSample m = microfacet_sample(P, V3f(wi[0], wi[1], wi[2]), s3, true);
+    wo_out[0] = m.wo.x; wo_out[1] = m.wo.y; wo_out[2] = m.wo.z; *pdf_out = m.pdf;
+    return m.valid ? 1 : 0;
+}
+float kat_ggx_eval(float alpha, const float *m) { GGX<float> g{alpha}; return g.eval(V3f(m[0], m[1], m[2])); }
 void kat_cosine_hemisphere(float sx, float sy, float *o) { V3f v = square_to_cosine_hemisphere(sx, sy); o[0] = v.x; o[1] = v.y; o[2] = v.z; }
 void kat_uniform_triangle(float sx, float sy, float *o) { square_to_uniform_triangle(sx, sy, o[0], o[1]); }
 void kat_coordinate_system(const float *n, float *s, float *t) {

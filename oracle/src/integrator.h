@@ -57,6 +57,10 @@ int eval_secondary_edge(const Scene &sc, const CameraC &cam, const V3f &sample3,
 
 void kat_env_sample(const Scene &sc, const V3f &ref_p, float sx, float sy, V3f &p, V3f &n, float &pdf);
 float kat_env_pdf(const Scene &sc, const V3f &ref_p, const V3f &p, const V3f &n);
+void kat_microfacet_eval(const float *params, int two_sided, const float *wi, const float *wo, float *out);
+float kat_microfacet_pdf(float roughness, int two_sided, const float *wi, const float *wo);
+int kat_microfacet_sample(float roughness, int two_sided, const float *wi, const float *s3, float *wo_out, float *pdf_out);
+float kat_ggx_eval(float alpha, const float *m);
 void kat_cosine_hemisphere(float sx, float sy, float *o);
 void kat_uniform_triangle(float sx, float sy, float *o);
 void kat_coordinate_system(const float *n, float *s, float *t);

@@ -1,0 +1,139 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see num.h header).  PARITY UNPINNED.
+//
+// microfacet.h — Microfacet BSDF (reference src/bsdf/microfacet.cpp:18-134: Lambertian diffuse + GGX specular with the
+// Schlick-style 2^(...) Fresnel) and its GGXDistribution (src/bsdf/ggx.cpp:8-107, visible-normal sampling).
+// drjit::pow(2, x) is not in /root/reference; it is restated as the Cephes exp2f polynomial with explicit fma
+// (the HIP path states the same); drjit::rsqrt is taken as 1/sqrt.
+#pragma once
+#include <cmath>
+#include "scene.h"
+
+namespace orc {
+
+void sincos_cephes(float xx, float &s_out, float &c_out);     // integrator.cpp
+
+inline float exp2_cephes(float x) {
+    if (x > 127.f) return INFINITY;
+    if (x < -127.f) return 0.f;
+    float px = std::floor(x);
+    int i0 = (int) px;
+    x = x - px;
+    if (x > 0.5f) { i0 += 1; x = x - 1.f; }
+    px = fma_(fma_(fma_(fma_(fma_(1.535336188319500e-4f, x, 1.339887440266574e-3f), x, 9.618437357674640e-3f), x, 5.550332471162809e-2f), x,
+                   2.402264791363012e-1f), x, 6.931472028550421e-1f);
+    px = fma_(px, x, 1.0f);
+    return std::ldexp(px, i0);
+}
+inline float exp2_(float x) { return exp2_cephes(x); }
+inline Dual exp2_(const Dual &x) { const float v = exp2_cephes(x.v); return Dual(v, v * 0.6931471805599453f * x.d); }
+
+struct MicrofacetParams { V3d specular, diffuse; Dual roughness; bool two_sided; };
+
+template <typename R> struct GGX {
+    R a;                                                           // alpha_u = alpha_v
+    // ggx.cpp:13-33
+    R eval(const V3<R> &m) const {
+        const R alpha_uv = a * a;
+        const R cos_theta = m.z;
+        const R r = rcp(R(Pi) * alpha_uv * sqr(sqr(m.x / a) + sqr(m.y / a) + sqr(m.z)));
+        return (detach(r) * detach(cos_theta) > 1e-20f) ? r : R(0.f);
+    }
+    // ggx.cpp:84-97
+    R smith_g1(const V3<R> &v, const V3<R> &m) const {
+        const R xy_alpha_2 = sqr(a * v.x) + sqr(a * v.y);
+        const R tan_theta_alpha_2 = xy_alpha_2 / sqr(v.z);
+        R result = R(2.f) / (R(1.f) + sqrt_(R(1.f) + tan_theta_alpha_2));
+        if (detach(xy_alpha_2) == 0.f) result = R(1.f);
+        if (detach(dot(v, m)) * detach(v.z) <= 0.f) result = R(0.f);
+        return result;
+    }
+};
+
+// warp.h:16-52
+inline V2f square_to_uniform_disk_concentric(float sx, float sy) {
+    float x = fma_(2.f, sx, -1.f), y = fma_(2.f, sy, -1.f);
+    bool is_zero = (x == 0.f) && (y == 0.f), q13 = std::fabs(x) < std::fabs(y);
+    float r = q13 ? y : x, rp = q13 ? x : y;
+    float phi = .25f * Pi * rp / r;
+    if (q13) phi = .5f * Pi - phi;
+    if (is_zero) phi = 0.f;
+    float s, c;
+    sincos_cephes(phi, s, c);
+    return V2f(r * c, r * s);
+}
+// ggx.cpp:99-107
+inline V2f ggx_sample_visible_11(float cos_theta_i, float sx, float sy) {
+    V2f p = square_to_uniform_disk_concentric(sx, sy);
+    const float s = .5f * (1.f + cos_theta_i);
+    const float a0 = safe_sqrt(1.f - sqr(p.x));
+    p.y = fma_(p.y, s, fma_(-a0, s, a0));                          // drjit::lerp(a, b, t) = fmadd(b, t, fnmadd(a, t, a))
+    const float x = p.x, y = p.y, z = safe_sqrt(1.f - fma_(p.y, p.y, p.x * p.x));
+    const float sin_theta_i = safe_sqrt(1.f - sqr(cos_theta_i));
+    const float norm = 1.f / fma_(sin_theta_i, y, cos_theta_i * z);
+    return V2f(fma_(cos_theta_i, y, -(sin_theta_i * z)) * norm, x * norm);
+}
+// ggx.cpp:35-82 (everything detached)
+inline V3f ggx_sample(float a, const V3f &wi, float sx, float sy, float &pdf) {
+    const V3f wi_p = normalize(V3f(a * wi.x, a * wi.y, wi.z));
+    const float sin_theta_2 = fma_(wi_p.x, wi_p.x, sqr(wi_p.y));                          // frame.h:81
+    const float inv_sin_theta = 1.f / std::sqrt(sin_theta_2);
+    const bool deg = std::fabs(sin_theta_2) <= 4.f * Epsilon;
+    const float sin_phi = deg ? 0.f : std::min(std::max(wi_p.y * inv_sin_theta, -1.f), 1.f);
+    const float cos_phi = deg ? 1.f : std::min(std::max(wi_p.x * inv_sin_theta, -1.f), 1.f);
+    V2f slope = ggx_sample_visible_11(wi_p.z, sx, sy);
+    slope = V2f(fma_(cos_phi, slope.x, -(sin_phi * slope.y)) * a, fma_(sin_phi, slope.x, cos_phi * slope.y) * a);
+    const V3f m = normalize(V3f(-slope.x, -slope.y, 1.f));
+    GGX<float> g{a};
+    pdf = g.smith_g1(wi, m) * std::fabs(dot(wi, m)) * g.eval(m) / std::fabs(wi.z);
+    return m;
+}
+
+// microfacet.cpp:22-62
+template <bool ad> V3<Real<ad>> microfacet_eval(const MicrofacetParams &P, V3<Real<ad>> wi, V3<Real<ad>> wo, bool active) {
+    using R = Real<ad>; using V = V3<R>;
+    if (P.two_sided) { wo.z = mulsign(wo.z, detach(wi.z)); wi.z = abs_(wi.z); }
+    const R cos_theta_nv = wi.z, cos_theta_nl = wo.z;
+    active = active && (detach(cos_theta_nv) > 0.f && detach(cos_theta_nl) > 0.f);
+    if (!active) return V(R(0.f));
+    const V diffuse = pick<ad>(P.diffuse) * R(InvPi);
+    const V H = normalize(wi + wo);
+    const R cos_theta_vh = dot(H, wi);
+    const V F0 = pick<ad>(P.specular);
+    R roughness;
+    if constexpr (ad) roughness = P.roughness; else roughness = P.roughness.v;
+    GGX<R> distr{sqr(roughness)};
+    const R ggx = distr.eval(H);
+    const R coeff = cos_theta_vh * (R(-5.55473f) * cos_theta_vh - R(6.8316f));
+    const V fresnel = F0 + (V(R(1.f)) - F0) * exp2_(coeff);
+    const R smithG = distr.smith_g1(wi, H) * distr.smith_g1(wo, H);
+    const V numerator = fresnel * (ggx * smithG);
+    const R denominator = R(4.f) * cos_theta_nl * cos_theta_nv;
+    const V specular = numerator / (denominator + R(1e-6f));
+    return (diffuse + specular) * cos_theta_nl;
+}
+// microfacet.cpp:108-131 (detached)
+inline float microfacet_pdf(const MicrofacetParams &P, V3f wi, V3f wo, bool active) {
+    if (P.two_sided) { wo.z = mulsign(wo.z, wi.z); wi.z = std::fabs(wi.z); }
+    const float cos_theta_i = wi.z, cos_theta_o = wo.z;
+    const V3f m = normalize(wo + wi);
+    active = active && cos_theta_i > 0.f && cos_theta_o > 0.f && dot(wi, m) > 0.f && dot(wo, m) > 0.f;
+    if (!active) return 0.f;
+    GGX<float> distr{sqr(P.roughness.v)};
+    return distr.eval(m) * distr.smith_g1(wi, m) / (4.f * cos_theta_i);
+}
+// microfacet.cpp:75-98: uses sample.x, sample.y (not the tail); the sampled direction stays in the upper hemisphere
+struct MicrofacetSample { V3f wo; float pdf; bool valid; };
+inline MicrofacetSample microfacet_sample(const MicrofacetParams &P, V3f wi, const float s3[3], bool active) {
+    if (P.two_sided) wi.z = std::fabs(wi.z);
+    MicrofacetSample bs;
+    const float cos_theta_i = wi.z;
+    float m_pdf;
+    const V3f m = ggx_sample(sqr(P.roughness.v), wi, s3[0], s3[1], m_pdf);
+    const float k = 2.f * dot(wi, m);
+    bs.wo = V3f(fma_(m.x, k, -wi.x), fma_(m.y, k, -wi.y), fma_(m.z, k, -wi.z));
+    bs.pdf = m_pdf / (4.f * dot(bs.wo, m));
+    bs.valid = active && (cos_theta_i > 0.f) && (bs.pdf != 0.f) && (bs.wo.z > 0.f);
+    return bs;
+}
+
+} // namespace orc

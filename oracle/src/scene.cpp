@@ -185,6 +185,9 @@ Scene *configure_scene(const orc_scene_desc &d, const int *active, int n_active)
         bc.type = b.type; bc.two_sided = b.two_sided != 0;
         bc.reflectance = V3d(Dual(b.reflectance[0], b.d_reflectance[0]), Dual(b.reflectance[1], b.d_reflectance[1]),
                              Dual(b.reflectance[2], b.d_reflectance[2]));
+        bc.specular = V3d(Dual(b.specular[0], b.d_specular[0]), Dual(b.specular[1], b.d_specular[1]), Dual(b.specular[2], b.d_specular[2]));
+        bc.roughness = Dual(b.roughness, b.d_roughness);
+        if (b.type != 0 && b.type != 1) throw std::runtime_error("Unknown BSDF type!");
         if (b.tex_data != nullptr) {
             if (b.tex_width < 2 || b.tex_height < 2) throw std::runtime_error("Bitmap: invalid resolution!");
             bc.tex_w = b.tex_width; bc.tex_h = b.tex_height;

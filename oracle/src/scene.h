@@ -79,7 +79,8 @@ struct MeshC {
     float total_area = 0.f, inv_total_area = 0.f;
     Distrb face_distrb;
 };
-struct BsdfC { int type; V3d reflectance; bool two_sided; int tex_w = 0, tex_h = 0; std::vector<float> tex, d_tex; };   // tex: Bitmap3fD texels when textured
+struct BsdfC { int type; V3d reflectance; bool two_sided; int tex_w = 0, tex_h = 0; std::vector<float> tex, d_tex;
+               V3d specular; Dual roughness; };   // type 1 = Microfacet: reflectance is its diffuse reflectance   // tex: Bitmap3fD texels when textured
 // type 0 = AreaLight (area.h), 1 = EnvironmentMap (envmap.h); an envmap's mesh is the bounding cube scene.cpp:442-480 adds
 struct EmitterC { V3d radiance; int mesh = -1; float sampling_weight = 1.f; int type = 0; };
 

@@ -244,3 +244,79 @@ def test_orthographic_camera_projection(orc):
         assert np.allclose(img[16, 16], [3.0, 2.0, 1.0])
         assert np.allclose(img[0, 0], 0.0)
     assert counts[0] == counts[1] == 16 * 16
+
+
+def _mf(orc):
+    import ctypes as C
+    L = orc.lib()
+    f3 = C.c_float * 3
+    L.orc_microfacet_pdf.restype = C.c_float
+    L.orc_microfacet_pdf.argtypes = [C.c_float, C.c_int, f3, f3]
+    L.orc_ggx_eval.restype = C.c_float
+    L.orc_ggx_eval.argtypes = [C.c_float, f3]
+    L.orc_microfacet_sample.restype = C.c_int
+    L.orc_microfacet_sample.argtypes = [C.c_float, C.c_int, f3, f3, f3, C.POINTER(C.c_float)]
+    L.orc_microfacet_eval.restype = None
+    L.orc_microfacet_eval.argtypes = [C.c_float * 14, C.c_int, f3, f3, C.c_float * 6]
+
+    def ev(spec, diff, rough, wi, wo, d=(0,) * 7, two_sided=0):
+        out = (C.c_float * 6)()
+        L.orc_microfacet_eval((C.c_float * 14)(*spec, *diff, rough, *d), two_sided, f3(*wi), f3(*wo), out)
+        return np.array(out[:3]), np.array(out[3:])
+
+    def pdf(rough, wi, wo, two_sided=0):
+        return float(L.orc_microfacet_pdf(rough, two_sided, f3(*wi), f3(*wo)))
+
+    def sample(rough, wi, s3):
+        wo = f3(); p = C.c_float()
+        ok = L.orc_microfacet_sample(rough, 0, f3(*wi), f3(*s3), wo, C.byref(p))
+        return ok, np.array(wo[:]), float(p.value)
+
+    return ev, pdf, sample, lambda a, m: float(L.orc_ggx_eval(a, f3(*m)))
+
+
+def test_microfacet_bsdf_known_answers(orc):
+    """GGX normalisation, pdf of the visible-normal sampler, reciprocity, energy bound and the roughness derivative of the
+    Microfacet BSDF restatement (reference microfacet.cpp / ggx.cpp)"""
+    ev, pdf, sample, ggx = _mf(orc)
+    n_t, n_p = 400, 400
+    th = (np.arange(n_t) + 0.5) * (0.5 * np.pi / n_t)
+    ph = (np.arange(n_p) + 0.5) * (2 * np.pi / n_p)
+    dw = (0.5 * np.pi / n_t) * (2 * np.pi / n_p)
+    dirs = [(np.sin(t) * np.cos(p), np.sin(t) * np.sin(p), np.cos(t), np.sin(t)) for t in th[::4] for p in ph[::4]]
+    for alpha in (0.1, 0.4):
+        tot = sum(ggx(alpha, d[:3]) * d[2] * d[3] for d in dirs) * dw * 16
+        assert abs(tot - 1.0) < 0.02, (alpha, tot)            # int D(m) cos(theta_m) dw = 1
+    rough = 0.5
+    wi = np.array([0.3, -0.2, 0.0]); wi[2] = np.sqrt(1 - wi[0] ** 2 - wi[1] ** 2)
+    tot = sum(pdf(rough, wi, d[:3]) * d[3] for d in dirs) * dw * 16
+    assert 0.9 < tot <= 1.01, tot                               # visible normals: only reflections below the horizon are lost
+    rng = np.random.default_rng(0)
+    n_ok = 0
+    for _ in range(300):
+        s3 = rng.random(3)
+        ok, wo, p = sample(rough, wi, s3)
+        if ok:
+            n_ok += 1
+            assert abs(np.linalg.norm(wo) - 1) < 1e-5 and wo[2] > 0
+            assert abs(pdf(rough, wi, wo) - p) < 2e-4 * max(1.0, p)        # the sampler's pdf is the pdf
+    assert n_ok > 250
+    spec, diff = (0.9, 0.8, 0.7), (0.1, 0.2, 0.3)
+    wo = np.array([-0.5, 0.1, 0.0]); wo[2] = np.sqrt(1 - wo[0] ** 2 - wo[1] ** 2)
+    a, _ = ev(spec, diff, rough, wi, wo)
+    b, _ = ev(spec, diff, rough, wo, wi)
+    assert np.allclose(a / wo[2], b / wi[2], rtol=1e-5)         # reciprocity of the BRDF
+    alb = sum(ev((1, 1, 1), (0, 0, 0), rough, wi, d[:3])[0] * d[3] for d in dirs) * dw * 16
+    assert np.all(alb < 1.0) and np.all(alb > 0.5)              # a white specular lobe loses only the multiple-scattering energy
+    # d/d roughness by the (value, tangent) arithmetic == finite difference
+    _, t = ev(spec, diff, rough, wi, wo, d=(0, 0, 0, 0, 0, 0, 1))
+    h = 1e-3
+    fd = (ev(spec, diff, rough + h, wi, wo)[0] - ev(spec, diff, rough - h, wi, wo)[0]) / (2 * h)
+    assert np.allclose(t, fd, rtol=2e-2, atol=1e-4)
+    _, t = ev(spec, diff, rough, wi, wo, d=(1, 1, 1, 0, 0, 0, 0))
+    fd = (ev((0.91, 0.81, 0.71), diff, rough, wi, wo)[0] - a) / 0.01
+    assert np.allclose(t, fd, rtol=1e-2, atol=1e-4)
+    # two-sided: flipping both directions through the surface gives the same value
+    c, _ = ev(spec, diff, rough, wi * [1, 1, -1], wo * [1, 1, -1], two_sided=1)
+    assert np.allclose(c, a, rtol=1e-6)
+    assert np.all(ev(spec, diff, rough, wi * [1, 1, -1], wo * [1, 1, -1])[0] == 0)
