@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PSDR_HIP_ABI_VERSION 5
+#define PSDR_HIP_ABI_VERSION 6
 
 /* TriangleInfo SoA, reference include/psdr/types.h:162-175 (+ Scene::m_triangle_uv,
  * m_triangle_face_normals, scene.cpp:528-542).  Arrays of n_triangles rows. */
@@ -55,7 +55,7 @@ typedef struct psdr_mesh_rec {       /* what the kernels need of reference Mesh 
 } psdr_mesh_rec;
 
 typedef struct psdr_bsdf_rec {       /* Diffuse, reference src/bsdf/diffuse.cpp */
-    int32_t type;                    /* 0 = diffuse */
+    int32_t type;                    /* 0 = Diffuse, 1 = Microfacet */
     int32_t two_sided;
     float reflectance[3], d_reflectance[3];
     /* textured reflectance: Bitmap3fD with a resolution above 1x1 (bitmap.cpp:47-128, looked up at its.uv with flip_v);
@@ -63,6 +63,9 @@ typedef struct psdr_bsdf_rec {       /* Diffuse, reference src/bsdf/diffuse.cpp 
     int32_t tex_width, tex_height;
     const float *tex_data;           /* [tex_height*tex_width*3] row-major rgb */
     const float *d_tex_data;         /* forward tangent of the texels, may be NULL */
+    /* type 1 = Microfacet (src/bsdf/microfacet.cpp, ggx.cpp): `reflectance` is its diffuse reflectance, plus */
+    float specular[3], d_specular[3];
+    float roughness, d_roughness;
 } psdr_bsdf_rec;
 
 typedef struct psdr_emitter_rec {    /* AreaLight (src/emitter/area.cpp) or EnvironmentMap (src/emitter/envmap.cpp) */

@@ -35,6 +35,7 @@ BSDF = _core.BSDF
 DiffuseBSDF = _core.DiffuseBSDF
 Emitter = _core.Emitter
 AreaLight = _core.AreaLight
+MicrofacetBSDF = _core.MicrofacetBSDF
 EnvironmentMap = _core.EnvironmentMap
 Sensor = _core.Sensor
 PerspectiveCamera = _core.PerspectiveCamera
@@ -168,6 +169,9 @@ for _cls in (Mesh, Sensor, PerspectiveCamera):
         setattr(_cls, _n, _make_param_property(_n, _m44))
 Mesh.vertex_positions = _make_param_property("vertex_positions", _vtx)
 DiffuseBSDF.reflectance = _make_param_property("reflectance", _refl_shape)
+MicrofacetBSDF.specularReflectance = _make_param_property("specularReflectance", _v3)
+MicrofacetBSDF.diffuseReflectance = _make_param_property("diffuseReflectance", _v3)
+MicrofacetBSDF.roughness = _make_param_property("roughness", lambda self, value: (1,))
 AreaLight.radiance = _make_param_property("radiance", _v3)
 
 
@@ -210,6 +214,22 @@ def _diffuse_init(self, reflectance=None):
 
 
 DiffuseBSDF.__init__ = _diffuse_init
+_MicrofacetBSDF_init = MicrofacetBSDF.__init__
+
+
+def _microfacet_init(self, specular=None, diffuse=None, roughness=None):
+    """MicrofacetBSDF() or MicrofacetBSDF(specularReflectance, diffuseReflectance, roughness) (reference psdr.cpp:298-304)"""
+    if specular is None:
+        _MicrofacetBSDF_init(self)
+        return
+    _MicrofacetBSDF_init(self, _split(specular, (-1,))[0] * _np.ones(3, _np.float32), _split(diffuse, (-1,))[0] * _np.ones(3, _np.float32),
+                         float(_split(roughness, (-1,))[0][0]))
+    for name, val in (("specularReflectance", specular), ("diffuseReflectance", diffuse), ("roughness", roughness)):
+        if isinstance(val, _torch.Tensor):
+            _params(self)[name] = val
+
+
+MicrofacetBSDF.__init__ = _microfacet_init
 _AreaLight_init = AreaLight.__init__
 
 

@@ -101,7 +101,12 @@ def snapshot_tensors(scene, sensor_id, leaf_of):
         prim = torch.zeros((0, 4), dtype=F64)
     nb = sum(1 for k in pm if k.startswith("BSDF[") and not k.startswith("BSDF[id="))
     ne = sum(1 for k in pm if k.startswith("Emitter[") and not k.startswith("Emitter[id="))
-    refl = torch.stack([leaf_of(pm["BSDF[%d]" % i], "reflectance").reshape(-1).expand(3) for i in range(nb)]) if nb else torch.zeros((0, 3), dtype=F64)
+    def _refl(b):     # the colour row g_bsdf refers to: Diffuse reflectance, Microfacet diffuse reflectance (textures: no adjoint)
+        if type(b).__name__ == "MicrofacetBSDF":
+            return leaf_of(b, "diffuseReflectance").reshape(-1).expand(3)
+        r = leaf_of(b, "reflectance")
+        return torch.zeros(3, dtype=F64) if r.dim() == 3 else r.reshape(-1).expand(3)
+    refl = torch.stack([_refl(pm["BSDF[%d]" % i]) for i in range(nb)]) if nb else torch.zeros((0, 3), dtype=F64)
     def _rad(e):      # the environment map's texels are not differentiated (its row of g_emitter stays zero)
         return torch.zeros(3, dtype=F64) if type(e).__name__ == "EnvironmentMap" else leaf_of(e, "radiance").reshape(-1).expand(3)
     rad = torch.stack([_rad(pm["Emitter[%d]" % i]) for i in range(ne)]) if ne else torch.zeros((0, 3), dtype=F64)

@@ -487,6 +487,25 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
             T.tex = sc->bufs.back()->as<TexDev>();
         }
     }
+    T.mat = nullptr;
+    {
+        bool any = false;
+        for (int i = 0; i < s->n_bsdfs; ++i) {
+            if (s->bsdfs[i].type != 0 && s->bsdfs[i].type != 1) return fail("Unknown BSDF type!");
+            any |= s->bsdfs[i].type == 1;
+        }
+        if (any) {
+            std::vector<MatDev> md((size_t) s->n_bsdfs);
+            for (int i = 0; i < s->n_bsdfs; ++i) {
+                const psdr_bsdf_rec &b = s->bsdfs[i];
+                for (int k = 0; k < 3; ++k) { md[i].specular[k] = b.specular[k]; md[i].d_specular[k] = b.d_specular[k]; }
+                md[i].roughness = b.roughness; md[i].d_roughness = b.d_roughness;
+            }
+            sc->bufs.emplace_back(new DevBuf());
+            if (sc->bufs.back()->upload(md.data(), md.size() * sizeof(MatDev))) return 1;
+            T.mat = sc->bufs.back()->as<MatDev>();
+        }
+    }
     std::vector<FilterPrim> filt;
     build_filter_prims(tr.p0, tr.e1, tr.e2, bvh.order.data(), n, filt);
     T.filt_off = (int) w;  w += 4 * filt.size();
@@ -568,8 +587,8 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     }
     for (int i = 0; i < s->n_bsdfs; ++i) {
         const psdr_bsdf_rec &b = s->bsdfs[i];
-        if (b.type != 0) return fail("Unknown BSDF type!");
-        put4(blob, T.bsdf_off + 2 * (size_t) i, b.reflectance[0], b.reflectance[1], b.reflectance[2], ibits((b.two_sided ? 1 : 0) | (b.tex_data ? 2 : 0)));
+        if (b.type != 0 && b.type != 1) return fail("Unknown BSDF type!");
+        put4(blob, T.bsdf_off + 2 * (size_t) i, b.reflectance[0], b.reflectance[1], b.reflectance[2], ibits((b.two_sided ? 1 : 0) | (b.tex_data ? 2 : 0) | (b.type == 1 ? 4 : 0)));
         put4(blob, T.bsdf_off + 2 * (size_t) i + 1, b.d_reflectance[0], b.d_reflectance[1], b.d_reflectance[2], 0.f);
     }
     for (int i = 0; i < s->n_emitters; ++i) {
@@ -614,7 +633,7 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     const size_t stack_bytes = (size_t) T.stack_depth * kBlock * sizeof(int);
     const size_t blob_bytes = (size_t) T.blob_words * 16;
     // keeps >= 4 workgroups per CU (160 KiB LDS); the environment-map and texture code lives in the LDS=false kernels only (shade.h)
-    sc->lds = blob_bytes + stack_bytes <= 40 * 1024 && T.env_emitter < 0 && T.tex == nullptr;
+    sc->lds = blob_bytes + stack_bytes <= 40 * 1024 && T.env_emitter < 0 && T.tex == nullptr && T.mat == nullptr;
     sc->smem_bytes = (sc->lds ? blob_bytes : 0) + stack_bytes;
     if (sc->smem_bytes > 64 * 1024) return fail("BVH too deep for the LDS traversal stack");
     sc->n_leaves = bvh.n_leaves; sc->max_depth = bvh.max_depth;

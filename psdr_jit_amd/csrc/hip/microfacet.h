@@ -1,0 +1,121 @@
+// microfacet.h — Microfacet BSDF (reference src/bsdf/microfacet.cpp:18-134: Lambertian diffuse + GGX specular with the
+// 2^(...) Schlick-style Fresnel) and GGXDistribution (src/bsdf/ggx.cpp:8-107, visible-normal sampling).
+// drjit::pow(2, x) = the Cephes exp2f polynomial with explicit fma (as in the oracle); drjit::rsqrt = 1/sqrt.
+// Only instantiated in the LDS=false kernels (shade.h).
+#pragma once
+#include "scene_dev.h"
+
+namespace psdr {
+
+PSDR_DEV float exp2_cephes(float x) {
+    if (x > 127.f) return __builtin_inff();
+    if (x < -127.f) return 0.f;
+    float px = floorf(x);
+    int i0 = (int) px;
+    x = x - px;
+    if (x > 0.5f) { i0 += 1; x = x - 1.f; }
+    px = fma_(fma_(fma_(fma_(fma_(1.535336188319500e-4f, x, 1.339887440266574e-3f), x, 9.618437357674640e-3f), x, 5.550332471162809e-2f), x,
+                   2.402264791363012e-1f), x, 6.931472028550421e-1f);
+    px = fma_(px, x, 1.0f);
+    return ldexpf(px, i0);
+}
+PSDR_DEV float exp2_(float x) { return exp2_cephes(x); }
+PSDR_DEV Dual exp2_(const Dual &x) { const float v = exp2_cephes(x.v); return Dual(v, v * 0.6931471805599453f * x.d); }
+
+template <typename R> struct GGX {
+    R a;
+    PSDR_DEV R eval(const Vec3<R> &m) const {                                     // ggx.cpp:13-33
+        const R alpha_uv = a * a;
+        const R r = rcp_(R(kPi) * alpha_uv * sqr(sqr(m.x / a) + sqr(m.y / a) + sqr(m.z)));
+        return (detach(r) * detach(m.z) > 1e-20f) ? r : R(0.f);
+    }
+    PSDR_DEV R smith_g1(const Vec3<R> &v, const Vec3<R> &m) const {                // ggx.cpp:84-97
+        const R xy_alpha_2 = sqr(a * v.x) + sqr(a * v.y);
+        const R tan_theta_alpha_2 = xy_alpha_2 / sqr(v.z);
+        R result = R(2.f) / (R(1.f) + sqrt_(R(1.f) + tan_theta_alpha_2));
+        if (detach(xy_alpha_2) == 0.f) result = R(1.f);
+        if (detach(dot(v, m)) * detach(v.z) <= 0.f) result = R(0.f);
+        return result;
+    }
+};
+
+PSDR_DEV void sincos_cephes(float xx, float &s_out, float &c_out);                // shade.h
+
+// ggx.cpp:99-107 on warp.h:16-52
+PSDR_DEV void ggx_sample_visible_11(float cos_theta_i, float sx, float sy, float &slope_x, float &slope_y) {
+    const float x0 = fma_(2.f, sx, -1.f), y0 = fma_(2.f, sy, -1.f);
+    const bool is_zero = (x0 == 0.f) && (y0 == 0.f), q13 = fabsf(x0) < fabsf(y0);
+    const float r = q13 ? y0 : x0, rp = q13 ? x0 : y0;
+    float phi = .25f * kPi * rp / r;
+    if (q13) phi = .5f * kPi - phi;
+    if (is_zero) phi = 0.f;
+    float sn, cs;
+    sincos_cephes(phi, sn, cs);
+    const float px = r * cs;
+    float py = r * sn;
+    const float s = .5f * (1.f + cos_theta_i);
+    const float a0 = safe_sqrt(1.f - sqr(px));
+    py = fma_(py, s, fma_(-a0, s, a0));                                           // drjit::lerp
+    const float z = safe_sqrt(1.f - fma_(py, py, px * px));
+    const float sin_theta_i = safe_sqrt(1.f - sqr(cos_theta_i));
+    const float norm = 1.f / fma_(sin_theta_i, py, cos_theta_i * z);
+    slope_x = fma_(cos_theta_i, py, -(sin_theta_i * z)) * norm;
+    slope_y = px * norm;
+}
+// ggx.cpp:35-82 (detached)
+PSDR_DEV Vec3f ggx_sample(float a, const Vec3f &wi, float sx, float sy, float &pdf) {
+    const Vec3f wi_p = normalize(Vec3f(a * wi.x, a * wi.y, wi.z));
+    const float sin_theta_2 = fma_(wi_p.x, wi_p.x, sqr(wi_p.y));
+    const float inv_sin_theta = 1.f / sqrtf(sin_theta_2);
+    const bool deg = fabsf(sin_theta_2) <= 4.f * kEpsilon;
+    const float sin_phi = deg ? 0.f : fminf(fmaxf(wi_p.y * inv_sin_theta, -1.f), 1.f);
+    const float cos_phi = deg ? 1.f : fminf(fmaxf(wi_p.x * inv_sin_theta, -1.f), 1.f);
+    float slx, sly;
+    ggx_sample_visible_11(wi_p.z, sx, sy, slx, sly);
+    const float s0 = fma_(cos_phi, slx, -(sin_phi * sly)) * a, s1 = fma_(sin_phi, slx, cos_phi * sly) * a;
+    const Vec3f m = normalize(Vec3f(-s0, -s1, 1.f));
+    GGX<float> g{a};
+    pdf = g.smith_g1(wi, m) * fabsf(dot(wi, m)) * g.eval(m) / fabsf(wi.z);
+    return m;
+}
+
+// microfacet.cpp:22-62
+template <typename R>
+PSDR_DEV Vec3<R> microfacet_eval(const Vec3<R> &spec, const Vec3<R> &diff, const R &roughness, bool two_sided, Vec3<R> wi, Vec3<R> wo, bool active) {
+    using V = Vec3<R>;
+    if (two_sided) { wo.z = mulsign(wo.z, detach(wi.z)); wi.z = abs_(wi.z); }
+    const R cos_theta_nv = wi.z, cos_theta_nl = wo.z;
+    if (!(active && detach(cos_theta_nv) > 0.f && detach(cos_theta_nl) > 0.f)) return V(R(0.f));
+    const V diffuse = diff * R(kInvPi);
+    const V H = normalize(wi + wo);
+    const R cos_theta_vh = dot(H, wi);
+    GGX<R> distr{sqr(roughness)};
+    const R ggx = distr.eval(H);
+    const R coeff = cos_theta_vh * (R(-5.55473f) * cos_theta_vh - R(6.8316f));
+    const V fresnel = spec + (V(R(1.f)) - spec) * exp2_(coeff);
+    const R smithG = distr.smith_g1(wi, H) * distr.smith_g1(wo, H);
+    const V numerator = fresnel * (ggx * smithG);
+    const R denominator = R(4.f) * cos_theta_nl * cos_theta_nv;
+    const V specular = numerator / (denominator + R(1e-6f));
+    return (diffuse + specular) * cos_theta_nl;
+}
+// microfacet.cpp:108-131
+PSDR_DEV float microfacet_pdf(float roughness, bool two_sided, Vec3f wi, Vec3f wo, bool active) {
+    if (two_sided) { wo.z = mulsign(wo.z, wi.z); wi.z = fabsf(wi.z); }
+    const Vec3f m = normalize(wo + wi);
+    if (!(active && wi.z > 0.f && wo.z > 0.f && dot(wi, m) > 0.f && dot(wo, m) > 0.f)) return 0.f;
+    GGX<float> distr{sqr(roughness)};
+    return distr.eval(m) * distr.smith_g1(wi, m) / (4.f * wi.z);
+}
+// microfacet.cpp:75-98: the first two of the three sample numbers; the direction stays in the upper hemisphere
+PSDR_DEV void microfacet_sample(float roughness, bool two_sided, Vec3f wi, float s0, float s1, bool active, Vec3f &wo, float &pdf, bool &valid) {
+    if (two_sided) wi.z = fabsf(wi.z);
+    float m_pdf;
+    const Vec3f m = ggx_sample(sqr(roughness), wi, s0, s1, m_pdf);
+    const float k = 2.f * dot(wi, m);
+    wo = Vec3f(fma_(m.x, k, -wi.x), fma_(m.y, k, -wi.y), fma_(m.z, k, -wi.z));
+    pdf = m_pdf / (4.f * dot(wo, m));
+    valid = active && (wi.z > 0.f) && (pdf != 0.f) && (wo.z > 0.f);
+}
+
+} // namespace psdr

@@ -159,7 +159,7 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
         if (do_bsdf) {
             const float s0 = rng.next_1d(), s1 = rng.next_1d(), s2 = rng.next_1d();
             (void) s0;
-            bs = bsdf_sample<AD, LDS>(S, its, s1, s2, true);
+            bs = bsdf_sample<AD, LDS>(S, its, s0, s1, s2, true);
             ext.o = its.p; ext.d = to_world<AD>(its, bs.wo);
         }
         Hit h, hx;

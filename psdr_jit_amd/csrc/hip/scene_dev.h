@@ -31,6 +31,9 @@ struct EnvDev {
 // reflectance texture of one BSDF (global memory; w == 0: constant colour)
 struct TexDev { const float *data, *d_data; int w, h; };
 
+// Microfacet parameters beyond the diffuse reflectance (global memory table, one entry per BSDF; microfacet.h)
+struct MatDev { float specular[3], d_specular[3], roughness, d_roughness; };
+
 struct SceneTables {
     // float4-word offsets into the blob
     int nodes_off, trav_off, shade_off, tan_off, map_off, mesh_off, bsdf_off, emit_off, ecdf_off, fcdf_off;
@@ -40,6 +43,7 @@ struct SceneTables {
     float center[3], radius;   // bounding sphere of all vertices
     int env_emitter;           // index of the EnvironmentMap among the emitters, -1 = none
     const TexDev *tex;         // [n_bsdfs] or NULL when no BSDF is textured
+    const MatDev *mat;         // [n_bsdfs] or NULL when every BSDF is Diffuse
     EnvDev env;
     float emitter_sum;
     int blob_words;            // float4 count

@@ -7,6 +7,7 @@
 #include "scene_dev.h"
 #include "sampler.h"
 #include "../common/envmath.h"
+#include "microfacet.h"
 
 namespace psdr {
 
@@ -347,6 +348,22 @@ template <bool AD, bool LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S
     if (mesh_bsdf(S, its.mesh) < 0) return V(R(0.f));          // the envmap's bounding cube has no BSDF (null vcall = zeros)
     const int w = S.T->bsdf_off + 2 * mesh_bsdf(S, its.mesh);
     const float4 a = S.ld(w);
+    if constexpr (!LDS) {
+        if (__float_as_int(a.w) & 4) {         // Microfacet (microfacet.cpp); its diffuse reflectance is the record's colour
+            const int id = mesh_bsdf(S, its.mesh);
+            const MatDev md = S.T->mat[id];
+            if constexpr (AD) {
+                const float4 b = S.rgb_tan(w + 1, 2, id);
+                const bool tan = S.mode == 0;          // (specular / roughness adjoints are not returned by reverse mode)
+                const Vec3d spec(Dual(md.specular[0], tan ? md.d_specular[0] : 0.f), Dual(md.specular[1], tan ? md.d_specular[1] : 0.f), Dual(md.specular[2], tan ? md.d_specular[2] : 0.f));
+                return microfacet_eval<Dual>(spec, make_dual(Vec3f(a.x, a.y, a.z), Vec3f(b.x, b.y, b.z)), Dual(md.roughness, tan ? md.d_roughness : 0.f),
+                                             (__float_as_int(a.w) & 1) != 0, its.wi, wo, active);
+            } else {
+                return microfacet_eval<float>(Vec3f(md.specular[0], md.specular[1], md.specular[2]), Vec3f(a.x, a.y, a.z), md.roughness,
+                                              (__float_as_int(a.w) & 1) != 0, its.wi, wo, active);
+            }
+        }
+    }
     R wiz = its.wi.z;
     if (__float_as_int(a.w) & 1) { wo.z = mulsign(wo.z, detach(wiz)); wiz = abs_(wiz); }
     if (!(active && detach(wiz) > 0.f && detach(wo.z) > 0.f)) return V(R(0.f));
@@ -376,6 +393,10 @@ template <bool AD, bool LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S
 template <bool AD, bool LDS> PSDR_DEV float bsdf_pdf(const SceneView<LDS> &S, const Its<AD> &its, const VecN<AD> &wo, bool active) {
     if (mesh_bsdf(S, its.mesh) < 0) return 0.f;
     const float4 a = S.ld(S.T->bsdf_off + 2 * mesh_bsdf(S, its.mesh));
+    if constexpr (!LDS) {
+        if (__float_as_int(a.w) & 4)
+            return microfacet_pdf(S.T->mat[mesh_bsdf(S, its.mesh)].roughness, (__float_as_int(a.w) & 1) != 0, detach(its.wi), detach(wo), active);
+    }
     float wiz = detach(its.wi.z), woz = detach(wo.z);
     if (__float_as_int(a.w) & 1) { woz = mulsign(woz, wiz); wiz = fabsf(wiz); }
     return (active && wiz > 0.f && woz > 0.f) ? kInvPi * woz : 0.f;
@@ -415,9 +436,17 @@ PSDR_DEV Vec3f square_to_cosine_hemisphere(float sx, float sy) {
     return Vec3f(px, py, safe_sqrt(1.f - fma_(py, py, px * px)));
 }
 struct BSDFSample { Vec3f wo; float pdf; bool valid; };
-template <bool AD, bool LDS> PSDR_DEV BSDFSample bsdf_sample(const SceneView<LDS> &S, const Its<AD> &its, float s1, float s2, bool active) {
+template <bool AD, bool LDS> PSDR_DEV BSDFSample bsdf_sample(const SceneView<LDS> &S, const Its<AD> &its, float s0, float s1, float s2, bool active) {
+    (void) s0;
     if (mesh_bsdf(S, its.mesh) < 0) { BSDFSample z; z.wo = Vec3f(0.f, 0.f, 0.f); z.pdf = 0.f; z.valid = false; return z; }
     const float4 a = S.ld(S.T->bsdf_off + 2 * mesh_bsdf(S, its.mesh));
+    if constexpr (!LDS) {
+        if (__float_as_int(a.w) & 4) {         // Microfacet::sample uses the first two numbers (microfacet.cpp:88)
+            BSDFSample m;
+            microfacet_sample(S.T->mat[mesh_bsdf(S, its.mesh)].roughness, (__float_as_int(a.w) & 1) != 0, detach(its.wi), s0, s1, active, m.wo, m.pdf, m.valid);
+            return m;
+        }
+    }
     float wiz = detach(its.wi.z);
     if (__float_as_int(a.w) & 1) wiz = fabsf(wiz);
     BSDFSample bs;
@@ -476,7 +505,7 @@ PSDR_DEV VecN<AD> Li(SceneView<LDS> &S, LaneRng &rng, const RayT<AD> &ray_in, bo
         if (mis != 0) {   // BSDF sampling (path.cpp:86-123)
             const float s0 = rng.next_1d(), s1 = rng.next_1d(), s2 = rng.next_1d();
             (void) s0;
-            const BSDFSample bs = bsdf_sample<AD, LDS>(S, its, s1, s2, true);
+            const BSDFSample bs = bsdf_sample<AD, LDS>(S, its, s0, s1, s2, true);
             RayT<AD> curr; curr.o = its.p; curr.d = to_world<AD>(its, bs.wo);
             Its<AD> its1 = ray_intersect<AD, AD, LDS, COUNT>(S, curr, bs.valid);     // (an invalid sample ends the path)
             active = bs.valid && its1.valid;

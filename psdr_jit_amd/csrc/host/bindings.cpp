@@ -90,6 +90,18 @@ PYBIND11_MODULE(_psdr_core, m) {
             d.reflectance = to_a3(v); d.d_reflectance = to_a3(t); })
         .def_readonly("_tex_width", &Diffuse::tex_w).def_readonly("_tex_height", &Diffuse::tex_h);
 
+    py::class_<Microfacet, BSDF>(m, "MicrofacetBSDF", py::dynamic_attr())
+        .def(py::init<>())
+        .def(py::init([](const farr &s, const farr &d, float r) { return new Microfacet(to_a3(s), to_a3(d), r); }))
+        .def("_get", [](const Microfacet &b, const std::string &name, bool tangent) {
+            if (name == "roughness") { farr a(1); a.mutable_data()[0] = tangent ? b.d_roughness : b.roughness; return a; }
+            const auto &r = name == "specularReflectance" ? (tangent ? b.d_specular : b.specular) : (tangent ? b.d_diffuse : b.diffuse);
+            farr a(3); std::memcpy(a.mutable_data(), r.data(), 12); return a; })
+        .def("_set", [](Microfacet &b, const std::string &name, const farr &v, const farr &t) {
+            if (name == "roughness") { b.roughness = v.data()[0]; b.d_roughness = t.size() ? t.data()[0] : 0.f; }
+            else if (name == "specularReflectance") { b.specular = to_a3(v); b.d_specular = to_a3(t); }
+            else { b.diffuse = to_a3(v); b.d_diffuse = to_a3(t); } });
+
     py::class_<Emitter, Object>(m, "Emitter", py::dynamic_attr());
     py::class_<AreaLight, Emitter>(m, "AreaLight", py::dynamic_attr())
         .def(py::init([](const farr &r) { return new AreaLight(to_a3(r)); }))

@@ -420,10 +420,11 @@ void Scene::add_Sensor(const Sensor *sensor) {       // scene.cpp:107-126 (the s
 }
 void Scene::add_BSDF(const BSDF *bsdf, const std::string &bsdf_id, bool twoSide) {      // scene.cpp:148-247
     const Diffuse *d = dynamic_cast<const Diffuse *>(bsdf);
-    PSDR_ASSERT_MSG(d != nullptr, "Unknown BSDF type!");
-    if (m_opts.log_level > 0) std::cout << "add_BSDF: Diffuse " << bsdf_id << std::endl;
+    const Microfacet *mf = dynamic_cast<const Microfacet *>(bsdf);
+    PSDR_ASSERT_MSG(d != nullptr || mf != nullptr, "Unknown BSDF type!");
+    if (m_opts.log_level > 0) std::cout << "add_BSDF: " << (d ? "Diffuse " : "Microfacet ") << bsdf_id << std::endl;
     PSDR_ASSERT_MSG(m_param_map.find("BSDF[id=" + bsdf_id + "]") == m_param_map.end(), std::string("Duplicate BSDF id: ") + bsdf_id);
-    Diffuse *c = new Diffuse(*d);
+    BSDF *c = d ? static_cast<BSDF *>(new Diffuse(*d)) : static_cast<BSDF *>(new Microfacet(*mf));
     c->m_twoSide = twoSide; c->m_id = bsdf_id;
     m_bsdfs.push_back(c);
     rebuild_param_map();
@@ -627,6 +628,17 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
         }
     }
     for (BSDF *b : m_bsdfs) {
+        if (const Microfacet *mf = dynamic_cast<const Microfacet *>(b)) {
+            psdr_bsdf_rec r{};
+            r.type = 1; r.two_sided = mf->m_twoSide ? 1 : 0;
+            for (int k = 0; k < 3; ++k) {
+                r.reflectance[k] = mf->diffuse[k]; r.d_reflectance[k] = mf->d_diffuse[k];
+                r.specular[k] = mf->specular[k]; r.d_specular[k] = mf->d_specular[k];
+            }
+            r.roughness = mf->roughness; r.d_roughness = mf->d_roughness;
+            S.bsdfs.push_back(r);
+            continue;
+        }
         const Diffuse *d = static_cast<const Diffuse *>(b);
         psdr_bsdf_rec r{};
         r.type = 0; r.two_sided = d->m_twoSide ? 1 : 0;

@@ -72,6 +72,17 @@ struct Diffuse : BSDF {
     std::vector<float> tex, d_tex;
 };
 
+// Microfacet, reference include/psdr/bsdf/microfacet.h (constant parameters; the reference's bitmap variants are not built)
+struct Microfacet : BSDF {
+    Microfacet() {}
+    Microfacet(const std::array<float, 3> &spec, const std::array<float, 3> &diff, float rough) : specular(spec), diffuse(diff), roughness(rough) {}
+    std::string type_name() const override { return "Microfacet"; }
+    std::string to_string() const override { return std::string("Microfacet[id=") + m_id + "]"; }
+    bool anisotropic() const override { return false; }
+    std::array<float, 3> specular{0.04f, 0.04f, 0.04f}, diffuse{0.5f, 0.5f, 0.5f}, d_specular{0, 0, 0}, d_diffuse{0, 0, 0};
+    float roughness = 0.8f, d_roughness = 0.f;
+};
+
 struct Mesh;
 struct Emitter : Object { float m_sampling_weight = 1.f; bool m_ready = false; };
 struct AreaLight : Emitter {

@@ -1,7 +1,7 @@
 """XML scene files (reference src/scene/scene_loader.cpp:174-510; a Mitsuba-0.6-style dialect): Scene.load_file /
 Scene.load_string.  Host-side parsing only - the result is a sequence of the same add_Sensor / add_BSDF /
 add_EnvironmentMap / add_Mesh calls a script would make, in the reference's order (sensors, BSDFs, emitters, shapes).
-Supported like the reference: perspective sensors, diffuse BSDFs (colour or bitmap texture), envmap and area emitters,
+Supported like the reference: perspective sensors, diffuse BSDFs (colour or bitmap texture), microfacet BSDFs (constants), envmap and area emitters,
 obj shapes, transforms (translate, rotate, scale, look_at, matrix).  The GGX BSDF family is not built."""
 import math
 import os
@@ -166,7 +166,13 @@ def load_scene(root, scene, psdr, base_dir=None):
                 b = psdr.DiffuseBSDF(psdr.Bitmap3fD(_parse_bitmap(refl, base_dir)))
             else:
                 b = psdr.DiffuseBSDF(_load_rgb(refl))
-        elif btype in ("roughconductor", "roughdielectric", "microfacet", "normalmap"):
+        elif btype == "microfacet":
+            nodes = [_child_by_name(node, {"specular_reflectance", "specularReflectance"}), _child_by_name(node, {"diffuse_reflectance", "diffuseReflectance"}),
+                     _child_by_name(node, {"roughness"})]
+            if any(n.tag == "texture" for n in nodes):
+                raise _Err("MicrofacetBSDF: bitmap parameters are not built, only constants")
+            b = psdr.MicrofacetBSDF(_load_rgb(nodes[0]), _load_rgb(nodes[1]), float(nodes[2].get("value")))
+        elif btype in ("roughconductor", "roughdielectric", "normalmap"):
             raise _Err("Unknown BSDF type! (%s: the GGX BSDF family is not built)" % btype)
         else:
             raise _Err("Unsupported BSDF: " + str(btype))

@@ -16,6 +16,13 @@ def build_scene(spec, configure=True, active=(0,), host_only=False, log_level=0)
         cam._set("to_world_right", c.to_world_right, c.d_to_world_right)
         sc.add_Sensor(cam)
     for i, b in enumerate(spec.bsdfs):
+        if getattr(b, "type", 0) == 1:
+            bs = psdr.MicrofacetBSDF(list(b.specular), list(b.reflectance), float(b.roughness))
+            bs._set("specularReflectance", np.asarray(b.specular, np.float32), np.asarray(b.d_specular, np.float32))
+            bs._set("diffuseReflectance", np.asarray(b.reflectance, np.float32), np.asarray(b.d_reflectance, np.float32))
+            bs._set("roughness", np.asarray([b.roughness], np.float32), np.asarray([b.d_roughness], np.float32))
+            sc.add_BSDF(bs, b.name or ("bsdf%d" % i), b.two_sided)
+            continue
         bs = psdr.DiffuseBSDF(list(b.reflectance))
         bs._set("reflectance", np.asarray(b.reflectance, np.float32), np.asarray(b.d_reflectance, np.float32))
         if getattr(b, "texture", None) is not None:

@@ -291,3 +291,24 @@ def ortho_cbox_scene(width=48, height=48, spp=4, sppe=0, sppse=0, param="box_x")
     elif param is not None:
         raise ValueError(param)
     return spec
+
+
+def microfacet_cbox_scene(width=48, height=48, spp=8, sppe=0, sppse=0, param="roughness", two_sided=False):
+    """The README Cornell box with Microfacet boxes and floor (reference src/bsdf/microfacet.cpp).
+    param: 'roughness' | 'specular' | 'diffuse' (d/dP = 1 on the boxes' BSDF) | 'box_x' | None"""
+    spec = cbox_scene(width, height, spp, sppe, sppse, param=None)
+    spec.bsdfs[1] = BsdfSpec((0.3, 0.4, 0.5), name="cat", type=1, specular=(0.6, 0.5, 0.4), roughness=0.35, two_sided=two_sided)
+    spec.bsdfs[2] = BsdfSpec((0.7, 0.7, 0.7), name="white", type=1, specular=(0.04, 0.04, 0.04), roughness=0.6)
+    if param == "roughness":
+        spec.bsdfs[1].d_roughness = 1.0
+    elif param == "specular":
+        spec.bsdfs[1].d_specular = (1.0, 1.0, 1.0)
+    elif param == "diffuse":
+        spec.bsdfs[1].d_reflectance = (1.0, 1.0, 1.0)
+    elif param == "box_x":
+        dT = np.zeros((4, 4), dtype=np.float32)
+        dT[0, 3] = 100.0
+        spec.meshes[1].d_to_world_left = dT
+    elif param is not None:
+        raise ValueError(param)
+    return spec

@@ -33,7 +33,7 @@ def test_cabi_exports_every_declared_symbol(psdr):
     for name in declared:
         assert hasattr(L, name), "libpsdr_hip.so does not export %s" % name
     assert sorted(cabi.SYMBOLS) == declared
-    assert L.psdr_hip_abi_version() == 5
+    assert L.psdr_hip_abi_version() == 6
     # host-side sampler building block is bit-exact with the oracle / golden table
     import json
     with open(os.path.join(ROOT, "tests", "golden", "tea64.json")) as fh:
@@ -149,6 +149,12 @@ def test_xml_scene_loader(psdr, tmp_path):
         assert np.allclose(np.asarray(box._get("to_world", False)), [[1, 0, 0, 10], [0, 0.5, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])   # scale, then translate
         s._configure_host([0])
         assert s.num_meshes == 4                            # + the environment map's bounding cube
+    mf = psdr.Scene()
+    mf.load_string('<scene><bsdf type="microfacet" id="m"><rgb name="specular_reflectance" value="0.6, 0.5, 0.4"/><rgb name="diffuseReflectance" value="0.1"/>'
+                   '<float name="roughness" value="0.3"/></bsdf></scene>', False)
+    b = mf.param_map["BSDF[id=m]"]
+    assert np.allclose(np.asarray(b._get("specularReflectance", False)), [0.6, 0.5, 0.4]) and np.allclose(np.asarray(b._get("diffuseReflectance", False)), 0.1)
+    assert abs(float(np.asarray(b._get("roughness", False))[0]) - 0.3) < 1e-7
     with pytest.raises(RuntimeError, match="Unknown BSDF type"):
         psdr.Scene().load_string('<scene><bsdf type="roughconductor" id="a"/></scene>', False)
     with pytest.raises(RuntimeError, match="BSDF must have an id"):
