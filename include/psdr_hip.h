@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PSDR_HIP_ABI_VERSION 6
+#define PSDR_HIP_ABI_VERSION 7
 
 /* TriangleInfo SoA, reference include/psdr/types.h:162-175 (+ Scene::m_triangle_uv,
  * m_triangle_face_normals, scene.cpp:528-542).  Arrays of n_triangles rows. */
@@ -55,7 +55,7 @@ typedef struct psdr_mesh_rec {       /* what the kernels need of reference Mesh 
 } psdr_mesh_rec;
 
 typedef struct psdr_bsdf_rec {       /* Diffuse, reference src/bsdf/diffuse.cpp */
-    int32_t type;                    /* 0 = Diffuse, 1 = Microfacet */
+    int32_t type;                    /* 0 = Diffuse, 1 = Microfacet, 2 = RoughConductor */
     int32_t two_sided;
     float reflectance[3], d_reflectance[3];
     /* textured reflectance: Bitmap3fD with a resolution above 1x1 (bitmap.cpp:47-128, looked up at its.uv with flip_v);
@@ -66,6 +66,9 @@ typedef struct psdr_bsdf_rec {       /* Diffuse, reference src/bsdf/diffuse.cpp 
     /* type 1 = Microfacet (src/bsdf/microfacet.cpp, ggx.cpp): `reflectance` is its diffuse reflectance, plus */
     float specular[3], d_specular[3];
     float roughness, d_roughness;
+    /* type 2 = RoughConductor (src/bsdf/roughconductor.cpp): `specular` is its specular_reflectance, plus */
+    float alpha_u, alpha_v, d_alpha_u, d_alpha_v;
+    float eta[3], d_eta[3], k[3], d_k[3];
 } psdr_bsdf_rec;
 
 typedef struct psdr_emitter_rec {    /* AreaLight (src/emitter/area.cpp) or EnvironmentMap (src/emitter/envmap.cpp) */

@@ -37,7 +37,7 @@ typedef struct orc_mesh {            /* reference Mesh, include/psdr/shape/mesh.
 } orc_mesh;
 
 typedef struct orc_bsdf {            /* Diffuse, include/psdr/bsdf/diffuse.h */
-    int type;                        /* 0 = Diffuse, 1 = Microfacet */
+    int type;                        /* 0 = Diffuse, 1 = Microfacet, 2 = RoughConductor */
     float reflectance[3], d_reflectance[3];
     int two_sided;
     /* textured reflectance (Bitmap3fD with resolution > 1x1, bitmap.cpp:47-128): tex_data != NULL overrides `reflectance` */
@@ -47,6 +47,9 @@ typedef struct orc_bsdf {            /* Diffuse, include/psdr/bsdf/diffuse.h */
     /* type 1 = Microfacet (src/bsdf/microfacet.cpp): reflectance = diffuse reflectance, plus */
     float specular[3], d_specular[3];
     float roughness, d_roughness;
+    /* type 2 = RoughConductor (src/bsdf/roughconductor.cpp): specular = specular_reflectance, plus */
+    float alpha_u, alpha_v, d_alpha_u, d_alpha_v;
+    float eta[3], d_eta[3], k[3], d_k[3];
 } orc_bsdf;
 
 typedef struct orc_emitter {         /* AreaLight (include/psdr/emitter/area.h) or EnvironmentMap (emitter/envmap.h) */
@@ -170,6 +173,7 @@ void orc_microfacet_eval(const float params[14], int two_sided, const float wi[3
 float orc_microfacet_pdf(float roughness, int two_sided, const float wi[3], const float wo[3]);
 int orc_microfacet_sample(float roughness, int two_sided, const float wi[3], const float s3[3], float wo_out[3], float *pdf_out);
 float orc_ggx_eval(float alpha, const float m[3]);
+float orc_fresnel_conductor(float eta, float k, float cos_theta_i);      /* utils.h:166-182 */
 
 #ifdef __cplusplus
 }

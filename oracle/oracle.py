@@ -67,11 +67,19 @@ class BsdfSpec:
     name: str = ""
     texture: Optional[np.ndarray] = None      # [H, W, 3] reflectance texture (Bitmap3fD), overrides `reflectance`
     d_texture: Optional[np.ndarray] = None    # tangent of the texels
-    type: int = 0                             # 0 = DiffuseBSDF, 1 = MicrofacetBSDF(specular, diffuse = reflectance, roughness)
+    type: int = 0                             # 0 = DiffuseBSDF, 1 = MicrofacetBSDF(specular, diffuse = reflectance, roughness), 2 = RoughConductorBSDF
     specular: tuple = (0.04, 0.04, 0.04)
     d_specular: tuple = (0.0, 0.0, 0.0)
     roughness: float = 0.5
     d_roughness: float = 0.0
+    alpha_u: float = 0.1                      # type 2 = RoughConductorBSDF(alpha_u, alpha_v, eta, k, specular = specular_reflectance)
+    alpha_v: float = 0.1
+    d_alpha_u: float = 0.0
+    d_alpha_v: float = 0.0
+    eta: tuple = (0.0, 0.0, 0.0)
+    d_eta: tuple = (0.0, 0.0, 0.0)
+    k: tuple = (1.0, 1.0, 1.0)
+    d_k: tuple = (0.0, 0.0, 0.0)
 
 
 @dataclass
@@ -131,7 +139,9 @@ class _Mesh(C.Structure):
 class _Bsdf(C.Structure):
     _fields_ = [("type", C.c_int), ("reflectance", _F3), ("d_reflectance", _F3), ("two_sided", C.c_int),
                 ("tex_width", C.c_int), ("tex_height", C.c_int), ("tex_data", C.POINTER(C.c_float)), ("d_tex_data", C.POINTER(C.c_float)),
-                ("specular", _F3), ("d_specular", _F3), ("roughness", C.c_float), ("d_roughness", C.c_float)]
+                ("specular", _F3), ("d_specular", _F3), ("roughness", C.c_float), ("d_roughness", C.c_float),
+                ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("d_alpha_u", C.c_float), ("d_alpha_v", C.c_float),
+                ("eta", _F3), ("d_eta", _F3), ("k", _F3), ("d_k", _F3)]
 
 
 class _Emitter(C.Structure):
@@ -269,6 +279,9 @@ class OracleScene:
             bsdfs[i].d_specular = _F3(*getattr(b, "d_specular", (0.0, 0.0, 0.0)))
             bsdfs[i].roughness = float(getattr(b, "roughness", 0.5))
             bsdfs[i].d_roughness = float(getattr(b, "d_roughness", 0.0))
+            bsdfs[i].alpha_u, bsdfs[i].alpha_v = float(b.alpha_u), float(b.alpha_v)
+            bsdfs[i].d_alpha_u, bsdfs[i].d_alpha_v = float(b.d_alpha_u), float(b.d_alpha_v)
+            bsdfs[i].eta, bsdfs[i].d_eta, bsdfs[i].k, bsdfs[i].d_k = _F3(*b.eta), _F3(*b.d_eta), _F3(*b.k), _F3(*b.d_k)
             bsdfs[i].reflectance = _F3(*b.reflectance)
             bsdfs[i].d_reflectance = _F3(*b.d_reflectance)
             bsdfs[i].two_sided = int(b.two_sided)

@@ -69,6 +69,7 @@ void orc_microfacet_eval(const float params[14], int two_sided, const float wi[3
 float orc_microfacet_pdf(float roughness, int two_sided, const float wi[3], const float wo[3]) { return orc::kat_microfacet_pdf(roughness, two_sided, wi, wo); }
 int orc_microfacet_sample(float roughness, int two_sided, const float wi[3], const float s3[3], float wo_out[3], float *pdf_out) { return orc::kat_microfacet_sample(roughness, two_sided, wi, s3, wo_out, pdf_out); }
 float orc_ggx_eval(float alpha, const float m[3]) { return orc::kat_ggx_eval(alpha, m); }
+float orc_fresnel_conductor(float eta, float k, float c) { return orc::kat_fresnel_conductor(eta, k, c); }
 void orc_set_direct_mis(orc_scene *s, int mis) { s->sc->direct_mis = mis; }
 float orc_emitter_sampling_weight(const orc_scene *s, int e) { return s->sc->emitters[e].sampling_weight; }
 int orc_envmap_info(const orc_scene *s, float bounds[6], int reso[2], float *cell_sum) {

@@ -336,6 +336,10 @@ template <bool ad> static V3<Real<ad>> bsdf_eval(const Scene &sc, const Its<ad> 
         MicrofacetParams P{b.specular, b.reflectance, b.roughness, b.two_sided};
         return microfacet_eval<ad>(P, its.wi, wo, active);
     }
+    if (b.type == 2) {          // RoughConductor (roughconductor.cpp)
+        ConductorParams P{b.alpha_u, b.alpha_v, b.eta, b.k, b.specular, b.two_sided};
+        return conductor_eval<ad>(P, its.wi, wo, active);
+    }
     R wiz = its.wi.z;
     if (b.two_sided) { wo.z = mulsign(wo.z, detach(wiz)); wiz = abs_(wiz); }
     active = active && (detach(wiz) > 0.f && detach(wo.z) > 0.f);
@@ -349,6 +353,10 @@ template <bool ad> static float bsdf_pdf(const Scene &sc, const Its<ad> &its, co
         MicrofacetParams P{b.specular, b.reflectance, b.roughness, b.two_sided};
         return microfacet_pdf(P, detach(its.wi), detach(wo_), active);
     }
+    if (b.type == 2) {
+        ConductorParams P{b.alpha_u, b.alpha_v, b.eta, b.k, b.specular, b.two_sided};
+        return conductor_pdf(P, detach(its.wi), detach(wo_), active);
+    }
     float wiz = detach(its.wi.z), woz = detach(wo_.z);
     if (b.two_sided) { woz = mulsign(woz, wiz); wiz = fabs(wiz); }
     active = active && (wiz > 0.f && woz > 0.f);
@@ -361,6 +369,12 @@ template <bool ad> static BSDFSample bsdf_sample(const Scene &sc, const Its<ad> 
     if (b.type == 1) {
         MicrofacetParams P{b.specular, b.reflectance, b.roughness, b.two_sided};
         const MicrofacetSample m = microfacet_sample(P, detach(its.wi), s3, active);
+        BSDFSample r; r.wo = m.wo; r.pdf = m.pdf; r.valid = m.valid;
+        return r;
+    }
+    if (b.type == 2) {
+        ConductorParams P{b.alpha_u, b.alpha_v, b.eta, b.k, b.specular, b.two_sided};
+        const MicrofacetSample m = conductor_sample(P, detach(its.wi), s3, active);
         BSDFSample r; r.wo = m.wo; r.pdf = m.pdf; r.valid = m.valid;
         return r;
     }
@@ -578,7 +592,8 @@ int kat_microfacet_sample(float roughness, int two_sided, const float *wi, const
     wo_out[0] = m.wo.x; wo_out[1] = m.wo.y; wo_out[2] = m.wo.z; *pdf_out = m.pdf;
     return m.valid ? 1 : 0;
 }
-float kat_ggx_eval(float alpha, const float *m) { GGX<float> g{alpha}; return g.eval(V3f(m[0], m[1], m[2])); }
+float kat_ggx_eval(float alpha, const float *m) { GGX<float> g{alpha, alpha}; return g.eval(V3f(m[0], m[1], m[2])); }
+float kat_fresnel_conductor(float eta, float k, float c) { return fresnel_conductor<float>(eta, k, c); }
 void kat_cosine_hemisphere(float sx, float sy, float *o) { V3f v = square_to_cosine_hemisphere(sx, sy); o[0] = v.x; o[1] = v.y; o[2] = v.z; }
 void kat_uniform_triangle(float sx, float sy, float *o) { square_to_uniform_triangle(sx, sy, o[0], o[1]); }
 void kat_coordinate_system(const float *n, float *s, float *t) {

@@ -61,6 +61,7 @@ void kat_microfacet_eval(const float *params, int two_sided, const float *wi, co
 float kat_microfacet_pdf(float roughness, int two_sided, const float *wi, const float *wo);
 int kat_microfacet_sample(float roughness, int two_sided, const float *wi, const float *s3, float *wo_out, float *pdf_out);
 float kat_ggx_eval(float alpha, const float *m);
+float kat_fresnel_conductor(float eta, float k, float c);
 void kat_cosine_hemisphere(float sx, float sy, float *o);
 void kat_uniform_triangle(float sx, float sy, float *o);
 void kat_coordinate_system(const float *n, float *s, float *t);

@@ -30,17 +30,17 @@ inline Dual exp2_(const Dual &x) { const float v = exp2_cephes(x.v); return Dual
 struct MicrofacetParams { V3d specular, diffuse; Dual roughness; bool two_sided; };
 
 template <typename R> struct GGX {
-    R a;                                                           // alpha_u = alpha_v
+    R au, av;                                                      // alpha_u, alpha_v (Microfacet: both = roughness^2)
     // ggx.cpp:13-33
     R eval(const V3<R> &m) const {
-        const R alpha_uv = a * a;
+        const R alpha_uv = au * av;
         const R cos_theta = m.z;
-        const R r = rcp(R(Pi) * alpha_uv * sqr(sqr(m.x / a) + sqr(m.y / a) + sqr(m.z)));
+        const R r = rcp(R(Pi) * alpha_uv * sqr(sqr(m.x / au) + sqr(m.y / av) + sqr(m.z)));
         return (detach(r) * detach(cos_theta) > 1e-20f) ? r : R(0.f);
     }
     // ggx.cpp:84-97
     R smith_g1(const V3<R> &v, const V3<R> &m) const {
-        const R xy_alpha_2 = sqr(a * v.x) + sqr(a * v.y);
+        const R xy_alpha_2 = sqr(au * v.x) + sqr(av * v.y);
         const R tan_theta_alpha_2 = xy_alpha_2 / sqr(v.z);
         R result = R(2.f) / (R(1.f) + sqrt_(R(1.f) + tan_theta_alpha_2));
         if (detach(xy_alpha_2) == 0.f) result = R(1.f);
@@ -73,17 +73,17 @@ inline V2f ggx_sample_visible_11(float cos_theta_i, float sx, float sy) {
     return V2f(fma_(cos_theta_i, y, -(sin_theta_i * z)) * norm, x * norm);
 }
 // ggx.cpp:35-82 (everything detached)
-inline V3f ggx_sample(float a, const V3f &wi, float sx, float sy, float &pdf) {
-    const V3f wi_p = normalize(V3f(a * wi.x, a * wi.y, wi.z));
+inline V3f ggx_sample(float au, float av, const V3f &wi, float sx, float sy, float &pdf) {
+    const V3f wi_p = normalize(V3f(au * wi.x, av * wi.y, wi.z));
     const float sin_theta_2 = fma_(wi_p.x, wi_p.x, sqr(wi_p.y));                          // frame.h:81
     const float inv_sin_theta = 1.f / std::sqrt(sin_theta_2);
     const bool deg = std::fabs(sin_theta_2) <= 4.f * Epsilon;
     const float sin_phi = deg ? 0.f : std::min(std::max(wi_p.y * inv_sin_theta, -1.f), 1.f);
     const float cos_phi = deg ? 1.f : std::min(std::max(wi_p.x * inv_sin_theta, -1.f), 1.f);
     V2f slope = ggx_sample_visible_11(wi_p.z, sx, sy);
-    slope = V2f(fma_(cos_phi, slope.x, -(sin_phi * slope.y)) * a, fma_(sin_phi, slope.x, cos_phi * slope.y) * a);
+    slope = V2f(fma_(cos_phi, slope.x, -(sin_phi * slope.y)) * au, fma_(sin_phi, slope.x, cos_phi * slope.y) * av);
     const V3f m = normalize(V3f(-slope.x, -slope.y, 1.f));
-    GGX<float> g{a};
+    GGX<float> g{au, av};
     pdf = g.smith_g1(wi, m) * std::fabs(dot(wi, m)) * g.eval(m) / std::fabs(wi.z);
     return m;
 }
@@ -101,7 +101,7 @@ template <bool ad> V3<Real<ad>> microfacet_eval(const MicrofacetParams &P, V3<Re
     const V F0 = pick<ad>(P.specular);
     R roughness;
     if constexpr (ad) roughness = P.roughness; else roughness = P.roughness.v;
-    GGX<R> distr{sqr(roughness)};
+    GGX<R> distr{sqr(roughness), sqr(roughness)};
     const R ggx = distr.eval(H);
     const R coeff = cos_theta_vh * (R(-5.55473f) * cos_theta_vh - R(6.8316f));
     const V fresnel = F0 + (V(R(1.f)) - F0) * exp2_(coeff);
@@ -118,7 +118,7 @@ inline float microfacet_pdf(const MicrofacetParams &P, V3f wi, V3f wo, bool acti
     const V3f m = normalize(wo + wi);
     active = active && cos_theta_i > 0.f && cos_theta_o > 0.f && dot(wi, m) > 0.f && dot(wo, m) > 0.f;
     if (!active) return 0.f;
-    GGX<float> distr{sqr(P.roughness.v)};
+    GGX<float> distr{sqr(P.roughness.v), sqr(P.roughness.v)};
     return distr.eval(m) * distr.smith_g1(wi, m) / (4.f * cos_theta_i);
 }
 // microfacet.cpp:75-98: uses sample.x, sample.y (not the tail); the sampled direction stays in the upper hemisphere
@@ -128,11 +128,63 @@ inline MicrofacetSample microfacet_sample(const MicrofacetParams &P, V3f wi, con
     MicrofacetSample bs;
     const float cos_theta_i = wi.z;
     float m_pdf;
-    const V3f m = ggx_sample(sqr(P.roughness.v), wi, s3[0], s3[1], m_pdf);
+    const V3f m = ggx_sample(sqr(P.roughness.v), sqr(P.roughness.v), wi, s3[0], s3[1], m_pdf);
     const float k = 2.f * dot(wi, m);
     bs.wo = V3f(fma_(m.x, k, -wi.x), fma_(m.y, k, -wi.y), fma_(m.z, k, -wi.z));
     bs.pdf = m_pdf / (4.f * dot(bs.wo, m));
     bs.valid = active && (cos_theta_i > 0.f) && (bs.pdf != 0.f) && (bs.wo.z > 0.f);
+    return bs;
+}
+
+// ---------------------------------------------------------------- RoughConductor (reference src/bsdf/roughconductor.cpp:30-118)
+struct ConductorParams { Dual alpha_u, alpha_v; V3d eta, k, specular; bool two_sided; };
+
+// conductor Fresnel, reference include/psdr/utils.h:166-182 (per colour channel)
+template <typename R> R fresnel_conductor(const R &eta_r, const R &eta_i, const R &cos_theta_i) {
+    const R cos_theta_i_2 = sqr(cos_theta_i), sin_theta_i_2 = R(1.f) - cos_theta_i_2, sin_theta_i_4 = sqr(sin_theta_i_2);
+    const R temp_1 = sqr(eta_r) - sqr(eta_i) - sin_theta_i_2;
+    const R a_2_pb_2 = safe_sqrt(sqr(temp_1) + R(4.f) * sqr(eta_i * eta_r));
+    const R a = safe_sqrt(R(.5f) * (a_2_pb_2 + temp_1));
+    const R term_1 = a_2_pb_2 + cos_theta_i_2, term_2 = R(2.f) * cos_theta_i * a;
+    const R r_s = (term_1 - term_2) / (term_1 + term_2);
+    const R term_3 = a_2_pb_2 * cos_theta_i_2 + sin_theta_i_4, term_4 = term_2 * sin_theta_i_2;
+    const R r_p = r_s * (term_3 - term_4) / (term_3 + term_4);
+    return R(.5f) * (r_s + r_p);
+}
+
+template <bool ad> V3<Real<ad>> conductor_eval(const ConductorParams &P, V3<Real<ad>> wi, V3<Real<ad>> wo, bool active) {
+    using R = Real<ad>; using V = V3<R>;
+    if (P.two_sided) { wo.z = mulsign(wo.z, detach(wi.z)); wi.z = abs_(wi.z); }
+    active = active && (detach(wi.z) > 0.f && detach(wo.z) > 0.f);
+    if (!active) return V(R(0.f));
+    GGX<R> distr{pick<ad>(P.alpha_u), pick<ad>(P.alpha_v)};
+    const V H = normalize(wo + wi);
+    const R D = distr.eval(H);
+    if (detach(D) == 0.f) return V(R(0.f));
+    const R G = distr.smith_g1(wi, H) * distr.smith_g1(wo, H);
+    const R result = D * G / (R(4.f) * wi.z);
+    const V eta = pick<ad>(P.eta), k = pick<ad>(P.k);
+    const R c = dot(wi, H);
+    const V F(fresnel_conductor<R>(eta.x, k.x, c), fresnel_conductor<R>(eta.y, k.y, c), fresnel_conductor<R>(eta.z, k.z, c));
+    return F * result * pick<ad>(P.specular);
+}
+inline float conductor_pdf(const ConductorParams &P, V3f wi, V3f wo, bool active) {
+    if (P.two_sided) { wo.z = mulsign(wo.z, wi.z); wi.z = std::fabs(wi.z); }
+    const V3f m = normalize(wo + wi);
+    active = active && wi.z > 0.f && wo.z > 0.f && dot(wi, m) > 0.f && dot(wo, m) > 0.f;
+    if (!active) return 0.f;
+    GGX<float> distr{P.alpha_u.v, P.alpha_v.v};
+    return distr.eval(m) * distr.smith_g1(wi, m) / (4.f * wi.z);
+}
+inline MicrofacetSample conductor_sample(const ConductorParams &P, V3f wi, const float s3[3], bool active) {
+    if (P.two_sided) wi.z = std::fabs(wi.z);
+    MicrofacetSample bs;
+    float m_pdf;
+    const V3f m = ggx_sample(P.alpha_u.v, P.alpha_v.v, wi, s3[0], s3[1], m_pdf);
+    const float kk = 2.f * dot(wi, m);
+    bs.wo = V3f(fma_(m.x, kk, -wi.x), fma_(m.y, kk, -wi.y), fma_(m.z, kk, -wi.z));
+    bs.pdf = m_pdf / (4.f * dot(bs.wo, m));
+    bs.valid = active && (wi.z > 0.f) && (bs.pdf != 0.f) && (bs.wo.z > 0.f);
     return bs;
 }
 

@@ -80,7 +80,8 @@ struct MeshC {
     Distrb face_distrb;
 };
 struct BsdfC { int type; V3d reflectance; bool two_sided; int tex_w = 0, tex_h = 0; std::vector<float> tex, d_tex;
-               V3d specular; Dual roughness; };   // type 1 = Microfacet: reflectance is its diffuse reflectance   // tex: Bitmap3fD texels when textured
+               V3d specular; Dual roughness;       // type 1 = Microfacet: reflectance is its diffuse reflectance
+               Dual alpha_u, alpha_v; V3d eta, k; };   // type 2 = RoughConductor (specular = specular_reflectance)   // tex: Bitmap3fD texels when textured
 // type 0 = AreaLight (area.h), 1 = EnvironmentMap (envmap.h); an envmap's mesh is the bounding cube scene.cpp:442-480 adds
 struct EmitterC { V3d radiance; int mesh = -1; float sampling_weight = 1.f; int type = 0; };
 

@@ -36,6 +36,7 @@ DiffuseBSDF = _core.DiffuseBSDF
 Emitter = _core.Emitter
 AreaLight = _core.AreaLight
 MicrofacetBSDF = _core.MicrofacetBSDF
+RoughConductorBSDF = _core.RoughConductorBSDF
 EnvironmentMap = _core.EnvironmentMap
 Sensor = _core.Sensor
 PerspectiveCamera = _core.PerspectiveCamera
@@ -172,6 +173,10 @@ DiffuseBSDF.reflectance = _make_param_property("reflectance", _refl_shape)
 MicrofacetBSDF.specularReflectance = _make_param_property("specularReflectance", _v3)
 MicrofacetBSDF.diffuseReflectance = _make_param_property("diffuseReflectance", _v3)
 MicrofacetBSDF.roughness = _make_param_property("roughness", lambda self, value: (1,))
+for _n in ("alpha_u", "alpha_v"):
+    setattr(RoughConductorBSDF, _n, _make_param_property(_n, lambda self, value: (1,)))
+for _n in ("eta", "k", "specular_reflectance"):
+    setattr(RoughConductorBSDF, _n, _make_param_property(_n, _v3))
 AreaLight.radiance = _make_param_property("radiance", _v3)
 
 
@@ -230,6 +235,28 @@ def _microfacet_init(self, specular=None, diffuse=None, roughness=None):
 
 
 MicrofacetBSDF.__init__ = _microfacet_init
+_RoughConductorBSDF_init = RoughConductorBSDF.__init__
+
+
+def _roughconductor_init(self, *args):
+    """RoughConductorBSDF(), (alpha, eta, k[, specular_reflectance]) or (alpha_u, alpha_v, eta, k[, specular_reflectance])
+    (reference roughconductor.h:10-26; constants instead of bitmaps)"""
+    _RoughConductorBSDF_init(self)
+    if not args:
+        return
+    scal = lambda x: float(_np.ravel(_split(x, (-1,))[0])[0])
+    first_two_scalar = len(args) >= 4 and _np.size(_split(args[1], (-1,))[0]) == 1
+    if first_two_scalar:
+        au, av, rest = args[0], args[1], args[2:]
+    else:
+        au, av, rest = args[0], args[0], args[1:]
+    self.alpha_u, self.alpha_v = [scal(au)], [scal(av)]
+    self.eta, self.k = rest[0], rest[1]
+    if len(rest) > 2:
+        self.specular_reflectance = rest[2]
+
+
+RoughConductorBSDF.__init__ = _roughconductor_init
 _AreaLight_init = AreaLight.__init__
 
 

@@ -491,8 +491,8 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     {
         bool any = false;
         for (int i = 0; i < s->n_bsdfs; ++i) {
-            if (s->bsdfs[i].type != 0 && s->bsdfs[i].type != 1) return fail("Unknown BSDF type!");
-            any |= s->bsdfs[i].type == 1;
+            if (s->bsdfs[i].type < 0 || s->bsdfs[i].type > 2) return fail("Unknown BSDF type!");
+            any |= s->bsdfs[i].type != 0;
         }
         if (any) {
             std::vector<MatDev> md((size_t) s->n_bsdfs);
@@ -500,6 +500,8 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
                 const psdr_bsdf_rec &b = s->bsdfs[i];
                 for (int k = 0; k < 3; ++k) { md[i].specular[k] = b.specular[k]; md[i].d_specular[k] = b.d_specular[k]; }
                 md[i].roughness = b.roughness; md[i].d_roughness = b.d_roughness;
+                md[i].alpha_u = b.alpha_u; md[i].alpha_v = b.alpha_v; md[i].d_alpha_u = b.d_alpha_u; md[i].d_alpha_v = b.d_alpha_v;
+                for (int k = 0; k < 3; ++k) { md[i].eta[k] = b.eta[k]; md[i].d_eta[k] = b.d_eta[k]; md[i].k[k] = b.k[k]; md[i].d_k[k] = b.d_k[k]; }
             }
             sc->bufs.emplace_back(new DevBuf());
             if (sc->bufs.back()->upload(md.data(), md.size() * sizeof(MatDev))) return 1;
@@ -587,8 +589,8 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     }
     for (int i = 0; i < s->n_bsdfs; ++i) {
         const psdr_bsdf_rec &b = s->bsdfs[i];
-        if (b.type != 0 && b.type != 1) return fail("Unknown BSDF type!");
-        put4(blob, T.bsdf_off + 2 * (size_t) i, b.reflectance[0], b.reflectance[1], b.reflectance[2], ibits((b.two_sided ? 1 : 0) | (b.tex_data ? 2 : 0) | (b.type == 1 ? 4 : 0)));
+        if (b.type < 0 || b.type > 2) return fail("Unknown BSDF type!");
+        put4(blob, T.bsdf_off + 2 * (size_t) i, b.reflectance[0], b.reflectance[1], b.reflectance[2], ibits((b.two_sided ? 1 : 0) | (b.tex_data ? 2 : 0) | (b.type == 1 ? 4 : 0) | (b.type == 2 ? 8 : 0)));
         put4(blob, T.bsdf_off + 2 * (size_t) i + 1, b.d_reflectance[0], b.d_reflectance[1], b.d_reflectance[2], 0.f);
     }
     for (int i = 0; i < s->n_emitters; ++i) {

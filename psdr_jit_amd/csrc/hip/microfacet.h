@@ -23,14 +23,14 @@ PSDR_DEV float exp2_(float x) { return exp2_cephes(x); }
 PSDR_DEV Dual exp2_(const Dual &x) { const float v = exp2_cephes(x.v); return Dual(v, v * 0.6931471805599453f * x.d); }
 
 template <typename R> struct GGX {
-    R a;
+    R au, av;                                                                      // alpha_u, alpha_v
     PSDR_DEV R eval(const Vec3<R> &m) const {                                     // ggx.cpp:13-33
-        const R alpha_uv = a * a;
-        const R r = rcp_(R(kPi) * alpha_uv * sqr(sqr(m.x / a) + sqr(m.y / a) + sqr(m.z)));
+        const R alpha_uv = au * av;
+        const R r = rcp_(R(kPi) * alpha_uv * sqr(sqr(m.x / au) + sqr(m.y / av) + sqr(m.z)));
         return (detach(r) * detach(m.z) > 1e-20f) ? r : R(0.f);
     }
     PSDR_DEV R smith_g1(const Vec3<R> &v, const Vec3<R> &m) const {                // ggx.cpp:84-97
-        const R xy_alpha_2 = sqr(a * v.x) + sqr(a * v.y);
+        const R xy_alpha_2 = sqr(au * v.x) + sqr(av * v.y);
         const R tan_theta_alpha_2 = xy_alpha_2 / sqr(v.z);
         R result = R(2.f) / (R(1.f) + sqrt_(R(1.f) + tan_theta_alpha_2));
         if (detach(xy_alpha_2) == 0.f) result = R(1.f);
@@ -63,8 +63,8 @@ PSDR_DEV void ggx_sample_visible_11(float cos_theta_i, float sx, float sy, float
     slope_y = px * norm;
 }
 // ggx.cpp:35-82 (detached)
-PSDR_DEV Vec3f ggx_sample(float a, const Vec3f &wi, float sx, float sy, float &pdf) {
-    const Vec3f wi_p = normalize(Vec3f(a * wi.x, a * wi.y, wi.z));
+PSDR_DEV Vec3f ggx_sample(float au, float av, const Vec3f &wi, float sx, float sy, float &pdf) {
+    const Vec3f wi_p = normalize(Vec3f(au * wi.x, av * wi.y, wi.z));
     const float sin_theta_2 = fma_(wi_p.x, wi_p.x, sqr(wi_p.y));
     const float inv_sin_theta = 1.f / sqrtf(sin_theta_2);
     const bool deg = fabsf(sin_theta_2) <= 4.f * kEpsilon;
@@ -72,9 +72,9 @@ PSDR_DEV Vec3f ggx_sample(float a, const Vec3f &wi, float sx, float sy, float &p
     const float cos_phi = deg ? 1.f : fminf(fmaxf(wi_p.x * inv_sin_theta, -1.f), 1.f);
     float slx, sly;
     ggx_sample_visible_11(wi_p.z, sx, sy, slx, sly);
-    const float s0 = fma_(cos_phi, slx, -(sin_phi * sly)) * a, s1 = fma_(sin_phi, slx, cos_phi * sly) * a;
+    const float s0 = fma_(cos_phi, slx, -(sin_phi * sly)) * au, s1 = fma_(sin_phi, slx, cos_phi * sly) * av;
     const Vec3f m = normalize(Vec3f(-s0, -s1, 1.f));
-    GGX<float> g{a};
+    GGX<float> g{au, av};
     pdf = g.smith_g1(wi, m) * fabsf(dot(wi, m)) * g.eval(m) / fabsf(wi.z);
     return m;
 }
@@ -89,7 +89,7 @@ PSDR_DEV Vec3<R> microfacet_eval(const Vec3<R> &spec, const Vec3<R> &diff, const
     const V diffuse = diff * R(kInvPi);
     const V H = normalize(wi + wo);
     const R cos_theta_vh = dot(H, wi);
-    GGX<R> distr{sqr(roughness)};
+    GGX<R> distr{sqr(roughness), sqr(roughness)};
     const R ggx = distr.eval(H);
     const R coeff = cos_theta_vh * (R(-5.55473f) * cos_theta_vh - R(6.8316f));
     const V fresnel = spec + (V(R(1.f)) - spec) * exp2_(coeff);
@@ -100,22 +100,55 @@ PSDR_DEV Vec3<R> microfacet_eval(const Vec3<R> &spec, const Vec3<R> &diff, const
     return (diffuse + specular) * cos_theta_nl;
 }
 // microfacet.cpp:108-131
-PSDR_DEV float microfacet_pdf(float roughness, bool two_sided, Vec3f wi, Vec3f wo, bool active) {
+// (alpha_u, alpha_v) = (roughness^2, roughness^2) for Microfacet; RoughConductor::__pdf (roughconductor.cpp:70-90) is the same
+PSDR_DEV float ggx_pdf(float au, float av, bool two_sided, Vec3f wi, Vec3f wo, bool active) {
     if (two_sided) { wo.z = mulsign(wo.z, wi.z); wi.z = fabsf(wi.z); }
     const Vec3f m = normalize(wo + wi);
     if (!(active && wi.z > 0.f && wo.z > 0.f && dot(wi, m) > 0.f && dot(wo, m) > 0.f)) return 0.f;
-    GGX<float> distr{sqr(roughness)};
+    GGX<float> distr{au, av};
     return distr.eval(m) * distr.smith_g1(wi, m) / (4.f * wi.z);
 }
 // microfacet.cpp:75-98: the first two of the three sample numbers; the direction stays in the upper hemisphere
-PSDR_DEV void microfacet_sample(float roughness, bool two_sided, Vec3f wi, float s0, float s1, bool active, Vec3f &wo, float &pdf, bool &valid) {
+// (also RoughConductor::__sample, roughconductor.cpp:92-116)
+PSDR_DEV void ggx_reflect_sample(float au, float av, bool two_sided, Vec3f wi, float s0, float s1, bool active, Vec3f &wo, float &pdf, bool &valid) {
     if (two_sided) wi.z = fabsf(wi.z);
     float m_pdf;
-    const Vec3f m = ggx_sample(sqr(roughness), wi, s0, s1, m_pdf);
+    const Vec3f m = ggx_sample(au, av, wi, s0, s1, m_pdf);
     const float k = 2.f * dot(wi, m);
     wo = Vec3f(fma_(m.x, k, -wi.x), fma_(m.y, k, -wi.y), fma_(m.z, k, -wi.z));
     pdf = m_pdf / (4.f * dot(wo, m));
     valid = active && (wi.z > 0.f) && (pdf != 0.f) && (wo.z > 0.f);
+}
+
+// conductor Fresnel, reference include/psdr/utils.h:166-182 (per colour channel)
+template <typename R> PSDR_DEV R fresnel_conductor(const R &eta_r, const R &eta_i, const R &cos_theta_i) {
+    const R cos_theta_i_2 = sqr(cos_theta_i), sin_theta_i_2 = R(1.f) - cos_theta_i_2, sin_theta_i_4 = sqr(sin_theta_i_2);
+    const R temp_1 = sqr(eta_r) - sqr(eta_i) - sin_theta_i_2;
+    const R a_2_pb_2 = safe_sqrt(sqr(temp_1) + R(4.f) * sqr(eta_i * eta_r));
+    const R a = safe_sqrt(R(.5f) * (a_2_pb_2 + temp_1));
+    const R term_1 = a_2_pb_2 + cos_theta_i_2, term_2 = R(2.f) * cos_theta_i * a;
+    const R r_s = (term_1 - term_2) / (term_1 + term_2);
+    const R term_3 = a_2_pb_2 * cos_theta_i_2 + sin_theta_i_4, term_4 = term_2 * sin_theta_i_2;
+    const R r_p = r_s * (term_3 - term_4) / (term_3 + term_4);
+    return R(.5f) * (r_s + r_p);
+}
+
+// RoughConductor::__eval, reference src/bsdf/roughconductor.cpp:30-68
+template <typename R>
+PSDR_DEV Vec3<R> conductor_eval(const R &au, const R &av, const Vec3<R> &eta, const Vec3<R> &k, const Vec3<R> &spec, bool two_sided,
+                                Vec3<R> wi, Vec3<R> wo, bool active) {
+    using V = Vec3<R>;
+    if (two_sided) { wo.z = mulsign(wo.z, detach(wi.z)); wi.z = abs_(wi.z); }
+    if (!(active && detach(wi.z) > 0.f && detach(wo.z) > 0.f)) return V(R(0.f));
+    GGX<R> distr{au, av};
+    const V H = normalize(wo + wi);
+    const R D = distr.eval(H);
+    if (detach(D) == 0.f) return V(R(0.f));
+    const R G = distr.smith_g1(wi, H) * distr.smith_g1(wo, H);
+    const R result = D * G / (R(4.f) * wi.z);
+    const R c = dot(wi, H);
+    const V F(fresnel_conductor<R>(eta.x, k.x, c), fresnel_conductor<R>(eta.y, k.y, c), fresnel_conductor<R>(eta.z, k.z, c));
+    return F * result * spec;
 }
 
 } // namespace psdr

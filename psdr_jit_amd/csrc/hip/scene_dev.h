@@ -32,7 +32,10 @@ struct EnvDev {
 struct TexDev { const float *data, *d_data; int w, h; };
 
 // Microfacet parameters beyond the diffuse reflectance (global memory table, one entry per BSDF; microfacet.h)
-struct MatDev { float specular[3], d_specular[3], roughness, d_roughness; };
+struct MatDev {
+    float specular[3], d_specular[3], roughness, d_roughness;                  // Microfacet; RoughConductor: specular = specular_reflectance
+    float alpha_u, alpha_v, d_alpha_u, d_alpha_v, eta[3], d_eta[3], k[3], d_k[3];   // RoughConductor
+};
 
 struct SceneTables {
     // float4-word offsets into the blob

@@ -363,6 +363,21 @@ template <bool AD, bool LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S
                                               (__float_as_int(a.w) & 1) != 0, its.wi, wo, active);
             }
         }
+        if (__float_as_int(a.w) & 8) {         // RoughConductor (roughconductor.cpp)
+            const MatDev md = S.T->mat[mesh_bsdf(S, its.mesh)];
+            const bool two = (__float_as_int(a.w) & 1) != 0;
+            if constexpr (AD) {
+                const float t = S.mode == 0 ? 1.f : 0.f;       // (its parameters have no reverse-mode adjoint yet)
+                return conductor_eval<Dual>(Dual(md.alpha_u, t * md.d_alpha_u), Dual(md.alpha_v, t * md.d_alpha_v),
+                                            Vec3d(Dual(md.eta[0], t * md.d_eta[0]), Dual(md.eta[1], t * md.d_eta[1]), Dual(md.eta[2], t * md.d_eta[2])),
+                                            Vec3d(Dual(md.k[0], t * md.d_k[0]), Dual(md.k[1], t * md.d_k[1]), Dual(md.k[2], t * md.d_k[2])),
+                                            Vec3d(Dual(md.specular[0], t * md.d_specular[0]), Dual(md.specular[1], t * md.d_specular[1]), Dual(md.specular[2], t * md.d_specular[2])),
+                                            two, its.wi, wo, active);
+            } else {
+                return conductor_eval<float>(md.alpha_u, md.alpha_v, Vec3f(md.eta[0], md.eta[1], md.eta[2]), Vec3f(md.k[0], md.k[1], md.k[2]),
+                                             Vec3f(md.specular[0], md.specular[1], md.specular[2]), two, its.wi, wo, active);
+            }
+        }
     }
     R wiz = its.wi.z;
     if (__float_as_int(a.w) & 1) { wo.z = mulsign(wo.z, detach(wiz)); wiz = abs_(wiz); }
@@ -394,8 +409,11 @@ template <bool AD, bool LDS> PSDR_DEV float bsdf_pdf(const SceneView<LDS> &S, co
     if (mesh_bsdf(S, its.mesh) < 0) return 0.f;
     const float4 a = S.ld(S.T->bsdf_off + 2 * mesh_bsdf(S, its.mesh));
     if constexpr (!LDS) {
-        if (__float_as_int(a.w) & 4)
-            return microfacet_pdf(S.T->mat[mesh_bsdf(S, its.mesh)].roughness, (__float_as_int(a.w) & 1) != 0, detach(its.wi), detach(wo), active);
+        if (__float_as_int(a.w) & 12) {
+            const MatDev md = S.T->mat[mesh_bsdf(S, its.mesh)];
+            const bool mf = (__float_as_int(a.w) & 4) != 0;
+            return ggx_pdf(mf ? sqr(md.roughness) : md.alpha_u, mf ? sqr(md.roughness) : md.alpha_v, (__float_as_int(a.w) & 1) != 0, detach(its.wi), detach(wo), active);
+        }
     }
     float wiz = detach(its.wi.z), woz = detach(wo.z);
     if (__float_as_int(a.w) & 1) { woz = mulsign(woz, wiz); wiz = fabsf(wiz); }
@@ -441,9 +459,12 @@ template <bool AD, bool LDS> PSDR_DEV BSDFSample bsdf_sample(const SceneView<LDS
     if (mesh_bsdf(S, its.mesh) < 0) { BSDFSample z; z.wo = Vec3f(0.f, 0.f, 0.f); z.pdf = 0.f; z.valid = false; return z; }
     const float4 a = S.ld(S.T->bsdf_off + 2 * mesh_bsdf(S, its.mesh));
     if constexpr (!LDS) {
-        if (__float_as_int(a.w) & 4) {         // Microfacet::sample uses the first two numbers (microfacet.cpp:88)
+        if (__float_as_int(a.w) & 12) {        // Microfacet / RoughConductor ::sample use the first two numbers (microfacet.cpp:88)
             BSDFSample m;
-            microfacet_sample(S.T->mat[mesh_bsdf(S, its.mesh)].roughness, (__float_as_int(a.w) & 1) != 0, detach(its.wi), s0, s1, active, m.wo, m.pdf, m.valid);
+            const MatDev md = S.T->mat[mesh_bsdf(S, its.mesh)];
+            const bool mf = (__float_as_int(a.w) & 4) != 0;
+            ggx_reflect_sample(mf ? sqr(md.roughness) : md.alpha_u, mf ? sqr(md.roughness) : md.alpha_v, (__float_as_int(a.w) & 1) != 0, detach(its.wi), s0, s1, active,
+                               m.wo, m.pdf, m.valid);
             return m;
         }
     }

@@ -102,6 +102,23 @@ PYBIND11_MODULE(_psdr_core, m) {
             else if (name == "specularReflectance") { b.specular = to_a3(v); b.d_specular = to_a3(t); }
             else { b.diffuse = to_a3(v); b.d_diffuse = to_a3(t); } });
 
+    py::class_<RoughConductor, BSDF>(m, "RoughConductorBSDF", py::dynamic_attr())
+        .def(py::init<>())
+        .def("_get", [](const RoughConductor &b, const std::string &name, bool tangent) {
+            if (name == "alpha_u" || name == "alpha_v") {
+                farr a(1);
+                a.mutable_data()[0] = name == "alpha_u" ? (tangent ? b.d_alpha_u : b.alpha_u) : (tangent ? b.d_alpha_v : b.alpha_v);
+                return a;
+            }
+            const auto &r = name == "eta" ? (tangent ? b.d_eta : b.eta) : (name == "k" ? (tangent ? b.d_k : b.k) : (tangent ? b.d_specular : b.specular));
+            farr a(3); std::memcpy(a.mutable_data(), r.data(), 12); return a; })
+        .def("_set", [](RoughConductor &b, const std::string &name, const farr &v, const farr &t) {
+            if (name == "alpha_u") { b.alpha_u = v.data()[0]; b.d_alpha_u = t.size() ? t.data()[0] : 0.f; }
+            else if (name == "alpha_v") { b.alpha_v = v.data()[0]; b.d_alpha_v = t.size() ? t.data()[0] : 0.f; }
+            else if (name == "eta") { b.eta = to_a3(v); b.d_eta = to_a3(t); }
+            else if (name == "k") { b.k = to_a3(v); b.d_k = to_a3(t); }
+            else { b.specular = to_a3(v); b.d_specular = to_a3(t); } });
+
     py::class_<Emitter, Object>(m, "Emitter", py::dynamic_attr());
     py::class_<AreaLight, Emitter>(m, "AreaLight", py::dynamic_attr())
         .def(py::init([](const farr &r) { return new AreaLight(to_a3(r)); }))

@@ -421,10 +421,11 @@ void Scene::add_Sensor(const Sensor *sensor) {       // scene.cpp:107-126 (the s
 void Scene::add_BSDF(const BSDF *bsdf, const std::string &bsdf_id, bool twoSide) {      // scene.cpp:148-247
     const Diffuse *d = dynamic_cast<const Diffuse *>(bsdf);
     const Microfacet *mf = dynamic_cast<const Microfacet *>(bsdf);
-    PSDR_ASSERT_MSG(d != nullptr || mf != nullptr, "Unknown BSDF type!");
-    if (m_opts.log_level > 0) std::cout << "add_BSDF: " << (d ? "Diffuse " : "Microfacet ") << bsdf_id << std::endl;
+    const RoughConductor *rc = dynamic_cast<const RoughConductor *>(bsdf);
+    PSDR_ASSERT_MSG(d != nullptr || mf != nullptr || rc != nullptr, "Unknown BSDF type!");
+    if (m_opts.log_level > 0) std::cout << "add_BSDF: " << (d ? "Diffuse " : (mf ? "Microfacet " : "RoughConductor ")) << bsdf_id << std::endl;
     PSDR_ASSERT_MSG(m_param_map.find("BSDF[id=" + bsdf_id + "]") == m_param_map.end(), std::string("Duplicate BSDF id: ") + bsdf_id);
-    BSDF *c = d ? static_cast<BSDF *>(new Diffuse(*d)) : static_cast<BSDF *>(new Microfacet(*mf));
+    BSDF *c = d ? static_cast<BSDF *>(new Diffuse(*d)) : (mf ? static_cast<BSDF *>(new Microfacet(*mf)) : static_cast<BSDF *>(new RoughConductor(*rc)));
     c->m_twoSide = twoSide; c->m_id = bsdf_id;
     m_bsdfs.push_back(c);
     rebuild_param_map();
@@ -636,6 +637,17 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
                 r.specular[k] = mf->specular[k]; r.d_specular[k] = mf->d_specular[k];
             }
             r.roughness = mf->roughness; r.d_roughness = mf->d_roughness;
+            S.bsdfs.push_back(r);
+            continue;
+        }
+        if (const RoughConductor *rc = dynamic_cast<const RoughConductor *>(b)) {
+            psdr_bsdf_rec r{};
+            r.type = 2; r.two_sided = rc->m_twoSide ? 1 : 0;
+            r.alpha_u = rc->alpha_u; r.alpha_v = rc->alpha_v; r.d_alpha_u = rc->d_alpha_u; r.d_alpha_v = rc->d_alpha_v;
+            for (int k = 0; k < 3; ++k) {
+                r.eta[k] = rc->eta[k]; r.d_eta[k] = rc->d_eta[k]; r.k[k] = rc->k[k]; r.d_k[k] = rc->d_k[k];
+                r.specular[k] = rc->specular[k]; r.d_specular[k] = rc->d_specular[k];
+            }
             S.bsdfs.push_back(r);
             continue;
         }

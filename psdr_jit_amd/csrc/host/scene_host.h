@@ -83,6 +83,16 @@ struct Microfacet : BSDF {
     float roughness = 0.8f, d_roughness = 0.f;
 };
 
+// RoughConductor, reference include/psdr/bsdf/roughconductor.h (constant parameters)
+struct RoughConductor : BSDF {
+    RoughConductor() {}
+    std::string type_name() const override { return "RoughConductor"; }
+    std::string to_string() const override { return std::string("RoughConductor[id=") + m_id + "]"; }
+    bool anisotropic() const override { return alpha_u != alpha_v; }
+    float alpha_u = 0.1f, alpha_v = 0.1f, d_alpha_u = 0.f, d_alpha_v = 0.f;
+    std::array<float, 3> eta{0, 0, 0}, k{1, 1, 1}, specular{1, 1, 1}, d_eta{0, 0, 0}, d_k{0, 0, 0}, d_specular{0, 0, 0};
+};
+
 struct Mesh;
 struct Emitter : Object { float m_sampling_weight = 1.f; bool m_ready = false; };
 struct AreaLight : Emitter {

@@ -172,7 +172,12 @@ def load_scene(root, scene, psdr, base_dir=None):
             if any(n.tag == "texture" for n in nodes):
                 raise _Err("MicrofacetBSDF: bitmap parameters are not built, only constants")
             b = psdr.MicrofacetBSDF(_load_rgb(nodes[0]), _load_rgb(nodes[1]), float(nodes[2].get("value")))
-        elif btype in ("roughconductor", "roughdielectric", "normalmap"):
+        elif btype == "roughconductor":
+            nodes = [_child_by_name(node, {"alpha"}), _child_by_name(node, {"eta"}), _child_by_name(node, {"k"})]
+            if any(n.tag == "texture" for n in nodes):
+                raise _Err("RoughConductorBSDF: bitmap parameters are not built, only constants")
+            b = psdr.RoughConductorBSDF(float(nodes[0].get("value")), _load_rgb(nodes[1]), _load_rgb(nodes[2]))
+        elif btype in ("roughdielectric", "normalmap"):
             raise _Err("Unknown BSDF type! (%s: the GGX BSDF family is not built)" % btype)
         else:
             raise _Err("Unsupported BSDF: " + str(btype))

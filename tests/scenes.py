@@ -312,3 +312,27 @@ def microfacet_cbox_scene(width=48, height=48, spp=8, sppe=0, sppse=0, param="ro
     elif param is not None:
         raise ValueError(param)
     return spec
+
+
+def conductor_cbox_scene(width=48, height=48, spp=8, sppe=0, sppse=0, param="alpha"):
+    """The README Cornell box with a gold-like anisotropic RoughConductor small box and an isotropic copper-like tall box
+    (reference src/bsdf/roughconductor.cpp).  param: 'alpha' | 'eta' | 'k' | 'box_x' | None (on the small box)"""
+    spec = cbox_scene(width, height, spp, sppe, sppse, param=None)
+    spec.bsdfs.append(BsdfSpec(name="gold", type=2, alpha_u=0.15, alpha_v=0.35, eta=(0.14, 0.37, 1.44), k=(3.98, 2.38, 1.60), specular=(1.0, 0.9, 0.8)))
+    spec.bsdfs.append(BsdfSpec(name="copper", type=2, alpha_u=0.3, alpha_v=0.3, eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), specular=(1.0, 1.0, 1.0), two_sided=True))
+    spec.meshes[1].bsdf = 5
+    spec.meshes[2].bsdf = 6
+    g = spec.bsdfs[5]
+    if param == "alpha":
+        g.d_alpha_u, g.d_alpha_v = 1.0, 0.5
+    elif param == "eta":
+        g.d_eta = (1.0, 1.0, 1.0)
+    elif param == "k":
+        g.d_k = (1.0, 0.5, 0.25); g.d_specular = (0.0, 1.0, 0.0)
+    elif param == "box_x":
+        dT = np.zeros((4, 4), dtype=np.float32)
+        dT[0, 3] = 100.0
+        spec.meshes[1].d_to_world_left = dT
+    elif param is not None:
+        raise ValueError(param)
+    return spec

@@ -255,3 +255,20 @@ def test_microfacet_api_and_reverse_mode(psdr, orc):
     assert abs(float(P.grad) - float((d_P * w).sum())) < 2e-3 * max(1.0, abs(float((d_P * w).sum())))
     lhs = float((diff.grad * torch.tensor([1.0, -0.5, 0.25])).sum())
     assert abs(lhs - float((d_diff * w).sum())) < 2e-3 * max(1.0, abs(lhs))
+
+
+@pytest.mark.parametrize("param", ["alpha", "eta", "k", "box_x"])
+def test_roughconductor_bsdf(psdr, orc, param):
+    """psdr.RoughConductorBSDF (reference roughconductor.cpp: anisotropic GGX + conductor Fresnel) against the oracle"""
+    spec = scenes.conductor_cbox_scene(48, 48, 8, 8, 8, param=param)
+    sc = product.build_scene(spec)
+    ref = orc.OracleScene(spec, [0])
+    integ = psdr.PathTracer(3)
+    c = integ.renderC(sc, 0, seed=3).cpu().numpy()
+    assert product.rel_l2(c, ref.render_c(max_depth=3, seed=3)) < 1e-3
+    img, dimg = psdr.render_d_fwd(integ, sc, 0, seed=6)
+    wimg, wd = ref.render_d(max_depth=3, seeds=(6, 6, 6))
+    assert product.rel_l2(img.cpu().numpy(), wimg) < 1e-3
+    assert np.abs(wd).max() > 0 and product.rel_l2(dimg.cpu().numpy(), wd) < 1e-3
+    b = psdr.RoughConductorBSDF(0.2, [0.2, 0.9, 1.1], [3.9, 2.4, 2.1])
+    assert float(np.asarray(b.alpha_u)[0]) == float(np.asarray(b.alpha_v)[0]) == np.float32(0.2) and np.allclose(np.asarray(b.k), [3.9, 2.4, 2.1])

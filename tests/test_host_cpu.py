@@ -33,7 +33,7 @@ def test_cabi_exports_every_declared_symbol(psdr):
     for name in declared:
         assert hasattr(L, name), "libpsdr_hip.so does not export %s" % name
     assert sorted(cabi.SYMBOLS) == declared
-    assert L.psdr_hip_abi_version() == 6
+    assert L.psdr_hip_abi_version() == 7
     # host-side sampler building block is bit-exact with the oracle / golden table
     import json
     with open(os.path.join(ROOT, "tests", "golden", "tea64.json")) as fh:
@@ -156,7 +156,7 @@ def test_xml_scene_loader(psdr, tmp_path):
     assert np.allclose(np.asarray(b._get("specularReflectance", False)), [0.6, 0.5, 0.4]) and np.allclose(np.asarray(b._get("diffuseReflectance", False)), 0.1)
     assert abs(float(np.asarray(b._get("roughness", False))[0]) - 0.3) < 1e-7
     with pytest.raises(RuntimeError, match="Unknown BSDF type"):
-        psdr.Scene().load_string('<scene><bsdf type="roughconductor" id="a"/></scene>', False)
+        psdr.Scene().load_string('<scene><bsdf type="roughdielectric" id="a"/></scene>', False)
     with pytest.raises(RuntimeError, match="BSDF must have an id"):
         psdr.Scene().load_string('<scene><bsdf type="diffuse"><rgb name="reflectance" value="1"/></bsdf></scene>', False)
     with pytest.raises(RuntimeError, match="XML parsing failed"):

@@ -320,3 +320,19 @@ def test_microfacet_bsdf_known_answers(orc):
     c, _ = ev(spec, diff, rough, wi * [1, 1, -1], wo * [1, 1, -1], two_sided=1)
     assert np.allclose(c, a, rtol=1e-6)
     assert np.all(ev(spec, diff, rough, wi * [1, 1, -1], wo * [1, 1, -1])[0] == 0)
+
+
+def test_conductor_fresnel_known_values(orc):
+    """utils.h:166-182: k = 0 reduces to the dielectric Fresnel reflectance; eta = 0, k = 1 (the RoughConductor default) reflects all"""
+    import ctypes as C
+    L = orc.lib()
+    L.orc_fresnel_conductor.restype = C.c_float
+    L.orc_fresnel_conductor.argtypes = [C.c_float] * 3
+    assert abs(L.orc_fresnel_conductor(1.5, 0.0, 1.0) - 0.04) < 1e-6                     # ((n-1)/(n+1))^2
+    for c in (1.0, 0.7, 0.2):
+        assert abs(L.orc_fresnel_conductor(0.0, 1.0, c) - 1.0) < 1e-6
+    n, c = 1.5, 0.6                                                                        # unpolarised dielectric Fresnel
+    ct = np.sqrt(1 - (1 - c * c) / (n * n))
+    rs, rp = ((c - n * ct) / (c + n * ct)) ** 2, ((n * c - ct) / (n * c + ct)) ** 2
+    assert abs(L.orc_fresnel_conductor(n, 0.0, c) - 0.5 * (rs + rp)) < 1e-5
+    assert 0.9 < L.orc_fresnel_conductor(0.2, 3.9, 0.8) < 1.0                             # a metal (gold-like, red)
