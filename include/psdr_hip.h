@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PSDR_HIP_ABI_VERSION 7
+#define PSDR_HIP_ABI_VERSION 8
 
 /* TriangleInfo SoA, reference include/psdr/types.h:162-175 (+ Scene::m_triangle_uv,
  * m_triangle_face_normals, scene.cpp:528-542).  Arrays of n_triangles rows. */
@@ -166,6 +166,11 @@ typedef struct psdr_render_args {
     int32_t zero_output;          /* 1: the call clears out buffers first (hipMemsetAsync on `stream`) */
     int32_t direct_mode;          /* 0: PathTracer(max_depth); 1 + mis: DirectIntegrator(mis), mis = 0/1/2 (reference
                                      src/integrator/direct.cpp:34-132: emitter sample only / BSDF sample only / both with MIS) */
+    int32_t field_mode;           /* 0: none; 1 + f: first-hit integrators (no secondary-edge term): FieldExtractionIntegrator (reference
+                                     src/integrator/field.cpp) f = 0 silhouette, 1 position, 2 depth, 3 geoNormal, 4 shNormal, 5 uv, 6 bsdf,
+                                     7 segmentation; f = 8: CollocatedIntegrator(intensity) (src/integrator/collocated.cpp) */
+    int32_t field_object;         /* mesh index the field is restricted to (field.cpp:59-66), -1 = all; only read when field_mode > 0 */
+    float intensity, d_intensity; /* CollocatedIntegrator::m_intensity and its forward tangent */
 } psdr_render_args;
 
 /* counters of the instrumented build: filled by psdr_hip_render_*_counted */

@@ -95,6 +95,10 @@ const char *orc_last_error(void);
 /* integrator used by the render calls that follow: -1 = PathTracer(max_depth) (default), 0/1/2 = DirectIntegrator(mis)
  * (reference src/integrator/direct.cpp: emitter sampling only / BSDF sampling only / both with MIS; max_depth is ignored) */
 void orc_set_direct_mis(orc_scene *s, int mis);
+/* first-hit integrators for the render calls that follow (no secondary-edge term): field = -1 none, 0 silhouette, 1 position,
+ * 2 depth, 3 geoNormal, 4 shNormal, 5 uv, 6 bsdf, 7 segmentation (FieldExtractionIntegrator, src/integrator/field.cpp), 8 =
+ * CollocatedIntegrator(intensity) (src/integrator/collocated.cpp); object = mesh index filter or -1 */
+void orc_set_field(orc_scene *s, int field, int object, float intensity, float d_intensity);
 void orc_set_num_threads(int n);     /* 0 = OpenMP default */
 int orc_get_num_threads(void);
 

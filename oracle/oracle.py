@@ -249,6 +249,9 @@ def get_num_threads() -> int:
     return lib().orc_get_num_threads()
 
 
+FIELDS = ["silhouette", "position", "depth", "geoNormal", "shNormal", "uv", "bsdf", "segmentation", "collocated"]
+
+
 class OracleScene:
     """A configured scene (= Scene.configure(active_sensors) of the reference)."""
 
@@ -382,6 +385,14 @@ class OracleScene:
         L = lib()
         L.orc_set_direct_mis.argtypes = [C.c_void_p, C.c_int]; L.orc_set_direct_mis.restype = None
         L.orc_set_direct_mis(self._h, int(mis))
+
+    def set_field(self, field=-1, obj=-1, intensity=1.0, d_intensity=0.0):
+        """first-hit integrators: see orc_set_field (field names: FIELDS)"""
+        L = lib()
+        L.orc_set_field.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]; L.orc_set_field.restype = None
+        if isinstance(field, str):
+            field = FIELDS.index(field)
+        L.orc_set_field(self._h, int(field), int(obj), float(intensity), float(d_intensity))
 
     def emitter_weight(self, i):
         L = lib()

@@ -71,6 +71,9 @@ int orc_microfacet_sample(float roughness, int two_sided, const float wi[3], con
 float orc_ggx_eval(float alpha, const float m[3]) { return orc::kat_ggx_eval(alpha, m); }
 float orc_fresnel_conductor(float eta, float k, float c) { return orc::kat_fresnel_conductor(eta, k, c); }
 void orc_set_direct_mis(orc_scene *s, int mis) { s->sc->direct_mis = mis; }
+void orc_set_field(orc_scene *s, int field, int object, float intensity, float d_intensity) {
+    s->sc->field = field; s->sc->field_object = object; s->sc->intensity = orc::Dual(intensity, d_intensity);
+}
 float orc_emitter_sampling_weight(const orc_scene *s, int e) { return s->sc->emitters[e].sampling_weight; }
 int orc_envmap_info(const orc_scene *s, float bounds[6], int reso[2], float *cell_sum) {
     if (s->sc->env_emitter < 0) return 0;
@@ -247,7 +250,7 @@ int orc_render_d(const orc_scene *s, int sensor_id, int max_depth, int hide, con
     }
 
     // secondary edges (path.cpp:274-294)
-    if ((terms & ORC_TERM_SECONDARY) && sc.sppse > 0 && !sc.sec_edges.empty()) {
+    if ((terms & ORC_TERM_SECONDARY) && sc.field < 0 && sc.sppse > 0 && !sc.sec_edges.empty()) {
         const int64_t lb = 0, le = npx * sc.sppse;
         for (int64_t c0 = lb; c0 < le; c0 += CH) {
             int64_t c1 = std::min(c0 + CH, le);

@@ -396,6 +396,27 @@ V3<Real<ad>> Li(const Scene &sc, LaneSampler &sampler, const Ray<ad> &ray_, bool
     Its<ad> its = ray_intersect<ad, false>(sc, curr, active);
     active = active && its.valid;
     V throughput(R(1.f));
+    if (sc.field >= 0) {
+        // FieldExtractionIntegrator::__Li (field.cpp:49-121) / CollocatedIntegrator::__Li (collocated.cpp:24-55): first hit only
+        bool ok = its.valid;
+        if (sc.env_emitter >= 0 && sc.field != 8) ok = ok && its.valid && sc.meshes[its.mesh].bsdf >= 0;     // field.cpp:55-58
+        if (sc.field_object >= 0) ok = ok && its.valid && its.mesh == sc.field_object;
+        if (!ok) return V(R(0.f));
+        switch (sc.field) {
+            case 0: return V(R(1.f));
+            case 1: return its.p;
+            case 2: return V(its.t);
+            case 3: return its.n;
+            case 4: return its.sh.n;
+            case 5: return V(its.uv.x, its.uv.y, R(0.f));
+            case 6: return bsdf_eval<ad>(sc, its, its.wi, true);
+            case 7: return V(R((float) (its.mesh + 1)));
+            default: {
+                V r = bsdf_eval<ad>(sc, its, its.wi, true) / sqr(its.t);
+                if constexpr (ad) return r * sc.intensity; else return r * sc.intensity.v;
+            }
+        }
+    }
     V result = hide_emitters ? V(R(0.f)) : Le<ad>(sc, its, active);
     // DirectIntegrator(mis) (reference src/integrator/direct.cpp:34-132) is the same body run once: mis = 0 draws and uses
     // only the emitter sample (weight 1), mis = 1 only the BSDF sample (weight 1), mis = 2 both with MIS; -1 = PathTracer

@@ -128,6 +128,10 @@ struct Scene {
     std::vector<int> bvh_tris;
     bool use_bvh = false;
     int direct_mis = -1;               // >= 0: Li is DirectIntegrator(mis) (direct.cpp), -1: PathTracer
+    // first-hit integrators: FieldExtractionIntegrator (field.cpp) 0 silhouette 1 position 2 depth 3 geoNormal 4 shNormal 5 uv
+    // 6 bsdf 7 segmentation, CollocatedIntegrator (collocated.cpp) 8; -1 = none.  field_object: mesh index filter or -1
+    int field = -1, field_object = -1;
+    Dual intensity = Dual(1.f);
 };
 
 Scene *configure_scene(const orc_scene_desc &d, const int *active, int n_active);

@@ -609,6 +609,12 @@ PathTracer.renderC = _renderC
 PathTracer.renderD = _renderD
 Direct.renderC = _renderC
 Direct.renderD = _renderD
+FieldExtractionIntegrator = _core.FieldExtractionIntegrator
+CollocatedIntegrator = _core.CollocatedIntegrator
+for _cls in (FieldExtractionIntegrator, CollocatedIntegrator):
+    _cls.renderC = _renderC
+    _cls.renderD = _renderD
+CollocatedIntegrator.m_intensity = _make_param_property("m_intensity", lambda self, value: (1,))
 
 
 def render_d_fwd(integrator, scene, sensor_id=0, seed=-1, batch_pix=-1, terms=TERM_ALL, tangents=None):

@@ -21,7 +21,8 @@ class Sampler(C.Structure):
 class RenderArgs(C.Structure):
     _fields_ = [("sensor_id", C.c_int32), ("max_depth", C.c_int32), ("hide_emitters", C.c_int32),
                 ("samplers", Sampler * 3), ("pix_ids", C.c_void_p), ("n_pix", C.c_int32), ("terms", C.c_int32),
-                ("shard_rank", C.c_int32), ("shard_count", C.c_int32), ("guiding", C.c_void_p), ("zero_output", C.c_int32), ("direct_mode", C.c_int32)]
+                ("shard_rank", C.c_int32), ("shard_count", C.c_int32), ("guiding", C.c_void_p), ("zero_output", C.c_int32), ("direct_mode", C.c_int32),
+                ("field_mode", C.c_int32), ("field_object", C.c_int32), ("intensity", C.c_float), ("d_intensity", C.c_float)]
 
 
 class Grads(C.Structure):
@@ -67,7 +68,7 @@ def check(rc):
 
 
 def make_args(sensor_id=0, max_depth=1, hide_emitters=False, seeds=(0, 0, 0), skips=(0, 0, 0), pix_ids_ptr=0, n_pix=0,
-              terms=7, shard_rank=0, shard_count=1, guiding=None, zero_output=True, direct_mis=-1):
+              terms=7, shard_rank=0, shard_count=1, guiding=None, zero_output=True, direct_mis=-1, field=-1, field_object=-1, intensity=1.0, d_intensity=0.0):
     a = RenderArgs()
     a.sensor_id, a.max_depth, a.hide_emitters = sensor_id, max_depth, int(hide_emitters)
     for k in range(3):
@@ -75,4 +76,5 @@ def make_args(sensor_id=0, max_depth=1, hide_emitters=False, seeds=(0, 0, 0), sk
     a.pix_ids, a.n_pix, a.terms = pix_ids_ptr or None, n_pix, terms
     a.shard_rank, a.shard_count, a.guiding, a.zero_output = shard_rank, shard_count, guiding, int(zero_output)
     a.direct_mode = int(direct_mis) + 1
+    a.field_mode, a.field_object, a.intensity, a.d_intensity = int(field) + 1, int(field_object), float(intensity), float(d_intensity)
     return a

@@ -34,6 +34,8 @@ struct AdjointParams {
     float *g_bsdf, *g_emitter;      // [n_bsdfs * 3], [n_emitters * 3]
     int lds_accum;                  // 1: accumulate in LDS first (small scenes), 0: global atomics
     int mis;                        // -1: PathTracer; 0/1/2: DirectIntegrator(mis)
+    int field, field_object;        // >= 0: first-hit integrator
+    float intensity, d_intensity;
 };
 
 template <bool LDS>

@@ -56,7 +56,7 @@ PSDR_DEV SceneView<LDS> make_view(const float4 *blob, const SceneTables &T, floa
     S.B = B; S.G = blob; S.T = &T;
     S.stack = reinterpret_cast<int *>(smem + (LDS ? T.blob_words : 0)) + threadIdx.x;
     S.c_nodes = S.c_tris = S.c_rays = S.c_hits = 0u;
-    S.mis = -1; S.mode = 0; S.rec = nullptr; S.rec_i = 0; S.rec_n = 0; S.ext = nullptr; S.ext_n = 0; S.probe_kind = 0; S.probe_id = 0; S.probe_comp = 0;
+    S.mis = -1; S.field = -1; S.field_object = -1; S.intensity = 1.f; S.d_intensity = 0.f; S.mode = 0; S.rec = nullptr; S.rec_i = 0; S.rec_n = 0; S.ext = nullptr; S.ext_n = 0; S.probe_kind = 0; S.probe_id = 0; S.probe_comp = 0;
     return S;
 }
 
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kBlock, (AD ? 3 : 4)) void k_paths(const float4 *__
                                                   const PathParams P, Counters *ctr) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     SceneView<LDS> S = make_view<LDS>(blob, T, smem);
-    S.mis = P.mis;
+    S.mis = P.mis; S.field = P.field; S.field_object = P.field_object; S.intensity = P.intensity; S.d_intensity = P.d_intensity;
     if (MODE == 1 && P.adj_w != nullptr && P.lds_acc) {
         // reverse mode of the primary-edge term: 8.4 M samples add into a 42 x 4 table - accumulate per workgroup in LDS
         float *acc = scratch_base<LDS>(smem, T);
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kBlock) void k_interior_adjoint(const float4 *__res
                                                              const AdjointParams P) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     SceneView<LDS> S = make_view<LDS>(blob, T, smem);
-    S.mis = P.mis;
+    S.mis = P.mis; S.field = P.field; S.field_object = P.field_object; S.intensity = P.intensity; S.d_intensity = P.d_intensity;
     run_interior_adjoint<LDS>(S, cam, P, scratch_base<LDS>(smem, T));
 }
 
@@ -711,10 +711,14 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
     Counters *ctr = (Counters *) sc->counters.p;
     if (COUNT) HIPCHK(hipMemsetAsync(ctr, 0, sizeof(Counters), st));
     const SensorDev &cam = sc->sensors[a->sensor_id];
-    const int terms = ad ? (a->terms ? a->terms : 7) : PSDR_TERM_INTERIOR;
+    const int terms = (ad ? (a->terms ? a->terms : 7) : PSDR_TERM_INTERIOR) & (a->field_mode > 0 ? ~PSDR_TERM_SECONDARY : ~0);   // first-hit integrators have no secondary-edge term
     const int count = a->shard_count > 1 ? a->shard_count : 1;
     const int rank = count > 1 ? a->shard_rank : 0;
     if (rank < 0 || rank >= count) return fail("bad shard rank");
+    // the first-hit integrators (field_mode) live in the LDS=false instantiations only
+    const bool use_lds = sc->lds && a->field_mode == 0;
+    const int fh_field = a->field_mode - 1;
+    if (a->field_mode < 0 || a->field_mode > 9) return fail("bad field_mode");
 
     auto next_queue = [&](unsigned long long *&q) -> int {
         q = (unsigned long long *) sc->queues.p + (sc->queue_slot++ % kQueueRing);
@@ -723,7 +727,7 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
     };
     if ((terms & PSDR_TERM_INTERIOR) && T.spp > 0) {
         PathParams P{};
-        P.max_depth = (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[0].seed; P.skip = a->samplers[0].skip;
+        P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[0].seed; P.skip = a->samplers[0].skip;
         P.pix_ids = a->pix_ids; P.begin = 0; P.end = npx * T.spp; P.shard_rank = rank; P.shard_count = count;
         P.out = out; P.dout = dout; P.lanes_out = lanes_out;
         if (lanes_out) { P.begin = lane_b; P.end = lane_e; P.shard_rank = 0; P.shard_count = 1; }
@@ -731,10 +735,10 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
         if (P.n_local > 0) {
             if (next_queue(P.counter)) return 1;
             if (ad) {
-                if (sc->lds) LAUNCH((k_paths<true, true, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
+                if (use_lds) LAUNCH((k_paths<true, true, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
                 else LAUNCH((k_paths<true, false, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
             } else {
-                if (sc->lds) LAUNCH((k_paths<false, true, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
+                if (use_lds) LAUNCH((k_paths<false, true, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
                 else LAUNCH((k_paths<false, false, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
             }
         }
@@ -742,18 +746,18 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
     if (ad && !a->pix_ids && !lanes_out) {
         if ((terms & PSDR_TERM_PRIMARY) && T.sppe > 0 && cam.n_edges > 0) {
             PathParams P{};
-            P.max_depth = (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[1].seed; P.skip = a->samplers[1].skip;
+            P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[1].seed; P.skip = a->samplers[1].skip;
             P.begin = 0; P.end = npx * T.sppe; P.shard_rank = rank; P.shard_count = count; P.dout = dout;
             P.n_local = local_lanes(P.end, rank, count);
             if (P.n_local > 0) {
                 if (next_queue(P.counter)) return 1;
-                if (sc->lds) LAUNCH((k_paths<false, true, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
+                if (use_lds) LAUNCH((k_paths<false, true, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
                 else LAUNCH((k_paths<false, false, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
             }
         }
         if ((terms & PSDR_TERM_SECONDARY) && T.sppse > 0 && sc->E.n > 0) {
             PathParams P{};
-            P.max_depth = (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[2].seed; P.skip = a->samplers[2].skip;
+            P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[2].seed; P.skip = a->samplers[2].skip;
             P.begin = 0; P.end = npx * T.sppse; P.shard_rank = rank; P.shard_count = count; P.dout = dout;
             P.n_local = local_lanes(P.end, rank, count);
             GuidingDev G{};
@@ -810,9 +814,13 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     const int count = a->shard_count > 1 ? a->shard_count : 1;
     const int rank = count > 1 ? a->shard_rank : 0;
     if (rank < 0 || rank >= count) return fail("bad shard rank");
+    // the first-hit integrators (field_mode) live in the LDS=false instantiations only
+    const bool use_lds = sc->lds && a->field_mode == 0;
+    const int fh_field = a->field_mode - 1;
+    if (a->field_mode < 0 || a->field_mode > 9) return fail("bad field_mode");
     SensorDev cam = sc->sensors[a->sensor_id];
     for (int i = 0; i < 16; ++i) { cam.d_to_world.m[i] = 0.f; cam.d_world_to_sample.m[i] = 0.f; }     // probes only
-    const int terms = a->terms ? a->terms : 7;
+    const int terms = (a->terms ? a->terms : 7) & (a->field_mode > 0 ? ~PSDR_TERM_SECONDARY : ~0);
     if (a->zero_output) {
         HIPCHK(hipMemsetAsync(g->g_triangles, 0, sizeof(float) * 22 * (size_t) T.n_tris, st));
         HIPCHK(hipMemsetAsync(g->g_bsdf, 0, sizeof(float) * 3 * (size_t) std::max(1, T.n_bsdfs), st));
@@ -840,34 +848,34 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     }
     if ((terms & PSDR_TERM_INTERIOR) && T.spp > 0) {
         AdjointParams P{};
-        P.max_depth = (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[0].seed; P.skip = a->samplers[0].skip;
+        P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[0].seed; P.skip = a->samplers[0].skip;
         P.begin = 0; P.end = npx * T.spp; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
         P.w = d_rgb; P.g_tri = g->g_triangles; P.g_bsdf = g->g_bsdf; P.g_emitter = g->g_emitter; P.lds_accum = lds_acc ? 1 : 0;
         if (P.n_local > 0) {
             if (next_queue(P.counter)) return 1;
             const int grid = grid_for(sc, P.n_local);
-            if (sc->lds) hipLaunchKernelGGL((k_interior_adjoint<true>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, cam, P);
+            if (use_lds) hipLaunchKernelGGL((k_interior_adjoint<true>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, cam, P);
             else hipLaunchKernelGGL((k_interior_adjoint<false>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, cam, P);
         }
     }
     if ((terms & PSDR_TERM_PRIMARY) && T.sppe > 0 && cam.n_edges > 0) {
         if (!g->g_prim_edges) return fail("g_prim_edges is required when the primary-edge term is requested");
         PathParams P{};
-        P.max_depth = (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[1].seed; P.skip = a->samplers[1].skip;
+        P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[1].seed; P.skip = a->samplers[1].skip;
         P.begin = 0; P.end = npx * T.sppe; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
         P.adj_w = d_rgb; P.g_prim = g->g_prim_edges; P.n_prim = cam.n_edges; P.lds_acc = (cam.n_edges <= 2048) ? 1 : 0;
         if (P.n_local > 0) {
             if (next_queue(P.counter)) return 1;
             const int grid = grid_for(sc, P.n_local);
             const size_t sm = sc->smem_bytes + (P.lds_acc ? sizeof(float) * 4 * (size_t) cam.n_edges : 0);
-            if (sc->lds) hipLaunchKernelGGL((k_paths<false, true, false, 1>), dim3(grid), dim3(kBlock), sm, st, sc->blob.as<float4>(), T, cam, P, (Counters *) nullptr);
+            if (use_lds) hipLaunchKernelGGL((k_paths<false, true, false, 1>), dim3(grid), dim3(kBlock), sm, st, sc->blob.as<float4>(), T, cam, P, (Counters *) nullptr);
             else hipLaunchKernelGGL((k_paths<false, false, false, 1>), dim3(grid), dim3(kBlock), sm, st, sc->blob.as<float4>(), T, cam, P, (Counters *) nullptr);
         }
     }
     if ((terms & PSDR_TERM_SECONDARY) && T.sppse > 0 && sc->E.n > 0) {
         if (!g->g_sec_edges) return fail("g_sec_edges is required when the secondary-edge term is requested");
         PathParams P{};
-        P.max_depth = (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[2].seed; P.skip = a->samplers[2].skip;
+        P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[2].seed; P.skip = a->samplers[2].skip;
         P.begin = 0; P.end = npx * T.sppse; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
         P.adj_w = d_rgb; P.g_sec = g->g_sec_edges; P.g_tri = g->g_triangles; P.n_sec = sc->E.n;
         const size_t sec_acc = sizeof(float) * (6 * (size_t) sc->E.n + 22 * (size_t) T.n_tris);

@@ -35,6 +35,8 @@ struct PathParams {
     float *g_tri;                    // [n_tris * 22]
     int lds_acc, n_prim, n_sec;      // 1: the kernel accumulates the adjoint tables in LDS first (same-address atomics)
     int mis;                         // -1: PathTracer; 0/1/2: DirectIntegrator(mis), reference direct.cpp:34-132 (max_depth = 1)
+    int field, field_object;         // >= 0: first-hit integrator (shade.h first_hit_value), max_depth = 0
+    float intensity, d_intensity;
 };
 
 constexpr int kFetchBatch = 256;
@@ -193,7 +195,8 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
             if (depth < 0) {
                 // first hit: result = Le (path.cpp:38-43)
                 its = itx;
-                if (!P.hide_emitters) res = eval_Le<AD, LDS>(S, itx, itx.valid);
+                if (S.field >= 0) { if constexpr (!LDS) res = first_hit_value<AD, LDS>(S, itx); }
+                else if (!P.hide_emitters) res = eval_Le<AD, LDS>(S, itx, itx.valid);
                 depth = 0;
                 finished = !itx.valid || P.max_depth == 0;
             } else {

@@ -88,6 +88,8 @@ template <bool LDS> struct SceneView {
     // on the scene quantities the path touched.  The hits found by the first (recording) run are replayed
     // instead of traversing again, so a probe costs shading only.
     int mis;                   // Li variant: -1 PathTracer, 0/1/2 DirectIntegrator(mis) (set by the kernels from their parameters)
+    int field, field_object;   // >= 0: first-hit integrator (FieldExtractionIntegrator / CollocatedIntegrator), shade.h first_hit_value
+    float intensity, d_intensity;
     int mode;                  // 0 = trace, 1 = trace + record hits, 2 = replay recorded hits
     float *rec;                // this lane's LDS record, stride kBlock: 4 words per hit (slot, u, v, t)
     int rec_i, rec_n;          // replay cursor / number of recorded hits

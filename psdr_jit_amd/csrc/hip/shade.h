@@ -130,7 +130,7 @@ PSDR_DEV Its<AD> make_its(const SceneView<LDS> &S, const Hit &h, const RayT<AD> 
         const float4 s4 = S.ld(w + 4), s5 = S.ld(w + 5);
         const float du0x = s4.z - s4.x, du0y = s4.w - s4.y, du1x = s5.x - s4.x, du1y = s5.y - s4.y;
         if constexpr (!LDS) {              // its.uv = bilinear2(uv0, uv1 - uv0, uv2 - uv0, barycentrics), scene.cpp:715/779
-            if (T.tex != nullptr) {
+            if (T.tex != nullptr || S.field == 5) {
                 its.tu = fma_(R(du0x), u, fma_(R(du1x), v, R(s4.x)));
                 its.tv = fma_(R(du0y), u, fma_(R(du1y), v, R(s4.y)));
             }
@@ -477,6 +477,30 @@ template <bool AD, bool LDS> PSDR_DEV BSDFSample bsdf_sample(const SceneView<LDS
     return bs;
 }
 
+// FieldExtractionIntegrator::__Li (reference src/integrator/field.cpp:49-121) and CollocatedIntegrator::__Li
+// (src/integrator/collocated.cpp:24-55): a function of the first hit only.  LDS=false instantiations only.
+template <bool AD, bool LDS> PSDR_DEV VecN<AD> first_hit_value(const SceneView<LDS> &S, const Its<AD> &its) {
+    using R = Num<AD>; using V = VecN<AD>;
+    bool ok = its.valid;
+    if (S.T->env_emitter >= 0 && S.field != 8) ok = ok && mesh_bsdf(S, its.mesh) >= 0;        // field.cpp:55-58
+    if (S.field_object >= 0) ok = ok && its.mesh == S.field_object;
+    if (!ok) return V(R(0.f));
+    switch (S.field) {
+        case 0: return V(R(1.f));
+        case 1: return its.p;
+        case 2: return V(its.t);
+        case 3: return its.n;
+        case 4: return its.fn;
+        case 5: return V(its.tu, its.tv, R(0.f));
+        case 6: return bsdf_eval<AD, LDS>(S, its, its.wi, true);
+        case 7: return V(R((float) (its.mesh + 1)));
+        default: {
+            const V r = bsdf_eval<AD, LDS>(S, its, its.wi, true) / sqr(its.t);
+            if constexpr (AD) return r * Dual(S.intensity, S.mode == 0 ? S.d_intensity : 0.f); else return r * S.intensity;
+        }
+    }
+}
+
 PSDR_DEV float mis_weight(float p1, float p2) { const float w1 = p1 * p1, w2 = p2 * p2; return w1 / (w1 + w2); }   // reference utils.h:277-281
 
 // ---------------------------------------------------------------- PathTracer::__Li, reference src/integrator/path.cpp:35-127
@@ -487,6 +511,7 @@ PSDR_DEV VecN<AD> Li(SceneView<LDS> &S, LaneRng &rng, const RayT<AD> &ray_in, bo
     Its<AD> its = ray_intersect<AD, false, LDS, COUNT>(S, ray_in, active);
     active = active && its.valid;
     V throughput(R(1.f));
+    if (S.field >= 0) { if constexpr (!LDS) return first_hit_value<AD, LDS>(S, its); else return V(R(0.f)); }
     V result = hide_emitters ? V(R(0.f)) : eval_Le<AD, LDS>(S, its, active);
     // DirectIntegrator(mis) (reference direct.cpp:34-132) is one pass of the same body: mis = 0 draws and uses only the emitter
     // sample (weight 1), mis = 1 only the BSDF sample (weight 1), mis = 2 both with MIS

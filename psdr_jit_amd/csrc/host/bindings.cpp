@@ -312,6 +312,8 @@ PYBIND11_MODULE(_psdr_core, m) {
         for (int k = 0; k < 3; ++k) { a.samplers[k].seed = seeds[k]; a.samplers[k].skip = skips[k]; }
         a.shard_rank = rank; a.shard_count = count; a.zero_output = 1; a.terms = terms; a.guiding = it.guiding(sensor_id);
         a.direct_mode = it.direct_mis() + 1;
+        a.field_mode = it.field() + 1; a.field_object = -1; a.intensity = it.intensity(false);
+        if (!it.field_object().empty()) throw Exception("reverse mode: FieldExtractionIntegrator with an object filter is not supported");
         psdr_grads g{reinterpret_cast<float *>(g_tri), reinterpret_cast<float *>(g_bsdf), reinterpret_cast<float *>(g_emitter),
                      reinterpret_cast<float *>(g_sec), reinterpret_cast<float *>(g_prim)};
         if (psdr_hip_render_d_bwd(scene.m_hip, &a, reinterpret_cast<const float *>(d_rgb), &g, reinterpret_cast<void *>(stream)))
@@ -324,6 +326,14 @@ PYBIND11_MODULE(_psdr_core, m) {
         .def("_guiding_mass", [](const PathTracer &p, int sid) { auto v = p.guiding_mass(sid); return from_vec(v, 1); })
         .def_readwrite("hide_emitters", &PathTracer::m_hide_emitters)
         .def_readonly("max_depth", &PathTracer::m_max_depth);
+    py::class_<FieldExtractionIntegrator, Integrator>(m, "FieldExtractionIntegrator", py::dynamic_attr())
+        .def(py::init<const std::string &>())
+        .def_readonly("field", &FieldExtractionIntegrator::m_field_name)
+        .def_readonly("object", &FieldExtractionIntegrator::m_object);
+    py::class_<CollocatedIntegrator, Integrator>(m, "CollocatedIntegrator", py::dynamic_attr())
+        .def(py::init<float>())
+        .def("_get", [](const CollocatedIntegrator &c, const std::string &, bool tangent) { farr a(1); a.mutable_data()[0] = tangent ? c.d_intensity : c.m_intensity; return a; })
+        .def("_set", [](CollocatedIntegrator &c, const std::string &, const farr &v, const farr &t) { c.m_intensity = v.data()[0]; c.d_intensity = t.size() ? t.data()[0] : 0.f; });
     py::class_<DirectIntegrator, PathTracer>(m, "Direct", py::dynamic_attr())
         .def(py::init<int>(), "mis"_a = 2)
         .def_readonly("mis", &DirectIntegrator::m_mis);

@@ -750,6 +750,18 @@ static void fill_args(psdr_render_args &a, const Scene &scene, const Integrator 
     a.shard_rank = rank; a.shard_count = count; a.zero_output = 1;
     a.guiding = it.guiding(sensor_id);
     a.direct_mode = it.direct_mis() + 1;
+    a.field_mode = it.field() + 1;
+    a.field_object = -1;
+    a.intensity = it.intensity(false); a.d_intensity = it.intensity(true);
+    const std::string obj = it.field_object();
+    if (!obj.empty()) {          // Mesh::get_obj_mask, reference mesh.h:49-63: a mesh with an id is matched by name, the others by index
+        int by_index = -1;
+        try { by_index = std::stoi(obj); } catch (...) { by_index = -1; }
+        for (const Mesh *m : scene.m_meshes) {
+            if (!m->m_id.empty() ? (m->m_id == obj) : (m->m_mesh_id == by_index)) { a.field_object = m->m_mesh_id; break; }
+        }
+        if (a.field_object < 0) a.field_object = 1 << 30;        // nothing matches: an empty field
+    }
 }
 
 void Integrator::renderC(const Scene &scene, int sensor_id, int seed, uintptr_t pix_ids, int n_pix, uintptr_t out, uintptr_t stream, int rank, int count) const {
@@ -790,6 +802,7 @@ void Integrator::renderD(const Scene &scene, int sensor_id, int seed, uintptr_t 
     }
     psdr_render_args a;
     fill_args(a, scene, *this, sensor_id, pix_ids, n_pix, rank, count);
+    if (field() >= 0) terms &= ~PSDR_TERM_SECONDARY;         // Integrator::render_secondary_edges is a no-op for the first-hit integrators
     a.terms = terms;
     hip_check(psdr_hip_render_d_fwd(scene.m_hip, &a, reinterpret_cast<float *>(out), reinterpret_cast<float *>(dout), reinterpret_cast<void *>(stream)));
     const PerspectiveCamera *cam = static_cast<const PerspectiveCamera *>(scene.m_sensors[sensor_id]);
@@ -801,6 +814,16 @@ void Integrator::renderD(const Scene &scene, int sensor_id, int seed, uintptr_t 
         oss << "Rendered in " << duration_cast<duration<double>>(high_resolution_clock::now() - start_time).count() << " seconds.";
         log(oss.str());
     }
+}
+
+FieldExtractionIntegrator::FieldExtractionIntegrator(const std::string &spec) {
+    std::istringstream iss(spec);
+    iss >> m_field_name;
+    iss >> m_object;
+    static const char *names[8] = {"silhouette", "position", "depth", "geoNormal", "shNormal", "uv", "bsdf", "segmentation"};
+    m_field = -1;
+    for (int i = 0; i < 8; ++i) if (m_field_name == names[i]) m_field = i;
+    PSDR_ASSERT_MSG(m_field >= 0, std::string("Unsupported field: ") + m_field_name);
 }
 
 PathTracer::PathTracer(int max_depth) : m_max_depth(max_depth) { PSDR_ASSERT(max_depth >= 0); }

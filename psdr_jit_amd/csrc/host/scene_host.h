@@ -255,6 +255,10 @@ struct Integrator : Object {
     virtual bool hide_emitters() const = 0;
     virtual const psdr_hip_guiding *guiding(int sensor_id) const { (void) sensor_id; return nullptr; }
     virtual int direct_mis() const { return -1; }                 // >= 0: DirectIntegrator(mis)
+    // first-hit integrators (psdr_render_args.field_mode): -1 = none, 0..7 FieldExtractionIntegrator fields, 8 CollocatedIntegrator
+    virtual int field() const { return -1; }
+    virtual std::string field_object() const { return ""; }
+    virtual float intensity(bool tangent) const { return tangent ? 0.f : 1.f; }
     int draws_per_level() const { const int m = direct_mis(); return m == 0 ? 2 : (m == 1 ? 3 : 5); }
 };
 
@@ -279,6 +283,30 @@ struct DirectIntegrator : PathTracer {
     std::string type_name() const override { return "DirectIntegrator"; }
     int direct_mis() const override { return m_mis; }
     int m_mis;
+};
+
+// FieldExtractionIntegrator("field [object]"), reference src/integrator/field.cpp:8-31: the first hit's silhouette, position, depth,
+// geoNormal, shNormal, uv, bsdf value or segmentation id; optionally restricted to one mesh (by id string or index).
+struct FieldExtractionIntegrator : Integrator {
+    explicit FieldExtractionIntegrator(const std::string &spec);
+    std::string type_name() const override { return "FieldExtractionIntegrator"; }
+    int max_depth() const override { return 0; }
+    bool hide_emitters() const override { return false; }
+    int field() const override { return m_field; }
+    std::string field_object() const override { return m_object; }
+    std::string m_field_name, m_object;
+    int m_field = 0;
+};
+
+// CollocatedIntegrator(intensity), reference src/integrator/collocated.cpp: bsdf(wi, wi) / t^2 * intensity at the first hit
+struct CollocatedIntegrator : Integrator {
+    explicit CollocatedIntegrator(float intensity_) : m_intensity(intensity_) {}
+    std::string type_name() const override { return "CollocatedIntegrator"; }
+    int max_depth() const override { return 0; }
+    bool hide_emitters() const override { return false; }
+    int field() const override { return 8; }
+    float intensity(bool tangent) const override { return tangent ? d_intensity : m_intensity; }
+    float m_intensity, d_intensity = 0.f;
 };
 
 } // namespace psdr_host

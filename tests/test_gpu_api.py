@@ -272,3 +272,50 @@ def test_roughconductor_bsdf(psdr, orc, param):
     assert np.abs(wd).max() > 0 and product.rel_l2(dimg.cpu().numpy(), wd) < 1e-3
     b = psdr.RoughConductorBSDF(0.2, [0.2, 0.9, 1.1], [3.9, 2.4, 2.1])
     assert float(np.asarray(b.alpha_u)[0]) == float(np.asarray(b.alpha_v)[0]) == np.float32(0.2) and np.allclose(np.asarray(b.k), [3.9, 2.4, 2.1])
+
+
+def test_field_extraction_and_collocated_integrators(psdr, orc):
+    """psdr.FieldExtractionIntegrator / psdr.CollocatedIntegrator (reference field.cpp, collocated.cpp) against the oracle"""
+    import torch
+    spec = scenes.cbox_scene(40, 40, 4, 8, 8, param="box_x")
+    sc = product.build_scene(spec)
+    ref = orc.OracleScene(spec, [0])
+    for name in ("silhouette", "position", "depth", "geoNormal", "shNormal", "uv", "bsdf", "segmentation"):
+        # (the silhouette of the closed box does not move with the small box: restrict it to that mesh)
+        integ = psdr.FieldExtractionIntegrator(name + (" 1" if name == "silhouette" else ""))
+        ref.set_field(name, obj=1 if name == "silhouette" else -1)
+        img, dimg = psdr.render_d_fwd(integ, sc, 0, seed=3)
+        wimg, wd = ref.render_d(max_depth=0, seeds=(3, 3, 3))
+        assert product.rel_l2(img.cpu().numpy(), wimg) < 1e-3, name
+        assert np.abs(wd).max() > 0 and product.rel_l2(dimg.cpu().numpy(), wd) < 1e-3, name
+    # object filter by mesh index, renderC, sampler continuation (2 draws per call)
+    integ = psdr.FieldExtractionIntegrator("depth 2")
+    ref.set_field("depth", obj=2)
+    a = integ.renderC(sc, 0, seed=5).cpu().numpy()
+    assert a.max() > 0 and product.rel_l2(a, ref.render_c(max_depth=0, seed=5)) < 1e-3
+    b = integ.renderC(sc, 0).cpu().numpy()
+    assert product.rel_l2(b, ref.render_c(max_depth=0, seed=5, skip=2)) < 1e-3
+    with pytest.raises(RuntimeError, match="Unsupported field"):
+        psdr.FieldExtractionIntegrator("albedo")
+    col = psdr.CollocatedIntegrator(5e5)
+    ref.set_field("collocated", intensity=5e5)
+    img, dimg = psdr.render_d_fwd(col, sc, 0, seed=7)
+    wimg, wd = ref.render_d(max_depth=0, seeds=(7, 7, 7))
+    assert product.rel_l2(img.cpu().numpy(), wimg) < 1e-3 and product.rel_l2(dimg.cpu().numpy(), wd) < 1e-3
+    # a microfacet scene through the collocated integrator (its usual companion) + reverse mode == forward mode
+    spec2 = scenes.microfacet_cbox_scene(40, 40, 4, 4, 0, param="diffuse")
+    sc2 = product.build_scene(spec2)
+    ref2 = orc.OracleScene(spec2, [0])
+    ref2.set_field("collocated", intensity=2e5)
+    col2 = psdr.CollocatedIntegrator(2e5)
+    img, dimg = psdr.render_d_fwd(col2, sc2, 0, seed=1)
+    wimg, wd = ref2.render_d(max_depth=0, seeds=(1, 1, 1))
+    assert product.rel_l2(img.cpu().numpy(), wimg) < 1e-3 and product.rel_l2(dimg.cpu().numpy(), wd) < 1e-3
+    P = psdr.FloatD(0.).requires_grad_()
+    sc3 = _readme_scene(psdr, P)
+    im = psdr.FieldExtractionIntegrator("depth").renderD(sc3, 0, seed=2)
+    w = torch.linspace(0.5, 1.5, im.numel(), device=im.device).reshape(im.shape)
+    d = psdr.forward_grad(im, P)
+    (im * w).sum().backward()
+    want = float((d * w).sum())
+    assert abs(want) > 1e-3 and abs(float(P.grad) - want) < 2e-3 * max(1.0, abs(want))

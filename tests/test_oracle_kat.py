@@ -336,3 +336,47 @@ def test_conductor_fresnel_known_values(orc):
     rs, rp = ((c - n * ct) / (c + n * ct)) ** 2, ((n * c - ct) / (n * c + ct)) ** 2
     assert abs(L.orc_fresnel_conductor(n, 0.0, c) - 0.5 * (rs + rp)) < 1e-5
     assert 0.9 < L.orc_fresnel_conductor(0.2, 3.9, 0.8) < 1.0                             # a metal (gold-like, red)
+
+
+def test_first_hit_integrators(orc):
+    """FieldExtractionIntegrator fields and CollocatedIntegrator (reference field.cpp:49-121, collocated.cpp:24-55)"""
+    import scenes
+    spec = scenes.cbox_scene(33, 33, 16, 0, 0, param=None)
+    sc = orc.OracleScene(spec, [0])
+
+    def field(name, **kw):
+        sc.set_field(name, **kw)
+        return sc.render_c(max_depth=3, seed=2).reshape(33, 33, 3)
+    sil = field("silhouette")
+    assert sil.max() <= 1.0 + 1e-6 and sil.min() >= 0.0
+    seg = field("segmentation")
+    pos = field("position")
+    dep = field("depth")
+    gn = field("geoNormal")
+    # a pixel that sees the back wall (mesh 5 -> id 6) everywhere within its footprint
+    ys, xs = np.nonzero(np.isclose(seg[..., 0], 6.0))
+    assert len(ys) > 20
+    y, x = ys[len(ys) // 2], xs[len(xs) // 2]
+    assert abs(pos[y, x, 2] - 559.2) < 1e-2 and np.allclose(gn[y, x], [0, 0, -1], atol=1e-5)
+    cam = np.array([208.0, 273.0, -800.0])
+    assert abs(dep[y, x, 0] - np.linalg.norm(pos[y, x] - cam)) < 0.5            # averaged over the pixel footprint
+    assert np.allclose(field("shNormal")[y, x], [0, 0, -1], atol=1e-5)
+    uvf = field("uv")[y, x]                                                     # cbox_back.obj carries texture coordinates
+    assert 0.0 <= uvf[0] <= 1.0 and 0.0 <= uvf[1] <= 1.0 and uvf[2] == 0.0
+    # bsdf field = f(wi, wi) * cos = albedo / pi * cos(theta); collocated = that / t^2 * intensity
+    b = field("bsdf")
+    wi = (cam - pos[y, x]) / np.linalg.norm(cam - pos[y, x])
+    assert np.allclose(b[y, x], 0.95 / np.pi * wi @ np.array([0, 0, -1.0]), rtol=2e-3)
+    col = field("collocated", intensity=5e5)
+    assert np.allclose(col[y, x], b[y, x] / dep[y, x, 0] ** 2 * 5e5, rtol=2e-3)
+    # object filter: only the tall box (mesh 2)
+    only = field("silhouette", obj=2)
+    assert 0 < (only[..., 0] > 0.5).sum() < (sil[..., 0] > 0.5).sum()
+    # derivative of the silhouette field comes from the primary-edge term alone
+    spec2 = scenes.cbox_scene(33, 33, 4, 16, 0, param="box_x")
+    sc2 = orc.OracleScene(spec2, [0])
+    sc2.set_field("silhouette", obj=1)
+    img, dimg = sc2.render_d(max_depth=0, seeds=(1, 1, 1))
+    assert np.abs(dimg).sum() > 0 and np.all(np.isfinite(dimg))
+    _, d_int = sc2.render_d(max_depth=0, seeds=(1, 1, 1), terms=orc.TERM_INTERIOR)
+    assert np.abs(d_int).max() == 0.0
