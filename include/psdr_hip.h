@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PSDR_HIP_ABI_VERSION 8
+#define PSDR_HIP_ABI_VERSION 9
 
 /* TriangleInfo SoA, reference include/psdr/types.h:162-175 (+ Scene::m_triangle_uv,
  * m_triangle_face_normals, scene.cpp:528-542).  Arrays of n_triangles rows. */
@@ -218,6 +218,9 @@ typedef struct psdr_grads {
     float *g_emitter;      /* [n_emitters*3] radiance */
     float *g_sec_edges;    /* [n_sec_edges*6] (p0, e1); required when sppse > 0 and the term is requested */
     float *g_prim_edges;   /* [n_primary_edges(sensor)*4] sample-space (p0.xy, p1.xy); required when sppe > 0 */
+    /* optional filter (autograd's requires_grad at the level of the snapshot): the interior adjoint skips what is not wanted */
+    const uint8_t *mesh_filter;   /* DEVICE [n_meshes]: 1 = triangle rows of this mesh are wanted; NULL = all meshes */
+    int32_t skip_bsdf, skip_emitter;   /* 1 = g_bsdf / g_emitter are not wanted (left untouched by the interior term) */
 } psdr_grads;
 int psdr_hip_render_d_bwd(const psdr_hip_scene *scene, const psdr_render_args *args, const float *d_rgb,
                           const psdr_grads *grads, void *stream);

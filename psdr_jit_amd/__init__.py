@@ -470,6 +470,13 @@ def _render_d_raw(self, scene, sensor_id, seed, batch_pix, terms, distributed=No
     return buf[0], buf[1]
 
 
+def _mesh_index(scene, mesh):
+    for i in range(scene.num_meshes):
+        if scene.param_map.get("Mesh[%d]" % i) is mesh:
+            return i
+    raise RuntimeError("mesh is not part of the scene")
+
+
 class _RenderDFn(_torch.autograd.Function):
     """Autograd node of renderD.  forward = primal image; backward = the reverse-mode kernels
     (psdr_hip_render_d_bwd: adjoints of the configured snapshot) followed by the host chain rule of
@@ -511,8 +518,22 @@ class _RenderDFn(_torch.autograd.Function):
         else:
             seeds, skips = [s[2] for s in st["samplers"]], [s[3] for s in st["samplers"]]
         rank, world = _shard()
+        # requires_grad at the level of the configured snapshot: which meshes' triangle rows, and whether any BSDF colour /
+        # emitter radiance, are wanted.  The interior adjoint probes only those (psdr_grads.mesh_filter / skip_*).
+        want_mesh = _np.zeros(max(1, scene.num_meshes), dtype=_np.uint8)
+        want_bsdf = want_em = False
+        for (obj, name, t), need in zip(leaves, needs):
+            if not need:
+                continue
+            if isinstance(obj, Mesh):
+                want_mesh[_mesh_index(scene, obj)] = 1
+            elif isinstance(obj, _core.BSDF):
+                want_bsdf = True
+            elif isinstance(obj, _core.Emitter):
+                want_em = True
+        mesh_filter = _torch.from_numpy(want_mesh).to(dev)
         _core._render_d_bwd(integ, scene, st["sensor_id"], seeds, skips, g_img.data_ptr(), ptr[0], ptr[1], ptr[2], ptr[3], ptr[4],
-                            _stream_ptr(), rank, world, st["terms"])
+                            _stream_ptr(), rank, world, st["terms"], mesh_filter.data_ptr(), not want_bsdf, not want_em)
         _all_reduce(flat, world > 1)
         g = flat.to("cpu", _torch.float64)
         g_tri, g_bsdf, g_em = g[offs[0]:offs[1]].reshape(n_tris, 22), g[offs[1]:offs[2]].reshape(-1, 3)[:nb], g[offs[2]:offs[3]].reshape(-1, 3)[:ne]

@@ -36,6 +36,8 @@ struct AdjointParams {
     int mis;                        // -1: PathTracer; 0/1/2: DirectIntegrator(mis)
     int field, field_object;        // >= 0: first-hit integrator
     float intensity, d_intensity;
+    const unsigned char *mesh_filter;   // [n_meshes] or NULL: only these meshes' triangle rows are probed
+    int skip_bsdf, skip_emitter;
 };
 
 template <bool LDS>
@@ -138,43 +140,51 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                 return g;
             };
             auto slot_at = [&](int i) -> int { return i < n_hits ? __float_as_int(rec[4 * i * kBlock]) : ext[(i - n_hits) * kBlock]; };
-            if (w[0] != 0.f || w[1] != 0.f || w[2] != 0.f) {
+            {
+                // One probe loop with ONE call site of the replay: every lane walks its own list of (kind, id, component)
+                // probes - triangle rows of the distinct triangles it touched (22 each), then the colours of the distinct
+                // BSDFs and emitters (3 each) - and all lanes that still have a probe run it together.  (Three nested
+                // loops with a replay call each inlined Li<true> four times; the kernel spent its time fetching code.)
                 const int n_all = n_hits + n_ext;
-                // triangles
-                for (int i = 0; i < n_all; ++i) {
-                    const int slot = slot_at(i);
-                    if (slot < 0) continue;
-                    bool dup = false;
-                    for (int j = 0; j < i; ++j) dup = dup || (slot_at(j) == slot);
-                    if (dup) continue;
-                    const int orig = __float_as_int(S.ld(T.shade_off + 6 * slot + 3).w);
-                    S.probe_kind = 1; S.probe_id = slot;
-                    for (int comp = 0; comp < 22; ++comp) {
-                        S.probe_comp = comp;
-                        adj_add<LDS>(acc, P.g_tri, orig * 22 + comp, probe(), use_lds);
+                const bool wactive = (w[0] != 0.f || w[1] != 0.f || w[2] != 0.f);
+                int st_stage = 0, st_i = 0, st_comp = 0, st_id = -1, st_orig = 0;
+                auto advance = [&]() -> bool {
+                    while (st_stage < 3) {
+                        if (st_i >= n_all) { ++st_stage; st_i = 0; st_comp = 0; continue; }
+                        const int slot = slot_at(st_i);
+                        bool valid = slot >= 0;
+                        if (valid && st_stage == 0) {
+                            for (int q = 0; q < st_i; ++q) valid = valid && (slot_at(q) != slot);
+                            if (valid && P.mesh_filter != nullptr) valid = P.mesh_filter[__float_as_int(S.ld(T.shade_off + 6 * slot + 1).w)] != 0;
+                            if (valid) { st_id = slot; st_orig = __float_as_int(S.ld(T.shade_off + 6 * slot + 3).w); }
+                        } else if (valid) {
+                            const int mesh = __float_as_int(S.ld(T.shade_off + 6 * slot + 1).w);
+                            const int id = st_stage == 1 ? mesh_bsdf(S, mesh) : mesh_emitter(S, mesh);
+                            valid = id >= 0 && !(st_stage == 1 ? P.skip_bsdf : P.skip_emitter);
+                            for (int q = 0; q < st_i && valid; ++q) {
+                                const int sq = slot_at(q);
+                                if (sq < 0) continue;
+                                const int mq = __float_as_int(S.ld(T.shade_off + 6 * sq + 1).w);
+                                valid = (st_stage == 1 ? mesh_bsdf(S, mq) : mesh_emitter(S, mq)) != id;
+                            }
+                            st_id = id;
+                        }
+                        if (!valid) { ++st_i; st_comp = 0; continue; }
+                        return true;
                     }
-                }
-                // reflectances and radiances of the meshes met along the path
-                for (int i = 0; i < n_all; ++i) {
-                    const int slot = slot_at(i);
-                    if (slot < 0) continue;
-                    const int mesh = __float_as_int(S.ld(T.shade_off + 6 * slot + 1).w);
-                    const int bs = mesh_bsdf(S, mesh), em = mesh_emitter(S, mesh);
-                    bool dup_b = false, dup_e = false;
-                    for (int j = 0; j < i; ++j) {
-                        const int sj = slot_at(j);
-                        if (sj < 0) continue;
-                        const int mj = __float_as_int(S.ld(T.shade_off + 6 * sj + 1).w);
-                        dup_b = dup_b || (mesh_bsdf(S, mj) == bs);
-                        dup_e = dup_e || (mesh_emitter(S, mj) == em);
-                    }
-                    if (bs >= 0 && !dup_b) {
-                        S.probe_kind = 2; S.probe_id = bs;
-                        for (int comp = 0; comp < 3; ++comp) { S.probe_comp = comp; adj_add<LDS>(acc_bsdf, P.g_bsdf, bs * 3 + comp, probe(), use_lds); }
-                    }
-                    if (em >= 0 && !dup_e) {
-                        S.probe_kind = 3; S.probe_id = em;
-                        for (int comp = 0; comp < 3; ++comp) { S.probe_comp = comp; adj_add<LDS>(acc_emit, P.g_emitter, em * 3 + comp, probe(), use_lds); }
+                    return false;
+                };
+                bool more = wactive && advance();
+                while (__ballot(more) != 0ull) {
+                    if (more) {
+                        S.probe_kind = st_stage + 1; S.probe_id = st_id; S.probe_comp = st_comp;
+                        const float gval = probe();
+                        if (st_stage == 0) adj_add<LDS>(acc, P.g_tri, st_orig * 22 + st_comp, gval, use_lds);
+                        else if (st_stage == 1) adj_add<LDS>(acc_bsdf, P.g_bsdf, st_id * 3 + st_comp, gval, use_lds);
+                        else adj_add<LDS>(acc_emit, P.g_emitter, st_id * 3 + st_comp, gval, use_lds);
+                        ++st_comp;
+                        if (st_comp >= (st_stage == 0 ? 22 : 3)) { st_comp = 0; ++st_i; }
+                        more = advance();
                     }
                 }
             }

@@ -851,6 +851,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[0].seed; P.skip = a->samplers[0].skip;
         P.begin = 0; P.end = npx * T.spp; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
         P.w = d_rgb; P.g_tri = g->g_triangles; P.g_bsdf = g->g_bsdf; P.g_emitter = g->g_emitter; P.lds_accum = lds_acc ? 1 : 0;
+        P.mesh_filter = g->mesh_filter; P.skip_bsdf = g->skip_bsdf; P.skip_emitter = g->skip_emitter;
         if (P.n_local > 0) {
             if (next_queue(P.counter)) return 1;
             const int grid = grid_for(sc, P.n_local);
