@@ -14,8 +14,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--res", type=int, default=512); ap.add_argument("--spp", type=int, default=16); ap.add_argument("--level", type=int, default=6)
 ap.add_argument("--depth", type=int, default=3); ap.add_argument("--check", action="store_true"); ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--guiding", type=int, nargs=4, default=[2000, 5, 5, 32])
+ap.add_argument("--env-res", type=int, nargs=2, default=[1024, 512])
 a = ap.parse_args()
-spec = scenes.config5_scene(a.res, a.res, a.spp, a.spp, a.spp, level=a.level)
+spec = scenes.config5_scene(a.res, a.res, a.spp, a.spp, a.spp, level=a.level, env_res=tuple(a.env_res))
 t0 = time.time()
 sc = product.build_scene(spec)
 t_cfg = time.time() - t0
