@@ -694,6 +694,9 @@ static int check_args(const psdr_hip_scene *sc, const psdr_render_args *a) {
     if (a->sensor_id < 0 || a->sensor_id >= (int) sc->sensors.size()) return fail("Invalid sensor id!");
     if (a->max_depth < 0) return fail("max_depth >= 0");
     if (a->pix_ids && a->n_pix <= 0) return fail("batch rendering needs n_pix > 0");
+    // Scene::sample_emitter_position asserts "No Emitter!" (reference scene.cpp:989); the first-hit integrators and
+    // PathTracer(0) never sample an emitter, so emitter-less scenes (silhouette / depth rendering) are fine there
+    if (sc->T.n_emitters == 0 && a->field_mode == 0 && (a->direct_mode > 0 || a->max_depth > 0)) return fail("No Emitter!");
     return 0;
 }
 
@@ -711,7 +714,7 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
     Counters *ctr = (Counters *) sc->counters.p;
     if (COUNT) HIPCHK(hipMemsetAsync(ctr, 0, sizeof(Counters), st));
     const SensorDev &cam = sc->sensors[a->sensor_id];
-    const int terms = (ad ? (a->terms ? a->terms : 7) : PSDR_TERM_INTERIOR) & (a->field_mode > 0 ? ~PSDR_TERM_SECONDARY : ~0);   // first-hit integrators have no secondary-edge term
+    const int terms = (ad ? (a->terms ? a->terms : 7) : PSDR_TERM_INTERIOR) & ((a->field_mode > 0 || sc->T.n_emitters == 0) ? ~PSDR_TERM_SECONDARY : ~0);   // first-hit integrators have no secondary-edge term
     const int count = a->shard_count > 1 ? a->shard_count : 1;
     const int rank = count > 1 ? a->shard_rank : 0;
     if (rank < 0 || rank >= count) return fail("bad shard rank");
@@ -820,7 +823,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     if (a->field_mode < 0 || a->field_mode > 9) return fail("bad field_mode");
     SensorDev cam = sc->sensors[a->sensor_id];
     for (int i = 0; i < 16; ++i) { cam.d_to_world.m[i] = 0.f; cam.d_world_to_sample.m[i] = 0.f; }     // probes only
-    const int terms = (a->terms ? a->terms : 7) & (a->field_mode > 0 ? ~PSDR_TERM_SECONDARY : ~0);
+    const int terms = (a->terms ? a->terms : 7) & ((a->field_mode > 0 || sc->T.n_emitters == 0) ? ~PSDR_TERM_SECONDARY : ~0);
     if (a->zero_output) {
         HIPCHK(hipMemsetAsync(g->g_triangles, 0, sizeof(float) * 22 * (size_t) T.n_tris, st));
         HIPCHK(hipMemsetAsync(g->g_bsdf, 0, sizeof(float) * 3 * (size_t) std::max(1, T.n_bsdfs), st));

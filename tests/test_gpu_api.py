@@ -319,3 +319,32 @@ def test_field_extraction_and_collocated_integrators(psdr, orc):
     (im * w).sum().backward()
     want = float((d * w).sum())
     assert abs(want) > 1e-3 and abs(float(P.grad) - want) < 2e-3 * max(1.0, abs(want))
+
+
+def test_scene_without_emitters(psdr):
+    """silhouette / depth rendering needs no light: the first-hit integrators and PathTracer(0) work, anything that samples
+    an emitter raises the reference's "No Emitter!" (scene.cpp:989)"""
+    import torch
+    D = scenes.DATA
+    sc = psdr.Scene()
+    sc.opts.spp, sc.opts.sppe, sc.opts.sppse = 4, 8, 0
+    sc.opts.width = sc.opts.height = 32
+    sc.opts.log_level = 0
+    cam = psdr.PerspectiveCamera(60, 0.000001, 10000000.)
+    cam.to_world = psdr.Matrix4fD([[1., 0., 0., 208.], [0., 1., 0., 273.], [0., 0., 1., -800.], [0., 0., 0., 1.]])
+    sc.add_Sensor(cam)
+    sc.add_BSDF(psdr.DiffuseBSDF([0.5, 0.5, 0.5]), "cat")
+    P = psdr.FloatD(0.).requires_grad_()
+    sc.add_Mesh(os.path.join(D, "cbox_smallbox.obj"), psdr.Matrix4fC(np.eye(4, dtype=np.float32).tolist()), "cat", None)
+    sc.param_map["Mesh[0]"].set_transform(psdr.Matrix4fD([[1., 0., 0., P * 100.], [0., 1., 0., 0.], [0., 0., 1., 0.], [0., 0., 0., 1.]]))
+    sc.configure()
+    sc.configure([0])
+    sil = psdr.FieldExtractionIntegrator("silhouette").renderD(sc, 0, seed=1)
+    assert 0.02 < float(sil.detach().mean()) < 0.5
+    d = psdr.forward_grad(sil, P)
+    assert float(d.abs().sum()) > 0                       # the silhouette moves with the box (primary-edge term)
+    sil.sum().backward()
+    assert abs(float(P.grad) - float(d.sum())) < 1e-3 * max(1.0, abs(float(d.sum())))
+    assert float(psdr.PathTracer(0).renderC(sc, 0, seed=1).abs().max()) == 0.0
+    with pytest.raises(RuntimeError, match="No Emitter"):
+        psdr.PathTracer(1).renderC(sc, 0, seed=1)
