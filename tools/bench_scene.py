@@ -1,0 +1,23 @@
+"""Per-term renderD timings of a named test scene (tests/scenes.py) at the C3 settings: 512x512, spp = sppe = sppse = 32, depth 3.
+    python tools/bench_scene.py sphere|cbox|envballs"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import __graft_entry__; __graft_entry__.build()
+import scenes, product
+import psdr_jit_amd as psdr
+name = sys.argv[1] if len(sys.argv) > 1 else "sphere"
+res, spp = 512, 32
+spec = {"sphere": lambda: scenes.sphere_scene(res, res, spp, spp, spp),
+        "cbox": lambda: scenes.cbox_scene(res, res, spp, spp, spp),
+        "envballs": lambda: scenes.envmap_scene(res, res, spp, spp, spp, param="albedo", balls=True)}[name]()
+sc = product.build_scene(spec)
+integ = psdr.PathTracer(3)
+for terms, label in ((1, "interior"), (2, "primary"), (4, "secondary"), (7, "all")):
+    psdr.render_d_fwd(integ, sc, 0, seed=1, terms=terms); torch.cuda.synchronize()
+    t0 = time.time()
+    for i in range(5): psdr.render_d_fwd(integ, sc, 0, seed=i, terms=terms)
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / 5
+    print("%-8s renderD %-9s %8.2f ms  %8.1f Msamples/s" % (name, label, dt * 1e3, res * res * spp / dt / 1e6))
