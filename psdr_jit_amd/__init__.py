@@ -161,6 +161,35 @@ class Bitmap3fD:
         return (self.data.shape[1], self.data.shape[0])
 
 
+class Bitmap1fD:
+    """Stand-in for the reference's Bitmap1fD: an [H, W] array (Bitmap1fD(), Bitmap1fD(value), Bitmap1fD(width, height, data))."""
+
+    def __init__(self, *args):
+        if len(args) == 0:
+            self.data = _np.zeros((1, 1), _np.float32)
+        elif len(args) == 1:
+            a = args[0].detach().cpu().numpy() if isinstance(args[0], _torch.Tensor) else _np.asarray(args[0], _np.float32)
+            self.data = a.reshape(1, 1) if a.size == 1 else _np.ascontiguousarray(a, _np.float32)
+        else:
+            w, h, d = args
+            d = d.detach().cpu().numpy() if isinstance(d, _torch.Tensor) else _np.asarray(d, _np.float32)
+            self.data = _np.ascontiguousarray(d, _np.float32).reshape(int(h), int(w))
+
+    @property
+    def resolution(self):
+        return (self.data.shape[1], self.data.shape[0])
+
+
+def _const_of(x, n):
+    """a constant parameter given as a number/vector or as a 1x1 Bitmap (bitmap parameters larger than 1x1 are not built
+    for the GGX BSDFs)"""
+    if isinstance(x, (Bitmap3fD, Bitmap1fD)):
+        if x.data.size != n:
+            raise RuntimeError("bitmap parameters larger than 1x1 are only built for DiffuseBSDF.reflectance")
+        return x.data.reshape(n)
+    return x
+
+
 def _vtx(self, value):
     return (self.num_vertices, 3)
 
@@ -227,6 +256,7 @@ def _microfacet_init(self, specular=None, diffuse=None, roughness=None):
     if specular is None:
         _MicrofacetBSDF_init(self)
         return
+    specular, diffuse, roughness = _const_of(specular, 3), _const_of(diffuse, 3), _const_of(roughness, 1)
     _MicrofacetBSDF_init(self, _split(specular, (-1,))[0] * _np.ones(3, _np.float32), _split(diffuse, (-1,))[0] * _np.ones(3, _np.float32),
                          float(_split(roughness, (-1,))[0][0]))
     for name, val in (("specularReflectance", specular), ("diffuseReflectance", diffuse), ("roughness", roughness)):
