@@ -55,7 +55,7 @@ typedef struct psdr_mesh_rec {       /* what the kernels need of reference Mesh 
 } psdr_mesh_rec;
 
 typedef struct psdr_bsdf_rec {       /* Diffuse, reference src/bsdf/diffuse.cpp */
-    int32_t type;                    /* 0 = Diffuse, 1 = Microfacet, 2 = RoughConductor */
+    int32_t type;                    /* 0 = Diffuse, 1 = Microfacet, 2 = RoughConductor, 3 = RoughDielectric */
     int32_t two_sided;
     float reflectance[3], d_reflectance[3];
     /* textured reflectance: Bitmap3fD with a resolution above 1x1 (bitmap.cpp:47-128, looked up at its.uv with flip_v);
@@ -69,6 +69,8 @@ typedef struct psdr_bsdf_rec {       /* Diffuse, reference src/bsdf/diffuse.cpp 
     /* type 2 = RoughConductor (src/bsdf/roughconductor.cpp): `specular` is its specular_reflectance, plus */
     float alpha_u, alpha_v, d_alpha_u, d_alpha_v;
     float eta[3], d_eta[3], k[3], d_k[3];
+    /* type 3 = RoughDielectric (src/bsdf/roughdielectric.cpp): alpha_u / alpha_v as above, eta[0] = m_eta = intIOR / extIOR,
+     * eta[1] = m_inv_eta = extIOR / intIOR (the reference stores both), d_eta[0..1] their tangents */
 } psdr_bsdf_rec;
 
 typedef struct psdr_emitter_rec {    /* AreaLight (src/emitter/area.cpp) or EnvironmentMap (src/emitter/envmap.cpp) */

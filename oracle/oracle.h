@@ -37,7 +37,7 @@ typedef struct orc_mesh {            /* reference Mesh, include/psdr/shape/mesh.
 } orc_mesh;
 
 typedef struct orc_bsdf {            /* Diffuse, include/psdr/bsdf/diffuse.h */
-    int type;                        /* 0 = Diffuse, 1 = Microfacet, 2 = RoughConductor */
+    int type;                        /* 0 = Diffuse, 1 = Microfacet, 2 = RoughConductor, 3 = RoughDielectric (alpha_u/v; eta[0] = intIOR/extIOR, eta[1] = extIOR/intIOR) */
     float reflectance[3], d_reflectance[3];
     int two_sided;
     /* textured reflectance (Bitmap3fD with resolution > 1x1, bitmap.cpp:47-128): tex_data != NULL overrides `reflectance` */
@@ -178,6 +178,11 @@ float orc_microfacet_pdf(float roughness, int two_sided, const float wi[3], cons
 int orc_microfacet_sample(float roughness, int two_sided, const float wi[3], const float s3[3], float wo_out[3], float *pdf_out);
 float orc_ggx_eval(float alpha, const float m[3]);
 float orc_fresnel_conductor(float eta, float k, float cos_theta_i);      /* utils.h:166-182 */
+/* RoughDielectric (roughdielectric.cpp): q = {alpha, intIOR/extIOR}; eval out = {value, d/d alpha, d/d eta} */
+void orc_dielectric_eval(const float q[2], const float wi[3], const float wo[3], float out[3]);
+float orc_dielectric_pdf(const float q[2], const float wi[3], const float wo[3]);
+int orc_dielectric_sample(const float q[2], const float wi[3], const float s3[3], float wo_out[3], float *pdf_out);
+void orc_fresnel_dielectric(float eta, float c, float out[4]);   /* F, cos_theta_t, eta_it, eta_ti (utils.h:184-215) */
 
 #ifdef __cplusplus
 }

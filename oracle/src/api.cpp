@@ -70,6 +70,10 @@ float orc_microfacet_pdf(float roughness, int two_sided, const float wi[3], cons
 int orc_microfacet_sample(float roughness, int two_sided, const float wi[3], const float s3[3], float wo_out[3], float *pdf_out) { return orc::kat_microfacet_sample(roughness, two_sided, wi, s3, wo_out, pdf_out); }
 float orc_ggx_eval(float alpha, const float m[3]) { return orc::kat_ggx_eval(alpha, m); }
 float orc_fresnel_conductor(float eta, float k, float c) { return orc::kat_fresnel_conductor(eta, k, c); }
+void orc_dielectric_eval(const float q[2], const float wi[3], const float wo[3], float out[3]) { orc::kat_dielectric_eval(q, wi, wo, out); }
+float orc_dielectric_pdf(const float q[2], const float wi[3], const float wo[3]) { return orc::kat_dielectric_pdf(q, wi, wo); }
+int orc_dielectric_sample(const float q[2], const float wi[3], const float s3[3], float wo_out[3], float *pdf_out) { return orc::kat_dielectric_sample(q, wi, s3, wo_out, pdf_out); }
+void orc_fresnel_dielectric(float eta, float c, float out[4]) { orc::kat_fresnel_dielectric(eta, c, out); }
 void orc_set_direct_mis(orc_scene *s, int mis) { s->sc->direct_mis = mis; }
 void orc_set_field(orc_scene *s, int field, int object, float intensity, float d_intensity) {
     s->sc->field = field; s->sc->field_object = object; s->sc->intensity = orc::Dual(intensity, d_intensity);

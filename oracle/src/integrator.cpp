@@ -340,6 +340,10 @@ template <bool ad> static V3<Real<ad>> bsdf_eval(const Scene &sc, const Its<ad> 
         ConductorParams P{b.alpha_u, b.alpha_v, b.eta, b.k, b.specular, b.two_sided};
         return conductor_eval<ad>(P, its.wi, wo, active);
     }
+    if (b.type == 3) {          // RoughDielectric (roughdielectric.cpp); eta.x = intIOR / extIOR, eta.y = extIOR / intIOR
+        DielectricParams P{b.alpha_u, b.alpha_v, b.eta.x, b.eta.y, b.two_sided};
+        return dielectric_eval<ad>(P, its.wi, wo, active);
+    }
     R wiz = its.wi.z;
     if (b.two_sided) { wo.z = mulsign(wo.z, detach(wiz)); wiz = abs_(wiz); }
     active = active && (detach(wiz) > 0.f && detach(wo.z) > 0.f);
@@ -356,6 +360,10 @@ template <bool ad> static float bsdf_pdf(const Scene &sc, const Its<ad> &its, co
     if (b.type == 2) {
         ConductorParams P{b.alpha_u, b.alpha_v, b.eta, b.k, b.specular, b.two_sided};
         return conductor_pdf(P, detach(its.wi), detach(wo_), active);
+    }
+    if (b.type == 3) {
+        DielectricParams P{b.alpha_u, b.alpha_v, b.eta.x, b.eta.y, b.two_sided};
+        return dielectric_pdf(P, detach(its.wi), detach(wo_), active);
     }
     float wiz = detach(its.wi.z), woz = detach(wo_.z);
     if (b.two_sided) { woz = mulsign(woz, wiz); wiz = fabs(wiz); }
@@ -375,6 +383,12 @@ template <bool ad> static BSDFSample bsdf_sample(const Scene &sc, const Its<ad> 
     if (b.type == 2) {
         ConductorParams P{b.alpha_u, b.alpha_v, b.eta, b.k, b.specular, b.two_sided};
         const MicrofacetSample m = conductor_sample(P, detach(its.wi), s3, active);
+        BSDFSample r; r.wo = m.wo; r.pdf = m.pdf; r.valid = m.valid;
+        return r;
+    }
+    if (b.type == 3) {
+        DielectricParams P{b.alpha_u, b.alpha_v, b.eta.x, b.eta.y, b.two_sided};
+        const MicrofacetSample m = dielectric_sample(P, detach(its.wi), s3, active);
         BSDFSample r; r.wo = m.wo; r.pdf = m.pdf; r.valid = m.valid;
         return r;
     }
@@ -615,6 +629,30 @@ int kat_microfacet_sample(float roughness, int two_sided, const float *wi, const
 }
 float kat_ggx_eval(float alpha, const float *m) { GGX<float> g{alpha, alpha}; return g.eval(V3f(m[0], m[1], m[2])); }
 float kat_fresnel_conductor(float eta, float k, float c) { return fresnel_conductor<float>(eta, k, c); }
+// RoughDielectric hooks: q = {alpha, eta}; eval out = value (scalar), d/d(alpha), d/d(eta)
+static DielectricParams kat_dielectric_params(const float *q, float da, float de) {
+    DielectricParams P; P.alpha_u = Dual(q[0], da); P.alpha_v = Dual(q[0], da); P.eta = Dual(q[1], de);
+    P.inv_eta = Dual(1.f / q[1], -de / (q[1] * q[1])); P.two_sided = false;
+    return P;
+}
+void kat_dielectric_eval(const float *q, const float *wi, const float *wo, float *out) {
+    const V3f a(wi[0], wi[1], wi[2]), b(wo[0], wo[1], wo[2]);
+    out[0] = dielectric_eval<false>(kat_dielectric_params(q, 0.f, 0.f), a, b, true).x;
+    out[1] = dielectric_eval<true>(kat_dielectric_params(q, 1.f, 0.f), V3d(a), V3d(b), true).x.d;
+    out[2] = dielectric_eval<true>(kat_dielectric_params(q, 0.f, 1.f), V3d(a), V3d(b), true).x.d;
+}
+float kat_dielectric_pdf(const float *q, const float *wi, const float *wo) {
+    return dielectric_pdf(kat_dielectric_params(q, 0.f, 0.f), V3f(wi[0], wi[1], wi[2]), V3f(wo[0], wo[1], wo[2]), true);
+}
+int kat_dielectric_sample(const float *q, const float *wi, const float *s3, float *wo_out, float *pdf_out) {
+    const MicrofacetSample m = dielectric_sample(kat_dielectric_params(q, 0.f, 0.f), V3f(wi[0], wi[1], wi[2]), s3, true);
+    wo_out[0] = m.wo.x; wo_out[1] = m.wo.y; wo_out[2] = m.wo.z; *pdf_out = m.pdf;
+    return m.valid ? 1 : 0;
+}
+void kat_fresnel_dielectric(float eta, float c, float *out) {
+    float F, ct, it, ti; fresnel_dielectric<float>(eta, c, F, ct, it, ti);
+    out[0] = F; out[1] = ct; out[2] = it; out[3] = ti;
+}
 void kat_cosine_hemisphere(float sx, float sy, float *o) { V3f v = square_to_cosine_hemisphere(sx, sy); o[0] = v.x; o[1] = v.y; o[2] = v.z; }
 void kat_uniform_triangle(float sx, float sy, float *o) { square_to_uniform_triangle(sx, sy, o[0], o[1]); }
 void kat_coordinate_system(const float *n, float *s, float *t) {

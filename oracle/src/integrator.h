@@ -62,6 +62,10 @@ float kat_microfacet_pdf(float roughness, int two_sided, const float *wi, const 
 int kat_microfacet_sample(float roughness, int two_sided, const float *wi, const float *s3, float *wo_out, float *pdf_out);
 float kat_ggx_eval(float alpha, const float *m);
 float kat_fresnel_conductor(float eta, float k, float c);
+void kat_dielectric_eval(const float *q, const float *wi, const float *wo, float *out);
+float kat_dielectric_pdf(const float *q, const float *wi, const float *wo);
+int kat_dielectric_sample(const float *q, const float *wi, const float *s3, float *wo_out, float *pdf_out);
+void kat_fresnel_dielectric(float eta, float c, float *out);
 void kat_cosine_hemisphere(float sx, float sy, float *o);
 void kat_uniform_triangle(float sx, float sy, float *o);
 void kat_coordinate_system(const float *n, float *s, float *t);

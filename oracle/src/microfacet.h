@@ -188,4 +188,96 @@ inline MicrofacetSample conductor_sample(const ConductorParams &P, V3f wi, const
     return bs;
 }
 
+// ---------------------------------------------------------------- RoughDielectric (reference src/bsdf/roughdielectric.cpp:35-237)
+struct DielectricParams { Dual alpha_u, alpha_v, eta, inv_eta; bool two_sided; };
+
+// fresnel_dielectric, reference include/psdr/utils.h:184-215: returns F, cos_theta_t, eta_it, eta_ti
+template <typename R> void fresnel_dielectric(const R &eta, const R &cos_theta_i, R &F, R &cos_theta_t, R &eta_it, R &eta_ti) {
+    const bool outside = detach(cos_theta_i) >= 0.f;
+    const R rcp_eta = rcp(eta);
+    eta_it = outside ? eta : rcp_eta;
+    eta_ti = outside ? rcp_eta : eta;
+    const R cos_theta_t_sqr = fma_(-fma_(-cos_theta_i, cos_theta_i, R(1.f)), eta_ti * eta_ti, R(1.f));
+    const R cos_theta_i_abs = abs_(cos_theta_i), cos_theta_t_abs = safe_sqrt(cos_theta_t_sqr);
+    const bool index_matched = detach(eta) == 1.f, special = index_matched || detach(cos_theta_i_abs) == 0.f;
+    const R a_s = fma_(-eta_it, cos_theta_t_abs, cos_theta_i_abs) / fma_(eta_it, cos_theta_t_abs, cos_theta_i_abs);
+    const R a_p = fma_(-eta_it, cos_theta_i_abs, cos_theta_t_abs) / fma_(eta_it, cos_theta_i_abs, cos_theta_t_abs);
+    F = R(.5f) * (sqr(a_s) + sqr(a_p));
+    if (special) F = index_matched ? R(0.f) : R(1.f);
+    cos_theta_t = std::signbit(detach(cos_theta_i)) ? cos_theta_t_abs : -cos_theta_t_abs;       // mulsign_neg
+}
+
+template <bool ad> V3<Real<ad>> dielectric_eval(const DielectricParams &P, V3<Real<ad>> wi, V3<Real<ad>> wo, bool active) {
+    using R = Real<ad>; using V = V3<R>;
+    if (P.two_sided) { wo.z = mulsign(wo.z, detach(wi.z)); wi.z = abs_(wi.z); }
+    const R cos_theta_i = wi.z, cos_theta_o = wo.z;
+    active = active && detach(cos_theta_i) != 0.f;
+    if (!active) return V(R(0.f));
+    const bool reflect = detach(cos_theta_i) * detach(cos_theta_o) > 0.f;
+    const bool front = detach(cos_theta_i) > 0.f;
+    const R eta = front ? pick<ad>(P.eta) : pick<ad>(P.inv_eta), inv_eta = front ? pick<ad>(P.inv_eta) : pick<ad>(P.eta);
+    V m = normalize(wi + wo * (reflect ? R(1.f) : eta));
+    if (std::signbit(detach(m.z))) m = -m;                                          // mulsign(m, cos_theta(m))
+    GGX<R> distr{pick<ad>(P.alpha_u), pick<ad>(P.alpha_v)};
+    const R D = distr.eval(m);
+    R F, ct, e_it, e_ti;
+    fresnel_dielectric<R>(pick<ad>(P.eta), dot(wi, m), F, ct, e_it, e_ti);
+    const R G = distr.smith_g1(wi, m) * distr.smith_g1(wo, m);
+    if (reflect) return V(F * D * G / (R(4.f) * abs_(cos_theta_i)));
+    const R scale = sqr(inv_eta);
+    const R value = abs_((scale * (R(1.f) - F) * D * G * eta * eta * dot(wi, m) * dot(wo, m)) / (cos_theta_i * sqr(dot(wi, m) + eta * dot(wo, m))));
+    return V(value);
+}
+inline float dielectric_pdf(const DielectricParams &P, V3f wi, V3f wo, bool active) {
+    if (P.two_sided) { wo.z = mulsign(wo.z, wi.z); wi.z = std::fabs(wi.z); }
+    const float cos_theta_i = wi.z, cos_theta_o = wo.z;
+    active = active && cos_theta_i != 0.f;
+    const bool reflect = cos_theta_i * cos_theta_o > 0.f;
+    const float eta = cos_theta_i > 0.f ? P.eta.v : P.inv_eta.v;
+    V3f m = normalize(wi + wo * (reflect ? 1.f : eta));
+    if (std::signbit(m.z)) m = -m;
+    active = active && dot(wi, m) * wi.z > 0.f && dot(wo, m) * wo.z > 0.f;
+    if (!active) return 0.f;
+    const float dwh_dwo = reflect ? 1.f / (4.f * dot(wo, m)) : (eta * eta * dot(wo, m)) / sqr(dot(wi, m) + eta * dot(wo, m));
+    GGX<float> distr{P.alpha_u.v, P.alpha_v.v};
+    const V3f pwi = std::signbit(wi.z) ? -wi : wi;
+    float prob = distr.eval(m) * distr.smith_g1(pwi, m) / pwi.z;
+    float F, ct, e_it, e_ti;
+    fresnel_dielectric<float>(P.eta.v, dot(wi, m), F, ct, e_it, e_ti);
+    prob *= reflect ? F : 1.f - F;
+    return prob * std::fabs(dwh_dwo);
+}
+inline MicrofacetSample dielectric_sample(const DielectricParams &P, V3f wi, const float s3[3], bool active) {
+    if (P.two_sided) wi.z = std::fabs(wi.z);
+    MicrofacetSample bs;
+    bs.wo = V3f(0.f, 0.f, 0.f); bs.pdf = 0.f; bs.valid = false;
+    const float cos_theta_i = wi.z;
+    active = active && cos_theta_i != 0.f;
+    const V3f pwi = std::signbit(cos_theta_i) ? -wi : wi;
+    float m_pdf;
+    const V3f m = ggx_sample(P.alpha_u.v, P.alpha_v.v, pwi, s3[0], s3[1], m_pdf);
+    active = active && m_pdf != 0.f;
+    float F, cos_theta_t, eta_it, eta_ti;
+    fresnel_dielectric<float>(P.eta.v, dot(wi, m), F, cos_theta_t, eta_it, eta_ti);
+    const bool sel_r = (s3[2] <= F) && active, sel_t = !sel_r && active;
+    float pdf = m_pdf * (sel_r ? F : 1.f - F);
+    const float bs_eta = sel_r ? 1.f : eta_it;
+    float dwh_dwo = 0.f;
+    if (sel_r) {
+        const float k = 2.f * dot(wi, m);
+        bs.wo = V3f(fma_(m.x, k, -wi.x), fma_(m.y, k, -wi.y), fma_(m.z, k, -wi.z));
+        dwh_dwo = 1.f / (4.f * dot(bs.wo, m));
+    }
+    if (sel_t) {
+        const float k = fma_(dot(wi, m), eta_ti, cos_theta_t);
+        bs.wo = V3f(fma_(m.x, k, -(wi.x * eta_ti)), fma_(m.y, k, -(wi.y * eta_ti)), fma_(m.z, k, -(wi.z * eta_ti)));
+        dwh_dwo = (sqr(bs_eta) * dot(bs.wo, m)) / sqr(dot(wi, m) + bs_eta * dot(bs.wo, m));
+    }
+    GGX<float> distr{P.alpha_u.v, P.alpha_v.v};
+    pdf *= std::fabs(dwh_dwo) * distr.smith_g1(bs.wo, m);
+    bs.pdf = pdf;
+    bs.valid = active && (sel_t || sel_r);
+    return bs;
+}
+
 } // namespace orc

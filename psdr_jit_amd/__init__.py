@@ -37,6 +37,7 @@ Emitter = _core.Emitter
 AreaLight = _core.AreaLight
 MicrofacetBSDF = _core.MicrofacetBSDF
 RoughConductorBSDF = _core.RoughConductorBSDF
+RoughDielectricBSDF = _core.RoughDielectricBSDF
 EnvironmentMap = _core.EnvironmentMap
 Sensor = _core.Sensor
 PerspectiveCamera = _core.PerspectiveCamera
@@ -206,6 +207,8 @@ for _n in ("alpha_u", "alpha_v"):
     setattr(RoughConductorBSDF, _n, _make_param_property(_n, lambda self, value: (1,)))
 for _n in ("eta", "k", "specular_reflectance"):
     setattr(RoughConductorBSDF, _n, _make_param_property(_n, _v3))
+for _n in ("alpha_u", "alpha_v", "eta"):
+    setattr(RoughDielectricBSDF, _n, _make_param_property(_n, lambda self, value: (1,)))
 AreaLight.radiance = _make_param_property("radiance", _v3)
 
 
@@ -287,6 +290,23 @@ def _roughconductor_init(self, *args):
 
 
 RoughConductorBSDF.__init__ = _roughconductor_init
+_RoughDielectricBSDF_init = RoughDielectricBSDF.__init__
+
+
+def _roughdielectric_init(self, *args):
+    """RoughDielectricBSDF(), (intIOR, extIOR) or (alpha, intIOR, extIOR) (reference roughdielectric.h:10-27; alpha a constant
+    or a 1x1 Bitmap1fD).  The reference binds the class without a constructor (psdr.cpp:295) and only builds it from XML."""
+    if len(args) == 3:
+        _RoughDielectricBSDF_init(self, float(args[1]), float(args[2]))
+        a = float(_np.ravel(_split(_const_of(args[0], 1), (-1,))[0])[0])
+        self.alpha_u, self.alpha_v = [a], [a]
+    elif len(args) == 2:
+        _RoughDielectricBSDF_init(self, float(args[0]), float(args[1]))
+    else:
+        _RoughDielectricBSDF_init(self)
+
+
+RoughDielectricBSDF.__init__ = _roughdielectric_init
 _AreaLight_init = AreaLight.__init__
 
 

@@ -151,4 +151,94 @@ PSDR_DEV Vec3<R> conductor_eval(const R &au, const R &av, const Vec3<R> &eta, co
     return F * result * spec;
 }
 
+// ---------------------------------------------------------------- RoughDielectric, reference src/bsdf/roughdielectric.cpp:35-237
+// fresnel_dielectric, reference include/psdr/utils.h:184-215
+template <typename R> PSDR_DEV void fresnel_dielectric(const R &eta, const R &cos_theta_i, R &F, R &cos_theta_t, R &eta_it, R &eta_ti) {
+    const bool outside = detach(cos_theta_i) >= 0.f;
+    const R rcp_eta = rcp_(eta);
+    eta_it = outside ? eta : rcp_eta;
+    eta_ti = outside ? rcp_eta : eta;
+    const R cos_theta_t_sqr = fma_(-fma_(-cos_theta_i, cos_theta_i, R(1.f)), eta_ti * eta_ti, R(1.f));
+    const R cos_theta_i_abs = abs_(cos_theta_i), cos_theta_t_abs = safe_sqrt(cos_theta_t_sqr);
+    const bool index_matched = detach(eta) == 1.f, special = index_matched || detach(cos_theta_i_abs) == 0.f;
+    const R a_s = fma_(-eta_it, cos_theta_t_abs, cos_theta_i_abs) / fma_(eta_it, cos_theta_t_abs, cos_theta_i_abs);
+    const R a_p = fma_(-eta_it, cos_theta_i_abs, cos_theta_t_abs) / fma_(eta_it, cos_theta_i_abs, cos_theta_t_abs);
+    F = R(.5f) * (sqr(a_s) + sqr(a_p));
+    if (special) F = index_matched ? R(0.f) : R(1.f);
+    cos_theta_t = signbit_(detach(cos_theta_i)) ? cos_theta_t_abs : -cos_theta_t_abs;      // mulsign_neg
+}
+
+// eta_p = intIOR / extIOR, inv_eta_p = extIOR / intIOR (RoughDielectric::m_eta, m_inv_eta)
+template <typename R>
+PSDR_DEV Vec3<R> dielectric_eval(const R &au, const R &av, const R &eta_p, const R &inv_eta_p, bool two_sided, Vec3<R> wi, Vec3<R> wo, bool active) {
+    using V = Vec3<R>;
+    if (two_sided) { wo.z = mulsign(wo.z, detach(wi.z)); wi.z = abs_(wi.z); }
+    const R cos_theta_i = wi.z, cos_theta_o = wo.z;
+    if (!(active && detach(cos_theta_i) != 0.f)) return V(R(0.f));
+    const bool reflect = detach(cos_theta_i) * detach(cos_theta_o) > 0.f;
+    const bool front = detach(cos_theta_i) > 0.f;
+    const R eta = front ? eta_p : inv_eta_p, inv_eta = front ? inv_eta_p : eta_p;
+    V m = normalize(wi + wo * (reflect ? R(1.f) : eta));
+    if (signbit_(detach(m.z))) m = -m;
+    GGX<R> distr{au, av};
+    const R D = distr.eval(m);
+    R F, ct, e_it, e_ti;
+    fresnel_dielectric<R>(eta_p, dot(wi, m), F, ct, e_it, e_ti);
+    const R G = distr.smith_g1(wi, m) * distr.smith_g1(wo, m);
+    if (reflect) return V(F * D * G / (R(4.f) * abs_(cos_theta_i)));
+    const R scale = sqr(inv_eta);
+    const R value = abs_((scale * (R(1.f) - F) * D * G * eta * eta * dot(wi, m) * dot(wo, m)) / (cos_theta_i * sqr(dot(wi, m) + eta * dot(wo, m))));
+    return V(value);
+}
+PSDR_DEV float dielectric_pdf(float au, float av, float eta_p, float inv_eta_p, bool two_sided, Vec3f wi, Vec3f wo, bool active) {
+    if (two_sided) { wo.z = mulsign(wo.z, wi.z); wi.z = fabsf(wi.z); }
+    const float cos_theta_i = wi.z, cos_theta_o = wo.z;
+    active = active && cos_theta_i != 0.f;
+    const bool reflect = cos_theta_i * cos_theta_o > 0.f;
+    const float eta = cos_theta_i > 0.f ? eta_p : inv_eta_p;
+    Vec3f m = normalize(wi + wo * (reflect ? 1.f : eta));
+    if (signbit_(m.z)) m = -m;
+    active = active && dot(wi, m) * wi.z > 0.f && dot(wo, m) * wo.z > 0.f;
+    if (!active) return 0.f;
+    const float dwh_dwo = reflect ? 1.f / (4.f * dot(wo, m)) : (eta * eta * dot(wo, m)) / sqr(dot(wi, m) + eta * dot(wo, m));
+    GGX<float> distr{au, av};
+    const Vec3f pwi = signbit_(wi.z) ? -wi : wi;
+    float prob = distr.eval(m) * distr.smith_g1(pwi, m) / pwi.z;
+    float F, ct, e_it, e_ti;
+    fresnel_dielectric<float>(eta_p, dot(wi, m), F, ct, e_it, e_ti);
+    prob *= reflect ? F : 1.f - F;
+    return prob * fabsf(dwh_dwo);
+}
+PSDR_DEV void dielectric_sample(float au, float av, float eta_p, bool two_sided, Vec3f wi, float s0, float s1, float s2, bool active,
+                                Vec3f &wo, float &pdf_out, bool &valid) {
+    if (two_sided) wi.z = fabsf(wi.z);
+    wo = Vec3f(0.f, 0.f, 0.f);
+    const float cos_theta_i = wi.z;
+    active = active && cos_theta_i != 0.f;
+    const Vec3f pwi = signbit_(cos_theta_i) ? -wi : wi;
+    float m_pdf;
+    const Vec3f m = ggx_sample(au, av, pwi, s0, s1, m_pdf);
+    active = active && m_pdf != 0.f;
+    float F, cos_theta_t, eta_it, eta_ti;
+    fresnel_dielectric<float>(eta_p, dot(wi, m), F, cos_theta_t, eta_it, eta_ti);
+    const bool sel_r = (s2 <= F) && active, sel_t = !sel_r && active;
+    float pdf = m_pdf * (sel_r ? F : 1.f - F);
+    const float bs_eta = sel_r ? 1.f : eta_it;
+    float dwh_dwo = 0.f;
+    if (sel_r) {
+        const float k = 2.f * dot(wi, m);
+        wo = Vec3f(fma_(m.x, k, -wi.x), fma_(m.y, k, -wi.y), fma_(m.z, k, -wi.z));
+        dwh_dwo = 1.f / (4.f * dot(wo, m));
+    }
+    if (sel_t) {
+        const float k = fma_(dot(wi, m), eta_ti, cos_theta_t);
+        wo = Vec3f(fma_(m.x, k, -(wi.x * eta_ti)), fma_(m.y, k, -(wi.y * eta_ti)), fma_(m.z, k, -(wi.z * eta_ti)));
+        dwh_dwo = (sqr(bs_eta) * dot(wo, m)) / sqr(dot(wi, m) + bs_eta * dot(wo, m));
+    }
+    GGX<float> distr{au, av};
+    pdf *= fabsf(dwh_dwo) * distr.smith_g1(wo, m);
+    pdf_out = pdf;
+    valid = active && (sel_t || sel_r);
+}
+
 } // namespace psdr

@@ -379,6 +379,19 @@ template <bool AD, bool LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S
             }
         }
     }
+    if constexpr (!LDS) {
+        if (__float_as_int(a.w) & 16) {        // RoughDielectric (roughdielectric.cpp): eta[0] = intIOR/extIOR, eta[1] = extIOR/intIOR
+            const MatDev md = S.T->mat[mesh_bsdf(S, its.mesh)];
+            const bool two = (__float_as_int(a.w) & 1) != 0;
+            if constexpr (AD) {
+                const float t = S.mode == 0 ? 1.f : 0.f;
+                return dielectric_eval<Dual>(Dual(md.alpha_u, t * md.d_alpha_u), Dual(md.alpha_v, t * md.d_alpha_v), Dual(md.eta[0], t * md.d_eta[0]),
+                                             Dual(md.eta[1], t * md.d_eta[1]), two, its.wi, wo, active);
+            } else {
+                return dielectric_eval<float>(md.alpha_u, md.alpha_v, md.eta[0], md.eta[1], two, its.wi, wo, active);
+            }
+        }
+    }
     R wiz = its.wi.z;
     if (__float_as_int(a.w) & 1) { wo.z = mulsign(wo.z, detach(wiz)); wiz = abs_(wiz); }
     if (!(active && detach(wiz) > 0.f && detach(wo.z) > 0.f)) return V(R(0.f));
@@ -413,6 +426,10 @@ template <bool AD, bool LDS> PSDR_DEV float bsdf_pdf(const SceneView<LDS> &S, co
             const MatDev md = S.T->mat[mesh_bsdf(S, its.mesh)];
             const bool mf = (__float_as_int(a.w) & 4) != 0;
             return ggx_pdf(mf ? sqr(md.roughness) : md.alpha_u, mf ? sqr(md.roughness) : md.alpha_v, (__float_as_int(a.w) & 1) != 0, detach(its.wi), detach(wo), active);
+        }
+        if (__float_as_int(a.w) & 16) {
+            const MatDev md = S.T->mat[mesh_bsdf(S, its.mesh)];
+            return dielectric_pdf(md.alpha_u, md.alpha_v, md.eta[0], md.eta[1], (__float_as_int(a.w) & 1) != 0, detach(its.wi), detach(wo), active);
         }
     }
     float wiz = detach(its.wi.z), woz = detach(wo.z);
@@ -465,6 +482,12 @@ template <bool AD, bool LDS> PSDR_DEV BSDFSample bsdf_sample(const SceneView<LDS
             const bool mf = (__float_as_int(a.w) & 4) != 0;
             ggx_reflect_sample(mf ? sqr(md.roughness) : md.alpha_u, mf ? sqr(md.roughness) : md.alpha_v, (__float_as_int(a.w) & 1) != 0, detach(its.wi), s0, s1, active,
                                m.wo, m.pdf, m.valid);
+            return m;
+        }
+        if (__float_as_int(a.w) & 16) {        // RoughDielectric::sample: the third number picks reflection or refraction
+            BSDFSample m;
+            const MatDev md = S.T->mat[mesh_bsdf(S, its.mesh)];
+            dielectric_sample(md.alpha_u, md.alpha_v, md.eta[0], (__float_as_int(a.w) & 1) != 0, detach(its.wi), s0, s1, s2, active, m.wo, m.pdf, m.valid);
             return m;
         }
     }

@@ -119,6 +119,21 @@ PYBIND11_MODULE(_psdr_core, m) {
             else if (name == "k") { b.k = to_a3(v); b.d_k = to_a3(t); }
             else { b.specular = to_a3(v); b.d_specular = to_a3(t); } });
 
+    py::class_<RoughDielectric, BSDF>(m, "RoughDielectricBSDF", py::dynamic_attr())
+        .def(py::init<>())
+        .def(py::init<float, float>())
+        .def("_get", [](const RoughDielectric &b, const std::string &name, bool tangent) {
+            farr a(1);
+            a.mutable_data()[0] = name == "alpha_u" ? (tangent ? b.d_alpha_u : b.alpha_u) : name == "alpha_v" ? (tangent ? b.d_alpha_v : b.alpha_v)
+                                : name == "eta" ? (tangent ? b.d_eta : b.eta) : (tangent ? b.d_inv_eta : b.inv_eta);
+            return a; })
+        .def("_set", [](RoughDielectric &b, const std::string &name, const farr &v, const farr &t) {
+            const float x = v.data()[0], dx = t.size() ? t.data()[0] : 0.f;
+            if (name == "alpha_u") { b.alpha_u = x; b.d_alpha_u = dx; }
+            else if (name == "alpha_v") { b.alpha_v = x; b.d_alpha_v = dx; }
+            else if (name == "eta") { b.eta = x; b.d_eta = dx; b.inv_eta = 1.f / x; b.d_inv_eta = -dx / (x * x); }
+            else { b.inv_eta = x; b.d_inv_eta = dx; } });
+
     py::class_<Emitter, Object>(m, "Emitter", py::dynamic_attr());
     py::class_<AreaLight, Emitter>(m, "AreaLight", py::dynamic_attr())
         .def(py::init([](const farr &r) { return new AreaLight(to_a3(r)); }))

@@ -422,10 +422,11 @@ void Scene::add_BSDF(const BSDF *bsdf, const std::string &bsdf_id, bool twoSide)
     const Diffuse *d = dynamic_cast<const Diffuse *>(bsdf);
     const Microfacet *mf = dynamic_cast<const Microfacet *>(bsdf);
     const RoughConductor *rc = dynamic_cast<const RoughConductor *>(bsdf);
-    PSDR_ASSERT_MSG(d != nullptr || mf != nullptr || rc != nullptr, "Unknown BSDF type!");
-    if (m_opts.log_level > 0) std::cout << "add_BSDF: " << (d ? "Diffuse " : (mf ? "Microfacet " : "RoughConductor ")) << bsdf_id << std::endl;
+    const RoughDielectric *rd = dynamic_cast<const RoughDielectric *>(bsdf);     // (the reference only reaches it through the XML loader)
+    PSDR_ASSERT_MSG(d != nullptr || mf != nullptr || rc != nullptr || rd != nullptr, "Unknown BSDF type!");
+    if (m_opts.log_level > 0) std::cout << "add_BSDF: " << bsdf->type_name() << " " << bsdf_id << std::endl;
     PSDR_ASSERT_MSG(m_param_map.find("BSDF[id=" + bsdf_id + "]") == m_param_map.end(), std::string("Duplicate BSDF id: ") + bsdf_id);
-    BSDF *c = d ? static_cast<BSDF *>(new Diffuse(*d)) : (mf ? static_cast<BSDF *>(new Microfacet(*mf)) : static_cast<BSDF *>(new RoughConductor(*rc)));
+    BSDF *c = d ? static_cast<BSDF *>(new Diffuse(*d)) : (mf ? static_cast<BSDF *>(new Microfacet(*mf)) : (rc ? static_cast<BSDF *>(new RoughConductor(*rc)) : static_cast<BSDF *>(new RoughDielectric(*rd))));
     c->m_twoSide = twoSide; c->m_id = bsdf_id;
     m_bsdfs.push_back(c);
     rebuild_param_map();
@@ -648,6 +649,14 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
                 r.eta[k] = rc->eta[k]; r.d_eta[k] = rc->d_eta[k]; r.k[k] = rc->k[k]; r.d_k[k] = rc->d_k[k];
                 r.specular[k] = rc->specular[k]; r.d_specular[k] = rc->d_specular[k];
             }
+            S.bsdfs.push_back(r);
+            continue;
+        }
+        if (const RoughDielectric *rd = dynamic_cast<const RoughDielectric *>(b)) {
+            psdr_bsdf_rec r{};
+            r.type = 3; r.two_sided = rd->m_twoSide ? 1 : 0;
+            r.alpha_u = rd->alpha_u; r.alpha_v = rd->alpha_v; r.d_alpha_u = rd->d_alpha_u; r.d_alpha_v = rd->d_alpha_v;
+            r.eta[0] = rd->eta; r.eta[1] = rd->inv_eta; r.d_eta[0] = rd->d_eta; r.d_eta[1] = rd->d_inv_eta;
             S.bsdfs.push_back(r);
             continue;
         }

@@ -93,6 +93,17 @@ struct RoughConductor : BSDF {
     std::array<float, 3> eta{0, 0, 0}, k{1, 1, 1}, specular{1, 1, 1}, d_eta{0, 0, 0}, d_k{0, 0, 0}, d_specular{0, 0, 0};
 };
 
+// RoughDielectric, reference include/psdr/bsdf/roughdielectric.h (constant alpha; m_eta = intIOR / extIOR, m_inv_eta = extIOR / intIOR)
+struct RoughDielectric : BSDF {
+    RoughDielectric() { eta = 1.5f / 1.0f; inv_eta = 1.f / eta; }
+    RoughDielectric(float intIOR, float extIOR) : eta(intIOR / extIOR), inv_eta(extIOR / intIOR) {}
+    std::string type_name() const override { return "RoughDielectric"; }
+    std::string to_string() const override { return std::string("RoughDielectric[id=") + m_id + "]"; }
+    bool anisotropic() const override { return false; }
+    float alpha_u = 0.1f, alpha_v = 0.1f, d_alpha_u = 0.f, d_alpha_v = 0.f;
+    float eta, inv_eta, d_eta = 0.f, d_inv_eta = 0.f;
+};
+
 struct Mesh;
 struct Emitter : Object { float m_sampling_weight = 1.f; bool m_ready = false; };
 struct AreaLight : Emitter {

@@ -177,8 +177,14 @@ def load_scene(root, scene, psdr, base_dir=None):
             if any(n.tag == "texture" for n in nodes):
                 raise _Err("RoughConductorBSDF: bitmap parameters are not built, only constants")
             b = psdr.RoughConductorBSDF(float(nodes[0].get("value")), _load_rgb(nodes[1]), _load_rgb(nodes[2]))
-        elif btype in ("roughdielectric", "normalmap"):
-            raise _Err("Unknown BSDF type! (%s: the GGX BSDF family is not built)" % btype)
+        elif btype == "roughdielectric":     # scene_loader.cpp:346-360
+            alpha = _child_by_name(node, {"alpha"})
+            if alpha.tag == "texture":
+                raise _Err("RoughDielectricBSDF: bitmap parameters are not built, only constants")
+            ior = [_child_by_name(node, {"intIOR"}), _child_by_name(node, {"extIOR"})]
+            b = psdr.RoughDielectricBSDF(float(alpha.get("value")), float(ior[0].get("value")), float(ior[1].get("value")))
+        elif btype == "normalmap":
+            raise _Err("Unknown BSDF type! (normalmap is not built)")
         else:
             raise _Err("Unsupported BSDF: " + str(btype))
         scene.add_BSDF(b, bsdf_id)

@@ -32,6 +32,13 @@ def build_scene(spec, configure=True, active=(0,), host_only=False, log_level=0)
             bs._set("specular_reflectance", np.asarray(b.specular, np.float32), np.asarray(b.d_specular, np.float32))
             sc.add_BSDF(bs, b.name or ("bsdf%d" % i), b.two_sided)
             continue
+        if getattr(b, "type", 0) == 3:
+            bs = psdr.RoughDielectricBSDF()
+            f1 = lambda x: np.asarray([x], np.float32)
+            bs._set("alpha_u", f1(b.alpha_u), f1(b.d_alpha_u)); bs._set("alpha_v", f1(b.alpha_v), f1(b.d_alpha_v))
+            bs._set("eta", f1(b.eta[0]), f1(b.d_eta[0])); bs._set("inv_eta", f1(b.eta[1]), f1(b.d_eta[1]))
+            sc.add_BSDF(bs, b.name or ("bsdf%d" % i), b.two_sided)
+            continue
         bs = psdr.DiffuseBSDF(list(b.reflectance))
         bs._set("reflectance", np.asarray(b.reflectance, np.float32), np.asarray(b.d_reflectance, np.float32))
         if getattr(b, "texture", None) is not None:

@@ -336,3 +336,26 @@ def conductor_cbox_scene(width=48, height=48, spp=8, sppe=0, sppse=0, param="alp
     elif param is not None:
         raise ValueError(param)
     return spec
+
+
+def dielectric_cbox_scene(width=48, height=48, spp=8, sppe=0, sppse=0, param="alpha"):
+    """The README Cornell box with a rough-glass small box (one-sided: rays refract in and out through the closed mesh) and a
+    two-sided frosted tall box (reference src/bsdf/roughdielectric.cpp).  param: 'alpha' | 'eta' | 'box_x' | None (small box)"""
+    spec = cbox_scene(width, height, spp, sppe, sppse, param=None)
+    e1, e2 = np.float32(1.5), np.float32(1.33)
+    spec.bsdfs.append(BsdfSpec(name="glass", type=3, alpha_u=0.12, alpha_v=0.12, eta=(float(e1), float(np.float32(1.0) / e1), 0.0)))
+    spec.bsdfs.append(BsdfSpec(name="frosted", type=3, alpha_u=0.4, alpha_v=0.4, eta=(float(e2), float(np.float32(1.0) / e2), 0.0), two_sided=True))
+    spec.meshes[1].bsdf = 5
+    spec.meshes[2].bsdf = 6
+    g = spec.bsdfs[5]
+    if param == "alpha":
+        g.d_alpha_u, g.d_alpha_v = 1.0, 1.0
+    elif param == "eta":
+        g.d_eta = (1.0, float(-np.float32(1.0) / (e1 * e1)), 0.0)
+    elif param == "box_x":
+        dT = np.zeros((4, 4), dtype=np.float32)
+        dT[0, 3] = 100.0
+        spec.meshes[1].d_to_world_left = dT
+    elif param is not None:
+        raise ValueError(param)
+    return spec

@@ -274,6 +274,24 @@ def test_roughconductor_bsdf(psdr, orc, param):
     assert float(np.asarray(b.alpha_u)[0]) == float(np.asarray(b.alpha_v)[0]) == np.float32(0.2) and np.allclose(np.asarray(b.k), [3.9, 2.4, 2.1])
 
 
+@pytest.mark.parametrize("param", ["alpha", "eta", "box_x"])
+def test_roughdielectric_bsdf(psdr, orc, param):
+    """psdr.RoughDielectricBSDF (reference roughdielectric.cpp: GGX reflection + refraction, dielectric Fresnel) against the oracle"""
+    spec = scenes.dielectric_cbox_scene(48, 48, 8, 8, 8, param=param)
+    sc = product.build_scene(spec)
+    ref = orc.OracleScene(spec, [0])
+    integ = psdr.PathTracer(4)
+    c = integ.renderC(sc, 0, seed=3).cpu().numpy()
+    assert product.rel_l2(c, ref.render_c(max_depth=4, seed=3)) < 1e-3
+    img, dimg = psdr.render_d_fwd(integ, sc, 0, seed=6)
+    wimg, wd = ref.render_d(max_depth=4, seeds=(6, 6, 6))
+    assert product.rel_l2(img.cpu().numpy(), wimg) < 1e-3
+    assert np.abs(wd).max() > 0 and product.rel_l2(dimg.cpu().numpy(), wd) < 1e-3
+    b = psdr.RoughDielectricBSDF(0.2, 1.5, 1.0)
+    assert float(np.asarray(b.alpha_u)[0]) == float(np.asarray(b.alpha_v)[0]) == np.float32(0.2) and float(np.asarray(b.eta)[0]) == 1.5
+    assert float(np.asarray(psdr.RoughDielectricBSDF().eta)[0]) == 1.5 and float(np.asarray(psdr.RoughDielectricBSDF(1.33, 1.0).alpha_u)[0]) == np.float32(0.1)
+
+
 def test_field_extraction_and_collocated_integrators(psdr, orc):
     """psdr.FieldExtractionIntegrator / psdr.CollocatedIntegrator (reference field.cpp, collocated.cpp) against the oracle"""
     import torch

@@ -155,8 +155,15 @@ def test_xml_scene_loader(psdr, tmp_path):
     b = mf.param_map["BSDF[id=m]"]
     assert np.allclose(np.asarray(b._get("specularReflectance", False)), [0.6, 0.5, 0.4]) and np.allclose(np.asarray(b._get("diffuseReflectance", False)), 0.1)
     assert abs(float(np.asarray(b._get("roughness", False))[0]) - 0.3) < 1e-7
+    rd = psdr.Scene()
+    rd.opts.log_level = 0
+    rd.load_string('<scene><bsdf type="roughdielectric" id="g"><float name="alpha" value="0.2"/><float name="intIOR" value="1.5"/>'
+                   '<float name="extIOR" value="1.2"/></bsdf></scene>', False)
+    g = rd.param_map["BSDF[id=g]"]
+    assert type(g).__name__ == "RoughDielectricBSDF" and float(np.asarray(g._get("eta", False))[0]) == np.float32(1.5) / np.float32(1.2)
+    assert float(np.asarray(g._get("inv_eta", False))[0]) == np.float32(1.2) / np.float32(1.5) and float(np.asarray(g._get("alpha_v", False))[0]) == np.float32(0.2)
     with pytest.raises(RuntimeError, match="Unknown BSDF type"):
-        psdr.Scene().load_string('<scene><bsdf type="roughdielectric" id="a"/></scene>', False)
+        psdr.Scene().load_string('<scene><bsdf type="normalmap" id="a"/></scene>', False)
     with pytest.raises(RuntimeError, match="BSDF must have an id"):
         psdr.Scene().load_string('<scene><bsdf type="diffuse"><rgb name="reflectance" value="1"/></bsdf></scene>', False)
     with pytest.raises(RuntimeError, match="XML parsing failed"):
