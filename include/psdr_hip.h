@@ -71,6 +71,12 @@ typedef struct psdr_bsdf_rec {       /* Diffuse, reference src/bsdf/diffuse.cpp 
     float eta[3], d_eta[3], k[3], d_k[3];
     /* type 3 = RoughDielectric (src/bsdf/roughdielectric.cpp): alpha_u / alpha_v as above, eta[0] = m_eta = intIOR / extIOR,
      * eta[1] = m_inv_eta = extIOR / intIOR (the reference stores both), d_eta[0..1] their tangents */
+    /* Microfacet bitmap parameters with a resolution above 1x1 (microfacet.cpp:38-45, looked up at its.uv like tex_data, which
+     * is then the diffuse reflectance map): override `specular` (rgb) / `roughness` (one channel).  Host pointers, copied. */
+    int32_t spec_tex_width, spec_tex_height;
+    const float *spec_tex_data, *d_spec_tex_data;
+    int32_t rough_tex_width, rough_tex_height;
+    const float *rough_tex_data, *d_rough_tex_data;
 } psdr_bsdf_rec;
 
 typedef struct psdr_emitter_rec {    /* AreaLight (src/emitter/area.cpp) or EnvironmentMap (src/emitter/envmap.cpp) */

@@ -50,6 +50,12 @@ typedef struct orc_bsdf {            /* Diffuse, include/psdr/bsdf/diffuse.h */
     /* type 2 = RoughConductor (src/bsdf/roughconductor.cpp): specular = specular_reflectance, plus */
     float alpha_u, alpha_v, d_alpha_u, d_alpha_v;
     float eta[3], d_eta[3], k[3], d_k[3];
+    /* Microfacet bitmap parameters above 1x1 (microfacet.cpp:38-45): override specular / roughness; tex_data is then the
+     * diffuse reflectance map.  spec: rgb, rough: one channel */
+    int spec_tex_width, spec_tex_height;
+    const float *spec_tex_data, *d_spec_tex_data;
+    int rough_tex_width, rough_tex_height;
+    const float *rough_tex_data, *d_rough_tex_data;
 } orc_bsdf;
 
 typedef struct orc_emitter {         /* AreaLight (include/psdr/emitter/area.h) or EnvironmentMap (emitter/envmap.h) */

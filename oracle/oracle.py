@@ -80,6 +80,10 @@ class BsdfSpec:
     d_eta: tuple = (0.0, 0.0, 0.0)
     k: tuple = (1.0, 1.0, 1.0)
     d_k: tuple = (0.0, 0.0, 0.0)
+    spec_texture: Optional[np.ndarray] = None   # MicrofacetBSDF bitmap parameters: [H, W, 3] specular reflectance,
+    d_spec_texture: Optional[np.ndarray] = None
+    rough_texture: Optional[np.ndarray] = None  # [H, W] roughness (`texture` is then its diffuse reflectance map)
+    d_rough_texture: Optional[np.ndarray] = None
 
 
 @dataclass
@@ -141,7 +145,9 @@ class _Bsdf(C.Structure):
                 ("tex_width", C.c_int), ("tex_height", C.c_int), ("tex_data", C.POINTER(C.c_float)), ("d_tex_data", C.POINTER(C.c_float)),
                 ("specular", _F3), ("d_specular", _F3), ("roughness", C.c_float), ("d_roughness", C.c_float),
                 ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("d_alpha_u", C.c_float), ("d_alpha_v", C.c_float),
-                ("eta", _F3), ("d_eta", _F3), ("k", _F3), ("d_k", _F3)]
+                ("eta", _F3), ("d_eta", _F3), ("k", _F3), ("d_k", _F3),
+                ("spec_tex_width", C.c_int), ("spec_tex_height", C.c_int), ("spec_tex_data", C.POINTER(C.c_float)), ("d_spec_tex_data", C.POINTER(C.c_float)),
+                ("rough_tex_width", C.c_int), ("rough_tex_height", C.c_int), ("rough_tex_data", C.POINTER(C.c_float)), ("d_rough_tex_data", C.POINTER(C.c_float))]
 
 
 class _Emitter(C.Structure):
@@ -299,6 +305,20 @@ class OracleScene:
                     assert dt.shape == tex.shape
                     self._keep.append(dt)
                     bsdfs[i].d_tex_data = dt.ctypes.data_as(C.POINTER(C.c_float))
+            for name, ch in (("spec", 3), ("rough", 1)):      # Microfacet bitmap parameters
+                t = getattr(b, name + "_texture", None)
+                if t is None:
+                    continue
+                tex = np.ascontiguousarray(np.asarray(t, dtype=np.float32))
+                tex = tex.reshape(tex.shape[0], tex.shape[1], ch)
+                self._keep.append(tex)
+                setattr(bsdfs[i], name + "_tex_height", tex.shape[0]); setattr(bsdfs[i], name + "_tex_width", tex.shape[1])
+                setattr(bsdfs[i], name + "_tex_data", tex.ctypes.data_as(C.POINTER(C.c_float)))
+                dt = getattr(b, "d_" + name + "_texture", None)
+                if dt is not None:
+                    dt = np.ascontiguousarray(np.asarray(dt, dtype=np.float32)).reshape(tex.shape)
+                    self._keep.append(dt)
+                    setattr(bsdfs[i], "d_" + name + "_tex_data", dt.ctypes.data_as(C.POINTER(C.c_float)))
         emitters = (_Emitter * max(1, len(spec.emitters)))()
         for i, e in enumerate(spec.emitters):
             emitters[i].radiance = _F3(*e.radiance)

@@ -103,14 +103,11 @@ template <typename R> V3<R> envmap_bitmap_eval(const EnvmapC &E, R u, R v) {
     return lerp3(w0y, v0, w1y, v1);
 }
 
-// Bitmap<3>::eval<ad>(uv, flip_v = true, envmap_mode = false): the reflectance texture of Diffuse (diffuse.cpp:38);
-// 1x1 bitmaps return their value (bitmap.cpp:54-59).  Texels carry the tangent d_tex.
-template <bool ad> V3<Real<ad>> bsdf_reflectance(const BsdfC &b, const V2<Real<ad>> &uv) {
+// Bitmap<CH>::eval<ad>(uv, flip_v = true, envmap_mode = false) for a resolution above 1x1 (bitmap.cpp:60-128): the texture
+// lookup of Diffuse::m_reflectance (diffuse.cpp:38) and of Microfacet's three parameters (microfacet.cpp:38-45).
+// Texels carry the tangent d_data.
+template <bool ad> void tex_eval(const float *data, const float *d_data, int W, int H, int CH, const V2<Real<ad>> &uv, Real<ad> *out) {
     using R = Real<ad>;
-    if (b.tex_w == 0) {
-        if constexpr (ad) return b.reflectance; else return detach(b.reflectance);
-    }
-    const int W = b.tex_w, H = b.tex_h;
     float sr, cr;
     sincos_cephes(0.f, sr, cr);
     R x = (uv.x - R(0.5f)) * R(cr) + (uv.y - R(0.5f)) * R(sr);
@@ -127,15 +124,36 @@ template <bool ad> V3<Real<ad>> bsdf_reflectance(const BsdfC &b, const V2<Real<a
     px = std::max(std::min(px, W - 2), 0); py = std::max(std::min(py, H - 2), 0);
     const int i00 = py * W + px, i10 = i00 + 1, i01 = i00 + W, i11 = i01 + 1;
     auto texel = [&](int i, int c) -> R {
-        if constexpr (ad) return Dual(b.tex[3 * i + c], b.d_tex[3 * i + c]); else return b.tex[3 * i + c];
+        if constexpr (ad) return Dual(data[CH * i + c], d_data[CH * i + c]); else return data[CH * i + c];
     };
-    R out[3];
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < CH; ++c) {
         const R v0 = fma_(w0x, texel(i00, c), w1x * texel(i10, c));
         const R v1 = fma_(w0x, texel(i01, c), w1x * texel(i11, c));
         out[c] = fma_(w0y, v0, w1y * v1);
     }
+}
+// 1x1 bitmaps return their value (bitmap.cpp:54-59)
+template <bool ad> V3<Real<ad>> bsdf_reflectance(const BsdfC &b, const V2<Real<ad>> &uv) {
+    using R = Real<ad>;
+    if (b.tex_w == 0) {
+        if constexpr (ad) return b.reflectance; else return detach(b.reflectance);
+    }
+    R out[3];
+    tex_eval<ad>(b.tex.data(), b.d_tex.data(), b.tex_w, b.tex_h, 3, uv, out);
     return V3<R>(out[0], out[1], out[2]);
+}
+// Microfacet: m_specularReflectance / m_roughness as bitmaps (value, tangent); the caller detaches in C mode
+template <bool ad> V3d bsdf_specular(const BsdfC &b, const V2<Real<ad>> &uv) {
+    if (b.spec_w == 0) return b.specular;
+    Dual out[3];
+    tex_eval<true>(b.spec_tex.data(), b.d_spec_tex.data(), b.spec_w, b.spec_h, 3, V2d(Dual(uv.x), Dual(uv.y)), out);
+    return V3d(out[0], out[1], out[2]);
+}
+template <bool ad> Dual bsdf_roughness(const BsdfC &b, const V2<Real<ad>> &uv) {
+    if (b.rough_w == 0) return b.roughness;
+    Dual out[1];
+    tex_eval<true>(b.rough_tex.data(), b.d_rough_tex.data(), b.rough_w, b.rough_h, 1, V2d(Dual(uv.x), Dual(uv.y)), out);
+    return out[0];
 }
 
 // EnvironmentMap::configure (envmap.cpp:17-44)

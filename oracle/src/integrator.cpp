@@ -333,7 +333,9 @@ template <bool ad> static V3<Real<ad>> bsdf_eval(const Scene &sc, const Its<ad> 
     if (sc.meshes[its.mesh].bsdf < 0) return V(R(0.f));
     const BsdfC &b = sc.bsdfs[sc.meshes[its.mesh].bsdf];
     if (b.type == 1) {          // Microfacet (microfacet.cpp); its diffuse reflectance is b.reflectance
-        MicrofacetParams P{b.specular, b.reflectance, b.roughness, b.two_sided};
+        V3d diff = b.reflectance;
+        if (b.tex_w != 0) { const V3<R> t = bsdf_reflectance<ad>(b, its.uv); diff = V3d(Dual(t.x), Dual(t.y), Dual(t.z)); }
+        MicrofacetParams P{bsdf_specular<ad>(b, its.uv), diff, bsdf_roughness<ad>(b, its.uv), b.two_sided};
         return microfacet_eval<ad>(P, its.wi, wo, active);
     }
     if (b.type == 2) {          // RoughConductor (roughconductor.cpp)
@@ -354,7 +356,7 @@ template <bool ad> static float bsdf_pdf(const Scene &sc, const Its<ad> &its, co
     if (sc.meshes[its.mesh].bsdf < 0) return 0.f;
     const BsdfC &b = sc.bsdfs[sc.meshes[its.mesh].bsdf];
     if (b.type == 1) {
-        MicrofacetParams P{b.specular, b.reflectance, b.roughness, b.two_sided};
+        MicrofacetParams P{b.specular, b.reflectance, bsdf_roughness<ad>(b, its.uv), b.two_sided};
         return microfacet_pdf(P, detach(its.wi), detach(wo_), active);
     }
     if (b.type == 2) {
@@ -375,7 +377,7 @@ template <bool ad> static BSDFSample bsdf_sample(const Scene &sc, const Its<ad> 
     if (sc.meshes[its.mesh].bsdf < 0) { BSDFSample z; z.wo = V3f(0.f, 0.f, 0.f); z.pdf = 0.f; z.valid = false; return z; }
     const BsdfC &b = sc.bsdfs[sc.meshes[its.mesh].bsdf];
     if (b.type == 1) {
-        MicrofacetParams P{b.specular, b.reflectance, b.roughness, b.two_sided};
+        MicrofacetParams P{b.specular, b.reflectance, bsdf_roughness<ad>(b, its.uv), b.two_sided};
         const MicrofacetSample m = microfacet_sample(P, detach(its.wi), s3, active);
         BSDFSample r; r.wo = m.wo; r.pdf = m.pdf; r.valid = m.valid;
         return r;

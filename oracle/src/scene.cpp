@@ -198,6 +198,16 @@ Scene *configure_scene(const orc_scene_desc &d, const int *active, int n_active)
             bc.tex.assign(b.tex_data, b.tex_data + n);
             if (b.d_tex_data) bc.d_tex.assign(b.d_tex_data, b.d_tex_data + n); else bc.d_tex.assign(n, 0.f);
         }
+        auto take = [](const float *src, const float *dsrc, int w, int h, int ch, int &ow, int &oh, std::vector<float> &dst, std::vector<float> &ddst) {
+            if (src == nullptr) return;
+            if (w < 2 || h < 2) throw std::runtime_error("Bitmap: invalid resolution!");
+            ow = w; oh = h;
+            const size_t n = (size_t) ch * w * h;
+            dst.assign(src, src + n);
+            if (dsrc) ddst.assign(dsrc, dsrc + n); else ddst.assign(n, 0.f);
+        };
+        take(b.spec_tex_data, b.d_spec_tex_data, b.spec_tex_width, b.spec_tex_height, 3, bc.spec_w, bc.spec_h, bc.spec_tex, bc.d_spec_tex);
+        take(b.rough_tex_data, b.d_rough_tex_data, b.rough_tex_width, b.rough_tex_height, 1, bc.rough_w, bc.rough_h, bc.rough_tex, bc.d_rough_tex);
         sc->bsdfs.push_back(bc);
     }
     for (int i = 0; i < d.n_emitters; ++i) {

@@ -182,11 +182,10 @@ class Bitmap1fD:
 
 
 def _const_of(x, n):
-    """a constant parameter given as a number/vector or as a 1x1 Bitmap (bitmap parameters larger than 1x1 are not built
-    for the GGX BSDFs)"""
+    """a constant parameter given as a number/vector or as a 1x1 Bitmap (larger bitmaps: DiffuseBSDF and MicrofacetBSDF only)"""
     if isinstance(x, (Bitmap3fD, Bitmap1fD)):
         if x.data.size != n:
-            raise RuntimeError("bitmap parameters larger than 1x1 are only built for DiffuseBSDF.reflectance")
+            raise RuntimeError("bitmap parameters larger than 1x1 are only built for DiffuseBSDF and MicrofacetBSDF")
         return x.data.reshape(n)
     return x
 
@@ -200,9 +199,15 @@ for _cls in (Mesh, Sensor, PerspectiveCamera):
         setattr(_cls, _n, _make_param_property(_n, _m44))
 Mesh.vertex_positions = _make_param_property("vertex_positions", _vtx)
 DiffuseBSDF.reflectance = _make_param_property("reflectance", _refl_shape)
-MicrofacetBSDF.specularReflectance = _make_param_property("specularReflectance", _v3)
-MicrofacetBSDF.diffuseReflectance = _make_param_property("diffuseReflectance", _v3)
-MicrofacetBSDF.roughness = _make_param_property("roughness", lambda self, value: (1,))
+def _rough_shape(self, value):
+    """a number or a roughness map [H, W] (the reference's Bitmap1fD)"""
+    shp = tuple(value.shape) if hasattr(value, "shape") else _np.shape(value)
+    return shp if len(shp) == 2 and shp[0] > 1 else (1,)
+
+
+MicrofacetBSDF.specularReflectance = _make_param_property("specularReflectance", _refl_shape)
+MicrofacetBSDF.diffuseReflectance = _make_param_property("diffuseReflectance", _refl_shape)
+MicrofacetBSDF.roughness = _make_param_property("roughness", _rough_shape)
 for _n in ("alpha_u", "alpha_v"):
     setattr(RoughConductorBSDF, _n, _make_param_property(_n, lambda self, value: (1,)))
 for _n in ("eta", "k", "specular_reflectance"):
@@ -255,16 +260,20 @@ _MicrofacetBSDF_init = MicrofacetBSDF.__init__
 
 
 def _microfacet_init(self, specular=None, diffuse=None, roughness=None):
-    """MicrofacetBSDF() or MicrofacetBSDF(specularReflectance, diffuseReflectance, roughness) (reference psdr.cpp:298-304)"""
+    """MicrofacetBSDF() or MicrofacetBSDF(specularReflectance, diffuseReflectance, roughness) (reference psdr.cpp:298-304); each
+    parameter a constant, a Bitmap3fD / Bitmap1fD, or an array [H, W, 3] / [H, W] (a bitmap with a resolution above 1x1)"""
+    _MicrofacetBSDF_init(self)
     if specular is None:
-        _MicrofacetBSDF_init(self)
         return
-    specular, diffuse, roughness = _const_of(specular, 3), _const_of(diffuse, 3), _const_of(roughness, 1)
-    _MicrofacetBSDF_init(self, _split(specular, (-1,))[0] * _np.ones(3, _np.float32), _split(diffuse, (-1,))[0] * _np.ones(3, _np.float32),
-                         float(_split(roughness, (-1,))[0][0]))
-    for name, val in (("specularReflectance", specular), ("diffuseReflectance", diffuse), ("roughness", roughness)):
-        if isinstance(val, _torch.Tensor):
-            _params(self)[name] = val
+    for name, val, n in (("specularReflectance", specular, 3), ("diffuseReflectance", diffuse, 3), ("roughness", roughness, 1)):
+        if isinstance(val, (Bitmap3fD, Bitmap1fD)):
+            val = val.data.reshape(n) if val.data.size == n else val.data
+        shp = tuple(val.shape) if hasattr(val, "shape") else _np.shape(val)
+        if len(shp) < 2:
+            v = _split(val, (-1,))[0]
+            if n == 3 and v.size == 1 and not isinstance(val, _torch.Tensor):
+                val = v * _np.ones(3, _np.float32)
+        setattr(self, name, val)
 
 
 MicrofacetBSDF.__init__ = _microfacet_init

@@ -105,7 +105,8 @@ def snapshot_tensors(scene, sensor_id, leaf_of):
         if type(b).__name__ in ("RoughConductorBSDF", "RoughDielectricBSDF"):
             return torch.zeros(3, dtype=F64)
         if type(b).__name__ == "MicrofacetBSDF":
-            return leaf_of(b, "diffuseReflectance").reshape(-1).expand(3)
+            r = leaf_of(b, "diffuseReflectance")
+            return torch.zeros(3, dtype=F64) if r.dim() == 3 else r.reshape(-1).expand(3)
         r = leaf_of(b, "reflectance")
         return torch.zeros(3, dtype=F64) if r.dim() == 3 else r.reshape(-1).expand(3)
     refl = torch.stack([_refl(pm["BSDF[%d]" % i]) for i in range(nb)]) if nb else torch.zeros((0, 3), dtype=F64)

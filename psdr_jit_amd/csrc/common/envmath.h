@@ -118,11 +118,11 @@ PSDR_HD void bitmap_eval(const float *data, int W, int H, R u, R v, R out[3]) {
     }
 }
 
-// Bitmap<3>::eval<ad>(uv, flip_v, envmap_mode = false) with m_rot = 0, m_scale = 1, m_trans = 0 (bitmap.cpp:47-128):
+// Bitmap<CH>::eval<ad>(uv, flip_v, envmap_mode = false) with m_rot = 0, m_scale = 1, m_trans = 0 (bitmap.cpp:47-128):
 // the texture lookup of Diffuse::m_reflectance (diffuse.cpp:38, flip_v = true).  texel(i, c) returns channel c of
 // texel i as an R (so that a (value, tangent) texel can be supplied).
-template <typename R, typename TexelFn>
-PSDR_HD void bitmap_eval_tex(TexelFn texel, int W, int H, R u, R v, bool flip_v, R out[3]) {
+template <typename R, int CH = 3, typename TexelFn>
+PSDR_HD void bitmap_eval_tex(TexelFn texel, int W, int H, R u, R v, bool flip_v, R *out) {
     float sr, cr;
     sincos_f(0.f, sr, cr);
     R x = (u - R(0.5f)) * R(cr) + (v - R(0.5f)) * R(sr);
@@ -139,7 +139,7 @@ PSDR_HD void bitmap_eval_tex(TexelFn texel, int W, int H, R u, R v, bool flip_v,
     px = px < W - 2 ? px : W - 2; py = py < H - 2 ? py : H - 2;
     px = px < 0 ? 0 : px; py = py < 0 ? 0 : py;
     const int i00 = py * W + px, i10 = i00 + 1, i01 = i00 + W, i11 = i01 + 1;
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < CH; ++c) {
         const R v0 = e_fma(w0x, texel(i00, c), w1x * texel(i10, c));
         const R v1 = e_fma(w0x, texel(i01, c), w1x * texel(i11, c));
         out[c] = e_fma(w0y, v0, w1y * v1);

@@ -466,20 +466,25 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
         for (int k = 0; k < 3; ++k) { ED.lower[k] = er->lower[k]; ED.upper[k] = er->upper[k]; }
     }
     T.tex = nullptr;
-    {
+    {   // bitmap parameters: three slots per BSDF - [0] reflectance / diffuse reflectance (rgb), [1] specular (rgb), [2] roughness (1 channel)
         bool any_tex = false;
-        for (int i = 0; i < s->n_bsdfs; ++i) any_tex |= s->bsdfs[i].tex_data != nullptr;
+        for (int i = 0; i < s->n_bsdfs; ++i) any_tex |= s->bsdfs[i].tex_data != nullptr || s->bsdfs[i].spec_tex_data != nullptr || s->bsdfs[i].rough_tex_data != nullptr;
         if (any_tex) {
-            std::vector<TexDev> td((size_t) s->n_bsdfs, TexDev{nullptr, nullptr, 0, 0});
+            std::vector<TexDev> td((size_t) 3 * s->n_bsdfs, TexDev{nullptr, nullptr, 0, 0});
             int rc = 0;
             for (int i = 0; i < s->n_bsdfs; ++i) {
                 const psdr_bsdf_rec &b = s->bsdfs[i];
-                if (!b.tex_data) continue;
-                if (b.tex_width < 2 || b.tex_height < 2) return fail("Bitmap: invalid resolution!");
-                const size_t nt = (size_t) 3 * b.tex_width * b.tex_height;
-                td[i].data = sc->up(b.tex_data, nt, rc);
-                td[i].d_data = sc->up(b.d_tex_data, nt, rc);
-                td[i].w = b.tex_width; td[i].h = b.tex_height;
+                const float *src[3] = {b.tex_data, b.spec_tex_data, b.rough_tex_data}, *dsrc[3] = {b.d_tex_data, b.d_spec_tex_data, b.d_rough_tex_data};
+                const int tw[3] = {b.tex_width, b.spec_tex_width, b.rough_tex_width}, th[3] = {b.tex_height, b.spec_tex_height, b.rough_tex_height};
+                for (int k = 0; k < 3; ++k) {
+                    if (!src[k]) continue;
+                    if (k > 0 && b.type != 1) return fail("specular / roughness bitmaps belong to the Microfacet BSDF");
+                    if (tw[k] < 2 || th[k] < 2) return fail("Bitmap: invalid resolution!");
+                    const size_t nt = (size_t) (k == 2 ? 1 : 3) * tw[k] * th[k];
+                    td[3 * i + k].data = sc->up(src[k], nt, rc);
+                    td[3 * i + k].d_data = sc->up(dsrc[k], nt, rc);
+                    td[3 * i + k].w = tw[k]; td[3 * i + k].h = th[k];
+                }
             }
             sc->bufs.emplace_back(new DevBuf());
             rc |= sc->bufs.back()->upload(td.data(), td.size() * sizeof(TexDev));
@@ -590,7 +595,7 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     for (int i = 0; i < s->n_bsdfs; ++i) {
         const psdr_bsdf_rec &b = s->bsdfs[i];
         if (b.type < 0 || b.type > 3) return fail("Unknown BSDF type!");
-        put4(blob, T.bsdf_off + 2 * (size_t) i, b.reflectance[0], b.reflectance[1], b.reflectance[2], ibits((b.two_sided ? 1 : 0) | (b.tex_data ? 2 : 0) | (b.type == 1 ? 4 : 0) | (b.type == 2 ? 8 : 0) | (b.type == 3 ? 16 : 0)));
+        put4(blob, T.bsdf_off + 2 * (size_t) i, b.reflectance[0], b.reflectance[1], b.reflectance[2], ibits((b.two_sided ? 1 : 0) | (b.tex_data ? 2 : 0) | (b.type == 1 ? 4 : 0) | (b.type == 2 ? 8 : 0) | (b.type == 3 ? 16 : 0) | (b.spec_tex_data ? 32 : 0) | (b.rough_tex_data ? 64 : 0)));
         put4(blob, T.bsdf_off + 2 * (size_t) i + 1, b.d_reflectance[0], b.d_reflectance[1], b.d_reflectance[2], 0.f);
     }
     for (int i = 0; i < s->n_emitters; ++i) {

@@ -343,6 +343,13 @@ template <bool AD, bool LDS> PSDR_DEV float emitter_position_pdf(const SceneView
 }
 
 // ---------------------------------------------------------------- Diffuse BSDF, reference src/bsdf/diffuse.cpp:24-108
+// Microfacet::m_roughness as a bitmap, detached (microfacet.cpp:88,117)
+template <bool AD, bool LDS> PSDR_DEV float roughness_lookup(const SceneView<LDS> &S, int id, const Its<AD> &its) {
+    const TexDev td = S.T->tex[3 * id + 2];
+    float o[1];
+    env::bitmap_eval_tex<float, 1>([&](int i, int) { return td.data[i]; }, td.w, td.h, detach(its.tu), detach(its.tv), true, o);
+    return o[0];
+}
 template <bool AD, bool LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S, const Its<AD> &its, VecN<AD> wo, bool active) {
     using R = Num<AD>; using V = VecN<AD>;
     if (mesh_bsdf(S, its.mesh) < 0) return V(R(0.f));          // the envmap's bounding cube has no BSDF (null vcall = zeros)
@@ -352,16 +359,29 @@ template <bool AD, bool LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S
         if (__float_as_int(a.w) & 4) {         // Microfacet (microfacet.cpp); its diffuse reflectance is the record's colour
             const int id = mesh_bsdf(S, its.mesh);
             const MatDev md = S.T->mat[id];
-            if constexpr (AD) {
-                const float4 b = S.rgb_tan(w + 1, 2, id);
-                const bool tan = S.mode == 0;          // (specular / roughness adjoints are not returned by reverse mode)
-                const Vec3d spec(Dual(md.specular[0], tan ? md.d_specular[0] : 0.f), Dual(md.specular[1], tan ? md.d_specular[1] : 0.f), Dual(md.specular[2], tan ? md.d_specular[2] : 0.f));
-                return microfacet_eval<Dual>(spec, make_dual(Vec3f(a.x, a.y, a.z), Vec3f(b.x, b.y, b.z)), Dual(md.roughness, tan ? md.d_roughness : 0.f),
-                                             (__float_as_int(a.w) & 1) != 0, its.wi, wo, active);
-            } else {
-                return microfacet_eval<float>(Vec3f(md.specular[0], md.specular[1], md.specular[2]), Vec3f(a.x, a.y, a.z), md.roughness,
-                                              (__float_as_int(a.w) & 1) != 0, its.wi, wo, active);
+            const int fl = __float_as_int(a.w);
+            // bitmap parameters (microfacet.cpp:38-45): looked up with (value, tangent) texels and uv, detached in C mode
+            const bool tan = AD && S.mode == 0;            // (specular / roughness / texel adjoints are not returned by reverse mode)
+            const Dual tu = Dual(its.tu), tv = Dual(its.tv);
+            Vec3d spec(Dual(md.specular[0], tan ? md.d_specular[0] : 0.f), Dual(md.specular[1], tan ? md.d_specular[1] : 0.f), Dual(md.specular[2], tan ? md.d_specular[2] : 0.f));
+            Dual rough(md.roughness, tan ? md.d_roughness : 0.f);
+            Vec3d diff;
+            if constexpr (AD) { const float4 b = S.rgb_tan(w + 1, 2, id); diff = make_dual(Vec3f(a.x, a.y, a.z), Vec3f(b.x, b.y, b.z)); }
+            else diff = make_dual(Vec3f(a.x, a.y, a.z), Vec3f(0.f, 0.f, 0.f));
+            if (fl & (2 | 32 | 64)) {
+                auto look = [&](int slot, auto ch, Dual *out) {
+                    const TexDev td = S.T->tex[3 * id + slot];
+                    constexpr int CH = decltype(ch)::value;
+                    const bool tt = tan && td.d_data != nullptr;
+                    env::bitmap_eval_tex<Dual, CH>([&](int i, int c) { return Dual(td.data[CH * i + c], tt ? td.d_data[CH * i + c] : 0.f); }, td.w, td.h, tu, tv, true, out);
+                };
+                Dual o[3];
+                if (fl & 2) { look(0, std::integral_constant<int, 3>(), o); diff = Vec3d(o[0], o[1], o[2]); }
+                if (fl & 32) { look(1, std::integral_constant<int, 3>(), o); spec = Vec3d(o[0], o[1], o[2]); }
+                if (fl & 64) { look(2, std::integral_constant<int, 1>(), o); rough = o[0]; }
             }
+            if constexpr (AD) return microfacet_eval<Dual>(spec, diff, rough, (fl & 1) != 0, its.wi, wo, active);
+            else return microfacet_eval<float>(detach(spec), detach(diff), rough.v, (fl & 1) != 0, its.wi, wo, active);
         }
         if (__float_as_int(a.w) & 8) {         // RoughConductor (roughconductor.cpp)
             const MatDev md = S.T->mat[mesh_bsdf(S, its.mesh)];
@@ -400,7 +420,7 @@ template <bool AD, bool LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S
     if constexpr (!LDS) {
         if (__float_as_int(a.w) & 2) {         // Bitmap3fD reflectance, diffuse.cpp:38 -> bitmap.cpp:47-128 (flip_v)
             textured = true;
-            const TexDev td = S.T->tex[mesh_bsdf(S, its.mesh)];
+            const TexDev td = S.T->tex[3 * mesh_bsdf(S, its.mesh)];
             R rgb[3];
             if constexpr (AD) {
                 const bool tan = td.d_data != nullptr && S.mode == 0;      // (texel adjoints are not returned by reverse mode)
@@ -425,7 +445,8 @@ template <bool AD, bool LDS> PSDR_DEV float bsdf_pdf(const SceneView<LDS> &S, co
         if (__float_as_int(a.w) & 12) {
             const MatDev md = S.T->mat[mesh_bsdf(S, its.mesh)];
             const bool mf = (__float_as_int(a.w) & 4) != 0;
-            return ggx_pdf(mf ? sqr(md.roughness) : md.alpha_u, mf ? sqr(md.roughness) : md.alpha_v, (__float_as_int(a.w) & 1) != 0, detach(its.wi), detach(wo), active);
+            const float rough = (__float_as_int(a.w) & 64) ? roughness_lookup(S, mesh_bsdf(S, its.mesh), its) : md.roughness;
+            return ggx_pdf(mf ? sqr(rough) : md.alpha_u, mf ? sqr(rough) : md.alpha_v, (__float_as_int(a.w) & 1) != 0, detach(its.wi), detach(wo), active);
         }
         if (__float_as_int(a.w) & 16) {
             const MatDev md = S.T->mat[mesh_bsdf(S, its.mesh)];
@@ -480,7 +501,8 @@ template <bool AD, bool LDS> PSDR_DEV BSDFSample bsdf_sample(const SceneView<LDS
             BSDFSample m;
             const MatDev md = S.T->mat[mesh_bsdf(S, its.mesh)];
             const bool mf = (__float_as_int(a.w) & 4) != 0;
-            ggx_reflect_sample(mf ? sqr(md.roughness) : md.alpha_u, mf ? sqr(md.roughness) : md.alpha_v, (__float_as_int(a.w) & 1) != 0, detach(its.wi), s0, s1, active,
+            const float rough = (__float_as_int(a.w) & 64) ? roughness_lookup(S, mesh_bsdf(S, its.mesh), its) : md.roughness;
+            ggx_reflect_sample(mf ? sqr(rough) : md.alpha_u, mf ? sqr(rough) : md.alpha_v, (__float_as_int(a.w) & 1) != 0, detach(its.wi), s0, s1, active,
                                m.wo, m.pdf, m.valid);
             return m;
         }

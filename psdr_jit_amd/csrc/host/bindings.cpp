@@ -94,10 +94,27 @@ PYBIND11_MODULE(_psdr_core, m) {
         .def(py::init<>())
         .def(py::init([](const farr &s, const farr &d, float r) { return new Microfacet(to_a3(s), to_a3(d), r); }))
         .def("_get", [](const Microfacet &b, const std::string &name, bool tangent) {
+            const ParamTex &tx = name == "roughness" ? b.roughness_tex : (name == "specularReflectance" ? b.specular_tex : b.diffuse_tex);
+            if (tx.w > 0) {             // a bitmap parameter: [H, W, 3] or [H, W]
+                const std::vector<float> &src = tangent ? tx.d : tx.v;
+                farr a = name == "roughness" ? farr({(py::ssize_t) tx.h, (py::ssize_t) tx.w}) : farr({(py::ssize_t) tx.h, (py::ssize_t) tx.w, (py::ssize_t) 3});
+                if (src.size() == (size_t) a.size()) std::memcpy(a.mutable_data(), src.data(), sizeof(float) * src.size()); else std::memset(a.mutable_data(), 0, sizeof(float) * a.size());
+                return a;
+            }
             if (name == "roughness") { farr a(1); a.mutable_data()[0] = tangent ? b.d_roughness : b.roughness; return a; }
             const auto &r = name == "specularReflectance" ? (tangent ? b.d_specular : b.specular) : (tangent ? b.d_diffuse : b.diffuse);
             farr a(3); std::memcpy(a.mutable_data(), r.data(), 12); return a; })
         .def("_set", [](Microfacet &b, const std::string &name, const farr &v, const farr &t) {
+            ParamTex &tx = name == "roughness" ? b.roughness_tex : (name == "specularReflectance" ? b.specular_tex : b.diffuse_tex);
+            const int want = name == "roughness" ? 2 : 3;
+            if (v.ndim() == want && v.ndim() >= 2) {          // Bitmap3fD / Bitmap1fD (width, height, data)
+                if (v.shape(0) < 2 || v.shape(1) < 2 || (want == 3 && v.shape(2) != 3)) throw Exception("Bitmap: invalid resolution!");
+                tx.h = (int) v.shape(0); tx.w = (int) v.shape(1);
+                tx.v.assign(v.data(), v.data() + v.size());
+                if (t.size() == v.size()) tx.d.assign(t.data(), t.data() + t.size()); else tx.d.assign((size_t) v.size(), 0.f);
+                return;
+            }
+            tx = ParamTex();
             if (name == "roughness") { b.roughness = v.data()[0]; b.d_roughness = t.size() ? t.data()[0] : 0.f; }
             else if (name == "specularReflectance") { b.specular = to_a3(v); b.d_specular = to_a3(t); }
             else { b.diffuse = to_a3(v); b.d_diffuse = to_a3(t); } });

@@ -638,6 +638,24 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
                 r.specular[k] = mf->specular[k]; r.d_specular[k] = mf->d_specular[k];
             }
             r.roughness = mf->roughness; r.d_roughness = mf->d_roughness;
+            auto chk = [](const ParamTex &t, int ch) {
+                if (t.w == 0) return false;
+                PSDR_ASSERT_MSG(t.w >= 2 && t.h >= 2, "Bitmap: invalid resolution!");
+                PSDR_ASSERT_MSG(t.v.size() == (size_t) ch * t.w * t.h, "Bitmap: invalid data size!");
+                return true;
+            };
+            if (chk(mf->diffuse_tex, 3)) {
+                r.tex_width = mf->diffuse_tex.w; r.tex_height = mf->diffuse_tex.h; r.tex_data = mf->diffuse_tex.v.data();
+                r.d_tex_data = mf->diffuse_tex.d.size() == mf->diffuse_tex.v.size() ? mf->diffuse_tex.d.data() : nullptr;
+            }
+            if (chk(mf->specular_tex, 3)) {
+                r.spec_tex_width = mf->specular_tex.w; r.spec_tex_height = mf->specular_tex.h; r.spec_tex_data = mf->specular_tex.v.data();
+                r.d_spec_tex_data = mf->specular_tex.d.size() == mf->specular_tex.v.size() ? mf->specular_tex.d.data() : nullptr;
+            }
+            if (chk(mf->roughness_tex, 1)) {
+                r.rough_tex_width = mf->roughness_tex.w; r.rough_tex_height = mf->roughness_tex.h; r.rough_tex_data = mf->roughness_tex.v.data();
+                r.d_rough_tex_data = mf->roughness_tex.d.size() == mf->roughness_tex.v.size() ? mf->roughness_tex.d.data() : nullptr;
+            }
             S.bsdfs.push_back(r);
             continue;
         }

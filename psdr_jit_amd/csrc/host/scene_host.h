@@ -72,7 +72,10 @@ struct Diffuse : BSDF {
     std::vector<float> tex, d_tex;
 };
 
-// Microfacet, reference include/psdr/bsdf/microfacet.h (constant parameters; the reference's bitmap variants are not built)
+// a bitmap parameter with a resolution above 1x1: [h*w*ch] row-major texels (+ their forward tangent); w == 0: constant
+struct ParamTex { int w = 0, h = 0; std::vector<float> v, d; };
+
+// Microfacet, reference include/psdr/bsdf/microfacet.h: three Bitmap parameters, each a constant (1x1) or a texture
 struct Microfacet : BSDF {
     Microfacet() {}
     Microfacet(const std::array<float, 3> &spec, const std::array<float, 3> &diff, float rough) : specular(spec), diffuse(diff), roughness(rough) {}
@@ -81,6 +84,7 @@ struct Microfacet : BSDF {
     bool anisotropic() const override { return false; }
     std::array<float, 3> specular{0.04f, 0.04f, 0.04f}, diffuse{0.5f, 0.5f, 0.5f}, d_specular{0, 0, 0}, d_diffuse{0, 0, 0};
     float roughness = 0.8f, d_roughness = 0.f;
+    ParamTex specular_tex, diffuse_tex, roughness_tex;      // rgb, rgb, one channel
 };
 
 // RoughConductor, reference include/psdr/bsdf/roughconductor.h (constant parameters)

@@ -169,9 +169,14 @@ def load_scene(root, scene, psdr, base_dir=None):
         elif btype == "microfacet":
             nodes = [_child_by_name(node, {"specular_reflectance", "specularReflectance"}), _child_by_name(node, {"diffuse_reflectance", "diffuseReflectance"}),
                      _child_by_name(node, {"roughness"})]
-            if any(n.tag == "texture" for n in nodes):
-                raise _Err("MicrofacetBSDF: bitmap parameters are not built, only constants")
-            b = psdr.MicrofacetBSDF(_load_rgb(nodes[0]), _load_rgb(nodes[1]), float(nodes[2].get("value")))
+            # load_texture (scene_loader.cpp:289-319): a <texture> child is a bitmap file, anything else a constant;
+            # a one-channel Bitmap takes the first channel of the image (bitmap.cpp:38-39)
+            vals = [psdr.Bitmap3fD(_parse_bitmap(n, base_dir)) if n.tag == "texture" else _load_rgb(n) for n in nodes[:2]]
+            if nodes[2].tag == "texture":
+                vals.append(psdr.Bitmap1fD(np.ascontiguousarray(psdr.Bitmap3fD(_parse_bitmap(nodes[2], base_dir)).data[..., 0])))
+            else:
+                vals.append(float(nodes[2].get("value")))
+            b = psdr.MicrofacetBSDF(*vals)
         elif btype == "roughconductor":
             nodes = [_child_by_name(node, {"alpha"}), _child_by_name(node, {"eta"}), _child_by_name(node, {"k"})]
             if any(n.tag == "texture" for n in nodes):

@@ -21,6 +21,12 @@ def build_scene(spec, configure=True, active=(0,), host_only=False, log_level=0)
             bs._set("specularReflectance", np.asarray(b.specular, np.float32), np.asarray(b.d_specular, np.float32))
             bs._set("diffuseReflectance", np.asarray(b.reflectance, np.float32), np.asarray(b.d_reflectance, np.float32))
             bs._set("roughness", np.asarray([b.roughness], np.float32), np.asarray([b.d_roughness], np.float32))
+            for attr, name in (("texture", "diffuseReflectance"), ("spec_texture", "specularReflectance"), ("rough_texture", "roughness")):
+                t = getattr(b, attr, None)
+                if t is not None:
+                    tex = np.ascontiguousarray(np.asarray(t, np.float32))
+                    dt = getattr(b, "d_" + attr, None)
+                    bs._set(name, tex, np.ascontiguousarray(np.asarray(dt, np.float32)) if dt is not None else np.zeros_like(tex))
             sc.add_BSDF(bs, b.name or ("bsdf%d" % i), b.two_sided)
             continue
         if getattr(b, "type", 0) == 2:

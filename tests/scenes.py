@@ -359,3 +359,24 @@ def dielectric_cbox_scene(width=48, height=48, spp=8, sppe=0, sppse=0, param="al
     elif param is not None:
         raise ValueError(param)
     return spec
+
+
+def textured_microfacet_scene(width=48, height=48, spp=4, sppe=0, sppse=0, param=None):
+    """textured_scene (Cornell luminaire) whose floor is a MicrofacetBSDF with all three parameters as bitmaps of different
+    resolutions (reference microfacet.cpp:38-45).  param: 'diffuse' | 'specular' | 'roughness' (d texel / dP = 1) | 'box_x' | None"""
+    spec = textured_scene(width, height, spp, sppe, sppse, texture=checker_texture(8, 8), param="box_x" if param == "box_x" else None, env=False)
+    rng = np.random.default_rng(5)
+    b = spec.bsdfs[0]
+    b.type = 1
+    b.spec_texture = (0.2 + 0.7 * rng.random((6, 5, 3))).astype(np.float32)
+    yy, xx = np.meshgrid(np.linspace(0, 1, 7, dtype=np.float32), np.linspace(0, 1, 9, dtype=np.float32), indexing="ij")
+    b.rough_texture = (0.15 + 0.5 * (0.5 + 0.5 * np.sin(5 * xx) * np.cos(4 * yy))).astype(np.float32)
+    if param == "diffuse":
+        b.d_texture = np.ones_like(b.texture)
+    elif param == "specular":
+        b.d_spec_texture = np.ones_like(b.spec_texture)
+    elif param == "roughness":
+        b.d_rough_texture = np.ones_like(b.rough_texture)
+    elif param not in (None, "box_x"):
+        raise ValueError(param)
+    return spec

@@ -126,3 +126,39 @@ def test_texture_derivative_is_exact_at_depth_one(orc):
     img2, _ = orc.OracleScene(spec2, [0]).render_d(max_depth=1, seeds=(3, 3, 3))
     assert np.abs(dimg).sum() > 1.0
     assert np.allclose(dimg, (img2 - img) / 0.125, rtol=1e-4, atol=1e-5)
+
+
+def test_microfacet_bitmap_parameters(orc):
+    """Microfacet with bitmap parameters (microfacet.cpp:38-45): maps of equal texels are the constants; the (value, tangent)
+    arithmetic through the roughness / specular / diffuse maps equals finite differences of the maps"""
+    spec_t = scenes.textured_microfacet_scene(24, 24, 16, 0, 0)
+    b = spec_t.bsdfs[0]
+    b.texture = np.full((4, 4, 3), 0.3, np.float32); b.spec_texture = np.full((3, 5, 3), 0.6, np.float32); b.rough_texture = np.full((5, 3), 0.4, np.float32)
+    spec_k = scenes.textured_microfacet_scene(24, 24, 16, 0, 0)
+    k = spec_k.bsdfs[0]
+    k.texture = k.spec_texture = k.rough_texture = None
+    k.reflectance, k.specular, k.roughness = (0.3, 0.3, 0.3), (0.6, 0.6, 0.6), 0.4
+    a = orc.OracleScene(spec_t, [0]).render_c(max_depth=2, seed=2)
+    c = orc.OracleScene(spec_k, [0]).render_c(max_depth=2, seed=2)
+    assert a.max() > 0 and np.allclose(a, c, rtol=2e-5, atol=1e-6)
+    for param, attr, h in (("roughness", "rough_texture", 1e-2), ("specular", "spec_texture", 0.0625), ("diffuse", "texture", 0.0625)):
+        # emitter sampling only (Direct(0)): the sample placement must not depend on the roughness for FD to apply
+        def scene_of(spec):
+            s = orc.OracleScene(spec, [0])
+            s.set_direct_mis(0)
+            return s
+        spec = scenes.textured_microfacet_scene(24, 24, 32, 0, 0, param=param)
+        img, dimg = scene_of(spec).render_d(max_depth=1, seeds=(3, 3, 3))
+        assert np.abs(dimg).sum() > 0.1, param
+        up = scenes.textured_microfacet_scene(24, 24, 32, 0, 0)
+        dn = scenes.textured_microfacet_scene(24, 24, 32, 0, 0)
+        setattr(up.bsdfs[0], attr, getattr(up.bsdfs[0], attr) + np.float32(h))
+        setattr(dn.bsdfs[0], attr, getattr(dn.bsdfs[0], attr) - np.float32(h))
+        iu = scene_of(up).render_c(max_depth=1, seed=3)
+        idn = scene_of(dn).render_c(max_depth=1, seed=3)
+        fd = (iu - idn) / (2 * h)
+        assert product_rel(dimg, fd) < (3e-2 if param == "roughness" else 2e-3), (param, product_rel(dimg, fd))
+
+
+def product_rel(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-20))
