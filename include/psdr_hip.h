@@ -229,7 +229,14 @@ typedef struct psdr_grads {
     /* optional filter (autograd's requires_grad at the level of the snapshot): the interior adjoint skips what is not wanted */
     const uint8_t *mesh_filter;   /* DEVICE [n_meshes]: 1 = triangle rows of this mesh are wanted; NULL = all meshes */
     int32_t skip_bsdf, skip_emitter;   /* 1 = g_bsdf / g_emitter are not wanted (left untouched by the interior term) */
+    /* texel adjoints of the bitmap parameters (drjit.backward into Bitmap3fD / Bitmap1fD data): DEVICE [total] floats laid out
+     * as psdr_hip_scene_tex_layout reports, or NULL = not wanted */
+    float *g_tex;
 } psdr_grads;
+/* offsets[3*n_bsdfs] (HOST): float offset of the texel block of BSDF b's bitmap k (0 reflectance / diffuse reflectance rgb,
+ * 1 specular reflectance rgb, 2 roughness) inside psdr_grads.g_tex, same row-major layout as the bitmap; -1 = constant.
+ * *total = floats to allocate (0 = the scene has no bitmap parameter).  Either pointer may be NULL. */
+int psdr_hip_scene_tex_layout(const psdr_hip_scene *scene, int64_t *offsets, int64_t *total);
 int psdr_hip_render_d_bwd(const psdr_hip_scene *scene, const psdr_render_args *args, const float *d_rgb,
                           const psdr_grads *grads, void *stream);
 /* same kernels with traversal counters enabled (slower; counters is a HOST struct, call synchronises) */

@@ -467,6 +467,8 @@ def _sync_params(scene, tangents=None):
     for obj, name, t in _leaves(scene):
         v = t.detach().to("cpu", _torch.float32).numpy()
         shape = (4, 4) if name.startswith("to_world") else ((obj.num_vertices, 3) if name == "vertex_positions" else (-1,))
+        if isinstance(obj, _core.BSDF) and t.dim() >= 2:      # a bitmap parameter keeps its [H, W(, 3)] shape
+            shape = tuple(t.shape)
         v = v.reshape(shape)
         d = _zeros_like(v)
         if tangents is not None and id(t) in tangents:
@@ -587,13 +589,22 @@ class _RenderDFn(_torch.autograd.Function):
             if isinstance(obj, Mesh):
                 want_mesh[_mesh_index(scene, obj)] = 1
             elif isinstance(obj, _core.BSDF):
-                want_bsdf = True
+                want_bsdf = want_bsdf or t.dim() < 2          # (bitmap leaves are served by g_tex)
             elif isinstance(obj, _core.Emitter):
                 want_em = True
         mesh_filter = _torch.from_numpy(want_mesh).to(dev)
+        # bitmap parameters (a leaf of 2 or 3 dimensions on a BSDF): their texel adjoints come back in one flat buffer
+        tex_leaves = [i for i, ((obj, name, t), need) in enumerate(zip(leaves, needs)) if need and isinstance(obj, _core.BSDF) and t.dim() >= 2]
+        g_tex = None
+        if tex_leaves:
+            tex_off, tex_total = _core._tex_layout(scene)
+            g_tex = _torch.zeros(max(1, int(tex_total)), dtype=_torch.float32, device=dev)
         _core._render_d_bwd(integ, scene, st["sensor_id"], seeds, skips, g_img.data_ptr(), ptr[0], ptr[1], ptr[2], ptr[3], ptr[4],
-                            _stream_ptr(), rank, world, st["terms"], mesh_filter.data_ptr(), not want_bsdf, not want_em)
+                            _stream_ptr(), rank, world, st["terms"], mesh_filter.data_ptr(), not want_bsdf, not want_em,
+                            g_tex.data_ptr() if g_tex is not None else 0)
         _all_reduce(flat, world > 1)
+        if g_tex is not None:
+            _all_reduce(g_tex, world > 1)
         g = flat.to("cpu", _torch.float64)
         g_tri, g_bsdf, g_em = g[offs[0]:offs[1]].reshape(n_tris, 22), g[offs[1]:offs[2]].reshape(-1, 3)[:nb], g[offs[2]:offs[3]].reshape(-1, 3)[:ne]
         g_sec, g_prim = g[offs[3]:offs[4]].reshape(-1, 6)[:n_sec], g[offs[4]:offs[5]].reshape(-1, 4)[:n_prim]
@@ -624,6 +635,12 @@ class _RenderDFn(_torch.autograd.Function):
             for (i, f), r in zip(wanted, res):
                 t = leaves[i][2]
                 grads[i] = _torch.zeros_like(t) if r is None else r.reshape(t.shape).to(t.device, t.dtype)
+        for i in tex_leaves:          # the leaf IS the texel array: its gradient is its block of g_tex
+            obj, name, t = leaves[i]
+            b = next(k for k in range(nb) if pm["BSDF[%d]" % k] is obj)
+            slot = {"reflectance": 0, "diffuseReflectance": 0, "specularReflectance": 1, "roughness": 2}[name]
+            off = int(tex_off[3 * b + slot])
+            grads[i] = _torch.zeros_like(t) if off < 0 else g_tex[off:off + t.numel()].reshape(t.shape).to(t.device, t.dtype)
         return (None,) + tuple(grads)
 
 

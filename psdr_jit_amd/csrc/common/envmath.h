@@ -146,6 +146,27 @@ PSDR_HD void bitmap_eval_tex(TexelFn texel, int W, int H, R u, R v, bool flip_v,
     }
 }
 
+// the four texels and bilinear weights bitmap_eval_tex reads at (u, v): d out[c] / d texel[idx[k]][c] = w[k]
+PSDR_HD void bitmap_footprint(int W, int H, float u, float v, bool flip_v, int idx[4], float w[4]) {
+    float sr, cr;
+    sincos_f(0.f, sr, cr);
+    float x = (u - 0.5f) * cr + (v - 0.5f) * sr;
+    float y = -(u - 0.5f) * sr + (v - 0.5f) * cr;
+    x = x + 0.5f; y = y + 0.5f;
+    if (flip_v) y = -y;
+    x = x * 1.f; y = y * 1.f;
+    x = x - (-.5f + 1.f / 2); y = y + (-.5f + 1.f / 2);
+    x = x + 0.f; y = y + 0.f;
+    x = x - floorf(x); y = y - floorf(y);
+    x = x * (float) (W - 1); y = y * (float) (H - 1);
+    int px = (int) floorf(x), py = (int) floorf(y);
+    const float w1x = x - (float) px, w1y = y - (float) py, w0x = 1.0f - w1x, w0y = 1.0f - w1y;
+    px = px < W - 2 ? px : W - 2; py = py < H - 2 ? py : H - 2;
+    px = px < 0 ? 0 : px; py = py < 0 ? 0 : py;
+    idx[0] = py * W + px; idx[1] = idx[0] + 1; idx[2] = idx[0] + W; idx[3] = idx[2] + 1;
+    w[0] = w0y * w0x; w[1] = w0y * w1x; w[2] = w1y * w0x; w[3] = w1y * w1x;
+}
+
 // mass of cell idx of HyperCubeDistribution2f (envmap.cpp:28-31, cube_distrb.cpp:22-29): luminance * sin(theta)
 PSDR_HD float cell_mass(const float *data, int W, int H, int w2, int h2, int idx) {
     const int cx = idx / h2, cy = idx - cx * h2;

@@ -20,6 +20,8 @@ namespace psdr {
 constexpr int kAdjMaxDepth = 4;
 constexpr int kAdjHitWords = 4 * (1 + 2 * kAdjMaxDepth);      // recorded hits per lane
 constexpr int kAdjExtWords = 8;                                // light-sample slots per lane
+constexpr int kAdjLkWords = 3 * kAdjMaxLookups;                // bitmap lookups per lane (id, u, v)
+constexpr int kAdjLaneWords = kAdjHitWords + kAdjExtWords + kAdjLkWords;
 
 struct AdjointParams {
     int max_depth, hide_emitters;
@@ -38,6 +40,7 @@ struct AdjointParams {
     float intensity, d_intensity;
     const unsigned char *mesh_filter;   // [n_meshes] or NULL: only these meshes' triangle rows are probed
     int skip_bsdf, skip_emitter;
+    float *g_tex;                   // texel adjoints of the bitmap parameters (TexDev::g_off), or NULL
 };
 
 template <bool LDS>
@@ -46,7 +49,7 @@ PSDR_DEV void adj_add(float *lds_g, float *glob, int idx, float v, bool use_lds)
     if (use_lds) atomicAdd(&lds_g[idx], v); else atomicAdd(&glob[idx], v);
 }
 
-// scratch: per-block LDS region behind the blob/stack: [hits: kAdjHitWords x 256][ext: kAdjExtWords x 256][accumulators]
+// scratch: per-block LDS region behind the blob/stack: [hits: kAdjHitWords x 256][ext: kAdjExtWords x 256][lookups: kAdjLkWords x 256][accumulators]
 template <bool LDS>
 PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, const AdjointParams &P, float *scratch) {
     const SceneTables &T = *S.T;
@@ -55,7 +58,8 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
     const float inv_spp = T.spp > 1 ? 1.f / (float) T.spp : 1.f;
     float *rec = scratch + threadIdx.x;
     int *ext = reinterpret_cast<int *>(scratch + kAdjHitWords * kBlock) + threadIdx.x;
-    float *acc = scratch + (kAdjHitWords + kAdjExtWords) * kBlock;
+    float *lk = scratch + (kAdjHitWords + kAdjExtWords) * kBlock + threadIdx.x;
+    float *acc = scratch + kAdjLaneWords * kBlock;
     const int n_acc = T.n_tris * 22 + T.n_bsdfs * 3 + T.n_emitters * 3;
     const bool use_lds = P.lds_accum != 0;
     if (use_lds) {
@@ -63,7 +67,7 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
         __syncthreads();
     }
     float *acc_bsdf = acc + T.n_tris * 22, *acc_emit = acc_bsdf + T.n_bsdfs * 3;
-    S.rec = rec; S.ext = ext;
+    S.rec = rec; S.ext = ext; S.lk = lk;
 
     long long q_next = 0, q_end = 0;
     bool exhausted = false;
@@ -119,9 +123,9 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
             const float jx = rng.next_1d(), jy = rng.next_1d();
             const RayT<true> ray = sample_primary_ray<true>(cam, (bx + jx) / (float) T.width, (by + jy) / (float) T.height);
             const LaneRng rng0 = rng;
-            S.mode = 1; S.rec_n = 0; S.rec_i = 0; S.ext_n = 0; S.probe_kind = 0;
+            S.mode = 1; S.rec_n = 0; S.rec_i = 0; S.ext_n = 0; S.lk_n = 0; S.probe_kind = 0;
             const Vec3d L0 = Li<true, LDS, false>(S, rng, ray, true, P.max_depth, P.hide_emitters != 0);
-            const int n_hits = S.rec_n, n_ext = S.ext_n;
+            const int n_hits = S.rec_n, n_ext = S.ext_n, n_lk = (!LDS && P.g_tex != nullptr) ? S.lk_n : 0;
             float w[3];
             {
                 const float pv[3] = {L0.x.v, L0.y.v, L0.z.v};
@@ -172,18 +176,38 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                         if (!valid) { ++st_i; st_comp = 0; continue; }
                         return true;
                     }
+                    // stage 3: the bitmap lookups the path made - components 0..2 the diffuse / reflectance map, 3..5 the
+                    // specular map, 6 the roughness map of the BSDF; only the maps that exist are probed
+                    while (st_i < n_lk) {
+                        const int id = __float_as_int(lk[3 * st_i * kBlock]);
+                        const int fl = __float_as_int(S.ld(T.bsdf_off + 2 * id).w);
+                        while (st_comp < 7 && !(fl & (st_comp < 3 ? 2 : (st_comp < 6 ? 32 : 64)))) st_comp = st_comp < 3 ? 3 : (st_comp < 6 ? 6 : 7);
+                        if (st_comp >= 7) { ++st_i; st_comp = 0; continue; }
+                        st_id = id;
+                        return true;
+                    }
                     return false;
                 };
                 bool more = wactive && advance();
                 while (__ballot(more) != 0ull) {
                     if (more) {
-                        S.probe_kind = st_stage + 1; S.probe_id = st_id; S.probe_comp = st_comp;
+                        S.probe_kind = st_stage < 3 ? st_stage + 1 : 5; S.probe_id = st_id; S.probe_comp = st_comp;
+                        if (st_stage == 3) { S.probe_u = lk[(3 * st_i + 1) * kBlock]; S.probe_v = lk[(3 * st_i + 2) * kBlock]; }
                         const float gval = probe();
                         if (st_stage == 0) adj_add<LDS>(acc, P.g_tri, st_orig * 22 + st_comp, gval, use_lds);
                         else if (st_stage == 1) adj_add<LDS>(acc_bsdf, P.g_bsdf, st_id * 3 + st_comp, gval, use_lds);
-                        else adj_add<LDS>(acc_emit, P.g_emitter, st_id * 3 + st_comp, gval, use_lds);
+                        else if (st_stage == 2) adj_add<LDS>(acc_emit, P.g_emitter, st_id * 3 + st_comp, gval, use_lds);
+                        else if constexpr (!LDS) {
+                            // scatter over the footprint of the lookup (the transpose of the bilinear interpolation)
+                            const int tslot = st_comp < 3 ? 0 : (st_comp < 6 ? 1 : 2), ch = tslot == 2 ? 1 : 3, c = st_comp - 3 * tslot;
+                            const TexDev td = T.tex[3 * st_id + tslot];
+                            int idx[4]; float wt[4];
+                            env::bitmap_footprint(td.w, td.h, S.probe_u, S.probe_v, true, idx, wt);
+                            if (gval != 0.f && finite_(gval))
+                                for (int k = 0; k < 4; ++k) atomicAdd(&P.g_tex[td.g_off + (long long) ch * idx[k] + c], gval * wt[k]);
+                        }
                         ++st_comp;
-                        if (st_comp >= (st_stage == 0 ? 22 : 3)) { st_comp = 0; ++st_i; }
+                        if (st_comp >= (st_stage == 0 ? 22 : (st_stage == 3 ? 7 : 3))) { st_comp = 0; ++st_i; }
                         more = advance();
                     }
                 }

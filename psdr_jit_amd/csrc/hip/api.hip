@@ -57,6 +57,7 @@ PSDR_DEV SceneView<LDS> make_view(const float4 *blob, const SceneTables &T, floa
     S.stack = reinterpret_cast<int *>(smem + (LDS ? T.blob_words : 0)) + threadIdx.x;
     S.c_nodes = S.c_tris = S.c_rays = S.c_hits = 0u;
     S.mis = -1; S.field = -1; S.field_object = -1; S.intensity = 1.f; S.d_intensity = 0.f; S.mode = 0; S.rec = nullptr; S.rec_i = 0; S.rec_n = 0; S.ext = nullptr; S.ext_n = 0; S.probe_kind = 0; S.probe_id = 0; S.probe_comp = 0;
+    S.lk = nullptr; S.lk_n = 0; S.probe_u = 0.f; S.probe_v = 0.f;
     return S;
 }
 
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edges(const float4 *__rest
     bss.valid = false;
     float pdf0 = 1.f;
     if constexpr (ADJ) if (P.lds_acc) {
-        float *acc = scratch_base<LDS>(smem, T) + (kAdjHitWords + kAdjExtWords) * kBlock;
+        float *acc = scratch_base<LDS>(smem, T) + kAdjLaneWords * kBlock;
         for (int i = threadIdx.x; i < 6 * P.n_sec + 22 * T.n_tris; i += kBlock) acc[i] = 0.f;
         __syncthreads();
     }
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edges(const float4 *__rest
         if constexpr (ADJ) if (have) {
             // reverse mode: record the three rays once, then probe the quantities the tangent is linear in
             float *rec = scratch_base<LDS>(smem, T) + threadIdx.x;
-            float *g_sec = P.lds_acc ? scratch_base<LDS>(smem, T) + (kAdjHitWords + kAdjExtWords) * kBlock : P.g_sec;
+            float *g_sec = P.lds_acc ? scratch_base<LDS>(smem, T) + kAdjLaneWords * kBlock : P.g_sec;
             float *g_tri = P.lds_acc ? g_sec + 6 * P.n_sec : P.g_tri;
             S.rec = rec; S.mode = 1; S.rec_n = 0; S.rec_i = 0; S.probe_kind = 0;
             BoundarySegSampleDirect b0 = bss;
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edges(const float4 *__rest
         }
     }
     if constexpr (ADJ) if (P.lds_acc) {
-        float *acc = scratch_base<LDS>(smem, T) + (kAdjHitWords + kAdjExtWords) * kBlock;
+        float *acc = scratch_base<LDS>(smem, T) + kAdjLaneWords * kBlock;
         __syncthreads();
         for (int i = threadIdx.x; i < 6 * P.n_sec; i += kBlock) if (acc[i] != 0.f) atomicAdd(&P.g_sec[i], acc[i]);
         for (int i = threadIdx.x; i < 22 * T.n_tris; i += kBlock) if (acc[6 * P.n_sec + i] != 0.f) atomicAdd(&P.g_tri[i], acc[6 * P.n_sec + i]);
@@ -390,6 +391,8 @@ struct psdr_hip_scene {
     DevBuf queues;                       // ring of work-queue heads, one per path-kernel launch
     mutable unsigned queue_slot = 0;
     int n_leaves = 0, max_depth = 0, grid = 0;
+    long long tex_total = 0;             // floats of all bitmap parameters (psdr_grads.g_tex)
+    std::vector<long long> tex_layout;   // [3*n_bsdfs] offsets into g_tex, -1 = constant
     const float *up(const float *src, size_t n, int &rc) {
         if (!src) return nullptr;
         bufs.emplace_back(new DevBuf());
@@ -470,7 +473,8 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
         bool any_tex = false;
         for (int i = 0; i < s->n_bsdfs; ++i) any_tex |= s->bsdfs[i].tex_data != nullptr || s->bsdfs[i].spec_tex_data != nullptr || s->bsdfs[i].rough_tex_data != nullptr;
         if (any_tex) {
-            std::vector<TexDev> td((size_t) 3 * s->n_bsdfs, TexDev{nullptr, nullptr, 0, 0});
+            std::vector<TexDev> td((size_t) 3 * s->n_bsdfs, TexDev{nullptr, nullptr, 0, 0, -1});
+            sc->tex_total = 0;
             int rc = 0;
             for (int i = 0; i < s->n_bsdfs; ++i) {
                 const psdr_bsdf_rec &b = s->bsdfs[i];
@@ -484,12 +488,15 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
                     td[3 * i + k].data = sc->up(src[k], nt, rc);
                     td[3 * i + k].d_data = sc->up(dsrc[k], nt, rc);
                     td[3 * i + k].w = tw[k]; td[3 * i + k].h = th[k];
+                    td[3 * i + k].g_off = sc->tex_total; sc->tex_total += (long long) nt;
                 }
             }
             sc->bufs.emplace_back(new DevBuf());
             rc |= sc->bufs.back()->upload(td.data(), td.size() * sizeof(TexDev));
             if (rc) return 1;
             T.tex = sc->bufs.back()->as<TexDev>();
+            sc->tex_layout.resize(td.size());
+            for (size_t i = 0; i < td.size(); ++i) sc->tex_layout[i] = td[i].g_off;
         }
     }
     T.mat = nullptr;
@@ -811,6 +818,14 @@ int psdr_hip_li_lanes(const psdr_hip_scene *sc, const psdr_render_args *a, int64
     return render_impl<false>(sc, a, false, nullptr, nullptr, out, lane_begin, lane_end, nullptr, stream);
 }
 
+int psdr_hip_scene_tex_layout(const psdr_hip_scene *sc, int64_t *offsets, int64_t *total) {
+    if (!sc) return fail("null scene");
+    if (total) *total = sc->tex_total;
+    if (offsets)
+        for (int i = 0; i < 3 * sc->T.n_bsdfs; ++i) offsets[i] = (size_t) i < sc->tex_layout.size() ? sc->tex_layout[i] : -1;
+    return 0;
+}
+
 int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, const float *d_rgb, const psdr_grads *g, void *stream) {
     if (check_args(sc, a)) return 1;
     if (!d_rgb || !g || !g->g_triangles || !g->g_bsdf || !g->g_emitter) return fail("null gradient buffer");
@@ -833,6 +848,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         HIPCHK(hipMemsetAsync(g->g_triangles, 0, sizeof(float) * 22 * (size_t) T.n_tris, st));
         HIPCHK(hipMemsetAsync(g->g_bsdf, 0, sizeof(float) * 3 * (size_t) std::max(1, T.n_bsdfs), st));
         HIPCHK(hipMemsetAsync(g->g_emitter, 0, sizeof(float) * 3 * (size_t) std::max(1, T.n_emitters), st));
+        if (g->g_tex && sc->tex_total > 0) HIPCHK(hipMemsetAsync(g->g_tex, 0, sizeof(float) * (size_t) sc->tex_total, st));
         if (g->g_sec_edges && sc->E.n > 0) HIPCHK(hipMemsetAsync(g->g_sec_edges, 0, sizeof(float) * 6 * (size_t) sc->E.n, st));
         if (g->g_prim_edges && cam.n_edges > 0) HIPCHK(hipMemsetAsync(g->g_prim_edges, 0, sizeof(float) * 4 * (size_t) cam.n_edges, st));
     }
@@ -843,7 +859,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     };
     const size_t n_acc = (size_t) T.n_tris * 22 + (size_t) T.n_bsdfs * 3 + (size_t) T.n_emitters * 3;
     const bool lds_acc = n_acc * sizeof(float) <= 32 * 1024;
-    const size_t adj_bytes = sizeof(float) * ((size_t) (kAdjHitWords + kAdjExtWords) * kBlock + (lds_acc ? n_acc : 0));
+    const size_t adj_bytes = sizeof(float) * ((size_t) kAdjLaneWords * kBlock + (lds_acc ? n_acc : 0));
     const size_t smem = sc->smem_bytes + adj_bytes;
     if (smem > 160 * 1024) return fail("scene too large for the adjoint kernel's LDS records");
     static bool attr_set = false;
@@ -860,6 +876,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         P.begin = 0; P.end = npx * T.spp; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
         P.w = d_rgb; P.g_tri = g->g_triangles; P.g_bsdf = g->g_bsdf; P.g_emitter = g->g_emitter; P.lds_accum = lds_acc ? 1 : 0;
         P.mesh_filter = g->mesh_filter; P.skip_bsdf = g->skip_bsdf; P.skip_emitter = g->skip_emitter;
+        P.g_tex = sc->tex_total > 0 ? g->g_tex : nullptr;
         if (P.n_local > 0) {
             if (next_queue(P.counter)) return 1;
             const int grid = grid_for(sc, P.n_local);
@@ -889,7 +906,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         P.adj_w = d_rgb; P.g_sec = g->g_sec_edges; P.g_tri = g->g_triangles; P.n_sec = sc->E.n;
         const size_t sec_acc = sizeof(float) * (6 * (size_t) sc->E.n + 22 * (size_t) T.n_tris);
         P.lds_acc = (sec_acc <= 48 * 1024) ? 1 : 0;
-        const size_t smem_sec = sc->smem_bytes + sizeof(float) * (size_t) (kAdjHitWords + kAdjExtWords) * kBlock + (P.lds_acc ? sec_acc : 0);
+        const size_t smem_sec = sc->smem_bytes + sizeof(float) * (size_t) kAdjLaneWords * kBlock + (P.lds_acc ? sec_acc : 0);
         GuidingDev G{};
         const int use_g = a->guiding ? 1 : 0;
         if (a->guiding) G = a->guiding->G;

@@ -28,8 +28,9 @@ struct EnvDev {
     float lower[3], upper[3];
 };
 
-// reflectance texture of one BSDF (global memory; w == 0: constant colour)
-struct TexDev { const float *data, *d_data; int w, h; };
+// one bitmap parameter of a BSDF (global memory; w == 0: constant).  SceneTables::tex holds three per BSDF:
+// [0] reflectance / diffuse reflectance (rgb), [1] specular reflectance (rgb), [2] roughness (one channel)
+struct TexDev { const float *data, *d_data; int w, h; long long g_off; };    // g_off: offset of its texel adjoints in psdr_grads.g_tex
 
 // Microfacet parameters beyond the diffuse reflectance (global memory table, one entry per BSDF; microfacet.h)
 struct MatDev {
@@ -76,6 +77,8 @@ struct SensorDev {
 struct Counters { unsigned long long rays, nodes, tris, hits; };
 
 // per-lane view used by every device function
+constexpr int kAdjMaxLookups = 6;      // bitmap lookups recorded per path (one per textured vertex; max_depth <= 4)
+
 template <bool LDS> struct SceneView {
     const float4 *B;           // blob base (LDS or global)
     const float4 *G;           // blob base in global memory (wave-uniform reads become scalar loads)
@@ -95,8 +98,28 @@ template <bool LDS> struct SceneView {
     int rec_i, rec_n;          // replay cursor / number of recorded hits
     int *ext;                  // extra triangle slots read without a trace (light samples), stride kBlock
     int ext_n;
-    int probe_kind;            // 0 none, 1 triangle field, 2 bsdf reflectance, 3 emitter radiance, 4 camera to_world
+    int probe_kind;            // 0 none, 1 triangle field, 2 bsdf reflectance, 3 emitter radiance, 4 camera to_world, 5 bitmap lookup
     int probe_id, probe_comp;
+    // bitmap-parameter lookups (textured BSDFs): the recording run notes (bsdf id, u, v) of every lookup; a probe of kind 5
+    // puts a unit tangent on one component of the looked-up value of ONE such lookup (matched by id and the bit-equal uv the
+    // replay reproduces); the kernel scatters the result over the four texels of the lookup's footprint
+    float *lk;                 // this lane's LDS lookup record, stride kBlock: 3 words per entry (id, u, v)
+    mutable int lk_n;
+    float probe_u, probe_v;
+    PSDR_DEV void note_lookup(int id, float u, float v) const {
+        if (mode != 1) return;
+        for (int i = 0; i < lk_n; ++i)
+            if (__float_as_int(lk[3 * i * kBlock]) == id && lk[(3 * i + 1) * kBlock] == u && lk[(3 * i + 2) * kBlock] == v) return;
+        if (lk_n >= kAdjMaxLookups) return;
+        lk[3 * lk_n * kBlock] = __int_as_float(id); lk[(3 * lk_n + 1) * kBlock] = u; lk[(3 * lk_n + 2) * kBlock] = v;
+        ++lk_n;
+    }
+    // component c0..c0+n-1 of the probe belongs to this lookup: which one gets the unit tangent (-1 = none)
+    PSDR_DEV int lookup_hot(int id, float u, float v, int c0, int n) const {
+        if (probe_kind != 5 || probe_id != id || u != probe_u || v != probe_v) return -1;
+        const int c = probe_comp - c0;
+        return (c >= 0 && c < n) ? c : -1;
+    }
 
     PSDR_DEV bool tan_on() const { return probe_kind != 0 || T->has_tangent != 0; }
     // word k (0..5) of the 22-float tangent row [p0 e1 e2 n0 n1 n2 fn area] of triangle slot `slot`

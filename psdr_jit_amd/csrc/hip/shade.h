@@ -361,7 +361,7 @@ template <bool AD, bool LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S
             const MatDev md = S.T->mat[id];
             const int fl = __float_as_int(a.w);
             // bitmap parameters (microfacet.cpp:38-45): looked up with (value, tangent) texels and uv, detached in C mode
-            const bool tan = AD && S.mode == 0;            // (specular / roughness / texel adjoints are not returned by reverse mode)
+            const bool tan = AD && S.mode == 0;            // (reverse mode returns no adjoint for the constant specular / roughness)
             const Dual tu = Dual(its.tu), tv = Dual(its.tv);
             Vec3d spec(Dual(md.specular[0], tan ? md.d_specular[0] : 0.f), Dual(md.specular[1], tan ? md.d_specular[1] : 0.f), Dual(md.specular[2], tan ? md.d_specular[2] : 0.f));
             Dual rough(md.roughness, tan ? md.d_roughness : 0.f);
@@ -374,6 +374,11 @@ template <bool AD, bool LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S
                     constexpr int CH = decltype(ch)::value;
                     const bool tt = tan && td.d_data != nullptr;
                     env::bitmap_eval_tex<Dual, CH>([&](int i, int c) { return Dual(td.data[CH * i + c], tt ? td.d_data[CH * i + c] : 0.f); }, td.w, td.h, tu, tv, true, out);
+                    if constexpr (AD) {                    // reverse mode: note the lookup / carry the probe's unit tangent (scene_dev.h)
+                        S.note_lookup(id, tu.v, tv.v);
+                        const int hot = S.lookup_hot(id, tu.v, tv.v, 3 * slot, CH);
+                        if (hot >= 0) out[hot].d += 1.f;
+                    }
                 };
                 Dual o[3];
                 if (fl & 2) { look(0, std::integral_constant<int, 3>(), o); diff = Vec3d(o[0], o[1], o[2]); }
@@ -423,9 +428,12 @@ template <bool AD, bool LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S
             const TexDev td = S.T->tex[3 * mesh_bsdf(S, its.mesh)];
             R rgb[3];
             if constexpr (AD) {
-                const bool tan = td.d_data != nullptr && S.mode == 0;      // (texel adjoints are not returned by reverse mode)
+                const bool tan = td.d_data != nullptr && S.mode == 0;      // (reverse mode: the texel adjoints come from the lookup probes)
                 env::bitmap_eval_tex<Dual>([&](int i, int c) { return Dual(td.data[3 * i + c], tan ? td.d_data[3 * i + c] : 0.f); },
                                            td.w, td.h, its.tu, its.tv, true, rgb);
+                S.note_lookup(mesh_bsdf(S, its.mesh), its.tu.v, its.tv.v);
+                const int hot = S.lookup_hot(mesh_bsdf(S, its.mesh), its.tu.v, its.tv.v, 0, 3);
+                if (hot >= 0) rgb[hot].d += 1.f;
             } else {
                 env::bitmap_eval_tex<float>([&](int i, int c) { return td.data[3 * i + c]; }, td.w, td.h, its.tu, its.tv, true, rgb);
             }

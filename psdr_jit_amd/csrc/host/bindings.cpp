@@ -7,6 +7,7 @@
 #include <pybind11/stl.h>
 
 #include "scene_host.h"
+#include "exr_piz.h"
 
 namespace py = pybind11;
 using namespace py::literals;
@@ -336,7 +337,7 @@ PYBIND11_MODULE(_psdr_core, m) {
 
     m.def("_render_d_bwd", [](const Integrator &it, const Scene &scene, int sensor_id, const std::vector<uint64_t> &seeds, const std::vector<uint64_t> &skips,
                               uintptr_t d_rgb, uintptr_t g_tri, uintptr_t g_bsdf, uintptr_t g_emitter, uintptr_t g_sec, uintptr_t g_prim, uintptr_t stream,
-                              int rank, int count, int terms, uintptr_t mesh_filter, bool skip_bsdf, bool skip_emitter) {
+                              int rank, int count, int terms, uintptr_t mesh_filter, bool skip_bsdf, bool skip_emitter, uintptr_t g_tex) {
         if (!scene.is_ready()) throw Exception("Input scene must be configured!");
         psdr_render_args a;
         std::memset(&a, 0, sizeof(a));
@@ -348,9 +349,31 @@ PYBIND11_MODULE(_psdr_core, m) {
         if (!it.field_object().empty()) throw Exception("reverse mode: FieldExtractionIntegrator with an object filter is not supported");
         psdr_grads g{reinterpret_cast<float *>(g_tri), reinterpret_cast<float *>(g_bsdf), reinterpret_cast<float *>(g_emitter),
                      reinterpret_cast<float *>(g_sec), reinterpret_cast<float *>(g_prim),
-                     reinterpret_cast<const uint8_t *>(mesh_filter), skip_bsdf ? 1 : 0, skip_emitter ? 1 : 0};
+                     reinterpret_cast<const uint8_t *>(mesh_filter), skip_bsdf ? 1 : 0, skip_emitter ? 1 : 0, reinterpret_cast<float *>(g_tex)};
         if (psdr_hip_render_d_bwd(scene.m_hip, &a, reinterpret_cast<const float *>(d_rgb), &g, reinterpret_cast<void *>(stream)))
             throw Exception(std::string("libpsdr_hip: ") + psdr_hip_last_error());
+    });
+
+    // one PIZ chunk of an EXR file -> its uncompressed 16-bit words (exr_piz.cpp; used by psdr_jit_amd/exr.py)
+    m.def("_piz_decode", [](const py::bytes &chunk, int nx, int ny, const std::vector<int> &words_per_sample) {
+        const std::string buf = chunk;
+        size_t total = 0;
+        for (int w : words_per_sample) total += (size_t) nx * ny * w;
+        py::array_t<uint16_t> out((py::ssize_t) total);
+        try {
+            piz_decode_chunk(reinterpret_cast<const uint8_t *>(buf.data()), buf.size(), nx, ny, words_per_sample, out.mutable_data());
+        } catch (const std::runtime_error &e) { throw Exception(e.what()); }
+        return out;
+    });
+
+    // (offsets[3*n_bsdfs], total) of psdr_hip_scene_tex_layout
+    m.def("_tex_layout", [](const Scene &scene) {
+        if (!scene.is_ready()) throw Exception("Input scene must be configured!");
+        std::vector<int64_t> off((size_t) 3 * std::max<size_t>(1, scene.m_bsdfs.size()), -1);
+        int64_t total = 0;
+        if (psdr_hip_scene_tex_layout(scene.m_hip, off.data(), &total)) throw Exception(std::string("libpsdr_hip: ") + psdr_hip_last_error());
+        off.resize((size_t) 3 * scene.m_bsdfs.size());
+        return py::make_tuple(off, total);
     });
 
     py::class_<PathTracer, Integrator>(m, "PathTracer", py::dynamic_attr())

@@ -1,6 +1,6 @@
 """Minimal OpenEXR reader/writer for radiance images (host-side file I/O of EnvironmentMap / Bitmap, which the
 reference delegates to tinyexr in src/core/bitmap_loader.cpp).  Supports what lat-long environment maps use in practice:
-single-part scanline files, channels of type HALF or FLOAT (any of R, G, B, A, Y), compression NONE, ZIPS or ZIP,
+single-part scanline files, channels of type HALF or FLOAT (any of R, G, B, A, Y), compression NONE, ZIPS, ZIP or PIZ,
 increasing-y line order.  Anything else raises.  Format: "OpenEXR File Layout" (magic 20000630, version 2)."""
 import struct
 import zlib
@@ -57,13 +57,13 @@ def read_rgb(path):
             raise RuntimeError("EXR: subsampled channels are not supported")
         channels.append((cname, ptype))
     comp = attrs["compression"][1][0]
-    if comp not in (0, 2, 3):
-        raise RuntimeError("EXR: compression %d not supported (NONE, ZIPS, ZIP only)" % comp)
+    if comp not in (0, 2, 3, 4):
+        raise RuntimeError("EXR: compression %d not supported (NONE, ZIPS, ZIP, PIZ only)" % comp)
     xmin, ymin, xmax, ymax = struct.unpack("<4i", attrs["dataWindow"][1])
     W, H = xmax - xmin + 1, ymax - ymin + 1
     if attrs.get("lineOrder", ("", b"\0"))[1][0] not in (0, 1):
         raise RuntimeError("EXR: random line order is not supported")
-    lines_per_block = 16 if comp == 3 else 1
+    lines_per_block = {3: 16, 4: 32}.get(comp, 1)
     n_blocks = (H + lines_per_block - 1) // lines_per_block
     offsets = struct.unpack_from("<%dQ" % n_blocks, buf, pos)
     bpp = {0: 4, 1: 2, 2: 4}
@@ -74,7 +74,10 @@ def read_rgb(path):
         data = buf[off + 8:off + 8 + size]
         rows = min(lines_per_block, ymax - y + 1)
         raw_size = rows * W * sum(bpp[t] for _, t in channels)
-        if comp != 0 and size < raw_size:
+        if comp == 4 and size < raw_size:
+            from . import _psdr_core                         # the PIZ decoder is native (csrc/host/exr_piz.cpp)
+            data = _psdr_core._piz_decode(bytes(data), W, rows, [bpp[t] // 2 for _, t in channels]).tobytes()
+        elif comp != 0 and size < raw_size:
             data = _unpredict(zlib.decompress(data))
         q = 0
         for r in range(rows):

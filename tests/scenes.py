@@ -380,3 +380,31 @@ def textured_microfacet_scene(width=48, height=48, spp=4, sppe=0, sppse=0, param
     elif param not in (None, "box_x"):
         raise ValueError(param)
     return spec
+
+
+def envmap_tutorial_scene(width=48, height=48, spp=4, sppe=0, sppse=0, param="bunny_x", env_stride=8):
+    """The reference's tutorials/Forward_AD_envmap.ipynb scene: bunny_low.obj (4968 triangles) with
+    MicrofacetBSDF([0.2, 0.9, 0.9], [0.01, 0.01, 0.01], 0.3), translated to z = -100, lit by ballroom_1k.exr (the tutorial's own
+    PIZ-compressed environment map, read with psdr_jit_amd.exr and decimated by env_stride to keep the oracle quick), camera
+    fov 80 looking down -z.  param: 'bunny_x' (Mesh[0].to_world_left = T(100 P, 0, 0), as in the notebook) | 'roughness' | None"""
+    from psdr_jit_amd import exr
+    root = os.path.dirname(os.path.dirname(DATA))
+    env = exr.read_rgb(os.path.join(root, "data", "envmap", "ballroom_1k.exr"))
+    env = np.ascontiguousarray(env[::env_stride, ::env_stride])
+    path = os.path.join(root, "data", "mesh", "bunny_low.obj")
+    v, f, uv, fuv = load_obj(path)
+    bunny = MeshSpec(vertices=v, faces=f, uvs=uv, face_uvs=fuv, bsdf=0, emitter=-1, path=path)
+    bunny.to_world_raw = translate(0.0, 0.0, -100.0)
+    bsdfs = [BsdfSpec((0.01, 0.01, 0.01), name="bunny", type=1, specular=(0.2, 0.9, 0.9), roughness=0.3)]
+    cam_m = np.diag([-1.0, 1.0, -1.0, 1.0]).astype(np.float32)
+    cam = CameraSpec(80.0, 0.000001, 10000000.0, to_world_raw=cam_m)
+    emitters = [EmitterSpec(type=1, env_data=env, env_scale=1.0)]
+    if param == "bunny_x":
+        dT = np.zeros((4, 4), dtype=np.float32)
+        dT[0, 3] = 100.0
+        bunny.d_to_world_left = dT
+    elif param == "roughness":
+        bsdfs[0].d_roughness = 1.0
+    elif param is not None:
+        raise ValueError(param)
+    return SceneSpec([bunny], bsdfs, emitters, [cam], width, height, spp, sppe, sppse)
