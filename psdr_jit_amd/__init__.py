@@ -286,6 +286,8 @@ def _roughconductor_init(self, *args):
     _RoughConductorBSDF_init(self)
     if not args:
         return
+    # 1x1 Bitmap1fD / Bitmap3fD arguments (tutorials/batch_render.ipynb) are the constants they hold
+    args = tuple(_const_of(a, a.data.size) if isinstance(a, (Bitmap3fD, Bitmap1fD)) and a.data.size in (1, 3) else a for a in args)
     scal = lambda x: float(_np.ravel(_split(x, (-1,))[0])[0])
     first_two_scalar = len(args) >= 4 and _np.size(_split(args[1], (-1,))[0]) == 1
     if first_two_scalar:
