@@ -527,7 +527,7 @@ def _render_d_raw(self, scene, sensor_id, seed, batch_pix, terms, distributed=No
     pix = _pix(batch_pix, dev)
     n = int(pix.numel()) if pix is not None else scene.opts.width * scene.opts.height
     rank, world = _shard() if distributed in (None, True) else (0, 1)
-    buf = _torch.empty((2, n, 3), dtype=_torch.float32, device=dev)
+    buf = (_torch.empty if (terms & 7) else _torch.zeros)((2, n, 3), dtype=_torch.float32, device=dev)
     self._renderD(scene, sensor_id, seed, pix.data_ptr() if pix is not None else 0, n, buf[0].data_ptr(), buf[1].data_ptr(), _stream_ptr(), rank, world, terms)
     _all_reduce(buf, world > 1)      # one collective for image + derivative
     return buf[0], buf[1]
@@ -666,11 +666,14 @@ def _renderD(self, scene, sensor_id=0, seed=-1, batch_pix=-1, terms=TERM_ALL):
     state = {"integrator": self, "scene": scene, "sensor_id": sensor_id, "batch_pix": batch_pix, "terms": terms,
              "active": scene.__dict__.get("_psdr_active", []), "leaves": leaves, "seed": seed,
              "samplers": [scene._sampler_state(k) for k in range(3)]}      # the streams this call starts from
-    img, dimg = _render_d_raw(self, scene, sensor_id, seed, batch_pix, terms)
-    state["img"] = img
     tens = [t for (_, _, t) in leaves]
     if any(t.requires_grad for t in tens):
+        # the derivative is computed later (forward_grad / backward) from the recorded sampler state: now only the primal
+        # image is needed, and both edge terms have zero primal - launch the interior term, advance all three samplers
+        img, _ = _render_d_raw(self, scene, sensor_id, seed, batch_pix, (terms & TERM_INTERIOR) | ((terms & 7) << 4))
+        state["img"] = img
         return _RenderDFn.apply(state, *tens)
+    img, dimg = _render_d_raw(self, scene, sensor_id, seed, batch_pix, terms)
     return img
 
 

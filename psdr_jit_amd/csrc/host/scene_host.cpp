@@ -829,9 +829,15 @@ void Integrator::renderD(const Scene &scene, int sensor_id, int seed, uintptr_t 
     }
     psdr_render_args a;
     fill_args(a, scene, *this, sensor_id, pix_ids, n_pix, rank, count);
+    // terms: bits 0-2 = the terms to launch; bits 4-6 (optional) = the terms whose samplers advance, as in a full renderD.
+    // The Python layer renders the primal image with the interior term alone (both edge terms have zero primal,
+    // integrator.cpp:192, path.cpp:265) and computes derivatives later from the recorded sampler state.
+    const int launch = terms & 7;
+    terms = ((terms >> 4) & 7) ? ((terms >> 4) & 7) : launch;
     if (field() >= 0) terms &= ~PSDR_TERM_SECONDARY;         // Integrator::render_secondary_edges is a no-op for the first-hit integrators
-    a.terms = terms;
-    hip_check(psdr_hip_render_d_fwd(scene.m_hip, &a, reinterpret_cast<float *>(out), reinterpret_cast<float *>(dout), reinterpret_cast<void *>(stream)));
+    a.terms = launch & terms;
+    if (a.terms)
+        hip_check(psdr_hip_render_d_fwd(scene.m_hip, &a, reinterpret_cast<float *>(out), reinterpret_cast<float *>(dout), reinterpret_cast<void *>(stream)));
     const PerspectiveCamera *cam = static_cast<const PerspectiveCamera *>(scene.m_sensors[sensor_id]);
     if (opts.spp > 0 && (terms & PSDR_TERM_INTERIOR)) scene.m_samplers[0].skip += 2 + (uint64_t) draws_per_level() * (uint64_t) max_depth();
     if (opts.sppe > 0 && cam->m_enable_edges && (terms & PSDR_TERM_PRIMARY) && !pix_ids) scene.m_samplers[1].skip += 1 + 2 * (uint64_t) draws_per_level() * (uint64_t) max_depth();
