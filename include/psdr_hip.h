@@ -232,6 +232,11 @@ typedef struct psdr_grads {
     /* texel adjoints of the bitmap parameters (drjit.backward into Bitmap3fD / Bitmap1fD data): DEVICE [total] floats laid out
      * as psdr_hip_scene_tex_layout reports, or NULL = not wanted */
     float *g_tex;
+    /* adjoint of the sensor's to_world through the camera rays of the interior and secondary-edge terms (DEVICE [16], row major,
+     * rows 0-2 filled),
+     * or NULL = not wanted.  The camera's share of the primary-edge term arrives through g_prim_edges (sample-space edge
+     * endpoints = world_to_sample . vertex: the host chains both). */
+    float *g_camera;
 } psdr_grads;
 /* offsets[3*n_bsdfs] (HOST): float offset of the texel block of BSDF b's bitmap k (0 reflectance / diffuse reflectance rgb,
  * 1 specular reflectance rgb, 2 roughness) inside psdr_grads.g_tex, same row-major layout as the bitmap; -1 = constant.

@@ -557,9 +557,7 @@ class _RenderDFn(_torch.autograd.Function):
         integ, scene = st["integrator"], st["scene"]
         leaves = st["leaves"]
         needs = ctx.needs_input_grad[1:]
-        for (obj, name, t), need in zip(leaves, needs):
-            if need and isinstance(obj, Sensor):
-                raise NotImplementedError("reverse mode w.r.t. the camera pose is not implemented; use forward_grad()")
+        want_cam = any(need and isinstance(obj, Sensor) for (obj, name, t), need in zip(leaves, needs))
         dev = grad_img.device
         g_img = grad_img.contiguous().to(_torch.float32)
         snap = scene._snapshot()
@@ -601,10 +599,13 @@ class _RenderDFn(_torch.autograd.Function):
         if tex_leaves:
             tex_off, tex_total = _core._tex_layout(scene)
             g_tex = _torch.zeros(max(1, int(tex_total)), dtype=_torch.float32, device=dev)
+        g_cam = _torch.zeros(16, dtype=_torch.float32, device=dev) if want_cam else None
         _core._render_d_bwd(integ, scene, st["sensor_id"], seeds, skips, g_img.data_ptr(), ptr[0], ptr[1], ptr[2], ptr[3], ptr[4],
                             _stream_ptr(), rank, world, st["terms"], mesh_filter.data_ptr(), not want_bsdf, not want_em,
-                            g_tex.data_ptr() if g_tex is not None else 0)
+                            g_tex.data_ptr() if g_tex is not None else 0, g_cam.data_ptr() if g_cam is not None else 0)
         _all_reduce(flat, world > 1)
+        if g_cam is not None:
+            _all_reduce(g_cam, world > 1)
         if g_tex is not None:
             _all_reduce(g_tex, world > 1)
         g = flat.to("cpu", _torch.float64)
@@ -623,9 +624,10 @@ class _RenderDFn(_torch.autograd.Function):
             return _torch.as_tensor(_np.asarray(obj._get(name, False), dtype=_np.float64))
 
         with _torch.enable_grad():          # autograd runs backward() with grad mode off
-            tri, sec, prim, refl, rad = chain.snapshot_tensors(scene, st["sensor_id"], leaf_of)
+            tri, sec, prim, refl, rad, cam_tw = chain.snapshot_tensors(scene, st["sensor_id"], leaf_of)
+        g_camera = g_cam.to("cpu", _torch.float64).reshape(4, 4) if g_cam is not None else _torch.zeros((4, 4), dtype=_torch.float64)
         outs, gos = [], []
-        for o, go in ((tri, g_tri), (sec, g_sec), (prim, g_prim), (refl, g_bsdf), (rad, g_em)):
+        for o, go in ((tri, g_tri), (sec, g_sec), (prim, g_prim), (refl, g_bsdf), (rad, g_em), (cam_tw, g_camera)):
             if o.requires_grad and o.numel() > 0:
                 outs.append(o)
                 gos.append(go.reshape(o.shape))

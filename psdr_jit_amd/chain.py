@@ -5,7 +5,7 @@ psdr_hip_render_d_bwd returns: TriangleInfo rows, edge tables, colours) to the u
 The differentiable part of Scene::configure (reference src/shape/mesh.cpp:23-62,317-369 process_mesh +
 SecondaryEdgeInfo, src/sensor/perspective.cpp:130-143 primary-edge projection) is restated with torch
 ops in float64 and differentiated by torch.autograd — O(#triangles) glue; the per-sample work is all
-in the HIP kernels.  (Camera-pose leaves are forward-mode only.)
+in the HIP kernels.
 """
 import math
 
@@ -61,7 +61,7 @@ def _camera_to_sample(fov_x, near, far, aspect):
 
 def snapshot_tensors(scene, sensor_id, leaf_of):
     """leaf_of(obj, name) -> float64 tensor (a fresh leaf for differentiable parameters, a constant otherwise).
-    Returns (tri_rows, sec_rows, prim_rows, refl_rows, rad_rows) in the snapshot's row order."""
+    Returns (tri_rows, sec_rows, prim_rows, refl_rows, rad_rows, camera to_world) in the snapshot's row order."""
     pm = scene.param_map
     Vws, tri_rows, sec_rows = [], [], []
     for i in range(scene.num_meshes):
@@ -85,10 +85,11 @@ def snapshot_tensors(scene, sensor_id, leaf_of):
     sec = torch.cat(sec_rows, dim=0) if sec_rows else torch.zeros((0, 6), dtype=F64)
     cam = pm["Sensor[%d]" % sensor_id]
     ids = torch.as_tensor(np.asarray(cam._primary_edge_ids(), dtype=np.int64)).reshape(-1, 3)
+    # Sensor::configure: to_world = left . raw . right (sensor.cpp); the interior term's adjoint of it is psdr_grads.g_camera
+    tw = leaf_of(cam, "to_world_left").reshape(4, 4) @ leaf_of(cam, "to_world").reshape(4, 4) @ leaf_of(cam, "to_world_right").reshape(4, 4)
     if ids.shape[0] > 0:
         fov, near, far = cam._camera_params()
         aspect = float(scene.opts.width) / float(scene.opts.height)
-        tw = leaf_of(cam, "to_world_left").reshape(4, 4) @ leaf_of(cam, "to_world").reshape(4, 4) @ leaf_of(cam, "to_world_right").reshape(4, 4)
         w2s = _camera_to_sample(fov, near, far, aspect) @ torch.linalg.inv(tw)
         q0, q1 = [], []
         for mid, v0, v1 in ids.tolist():
@@ -113,4 +114,4 @@ def snapshot_tensors(scene, sensor_id, leaf_of):
     def _rad(e):      # the environment map's texels are not differentiated (its row of g_emitter stays zero)
         return torch.zeros(3, dtype=F64) if type(e).__name__ == "EnvironmentMap" else leaf_of(e, "radiance").reshape(-1).expand(3)
     rad = torch.stack([_rad(pm["Emitter[%d]" % i]) for i in range(ne)]) if ne else torch.zeros((0, 3), dtype=F64)
-    return tri, sec, prim, refl, rad
+    return tri, sec, prim, refl, rad, tw

@@ -41,6 +41,7 @@ struct AdjointParams {
     const unsigned char *mesh_filter;   // [n_meshes] or NULL: only these meshes' triangle rows are probed
     int skip_bsdf, skip_emitter;
     float *g_tex;                   // texel adjoints of the bitmap parameters (TexDev::g_off), or NULL
+    float *g_cam;                   // [16] adjoint of the sensor's to_world (row major, rows 0-2 filled), or NULL
 };
 
 template <bool LDS>
@@ -59,7 +60,8 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
     float *rec = scratch + threadIdx.x;
     int *ext = reinterpret_cast<int *>(scratch + kAdjHitWords * kBlock) + threadIdx.x;
     float *lk = scratch + (kAdjHitWords + kAdjExtWords) * kBlock + threadIdx.x;
-    float *acc = scratch + kAdjLaneWords * kBlock;
+    float *acc_cam = scratch + kAdjLaneWords * kBlock;        // 16 floats, always in LDS: every path adds to the same 12 entries
+    float *acc = acc_cam + 16;
     const int n_acc = T.n_tris * 22 + T.n_bsdfs * 3 + T.n_emitters * 3;
     const bool use_lds = P.lds_accum != 0;
     if (use_lds) {
@@ -67,6 +69,10 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
         __syncthreads();
     }
     float *acc_bsdf = acc + T.n_tris * 22, *acc_emit = acc_bsdf + T.n_bsdfs * 3;
+    if (P.g_cam != nullptr) {
+        if (threadIdx.x < 16) acc_cam[threadIdx.x] = 0.f;
+        __syncthreads();
+    }
     S.rec = rec; S.ext = ext; S.lk = lk;
 
     long long q_next = 0, q_end = 0;
@@ -121,7 +127,9 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
             rng.seed(P.seed + (P.pix_ids ? (unsigned long long) (long long) pix : (unsigned long long) lane), (unsigned long long) lane, P.skip);
             const float bx = (float) (pix % T.width), by = (float) (pix / T.width);
             const float jx = rng.next_1d(), jy = rng.next_1d();
-            const RayT<true> ray = sample_primary_ray<true>(cam, (bx + jx) / (float) T.width, (by + jy) / (float) T.height);
+            const float sx = (bx + jx) / (float) T.width, sy = (by + jy) / (float) T.height;
+            const RayT<true> ray = sample_primary_ray<true>(cam, sx, sy);
+            RayT<true> ray_p = ray;                             // the ray the probes shade: `ray`, or `ray` with a camera-pose tangent
             const LaneRng rng0 = rng;
             S.mode = 1; S.rec_n = 0; S.rec_i = 0; S.ext_n = 0; S.lk_n = 0; S.probe_kind = 0;
             const Vec3d L0 = Li<true, LDS, false>(S, rng, ray, true, P.max_depth, P.hide_emitters != 0);
@@ -136,7 +144,7 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
             auto probe = [&]() -> float {
                 S.rec_i = 0;
                 LaneRng r = rng0;
-                const Vec3d L = Li<true, LDS, false>(S, r, ray, true, P.max_depth, P.hide_emitters != 0);
+                const Vec3d L = Li<true, LDS, false>(S, r, ray_p, true, P.max_depth, P.hide_emitters != 0);
                 const float t[3] = {L.x.d, L.y.d, L.z.d};
                 float g = 0.f;
 #pragma unroll
@@ -186,17 +194,22 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                         st_id = id;
                         return true;
                     }
-                    return false;
+                    // stage 4: the camera pose - entry (r, c) of rows 0-2 of to_world moves the primary ray (origin = to_world . o_cam,
+                    // direction = to_world . d_cam, perspective.cpp:160-178 / orthographic.cpp:161-181)
+                    if (st_stage == 3 && P.g_cam != nullptr) { st_stage = 4; st_comp = 0; }
+                    return st_stage == 4 && st_comp < 12;
                 };
                 bool more = wactive && advance();
                 while (__ballot(more) != 0ull) {
                     if (more) {
-                        S.probe_kind = st_stage < 3 ? st_stage + 1 : 5; S.probe_id = st_id; S.probe_comp = st_comp;
+                        S.probe_kind = st_stage < 3 ? st_stage + 1 : (st_stage == 3 ? 5 : 4); S.probe_id = st_id; S.probe_comp = st_comp;
                         if (st_stage == 3) { S.probe_u = lk[(3 * st_i + 1) * kBlock]; S.probe_v = lk[(3 * st_i + 2) * kBlock]; }
+                        if (st_stage == 4) { ray_p = ray; primary_ray_pose_tangent(cam, sx, sy, st_comp, ray_p); }
                         const float gval = probe();
                         if (st_stage == 0) adj_add<LDS>(acc, P.g_tri, st_orig * 22 + st_comp, gval, use_lds);
                         else if (st_stage == 1) adj_add<LDS>(acc_bsdf, P.g_bsdf, st_id * 3 + st_comp, gval, use_lds);
                         else if (st_stage == 2) adj_add<LDS>(acc_emit, P.g_emitter, st_id * 3 + st_comp, gval, use_lds);
+                        else if (st_stage == 4) { adj_add<LDS>(acc_cam, acc_cam, st_comp, gval, true); ray_p = ray; }
                         else if constexpr (!LDS) {
                             // scatter over the footprint of the lookup (the transpose of the bilinear interpolation)
                             const int tslot = st_comp < 3 ? 0 : (st_comp < 6 ? 1 : 2), ch = tslot == 2 ? 1 : 3, c = st_comp - 3 * tslot;
@@ -207,7 +220,7 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                                 for (int k = 0; k < 4; ++k) atomicAdd(&P.g_tex[td.g_off + (long long) ch * idx[k] + c], gval * wt[k]);
                         }
                         ++st_comp;
-                        if (st_comp >= (st_stage == 0 ? 22 : (st_stage == 3 ? 7 : 3))) { st_comp = 0; ++st_i; }
+                        if (st_stage < 4 && st_comp >= (st_stage == 0 ? 22 : (st_stage == 3 ? 7 : 3))) { st_comp = 0; ++st_i; }
                         more = advance();
                     }
                 }
@@ -215,6 +228,10 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
             S.mode = 0; S.probe_kind = 0;
             have = false;
         }
+    }
+    if (P.g_cam != nullptr) {
+        __syncthreads();
+        if (threadIdx.x < 12 && acc_cam[threadIdx.x] != 0.f) atomicAdd(&P.g_cam[threadIdx.x], acc_cam[threadIdx.x]);
     }
     if (use_lds) {
         __syncthreads();

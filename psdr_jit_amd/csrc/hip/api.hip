@@ -163,6 +163,12 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edges(const float4 *__rest
         for (int i = threadIdx.x; i < 6 * P.n_sec + 22 * T.n_tris; i += kBlock) acc[i] = 0.f;
         __syncthreads();
     }
+    // camera-pose adjoint: 12 entries every sample adds to - kept in LDS (behind the 3 recorded hits of this kernel)
+    float *acc_cam = scratch_base<LDS>(smem, T) + kAdjHitWords * kBlock;
+    if constexpr (ADJ) if (P.g_cam != nullptr) {
+        if (threadIdx.x < 16) acc_cam[threadIdx.x] = 0.f;
+        __syncthreads();
+    }
     for (;;) {
         for (int round = 0; round < 16; ++round) {
             const unsigned long long need = __ballot(!have);
@@ -243,6 +249,18 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edges(const float4 *__rest
                     }
                     S.probe_kind = 0;
                 }
+                if (P.g_cam != nullptr)                            // the camera ray through p1 moves with the pose (path.cpp:214)
+                    for (int comp = 0; comp < 12; ++comp) {
+                        S.rec_i = 0;
+                        Vec3f t;
+                        const int id = eval_boundary_segment<true, LDS, false>(S, cam, b0, t, comp);
+                        if (id < 0) continue;
+                        float g = 0.f;
+                        if (finite_(t.x)) g += w3[0] * t.x;
+                        if (finite_(t.y)) g += w3[1] * t.y;
+                        if (finite_(t.z)) g += w3[2] * t.z;
+                        if (g != 0.f) atomicAdd(&acc_cam[comp], g);
+                    }
             }
             S.mode = 0;
             have = false;
@@ -261,6 +279,10 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edges(const float4 *__rest
             }
             have = false;
         }
+    }
+    if constexpr (ADJ) if (P.g_cam != nullptr) {
+        __syncthreads();
+        if (threadIdx.x < 12 && acc_cam[threadIdx.x] != 0.f) atomicAdd(&P.g_cam[threadIdx.x], acc_cam[threadIdx.x]);
     }
     if constexpr (ADJ) if (P.lds_acc) {
         float *acc = scratch_base<LDS>(smem, T) + kAdjLaneWords * kBlock;
@@ -849,6 +871,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         HIPCHK(hipMemsetAsync(g->g_bsdf, 0, sizeof(float) * 3 * (size_t) std::max(1, T.n_bsdfs), st));
         HIPCHK(hipMemsetAsync(g->g_emitter, 0, sizeof(float) * 3 * (size_t) std::max(1, T.n_emitters), st));
         if (g->g_tex && sc->tex_total > 0) HIPCHK(hipMemsetAsync(g->g_tex, 0, sizeof(float) * (size_t) sc->tex_total, st));
+        if (g->g_camera) HIPCHK(hipMemsetAsync(g->g_camera, 0, sizeof(float) * 16, st));
         if (g->g_sec_edges && sc->E.n > 0) HIPCHK(hipMemsetAsync(g->g_sec_edges, 0, sizeof(float) * 6 * (size_t) sc->E.n, st));
         if (g->g_prim_edges && cam.n_edges > 0) HIPCHK(hipMemsetAsync(g->g_prim_edges, 0, sizeof(float) * 4 * (size_t) cam.n_edges, st));
     }
@@ -859,7 +882,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     };
     const size_t n_acc = (size_t) T.n_tris * 22 + (size_t) T.n_bsdfs * 3 + (size_t) T.n_emitters * 3;
     const bool lds_acc = n_acc * sizeof(float) <= 32 * 1024;
-    const size_t adj_bytes = sizeof(float) * ((size_t) kAdjLaneWords * kBlock + (lds_acc ? n_acc : 0));
+    const size_t adj_bytes = sizeof(float) * ((size_t) kAdjLaneWords * kBlock + 16 + (lds_acc ? n_acc : 0));
     const size_t smem = sc->smem_bytes + adj_bytes;
     if (smem > 160 * 1024) return fail("scene too large for the adjoint kernel's LDS records");
     static bool attr_set = false;
@@ -877,6 +900,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         P.w = d_rgb; P.g_tri = g->g_triangles; P.g_bsdf = g->g_bsdf; P.g_emitter = g->g_emitter; P.lds_accum = lds_acc ? 1 : 0;
         P.mesh_filter = g->mesh_filter; P.skip_bsdf = g->skip_bsdf; P.skip_emitter = g->skip_emitter;
         P.g_tex = sc->tex_total > 0 ? g->g_tex : nullptr;
+        P.g_cam = g->g_camera;
         if (P.n_local > 0) {
             if (next_queue(P.counter)) return 1;
             const int grid = grid_for(sc, P.n_local);
@@ -904,6 +928,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[2].seed; P.skip = a->samplers[2].skip;
         P.begin = 0; P.end = npx * T.sppse; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
         P.adj_w = d_rgb; P.g_sec = g->g_sec_edges; P.g_tri = g->g_triangles; P.n_sec = sc->E.n;
+        P.g_cam = g->g_camera;
         const size_t sec_acc = sizeof(float) * (6 * (size_t) sc->E.n + 22 * (size_t) T.n_tris);
         P.lds_acc = (sec_acc <= 48 * 1024) ? 1 : 0;
         const size_t smem_sec = sc->smem_bytes + sizeof(float) * (size_t) kAdjLaneWords * kBlock + (P.lds_acc ? sec_acc : 0);

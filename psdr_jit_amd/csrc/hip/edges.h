@@ -41,6 +41,18 @@ template <bool AD> PSDR_DEV RayT<AD> sample_primary_ray(const SensorDev &cam, fl
     return r;
 }
 
+// reverse mode w.r.t. the camera pose: the tangent of the primary ray for a unit tangent on entry (r, c) = (comp / 4, comp % 4)
+// of rows 0-2 of to_world (origin = to_world . o_cam, direction = to_world . d_cam; all other tangents of `ray` are cleared)
+PSDR_DEV void primary_ray_pose_tangent(const SensorDev &cam, float sx, float sy, int comp, RayT<true> &ray) {
+    const int r = comp >> 2, c = comp & 3;
+    const Vec3f pc = xform_pos(cam.sample_to_camera, Vec3f(sx, sy, 0.f));
+    const Vec3f o_cam = cam.ortho ? pc : Vec3f(0.f), d_cam = cam.ortho ? Vec3f(0.f, 0.f, 1.f) : normalize(pc);
+    const float od = c == 0 ? o_cam.x : (c == 1 ? o_cam.y : (c == 2 ? o_cam.z : 1.f));
+    const float dd = c == 0 ? d_cam.x : (c == 1 ? d_cam.y : (c == 2 ? d_cam.z : 0.f));
+    ray.o.x.d = r == 0 ? od : 0.f; ray.o.y.d = r == 1 ? od : 0.f; ray.o.z.d = r == 2 ? od : 0.f;
+    ray.d.x.d = r == 0 ? dd : 0.f; ray.d.y.d = r == 1 ? dd : 0.f; ray.d.z.d = r == 2 ? dd : 0.f;
+}
+
 struct SensorDirectSample { float qx, qy; int pixel_idx; float sensor_val; bool valid; };
 // PerspectiveCamera::sample_direct, reference perspective.cpp:181-197
 PSDR_DEV SensorDirectSample sample_direct(const SceneTables &T, const SensorDev &cam, const Vec3f &p) {
@@ -97,7 +109,7 @@ template <bool LDS> PSDR_DEV BoundarySegSampleDirect sample_boundary_segment_dir
 // AD=true : returns the pixel index (or -1) and the tangent of the estimator in `value`.
 // AD=false: guiding pass, `value` = value0 without the normal velocity (path.cpp:267-268), returns -1.
 template <bool AD, bool LDS, bool COUNT>
-PSDR_DEV int eval_boundary_segment(SceneView<LDS> &S, const SensorDev &cam, const BoundarySegSampleDirect &bss, Vec3f &value);
+PSDR_DEV int eval_boundary_segment(SceneView<LDS> &S, const SensorDev &cam, const BoundarySegSampleDirect &bss, Vec3f &value, int cam_comp = -1);
 
 template <bool AD, bool LDS, bool COUNT>
 PSDR_DEV int eval_secondary_edge(SceneView<LDS> &S, const SecEdgeTables &E, const SensorDev &cam, const Vec3f &s3, Vec3f &value) {
@@ -109,7 +121,7 @@ PSDR_DEV int eval_secondary_edge(SceneView<LDS> &S, const SecEdgeTables &E, cons
 
 // the traced part of eval_secondary_edge (path.cpp:176-270) for an already sampled, valid boundary segment
 template <bool AD, bool LDS, bool COUNT>
-PSDR_DEV int eval_boundary_segment(SceneView<LDS> &S, const SensorDev &cam, const BoundarySegSampleDirect &bss, Vec3f &value) {
+PSDR_DEV int eval_boundary_segment(SceneView<LDS> &S, const SensorDev &cam, const BoundarySegSampleDirect &bss, Vec3f &value, int cam_comp) {
     value = Vec3f(0.f);
     const SceneTables &T = *S.T;
     const Vec3f _p0 = detach(bss.p0), _p2 = bss.p2, _dir = normalize(_p2 - _p0);
@@ -126,7 +138,8 @@ PSDR_DEV int eval_boundary_segment(SceneView<LDS> &S, const SensorDev &cam, cons
     const SensorDirectSample sds = sample_direct(T, cam, _p1);
     if (!sds.valid) return -1;
 
-    const RayT<AD> camera_ray = sample_primary_ray<AD>(cam, sds.qx, sds.qy);
+    RayT<AD> camera_ray = sample_primary_ray<AD>(cam, sds.qx, sds.qy);
+    if constexpr (AD) if (cam_comp >= 0) primary_ray_pose_tangent(cam, sds.qx, sds.qy, cam_comp, camera_ray);      // camera-pose probe
     const Its<AD> its1 = ray_intersect<AD, false, LDS, COUNT>(S, camera_ray, true);
     if (!(its1.valid && norm(detach(its1.p) - _p1) < kShadowEpsilon)) return -1;
     if (mesh_bsdf(S, its1.mesh) < 0) return -1;

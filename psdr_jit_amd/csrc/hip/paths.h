@@ -33,6 +33,7 @@ struct PathParams {
     float *g_prim;                   // [n_primary_edges * 4]  (p0.xy, p1.xy in sample space)
     float *g_sec;                    // [n_sec_edges * 6]      (p0, e1)
     float *g_tri;                    // [n_tris * 22]
+    float *g_cam;                    // [16] adjoint of the sensor's to_world through the camera ray of the secondary-edge term, or NULL
     int lds_acc, n_prim, n_sec;      // 1: the kernel accumulates the adjoint tables in LDS first (same-address atomics)
     int mis;                         // -1: PathTracer; 0/1/2: DirectIntegrator(mis), reference direct.cpp:34-132 (max_depth = 1)
     int field, field_object;         // >= 0: first-hit integrator (shade.h first_hit_value), max_depth = 0

@@ -366,3 +366,39 @@ def test_scene_without_emitters(psdr):
     assert float(psdr.PathTracer(0).renderC(sc, 0, seed=1).abs().max()) == 0.0
     with pytest.raises(RuntimeError, match="No Emitter"):
         psdr.PathTracer(1).renderC(sc, 0, seed=1)
+
+
+def test_camera_pose_reverse_mode(psdr, orc):
+    """loss.backward() w.r.t. the camera pose (a translation and a rotation angle inside sensor.to_world): equal to
+    <w, forward_grad> for both parameters - the interior term through psdr_grads.g_camera, the primary-edge term through the
+    projected edge endpoints"""
+    import torch
+    from psdr_jit_amd import Matrix4fC, Matrix4fD
+    D = scenes.DATA
+    tx = psdr.FloatD(0.).requires_grad_()
+    ang = psdr.FloatD(0.).requires_grad_()
+    sc = psdr.Scene()
+    sc.opts.spp = sc.opts.sppe = sc.opts.sppse = 8
+    sc.opts.width = sc.opts.height = 40
+    sc.opts.log_level = 0
+    cam = psdr.PerspectiveCamera(60, 0.000001, 10000000.)
+    c, s = torch.cos(ang * 0.1), torch.sin(ang * 0.1)
+    cam.to_world = Matrix4fD([[c, 0., s, 208. + tx * 50.], [0., 1., 0., 273.], [-s, 0., c, -800.], [0., 0., 0., 1.]])
+    sc.add_Sensor(cam)
+    sc.add_BSDF(psdr.DiffuseBSDF([0.0, 0.0, 0.0]), "light")
+    sc.add_BSDF(psdr.DiffuseBSDF(), "cat")
+    sc.add_BSDF(psdr.DiffuseBSDF([0.95, 0.95, 0.95]), "white")
+    I = np.eye(4, dtype=np.float32).tolist()
+    sc.add_Mesh(os.path.join(D, "cbox_luminaire.obj"), Matrix4fC([[1., 0., 0., 0.], [0., 1., 0., -0.5], [0., 0., 1., 0.], [0., 0., 0., 1.]]), "light", psdr.AreaLight([20.0, 20.0, 8.0]))
+    for f, b in (("cbox_smallbox", "cat"), ("cbox_largebox", "cat"), ("cbox_floor", "white"), ("cbox_back", "white")):
+        sc.add_Mesh(os.path.join(D, f + ".obj"), Matrix4fC(I), b, None)
+    sc.configure()
+    sc.configure([0])
+    img = psdr.PathTracer(2).renderD(sc, 0, seed=7)
+    w = torch.linspace(0.5, 1.5, img.numel(), device=img.device).reshape(img.shape)
+    want_t = float((psdr.forward_grad(img, tx) * w).sum())
+    want_a = float((psdr.forward_grad(img, ang) * w).sum())
+    (img * w).sum().backward()
+    assert abs(want_t) > 1e-2 and abs(want_a) > 1e-2
+    assert abs(float(tx.grad) - want_t) < 2e-3 * max(1.0, abs(want_t)), (float(tx.grad), want_t)
+    assert abs(float(ang.grad) - want_a) < 2e-3 * max(1.0, abs(want_a)), (float(ang.grad), want_a)
