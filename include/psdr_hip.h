@@ -97,6 +97,11 @@ typedef struct psdr_envmap_rec {
     int32_t reso[2];
     const float *cell_pmf, *cell_cmf; /* unnormalised masses and their running sums, [reso[0]*reso[1]] */
     float cell_sum;
+    /* forward tangents of the differentiable members (envmap.h:40-45): texels of m_radiance (host pointer, may be NULL),
+     * m_scale, m_to_world / m_from_world */
+    const float *d_radiance;
+    float d_scale;
+    float d_to_world[16], d_from_world[16];
 } psdr_envmap_rec;
 
 /* SecondaryEdgeInfo SoA, reference include/psdr/edge/edge.h:49-68 */
@@ -237,6 +242,8 @@ typedef struct psdr_grads {
      * or NULL = not wanted.  The camera's share of the primary-edge term arrives through g_prim_edges (sample-space edge
      * endpoints = world_to_sample . vertex: the host chains both). */
     float *g_camera;
+    /* adjoints of the environment map: its texels (DEVICE [height*width*3]) and its scale (DEVICE [1]); NULL = not wanted */
+    float *g_env, *g_env_scale;
 } psdr_grads;
 /* offsets[3*n_bsdfs] (HOST): float offset of the texel block of BSDF b's bitmap k (0 reflectance / diffuse reflectance rgb,
  * 1 specular reflectance rgb, 2 roughness) inside psdr_grads.g_tex, same row-major layout as the bitmap; -1 = constant.

@@ -65,6 +65,10 @@ typedef struct orc_emitter {         /* AreaLight (include/psdr/emitter/area.h) 
     const float *env_data;           /* [env_height*env_width*3] row-major rgb, lat-long */
     float env_scale;                 /* m_scale */
     float env_to_world_left[16], env_to_world_raw[16];
+    /* tangents of the differentiable members (envmap.h:40-45): texels of m_radiance (may be NULL), m_scale, m_to_world_left */
+    const float *d_env_data;
+    float d_env_scale;
+    float d_env_to_world_left[16];
 } orc_emitter;
 
 typedef struct orc_camera {          /* PerspectiveCamera(fov_x, near, far) */

@@ -97,6 +97,9 @@ class EmitterSpec:
     env_scale: float = 1.0
     env_to_world_left: np.ndarray = field(default_factory=_eye)
     env_to_world_raw: np.ndarray = field(default_factory=_eye)
+    d_env_data: Optional[np.ndarray] = None        # tangents of the texels / scale / to_world_left
+    d_env_scale: float = 0.0
+    d_env_to_world_left: np.ndarray = field(default_factory=lambda: np.zeros((4, 4), dtype=np.float32))
 
 
 @dataclass
@@ -152,7 +155,8 @@ class _Bsdf(C.Structure):
 
 class _Emitter(C.Structure):
     _fields_ = [("radiance", _F3), ("d_radiance", _F3), ("type", C.c_int), ("env_width", C.c_int), ("env_height", C.c_int),
-                ("env_data", C.POINTER(C.c_float)), ("env_scale", C.c_float), ("env_to_world_left", _F16), ("env_to_world_raw", _F16)]
+                ("env_data", C.POINTER(C.c_float)), ("env_scale", C.c_float), ("env_to_world_left", _F16), ("env_to_world_raw", _F16),
+                ("d_env_data", C.POINTER(C.c_float)), ("d_env_scale", C.c_float), ("d_env_to_world_left", _F16)]
 
 
 class _Camera(C.Structure):
@@ -326,6 +330,13 @@ class OracleScene:
             emitters[i].type = int(e.type)
             emitters[i].env_to_world_left, emitters[i].env_to_world_raw = _m16(e.env_to_world_left), _m16(e.env_to_world_raw)
             emitters[i].env_scale = float(e.env_scale)
+            emitters[i].d_env_scale = float(getattr(e, "d_env_scale", 0.0))
+            emitters[i].d_env_to_world_left = _m16(getattr(e, "d_env_to_world_left", np.zeros((4, 4), np.float32)))
+            if e.type == 1 and getattr(e, "d_env_data", None) is not None:
+                dimg = np.ascontiguousarray(np.asarray(e.d_env_data, dtype=np.float32))
+                assert dimg.shape == np.asarray(e.env_data).shape
+                self._keep.append(dimg)
+                emitters[i].d_env_data = dimg.ctypes.data_as(C.POINTER(C.c_float))
             if e.type == 1:
                 img = np.ascontiguousarray(np.asarray(e.env_data, dtype=np.float32))
                 assert img.ndim == 3 and img.shape[2] == 3

@@ -10,6 +10,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 #include <vector>
 #include "scene.h"
 
@@ -94,12 +95,20 @@ template <typename R> V3<R> envmap_bitmap_eval(const EnvmapC &E, R u, R v) {
     const int yw = std::min(py, H - 2) * W;
     const int xp1 = (px + 1) % W;
     const int last = W * H - 1;
-    auto texel = [&](int i) { i = std::min(std::max(i, 0), last); return V3f(E.data[3 * i], E.data[3 * i + 1], E.data[3 * i + 2]); };
-    const V3f v00 = texel(yw + px), v10 = texel(yw + xp1), v01 = texel(yw + px + W), v11 = texel(yw + xp1 + W);
+    // texels carry the tangent d_data when one was given (m_radiance is a Bitmap3fD: differentiable)
+    auto texel = [&](int i) -> V3<R> {
+        i = std::min(std::max(i, 0), last);
+        if constexpr (std::is_same<R, Dual>::value) {
+            if (!E.d_data.empty())
+                return V3<R>(Dual(E.data[3 * i], E.d_data[3 * i]), Dual(E.data[3 * i + 1], E.d_data[3 * i + 1]), Dual(E.data[3 * i + 2], E.d_data[3 * i + 2]));
+        }
+        return V3<R>(R(E.data[3 * i]), R(E.data[3 * i + 1]), R(E.data[3 * i + 2]));
+    };
+    const V3<R> v00 = texel(yw + px), v10 = texel(yw + xp1), v01 = texel(yw + px + W), v11 = texel(yw + xp1 + W);
     auto lerp3 = [](const R &a, const V3<R> &p, const R &b, const V3<R> &q) {
         return V3<R>(fma_(a, p.x, b * q.x), fma_(a, p.y, b * q.y), fma_(a, p.z, b * q.z));
     };
-    const V3<R> v0 = lerp3(w0x, V3<R>(v00), w1x, V3<R>(v10)), v1 = lerp3(w0x, V3<R>(v01), w1x, V3<R>(v11));
+    const V3<R> v0 = lerp3(w0x, v00, w1x, v10), v1 = lerp3(w0x, v01, w1x, v11);
     return lerp3(w0y, v0, w1y, v1);
 }
 
@@ -185,7 +194,7 @@ template <bool ad> V3<Real<ad>> envmap_eval_direction(const EnvmapC &E, const V3
     if constexpr (ad) v = transform_dir(E.from_world, wi); else v = transform_dir(detach(E.from_world), wi);
     R u = atan2_(v.x, -v.z) * R(InvTwoPi), w = safe_acos_(v.y) * R(InvPi);
     u = u - floor_(u); w = w - floor_(w);
-    return envmap_bitmap_eval<R>(E, u, w) * R(E.scale);
+    if constexpr (ad) return envmap_bitmap_eval<R>(E, u, w) * E.scale; else return envmap_bitmap_eval<R>(E, u, w) * E.scale.v;
 }
 
 // HyperCubeDistribution<2>::sample_reuse / pdf (cube_distrb.cpp:42-64)

@@ -223,9 +223,10 @@ Scene *configure_scene(const orc_scene_desc &d, const int *active, int n_active)
             E.width = e.env_width; E.height = e.env_height;
             if (!e.env_data || E.width < 1 || E.height < 1) throw std::runtime_error("EnvironmentMap: missing radiance data");
             E.data.assign(e.env_data, e.env_data + (size_t) 3 * E.width * E.height);
-            E.scale = e.env_scale;
+            if (e.d_env_data) E.d_data.assign(e.d_env_data, e.d_env_data + (size_t) 3 * E.width * E.height);
+            E.scale = Dual(e.env_scale, e.d_env_scale);
             const float zero16[16] = {0};
-            E.to_world = make_m4d(e.env_to_world_left, zero16) * make_m4d(e.env_to_world_raw, zero16);      // envmap.cpp:41
+            E.to_world = make_m4d(e.env_to_world_left, e.d_env_to_world_left) * make_m4d(e.env_to_world_raw, zero16);      // envmap.cpp:41
         }
         sc->emitters.push_back(ec);
     }

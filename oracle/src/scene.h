@@ -89,8 +89,8 @@ struct EmitterC { V3d radiance; int mesh = -1; float sampling_weight = 1.f; int 
 
 struct EnvmapC {
     int width = 0, height = 0;               // m_radiance.m_resolution
-    std::vector<float> data;                 // [height*width*3], row-major rgb
-    float scale = 1.f;                       // m_scale
+    std::vector<float> data, d_data;         // [height*width*3], row-major rgb (+ optional tangent of the texels)
+    Dual scale = Dual(1.f);                  // m_scale (FloatD)
     M4d to_world, from_world;                // envmap.cpp:41-42
     V3f lower, upper;                        // scene AABB + margin (scene.cpp:436-440)
     // HyperCubeDistribution2f m_cell_distrb

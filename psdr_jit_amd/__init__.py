@@ -382,12 +382,32 @@ def _envmap_init(self, radiance=None):
     else:
         r = radiance.detach().cpu().numpy() if isinstance(radiance, _torch.Tensor) else radiance
         _EnvironmentMap_init(self, _np.ascontiguousarray(_np.asarray(r, dtype=_np.float32)))
+        if isinstance(radiance, _torch.Tensor):
+            _params(self)["radiance"] = radiance
 
 
 EnvironmentMap.__init__ = _envmap_init
-EnvironmentMap.radiance = property(lambda self: self._get("radiance", False), lambda self, v: self._set("radiance", _np.ascontiguousarray(_np.asarray(v, dtype=_np.float32)), _np.zeros((1, 1, 3), _np.float32)))
+# m_radiance (texels), m_scale and m_to_world_left are differentiable members (envmap.h:40-45): tensors assigned here are leaves
+EnvironmentMap.radiance = _make_param_property("radiance", lambda self, value: tuple(value.shape) if hasattr(value, "shape") else _np.shape(value))
+
+
+def _env_scale_get(self):
+    t = _params(self).get("scale")
+    return t if t is not None else float(self._get("scale", False)[0])
+
+
+def _env_scale_set(self, value):
+    v, t = _split(value, (1,))
+    self._set("scale", v, _zeros_like(v))
+    if t is not None:
+        _params(self)["scale"] = t
+    else:
+        _params(self).pop("scale", None)
+
+
+EnvironmentMap.scale = property(_env_scale_get, _env_scale_set)
 EnvironmentMap.to_world = property(lambda self: self._get("to_world_raw", False), lambda self, v: self._set("to_world_raw", _np.ascontiguousarray(_np.asarray(_split(v, (4, 4))[0], dtype=_np.float32)), _np.zeros((4, 4), _np.float32)))
-EnvironmentMap.to_world_left = property(lambda self: self._get("to_world_left", False), lambda self, v: self._set("to_world_left", _np.ascontiguousarray(_np.asarray(_split(v, (4, 4))[0], dtype=_np.float32)), _np.zeros((4, 4), _np.float32)))
+EnvironmentMap.to_world_left = _make_param_property("to_world_left", _m44)
 EnvironmentMap.set_transform = lambda self, mat: setattr(self, "to_world_left", mat)
 
 
@@ -395,14 +415,14 @@ def _add_EnvironmentMap(self, emitter_or_path, to_world=None, scale=1.0):
     """add_EnvironmentMap(fname, to_world, scale) or add_EnvironmentMap(emitter), reference scene.cpp:85-105."""
     n_em = self.get_num_emitters()
     if isinstance(emitter_or_path, EnvironmentMap):
-        self._add_EnvironmentMap(emitter_or_path)
+        e = emitter_or_path
     else:
         e = EnvironmentMap(emitter_or_path)
-        e.scale = float(scale)
+        e.scale = scale
         if to_world is not None:
             e.to_world = to_world
-        self._add_EnvironmentMap(e)
-    _keep(self, "Emitter[%d]" % n_em, None)
+    self._add_EnvironmentMap(e)
+    _keep(self, "Emitter[%d]" % n_em, e)
 
 
 def _add_Mesh(self, mesh_or_path, *args):
@@ -469,8 +489,8 @@ def _sync_params(scene, tangents=None):
     for obj, name, t in _leaves(scene):
         v = t.detach().to("cpu", _torch.float32).numpy()
         shape = (4, 4) if name.startswith("to_world") else ((obj.num_vertices, 3) if name == "vertex_positions" else (-1,))
-        if isinstance(obj, _core.BSDF) and t.dim() >= 2:      # a bitmap parameter keeps its [H, W(, 3)] shape
-            shape = tuple(t.shape)
+        if isinstance(obj, (_core.BSDF, _core.Emitter)) and t.dim() >= 2 and not name.startswith("to_world"):
+            shape = tuple(t.shape)                           # a bitmap parameter keeps its [H, W(, 3)] shape
         v = v.reshape(shape)
         d = _zeros_like(v)
         if tangents is not None and id(t) in tangents:
@@ -591,7 +611,7 @@ class _RenderDFn(_torch.autograd.Function):
             elif isinstance(obj, _core.BSDF):
                 want_bsdf = want_bsdf or t.dim() < 2          # (bitmap leaves are served by g_tex)
             elif isinstance(obj, _core.Emitter):
-                want_em = True
+                want_em = want_em or not isinstance(obj, EnvironmentMap)     # (the map's adjoints come back in g_env / g_env_scale)
         mesh_filter = _torch.from_numpy(want_mesh).to(dev)
         # bitmap parameters (a leaf of 2 or 3 dimensions on a BSDF): their texel adjoints come back in one flat buffer
         tex_leaves = [i for i, ((obj, name, t), need) in enumerate(zip(leaves, needs)) if need and isinstance(obj, _core.BSDF) and t.dim() >= 2]
@@ -600,10 +620,26 @@ class _RenderDFn(_torch.autograd.Function):
             tex_off, tex_total = _core._tex_layout(scene)
             g_tex = _torch.zeros(max(1, int(tex_total)), dtype=_torch.float32, device=dev)
         g_cam = _torch.zeros(16, dtype=_torch.float32, device=dev) if want_cam else None
+        env_leaves = [i for i, ((obj, name, t), need) in enumerate(zip(leaves, needs)) if need and isinstance(obj, EnvironmentMap)]
+        g_env = g_env_scale = None
+        for i in env_leaves:
+            obj, name, t = leaves[i]
+            if name == "radiance":
+                g_env = _torch.zeros(t.numel(), dtype=_torch.float32, device=dev)
+            elif name == "scale":
+                g_env_scale = _torch.zeros(1, dtype=_torch.float32, device=dev)
+            else:
+                raise NotImplementedError("reverse mode w.r.t. the environment map's transform is not implemented; use forward_grad()")
+        if g_env_scale is not None and g_env is None:        # the scale adjoint is assembled from the texel probes
+            g_env = _torch.zeros(int(_np.prod(leaves[env_leaves[0]][0]._get("radiance", False).shape)), dtype=_torch.float32, device=dev)
         _core._render_d_bwd(integ, scene, st["sensor_id"], seeds, skips, g_img.data_ptr(), ptr[0], ptr[1], ptr[2], ptr[3], ptr[4],
                             _stream_ptr(), rank, world, st["terms"], mesh_filter.data_ptr(), not want_bsdf, not want_em,
-                            g_tex.data_ptr() if g_tex is not None else 0, g_cam.data_ptr() if g_cam is not None else 0)
+                            g_tex.data_ptr() if g_tex is not None else 0, g_cam.data_ptr() if g_cam is not None else 0,
+                            g_env.data_ptr() if g_env is not None else 0, g_env_scale.data_ptr() if g_env_scale is not None else 0)
         _all_reduce(flat, world > 1)
+        for extra in (g_env, g_env_scale):
+            if extra is not None:
+                _all_reduce(extra, world > 1)
         if g_cam is not None:
             _all_reduce(g_cam, world > 1)
         if g_tex is not None:
@@ -645,6 +681,10 @@ class _RenderDFn(_torch.autograd.Function):
             slot = {"reflectance": 0, "diffuseReflectance": 0, "specularReflectance": 1, "roughness": 2}[name]
             off = int(tex_off[3 * b + slot])
             grads[i] = _torch.zeros_like(t) if off < 0 else g_tex[off:off + t.numel()].reshape(t.shape).to(t.device, t.dtype)
+        for i in env_leaves:
+            obj, name, t = leaves[i]
+            src = g_env if name == "radiance" else g_env_scale
+            grads[i] = src.reshape(t.shape).to(t.device, t.dtype)
         return (None,) + tuple(grads)
 
 

@@ -90,8 +90,9 @@ PSDR_HD float e_value(float a) { return a; }
 
 // Bitmap<3>::eval<ad>(uv, flip_v = false, envmap_mode = true) with m_rot = 0, m_scale = 1, m_trans = 0
 // (bitmap.cpp:47-128).  data: [H*W*3] row-major rgb; the texels carry no tangent, the position does.
-template <typename R>
-PSDR_HD void bitmap_eval(const float *data, int W, int H, R u, R v, R out[3]) {
+// texel(i, c) returns channel c of texel i as an R (so that (value, tangent) texels can be supplied)
+template <typename R, typename TexelFn>
+PSDR_HD void bitmap_eval_fn(TexelFn texel, int W, int H, R u, R v, R out[3]) {
     float sr, cr;
     sincos_f(0.f, sr, cr);                                                        // cos(m_rot), sin(m_rot)
     R x = (u - R(0.5f)) * R(cr) + (v - R(0.5f)) * R(sr);
@@ -112,10 +113,37 @@ PSDR_HD void bitmap_eval(const float *data, int W, int H, R u, R v, R out[3]) {
     i00 = i00 < 0 ? 0 : (i00 > last ? last : i00); i10 = i10 < 0 ? 0 : (i10 > last ? last : i10);
     i01 = i01 < 0 ? 0 : (i01 > last ? last : i01); i11 = i11 < 0 ? 0 : (i11 > last ? last : i11);
     for (int c = 0; c < 3; ++c) {
-        const R v0 = e_fma(w0x, R(data[3 * i00 + c]), w1x * R(data[3 * i10 + c]));
-        const R v1 = e_fma(w0x, R(data[3 * i01 + c]), w1x * R(data[3 * i11 + c]));
+        const R v0 = e_fma(w0x, texel(i00, c), w1x * texel(i10, c));
+        const R v1 = e_fma(w0x, texel(i01, c), w1x * texel(i11, c));
         out[c] = e_fma(w0y, v0, w1y * v1);
     }
+}
+template <typename R>
+PSDR_HD void bitmap_eval(const float *data, int W, int H, R u, R v, R out[3]) {
+    bitmap_eval_fn<R>([&](int i, int c) { return R(data[3 * i + c]); }, W, H, u, v, out);
+}
+// the four texels and weights bitmap_eval reads at (u, v) (envmap mode): d out[c] / d texel[idx[k]][c] = w[k]
+PSDR_HD void bitmap_footprint_env(int W, int H, float u, float v, int idx[4], float w[4]) {
+    float sr, cr;
+    sincos_f(0.f, sr, cr);
+    float x = (u - 0.5f) * cr + (v - 0.5f) * sr;
+    float y = -(u - 0.5f) * sr + (v - 0.5f) * cr;
+    x = x + 0.5f; y = y + 0.5f;
+    x = x * 1.f; y = y * 1.f;
+    x = x - (-.5f + 1.f / 2); y = y + (-.5f + 1.f / 2);
+    x = x + 0.f; y = y + 0.f;
+    x = x - (float) (0.5 / W);
+    x = x - floorf(x); y = y - floorf(y);
+    x = x * (float) W; y = y * (float) (H - 1);
+    const int px = (int) floorf(x), py = (int) floorf(y);
+    const float w1x = x - (float) px, w1y = y - (float) py, w0x = 1.0f - w1x, w0y = 1.0f - w1y;
+    const int yw = (py < H - 2 ? py : H - 2) * W;
+    const int xp1 = (px + 1) % W;
+    const int last = W * H - 1;
+    int i00 = yw + px, i10 = yw + xp1, i01 = yw + px + W, i11 = yw + xp1 + W;
+    idx[0] = i00 < 0 ? 0 : (i00 > last ? last : i00); idx[1] = i10 < 0 ? 0 : (i10 > last ? last : i10);
+    idx[2] = i01 < 0 ? 0 : (i01 > last ? last : i01); idx[3] = i11 < 0 ? 0 : (i11 > last ? last : i11);
+    w[0] = w0y * w0x; w[1] = w0y * w1x; w[2] = w1y * w0x; w[3] = w1y * w1x;
 }
 
 // Bitmap<CH>::eval<ad>(uv, flip_v, envmap_mode = false) with m_rot = 0, m_scale = 1, m_trans = 0 (bitmap.cpp:47-128):

@@ -21,7 +21,12 @@ constexpr int kAdjMaxDepth = 4;
 constexpr int kAdjHitWords = 4 * (1 + 2 * kAdjMaxDepth);      // recorded hits per lane
 constexpr int kAdjExtWords = 8;                                // light-sample slots per lane
 constexpr int kAdjLkWords = 3 * kAdjMaxLookups;                // bitmap lookups per lane (id, u, v)
-constexpr int kAdjLaneWords = kAdjHitWords + kAdjExtWords + kAdjLkWords;
+// LDS words per lane of the interior adjoint kernel: the small-scene (LDS = true) instantiation has no bitmap / environment
+// lookups (such scenes are never staged into LDS), so it carries no lookup record and keeps two workgroups per CU
+template <bool LDS> constexpr int adj_lane_words() { return kAdjHitWords + kAdjExtWords + (LDS ? 0 : kAdjLkWords); }
+// the secondary-edge adjoint records three hits per lane, followed by 16 floats of camera-pose accumulators
+constexpr int kSecAdjLaneWords = 12;
+constexpr int kSecAdjScratch = kSecAdjLaneWords * kBlock + 16;
 
 struct AdjointParams {
     int max_depth, hide_emitters;
@@ -42,6 +47,7 @@ struct AdjointParams {
     int skip_bsdf, skip_emitter;
     float *g_tex;                   // texel adjoints of the bitmap parameters (TexDev::g_off), or NULL
     float *g_cam;                   // [16] adjoint of the sensor's to_world (row major, rows 0-2 filled), or NULL
+    float *g_env, *g_env_scale;     // texel adjoints [H*W*3] and scale adjoint [1] of the environment map, or NULL
 };
 
 template <bool LDS>
@@ -60,7 +66,7 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
     float *rec = scratch + threadIdx.x;
     int *ext = reinterpret_cast<int *>(scratch + kAdjHitWords * kBlock) + threadIdx.x;
     float *lk = scratch + (kAdjHitWords + kAdjExtWords) * kBlock + threadIdx.x;
-    float *acc_cam = scratch + kAdjLaneWords * kBlock;        // 16 floats, always in LDS: every path adds to the same 12 entries
+    float *acc_cam = scratch + adj_lane_words<LDS>() * kBlock;        // 16 floats, always in LDS: every path adds to the same 12 entries
     float *acc = acc_cam + 16;
     const int n_acc = T.n_tris * 22 + T.n_bsdfs * 3 + T.n_emitters * 3;
     const bool use_lds = P.lds_accum != 0;
@@ -69,10 +75,8 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
         __syncthreads();
     }
     float *acc_bsdf = acc + T.n_tris * 22, *acc_emit = acc_bsdf + T.n_bsdfs * 3;
-    if (P.g_cam != nullptr) {
-        if (threadIdx.x < 16) acc_cam[threadIdx.x] = 0.f;
-        __syncthreads();
-    }
+    if (threadIdx.x < 16) acc_cam[threadIdx.x] = 0.f;          // [0..11] camera pose, [12] environment-map scale
+    __syncthreads();
     S.rec = rec; S.ext = ext; S.lk = lk;
 
     long long q_next = 0, q_end = 0;
@@ -133,7 +137,7 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
             const LaneRng rng0 = rng;
             S.mode = 1; S.rec_n = 0; S.rec_i = 0; S.ext_n = 0; S.lk_n = 0; S.probe_kind = 0;
             const Vec3d L0 = Li<true, LDS, false>(S, rng, ray, true, P.max_depth, P.hide_emitters != 0);
-            const int n_hits = S.rec_n, n_ext = S.ext_n, n_lk = (!LDS && P.g_tex != nullptr) ? S.lk_n : 0;
+            const int n_hits = S.rec_n, n_ext = S.ext_n, n_lk = (!LDS && (P.g_tex != nullptr || P.g_env != nullptr)) ? S.lk_n : 0;
             float w[3];
             {
                 const float pv[3] = {L0.x.v, L0.y.v, L0.z.v};
@@ -188,7 +192,8 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                     // specular map, 6 the roughness map of the BSDF; only the maps that exist are probed
                     while (st_i < n_lk) {
                         const int id = __float_as_int(lk[3 * st_i * kBlock]);
-                        const int fl = __float_as_int(S.ld(T.bsdf_off + 2 * id).w);
+                        // an environment-map lookup has the three radiance components; a BSDF the maps it owns
+                        const int fl = id == kEnvLookup ? (P.g_env != nullptr ? 2 : 0) : (P.g_tex != nullptr ? __float_as_int(S.ld(T.bsdf_off + 2 * id).w) : 0);
                         while (st_comp < 7 && !(fl & (st_comp < 3 ? 2 : (st_comp < 6 ? 32 : 64)))) st_comp = st_comp < 3 ? 3 : (st_comp < 6 ? 6 : 7);
                         if (st_comp >= 7) { ++st_i; st_comp = 0; continue; }
                         st_id = id;
@@ -212,12 +217,27 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                         else if (st_stage == 4) { adj_add<LDS>(acc_cam, acc_cam, st_comp, gval, true); ray_p = ray; }
                         else if constexpr (!LDS) {
                             // scatter over the footprint of the lookup (the transpose of the bilinear interpolation)
-                            const int tslot = st_comp < 3 ? 0 : (st_comp < 6 ? 1 : 2), ch = tslot == 2 ? 1 : 3, c = st_comp - 3 * tslot;
-                            const TexDev td = T.tex[3 * st_id + tslot];
                             int idx[4]; float wt[4];
-                            env::bitmap_footprint(td.w, td.h, S.probe_u, S.probe_v, true, idx, wt);
-                            if (gval != 0.f && finite_(gval))
-                                for (int k = 0; k < 4; ++k) atomicAdd(&P.g_tex[td.g_off + (long long) ch * idx[k] + c], gval * wt[k]);
+                            if (st_id == kEnvLookup) {
+                                // gval = d L / d rgb[c] of this lookup (before the scale): texels by the footprint, and
+                                // d L / d scale = sum_c gval_c . rgb[c] / scale
+                                const EnvDev &E = T.env;
+                                env::bitmap_footprint_env(E.width, E.height, S.probe_u, S.probe_v, idx, wt);
+                                if (gval != 0.f && finite_(gval)) {
+                                    float rgb_c = 0.f;
+                                    for (int k = 0; k < 4; ++k) {
+                                        atomicAdd(&P.g_env[3ll * idx[k] + st_comp], gval * wt[k]);
+                                        rgb_c += wt[k] * E.radiance[3ll * idx[k] + st_comp];
+                                    }
+                                    if (P.g_env_scale != nullptr && E.scale != 0.f) atomicAdd(&acc_cam[12], gval * rgb_c / E.scale);
+                                }
+                            } else {
+                                const int tslot = st_comp < 3 ? 0 : (st_comp < 6 ? 1 : 2), ch = tslot == 2 ? 1 : 3, c = st_comp - 3 * tslot;
+                                const TexDev td = T.tex[3 * st_id + tslot];
+                                env::bitmap_footprint(td.w, td.h, S.probe_u, S.probe_v, true, idx, wt);
+                                if (gval != 0.f && finite_(gval))
+                                    for (int k = 0; k < 4; ++k) atomicAdd(&P.g_tex[td.g_off + (long long) ch * idx[k] + c], gval * wt[k]);
+                            }
                         }
                         ++st_comp;
                         if (st_stage < 4 && st_comp >= (st_stage == 0 ? 22 : (st_stage == 3 ? 7 : 3))) { st_comp = 0; ++st_i; }
@@ -229,10 +249,9 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
             have = false;
         }
     }
-    if (P.g_cam != nullptr) {
-        __syncthreads();
-        if (threadIdx.x < 12 && acc_cam[threadIdx.x] != 0.f) atomicAdd(&P.g_cam[threadIdx.x], acc_cam[threadIdx.x]);
-    }
+    __syncthreads();
+    if (P.g_cam != nullptr && threadIdx.x < 12 && acc_cam[threadIdx.x] != 0.f) atomicAdd(&P.g_cam[threadIdx.x], acc_cam[threadIdx.x]);
+    if (P.g_env_scale != nullptr && threadIdx.x == 12 && acc_cam[12] != 0.f) atomicAdd(P.g_env_scale, acc_cam[12]);
     if (use_lds) {
         __syncthreads();
         for (int i = threadIdx.x; i < T.n_tris * 22; i += kBlock) if (acc[i] != 0.f) atomicAdd(&P.g_tri[i], acc[i]);

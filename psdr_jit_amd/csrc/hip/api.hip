@@ -159,12 +159,12 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edges(const float4 *__rest
     bss.valid = false;
     float pdf0 = 1.f;
     if constexpr (ADJ) if (P.lds_acc) {
-        float *acc = scratch_base<LDS>(smem, T) + kAdjLaneWords * kBlock;
+        float *acc = scratch_base<LDS>(smem, T) + kSecAdjScratch;
         for (int i = threadIdx.x; i < 6 * P.n_sec + 22 * T.n_tris; i += kBlock) acc[i] = 0.f;
         __syncthreads();
     }
     // camera-pose adjoint: 12 entries every sample adds to - kept in LDS (behind the 3 recorded hits of this kernel)
-    float *acc_cam = scratch_base<LDS>(smem, T) + kAdjHitWords * kBlock;
+    float *acc_cam = scratch_base<LDS>(smem, T) + kSecAdjLaneWords * kBlock;
     if constexpr (ADJ) if (P.g_cam != nullptr) {
         if (threadIdx.x < 16) acc_cam[threadIdx.x] = 0.f;
         __syncthreads();
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edges(const float4 *__rest
         if constexpr (ADJ) if (have) {
             // reverse mode: record the three rays once, then probe the quantities the tangent is linear in
             float *rec = scratch_base<LDS>(smem, T) + threadIdx.x;
-            float *g_sec = P.lds_acc ? scratch_base<LDS>(smem, T) + kAdjLaneWords * kBlock : P.g_sec;
+            float *g_sec = P.lds_acc ? scratch_base<LDS>(smem, T) + kSecAdjScratch : P.g_sec;
             float *g_tri = P.lds_acc ? g_sec + 6 * P.n_sec : P.g_tri;
             S.rec = rec; S.mode = 1; S.rec_n = 0; S.rec_i = 0; S.probe_kind = 0;
             BoundarySegSampleDirect b0 = bss;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edges(const float4 *__rest
         if (threadIdx.x < 12 && acc_cam[threadIdx.x] != 0.f) atomicAdd(&P.g_cam[threadIdx.x], acc_cam[threadIdx.x]);
     }
     if constexpr (ADJ) if (P.lds_acc) {
-        float *acc = scratch_base<LDS>(smem, T) + kAdjLaneWords * kBlock;
+        float *acc = scratch_base<LDS>(smem, T) + kSecAdjScratch;
         __syncthreads();
         for (int i = threadIdx.x; i < 6 * P.n_sec; i += kBlock) if (acc[i] != 0.f) atomicAdd(&P.g_sec[i], acc[i]);
         for (int i = threadIdx.x; i < 22 * T.n_tris; i += kBlock) if (acc[6 * P.n_sec + i] != 0.f) atomicAdd(&P.g_tri[i], acc[6 * P.n_sec + i]);
@@ -484,10 +484,12 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
         ED.radiance = sc->up(er->radiance, (size_t) 3 * er->width * er->height, rc);
         ED.cell_pmf = sc->up(er->cell_pmf, cells, rc);
         ED.cell_cmf = sc->up(er->cell_cmf, cells, rc);
+        ED.d_radiance = sc->up(er->d_radiance, (size_t) 3 * er->width * er->height, rc);
         if (rc) return 1;
         ED.width = er->width; ED.height = er->height; ED.reso0 = er->reso[0]; ED.reso1 = er->reso[1]; ED.num_cells = (int) cells;
         ED.scale = er->scale; ED.cell_sum = er->cell_sum;
         std::memcpy(ED.to_world.m, er->to_world, 64); std::memcpy(ED.from_world.m, er->from_world, 64);
+        std::memcpy(ED.d_from_world.m, er->d_from_world, 64); ED.d_scale = er->d_scale;
         for (int k = 0; k < 3; ++k) { ED.lower[k] = er->lower[k]; ED.upper[k] = er->upper[k]; }
     }
     T.tex = nullptr;
@@ -872,6 +874,8 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         HIPCHK(hipMemsetAsync(g->g_emitter, 0, sizeof(float) * 3 * (size_t) std::max(1, T.n_emitters), st));
         if (g->g_tex && sc->tex_total > 0) HIPCHK(hipMemsetAsync(g->g_tex, 0, sizeof(float) * (size_t) sc->tex_total, st));
         if (g->g_camera) HIPCHK(hipMemsetAsync(g->g_camera, 0, sizeof(float) * 16, st));
+        if (g->g_env && T.env_emitter >= 0) HIPCHK(hipMemsetAsync(g->g_env, 0, sizeof(float) * 3 * (size_t) T.env.width * T.env.height, st));
+        if (g->g_env_scale) HIPCHK(hipMemsetAsync(g->g_env_scale, 0, sizeof(float), st));
         if (g->g_sec_edges && sc->E.n > 0) HIPCHK(hipMemsetAsync(g->g_sec_edges, 0, sizeof(float) * 6 * (size_t) sc->E.n, st));
         if (g->g_prim_edges && cam.n_edges > 0) HIPCHK(hipMemsetAsync(g->g_prim_edges, 0, sizeof(float) * 4 * (size_t) cam.n_edges, st));
     }
@@ -882,7 +886,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     };
     const size_t n_acc = (size_t) T.n_tris * 22 + (size_t) T.n_bsdfs * 3 + (size_t) T.n_emitters * 3;
     const bool lds_acc = n_acc * sizeof(float) <= 32 * 1024;
-    const size_t adj_bytes = sizeof(float) * ((size_t) kAdjLaneWords * kBlock + 16 + (lds_acc ? n_acc : 0));
+    const size_t adj_bytes = sizeof(float) * ((size_t) (use_lds ? adj_lane_words<true>() : adj_lane_words<false>()) * kBlock + 16 + (lds_acc ? n_acc : 0));
     const size_t smem = sc->smem_bytes + adj_bytes;
     if (smem > 160 * 1024) return fail("scene too large for the adjoint kernel's LDS records");
     static bool attr_set = false;
@@ -901,6 +905,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         P.mesh_filter = g->mesh_filter; P.skip_bsdf = g->skip_bsdf; P.skip_emitter = g->skip_emitter;
         P.g_tex = sc->tex_total > 0 ? g->g_tex : nullptr;
         P.g_cam = g->g_camera;
+        P.g_env = sc->T.env_emitter >= 0 ? g->g_env : nullptr; P.g_env_scale = sc->T.env_emitter >= 0 ? g->g_env_scale : nullptr;
         if (P.n_local > 0) {
             if (next_queue(P.counter)) return 1;
             const int grid = grid_for(sc, P.n_local);
@@ -931,7 +936,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         P.g_cam = g->g_camera;
         const size_t sec_acc = sizeof(float) * (6 * (size_t) sc->E.n + 22 * (size_t) T.n_tris);
         P.lds_acc = (sec_acc <= 48 * 1024) ? 1 : 0;
-        const size_t smem_sec = sc->smem_bytes + sizeof(float) * (size_t) kAdjLaneWords * kBlock + (P.lds_acc ? sec_acc : 0);
+        const size_t smem_sec = sc->smem_bytes + sizeof(float) * (size_t) kSecAdjScratch + (P.lds_acc ? sec_acc : 0);
         GuidingDev G{};
         const int use_g = a->guiding ? 1 : 0;
         if (a->guiding) G = a->guiding->G;

@@ -24,7 +24,9 @@ struct EnvDev {
     const float *cell_pmf, *cell_cmf;
     int width, height, reso0, reso1, num_cells;
     float scale, cell_sum;
-    Mat4<float> to_world, from_world;
+    const float *d_radiance;        // forward tangent of the texels, or NULL
+    float d_scale;
+    Mat4<float> to_world, from_world, d_from_world;
     float lower[3], upper[3];
 };
 
@@ -77,7 +79,8 @@ struct SensorDev {
 struct Counters { unsigned long long rays, nodes, tris, hits; };
 
 // per-lane view used by every device function
-constexpr int kAdjMaxLookups = 6;      // bitmap lookups recorded per path (one per textured vertex; max_depth <= 4)
+constexpr int kEnvLookup = -1;         // id of an environment-map lookup in the lookup record (BSDF ids are >= 0)
+constexpr int kAdjMaxLookups = 8;      // bitmap lookups recorded per path (one per textured vertex; max_depth <= 4)
 
 template <bool LDS> struct SceneView {
     const float4 *B;           // blob base (LDS or global)

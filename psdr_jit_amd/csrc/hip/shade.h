@@ -204,18 +204,37 @@ PSDR_DEV Mat4<Dual> promote(const Mat4<float> &M) { Mat4<Dual> r; for (int i = 0
 PSDR_DEV float env_floor(float a) { return floorf(a); }
 PSDR_DEV Dual env_floor(const Dual &a) { return Dual(floorf(a.v), 0.f); }
 
-// EnvironmentMap::eval_direction, envmap.cpp:59-77 (the map's own transform and texels carry no tangent)
+// EnvironmentMap::eval_direction, envmap.cpp:59-77.  m_radiance (texels), m_scale and m_from_world are differentiable
+// (envmap.h:40-45): forward mode carries their tangents; in reverse mode the lookup is noted / probed like a BSDF bitmap
+// (scene_dev.h: id kEnvLookup), which yields the texel and scale adjoints.
 // The environment-map branches exist only in the LDS=false instantiations: a scene with an environment map is never
 // staged into LDS (api.hip), so the small-scene kernels (all Cornell boxes) carry none of this code or its registers.
-template <bool AD> PSDR_DEV VecN<AD> env_eval_direction(const EnvDev &E, const VecN<AD> &wi) {
+template <bool AD, bool LDS> PSDR_DEV VecN<AD> env_eval_direction(const SceneView<LDS> &S, const EnvDev &E, const VecN<AD> &wi) {
     using R = Num<AD>;
     VecN<AD> v;
-    if constexpr (AD) v = xform_dir(promote(E.from_world), wi); else v = xform_dir(E.from_world, wi);
+    if constexpr (AD) {
+        const bool tan = S.mode == 0;                              // probes put their own unit tangents
+        Mat4<Dual> M;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) M.m[i] = Dual(E.from_world.m[i], tan ? E.d_from_world.m[i] : 0.f);
+        v = xform_dir(M, wi);
+    } else {
+        v = xform_dir(E.from_world, wi);
+    }
     R u = env_atan2(v.x, -v.z) * R(env::kInvTwoPi), w = env_safe_acos(v.y) * R(env::kInvPi);
     u = u - env_floor(u); w = w - env_floor(w);
     R rgb[3];
-    env::bitmap_eval<R>(E.radiance, E.width, E.height, u, w, rgb);
-    return VecN<AD>(rgb[0], rgb[1], rgb[2]) * R(E.scale);
+    if constexpr (AD) {
+        const bool tt = S.mode == 0 && E.d_radiance != nullptr;
+        env::bitmap_eval_fn<Dual>([&](int i, int c) { return Dual(E.radiance[3 * i + c], tt ? E.d_radiance[3 * i + c] : 0.f); }, E.width, E.height, u, w, rgb);
+        S.note_lookup(kEnvLookup, u.v, w.v);
+        const int hot = S.lookup_hot(kEnvLookup, u.v, w.v, 0, 3);
+        if (hot >= 0) rgb[hot].d += 1.f;
+        return VecN<AD>(rgb[0], rgb[1], rgb[2]) * Dual(E.scale, S.mode == 0 ? E.d_scale : 0.f);
+    } else {
+        env::bitmap_eval<R>(E.radiance, E.width, E.height, u, w, rgb);
+        return VecN<AD>(rgb[0], rgb[1], rgb[2]) * R(E.scale);
+    }
 }
 
 // EnvironmentMap::__sample_position_pdf, envmap.cpp:146-166
@@ -271,7 +290,7 @@ template <bool AD, bool LDS> PSDR_DEV VecN<AD> eval_Le(const SceneView<LDS> &S, 
         if (e == S.T->env_emitter) {           // EnvironmentMap::eval, envmap.cpp:47-56
             V wi_world;
             if constexpr (AD) wi_world = to_world_d(its, its.wi); else wi_world = to_world<false>(its, its.wi);
-            return env_eval_direction<AD>(S.T->env, -wi_world);
+            return env_eval_direction<AD, LDS>(S, S.T->env, -wi_world);
         }
     }
     if (!(detach(its.wi.z) > 0.f)) return V(Num<AD>(0.f));

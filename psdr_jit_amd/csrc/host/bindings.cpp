@@ -240,23 +240,27 @@ PYBIND11_MODULE(_psdr_core, m) {
             std::vector<float> d(rgb.data(), rgb.data() + rgb.size());
             return new EnvironmentMap((int) rgb.shape(1), (int) rgb.shape(0), d); }))
         .def_readonly("sampling_weight", &EnvironmentMap::m_sampling_weight)
-        .def_readwrite("scale", &EnvironmentMap::scale)
         .def_readonly("width", &EnvironmentMap::width).def_readonly("height", &EnvironmentMap::height)
         .def("_get", [](const EnvironmentMap &e, const std::string &name, bool tangent) {
             if (name == "radiance") {
                 farr a({(py::ssize_t) e.height, (py::ssize_t) e.width, (py::ssize_t) 3});
-                if (tangent) std::memset(a.mutable_data(), 0, sizeof(float) * a.size()); else std::memcpy(a.mutable_data(), e.data.data(), sizeof(float) * e.data.size());
+                const std::vector<float> &src = tangent ? e.d_data : e.data;
+                if (src.size() == (size_t) a.size()) std::memcpy(a.mutable_data(), src.data(), sizeof(float) * src.size()); else std::memset(a.mutable_data(), 0, sizeof(float) * a.size());
                 return a;
             }
-            const M16 &mm = name == "to_world_left" ? e.to_world_left : e.to_world_raw;
+            if (name == "scale") { farr a(1); a.mutable_data()[0] = tangent ? e.d_scale : e.scale; return a; }
             farr a({4, 4});
-            if (tangent) std::memset(a.mutable_data(), 0, 64); else std::memcpy(a.mutable_data(), mm.data(), 64);
+            if (name == "to_world_left") std::memcpy(a.mutable_data(), (tangent ? e.d_to_world_left : e.to_world_left).data(), 64);
+            else if (tangent) std::memset(a.mutable_data(), 0, 64);
+            else std::memcpy(a.mutable_data(), e.to_world_raw.data(), 64);
             return a; })
-        .def("_set", [](EnvironmentMap &e, const std::string &name, const farr &v, const farr &) {
+        .def("_set", [](EnvironmentMap &e, const std::string &name, const farr &v, const farr &t) {
             if (name == "radiance") {
                 if (v.ndim() != 3 || v.shape(2) != 3) throw Exception("EnvironmentMap: radiance must be a [height, width, 3] array");
                 e.height = (int) v.shape(0); e.width = (int) v.shape(1); e.data.assign(v.data(), v.data() + v.size());
-            } else if (name == "to_world_left") e.to_world_left = to_m16(v);
+                if (t.size() == v.size()) e.d_data.assign(t.data(), t.data() + t.size()); else e.d_data.clear();
+            } else if (name == "scale") { e.scale = v.data()[0]; e.d_scale = t.size() ? t.data()[0] : 0.f; }
+            else if (name == "to_world_left") { e.to_world_left = to_m16(v); e.d_to_world_left = t.size() == 16 ? to_m16(t) : zeros16(); }
             else e.to_world_raw = to_m16(v);
             e.m_ready = false; });
 
@@ -337,7 +341,7 @@ PYBIND11_MODULE(_psdr_core, m) {
 
     m.def("_render_d_bwd", [](const Integrator &it, const Scene &scene, int sensor_id, const std::vector<uint64_t> &seeds, const std::vector<uint64_t> &skips,
                               uintptr_t d_rgb, uintptr_t g_tri, uintptr_t g_bsdf, uintptr_t g_emitter, uintptr_t g_sec, uintptr_t g_prim, uintptr_t stream,
-                              int rank, int count, int terms, uintptr_t mesh_filter, bool skip_bsdf, bool skip_emitter, uintptr_t g_tex, uintptr_t g_cam) {
+                              int rank, int count, int terms, uintptr_t mesh_filter, bool skip_bsdf, bool skip_emitter, uintptr_t g_tex, uintptr_t g_cam, uintptr_t g_env, uintptr_t g_env_scale) {
         if (!scene.is_ready()) throw Exception("Input scene must be configured!");
         psdr_render_args a;
         std::memset(&a, 0, sizeof(a));
@@ -349,7 +353,8 @@ PYBIND11_MODULE(_psdr_core, m) {
         if (!it.field_object().empty()) throw Exception("reverse mode: FieldExtractionIntegrator with an object filter is not supported");
         psdr_grads g{reinterpret_cast<float *>(g_tri), reinterpret_cast<float *>(g_bsdf), reinterpret_cast<float *>(g_emitter),
                      reinterpret_cast<float *>(g_sec), reinterpret_cast<float *>(g_prim),
-                     reinterpret_cast<const uint8_t *>(mesh_filter), skip_bsdf ? 1 : 0, skip_emitter ? 1 : 0, reinterpret_cast<float *>(g_tex), reinterpret_cast<float *>(g_cam)};
+                     reinterpret_cast<const uint8_t *>(mesh_filter), skip_bsdf ? 1 : 0, skip_emitter ? 1 : 0, reinterpret_cast<float *>(g_tex), reinterpret_cast<float *>(g_cam),
+                     reinterpret_cast<float *>(g_env), reinterpret_cast<float *>(g_env_scale)};
         if (psdr_hip_render_d_bwd(scene.m_hip, &a, reinterpret_cast<const float *>(d_rgb), &g, reinterpret_cast<void *>(stream)))
             throw Exception(std::string("libpsdr_hip: ") + psdr_hip_last_error());
     });

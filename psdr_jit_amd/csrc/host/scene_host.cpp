@@ -58,9 +58,12 @@ void EnvironmentMap::configure() {
     for (int idx = 0; idx < w2 * h2; ++idx) mass[idx] = psdr::env::cell_mass(data.data(), width, height, w2, h2, idx);
     cell_distrb.init(mass);
     const M16 z = zeros16();
-    const DM4 tw = DM4::from(to_world_left, z) * DM4::from(to_world_raw, z);
+    const DM4 tw = DM4::from(to_world_left, d_to_world_left) * DM4::from(to_world_raw, z);
     const DM4 fw = inverse(tw);
-    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { to_world[4 * i + j] = tw.m[i][j].v; from_world[4 * i + j] = fw.m[i][j].v; }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
+        to_world[4 * i + j] = tw.m[i][j].v; from_world[4 * i + j] = fw.m[i][j].v;
+        d_to_world[4 * i + j] = tw.m[i][j].d; d_from_world[4 * i + j] = fw.m[i][j].d;
+    }
     m_ready = true;
 }
 std::string EnvironmentMap::to_string() const {
@@ -617,6 +620,9 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
                 psdr_envmap_rec &er = S.envmap;
                 er.width = env->width; er.height = env->height; er.radiance = env->data.data(); er.scale = env->scale;
                 std::memcpy(er.to_world, env->to_world, 64); std::memcpy(er.from_world, env->from_world, 64);
+                std::memcpy(er.d_to_world, env->d_to_world, 64); std::memcpy(er.d_from_world, env->d_from_world, 64);
+                er.d_scale = env->d_scale;
+                er.d_radiance = env->d_data.size() == env->data.size() ? env->d_data.data() : nullptr;
                 for (int k = 0; k < 3; ++k) { er.lower[k] = env->lower[k]; er.upper[k] = env->upper[k]; }
                 er.reso[0] = env->reso[0]; er.reso[1] = env->reso[1];
                 er.cell_pmf = env->cell_distrb.pmf.data(); er.cell_cmf = env->cell_distrb.cmf.data(); er.cell_sum = env->cell_distrb.sum;

@@ -127,11 +127,11 @@ struct EnvironmentMap : Emitter {
     void set_transform(const M16 &mat) { to_world_left = mat; m_ready = false; }      // envmap.h:19-22
     void configure();                                                                  // envmap.cpp:17-44
     int width = 0, height = 0;
-    std::vector<float> data;                                                           // [height*width*3] row-major rgb
-    float scale = 1.f;
-    M16 to_world_raw = identity16(), to_world_left = identity16();
+    std::vector<float> data, d_data;                                                   // [height*width*3] row-major rgb (+ forward tangent, may be empty)
+    float scale = 1.f, d_scale = 0.f;
+    M16 to_world_raw = identity16(), to_world_left = identity16(), d_to_world_left = zeros16();
     // configured state
-    float to_world[16], from_world[16];
+    float to_world[16], from_world[16], d_to_world[16], d_from_world[16];
     float lower[3] = {0, 0, 0}, upper[3] = {0, 0, 0};
     int reso[2] = {0, 0};
     Distrb cell_distrb;

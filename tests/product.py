@@ -60,6 +60,11 @@ def build_scene(spec, configure=True, active=(0,), host_only=False, log_level=0)
                 env.scale = float(e.env_scale)
                 env.to_world = np.asarray(e.env_to_world_raw, np.float32)
                 env.to_world_left = np.asarray(e.env_to_world_left, np.float32)
+                # forward tangents of the differentiable members (texels, scale, to_world_left)
+                if getattr(e, "d_env_data", None) is not None:
+                    env._set("radiance", np.ascontiguousarray(np.asarray(e.env_data, np.float32)), np.ascontiguousarray(np.asarray(e.d_env_data, np.float32)))
+                env._set("scale", np.asarray([e.env_scale], np.float32), np.asarray([getattr(e, "d_env_scale", 0.0)], np.float32))
+                env._set("to_world_left", np.asarray(e.env_to_world_left, np.float32), np.asarray(getattr(e, "d_env_to_world_left", np.zeros((4, 4))), np.float32))
                 sc.add_EnvironmentMap(env)
                 added_env.add(i)
 

@@ -302,3 +302,73 @@ def test_envmap_tutorial_scene(psdr, orc, param):
     wimg, wd = ref.render_d(max_depth=1, seeds=(4, 4, 4))
     assert product.rel_l2(img.cpu().numpy(), wimg) < TOL
     assert np.abs(wd).max() > 0 and product.rel_l2(dimg.cpu().numpy(), wd) < TOL
+
+
+@pytest.mark.parametrize("param", ["texels", "scale", "rotation"])
+def test_envmap_parameter_tangents(psdr, orc, param):
+    """forward tangents of the EnvironmentMap's differentiable members (texels of m_radiance, m_scale, m_to_world_left;
+    envmap.h:40-45) against the oracle, with the area light as a second emitter"""
+    env = scenes.synthetic_envmap(64, 32)
+    spec = scenes.envmap_scene(48, 48, 8, 0, 0, param=None, env=env, area_light=True)
+    e = spec.emitters[0]
+    if param == "texels":
+        rng = np.random.default_rng(2)
+        e.d_env_data = rng.random(env.shape).astype(np.float32)
+    elif param == "scale":
+        e.env_scale, e.d_env_scale = 1.5, 1.0
+    else:
+        a = 0.4
+        m = np.eye(4, dtype=np.float32); m[0, 0], m[0, 2], m[2, 0], m[2, 2] = np.cos(a), np.sin(a), -np.sin(a), np.cos(a)
+        dm = np.zeros((4, 4), np.float32); dm[0, 0], dm[0, 2], dm[2, 0], dm[2, 2] = -np.sin(a), np.cos(a), -np.cos(a), -np.sin(a)
+        e.env_to_world_left, e.d_env_to_world_left = m, dm
+    sc = product.build_scene(spec)
+    ref = orc.OracleScene(spec, [0])
+    integ = psdr.PathTracer(2)
+    img, dimg = psdr.render_d_fwd(integ, sc, 0, seed=4)
+    wimg, wd = ref.render_d(max_depth=2, seeds=(4, 4, 4))
+    assert product.rel_l2(img.cpu().numpy(), wimg) < TOL
+    assert np.abs(wd).max() > 0 and product.rel_l2(dimg.cpu().numpy(), wd) < TOL
+
+
+def test_envmap_reverse_mode(psdr, orc):
+    """loss.backward() into the environment map's texels and scale (lighting optimisation): <w, J v> == <J^T w, v> against forward
+    mode; the scene also holds a textured floor, so BSDF and environment lookups share the lookup record"""
+    import torch
+    rng = np.random.default_rng(3)
+    spec = scenes.textured_scene(40, 40, 8, 0, 0, texture=scenes.checker_texture(8, 8), env=True)
+    env0 = np.asarray(spec.emitters[0].env_data, np.float32)
+    rad = torch.tensor(env0, requires_grad=True)
+    scale = psdr.FloatD(1.25).requires_grad_()
+    tex = torch.tensor(spec.bsdfs[0].texture, requires_grad=True)
+    sc = psdr.Scene()
+    sc.opts.spp, sc.opts.sppe, sc.opts.sppse = 8, 0, 0
+    sc.opts.width = sc.opts.height = 40
+    sc.opts.log_level = 0
+    cam = psdr.PerspectiveCamera(60, 0.000001, 10000000.)
+    cam.to_world = psdr.Matrix4fD(np.asarray(spec.cameras[0].to_world_raw).tolist())
+    sc.add_Sensor(cam)
+    sc.add_BSDF(psdr.DiffuseBSDF(tex), "tex")
+    sc.add_BSDF(psdr.DiffuseBSDF([0.5, 0.5, 0.5]), "cat")
+    floor = psdr.Mesh()
+    m = spec.meshes[0]
+    floor.load_raw(m.vertices, m.faces, m.uvs, m.face_uvs)
+    sc.add_Mesh(floor, "tex", None)
+    sc.add_Mesh(os.path.join(scenes.DATA, "cbox_smallbox.obj"), psdr.Matrix4fC(np.eye(4, dtype=np.float32).tolist()), "cat", None)
+    e = psdr.EnvironmentMap(rad)
+    e.scale = scale
+    sc.add_EnvironmentMap(e)
+    sc.configure()
+    sc.configure([0])
+    img = psdr.PathTracer(2).renderD(sc, 0, seed=5)
+    w = torch.linspace(0.5, 1.5, img.numel(), device=img.device).reshape(img.shape)
+    v_rad = torch.tensor(rng.standard_normal(env0.shape).astype(np.float32))
+    v_tex = torch.tensor(rng.standard_normal(tuple(tex.shape)).astype(np.float32))
+    want_rad = float((psdr.forward_grad(img, rad, direction=v_rad) * w).sum())
+    want_scale = float((psdr.forward_grad(img, scale) * w).sum())
+    want_tex = float((psdr.forward_grad(img, tex, direction=v_tex) * w).sum())
+    (img * w).sum().backward()
+    got_rad, got_scale, got_tex = float((rad.grad * v_rad).sum()), float(scale.grad), float((tex.grad * v_tex).sum())
+    for name, got, want in (("radiance", got_rad, want_rad), ("scale", got_scale, want_scale), ("texture", got_tex, want_tex)):
+        assert abs(want) > 1e-3 and abs(got - want) < 2e-3 * max(1.0, abs(want)), (name, got, want)
+    # the image is linear in the scale: d/d scale = image / scale
+    assert abs(got_scale - float((img.detach() * w).sum()) / 1.25) < 2e-3 * abs(got_scale)
