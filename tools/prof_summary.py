@@ -50,7 +50,7 @@ def kernel_stats(tag):
         for name, calls, total, avg, pct in rows:
             mn, mx, gx, wx, lds, vg, sg, scr = det.get(name, (0,) * 8)
             fh.write("%-46s %6d %12.1f %10.1f %10.1f %10.1f %6.2f %9d %6d %8d %5d %5d\n" %
-                     (short(name)[:46], calls, total / 1e3, avg / 1e3, mn / 1e3, mx / 1e3, pct, gx, wx, lds, vg, sg))
+                     (short(name)[:46], calls, total, avg, mn / 1e3, mx / 1e3, pct, gx, wx, lds, vg, sg))     # top_kernels is in us, kernels.duration in ns
 
 
 def pmc(tag):
