@@ -202,6 +202,11 @@ int psdr_hip_scene_destroy(psdr_hip_scene *scene);
 /* BVH statistics for DESIGN/bench: nodes, leaves, max depth, bytes resident in LDS per workgroup */
 int psdr_hip_scene_stats(const psdr_hip_scene *scene, int32_t *n_nodes, int32_t *n_leaves, int32_t *max_depth, int32_t *lds_bytes);
 
+/* Scene::ray_intersect<false> for a batch of rays (reference src/scene/scene.cpp:612-806; bound to Python as
+ * Scene.unit_ray_intersect, src/psdr.cpp:404).  Device arrays o[n*3], d[n*3] -> out[n*24]:
+ * {valid, mesh id (-1 = miss), t, J, p.xyz, n.xyz (geometric), sh_frame.s.xyz, .t.xyz, .n.xyz, wi.xyz (local), uv.xy} */
+#define PSDR_ITS_STRIDE 24
+int psdr_hip_ray_intersect(const psdr_hip_scene *scene, int32_t n, const float *o, const float *d, float *out, void *stream);
 /* closest hit for a batch of rays (device arrays o[n*3], d[n*3] -> tri[n], uv[n*2], t[n]); parity aid */
 int psdr_hip_trace(const psdr_hip_scene *scene, int32_t n, const float *o, const float *d,
                    int32_t *out_tri, float *out_uv, float *out_t, void *stream);

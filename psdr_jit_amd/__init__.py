@@ -452,6 +452,63 @@ def _configure(self, active_sensor=()):
 Scene.add_Sensor = _add_Sensor
 Scene.add_BSDF = _add_BSDF
 Scene.add_Mesh = _add_Mesh
+class RayC:
+    """Stand-in for the reference's RayC / RayD (ray.h): origins and directions as [N, 3] tensors."""
+
+    def __init__(self, o=None, d=None):
+        self.o, self.d = o, d
+
+    def reversed(self):
+        return RayC(self.o, -self.d)
+
+
+RayD = RayC
+
+
+class FrameC:
+    def __init__(self, s, t, n):
+        self.s, self.t, self.n = s, t, n
+
+
+class IntersectionC:
+    """What Scene.unit_ray_intersect returns (reference intersection.h:24-60): wi, p, t, n, sh_frame, uv, J, shape as tensors
+    over the rays; `shape` holds mesh indices (-1 = miss) where the reference holds mesh pointers."""
+
+    def __init__(self, rec):
+        self._valid = rec[:, 0] > 0
+        self.shape = rec[:, 1].to(_torch.int32)
+        self.t, self.J = rec[:, 2], rec[:, 3]
+        self.p, self.n = rec[:, 4:7], rec[:, 7:10]
+        self.sh_frame = FrameC(rec[:, 10:13], rec[:, 13:16], rec[:, 16:19])
+        self.wi, self.uv = rec[:, 19:22], rec[:, 22:24]
+
+    def is_valid(self):
+        return self._valid
+
+
+IntersectionD = IntersectionC
+
+
+def _unit_ray_intersect(self, ray, active=None):
+    """Scene.unit_ray_intersect (reference psdr.cpp:404, scene.cpp:809-...): closest hits of a batch of rays on the GPU.
+    The AD variant returns the same detached record (derivatives of intersections are taken inside renderD)."""
+    dev = _device()
+    o = _torch.as_tensor(ray.o, dtype=_torch.float32).to(dev).reshape(-1, 3).contiguous()
+    d = _torch.as_tensor(ray.d, dtype=_torch.float32).to(dev).reshape(-1, 3).contiguous()
+    if o.shape != d.shape:
+        raise RuntimeError("unit_ray_intersect: origins and directions differ in size")
+    n = int(o.shape[0])
+    rec = _torch.zeros((n, 24), dtype=_torch.float32, device=dev)
+    if n:
+        _core._ray_intersect(self, n, o.data_ptr(), d.data_ptr(), rec.data_ptr(), _stream_ptr())
+    its = IntersectionC(rec)
+    if active is not None:
+        its._valid = its._valid & _torch.as_tensor(active, dtype=_torch.bool, device=dev).reshape(-1)
+    return its
+
+
+Scene.unit_ray_intersect = _unit_ray_intersect
+Scene.unit_ray_intersectAD = _unit_ray_intersect
 Scene.add_EnvironmentMap = _add_EnvironmentMap
 
 

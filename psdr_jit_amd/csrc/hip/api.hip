@@ -357,6 +357,32 @@ __global__ __launch_bounds__(kBlock) void k_trace(const float4 *__restrict__ blo
     }
 }
 
+// Scene::ray_intersect<false> for a batch of rays (the reference exposes it as Scene.unit_ray_intersect, psdr.cpp:404):
+// 24 floats per ray - valid, mesh id, t, J, p, n (geometric), sh_frame.s/t/n, wi (local), uv
+template <bool LDS>
+__global__ __launch_bounds__(kBlock) void k_intersect(const float4 *__restrict__ blob, const SceneTables T, int n, const float *__restrict__ o,
+                                                      const float *__restrict__ d, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    SceneView<LDS> S = make_view<LDS>(blob, T, smem);
+    for (long long i = (long long) blockIdx.x * kBlock + threadIdx.x; i < (long long) ((n + kBlock - 1) / kBlock) * kBlock; i += (long long) gridDim.x * kBlock) {
+        if (i < n) {
+            RayT<false> r;
+            r.o = Vec3f(o[3 * i], o[3 * i + 1], o[3 * i + 2]); r.d = Vec3f(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+            const Hit h = trace<LDS, false>(S, r.o, r.d);
+            const Its<false> its = make_its<false, LDS, true>(S, h, r, false);
+            float *q = out + 24 * i;
+            if (!its.valid) { for (int k = 0; k < 24; ++k) q[k] = 0.f; q[1] = -1.f; continue; }
+            // its.uv = bilinear2(uv0, uv1 - uv0, uv2 - uv0, barycentrics), scene.cpp:756-759 (the path kernels keep it only when a texture needs it)
+            const float4 c = S.ld(T.shade_off + 6 * its.slot + 4), e = S.ld(T.shade_off + 6 * its.slot + 5);
+            const float tu = fma_(c.z - c.x, h.u, fma_(e.x - c.x, h.v, c.x)), tv = fma_(c.w - c.y, h.u, fma_(e.y - c.y, h.v, c.y));
+            const float v[24] = {1.f, (float) its.mesh, its.t, its.J, its.p.x, its.p.y, its.p.z, its.n.x, its.n.y, its.n.z,
+                                 its.fs.x, its.fs.y, its.fs.z, its.ft.x, its.ft.y, its.ft.z, its.fn.x, its.fn.y, its.fn.z,
+                                 its.wi.x, its.wi.y, its.wi.z, tu, tv};
+            for (int k = 0; k < 24; ++k) q[k] = v[k];
+        }
+    }
+}
+
 // EnvironmentMap::sample_position / sample_position_pdf alone (parity aids)
 __global__ void k_env_sample(const SceneTables T, int n, const float *__restrict__ ref_p, const float *__restrict__ s2,
                              float *__restrict__ out_p, float *__restrict__ out_n, float *__restrict__ out_pdf) {
@@ -972,6 +998,15 @@ int psdr_hip_env_pdf(const psdr_hip_scene *sc, int32_t n, const float *ref_p, co
     if (sc->T.env_emitter < 0) return fail("the scene has no EnvironmentMap");
     if (n <= 0) return 0;
     hipLaunchKernelGGL(k_env_pdf, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t) stream, sc->T, n, ref_p, p, nrm, out_pdf);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int psdr_hip_ray_intersect(const psdr_hip_scene *sc, int32_t n, const float *o, const float *d, float *out, void *stream) {
+    if (!sc) return fail("null scene");
+    if (n <= 0) return 0;
+    if (!o || !d || !out) return fail("null ray / output buffer");
+    if (sc->lds) LAUNCH((k_intersect<true>), sc, (long long) n, stream, sc->blob.as<float4>(), sc->T, n, o, d, out);
+    else LAUNCH((k_intersect<false>), sc, (long long) n, stream, sc->blob.as<float4>(), sc->T, n, o, d, out);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -371,6 +371,14 @@ PYBIND11_MODULE(_psdr_core, m) {
         return out;
     });
 
+    // Scene::ray_intersect<false> for device arrays of rays (psdr_hip_ray_intersect)
+    m.def("_ray_intersect", [](const Scene &scene, int n, uintptr_t o, uintptr_t d, uintptr_t out, uintptr_t stream) {
+        if (!scene.is_ready()) throw Exception("Input scene must be configured!");
+        if (psdr_hip_ray_intersect(scene.m_hip, n, reinterpret_cast<const float *>(o), reinterpret_cast<const float *>(d), reinterpret_cast<float *>(out),
+                                   reinterpret_cast<void *>(stream)))
+            throw Exception(std::string("libpsdr_hip: ") + psdr_hip_last_error());
+    });
+
     // (offsets[3*n_bsdfs], total) of psdr_hip_scene_tex_layout
     m.def("_tex_layout", [](const Scene &scene) {
         if (!scene.is_ready()) throw Exception("Input scene must be configured!");

@@ -402,3 +402,42 @@ def test_camera_pose_reverse_mode(psdr, orc):
     assert abs(want_t) > 1e-2 and abs(want_a) > 1e-2
     assert abs(float(tx.grad) - want_t) < 2e-3 * max(1.0, abs(want_t)), (float(tx.grad), want_t)
     assert abs(float(ang.grad) - want_a) < 2e-3 * max(1.0, abs(want_a)), (float(ang.grad), want_a)
+
+
+def test_unit_ray_intersect(psdr, orc):
+    """Scene.unit_ray_intersect (reference psdr.cpp:404): the Intersection record of a batch of rays against the oracle's closest
+    hits (same triangle, t) and the snapshot's triangle rows (p, geometric normal, shading frame, uv, wi)"""
+    import torch
+    for spec in (scenes.cbox_scene(16, 16, 1, 0, 0, param=None), scenes.textured_scene(16, 16, 1, 0, 0, env=False)):
+        sc = product.build_scene(spec)
+        ref = orc.OracleScene(spec, [0])
+        rng = np.random.default_rng(4)
+        n = 4096
+        o = np.tile(np.array([[278.0, 273.0, -300.0]], np.float32), (n, 1)) + rng.normal(0, 20, (n, 3)).astype(np.float32)
+        d = rng.normal(0, 1, (n, 3)).astype(np.float32); d[:, 2] = np.abs(d[:, 2]) + 0.3
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        its = sc.unit_ray_intersect(psdr.RayC(torch.from_numpy(o), torch.from_numpy(d)))
+        tri, uv, t = ref.trace(o, d)
+        valid = its.is_valid().cpu().numpy()
+        assert np.array_equal(valid, tri >= 0) and valid.sum() > 200
+        rows = np.asarray(sc._snapshot()["triangles"], np.float64)
+        tri_mesh = np.concatenate([np.full(len(m.faces), i) for i, m in enumerate(spec.meshes)])
+        k = tri[valid]
+        p0, e1, e2, fn = rows[k, 0:3], rows[k, 3:6], rows[k, 6:9], rows[k, 18:21]
+        p = p0 + uv[valid, :1] * e1 + uv[valid, 1:] * e2
+        assert np.allclose(its.p.cpu().numpy()[valid], p, rtol=1e-5, atol=1e-3)
+        assert np.allclose(its.t.cpu().numpy()[valid], t[valid], rtol=1e-5, atol=1e-3)
+        assert np.allclose(its.n.cpu().numpy()[valid], fn, atol=1e-6)
+        assert np.array_equal(its.shape.cpu().numpy()[valid], tri_mesh[k]) and np.all(its.shape.cpu().numpy()[~valid] == -1)
+        s_, t_, n_ = (x.cpu().numpy()[valid].astype(np.float64) for x in (its.sh_frame.s, its.sh_frame.t, its.sh_frame.n))
+        assert np.allclose((s_ * t_).sum(1), 0, atol=1e-5) and np.allclose((s_ * n_).sum(1), 0, atol=1e-5) and np.allclose((n_ * n_).sum(1), 1, atol=1e-5)
+        wi = its.wi.cpu().numpy()[valid]
+        want_wi = np.stack([(-d[valid] * s_).sum(1), (-d[valid] * t_).sum(1), (-d[valid] * n_).sum(1)], axis=1)
+        assert np.allclose(wi, want_wi, atol=1e-5)
+        assert np.all(its.J.cpu().numpy()[valid] == 1.0)
+        # texture coordinates: the uv-mapped floor of the textured scene is uv = (x, z) / 560
+        if spec.meshes[0].uvs is not None and len(spec.meshes[0].uvs) == 4:
+            on_floor = valid & (its.shape.cpu().numpy() == 0)
+            if on_floor.any():
+                pf = its.p.cpu().numpy()[on_floor]
+                assert np.allclose(its.uv.cpu().numpy()[on_floor], pf[:, [0, 2]] / 560.0, atol=1e-4)
