@@ -452,6 +452,8 @@ def _configure(self, active_sensor=()):
 Scene.add_Sensor = _add_Sensor
 Scene.add_BSDF = _add_BSDF
 Scene.add_Mesh = _add_Mesh
+
+
 class RayC:
     """Stand-in for the reference's RayC / RayD (ray.h): origins and directions as [N, 3] tensors."""
 
@@ -507,6 +509,36 @@ def _unit_ray_intersect(self, ray, active=None):
     return its
 
 
+class SensorDirectSample:
+    """reference include/psdr/sensor/sensor.h SensorDirectSample_: q (sample-space position), pixel_idx, sensor_val, is_valid"""
+
+    def __init__(self, q, pixel_idx, sensor_val, is_valid):
+        self.q, self.pixel_idx, self.sensor_val, self.is_valid = q, pixel_idx, sensor_val, is_valid
+
+
+def _sample_direct(self, p):
+    """PerspectiveCamera.sample_direct(points[N, 3]) (reference perspective.cpp:181-197): where world points land on the film of the
+    configured camera and the importance they carry.  Host-side utility in torch (the kernels have their own copy, edges.h)."""
+    W, H, px, py, pz, dx, dy, dz, inv_area = self._direct_params()
+    if W <= 0:
+        raise RuntimeError("sample_direct: the camera has not been configured by a scene")
+    p = _torch.as_tensor(p, dtype=_torch.float32).reshape(-1, 3)
+    M = _torch.as_tensor(_np.asarray(self.world_to_sample, dtype=_np.float32)).to(p.device)
+    h = p @ M[:3, :3].T + M[:3, 3]
+    wq = p @ M[3, :3] + M[3, 3]
+    q = (h / wq[:, None])[:, :2]
+    ix, iy = _torch.floor(q[:, 0] * W).to(_torch.int64), _torch.floor(q[:, 1] * H).to(_torch.int64)
+    valid = (ix >= 0) & (ix < W) & (iy >= 0) & (iy < H)
+    idx = _torch.where(valid, iy * W + ix, _torch.full_like(ix, -1))
+    d = p - _torch.tensor([px, py, pz], dtype=_torch.float32, device=p.device)
+    dist2 = (d * d).sum(dim=1)
+    d = d / _torch.sqrt(dist2)[:, None]
+    cos_t = d @ _torch.tensor([dx, dy, dz], dtype=_torch.float32, device=p.device)
+    val = (1.0 / dist2) * (1.0 / cos_t) ** 3 * inv_area
+    return SensorDirectSample(q, idx.to(_torch.int32), val, valid)
+
+
+PerspectiveCamera.sample_direct = _sample_direct
 Scene.unit_ray_intersect = _unit_ray_intersect
 Scene.unit_ray_intersectAD = _unit_ray_intersect
 Scene.add_EnvironmentMap = _add_EnvironmentMap

@@ -184,6 +184,8 @@ PYBIND11_MODULE(_psdr_core, m) {
         .def_readonly("orthographic", &PerspectiveCamera::m_orthographic)
         .def(py::init<float, float, float>())
         .def_property_readonly("world_to_sample", [](const PerspectiveCamera &c) { farr a({4, 4}); std::memcpy(a.mutable_data(), c.rec.world_to_sample, 64); return a; })
+        .def("_direct_params", [](const PerspectiveCamera &c) {        // what sample_direct needs (perspective.cpp:181-197)
+            return py::make_tuple(c.m_width, c.m_height, c.rec.cam_pos[0], c.rec.cam_pos[1], c.rec.cam_pos[2], c.rec.cam_dir[0], c.rec.cam_dir[1], c.rec.cam_dir[2], c.rec.inv_area); })
         .def("_primary_edge_ids", [](const PerspectiveCamera &c) { return from_ivec(c.m_edges.ids, 3); })
         .def("_camera_params", [](const PerspectiveCamera &c) { return py::make_tuple(c.m_fov_x, c.m_near_clip, c.m_far_clip); })
         .def("_primary_edges", [](const PerspectiveCamera &c, bool tangent) {

@@ -321,6 +321,7 @@ static float fdot(D3 a, D3 b) { return ddot(a, b).v; }
 
 void PerspectiveCamera::configure(const Scene &scene, bool keep_edges) {
     const RenderOption &o = scene.m_opts;
+    m_width = o.width; m_height = o.height;                    // Sensor::m_resolution (sensor.cpp:16-22)
     const float aspect = (float) o.width / (float) o.height;
     const DM4 tw = to_world();
     PSDR_ASSERT_MSG(std::fabs(det3(tw) - 1.f) < Epsilon, "Sensor transformation should not involve scaling!");

@@ -195,6 +195,7 @@ struct PerspectiveCamera : Sensor {
     std::string type_name() const override { return "PerspectiveCamera"; }
     void configure(const Scene &scene, bool keep_edges) override;
     float m_fov_x, m_near_clip, m_far_clip;
+    int m_width = 0, m_height = 0;
     bool m_orthographic = false;   // OrthographicCamera(near, far), reference src/sensor/orthographic.cpp (same class here: it differs from
                                    // the perspective camera only in the projection matrix and in sample_primary_ray)
     psdr_sensor_rec rec{};     // filled by configure (edge pointers are patched when the snapshot is assembled)

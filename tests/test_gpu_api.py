@@ -441,3 +441,23 @@ def test_unit_ray_intersect(psdr, orc):
             if on_floor.any():
                 pf = its.p.cpu().numpy()[on_floor]
                 assert np.allclose(its.uv.cpu().numpy()[on_floor], pf[:, [0, 2]] / 560.0, atol=1e-4)
+
+
+def test_sample_direct_projects_first_hits_back_to_their_pixels(psdr, orc):
+    """PerspectiveCamera.sample_direct (perspective.cpp:181-197) on the `position` field image: every first-hit point lands in the
+    pixel it was seen through; sensor_val = 1 / (dist^2 cos^3 film area)"""
+    import torch
+    spec = scenes.cbox_scene(32, 32, 1, 0, 0, param=None)
+    sc = product.build_scene(spec)
+    pos = psdr.FieldExtractionIntegrator("position").renderC(sc, 0, seed=1)
+    mask = psdr.FieldExtractionIntegrator("silhouette").renderC(sc, 0, seed=1)[:, 0] > 0
+    cam = sc.param_map["Sensor[0]"]
+    sds = cam.sample_direct(pos[mask])
+    want = torch.arange(32 * 32, device=pos.device)[mask]
+    assert bool(sds.is_valid.all()) and torch.equal(sds.pixel_idx.to(torch.int64), want)
+    d = pos[mask] - torch.tensor([208.0, 273.0, -800.0], device=pos.device)
+    dist2 = (d * d).sum(1)
+    cos_t = d[:, 2] / dist2.sqrt()
+    a = 2 * np.tan(np.radians(30.0))              # film width at unit distance, aspect 1
+    assert torch.allclose(sds.sensor_val, 1.0 / (dist2 * cos_t ** 3 * a * a), rtol=1e-4)
+    assert not bool(cam.sample_direct(torch.tensor([[5000.0, 273.0, 0.0]])).is_valid.any())        # far outside the field of view
