@@ -40,6 +40,8 @@ typedef struct psdr_triangles {
     const float *uv;                                          /* [n*6] uv0 uv1 uv2, zeros if no uv */
     const int32_t *mesh_id;                                   /* [n]   */
     const uint8_t *use_face_normal;                           /* [n]   */
+    const int32_t *face_indices;                              /* [n*3] mesh-local vertex ids (TriangleInfo::face_indices, types.h:172); may be NULL
+                                                                 unless a MicrofacetPerVertex BSDF is present */
     /* forward tangents (NULL = none) */
     const float *d_p0, *d_e1, *d_e2, *d_n0, *d_n1, *d_n2, *d_face_normal, *d_face_area;
 } psdr_triangles;
@@ -55,7 +57,7 @@ typedef struct psdr_mesh_rec {       /* what the kernels need of reference Mesh 
 } psdr_mesh_rec;
 
 typedef struct psdr_bsdf_rec {       /* Diffuse, reference src/bsdf/diffuse.cpp */
-    int32_t type;                    /* 0 = Diffuse, 1 = Microfacet, 2 = RoughConductor, 3 = RoughDielectric */
+    int32_t type;                    /* 0 = Diffuse, 1 = Microfacet, 2 = RoughConductor, 3 = RoughDielectric, 4 = MicrofacetPerVertex */
     int32_t two_sided;
     float reflectance[3], d_reflectance[3];
     /* textured reflectance: Bitmap3fD with a resolution above 1x1 (bitmap.cpp:47-128, looked up at its.uv with flip_v);
@@ -77,6 +79,11 @@ typedef struct psdr_bsdf_rec {       /* Diffuse, reference src/bsdf/diffuse.cpp 
     const float *spec_tex_data, *d_spec_tex_data;
     int32_t rough_tex_width, rough_tex_height;
     const float *rough_tex_data, *d_rough_tex_data;
+    /* type 4 = MicrofacetPerVertex (src/bsdf/microfacet_pv.cpp): parameters per mesh-local vertex, interpolated over the hit
+     * triangle with the barycentrics (its.face_indices, its.bc).  Host pointers, copied. */
+    int32_t pv_count;
+    const float *pv_specular, *pv_diffuse, *pv_roughness;          /* [n*3], [n*3], [n] */
+    const float *d_pv_specular, *d_pv_diffuse, *d_pv_roughness;    /* forward tangents, may be NULL */
 } psdr_bsdf_rec;
 
 typedef struct psdr_emitter_rec {    /* AreaLight (src/emitter/area.cpp) or EnvironmentMap (src/emitter/envmap.cpp) */

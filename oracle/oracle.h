@@ -56,6 +56,10 @@ typedef struct orc_bsdf {            /* Diffuse, include/psdr/bsdf/diffuse.h */
     const float *spec_tex_data, *d_spec_tex_data;
     int rough_tex_width, rough_tex_height;
     const float *rough_tex_data, *d_rough_tex_data;
+    /* type 4 = MicrofacetPerVertex (src/bsdf/microfacet_pv.cpp): values per mesh-local vertex, interpolated with the barycentrics */
+    int pv_count;
+    const float *pv_specular, *pv_diffuse, *pv_roughness;          /* [n*3], [n*3], [n] */
+    const float *d_pv_specular, *d_pv_diffuse, *d_pv_roughness;    /* optional tangents */
 } orc_bsdf;
 
 typedef struct orc_emitter {         /* AreaLight (include/psdr/emitter/area.h) or EnvironmentMap (emitter/envmap.h) */

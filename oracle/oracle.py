@@ -84,6 +84,12 @@ class BsdfSpec:
     d_spec_texture: Optional[np.ndarray] = None
     rough_texture: Optional[np.ndarray] = None  # [H, W] roughness (`texture` is then its diffuse reflectance map)
     d_rough_texture: Optional[np.ndarray] = None
+    pv_specular: Optional[np.ndarray] = None    # type 4 = MicrofacetBSDFPerVertex: [n, 3], [n, 3], [n] per mesh-local vertex
+    pv_diffuse: Optional[np.ndarray] = None
+    pv_roughness: Optional[np.ndarray] = None
+    d_pv_specular: Optional[np.ndarray] = None
+    d_pv_diffuse: Optional[np.ndarray] = None
+    d_pv_roughness: Optional[np.ndarray] = None
 
 
 @dataclass
@@ -150,7 +156,9 @@ class _Bsdf(C.Structure):
                 ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("d_alpha_u", C.c_float), ("d_alpha_v", C.c_float),
                 ("eta", _F3), ("d_eta", _F3), ("k", _F3), ("d_k", _F3),
                 ("spec_tex_width", C.c_int), ("spec_tex_height", C.c_int), ("spec_tex_data", C.POINTER(C.c_float)), ("d_spec_tex_data", C.POINTER(C.c_float)),
-                ("rough_tex_width", C.c_int), ("rough_tex_height", C.c_int), ("rough_tex_data", C.POINTER(C.c_float)), ("d_rough_tex_data", C.POINTER(C.c_float))]
+                ("rough_tex_width", C.c_int), ("rough_tex_height", C.c_int), ("rough_tex_data", C.POINTER(C.c_float)), ("d_rough_tex_data", C.POINTER(C.c_float)),
+                ("pv_count", C.c_int), ("pv_specular", C.POINTER(C.c_float)), ("pv_diffuse", C.POINTER(C.c_float)), ("pv_roughness", C.POINTER(C.c_float)),
+                ("d_pv_specular", C.POINTER(C.c_float)), ("d_pv_diffuse", C.POINTER(C.c_float)), ("d_pv_roughness", C.POINTER(C.c_float))]
 
 
 class _Emitter(C.Structure):
@@ -323,6 +331,17 @@ class OracleScene:
                     dt = np.ascontiguousarray(np.asarray(dt, dtype=np.float32)).reshape(tex.shape)
                     self._keep.append(dt)
                     setattr(bsdfs[i], "d_" + name + "_tex_data", dt.ctypes.data_as(C.POINTER(C.c_float)))
+            if int(getattr(b, "type", 0)) == 4:               # MicrofacetBSDFPerVertex
+                n = len(np.asarray(b.pv_roughness).reshape(-1))
+                bsdfs[i].pv_count = n
+                for name, width in (("pv_specular", 3), ("pv_diffuse", 3), ("pv_roughness", 1)):
+                    for pre in ("", "d_"):
+                        a = getattr(b, pre + name, None)
+                        if a is None:
+                            continue
+                        a = np.ascontiguousarray(np.asarray(a, dtype=np.float32).reshape(n, width))
+                        self._keep.append(a)
+                        setattr(bsdfs[i], pre + name, a.ctypes.data_as(C.POINTER(C.c_float)))
         emitters = (_Emitter * max(1, len(spec.emitters)))()
         for i, e in enumerate(spec.emitters):
             emitters[i].radiance = _F3(*e.radiance)

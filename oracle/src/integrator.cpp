@@ -221,7 +221,7 @@ Its<ad> ray_intersect(const Scene &sc, const Ray<ad> &ray, bool active, int *out
         its.sh.t = cross(sh_n, its.sh.s);
     }
     its.wi = to_local<ad>(its.sh, -dir_in);
-    its.bc = V2f(detach(u), detach(v));
+    its.bc = V2<R>(u, v);
     return its;
 }
 template Its<false> ray_intersect<false, false>(const Scene &, const RayC &, bool, int *);
@@ -326,6 +326,23 @@ float kat_env_pdf(const Scene &sc, const V3f &ref_p, const V3f &p, const V3f &n)
     }
 }
 
+// MicrofacetPerVertex::__interpolate (microfacet_pv.cpp:145-160): v0 + (v1 - v0) bc.x + (v2 - v0) bc.y over the hit triangle's
+// (mesh-local) vertex indices; the per-vertex values carry tangents, the barycentrics do where the intersection does
+template <bool ad> static Dual pv_interp1(const std::vector<float> &v, const std::vector<float> &d, const int fi[3], const V2<Real<ad>> &bc) {
+    auto at = [&](int i) { return Dual(v[i], d.empty() ? 0.f : d[i]); };
+    const Dual v0 = at(fi[0]), v1 = at(fi[1]), v2 = at(fi[2]);
+    return fma_(v1 - v0, Dual(bc.x), fma_(v2 - v0, Dual(bc.y), v0));
+}
+template <bool ad> static V3d pv_interp3(const std::vector<float> &v, const std::vector<float> &d, const int fi[3], const V2<Real<ad>> &bc) {
+    Dual o[3];
+    for (int c = 0; c < 3; ++c) {
+        auto at = [&](int i) { return Dual(v[3 * i + c], d.empty() ? 0.f : d[3 * i + c]); };
+        const Dual v0 = at(fi[0]), v1 = at(fi[1]), v2 = at(fi[2]);
+        o[c] = fma_(v1 - v0, Dual(bc.x), fma_(v2 - v0, Dual(bc.y), v0));
+    }
+    return V3d(o[0], o[1], o[2]);
+}
+
 // ---------------------------------------------------------------- Diffuse BSDF (diffuse.cpp:24-108)
 // a mesh without BSDF (the envmap's bounding cube): drjit's vcall on a null pointer returns zeros
 template <bool ad> static V3<Real<ad>> bsdf_eval(const Scene &sc, const Its<ad> &its, V3<Real<ad>> wo, bool active) {
@@ -341,6 +358,11 @@ template <bool ad> static V3<Real<ad>> bsdf_eval(const Scene &sc, const Its<ad> 
     if (b.type == 2) {          // RoughConductor (roughconductor.cpp)
         ConductorParams P{b.alpha_u, b.alpha_v, b.eta, b.k, b.specular, b.two_sided};
         return conductor_eval<ad>(P, its.wi, wo, active);
+    }
+    if (b.type == 4) {          // MicrofacetPerVertex (microfacet_pv.cpp): parameters interpolated over the hit triangle's vertices
+        MicrofacetParams P{pv_interp3<ad>(b.pv_spec, b.d_pv_spec, sc.tris[its.tri].fi, its.bc), pv_interp3<ad>(b.pv_diff, b.d_pv_diff, sc.tris[its.tri].fi, its.bc),
+                           pv_interp1<ad>(b.pv_rough, b.d_pv_rough, sc.tris[its.tri].fi, its.bc), b.two_sided};
+        return microfacet_pv_eval<ad>(P, its.wi, wo, active);
     }
     if (b.type == 3) {          // RoughDielectric (roughdielectric.cpp); eta.x = intIOR / extIOR, eta.y = extIOR / intIOR
         DielectricParams P{b.alpha_u, b.alpha_v, b.eta.x, b.eta.y, b.two_sided};
@@ -363,6 +385,10 @@ template <bool ad> static float bsdf_pdf(const Scene &sc, const Its<ad> &its, co
         ConductorParams P{b.alpha_u, b.alpha_v, b.eta, b.k, b.specular, b.two_sided};
         return conductor_pdf(P, detach(its.wi), detach(wo_), active);
     }
+    if (b.type == 4) {
+        MicrofacetParams P{b.specular, b.reflectance, pv_interp1<ad>(b.pv_rough, b.d_pv_rough, sc.tris[its.tri].fi, its.bc), b.two_sided};
+        return microfacet_pdf(P, detach(its.wi), detach(wo_), active);
+    }
     if (b.type == 3) {
         DielectricParams P{b.alpha_u, b.alpha_v, b.eta.x, b.eta.y, b.two_sided};
         return dielectric_pdf(P, detach(its.wi), detach(wo_), active);
@@ -378,6 +404,12 @@ template <bool ad> static BSDFSample bsdf_sample(const Scene &sc, const Its<ad> 
     const BsdfC &b = sc.bsdfs[sc.meshes[its.mesh].bsdf];
     if (b.type == 1) {
         MicrofacetParams P{b.specular, b.reflectance, bsdf_roughness<ad>(b, its.uv), b.two_sided};
+        const MicrofacetSample m = microfacet_sample(P, detach(its.wi), s3, active);
+        BSDFSample r; r.wo = m.wo; r.pdf = m.pdf; r.valid = m.valid;
+        return r;
+    }
+    if (b.type == 4) {
+        MicrofacetParams P{b.specular, b.reflectance, pv_interp1<ad>(b.pv_rough, b.d_pv_rough, sc.tris[its.tri].fi, its.bc), b.two_sided};
         const MicrofacetSample m = microfacet_sample(P, detach(its.wi), s3, active);
         BSDFSample r; r.wo = m.wo; r.pdf = m.pdf; r.valid = m.valid;
         return r;

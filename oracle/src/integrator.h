@@ -23,7 +23,7 @@ template <bool ad> struct Its {
     R t = R(0.f), J = R(1.f);
     Frame<ad> sh;
     V2<R> uv;
-    V2f bc;
+    V2<R> bc;                    // barycentrics (Intersection::bc): detached in C / path-space mode, differentiable otherwise
 };
 
 struct PrimaryEdgeSample { Dual x_dot_n; int idx; RayC ray_n, ray_p; float pdf; };

@@ -188,6 +188,33 @@ inline MicrofacetSample conductor_sample(const ConductorParams &P, V3f wi, const
     return bs;
 }
 
+// MicrofacetPerVertex::__eval (microfacet_pv.cpp:21-66): its own GGX / Smith-Schlick terms, not GGXDistribution's
+template <bool ad> V3<Real<ad>> microfacet_pv_eval(const MicrofacetParams &P, V3<Real<ad>> wi, V3<Real<ad>> wo, bool active) {
+    using R = Real<ad>; using V = V3<R>;
+    if (P.two_sided) { wo.z = mulsign(wo.z, detach(wi.z)); wi.z = abs_(wi.z); }
+    const R cos_theta_nv = wi.z, cos_theta_nl = wo.z;
+    active = active && (detach(cos_theta_nv) > 0.f && detach(cos_theta_nl) > 0.f);
+    if (!active) return V(R(0.f));
+    const V diffuse = pick<ad>(P.diffuse) * R(InvPi);
+    const V H = normalize(wi + wo);
+    const R cos_theta_nh = H.z, cos_theta_vh = dot(H, wi);
+    const V F0 = pick<ad>(P.specular);
+    const R roughness = pick<ad>(P.roughness);
+    const R alpha = sqr(roughness);
+    const R k = sqr(roughness + R(1.f)) / R(8.f);
+    const R tmp = alpha / (cos_theta_nh * cos_theta_nh * (sqr(alpha) - R(1.f)) + R(1.f));
+    const R ggx = tmp * tmp * R(InvPi);
+    const R coeff = cos_theta_vh * (R(-5.55473f) * cos_theta_vh - R(6.8316f));
+    const V fresnel = F0 + (V(R(1.f)) - F0) * exp2_(coeff);
+    const R smithG1 = cos_theta_nv / (cos_theta_nv * (R(1.f) - k) + k);
+    const R smithG2 = cos_theta_nl / (cos_theta_nl * (R(1.f) - k) + k);
+    const R smithG = smithG1 * smithG2;
+    const V numerator = fresnel * (ggx * smithG);
+    const R denominator = R(4.f) * cos_theta_nl * cos_theta_nv;
+    const V specular = numerator / (denominator + R(1e-6f));
+    return (diffuse + specular) * cos_theta_nl;
+}
+
 // ---------------------------------------------------------------- RoughDielectric (reference src/bsdf/roughdielectric.cpp:35-237)
 struct DielectricParams { Dual alpha_u, alpha_v, eta, inv_eta; bool two_sided; };
 

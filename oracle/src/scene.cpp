@@ -190,7 +190,7 @@ Scene *configure_scene(const orc_scene_desc &d, const int *active, int n_active)
         bc.alpha_u = Dual(b.alpha_u, b.d_alpha_u); bc.alpha_v = Dual(b.alpha_v, b.d_alpha_v);
         bc.eta = V3d(Dual(b.eta[0], b.d_eta[0]), Dual(b.eta[1], b.d_eta[1]), Dual(b.eta[2], b.d_eta[2]));
         bc.k = V3d(Dual(b.k[0], b.d_k[0]), Dual(b.k[1], b.d_k[1]), Dual(b.k[2], b.d_k[2]));
-        if (b.type < 0 || b.type > 3) throw std::runtime_error("Unknown BSDF type!");
+        if (b.type < 0 || b.type > 4) throw std::runtime_error("Unknown BSDF type!");
         if (b.tex_data != nullptr) {
             if (b.tex_width < 2 || b.tex_height < 2) throw std::runtime_error("Bitmap: invalid resolution!");
             bc.tex_w = b.tex_width; bc.tex_h = b.tex_height;
@@ -206,6 +206,14 @@ Scene *configure_scene(const orc_scene_desc &d, const int *active, int n_active)
             dst.assign(src, src + n);
             if (dsrc) ddst.assign(dsrc, dsrc + n); else ddst.assign(n, 0.f);
         };
+        if (b.type == 4) {
+            if (b.pv_count <= 0 || !b.pv_specular || !b.pv_diffuse || !b.pv_roughness) throw std::runtime_error("MicrofacetPerVertex: missing per-vertex data");
+            const size_t n = (size_t) b.pv_count;
+            bc.pv_spec.assign(b.pv_specular, b.pv_specular + 3 * n); bc.pv_diff.assign(b.pv_diffuse, b.pv_diffuse + 3 * n); bc.pv_rough.assign(b.pv_roughness, b.pv_roughness + n);
+            if (b.d_pv_specular) bc.d_pv_spec.assign(b.d_pv_specular, b.d_pv_specular + 3 * n);
+            if (b.d_pv_diffuse) bc.d_pv_diff.assign(b.d_pv_diffuse, b.d_pv_diffuse + 3 * n);
+            if (b.d_pv_roughness) bc.d_pv_rough.assign(b.d_pv_roughness, b.d_pv_roughness + n);
+        }
         take(b.spec_tex_data, b.d_spec_tex_data, b.spec_tex_width, b.spec_tex_height, 3, bc.spec_w, bc.spec_h, bc.spec_tex, bc.d_spec_tex);
         take(b.rough_tex_data, b.d_rough_tex_data, b.rough_tex_width, b.rough_tex_height, 1, bc.rough_w, bc.rough_h, bc.rough_tex, bc.d_rough_tex);
         sc->bsdfs.push_back(bc);

@@ -38,6 +38,7 @@ AreaLight = _core.AreaLight
 MicrofacetBSDF = _core.MicrofacetBSDF
 RoughConductorBSDF = _core.RoughConductorBSDF
 RoughDielectricBSDF = _core.RoughDielectricBSDF
+MicrofacetBSDFPerVertex = _core.MicrofacetBSDFPerVertex
 EnvironmentMap = _core.EnvironmentMap
 Sensor = _core.Sensor
 PerspectiveCamera = _core.PerspectiveCamera
@@ -214,6 +215,9 @@ for _n in ("eta", "k", "specular_reflectance"):
     setattr(RoughConductorBSDF, _n, _make_param_property(_n, _v3))
 for _n in ("alpha_u", "alpha_v", "eta"):
     setattr(RoughDielectricBSDF, _n, _make_param_property(_n, lambda self, value: (1,)))
+for _n in ("specularReflectance", "diffuseReflectance"):
+    setattr(MicrofacetBSDFPerVertex, _n, _make_param_property(_n, lambda self, value: (-1, 3)))
+MicrofacetBSDFPerVertex.roughness = _make_param_property("roughness", lambda self, value: (-1,))
 AreaLight.radiance = _make_param_property("radiance", _v3)
 
 
@@ -301,6 +305,17 @@ def _roughconductor_init(self, *args):
 
 
 RoughConductorBSDF.__init__ = _roughconductor_init
+_MicrofacetBSDFPerVertex_init = MicrofacetBSDFPerVertex.__init__
+
+
+def _microfacet_pv_init(self, specular, diffuse, roughness):
+    """MicrofacetBSDFPerVertex(specularReflectance[n, 3], diffuseReflectance[n, 3], roughness[n]) (reference psdr.cpp:306-310,
+    microfacet_pv.h): one value per vertex of the mesh the BSDF is used on"""
+    _MicrofacetBSDFPerVertex_init(self)
+    self.specularReflectance, self.diffuseReflectance, self.roughness = specular, diffuse, roughness
+
+
+MicrofacetBSDFPerVertex.__init__ = _microfacet_pv_init
 _RoughDielectricBSDF_init = RoughDielectricBSDF.__init__
 
 
@@ -580,6 +595,8 @@ def _sync_params(scene, tangents=None):
         shape = (4, 4) if name.startswith("to_world") else ((obj.num_vertices, 3) if name == "vertex_positions" else (-1,))
         if isinstance(obj, (_core.BSDF, _core.Emitter)) and t.dim() >= 2 and not name.startswith("to_world"):
             shape = tuple(t.shape)                           # a bitmap parameter keeps its [H, W(, 3)] shape
+        if isinstance(obj, MicrofacetBSDFPerVertex):
+            shape = (-1,) if name == "roughness" else (-1, 3)
         v = v.reshape(shape)
         d = _zeros_like(v)
         if tangents is not None and id(t) in tangents:
@@ -667,6 +684,8 @@ class _RenderDFn(_torch.autograd.Function):
         leaves = st["leaves"]
         needs = ctx.needs_input_grad[1:]
         want_cam = any(need and isinstance(obj, Sensor) for (obj, name, t), need in zip(leaves, needs))
+        if any(need and isinstance(obj, MicrofacetBSDFPerVertex) for (obj, name, t), need in zip(leaves, needs)):
+            raise NotImplementedError("reverse mode w.r.t. per-vertex BSDF values is not implemented; use forward_grad()")
         dev = grad_img.device
         g_img = grad_img.contiguous().to(_torch.float32)
         snap = scene._snapshot()
@@ -703,7 +722,7 @@ class _RenderDFn(_torch.autograd.Function):
                 want_em = want_em or not isinstance(obj, EnvironmentMap)     # (the map's adjoints come back in g_env / g_env_scale)
         mesh_filter = _torch.from_numpy(want_mesh).to(dev)
         # bitmap parameters (a leaf of 2 or 3 dimensions on a BSDF): their texel adjoints come back in one flat buffer
-        tex_leaves = [i for i, ((obj, name, t), need) in enumerate(zip(leaves, needs)) if need and isinstance(obj, _core.BSDF) and t.dim() >= 2]
+        tex_leaves = [i for i, ((obj, name, t), need) in enumerate(zip(leaves, needs)) if need and isinstance(obj, _core.BSDF) and t.dim() >= 2 and not isinstance(obj, MicrofacetBSDFPerVertex)]
         g_tex = None
         if tex_leaves:
             tex_off, tex_total = _core._tex_layout(scene)

@@ -553,7 +553,7 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     {
         bool any = false;
         for (int i = 0; i < s->n_bsdfs; ++i) {
-            if (s->bsdfs[i].type < 0 || s->bsdfs[i].type > 3) return fail("Unknown BSDF type!");
+            if (s->bsdfs[i].type < 0 || s->bsdfs[i].type > 4) return fail("Unknown BSDF type!");
             any |= s->bsdfs[i].type != 0;
         }
         if (any) {
@@ -568,6 +568,43 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
             sc->bufs.emplace_back(new DevBuf());
             if (sc->bufs.back()->upload(md.data(), md.size() * sizeof(MatDev))) return 1;
             T.mat = sc->bufs.back()->as<MatDev>();
+        }
+    }
+    T.pv = nullptr; T.tri_fi = nullptr;
+    {   // MicrofacetPerVertex: parameter arrays per BSDF + the mesh-local vertex ids of every triangle slot
+        bool any_pv = false;
+        for (int i = 0; i < s->n_bsdfs; ++i) any_pv |= s->bsdfs[i].type == 4;
+        if (any_pv) {
+            if (!tr.face_indices) return fail("MicrofacetPerVertex needs psdr_triangles.face_indices");
+            std::vector<PvDev> pd((size_t) s->n_bsdfs, PvDev{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0});
+            int rc = 0;
+            for (int i = 0; i < s->n_bsdfs; ++i) {
+                const psdr_bsdf_rec &b = s->bsdfs[i];
+                if (b.type != 4) continue;
+                if (b.pv_count <= 0 || !b.pv_specular || !b.pv_diffuse || !b.pv_roughness) return fail("MicrofacetPerVertex: missing per-vertex data");
+                const size_t nv = (size_t) b.pv_count;
+                pd[i].spec = sc->up(b.pv_specular, 3 * nv, rc); pd[i].d_spec = sc->up(b.d_pv_specular, 3 * nv, rc);
+                pd[i].diff = sc->up(b.pv_diffuse, 3 * nv, rc); pd[i].d_diff = sc->up(b.d_pv_diffuse, 3 * nv, rc);
+                pd[i].rough = sc->up(b.pv_roughness, nv, rc); pd[i].d_rough = sc->up(b.d_pv_roughness, nv, rc);
+                pd[i].n = b.pv_count;
+            }
+            // every mesh that uses a per-vertex BSDF must index inside its arrays
+            for (int i = 0; i < n; ++i) {
+                const int bid = s->meshes[tr.mesh_id[i]].bsdf_id;
+                if (bid >= 0 && s->bsdfs[bid].type == 4)
+                    for (int k = 0; k < 3; ++k)
+                        if (tr.face_indices[3 * i + k] < 0 || tr.face_indices[3 * i + k] >= s->bsdfs[bid].pv_count) return fail("MicrofacetPerVertex: fewer values than mesh vertices");
+            }
+            std::vector<int> fi((size_t) 3 * n);
+            for (int slot = 0; slot < n; ++slot)
+                for (int k = 0; k < 3; ++k) fi[3 * (size_t) slot + k] = tr.face_indices[3 * (size_t) bvh.order[slot] + k];
+            sc->bufs.emplace_back(new DevBuf());
+            rc |= sc->bufs.back()->upload(fi.data(), fi.size() * sizeof(int));
+            T.tri_fi = sc->bufs.back()->as<int>();
+            sc->bufs.emplace_back(new DevBuf());
+            rc |= sc->bufs.back()->upload(pd.data(), pd.size() * sizeof(PvDev));
+            if (rc) return 1;
+            T.pv = sc->bufs.back()->as<PvDev>();
         }
     }
     std::vector<FilterPrim> filt;
@@ -651,8 +688,8 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     }
     for (int i = 0; i < s->n_bsdfs; ++i) {
         const psdr_bsdf_rec &b = s->bsdfs[i];
-        if (b.type < 0 || b.type > 3) return fail("Unknown BSDF type!");
-        put4(blob, T.bsdf_off + 2 * (size_t) i, b.reflectance[0], b.reflectance[1], b.reflectance[2], ibits((b.two_sided ? 1 : 0) | (b.tex_data ? 2 : 0) | (b.type == 1 ? 4 : 0) | (b.type == 2 ? 8 : 0) | (b.type == 3 ? 16 : 0) | (b.spec_tex_data ? 32 : 0) | (b.rough_tex_data ? 64 : 0)));
+        if (b.type < 0 || b.type > 4) return fail("Unknown BSDF type!");
+        put4(blob, T.bsdf_off + 2 * (size_t) i, b.reflectance[0], b.reflectance[1], b.reflectance[2], ibits((b.two_sided ? 1 : 0) | (b.tex_data ? 2 : 0) | (b.type == 1 ? 4 : 0) | (b.type == 2 ? 8 : 0) | (b.type == 3 ? 16 : 0) | (b.spec_tex_data ? 32 : 0) | (b.rough_tex_data ? 64 : 0) | (b.type == 4 ? 128 : 0)));
         put4(blob, T.bsdf_off + 2 * (size_t) i + 1, b.d_reflectance[0], b.d_reflectance[1], b.d_reflectance[2], 0.f);
     }
     for (int i = 0; i < s->n_emitters; ++i) {
@@ -697,7 +734,7 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     const size_t stack_bytes = (size_t) T.stack_depth * kBlock * sizeof(int);
     const size_t blob_bytes = (size_t) T.blob_words * 16;
     // keeps >= 4 workgroups per CU (160 KiB LDS); the environment-map and texture code lives in the LDS=false kernels only (shade.h)
-    sc->lds = blob_bytes + stack_bytes <= 40 * 1024 && T.env_emitter < 0 && T.tex == nullptr && T.mat == nullptr;
+    sc->lds = blob_bytes + stack_bytes <= 40 * 1024 && T.env_emitter < 0 && T.tex == nullptr && T.mat == nullptr && T.pv == nullptr;
     sc->smem_bytes = (sc->lds ? blob_bytes : 0) + stack_bytes;
     if (sc->smem_bytes > 64 * 1024) return fail("BVH too deep for the LDS traversal stack");
     sc->n_leaves = bvh.n_leaves; sc->max_depth = bvh.max_depth;

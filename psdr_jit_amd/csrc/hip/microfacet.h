@@ -151,6 +151,31 @@ PSDR_DEV Vec3<R> conductor_eval(const R &au, const R &av, const Vec3<R> &eta, co
     return F * result * spec;
 }
 
+// MicrofacetPerVertex::__eval, reference src/bsdf/microfacet_pv.cpp:21-66 (its own GGX / Smith-Schlick terms)
+template <typename R>
+PSDR_DEV Vec3<R> microfacet_pv_eval(const Vec3<R> &spec, const Vec3<R> &diff, const R &roughness, bool two_sided, Vec3<R> wi, Vec3<R> wo, bool active) {
+    using V = Vec3<R>;
+    if (two_sided) { wo.z = mulsign(wo.z, detach(wi.z)); wi.z = abs_(wi.z); }
+    const R cos_theta_nv = wi.z, cos_theta_nl = wo.z;
+    if (!(active && detach(cos_theta_nv) > 0.f && detach(cos_theta_nl) > 0.f)) return V(R(0.f));
+    const V diffuse = diff * R(kInvPi);
+    const V H = normalize(wi + wo);
+    const R cos_theta_nh = H.z, cos_theta_vh = dot(H, wi);
+    const R alpha = sqr(roughness);
+    const R k = sqr(roughness + R(1.f)) / R(8.f);
+    const R tmp = alpha / (cos_theta_nh * cos_theta_nh * (sqr(alpha) - R(1.f)) + R(1.f));
+    const R ggx = tmp * tmp * R(kInvPi);
+    const R coeff = cos_theta_vh * (R(-5.55473f) * cos_theta_vh - R(6.8316f));
+    const V fresnel = spec + (V(R(1.f)) - spec) * exp2_(coeff);
+    const R smithG1 = cos_theta_nv / (cos_theta_nv * (R(1.f) - k) + k);
+    const R smithG2 = cos_theta_nl / (cos_theta_nl * (R(1.f) - k) + k);
+    const R smithG = smithG1 * smithG2;
+    const V numerator = fresnel * (ggx * smithG);
+    const R denominator = R(4.f) * cos_theta_nl * cos_theta_nv;
+    const V specular = numerator / (denominator + R(1e-6f));
+    return (diffuse + specular) * cos_theta_nl;
+}
+
 // ---------------------------------------------------------------- RoughDielectric, reference src/bsdf/roughdielectric.cpp:35-237
 // fresnel_dielectric, reference include/psdr/utils.h:184-215
 template <typename R> PSDR_DEV void fresnel_dielectric(const R &eta, const R &cos_theta_i, R &F, R &cos_theta_t, R &eta_it, R &eta_ti) {

@@ -34,6 +34,9 @@ struct EnvDev {
 // [0] reflectance / diffuse reflectance (rgb), [1] specular reflectance (rgb), [2] roughness (one channel)
 struct TexDev { const float *data, *d_data; int w, h; long long g_off; };    // g_off: offset of its texel adjoints in psdr_grads.g_tex
 
+// MicrofacetPerVertex (microfacet_pv.cpp): per-vertex parameter arrays of one BSDF in global memory (n == 0: not per-vertex)
+struct PvDev { const float *spec, *d_spec, *diff, *d_diff, *rough, *d_rough; int n; };
+
 // Microfacet parameters beyond the diffuse reflectance (global memory table, one entry per BSDF; microfacet.h)
 struct MatDev {
     float specular[3], d_specular[3], roughness, d_roughness;                  // Microfacet; RoughConductor: specular = specular_reflectance
@@ -50,6 +53,8 @@ struct SceneTables {
     int env_emitter;           // index of the EnvironmentMap among the emitters, -1 = none
     const TexDev *tex;         // [n_bsdfs] or NULL when no BSDF is textured
     const MatDev *mat;         // [n_bsdfs] or NULL when every BSDF is Diffuse
+    const PvDev *pv;           // [n_bsdfs] or NULL when no BSDF is per-vertex
+    const int *tri_fi;         // [n_tris*3] mesh-local vertex ids per triangle SLOT (with pv only)
     EnvDev env;
     float emitter_sum;
     int blob_words;            // float4 count

@@ -19,6 +19,7 @@ template <bool AD> struct Its {
     int slot, mesh;
     VecN<AD> p, n, wi, fs, ft, fn;     // position, geometric normal, local incident dir, shading frame
     Num<AD> t, J;
+    Num<AD> bu, bv;                    // barycentrics (Intersection::bc); only kept when a per-vertex BSDF exists (LDS=false kernels)
     Num<AD> tu, tv;                    // texture coordinates (Intersection::uv); only kept by the LDS=false kernels of textured scenes
 };
 
@@ -135,6 +136,7 @@ PSDR_DEV Its<AD> make_its(const SceneView<LDS> &S, const Hit &h, const RayT<AD> 
                 its.tv = fma_(R(du0y), u, fma_(R(du1y), v, R(s4.y)));
             }
         }
+        if constexpr (!LDS) if (T.pv != nullptr) { its.bu = u; its.bv = v; }
         const float det = fma_(du0x, du1y, -(du0y * du1x));
         if (det != 0.f) {
             const float inv_det = 1.f / det;
@@ -362,6 +364,13 @@ template <bool AD, bool LDS> PSDR_DEV float emitter_position_pdf(const SceneView
 }
 
 // ---------------------------------------------------------------- Diffuse BSDF, reference src/bsdf/diffuse.cpp:24-108
+// MicrofacetPerVertex::__interpolate<1> of the roughness, detached (microfacet_pv.cpp:89,127)
+template <bool AD, bool LDS> PSDR_DEV float pv_roughness(const SceneView<LDS> &S, int id, const Its<AD> &its) {
+    const PvDev pv = S.T->pv[id];
+    const int *fi = S.T->tri_fi + 3 * its.slot;
+    const float v0 = pv.rough[fi[0]], v1 = pv.rough[fi[1]], v2 = pv.rough[fi[2]];
+    return fma_(v1 - v0, detach(its.bu), fma_(v2 - v0, detach(its.bv), v0));
+}
 // Microfacet::m_roughness as a bitmap, detached (microfacet.cpp:88,117)
 template <bool AD, bool LDS> PSDR_DEV float roughness_lookup(const SceneView<LDS> &S, int id, const Its<AD> &its) {
     const TexDev td = S.T->tex[3 * id + 2];
@@ -406,6 +415,23 @@ template <bool AD, bool LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S
             }
             if constexpr (AD) return microfacet_eval<Dual>(spec, diff, rough, (fl & 1) != 0, its.wi, wo, active);
             else return microfacet_eval<float>(detach(spec), detach(diff), rough.v, (fl & 1) != 0, its.wi, wo, active);
+        }
+        if (__float_as_int(a.w) & 128) {       // MicrofacetPerVertex (microfacet_pv.cpp)
+            const PvDev pv = S.T->pv[mesh_bsdf(S, its.mesh)];
+            const int *fi = S.T->tri_fi + 3 * its.slot;
+            const bool tan = AD && S.mode == 0;            // (no reverse-mode adjoint of the per-vertex values yet)
+            const Dual bu = Dual(its.bu), bv = Dual(its.bv);
+            auto lerp = [&](const float *val, const float *dval, int stride, int c) {
+                auto at = [&](int i) { return Dual(val[stride * i + c], (tan && dval) ? dval[stride * i + c] : 0.f); };
+                const Dual v0 = at(fi[0]), v1 = at(fi[1]), v2 = at(fi[2]);
+                return fma_(v1 - v0, bu, fma_(v2 - v0, bv, v0));
+            };
+            const Vec3d spec(lerp(pv.spec, pv.d_spec, 3, 0), lerp(pv.spec, pv.d_spec, 3, 1), lerp(pv.spec, pv.d_spec, 3, 2));
+            const Vec3d diff(lerp(pv.diff, pv.d_diff, 3, 0), lerp(pv.diff, pv.d_diff, 3, 1), lerp(pv.diff, pv.d_diff, 3, 2));
+            const Dual rough = lerp(pv.rough, pv.d_rough, 1, 0);
+            const bool two = (__float_as_int(a.w) & 1) != 0;
+            if constexpr (AD) return microfacet_pv_eval<Dual>(spec, diff, rough, two, its.wi, wo, active);
+            else return microfacet_pv_eval<float>(detach(spec), detach(diff), rough.v, two, its.wi, wo, active);
         }
         if (__float_as_int(a.w) & 8) {         // RoughConductor (roughconductor.cpp)
             const MatDev md = S.T->mat[mesh_bsdf(S, its.mesh)];
@@ -469,6 +495,10 @@ template <bool AD, bool LDS> PSDR_DEV float bsdf_pdf(const SceneView<LDS> &S, co
     if (mesh_bsdf(S, its.mesh) < 0) return 0.f;
     const float4 a = S.ld(S.T->bsdf_off + 2 * mesh_bsdf(S, its.mesh));
     if constexpr (!LDS) {
+        if (__float_as_int(a.w) & 128) {
+            const float r = pv_roughness(S, mesh_bsdf(S, its.mesh), its);
+            return ggx_pdf(sqr(r), sqr(r), (__float_as_int(a.w) & 1) != 0, detach(its.wi), detach(wo), active);
+        }
         if (__float_as_int(a.w) & 12) {
             const MatDev md = S.T->mat[mesh_bsdf(S, its.mesh)];
             const bool mf = (__float_as_int(a.w) & 4) != 0;
@@ -524,6 +554,12 @@ template <bool AD, bool LDS> PSDR_DEV BSDFSample bsdf_sample(const SceneView<LDS
     if (mesh_bsdf(S, its.mesh) < 0) { BSDFSample z; z.wo = Vec3f(0.f, 0.f, 0.f); z.pdf = 0.f; z.valid = false; return z; }
     const float4 a = S.ld(S.T->bsdf_off + 2 * mesh_bsdf(S, its.mesh));
     if constexpr (!LDS) {
+        if (__float_as_int(a.w) & 128) {       // MicrofacetPerVertex::__sample (microfacet_pv.cpp:80-103)
+            BSDFSample m;
+            const float r = pv_roughness(S, mesh_bsdf(S, its.mesh), its);
+            ggx_reflect_sample(sqr(r), sqr(r), (__float_as_int(a.w) & 1) != 0, detach(its.wi), s0, s1, active, m.wo, m.pdf, m.valid);
+            return m;
+        }
         if (__float_as_int(a.w) & 12) {        // Microfacet / RoughConductor ::sample use the first two numbers (microfacet.cpp:88)
             BSDFSample m;
             const MatDev md = S.T->mat[mesh_bsdf(S, its.mesh)];

@@ -137,6 +137,25 @@ PYBIND11_MODULE(_psdr_core, m) {
             else if (name == "k") { b.k = to_a3(v); b.d_k = to_a3(t); }
             else { b.specular = to_a3(v); b.d_specular = to_a3(t); } });
 
+    py::class_<MicrofacetPerVertex, BSDF>(m, "MicrofacetBSDFPerVertex", py::dynamic_attr())
+        .def(py::init<>())
+        .def("_get", [](const MicrofacetPerVertex &b, const std::string &name, bool tangent) {
+            const bool r = name == "roughness";
+            const std::vector<float> &v = r ? b.roughness : (name == "specularReflectance" ? b.specular : b.diffuse);
+            const std::vector<float> &d = r ? b.d_roughness : (name == "specularReflectance" ? b.d_specular : b.d_diffuse);
+            const py::ssize_t n = (py::ssize_t) (r ? v.size() : v.size() / 3);
+            farr a = r ? farr(n) : farr({n, (py::ssize_t) 3});
+            const std::vector<float> &src = tangent ? d : v;
+            if (src.size() == (size_t) a.size()) std::memcpy(a.mutable_data(), src.data(), sizeof(float) * src.size()); else if (a.size()) std::memset(a.mutable_data(), 0, sizeof(float) * a.size());
+            return a; })
+        .def("_set", [](MicrofacetPerVertex &b, const std::string &name, const farr &v, const farr &t) {
+            const bool r = name == "roughness";
+            if (!r && (v.size() % 3) != 0) throw Exception("MicrofacetBSDFPerVertex: expected [n, 3] values");
+            std::vector<float> &dst = r ? b.roughness : (name == "specularReflectance" ? b.specular : b.diffuse);
+            std::vector<float> &ddst = r ? b.d_roughness : (name == "specularReflectance" ? b.d_specular : b.d_diffuse);
+            dst.assign(v.data(), v.data() + v.size());
+            if (t.size() == v.size()) ddst.assign(t.data(), t.data() + t.size()); else ddst.clear(); });
+
     py::class_<RoughDielectric, BSDF>(m, "RoughDielectricBSDF", py::dynamic_attr())
         .def(py::init<>())
         .def(py::init<float, float>())

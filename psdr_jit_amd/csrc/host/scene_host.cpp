@@ -427,10 +427,11 @@ void Scene::add_BSDF(const BSDF *bsdf, const std::string &bsdf_id, bool twoSide)
     const Microfacet *mf = dynamic_cast<const Microfacet *>(bsdf);
     const RoughConductor *rc = dynamic_cast<const RoughConductor *>(bsdf);
     const RoughDielectric *rd = dynamic_cast<const RoughDielectric *>(bsdf);     // (the reference only reaches it through the XML loader)
-    PSDR_ASSERT_MSG(d != nullptr || mf != nullptr || rc != nullptr || rd != nullptr, "Unknown BSDF type!");
+    const MicrofacetPerVertex *pvb = dynamic_cast<const MicrofacetPerVertex *>(bsdf);
+    PSDR_ASSERT_MSG(d != nullptr || mf != nullptr || rc != nullptr || rd != nullptr || pvb != nullptr, "Unknown BSDF type!");
     if (m_opts.log_level > 0) std::cout << "add_BSDF: " << bsdf->type_name() << " " << bsdf_id << std::endl;
     PSDR_ASSERT_MSG(m_param_map.find("BSDF[id=" + bsdf_id + "]") == m_param_map.end(), std::string("Duplicate BSDF id: ") + bsdf_id);
-    BSDF *c = d ? static_cast<BSDF *>(new Diffuse(*d)) : (mf ? static_cast<BSDF *>(new Microfacet(*mf)) : (rc ? static_cast<BSDF *>(new RoughConductor(*rc)) : static_cast<BSDF *>(new RoughDielectric(*rd))));
+    BSDF *c = d ? static_cast<BSDF *>(new Diffuse(*d)) : (mf ? static_cast<BSDF *>(new Microfacet(*mf)) : (rc ? static_cast<BSDF *>(new RoughConductor(*rc)) : (rd ? static_cast<BSDF *>(new RoughDielectric(*rd)) : static_cast<BSDF *>(new MicrofacetPerVertex(*pvb)))));
     c->m_twoSide = twoSide; c->m_id = bsdf_id;
     m_bsdfs.push_back(c);
     rebuild_param_map();
@@ -539,6 +540,7 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
                 else { S.uv.push_back(0.f); S.uv.push_back(0.f); }
             }
             S.mesh_id.push_back(mesh->m_mesh_id);
+            for (int k = 0; k < 3; ++k) S.face_indices.push_back(mesh->face_indices[3 * f + k]);
             S.flat.push_back(mesh->m_use_face_normals ? 1 : 0);
         }
         face_offset += mesh->m_num_faces;
@@ -677,6 +679,19 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
             S.bsdfs.push_back(r);
             continue;
         }
+        if (const MicrofacetPerVertex *pv = dynamic_cast<const MicrofacetPerVertex *>(b)) {
+            psdr_bsdf_rec r{};
+            r.type = 4; r.two_sided = pv->m_twoSide ? 1 : 0;
+            const size_t nv = pv->roughness.size();
+            PSDR_ASSERT_MSG(nv > 0 && pv->specular.size() == 3 * nv && pv->diffuse.size() == 3 * nv, "MicrofacetPerVertex: specular / diffuse need 3 values and roughness 1 value per vertex");
+            r.pv_count = (int) nv;
+            r.pv_specular = pv->specular.data(); r.pv_diffuse = pv->diffuse.data(); r.pv_roughness = pv->roughness.data();
+            r.d_pv_specular = pv->d_specular.size() == 3 * nv ? pv->d_specular.data() : nullptr;
+            r.d_pv_diffuse = pv->d_diffuse.size() == 3 * nv ? pv->d_diffuse.data() : nullptr;
+            r.d_pv_roughness = pv->d_roughness.size() == nv ? pv->d_roughness.data() : nullptr;
+            S.bsdfs.push_back(r);
+            continue;
+        }
         if (const RoughDielectric *rd = dynamic_cast<const RoughDielectric *>(b)) {
             psdr_bsdf_rec r{};
             r.type = 3; r.two_sided = rd->m_twoSide ? 1 : 0;
@@ -741,6 +756,7 @@ void Scene::upload() {
     t.n_triangles = (int) S.area.size();
     t.p0 = S.p0.data(); t.e1 = S.e1.data(); t.e2 = S.e2.data(); t.n0 = S.n0.data(); t.n1 = S.n1.data(); t.n2 = S.n2.data();
     t.face_normal = S.fn.data(); t.face_area = S.area.data(); t.uv = S.uv.data(); t.mesh_id = S.mesh_id.data(); t.use_face_normal = S.flat.data();
+    t.face_indices = S.face_indices.data();
     t.d_p0 = S.d_p0.data(); t.d_e1 = S.d_e1.data(); t.d_e2 = S.d_e2.data(); t.d_n0 = S.d_n0.data(); t.d_n1 = S.d_n1.data(); t.d_n2 = S.d_n2.data();
     t.d_face_normal = S.d_fn.data(); t.d_face_area = S.d_area.data();
     sn.n_meshes = (int) S.meshes.size(); sn.meshes = S.meshes.data();

@@ -97,6 +97,16 @@ struct RoughConductor : BSDF {
     std::array<float, 3> eta{0, 0, 0}, k{1, 1, 1}, specular{1, 1, 1}, d_eta{0, 0, 0}, d_k{0, 0, 0}, d_specular{0, 0, 0};
 };
 
+// MicrofacetPerVertex, reference include/psdr/bsdf/microfacet_pv.h: one value per mesh-local vertex
+struct MicrofacetPerVertex : BSDF {
+    MicrofacetPerVertex() {}
+    MicrofacetPerVertex(const std::vector<float> &s, const std::vector<float> &d, const std::vector<float> &r) : specular(s), diffuse(d), roughness(r) {}
+    std::string type_name() const override { return "MicrofacetPerVertex"; }
+    std::string to_string() const override { return std::string("MicrofacetPerVertex[id=") + m_id + "]"; }
+    bool anisotropic() const override { return false; }
+    std::vector<float> specular, diffuse, roughness, d_specular, d_diffuse, d_roughness;      // [n*3], [n*3], [n] (+ forward tangents)
+};
+
 // RoughDielectric, reference include/psdr/bsdf/roughdielectric.h (constant alpha; m_eta = intIOR / extIOR, m_inv_eta = extIOR / intIOR)
 struct RoughDielectric : BSDF {
     RoughDielectric() { eta = 1.5f / 1.0f; inv_eta = 1.f / eta; }
@@ -240,7 +250,7 @@ struct Scene : Object {
     // configured snapshot (host arrays the psdr_scene_snapshot points into)
     struct Snapshot {
         std::vector<float> p0, e1, e2, n0, n1, n2, fn, area, uv, d_p0, d_e1, d_e2, d_n0, d_n1, d_n2, d_fn, d_area;
-        std::vector<int32_t> mesh_id;
+        std::vector<int32_t> mesh_id, face_indices;
         std::vector<uint8_t> flat;
         std::vector<psdr_mesh_rec> meshes;
         std::vector<psdr_bsdf_rec> bsdfs;

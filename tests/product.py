@@ -38,6 +38,14 @@ def build_scene(spec, configure=True, active=(0,), host_only=False, log_level=0)
             bs._set("specular_reflectance", np.asarray(b.specular, np.float32), np.asarray(b.d_specular, np.float32))
             sc.add_BSDF(bs, b.name or ("bsdf%d" % i), b.two_sided)
             continue
+        if getattr(b, "type", 0) == 4:
+            f2 = lambda x, w: np.ascontiguousarray(np.asarray(x, np.float32).reshape(-1, w) if w == 3 else np.asarray(x, np.float32).reshape(-1))
+            bs = psdr.MicrofacetBSDFPerVertex(f2(b.pv_specular, 3), f2(b.pv_diffuse, 3), f2(b.pv_roughness, 1))
+            for attr, name, w in (("pv_specular", "specularReflectance", 3), ("pv_diffuse", "diffuseReflectance", 3), ("pv_roughness", "roughness", 1)):
+                d = getattr(b, "d_" + attr, None)
+                bs._set(name, f2(getattr(b, attr), w), f2(d, w) if d is not None else np.zeros_like(f2(getattr(b, attr), w)))
+            sc.add_BSDF(bs, b.name or ("bsdf%d" % i), b.two_sided)
+            continue
         if getattr(b, "type", 0) == 3:
             bs = psdr.RoughDielectricBSDF()
             f1 = lambda x: np.asarray([x], np.float32)

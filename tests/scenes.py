@@ -408,3 +408,32 @@ def envmap_tutorial_scene(width=48, height=48, spp=4, sppe=0, sppse=0, param="bu
     elif param is not None:
         raise ValueError(param)
     return SceneSpec([bunny], bsdfs, emitters, [cam], width, height, spp, sppe, sppse)
+
+
+def pervertex_scene(width=48, height=48, spp=4, sppe=0, sppse=0, param=None):
+    """The Cornell box whose large sphere-less furniture is replaced by the tutorial's small sphere (cbox_smallball.obj, smooth
+    normals) with a MicrofacetBSDFPerVertex (reference src/bsdf/microfacet_pv.cpp): seeded per-vertex specular / diffuse /
+    roughness.  param: 'diffuse' | 'specular' | 'roughness' (d value / dP = 1 on every vertex) | 'ball_x' | None"""
+    spec = cbox_scene(width, height, spp, sppe, sppse, param=None)
+    ball = _mesh("cbox_smallball.obj", 5)
+    spec.meshes[1] = ball                      # replaces the small box
+    n = len(ball.vertices)
+    rng = np.random.default_rng(9)
+    b = BsdfSpec(name="pv", type=4)
+    b.pv_specular = (0.2 + 0.6 * rng.random((n, 3))).astype(np.float32)
+    b.pv_diffuse = (0.1 + 0.5 * rng.random((n, 3))).astype(np.float32)
+    b.pv_roughness = (0.2 + 0.5 * rng.random(n)).astype(np.float32)
+    spec.bsdfs.append(b)
+    if param == "diffuse":
+        b.d_pv_diffuse = np.ones_like(b.pv_diffuse)
+    elif param == "specular":
+        b.d_pv_specular = np.ones_like(b.pv_specular)
+    elif param == "roughness":
+        b.d_pv_roughness = np.ones_like(b.pv_roughness)
+    elif param == "ball_x":
+        dT = np.zeros((4, 4), dtype=np.float32)
+        dT[0, 3] = 100.0
+        ball.d_to_world_left = dT
+    elif param is not None:
+        raise ValueError(param)
+    return spec

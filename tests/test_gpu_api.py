@@ -461,3 +461,21 @@ def test_sample_direct_projects_first_hits_back_to_their_pixels(psdr, orc):
     a = 2 * np.tan(np.radians(30.0))              # film width at unit distance, aspect 1
     assert torch.allclose(sds.sensor_val, 1.0 / (dist2 * cos_t ** 3 * a * a), rtol=1e-4)
     assert not bool(cam.sample_direct(torch.tensor([[5000.0, 273.0, 0.0]])).is_valid.any())        # far outside the field of view
+
+
+@pytest.mark.parametrize("param", ["diffuse", "specular", "roughness", "ball_x"])
+def test_microfacet_per_vertex_bsdf(psdr, orc, param):
+    """psdr.MicrofacetBSDFPerVertex (reference microfacet_pv.cpp: parameters interpolated over the hit triangle's vertices with the
+    barycentrics, which are differentiable at the first hit) against the oracle"""
+    spec = scenes.pervertex_scene(48, 48, 8, 8, 8, param=param)
+    sc = product.build_scene(spec)
+    ref = orc.OracleScene(spec, [0])
+    integ = psdr.PathTracer(3)
+    c = integ.renderC(sc, 0, seed=3).cpu().numpy()
+    assert product.rel_l2(c, ref.render_c(max_depth=3, seed=3)) < 1e-3
+    img, dimg = psdr.render_d_fwd(integ, sc, 0, seed=6)
+    wimg, wd = ref.render_d(max_depth=3, seeds=(6, 6, 6))
+    assert product.rel_l2(img.cpu().numpy(), wimg) < 1e-3
+    assert np.abs(wd).max() > 0 and product.rel_l2(dimg.cpu().numpy(), wd) < 1e-3
+    b = sc.param_map["BSDF[id=pv]"]
+    assert type(b).__name__ == "MicrofacetBSDFPerVertex" and tuple(b.roughness.shape) == (len(spec.meshes[1].vertices),)

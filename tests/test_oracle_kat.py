@@ -478,3 +478,48 @@ def test_rough_dielectric_known_answers(orc):
         fd_e = (ev(alpha, eta + h, wi, wo)[0] - ev(alpha, eta - h, wi, wo)[0]) / (2 * h)
         assert abs(da - fd_a) < 2e-2 * abs(fd_a) + 1e-4, (da, fd_a)
         assert abs(de - fd_e) < 2e-2 * abs(fd_e) + 1e-4, (de, fd_e)
+
+
+def test_microfacet_per_vertex_known_answers(orc):
+    """MicrofacetPerVertex restatement (microfacet_pv.cpp): equal values on every vertex give the closed-form BRDF the `bsdf` field
+    shows (wo = wi, so H = wi and the Fresnel exponent is its grazing-free constant); the tangent of the interpolated values
+    equals finite differences under emitter sampling only"""
+    spec = scenes.pervertex_scene(96, 96, 1, 0, 0)      # one sample per pixel: every field image shows the same first hits
+    b = spec.bsdfs[5]
+    n = len(b.pv_roughness)
+    b.pv_specular = np.tile(np.array([[0.6, 0.5, 0.4]], np.float32), (n, 1)); b.pv_diffuse = np.tile(np.array([[0.3, 0.2, 0.1]], np.float32), (n, 1))
+    b.pv_roughness = np.full(n, 0.5, np.float32)
+    s = orc.OracleScene(spec, [0])
+    s.set_field("bsdf", obj=1)
+    val = s.render_c(max_depth=0, seed=2).reshape(96, 96, 3)
+    s.set_field("shNormal", obj=1)
+    nrm = s.render_c(max_depth=0, seed=2).reshape(96, 96, 3)
+    s.set_field("position", obj=1)
+    pos = s.render_c(max_depth=0, seed=2).reshape(96, 96, 3)
+    s.set_field("silhouette", obj=1)
+    cov = s.render_c(max_depth=0, seed=2).reshape(96, 96, 3)[..., 0]
+    inside = cov > 0.999
+    assert inside.sum() > 20
+    d = np.array([208.0, 273.0, -800.0]) - pos[inside]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    nn = nrm[inside] / np.linalg.norm(nrm[inside], axis=1, keepdims=True)
+    c = (d * nn).sum(1)
+    r, alpha = 0.5, 0.25
+    k = (r + 1) ** 2 / 8
+    ggx = (alpha / (c * c * (alpha * alpha - 1) + 1)) ** 2 / np.pi
+    g = (c / (c * (1 - k) + k)) ** 2
+    fres = np.array([0.6, 0.5, 0.4]) + (1 - np.array([0.6, 0.5, 0.4])) * 2.0 ** (-5.55473 - 6.8316)
+    want = (np.array([0.3, 0.2, 0.1]) / np.pi + fres[None, :] * (ggx * g / (4 * c * c + 1e-6))[:, None]) * c[:, None]
+    lit = c > 1e-3                                 # (a shading normal facing away gives 0, not the formula)
+    assert lit.sum() > 100 and np.allclose(val[inside][lit], want[lit], rtol=2e-4)
+    assert np.all(val[inside][~lit] == 0)
+    for param, attr, h in (("roughness", "pv_roughness", 1e-2), ("specular", "pv_specular", 0.0625), ("diffuse", "pv_diffuse", 0.0625)):
+        def scene_of(sp):
+            o = orc.OracleScene(sp, [0]); o.set_direct_mis(0); return o
+        sp = scenes.pervertex_scene(24, 24, 32, 0, 0, param=param)
+        _, dimg = scene_of(sp).render_d(max_depth=1, seeds=(3, 3, 3))
+        up, dn = scenes.pervertex_scene(24, 24, 32, 0, 0), scenes.pervertex_scene(24, 24, 32, 0, 0)
+        setattr(up.bsdfs[5], attr, getattr(up.bsdfs[5], attr) + np.float32(h)); setattr(dn.bsdfs[5], attr, getattr(dn.bsdfs[5], attr) - np.float32(h))
+        fd = (scene_of(up).render_c(max_depth=1, seed=3) - scene_of(dn).render_c(max_depth=1, seed=3)) / (2 * h)
+        rel = float(np.linalg.norm(dimg - fd) / np.linalg.norm(fd))
+        assert np.abs(fd).sum() > 0.1 and rel < (3e-2 if param == "roughness" else 6e-3), (param, rel)
