@@ -684,8 +684,6 @@ class _RenderDFn(_torch.autograd.Function):
         leaves = st["leaves"]
         needs = ctx.needs_input_grad[1:]
         want_cam = any(need and isinstance(obj, Sensor) for (obj, name, t), need in zip(leaves, needs))
-        if any(need and isinstance(obj, MicrofacetBSDFPerVertex) for (obj, name, t), need in zip(leaves, needs)):
-            raise NotImplementedError("reverse mode w.r.t. per-vertex BSDF values is not implemented; use forward_grad()")
         dev = grad_img.device
         g_img = grad_img.contiguous().to(_torch.float32)
         snap = scene._snapshot()
@@ -717,12 +715,12 @@ class _RenderDFn(_torch.autograd.Function):
             if isinstance(obj, Mesh):
                 want_mesh[_mesh_index(scene, obj)] = 1
             elif isinstance(obj, _core.BSDF):
-                want_bsdf = want_bsdf or t.dim() < 2          # (bitmap leaves are served by g_tex)
+                want_bsdf = want_bsdf or (t.dim() < 2 and not isinstance(obj, MicrofacetBSDFPerVertex))     # (bitmap / per-vertex leaves are served by g_tex)
             elif isinstance(obj, _core.Emitter):
                 want_em = want_em or not isinstance(obj, EnvironmentMap)     # (the map's adjoints come back in g_env / g_env_scale)
         mesh_filter = _torch.from_numpy(want_mesh).to(dev)
-        # bitmap parameters (a leaf of 2 or 3 dimensions on a BSDF): their texel adjoints come back in one flat buffer
-        tex_leaves = [i for i, ((obj, name, t), need) in enumerate(zip(leaves, needs)) if need and isinstance(obj, _core.BSDF) and t.dim() >= 2 and not isinstance(obj, MicrofacetBSDFPerVertex)]
+        # bitmap parameters (a leaf of 2 or 3 dimensions on a BSDF) and per-vertex values: their adjoints come back in one flat buffer
+        tex_leaves = [i for i, ((obj, name, t), need) in enumerate(zip(leaves, needs)) if need and isinstance(obj, _core.BSDF) and (t.dim() >= 2 or isinstance(obj, MicrofacetBSDFPerVertex))]
         g_tex = None
         if tex_leaves:
             tex_off, tex_total = _core._tex_layout(scene)

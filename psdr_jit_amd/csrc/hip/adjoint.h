@@ -193,7 +193,8 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                     while (st_i < n_lk) {
                         const int id = __float_as_int(lk[3 * st_i * kBlock]);
                         // an environment-map lookup has the three radiance components; a BSDF the maps it owns
-                        const int fl = id == kEnvLookup ? (P.g_env != nullptr ? 2 : 0) : (P.g_tex != nullptr ? __float_as_int(S.ld(T.bsdf_off + 2 * id).w) : 0);
+                        const int fl = id == kEnvLookup ? (P.g_env != nullptr ? 2 : 0) : (id <= kPvLookup ? (P.g_tex != nullptr ? (2 | 32 | 64) : 0)
+                                                                                                  : (P.g_tex != nullptr ? __float_as_int(S.ld(T.bsdf_off + 2 * id).w) : 0));
                         while (st_comp < 7 && !(fl & (st_comp < 3 ? 2 : (st_comp < 6 ? 32 : 64)))) st_comp = st_comp < 3 ? 3 : (st_comp < 6 ? 6 : 7);
                         if (st_comp >= 7) { ++st_i; st_comp = 0; continue; }
                         st_id = id;
@@ -231,6 +232,16 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                                     }
                                     if (P.g_env_scale != nullptr && E.scale != 0.f) atomicAdd(&acc_cam[12], gval * rgb_c / E.scale);
                                 }
+                            } else if (st_id <= kPvLookup) {
+                                // per-vertex values: the transpose of the barycentric interpolation over the triangle's three vertices
+                                const int slot = kPvLookup - st_id;
+                                const int bid = mesh_bsdf(S, __float_as_int(S.ld(T.shade_off + 6 * slot + 1).w));
+                                const PvDev pv = T.pv[bid];
+                                const int *fi = T.tri_fi + 3 * slot;
+                                const int tslot = st_comp < 3 ? 0 : (st_comp < 6 ? 1 : 2), ch = tslot == 2 ? 1 : 3, c = st_comp - 3 * tslot;
+                                const float wv[3] = {1.f - S.probe_u - S.probe_v, S.probe_u, S.probe_v};
+                                if (gval != 0.f && finite_(gval))
+                                    for (int k = 0; k < 3; ++k) atomicAdd(&P.g_tex[pv.g_off[tslot] + (long long) ch * fi[k] + c], gval * wv[k]);
                             } else {
                                 const int tslot = st_comp < 3 ? 0 : (st_comp < 6 ? 1 : 2), ch = tslot == 2 ? 1 : 3, c = st_comp - 3 * tslot;
                                 const TexDev td = T.tex[3 * st_id + tslot];

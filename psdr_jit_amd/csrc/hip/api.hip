@@ -576,7 +576,8 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
         for (int i = 0; i < s->n_bsdfs; ++i) any_pv |= s->bsdfs[i].type == 4;
         if (any_pv) {
             if (!tr.face_indices) return fail("MicrofacetPerVertex needs psdr_triangles.face_indices");
-            std::vector<PvDev> pd((size_t) s->n_bsdfs, PvDev{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0});
+            std::vector<PvDev> pd((size_t) s->n_bsdfs, PvDev{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, {-1, -1, -1}});
+            if (sc->tex_layout.size() < (size_t) 3 * s->n_bsdfs) sc->tex_layout.resize((size_t) 3 * s->n_bsdfs, -1);
             int rc = 0;
             for (int i = 0; i < s->n_bsdfs; ++i) {
                 const psdr_bsdf_rec &b = s->bsdfs[i];
@@ -587,6 +588,9 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
                 pd[i].diff = sc->up(b.pv_diffuse, 3 * nv, rc); pd[i].d_diff = sc->up(b.d_pv_diffuse, 3 * nv, rc);
                 pd[i].rough = sc->up(b.pv_roughness, nv, rc); pd[i].d_rough = sc->up(b.d_pv_roughness, nv, rc);
                 pd[i].n = b.pv_count;
+                // adjoint blocks in psdr_grads.g_tex, numbered like Microfacet's maps: 0 diffuse, 1 specular, 2 roughness
+                const size_t sizes[3] = {3 * nv, 3 * nv, nv};
+                for (int k = 0; k < 3; ++k) { pd[i].g_off[k] = sc->tex_total; sc->tex_layout[3 * (size_t) i + k] = sc->tex_total; sc->tex_total += (long long) sizes[k]; }
             }
             // every mesh that uses a per-vertex BSDF must index inside its arrays
             for (int i = 0; i < n; ++i) {

@@ -35,7 +35,7 @@ struct EnvDev {
 struct TexDev { const float *data, *d_data; int w, h; long long g_off; };    // g_off: offset of its texel adjoints in psdr_grads.g_tex
 
 // MicrofacetPerVertex (microfacet_pv.cpp): per-vertex parameter arrays of one BSDF in global memory (n == 0: not per-vertex)
-struct PvDev { const float *spec, *d_spec, *diff, *d_diff, *rough, *d_rough; int n; };
+struct PvDev { const float *spec, *d_spec, *diff, *d_diff, *rough, *d_rough; int n; long long g_off[3]; };   // g_off: diffuse / specular / roughness adjoints in psdr_grads.g_tex
 
 // Microfacet parameters beyond the diffuse reflectance (global memory table, one entry per BSDF; microfacet.h)
 struct MatDev {
@@ -85,6 +85,8 @@ struct Counters { unsigned long long rays, nodes, tris, hits; };
 
 // per-lane view used by every device function
 constexpr int kEnvLookup = -1;         // id of an environment-map lookup in the lookup record (BSDF ids are >= 0)
+// a per-vertex BSDF interpolation at triangle slot s is recorded as id = kPvLookup - s, with the barycentrics as (u, v)
+constexpr int kPvLookup = -2;
 constexpr int kAdjMaxLookups = 8;      // bitmap lookups recorded per path (one per textured vertex; max_depth <= 4)
 
 template <bool LDS> struct SceneView {

@@ -419,16 +419,24 @@ template <bool AD, bool LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S
         if (__float_as_int(a.w) & 128) {       // MicrofacetPerVertex (microfacet_pv.cpp)
             const PvDev pv = S.T->pv[mesh_bsdf(S, its.mesh)];
             const int *fi = S.T->tri_fi + 3 * its.slot;
-            const bool tan = AD && S.mode == 0;            // (no reverse-mode adjoint of the per-vertex values yet)
+            const bool tan = AD && S.mode == 0;            // (reverse mode: the adjoints of the per-vertex values come from the lookup probes)
             const Dual bu = Dual(its.bu), bv = Dual(its.bv);
             auto lerp = [&](const float *val, const float *dval, int stride, int c) {
                 auto at = [&](int i) { return Dual(val[stride * i + c], (tan && dval) ? dval[stride * i + c] : 0.f); };
                 const Dual v0 = at(fi[0]), v1 = at(fi[1]), v2 = at(fi[2]);
                 return fma_(v1 - v0, bu, fma_(v2 - v0, bv, v0));
             };
-            const Vec3d spec(lerp(pv.spec, pv.d_spec, 3, 0), lerp(pv.spec, pv.d_spec, 3, 1), lerp(pv.spec, pv.d_spec, 3, 2));
-            const Vec3d diff(lerp(pv.diff, pv.d_diff, 3, 0), lerp(pv.diff, pv.d_diff, 3, 1), lerp(pv.diff, pv.d_diff, 3, 2));
-            const Dual rough = lerp(pv.rough, pv.d_rough, 1, 0);
+            Vec3d spec(lerp(pv.spec, pv.d_spec, 3, 0), lerp(pv.spec, pv.d_spec, 3, 1), lerp(pv.spec, pv.d_spec, 3, 2));
+            Vec3d diff(lerp(pv.diff, pv.d_diff, 3, 0), lerp(pv.diff, pv.d_diff, 3, 1), lerp(pv.diff, pv.d_diff, 3, 2));
+            Dual rough = lerp(pv.rough, pv.d_rough, 1, 0);
+            if constexpr (AD) {                    // reverse mode: note the interpolation / carry the probe's unit tangent (components as Microfacet's maps)
+                S.note_lookup(kPvLookup - its.slot, bu.v, bv.v);
+                const int hot = S.lookup_hot(kPvLookup - its.slot, bu.v, bv.v, 0, 7);
+                if (hot >= 0) {
+                    Dual &q = hot == 0 ? diff.x : hot == 1 ? diff.y : hot == 2 ? diff.z : hot == 3 ? spec.x : hot == 4 ? spec.y : hot == 5 ? spec.z : rough;
+                    q.d += 1.f;
+                }
+            }
             const bool two = (__float_as_int(a.w) & 1) != 0;
             if constexpr (AD) return microfacet_pv_eval<Dual>(spec, diff, rough, two, its.wi, wo, active);
             else return microfacet_pv_eval<float>(detach(spec), detach(diff), rough.v, two, its.wi, wo, active);

@@ -479,3 +479,43 @@ def test_microfacet_per_vertex_bsdf(psdr, orc, param):
     assert np.abs(wd).max() > 0 and product.rel_l2(dimg.cpu().numpy(), wd) < 1e-3
     b = sc.param_map["BSDF[id=pv]"]
     assert type(b).__name__ == "MicrofacetBSDFPerVertex" and tuple(b.roughness.shape) == (len(spec.meshes[1].vertices),)
+
+
+def test_microfacet_per_vertex_reverse_mode(psdr, orc):
+    """loss.backward() into per-vertex BSDF values (per-vertex material optimisation): <w, J v> == <J^T w, v> against forward mode"""
+    import torch
+    from psdr_jit_amd import Matrix4fC, Matrix4fD
+    rng = np.random.default_rng(13)
+    spec = scenes.pervertex_scene(40, 40, 8, 0, 0)
+    b = spec.bsdfs[5]
+    sp = torch.tensor(b.pv_specular, requires_grad=True)
+    df = torch.tensor(b.pv_diffuse, requires_grad=True)
+    rg = torch.tensor(b.pv_roughness, requires_grad=True)
+    D = scenes.DATA
+    sc = psdr.Scene()
+    sc.opts.spp, sc.opts.sppe, sc.opts.sppse = 8, 0, 0
+    sc.opts.width = sc.opts.height = 40
+    sc.opts.log_level = 0
+    cam = psdr.PerspectiveCamera(60, 0.000001, 10000000.)
+    cam.to_world = Matrix4fD([[1., 0., 0., 208.], [0., 1., 0., 273.], [0., 0., 1., -800.], [0., 0., 0., 1.]])
+    sc.add_Sensor(cam)
+    sc.add_BSDF(psdr.DiffuseBSDF([0.0, 0.0, 0.0]), "light")
+    sc.add_BSDF(psdr.MicrofacetBSDFPerVertex(sp, df, rg), "pv")
+    sc.add_BSDF(psdr.DiffuseBSDF([0.95, 0.95, 0.95]), "white")
+    I = np.eye(4, dtype=np.float32).tolist()
+    sc.add_Mesh(os.path.join(D, "cbox_luminaire.obj"), Matrix4fC([[1., 0., 0., 0.], [0., 1., 0., -0.5], [0., 0., 1., 0.], [0., 0., 0., 1.]]), "light", psdr.AreaLight([20.0, 20.0, 8.0]))
+    sc.add_Mesh(os.path.join(D, "cbox_smallball.obj"), Matrix4fC(I), "pv", None)
+    for f in ("cbox_floor", "cbox_back"):
+        sc.add_Mesh(os.path.join(D, f + ".obj"), Matrix4fC(I), "white", None)
+    sc.configure()
+    sc.configure([0])
+    img = psdr.PathTracer(2).renderD(sc, 0, seed=5)
+    w = torch.linspace(0.5, 1.5, img.numel(), device=img.device).reshape(img.shape)
+    fwd = {}
+    for name, t in (("specular", sp), ("diffuse", df), ("roughness", rg)):
+        v = torch.tensor(rng.standard_normal(tuple(t.shape)).astype(np.float32))
+        fwd[name] = (t, v, float((psdr.forward_grad(img, t, direction=v) * w).sum()))
+    (img * w).sum().backward()
+    for name, (t, v, want) in fwd.items():
+        got = float((t.grad * v).sum())
+        assert abs(want) > 1e-4 and abs(got - want) < 2e-3 * max(1.0, abs(want)), (name, got, want)
