@@ -256,6 +256,11 @@ typedef struct psdr_grads {
     float *g_camera;
     /* adjoints of the environment map: its texels (DEVICE [height*width*3]) and its scale (DEVICE [1]); NULL = not wanted */
     float *g_env, *g_env_scale;
+    /* adjoints of the constant parameters of the GGX BSDFs, DEVICE [n_bsdfs*16], one row per BSDF, or NULL = not wanted:
+     *   Microfacet      [specular rgb, roughness]
+     *   RoughConductor  [alpha_u, alpha_v, eta rgb, k rgb, specular_reflectance rgb]
+     *   RoughDielectric [alpha_u, alpha_v, eta (= intIOR / extIOR)]                     (the diffuse colour stays in g_bsdf) */
+    float *g_mat;
 } psdr_grads;
 /* offsets[3*n_bsdfs] (HOST): float offset of the texel block of BSDF b's bitmap k (0 reflectance / diffuse reflectance rgb,
  * 1 specular reflectance rgb, 2 roughness) inside psdr_grads.g_tex, same row-major layout as the bitmap; -1 = constant.

@@ -298,7 +298,8 @@ def _roughconductor_init(self, *args):
         au, av, rest = args[0], args[1], args[2:]
     else:
         au, av, rest = args[0], args[0], args[1:]
-    self.alpha_u, self.alpha_v = [scal(au)], [scal(av)]
+    keep = lambda x: x.reshape(1) if isinstance(x, _torch.Tensor) else [scal(x)]      # a tensor stays a leaf
+    self.alpha_u, self.alpha_v = keep(au), keep(av)
     self.eta, self.k = rest[0], rest[1]
     if len(rest) > 2:
         self.specular_reflectance = rest[2]
@@ -715,7 +716,7 @@ class _RenderDFn(_torch.autograd.Function):
             if isinstance(obj, Mesh):
                 want_mesh[_mesh_index(scene, obj)] = 1
             elif isinstance(obj, _core.BSDF):
-                want_bsdf = want_bsdf or (t.dim() < 2 and not isinstance(obj, MicrofacetBSDFPerVertex))     # (bitmap / per-vertex leaves are served by g_tex)
+                want_bsdf = want_bsdf or (t.dim() < 2 and name in ("reflectance", "diffuseReflectance"))     # (the rest: g_tex / g_mat)
             elif isinstance(obj, _core.Emitter):
                 want_em = want_em or not isinstance(obj, EnvironmentMap)     # (the map's adjoints come back in g_env / g_env_scale)
         mesh_filter = _torch.from_numpy(want_mesh).to(dev)
@@ -726,6 +727,13 @@ class _RenderDFn(_torch.autograd.Function):
             tex_off, tex_total = _core._tex_layout(scene)
             g_tex = _torch.zeros(max(1, int(tex_total)), dtype=_torch.float32, device=dev)
         g_cam = _torch.zeros(16, dtype=_torch.float32, device=dev) if want_cam else None
+        # constant parameters of the GGX BSDFs: (row offset, length) inside the BSDF's 16-float row of psdr_grads.g_mat
+        mat_rows = {"MicrofacetBSDF": {"specularReflectance": (0, 3), "roughness": (3, 1)},
+                    "RoughConductorBSDF": {"alpha_u": (0, 1), "alpha_v": (1, 1), "eta": (2, 3), "k": (5, 3), "specular_reflectance": (8, 3)},
+                    "RoughDielectricBSDF": {"alpha_u": (0, 1), "alpha_v": (1, 1), "eta": (2, 1)}}
+        mat_leaves = [i for i, ((obj, name, t), need) in enumerate(zip(leaves, needs))
+                      if need and t.dim() < 2 and name in mat_rows.get(type(obj).__name__, {})]
+        g_mat = _torch.zeros(16 * max(1, nb), dtype=_torch.float32, device=dev) if mat_leaves else None
         env_leaves = [i for i, ((obj, name, t), need) in enumerate(zip(leaves, needs)) if need and isinstance(obj, EnvironmentMap)]
         g_env = g_env_scale = None
         for i in env_leaves:
@@ -741,9 +749,10 @@ class _RenderDFn(_torch.autograd.Function):
         _core._render_d_bwd(integ, scene, st["sensor_id"], seeds, skips, g_img.data_ptr(), ptr[0], ptr[1], ptr[2], ptr[3], ptr[4],
                             _stream_ptr(), rank, world, st["terms"], mesh_filter.data_ptr(), not want_bsdf, not want_em,
                             g_tex.data_ptr() if g_tex is not None else 0, g_cam.data_ptr() if g_cam is not None else 0,
-                            g_env.data_ptr() if g_env is not None else 0, g_env_scale.data_ptr() if g_env_scale is not None else 0)
+                            g_env.data_ptr() if g_env is not None else 0, g_env_scale.data_ptr() if g_env_scale is not None else 0,
+                            g_mat.data_ptr() if g_mat is not None else 0)
         _all_reduce(flat, world > 1)
-        for extra in (g_env, g_env_scale):
+        for extra in (g_env, g_env_scale, g_mat):
             if extra is not None:
                 _all_reduce(extra, world > 1)
         if g_cam is not None:
@@ -787,6 +796,12 @@ class _RenderDFn(_torch.autograd.Function):
             slot = {"reflectance": 0, "diffuseReflectance": 0, "specularReflectance": 1, "roughness": 2}[name]
             off = int(tex_off[3 * b + slot])
             grads[i] = _torch.zeros_like(t) if off < 0 else g_tex[off:off + t.numel()].reshape(t.shape).to(t.device, t.dtype)
+        for i in mat_leaves:          # a colour given as one number is the sum of its three components
+            obj, name, t = leaves[i]
+            b = next(k for k in range(nb) if pm["BSDF[%d]" % k] is obj)
+            off, n = mat_rows[type(obj).__name__][name]
+            row = g_mat[16 * b + off:16 * b + off + n]
+            grads[i] = (row if t.numel() == n else row.sum().reshape(1)).reshape(t.shape).to(t.device, t.dtype)
         for i in env_leaves:
             obj, name, t = leaves[i]
             src = g_env if name == "radiance" else g_env_scale

@@ -48,7 +48,12 @@ struct AdjointParams {
     float *g_tex;                   // texel adjoints of the bitmap parameters (TexDev::g_off), or NULL
     float *g_cam;                   // [16] adjoint of the sensor's to_world (row major, rows 0-2 filled), or NULL
     float *g_env, *g_env_scale;     // texel adjoints [H*W*3] and scale adjoint [1] of the environment map, or NULL
+    float *g_mat;                   // [n_bsdfs*16] adjoints of the constant parameters of the GGX BSDFs (psdr_grads.g_mat), or NULL
 };
+
+constexpr int kMatRow = 16;
+// number of constant material parameters a BSDF record's flags announce (Microfacet 4 - fewer with maps -, RoughConductor 11, RoughDielectric 3)
+PSDR_DEV int mat_param_count(int fl) { return (fl & 4) ? 4 : ((fl & 8) ? 11 : ((fl & 16) ? 3 : 0)); }
 
 template <bool LDS>
 PSDR_DEV void adj_add(float *lds_g, float *glob, int idx, float v, bool use_lds) {
@@ -67,7 +72,8 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
     int *ext = reinterpret_cast<int *>(scratch + kAdjHitWords * kBlock) + threadIdx.x;
     float *lk = scratch + (kAdjHitWords + kAdjExtWords) * kBlock + threadIdx.x;
     float *acc_cam = scratch + adj_lane_words<LDS>() * kBlock;        // 16 floats, always in LDS: every path adds to the same 12 entries
-    float *acc = acc_cam + 16;
+    float *acc_mat = acc_cam + 16;                               // [n_bsdfs * kMatRow], always in LDS like the camera block
+    float *acc = acc_mat + T.n_bsdfs * kMatRow;
     const int n_acc = T.n_tris * 22 + T.n_bsdfs * 3 + T.n_emitters * 3;
     const bool use_lds = P.lds_accum != 0;
     if (use_lds) {
@@ -76,6 +82,7 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
     }
     float *acc_bsdf = acc + T.n_tris * 22, *acc_emit = acc_bsdf + T.n_bsdfs * 3;
     if (threadIdx.x < 16) acc_cam[threadIdx.x] = 0.f;          // [0..11] camera pose, [12] environment-map scale
+    for (int i = threadIdx.x; i < T.n_bsdfs * kMatRow; i += kBlock) acc_mat[i] = 0.f;
     __syncthreads();
     S.rec = rec; S.ext = ext; S.lk = lk;
 
@@ -176,7 +183,7 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                         } else if (valid) {
                             const int mesh = __float_as_int(S.ld(T.shade_off + 6 * slot + 1).w);
                             const int id = st_stage == 1 ? mesh_bsdf(S, mesh) : mesh_emitter(S, mesh);
-                            valid = id >= 0 && !(st_stage == 1 ? P.skip_bsdf : P.skip_emitter);
+                            valid = id >= 0 && !(st_stage == 1 ? (P.skip_bsdf && P.g_mat == nullptr) : P.skip_emitter);
                             for (int q = 0; q < st_i && valid; ++q) {
                                 const int sq = slot_at(q);
                                 if (sq < 0) continue;
@@ -184,6 +191,12 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                                 valid = (st_stage == 1 ? mesh_bsdf(S, mq) : mesh_emitter(S, mq)) != id;
                             }
                             st_id = id;
+                            if (valid && st_stage == 1) {
+                                // components 0-2 the colour (g_bsdf), 3.. the constant parameters of a GGX BSDF (g_mat)
+                                if (P.skip_bsdf && st_comp < 3) st_comp = 3;
+                                const int nm = P.g_mat != nullptr ? mat_param_count(__float_as_int(S.ld(T.bsdf_off + 2 * id).w)) : 0;
+                                if (st_comp >= 3 + nm) valid = false;
+                            }
                         }
                         if (!valid) { ++st_i; st_comp = 0; continue; }
                         return true;
@@ -209,10 +222,12 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                 while (__ballot(more) != 0ull) {
                     if (more) {
                         S.probe_kind = st_stage < 3 ? st_stage + 1 : (st_stage == 3 ? 5 : 4); S.probe_id = st_id; S.probe_comp = st_comp;
+                        if (st_stage == 1 && st_comp >= 3) { S.probe_kind = 6; S.probe_comp = st_comp - 3; }
                         if (st_stage == 3) { S.probe_u = lk[(3 * st_i + 1) * kBlock]; S.probe_v = lk[(3 * st_i + 2) * kBlock]; }
                         if (st_stage == 4) { ray_p = ray; primary_ray_pose_tangent(cam, sx, sy, st_comp, ray_p); }
                         const float gval = probe();
                         if (st_stage == 0) adj_add<LDS>(acc, P.g_tri, st_orig * 22 + st_comp, gval, use_lds);
+                        else if (st_stage == 1 && st_comp >= 3) adj_add<LDS>(acc_mat, acc_mat, st_id * kMatRow + st_comp - 3, gval, true);
                         else if (st_stage == 1) adj_add<LDS>(acc_bsdf, P.g_bsdf, st_id * 3 + st_comp, gval, use_lds);
                         else if (st_stage == 2) adj_add<LDS>(acc_emit, P.g_emitter, st_id * 3 + st_comp, gval, use_lds);
                         else if (st_stage == 4) { adj_add<LDS>(acc_cam, acc_cam, st_comp, gval, true); ray_p = ray; }
@@ -251,7 +266,7 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                             }
                         }
                         ++st_comp;
-                        if (st_stage < 4 && st_comp >= (st_stage == 0 ? 22 : (st_stage == 3 ? 7 : 3))) { st_comp = 0; ++st_i; }
+                        if (st_stage < 4 && st_stage != 1 && st_comp >= (st_stage == 0 ? 22 : (st_stage == 3 ? 7 : 3))) { st_comp = 0; ++st_i; }      // (stage 1 ends in advance())
                         more = advance();
                     }
                 }
@@ -263,6 +278,8 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
     __syncthreads();
     if (P.g_cam != nullptr && threadIdx.x < 12 && acc_cam[threadIdx.x] != 0.f) atomicAdd(&P.g_cam[threadIdx.x], acc_cam[threadIdx.x]);
     if (P.g_env_scale != nullptr && threadIdx.x == 12 && acc_cam[12] != 0.f) atomicAdd(P.g_env_scale, acc_cam[12]);
+    if (P.g_mat != nullptr)
+        for (int i = threadIdx.x; i < T.n_bsdfs * kMatRow; i += kBlock) if (acc_mat[i] != 0.f) atomicAdd(&P.g_mat[i], acc_mat[i]);
     if (use_lds) {
         __syncthreads();
         for (int i = threadIdx.x; i < T.n_tris * 22; i += kBlock) if (acc[i] != 0.f) atomicAdd(&P.g_tri[i], acc[i]);

@@ -108,7 +108,7 @@ template <bool LDS> struct SceneView {
     int rec_i, rec_n;          // replay cursor / number of recorded hits
     int *ext;                  // extra triangle slots read without a trace (light samples), stride kBlock
     int ext_n;
-    int probe_kind;            // 0 none, 1 triangle field, 2 bsdf reflectance, 3 emitter radiance, 4 camera to_world, 5 bitmap lookup
+    int probe_kind;            // 0 none, 1 triangle field, 2 bsdf reflectance, 3 emitter radiance, 4 camera to_world, 5 bitmap lookup, 6 material constant
     int probe_id, probe_comp;
     // bitmap-parameter lookups (textured BSDFs): the recording run notes (bsdf id, u, v) of every lookup; a probe of kind 5
     // puts a unit tangent on one component of the looked-up value of ONE such lookup (matched by id and the bit-equal uv the
@@ -143,6 +143,12 @@ template <bool LDS> struct SceneView {
         if (probe_kind == 0) return B[word];
         const bool on = probe_kind == kind && id == probe_id;
         return make_float4(on && probe_comp == 0 ? 1.f : 0.f, on && probe_comp == 1 ? 1.f : 0.f, on && probe_comp == 2 ? 1.f : 0.f, 0.f);
+    }
+    // tangent of constant material parameter k of BSDF id (psdr_grads.g_mat row layout): the forward tangent in a render,
+    // a unit tangent when a probe of kind 6 asks for exactly this one, zero in every other replay
+    PSDR_DEV float mat_tan(int id, int k, float fwd) const {
+        if (mode == 0) return fwd;
+        return (probe_kind == 6 && probe_id == id && probe_comp == k) ? 1.f : 0.f;
     }
     PSDR_DEV void note_slot(int slot) { if (mode == 1 && slot >= 0 && ext_n < 8) { ext[ext_n * kBlock] = slot; ++ext_n; } }
 

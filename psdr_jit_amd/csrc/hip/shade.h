@@ -391,8 +391,10 @@ template <bool AD, bool LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S
             // bitmap parameters (microfacet.cpp:38-45): looked up with (value, tangent) texels and uv, detached in C mode
             const bool tan = AD && S.mode == 0;            // (reverse mode returns no adjoint for the constant specular / roughness)
             const Dual tu = Dual(its.tu), tv = Dual(its.tv);
-            Vec3d spec(Dual(md.specular[0], tan ? md.d_specular[0] : 0.f), Dual(md.specular[1], tan ? md.d_specular[1] : 0.f), Dual(md.specular[2], tan ? md.d_specular[2] : 0.f));
-            Dual rough(md.roughness, tan ? md.d_roughness : 0.f);
+            // constants: g_mat row = [specular rgb, roughness]
+            Vec3d spec(Dual(md.specular[0], AD ? S.mat_tan(id, 0, md.d_specular[0]) : 0.f), Dual(md.specular[1], AD ? S.mat_tan(id, 1, md.d_specular[1]) : 0.f),
+                       Dual(md.specular[2], AD ? S.mat_tan(id, 2, md.d_specular[2]) : 0.f));
+            Dual rough(md.roughness, AD ? S.mat_tan(id, 3, md.d_roughness) : 0.f);
             Vec3d diff;
             if constexpr (AD) { const float4 b = S.rgb_tan(w + 1, 2, id); diff = make_dual(Vec3f(a.x, a.y, a.z), Vec3f(b.x, b.y, b.z)); }
             else diff = make_dual(Vec3f(a.x, a.y, a.z), Vec3f(0.f, 0.f, 0.f));
@@ -446,10 +448,14 @@ template <bool AD, bool LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S
             const bool two = (__float_as_int(a.w) & 1) != 0;
             if constexpr (AD) {
                 const float t = S.mode == 0 ? 1.f : 0.f;       // (its parameters have no reverse-mode adjoint yet)
-                return conductor_eval<Dual>(Dual(md.alpha_u, t * md.d_alpha_u), Dual(md.alpha_v, t * md.d_alpha_v),
-                                            Vec3d(Dual(md.eta[0], t * md.d_eta[0]), Dual(md.eta[1], t * md.d_eta[1]), Dual(md.eta[2], t * md.d_eta[2])),
-                                            Vec3d(Dual(md.k[0], t * md.d_k[0]), Dual(md.k[1], t * md.d_k[1]), Dual(md.k[2], t * md.d_k[2])),
-                                            Vec3d(Dual(md.specular[0], t * md.d_specular[0]), Dual(md.specular[1], t * md.d_specular[1]), Dual(md.specular[2], t * md.d_specular[2])),
+                // g_mat row = [alpha_u, alpha_v, eta rgb, k rgb, specular_reflectance rgb]
+                const int bid = mesh_bsdf(S, its.mesh);
+                (void) t;
+                auto mt = [&](int kk, float fwd) { return S.mat_tan(bid, kk, fwd); };
+                return conductor_eval<Dual>(Dual(md.alpha_u, mt(0, md.d_alpha_u)), Dual(md.alpha_v, mt(1, md.d_alpha_v)),
+                                            Vec3d(Dual(md.eta[0], mt(2, md.d_eta[0])), Dual(md.eta[1], mt(3, md.d_eta[1])), Dual(md.eta[2], mt(4, md.d_eta[2]))),
+                                            Vec3d(Dual(md.k[0], mt(5, md.d_k[0])), Dual(md.k[1], mt(6, md.d_k[1])), Dual(md.k[2], mt(7, md.d_k[2]))),
+                                            Vec3d(Dual(md.specular[0], mt(8, md.d_specular[0])), Dual(md.specular[1], mt(9, md.d_specular[1])), Dual(md.specular[2], mt(10, md.d_specular[2]))),
                                             two, its.wi, wo, active);
             } else {
                 return conductor_eval<float>(md.alpha_u, md.alpha_v, Vec3f(md.eta[0], md.eta[1], md.eta[2]), Vec3f(md.k[0], md.k[1], md.k[2]),
@@ -463,8 +469,13 @@ template <bool AD, bool LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S
             const bool two = (__float_as_int(a.w) & 1) != 0;
             if constexpr (AD) {
                 const float t = S.mode == 0 ? 1.f : 0.f;
-                return dielectric_eval<Dual>(Dual(md.alpha_u, t * md.d_alpha_u), Dual(md.alpha_v, t * md.d_alpha_v), Dual(md.eta[0], t * md.d_eta[0]),
-                                             Dual(md.eta[1], t * md.d_eta[1]), two, its.wi, wo, active);
+                // g_mat row = [alpha_u, alpha_v, eta]; m_inv_eta = 1 / m_eta moves with eta
+                const int bid = mesh_bsdf(S, its.mesh);
+                (void) t;
+                const float de = S.mat_tan(bid, 2, md.d_eta[0]);
+                const float dinv = S.mode == 0 ? md.d_eta[1] : -de / (md.eta[0] * md.eta[0]);
+                return dielectric_eval<Dual>(Dual(md.alpha_u, S.mat_tan(bid, 0, md.d_alpha_u)), Dual(md.alpha_v, S.mat_tan(bid, 1, md.d_alpha_v)), Dual(md.eta[0], de),
+                                             Dual(md.eta[1], dinv), two, its.wi, wo, active);
             } else {
                 return dielectric_eval<float>(md.alpha_u, md.alpha_v, md.eta[0], md.eta[1], two, its.wi, wo, active);
             }

@@ -519,3 +519,53 @@ def test_microfacet_per_vertex_reverse_mode(psdr, orc):
     for name, (t, v, want) in fwd.items():
         got = float((t.grad * v).sum())
         assert abs(want) > 1e-4 and abs(got - want) < 2e-3 * max(1.0, abs(want)), (name, got, want)
+
+
+@pytest.mark.parametrize("kind", ["microfacet", "roughconductor", "roughdielectric"])
+def test_ggx_constant_parameters_reverse_mode(psdr, orc, kind):
+    """loss.backward() into the constant parameters of the GGX BSDFs (roughness, specular colour, alpha, eta, k ...):
+    <w, J v> == <J^T w, v> against forward mode for every parameter"""
+    import torch
+    from psdr_jit_amd import Matrix4fC, Matrix4fD
+    D = scenes.DATA
+    if kind == "microfacet":
+        leaves = {"specularReflectance": torch.tensor([0.6, 0.5, 0.4], requires_grad=True), "diffuseReflectance": torch.tensor([0.3, 0.2, 0.1], requires_grad=True),
+                  "roughness": psdr.FloatD(0.35).requires_grad_()}
+        bsdf = psdr.MicrofacetBSDF(leaves["specularReflectance"], leaves["diffuseReflectance"], leaves["roughness"])
+    elif kind == "roughconductor":
+        leaves = {"alpha_u": psdr.FloatD(0.2).requires_grad_(), "alpha_v": psdr.FloatD(0.3).requires_grad_(), "eta": torch.tensor([0.2, 0.9, 1.1], requires_grad=True),
+                  "k": torch.tensor([3.9, 2.4, 2.1], requires_grad=True), "specular_reflectance": torch.tensor([1.0, 0.9, 0.8], requires_grad=True)}
+        bsdf = psdr.RoughConductorBSDF(leaves["alpha_u"], leaves["alpha_v"], leaves["eta"], leaves["k"], leaves["specular_reflectance"])
+    else:
+        leaves = {"alpha_u": psdr.FloatD(0.15).requires_grad_(), "alpha_v": psdr.FloatD(0.15).requires_grad_(), "eta": psdr.FloatD(1.5).requires_grad_()}
+        bsdf = psdr.RoughDielectricBSDF(1.5, 1.0)
+        bsdf.alpha_u, bsdf.alpha_v, bsdf.eta = leaves["alpha_u"], leaves["alpha_v"], leaves["eta"]
+    sc = psdr.Scene()
+    sc.opts.spp, sc.opts.sppe, sc.opts.sppse = 8, 0, 0
+    sc.opts.width = sc.opts.height = 40
+    sc.opts.log_level = 0
+    cam = psdr.PerspectiveCamera(60, 0.000001, 10000000.)
+    cam.to_world = Matrix4fD([[1., 0., 0., 208.], [0., 1., 0., 273.], [0., 0., 1., -800.], [0., 0., 0., 1.]])
+    sc.add_Sensor(cam)
+    sc.add_BSDF(psdr.DiffuseBSDF([0.0, 0.0, 0.0]), "light")
+    sc.add_BSDF(bsdf, "m")
+    sc.add_BSDF(psdr.DiffuseBSDF([0.95, 0.95, 0.95]), "white")
+    I = np.eye(4, dtype=np.float32).tolist()
+    sc.add_Mesh(os.path.join(D, "cbox_luminaire.obj"), Matrix4fC([[1., 0., 0., 0.], [0., 1., 0., -0.5], [0., 0., 1., 0.], [0., 0., 0., 1.]]), "light", psdr.AreaLight([20.0, 20.0, 8.0]))
+    for f, b in (("cbox_smallbox", "m"), ("cbox_largebox", "m"), ("cbox_floor", "white"), ("cbox_back", "white")):
+        sc.add_Mesh(os.path.join(D, f + ".obj"), Matrix4fC(I), b, None)
+    sc.configure()
+    sc.configure([0])
+    img = psdr.PathTracer(3).renderD(sc, 0, seed=4)
+    w = torch.linspace(0.5, 1.5, img.numel(), device=img.device).reshape(img.shape)
+    rng = np.random.default_rng(5)
+    fwd = {}
+    for name, t in leaves.items():
+        v = torch.tensor(rng.standard_normal(tuple(t.shape)).astype(np.float32)) if t.dim() > 0 else torch.tensor(1.0)
+        fwd[name] = (v, float((psdr.forward_grad(img, t, direction=v) * w).sum()))
+    (img * w).sum().backward()
+    for name, t in leaves.items():
+        v, want = fwd[name]
+        assert t.grad is not None, name
+        got = float((t.grad * v).sum())
+        assert abs(want) > 1e-4 and abs(got - want) < 3e-3 * max(1.0, abs(want)), (kind, name, got, want)
