@@ -23,7 +23,7 @@ constexpr int kAdjExtWords = 8;                                // light-sample s
 constexpr int kAdjLkWords = 3 * kAdjMaxLookups;                // bitmap lookups per lane (id, u, v)
 // LDS words per lane of the interior adjoint kernel: the small-scene (LDS = true) instantiation has no bitmap / environment
 // lookups (such scenes are never staged into LDS), so it carries no lookup record and keeps two workgroups per CU
-template <bool LDS> constexpr int adj_lane_words() { return kAdjHitWords + kAdjExtWords + (LDS ? 0 : kAdjLkWords); }
+template <int LDS> constexpr int adj_lane_words() { return kAdjHitWords + kAdjExtWords + (in_lds(LDS) ? 0 : kAdjLkWords); }
 // the secondary-edge adjoint records three hits per lane, followed by 16 floats of camera-pose accumulators
 constexpr int kSecAdjLaneWords = 12;
 constexpr int kSecAdjScratch = kSecAdjLaneWords * kBlock + 16;
@@ -55,14 +55,14 @@ constexpr int kMatRow = 16;
 // number of constant material parameters a BSDF record's flags announce (Microfacet 4 - fewer with maps -, RoughConductor 11, RoughDielectric 3)
 PSDR_DEV int mat_param_count(int fl) { return (fl & 4) ? 4 : ((fl & 8) ? 11 : ((fl & 16) ? 3 : 0)); }
 
-template <bool LDS>
+template <int LDS>
 PSDR_DEV void adj_add(float *lds_g, float *glob, int idx, float v, bool use_lds) {
     if (v == 0.f || !finite_(v)) return;
     if (use_lds) atomicAdd(&lds_g[idx], v); else atomicAdd(&glob[idx], v);
 }
 
 // scratch: per-block LDS region behind the blob/stack: [hits: kAdjHitWords x 256][ext: kAdjExtWords x 256][lookups: kAdjLkWords x 256][accumulators]
-template <bool LDS>
+template <int LDS>
 PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, const AdjointParams &P, float *scratch) {
     const SceneTables &T = *S.T;
     const int lane_id = threadIdx.x & 63;
@@ -144,7 +144,7 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
             const LaneRng rng0 = rng;
             S.mode = 1; S.rec_n = 0; S.rec_i = 0; S.ext_n = 0; S.lk_n = 0; S.probe_kind = 0;
             const Vec3d L0 = Li<true, LDS, false>(S, rng, ray, true, P.max_depth, P.hide_emitters != 0);
-            const int n_hits = S.rec_n, n_ext = S.ext_n, n_lk = (!LDS && (P.g_tex != nullptr || P.g_env != nullptr)) ? S.lk_n : 0;
+            const int n_hits = S.rec_n, n_ext = S.ext_n, n_lk = (has_env(LDS) && (P.g_tex != nullptr || P.g_env != nullptr)) ? S.lk_n : 0;
             float w[3];
             {
                 const float pv[3] = {L0.x.v, L0.y.v, L0.z.v};
@@ -231,7 +231,7 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                         else if (st_stage == 1) adj_add<LDS>(acc_bsdf, P.g_bsdf, st_id * 3 + st_comp, gval, use_lds);
                         else if (st_stage == 2) adj_add<LDS>(acc_emit, P.g_emitter, st_id * 3 + st_comp, gval, use_lds);
                         else if (st_stage == 4) { adj_add<LDS>(acc_cam, acc_cam, st_comp, gval, true); ray_p = ray; }
-                        else if constexpr (!LDS) {
+                        else if constexpr (has_env(LDS)) {
                             // scatter over the footprint of the lookup (the transpose of the bilinear interpolation)
                             int idx[4]; float wt[4];
                             if (st_id == kEnvLookup) {
@@ -247,6 +247,7 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                                     }
                                     if (P.g_env_scale != nullptr && E.scale != 0.f) atomicAdd(&acc_cam[12], gval * rgb_c / E.scale);
                                 }
+                            } else if (!has_mat(LDS)) {
                             } else if (st_id <= kPvLookup) {
                                 // per-vertex values: the transpose of the barycentric interpolation over the triangle's three vertices
                                 const int slot = kPvLookup - st_id;

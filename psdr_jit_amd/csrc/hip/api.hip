@@ -44,24 +44,24 @@ struct RenderParams {
     int shard_rank, shard_count;   // rank r of c evaluates the 256-lane chunks k with k % c == r
 };
 
-template <bool LDS>
+template <int LDS>
 PSDR_DEV SceneView<LDS> make_view(const float4 *blob, const SceneTables &T, float4 *smem) {
     const float4 *B = blob;
-    if (LDS) {
+    if (in_lds(LDS)) {
         for (int i = threadIdx.x; i < T.blob_words; i += kBlock) smem[i] = blob[i];
         __syncthreads();
         B = smem;
     }
     SceneView<LDS> S;
     S.B = B; S.G = blob; S.T = &T;
-    S.stack = reinterpret_cast<int *>(smem + (LDS ? T.blob_words : 0)) + threadIdx.x;
+    S.stack = reinterpret_cast<int *>(smem + (in_lds(LDS) ? T.blob_words : 0)) + threadIdx.x;
     S.c_nodes = S.c_tris = S.c_rays = S.c_hits = 0u;
     S.mis = -1; S.field = -1; S.field_object = -1; S.intensity = 1.f; S.d_intensity = 0.f; S.mode = 0; S.rec = nullptr; S.rec_i = 0; S.rec_n = 0; S.ext = nullptr; S.ext_n = 0; S.probe_kind = 0; S.probe_id = 0; S.probe_comp = 0;
     S.lk = nullptr; S.lk_n = 0; S.probe_u = 0.f; S.probe_v = 0.f;
     return S;
 }
 
-template <bool LDS> PSDR_DEV void flush_counters(const SceneView<LDS> &S, Counters *ctr) {
+template <int LDS> PSDR_DEV void flush_counters(const SceneView<LDS> &S, Counters *ctr) {
     unsigned long long v[4] = {S.c_rays, S.c_nodes, S.c_tris, S.c_hits};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -82,13 +82,13 @@ PSDR_DEV float seg_scan(float v, int key, int lane_id) {
     return v;
 }
 
-template <bool LDS> PSDR_DEV float *scratch_base(float4 *smem, const SceneTables &T) {
-    return reinterpret_cast<float *>(smem + (LDS ? T.blob_words : 0)) + T.stack_depth * kBlock;
+template <int LDS> PSDR_DEV float *scratch_base(float4 *smem, const SceneTables &T) {
+    return reinterpret_cast<float *>(smem + (in_lds(LDS) ? T.blob_words : 0)) + T.stack_depth * kBlock;
 }
 
 // ------------------------------------------------------------------------------------------------
 // interior term (MODE 0) and primary-edge term (MODE 1): persistent lanes with path regeneration, paths.h
-template <bool AD, bool LDS, bool COUNT, int MODE>
+template <bool AD, int LDS, bool COUNT, int MODE>
 __global__ __launch_bounds__(kBlock, (AD ? 3 : 4)) void k_paths(const float4 *__restrict__ blob, const SceneTables T, const SensorDev cam,
                                                   const PathParams P, Counters *ctr) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kBlock, (AD ? 3 : 4)) void k_paths(const float4 *__
 }
 
 // reverse mode of the interior term (adjoint.h)
-template <bool LDS>
+template <int LDS>
 __global__ __launch_bounds__(kBlock) void k_interior_adjoint(const float4 *__restrict__ blob, const SceneTables T, const SensorDev cam,
                                                              const AdjointParams P) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
@@ -144,7 +144,7 @@ PSDR_DEV float guiding_sample_reuse(const GuidingDev &G, Vec3f &s) {
 // sample_boundary_segment_direct (silhouette condition + light facing), and only those trace rays.  Each lane
 // therefore keeps drawing candidates (RNG seed + three draws + the validity test, no ray) until the wave holds
 // enough valid ones, and the traced part (3 rays) runs with nearly all lanes active (stage r01a: 17 %).
-template <bool LDS, bool COUNT, bool ADJ>
+template <int LDS, bool COUNT, bool ADJ>
 __global__ __launch_bounds__(kBlock) void k_secondary_edges(const float4 *__restrict__ blob, const SceneTables T, const SecEdgeTables E,
                                                             const SensorDev cam, const PathParams P, const GuidingDev G, const int use_guiding,
                                                             Counters *ctr) {
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edges(const float4 *__rest
 }
 
 // guiding grid: PathTracer::preprocess_secondary_edges, reference path.cpp:130-168 (one round per launch)
-template <bool LDS>
+template <int LDS>
 __global__ __launch_bounds__(kBlock) void k_guiding_round(const float4 *__restrict__ blob, const SceneTables T, const SecEdgeTables E,
                                                           const SensorDev cam, const GuidingDev G, const int per_cell, const int seed,
                                                           const int round, float *__restrict__ mass) {
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(kBlock) void k_guiding_round(const float4 *__restri
 }
 
 // batch closest-hit query (parity aid for the traversal alone)
-template <bool LDS>
+template <int LDS>
 __global__ __launch_bounds__(kBlock) void k_trace(const float4 *__restrict__ blob, const SceneTables T, int n, const float *__restrict__ o,
                                                   const float *__restrict__ d, int *__restrict__ out_tri, float *__restrict__ out_uv, float *__restrict__ out_t,
                                                   int pairs) {
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const float4 *__restrict__ blo
 
 // Scene::ray_intersect<false> for a batch of rays (the reference exposes it as Scene.unit_ray_intersect, psdr.cpp:404):
 // 24 floats per ray - valid, mesh id, t, J, p, n (geometric), sh_frame.s/t/n, wi (local), uv
-template <bool LDS>
+template <int LDS>
 __global__ __launch_bounds__(kBlock) void k_intersect(const float4 *__restrict__ blob, const SceneTables T, int n, const float *__restrict__ o,
                                                       const float *__restrict__ d, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
@@ -430,7 +430,8 @@ constexpr unsigned kQueueRing = 1024;
 struct psdr_hip_scene {
     SceneTables T{};
     DevBuf blob;
-    bool lds = false;
+    bool lds = false;                    // scene class 1: staged in LDS (scene_dev.h)
+    bool lean = false;                   // scene class 2: global memory, Diffuse BSDFs + area lights + environment map only
     size_t smem_bytes = 0;
     SecEdgeTables E{};
     std::vector<std::unique_ptr<DevBuf>> bufs;
@@ -739,6 +740,7 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     const size_t blob_bytes = (size_t) T.blob_words * 16;
     // keeps >= 4 workgroups per CU (160 KiB LDS); the environment-map and texture code lives in the LDS=false kernels only (shade.h)
     sc->lds = blob_bytes + stack_bytes <= 40 * 1024 && T.env_emitter < 0 && T.tex == nullptr && T.mat == nullptr && T.pv == nullptr;
+    sc->lean = !sc->lds && T.tex == nullptr && T.mat == nullptr && T.pv == nullptr;
     sc->smem_bytes = (sc->lds ? blob_bytes : 0) + stack_bytes;
     if (sc->smem_bytes > 64 * 1024) return fail("BVH too deep for the LDS traversal stack");
     sc->n_leaves = bvh.n_leaves; sc->max_depth = bvh.max_depth;
@@ -823,6 +825,7 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
     if (rank < 0 || rank >= count) return fail("bad shard rank");
     // the first-hit integrators (field_mode) live in the LDS=false instantiations only
     const bool use_lds = sc->lds && a->field_mode == 0;
+    const int cls = use_lds ? 1 : ((sc->lean && a->field_mode == 0) ? 2 : 0);        // scene class of the kernels (scene_dev.h)
     const int fh_field = a->field_mode - 1;
     if (a->field_mode < 0 || a->field_mode > 9) return fail("bad field_mode");
 
@@ -841,11 +844,13 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
         if (P.n_local > 0) {
             if (next_queue(P.counter)) return 1;
             if (ad) {
-                if (use_lds) LAUNCH((k_paths<true, true, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
-                else LAUNCH((k_paths<true, false, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
+                if (cls == 1) LAUNCH((k_paths<true, 1, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
+                else if (cls == 2) LAUNCH((k_paths<true, 2, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
+                else LAUNCH((k_paths<true, 0, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
             } else {
-                if (use_lds) LAUNCH((k_paths<false, true, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
-                else LAUNCH((k_paths<false, false, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
+                if (cls == 1) LAUNCH((k_paths<false, 1, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
+                else if (cls == 2) LAUNCH((k_paths<false, 2, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
+                else LAUNCH((k_paths<false, 0, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
             }
         }
     }
@@ -857,8 +862,9 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
             P.n_local = local_lanes(P.end, rank, count);
             if (P.n_local > 0) {
                 if (next_queue(P.counter)) return 1;
-                if (use_lds) LAUNCH((k_paths<false, true, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
-                else LAUNCH((k_paths<false, false, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
+                if (cls == 1) LAUNCH((k_paths<false, 1, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
+                else if (cls == 2) LAUNCH((k_paths<false, 2, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
+                else LAUNCH((k_paths<false, 0, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
             }
         }
         if ((terms & PSDR_TERM_SECONDARY) && T.sppse > 0 && sc->E.n > 0) {
@@ -871,8 +877,9 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
             if (a->guiding) G = a->guiding->G;
             if (P.n_local > 0) {
                 if (next_queue(P.counter)) return 1;
-                if (sc->lds) LAUNCH((k_secondary_edges<true, COUNT, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr);
-                else LAUNCH((k_secondary_edges<false, COUNT, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr);
+                if (sc->lds) LAUNCH((k_secondary_edges<1, COUNT, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr);
+                else if (sc->lean) LAUNCH((k_secondary_edges<2, COUNT, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr);
+                else LAUNCH((k_secondary_edges<0, COUNT, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr);
             }
         }
     }
@@ -930,6 +937,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     if (rank < 0 || rank >= count) return fail("bad shard rank");
     // the first-hit integrators (field_mode) live in the LDS=false instantiations only
     const bool use_lds = sc->lds && a->field_mode == 0;
+    const int cls = use_lds ? 1 : ((sc->lean && a->field_mode == 0) ? 2 : 0);        // scene class of the kernels (scene_dev.h)
     const int fh_field = a->field_mode - 1;
     if (a->field_mode < 0 || a->field_mode > 9) return fail("bad field_mode");
     SensorDev cam = sc->sensors[a->sensor_id];
@@ -992,8 +1000,9 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
             if (next_queue(P.counter)) return 1;
             const int grid = grid_for(sc, P.n_local);
             const size_t sm = sc->smem_bytes + (P.lds_acc ? sizeof(float) * 4 * (size_t) cam.n_edges : 0);
-            if (use_lds) hipLaunchKernelGGL((k_paths<false, true, false, 1>), dim3(grid), dim3(kBlock), sm, st, sc->blob.as<float4>(), T, cam, P, (Counters *) nullptr);
-            else hipLaunchKernelGGL((k_paths<false, false, false, 1>), dim3(grid), dim3(kBlock), sm, st, sc->blob.as<float4>(), T, cam, P, (Counters *) nullptr);
+            if (cls == 1) hipLaunchKernelGGL((k_paths<false, 1, false, 1>), dim3(grid), dim3(kBlock), sm, st, sc->blob.as<float4>(), T, cam, P, (Counters *) nullptr);
+            else if (cls == 2) hipLaunchKernelGGL((k_paths<false, 2, false, 1>), dim3(grid), dim3(kBlock), sm, st, sc->blob.as<float4>(), T, cam, P, (Counters *) nullptr);
+            else hipLaunchKernelGGL((k_paths<false, 0, false, 1>), dim3(grid), dim3(kBlock), sm, st, sc->blob.as<float4>(), T, cam, P, (Counters *) nullptr);
         }
     }
     if ((terms & PSDR_TERM_SECONDARY) && T.sppse > 0 && sc->E.n > 0) {

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -72,16 +73,22 @@ inline void build_bvh(const float *p0, const float *e1, const float *e2, int n, 
         for (int i = j.first; i < j.first + j.count; ++i) { box.grow(tb[out.order[i]]); cb.grow(&ctr[3 * (size_t) out.order[i]]); }
         TmpNode nd; nd.box = box; nd.first = j.first; nd.count = j.count;
         if (j.count > kLeafMax || (j.node == 0 && j.count > 1)) {
-            int axis = 0;
-            for (int k = 1; k < 3; ++k) if (cb.hi[k] - cb.lo[k] > cb.hi[axis] - cb.lo[axis]) axis = k;
-            int mid = -1;
-            float ext = cb.hi[axis] - cb.lo[axis];
-            if (ext > 0.f) {
+            // binned SAH over all three axes: the cheapest (left area x count + right area x count) split wins
+            int mid = -1, best_axis = -1, best_split = -1;
+            float best = std::numeric_limits<float>::max();
+            auto bin_of = [&](int t, int axis) {
+                const float ext = cb.hi[axis] - cb.lo[axis];
+                int b = (int) ((ctr[3 * (size_t) t + axis] - cb.lo[axis]) * (kBins / ext));
+                return std::min(std::max(b, 0), kBins - 1);
+            };
+            int widest = 0;
+            for (int k = 1; k < 3; ++k) if (cb.hi[k] - cb.lo[k] > cb.hi[widest] - cb.lo[widest]) widest = k;
+            static const bool all_axes = std::getenv("PSDR_BVH_WIDEST_AXIS") == nullptr;
+            for (int axis = 0; axis < 3; ++axis) {
+                if (!all_axes && axis != widest) continue;
+                if (!(cb.hi[axis] - cb.lo[axis] > 0.f)) continue;
                 Box bb[kBins]; int bc[kBins] = {0};
-                float scale = kBins / ext;
-                auto bin_of = [&](int t) { int b = (int) ((ctr[3 * (size_t) t + axis] - cb.lo[axis]) * scale); return std::min(std::max(b, 0), kBins - 1); };
-                for (int i = j.first; i < j.first + j.count; ++i) { int t = out.order[i]; int b = bin_of(t); bb[b].grow(tb[t]); bc[b]++; }
-                float best = std::numeric_limits<float>::max(); int best_split = -1;
+                for (int i = j.first; i < j.first + j.count; ++i) { int t = out.order[i]; int b = bin_of(t, axis); bb[b].grow(tb[t]); bc[b]++; }
                 Box r[kBins]; int rc[kBins];
                 Box acc; int cnt = 0;
                 for (int b = kBins - 1; b > 0; --b) { acc.grow(bb[b]); cnt += bc[b]; r[b] = acc; rc[b] = cnt; }
@@ -90,13 +97,13 @@ inline void build_bvh(const float *p0, const float *e1, const float *e2, int n, 
                     acc.grow(bb[b]); cnt += bc[b];
                     if (cnt == 0 || rc[b + 1] == 0) continue;
                     float cost = acc.half_area() * cnt + r[b + 1].half_area() * rc[b + 1];
-                    if (cost < best) { best = cost; best_split = b; }
+                    if (cost < best) { best = cost; best_split = b; best_axis = axis; }
                 }
-                if (best_split >= 0) {
-                    auto it = std::stable_partition(out.order.begin() + j.first, out.order.begin() + j.first + j.count,
-                                                    [&](int t) { return bin_of(t) <= best_split; });
-                    mid = (int) (it - out.order.begin());
-                }
+            }
+            if (best_axis >= 0) {
+                auto it = std::stable_partition(out.order.begin() + j.first, out.order.begin() + j.first + j.count,
+                                                [&](int t) { return bin_of(t, best_axis) <= best_split; });
+                mid = (int) (it - out.order.begin());
             }
             if (mid <= j.first || mid >= j.first + j.count) {   // degenerate: split by index
                 mid = j.first + j.count / 2;

@@ -77,7 +77,7 @@ PSDR_DEV int sign_eps(float x, float eps) { return x > eps ? 1 : (x < -eps ? -1 
 PSDR_DEV float sign1(float x) { return signbit_(x) ? -1.f : 1.f; }                          // drjit::sign
 
 // Scene::sample_boundary_segment_direct, reference scene.cpp:1027-1068
-template <bool LDS> PSDR_DEV BoundarySegSampleDirect sample_boundary_segment_direct(const SceneView<LDS> &S, const SecEdgeTables &E, Vec3f s3) {
+template <int LDS> PSDR_DEV BoundarySegSampleDirect sample_boundary_segment_direct(const SceneView<LDS> &S, const SecEdgeTables &E, Vec3f s3) {
     BoundarySegSampleDirect r;
     float sample1 = s3.x, pdf0;
     const int ei = sample_reuse(E.n, E.sum, [&](int i) { return S.ldf(E.cdf_off, i); }, [&](int i) { return S.ldf(E.cdf_off, E.n + i); }, sample1, pdf0);
@@ -108,10 +108,10 @@ template <bool LDS> PSDR_DEV BoundarySegSampleDirect sample_boundary_segment_dir
 // PathTracer::eval_secondary_edge<ad>, reference path.cpp:171-270.
 // AD=true : returns the pixel index (or -1) and the tangent of the estimator in `value`.
 // AD=false: guiding pass, `value` = value0 without the normal velocity (path.cpp:267-268), returns -1.
-template <bool AD, bool LDS, bool COUNT>
+template <bool AD, int LDS, bool COUNT>
 PSDR_DEV int eval_boundary_segment(SceneView<LDS> &S, const SensorDev &cam, const BoundarySegSampleDirect &bss, Vec3f &value, int cam_comp = -1);
 
-template <bool AD, bool LDS, bool COUNT>
+template <bool AD, int LDS, bool COUNT>
 PSDR_DEV int eval_secondary_edge(SceneView<LDS> &S, const SecEdgeTables &E, const SensorDev &cam, const Vec3f &s3, Vec3f &value) {
     value = Vec3f(0.f);
     const BoundarySegSampleDirect bss = sample_boundary_segment_direct<LDS>(S, E, s3);
@@ -120,7 +120,7 @@ PSDR_DEV int eval_secondary_edge(SceneView<LDS> &S, const SecEdgeTables &E, cons
 }
 
 // the traced part of eval_secondary_edge (path.cpp:176-270) for an already sampled, valid boundary segment
-template <bool AD, bool LDS, bool COUNT>
+template <bool AD, int LDS, bool COUNT>
 PSDR_DEV int eval_boundary_segment(SceneView<LDS> &S, const SensorDev &cam, const BoundarySegSampleDirect &bss, Vec3f &value, int cam_comp) {
     value = Vec3f(0.f);
     const SceneTables &T = *S.T;

@@ -46,7 +46,7 @@ constexpr int kFetchBatch = 256;
 #endif
 constexpr int kRegenMin = PSDR_REGEN_MIN;
 
-template <bool AD, bool LDS, bool COUNT, int MODE>
+template <bool AD, int LDS, bool COUNT, int MODE>
 PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParams &P) {
     using R = Num<AD>; using V = VecN<AD>;
     const SceneTables &T = *S.T;
@@ -175,7 +175,7 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
                 // shadow hits only need n, wi.z, t, J - except on the environment map, whose radiance is looked up along
                 // the direction rebuilt from the shading frame (envmap.cpp:47-56)
                 Its<AD> its1 = make_its<AD, LDS, false>(S, h, ray1, true);
-                if constexpr (!LDS) { if (T.env_emitter >= 0 && mesh_emitter(S, its1.mesh) == T.env_emitter) its1 = make_its<AD, LDS, true>(S, h, ray1, true); }
+                if constexpr (has_env(LDS)) { if (T.env_emitter >= 0 && mesh_emitter(S, its1.mesh) == T.env_emitter) its1 = make_its<AD, LDS, true>(S, h, ray1, true); }
                 if ((detach(its1.t) > detach(dist) - kShadowEpsilon) && (mesh_emitter(S, its1.mesh) >= 0)) {
                     const R cos_val = dot(its1.n, -wod);
                     const R G_val = abs_(cos_val) / dist_sqr;
@@ -196,7 +196,7 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
             if (depth < 0) {
                 // first hit: result = Le (path.cpp:38-43)
                 its = itx;
-                if (S.field >= 0) { if constexpr (!LDS) res = first_hit_value<AD, LDS>(S, itx); }
+                if (S.field >= 0) { if constexpr (has_mat(LDS)) res = first_hit_value<AD, LDS>(S, itx); }
                 else if (!P.hide_emitters) res = eval_Le<AD, LDS>(S, itx, itx.valid);
                 depth = 0;
                 finished = !itx.valid || P.max_depth == 0;

@@ -84,12 +84,21 @@ struct SensorDev {
 struct Counters { unsigned long long rays, nodes, tris, hits; };
 
 // per-lane view used by every device function
+// Scene classes (the `LDS` template parameter of every kernel and device function):
+//   0  global memory, every feature (GGX BSDFs, bitmap / per-vertex parameters, first-hit integrators, environment map)
+//   1  small scene staged in LDS: Diffuse BSDFs and area lights only (all Cornell boxes)
+//   2  global memory, lean: Diffuse BSDFs, area lights and the environment map - the BVH scenes of the tutorials and of
+//      BASELINE config 5 do not pay registers for material code they do not use
+constexpr bool in_lds(int cls) { return cls == 1; }
+constexpr bool has_env(int cls) { return cls != 1; }
+constexpr bool has_mat(int cls) { return cls == 0; }
+
 constexpr int kEnvLookup = -1;         // id of an environment-map lookup in the lookup record (BSDF ids are >= 0)
 // a per-vertex BSDF interpolation at triangle slot s is recorded as id = kPvLookup - s, with the barycentrics as (u, v)
 constexpr int kPvLookup = -2;
 constexpr int kAdjMaxLookups = 8;      // bitmap lookups recorded per path (one per textured vertex; max_depth <= 4)
 
-template <bool LDS> struct SceneView {
+template <int LDS> struct SceneView {
     const float4 *B;           // blob base (LDS or global)
     const float4 *G;           // blob base in global memory (wave-uniform reads become scalar loads)
     const SceneTables *T;      // kernel-argument copy
@@ -178,9 +187,9 @@ PSDR_DEV bool tri_test(const float4 &a, const float4 &b, const float4 &c, const 
 
 // Closest hit in (RayEpsilon, 1e8), ties -> smallest original triangle id
 // (replaces jit_optix_ray_trace, reference scene_optix.cpp:343-410; NaN rays miss, :348-353).
-template <bool LDS, bool COUNT> PSDR_DEV Hit trace_scene(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d);
+template <int LDS, bool COUNT> PSDR_DEV Hit trace_scene(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d);
 
-template <bool LDS, bool COUNT>
+template <int LDS, bool COUNT>
 PSDR_DEV Hit trace(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
     if (S.mode == 2) {                       // replay: pop the hit the recording run found for this ray
         Hit h; h.slot = -1; h.u = h.v = h.t = 0.f;
@@ -206,7 +215,7 @@ PSDR_DEV Hit trace(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
 // single lane was at a leaf) with a per-lane ray queue: a lane that finishes its first ray starts its second one in the
 // next round instead of idling until the whole wave has finished the first pass (config 5 measured 13 % of the lanes
 // active per VALU instruction with one pass per ray).  Each ray sees the same nodes, tests and (t, id) order as alone.
-template <bool LDS, bool COUNT>
+template <int LDS, bool COUNT>
 PSDR_DEV void bvh_trace2(SceneView<LDS> &S, const Vec3f &oA, const Vec3f &dA, bool actA, const Vec3f &oB, const Vec3f &dB, bool actB,
                          Hit &hA, Hit &hB) {
     const SceneTables &T = *S.T;
@@ -280,7 +289,7 @@ PSDR_DEV void bvh_trace2(SceneView<LDS> &S, const Vec3f &oA, const Vec3f &dA, bo
     }
 }
 
-template <bool LDS, bool COUNT>
+template <int LDS, bool COUNT>
 PSDR_DEV Hit trace_scene(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
     Hit best; best.slot = -1; best.u = best.v = 0.f; best.t = 0.f;
     if (!(o.x == o.x && o.y == o.y && o.z == o.z && d.x == d.x && d.y == d.y && d.z == d.z)) return best;
@@ -350,7 +359,7 @@ PSDR_DEV Hit trace_scene(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
 // independent dependency chains fill each other's latency slots; every ray still sees exactly tri_test's
 // arithmetic and the (t, id) order, so the hits equal two trace() calls.  Inactive rays are given a NaN origin,
 // which fails every comparison.  BVH scenes and the record/replay modes trace the rays one after the other.
-template <bool LDS, bool COUNT>
+template <int LDS, bool COUNT>
 PSDR_DEV void trace2(SceneView<LDS> &S, const Vec3f &oA_, const Vec3f &dA, bool actA, const Vec3f &oB_, const Vec3f &dB, bool actB,
                      Hit &hA, Hit &hB) {
     hA.slot = -1; hA.u = hA.v = hA.t = 0.f;

@@ -39,14 +39,14 @@ template <typename T> PSDR_DEV void coordinate_system(const Vec3<T> &n, Vec3<T> 
     t = Vec3<T>(b, T(sg) + sqr(n.y) * a, -n.y);
 }
 
-template <bool AD, bool LDS> struct TriData { VecN<AD> p0, e1, e2; };
+template <bool AD, int LDS> struct TriData { VecN<AD> p0, e1, e2; };
 
-template <bool AD, bool LDS> PSDR_DEV VecN<AD> pick3(const Vec3f &v, const Vec3f &d) {
+template <bool AD, int LDS> PSDR_DEV VecN<AD> pick3(const Vec3f &v, const Vec3f &d) {
     if constexpr (AD) return make_dual(v, d); else return v;
 }
 
 // load p0,e1,e2 (+tangents) of a triangle slot
-template <bool AD, bool LDS> PSDR_DEV void load_geom(const SceneView<LDS> &S, int slot, VecN<AD> &p0, VecN<AD> &e1, VecN<AD> &e2) {
+template <bool AD, int LDS> PSDR_DEV void load_geom(const SceneView<LDS> &S, int slot, VecN<AD> &p0, VecN<AD> &e1, VecN<AD> &e2) {
     const SceneTables &T = *S.T;
     const int w = T.trav_off + 3 * slot;
     const float4 a = S.ld(w), b = S.ld(w + 1), c = S.ld(w + 2);
@@ -74,7 +74,7 @@ template <typename T> PSDR_DEV void ray_tri_uvt(const Vec3<T> &p0, const Vec3<T>
 // `path_space` is a run-time flag so that lanes at different path depths can share one instruction stream
 // (it only matters in AD mode: first camera hit = solid-angle form, later hits = material form).
 // FRAME=false skips the tangent frame (shadow rays only need n, wi.z, t, J).
-template <bool AD, bool LDS, bool FRAME>
+template <bool AD, int LDS, bool FRAME>
 PSDR_DEV Its<AD> make_its(const SceneView<LDS> &S, const Hit &h, const RayT<AD> &ray, bool path_space) {
     using R = Num<AD>; using V = VecN<AD>;
     Its<AD> its;
@@ -130,13 +130,13 @@ PSDR_DEV Its<AD> make_its(const SceneView<LDS> &S, const Hit &h, const RayT<AD> 
         // tangent frame from the uv parameterisation when it is non-degenerate (scene.cpp:724-766)
         const float4 s4 = S.ld(w + 4), s5 = S.ld(w + 5);
         const float du0x = s4.z - s4.x, du0y = s4.w - s4.y, du1x = s5.x - s4.x, du1y = s5.y - s4.y;
-        if constexpr (!LDS) {              // its.uv = bilinear2(uv0, uv1 - uv0, uv2 - uv0, barycentrics), scene.cpp:715/779
+        if constexpr (has_mat(LDS)) {              // its.uv = bilinear2(uv0, uv1 - uv0, uv2 - uv0, barycentrics), scene.cpp:715/779
             if (T.tex != nullptr || S.field == 5) {
                 its.tu = fma_(R(du0x), u, fma_(R(du1x), v, R(s4.x)));
                 its.tv = fma_(R(du0y), u, fma_(R(du1y), v, R(s4.y)));
             }
         }
-        if constexpr (!LDS) if (T.pv != nullptr) { its.bu = u; its.bv = v; }
+        if constexpr (has_mat(LDS)) if (T.pv != nullptr) { its.bu = u; its.bv = v; }
         const float det = fma_(du0x, du1y, -(du0y * du1x));
         if (det != 0.f) {
             const float inv_det = 1.f / det;
@@ -152,7 +152,7 @@ PSDR_DEV Its<AD> make_its(const SceneView<LDS> &S, const Hit &h, const RayT<AD> 
 }
 
 // Scene::ray_intersect<ad, path_space>, reference src/scene/scene.cpp:612-806
-template <bool AD, bool PATH_SPACE, bool LDS, bool COUNT, bool FRAME = true>
+template <bool AD, bool PATH_SPACE, int LDS, bool COUNT, bool FRAME = true>
 PSDR_DEV Its<AD> ray_intersect(SceneView<LDS> &S, const RayT<AD> &ray, bool active) {
     static_assert(AD || !PATH_SPACE, "path-space needs AD");
     Hit h; h.slot = -1; h.u = h.v = h.t = 0.f;
@@ -163,7 +163,7 @@ PSDR_DEV Its<AD> ray_intersect(SceneView<LDS> &S, const RayT<AD> &ray, bool acti
 
 // ---------------------------------------------------------------- records from the blob
 struct MeshRec { int bsdf, emitter, face_offset, n_faces; float inv_total_area; int distrb_offset; float distrb_sum; };
-template <bool LDS> PSDR_DEV MeshRec load_mesh(const SceneView<LDS> &S, int mesh) {
+template <int LDS> PSDR_DEV MeshRec load_mesh(const SceneView<LDS> &S, int mesh) {
     const int w = S.T->mesh_off + 2 * mesh;
     const float4 a = S.ld(w), b = S.ld(w + 1);
     MeshRec m;
@@ -171,8 +171,8 @@ template <bool LDS> PSDR_DEV MeshRec load_mesh(const SceneView<LDS> &S, int mesh
     m.inv_total_area = b.x; m.distrb_offset = __float_as_int(b.y); m.distrb_sum = b.z;
     return m;
 }
-template <bool LDS> PSDR_DEV int mesh_emitter(const SceneView<LDS> &S, int mesh) { return __float_as_int(S.ld(S.T->mesh_off + 2 * mesh).y); }
-template <bool LDS> PSDR_DEV int mesh_bsdf(const SceneView<LDS> &S, int mesh) { return __float_as_int(S.ld(S.T->mesh_off + 2 * mesh).x); }
+template <int LDS> PSDR_DEV int mesh_emitter(const SceneView<LDS> &S, int mesh) { return __float_as_int(S.ld(S.T->mesh_off + 2 * mesh).y); }
+template <int LDS> PSDR_DEV int mesh_bsdf(const SceneView<LDS> &S, int mesh) { return __float_as_int(S.ld(S.T->mesh_off + 2 * mesh).x); }
 
 // DiscreteDistribution::sample_reuse, reference src/core/pmf.cpp:26-45 (size 1 leaves the sample untouched)
 template <typename PmfFn, typename CmfFn>
@@ -211,7 +211,7 @@ PSDR_DEV Dual env_floor(const Dual &a) { return Dual(floorf(a.v), 0.f); }
 // (scene_dev.h: id kEnvLookup), which yields the texel and scale adjoints.
 // The environment-map branches exist only in the LDS=false instantiations: a scene with an environment map is never
 // staged into LDS (api.hip), so the small-scene kernels (all Cornell boxes) carry none of this code or its registers.
-template <bool AD, bool LDS> PSDR_DEV VecN<AD> env_eval_direction(const SceneView<LDS> &S, const EnvDev &E, const VecN<AD> &wi) {
+template <bool AD, int LDS> PSDR_DEV VecN<AD> env_eval_direction(const SceneView<LDS> &S, const EnvDev &E, const VecN<AD> &wi) {
     using R = Num<AD>;
     VecN<AD> v;
     if constexpr (AD) {
@@ -283,12 +283,12 @@ PSDR_DEV void env_sample_position(const EnvDev &E, const Vec3f &ref_p, float sx,
 
 // ---------------------------------------------------------------- emitters
 // Intersection::Le -> AreaLight::eval, reference intersection.h:35-42, area.cpp:17-26
-template <bool AD, bool LDS> PSDR_DEV VecN<AD> eval_Le(const SceneView<LDS> &S, const Its<AD> &its, bool active) {
+template <bool AD, int LDS> PSDR_DEV VecN<AD> eval_Le(const SceneView<LDS> &S, const Its<AD> &its, bool active) {
     using V = VecN<AD>;
     if (!active || !its.valid) return V(Num<AD>(0.f));
     const int e = mesh_emitter(S, its.mesh);
     if (e < 0) return V(Num<AD>(0.f));
-    if constexpr (!LDS) {
+    if constexpr (has_env(LDS)) {
         if (e == S.T->env_emitter) {           // EnvironmentMap::eval, envmap.cpp:47-56
             V wi_world;
             if constexpr (AD) wi_world = to_world_d(its, its.wi); else wi_world = to_world<false>(its, its.wi);
@@ -306,7 +306,7 @@ template <bool AD> struct PositionSample { VecN<AD> p, n; Num<AD> J; float pdf; 
 
 // Scene::sample_emitter_position -> AreaLight::sample_position -> Mesh::__sample_position
 // reference scene.cpp:987-1013, mesh.cpp:413-454, warp.h:79-82
-template <bool AD, bool LDS> PSDR_DEV PositionSample<AD> sample_emitter_position(const SceneView<LDS> &S, const Vec3f &ref_p, float sx, float sy) {
+template <bool AD, int LDS> PSDR_DEV PositionSample<AD> sample_emitter_position(const SceneView<LDS> &S, const Vec3f &ref_p, float sx, float sy) {
     const SceneTables &T = *S.T;
     float epdf = 1.f;
     int ei = 0;
@@ -315,7 +315,7 @@ template <bool AD, bool LDS> PSDR_DEV PositionSample<AD> sample_emitter_position
                           [&](int i) { return S.ldf(T.ecdf_off, i); },
                           [&](int i) { return S.ldf(T.ecdf_off, T.n_emitters + i); }, sy, epdf);
     }
-    if (!LDS && ei == T.env_emitter) {
+    if (has_env(LDS) && ei == T.env_emitter) {
         Vec3f p, nn;
         float pdf_env;
         env_sample_position(T.env, ref_p, sx, sy, p, nn, pdf_env);
@@ -355,35 +355,35 @@ template <bool AD, bool LDS> PSDR_DEV PositionSample<AD> sample_emitter_position
 }
 
 // Scene::emitter_position_pdf, reference scene.cpp:1016-1024 -> area.cpp:48-59 -> mesh.cpp:457-466
-template <bool AD, bool LDS> PSDR_DEV float emitter_position_pdf(const SceneView<LDS> &S, const Vec3f &ref_p, const Its<AD> &its) {
+template <bool AD, int LDS> PSDR_DEV float emitter_position_pdf(const SceneView<LDS> &S, const Vec3f &ref_p, const Its<AD> &its) {
     if (!its.valid) return 0.f;
     const MeshRec m = load_mesh(S, its.mesh);
     if (m.emitter < 0) return 0.f;
-    if (!LDS && m.emitter == S.T->env_emitter) return env_position_pdf(S.T->env, ref_p, detach(its.p), detach(its.n));
+    if (has_env(LDS) && m.emitter == S.T->env_emitter) return env_position_pdf(S.T->env, ref_p, detach(its.p), detach(its.n));
     return S.ld(S.T->emit_off + 2 * m.emitter).w * m.inv_total_area;
 }
 
 // ---------------------------------------------------------------- Diffuse BSDF, reference src/bsdf/diffuse.cpp:24-108
 // MicrofacetPerVertex::__interpolate<1> of the roughness, detached (microfacet_pv.cpp:89,127)
-template <bool AD, bool LDS> PSDR_DEV float pv_roughness(const SceneView<LDS> &S, int id, const Its<AD> &its) {
+template <bool AD, int LDS> PSDR_DEV float pv_roughness(const SceneView<LDS> &S, int id, const Its<AD> &its) {
     const PvDev pv = S.T->pv[id];
     const int *fi = S.T->tri_fi + 3 * its.slot;
     const float v0 = pv.rough[fi[0]], v1 = pv.rough[fi[1]], v2 = pv.rough[fi[2]];
     return fma_(v1 - v0, detach(its.bu), fma_(v2 - v0, detach(its.bv), v0));
 }
 // Microfacet::m_roughness as a bitmap, detached (microfacet.cpp:88,117)
-template <bool AD, bool LDS> PSDR_DEV float roughness_lookup(const SceneView<LDS> &S, int id, const Its<AD> &its) {
+template <bool AD, int LDS> PSDR_DEV float roughness_lookup(const SceneView<LDS> &S, int id, const Its<AD> &its) {
     const TexDev td = S.T->tex[3 * id + 2];
     float o[1];
     env::bitmap_eval_tex<float, 1>([&](int i, int) { return td.data[i]; }, td.w, td.h, detach(its.tu), detach(its.tv), true, o);
     return o[0];
 }
-template <bool AD, bool LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S, const Its<AD> &its, VecN<AD> wo, bool active) {
+template <bool AD, int LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S, const Its<AD> &its, VecN<AD> wo, bool active) {
     using R = Num<AD>; using V = VecN<AD>;
     if (mesh_bsdf(S, its.mesh) < 0) return V(R(0.f));          // the envmap's bounding cube has no BSDF (null vcall = zeros)
     const int w = S.T->bsdf_off + 2 * mesh_bsdf(S, its.mesh);
     const float4 a = S.ld(w);
-    if constexpr (!LDS) {
+    if constexpr (has_mat(LDS)) {
         if (__float_as_int(a.w) & 4) {         // Microfacet (microfacet.cpp); its diffuse reflectance is the record's colour
             const int id = mesh_bsdf(S, its.mesh);
             const MatDev md = S.T->mat[id];
@@ -463,7 +463,7 @@ template <bool AD, bool LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S
             }
         }
     }
-    if constexpr (!LDS) {
+    if constexpr (has_mat(LDS)) {
         if (__float_as_int(a.w) & 16) {        // RoughDielectric (roughdielectric.cpp): eta[0] = intIOR/extIOR, eta[1] = extIOR/intIOR
             const MatDev md = S.T->mat[mesh_bsdf(S, its.mesh)];
             const bool two = (__float_as_int(a.w) & 1) != 0;
@@ -486,7 +486,7 @@ template <bool AD, bool LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S
     if (!(active && detach(wiz) > 0.f && detach(wo.z) > 0.f)) return V(R(0.f));
     V refl;
     bool textured = false;
-    if constexpr (!LDS) {
+    if constexpr (has_mat(LDS)) {
         if (__float_as_int(a.w) & 2) {         // Bitmap3fD reflectance, diffuse.cpp:38 -> bitmap.cpp:47-128 (flip_v)
             textured = true;
             const TexDev td = S.T->tex[3 * mesh_bsdf(S, its.mesh)];
@@ -510,10 +510,10 @@ template <bool AD, bool LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S
     }
     return refl * R(kInvPi) * wo.z;
 }
-template <bool AD, bool LDS> PSDR_DEV float bsdf_pdf(const SceneView<LDS> &S, const Its<AD> &its, const VecN<AD> &wo, bool active) {
+template <bool AD, int LDS> PSDR_DEV float bsdf_pdf(const SceneView<LDS> &S, const Its<AD> &its, const VecN<AD> &wo, bool active) {
     if (mesh_bsdf(S, its.mesh) < 0) return 0.f;
     const float4 a = S.ld(S.T->bsdf_off + 2 * mesh_bsdf(S, its.mesh));
-    if constexpr (!LDS) {
+    if constexpr (has_mat(LDS)) {
         if (__float_as_int(a.w) & 128) {
             const float r = pv_roughness(S, mesh_bsdf(S, its.mesh), its);
             return ggx_pdf(sqr(r), sqr(r), (__float_as_int(a.w) & 1) != 0, detach(its.wi), detach(wo), active);
@@ -568,11 +568,11 @@ PSDR_DEV Vec3f square_to_cosine_hemisphere(float sx, float sy) {
     return Vec3f(px, py, safe_sqrt(1.f - fma_(py, py, px * px)));
 }
 struct BSDFSample { Vec3f wo; float pdf; bool valid; };
-template <bool AD, bool LDS> PSDR_DEV BSDFSample bsdf_sample(const SceneView<LDS> &S, const Its<AD> &its, float s0, float s1, float s2, bool active) {
+template <bool AD, int LDS> PSDR_DEV BSDFSample bsdf_sample(const SceneView<LDS> &S, const Its<AD> &its, float s0, float s1, float s2, bool active) {
     (void) s0;
     if (mesh_bsdf(S, its.mesh) < 0) { BSDFSample z; z.wo = Vec3f(0.f, 0.f, 0.f); z.pdf = 0.f; z.valid = false; return z; }
     const float4 a = S.ld(S.T->bsdf_off + 2 * mesh_bsdf(S, its.mesh));
-    if constexpr (!LDS) {
+    if constexpr (has_mat(LDS)) {
         if (__float_as_int(a.w) & 128) {       // MicrofacetPerVertex::__sample (microfacet_pv.cpp:80-103)
             BSDFSample m;
             const float r = pv_roughness(S, mesh_bsdf(S, its.mesh), its);
@@ -606,7 +606,7 @@ template <bool AD, bool LDS> PSDR_DEV BSDFSample bsdf_sample(const SceneView<LDS
 
 // FieldExtractionIntegrator::__Li (reference src/integrator/field.cpp:49-121) and CollocatedIntegrator::__Li
 // (src/integrator/collocated.cpp:24-55): a function of the first hit only.  LDS=false instantiations only.
-template <bool AD, bool LDS> PSDR_DEV VecN<AD> first_hit_value(const SceneView<LDS> &S, const Its<AD> &its) {
+template <bool AD, int LDS> PSDR_DEV VecN<AD> first_hit_value(const SceneView<LDS> &S, const Its<AD> &its) {
     using R = Num<AD>; using V = VecN<AD>;
     bool ok = its.valid;
     if (S.T->env_emitter >= 0 && S.field != 8) ok = ok && mesh_bsdf(S, its.mesh) >= 0;        // field.cpp:55-58
@@ -632,13 +632,13 @@ PSDR_DEV float mis_weight(float p1, float p2) { const float w1 = p1 * p1, w2 = p
 
 // ---------------------------------------------------------------- PathTracer::__Li, reference src/integrator/path.cpp:35-127
 // Consumes exactly 5*max_depth draws of `rng` whatever the path does (the reference draws for masked lanes too).
-template <bool AD, bool LDS, bool COUNT>
+template <bool AD, int LDS, bool COUNT>
 PSDR_DEV VecN<AD> Li(SceneView<LDS> &S, LaneRng &rng, const RayT<AD> &ray_in, bool active, int max_depth, bool hide_emitters) {
     using R = Num<AD>; using V = VecN<AD>;
     Its<AD> its = ray_intersect<AD, false, LDS, COUNT>(S, ray_in, active);
     active = active && its.valid;
     V throughput(R(1.f));
-    if (S.field >= 0) { if constexpr (!LDS) return first_hit_value<AD, LDS>(S, its); else return V(R(0.f)); }
+    if (S.field >= 0) { if constexpr (has_mat(LDS)) return first_hit_value<AD, LDS>(S, its); else return V(R(0.f)); }
     V result = hide_emitters ? V(R(0.f)) : eval_Le<AD, LDS>(S, its, active);
     // DirectIntegrator(mis) (reference direct.cpp:34-132) is one pass of the same body: mis = 0 draws and uses only the emitter
     // sample (weight 1), mis = 1 only the BSDF sample (weight 1), mis = 2 both with MIS
