@@ -89,7 +89,10 @@ template <int LDS> PSDR_DEV float *scratch_base(float4 *smem, const SceneTables 
 // ------------------------------------------------------------------------------------------------
 // interior term (MODE 0) and primary-edge term (MODE 1): persistent lanes with path regeneration, paths.h
 template <bool AD, int LDS, bool COUNT, int MODE>
-__global__ __launch_bounds__(kBlock, (AD ? 3 : 4)) void k_paths(const float4 *__restrict__ blob, const SceneTables T, const SensorDev cam,
+#ifndef PSDR_GLOBAL_C_WAVES
+#define PSDR_GLOBAL_C_WAVES 4
+#endif
+__global__ __launch_bounds__(kBlock, (AD ? 3 : (in_lds(LDS) ? 4 : PSDR_GLOBAL_C_WAVES))) void k_paths(const float4 *__restrict__ blob, const SceneTables T, const SensorDev cam,
                                                   const PathParams P, Counters *ctr) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     SceneView<LDS> S = make_view<LDS>(blob, T, smem);
