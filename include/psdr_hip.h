@@ -57,7 +57,7 @@ typedef struct psdr_mesh_rec {       /* what the kernels need of reference Mesh 
 } psdr_mesh_rec;
 
 typedef struct psdr_bsdf_rec {       /* Diffuse, reference src/bsdf/diffuse.cpp */
-    int32_t type;                    /* 0 = Diffuse, 1 = Microfacet, 2 = RoughConductor, 3 = RoughDielectric, 4 = MicrofacetPerVertex */
+    int32_t type;                    /* 0 = Diffuse, 1 = Microfacet, 2 = RoughConductor, 3 = RoughDielectric, 4 = MicrofacetPerVertex, 5 = NormalMap */
     int32_t two_sided;
     float reflectance[3], d_reflectance[3];
     /* textured reflectance: Bitmap3fD with a resolution above 1x1 (bitmap.cpp:47-128, looked up at its.uv with flip_v);
@@ -84,6 +84,10 @@ typedef struct psdr_bsdf_rec {       /* Diffuse, reference src/bsdf/diffuse.cpp 
     int32_t pv_count;
     const float *pv_specular, *pv_diffuse, *pv_roughness;          /* [n*3], [n*3], [n] */
     const float *d_pv_specular, *d_pv_diffuse, *d_pv_roughness;    /* forward tangents, may be NULL */
+    /* type 5 = NormalMap (src/bsdf/normalmap.cpp): `reflectance` / tex_data = the normal map (rgb in [0, 1], looked up at its.uv),
+     * nested_bsdf = index in psdr_scene_snapshot.bsdfs of the BSDF it perturbs (any type but NormalMap; the host may append the
+     * nested BSDF as an extra entry no mesh refers to) */
+    int32_t nested_bsdf;
 } psdr_bsdf_rec;
 
 typedef struct psdr_emitter_rec {    /* AreaLight (src/emitter/area.cpp) or EnvironmentMap (src/emitter/envmap.cpp) */

@@ -37,7 +37,7 @@ typedef struct orc_mesh {            /* reference Mesh, include/psdr/shape/mesh.
 } orc_mesh;
 
 typedef struct orc_bsdf {            /* Diffuse, include/psdr/bsdf/diffuse.h */
-    int type;                        /* 0 = Diffuse, 1 = Microfacet, 2 = RoughConductor, 3 = RoughDielectric (alpha_u/v; eta[0] = intIOR/extIOR, eta[1] = extIOR/intIOR) */
+    int type;                        /* 0 = Diffuse, 1 = Microfacet, 2 = RoughConductor, 3 = RoughDielectric (alpha_u/v; eta[0] = intIOR/extIOR, eta[1] = extIOR/intIOR), 4 = MicrofacetPerVertex, 5 = NormalMap */
     float reflectance[3], d_reflectance[3];
     int two_sided;
     /* textured reflectance (Bitmap3fD with resolution > 1x1, bitmap.cpp:47-128): tex_data != NULL overrides `reflectance` */
@@ -60,6 +60,9 @@ typedef struct orc_bsdf {            /* Diffuse, include/psdr/bsdf/diffuse.h */
     int pv_count;
     const float *pv_specular, *pv_diffuse, *pv_roughness;          /* [n*3], [n*3], [n] */
     const float *d_pv_specular, *d_pv_diffuse, *d_pv_roughness;    /* optional tangents */
+    /* type 5 = NormalMap (src/bsdf/normalmap.cpp): reflectance / tex_data = the normal map (rgb in [0,1]), nested_bsdf = index of the
+     * BSDF it perturbs (any type but NormalMap) */
+    int nested_bsdf;
 } orc_bsdf;
 
 typedef struct orc_emitter {         /* AreaLight (include/psdr/emitter/area.h) or EnvironmentMap (emitter/envmap.h) */

@@ -90,6 +90,7 @@ class BsdfSpec:
     d_pv_specular: Optional[np.ndarray] = None
     d_pv_diffuse: Optional[np.ndarray] = None
     d_pv_roughness: Optional[np.ndarray] = None
+    nested: int = -1                            # type 5 = NormalMapBSDF: index of the nested BSDF; `reflectance` / `texture` = the normal map
 
 
 @dataclass
@@ -158,7 +159,8 @@ class _Bsdf(C.Structure):
                 ("spec_tex_width", C.c_int), ("spec_tex_height", C.c_int), ("spec_tex_data", C.POINTER(C.c_float)), ("d_spec_tex_data", C.POINTER(C.c_float)),
                 ("rough_tex_width", C.c_int), ("rough_tex_height", C.c_int), ("rough_tex_data", C.POINTER(C.c_float)), ("d_rough_tex_data", C.POINTER(C.c_float)),
                 ("pv_count", C.c_int), ("pv_specular", C.POINTER(C.c_float)), ("pv_diffuse", C.POINTER(C.c_float)), ("pv_roughness", C.POINTER(C.c_float)),
-                ("d_pv_specular", C.POINTER(C.c_float)), ("d_pv_diffuse", C.POINTER(C.c_float)), ("d_pv_roughness", C.POINTER(C.c_float))]
+                ("d_pv_specular", C.POINTER(C.c_float)), ("d_pv_diffuse", C.POINTER(C.c_float)), ("d_pv_roughness", C.POINTER(C.c_float)),
+                ("nested_bsdf", C.c_int)]
 
 
 class _Emitter(C.Structure):
@@ -296,6 +298,7 @@ class OracleScene:
         bsdfs = (_Bsdf * max(1, len(spec.bsdfs)))()
         for i, b in enumerate(spec.bsdfs):
             bsdfs[i].type = int(getattr(b, "type", 0))
+            bsdfs[i].nested_bsdf = int(getattr(b, "nested", -1))
             bsdfs[i].specular = _F3(*getattr(b, "specular", (0.04, 0.04, 0.04)))
             bsdfs[i].d_specular = _F3(*getattr(b, "d_specular", (0.0, 0.0, 0.0)))
             bsdfs[i].roughness = float(getattr(b, "roughness", 0.5))

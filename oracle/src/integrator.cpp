@@ -217,6 +217,7 @@ Its<ad> ray_intersect(const Scene &sc, const Ray<ad> &ray, bool active, int *out
     if (valid_dp) {
         // dp_du = fmsub(duv1.y, dp0, duv0.y*dp1) * inv_det   (scene.cpp:762)
         V dp_du = (e1 * R(duv1.y) - e2 * R(duv0.y)) * R(inv_det);
+        its.dp_du = dp_du;
         its.sh.s = normalize(dp_du - sh_n * dot(sh_n, dp_du));
         its.sh.t = cross(sh_n, its.sh.s);
     }
@@ -345,94 +346,197 @@ template <bool ad> static V3d pv_interp3(const std::vector<float> &v, const std:
 
 // ---------------------------------------------------------------- Diffuse BSDF (diffuse.cpp:24-108)
 // a mesh without BSDF (the envmap's bounding cube): drjit's vcall on a null pointer returns zeros
-template <bool ad> static V3<Real<ad>> bsdf_eval(const Scene &sc, const Its<ad> &its, V3<Real<ad>> wo, bool active) {
+// (bid, wi) are explicit so that NormalMap can evaluate its nested BSDF with a perturbed incident direction
+template <bool ad> static V3<Real<ad>> bsdf_eval_id(const Scene &sc, int bid, const Its<ad> &its, const V3<Real<ad>> &wi_, V3<Real<ad>> wo, bool active) {
     using R = Real<ad>; using V = V3<R>;
-    if (sc.meshes[its.mesh].bsdf < 0) return V(R(0.f));
-    const BsdfC &b = sc.bsdfs[sc.meshes[its.mesh].bsdf];
+    if (bid < 0) return V(R(0.f));
+    const BsdfC &b = sc.bsdfs[bid];
     if (b.type == 1) {          // Microfacet (microfacet.cpp); its diffuse reflectance is b.reflectance
         V3d diff = b.reflectance;
         if (b.tex_w != 0) { const V3<R> t = bsdf_reflectance<ad>(b, its.uv); diff = V3d(Dual(t.x), Dual(t.y), Dual(t.z)); }
         MicrofacetParams P{bsdf_specular<ad>(b, its.uv), diff, bsdf_roughness<ad>(b, its.uv), b.two_sided};
-        return microfacet_eval<ad>(P, its.wi, wo, active);
+        return microfacet_eval<ad>(P, wi_, wo, active);
     }
     if (b.type == 2) {          // RoughConductor (roughconductor.cpp)
         ConductorParams P{b.alpha_u, b.alpha_v, b.eta, b.k, b.specular, b.two_sided};
-        return conductor_eval<ad>(P, its.wi, wo, active);
+        return conductor_eval<ad>(P, wi_, wo, active);
     }
     if (b.type == 4) {          // MicrofacetPerVertex (microfacet_pv.cpp): parameters interpolated over the hit triangle's vertices
         MicrofacetParams P{pv_interp3<ad>(b.pv_spec, b.d_pv_spec, sc.tris[its.tri].fi, its.bc), pv_interp3<ad>(b.pv_diff, b.d_pv_diff, sc.tris[its.tri].fi, its.bc),
                            pv_interp1<ad>(b.pv_rough, b.d_pv_rough, sc.tris[its.tri].fi, its.bc), b.two_sided};
-        return microfacet_pv_eval<ad>(P, its.wi, wo, active);
+        return microfacet_pv_eval<ad>(P, wi_, wo, active);
     }
     if (b.type == 3) {          // RoughDielectric (roughdielectric.cpp); eta.x = intIOR / extIOR, eta.y = extIOR / intIOR
         DielectricParams P{b.alpha_u, b.alpha_v, b.eta.x, b.eta.y, b.two_sided};
-        return dielectric_eval<ad>(P, its.wi, wo, active);
+        return dielectric_eval<ad>(P, wi_, wo, active);
     }
-    R wiz = its.wi.z;
+    R wiz = wi_.z;
     if (b.two_sided) { wo.z = mulsign(wo.z, detach(wiz)); wiz = abs_(wiz); }
     active = active && (detach(wiz) > 0.f && detach(wo.z) > 0.f);
     if (!active) return V(R(0.f));
     return bsdf_reflectance<ad>(b, its.uv) * R(InvPi) * wo.z;
 }
-template <bool ad> static float bsdf_pdf(const Scene &sc, const Its<ad> &its, const V3<Real<ad>> &wo_, bool active) {
-    if (sc.meshes[its.mesh].bsdf < 0) return 0.f;
-    const BsdfC &b = sc.bsdfs[sc.meshes[its.mesh].bsdf];
+template <bool ad> static float bsdf_pdf_id(const Scene &sc, int bid, const Its<ad> &its, const V3<Real<ad>> &wi_, const V3<Real<ad>> &wo_, bool active) {
+    if (bid < 0) return 0.f;
+    const BsdfC &b = sc.bsdfs[bid];
     if (b.type == 1) {
         MicrofacetParams P{b.specular, b.reflectance, bsdf_roughness<ad>(b, its.uv), b.two_sided};
-        return microfacet_pdf(P, detach(its.wi), detach(wo_), active);
+        return microfacet_pdf(P, detach(wi_), detach(wo_), active);
     }
     if (b.type == 2) {
         ConductorParams P{b.alpha_u, b.alpha_v, b.eta, b.k, b.specular, b.two_sided};
-        return conductor_pdf(P, detach(its.wi), detach(wo_), active);
+        return conductor_pdf(P, detach(wi_), detach(wo_), active);
     }
     if (b.type == 4) {
         MicrofacetParams P{b.specular, b.reflectance, pv_interp1<ad>(b.pv_rough, b.d_pv_rough, sc.tris[its.tri].fi, its.bc), b.two_sided};
-        return microfacet_pdf(P, detach(its.wi), detach(wo_), active);
+        return microfacet_pdf(P, detach(wi_), detach(wo_), active);
     }
     if (b.type == 3) {
         DielectricParams P{b.alpha_u, b.alpha_v, b.eta.x, b.eta.y, b.two_sided};
-        return dielectric_pdf(P, detach(its.wi), detach(wo_), active);
+        return dielectric_pdf(P, detach(wi_), detach(wo_), active);
     }
-    float wiz = detach(its.wi.z), woz = detach(wo_.z);
+    float wiz = detach(wi_.z), woz = detach(wo_.z);
     if (b.two_sided) { woz = mulsign(woz, wiz); wiz = fabs(wiz); }
     active = active && (wiz > 0.f && woz > 0.f);
     return active ? InvPi * woz : 0.f;
 }
 struct BSDFSample { V3f wo; float pdf; bool valid; };
-template <bool ad> static BSDFSample bsdf_sample(const Scene &sc, const Its<ad> &its, const float s3[3], bool active) {
-    if (sc.meshes[its.mesh].bsdf < 0) { BSDFSample z; z.wo = V3f(0.f, 0.f, 0.f); z.pdf = 0.f; z.valid = false; return z; }
-    const BsdfC &b = sc.bsdfs[sc.meshes[its.mesh].bsdf];
+template <bool ad> static BSDFSample bsdf_sample_id(const Scene &sc, int bid, const Its<ad> &its, const V3<Real<ad>> &wi_, const float s3[3], bool active) {
+    if (bid < 0) { BSDFSample z; z.wo = V3f(0.f, 0.f, 0.f); z.pdf = 0.f; z.valid = false; return z; }
+    const BsdfC &b = sc.bsdfs[bid];
     if (b.type == 1) {
         MicrofacetParams P{b.specular, b.reflectance, bsdf_roughness<ad>(b, its.uv), b.two_sided};
-        const MicrofacetSample m = microfacet_sample(P, detach(its.wi), s3, active);
+        const MicrofacetSample m = microfacet_sample(P, detach(wi_), s3, active);
         BSDFSample r; r.wo = m.wo; r.pdf = m.pdf; r.valid = m.valid;
         return r;
     }
     if (b.type == 4) {
         MicrofacetParams P{b.specular, b.reflectance, pv_interp1<ad>(b.pv_rough, b.d_pv_rough, sc.tris[its.tri].fi, its.bc), b.two_sided};
-        const MicrofacetSample m = microfacet_sample(P, detach(its.wi), s3, active);
+        const MicrofacetSample m = microfacet_sample(P, detach(wi_), s3, active);
         BSDFSample r; r.wo = m.wo; r.pdf = m.pdf; r.valid = m.valid;
         return r;
     }
     if (b.type == 2) {
         ConductorParams P{b.alpha_u, b.alpha_v, b.eta, b.k, b.specular, b.two_sided};
-        const MicrofacetSample m = conductor_sample(P, detach(its.wi), s3, active);
+        const MicrofacetSample m = conductor_sample(P, detach(wi_), s3, active);
         BSDFSample r; r.wo = m.wo; r.pdf = m.pdf; r.valid = m.valid;
         return r;
     }
     if (b.type == 3) {
         DielectricParams P{b.alpha_u, b.alpha_v, b.eta.x, b.eta.y, b.two_sided};
-        const MicrofacetSample m = dielectric_sample(P, detach(its.wi), s3, active);
+        const MicrofacetSample m = dielectric_sample(P, detach(wi_), s3, active);
         BSDFSample r; r.wo = m.wo; r.pdf = m.pdf; r.valid = m.valid;
         return r;
     }
-    float wiz = detach(its.wi.z);
+    float wiz = detach(wi_.z);
     if (b.two_sided) wiz = fabs(wiz);
     BSDFSample bs;
     bs.wo = square_to_cosine_hemisphere(s3[1], s3[2]);      // tail<2>(sample), diffuse.cpp:63
     bs.pdf = InvPi * bs.wo.z;
     bs.valid = active && (wiz > 0.f);
     return bs;
+}
+
+// ---------------------------------------------------------------- NormalMap (normalmap.cpp:20-187)
+// wp = the normal of the map in the shading frame; the "tangent facet" wt closes the microsurface (Schuessler et al. 2017, without
+// the i -> p -> t -> o path, which the reference comments out)
+template <typename R> static V3<R> nm_wt(const V3<R> &wp) { return normalize(V3<R>(-wp.x, -wp.y, R(0.f))); }
+template <typename R> static R nm_pdot(const V3<R> &a, const V3<R> &b) { const R d = dot(a, b); return detach(d) > 0.f ? d : R(0.f); }
+template <typename R> static R nm_sin_theta(const V3<R> &v) { return safe_sqrt(fma_(v.x, v.x, v.y * v.y)); }       // frame.h:81 sin_theta_2 = x^2 + y^2
+template <typename R> static R nm_G1(const V3<R> &wp, const V3<R> &w) {
+    const R cw = detach(w.z) > 0.f ? w.z : R(0.f), cp = detach(wp.z) > 0.f ? wp.z : R(0.f);
+    const R g = cw * cp / (nm_pdot(w, wp) + nm_pdot(w, nm_wt(wp)) * nm_sin_theta(wp));
+    return detach(g) < 1.f ? g : R(1.f);                          // minimum(1, .): a NaN passes through, as in drjit
+}
+template <typename R> static R nm_lambda_p(const V3<R> &wp, const V3<R> &wi) {
+    const R i_dot_p = nm_pdot(wp, wi);
+    return i_dot_p / (i_dot_p + nm_pdot(nm_wt(wp), wi) * nm_sin_theta(wp));
+}
+// Frame(n, s): t = normalize(n x s), s = normalize(t x n)  (frame.h:43-46)
+template <typename R> struct NmFrame {
+    V3<R> s, t, n;
+    NmFrame(const V3<R> &n_, const V3<R> &s_) : n(n_) { t = normalize(cross(n_, s_)); s = normalize(cross(t, n_)); }
+    V3<R> to_local(const V3<R> &v) const { return V3<R>(dot(v, s), dot(v, t), dot(v, n)); }
+    V3<R> to_world(const V3<R> &v) const { return s * v.x + t * v.y + n * v.z; }
+};
+template <bool ad> static NmFrame<Real<ad>> nm_frame(const BsdfC &b, const Its<ad> &its, V3<Real<ad>> &wp) {
+    using R = Real<ad>; using V = V3<R>;
+    const V c = bsdf_reflectance<ad>(b, its.uv);                  // m_nmap.eval<ad>(its.uv)
+    wp = normalize(V(fma_(c.x, R(2.f), R(-1.f)), fma_(c.y, R(2.f), R(-1.f)), fma_(c.z, R(2.f), R(-1.f))));
+    const V s = normalize(its.dp_du - wp * dot(wp, its.dp_du));   // fnmadd(wp, dot(wp, dp_du), dp_du): mixes the local wp with the world dp_du (kept)
+    return NmFrame<R>(wp, s);
+}
+template <bool ad> static V3<Real<ad>> normalmap_eval(const Scene &sc, const BsdfC &b, const Its<ad> &its, V3<Real<ad>> wo, bool active) {
+    using R = Real<ad>; using V = V3<R>;
+    V wi = its.wi;
+    if (b.two_sided) { wo.z = mulsign(wo.z, detach(wi.z)); wi.z = abs_(wi.z); }
+    active = active && detach(wi.z) > 0.f && detach(wo.z) > 0.f;
+    V wp;
+    const NmFrame<R> pf = nm_frame<ad>(b, its, wp);
+    const V pwi = pf.to_local(wi), pwo = pf.to_local(wo);
+    const R shadowing = nm_G1(wp, wo), lambda_p = nm_lambda_p(wp, wi);
+    const V wt = nm_wt(wp);
+    V value = bsdf_eval_id<ad>(sc, b.nested, its, pwi, pwo, active) * lambda_p * shadowing;              // i -> p -> o
+    if (detach(dot(wi, wt)) > 0.f) {                                                                      // i -> t -> p -> o
+        const V wi_r = normalize(wi - wt * (R(2.0f) * dot(wi, wt)));
+        value = value + bsdf_eval_id<ad>(sc, b.nested, its, pf.to_local(wi_r), pwo, active) * (R(1.f) - lambda_p) * shadowing;
+    }
+    return active ? value : V(R(0.f));
+}
+template <bool ad> static float normalmap_pdf(const Scene &sc, const BsdfC &b, const Its<ad> &its, const V3<Real<ad>> &wo_, bool active) {
+    using R = Real<ad>; using V = V3<R>;
+    V wi = its.wi, wo = wo_;
+    if (b.two_sided) { wo.z = mulsign(wo.z, detach(wi.z)); wi.z = abs_(wi.z); }
+    active = active && detach(wi.z) > 0.f && detach(wo.z) > 0.f;
+    V wp;
+    const NmFrame<R> pf = nm_frame<ad>(b, its, wp);
+    const V pwo = pf.to_local(wo);
+    const float prob = detach(nm_lambda_p(wp, wi));
+    const V wt = nm_wt(wp);
+    const V wi_r = normalize(wi - wt * (R(2.0f) * dot(wi, wt)));
+    const float value = prob * bsdf_pdf_id<ad>(sc, b.nested, its, pf.to_local(wi), pwo, active)
+                        + (1.f - prob) * bsdf_pdf_id<ad>(sc, b.nested, its, pf.to_local(wi_r), pwo, active);
+    return active ? value : 0.f;
+}
+template <bool ad> static BSDFSample normalmap_sample(const Scene &sc, const BsdfC &b, const Its<ad> &its, const float s3[3], bool active) {
+    using R = Real<ad>; using V = V3<R>;
+    V wi = its.wi;
+    if (b.two_sided) wi.z = abs_(wi.z);
+    V wp;
+    const NmFrame<R> pf = nm_frame<ad>(b, its, wp);
+    const V pwi = pf.to_local(wi);
+    const float prob = detach(nm_lambda_p(wp, wi));
+    const V wt = nm_wt(wp);
+    const bool itpo = s3[2] >= prob;
+    BSDFSample bs = bsdf_sample_id<ad>(sc, b.nested, its, pwi, s3, active && !itpo);                    // i -> p -> o
+    const V wi_r = normalize(wi - wt * (R(2.0f) * dot(wi, wt)));
+    const V rwi = pf.to_local(wi_r);
+    const BSDFSample bs2 = bsdf_sample_id<ad>(sc, b.nested, its, rwi, s3, active && itpo);              // i -> t -> p -> o
+    if (itpo) bs.wo = bs2.wo;
+    const V wo_l(R(bs.wo.x), R(bs.wo.y), R(bs.wo.z));
+    const float pdf1 = bsdf_pdf_id<ad>(sc, b.nested, its, pwi, wo_l, active), pdf2 = bsdf_pdf_id<ad>(sc, b.nested, its, rwi, wo_l, active);
+    bs.pdf = prob * pdf1 + (1.f - prob) * pdf2;
+    const V3f wo_w = detach(pf.to_world(wo_l));
+    bs.wo = wo_w;
+    bs.valid = active && (bs.valid || bs2.valid);
+    return bs;
+}
+
+// BSDF of the mesh the intersection lies on (null vcall = zeros for the envmap's bounding cube)
+template <bool ad> static V3<Real<ad>> bsdf_eval(const Scene &sc, const Its<ad> &its, V3<Real<ad>> wo, bool active) {
+    const int bid = sc.meshes[its.mesh].bsdf;
+    if (bid >= 0 && sc.bsdfs[bid].type == 5) return normalmap_eval<ad>(sc, sc.bsdfs[bid], its, wo, active);
+    return bsdf_eval_id<ad>(sc, bid, its, its.wi, wo, active);
+}
+template <bool ad> static float bsdf_pdf(const Scene &sc, const Its<ad> &its, const V3<Real<ad>> &wo_, bool active) {
+    const int bid = sc.meshes[its.mesh].bsdf;
+    if (bid >= 0 && sc.bsdfs[bid].type == 5) return normalmap_pdf<ad>(sc, sc.bsdfs[bid], its, wo_, active);
+    return bsdf_pdf_id<ad>(sc, bid, its, its.wi, wo_, active);
+}
+template <bool ad> static BSDFSample bsdf_sample(const Scene &sc, const Its<ad> &its, const float s3[3], bool active) {
+    const int bid = sc.meshes[its.mesh].bsdf;
+    if (bid >= 0 && sc.bsdfs[bid].type == 5) return normalmap_sample<ad>(sc, sc.bsdfs[bid], its, s3, active);
+    return bsdf_sample_id<ad>(sc, bid, its, its.wi, s3, active);
 }
 
 // ---------------------------------------------------------------- PathTracer::__Li (path.cpp:35-127)

@@ -23,6 +23,7 @@ template <bool ad> struct Its {
     R t = R(0.f), J = R(1.f);
     Frame<ad> sh;
     V2<R> uv;
+    V3<R> dp_du = V3<R>(R(0.f));   // zeros without a uv parameterisation (scene.cpp:760-762)
     V2<R> bc;                    // barycentrics (Intersection::bc): detached in C / path-space mode, differentiable otherwise
 };
 

@@ -190,7 +190,11 @@ Scene *configure_scene(const orc_scene_desc &d, const int *active, int n_active)
         bc.alpha_u = Dual(b.alpha_u, b.d_alpha_u); bc.alpha_v = Dual(b.alpha_v, b.d_alpha_v);
         bc.eta = V3d(Dual(b.eta[0], b.d_eta[0]), Dual(b.eta[1], b.d_eta[1]), Dual(b.eta[2], b.d_eta[2]));
         bc.k = V3d(Dual(b.k[0], b.d_k[0]), Dual(b.k[1], b.d_k[1]), Dual(b.k[2], b.d_k[2]));
-        if (b.type < 0 || b.type > 4) throw std::runtime_error("Unknown BSDF type!");
+        if (b.type < 0 || b.type > 5) throw std::runtime_error("Unknown BSDF type!");
+        if (b.type == 5) {
+            if (b.nested_bsdf < 0 || b.nested_bsdf >= d.n_bsdfs || d.bsdfs[b.nested_bsdf].type == 5) throw std::runtime_error("NormalMap: invalid nested BSDF");
+            bc.nested = b.nested_bsdf;
+        }
         if (b.tex_data != nullptr) {
             if (b.tex_width < 2 || b.tex_height < 2) throw std::runtime_error("Bitmap: invalid resolution!");
             bc.tex_w = b.tex_width; bc.tex_h = b.tex_height;

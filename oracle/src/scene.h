@@ -85,7 +85,8 @@ struct BsdfC { int type; V3d reflectance; bool two_sided; int tex_w = 0, tex_h =
                int spec_w = 0, spec_h = 0, rough_w = 0, rough_h = 0;       // Microfacet bitmap parameters (rgb / 1 channel)
                std::vector<float> spec_tex, d_spec_tex, rough_tex, d_rough_tex;
                // type 4 = MicrofacetPerVertex: [n*3], [n*3], [n] values per (mesh-local) vertex, with optional tangents
-               std::vector<float> pv_spec, pv_diff, pv_rough, d_pv_spec, d_pv_diff, d_pv_rough; };   // type 2 = RoughConductor (specular = specular_reflectance)   // tex: Bitmap3fD texels when textured
+               std::vector<float> pv_spec, pv_diff, pv_rough, d_pv_spec, d_pv_diff, d_pv_rough;
+               int nested = -1; };                // type 5 = NormalMap: index of the nested BSDF; reflectance / tex = the normal map   // type 2 = RoughConductor (specular = specular_reflectance)   // tex: Bitmap3fD texels when textured
 // type 0 = AreaLight (area.h), 1 = EnvironmentMap (envmap.h); an envmap's mesh is the bounding cube scene.cpp:442-480 adds
 struct EmitterC { V3d radiance; int mesh = -1; float sampling_weight = 1.f; int type = 0; };
 

@@ -39,6 +39,7 @@ MicrofacetBSDF = _core.MicrofacetBSDF
 RoughConductorBSDF = _core.RoughConductorBSDF
 RoughDielectricBSDF = _core.RoughDielectricBSDF
 MicrofacetBSDFPerVertex = _core.MicrofacetBSDFPerVertex
+NormalMapBSDF = _core.NormalMapBSDF
 EnvironmentMap = _core.EnvironmentMap
 Sensor = _core.Sensor
 PerspectiveCamera = _core.PerspectiveCamera
@@ -218,6 +219,7 @@ for _n in ("alpha_u", "alpha_v", "eta"):
 for _n in ("specularReflectance", "diffuseReflectance"):
     setattr(MicrofacetBSDFPerVertex, _n, _make_param_property(_n, lambda self, value: (-1, 3)))
 MicrofacetBSDFPerVertex.roughness = _make_param_property("roughness", lambda self, value: (-1,))
+NormalMapBSDF.normal_map = _make_param_property("normal_map", _refl_shape)
 AreaLight.radiance = _make_param_property("radiance", _v3)
 
 
@@ -317,6 +319,35 @@ def _microfacet_pv_init(self, specular, diffuse, roughness):
 
 
 MicrofacetBSDFPerVertex.__init__ = _microfacet_pv_init
+_NormalMapBSDF_init = NormalMapBSDF.__init__
+
+
+def _normalmap_init(self, normal_map=None):
+    """NormalMapBSDF() or NormalMapBSDF(vec3 | Bitmap3fD | array[H, W, 3]) (reference psdr.cpp:273-277, normalmap.h); the BSDF it
+    perturbs is assigned through `nested_bsdf`"""
+    _NormalMapBSDF_init(self)
+    if normal_map is not None:
+        if isinstance(normal_map, Bitmap3fD):
+            normal_map = normal_map.data.reshape(3) if normal_map.data.size == 3 else normal_map.data
+        self.normal_map = normal_map
+
+
+def _nm_get_nested(self):
+    n = self._nested
+    if n is not None:
+        src = self.__dict__.get("_psdr_nested_src")
+        if src is not None and "_psdr_params" in src.__dict__ and "_psdr_params" not in n.__dict__:
+            n.__dict__["_psdr_params"] = dict(src.__dict__["_psdr_params"])
+    return n
+
+
+def _nm_set_nested(self, bsdf):
+    self._set_nested(bsdf)                       # the map keeps its own copy, as the scene does with everything it is given
+    self.__dict__["_psdr_nested_src"] = bsdf
+
+
+NormalMapBSDF.__init__ = _normalmap_init
+NormalMapBSDF.nested_bsdf = property(_nm_get_nested, _nm_set_nested)
 _RoughDielectricBSDF_init = RoughDielectricBSDF.__init__
 
 
@@ -368,7 +399,23 @@ def _add_Sensor(self, sensor):
 
 def _add_BSDF(self, bsdf, name, twoSide=False):
     _Scene_add_BSDF(self, bsdf, name, twoSide)
-    _keep(self, "BSDF[id=%s]" % name, bsdf)
+    live = _keep(self, "BSDF[id=%s]" % name, bsdf)
+    if isinstance(bsdf, NormalMapBSDF):          # the nested BSDF's leaves travel with it
+        src = bsdf.__dict__.get("_psdr_nested_src")
+        nested = live._nested
+        if nested is not None:
+            self.__dict__.setdefault("_psdr_objs", {})["BSDF[id=%s].nested" % name] = nested
+            if src is not None and "_psdr_params" in src.__dict__:
+                nested.__dict__["_psdr_params"] = dict(src.__dict__["_psdr_params"])
+
+
+def _add_normalmap_BSDF(self, bsdf1, bsdf2, name, twoSide=False):
+    """Scene.add_normalmap_BSDF(NormalMapBSDF, MicrofacetBSDF, name, twoSide) (reference scene.cpp:128-145)"""
+    nm = NormalMapBSDF(bsdf1.normal_map)
+    if "_psdr_params" in bsdf1.__dict__:
+        nm.__dict__["_psdr_params"] = dict(bsdf1.__dict__["_psdr_params"])
+    nm.nested_bsdf = bsdf2
+    _add_BSDF(self, nm, name, twoSide)
 
 
 def load_radiance_image(path):
@@ -467,6 +514,7 @@ def _configure(self, active_sensor=()):
 
 Scene.add_Sensor = _add_Sensor
 Scene.add_BSDF = _add_BSDF
+Scene.add_normalmap_BSDF = _add_normalmap_BSDF
 Scene.add_Mesh = _add_Mesh
 
 

@@ -103,7 +103,7 @@ def snapshot_tensors(scene, sensor_id, leaf_of):
     nb = sum(1 for k in pm if k.startswith("BSDF[") and not k.startswith("BSDF[id="))
     ne = sum(1 for k in pm if k.startswith("Emitter[") and not k.startswith("Emitter[id="))
     def _refl(b):     # the colour row g_bsdf refers to: Diffuse reflectance, Microfacet diffuse reflectance (textures: no adjoint)
-        if type(b).__name__ in ("RoughConductorBSDF", "RoughDielectricBSDF", "MicrofacetBSDFPerVertex"):
+        if type(b).__name__ in ("RoughConductorBSDF", "RoughDielectricBSDF", "MicrofacetBSDFPerVertex", "NormalMapBSDF"):
             return torch.zeros(3, dtype=F64)
         if type(b).__name__ == "MicrofacetBSDF":
             r = leaf_of(b, "diffuseReflectance")

@@ -557,7 +557,7 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     {
         bool any = false;
         for (int i = 0; i < s->n_bsdfs; ++i) {
-            if (s->bsdfs[i].type < 0 || s->bsdfs[i].type > 4) return fail("Unknown BSDF type!");
+            if (s->bsdfs[i].type < 0 || s->bsdfs[i].type > 5) return fail("Unknown BSDF type!");
             any |= s->bsdfs[i].type != 0;
         }
         if (any) {
@@ -696,9 +696,10 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     }
     for (int i = 0; i < s->n_bsdfs; ++i) {
         const psdr_bsdf_rec &b = s->bsdfs[i];
-        if (b.type < 0 || b.type > 4) return fail("Unknown BSDF type!");
-        put4(blob, T.bsdf_off + 2 * (size_t) i, b.reflectance[0], b.reflectance[1], b.reflectance[2], ibits((b.two_sided ? 1 : 0) | (b.tex_data ? 2 : 0) | (b.type == 1 ? 4 : 0) | (b.type == 2 ? 8 : 0) | (b.type == 3 ? 16 : 0) | (b.spec_tex_data ? 32 : 0) | (b.rough_tex_data ? 64 : 0) | (b.type == 4 ? 128 : 0)));
-        put4(blob, T.bsdf_off + 2 * (size_t) i + 1, b.d_reflectance[0], b.d_reflectance[1], b.d_reflectance[2], 0.f);
+        if (b.type < 0 || b.type > 5) return fail("Unknown BSDF type!");
+        if (b.type == 5 && (b.nested_bsdf < 0 || b.nested_bsdf >= s->n_bsdfs || s->bsdfs[b.nested_bsdf].type == 5)) return fail("NormalMap: invalid nested BSDF");
+        put4(blob, T.bsdf_off + 2 * (size_t) i, b.reflectance[0], b.reflectance[1], b.reflectance[2], ibits((b.two_sided ? 1 : 0) | (b.tex_data ? 2 : 0) | (b.type == 1 ? 4 : 0) | (b.type == 2 ? 8 : 0) | (b.type == 3 ? 16 : 0) | (b.spec_tex_data ? 32 : 0) | (b.rough_tex_data ? 64 : 0) | (b.type == 4 ? 128 : 0) | (b.type == 5 ? 256 : 0)));
+        put4(blob, T.bsdf_off + 2 * (size_t) i + 1, b.d_reflectance[0], b.d_reflectance[1], b.d_reflectance[2], ibits(b.type == 5 ? b.nested_bsdf : -1));
     }
     for (int i = 0; i < s->n_emitters; ++i) {
         const psdr_emitter_rec &e = s->emitters[i];

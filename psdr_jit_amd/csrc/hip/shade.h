@@ -19,6 +19,7 @@ template <bool AD> struct Its {
     int slot, mesh;
     VecN<AD> p, n, wi, fs, ft, fn;     // position, geometric normal, local incident dir, shading frame
     Num<AD> t, J;
+    VecN<AD> dp_du;                    // world-space dp/du (Intersection::dp_du), zeros without a uv parameterisation; scene class 0 only
     Num<AD> bu, bv;                    // barycentrics (Intersection::bc); only kept when a per-vertex BSDF exists (LDS=false kernels)
     Num<AD> tu, tv;                    // texture coordinates (Intersection::uv); only kept by the LDS=false kernels of textured scenes
 };
@@ -137,10 +138,12 @@ PSDR_DEV Its<AD> make_its(const SceneView<LDS> &S, const Hit &h, const RayT<AD> 
             }
         }
         if constexpr (has_mat(LDS)) if (T.pv != nullptr) { its.bu = u; its.bv = v; }
+        if constexpr (has_mat(LDS)) its.dp_du = V(R(0.f));
         const float det = fma_(du0x, du1y, -(du0y * du1x));
         if (det != 0.f) {
             const float inv_det = 1.f / det;
             V dp_du = (e1 * R(du1y) - e2 * R(du0y)) * R(inv_det);
+            if constexpr (has_mat(LDS)) its.dp_du = dp_du;
             its.fs = normalize(dp_du - sh_n * dot(sh_n, dp_du));
             its.ft = cross(sh_n, its.fs);
         }
@@ -378,14 +381,15 @@ template <bool AD, int LDS> PSDR_DEV float roughness_lookup(const SceneView<LDS>
     env::bitmap_eval_tex<float, 1>([&](int i, int) { return td.data[i]; }, td.w, td.h, detach(its.tu), detach(its.tv), true, o);
     return o[0];
 }
-template <bool AD, int LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S, const Its<AD> &its, VecN<AD> wo, bool active) {
+// (bid_, wi_) are explicit so that NormalMap can evaluate its nested BSDF with a perturbed incident direction
+template <bool AD, int LDS> PSDR_DEV VecN<AD> bsdf_eval_id(const SceneView<LDS> &S, int bid_, const Its<AD> &its, const VecN<AD> &wi_, VecN<AD> wo, bool active) {
     using R = Num<AD>; using V = VecN<AD>;
-    if (mesh_bsdf(S, its.mesh) < 0) return V(R(0.f));          // the envmap's bounding cube has no BSDF (null vcall = zeros)
-    const int w = S.T->bsdf_off + 2 * mesh_bsdf(S, its.mesh);
+    if (bid_ < 0) return V(R(0.f));          // the envmap's bounding cube has no BSDF (null vcall = zeros)
+    const int w = S.T->bsdf_off + 2 * bid_;
     const float4 a = S.ld(w);
     if constexpr (has_mat(LDS)) {
         if (__float_as_int(a.w) & 4) {         // Microfacet (microfacet.cpp); its diffuse reflectance is the record's colour
-            const int id = mesh_bsdf(S, its.mesh);
+            const int id = bid_;
             const MatDev md = S.T->mat[id];
             const int fl = __float_as_int(a.w);
             // bitmap parameters (microfacet.cpp:38-45): looked up with (value, tangent) texels and uv, detached in C mode
@@ -415,11 +419,11 @@ template <bool AD, int LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S,
                 if (fl & 32) { look(1, std::integral_constant<int, 3>(), o); spec = Vec3d(o[0], o[1], o[2]); }
                 if (fl & 64) { look(2, std::integral_constant<int, 1>(), o); rough = o[0]; }
             }
-            if constexpr (AD) return microfacet_eval<Dual>(spec, diff, rough, (fl & 1) != 0, its.wi, wo, active);
-            else return microfacet_eval<float>(detach(spec), detach(diff), rough.v, (fl & 1) != 0, its.wi, wo, active);
+            if constexpr (AD) return microfacet_eval<Dual>(spec, diff, rough, (fl & 1) != 0, wi_, wo, active);
+            else return microfacet_eval<float>(detach(spec), detach(diff), rough.v, (fl & 1) != 0, wi_, wo, active);
         }
         if (__float_as_int(a.w) & 128) {       // MicrofacetPerVertex (microfacet_pv.cpp)
-            const PvDev pv = S.T->pv[mesh_bsdf(S, its.mesh)];
+            const PvDev pv = S.T->pv[bid_];
             const int *fi = S.T->tri_fi + 3 * its.slot;
             const bool tan = AD && S.mode == 0;            // (reverse mode: the adjoints of the per-vertex values come from the lookup probes)
             const Dual bu = Dual(its.bu), bv = Dual(its.bv);
@@ -440,48 +444,48 @@ template <bool AD, int LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S,
                 }
             }
             const bool two = (__float_as_int(a.w) & 1) != 0;
-            if constexpr (AD) return microfacet_pv_eval<Dual>(spec, diff, rough, two, its.wi, wo, active);
-            else return microfacet_pv_eval<float>(detach(spec), detach(diff), rough.v, two, its.wi, wo, active);
+            if constexpr (AD) return microfacet_pv_eval<Dual>(spec, diff, rough, two, wi_, wo, active);
+            else return microfacet_pv_eval<float>(detach(spec), detach(diff), rough.v, two, wi_, wo, active);
         }
         if (__float_as_int(a.w) & 8) {         // RoughConductor (roughconductor.cpp)
-            const MatDev md = S.T->mat[mesh_bsdf(S, its.mesh)];
+            const MatDev md = S.T->mat[bid_];
             const bool two = (__float_as_int(a.w) & 1) != 0;
             if constexpr (AD) {
                 const float t = S.mode == 0 ? 1.f : 0.f;       // (its parameters have no reverse-mode adjoint yet)
                 // g_mat row = [alpha_u, alpha_v, eta rgb, k rgb, specular_reflectance rgb]
-                const int bid = mesh_bsdf(S, its.mesh);
+                const int bid = bid_;
                 (void) t;
                 auto mt = [&](int kk, float fwd) { return S.mat_tan(bid, kk, fwd); };
                 return conductor_eval<Dual>(Dual(md.alpha_u, mt(0, md.d_alpha_u)), Dual(md.alpha_v, mt(1, md.d_alpha_v)),
                                             Vec3d(Dual(md.eta[0], mt(2, md.d_eta[0])), Dual(md.eta[1], mt(3, md.d_eta[1])), Dual(md.eta[2], mt(4, md.d_eta[2]))),
                                             Vec3d(Dual(md.k[0], mt(5, md.d_k[0])), Dual(md.k[1], mt(6, md.d_k[1])), Dual(md.k[2], mt(7, md.d_k[2]))),
                                             Vec3d(Dual(md.specular[0], mt(8, md.d_specular[0])), Dual(md.specular[1], mt(9, md.d_specular[1])), Dual(md.specular[2], mt(10, md.d_specular[2]))),
-                                            two, its.wi, wo, active);
+                                            two, wi_, wo, active);
             } else {
                 return conductor_eval<float>(md.alpha_u, md.alpha_v, Vec3f(md.eta[0], md.eta[1], md.eta[2]), Vec3f(md.k[0], md.k[1], md.k[2]),
-                                             Vec3f(md.specular[0], md.specular[1], md.specular[2]), two, its.wi, wo, active);
+                                             Vec3f(md.specular[0], md.specular[1], md.specular[2]), two, wi_, wo, active);
             }
         }
     }
     if constexpr (has_mat(LDS)) {
         if (__float_as_int(a.w) & 16) {        // RoughDielectric (roughdielectric.cpp): eta[0] = intIOR/extIOR, eta[1] = extIOR/intIOR
-            const MatDev md = S.T->mat[mesh_bsdf(S, its.mesh)];
+            const MatDev md = S.T->mat[bid_];
             const bool two = (__float_as_int(a.w) & 1) != 0;
             if constexpr (AD) {
                 const float t = S.mode == 0 ? 1.f : 0.f;
                 // g_mat row = [alpha_u, alpha_v, eta]; m_inv_eta = 1 / m_eta moves with eta
-                const int bid = mesh_bsdf(S, its.mesh);
+                const int bid = bid_;
                 (void) t;
                 const float de = S.mat_tan(bid, 2, md.d_eta[0]);
                 const float dinv = S.mode == 0 ? md.d_eta[1] : -de / (md.eta[0] * md.eta[0]);
                 return dielectric_eval<Dual>(Dual(md.alpha_u, S.mat_tan(bid, 0, md.d_alpha_u)), Dual(md.alpha_v, S.mat_tan(bid, 1, md.d_alpha_v)), Dual(md.eta[0], de),
-                                             Dual(md.eta[1], dinv), two, its.wi, wo, active);
+                                             Dual(md.eta[1], dinv), two, wi_, wo, active);
             } else {
-                return dielectric_eval<float>(md.alpha_u, md.alpha_v, md.eta[0], md.eta[1], two, its.wi, wo, active);
+                return dielectric_eval<float>(md.alpha_u, md.alpha_v, md.eta[0], md.eta[1], two, wi_, wo, active);
             }
         }
     }
-    R wiz = its.wi.z;
+    R wiz = wi_.z;
     if (__float_as_int(a.w) & 1) { wo.z = mulsign(wo.z, detach(wiz)); wiz = abs_(wiz); }
     if (!(active && detach(wiz) > 0.f && detach(wo.z) > 0.f)) return V(R(0.f));
     V refl;
@@ -489,14 +493,14 @@ template <bool AD, int LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S,
     if constexpr (has_mat(LDS)) {
         if (__float_as_int(a.w) & 2) {         // Bitmap3fD reflectance, diffuse.cpp:38 -> bitmap.cpp:47-128 (flip_v)
             textured = true;
-            const TexDev td = S.T->tex[3 * mesh_bsdf(S, its.mesh)];
+            const TexDev td = S.T->tex[3 * bid_];
             R rgb[3];
             if constexpr (AD) {
                 const bool tan = td.d_data != nullptr && S.mode == 0;      // (reverse mode: the texel adjoints come from the lookup probes)
                 env::bitmap_eval_tex<Dual>([&](int i, int c) { return Dual(td.data[3 * i + c], tan ? td.d_data[3 * i + c] : 0.f); },
                                            td.w, td.h, its.tu, its.tv, true, rgb);
-                S.note_lookup(mesh_bsdf(S, its.mesh), its.tu.v, its.tv.v);
-                const int hot = S.lookup_hot(mesh_bsdf(S, its.mesh), its.tu.v, its.tv.v, 0, 3);
+                S.note_lookup(bid_, its.tu.v, its.tv.v);
+                const int hot = S.lookup_hot(bid_, its.tu.v, its.tv.v, 0, 3);
                 if (hot >= 0) rgb[hot].d += 1.f;
             } else {
                 env::bitmap_eval_tex<float>([&](int i, int c) { return td.data[3 * i + c]; }, td.w, td.h, its.tu, its.tv, true, rgb);
@@ -505,31 +509,31 @@ template <bool AD, int LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S,
         }
     }
     if (!textured) {
-        if constexpr (AD) { const float4 b = S.rgb_tan(w + 1, 2, mesh_bsdf(S, its.mesh)); refl = make_dual(Vec3f(a.x, a.y, a.z), Vec3f(b.x, b.y, b.z)); }
+        if constexpr (AD) { const float4 b = S.rgb_tan(w + 1, 2, bid_); refl = make_dual(Vec3f(a.x, a.y, a.z), Vec3f(b.x, b.y, b.z)); }
         else refl = Vec3f(a.x, a.y, a.z);
     }
     return refl * R(kInvPi) * wo.z;
 }
-template <bool AD, int LDS> PSDR_DEV float bsdf_pdf(const SceneView<LDS> &S, const Its<AD> &its, const VecN<AD> &wo, bool active) {
-    if (mesh_bsdf(S, its.mesh) < 0) return 0.f;
-    const float4 a = S.ld(S.T->bsdf_off + 2 * mesh_bsdf(S, its.mesh));
+template <bool AD, int LDS> PSDR_DEV float bsdf_pdf_id(const SceneView<LDS> &S, int bid_, const Its<AD> &its, const VecN<AD> &wi_, const VecN<AD> &wo, bool active) {
+    if (bid_ < 0) return 0.f;
+    const float4 a = S.ld(S.T->bsdf_off + 2 * bid_);
     if constexpr (has_mat(LDS)) {
         if (__float_as_int(a.w) & 128) {
-            const float r = pv_roughness(S, mesh_bsdf(S, its.mesh), its);
-            return ggx_pdf(sqr(r), sqr(r), (__float_as_int(a.w) & 1) != 0, detach(its.wi), detach(wo), active);
+            const float r = pv_roughness(S, bid_, its);
+            return ggx_pdf(sqr(r), sqr(r), (__float_as_int(a.w) & 1) != 0, detach(wi_), detach(wo), active);
         }
         if (__float_as_int(a.w) & 12) {
-            const MatDev md = S.T->mat[mesh_bsdf(S, its.mesh)];
+            const MatDev md = S.T->mat[bid_];
             const bool mf = (__float_as_int(a.w) & 4) != 0;
-            const float rough = (__float_as_int(a.w) & 64) ? roughness_lookup(S, mesh_bsdf(S, its.mesh), its) : md.roughness;
-            return ggx_pdf(mf ? sqr(rough) : md.alpha_u, mf ? sqr(rough) : md.alpha_v, (__float_as_int(a.w) & 1) != 0, detach(its.wi), detach(wo), active);
+            const float rough = (__float_as_int(a.w) & 64) ? roughness_lookup(S, bid_, its) : md.roughness;
+            return ggx_pdf(mf ? sqr(rough) : md.alpha_u, mf ? sqr(rough) : md.alpha_v, (__float_as_int(a.w) & 1) != 0, detach(wi_), detach(wo), active);
         }
         if (__float_as_int(a.w) & 16) {
-            const MatDev md = S.T->mat[mesh_bsdf(S, its.mesh)];
-            return dielectric_pdf(md.alpha_u, md.alpha_v, md.eta[0], md.eta[1], (__float_as_int(a.w) & 1) != 0, detach(its.wi), detach(wo), active);
+            const MatDev md = S.T->mat[bid_];
+            return dielectric_pdf(md.alpha_u, md.alpha_v, md.eta[0], md.eta[1], (__float_as_int(a.w) & 1) != 0, detach(wi_), detach(wo), active);
         }
     }
-    float wiz = detach(its.wi.z), woz = detach(wo.z);
+    float wiz = detach(wi_.z), woz = detach(wo.z);
     if (__float_as_int(a.w) & 1) { woz = mulsign(woz, wiz); wiz = fabsf(wiz); }
     return (active && wiz > 0.f && woz > 0.f) ? kInvPi * woz : 0.f;
 }
@@ -568,34 +572,34 @@ PSDR_DEV Vec3f square_to_cosine_hemisphere(float sx, float sy) {
     return Vec3f(px, py, safe_sqrt(1.f - fma_(py, py, px * px)));
 }
 struct BSDFSample { Vec3f wo; float pdf; bool valid; };
-template <bool AD, int LDS> PSDR_DEV BSDFSample bsdf_sample(const SceneView<LDS> &S, const Its<AD> &its, float s0, float s1, float s2, bool active) {
+template <bool AD, int LDS> PSDR_DEV BSDFSample bsdf_sample_id(const SceneView<LDS> &S, int bid_, const Its<AD> &its, const VecN<AD> &wi_, float s0, float s1, float s2, bool active) {
     (void) s0;
-    if (mesh_bsdf(S, its.mesh) < 0) { BSDFSample z; z.wo = Vec3f(0.f, 0.f, 0.f); z.pdf = 0.f; z.valid = false; return z; }
-    const float4 a = S.ld(S.T->bsdf_off + 2 * mesh_bsdf(S, its.mesh));
+    if (bid_ < 0) { BSDFSample z; z.wo = Vec3f(0.f, 0.f, 0.f); z.pdf = 0.f; z.valid = false; return z; }
+    const float4 a = S.ld(S.T->bsdf_off + 2 * bid_);
     if constexpr (has_mat(LDS)) {
         if (__float_as_int(a.w) & 128) {       // MicrofacetPerVertex::__sample (microfacet_pv.cpp:80-103)
             BSDFSample m;
-            const float r = pv_roughness(S, mesh_bsdf(S, its.mesh), its);
-            ggx_reflect_sample(sqr(r), sqr(r), (__float_as_int(a.w) & 1) != 0, detach(its.wi), s0, s1, active, m.wo, m.pdf, m.valid);
+            const float r = pv_roughness(S, bid_, its);
+            ggx_reflect_sample(sqr(r), sqr(r), (__float_as_int(a.w) & 1) != 0, detach(wi_), s0, s1, active, m.wo, m.pdf, m.valid);
             return m;
         }
         if (__float_as_int(a.w) & 12) {        // Microfacet / RoughConductor ::sample use the first two numbers (microfacet.cpp:88)
             BSDFSample m;
-            const MatDev md = S.T->mat[mesh_bsdf(S, its.mesh)];
+            const MatDev md = S.T->mat[bid_];
             const bool mf = (__float_as_int(a.w) & 4) != 0;
-            const float rough = (__float_as_int(a.w) & 64) ? roughness_lookup(S, mesh_bsdf(S, its.mesh), its) : md.roughness;
-            ggx_reflect_sample(mf ? sqr(rough) : md.alpha_u, mf ? sqr(rough) : md.alpha_v, (__float_as_int(a.w) & 1) != 0, detach(its.wi), s0, s1, active,
+            const float rough = (__float_as_int(a.w) & 64) ? roughness_lookup(S, bid_, its) : md.roughness;
+            ggx_reflect_sample(mf ? sqr(rough) : md.alpha_u, mf ? sqr(rough) : md.alpha_v, (__float_as_int(a.w) & 1) != 0, detach(wi_), s0, s1, active,
                                m.wo, m.pdf, m.valid);
             return m;
         }
         if (__float_as_int(a.w) & 16) {        // RoughDielectric::sample: the third number picks reflection or refraction
             BSDFSample m;
-            const MatDev md = S.T->mat[mesh_bsdf(S, its.mesh)];
-            dielectric_sample(md.alpha_u, md.alpha_v, md.eta[0], (__float_as_int(a.w) & 1) != 0, detach(its.wi), s0, s1, s2, active, m.wo, m.pdf, m.valid);
+            const MatDev md = S.T->mat[bid_];
+            dielectric_sample(md.alpha_u, md.alpha_v, md.eta[0], (__float_as_int(a.w) & 1) != 0, detach(wi_), s0, s1, s2, active, m.wo, m.pdf, m.valid);
             return m;
         }
     }
-    float wiz = detach(its.wi.z);
+    float wiz = detach(wi_.z);
     if (__float_as_int(a.w) & 1) wiz = fabsf(wiz);
     BSDFSample bs;
     bs.wo = square_to_cosine_hemisphere(s1, s2);
@@ -603,6 +607,133 @@ template <bool AD, int LDS> PSDR_DEV BSDFSample bsdf_sample(const SceneView<LDS>
     bs.valid = active && (wiz > 0.f);
     return bs;
 }
+
+// ---------------------------------------------------------------- NormalMap, reference src/bsdf/normalmap.cpp:20-187
+// wp = the normal of the map in the shading frame; the "tangent facet" wt closes the microsurface (the i -> p -> t -> o path is
+// commented out in the reference).  Scene class 0 only.
+template <typename R> PSDR_DEV Vec3<R> nm_wt(const Vec3<R> &wp) { return normalize(Vec3<R>(-wp.x, -wp.y, R(0.f))); }
+template <typename R> PSDR_DEV R nm_pdot(const Vec3<R> &a, const Vec3<R> &b) { const R d = dot(a, b); return detach(d) > 0.f ? d : R(0.f); }
+template <typename R> PSDR_DEV R nm_sin_theta(const Vec3<R> &v) { return safe_sqrt(fma_(v.x, v.x, v.y * v.y)); }
+template <typename R> PSDR_DEV R nm_G1(const Vec3<R> &wp, const Vec3<R> &w) {
+    const R cw = detach(w.z) > 0.f ? w.z : R(0.f), cp = detach(wp.z) > 0.f ? wp.z : R(0.f);
+    const R g = cw * cp / (nm_pdot(w, wp) + nm_pdot(w, nm_wt(wp)) * nm_sin_theta(wp));
+    return detach(g) < 1.f ? g : R(1.f);
+}
+template <typename R> PSDR_DEV R nm_lambda_p(const Vec3<R> &wp, const Vec3<R> &wi) {
+    const R i_dot_p = nm_pdot(wp, wi);
+    return i_dot_p / (i_dot_p + nm_pdot(nm_wt(wp), wi) * nm_sin_theta(wp));
+}
+template <typename R> struct NmFrame {          // Frame(n, s): t = normalize(n x s), s = normalize(t x n)  (frame.h:43-46)
+    Vec3<R> s, t, n;
+    PSDR_DEV NmFrame(const Vec3<R> &n_, const Vec3<R> &s_) : n(n_) { t = normalize(cross(n_, s_)); s = normalize(cross(t, n_)); }
+    PSDR_DEV Vec3<R> to_local(const Vec3<R> &v) const { return Vec3<R>(dot(v, s), dot(v, t), dot(v, n)); }
+    PSDR_DEV Vec3<R> to_world(const Vec3<R> &v) const { return s * v.x + t * v.y + n * v.z; }
+};
+// m_nmap.eval(its.uv) (constant or bitmap, slot 0 of the NormalMap's own record) -> wp and the perturbed frame
+template <bool AD, int LDS> PSDR_DEV NmFrame<Num<AD>> nm_frame(const SceneView<LDS> &S, int bid, const Its<AD> &its, VecN<AD> &wp) {
+    using R = Num<AD>; using V = VecN<AD>;
+    const int w = S.T->bsdf_off + 2 * bid;
+    const float4 a = S.ld(w);
+    V c;
+    if (__float_as_int(a.w) & 2) {
+        const TexDev td = S.T->tex[3 * bid];
+        R rgb[3];
+        if constexpr (AD) {
+            const bool tan = td.d_data != nullptr && S.mode == 0;
+            env::bitmap_eval_tex<Dual>([&](int i, int ch) { return Dual(td.data[3 * i + ch], tan ? td.d_data[3 * i + ch] : 0.f); }, td.w, td.h, its.tu, its.tv, true, rgb);
+            S.note_lookup(bid, its.tu.v, its.tv.v);
+            const int hot = S.lookup_hot(bid, its.tu.v, its.tv.v, 0, 3);
+            if (hot >= 0) rgb[hot].d += 1.f;
+        } else {
+            env::bitmap_eval_tex<float>([&](int i, int ch) { return td.data[3 * i + ch]; }, td.w, td.h, its.tu, its.tv, true, rgb);
+        }
+        c = V(rgb[0], rgb[1], rgb[2]);
+    } else {
+        if constexpr (AD) { const float4 b = S.rgb_tan(w + 1, 2, bid); c = make_dual(Vec3f(a.x, a.y, a.z), Vec3f(b.x, b.y, b.z)); }
+        else c = Vec3f(a.x, a.y, a.z);
+    }
+    wp = normalize(V(fma_(c.x, R(2.f), R(-1.f)), fma_(c.y, R(2.f), R(-1.f)), fma_(c.z, R(2.f), R(-1.f))));
+    const V s = normalize(its.dp_du - wp * dot(wp, its.dp_du));
+    return NmFrame<R>(wp, s);
+}
+template <bool AD, int LDS> PSDR_DEV VecN<AD> normalmap_eval(const SceneView<LDS> &S, int bid, const Its<AD> &its, VecN<AD> wo, bool active) {
+    using R = Num<AD>; using V = VecN<AD>;
+    const float4 a = S.ld(S.T->bsdf_off + 2 * bid);
+    const int nested = __float_as_int(S.ld(S.T->bsdf_off + 2 * bid + 1).w);
+    V wi = its.wi;
+    if (__float_as_int(a.w) & 1) { wo.z = mulsign(wo.z, detach(wi.z)); wi.z = abs_(wi.z); }
+    active = active && detach(wi.z) > 0.f && detach(wo.z) > 0.f;
+    V wp;
+    const NmFrame<R> pf = nm_frame<AD, LDS>(S, bid, its, wp);
+    const V pwi = pf.to_local(wi), pwo = pf.to_local(wo);
+    const R shadowing = nm_G1(wp, wo), lambda_p = nm_lambda_p(wp, wi);
+    const V wt = nm_wt(wp);
+    V value = bsdf_eval_id<AD, LDS>(S, nested, its, pwi, pwo, active) * lambda_p * shadowing;
+    if (detach(dot(wi, wt)) > 0.f) {
+        const V wi_r = normalize(wi - wt * (R(2.0f) * dot(wi, wt)));
+        value = value + bsdf_eval_id<AD, LDS>(S, nested, its, pf.to_local(wi_r), pwo, active) * (R(1.f) - lambda_p) * shadowing;
+    }
+    return active ? value : V(R(0.f));
+}
+template <bool AD, int LDS> PSDR_DEV float normalmap_pdf(const SceneView<LDS> &S, int bid, const Its<AD> &its, const VecN<AD> &wo_, bool active) {
+    using R = Num<AD>; using V = VecN<AD>;
+    const float4 a = S.ld(S.T->bsdf_off + 2 * bid);
+    const int nested = __float_as_int(S.ld(S.T->bsdf_off + 2 * bid + 1).w);
+    V wi = its.wi, wo = wo_;
+    if (__float_as_int(a.w) & 1) { wo.z = mulsign(wo.z, detach(wi.z)); wi.z = abs_(wi.z); }
+    active = active && detach(wi.z) > 0.f && detach(wo.z) > 0.f;
+    V wp;
+    const NmFrame<R> pf = nm_frame<AD, LDS>(S, bid, its, wp);
+    const V pwo = pf.to_local(wo);
+    const float prob = detach(nm_lambda_p(wp, wi));
+    const V wt = nm_wt(wp);
+    const V wi_r = normalize(wi - wt * (R(2.0f) * dot(wi, wt)));
+    const float value = prob * bsdf_pdf_id<AD, LDS>(S, nested, its, pf.to_local(wi), pwo, active)
+                        + (1.f - prob) * bsdf_pdf_id<AD, LDS>(S, nested, its, pf.to_local(wi_r), pwo, active);
+    return active ? value : 0.f;
+}
+template <bool AD, int LDS> PSDR_DEV BSDFSample normalmap_sample(const SceneView<LDS> &S, int bid, const Its<AD> &its, float s0, float s1, float s2, bool active) {
+    using R = Num<AD>; using V = VecN<AD>;
+    const float4 a = S.ld(S.T->bsdf_off + 2 * bid);
+    const int nested = __float_as_int(S.ld(S.T->bsdf_off + 2 * bid + 1).w);
+    V wi = its.wi;
+    if (__float_as_int(a.w) & 1) wi.z = abs_(wi.z);
+    V wp;
+    const NmFrame<R> pf = nm_frame<AD, LDS>(S, bid, its, wp);
+    const V pwi = pf.to_local(wi);
+    const float prob = detach(nm_lambda_p(wp, wi));
+    const V wt = nm_wt(wp);
+    const bool itpo = s2 >= prob;
+    BSDFSample bs = bsdf_sample_id<AD, LDS>(S, nested, its, pwi, s0, s1, s2, active && !itpo);
+    const V wi_r = normalize(wi - wt * (R(2.0f) * dot(wi, wt)));
+    const V rwi = pf.to_local(wi_r);
+    const BSDFSample bs2 = bsdf_sample_id<AD, LDS>(S, nested, its, rwi, s0, s1, s2, active && itpo);
+    if (itpo) bs.wo = bs2.wo;
+    const V wo_l(R(bs.wo.x), R(bs.wo.y), R(bs.wo.z));
+    const float pdf1 = bsdf_pdf_id<AD, LDS>(S, nested, its, pwi, wo_l, active), pdf2 = bsdf_pdf_id<AD, LDS>(S, nested, its, rwi, wo_l, active);
+    bs.pdf = prob * pdf1 + (1.f - prob) * pdf2;
+    bs.wo = detach(pf.to_world(wo_l));
+    bs.valid = active && (bs.valid || bs2.valid);
+    return bs;
+}
+
+// BSDF of the mesh the intersection lies on (a mesh without BSDF - the envmap's bounding cube - gives zeros, as drjit's null vcall)
+template <bool AD, int LDS> PSDR_DEV VecN<AD> bsdf_eval(const SceneView<LDS> &S, const Its<AD> &its, VecN<AD> wo, bool active) {
+    const int bid = mesh_bsdf(S, its.mesh);
+    if constexpr (has_mat(LDS)) if (bid >= 0 && (__float_as_int(S.ld(S.T->bsdf_off + 2 * bid).w) & 256)) return normalmap_eval<AD, LDS>(S, bid, its, wo, active);
+    return bsdf_eval_id<AD, LDS>(S, bid, its, its.wi, wo, active);
+}
+template <bool AD, int LDS> PSDR_DEV float bsdf_pdf(const SceneView<LDS> &S, const Its<AD> &its, const VecN<AD> &wo, bool active) {
+    const int bid = mesh_bsdf(S, its.mesh);
+    if constexpr (has_mat(LDS)) if (bid >= 0 && (__float_as_int(S.ld(S.T->bsdf_off + 2 * bid).w) & 256)) return normalmap_pdf<AD, LDS>(S, bid, its, wo, active);
+    return bsdf_pdf_id<AD, LDS>(S, bid, its, its.wi, wo, active);
+}
+template <bool AD, int LDS> PSDR_DEV BSDFSample bsdf_sample(const SceneView<LDS> &S, const Its<AD> &its, float s0, float s1, float s2, bool active) {
+    const int bid = mesh_bsdf(S, its.mesh);
+    if constexpr (has_mat(LDS)) if (bid >= 0 && (__float_as_int(S.ld(S.T->bsdf_off + 2 * bid).w) & 256)) return normalmap_sample<AD, LDS>(S, bid, its, s0, s1, s2, active);
+    return bsdf_sample_id<AD, LDS>(S, bid, its, its.wi, s0, s1, s2, active);
+}
+
 
 // FieldExtractionIntegrator::__Li (reference src/integrator/field.cpp:49-121) and CollocatedIntegrator::__Li
 // (src/integrator/collocated.cpp:24-55): a function of the first hit only.  LDS=false instantiations only.

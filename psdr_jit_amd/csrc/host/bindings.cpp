@@ -137,6 +137,30 @@ PYBIND11_MODULE(_psdr_core, m) {
             else if (name == "k") { b.k = to_a3(v); b.d_k = to_a3(t); }
             else { b.specular = to_a3(v); b.d_specular = to_a3(t); } });
 
+    py::class_<NormalMap, BSDF>(m, "NormalMapBSDF", py::dynamic_attr())
+        .def(py::init<>())
+        .def(py::init([](const farr &n) { return new NormalMap(to_a3(n)); }))
+        .def_property_readonly("_nested", [](NormalMap &b) { return b.m_bsdf; }, py::return_value_policy::reference_internal)
+        .def("_set_nested", [](NormalMap &b, const BSDF *n) { b.set_nested(n); })
+        .def("_get", [](const NormalMap &d, const std::string &, bool tangent) {
+            if (d.tex_w > 0) {
+                farr a({(py::ssize_t) d.tex_h, (py::ssize_t) d.tex_w, (py::ssize_t) 3});
+                const std::vector<float> &src = tangent ? d.d_tex : d.tex;
+                if (src.size() == (size_t) a.size()) std::memcpy(a.mutable_data(), src.data(), sizeof(float) * src.size()); else std::memset(a.mutable_data(), 0, sizeof(float) * a.size());
+                return a;
+            }
+            auto &r = tangent ? d.d_normal : d.normal; farr a(3); std::memcpy(a.mutable_data(), r.data(), 12); return a; })
+        .def("_set", [](NormalMap &d, const std::string &, const farr &v, const farr &t) {
+            if (v.ndim() == 3) {
+                if (v.shape(2) != 3 || v.shape(0) < 2 || v.shape(1) < 2) throw Exception("Bitmap: invalid resolution!");
+                d.tex_h = (int) v.shape(0); d.tex_w = (int) v.shape(1);
+                d.tex.assign(v.data(), v.data() + v.size());
+                if (t.size() == v.size()) d.d_tex.assign(t.data(), t.data() + t.size()); else d.d_tex.assign((size_t) v.size(), 0.f);
+                return;
+            }
+            d.tex_w = d.tex_h = 0; d.tex.clear(); d.d_tex.clear();
+            d.normal = to_a3(v); d.d_normal = to_a3(t); });
+
     py::class_<MicrofacetPerVertex, BSDF>(m, "MicrofacetBSDFPerVertex", py::dynamic_attr())
         .def(py::init<>())
         .def("_get", [](const MicrofacetPerVertex &b, const std::string &name, bool tangent) {
@@ -292,6 +316,7 @@ PYBIND11_MODULE(_psdr_core, m) {
         .def("_add_Mesh_file", [](Scene &s, const std::string &f, const farr &t, const std::string &b, const Emitter *e) { s.add_Mesh(f, to_m16(t), b, e); })
         .def("_add_Mesh_obj", [](Scene &s, const Mesh *mesh, const std::string &b, const Emitter *e) { s.add_Mesh(mesh, b, e); })
         .def("add_BSDF", &Scene::add_BSDF, "Add BSDF", "bsdf"_a, "name"_a, "twoSide"_a = false)
+        .def("_add_normalmap_BSDF", &Scene::add_normalmap_BSDF, "bsdf1"_a, "bsdf2"_a, "name"_a, "twoSide"_a = false)
         .def("_configure", &Scene::configure, "active_sensor"_a = std::vector<int>(), py::call_guard<py::gil_scoped_release>())
         .def("_configure_host", &Scene::configure_host, "active_sensor"_a = std::vector<int>())
         .def("is_ready", &Scene::is_ready)

@@ -422,12 +422,44 @@ void Scene::add_Sensor(const Sensor *sensor) {       // scene.cpp:107-126 (the s
     m_num_sensors = (int) m_sensors.size();
     rebuild_param_map();
 }
+// a heap copy of one of the plain BSDFs (nullptr in -> a default Microfacet, as the reference's add_BSDF gives a NormalMap)
+static BSDF *clone_bsdf(const BSDF *b) {
+    if (const Diffuse *d = dynamic_cast<const Diffuse *>(b)) return new Diffuse(*d);
+    if (const Microfacet *m = dynamic_cast<const Microfacet *>(b)) return new Microfacet(*m);
+    if (const RoughConductor *r = dynamic_cast<const RoughConductor *>(b)) return new RoughConductor(*r);
+    if (const RoughDielectric *r = dynamic_cast<const RoughDielectric *>(b)) return new RoughDielectric(*r);
+    if (const MicrofacetPerVertex *r = dynamic_cast<const MicrofacetPerVertex *>(b)) return new MicrofacetPerVertex(*r);
+    PSDR_ASSERT_MSG(b == nullptr, "Unsupported normal map nested BSDF");
+    return new Microfacet();
+}
+NormalMap::~NormalMap() { delete m_bsdf; }
+void NormalMap::set_nested(const BSDF *b) { BSDF *c = clone_bsdf(b); delete m_bsdf; m_bsdf = c; }
+// Scene::add_normalmap_BSDF, reference scene.cpp:128-145
+void Scene::add_normalmap_BSDF(const NormalMap *bsdf, const Microfacet *micro, const std::string &bsdf_id, bool twoSide) {
+    PSDR_ASSERT_MSG(bsdf != nullptr && micro != nullptr, "add_normalmap_BSDF: null argument");
+    NormalMap tmp(*bsdf);
+    tmp.m_bsdf = const_cast<Microfacet *>(micro);          // cloned by add_BSDF
+    try { add_BSDF(&tmp, bsdf_id, twoSide); } catch (...) { tmp.m_bsdf = nullptr; throw; }
+    tmp.m_bsdf = nullptr;
+}
 void Scene::add_BSDF(const BSDF *bsdf, const std::string &bsdf_id, bool twoSide) {      // scene.cpp:148-247
     const Diffuse *d = dynamic_cast<const Diffuse *>(bsdf);
     const Microfacet *mf = dynamic_cast<const Microfacet *>(bsdf);
     const RoughConductor *rc = dynamic_cast<const RoughConductor *>(bsdf);
     const RoughDielectric *rd = dynamic_cast<const RoughDielectric *>(bsdf);     // (the reference only reaches it through the XML loader)
     const MicrofacetPerVertex *pvb = dynamic_cast<const MicrofacetPerVertex *>(bsdf);
+    if (const NormalMap *nm = dynamic_cast<const NormalMap *>(bsdf)) {
+        // (the reference's add_BSDF replaces a NormalMap by a flat one over a default Microfacet, scene.cpp:219-228; its
+        //  add_normalmap_BSDF and its XML loader keep the map and the nested BSDF - as done here)
+        if (m_opts.log_level > 0) std::cout << "add_BSDF: NormalMapBSDF " << bsdf_id << std::endl;
+        PSDR_ASSERT_MSG(m_param_map.find("BSDF[id=" + bsdf_id + "]") == m_param_map.end(), std::string("Duplicate BSDF id: ") + bsdf_id);
+        NormalMap *c = new NormalMap(*nm);
+        c->m_bsdf = clone_bsdf(nm->m_bsdf);
+        c->m_twoSide = twoSide; c->m_id = bsdf_id;
+        m_bsdfs.push_back(c);
+        rebuild_param_map();
+        return;
+    }
     PSDR_ASSERT_MSG(d != nullptr || mf != nullptr || rc != nullptr || rd != nullptr || pvb != nullptr, "Unknown BSDF type!");
     if (m_opts.log_level > 0) std::cout << "add_BSDF: " << bsdf->type_name() << " " << bsdf_id << std::endl;
     PSDR_ASSERT_MSG(m_param_map.find("BSDF[id=" + bsdf_id + "]") == m_param_map.end(), std::string("Duplicate BSDF id: ") + bsdf_id);
@@ -638,7 +670,20 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
             S.emitters.push_back(r);
         }
     }
-    for (BSDF *b : m_bsdfs) {
+    auto rec_of = [&](const BSDF *b, std::vector<psdr_bsdf_rec> &dst) {
+        if (const NormalMap *nm = dynamic_cast<const NormalMap *>(b)) {
+            psdr_bsdf_rec r{};
+            r.type = 5; r.two_sided = nm->m_twoSide ? 1 : 0; r.nested_bsdf = -1;       // patched below
+            for (int k = 0; k < 3; ++k) { r.reflectance[k] = nm->normal[k]; r.d_reflectance[k] = nm->d_normal[k]; }
+            if (nm->tex_w > 0) {
+                PSDR_ASSERT_MSG(nm->tex_w >= 2 && nm->tex_h >= 2, "Bitmap: invalid resolution!");
+                PSDR_ASSERT_MSG(nm->tex.size() == (size_t) 3 * nm->tex_w * nm->tex_h, "Bitmap: invalid data size!");
+                r.tex_width = nm->tex_w; r.tex_height = nm->tex_h; r.tex_data = nm->tex.data();
+                r.d_tex_data = nm->d_tex.size() == nm->tex.size() ? nm->d_tex.data() : nullptr;
+            }
+            dst.push_back(r);
+            return;
+        }
         if (const Microfacet *mf = dynamic_cast<const Microfacet *>(b)) {
             psdr_bsdf_rec r{};
             r.type = 1; r.two_sided = mf->m_twoSide ? 1 : 0;
@@ -665,8 +710,8 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
                 r.rough_tex_width = mf->roughness_tex.w; r.rough_tex_height = mf->roughness_tex.h; r.rough_tex_data = mf->roughness_tex.v.data();
                 r.d_rough_tex_data = mf->roughness_tex.d.size() == mf->roughness_tex.v.size() ? mf->roughness_tex.d.data() : nullptr;
             }
-            S.bsdfs.push_back(r);
-            continue;
+            dst.push_back(r);
+            return;
         }
         if (const RoughConductor *rc = dynamic_cast<const RoughConductor *>(b)) {
             psdr_bsdf_rec r{};
@@ -676,8 +721,8 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
                 r.eta[k] = rc->eta[k]; r.d_eta[k] = rc->d_eta[k]; r.k[k] = rc->k[k]; r.d_k[k] = rc->d_k[k];
                 r.specular[k] = rc->specular[k]; r.d_specular[k] = rc->d_specular[k];
             }
-            S.bsdfs.push_back(r);
-            continue;
+            dst.push_back(r);
+            return;
         }
         if (const MicrofacetPerVertex *pv = dynamic_cast<const MicrofacetPerVertex *>(b)) {
             psdr_bsdf_rec r{};
@@ -689,16 +734,16 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
             r.d_pv_specular = pv->d_specular.size() == 3 * nv ? pv->d_specular.data() : nullptr;
             r.d_pv_diffuse = pv->d_diffuse.size() == 3 * nv ? pv->d_diffuse.data() : nullptr;
             r.d_pv_roughness = pv->d_roughness.size() == nv ? pv->d_roughness.data() : nullptr;
-            S.bsdfs.push_back(r);
-            continue;
+            dst.push_back(r);
+            return;
         }
         if (const RoughDielectric *rd = dynamic_cast<const RoughDielectric *>(b)) {
             psdr_bsdf_rec r{};
             r.type = 3; r.two_sided = rd->m_twoSide ? 1 : 0;
             r.alpha_u = rd->alpha_u; r.alpha_v = rd->alpha_v; r.d_alpha_u = rd->d_alpha_u; r.d_alpha_v = rd->d_alpha_v;
             r.eta[0] = rd->eta; r.eta[1] = rd->inv_eta; r.d_eta[0] = rd->d_eta; r.d_eta[1] = rd->d_inv_eta;
-            S.bsdfs.push_back(r);
-            continue;
+            dst.push_back(r);
+            return;
         }
         const Diffuse *d = static_cast<const Diffuse *>(b);
         psdr_bsdf_rec r{};
@@ -710,8 +755,16 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
             r.tex_width = d->tex_w; r.tex_height = d->tex_h; r.tex_data = d->tex.data();
             r.d_tex_data = d->d_tex.size() == d->tex.size() ? d->d_tex.data() : nullptr;
         }
-        S.bsdfs.push_back(r);
-    }
+        dst.push_back(r);
+    };
+    for (BSDF *b : m_bsdfs) rec_of(b, S.bsdfs);
+    // the BSDF a NormalMap perturbs travels as an extra entry behind the scene's own (no mesh refers to it)
+    for (size_t i = 0; i < m_bsdfs.size(); ++i)
+        if (const NormalMap *nm = dynamic_cast<const NormalMap *>(m_bsdfs[i])) {
+            PSDR_ASSERT_MSG(nm->m_bsdf != nullptr && dynamic_cast<const NormalMap *>(nm->m_bsdf) == nullptr, "NormalMap: missing or unsupported nested BSDF");
+            S.bsdfs[i].nested_bsdf = (int) S.bsdfs.size();
+            rec_of(nm->m_bsdf, S.bsdfs);
+        }
 
     // secondary edges (mesh.cpp:355-369, scene.cpp:546-571): every mesh edge is kept
     if (m_opts.sppse > 0) {

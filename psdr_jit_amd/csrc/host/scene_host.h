@@ -107,6 +107,23 @@ struct MicrofacetPerVertex : BSDF {
     std::vector<float> specular, diffuse, roughness, d_specular, d_diffuse, d_roughness;      // [n*3], [n*3], [n] (+ forward tangents)
 };
 
+// NormalMap, reference include/psdr/bsdf/normalmap.h: a normal map (Bitmap3fD: constant or texture) over a nested BSDF it owns
+struct NormalMap : BSDF {
+    NormalMap() {}
+    explicit NormalMap(const std::array<float, 3> &n) : normal(n) {}
+    NormalMap(const NormalMap &o) : BSDF(o), normal(o.normal), d_normal(o.d_normal), tex_w(o.tex_w), tex_h(o.tex_h), tex(o.tex), d_tex(o.d_tex), m_bsdf(nullptr) {}
+    NormalMap &operator=(const NormalMap &) = delete;
+    ~NormalMap() override;
+    void set_nested(const BSDF *b);                    // takes a copy
+    std::string type_name() const override { return "NormalMap"; }
+    std::string to_string() const override { return std::string("NormalMap[id=") + m_id + "]"; }
+    bool anisotropic() const override { return false; }
+    std::array<float, 3> normal{0.5f, 0.5f, 1.f}, d_normal{0, 0, 0};       // Bitmap3fD with 1x1 resolution
+    int tex_w = 0, tex_h = 0;
+    std::vector<float> tex, d_tex;
+    BSDF *m_bsdf = nullptr;
+};
+
 // RoughDielectric, reference include/psdr/bsdf/roughdielectric.h (constant alpha; m_eta = intIOR / extIOR, m_inv_eta = extIOR / intIOR)
 struct RoughDielectric : BSDF {
     RoughDielectric() { eta = 1.5f / 1.0f; inv_eta = 1.f / eta; }
@@ -225,6 +242,7 @@ struct Scene : Object {
 
     void add_Sensor(const Sensor *sensor);
     void add_BSDF(const BSDF *bsdf, const std::string &bsdf_id, bool twoSide = false);
+    void add_normalmap_BSDF(const NormalMap *bsdf, const Microfacet *micro, const std::string &bsdf_id, bool twoSide = false);
     void add_Mesh(const std::string &fname, const M16 &transform, const std::string &bsdf_id, const Emitter *emitter);
     void add_Mesh(const Mesh *mesh, const std::string &bsdf_id, const Emitter *emitter);
     void add_EnvironmentMap(const EnvironmentMap *emitter);             // scene.cpp:85-105 (one per scene)

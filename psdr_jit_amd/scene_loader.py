@@ -120,6 +120,40 @@ def _parse_bitmap(node, base_dir):
     return _resolve(fn.get("value"), base_dir)
 
 
+def _load_plain_bsdf(node, btype, psdr, base_dir):
+    """the BSDFs that can stand alone or inside a normal map (scene_loader.cpp:325-372, 381-425); None for another type"""
+    b = None
+    if btype == "diffuse":
+        refl = _child_by_name(node, {"reflectance"})
+        if refl.tag == "texture":
+            b = psdr.DiffuseBSDF(psdr.Bitmap3fD(_parse_bitmap(refl, base_dir)))
+        else:
+            b = psdr.DiffuseBSDF(_load_rgb(refl))
+    elif btype == "microfacet":
+        nodes = [_child_by_name(node, {"specular_reflectance", "specularReflectance"}), _child_by_name(node, {"diffuse_reflectance", "diffuseReflectance"}),
+                 _child_by_name(node, {"roughness"})]
+        # load_texture (scene_loader.cpp:289-319): a <texture> child is a bitmap file, anything else a constant;
+        # a one-channel Bitmap takes the first channel of the image (bitmap.cpp:38-39)
+        vals = [psdr.Bitmap3fD(_parse_bitmap(n, base_dir)) if n.tag == "texture" else _load_rgb(n) for n in nodes[:2]]
+        if nodes[2].tag == "texture":
+            vals.append(psdr.Bitmap1fD(np.ascontiguousarray(psdr.Bitmap3fD(_parse_bitmap(nodes[2], base_dir)).data[..., 0])))
+        else:
+            vals.append(float(nodes[2].get("value")))
+        b = psdr.MicrofacetBSDF(*vals)
+    elif btype == "roughconductor":
+        nodes = [_child_by_name(node, {"alpha"}), _child_by_name(node, {"eta"}), _child_by_name(node, {"k"})]
+        if any(n.tag == "texture" for n in nodes):
+            raise _Err("RoughConductorBSDF: bitmap parameters are not built, only constants")
+        b = psdr.RoughConductorBSDF(float(nodes[0].get("value")), _load_rgb(nodes[1]), _load_rgb(nodes[2]))
+    elif btype == "roughdielectric":     # scene_loader.cpp:346-360
+        alpha = _child_by_name(node, {"alpha"})
+        if alpha.tag == "texture":
+            raise _Err("RoughDielectricBSDF: bitmap parameters are not built, only constants")
+        ior = [_child_by_name(node, {"intIOR"}), _child_by_name(node, {"extIOR"})]
+        b = psdr.RoughDielectricBSDF(float(alpha.get("value")), float(ior[0].get("value")), float(ior[1].get("value")))
+    return b
+
+
 def load_scene(root, scene, psdr, base_dir=None):
     if root.tag != "scene":
         raise _Err("XML parsing failed")
@@ -160,36 +194,19 @@ def load_scene(root, scene, psdr, base_dir=None):
         if not bsdf_id:
             raise _Err("BSDF must have an id")
         btype = node.get("type")
-        if btype == "diffuse":
-            refl = _child_by_name(node, {"reflectance"})
-            if refl.tag == "texture":
-                b = psdr.DiffuseBSDF(psdr.Bitmap3fD(_parse_bitmap(refl, base_dir)))
-            else:
-                b = psdr.DiffuseBSDF(_load_rgb(refl))
-        elif btype == "microfacet":
-            nodes = [_child_by_name(node, {"specular_reflectance", "specularReflectance"}), _child_by_name(node, {"diffuse_reflectance", "diffuseReflectance"}),
-                     _child_by_name(node, {"roughness"})]
-            # load_texture (scene_loader.cpp:289-319): a <texture> child is a bitmap file, anything else a constant;
-            # a one-channel Bitmap takes the first channel of the image (bitmap.cpp:38-39)
-            vals = [psdr.Bitmap3fD(_parse_bitmap(n, base_dir)) if n.tag == "texture" else _load_rgb(n) for n in nodes[:2]]
-            if nodes[2].tag == "texture":
-                vals.append(psdr.Bitmap1fD(np.ascontiguousarray(psdr.Bitmap3fD(_parse_bitmap(nodes[2], base_dir)).data[..., 0])))
-            else:
-                vals.append(float(nodes[2].get("value")))
-            b = psdr.MicrofacetBSDF(*vals)
-        elif btype == "roughconductor":
-            nodes = [_child_by_name(node, {"alpha"}), _child_by_name(node, {"eta"}), _child_by_name(node, {"k"})]
-            if any(n.tag == "texture" for n in nodes):
-                raise _Err("RoughConductorBSDF: bitmap parameters are not built, only constants")
-            b = psdr.RoughConductorBSDF(float(nodes[0].get("value")), _load_rgb(nodes[1]), _load_rgb(nodes[2]))
-        elif btype == "roughdielectric":     # scene_loader.cpp:346-360
-            alpha = _child_by_name(node, {"alpha"})
-            if alpha.tag == "texture":
-                raise _Err("RoughDielectricBSDF: bitmap parameters are not built, only constants")
-            ior = [_child_by_name(node, {"intIOR"}), _child_by_name(node, {"extIOR"})]
-            b = psdr.RoughDielectricBSDF(float(alpha.get("value")), float(ior[0].get("value")), float(ior[1].get("value")))
-        elif btype == "normalmap":
-            raise _Err("Unknown BSDF type! (normalmap is not built)")
+        b = _load_plain_bsdf(node, btype, psdr, base_dir)
+        if b is not None:
+            pass
+        elif btype == "normalmap":           # scene_loader.cpp:373-430: a <bsdf> child is the BSDF the map perturbs
+            inner = node.find("bsdf")
+            if inner is None:
+                raise _Err("Unsupported normal map nested BSDF: none")
+            nested = _load_plain_bsdf(inner, inner.get("type"), psdr, base_dir)
+            if nested is None:
+                raise _Err("Unsupported normal map nested BSDF: " + str(inner.get("type")))
+            nm_node = _child_by_name(node, {"normalmap"})
+            b = psdr.NormalMapBSDF(psdr.Bitmap3fD(_parse_bitmap(nm_node, base_dir)) if nm_node.tag == "texture" else _load_rgb(nm_node))
+            b.nested_bsdf = nested
         else:
             raise _Err("Unsupported BSDF: " + str(btype))
         scene.add_BSDF(b, bsdf_id)

@@ -15,7 +15,40 @@ def build_scene(spec, configure=True, active=(0,), host_only=False, log_level=0)
         cam._set("to_world_left", c.to_world_left, c.d_to_world_left)
         cam._set("to_world_right", c.to_world_right, c.d_to_world_right)
         sc.add_Sensor(cam)
+    def plain_bsdf(b):
+        """a stand-alone psdr BSDF object for one BsdfSpec of type 0-3 (used for the BSDF nested in a NormalMap)"""
+        f1 = lambda x: np.asarray([x], np.float32)
+        t = getattr(b, "type", 0)
+        if t == 1:
+            bs = psdr.MicrofacetBSDF(list(b.specular), list(b.reflectance), float(b.roughness))
+            bs._set("specularReflectance", np.asarray(b.specular, np.float32), np.asarray(b.d_specular, np.float32))
+            bs._set("diffuseReflectance", np.asarray(b.reflectance, np.float32), np.asarray(b.d_reflectance, np.float32))
+            bs._set("roughness", f1(b.roughness), f1(b.d_roughness))
+        elif t == 2:
+            bs = psdr.RoughConductorBSDF()
+            bs._set("alpha_u", f1(b.alpha_u), f1(b.d_alpha_u)); bs._set("alpha_v", f1(b.alpha_v), f1(b.d_alpha_v))
+            bs._set("eta", np.asarray(b.eta, np.float32), np.asarray(b.d_eta, np.float32))
+            bs._set("k", np.asarray(b.k, np.float32), np.asarray(b.d_k, np.float32))
+            bs._set("specular_reflectance", np.asarray(b.specular, np.float32), np.asarray(b.d_specular, np.float32))
+        elif t == 0:
+            bs = psdr.DiffuseBSDF(list(b.reflectance))
+            bs._set("reflectance", np.asarray(b.reflectance, np.float32), np.asarray(b.d_reflectance, np.float32))
+        else:
+            raise ValueError("nested BSDF type %d" % t)
+        bs.twoSide = bool(b.two_sided)
+        return bs
+
     for i, b in enumerate(spec.bsdfs):
+        if getattr(b, "type", 0) == 5:              # NormalMapBSDF over spec.bsdfs[b.nested] (which the scene also holds as its own entry)
+            nm = psdr.NormalMapBSDF(list(b.reflectance))
+            nm._set("normal_map", np.asarray(b.reflectance, np.float32), np.asarray(b.d_reflectance, np.float32))
+            if getattr(b, "texture", None) is not None:
+                tex = np.ascontiguousarray(np.asarray(b.texture, np.float32))
+                dtex = np.ascontiguousarray(np.asarray(b.d_texture, np.float32)) if getattr(b, "d_texture", None) is not None else np.zeros_like(tex)
+                nm._set("normal_map", tex, dtex)
+            nm.nested_bsdf = plain_bsdf(spec.bsdfs[b.nested])
+            sc.add_BSDF(nm, b.name or ("bsdf%d" % i), b.two_sided)
+            continue
         if getattr(b, "type", 0) == 1:
             bs = psdr.MicrofacetBSDF(list(b.specular), list(b.reflectance), float(b.roughness))
             bs._set("specularReflectance", np.asarray(b.specular, np.float32), np.asarray(b.d_specular, np.float32))

@@ -437,3 +437,42 @@ def pervertex_scene(width=48, height=48, spp=4, sppe=0, sppse=0, param=None):
     elif param is not None:
         raise ValueError(param)
     return spec
+
+
+def bumpy_normal_map(width=16, height=16, amp=0.35):
+    """A smooth normal map (rgb = 0.5 + 0.5 n, n the unit normal of a sine bump field), bitmap.cpp conventions"""
+    yy, xx = np.meshgrid(np.linspace(0, 1, height, dtype=np.float32), np.linspace(0, 1, width, dtype=np.float32), indexing="ij")
+    nx, ny = amp * np.cos(7 * xx) * np.sin(5 * yy), amp * np.sin(6 * xx + 1.0) * np.cos(4 * yy)
+    n = np.stack([nx, ny, np.ones_like(nx)], axis=-1)
+    n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    return (0.5 + 0.5 * n).astype(np.float32)
+
+
+def normalmap_scene(width=48, height=48, spp=4, sppe=0, sppse=0, param=None, nested="microfacet", nmap="bumpy"):
+    """textured_scene (Cornell luminaire) whose uv-mapped floor is a NormalMapBSDF (reference src/bsdf/normalmap.cpp) over a
+    Microfacet / Diffuse / RoughConductor BSDF.  nmap: 'bumpy' (16x16 map) | 'flat' (the constant (.499999, .499999, 1) the reference's
+    add_BSDF uses) | 'tilted' (a constant).  param: 'nmap' (d texel / dP = (1, 0.5, 0)) | 'nested' (d nested diffuse colour) | 'box_x' | None"""
+    spec = textured_scene(width, height, spp, sppe, sppse, texture=checker_texture(8, 8), param="box_x" if param == "box_x" else None, env=False)
+    inner = {"microfacet": BsdfSpec((0.3, 0.25, 0.2), name="inner", type=1, specular=(0.7, 0.6, 0.5), roughness=0.35),
+             "diffuse": BsdfSpec((0.6, 0.5, 0.4), name="inner"),
+             "roughconductor": BsdfSpec(name="inner", type=2, alpha_u=0.2, alpha_v=0.3, eta=(0.2, 0.9, 1.1), k=(3.9, 2.4, 2.1), specular=(1.0, 0.9, 0.8))}[nested]
+    spec.bsdfs.append(inner)
+    b = spec.bsdfs[0]
+    b.type, b.nested, b.texture = 5, len(spec.bsdfs) - 1, None
+    if nmap == "bumpy":
+        b.texture = bumpy_normal_map()
+    elif nmap == "flat":
+        b.reflectance = (0.499999, 0.499999, 1.0)
+    else:
+        b.reflectance = (0.62, 0.43, 0.93)
+    if param == "nmap":
+        if b.texture is not None:
+            d = np.zeros_like(b.texture); d[..., 0], d[..., 1] = 1.0, 0.5
+            b.d_texture = d
+        else:
+            b.d_reflectance = (1.0, 0.5, 0.0)
+    elif param == "nested":
+        inner.d_reflectance = (1.0, 1.0, 1.0)
+    elif param not in (None, "box_x"):
+        raise ValueError(param)
+    return spec

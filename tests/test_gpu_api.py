@@ -569,3 +569,42 @@ def test_ggx_constant_parameters_reverse_mode(psdr, orc, kind):
         assert t.grad is not None, name
         got = float((t.grad * v).sum())
         assert abs(want) > 1e-4 and abs(got - want) < 3e-3 * max(1.0, abs(want)), (kind, name, got, want)
+
+
+@pytest.mark.parametrize("nested,nmap,param", [("microfacet", "bumpy", "nmap"), ("microfacet", "bumpy", "box_x"), ("diffuse", "tilted", "nmap"),
+                                               ("roughconductor", "bumpy", None), ("microfacet", "flat", "nested")])
+def test_normalmap_bsdf(psdr, orc, nested, nmap, param):
+    """psdr.NormalMapBSDF (reference normalmap.cpp: the map's normal and a tangent facet, the nested BSDF evaluated / sampled in the
+    perturbed frame) against the oracle: image, texel / constant tangents of the map, of the nested BSDF and of the geometry"""
+    spec = scenes.normalmap_scene(48, 48, 8, 8, 8, param=param, nested=nested, nmap=nmap)
+    sc = product.build_scene(spec)
+    ref = orc.OracleScene(spec, [0])
+    integ = psdr.PathTracer(2)
+    c = integ.renderC(sc, 0, seed=3).cpu().numpy()
+    assert np.isfinite(c).all() and product.rel_l2(c, ref.render_c(max_depth=2, seed=3)) < 1e-3
+    img, dimg = psdr.render_d_fwd(integ, sc, 0, seed=6)
+    wimg, wd = ref.render_d(max_depth=2, seeds=(6, 6, 6))
+    assert product.rel_l2(img.cpu().numpy(), wimg) < 1e-3
+    if param is not None:
+        assert np.abs(wd).max() > 0 and product.rel_l2(dimg.cpu().numpy(), wd) < 1e-3
+    live = sc.param_map["BSDF[id=tex]"]
+    assert type(live).__name__ == "NormalMapBSDF" and type(live.nested_bsdf).__name__ in ("MicrofacetBSDF", "DiffuseBSDF", "RoughConductorBSDF")
+
+
+def test_normalmap_api_and_xml(psdr, orc):
+    """Scene.add_normalmap_BSDF(NormalMapBSDF, MicrofacetBSDF, name) and the XML form (scene_loader.cpp:373-430)"""
+    nm = psdr.NormalMapBSDF([0.6, 0.45, 0.9])
+    mf = psdr.MicrofacetBSDF([0.7, 0.6, 0.5], [0.3, 0.25, 0.2], 0.35)
+    sc = psdr.Scene()
+    sc.opts.log_level = 0
+    sc.add_normalmap_BSDF(nm, mf, "n")
+    live = sc.param_map["BSDF[id=n]"]
+    assert np.allclose(np.asarray(live.normal_map), [0.6, 0.45, 0.9]) and abs(float(np.asarray(live.nested_bsdf.roughness)[0]) - 0.35) < 1e-7
+    x = psdr.Scene()
+    x.opts.log_level = 0
+    x.load_string('<scene><bsdf type="normalmap" id="g"><rgb name="normalmap" value="0.5, 0.5, 1.0"/><bsdf type="roughconductor">'
+                  '<float name="alpha" value="0.2"/><rgb name="eta" value="0.2, 0.9, 1.1"/><rgb name="k" value="3.9, 2.4, 2.1"/></bsdf></bsdf></scene>', False)
+    g = x.param_map["BSDF[id=g]"]
+    assert type(g).__name__ == "NormalMapBSDF" and type(g.nested_bsdf).__name__ == "RoughConductorBSDF"
+    with pytest.raises(RuntimeError, match="Unsupported normal map nested BSDF"):
+        psdr.Scene().load_string('<scene><bsdf type="normalmap" id="g"><rgb name="normalmap" value="0.5"/><bsdf type="normalmap"/></bsdf></scene>', False)

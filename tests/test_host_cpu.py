@@ -162,7 +162,7 @@ def test_xml_scene_loader(psdr, tmp_path):
     g = rd.param_map["BSDF[id=g]"]
     assert type(g).__name__ == "RoughDielectricBSDF" and float(np.asarray(g._get("eta", False))[0]) == np.float32(1.5) / np.float32(1.2)
     assert float(np.asarray(g._get("inv_eta", False))[0]) == np.float32(1.2) / np.float32(1.5) and float(np.asarray(g._get("alpha_v", False))[0]) == np.float32(0.2)
-    with pytest.raises(RuntimeError, match="Unknown BSDF type"):
+    with pytest.raises(RuntimeError, match="Unsupported normal map nested BSDF"):
         psdr.Scene().load_string('<scene><bsdf type="normalmap" id="a"/></scene>', False)
     with pytest.raises(RuntimeError, match="BSDF must have an id"):
         psdr.Scene().load_string('<scene><bsdf type="diffuse"><rgb name="reflectance" value="1"/></bsdf></scene>', False)

@@ -523,3 +523,34 @@ def test_microfacet_per_vertex_known_answers(orc):
         fd = (scene_of(up).render_c(max_depth=1, seed=3) - scene_of(dn).render_c(max_depth=1, seed=3)) / (2 * h)
         rel = float(np.linalg.norm(dimg - fd) / np.linalg.norm(fd))
         assert np.abs(fd).sum() > 0.1 and rel < (3e-2 if param == "roughness" else 6e-3), (param, rel)
+
+
+def test_normalmap_known_answers(orc):
+    """NormalMap restatement (normalmap.cpp): the flat map the reference's add_BSDF installs leaves a Diffuse BSDF unchanged under
+    emitter sampling; a tilted constant map moves energy but keeps it finite and non-negative; the tangent of the map's texels equals
+    finite differences (emitter sampling only, so that the sample placement does not depend on the map)"""
+    def scene_of(sp):
+        o = orc.OracleScene(sp, [0]); o.set_direct_mis(0); return o
+    flat = scenes.normalmap_scene(24, 24, 16, 0, 0, nested="diffuse", nmap="flat")
+    plain = scenes.normalmap_scene(24, 24, 16, 0, 0, nested="diffuse", nmap="flat")
+    plain.meshes[0].bsdf = plain.bsdfs[0].nested            # the floor uses the inner Diffuse BSDF directly
+    a = scene_of(flat).render_c(max_depth=1, seed=2)
+    b = scene_of(plain).render_c(max_depth=1, seed=2)
+    assert b.max() > 0 and np.allclose(a, b, rtol=2e-4, atol=1e-6)
+    for nested in ("diffuse", "microfacet", "roughconductor"):
+        t = scene_of(scenes.normalmap_scene(24, 24, 16, 0, 0, nested=nested, nmap="tilted")).render_c(max_depth=2, seed=2)
+        assert np.isfinite(t).all() and t.min() >= 0 and t.max() > 0
+        assert product_rel(t, scene_of(scenes.normalmap_scene(24, 24, 16, 0, 0, nested=nested, nmap="flat")).render_c(max_depth=2, seed=2)) > 0.02
+    sp = scenes.normalmap_scene(24, 24, 32, 0, 0, param="nmap")
+    _, dimg = scene_of(sp).render_d(max_depth=1, seeds=(3, 3, 3))
+    h = 2e-3
+    up, dn = scenes.normalmap_scene(24, 24, 32, 0, 0), scenes.normalmap_scene(24, 24, 32, 0, 0)
+    d = np.zeros_like(up.bsdfs[0].texture); d[..., 0], d[..., 1] = 1.0, 0.5
+    up.bsdfs[0].texture = up.bsdfs[0].texture + np.float32(h) * d
+    dn.bsdfs[0].texture = dn.bsdfs[0].texture - np.float32(h) * d
+    fd = (scene_of(up).render_c(max_depth=1, seed=3) - scene_of(dn).render_c(max_depth=1, seed=3)) / (2 * h)
+    assert np.abs(fd).sum() > 0.1 and product_rel(dimg, fd) < 0.03, product_rel(dimg, fd)
+
+
+def product_rel(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-20))
