@@ -21,9 +21,9 @@ constexpr int kAdjMaxDepth = 4;
 constexpr int kAdjHitWords = 4 * (1 + 2 * kAdjMaxDepth);      // recorded hits per lane
 constexpr int kAdjExtWords = 8;                                // light-sample slots per lane
 constexpr int kAdjLkWords = 3 * kAdjMaxLookups;                // bitmap lookups per lane (id, u, v)
-// LDS words per lane of the interior adjoint kernel: the small-scene (LDS = true) instantiation has no bitmap / environment
-// lookups (such scenes are never staged into LDS), so it carries no lookup record and keeps two workgroups per CU
-template <int LDS> constexpr int adj_lane_words() { return kAdjHitWords + kAdjExtWords + (in_lds(LDS) ? 0 : kAdjLkWords); }
+// LDS words per lane of the interior adjoint kernel: scenes without bitmap / per-vertex parameters and without an environment map
+// make no lookups, carry no lookup record and keep more workgroups per CU (AdjointParams::lk_words)
+inline __host__ __device__ int adj_lane_words(bool with_lookups) { return kAdjHitWords + kAdjExtWords + (with_lookups ? kAdjLkWords : 0); }
 // the secondary-edge adjoint records three hits per lane, followed by 16 floats of camera-pose accumulators
 constexpr int kSecAdjLaneWords = 12;
 constexpr int kSecAdjScratch = kSecAdjLaneWords * kBlock + 16;
@@ -48,6 +48,7 @@ struct AdjointParams {
     float *g_tex;                   // texel adjoints of the bitmap parameters (TexDev::g_off), or NULL
     float *g_cam;                   // [16] adjoint of the sensor's to_world (row major, rows 0-2 filled), or NULL
     float *g_env, *g_env_scale;     // texel adjoints [H*W*3] and scale adjoint [1] of the environment map, or NULL
+    int lk_words;                   // kAdjLkWords when the scene can make lookups (bitmaps, per-vertex values, environment map), else 0
     float *g_mat;                   // [n_bsdfs*16] adjoints of the constant parameters of the GGX BSDFs (psdr_grads.g_mat), or NULL
 };
 
@@ -71,7 +72,7 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
     float *rec = scratch + threadIdx.x;
     int *ext = reinterpret_cast<int *>(scratch + kAdjHitWords * kBlock) + threadIdx.x;
     float *lk = scratch + (kAdjHitWords + kAdjExtWords) * kBlock + threadIdx.x;
-    float *acc_cam = scratch + adj_lane_words<LDS>() * kBlock;        // 16 floats, always in LDS: every path adds to the same 12 entries
+    float *acc_cam = scratch + (kAdjHitWords + kAdjExtWords + P.lk_words) * kBlock;        // 16 floats, always in LDS: every path adds to the same 12 entries
     float *acc_mat = acc_cam + 16;                               // [n_bsdfs * kMatRow], always in LDS like the camera block
     float *acc = acc_mat + T.n_bsdfs * kMatRow;
     const int n_acc = T.n_tris * 22 + T.n_bsdfs * 3 + T.n_emitters * 3;

@@ -966,13 +966,18 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     };
     const size_t n_acc = (size_t) T.n_tris * 22 + (size_t) T.n_bsdfs * 3 + (size_t) T.n_emitters * 3;
     const bool lds_acc = n_acc * sizeof(float) <= 32 * 1024;
-    const size_t adj_bytes = sizeof(float) * ((size_t) (use_lds ? adj_lane_words<true>() : adj_lane_words<false>()) * kBlock + 16 + (size_t) T.n_bsdfs * kMatRow + (lds_acc ? n_acc : 0));
-    const size_t smem = sc->smem_bytes + adj_bytes;
+    const bool with_lookups = T.tex != nullptr || T.pv != nullptr || T.env_emitter >= 0;
+    // PSDR_ADJ_GLOBAL=1: run the interior adjoint of an LDS-class scene from global memory (no blob copy in LDS: more workgroups per CU)
+    static const bool adj_global = std::getenv("PSDR_ADJ_GLOBAL") != nullptr;
+    const int adj_cls = (use_lds && !adj_global) ? 1 : ((sc->lean || use_lds) && a->field_mode == 0 ? 2 : 0);
+    const size_t adj_bytes = sizeof(float) * ((size_t) adj_lane_words(with_lookups) * kBlock + 16 + (size_t) T.n_bsdfs * kMatRow + (lds_acc ? n_acc : 0));
+    const size_t smem = (adj_cls == 1 ? sc->smem_bytes : sc->smem_bytes - (sc->lds ? (size_t) T.blob_words * 16 : 0)) + adj_bytes;
     if (smem > 160 * 1024) return fail("scene too large for the adjoint kernel's LDS records");
     static bool attr_set = false;
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute((const void *) k_interior_adjoint<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *) k_interior_adjoint<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *) k_interior_adjoint<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *) k_secondary_edges<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *) k_secondary_edges<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
@@ -990,8 +995,10 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         if (P.n_local > 0) {
             if (next_queue(P.counter)) return 1;
             const int grid = grid_for(sc, P.n_local);
-            if (use_lds) hipLaunchKernelGGL((k_interior_adjoint<true>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, cam, P);
-            else hipLaunchKernelGGL((k_interior_adjoint<false>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, cam, P);
+            P.lk_words = with_lookups ? kAdjLkWords : 0;
+            if (adj_cls == 1) hipLaunchKernelGGL((k_interior_adjoint<1>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, cam, P);
+            else if (adj_cls == 2) hipLaunchKernelGGL((k_interior_adjoint<2>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, cam, P);
+            else hipLaunchKernelGGL((k_interior_adjoint<0>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, cam, P);
         }
     }
     if ((terms & PSDR_TERM_PRIMARY) && T.sppe > 0 && cam.n_edges > 0) {
