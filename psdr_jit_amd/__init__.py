@@ -164,6 +164,16 @@ class Bitmap3fD:
         return (self.data.shape[1], self.data.shape[0])
 
 
+def _bitmap_eval(self, uv, flip_v=True, envmap_mode=False):
+    """Bitmap::eval(uv[N, 2]) (reference bitmap.cpp:47-128, default translate / rotate / scale) -> [N, channels] numpy array"""
+    from .host_utils import bitmap_eval
+    uv = uv.detach().cpu().numpy() if isinstance(uv, _torch.Tensor) else uv
+    return bitmap_eval(self.data, uv, flip_v, envmap_mode)
+
+
+Bitmap3fD.eval = _bitmap_eval
+
+
 class Bitmap1fD:
     """Stand-in for the reference's Bitmap1fD: an [H, W] array (Bitmap1fD(), Bitmap1fD(value), Bitmap1fD(width, height, data))."""
 
@@ -181,6 +191,10 @@ class Bitmap1fD:
     @property
     def resolution(self):
         return (self.data.shape[1], self.data.shape[0])
+
+
+Bitmap1fD.eval = _bitmap_eval
+from .host_utils import Sampler, DiscreteDistribution  # noqa: E402,F401
 
 
 def _const_of(x, n):

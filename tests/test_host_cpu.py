@@ -425,3 +425,36 @@ def test_exr_piz_tutorial_envmap(psdr):
     assert np.abs(np.diff(img, axis=1)).mean() < 0.2 * img.mean()
     e = psdr.EnvironmentMap(path)
     assert e.width == 1024 and e.height == 512
+
+
+def test_python_sampler_and_distribution_match_the_fixtures(psdr, orc):
+    """psdr.Sampler (numpy, host_utils.py) reproduces the frozen TEA-64 / PCG32 tables bit for bit; psdr.DiscreteDistribution and
+    Bitmap.eval agree with the oracle's restatements"""
+    import json
+    from psdr_jit_amd import host_utils
+    here = os.path.dirname(os.path.abspath(__file__))
+    for v0, v1, want in json.load(open(os.path.join(here, "golden", "tea64.json"))):
+        got = host_utils._tea64(np.array([int(v0)], np.uint64), np.array([int(v1)], np.uint64))
+        assert int(got[0]) == int(want)
+    for rec in json.load(open(os.path.join(here, "golden", "sampler_floats.json"))):
+        lane, sv = int(rec["lane"]), int(rec["seed_value"])
+        s = psdr.Sampler()
+        s.seed(np.array([sv], np.uint64), lane_index=[lane])
+        bits = [int(s.next_1d()[0].view(np.uint32)) for _ in rec["bits"]]
+        assert bits == rec["bits"], (lane, sv)
+    d = psdr.DiscreteDistribution()
+    pmf = np.array([0.5, 0.0, 2.0, 1.5, 0.25], np.float32)
+    d.init(pmf)
+    assert abs(d.sum - 4.25) < 1e-6 and np.allclose(d.pmf(), pmf / 4.25)
+    u = np.array([0.0, 0.1, 0.1177, 0.3, 0.6, 0.95, 0.999], np.float32)
+    idx, p = d.sample(u)
+    assert list(idx) == [0, 0, 2, 2, 3, 4, 4] and np.allclose(p, pmf[idx] / 4.25)
+    # Bitmap::eval: texel centres of a ramp, both modes
+    tex = scenes.ramp_texture()
+    b = psdr.Bitmap3fD(tex)
+    H, W = tex.shape[:2]
+    uv = np.array([[0.0, 0.0], [1.0 - 1e-6, 0.0], [0.5, -0.5]], np.float32)
+    got = b.eval(uv)
+    assert np.allclose(got[0], tex[0, 0], atol=1e-5) and np.allclose(got[1], tex[0, W - 1], atol=1e-4)
+    one = psdr.Bitmap3fD([0.2, 0.4, 0.6])
+    assert np.allclose(one.eval(uv), [[0.2, 0.4, 0.6]] * 3)
