@@ -346,6 +346,21 @@ template <bool ad> static V3d pv_interp3(const std::vector<float> &v, const std:
 
 // ---------------------------------------------------------------- Diffuse BSDF (diffuse.cpp:24-108)
 // a mesh without BSDF (the envmap's bounding cube): drjit's vcall on a null pointer returns zeros
+// RoughConductor / RoughDielectric parameters with their optional bitmaps (roughconductor.cpp:37-43, roughdielectric.cpp:75-78):
+// tex = eta map, spec_tex = k map, rough_tex = alpha map (both axes, as the XML loader fills them)
+template <bool ad> static ConductorParams conductor_params(const BsdfC &b, const V2<Real<ad>> &uv) {
+    ConductorParams P{b.alpha_u, b.alpha_v, b.eta, b.k, b.specular, b.two_sided};
+    if (b.tex_w != 0) { const V3<Real<ad>> t = bsdf_reflectance<ad>(b, uv); P.eta = V3d(Dual(t.x), Dual(t.y), Dual(t.z)); }
+    if (b.spec_w != 0) P.k = bsdf_specular<ad>(b, uv);
+    if (b.rough_w != 0) { P.alpha_u = bsdf_roughness<ad>(b, uv); P.alpha_v = P.alpha_u; }
+    return P;
+}
+template <bool ad> static DielectricParams dielectric_params(const BsdfC &b, const V2<Real<ad>> &uv) {
+    DielectricParams P{b.alpha_u, b.alpha_v, b.eta.x, b.eta.y, b.two_sided};
+    if (b.rough_w != 0) { P.alpha_u = bsdf_roughness<ad>(b, uv); P.alpha_v = P.alpha_u; }
+    return P;
+}
+
 // (bid, wi) are explicit so that NormalMap can evaluate its nested BSDF with a perturbed incident direction
 template <bool ad> static V3<Real<ad>> bsdf_eval_id(const Scene &sc, int bid, const Its<ad> &its, const V3<Real<ad>> &wi_, V3<Real<ad>> wo, bool active) {
     using R = Real<ad>; using V = V3<R>;
@@ -358,7 +373,7 @@ template <bool ad> static V3<Real<ad>> bsdf_eval_id(const Scene &sc, int bid, co
         return microfacet_eval<ad>(P, wi_, wo, active);
     }
     if (b.type == 2) {          // RoughConductor (roughconductor.cpp)
-        ConductorParams P{b.alpha_u, b.alpha_v, b.eta, b.k, b.specular, b.two_sided};
+        const ConductorParams P = conductor_params<ad>(b, its.uv);
         return conductor_eval<ad>(P, wi_, wo, active);
     }
     if (b.type == 4) {          // MicrofacetPerVertex (microfacet_pv.cpp): parameters interpolated over the hit triangle's vertices
@@ -367,7 +382,7 @@ template <bool ad> static V3<Real<ad>> bsdf_eval_id(const Scene &sc, int bid, co
         return microfacet_pv_eval<ad>(P, wi_, wo, active);
     }
     if (b.type == 3) {          // RoughDielectric (roughdielectric.cpp); eta.x = intIOR / extIOR, eta.y = extIOR / intIOR
-        DielectricParams P{b.alpha_u, b.alpha_v, b.eta.x, b.eta.y, b.two_sided};
+        const DielectricParams P = dielectric_params<ad>(b, its.uv);
         return dielectric_eval<ad>(P, wi_, wo, active);
     }
     R wiz = wi_.z;
@@ -384,7 +399,7 @@ template <bool ad> static float bsdf_pdf_id(const Scene &sc, int bid, const Its<
         return microfacet_pdf(P, detach(wi_), detach(wo_), active);
     }
     if (b.type == 2) {
-        ConductorParams P{b.alpha_u, b.alpha_v, b.eta, b.k, b.specular, b.two_sided};
+        const ConductorParams P = conductor_params<ad>(b, its.uv);
         return conductor_pdf(P, detach(wi_), detach(wo_), active);
     }
     if (b.type == 4) {
@@ -392,7 +407,7 @@ template <bool ad> static float bsdf_pdf_id(const Scene &sc, int bid, const Its<
         return microfacet_pdf(P, detach(wi_), detach(wo_), active);
     }
     if (b.type == 3) {
-        DielectricParams P{b.alpha_u, b.alpha_v, b.eta.x, b.eta.y, b.two_sided};
+        const DielectricParams P = dielectric_params<ad>(b, its.uv);
         return dielectric_pdf(P, detach(wi_), detach(wo_), active);
     }
     float wiz = detach(wi_.z), woz = detach(wo_.z);
@@ -417,13 +432,13 @@ template <bool ad> static BSDFSample bsdf_sample_id(const Scene &sc, int bid, co
         return r;
     }
     if (b.type == 2) {
-        ConductorParams P{b.alpha_u, b.alpha_v, b.eta, b.k, b.specular, b.two_sided};
+        const ConductorParams P = conductor_params<ad>(b, its.uv);
         const MicrofacetSample m = conductor_sample(P, detach(wi_), s3, active);
         BSDFSample r; r.wo = m.wo; r.pdf = m.pdf; r.valid = m.valid;
         return r;
     }
     if (b.type == 3) {
-        DielectricParams P{b.alpha_u, b.alpha_v, b.eta.x, b.eta.y, b.two_sided};
+        const DielectricParams P = dielectric_params<ad>(b, its.uv);
         const MicrofacetSample m = dielectric_sample(P, detach(wi_), s3, active);
         BSDFSample r; r.wo = m.wo; r.pdf = m.pdf; r.valid = m.valid;
         return r;

@@ -224,12 +224,14 @@ def _rough_shape(self, value):
 MicrofacetBSDF.specularReflectance = _make_param_property("specularReflectance", _refl_shape)
 MicrofacetBSDF.diffuseReflectance = _make_param_property("diffuseReflectance", _refl_shape)
 MicrofacetBSDF.roughness = _make_param_property("roughness", _rough_shape)
+# alpha / eta / k of RoughConductor and alpha of RoughDielectric may be bitmaps above 1x1 (an alpha map serves both axes)
 for _n in ("alpha_u", "alpha_v"):
-    setattr(RoughConductorBSDF, _n, _make_param_property(_n, lambda self, value: (1,)))
-for _n in ("eta", "k", "specular_reflectance"):
-    setattr(RoughConductorBSDF, _n, _make_param_property(_n, _v3))
-for _n in ("alpha_u", "alpha_v", "eta"):
-    setattr(RoughDielectricBSDF, _n, _make_param_property(_n, lambda self, value: (1,)))
+    setattr(RoughConductorBSDF, _n, _make_param_property(_n, _rough_shape))
+    setattr(RoughDielectricBSDF, _n, _make_param_property(_n, _rough_shape))
+for _n in ("eta", "k"):
+    setattr(RoughConductorBSDF, _n, _make_param_property(_n, _refl_shape))
+RoughConductorBSDF.specular_reflectance = _make_param_property("specular_reflectance", _v3)
+RoughDielectricBSDF.eta = _make_param_property("eta", lambda self, value: (1,))
 for _n in ("specularReflectance", "diffuseReflectance"):
     setattr(MicrofacetBSDFPerVertex, _n, _make_param_property(_n, lambda self, value: (-1, 3)))
 MicrofacetBSDFPerVertex.roughness = _make_param_property("roughness", lambda self, value: (-1,))
@@ -307,14 +309,14 @@ def _roughconductor_init(self, *args):
     if not args:
         return
     # 1x1 Bitmap1fD / Bitmap3fD arguments (tutorials/batch_render.ipynb) are the constants they hold
-    args = tuple(_const_of(a, a.data.size) if isinstance(a, (Bitmap3fD, Bitmap1fD)) and a.data.size in (1, 3) else a for a in args)
+    args = tuple((_const_of(a, a.data.size) if a.data.size in (1, 3) else a.data) if isinstance(a, (Bitmap3fD, Bitmap1fD)) else a for a in args)
     scal = lambda x: float(_np.ravel(_split(x, (-1,))[0])[0])
     first_two_scalar = len(args) >= 4 and _np.size(_split(args[1], (-1,))[0]) == 1
     if first_two_scalar:
         au, av, rest = args[0], args[1], args[2:]
     else:
         au, av, rest = args[0], args[0], args[1:]
-    keep = lambda x: x.reshape(1) if isinstance(x, _torch.Tensor) else [scal(x)]      # a tensor stays a leaf
+    keep = lambda x: (x if x.dim() == 2 else x.reshape(1)) if isinstance(x, _torch.Tensor) else (x if _np.ndim(x) == 2 else [scal(x)])      # a tensor stays a leaf, a map a map
     self.alpha_u, self.alpha_v = keep(au), keep(av)
     self.eta, self.k = rest[0], rest[1]
     if len(rest) > 2:
@@ -370,8 +372,14 @@ def _roughdielectric_init(self, *args):
     or a 1x1 Bitmap1fD).  The reference binds the class without a constructor (psdr.cpp:295) and only builds it from XML."""
     if len(args) == 3:
         _RoughDielectricBSDF_init(self, float(args[1]), float(args[2]))
-        a = float(_np.ravel(_split(_const_of(args[0], 1), (-1,))[0])[0])
-        self.alpha_u, self.alpha_v = [a], [a]
+        al = args[0]
+        if isinstance(al, Bitmap1fD):
+            al = al.data.reshape(1) if al.data.size == 1 else al.data
+        if _np.ndim(al.detach().cpu().numpy() if isinstance(al, _torch.Tensor) else al) == 2:
+            self.alpha_u = al                                   # an alpha map (serves both axes)
+        else:
+            a = float(_np.ravel(_split(al, (-1,))[0])[0])
+            self.alpha_u, self.alpha_v = [a], [a]
     elif len(args) == 2:
         _RoughDielectricBSDF_init(self, float(args[0]), float(args[1]))
     else:

@@ -536,7 +536,7 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
                 const int tw[3] = {b.tex_width, b.spec_tex_width, b.rough_tex_width}, th[3] = {b.tex_height, b.spec_tex_height, b.rough_tex_height};
                 for (int k = 0; k < 3; ++k) {
                     if (!src[k]) continue;
-                    if (k > 0 && b.type != 1) return fail("specular / roughness bitmaps belong to the Microfacet BSDF");
+                    if (k > 0 && b.type != 1 && b.type != 2 && !(b.type == 3 && k == 2)) return fail("this BSDF type has no second / third bitmap parameter");
                     if (tw[k] < 2 || th[k] < 2) return fail("Bitmap: invalid resolution!");
                     const size_t nt = (size_t) (k == 2 ? 1 : 3) * tw[k] * th[k];
                     td[3 * i + k].data = sc->up(src[k], nt, rc);

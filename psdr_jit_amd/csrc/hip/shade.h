@@ -381,6 +381,20 @@ template <bool AD, int LDS> PSDR_DEV float roughness_lookup(const SceneView<LDS>
     env::bitmap_eval_tex<float, 1>([&](int i, int) { return td.data[i]; }, td.w, td.h, detach(its.tu), detach(its.tv), true, o);
     return o[0];
 }
+// bitmap parameter `slot` (0..2) of BSDF `id` at its.uv as (value, tangent): forward texel tangents in a render, the probe's unit
+// tangent in a reverse-mode replay (components 3*slot .. of the lookup record)
+template <int CH, bool AD, int LDS> PSDR_DEV void param_lookup(const SceneView<LDS> &S, int id, int slot, const Its<AD> &its, Dual *out) {
+    const TexDev td = S.T->tex[3 * id + slot];
+    const bool tt = AD && S.mode == 0 && td.d_data != nullptr;
+    const Dual tu = Dual(its.tu), tv = Dual(its.tv);
+    env::bitmap_eval_tex<Dual, CH>([&](int i, int c) { return Dual(td.data[CH * i + c], tt ? td.d_data[CH * i + c] : 0.f); }, td.w, td.h, tu, tv, true, out);
+    if constexpr (AD) {
+        S.note_lookup(id, tu.v, tv.v);
+        const int hot = S.lookup_hot(id, tu.v, tv.v, 3 * slot, CH);
+        if (hot >= 0) out[hot].d += 1.f;
+    }
+}
+
 // (bid_, wi_) are explicit so that NormalMap can evaluate its nested BSDF with a perturbed incident direction
 template <bool AD, int LDS> PSDR_DEV VecN<AD> bsdf_eval_id(const SceneView<LDS> &S, int bid_, const Its<AD> &its, const VecN<AD> &wi_, VecN<AD> wo, bool active) {
     using R = Num<AD>; using V = VecN<AD>;
@@ -450,39 +464,36 @@ template <bool AD, int LDS> PSDR_DEV VecN<AD> bsdf_eval_id(const SceneView<LDS> 
         if (__float_as_int(a.w) & 8) {         // RoughConductor (roughconductor.cpp)
             const MatDev md = S.T->mat[bid_];
             const bool two = (__float_as_int(a.w) & 1) != 0;
-            if constexpr (AD) {
-                const float t = S.mode == 0 ? 1.f : 0.f;       // (its parameters have no reverse-mode adjoint yet)
-                // g_mat row = [alpha_u, alpha_v, eta rgb, k rgb, specular_reflectance rgb]
-                const int bid = bid_;
-                (void) t;
-                auto mt = [&](int kk, float fwd) { return S.mat_tan(bid, kk, fwd); };
-                return conductor_eval<Dual>(Dual(md.alpha_u, mt(0, md.d_alpha_u)), Dual(md.alpha_v, mt(1, md.d_alpha_v)),
-                                            Vec3d(Dual(md.eta[0], mt(2, md.d_eta[0])), Dual(md.eta[1], mt(3, md.d_eta[1])), Dual(md.eta[2], mt(4, md.d_eta[2]))),
-                                            Vec3d(Dual(md.k[0], mt(5, md.d_k[0])), Dual(md.k[1], mt(6, md.d_k[1])), Dual(md.k[2], mt(7, md.d_k[2]))),
-                                            Vec3d(Dual(md.specular[0], mt(8, md.d_specular[0])), Dual(md.specular[1], mt(9, md.d_specular[1])), Dual(md.specular[2], mt(10, md.d_specular[2]))),
-                                            two, wi_, wo, active);
-            } else {
-                return conductor_eval<float>(md.alpha_u, md.alpha_v, Vec3f(md.eta[0], md.eta[1], md.eta[2]), Vec3f(md.k[0], md.k[1], md.k[2]),
-                                             Vec3f(md.specular[0], md.specular[1], md.specular[2]), two, wi_, wo, active);
+            // g_mat row = [alpha_u, alpha_v, eta rgb, k rgb, specular_reflectance rgb]; bitmaps: slot 0 eta, 1 k, 2 alpha (both axes,
+            // as the XML loader fills them, scene_loader.cpp:334-344)
+            const int bid = bid_, fl = __float_as_int(a.w);
+            auto mt = [&](int kk, float fwd) { return AD ? S.mat_tan(bid, kk, fwd) : 0.f; };
+            Dual au(md.alpha_u, mt(0, md.d_alpha_u)), av(md.alpha_v, mt(1, md.d_alpha_v));
+            Vec3d eta(Dual(md.eta[0], mt(2, md.d_eta[0])), Dual(md.eta[1], mt(3, md.d_eta[1])), Dual(md.eta[2], mt(4, md.d_eta[2])));
+            Vec3d kk3(Dual(md.k[0], mt(5, md.d_k[0])), Dual(md.k[1], mt(6, md.d_k[1])), Dual(md.k[2], mt(7, md.d_k[2])));
+            const Vec3d spec(Dual(md.specular[0], mt(8, md.d_specular[0])), Dual(md.specular[1], mt(9, md.d_specular[1])), Dual(md.specular[2], mt(10, md.d_specular[2])));
+            if (fl & (2 | 32 | 64)) {
+                Dual o[3];
+                if (fl & 2) { param_lookup<3, AD, LDS>(S, bid, 0, its, o); eta = Vec3d(o[0], o[1], o[2]); }
+                if (fl & 32) { param_lookup<3, AD, LDS>(S, bid, 1, its, o); kk3 = Vec3d(o[0], o[1], o[2]); }
+                if (fl & 64) { param_lookup<1, AD, LDS>(S, bid, 2, its, o); au = o[0]; av = o[0]; }
             }
+            if constexpr (AD) return conductor_eval<Dual>(au, av, eta, kk3, spec, two, wi_, wo, active);
+            else return conductor_eval<float>(au.v, av.v, detach(eta), detach(kk3), detach(spec), two, wi_, wo, active);
         }
     }
     if constexpr (has_mat(LDS)) {
         if (__float_as_int(a.w) & 16) {        // RoughDielectric (roughdielectric.cpp): eta[0] = intIOR/extIOR, eta[1] = extIOR/intIOR
             const MatDev md = S.T->mat[bid_];
             const bool two = (__float_as_int(a.w) & 1) != 0;
-            if constexpr (AD) {
-                const float t = S.mode == 0 ? 1.f : 0.f;
-                // g_mat row = [alpha_u, alpha_v, eta]; m_inv_eta = 1 / m_eta moves with eta
-                const int bid = bid_;
-                (void) t;
-                const float de = S.mat_tan(bid, 2, md.d_eta[0]);
-                const float dinv = S.mode == 0 ? md.d_eta[1] : -de / (md.eta[0] * md.eta[0]);
-                return dielectric_eval<Dual>(Dual(md.alpha_u, S.mat_tan(bid, 0, md.d_alpha_u)), Dual(md.alpha_v, S.mat_tan(bid, 1, md.d_alpha_v)), Dual(md.eta[0], de),
-                                             Dual(md.eta[1], dinv), two, wi_, wo, active);
-            } else {
-                return dielectric_eval<float>(md.alpha_u, md.alpha_v, md.eta[0], md.eta[1], two, wi_, wo, active);
-            }
+            // g_mat row = [alpha_u, alpha_v, eta]; m_inv_eta = 1 / m_eta moves with eta; bitmap: slot 2 alpha (both axes)
+            const int bid = bid_;
+            const float de = AD ? S.mat_tan(bid, 2, md.d_eta[0]) : 0.f;
+            const float dinv = (!AD || S.mode == 0) ? (AD ? md.d_eta[1] : 0.f) : -de / (md.eta[0] * md.eta[0]);
+            Dual au(md.alpha_u, AD ? S.mat_tan(bid, 0, md.d_alpha_u) : 0.f), av(md.alpha_v, AD ? S.mat_tan(bid, 1, md.d_alpha_v) : 0.f);
+            if (__float_as_int(a.w) & 64) { Dual o[1]; param_lookup<1, AD, LDS>(S, bid, 2, its, o); au = o[0]; av = o[0]; }
+            if constexpr (AD) return dielectric_eval<Dual>(au, av, Dual(md.eta[0], de), Dual(md.eta[1], dinv), two, wi_, wo, active);
+            else return dielectric_eval<float>(au.v, av.v, md.eta[0], md.eta[1], two, wi_, wo, active);
         }
     }
     R wiz = wi_.z;
@@ -525,11 +536,13 @@ template <bool AD, int LDS> PSDR_DEV float bsdf_pdf_id(const SceneView<LDS> &S, 
         if (__float_as_int(a.w) & 12) {
             const MatDev md = S.T->mat[bid_];
             const bool mf = (__float_as_int(a.w) & 4) != 0;
-            const float rough = (__float_as_int(a.w) & 64) ? roughness_lookup(S, bid_, its) : md.roughness;
+            const float rough = (__float_as_int(a.w) & 64) ? roughness_lookup(S, bid_, its) : md.roughness;      // (conductor: the alpha map)
+            if (!mf && (__float_as_int(a.w) & 64)) return ggx_pdf(rough, rough, (__float_as_int(a.w) & 1) != 0, detach(wi_), detach(wo), active);
             return ggx_pdf(mf ? sqr(rough) : md.alpha_u, mf ? sqr(rough) : md.alpha_v, (__float_as_int(a.w) & 1) != 0, detach(wi_), detach(wo), active);
         }
         if (__float_as_int(a.w) & 16) {
             const MatDev md = S.T->mat[bid_];
+            if (__float_as_int(a.w) & 64) { const float al = roughness_lookup(S, bid_, its); return dielectric_pdf(al, al, md.eta[0], md.eta[1], (__float_as_int(a.w) & 1) != 0, detach(wi_), detach(wo), active); }
             return dielectric_pdf(md.alpha_u, md.alpha_v, md.eta[0], md.eta[1], (__float_as_int(a.w) & 1) != 0, detach(wi_), detach(wo), active);
         }
     }
@@ -588,14 +601,16 @@ template <bool AD, int LDS> PSDR_DEV BSDFSample bsdf_sample_id(const SceneView<L
             const MatDev md = S.T->mat[bid_];
             const bool mf = (__float_as_int(a.w) & 4) != 0;
             const float rough = (__float_as_int(a.w) & 64) ? roughness_lookup(S, bid_, its) : md.roughness;
-            ggx_reflect_sample(mf ? sqr(rough) : md.alpha_u, mf ? sqr(rough) : md.alpha_v, (__float_as_int(a.w) & 1) != 0, detach(wi_), s0, s1, active,
+            const bool amap = !mf && (__float_as_int(a.w) & 64);
+            ggx_reflect_sample(mf ? sqr(rough) : (amap ? rough : md.alpha_u), mf ? sqr(rough) : (amap ? rough : md.alpha_v), (__float_as_int(a.w) & 1) != 0, detach(wi_), s0, s1, active,
                                m.wo, m.pdf, m.valid);
             return m;
         }
         if (__float_as_int(a.w) & 16) {        // RoughDielectric::sample: the third number picks reflection or refraction
             BSDFSample m;
             const MatDev md = S.T->mat[bid_];
-            dielectric_sample(md.alpha_u, md.alpha_v, md.eta[0], (__float_as_int(a.w) & 1) != 0, detach(wi_), s0, s1, s2, active, m.wo, m.pdf, m.valid);
+            const float al_u = (__float_as_int(a.w) & 64) ? roughness_lookup(S, bid_, its) : md.alpha_u, al_v = (__float_as_int(a.w) & 64) ? al_u : md.alpha_v;
+            dielectric_sample(al_u, al_v, md.eta[0], (__float_as_int(a.w) & 1) != 0, detach(wi_), s0, s1, s2, active, m.wo, m.pdf, m.valid);
             return m;
         }
     }

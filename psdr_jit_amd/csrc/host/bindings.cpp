@@ -123,6 +123,14 @@ PYBIND11_MODULE(_psdr_core, m) {
     py::class_<RoughConductor, BSDF>(m, "RoughConductorBSDF", py::dynamic_attr())
         .def(py::init<>())
         .def("_get", [](const RoughConductor &b, const std::string &name, bool tangent) {
+            const ParamTex *tx = (name == "alpha_u" || name == "alpha_v") ? &b.alpha_tex : (name == "eta" ? &b.eta_tex : (name == "k" ? &b.k_tex : nullptr));
+            if (tx && tx->w > 0) {
+                const bool one = tx == &b.alpha_tex;
+                farr a = one ? farr({(py::ssize_t) tx->h, (py::ssize_t) tx->w}) : farr({(py::ssize_t) tx->h, (py::ssize_t) tx->w, (py::ssize_t) 3});
+                const std::vector<float> &src = tangent ? tx->d : tx->v;
+                if (src.size() == (size_t) a.size()) std::memcpy(a.mutable_data(), src.data(), sizeof(float) * src.size()); else std::memset(a.mutable_data(), 0, sizeof(float) * a.size());
+                return a;
+            }
             if (name == "alpha_u" || name == "alpha_v") {
                 farr a(1);
                 a.mutable_data()[0] = name == "alpha_u" ? (tangent ? b.d_alpha_u : b.alpha_u) : (tangent ? b.d_alpha_v : b.alpha_v);
@@ -131,6 +139,15 @@ PYBIND11_MODULE(_psdr_core, m) {
             const auto &r = name == "eta" ? (tangent ? b.d_eta : b.eta) : (name == "k" ? (tangent ? b.d_k : b.k) : (tangent ? b.d_specular : b.specular));
             farr a(3); std::memcpy(a.mutable_data(), r.data(), 12); return a; })
         .def("_set", [](RoughConductor &b, const std::string &name, const farr &v, const farr &t) {
+            ParamTex *tx = (name == "alpha_u" || name == "alpha_v") ? &b.alpha_tex : (name == "eta" ? &b.eta_tex : (name == "k" ? &b.k_tex : nullptr));
+            if (tx && v.ndim() == (tx == &b.alpha_tex ? 2 : 3) && v.shape(0) >= 2 && v.shape(1) >= 2) {     // a bitmap above 1x1
+                if (tx != &b.alpha_tex && v.shape(2) != 3) throw Exception("Bitmap: invalid resolution!");
+                tx->h = (int) v.shape(0); tx->w = (int) v.shape(1);
+                tx->v.assign(v.data(), v.data() + v.size());
+                if (t.size() == v.size()) tx->d.assign(t.data(), t.data() + t.size()); else tx->d.assign((size_t) v.size(), 0.f);
+                return;
+            }
+            if (tx) *tx = ParamTex();
             if (name == "alpha_u") { b.alpha_u = v.data()[0]; b.d_alpha_u = t.size() ? t.data()[0] : 0.f; }
             else if (name == "alpha_v") { b.alpha_v = v.data()[0]; b.d_alpha_v = t.size() ? t.data()[0] : 0.f; }
             else if (name == "eta") { b.eta = to_a3(v); b.d_eta = to_a3(t); }
@@ -184,11 +201,25 @@ PYBIND11_MODULE(_psdr_core, m) {
         .def(py::init<>())
         .def(py::init<float, float>())
         .def("_get", [](const RoughDielectric &b, const std::string &name, bool tangent) {
+            if ((name == "alpha_u" || name == "alpha_v") && b.alpha_tex.w > 0) {
+                farr m2({(py::ssize_t) b.alpha_tex.h, (py::ssize_t) b.alpha_tex.w});
+                const std::vector<float> &src = tangent ? b.alpha_tex.d : b.alpha_tex.v;
+                if (src.size() == (size_t) m2.size()) std::memcpy(m2.mutable_data(), src.data(), sizeof(float) * src.size()); else std::memset(m2.mutable_data(), 0, sizeof(float) * m2.size());
+                return m2;
+            }
             farr a(1);
             a.mutable_data()[0] = name == "alpha_u" ? (tangent ? b.d_alpha_u : b.alpha_u) : name == "alpha_v" ? (tangent ? b.d_alpha_v : b.alpha_v)
                                 : name == "eta" ? (tangent ? b.d_eta : b.eta) : (tangent ? b.d_inv_eta : b.inv_eta);
             return a; })
         .def("_set", [](RoughDielectric &b, const std::string &name, const farr &v, const farr &t) {
+            if ((name == "alpha_u" || name == "alpha_v") && v.ndim() == 2 && v.shape(0) >= 2 && v.shape(1) >= 2) {
+                ParamTex &tx = b.alpha_tex;
+                tx.h = (int) v.shape(0); tx.w = (int) v.shape(1);
+                tx.v.assign(v.data(), v.data() + v.size());
+                if (t.size() == v.size()) tx.d.assign(t.data(), t.data() + t.size()); else tx.d.assign((size_t) v.size(), 0.f);
+                return;
+            }
+            if (name == "alpha_u" || name == "alpha_v") b.alpha_tex = ParamTex();
             const float x = v.data()[0], dx = t.size() ? t.data()[0] : 0.f;
             if (name == "alpha_u") { b.alpha_u = x; b.d_alpha_u = dx; }
             else if (name == "alpha_v") { b.alpha_v = x; b.d_alpha_v = dx; }

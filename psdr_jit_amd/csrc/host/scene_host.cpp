@@ -721,6 +721,15 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
                 r.eta[k] = rc->eta[k]; r.d_eta[k] = rc->d_eta[k]; r.k[k] = rc->k[k]; r.d_k[k] = rc->d_k[k];
                 r.specular[k] = rc->specular[k]; r.d_specular[k] = rc->d_specular[k];
             }
+            auto put_tex = [](const ParamTex &t, int ch, int32_t &w, int32_t &h, const float *&data, const float *&ddata) {
+                if (t.w == 0) return;
+                PSDR_ASSERT_MSG(t.w >= 2 && t.h >= 2, "Bitmap: invalid resolution!");
+                PSDR_ASSERT_MSG(t.v.size() == (size_t) ch * t.w * t.h, "Bitmap: invalid data size!");
+                w = t.w; h = t.h; data = t.v.data(); ddata = t.d.size() == t.v.size() ? t.d.data() : nullptr;
+            };
+            put_tex(rc->eta_tex, 3, r.tex_width, r.tex_height, r.tex_data, r.d_tex_data);                         // slot 0 = eta
+            put_tex(rc->k_tex, 3, r.spec_tex_width, r.spec_tex_height, r.spec_tex_data, r.d_spec_tex_data);       // slot 1 = k
+            put_tex(rc->alpha_tex, 1, r.rough_tex_width, r.rough_tex_height, r.rough_tex_data, r.d_rough_tex_data);   // slot 2 = alpha
             dst.push_back(r);
             return;
         }
@@ -742,6 +751,11 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
             r.type = 3; r.two_sided = rd->m_twoSide ? 1 : 0;
             r.alpha_u = rd->alpha_u; r.alpha_v = rd->alpha_v; r.d_alpha_u = rd->d_alpha_u; r.d_alpha_v = rd->d_alpha_v;
             r.eta[0] = rd->eta; r.eta[1] = rd->inv_eta; r.d_eta[0] = rd->d_eta; r.d_eta[1] = rd->d_inv_eta;
+            if (rd->alpha_tex.w > 0) {
+                const ParamTex &t = rd->alpha_tex;
+                PSDR_ASSERT_MSG(t.w >= 2 && t.h >= 2 && t.v.size() == (size_t) t.w * t.h, "Bitmap: invalid resolution!");
+                r.rough_tex_width = t.w; r.rough_tex_height = t.h; r.rough_tex_data = t.v.data(); r.d_rough_tex_data = t.d.size() == t.v.size() ? t.d.data() : nullptr;
+            }
             dst.push_back(r);
             return;
         }

@@ -95,6 +95,7 @@ struct RoughConductor : BSDF {
     bool anisotropic() const override { return alpha_u != alpha_v; }
     float alpha_u = 0.1f, alpha_v = 0.1f, d_alpha_u = 0.f, d_alpha_v = 0.f;
     std::array<float, 3> eta{0, 0, 0}, k{1, 1, 1}, specular{1, 1, 1}, d_eta{0, 0, 0}, d_k{0, 0, 0}, d_specular{0, 0, 0};
+    ParamTex eta_tex, k_tex, alpha_tex;     // bitmaps above 1x1: rgb, rgb, one channel (the alpha map serves both axes, as in the XML loader)
 };
 
 // MicrofacetPerVertex, reference include/psdr/bsdf/microfacet_pv.h: one value per mesh-local vertex
@@ -133,6 +134,7 @@ struct RoughDielectric : BSDF {
     bool anisotropic() const override { return false; }
     float alpha_u = 0.1f, alpha_v = 0.1f, d_alpha_u = 0.f, d_alpha_v = 0.f;
     float eta, inv_eta, d_eta = 0.f, d_inv_eta = 0.f;
+    ParamTex alpha_tex;                     // alpha bitmap above 1x1 (both axes)
 };
 
 struct Mesh;

@@ -142,15 +142,14 @@ def _load_plain_bsdf(node, btype, psdr, base_dir):
         b = psdr.MicrofacetBSDF(*vals)
     elif btype == "roughconductor":
         nodes = [_child_by_name(node, {"alpha"}), _child_by_name(node, {"eta"}), _child_by_name(node, {"k"})]
-        if any(n.tag == "texture" for n in nodes):
-            raise _Err("RoughConductorBSDF: bitmap parameters are not built, only constants")
-        b = psdr.RoughConductorBSDF(float(nodes[0].get("value")), _load_rgb(nodes[1]), _load_rgb(nodes[2]))
+        one = lambda n: psdr.Bitmap1fD(np.ascontiguousarray(psdr.Bitmap3fD(_parse_bitmap(n, base_dir)).data[..., 0])) if n.tag == "texture" else float(n.get("value"))
+        rgb = lambda n: psdr.Bitmap3fD(_parse_bitmap(n, base_dir)) if n.tag == "texture" else _load_rgb(n)
+        b = psdr.RoughConductorBSDF(one(nodes[0]), rgb(nodes[1]), rgb(nodes[2]))
     elif btype == "roughdielectric":     # scene_loader.cpp:346-360
         alpha = _child_by_name(node, {"alpha"})
-        if alpha.tag == "texture":
-            raise _Err("RoughDielectricBSDF: bitmap parameters are not built, only constants")
         ior = [_child_by_name(node, {"intIOR"}), _child_by_name(node, {"extIOR"})]
-        b = psdr.RoughDielectricBSDF(float(alpha.get("value")), float(ior[0].get("value")), float(ior[1].get("value")))
+        al = psdr.Bitmap1fD(np.ascontiguousarray(psdr.Bitmap3fD(_parse_bitmap(alpha, base_dir)).data[..., 0])) if alpha.tag == "texture" else float(alpha.get("value"))
+        b = psdr.RoughDielectricBSDF(al, float(ior[0].get("value")), float(ior[1].get("value")))
     return b
 
 

@@ -69,6 +69,12 @@ def build_scene(spec, configure=True, active=(0,), host_only=False, log_level=0)
             bs._set("eta", np.asarray(b.eta, np.float32), np.asarray(b.d_eta, np.float32))
             bs._set("k", np.asarray(b.k, np.float32), np.asarray(b.d_k, np.float32))
             bs._set("specular_reflectance", np.asarray(b.specular, np.float32), np.asarray(b.d_specular, np.float32))
+            for attr, name in (("texture", "eta"), ("spec_texture", "k"), ("rough_texture", "alpha_u")):       # bitmap parameters
+                t = getattr(b, attr, None)
+                if t is not None:
+                    tex = np.ascontiguousarray(np.asarray(t, np.float32))
+                    dt = getattr(b, "d_" + attr, None)
+                    bs._set(name, tex, np.ascontiguousarray(np.asarray(dt, np.float32)) if dt is not None else np.zeros_like(tex))
             sc.add_BSDF(bs, b.name or ("bsdf%d" % i), b.two_sided)
             continue
         if getattr(b, "type", 0) == 4:
@@ -84,6 +90,10 @@ def build_scene(spec, configure=True, active=(0,), host_only=False, log_level=0)
             f1 = lambda x: np.asarray([x], np.float32)
             bs._set("alpha_u", f1(b.alpha_u), f1(b.d_alpha_u)); bs._set("alpha_v", f1(b.alpha_v), f1(b.d_alpha_v))
             bs._set("eta", f1(b.eta[0]), f1(b.d_eta[0])); bs._set("inv_eta", f1(b.eta[1]), f1(b.d_eta[1]))
+            if getattr(b, "rough_texture", None) is not None:
+                tex = np.ascontiguousarray(np.asarray(b.rough_texture, np.float32))
+                dt = getattr(b, "d_rough_texture", None)
+                bs._set("alpha_u", tex, np.ascontiguousarray(np.asarray(dt, np.float32)) if dt is not None else np.zeros_like(tex))
             sc.add_BSDF(bs, b.name or ("bsdf%d" % i), b.two_sided)
             continue
         bs = psdr.DiffuseBSDF(list(b.reflectance))

@@ -476,3 +476,33 @@ def normalmap_scene(width=48, height=48, spp=4, sppe=0, sppse=0, param=None, nes
     elif param not in (None, "box_x"):
         raise ValueError(param)
     return spec
+
+
+def textured_ggx_scene(width=48, height=48, spp=4, sppe=0, sppse=0, kind="roughconductor", param=None):
+    """textured_scene (Cornell luminaire) whose uv-mapped floor is a RoughConductor with eta / k / alpha bitmaps or a two-sided
+    RoughDielectric with an alpha bitmap (reference roughconductor.cpp:37-43, roughdielectric.cpp:75-78).
+    param: 'eta' | 'k' | 'alpha' (d texel / dP = 1) | 'box_x' | None"""
+    spec = textured_scene(width, height, spp, sppe, sppse, texture=checker_texture(8, 8), param="box_x" if param == "box_x" else None, env=False)
+    rng = np.random.default_rng(21)
+    b = spec.bsdfs[0]
+    yy, xx = np.meshgrid(np.linspace(0, 1, 6, dtype=np.float32), np.linspace(0, 1, 7, dtype=np.float32), indexing="ij")
+    alpha = (0.12 + 0.3 * (0.5 + 0.5 * np.sin(6 * xx) * np.cos(5 * yy))).astype(np.float32)
+    if kind == "roughconductor":
+        b.type, b.specular = 2, (1.0, 0.95, 0.9)
+        b.texture = (0.15 + 1.2 * rng.random((5, 4, 3))).astype(np.float32)          # eta map
+        b.spec_texture = (2.0 + 2.0 * rng.random((4, 6, 3))).astype(np.float32)      # k map
+        b.rough_texture = alpha
+    else:
+        b.type, b.texture, b.two_sided = 3, None, True
+        e = np.float32(1.5)
+        b.eta = (float(e), float(np.float32(1.0) / e), 0.0)
+        b.rough_texture = alpha
+    if param == "eta":
+        b.d_texture = np.ones_like(b.texture)
+    elif param == "k":
+        b.d_spec_texture = np.ones_like(b.spec_texture)
+    elif param == "alpha":
+        b.d_rough_texture = np.ones_like(b.rough_texture)
+    elif param not in (None, "box_x"):
+        raise ValueError(param)
+    return spec

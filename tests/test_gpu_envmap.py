@@ -372,3 +372,21 @@ def test_envmap_reverse_mode(psdr, orc):
         assert abs(want) > 1e-3 and abs(got - want) < 2e-3 * max(1.0, abs(want)), (name, got, want)
     # the image is linear in the scale: d/d scale = image / scale
     assert abs(got_scale - float((img.detach() * w).sum()) / 1.25) < 2e-3 * abs(got_scale)
+
+
+@pytest.mark.parametrize("kind,param", [("roughconductor", "eta"), ("roughconductor", "k"), ("roughconductor", "alpha"), ("roughconductor", "box_x"),
+                                        ("roughdielectric", "alpha"), ("roughdielectric", None)])
+def test_ggx_bitmap_parameters(psdr, orc, kind, param):
+    """RoughConductor with eta / k / alpha bitmaps and RoughDielectric with an alpha bitmap (roughconductor.cpp:37-43,
+    roughdielectric.cpp:75-78): image and texel tangents against the oracle"""
+    spec = scenes.textured_ggx_scene(48, 48, 8, 8, 8, kind=kind, param=param)
+    sc = product.build_scene(spec)
+    ref = orc.OracleScene(spec, [0])
+    integ = psdr.PathTracer(2)
+    img, dimg = psdr.render_d_fwd(integ, sc, 0, seed=4)
+    wimg, wd = ref.render_d(max_depth=2, seeds=(4, 4, 4))
+    assert product.rel_l2(img.cpu().numpy(), wimg) < TOL
+    if param is not None:
+        assert np.abs(wd).max() > 0 and product.rel_l2(dimg.cpu().numpy(), wd) < TOL
+    c = psdr.PathTracer(3).renderC(sc, 0, seed=2).cpu().numpy()
+    assert product.rel_l2(c, ref.render_c(max_depth=3, seed=2)) < TOL
