@@ -265,6 +265,8 @@ typedef struct psdr_grads {
      *   RoughConductor  [alpha_u, alpha_v, eta rgb, k rgb, specular_reflectance rgb]
      *   RoughDielectric [alpha_u, alpha_v, eta (= intIOR / extIOR)]                     (the diffuse colour stays in g_bsdf) */
     float *g_mat;
+    /* adjoint of the environment map's from_world (DEVICE [16], row major; the 3x3 block that maps world directions), or NULL */
+    float *g_env_from_world;
 } psdr_grads;
 /* offsets[3*n_bsdfs] (HOST): float offset of the texel block of BSDF b's bitmap k (0 reflectance / diffuse reflectance rgb,
  * 1 specular reflectance rgb, 2 roughness) inside psdr_grads.g_tex, same row-major layout as the bitmap; -1 = constant.

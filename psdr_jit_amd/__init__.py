@@ -805,24 +805,24 @@ class _RenderDFn(_torch.autograd.Function):
                       if need and t.dim() < 2 and name in mat_rows.get(type(obj).__name__, {})]
         g_mat = _torch.zeros(16 * max(1, nb), dtype=_torch.float32, device=dev) if mat_leaves else None
         env_leaves = [i for i, ((obj, name, t), need) in enumerate(zip(leaves, needs)) if need and isinstance(obj, EnvironmentMap)]
-        g_env = g_env_scale = None
+        g_env = g_env_scale = g_env_xf = None
         for i in env_leaves:
             obj, name, t = leaves[i]
             if name == "radiance":
                 g_env = _torch.zeros(t.numel(), dtype=_torch.float32, device=dev)
             elif name == "scale":
                 g_env_scale = _torch.zeros(1, dtype=_torch.float32, device=dev)
-            else:
-                raise NotImplementedError("reverse mode w.r.t. the environment map's transform is not implemented; use forward_grad()")
+            else:               # to_world_left: through the adjoint of from_world = (to_world_left . to_world_raw)^-1
+                g_env_xf = _torch.zeros(16, dtype=_torch.float32, device=dev)
         if g_env_scale is not None and g_env is None:        # the scale adjoint is assembled from the texel probes
             g_env = _torch.zeros(int(_np.prod(leaves[env_leaves[0]][0]._get("radiance", False).shape)), dtype=_torch.float32, device=dev)
         _core._render_d_bwd(integ, scene, st["sensor_id"], seeds, skips, g_img.data_ptr(), ptr[0], ptr[1], ptr[2], ptr[3], ptr[4],
                             _stream_ptr(), rank, world, st["terms"], mesh_filter.data_ptr(), not want_bsdf, not want_em,
                             g_tex.data_ptr() if g_tex is not None else 0, g_cam.data_ptr() if g_cam is not None else 0,
                             g_env.data_ptr() if g_env is not None else 0, g_env_scale.data_ptr() if g_env_scale is not None else 0,
-                            g_mat.data_ptr() if g_mat is not None else 0)
+                            g_mat.data_ptr() if g_mat is not None else 0, g_env_xf.data_ptr() if g_env_xf is not None else 0)
         _all_reduce(flat, world > 1)
-        for extra in (g_env, g_env_scale, g_mat):
+        for extra in (g_env, g_env_scale, g_mat, g_env_xf):
             if extra is not None:
                 _all_reduce(extra, world > 1)
         if g_cam is not None:
@@ -874,8 +874,16 @@ class _RenderDFn(_torch.autograd.Function):
             grads[i] = (row if t.numel() == n else row.sum().reshape(1)).reshape(t.shape).to(t.device, t.dtype)
         for i in env_leaves:
             obj, name, t = leaves[i]
-            src = g_env if name == "radiance" else g_env_scale
-            grads[i] = src.reshape(t.shape).to(t.device, t.dtype)
+            if name in ("radiance", "scale"):
+                src = g_env if name == "radiance" else g_env_scale
+                grads[i] = src.reshape(t.shape).to(t.device, t.dtype)
+            else:               # from_world = inverse(to_world_left . to_world_raw): d from = -from . d to . from
+                with _torch.enable_grad():
+                    L = t.detach().to("cpu", _torch.float64).reshape(4, 4).clone().requires_grad_(True)
+                    raw = _torch.as_tensor(_np.asarray(obj._get("to_world_raw", False), dtype=_np.float64))
+                    fw = _torch.linalg.inv(L @ raw)
+                    (gl,) = _torch.autograd.grad(fw, L, g_env_xf.to("cpu", _torch.float64).reshape(4, 4))
+                grads[i] = gl.reshape(t.shape).to(t.device, t.dtype)
         return (None,) + tuple(grads)
 
 

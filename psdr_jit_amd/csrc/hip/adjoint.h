@@ -48,11 +48,13 @@ struct AdjointParams {
     float *g_tex;                   // texel adjoints of the bitmap parameters (TexDev::g_off), or NULL
     float *g_cam;                   // [16] adjoint of the sensor's to_world (row major, rows 0-2 filled), or NULL
     float *g_env, *g_env_scale;     // texel adjoints [H*W*3] and scale adjoint [1] of the environment map, or NULL
+    float *g_env_xf;                // [16] adjoint of the environment map's from_world (rows 0-2, columns 0-2 filled), or NULL
     int lk_words;                   // kAdjLkWords when the scene can make lookups (bitmaps, per-vertex values, environment map), else 0
     float *g_mat;                   // [n_bsdfs*16] adjoints of the constant parameters of the GGX BSDFs (psdr_grads.g_mat), or NULL
 };
 
 constexpr int kMatRow = 16;
+constexpr int kAdjMisc = 32;        // LDS accumulators every path adds to: camera pose, environment scale and transform
 // number of constant material parameters a BSDF record's flags announce (Microfacet 4 - fewer with maps -, RoughConductor 11, RoughDielectric 3)
 PSDR_DEV int mat_param_count(int fl) { return (fl & 4) ? 4 : ((fl & 8) ? 11 : ((fl & 16) ? 3 : 0)); }
 
@@ -73,7 +75,7 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
     int *ext = reinterpret_cast<int *>(scratch + kAdjHitWords * kBlock) + threadIdx.x;
     float *lk = scratch + (kAdjHitWords + kAdjExtWords) * kBlock + threadIdx.x;
     float *acc_cam = scratch + (kAdjHitWords + kAdjExtWords + P.lk_words) * kBlock;        // 16 floats, always in LDS: every path adds to the same 12 entries
-    float *acc_mat = acc_cam + 16;                               // [n_bsdfs * kMatRow], always in LDS like the camera block
+    float *acc_mat = acc_cam + kAdjMisc;                               // [n_bsdfs * kMatRow], always in LDS like the camera block
     float *acc = acc_mat + T.n_bsdfs * kMatRow;
     const int n_acc = T.n_tris * 22 + T.n_bsdfs * 3 + T.n_emitters * 3;
     const bool use_lds = P.lds_accum != 0;
@@ -82,7 +84,7 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
         __syncthreads();
     }
     float *acc_bsdf = acc + T.n_tris * 22, *acc_emit = acc_bsdf + T.n_bsdfs * 3;
-    if (threadIdx.x < 16) acc_cam[threadIdx.x] = 0.f;          // [0..11] camera pose, [12] environment-map scale
+    if (threadIdx.x < kAdjMisc) acc_cam[threadIdx.x] = 0.f;    // [0..11] camera pose, [12] environment-map scale, [16..31] environment from_world
     for (int i = threadIdx.x; i < T.n_bsdfs * kMatRow; i += kBlock) acc_mat[i] = 0.f;
     __syncthreads();
     S.rec = rec; S.ext = ext; S.lk = lk;
@@ -145,7 +147,7 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
             const LaneRng rng0 = rng;
             S.mode = 1; S.rec_n = 0; S.rec_i = 0; S.ext_n = 0; S.lk_n = 0; S.probe_kind = 0;
             const Vec3d L0 = Li<true, LDS, false>(S, rng, ray, true, P.max_depth, P.hide_emitters != 0);
-            const int n_hits = S.rec_n, n_ext = S.ext_n, n_lk = (has_env(LDS) && (P.g_tex != nullptr || P.g_env != nullptr)) ? S.lk_n : 0;
+            const int n_hits = S.rec_n, n_ext = S.ext_n, n_lk = (has_env(LDS) && (P.g_tex != nullptr || P.g_env != nullptr || P.g_env_xf != nullptr)) ? S.lk_n : 0;
             float w[3];
             {
                 const float pv[3] = {L0.x.v, L0.y.v, L0.z.v};
@@ -216,13 +218,22 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                     }
                     // stage 4: the camera pose - entry (r, c) of rows 0-2 of to_world moves the primary ray (origin = to_world . o_cam,
                     // direction = to_world . d_cam, perspective.cpp:160-178 / orthographic.cpp:161-181)
-                    if (st_stage == 3 && P.g_cam != nullptr) { st_stage = 4; st_comp = 0; }
-                    return st_stage == 4 && st_comp < 12;
+                    if (st_stage == 3) { st_stage = 4; st_comp = P.g_cam != nullptr ? 0 : 12; }
+                    if (st_stage == 4 && st_comp < 12) return true;
+                    // stage 5: the environment map's from_world (the 3x3 block that turns world directions into map directions);
+                    // only paths that looked the map up can depend on it
+                    if (st_stage == 4) {
+                        bool env_seen = false;
+                        if (P.g_env_xf != nullptr) for (int q = 0; q < n_lk; ++q) env_seen = env_seen || __float_as_int(lk[3 * q * kBlock]) == kEnvLookup;
+                        st_stage = 5; st_comp = env_seen ? 0 : 11;
+                    }
+                    while (st_comp < 11 && (st_comp & 3) == 3) ++st_comp;      // entries 0,1,2, 4,5,6, 8,9,10
+                    return st_comp < 11;
                 };
                 bool more = wactive && advance();
                 while (__ballot(more) != 0ull) {
                     if (more) {
-                        S.probe_kind = st_stage < 3 ? st_stage + 1 : (st_stage == 3 ? 5 : 4); S.probe_id = st_id; S.probe_comp = st_comp;
+                        S.probe_kind = st_stage < 3 ? st_stage + 1 : (st_stage == 3 ? 5 : (st_stage == 4 ? 4 : 7)); S.probe_id = st_id; S.probe_comp = st_comp;
                         if (st_stage == 1 && st_comp >= 3) { S.probe_kind = 6; S.probe_comp = st_comp - 3; }
                         if (st_stage == 3) { S.probe_u = lk[(3 * st_i + 1) * kBlock]; S.probe_v = lk[(3 * st_i + 2) * kBlock]; }
                         if (st_stage == 4) { ray_p = ray; primary_ray_pose_tangent(cam, sx, sy, st_comp, ray_p); }
@@ -232,6 +243,7 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                         else if (st_stage == 1) adj_add<LDS>(acc_bsdf, P.g_bsdf, st_id * 3 + st_comp, gval, use_lds);
                         else if (st_stage == 2) adj_add<LDS>(acc_emit, P.g_emitter, st_id * 3 + st_comp, gval, use_lds);
                         else if (st_stage == 4) { adj_add<LDS>(acc_cam, acc_cam, st_comp, gval, true); ray_p = ray; }
+                        else if (st_stage == 5) adj_add<LDS>(acc_cam, acc_cam, 16 + st_comp, gval, true);
                         else if constexpr (has_env(LDS)) {
                             // scatter over the footprint of the lookup (the transpose of the bilinear interpolation)
                             int idx[4]; float wt[4];
@@ -280,6 +292,7 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
     __syncthreads();
     if (P.g_cam != nullptr && threadIdx.x < 12 && acc_cam[threadIdx.x] != 0.f) atomicAdd(&P.g_cam[threadIdx.x], acc_cam[threadIdx.x]);
     if (P.g_env_scale != nullptr && threadIdx.x == 12 && acc_cam[12] != 0.f) atomicAdd(P.g_env_scale, acc_cam[12]);
+    if (P.g_env_xf != nullptr && threadIdx.x >= 16 && threadIdx.x < 27 && acc_cam[threadIdx.x] != 0.f) atomicAdd(&P.g_env_xf[threadIdx.x - 16], acc_cam[threadIdx.x]);
     if (P.g_mat != nullptr)
         for (int i = threadIdx.x; i < T.n_bsdfs * kMatRow; i += kBlock) if (acc_mat[i] != 0.f) atomicAdd(&P.g_mat[i], acc_mat[i]);
     if (use_lds) {

@@ -955,6 +955,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         if (g->g_camera) HIPCHK(hipMemsetAsync(g->g_camera, 0, sizeof(float) * 16, st));
         if (g->g_env && T.env_emitter >= 0) HIPCHK(hipMemsetAsync(g->g_env, 0, sizeof(float) * 3 * (size_t) T.env.width * T.env.height, st));
         if (g->g_env_scale) HIPCHK(hipMemsetAsync(g->g_env_scale, 0, sizeof(float), st));
+        if (g->g_env_from_world) HIPCHK(hipMemsetAsync(g->g_env_from_world, 0, sizeof(float) * 16, st));
         if (g->g_mat) HIPCHK(hipMemsetAsync(g->g_mat, 0, sizeof(float) * kMatRow * (size_t) std::max(1, T.n_bsdfs), st));
         if (g->g_sec_edges && sc->E.n > 0) HIPCHK(hipMemsetAsync(g->g_sec_edges, 0, sizeof(float) * 6 * (size_t) sc->E.n, st));
         if (g->g_prim_edges && cam.n_edges > 0) HIPCHK(hipMemsetAsync(g->g_prim_edges, 0, sizeof(float) * 4 * (size_t) cam.n_edges, st));
@@ -970,7 +971,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     // PSDR_ADJ_GLOBAL=1: run the interior adjoint of an LDS-class scene from global memory (no blob copy in LDS: more workgroups per CU)
     static const bool adj_global = std::getenv("PSDR_ADJ_GLOBAL") != nullptr;
     const int adj_cls = (use_lds && !adj_global) ? 1 : ((sc->lean || use_lds) && a->field_mode == 0 ? 2 : 0);
-    const size_t adj_bytes = sizeof(float) * ((size_t) adj_lane_words(with_lookups) * kBlock + 16 + (size_t) T.n_bsdfs * kMatRow + (lds_acc ? n_acc : 0));
+    const size_t adj_bytes = sizeof(float) * ((size_t) adj_lane_words(with_lookups) * kBlock + kAdjMisc + (size_t) T.n_bsdfs * kMatRow + (lds_acc ? n_acc : 0));
     const size_t smem = (adj_cls == 1 ? sc->smem_bytes : sc->smem_bytes - (sc->lds ? (size_t) T.blob_words * 16 : 0)) + adj_bytes;
     if (smem > 160 * 1024) return fail("scene too large for the adjoint kernel's LDS records");
     static bool attr_set = false;
@@ -991,6 +992,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         P.g_tex = sc->tex_total > 0 ? g->g_tex : nullptr;
         P.g_cam = g->g_camera;
         P.g_mat = sc->T.mat != nullptr ? g->g_mat : nullptr;
+        P.g_env_xf = sc->T.env_emitter >= 0 ? g->g_env_from_world : nullptr;
         P.g_env = sc->T.env_emitter >= 0 ? g->g_env : nullptr; P.g_env_scale = sc->T.env_emitter >= 0 ? g->g_env_scale : nullptr;
         if (P.n_local > 0) {
             if (next_queue(P.counter)) return 1;

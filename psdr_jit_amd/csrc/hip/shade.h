@@ -218,10 +218,10 @@ template <bool AD, int LDS> PSDR_DEV VecN<AD> env_eval_direction(const SceneView
     using R = Num<AD>;
     VecN<AD> v;
     if constexpr (AD) {
-        const bool tan = S.mode == 0;                              // probes put their own unit tangents
+        const bool tan = S.mode == 0;                              // probes put their own unit tangents (kind 7: one entry of from_world)
         Mat4<Dual> M;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) M.m[i] = Dual(E.from_world.m[i], tan ? E.d_from_world.m[i] : 0.f);
+        for (int i = 0; i < 16; ++i) M.m[i] = Dual(E.from_world.m[i], tan ? E.d_from_world.m[i] : ((S.probe_kind == 7 && S.probe_comp == i) ? 1.f : 0.f));
         v = xform_dir(M, wi);
     } else {
         v = xform_dir(E.from_world, wi);

@@ -336,7 +336,7 @@ def test_envmap_reverse_mode(psdr, orc):
     import torch
     rng = np.random.default_rng(3)
     spec = scenes.textured_scene(40, 40, 8, 0, 0, texture=scenes.checker_texture(8, 8), env=True)
-    env0 = np.asarray(spec.emitters[0].env_data, np.float32)
+    env0 = scenes.synthetic_envmap(64, 32)                    # with the sun: rotating a constant map would change nothing
     rad = torch.tensor(env0, requires_grad=True)
     scale = psdr.FloatD(1.25).requires_grad_()
     tex = torch.tensor(spec.bsdfs[0].texture, requires_grad=True)
@@ -354,8 +354,11 @@ def test_envmap_reverse_mode(psdr, orc):
     floor.load_raw(m.vertices, m.faces, m.uvs, m.face_uvs)
     sc.add_Mesh(floor, "tex", None)
     sc.add_Mesh(os.path.join(scenes.DATA, "cbox_smallbox.obj"), psdr.Matrix4fC(np.eye(4, dtype=np.float32).tolist()), "cat", None)
+    ang = psdr.FloatD(0.3).requires_grad_()
+    ca, sa = torch.cos(ang), torch.sin(ang)
     e = psdr.EnvironmentMap(rad)
     e.scale = scale
+    e.set_transform(psdr.Matrix4fD([[ca, 0., sa, 0.], [0., 1., 0., 0.], [-sa, 0., ca, 0.], [0., 0., 0., 1.]]))
     sc.add_EnvironmentMap(e)
     sc.configure()
     sc.configure([0])
@@ -366,7 +369,9 @@ def test_envmap_reverse_mode(psdr, orc):
     want_rad = float((psdr.forward_grad(img, rad, direction=v_rad) * w).sum())
     want_scale = float((psdr.forward_grad(img, scale) * w).sum())
     want_tex = float((psdr.forward_grad(img, tex, direction=v_tex) * w).sum())
+    want_ang = float((psdr.forward_grad(img, ang) * w).sum())
     (img * w).sum().backward()
+    assert abs(want_ang) > 1e-3 and abs(float(ang.grad) - want_ang) < 3e-3 * max(1.0, abs(want_ang)), (float(ang.grad), want_ang)
     got_rad, got_scale, got_tex = float((rad.grad * v_rad).sum()), float(scale.grad), float((tex.grad * v_tex).sum())
     for name, got, want in (("radiance", got_rad, want_rad), ("scale", got_scale, want_scale), ("texture", got_tex, want_tex)):
         assert abs(want) > 1e-3 and abs(got - want) < 2e-3 * max(1.0, abs(want)), (name, got, want)
