@@ -730,6 +730,22 @@ def _render_d_raw(self, scene, sensor_id, seed, batch_pix, terms, distributed=No
     return buf[0], buf[1]
 
 
+def _bsdf_index(scene, obj):
+    """row of a BSDF in the configured snapshot: the scene's own BSDFs in order, then the BSDFs nested in normal maps"""
+    pm = scene.param_map
+    nb = sum(1 for k in pm if k.startswith("BSDF[") and not k.startswith("BSDF[id="))
+    hidden = nb
+    for k in range(nb):
+        b = pm["BSDF[%d]" % k]
+        if b is obj:
+            return k
+        if isinstance(b, NormalMapBSDF):
+            if b._nested is obj:
+                return hidden
+            hidden += 1
+    raise RuntimeError("BSDF is not part of the scene")
+
+
 def _mesh_index(scene, mesh):
     for i in range(scene.num_meshes):
         if scene.param_map.get("Mesh[%d]" % i) is mesh:
@@ -765,7 +781,9 @@ class _RenderDFn(_torch.autograd.Function):
         pm = scene.param_map
         nb = sum(1 for k in pm if k.startswith("BSDF[") and not k.startswith("BSDF[id="))
         ne = sum(1 for k in pm if k.startswith("Emitter[") and not k.startswith("Emitter[id="))
-        sizes = [n_tris * 22, max(1, nb) * 3, max(1, ne) * 3, max(1, n_sec) * 6, max(1, n_prim) * 4]
+        # BSDF rows of the snapshot: the scene's own, then the ones nested in normal maps
+        n_hidden = sum(1 for k in range(nb) if isinstance(pm["BSDF[%d]" % k], NormalMapBSDF))
+        sizes = [n_tris * 22, max(1, nb + n_hidden) * 3, max(1, ne) * 3, max(1, n_sec) * 6, max(1, n_prim) * 4]
         flat = _torch.zeros(sum(sizes), dtype=_torch.float32, device=dev)
         offs = [0]
         for z in sizes:
@@ -803,7 +821,7 @@ class _RenderDFn(_torch.autograd.Function):
                     "RoughDielectricBSDF": {"alpha_u": (0, 1), "alpha_v": (1, 1), "eta": (2, 1)}}
         mat_leaves = [i for i, ((obj, name, t), need) in enumerate(zip(leaves, needs))
                       if need and t.dim() < 2 and name in mat_rows.get(type(obj).__name__, {})]
-        g_mat = _torch.zeros(16 * max(1, nb), dtype=_torch.float32, device=dev) if mat_leaves else None
+        g_mat = _torch.zeros(16 * max(1, nb + n_hidden), dtype=_torch.float32, device=dev) if mat_leaves else None
         env_leaves = [i for i, ((obj, name, t), need) in enumerate(zip(leaves, needs)) if need and isinstance(obj, EnvironmentMap)]
         g_env = g_env_scale = g_env_xf = None
         for i in env_leaves:
@@ -830,7 +848,8 @@ class _RenderDFn(_torch.autograd.Function):
         if g_tex is not None:
             _all_reduce(g_tex, world > 1)
         g = flat.to("cpu", _torch.float64)
-        g_tri, g_bsdf, g_em = g[offs[0]:offs[1]].reshape(n_tris, 22), g[offs[1]:offs[2]].reshape(-1, 3)[:nb], g[offs[2]:offs[3]].reshape(-1, 3)[:ne]
+        g_bsdf_all = g[offs[1]:offs[2]].reshape(-1, 3)
+        g_tri, g_bsdf, g_em = g[offs[0]:offs[1]].reshape(n_tris, 22), g_bsdf_all[:nb], g[offs[2]:offs[3]].reshape(-1, 3)[:ne]
         g_sec, g_prim = g[offs[3]:offs[4]].reshape(-1, 6)[:n_sec], g[offs[4]:offs[5]].reshape(-1, 4)[:n_prim]
 
         fresh = {}
@@ -862,13 +881,20 @@ class _RenderDFn(_torch.autograd.Function):
                 grads[i] = _torch.zeros_like(t) if r is None else r.reshape(t.shape).to(t.device, t.dtype)
         for i in tex_leaves:          # the leaf IS the texel array: its gradient is its block of g_tex
             obj, name, t = leaves[i]
-            b = next(k for k in range(nb) if pm["BSDF[%d]" % k] is obj)
-            slot = {"reflectance": 0, "diffuseReflectance": 0, "specularReflectance": 1, "roughness": 2}[name]
+            b = _bsdf_index(scene, obj)
+            slot = {"reflectance": 0, "diffuseReflectance": 0, "specularReflectance": 1, "roughness": 2, "normal_map": 0,
+                    "eta": 0, "k": 1, "alpha_u": 2, "alpha_v": 2}[name]       # the three bitmap / per-vertex slots of a BSDF
             off = int(tex_off[3 * b + slot])
             grads[i] = _torch.zeros_like(t) if off < 0 else g_tex[off:off + t.numel()].reshape(t.shape).to(t.device, t.dtype)
+        for i, ((obj, name, t), need) in enumerate(zip(leaves, needs)):      # the colour of a BSDF nested in a normal map: its own g_bsdf row
+            if need and isinstance(obj, _core.BSDF) and t.dim() < 2 and name in ("reflectance", "diffuseReflectance"):
+                b = _bsdf_index(scene, obj)
+                if b >= nb:
+                    row = g_bsdf_all[b].to(_torch.float32)
+                    grads[i] = (row if t.numel() == 3 else row.sum().reshape(1)).reshape(t.shape).to(t.device, t.dtype)
         for i in mat_leaves:          # a colour given as one number is the sum of its three components
             obj, name, t = leaves[i]
-            b = next(k for k in range(nb) if pm["BSDF[%d]" % k] is obj)
+            b = _bsdf_index(scene, obj)
             off, n = mat_rows[type(obj).__name__][name]
             row = g_mat[16 * b + off:16 * b + off + n]
             grads[i] = (row if t.numel() == n else row.sum().reshape(1)).reshape(t.shape).to(t.device, t.dtype)

@@ -195,10 +195,19 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                             }
                             st_id = id;
                             if (valid && st_stage == 1) {
-                                // components 0-2 the colour (g_bsdf), 3.. the constant parameters of a GGX BSDF (g_mat)
-                                if (P.skip_bsdf && st_comp < 3) st_comp = 3;
-                                const int nm = P.g_mat != nullptr ? mat_param_count(__float_as_int(S.ld(T.bsdf_off + 2 * id).w)) : 0;
-                                if (st_comp >= 3 + nm) valid = false;
+                                // components 0-2 the colour (g_bsdf), 3.. the constant parameters of a GGX BSDF (g_mat); a normal map is
+                                // followed by the BSDF nested in it (components 32.. = the same list for the nested record)
+                                const int fl = __float_as_int(S.ld(T.bsdf_off + 2 * id).w);
+                                const int nested = (fl & 256) ? __float_as_int(S.ld(T.bsdf_off + 2 * id + 1).w) : -1;
+                                for (;;) {
+                                    const bool inner = st_comp >= 32;
+                                    const int c = inner ? st_comp - 32 : st_comp, bid = inner ? nested : id;
+                                    const int nm = P.g_mat != nullptr ? mat_param_count(__float_as_int(S.ld(T.bsdf_off + 2 * bid).w)) : 0;
+                                    if (P.skip_bsdf && c < 3) { st_comp += 3 - c; continue; }
+                                    if (c < 3 + nm) { st_id = bid; break; }
+                                    if (!inner && nested >= 0) { st_comp = 32; continue; }
+                                    valid = false; break;
+                                }
                             }
                         }
                         if (!valid) { ++st_i; st_comp = 0; continue; }
@@ -234,13 +243,14 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                 while (__ballot(more) != 0ull) {
                     if (more) {
                         S.probe_kind = st_stage < 3 ? st_stage + 1 : (st_stage == 3 ? 5 : (st_stage == 4 ? 4 : 7)); S.probe_id = st_id; S.probe_comp = st_comp;
-                        if (st_stage == 1 && st_comp >= 3) { S.probe_kind = 6; S.probe_comp = st_comp - 3; }
+                        const int bc = (st_stage == 1 && st_comp >= 32) ? st_comp - 32 : st_comp;      // component within the (own or nested) BSDF
+                        if (st_stage == 1) { S.probe_kind = bc >= 3 ? 6 : 2; S.probe_comp = bc >= 3 ? bc - 3 : bc; }
                         if (st_stage == 3) { S.probe_u = lk[(3 * st_i + 1) * kBlock]; S.probe_v = lk[(3 * st_i + 2) * kBlock]; }
                         if (st_stage == 4) { ray_p = ray; primary_ray_pose_tangent(cam, sx, sy, st_comp, ray_p); }
                         const float gval = probe();
                         if (st_stage == 0) adj_add<LDS>(acc, P.g_tri, st_orig * 22 + st_comp, gval, use_lds);
-                        else if (st_stage == 1 && st_comp >= 3) adj_add<LDS>(acc_mat, acc_mat, st_id * kMatRow + st_comp - 3, gval, true);
-                        else if (st_stage == 1) adj_add<LDS>(acc_bsdf, P.g_bsdf, st_id * 3 + st_comp, gval, use_lds);
+                        else if (st_stage == 1 && bc >= 3) adj_add<LDS>(acc_mat, acc_mat, st_id * kMatRow + bc - 3, gval, true);
+                        else if (st_stage == 1) adj_add<LDS>(acc_bsdf, P.g_bsdf, st_id * 3 + bc, gval, use_lds);
                         else if (st_stage == 2) adj_add<LDS>(acc_emit, P.g_emitter, st_id * 3 + st_comp, gval, use_lds);
                         else if (st_stage == 4) { adj_add<LDS>(acc_cam, acc_cam, st_comp, gval, true); ray_p = ray; }
                         else if (st_stage == 5) adj_add<LDS>(acc_cam, acc_cam, 16 + st_comp, gval, true);

@@ -459,10 +459,12 @@ PYBIND11_MODULE(_psdr_core, m) {
     // (offsets[3*n_bsdfs], total) of psdr_hip_scene_tex_layout
     m.def("_tex_layout", [](const Scene &scene) {
         if (!scene.is_ready()) throw Exception("Input scene must be configured!");
-        std::vector<int64_t> off((size_t) 3 * std::max<size_t>(1, scene.m_bsdfs.size()), -1);
+        // rows = the snapshot's BSDFs: the scene's own, then the ones nested in normal maps
+        const size_t nb = scene.snap.bsdfs.size();
+        std::vector<int64_t> off((size_t) 3 * std::max<size_t>(1, nb), -1);
         int64_t total = 0;
         if (psdr_hip_scene_tex_layout(scene.m_hip, off.data(), &total)) throw Exception(std::string("libpsdr_hip: ") + psdr_hip_last_error());
-        off.resize((size_t) 3 * scene.m_bsdfs.size());
+        off.resize((size_t) 3 * nb);
         return py::make_tuple(off, total);
     });
 

@@ -608,3 +608,51 @@ def test_normalmap_api_and_xml(psdr, orc):
     assert type(g).__name__ == "NormalMapBSDF" and type(g.nested_bsdf).__name__ == "RoughConductorBSDF"
     with pytest.raises(RuntimeError, match="Unsupported normal map nested BSDF"):
         psdr.Scene().load_string('<scene><bsdf type="normalmap" id="g"><rgb name="normalmap" value="0.5"/><bsdf type="normalmap"/></bsdf></scene>', False)
+
+
+def test_normalmap_and_conductor_maps_reverse_mode(psdr, orc):
+    """loss.backward() into a normal map's texels, into the parameters of the BSDF nested in it, and into the eta map of a RoughConductor:
+    <w, J v> == <J^T w, v> against forward mode"""
+    import torch
+    rng = np.random.default_rng(17)
+    spec = scenes.normalmap_scene(40, 40, 8, 0, 0)
+    nmap = torch.tensor(spec.bsdfs[0].texture, requires_grad=True)
+    rough = psdr.FloatD(0.35).requires_grad_()
+    diff = torch.tensor([0.3, 0.25, 0.2], requires_grad=True)
+    eta = torch.tensor((0.2 + rng.random((4, 5, 3))).astype(np.float32), requires_grad=True)
+    sc = psdr.Scene()
+    sc.opts.spp, sc.opts.sppe, sc.opts.sppse = 8, 0, 0
+    sc.opts.width = sc.opts.height = 40
+    sc.opts.log_level = 0
+    cam = psdr.PerspectiveCamera(60, 0.000001, 10000000.)
+    cam.to_world = psdr.Matrix4fD(np.asarray(spec.cameras[0].to_world_raw).tolist())
+    sc.add_Sensor(cam)
+    nm = psdr.NormalMapBSDF(nmap)
+    nm.nested_bsdf = psdr.MicrofacetBSDF([0.7, 0.6, 0.5], diff, rough)
+    sc.add_BSDF(nm, "tex")
+    sc.add_BSDF(psdr.RoughConductorBSDF(0.25, eta, [3.9, 2.4, 2.1]), "cat")
+    sc.add_BSDF(psdr.DiffuseBSDF([0.0, 0.0, 0.0]), "light")
+    floor = psdr.Mesh()
+    m = spec.meshes[0]
+    floor.load_raw(m.vertices, m.faces, m.uvs, m.face_uvs)
+    sc.add_Mesh(floor, "tex", None)
+    # the box needs uv for its eta map: give it the floor's quad layout per face is overkill - use a second uv-mapped quad instead
+    wall = psdr.Mesh()
+    v = np.array([[100, 0, 400], [460, 0, 400], [460, 300, 400], [100, 300, 400]], np.float32)
+    f = np.array([[0, 2, 1], [0, 3, 2]], np.int32)            # facing the camera (-z)
+    wall.load_raw(v, f, m.uvs, f.copy())
+    sc.add_Mesh(wall, "cat", None)
+    sc.add_Mesh(os.path.join(scenes.DATA, "cbox_luminaire.obj"), psdr.Matrix4fC(scenes.translate(0.0, -100.0, 0.0).tolist()), "light", psdr.AreaLight([20.0, 20.0, 8.0]))
+    sc.configure()
+    sc.configure([0])
+    img = psdr.PathTracer(2).renderD(sc, 0, seed=5)
+    w = torch.linspace(0.5, 1.5, img.numel(), device=img.device).reshape(img.shape)
+    fwd = {}
+    for name, t in (("normal map", nmap), ("nested roughness", rough), ("nested diffuse", diff), ("eta map", eta)):
+        v_ = torch.tensor(rng.standard_normal(tuple(t.shape)).astype(np.float32)) if t.dim() > 0 else torch.tensor(1.0)
+        fwd[name] = (t, v_, float((psdr.forward_grad(img, t, direction=v_) * w).sum()))
+    (img * w).sum().backward()
+    for name, (t, v_, want) in fwd.items():
+        assert t.grad is not None, name
+        got = float((t.grad * v_).sum())
+        assert abs(want) > 1e-4 and abs(got - want) < 3e-3 * max(1.0, abs(want)), (name, got, want)
