@@ -92,7 +92,10 @@ template <bool AD, int LDS, bool COUNT, int MODE>
 #ifndef PSDR_GLOBAL_C_WAVES
 #define PSDR_GLOBAL_C_WAVES 4
 #endif
-__global__ __launch_bounds__(kBlock, (AD ? 3 : (in_lds(LDS) ? 4 : PSDR_GLOBAL_C_WAVES))) void k_paths(const float4 *__restrict__ blob, const SceneTables T, const SensorDev cam,
+#ifndef PSDR_GLOBAL_AD_WAVES
+#define PSDR_GLOBAL_AD_WAVES 3
+#endif
+__global__ __launch_bounds__(kBlock, (AD ? (in_lds(LDS) ? 3 : PSDR_GLOBAL_AD_WAVES) : (in_lds(LDS) ? 4 : PSDR_GLOBAL_C_WAVES))) void k_paths(const float4 *__restrict__ blob, const SceneTables T, const SensorDev cam,
                                                   const PathParams P, Counters *ctr) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     SceneView<LDS> S = make_view<LDS>(blob, T, smem);
