@@ -78,7 +78,10 @@ def pmc(tag):
                 fh.write("    %-28s %18.0f   bytes/launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024\n" % ("HBM traffic", t))
                 key = {"k_interior<true, true, false>": "k_interior<AD>", "k_primary_edges<true, false>": "k_primary_edges",
                        "k_paths<true, true, false, 0>": "k_interior<AD>", "k_paths<false, true, false, 1>": "k_primary_edges",
-                       "k_secondary_edges<true, false>": "k_secondary_edges", "k_secondary_edges<true, false, false>": "k_secondary_edges"}.get(k, k)
+                       "k_secondary_edges<true, false>": "k_secondary_edges", "k_secondary_edges<true, false, false>": "k_secondary_edges",
+                       # scene classes (int template parameter since r01i): class 1 = the LDS kernels bench.py runs
+                       "k_paths<true, 1, false, 0>": "k_interior<AD>", "k_paths<false, 1, false, 1>": "k_primary_edges",
+                       "k_secondary_edges<1, false, false>": "k_secondary_edges"}.get(k, k)
                 traffic[key] = t
             tc, ai = cs.get("SQ_THREAD_CYCLES_VALU", (None, 0))[0], cs.get("SQ_ACTIVE_INST_VALU", (None, 0))[0]
             if tc is not None and ai:
@@ -86,8 +89,9 @@ def pmc(tag):
             h, m = cs.get("TCC_HIT_sum", (None, 0))[0], cs.get("TCC_MISS_sum", (None, 0))[0]
             if h is not None and m is not None and h + m > 0:
                 fh.write("    %-28s %18.4f   TCC_HIT/(TCC_HIT+TCC_MISS)\n" % ("L2 hit rate", h / (h + m)))
-    with open(os.path.join(PROF, "hbm_traffic.json"), "w") as fh:
-        json.dump(traffic, fh, indent=1)
+    if not PREFIX:          # only the bench.py profile (tools/profile.sh) feeds bench.py's roofline.traffic
+        with open(os.path.join(PROF, "hbm_traffic.json"), "w") as fh:
+            json.dump(traffic, fh, indent=1)
 
 
 if __name__ == "__main__":
