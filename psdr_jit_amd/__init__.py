@@ -815,6 +815,7 @@ class _RenderDFn(_torch.autograd.Function):
             tex_off, tex_total = _core._tex_layout(scene)
             g_tex = _torch.zeros(max(1, int(tex_total)), dtype=_torch.float32, device=dev)
         g_cam = _torch.zeros(16, dtype=_torch.float32, device=dev) if want_cam else None
+        bpix = _pix(st["batch_pix"], dev)             # batch rendering: the adjoint image is [len(batch_pix), 3]
         # constant parameters of the GGX BSDFs: (row offset, length) inside the BSDF's 16-float row of psdr_grads.g_mat
         mat_rows = {"MicrofacetBSDF": {"specularReflectance": (0, 3), "roughness": (3, 1)},
                     "RoughConductorBSDF": {"alpha_u": (0, 1), "alpha_v": (1, 1), "eta": (2, 3), "k": (5, 3), "specular_reflectance": (8, 3)},
@@ -838,7 +839,8 @@ class _RenderDFn(_torch.autograd.Function):
                             _stream_ptr(), rank, world, st["terms"], mesh_filter.data_ptr(), not want_bsdf, not want_em,
                             g_tex.data_ptr() if g_tex is not None else 0, g_cam.data_ptr() if g_cam is not None else 0,
                             g_env.data_ptr() if g_env is not None else 0, g_env_scale.data_ptr() if g_env_scale is not None else 0,
-                            g_mat.data_ptr() if g_mat is not None else 0, g_env_xf.data_ptr() if g_env_xf is not None else 0)
+                            g_mat.data_ptr() if g_mat is not None else 0, g_env_xf.data_ptr() if g_env_xf is not None else 0,
+                            bpix.data_ptr() if bpix is not None else 0, int(bpix.numel()) if bpix is not None else 0)
         _all_reduce(flat, world > 1)
         for extra in (g_env, g_env_scale, g_mat, g_env_xf):
             if extra is not None:

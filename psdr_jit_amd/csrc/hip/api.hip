@@ -934,11 +934,12 @@ int psdr_hip_scene_tex_layout(const psdr_hip_scene *sc, int64_t *offsets, int64_
 int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, const float *d_rgb, const psdr_grads *g, void *stream) {
     if (check_args(sc, a)) return 1;
     if (!d_rgb || !g || !g->g_triangles || !g->g_bsdf || !g->g_emitter) return fail("null gradient buffer");
-    if (a->pix_ids) return fail("reverse mode of batch rendering is not supported");
+    // batch rendering (integrator.cpp:139-176): d_rgb is [n_pix*3]; only the interior term exists for a pixel list (as in the forward path)
     if (a->max_depth > kAdjMaxDepth) return fail("reverse mode supports max_depth <= 4");
     const SceneTables &T = sc->T;
     hipStream_t st = (hipStream_t) stream;
-    const long long npx = (long long) T.width * T.height;
+    const long long npx_full = (long long) T.width * T.height;
+    const long long npx = a->pix_ids ? a->n_pix : npx_full;
     const int count = a->shard_count > 1 ? a->shard_count : 1;
     const int rank = count > 1 ? a->shard_rank : 0;
     if (rank < 0 || rank >= count) return fail("bad shard rank");
@@ -989,7 +990,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     if ((terms & PSDR_TERM_INTERIOR) && T.spp > 0) {
         AdjointParams P{};
         P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[0].seed; P.skip = a->samplers[0].skip;
-        P.begin = 0; P.end = npx * T.spp; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
+        P.pix_ids = a->pix_ids; P.begin = 0; P.end = npx * T.spp; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
         P.w = d_rgb; P.g_tri = g->g_triangles; P.g_bsdf = g->g_bsdf; P.g_emitter = g->g_emitter; P.lds_accum = lds_acc ? 1 : 0;
         P.mesh_filter = g->mesh_filter; P.skip_bsdf = g->skip_bsdf; P.skip_emitter = g->skip_emitter;
         P.g_tex = sc->tex_total > 0 ? g->g_tex : nullptr;
@@ -1006,11 +1007,11 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
             else hipLaunchKernelGGL((k_interior_adjoint<0>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, cam, P);
         }
     }
-    if ((terms & PSDR_TERM_PRIMARY) && T.sppe > 0 && cam.n_edges > 0) {
+    if (!a->pix_ids && (terms & PSDR_TERM_PRIMARY) && T.sppe > 0 && cam.n_edges > 0) {
         if (!g->g_prim_edges) return fail("g_prim_edges is required when the primary-edge term is requested");
         PathParams P{};
         P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[1].seed; P.skip = a->samplers[1].skip;
-        P.begin = 0; P.end = npx * T.sppe; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
+        P.begin = 0; P.end = npx_full * T.sppe; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
         P.adj_w = d_rgb; P.g_prim = g->g_prim_edges; P.n_prim = cam.n_edges; P.lds_acc = (cam.n_edges <= 2048) ? 1 : 0;
         if (P.n_local > 0) {
             if (next_queue(P.counter)) return 1;
@@ -1021,11 +1022,11 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
             else hipLaunchKernelGGL((k_paths<false, 0, false, 1>), dim3(grid), dim3(kBlock), sm, st, sc->blob.as<float4>(), T, cam, P, (Counters *) nullptr);
         }
     }
-    if ((terms & PSDR_TERM_SECONDARY) && T.sppse > 0 && sc->E.n > 0) {
+    if (!a->pix_ids && (terms & PSDR_TERM_SECONDARY) && T.sppse > 0 && sc->E.n > 0) {
         if (!g->g_sec_edges) return fail("g_sec_edges is required when the secondary-edge term is requested");
         PathParams P{};
         P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[2].seed; P.skip = a->samplers[2].skip;
-        P.begin = 0; P.end = npx * T.sppse; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
+        P.begin = 0; P.end = npx_full * T.sppse; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
         P.adj_w = d_rgb; P.g_sec = g->g_sec_edges; P.g_tri = g->g_triangles; P.n_sec = sc->E.n;
         P.g_cam = g->g_camera;
         const size_t sec_acc = sizeof(float) * (6 * (size_t) sc->E.n + 22 * (size_t) T.n_tris);

@@ -418,7 +418,7 @@ PYBIND11_MODULE(_psdr_core, m) {
 
     m.def("_render_d_bwd", [](const Integrator &it, const Scene &scene, int sensor_id, const std::vector<uint64_t> &seeds, const std::vector<uint64_t> &skips,
                               uintptr_t d_rgb, uintptr_t g_tri, uintptr_t g_bsdf, uintptr_t g_emitter, uintptr_t g_sec, uintptr_t g_prim, uintptr_t stream,
-                              int rank, int count, int terms, uintptr_t mesh_filter, bool skip_bsdf, bool skip_emitter, uintptr_t g_tex, uintptr_t g_cam, uintptr_t g_env, uintptr_t g_env_scale, uintptr_t g_mat, uintptr_t g_env_xf) {
+                              int rank, int count, int terms, uintptr_t mesh_filter, bool skip_bsdf, bool skip_emitter, uintptr_t g_tex, uintptr_t g_cam, uintptr_t g_env, uintptr_t g_env_scale, uintptr_t g_mat, uintptr_t g_env_xf, uintptr_t pix_ids, int n_pix) {
         if (!scene.is_ready()) throw Exception("Input scene must be configured!");
         psdr_render_args a;
         std::memset(&a, 0, sizeof(a));
@@ -426,6 +426,7 @@ PYBIND11_MODULE(_psdr_core, m) {
         for (int k = 0; k < 3; ++k) { a.samplers[k].seed = seeds[k]; a.samplers[k].skip = skips[k]; }
         a.shard_rank = rank; a.shard_count = count; a.zero_output = 1; a.terms = terms; a.guiding = it.guiding(sensor_id);
         a.direct_mode = it.direct_mis() + 1;
+        a.pix_ids = reinterpret_cast<const int32_t *>(pix_ids); a.n_pix = pix_ids ? n_pix : 0;       // batch rendering: interior term only
         a.field_mode = it.field() + 1; a.field_object = -1; a.intensity = it.intensity(false);
         if (!it.field_object().empty()) throw Exception("reverse mode: FieldExtractionIntegrator with an object filter is not supported");
         psdr_grads g{reinterpret_cast<float *>(g_tri), reinterpret_cast<float *>(g_bsdf), reinterpret_cast<float *>(g_emitter),

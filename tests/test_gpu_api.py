@@ -656,3 +656,29 @@ def test_normalmap_and_conductor_maps_reverse_mode(psdr, orc):
         assert t.grad is not None, name
         got = float((t.grad * v_).sum())
         assert abs(want) > 1e-4 and abs(got - want) < 3e-3 * max(1.0, abs(want)), (name, got, want)
+
+
+def test_batch_render_reverse_mode(psdr, orc):
+    """renderD(seed, batch_pix) followed by loss.backward() (crop-wise optimisation, reference integrator.cpp:139-176): the gradient
+    of a crop equals the forward derivative of the same crop, and a crop of the full-frame primal is reproduced"""
+    import torch
+    P = psdr.FloatD(0.).requires_grad_()
+    refl = torch.tensor([0.5, 0.5, 0.5], requires_grad=True)
+    sc = _readme_scene(psdr, P, res=32, spp=8)
+    sc.opts.sppe = sc.opts.sppse = 0
+    sc.param_map["BSDF[id=cat]"].reflectance = refl
+    sc.configure([0])
+    pix = np.arange(32 * 32).reshape(32, 32)[8:24, 4:20].reshape(-1)
+    integ = psdr.PathTracer(2)
+    img = integ.renderD(sc, 0, seed=3, batch_pix=pix)
+    assert tuple(img.shape) == (len(pix), 3)
+    full = integ.renderC(sc, 0, seed=3).cpu().numpy()
+    # (pixel k of the crop uses the seeds of pixel pix[k] of the full frame but its own lane index: equal in the mean)
+    assert abs(img.detach().cpu().numpy().mean() - full[pix].mean()) < 0.1 * full[pix].mean()
+    w = torch.linspace(0.5, 1.5, img.numel(), device=img.device).reshape(img.shape)
+    want_P = float((psdr.forward_grad(img, P) * w).sum())
+    want_r = float((psdr.forward_grad(img, refl, direction=torch.tensor([1.0, -0.5, 0.25])) * w).sum())
+    (img * w).sum().backward()
+    assert abs(want_P) > 1e-3 and abs(float(P.grad) - want_P) < 2e-3 * max(1.0, abs(want_P)), (float(P.grad), want_P)
+    got_r = float((refl.grad * torch.tensor([1.0, -0.5, 0.25])).sum())
+    assert abs(got_r - want_r) < 2e-3 * max(1.0, abs(want_r)), (got_r, want_r)
