@@ -649,9 +649,12 @@ Scene.load_string = _load_string
 Scene.configure = _configure
 
 
-def _leaves(scene):
-    """[(object, name, tensor)] for every torch-valued scene parameter."""
+def _leaves(scene, integ=None):
+    """[(object, name, tensor)] for every torch-valued scene parameter (and the integrator's own, e.g. CollocatedIntegrator.m_intensity)."""
     out = []
+    if integ is not None:
+        for name, t in sorted(integ.__dict__.get("_psdr_params", {}).items()):
+            out.append((integ, name, t))
     for key in sorted(scene.__dict__.get("_psdr_objs", {})):
         obj = scene.__dict__["_psdr_objs"][key]
         for name, t in sorted(obj.__dict__.get("_psdr_params", {}).items()):
@@ -659,9 +662,9 @@ def _leaves(scene):
     return out
 
 
-def _sync_params(scene, tangents=None):
+def _sync_params(scene, tangents=None, integ=None):
     """Push current tensor values (and optional tangents {id(tensor): array}) into the host objects."""
-    for obj, name, t in _leaves(scene):
+    for obj, name, t in _leaves(scene, integ):
         v = t.detach().to("cpu", _torch.float32).numpy()
         shape = (4, 4) if name.startswith("to_world") else ((obj.num_vertices, 3) if name == "vertex_positions" else (-1,))
         if isinstance(obj, (_core.BSDF, _core.Emitter)) and t.dim() >= 2 and not name.startswith("to_world"):
@@ -900,6 +903,9 @@ class _RenderDFn(_torch.autograd.Function):
             off, n = mat_rows[type(obj).__name__][name]
             row = g_mat[16 * b + off:16 * b + off + n]
             grads[i] = (row if t.numel() == n else row.sum().reshape(1)).reshape(t.shape).to(t.device, t.dtype)
+        for i, ((obj, name, t), need) in enumerate(zip(leaves, needs)):      # CollocatedIntegrator.m_intensity: the image is linear in it
+            if need and obj is integ and name == "m_intensity":
+                grads[i] = ((g_img * st["img"]).sum() / t.detach().to(dev).reshape(())).reshape(t.shape).to(t.device, t.dtype)
         for i in env_leaves:
             obj, name, t = leaves[i]
             if name in ("radiance", "scale"):
@@ -917,7 +923,7 @@ class _RenderDFn(_torch.autograd.Function):
 
 def _replay_forward(integ, scene, st, tangents):
     """Re-render with the sampler state of the recorded call and the given leaf tangents."""
-    _sync_params(scene, tangents)
+    _sync_params(scene, tangents, integ)
     scene._configure(st["active"])
     after = [scene._sampler_state(k) for k in range(3)]
     for k, s in enumerate(st["samplers"]):
@@ -931,7 +937,10 @@ def _replay_forward(integ, scene, st, tangents):
 def _renderD(self, scene, sensor_id=0, seed=-1, batch_pix=-1, terms=TERM_ALL):
     """Integrator.renderD (reference integrator.cpp:51-100).  Returns the image as a tensor attached
     to the autograd graph of the scene's torch parameters."""
-    leaves = _leaves(scene)
+    leaves = _leaves(scene, self)
+    for _name, _t in self.__dict__.get("_psdr_params", {}).items():       # the integrator's own tensor parameters (m_intensity)
+        _v = _t.detach().to("cpu", _torch.float32).numpy().reshape(-1)
+        self._set(_name, _v, _zeros_like(_v))
     state = {"integrator": self, "scene": scene, "sensor_id": sensor_id, "batch_pix": batch_pix, "terms": terms,
              "active": scene.__dict__.get("_psdr_active", []), "leaves": leaves, "seed": seed,
              "samplers": [scene._sampler_state(k) for k in range(3)]}      # the streams this call starts from
@@ -969,7 +978,7 @@ def forward_grad(img, param, direction=None):
         if jv is not None:
             tangents[id(t)] = jv.detach().cpu().numpy()
     dimg = _replay_forward(st["integrator"], st["scene"], st, tangents)
-    _sync_params(st["scene"])
+    _sync_params(st["scene"], None, st["integrator"])
     st["scene"]._configure(st["active"])
     return dimg
 

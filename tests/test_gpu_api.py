@@ -682,3 +682,20 @@ def test_batch_render_reverse_mode(psdr, orc):
     assert abs(want_P) > 1e-3 and abs(float(P.grad) - want_P) < 2e-3 * max(1.0, abs(want_P)), (float(P.grad), want_P)
     got_r = float((refl.grad * torch.tensor([1.0, -0.5, 0.25])).sum())
     assert abs(got_r - want_r) < 2e-3 * max(1.0, abs(want_r)), (got_r, want_r)
+
+
+def test_collocated_intensity_is_differentiable(psdr, orc):
+    """CollocatedIntegrator.m_intensity (FloatD in the reference, collocated.h): forward and reverse derivative = image / intensity"""
+    import torch
+    P = psdr.FloatD(0.).requires_grad_()
+    sc = _readme_scene(psdr, P, res=32, spp=4)
+    col = psdr.CollocatedIntegrator(2e5)
+    inten = psdr.FloatD(2e5).requires_grad_()
+    col.m_intensity = inten
+    img = col.renderD(sc, 0, seed=2)
+    w = torch.linspace(0.5, 1.5, img.numel(), device=img.device).reshape(img.shape)
+    d = psdr.forward_grad(img, inten)
+    assert float(img.detach().abs().sum()) > 0 and torch.allclose(d, img.detach() / 2e5, rtol=1e-4, atol=1e-12)
+    (img * w).sum().backward()
+    want = float((img.detach() * w).sum()) / 2e5
+    assert abs(float(inten.grad) - want) < 1e-4 * abs(want)
