@@ -56,7 +56,7 @@ def build_core(force=False):
     if force or _stale(CORE_LIB, HOST_SRCS + HOST_DEPS + [HIP_LIB]):
         import pybind11
         inc = ["-I" + sysconfig.get_paths()["include"], "-I" + pybind11.get_include()]
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden"] + inc + HOST_SRCS +
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-fopenmp"] + inc + HOST_SRCS +
              ["-o", CORE_LIB, "-L" + LIBDIR, "-lpsdr_hip", "-Wl,-rpath,$ORIGIN/lib"])
     return CORE_LIB
 

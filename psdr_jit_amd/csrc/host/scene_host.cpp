@@ -54,9 +54,16 @@ void EnvironmentMap::configure() {
     PSDR_ASSERT_MSG(data.size() == (size_t) 3 * width * height, "Bitmap: invalid data size!");
     const int w2 = (width - 1) << 1, h2 = (height - 1) << 1;
     reso[0] = w2; reso[1] = h2;
-    std::vector<float> mass((size_t) w2 * h2);
-    for (int idx = 0; idx < w2 * h2; ++idx) mass[idx] = psdr::env::cell_mass(data.data(), width, height, w2, h2, idx);
-    cell_distrb.init(mass);
+    // the cell distribution depends on the texels only: rebuilt when they changed (2 M cells for a 1024 x 512 map; the reference
+    // recomputes it on the device in every Scene::configure), independent cells in parallel on the host cores
+    if (m_cells_dirty || (int) cell_distrb.pmf.size() != w2 * h2) {
+        std::vector<float> mass((size_t) w2 * h2);
+        const int n_cells = w2 * h2;
+#pragma omp parallel for schedule(static)
+        for (int idx = 0; idx < n_cells; ++idx) mass[idx] = psdr::env::cell_mass(data.data(), width, height, w2, h2, idx);
+        cell_distrb.init(mass);
+        m_cells_dirty = false;
+    }
     const M16 z = zeros16();
     const DM4 tw = DM4::from(to_world_left, d_to_world_left) * DM4::from(to_world_raw, z);
     const DM4 fw = inverse(tw);

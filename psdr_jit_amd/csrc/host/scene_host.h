@@ -164,6 +164,7 @@ struct EnvironmentMap : Emitter {
     float lower[3] = {0, 0, 0}, upper[3] = {0, 0, 0};
     int reso[2] = {0, 0};
     Distrb cell_distrb;
+    bool m_cells_dirty = true;                                                         // texels changed since cell_distrb was built
     int m_bound_mesh_id = -1;
 };
 
