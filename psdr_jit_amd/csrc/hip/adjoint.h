@@ -39,7 +39,12 @@ struct AdjointParams {
     const float *w;                 // d loss / d image, [n_pixels * 3]
     float *g_tri;                   // [n_tris * 22], ORIGINAL triangle order
     float *g_bsdf, *g_emitter;      // [n_bsdfs * 3], [n_emitters * 3]
-    int lds_accum;                  // 1: accumulate in LDS first (small scenes), 0: global atomics
+    // Adjoint rows accumulate per workgroup in LDS for the scene's "hot" triangles - emitter meshes (every path's light samples
+    // land there) and the largest ones (hit most often) - and go to global memory with plain atomics for the rest.  Millions of paths
+    // adding to the 44 floats of a two-triangle luminaire in global memory serialise: 830 ms instead of 40 on the sphere scene.
+    const int *hot_map;             // [n_tris] original triangle id -> hot index, -1 = not hot
+    const int *hot_inv;             // [n_hot] hot index -> original triangle id
+    int n_hot;
     int mis;                        // -1: PathTracer; 0/1/2: DirectIntegrator(mis)
     int field, field_object;        // >= 0: first-hit integrator
     float intensity, d_intensity;
@@ -77,13 +82,10 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
     float *acc_cam = scratch + (kAdjHitWords + kAdjExtWords + P.lk_words) * kBlock;        // 16 floats, always in LDS: every path adds to the same 12 entries
     float *acc_mat = acc_cam + kAdjMisc;                               // [n_bsdfs * kMatRow], always in LDS like the camera block
     float *acc = acc_mat + T.n_bsdfs * kMatRow;
-    const int n_acc = T.n_tris * 22 + T.n_bsdfs * 3 + T.n_emitters * 3;
-    const bool use_lds = P.lds_accum != 0;
-    if (use_lds) {
-        for (int i = threadIdx.x; i < n_acc; i += kBlock) acc[i] = 0.f;
-        __syncthreads();
-    }
-    float *acc_bsdf = acc + T.n_tris * 22, *acc_emit = acc_bsdf + T.n_bsdfs * 3;
+    const int n_acc = P.n_hot * 22 + T.n_bsdfs * 3 + T.n_emitters * 3;
+    const bool use_lds = true;                                         // colours and emitters always accumulate in LDS
+    for (int i = threadIdx.x; i < n_acc; i += kBlock) acc[i] = 0.f;
+    float *acc_bsdf = acc + P.n_hot * 22, *acc_emit = acc_bsdf + T.n_bsdfs * 3;
     if (threadIdx.x < kAdjMisc) acc_cam[threadIdx.x] = 0.f;    // [0..11] camera pose, [12] environment-map scale, [16..31] environment from_world
     for (int i = threadIdx.x; i < T.n_bsdfs * kMatRow; i += kBlock) acc_mat[i] = 0.f;
     __syncthreads();
@@ -248,7 +250,11 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                         if (st_stage == 3) { S.probe_u = lk[(3 * st_i + 1) * kBlock]; S.probe_v = lk[(3 * st_i + 2) * kBlock]; }
                         if (st_stage == 4) { ray_p = ray; primary_ray_pose_tangent(cam, sx, sy, st_comp, ray_p); }
                         const float gval = probe();
-                        if (st_stage == 0) adj_add<LDS>(acc, P.g_tri, st_orig * 22 + st_comp, gval, use_lds);
+                        if (st_stage == 0) {
+                            const int hot = P.hot_map[st_orig];
+                            if (hot >= 0 && hot < P.n_hot) adj_add<LDS>(acc, acc, hot * 22 + st_comp, gval, true);      // (the launch may use fewer hot slots than the scene has)
+                            else adj_add<LDS>(acc, P.g_tri, st_orig * 22 + st_comp, gval, false);
+                        }
                         else if (st_stage == 1 && bc >= 3) adj_add<LDS>(acc_mat, acc_mat, st_id * kMatRow + bc - 3, gval, true);
                         else if (st_stage == 1) adj_add<LDS>(acc_bsdf, P.g_bsdf, st_id * 3 + bc, gval, use_lds);
                         else if (st_stage == 2) adj_add<LDS>(acc_emit, P.g_emitter, st_id * 3 + st_comp, gval, use_lds);
@@ -307,7 +313,7 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
         for (int i = threadIdx.x; i < T.n_bsdfs * kMatRow; i += kBlock) if (acc_mat[i] != 0.f) atomicAdd(&P.g_mat[i], acc_mat[i]);
     if (use_lds) {
         __syncthreads();
-        for (int i = threadIdx.x; i < T.n_tris * 22; i += kBlock) if (acc[i] != 0.f) atomicAdd(&P.g_tri[i], acc[i]);
+        for (int i = threadIdx.x; i < P.n_hot * 22; i += kBlock) if (acc[i] != 0.f) atomicAdd(&P.g_tri[P.hot_inv[i / 22] * 22 + i % 22], acc[i]);
         for (int i = threadIdx.x; i < T.n_bsdfs * 3; i += kBlock) if (acc_bsdf[i] != 0.f) atomicAdd(&P.g_bsdf[i], acc_bsdf[i]);
         for (int i = threadIdx.x; i < T.n_emitters * 3; i += kBlock) if (acc_emit[i] != 0.f) atomicAdd(&P.g_emitter[i], acc_emit[i]);
     }

@@ -447,6 +447,8 @@ struct psdr_hip_scene {
     mutable unsigned queue_slot = 0;
     int n_leaves = 0, max_depth = 0, grid = 0;
     long long tex_total = 0;             // floats of all bitmap parameters (psdr_grads.g_tex)
+    DevBuf hot_map, hot_inv;             // adjoint accumulators kept in LDS: emitter triangles first, then by area (adjoint.h)
+    int n_hot = 0;
     std::vector<long long> tex_layout;   // [3*n_bsdfs] offsets into g_tex, -1 = constant
     const float *up(const float *src, size_t n, int &rc) {
         if (!src) return nullptr;
@@ -617,6 +619,23 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
             if (rc) return 1;
             T.pv = sc->bufs.back()->as<PvDev>();
         }
+    }
+    {   // hot triangles of the reverse-mode accumulators: emitter meshes first, then by area, at most kHotMax
+        constexpr int kHotMax = 720;                                   // 720 x 22 floats = 62 KB of LDS
+        std::vector<int> ord((size_t) n);
+        std::vector<float> key((size_t) n);
+        for (int i = 0; i < n; ++i) {
+            ord[i] = i;
+            const float *a1 = tr.e1 + 3 * (size_t) i, *a2 = tr.e2 + 3 * (size_t) i;
+            const float cx = a1[1] * a2[2] - a1[2] * a2[1], cy = a1[2] * a2[0] - a1[0] * a2[2], cz = a1[0] * a2[1] - a1[1] * a2[0];
+            const bool emit = s->meshes[tr.mesh_id[i]].emitter_id >= 0;
+            key[i] = std::sqrt(cx * cx + cy * cy + cz * cz) * (emit ? 1e30f : 1.f);
+        }
+        std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return key[x] > key[y]; });
+        sc->n_hot = std::min(n, kHotMax);
+        std::vector<int> hmap((size_t) std::max(1, n), -1), hinv((size_t) std::max(1, sc->n_hot), 0);
+        for (int h = 0; h < sc->n_hot; ++h) { hmap[ord[h]] = h; hinv[h] = ord[h]; }
+        if (sc->hot_map.upload(hmap.data(), hmap.size() * sizeof(int)) || sc->hot_inv.upload(hinv.data(), hinv.size() * sizeof(int))) return 1;
     }
     std::vector<FilterPrim> filt;
     build_filter_prims(tr.p0, tr.e1, tr.e2, bvh.order.data(), n, filt);
@@ -969,14 +988,24 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         HIPCHK(hipMemsetAsync(q, 0, sizeof(unsigned long long), st));
         return 0;
     };
-    const size_t n_acc = (size_t) T.n_tris * 22 + (size_t) T.n_bsdfs * 3 + (size_t) T.n_emitters * 3;
-    const bool lds_acc = n_acc * sizeof(float) <= 32 * 1024;
+    const bool lds_acc = true;
     const bool with_lookups = T.tex != nullptr || T.pv != nullptr || T.env_emitter >= 0;
     // PSDR_ADJ_GLOBAL=1: run the interior adjoint of an LDS-class scene from global memory (no blob copy in LDS: more workgroups per CU)
     static const bool adj_global = std::getenv("PSDR_ADJ_GLOBAL") != nullptr;
     const int adj_cls = (use_lds && !adj_global) ? 1 : ((sc->lean || use_lds) && a->field_mode == 0 ? 2 : 0);
+    // LDS: [blob (class 1)] [stacks] [per-lane records] [camera / env / material accumulators] [hot triangle rows, colours, emitters];
+    // the number of hot triangle rows is what is left of the 160 KB
+    const size_t smem_base = adj_cls == 1 ? sc->smem_bytes : sc->smem_bytes - (sc->lds ? (size_t) T.blob_words * 16 : 0);
+    const size_t fixed_bytes = sizeof(float) * ((size_t) adj_lane_words(with_lookups) * kBlock + kAdjMisc + (size_t) T.n_bsdfs * kMatRow
+                                                + (size_t) T.n_bsdfs * 3 + (size_t) T.n_emitters * 3);
+    if (smem_base + fixed_bytes > 160 * 1024) return fail("scene too large for the adjoint kernel's LDS records");
+    // two workgroups per CU (80 KB each) when the fixed part allows it - one wave per SIMD cannot hide the global-memory latency of
+    // the replays -, with at least 64 hot rows (emitters + the largest triangles)
+    const size_t budget = (smem_base + fixed_bytes + 64 * 22 * sizeof(float) <= 80 * 1024) ? 80 * 1024 : 160 * 1024;
+    const int n_hot_used = (int) std::min<size_t>((size_t) sc->n_hot, (budget - smem_base - fixed_bytes) / (22 * sizeof(float)));
+    const size_t n_acc = (size_t) n_hot_used * 22 + (size_t) T.n_bsdfs * 3 + (size_t) T.n_emitters * 3;
     const size_t adj_bytes = sizeof(float) * ((size_t) adj_lane_words(with_lookups) * kBlock + kAdjMisc + (size_t) T.n_bsdfs * kMatRow + (lds_acc ? n_acc : 0));
-    const size_t smem = (adj_cls == 1 ? sc->smem_bytes : sc->smem_bytes - (sc->lds ? (size_t) T.blob_words * 16 : 0)) + adj_bytes;
+    const size_t smem = smem_base + adj_bytes;
     if (smem > 160 * 1024) return fail("scene too large for the adjoint kernel's LDS records");
     static bool attr_set = false;
     if (!attr_set) {
@@ -991,7 +1020,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         AdjointParams P{};
         P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[0].seed; P.skip = a->samplers[0].skip;
         P.pix_ids = a->pix_ids; P.begin = 0; P.end = npx * T.spp; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
-        P.w = d_rgb; P.g_tri = g->g_triangles; P.g_bsdf = g->g_bsdf; P.g_emitter = g->g_emitter; P.lds_accum = lds_acc ? 1 : 0;
+        P.w = d_rgb; P.g_tri = g->g_triangles; P.g_bsdf = g->g_bsdf; P.g_emitter = g->g_emitter; P.hot_map = sc->hot_map.as<int>(); P.hot_inv = sc->hot_inv.as<int>(); P.n_hot = n_hot_used;
         P.mesh_filter = g->mesh_filter; P.skip_bsdf = g->skip_bsdf; P.skip_emitter = g->skip_emitter;
         P.g_tex = sc->tex_total > 0 ? g->g_tex : nullptr;
         P.g_cam = g->g_camera;
