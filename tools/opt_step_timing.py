@@ -1,6 +1,6 @@
 """One optimisation step as a psdr-jit user writes it (README.md:87-106): move a parameter, configure, renderD, loss, backward.
 Wall-clock per stage on the README Cornell box at the BASELINE config-3 settings (512x512, spp = sppe = sppse = 32, depth 3).
-    python tools/opt_step_timing.py [scene]        scene: cbox (default) | sphere"""
+    python tools/opt_step_timing.py [scene]        scene: cbox (default) | sphere | envbunny"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "examples")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -14,6 +14,13 @@ which = sys.argv[1] if len(sys.argv) > 1 else "cbox"
 sc = tut._scene(512, 512, 32, 32, 32)
 if which == "sphere":
     tut._camera(sc); tut._sphere_box(sc)
+elif which == "envbunny":           # the Forward_AD_envmap notebook scene at 512x512 / 32 spp, depth 1
+    sensor = psdr.PerspectiveCamera(80, 0.000001, 10000000.)
+    sensor.to_world = Matrix4fD([[-1., 0., 0., 0.], [0., 1., 0., 0.], [0., 0., -1., 0.], [0., 0., 0., 1.]])
+    sc.add_Sensor(sensor)
+    sc.add_BSDF(psdr.MicrofacetBSDF([0.2, 0.9, 0.9], [0.01, 0.01, 0.01], 0.3), "bunny")
+    sc.add_Mesh(os.path.join(tut.DATA, "mesh", "bunny_low.obj"), Matrix4fC([[1., 0., 0., 0.], [0., 1., 0., 0.], [0., 0., 1., -100.], [0., 0., 0., 1.]]), "bunny", None)
+    sc.add_EnvironmentMap(os.path.join(tut.DATA, "envmap", "ballroom_1k.exr"), tut.I4, 1.0)
 else:
     tut._camera(sc, 208., 273., -800.)
     sc.add_BSDF(psdr.DiffuseBSDF([0.0, 0.0, 0.0]), "light"); sc.add_BSDF(psdr.DiffuseBSDF(), "cat"); sc.add_BSDF(psdr.DiffuseBSDF([0.95, 0.95, 0.95]), "white")
@@ -23,7 +30,7 @@ else:
     for f, b in (("smallbox", "cat"), ("largebox", "cat"), ("floor", "white"), ("ceiling", "white"), ("back", "white"), ("greenwall", "green"), ("redwall", "red")):
         sc.add_Mesh(os.path.join(cb, "cbox_%s.obj" % f), Matrix4fC(tut.I4), b, None)
 sc.configure(); sc.configure([0])
-integ = psdr.PathTracer(3)
+integ = psdr.PathTracer(1 if which == "envbunny" else 3)
 P = psdr.FloatD(0.).requires_grad_()
 target = None
 T = {k: [] for k in ("set_transform + configure", "renderD", "loss", "backward", "total")}
