@@ -240,7 +240,9 @@ int psdr_hip_render_d_fwd(const psdr_hip_scene *scene, const psdr_render_args *a
 /* Reverse mode of renderD (the reference's drjit.backward through Integrator::renderD, README.md:102-106):
  * given d_rgb = d loss / d image ([n_pixels*3], device), accumulate the adjoints of the snapshot quantities
  * the image depends on.  All buffers are DEVICE pointers owned by the caller; rows follow the snapshot order.
- * The host chains them to vertices / transforms / colours.  (d loss / d camera pose is forward-mode only.) */
+ * The host chains them to vertices / transforms / colours / camera pose.  With args->pix_ids (batch rendering) d_rgb is
+ * [n_pix*3] and only the interior term exists, as in the forward path.  g_bsdf / g_mat / psdr_hip_scene_tex_layout rows cover
+ * every entry of psdr_scene_snapshot.bsdfs, including the records nested in normal maps. */
 typedef struct psdr_grads {
     float *g_triangles;    /* [n_triangles*22] rows [p0 e1 e2 n0 n1 n2 face_normal face_area] */
     float *g_bsdf;         /* [n_bsdfs*3] reflectance */
@@ -254,8 +256,7 @@ typedef struct psdr_grads {
      * as psdr_hip_scene_tex_layout reports, or NULL = not wanted */
     float *g_tex;
     /* adjoint of the sensor's to_world through the camera rays of the interior and secondary-edge terms (DEVICE [16], row major,
-     * rows 0-2 filled),
-     * or NULL = not wanted.  The camera's share of the primary-edge term arrives through g_prim_edges (sample-space edge
+     * rows 0-2 filled), or NULL = not wanted.  The camera's share of the primary-edge term arrives through g_prim_edges (sample-space edge
      * endpoints = world_to_sample . vertex: the host chains both). */
     float *g_camera;
     /* adjoints of the environment map: its texels (DEVICE [height*width*3]) and its scale (DEVICE [1]); NULL = not wanted */
@@ -269,7 +270,8 @@ typedef struct psdr_grads {
     float *g_env_from_world;
 } psdr_grads;
 /* offsets[3*n_bsdfs] (HOST): float offset of the texel block of BSDF b's bitmap k (0 reflectance / diffuse reflectance rgb,
- * 1 specular reflectance rgb, 2 roughness) inside psdr_grads.g_tex, same row-major layout as the bitmap; -1 = constant.
+ * 1 specular reflectance rgb, 2 roughness; RoughConductor: eta, k, alpha; NormalMap: the map; MicrofacetPerVertex: the per-vertex
+ * diffuse / specular / roughness arrays) inside psdr_grads.g_tex, same row-major layout as the bitmap; -1 = constant.
  * *total = floats to allocate (0 = the scene has no bitmap parameter).  Either pointer may be NULL. */
 int psdr_hip_scene_tex_layout(const psdr_hip_scene *scene, int64_t *offsets, int64_t *total);
 int psdr_hip_render_d_bwd(const psdr_hip_scene *scene, const psdr_render_args *args, const float *d_rgb,
