@@ -333,9 +333,11 @@ PYBIND11_MODULE(_psdr_core, m) {
         .def("_set", [](EnvironmentMap &e, const std::string &name, const farr &v, const farr &t) {
             if (name == "radiance") {
                 if (v.ndim() != 3 || v.shape(2) != 3) throw Exception("EnvironmentMap: radiance must be a [height, width, 3] array");
-                e.height = (int) v.shape(0); e.width = (int) v.shape(1); e.data.assign(v.data(), v.data() + v.size());
+                const bool same = e.height == (int) v.shape(0) && e.width == (int) v.shape(1) && e.data.size() == (size_t) v.size() &&
+                                  std::memcmp(e.data.data(), v.data(), sizeof(float) * e.data.size()) == 0;
+                e.height = (int) v.shape(0); e.width = (int) v.shape(1);
+                if (!same) { e.data.assign(v.data(), v.data() + v.size()); e.m_cells_dirty = true; }      // (a tangent-only update keeps the cell distribution)
                 if (t.size() == v.size()) e.d_data.assign(t.data(), t.data() + t.size()); else e.d_data.clear();
-                e.m_cells_dirty = true;
             } else if (name == "scale") { e.scale = v.data()[0]; e.d_scale = t.size() ? t.data()[0] : 0.f; }
             else if (name == "to_world_left") { e.to_world_left = to_m16(v); e.d_to_world_left = t.size() == 16 ? to_m16(t) : zeros16(); }
             else e.to_world_raw = to_m16(v);
