@@ -1,0 +1,44 @@
+"""Lane-sharded renderD + loss.backward() on 2 ranks (one GPU, gloo) against the single-process result.
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/check_2rank_backward.py"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "examples")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import torch.distributed as dist
+import psdr_jit_amd as psdr
+from psdr_jit_amd import Matrix4fC, Matrix4fD
+import tutorials as tut
+
+
+def grad_of(distributed):
+    sc = tut._scene(64, 64, 8, 8, 8)
+    tut._camera(sc, 208., 273., -800.)
+    refl = torch.tensor([0.5, 0.4, 0.3], requires_grad=True)
+    sc.add_BSDF(psdr.DiffuseBSDF([0.0, 0.0, 0.0]), "light"); sc.add_BSDF(psdr.DiffuseBSDF(refl), "cat"); sc.add_BSDF(psdr.DiffuseBSDF([0.95, 0.95, 0.95]), "white")
+    cb = os.path.join(tut.DATA, "cbox")
+    sc.add_Mesh(os.path.join(cb, "cbox_luminaire.obj"), Matrix4fC([[1., 0., 0., 0.], [0., 1., 0., -0.5], [0., 0., 1., 0.], [0., 0., 0., 1.]]), "light", psdr.AreaLight([20.0, 20.0, 8.0]))
+    for f, b in (("smallbox", "cat"), ("largebox", "cat"), ("floor", "white"), ("back", "white")):
+        sc.add_Mesh(os.path.join(cb, "cbox_%s.obj" % f), Matrix4fC(tut.I4), b, None)
+    P = psdr.FloatD(0.).requires_grad_()
+    sc.param_map["Mesh[0]"].set_transform(Matrix4fD([[1., 0., 0., P * 100], [0., 1., 0., 0.], [0., 0., 1., 0.], [0., 0., 0., 1.]]))
+    sc.configure(); sc.configure([0])
+    img = psdr.PathTracer(2).renderD(sc, 0, seed=3)
+    w = torch.linspace(0.5, 1.5, img.numel(), device=img.device).reshape(img.shape)
+    (img * w).sum().backward()
+    return img.detach().cpu().numpy(), float(P.grad), refl.grad.numpy().copy()
+
+
+single = grad_of(False) if "RANK" not in os.environ else None
+if "RANK" in os.environ:
+    dist.init_process_group("gloo")
+    torch.cuda.set_device(0)
+    img, gp, gr = grad_of(True)                 # sharded over the 2 ranks, all-reduced
+    dist.destroy_process_group()
+    # reference: the same in one process (after the group is gone psdr shards over 1 rank)
+    img1, gp1, gr1 = grad_of(False)
+    if int(os.environ["RANK"]) == 0:
+        print("image rel L2 %.2e   dP %.6f vs %.6f   d refl %s vs %s" % (np.linalg.norm(img - img1) / np.linalg.norm(img1), gp, gp1, gr, gr1))
+        assert np.linalg.norm(img - img1) / np.linalg.norm(img1) < 1e-5 and abs(gp - gp1) < 1e-4 * max(1.0, abs(gp1)) and np.allclose(gr, gr1, rtol=1e-4)
+        print("2-rank backward OK")
+else:
+    print(single[1], single[2])
