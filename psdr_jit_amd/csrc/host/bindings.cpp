@@ -403,6 +403,14 @@ PYBIND11_MODULE(_psdr_core, m) {
             std::vector<float> ew;
             for (const psdr_emitter_rec &e : S.emitters) ew.push_back(e.sampling_weight);
             out["emitter_weights"] = from_vec(ew, 1);
+            {   // BSDF rows as the kernels see them: (type, nested row, bitmap widths of the three slots, per-vertex count)
+                py::list rows;
+                for (const psdr_bsdf_rec &b : S.bsdfs)
+                    rows.append(py::make_tuple(b.type, b.type == 5 ? b.nested_bsdf : -1, b.tex_data ? b.tex_width : 0, b.spec_tex_data ? b.spec_tex_width : 0,
+                                               b.rough_tex_data ? b.rough_tex_width : 0, b.type == 4 ? b.pv_count : 0));
+                out["bsdf_rows"] = rows;
+                out["face_indices"] = py::array_t<int32_t>(S.face_indices.size(), S.face_indices.data());
+            }
             if (S.has_envmap && s.m_emitter_env) {
                 const EnvironmentMap &E = *s.m_emitter_env;
                 out["env_cell_pmf"] = from_vec(E.cell_distrb.pmf, 1); out["env_cell_cmf"] = from_vec(E.cell_distrb.cmf, 1);

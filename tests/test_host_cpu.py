@@ -458,3 +458,31 @@ def test_python_sampler_and_distribution_match_the_fixtures(psdr, orc):
     assert np.allclose(got[0], tex[0, 0], atol=1e-5) and np.allclose(got[1], tex[0, W - 1], atol=1e-4)
     one = psdr.Bitmap3fD([0.2, 0.4, 0.6])
     assert np.allclose(one.eval(uv), [[0.2, 0.4, 0.6]] * 3)
+
+
+def test_host_snapshot_of_the_ggx_family(psdr):
+    """Scene::configure on the host for every BSDF type of the GGX family: record types, bitmap slots, per-vertex counts, the row of the
+    BSDF nested in a normal map (appended behind the scene's own), mesh-local face indices"""
+    cases = [(scenes.dielectric_cbox_scene(16, 16, 1, 1, 1), {5: (3, -1, 0, 0, 0, 0), 6: (3, -1, 0, 0, 0, 0)}),
+             (scenes.textured_microfacet_scene(16, 16, 1, 1, 1), {0: (1, -1, 8, 5, 9, 0)}),
+             (scenes.textured_ggx_scene(16, 16, 1, 1, 1, kind="roughconductor"), {0: (2, -1, 4, 6, 7, 0)}),
+             (scenes.textured_ggx_scene(16, 16, 1, 1, 1, kind="roughdielectric"), {0: (3, -1, 0, 0, 7, 0)})]
+    for spec, want in cases:
+        sc = product.build_scene(spec, host_only=True)
+        rows = sc._snapshot()["bsdf_rows"]
+        assert len(rows) == len(spec.bsdfs)
+        for i, w in want.items():
+            assert tuple(rows[i]) == w, (i, rows[i], w)
+    spec = scenes.pervertex_scene(16, 16, 1, 1, 1)
+    snap = product.build_scene(spec, host_only=True)._snapshot()
+    nv = len(spec.meshes[1].vertices)
+    assert tuple(snap["bsdf_rows"][5]) == (4, -1, 0, 0, 0, nv)
+    fi = np.asarray(snap["face_indices"]).reshape(-1, 3)
+    off = sum(len(m.faces) for m in spec.meshes[:1])
+    assert np.array_equal(fi[off:off + len(spec.meshes[1].faces)], spec.meshes[1].faces) and fi.max() < max(len(m.vertices) for m in spec.meshes)
+    spec = scenes.normalmap_scene(16, 16, 1, 1, 1, nested="roughconductor")
+    sc = product.build_scene(spec, host_only=True)
+    rows = sc._snapshot()["bsdf_rows"]
+    n_own = len([k for k in sc.param_map if k.startswith("BSDF[") and not k.startswith("BSDF[id=")])
+    assert len(rows) == n_own + 1 and tuple(rows[0])[:3] == (5, n_own, 16) and rows[n_own][0] == 2
+    assert type(sc.param_map["BSDF[id=tex]"].nested_bsdf).__name__ == "RoughConductorBSDF"
