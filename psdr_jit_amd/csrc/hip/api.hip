@@ -765,7 +765,8 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     const size_t stack_bytes = (size_t) T.stack_depth * kBlock * sizeof(int);
     const size_t blob_bytes = (size_t) T.blob_words * 16;
     // keeps >= 4 workgroups per CU (160 KiB LDS); the environment-map and texture code lives in the LDS=false kernels only (shade.h)
-    sc->lds = blob_bytes + stack_bytes <= 40 * 1024 && T.env_emitter < 0 && T.tex == nullptr && T.mat == nullptr && T.pv == nullptr;
+    static const bool no_lds = std::getenv("PSDR_NO_LDS") != nullptr;      // measurement knob: run small scenes through the global-memory classes
+    sc->lds = !no_lds && blob_bytes + stack_bytes <= 40 * 1024 && T.env_emitter < 0 && T.tex == nullptr && T.mat == nullptr && T.pv == nullptr;
     sc->lean = !sc->lds && T.tex == nullptr && T.mat == nullptr && T.pv == nullptr;
     sc->smem_bytes = (sc->lds ? blob_bytes : 0) + stack_bytes;
     if (sc->smem_bytes > 64 * 1024) return fail("BVH too deep for the LDS traversal stack");
