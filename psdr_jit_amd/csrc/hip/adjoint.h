@@ -17,13 +17,14 @@
 
 namespace psdr {
 
-constexpr int kAdjMaxDepth = 4;
-constexpr int kAdjHitWords = 4 * (1 + 2 * kAdjMaxDepth);      // recorded hits per lane
-constexpr int kAdjExtWords = 8;                                // light-sample slots per lane
-constexpr int kAdjLkWords = 3 * kAdjMaxLookups;                // bitmap lookups per lane (id, u, v)
+// per-lane LDS records of one path, sized from the path depth D by the launch: 1 + 2 D hits of 4 words, 2 D light-sample slots,
+// 3 D + 2 lookups of 3 words (one bitmap lookup per vertex, two environment lookups per bounce)
+inline __host__ __device__ int adj_hit_words(int depth) { return 4 * (1 + 2 * depth); }
+inline __host__ __device__ int adj_ext_words(int depth) { return 2 * depth > 2 ? 2 * depth : 2; }
+inline __host__ __device__ int adj_lk_entries(int depth) { return 3 * depth + 2; }
 // LDS words per lane of the interior adjoint kernel: scenes without bitmap / per-vertex parameters and without an environment map
 // make no lookups, carry no lookup record and keep more workgroups per CU (AdjointParams::lk_words)
-inline __host__ __device__ int adj_lane_words(bool with_lookups) { return kAdjHitWords + kAdjExtWords + (with_lookups ? kAdjLkWords : 0); }
+inline __host__ __device__ int adj_lane_words(int depth, bool with_lookups) { return adj_hit_words(depth) + adj_ext_words(depth) + (with_lookups ? 3 * adj_lk_entries(depth) : 0); }
 // the secondary-edge adjoint records three hits per lane, followed by 16 floats of camera-pose accumulators
 constexpr int kSecAdjLaneWords = 12;
 constexpr int kSecAdjScratch = kSecAdjLaneWords * kBlock + 16;
@@ -54,7 +55,7 @@ struct AdjointParams {
     float *g_cam;                   // [16] adjoint of the sensor's to_world (row major, rows 0-2 filled), or NULL
     float *g_env, *g_env_scale;     // texel adjoints [H*W*3] and scale adjoint [1] of the environment map, or NULL
     float *g_env_xf;                // [16] adjoint of the environment map's from_world (rows 0-2, columns 0-2 filled), or NULL
-    int lk_words;                   // kAdjLkWords when the scene can make lookups (bitmaps, per-vertex values, environment map), else 0
+    int hit_words, ext_words, lk_words;   // sizes of the three per-lane records (lk_words = 0 when the scene cannot make lookups)
     float *g_mat;                   // [n_bsdfs*16] adjoints of the constant parameters of the GGX BSDFs (psdr_grads.g_mat), or NULL
 };
 
@@ -69,7 +70,7 @@ PSDR_DEV void adj_add(float *lds_g, float *glob, int idx, float v, bool use_lds)
     if (use_lds) atomicAdd(&lds_g[idx], v); else atomicAdd(&glob[idx], v);
 }
 
-// scratch: per-block LDS region behind the blob/stack: [hits: kAdjHitWords x 256][ext: kAdjExtWords x 256][lookups: kAdjLkWords x 256][accumulators]
+// scratch: per-block LDS region behind the blob/stack: [hits: hit_words x 256][ext: ext_words x 256][lookups: lk_words x 256][accumulators]
 template <int LDS>
 PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, const AdjointParams &P, float *scratch) {
     const SceneTables &T = *S.T;
@@ -77,9 +78,9 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
     const unsigned long long lt_mask = (1ull << lane_id) - 1ull;
     const float inv_spp = T.spp > 1 ? 1.f / (float) T.spp : 1.f;
     float *rec = scratch + threadIdx.x;
-    int *ext = reinterpret_cast<int *>(scratch + kAdjHitWords * kBlock) + threadIdx.x;
-    float *lk = scratch + (kAdjHitWords + kAdjExtWords) * kBlock + threadIdx.x;
-    float *acc_cam = scratch + (kAdjHitWords + kAdjExtWords + P.lk_words) * kBlock;        // 16 floats, always in LDS: every path adds to the same 12 entries
+    int *ext = reinterpret_cast<int *>(scratch + P.hit_words * kBlock) + threadIdx.x;
+    float *lk = scratch + (P.hit_words + P.ext_words) * kBlock + threadIdx.x;
+    float *acc_cam = scratch + (P.hit_words + P.ext_words + P.lk_words) * kBlock;        // 16 floats, always in LDS: every path adds to the same 12 entries
     float *acc_mat = acc_cam + kAdjMisc;                               // [n_bsdfs * kMatRow], always in LDS like the camera block
     float *acc = acc_mat + T.n_bsdfs * kMatRow;
     const int n_acc = P.n_hot * 22 + T.n_bsdfs * 3 + T.n_emitters * 3;
@@ -89,7 +90,7 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
     if (threadIdx.x < kAdjMisc) acc_cam[threadIdx.x] = 0.f;    // [0..11] camera pose, [12] environment-map scale, [16..31] environment from_world
     for (int i = threadIdx.x; i < T.n_bsdfs * kMatRow; i += kBlock) acc_mat[i] = 0.f;
     __syncthreads();
-    S.rec = rec; S.ext = ext; S.lk = lk;
+    S.rec = rec; S.ext = ext; S.lk = lk; S.ext_max = P.ext_words; S.lk_max = P.lk_words / 3;
 
     long long q_next = 0, q_end = 0;
     bool exhausted = false;

@@ -57,7 +57,7 @@ PSDR_DEV SceneView<LDS> make_view(const float4 *blob, const SceneTables &T, floa
     S.stack = reinterpret_cast<int *>(smem + (in_lds(LDS) ? T.blob_words : 0)) + threadIdx.x;
     S.c_nodes = S.c_tris = S.c_rays = S.c_hits = 0u;
     S.mis = -1; S.field = -1; S.field_object = -1; S.intensity = 1.f; S.d_intensity = 0.f; S.mode = 0; S.rec = nullptr; S.rec_i = 0; S.rec_n = 0; S.ext = nullptr; S.ext_n = 0; S.probe_kind = 0; S.probe_id = 0; S.probe_comp = 0;
-    S.lk = nullptr; S.lk_n = 0; S.probe_u = 0.f; S.probe_v = 0.f;
+    S.lk = nullptr; S.lk_n = 0; S.lk_max = 0; S.ext_max = 0; S.probe_u = 0.f; S.probe_v = 0.f;
     return S;
 }
 
@@ -955,7 +955,6 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     if (check_args(sc, a)) return 1;
     if (!d_rgb || !g || !g->g_triangles || !g->g_bsdf || !g->g_emitter) return fail("null gradient buffer");
     // batch rendering (integrator.cpp:139-176): d_rgb is [n_pix*3]; only the interior term exists for a pixel list (as in the forward path)
-    if (a->max_depth > kAdjMaxDepth) return fail("reverse mode supports max_depth <= 4");
     const SceneTables &T = sc->T;
     hipStream_t st = (hipStream_t) stream;
     const long long npx_full = (long long) T.width * T.height;
@@ -997,15 +996,16 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     // LDS: [blob (class 1)] [stacks] [per-lane records] [camera / env / material accumulators] [hot triangle rows, colours, emitters];
     // the number of hot triangle rows is what is left of the 160 KB
     const size_t smem_base = adj_cls == 1 ? sc->smem_bytes : sc->smem_bytes - (sc->lds ? (size_t) T.blob_words * 16 : 0);
-    const size_t fixed_bytes = sizeof(float) * ((size_t) adj_lane_words(with_lookups) * kBlock + kAdjMisc + (size_t) T.n_bsdfs * kMatRow
+    const int adj_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth);
+    const size_t fixed_bytes = sizeof(float) * ((size_t) adj_lane_words(adj_depth, with_lookups) * kBlock + kAdjMisc + (size_t) T.n_bsdfs * kMatRow
                                                 + (size_t) T.n_bsdfs * 3 + (size_t) T.n_emitters * 3);
-    if (smem_base + fixed_bytes > 160 * 1024) return fail("scene too large for the adjoint kernel's LDS records");
+    if (smem_base + fixed_bytes > 160 * 1024) return fail("path depth / scene too large for the adjoint kernel's LDS records");
     // two workgroups per CU (80 KB each) when the fixed part allows it - one wave per SIMD cannot hide the global-memory latency of
     // the replays -, with at least 64 hot rows (emitters + the largest triangles)
     const size_t budget = (smem_base + fixed_bytes + 64 * 22 * sizeof(float) <= 80 * 1024) ? 80 * 1024 : 160 * 1024;
     const int n_hot_used = (int) std::min<size_t>((size_t) sc->n_hot, (budget - smem_base - fixed_bytes) / (22 * sizeof(float)));
     const size_t n_acc = (size_t) n_hot_used * 22 + (size_t) T.n_bsdfs * 3 + (size_t) T.n_emitters * 3;
-    const size_t adj_bytes = sizeof(float) * ((size_t) adj_lane_words(with_lookups) * kBlock + kAdjMisc + (size_t) T.n_bsdfs * kMatRow + (lds_acc ? n_acc : 0));
+    const size_t adj_bytes = sizeof(float) * ((size_t) adj_lane_words(adj_depth, with_lookups) * kBlock + kAdjMisc + (size_t) T.n_bsdfs * kMatRow + (lds_acc ? n_acc : 0));
     const size_t smem = smem_base + adj_bytes;
     if (smem > 160 * 1024) return fail("scene too large for the adjoint kernel's LDS records");
     static bool attr_set = false;
@@ -1031,7 +1031,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         if (P.n_local > 0) {
             if (next_queue(P.counter)) return 1;
             const int grid = grid_for(sc, P.n_local);
-            P.lk_words = with_lookups ? kAdjLkWords : 0;
+            P.hit_words = adj_hit_words(adj_depth); P.ext_words = adj_ext_words(adj_depth); P.lk_words = with_lookups ? 3 * adj_lk_entries(adj_depth) : 0;
             if (adj_cls == 1) hipLaunchKernelGGL((k_interior_adjoint<1>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, cam, P);
             else if (adj_cls == 2) hipLaunchKernelGGL((k_interior_adjoint<2>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, cam, P);
             else hipLaunchKernelGGL((k_interior_adjoint<0>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, cam, P);

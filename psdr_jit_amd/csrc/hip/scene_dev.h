@@ -96,7 +96,7 @@ constexpr bool has_mat(int cls) { return cls == 0; }
 constexpr int kEnvLookup = -1;         // id of an environment-map lookup in the lookup record (BSDF ids are >= 0)
 // a per-vertex BSDF interpolation at triangle slot s is recorded as id = kPvLookup - s, with the barycentrics as (u, v)
 constexpr int kPvLookup = -2;
-constexpr int kAdjMaxLookups = 8;      // bitmap lookups recorded per path (one per textured vertex; max_depth <= 4)
+// (the lookup record of a path holds up to 3 * max_depth + 2 entries: one bitmap lookup per vertex, two environment lookups per bounce)
 
 template <int LDS> struct SceneView {
     const float4 *B;           // blob base (LDS or global)
@@ -124,12 +124,13 @@ template <int LDS> struct SceneView {
     // replay reproduces); the kernel scatters the result over the four texels of the lookup's footprint
     float *lk;                 // this lane's LDS lookup record, stride kBlock: 3 words per entry (id, u, v)
     mutable int lk_n;
+    int lk_max, ext_max;       // capacities of the lookup / light-sample records (sized from max_depth by the launch)
     float probe_u, probe_v;
     PSDR_DEV void note_lookup(int id, float u, float v) const {
         if (mode != 1) return;
         for (int i = 0; i < lk_n; ++i)
             if (__float_as_int(lk[3 * i * kBlock]) == id && lk[(3 * i + 1) * kBlock] == u && lk[(3 * i + 2) * kBlock] == v) return;
-        if (lk_n >= kAdjMaxLookups) return;
+        if (lk_n >= lk_max) return;
         lk[3 * lk_n * kBlock] = __int_as_float(id); lk[(3 * lk_n + 1) * kBlock] = u; lk[(3 * lk_n + 2) * kBlock] = v;
         ++lk_n;
     }
@@ -159,7 +160,7 @@ template <int LDS> struct SceneView {
         if (mode == 0) return fwd;
         return (probe_kind == 6 && probe_id == id && probe_comp == k) ? 1.f : 0.f;
     }
-    PSDR_DEV void note_slot(int slot) { if (mode == 1 && slot >= 0 && ext_n < 8) { ext[ext_n * kBlock] = slot; ++ext_n; } }
+    PSDR_DEV void note_slot(int slot) { if (mode == 1 && slot >= 0 && ext_n < ext_max) { ext[ext_n * kBlock] = slot; ++ext_n; } }
 
     PSDR_DEV float4 ld(int word) const { return B[word]; }
     PSDR_DEV float ldf(int word_off, int idx) const { return reinterpret_cast<const float *>(B + word_off)[idx]; }

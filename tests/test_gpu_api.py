@@ -699,3 +699,43 @@ def test_collocated_intensity_is_differentiable(psdr, orc):
     (img * w).sum().backward()
     want = float((img.detach() * w).sum()) / 2e5
     assert abs(float(inten.grad) - want) < 1e-4 * abs(want)
+
+
+def test_reverse_mode_deep_paths_and_many_lookups(psdr, orc):
+    """loss.backward() at max_depth 6 (the per-lane records are sized from the depth) in a scene whose paths make many lookups
+    (textured floor under an environment map): gradients of the geometry, the texels and the radiance equal forward mode"""
+    import torch
+    rng = np.random.default_rng(23)
+    spec = scenes.textured_scene(32, 32, 8, 0, 0, texture=scenes.checker_texture(8, 8), env=True)
+    env0 = scenes.synthetic_envmap(32, 16)
+    rad = torch.tensor(env0, requires_grad=True)
+    tex = torch.tensor(spec.bsdfs[0].texture, requires_grad=True)
+    P = psdr.FloatD(0.).requires_grad_()
+    sc = psdr.Scene()
+    sc.opts.spp, sc.opts.sppe, sc.opts.sppse = 8, 0, 0
+    sc.opts.width = sc.opts.height = 32
+    sc.opts.log_level = 0
+    cam = psdr.PerspectiveCamera(60, 0.000001, 10000000.)
+    cam.to_world = psdr.Matrix4fD(np.asarray(spec.cameras[0].to_world_raw).tolist())
+    sc.add_Sensor(cam)
+    sc.add_BSDF(psdr.DiffuseBSDF(tex), "tex")
+    sc.add_BSDF(psdr.DiffuseBSDF([0.8, 0.7, 0.6]), "cat")
+    floor = psdr.Mesh()
+    m = spec.meshes[0]
+    floor.load_raw(m.vertices, m.faces, m.uvs, m.face_uvs)
+    sc.add_Mesh(floor, "tex", None)
+    sc.add_Mesh(os.path.join(scenes.DATA, "cbox_smallbox.obj"), psdr.Matrix4fC(np.eye(4, dtype=np.float32).tolist()), "cat", None)
+    sc.add_EnvironmentMap(psdr.EnvironmentMap(rad))
+    sc.param_map["Mesh[1]"].set_transform(psdr.Matrix4fD([[1., 0., 0., P * 100.], [0., 1., 0., 0.], [0., 0., 1., 0.], [0., 0., 0., 1.]]))
+    sc.configure()
+    sc.configure([0])
+    img = psdr.PathTracer(6).renderD(sc, 0, seed=5)
+    w = torch.linspace(0.5, 1.5, img.numel(), device=img.device).reshape(img.shape)
+    v_rad = torch.tensor(rng.standard_normal(env0.shape).astype(np.float32))
+    v_tex = torch.tensor(rng.standard_normal(tuple(tex.shape)).astype(np.float32))
+    want = {"P": float((psdr.forward_grad(img, P) * w).sum()), "rad": float((psdr.forward_grad(img, rad, direction=v_rad) * w).sum()),
+            "tex": float((psdr.forward_grad(img, tex, direction=v_tex) * w).sum())}
+    (img * w).sum().backward()
+    got = {"P": float(P.grad), "rad": float((rad.grad * v_rad).sum()), "tex": float((tex.grad * v_tex).sum())}
+    for k in want:
+        assert abs(want[k]) > 1e-4 and abs(got[k] - want[k]) < 3e-3 * max(1.0, abs(want[k])), (k, got[k], want[k])
