@@ -18,10 +18,10 @@
 namespace psdr {
 
 // per-lane LDS records of one path, sized from the path depth D by the launch: 1 + 2 D hits of 4 words, 2 D light-sample slots,
-// 3 D + 2 lookups of 3 words (one bitmap lookup per vertex, two environment lookups per bounce)
+// 4 D + 4 lookups of 3 words (per vertex: the BSDF's bitmaps and, under a normal map, the nested BSDF's; per bounce: two environment lookups)
 inline __host__ __device__ int adj_hit_words(int depth) { return 4 * (1 + 2 * depth); }
 inline __host__ __device__ int adj_ext_words(int depth) { return 2 * depth > 2 ? 2 * depth : 2; }
-inline __host__ __device__ int adj_lk_entries(int depth) { return 3 * depth + 2; }
+inline __host__ __device__ int adj_lk_entries(int depth) { return 4 * depth + 4; }
 // LDS words per lane of the interior adjoint kernel: scenes without bitmap / per-vertex parameters and without an environment map
 // make no lookups, carry no lookup record and keep more workgroups per CU (AdjointParams::lk_words)
 inline __host__ __device__ int adj_lane_words(int depth, bool with_lookups) { return adj_hit_words(depth) + adj_ext_words(depth) + (with_lookups ? 3 * adj_lk_entries(depth) : 0); }

@@ -96,7 +96,7 @@ constexpr bool has_mat(int cls) { return cls == 0; }
 constexpr int kEnvLookup = -1;         // id of an environment-map lookup in the lookup record (BSDF ids are >= 0)
 // a per-vertex BSDF interpolation at triangle slot s is recorded as id = kPvLookup - s, with the barycentrics as (u, v)
 constexpr int kPvLookup = -2;
-// (the lookup record of a path holds up to 3 * max_depth + 2 entries: one bitmap lookup per vertex, two environment lookups per bounce)
+// (the lookup record of a path holds 4 * max_depth + 4 entries, adjoint.h)
 
 template <int LDS> struct SceneView {
     const float4 *B;           // blob base (LDS or global)
