@@ -186,6 +186,7 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                             for (int q = 0; q < st_i; ++q) valid = valid && (slot_at(q) != slot);
                             if (valid && P.mesh_filter != nullptr) valid = P.mesh_filter[__float_as_int(S.ld(T.shade_off + 6 * slot + 1).w)] != 0;
                             if (valid) { st_id = slot; st_orig = __float_as_int(S.ld(T.shade_off + 6 * slot + 3).w); }
+                            if (valid && st_comp == 9) st_comp = 18;           // the vertex normals (9-17) are covered per hit by stage 6
                         } else if (valid) {
                             const int mesh = __float_as_int(S.ld(T.shade_off + 6 * slot + 1).w);
                             const int id = st_stage == 1 ? mesh_bsdf(S, mesh) : mesh_emitter(S, mesh);
@@ -239,13 +240,30 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                         if (P.g_env_xf != nullptr) for (int q = 0; q < n_lk; ++q) env_seen = env_seen || __float_as_int(lk[3 * q * kBlock]) == kEnvLookup;
                         st_stage = 5; st_comp = env_seen ? 0 : 11;
                     }
-                    while (st_comp < 11 && (st_comp & 3) == 3) ++st_comp;      // entries 0,1,2, 4,5,6, 8,9,10
-                    return st_comp < 11;
+                    if (st_stage == 5) {
+                        while (st_comp < 11 && (st_comp & 3) == 3) ++st_comp;      // entries 0,1,2, 4,5,6, 8,9,10
+                        if (st_comp < 11) return true;
+                        st_stage = 6; st_i = 0; st_comp = 0;
+                    }
+                    // stage 6: the blended shading normal of every traced hit on a wanted, smooth-shaded mesh (3 components per hit)
+                    while (st_i < n_hits) {
+                        const int slot = __float_as_int(rec[4 * st_i * kBlock]);
+                        bool valid = slot >= 0;
+                        if (valid) {
+                            const float4 s1 = S.ld(T.shade_off + 6 * slot + 1), s2 = S.ld(T.shade_off + 6 * slot + 2);
+                            valid = (__float_as_int(s2.w) & 1) == 0;                                              // flat meshes ignore vertex normals
+                            if (valid && P.mesh_filter != nullptr) valid = P.mesh_filter[__float_as_int(s1.w)] != 0;
+                        }
+                        if (!valid) { ++st_i; continue; }
+                        st_id = st_i; st_orig = __float_as_int(S.ld(T.shade_off + 6 * slot + 3).w);
+                        return true;
+                    }
+                    return false;
                 };
                 bool more = wactive && advance();
                 while (__ballot(more) != 0ull) {
                     if (more) {
-                        S.probe_kind = st_stage < 3 ? st_stage + 1 : (st_stage == 3 ? 5 : (st_stage == 4 ? 4 : 7)); S.probe_id = st_id; S.probe_comp = st_comp;
+                        S.probe_kind = st_stage < 3 ? st_stage + 1 : (st_stage == 3 ? 5 : (st_stage == 4 ? 4 : (st_stage == 5 ? 7 : 8))); S.probe_id = st_id; S.probe_comp = st_comp;
                         const int bc = (st_stage == 1 && st_comp >= 32) ? st_comp - 32 : st_comp;      // component within the (own or nested) BSDF
                         if (st_stage == 1) { S.probe_kind = bc >= 3 ? 6 : 2; S.probe_comp = bc >= 3 ? bc - 3 : bc; }
                         if (st_stage == 3) { S.probe_u = lk[(3 * st_i + 1) * kBlock]; S.probe_v = lk[(3 * st_i + 2) * kBlock]; }
@@ -261,6 +279,17 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                         else if (st_stage == 2) adj_add<LDS>(acc_emit, P.g_emitter, st_id * 3 + st_comp, gval, use_lds);
                         else if (st_stage == 4) { adj_add<LDS>(acc_cam, acc_cam, st_comp, gval, true); ray_p = ray; }
                         else if (st_stage == 5) adj_add<LDS>(acc_cam, acc_cam, 16 + st_comp, gval, true);
+                        else if (st_stage == 6) {
+                            // transpose of the blend n0 (1 - u - v) + n1 u + n2 v at this hit's barycentrics
+                            const float bu = rec[(4 * st_i + 1) * kBlock], bv = rec[(4 * st_i + 2) * kBlock];
+                            const float wv[3] = {1.f - bu - bv, bu, bv};
+                            const int hot = P.hot_map[st_orig];
+                            for (int k = 0; k < 3; ++k) {
+                                const int comp = 9 + 3 * k + st_comp;
+                                if (hot >= 0 && hot < P.n_hot) adj_add<LDS>(acc, acc, hot * 22 + comp, gval * wv[k], true);
+                                else adj_add<LDS>(acc, P.g_tri, st_orig * 22 + comp, gval * wv[k], false);
+                            }
+                        }
                         else if constexpr (has_env(LDS)) {
                             // scatter over the footprint of the lookup (the transpose of the bilinear interpolation)
                             int idx[4]; float wt[4];
@@ -298,6 +327,7 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                         }
                         ++st_comp;
                         if (st_stage < 4 && st_stage != 1 && st_comp >= (st_stage == 0 ? 22 : (st_stage == 3 ? 7 : 3))) { st_comp = 0; ++st_i; }      // (stage 1 ends in advance())
+                        if (st_stage == 6 && st_comp >= 3) { st_comp = 0; ++st_i; }
                         more = advance();
                     }
                 }

@@ -117,7 +117,7 @@ template <int LDS> struct SceneView {
     int rec_i, rec_n;          // replay cursor / number of recorded hits
     int *ext;                  // extra triangle slots read without a trace (light samples), stride kBlock
     int ext_n;
-    int probe_kind;            // 0 none, 1 triangle field, 2 bsdf reflectance, 3 emitter radiance, 4 camera to_world, 5 bitmap lookup, 6 material constant, 7 environment map from_world
+    int probe_kind;            // 0 none, 1 triangle field, 2 bsdf reflectance, 3 emitter radiance, 4 camera to_world, 5 bitmap lookup, 6 material constant, 7 environment map from_world, 8 blended normal of one hit
     int probe_id, probe_comp;
     // bitmap-parameter lookups (textured BSDFs): the recording run notes (bsdf id, u, v) of every lookup; a probe of kind 5
     // puts a unit tangent on one component of the looked-up value of ONE such lookup (matched by id and the bit-equal uv the

@@ -123,7 +123,13 @@ PSDR_DEV Its<AD> make_its(const SceneView<LDS> &S, const Hit &h, const RayT<AD> 
             dir_in = ray.d;
         }
     }
-    V sh_n = normalize(madd3(n1 - n0, u, n2 - n0, v, n0));
+    V nb = madd3(n1 - n0, u, n2 - n0, v, n0);                       // the vertex normals enter only through this blend
+    if constexpr (AD) {
+        // reverse mode, probe kind 8: a unit tangent on one component of the blend of ONE traced hit (the record just consumed);
+        // the kernel spreads the result over n0, n1, n2 with the barycentric weights - 3 probes per hit instead of 9 per triangle
+        if (S.probe_kind == 8 && S.rec_i - 1 == S.probe_id) { Dual &q = S.probe_comp == 0 ? nb.x : (S.probe_comp == 1 ? nb.y : nb.z); q.d += 1.f; }
+    }
+    V sh_n = normalize(nb);
     if (flat) sh_n = its.n;
     its.fn = sh_n;
     if constexpr (FRAME) {

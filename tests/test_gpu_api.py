@@ -739,3 +739,47 @@ def test_reverse_mode_deep_paths_and_many_lookups(psdr, orc):
     got = {"P": float(P.grad), "rad": float((rad.grad * v_rad).sum()), "tex": float((tex.grad * v_tex).sum())}
     for k in want:
         assert abs(want[k]) > 1e-4 and abs(got[k] - want[k]) < 3e-3 * max(1.0, abs(want[k])), (k, got[k], want[k])
+
+
+def test_reverse_mode_through_vertex_normals(psdr, orc):
+    """a rotation and a per-vertex displacement change the (smooth) vertex normals: the per-hit blended-normal probes of the
+    interior adjoint must reproduce forward mode"""
+    import torch
+    from psdr_jit_amd import Matrix4fC, Matrix4fD
+    D = scenes.DATA
+    ang = psdr.FloatD(0.).requires_grad_()
+    sc = psdr.Scene()
+    sc.opts.spp, sc.opts.sppe, sc.opts.sppse = 8, 8, 8
+    sc.opts.width = sc.opts.height = 40
+    sc.opts.log_level = 0
+    cam = psdr.PerspectiveCamera(60, 0.000001, 10000000.)
+    cam.to_world = Matrix4fD([[1., 0., 0., 278.], [0., 1., 0., 273.], [0., 0., 1., -500.], [0., 0., 0., 1.]])
+    sc.add_Sensor(cam)
+    sc.add_BSDF(psdr.DiffuseBSDF([0.0, 0.0, 0.0]), "light")
+    sc.add_BSDF(psdr.DiffuseBSDF([0.9, 0.6, 0.1]), "ball")
+    sc.add_BSDF(psdr.DiffuseBSDF([0.95, 0.95, 0.95]), "white")
+    I = np.eye(4, dtype=np.float32).tolist()
+    sc.add_Mesh(os.path.join(D, "cbox_luminaire.obj"), Matrix4fC([[1., 0., 0., 0.], [0., 1., 0., -0.5], [0., 0., 1., 0.], [0., 0., 0., 1.]]), "light", psdr.AreaLight([20.0, 20.0, 8.0]))
+    ball = psdr.Mesh()
+    ball.load(os.path.join(D, "cbox_smallball.obj"))
+    V0 = torch.tensor(np.asarray(ball.vertex_positions, np.float32))
+    disp = torch.zeros_like(V0, requires_grad=True)
+    ball.vertex_positions = V0 + disp
+    sc.add_Mesh(ball, "ball", None)
+    for f in ("cbox_floor", "cbox_back"):
+        sc.add_Mesh(os.path.join(D, f + ".obj"), Matrix4fC(I), "white", None)
+    c, s = torch.cos(ang), torch.sin(ang)
+    # rotate the (smooth-shaded) ball about a vertical axis through (185, *, 169): its vertex normals turn with it
+    sc.param_map["Mesh[1]"].set_transform(Matrix4fD([[c, 0., s, 185. - 185. * c - 169. * s], [0., 1., 0., 0.], [-s, 0., c, 169. + 185. * s - 169. * c], [0., 0., 0., 1.]]))
+    sc.configure()
+    sc.configure([0])
+    img = psdr.PathTracer(2).renderD(sc, 0, seed=9)
+    w = torch.linspace(0.5, 1.5, img.numel(), device=img.device).reshape(img.shape)
+    rng = np.random.default_rng(3)
+    v = torch.tensor(rng.standard_normal(tuple(V0.shape)).astype(np.float32))
+    want_d = float((psdr.forward_grad(img, disp, direction=v) * w).sum())
+    want_a = float((psdr.forward_grad(img, ang) * w).sum())
+    (img * w).sum().backward()
+    got_d, got_a = float((disp.grad * v).sum()), float(ang.grad)
+    assert abs(want_d) > 1e-3 and abs(got_d - want_d) < 3e-3 * max(1.0, abs(want_d)), (got_d, want_d)
+    assert abs(want_a) > 1e-3 and abs(got_a - want_a) < 3e-3 * max(1.0, abs(want_a)), (got_a, want_a)
