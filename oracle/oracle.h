@@ -134,6 +134,8 @@ void orc_get_primary_edges(const orc_scene *s, int sensor_id, int tangent, float
 int orc_get_mesh_edges(const orc_scene *s, int mesh, int *out, int cap);
 float orc_emitter_sampling_weight(const orc_scene *s, int emitter);
 /* configured EnvironmentMap (0 if the scene has none): bounds = lower xyz, upper xyz; reso = cell grid; cell arrays have reso[0]*reso[1] entries */
+/* Scene::m_lower / m_upper: lower xyz, upper xyz (all vertices and perspective-camera positions; with an environment map, + its 5 % margin) */
+void orc_scene_aabb(const orc_scene *s, float bounds[6]);
 int orc_envmap_info(const orc_scene *s, float bounds[6], int reso[2], float *cell_sum);
 void orc_envmap_cells(const orc_scene *s, float *pmf, float *cmf);
 /* EnvironmentMap::sample_position / sample_position_pdf alone (host arrays, same layout as psdr_hip_env_sample / _pdf) */

@@ -398,6 +398,15 @@ class OracleScene:
     def num_primary_edges(self, sensor=0):
         return lib().orc_num_primary_edges(self._h, sensor)
 
+    def aabb(self):
+        """(lower[3], upper[3]) of Scene::m_lower / m_upper"""
+        L = lib()
+        L.orc_scene_aabb.restype = None
+        L.orc_scene_aabb.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        b = (C.c_float * 6)()
+        L.orc_scene_aabb(self._h, b)
+        return np.array(b[:3], np.float32), np.array(b[3:], np.float32)
+
     def envmap_info(self):
         """(bounds[6], reso[2], cell_sum, pmf, cmf) of the configured EnvironmentMap, or None"""
         b = (C.c_float * 6)(); r = (C.c_int * 2)(); cs = C.c_float()

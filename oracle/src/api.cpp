@@ -79,6 +79,12 @@ void orc_set_field(orc_scene *s, int field, int object, float intensity, float d
     s->sc->field = field; s->sc->field_object = object; s->sc->intensity = orc::Dual(intensity, d_intensity);
 }
 float orc_emitter_sampling_weight(const orc_scene *s, int e) { return s->sc->emitters[e].sampling_weight; }
+/* Scene::m_lower / m_upper (scene.cpp:355-370, 383-387): what the reference logs as "[Scene] AABB" */
+void orc_scene_aabb(const orc_scene *s, float bounds[6]) {
+    const orc::Scene &sc = *s->sc;
+    bounds[0] = sc.lower.x; bounds[1] = sc.lower.y; bounds[2] = sc.lower.z; bounds[3] = sc.upper.x; bounds[4] = sc.upper.y; bounds[5] = sc.upper.z;
+}
+
 int orc_envmap_info(const orc_scene *s, float bounds[6], int reso[2], float *cell_sum) {
     if (s->sc->env_emitter < 0) return 0;
     const orc::EnvmapC &E = s->sc->env;

@@ -359,6 +359,10 @@ PYBIND11_MODULE(_psdr_core, m) {
         .def_readonly("num_sensors", &Scene::m_num_sensors)
         .def_readonly("num_meshes", &Scene::m_num_meshes)
         .def("get_num_emitters", &Scene::get_num_emitters)
+        .def_property_readonly("aabb", [](const Scene &s) {      // Scene::m_lower / m_upper, what configure() logs as "AABB"
+            farr a({2, 3});
+            for (int k = 0; k < 3; ++k) { a.mutable_data()[k] = s.m_lower[k]; a.mutable_data()[3 + k] = s.m_upper[k]; }
+            return a; })
         .def_property_readonly("param_map", [](Scene &s) {
             py::dict d;
             py::object self = py::cast(&s, py::return_value_policy::reference);

@@ -1,0 +1,161 @@
+"""PIN of the oracle against the reference's own outputs: the figures and log lines the reference's five tutorial notebooks
+embed (tests/golden/notebooks/, extracted from /root/reference/tutorials/*.ipynb by tests/golden/make_notebook_refs.py).
+They are the only hot-path outputs the reference holds (it has no tests and cannot be built here).
+
+The oracle renders each notebook's scene with the notebook's integrator and sample counts (at the notebook's resolution
+or a reduced one - block means do not care) and is compared with what the figure DISPLAYS: sRGB pixel values for the
+primal images, derivative values clipped to the colour bar's range for the viridis maps, both as means over a grid of
+blocks because the noise realisations differ (different RNG streams).  Stated metrics, with what the oracle measures today:
+
+  figure                                   what it shows                                          ncc     scale   (threshold)
+  Forward_AD cell 5                        renderD primal, sphere box, PathTracer(1)              0.998   0.999   (> 0.985, 1 +- 0.04)
+  Forward_AD cell 6                        d/dP all three terms, clipped to +-0.1                 0.998   0.996   (> 0.985, 1 +- 0.05)
+  secondary_edge_guiding cell 5 / 6        secondary-edge term alone, plain / guided              0.988 / 0.993, 0.986 / 1.006   (> 0.97, 1 +- 0.07)
+  different_integrator cell 6              primary-edge term of FieldExtraction("silhouette 1")   0.970   0.915   (> 0.95, 0.8 .. 1.1)
+  batch_render cell 5 / 6                  RoughConductor sphere, PathTracer(2), full / batch_pix 0.995 / 0.996, 0.990 / 1.003   (> 0.985, 1 +- 0.04)
+  Forward_AD_envmap cell 6                 bunny under ballroom_1k.exr, primal                    0.993   1.003   (> 0.985, 1 +- 0.04)
+  Forward_AD_envmap cell 8 / 10 / 12       interior / primary / secondary term                    see test_envmap_figures
+
+ncc = normalised cross-correlation of the block means, scale = least-squares factor ours ~ scale * reference.
+"""
+import numpy as np
+import pytest
+
+import notebook_refs as nr
+import scenes
+
+
+def _check(img, name, grid, ncc, scale_tol, size=None):
+    ref, spec = nr.figure(name)
+    if size is not None:
+        spec["width"], spec["height"] = size            # rendered smaller than the notebook: same field of view
+    m = nr.compare(img, name, grid)
+    assert m["ncc"] > ncc and abs(m["scale"] - 1.0) < scale_tol, (name, m)
+    return m
+
+
+def test_logged_integers_and_aabb(orc):
+    """Forward_AD.ipynb cell 4/5 stdout: '[Scene] AABB: [lower = [[0, -9.1e-05, -500]], upper = [[556, 548.8, 559.2]]]',
+    '(79) primary edges initialized', '990 secondary edges initialized'"""
+    log = nr.logs()
+    S = orc.OracleScene(scenes.sphere_scene(64, 64, 1, 1, 1), [0])
+    assert S.num_primary_edges(0) == log["primary_edges"][-1] == 79
+    assert S.num_sec_edges == log["secondary_edges"][-1] == 990
+    lo, hi = S.aabb()
+    # the log prints 6 significant digits
+    assert np.allclose(lo, log["aabb_lower"], rtol=2e-6, atol=1e-6) and np.allclose(hi, log["aabb_upper"], rtol=2e-6, atol=1e-6), (lo, hi)
+
+
+def test_forward_ad_figures(orc):
+    """Forward_AD.ipynb cells 5-6: PathTracer(1).renderD, spp = sppe = sppse = 32, light + small sphere moving in x"""
+    S = orc.OracleScene(scenes.sphere_scene(256, 256, 32, 32, 32), [0])
+    img, d = S.render_d(max_depth=1, seeds=(1, 2, 3))
+    _check(img, "Forward_AD_cell5", 32, 0.985, 0.04, (256, 256))
+    _check(d, "Forward_AD_cell6", 32, 0.985, 0.05, (256, 256))
+
+
+def test_secondary_edge_guiding_figures(orc):
+    """secondary_edge_guiding.ipynb cells 5-6: sppse = 4 alone, without and with preprocess_secondary_edges([2000,5,5,32], 1)"""
+    S = orc.OracleScene(scenes.sphere_scene(256, 256, 0, 0, 4), [0])
+    _, d = S.render_d(max_depth=1, seeds=(1, 2, 3))
+    _check(d, "secondary_edge_guiding_cell5", 32, 0.97, 0.07, (256, 256))
+    g = S.guiding_build(0, [2000, 5, 5, 32], 1, seed=0, max_depth=1)
+    _, d = S.render_d(max_depth=1, seeds=(1, 2, 3), guiding=g)
+    _check(d, "secondary_edge_guiding_cell6", 32, 0.97, 0.07, (256, 256))
+
+
+def test_different_integrator_figure(orc):
+    """different_integrator.ipynb cell 6: FieldExtractionIntegrator("silhouette 1") - the moving small sphere's mask; its
+    derivative is the primary-edge term alone, a one-pixel outline saturated at the colour bar's +-0.1.  Rendered at the
+    notebook's 512 x 512 because the outline's width in pixels sets the block means."""
+    S = orc.OracleScene(scenes.sphere_scene(512, 512, 4, 32, 0), [0])
+    S.set_field("silhouette", 1)
+    _, d = S.render_d(max_depth=0, seeds=(1, 2, 3))
+    m = nr.compare(d, "different_integrator_cell6", 32)
+    assert m["ncc"] > 0.95 and 0.8 < m["scale"] < 1.1, m
+
+
+def conductor_sphere_scene(width=400, height=300, spp=32):
+    """batch_render.ipynb cells 1-4: the sphere box with RoughConductorBSDF(alpha 0.01, eta, k) on the large sphere"""
+    spec = scenes.sphere_scene(width, height, spp, 0, 0)
+    b = spec.bsdfs[0]
+    b.type, b.alpha_u, b.alpha_v = 2, 0.01, 0.01
+    b.eta, b.k, b.specular = (0.155475, 0.116753, 0.138334), (4.83181, 3.12296, 2.1486), (1.0, 1.0, 1.0)
+    for m in spec.meshes:
+        m.d_to_world_left = np.zeros((4, 4), np.float32)
+    return spec
+
+
+def test_batch_render_figures(orc):
+    """batch_render.ipynb cells 5-6: PathTracer(2).renderC, 400 x 300, spp 32; then renderC(seed=0, batch_pix=crop)"""
+    S = orc.OracleScene(conductor_sphere_scene(), [0])
+    img = S.render_c(max_depth=2, seed=5)
+    _check(img, "batch_render_cell5", 32, 0.985, 0.04)
+    pix = np.arange(300 * 400).reshape(300, 400)[150:250, 100:200].reshape(-1).astype(np.int32)
+    part = S.render_c(max_depth=2, seed=0, pix_ids=pix)
+    _check(part, "batch_render_cell6", 25, 0.985, 0.04)
+
+
+def envelope(d, name, grid):
+    """ncc / scale of the block means of |displayed value| (values below one colour step count as zero on both sides)"""
+    ref, spec = nr.figure(name)
+    ours = np.abs(nr.displayed(d, spec))
+    step = (spec["vmax"] - spec["vmin"]) / 256.0
+    refa = np.abs(ref)
+    refa[refa < step] = 0.0
+    ours[ours < step] = 0.0
+    a, b = nr.block_means(ours, refa, spec, grid)
+    return float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum())), float((a * b).sum() / (b * b).sum())
+
+
+@pytest.mark.slow
+def test_envmap_figures(orc):
+    """Forward_AD_envmap.ipynb: bunny_low.obj with MicrofacetBSDF under ballroom_1k.exr, 128 x 128, 128 samples per term.
+    cell 6 primal; cells 8 / 10 / 12 the interior / primary-edge / secondary-edge derivative alone, colour bar +-50.
+
+    The derivative maps of this scene are dominated by the HDR texels of the map seen in a glossy surface at 128 samples:
+    pixel values differ between two noise realisations, so the interior term is compared through the ENVELOPE (block means
+    of |value|), the primary-edge outline through signed block means, and the secondary term (a few dozen isolated spikes in
+    the reference figure and here) through the count and location of its spikes.  Measured: interior envelope ncc 0.989,
+    scale 0.96; primary ncc 0.96 with an envelope scale of 0.82 - the reference's outline is stronger on the bunny's
+    right side (unclipped blocks 1.2-1.8 x), which this restatement does not reproduce and DESIGN.md lists as open."""
+    full = {}
+    for cell, n in ((8, (128, 0, 0)), (10, (0, 128, 0)), (12, (0, 0, 128))):
+        S = orc.OracleScene(scenes.envmap_tutorial_scene(128, 128, *n, param="bunny_x", env_stride=1), [0])
+        img, d = S.render_d(max_depth=1, seeds=(1, 2, 3))
+        full[cell] = d
+        if cell == 8:
+            _check(img, "Forward_AD_envmap_cell6", 32, 0.985, 0.04)
+    ncc, scale = envelope(full[8], "Forward_AD_envmap_cell8", 16)
+    assert ncc > 0.97 and 0.85 < scale < 1.1, (ncc, scale)
+    m = nr.compare(full[10], "Forward_AD_envmap_cell10", 32)
+    ncc, scale = envelope(full[10], "Forward_AD_envmap_cell10", 16)
+    assert m["ncc"] > 0.9 and ncc > 0.9 and 0.6 < scale < 1.1, (m, ncc, scale)
+    # secondary term: isolated spikes on the bunny, nothing elsewhere
+    ref, spec = nr.figure("Forward_AD_envmap_cell12")
+    ours = nr.displayed(full[12], spec)
+    n_ours = int((np.abs(ours) > 1.0).sum())
+    n_ref = (np.abs(ref) > 1.0).sum() * (128.0 / ref.shape[0]) * (128.0 / ref.shape[1])
+    assert 0.5 * n_ref < n_ours < 2.0 * n_ref, (n_ours, n_ref)
+    yy, xx = np.nonzero(np.abs(ours) > 1.0)
+    assert yy.min() >= 30 and yy.max() <= 110 and xx.min() >= 20 and xx.max() <= 105
+
+
+def test_product_host_matches_the_logged_scene_box_and_edge_counts():
+    """the product's host model (no GPU needed) against the same Forward_AD.ipynb log lines"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import __graft_entry__
+    __graft_entry__.build()
+    import tutorials as tut
+    sc = tut._scene(512, 512, 32, 32, 32)
+    tut._camera(sc)
+    tut._sphere_box(sc)
+    sc._configure_host([])
+    sc._configure_host([0])
+    log = nr.logs()
+    box = np.asarray(sc.aabb)
+    assert np.allclose(box[0], log["aabb_lower"], rtol=2e-6, atol=1e-6) and np.allclose(box[1], log["aabb_upper"], rtol=2e-6, atol=1e-6), box
+    assert sc._snapshot()["sec_edges"].shape[0] == log["secondary_edges"][-1] == 990
+    assert sc.param_map["Sensor[0]"]._primary_edges(False).shape[0] == log["primary_edges"][-1] == 79
