@@ -1,42 +1,95 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark: Msamples/s (spp x pixels / s) of PathTracer(3).renderD on the README
-Cornell box, 512x512, spp = sppe = sppse = 32, derivative w.r.t. the x-translation of Mesh[0]
-(BASELINE.json configs[2]), on N MI355X GPUs of one node.
+Cornell box, derivative w.r.t. the x-translation of Mesh[0], on N MI355X GPUs of one node.
 
-A "step" = one full renderD: image + d(image)/d(theta) = interior path tracer with its forward
-tangent + primary-edge + secondary-edge boundary integrals (3 kernels) and, for N > 1, ONE RCCL
-all-reduce of the stacked [image | derivative] buffer.  Inputs (scene snapshot, BVH) are resident in
-HBM before the timed region.  Work is never skipped: every step renders all lanes with fresh seeds.
+Workloads (BASELINE.json `configs`):
+  config 3 (default at N = 1): 512 x 512,  spp = sppe = sppse = 32  - the configuration the metric is quoted on
+  config 4 (default at N > 1): 2048 x 2048, spp = sppe = sppse = 64 - STRONG scaling: the frame is fixed and its
+           256-lane chunks are dealt round-robin to the ranks (interleaved pixel tiles), ONE RCCL all-reduce of the
+           stacked [image | derivative] buffer (96 MiB) assembles it.  `--config 4 --gpus 1` runs it on one GPU.
+  --weak   (N > 1): last round's mode - config 3 with spp = 32 * N, per-GPU work fixed.
 
-Multi-GPU (weak scaling): the frame stays 512x512 and every sampler's spp grows to 32*N; rank r
-renders the 256-lane chunks k with k % N == r of each sampler (interleaved pixel tiles), so the
-per-GPU work is that of the N=1 run; partial images are summed with all_reduce (torch.distributed
-"nccl" = RCCL over xGMI).
+A "step" = one full renderD: image + d(image)/d(theta) = interior path tracer with its forward tangent +
+primary-edge + secondary-edge boundary integrals (3 kernels) and, for N > 1, the all-reduce.  The scene is built
+through the package's public Python surface (the reference README's calls) and is resident in HBM before the timed
+region; the boundary hands over device pointers only (no PCIe term).  Work is never skipped: every step renders all
+lanes with fresh seeds.
 
-Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     — for the dominant kernel: algorithmic BVH-traversal bytes (64 B/node visit + 48 B/triangle
-                 test, counted by the instrumented build) / its HIP-event duration.  The scene is
-                 LDS-resident, so HBM is NOT the binding roofline: the fp32-VALU and
-                 LDS figures that do bound it are reported next to it.
-  cpu_baseline — the CPU restatement (oracle/, test infrastructure) timed on this host on a bounded
-                 1/k interleaved-chunk sample of the same workload.
+Prints ONE JSON line (rank 0).  Extra objects (N = 1, rank 0):
+  roofline     - the dominant kernel against the ceiling that binds it.  The scene is LDS / SGPR resident and the
+                 compulsory HBM traffic is the two output images, so the bound is fp32 VALU issue: achieved =
+                 SURVEY §8(d) flops (60 / node visit + 45 / triangle test + 250 / shaded hit, counted by the
+                 instrumented build in this run) / the kernel's HIP-event duration measured in this run.  `traffic`
+                 and `issue` are rocprofv3 PMC figures of the same command; they cannot be collected from inside the
+                 process, so they are read from the committed summary named in `counters_source` (null if absent).
+  parity       - relative L2 of this run's GPU image / derivative against the oracle on the same shard and seeds.
+  cpu_baseline - the CPU restatement (oracle/, test infrastructure), built -O3 -march=native on this host, 1 warm-up +
+                 median of 5 on a bounded shard of the same workload, all physical cores and one thread.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "tests")):
+for p in (ROOT, os.path.join(ROOT, "examples")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-W, H, SPP, DEPTH = 512, 512, 32, 3
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak
-LDS_PEAK_GBS = 150000.0        # ds_read_b128 aggregate, every CU streaming
+DEPTH = 3
+CONFIGS = {3: dict(res=512, spp=32), 4: dict(res=2048, spp=64)}
+VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: fp32 vector peak
+COUNTERS = os.path.join(ROOT, "profiles", "counters.json")      # written by tools/prof_summary.py from the rocprofv3 --pmc passes
+
+
+def readme_scene(psdr, res, spp):
+    """The reference README's Cornell box (README.md:54-90) through the public API: 8 OBJ meshes, 5 Diffuse BSDFs, one area
+    light, camera fov 60 at (208, 273, -800), Mesh[0] translated by 100 * P in x."""
+    from psdr_jit_amd import FloatD, Matrix4fC, Matrix4fD
+    sc = psdr.Scene()
+    sc.opts.spp, sc.opts.sppe, sc.opts.sppse = spp, spp, spp
+    sc.opts.width = sc.opts.height = res
+    sc.opts.log_level = 0
+    sensor = psdr.PerspectiveCamera(60, 0.000001, 10000000.)
+    sensor.to_world = Matrix4fD([[1., 0., 0., 208.], [0., 1., 0., 273.], [0., 0., 1., -800.], [0., 0., 0., 1.]])
+    sc.add_Sensor(sensor)
+    for name, rgb in (("light", [0.0, 0.0, 0.0]), ("cat", [0.5, 0.5, 0.5]), ("white", [0.95, 0.95, 0.95]), ("green", [0.20, 0.90, 0.20]), ("red", [0.90, 0.20, 0.20])):
+        sc.add_BSDF(psdr.DiffuseBSDF(rgb), name)
+    data = os.path.join(ROOT, "examples", "data", "cbox")
+    eye = [[1., 0., 0., 0.], [0., 1., 0., 0.], [0., 0., 1., 0.], [0., 0., 0., 1.]]
+    sc.add_Mesh(os.path.join(data, "cbox_luminaire.obj"), Matrix4fC([[1., 0., 0., 0.], [0., 1., 0., -0.5], [0., 0., 1., 0.], [0., 0., 0., 1.]]), "light",
+                psdr.AreaLight([20.0, 20.0, 8.0]))
+    for f, b in (("smallbox", "cat"), ("largebox", "cat"), ("floor", "white"), ("ceiling", "white"), ("back", "white"), ("greenwall", "green"), ("redwall", "red")):
+        sc.add_Mesh(os.path.join(data, "cbox_%s.obj" % f), Matrix4fC(eye), b, None)
+    P = FloatD(0.).requires_grad_()
+    sc.param_map["Mesh[0]"].set_transform(Matrix4fD([[1., 0., 0., P * 100], [0., 1., 0., 0.], [0., 0., 1., 0.], [0., 0., 0., 1.]]))
+    sc.configure()
+    sc.configure([0])
+    return sc, P
+
+
+def host_cpu():
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif k == "" and phys is not None and core is not None:
+                cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    return model, (len(cores) or os.cpu_count() or 1), (os.cpu_count() or 1)
 
 
 def main():
@@ -44,9 +97,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--cpu-sample", type=int, default=0, help="1/k of the lanes for the CPU baseline (0 = auto)")
+    ap.add_argument("--config", type=int, choices=(3, 4), default=0, help="BASELINE config (default: 3 at N = 1, 4 at N > 1)")
+    ap.add_argument("--weak", action="store_true", help="N > 1: config 3 with spp = 32 * N (weak scaling)")
+    ap.add_argument("--cpu-shard", type=int, default=0, help="the CPU baseline renders every k-th 256-lane chunk (0 = calibrate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
 
     import numpy as np
@@ -79,22 +135,31 @@ def main():
         dist.barrier()
     import psdr_jit_amd as psdr
     from psdr_jit_amd import cabi
-    import product
-    import scenes
 
     n = world
-    spp = SPP * n
-    spec = scenes.cbox_scene(W, H, spp, spp, spp, param="light_x")
-    sc = product.build_scene(spec)                      # host configure + BVH + upload (not timed)
+    weak = args.weak and n > 1
+    cfg = args.config or (3 if (n == 1 or weak) else 4)
+    res = CONFIGS[cfg]["res"]
+    spp = CONFIGS[cfg]["spp"] * (n if weak else 1)
+    sc, P = readme_scene(psdr, res, spp)                # host configure + filter primitives + upload (not timed)
+    integ = psdr.PathTracer(DEPTH)
+    # forward tangent of the parameter: d to_world_left / dP of Mesh[0]; one untimed call installs it in the device scene
+    leaf = sc.param_map["Mesh[0]"].to_world_left
+    d_leaf = np.zeros((4, 4), np.float32)
+    d_leaf[0, 3] = 100.0
+    psdr.render_d_fwd(integ, sc, 0, seed=12345, tangents={leaf: d_leaf})
     handle = sc._hip_handle()
     L = cabi.lib()
-    npx = W * H
+    npx = res * res
     buf = torch.empty((2, npx, 3), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step(i, terms=7):
-        a = cabi.make_args(max_depth=DEPTH, seeds=(i, i, i), terms=terms, shard_rank=rank, shard_count=world)
-        cabi.check(L.psdr_hip_render_d_fwd(handle, C.byref(a), buf[0].data_ptr(), buf[1].data_ptr(), stream))
+    def launch(seed, terms=7, shard_rank=rank, shard_count=world, zero=True, out=buf):
+        a = cabi.make_args(max_depth=DEPTH, seeds=(seed, seed, seed), terms=terms, shard_rank=shard_rank, shard_count=shard_count, zero_output=zero)
+        cabi.check(L.psdr_hip_render_d_fwd(handle, C.byref(a), out[0].data_ptr(), out[1].data_ptr(), stream))
+
+    def step(i):
+        launch(i)
         if world > 1:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)
 
@@ -122,12 +187,12 @@ def main():
     out = {
         "metric": "Msamples/s (spp x pixels/s) renderD, Cornell box depth=3",
         "value": round(value, 3), "unit": "Msamples/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "README Cornell box (36 triangles) %dx%d PathTracer(%d) renderD d/d(Mesh[0] x-translation), "
-                               "spp=sppe=sppse=%d (32 per GPU)" % (W, H, DEPTH, spp),
+        "config": {"workload": "BASELINE config %d%s: README Cornell box (36 triangles) %dx%d PathTracer(%d) renderD d/d(Mesh[0] x-translation), "
+                               "spp=sppe=sppse=%d" % (cfg, " weak-scaled" if weak else "", res, res, DEPTH, spp),
                    "rays_per_step": int(npx * spp * (1 + 2 * DEPTH) + npx * spp * 2 * (1 + 2 * DEPTH) + npx * spp * 3),
-                   "parallelism": "interleaved 256-lane chunks over %d GPU(s) + all_reduce(sum)" % n},
+                   "parallelism": "256-lane chunks dealt round-robin to %d GPU(s)%s" % (n, " + one all_reduce(sum) of [image | derivative]" if n > 1 else "")},
     }
 
     # ---------------------------------------------------------------- roofline of the dominant kernel (rank 0, N = 1)
@@ -135,14 +200,13 @@ def main():
         names = {1: "k_interior<AD>", 2: "k_primary_edges", 4: "k_secondary_edges"}
         per = {}
         for terms in (1, 2, 4):
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            step(77, terms)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # torch's current stream = the launch stream
+            launch(77, terms)
             torch.cuda.synchronize()
             reps = max(5, args.steps // 2)
             ev0.record()
             for i in range(reps):
-                a = cabi.make_args(max_depth=DEPTH, seeds=(i, i, i), terms=terms, zero_output=False)
-                cabi.check(L.psdr_hip_render_d_fwd(handle, C.byref(a), buf[0].data_ptr(), buf[1].data_ptr(), stream))
+                launch(i, terms, zero=False)
             ev1.record()
             torch.cuda.synchronize()
             ms = ev0.elapsed_time(ev1) / reps
@@ -151,52 +215,84 @@ def main():
             cabi.check(L.psdr_hip_render_d_fwd_counted(handle, C.byref(a), buf[0].data_ptr(), buf[1].data_ptr(), C.byref(c), stream))
             per[terms] = {"kernel": names[terms], "ms": ms, "rays": c.rays, "nodes": c.nodes_visited, "tris": c.tris_tested, "hits": c.shaded_hits}
         dom = max(per.values(), key=lambda r: r["ms"])
-        bytes_alg = 64.0 * dom["nodes"] + 48.0 * dom["tris"]
         flops_alg = 60.0 * dom["nodes"] + 45.0 * dom["tris"] + 250.0 * dom["hits"]
+        bytes_alg = 64.0 * dom["nodes"] + 48.0 * dom["tris"]
         sec = dom["ms"] * 1e-3
-        achieved = bytes_alg / sec / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")     # written from a rocprofv3 --pmc pass, see profiles/README.md
-        if os.path.exists(tpath):
+        achieved = flops_alg / sec / 1e12
+        counters = None
+        if os.path.exists(COUNTERS):
             try:
-                traffic = json.load(open(tpath)).get(dom["kernel"])
+                counters = json.load(open(COUNTERS))
             except Exception:
-                traffic = None
+                counters = None
+        krec = (counters or {}).get("kernels", {}).get(dom["kernel"], {})
         out["roofline"] = {
-            "bound": "hbm", "kernel": dom["kernel"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "note": "algorithmic BVH bytes (64 B/node + 48 B/triangle); the scene is LDS-resident so these bytes are served by LDS, "
-                    "not HBM - the binding ceilings are valu/lds below",
+            "bound": "valu", "kernel": dom["kernel"], "achieved": round(achieved, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / VALU_PEAK_TFLOPS, 4),
+            "traffic": krec.get("hbm_bytes_per_launch"), "counters_source": (counters or {}).get("source"),
+            "issue": krec.get("issue"),
+            "note": "SURVEY 8(d) flops (60/node + 45/triangle + 250/shaded hit, counted in this run) / HIP-event time of this run; "
+                    "compulsory HBM bytes per launch = the two output images (%.1f MB), so HBM is not the ceiling" % (2 * npx * 12 / 1e6),
             "avg_launch_ms": round(dom["ms"], 4), "rays": dom["rays"], "nodes_per_ray": round(dom["nodes"] / max(dom["rays"], 1), 2),
-            "tris_per_ray": round(dom["tris"] / max(dom["rays"], 1), 2),
-            "valu": {"achieved": round(flops_alg / sec / 1e12, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(flops_alg / sec / 1e12 / VALU_PEAK_TFLOPS, 4)},
-            "lds": {"achieved": round(achieved, 1), "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / LDS_PEAK_GBS, 4)},
+            "tris_per_ray": round(dom["tris"] / max(dom["rays"], 1), 2), "flops_per_launch": flops_alg,
+            "scene_bytes": {"algorithmic_per_launch": bytes_alg, "rate_GBps": round(bytes_alg / sec / 1e9, 1),
+                            "served_by": "wave-uniform scalar loads / LDS (one fetch serves 64 lanes): not HBM traffic"},
             "kernels": [{"kernel": r["kernel"], "avg_launch_ms": round(r["ms"], 4), "rays": r["rays"],
                          "Mrays_per_s": round(r["rays"] / (r["ms"] * 1e-3) / 1e6, 1)} for r in per.values()],
         }
 
-    # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1): the oracle, bounded sample
-    if rank == 0 and n == 1 and not args.no_cpu_baseline:
+    # ---------------------------------------------------------------- the oracle legs (rank 0, N = 1): parity + CPU baseline
+    if rank == 0 and n == 1 and not (args.no_cpu_baseline and args.no_parity):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
         from oracle import oracle as orc
+        import scenes                                    # the oracle's neutral description of the same README scene
+        orc.build(native=True)                           # -O3 -march=native on this host (bit-identical to the default build)
+        spec = scenes.cbox_scene(res, res, spp, spp, spp, param="light_x")
         ref = orc.OracleScene(spec, [0])
-        cores = orc.get_num_threads()
-        k = args.cpu_sample
+        model, phys, logical = host_cpu()
+        orc.set_num_threads(phys)
+        n_chunks = (npx * spp + 255) // 256
+
+        def lanes_of(k):
+            return ((n_chunks + k - 1) // k) * 256
+
+        k = args.cpu_shard
         if k <= 0:
-            # calibrate: aim at ~15 s of CPU work
+            # calibrate on a 1/512 shard: aim at ~3 s per run (1 warm-up + 5 timed + the one-thread runs stay within ~30 s)
             t = time.perf_counter()
-            ref.render_d(max_depth=DEPTH, seeds=(1, 1, 1), shard_rank=0, shard_count=256)
-            t256 = time.perf_counter() - t
-            k = int(min(256, max(1, round(256 * t256 / 15.0))))
-        t = time.perf_counter()
-        ref.render_d(max_depth=DEPTH, seeds=(0, 0, 0), shard_rank=0, shard_count=k)
-        tc = time.perf_counter() - t
-        lanes = sum(1 for c in range((npx * spp + 255) // 256) if c % k == 0) * 256
-        out["cpu_baseline"] = {
-            "value": round(lanes / tc / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "oracle/ (CPU restatement, OpenMP) renderD on every %d-th 256-lane chunk of the same 512x512 spp=sppe=sppse=32 "
-                      "depth-3 workload (%d interior lanes + the same share of edge lanes), %.1f s" % (k, lanes, tc),
-        }
+            ref.render_d(max_depth=DEPTH, seeds=(1, 1, 1), shard_rank=0, shard_count=512)
+            t512 = time.perf_counter() - t
+            k = int(min(512, max(1, round(512 * t512 / 3.0))))
+        if not args.no_parity:
+            want_img, want_d = ref.render_d(max_depth=DEPTH, seeds=(0, 0, 0), shard_rank=0, shard_count=k)
+            launch(0, 7, shard_rank=0, shard_count=k)
+            torch.cuda.synchronize()
+            got = buf.cpu().numpy()
+
+            def rel(a, b):
+                return float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
+            out["parity"] = {"rel_l2_image": rel(got[0], want_img), "rel_l2_derivative": rel(got[1], want_d), "tolerance": 1e-3,
+                             "sample": "every %d-th 256-lane chunk of each sampler of this workload, seeds (0,0,0), HIP vs oracle" % k}
+        if not args.no_cpu_baseline:
+            def timed(kk, runs):
+                ts = []
+                for r in range(runs + 1):                # first run = warm-up
+                    t = time.perf_counter()
+                    ref.render_d(max_depth=DEPTH, seeds=(r, r, r), shard_rank=0, shard_count=kk)
+                    ts.append(time.perf_counter() - t)
+                return statistics.median(ts[1:])
+            tc = timed(k, 5)
+            k1 = min(n_chunks, k * max(1, phys // 2))    # the one-thread runs get a proportionally smaller shard
+            orc.set_num_threads(1)
+            t1 = timed(k1, 3)
+            orc.set_num_threads(phys)
+            out["cpu_baseline"] = {
+                "value": round(lanes_of(k) / tc / 1e6, 4), "unit": "Msamples/s", "cores": phys, "kind": "port",
+                "one_thread": round(lanes_of(k1) / t1 / 1e6, 5), "cpu": model, "logical_cpus": logical,
+                "sample": "oracle/ (CPU restatement of the reference algorithm, g++ -O3 -march=native, OpenMP over %d physical cores) renderD on every "
+                          "%d-th 256-lane chunk of this workload (%d interior lanes + the same share of edge lanes): 1 warm-up + median of 5, %.2f s per run; "
+                          "one thread: every %d-th chunk, median of 3, %.2f s" % (phys, k, lanes_of(k), tc, k1, t1),
+            }
 
     if rank == 0:
         print(json.dumps(out))

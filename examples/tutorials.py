@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import psdr_jit_amd as psdr                                                    # noqa: E402
 from psdr_jit_amd import FloatD, Matrix4fC, Matrix4fD                          # noqa: E402
 
-DATA = os.path.join(os.path.dirname(psdr.__file__), "data")
+DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 I4 = [[1., 0., 0., 0.], [0., 1., 0., 0.], [0., 0., 1., 0.], [0., 0., 0., 1.]]
 
 

@@ -21,12 +21,16 @@ TERM_INTERIOR, TERM_PRIMARY, TERM_SECONDARY = 1, 2, 4
 TERM_ALL = 7
 
 
-def build(force: bool = False) -> str:
-    """Compile the oracle with g++ (a few seconds)."""
-    if force or not os.path.exists(_LIB_PATH):
-        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
-    else:
-        subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+def build(force: bool = False, native: bool = False) -> str:
+    """Compile the oracle with g++ (a few seconds).  native=True builds and SELECTS the -march=native variant
+    (bit-identical results, BASELINE.md §3's CPU-baseline protocol): call it before the first OracleScene."""
+    global _LIB_PATH, _lib
+    args = ["make", "-C", _HERE] + (["-B"] if force else []) + (["native"] if native else [])
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    if native:
+        path = os.path.join(_HERE, "_build", "liboracle_native.so")
+        if path != _LIB_PATH:
+            _LIB_PATH, _lib = path, None
     return _LIB_PATH
 
 

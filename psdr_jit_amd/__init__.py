@@ -309,10 +309,22 @@ def _roughconductor_init(self, *args):
     if not args:
         return
     # 1x1 Bitmap1fD / Bitmap3fD arguments (tutorials/batch_render.ipynb) are the constants they hold
+    orig = args
     args = tuple((_const_of(a, a.data.size) if a.data.size in (1, 3) else a.data) if isinstance(a, (Bitmap3fD, Bitmap1fD)) else a for a in args)
     scal = lambda x: float(_np.ravel(_split(x, (-1,))[0])[0])
-    first_two_scalar = len(args) >= 4 and _np.size(_split(args[1], (-1,))[0]) == 1
-    if first_two_scalar:
+    # the reference tells its two overloads apart by Bitmap1fD / Bitmap3fD types; plain numbers cannot: five arguments or a
+    # Bitmap1fD in second place select (alpha_u, alpha_v, eta, k[, specular]), anything else is (alpha, eta, k[, specular]),
+    # and a four-argument call whose second argument is a bare scalar could be either and is refused
+    if len(args) == 5 or (len(args) == 4 and isinstance(orig[1], Bitmap1fD)):
+        anisotropic = True
+    elif len(args) == 4 and not isinstance(orig[1], Bitmap3fD) and _np.size(_split(args[1], (-1,))[0]) == 1:
+        raise ValueError("RoughConductorBSDF: (a, b, c, d) with a scalar b is ambiguous between (alpha, eta, k, specular_reflectance) and "
+                         "(alpha_u, alpha_v, eta, k): pass Bitmap1fD / Bitmap3fD arguments as the reference does, or all five parameters")
+    else:
+        anisotropic = False
+    if len(args) < 3:
+        raise ValueError("RoughConductorBSDF takes (alpha, eta, k[, specular_reflectance]) or (alpha_u, alpha_v, eta, k[, specular_reflectance])")
+    if anisotropic:
         au, av, rest = args[0], args[1], args[2:]
     else:
         au, av, rest = args[0], args[0], args[1:]

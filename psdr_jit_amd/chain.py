@@ -43,15 +43,23 @@ def _process_mesh(Vw, F):
     return torch.cat([p0, e1, e2, n_v[i0], n_v[i1], n_v[i2], N / a[:, None], (0.5 * a)[:, None]], dim=1)
 
 
-def _camera_to_sample(fov_x, near, far, aspect):
+def _camera_to_sample(fov_x, near, far, aspect, orthographic=False):
     recip = 1.0 / (far - near)
-    cot = 1.0 / math.tan(math.radians(fov_x * 0.5))
     P = torch.zeros((4, 4), dtype=F64)
-    P[0, 0] = cot
-    P[1, 1] = cot
-    P[2, 2] = far * recip
-    P[2, 3] = -near * far * recip
-    P[3, 2] = 1.0
+    if orthographic:
+        # OrthographicCamera (reference orthographic.cpp, transform.h:75-78): scale(1, 1, 1 / (far - near)) . translate(0, 0, -near)
+        P[0, 0] = 1.0
+        P[1, 1] = 1.0
+        P[2, 2] = recip
+        P[2, 3] = -near * recip
+        P[3, 3] = 1.0
+    else:
+        cot = 1.0 / math.tan(math.radians(fov_x * 0.5))
+        P[0, 0] = cot
+        P[1, 1] = cot
+        P[2, 2] = far * recip
+        P[2, 3] = -near * far * recip
+        P[3, 2] = 1.0
     S = torch.diag(torch.tensor([-0.5, -0.5 * aspect, 1.0, 1.0], dtype=F64))
     T = torch.eye(4, dtype=F64)
     T[0, 3] = -1.0
@@ -90,7 +98,7 @@ def snapshot_tensors(scene, sensor_id, leaf_of):
     if ids.shape[0] > 0:
         fov, near, far = cam._camera_params()
         aspect = float(scene.opts.width) / float(scene.opts.height)
-        w2s = _camera_to_sample(fov, near, far, aspect) @ torch.linalg.inv(tw)
+        w2s = _camera_to_sample(fov, near, far, aspect, bool(cam.orthographic)) @ torch.linalg.inv(tw)
         q0, q1 = [], []
         for mid, v0, v1 in ids.tolist():
             q0.append(Vws[mid][v0])

@@ -71,17 +71,6 @@ template <int LDS> PSDR_DEV void flush_counters(const SceneView<LDS> &S, Counter
     }
 }
 
-// inclusive segmented scan over the wave: lanes with equal key are contiguous
-PSDR_DEV float seg_scan(float v, int key, int lane_id) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const float vu = __shfl_up(v, off);
-        const int ku = __shfl_up(key, off);
-        if (lane_id >= off && ku == key) v += vu;
-    }
-    return v;
-}
-
 template <int LDS> PSDR_DEV float *scratch_base(float4 *smem, const SceneTables &T) {
     return reinterpret_cast<float *>(smem + (in_lds(LDS) ? T.blob_words : 0)) + T.stack_depth * kBlock;
 }

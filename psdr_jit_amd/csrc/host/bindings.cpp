@@ -157,7 +157,10 @@ PYBIND11_MODULE(_psdr_core, m) {
     py::class_<NormalMap, BSDF>(m, "NormalMapBSDF", py::dynamic_attr())
         .def(py::init<>())
         .def(py::init([](const farr &n) { return new NormalMap(to_a3(n)); }))
-        .def_property_readonly("_nested", [](NormalMap &b) { return b.m_bsdf; }, py::return_value_policy::reference_internal)
+        .def_property_readonly("_nested", [](py::object self) {        // the owner is held by a visible attribute, see Scene.param_map
+            py::object o = py::cast(self.cast<NormalMap &>().m_bsdf, py::return_value_policy::reference);
+            if (!o.is_none()) o.attr("_psdr_owner") = self;
+            return o; })
         .def("_set_nested", [](NormalMap &b, const BSDF *n) { b.set_nested(n); })
         .def("_get", [](const NormalMap &d, const std::string &, bool tangent) {
             if (d.tex_w > 0) {
@@ -365,8 +368,15 @@ PYBIND11_MODULE(_psdr_core, m) {
             return a; })
         .def_property_readonly("param_map", [](Scene &s) {
             py::dict d;
+            // The wrappers keep their scene alive through a PYTHON attribute (a reference the garbage collector can see) instead
+            // of pybind11's hidden keep-alive list: the Python layer stores the wrappers in the scene's __dict__, and a hidden
+            // back reference made every populated Scene (host arrays, device blob, BVH) immortal.
             py::object self = py::cast(&s, py::return_value_policy::reference);
-            for (auto &kv : s.m_param_map) d[py::str(kv.first)] = py::cast(kv.second, py::return_value_policy::reference_internal, self);
+            for (auto &kv : s.m_param_map) {
+                py::object o = py::cast(kv.second, py::return_value_policy::reference);
+                o.attr("_psdr_scene") = self;
+                d[py::str(kv.first)] = o;
+            }
             return d; }, "Parameter map")
         .def("_sampler_state", [](const Scene &s, int k) { return py::make_tuple(s.m_samplers[k].ready, s.m_samplers[k].sample_count, s.m_samplers[k].seed, s.m_samplers[k].skip); })
         .def("_set_sampler_state", [](Scene &s, int k, bool ready, int64_t count, uint64_t seed, uint64_t skip) {

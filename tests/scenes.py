@@ -1,6 +1,6 @@
 """Scene descriptions shared by the tests: the README Cornell box (reference README.md:54-85,
 8 meshes / 36 triangles / 66 mesh edges) and the tutorial sphere box (tutorials/Forward_AD.ipynb
-cells 2-5, 652 triangles).  Geometry comes from the OBJ data files under psdr_jit_amd/data/cbox.
+cells 2-5, 652 triangles).  Geometry comes from the OBJ data files under examples/data/cbox.
 
 The OBJ reader here is the tests' own (fan triangulation = what an ear-clipping triangulator
 yields for convex polygons, which is what the reference gets from tinyobj)."""
@@ -10,7 +10,7 @@ import numpy as np
 
 from oracle.oracle import BsdfSpec, CameraSpec, EmitterSpec, MeshSpec, SceneSpec
 
-DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "psdr_jit_amd", "data", "cbox")
+DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "data", "cbox")
 
 
 def load_obj(path):

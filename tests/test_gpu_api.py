@@ -404,6 +404,42 @@ def test_camera_pose_reverse_mode(psdr, orc):
     assert abs(float(ang.grad) - want_a) < 2e-3 * max(1.0, abs(want_a)), (float(ang.grad), want_a)
 
 
+def test_orthographic_camera_reverse_mode(psdr, orc):
+    """loss.backward() through an OrthographicCamera with primary edges (the host chain rule projects the edge end points with the
+    orthographic camera_to_sample, chain.py): a box translation and a camera translation equal <w, forward_grad>"""
+    import torch
+    from psdr_jit_amd import Matrix4fC, Matrix4fD
+    D = scenes.DATA
+    tx = psdr.FloatD(0.).requires_grad_()
+    bx = psdr.FloatD(0.).requires_grad_()
+    sc = psdr.Scene()
+    sc.opts.spp = sc.opts.sppe = sc.opts.sppse = 8
+    sc.opts.width = sc.opts.height = 40
+    sc.opts.log_level = 0
+    cam = psdr.OrthographicCamera(0.1, 100.0)
+    cam.to_world = Matrix4fD([[1., 0., 0., tx * 0.2], [0., 1., 0., 0.], [0., 0., 1., -5.], [0., 0., 0., 1.]])
+    sc.add_Sensor(cam)
+    sc.add_BSDF(psdr.DiffuseBSDF([0.0, 0.0, 0.0]), "light")
+    sc.add_BSDF(psdr.DiffuseBSDF(), "cat")
+    sc.add_BSDF(psdr.DiffuseBSDF([0.95, 0.95, 0.95]), "white")
+    S = (scenes._scale_m(1.0 / 300.0) @ scenes.translate(-278.0, -273.0, -280.0)).astype(np.float32)
+    sc.add_Mesh(os.path.join(D, "cbox_luminaire.obj"), Matrix4fC((S @ scenes.translate(0.0, -0.5, 0.0)).tolist()), "light", psdr.AreaLight([20.0, 20.0, 8.0]))
+    for f, b in (("cbox_smallbox", "cat"), ("cbox_largebox", "cat"), ("cbox_floor", "white"), ("cbox_back", "white")):
+        sc.add_Mesh(os.path.join(D, f + ".obj"), Matrix4fC(S.tolist()), b, None)
+    sc.param_map["Mesh[1]"].set_transform(Matrix4fD([[1., 0., 0., bx * 0.3], [0., 1., 0., 0.], [0., 0., 1., 0.], [0., 0., 0., 1.]]))
+    sc.configure()
+    sc.configure([0])
+    assert sc.param_map["Sensor[0]"].orthographic
+    img = psdr.PathTracer(2).renderD(sc, 0, seed=7)
+    w = torch.linspace(0.5, 1.5, img.numel(), device=img.device).reshape(img.shape)
+    want_t = float((psdr.forward_grad(img, tx) * w).sum())
+    want_b = float((psdr.forward_grad(img, bx) * w).sum())
+    (img * w).sum().backward()
+    assert abs(want_t) > 1e-3 and abs(want_b) > 1e-3
+    assert abs(float(tx.grad) - want_t) < 2e-3 * max(1.0, abs(want_t)), (float(tx.grad), want_t)
+    assert abs(float(bx.grad) - want_b) < 2e-3 * max(1.0, abs(want_b)), (float(bx.grad), want_b)
+
+
 def test_unit_ray_intersect(psdr, orc):
     """Scene.unit_ray_intersect (reference psdr.cpp:404): the Intersection record of a batch of rays against the oracle's closest
     hits (same triangle, t) and the snapshot's triangle rows (p, geometric normal, shading frame, uv, wi)"""

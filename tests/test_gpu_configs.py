@@ -1,0 +1,146 @@
+"""BASELINE.json's configurations AS TIMED, HIP path (through the C ABI) vs the oracle:
+
+  config 2  Cornell box 512 x 512, spp 32, PathTracer(3) renderC           - full size, one 1/64 shard of the lanes
+  config 3  + sppe = sppse = 32, renderD w.r.t. Mesh[0] x-translation       - small at depth 3 (per term), and full size on a 1/64 shard
+            (the kernels bench.py times: the LDS-class AD interior kernel and both edge kernels at depth 3)
+  config 4  2048 x 2048, spp = sppe = sppse = 64 (268 M lanes per sampler)  - rank 3 of 8's lane arithmetic on 1/128 of its chunks
+  config 5  82 k-triangle mesh under a 1024 x 512 environment map, albedo parameter, guiding grid [2000, 5, 5, 32], PathTracer(3)
+            - the full mesh and map at 128 x 128 x 4 spp
+
+A shard = the 256-lane chunks k with k % count == rank of each of the three samplers (what a rank of the multi-GPU path
+renders); oracle and kernels enumerate the same lanes, so the comparison is exact up to float summation order.
+Tolerance: relative L2 < 1e-3 (BASELINE north_star), measured ~1e-7.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import product
+import scenes
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X (no CPU fallback exists)")
+    import __graft_entry__
+    __graft_entry__.build()
+    import psdr_jit_amd
+    from psdr_jit_amd import cabi
+    return torch, psdr_jit_amd, cabi
+
+
+def _render_d(env, sc, n_pix, depth, seeds, rank=0, count=1, terms=7, guiding=None):
+    torch, _, cabi = env
+    buf = torch.empty((2, n_pix, 3), dtype=torch.float32, device="cuda")
+    a = cabi.make_args(max_depth=depth, seeds=seeds, terms=terms, shard_rank=rank, shard_count=count, guiding=guiding)
+    cabi.check(cabi.lib().psdr_hip_render_d_fwd(sc._hip_handle(), C.byref(a), buf[0].data_ptr(), buf[1].data_ptr(), None))
+    torch.cuda.synchronize()
+    return buf.cpu().numpy()
+
+
+@pytest.mark.parametrize("param", ["light_x", "albedo"])
+def test_config3_depth3_small_per_term(env, orc, param):
+    """the timed kernels at the timed depth: class-1 (LDS) AD interior kernel + primary + secondary edges, PathTracer(3)"""
+    spec = scenes.cbox_scene(64, 64, 8, 8, 8, param=param)
+    sc = product.build_scene(spec)
+    ref = orc.OracleScene(spec, [0])
+    for terms in (orc.TERM_INTERIOR, orc.TERM_PRIMARY, orc.TERM_SECONDARY, orc.TERM_ALL):
+        got = _render_d(env, sc, 64 * 64, 3, (31, 32, 33), terms=terms)
+        wimg, wd = ref.render_d(max_depth=3, seeds=(31, 32, 33), terms=terms)
+        if terms & orc.TERM_INTERIOR:
+            assert product.rel_l2(got[0], wimg) < TOL
+        if np.abs(wd).max() > 0:
+            assert product.rel_l2(got[1], wd) < TOL, (param, terms)
+        else:
+            assert np.abs(got[1]).max() == 0.0
+
+
+def test_config3_full_size_shard(env, orc):
+    """512 x 512, 32 / 32 / 32, depth 3: shard 5 of 64 of every sampler (131 072 lanes each) - bench.py's workload and seeds layout"""
+    spec = scenes.cbox_scene(512, 512, 32, 32, 32, param="light_x")
+    sc = product.build_scene(spec)
+    ref = orc.OracleScene(spec, [0])
+    got = _render_d(env, sc, 512 * 512, 3, (7, 7, 7), rank=5, count=64)
+    wimg, wd = ref.render_d(max_depth=3, seeds=(7, 7, 7), shard_rank=5, shard_count=64)
+    assert np.isfinite(got).all()
+    assert product.rel_l2(got[0], wimg) < TOL and product.rel_l2(got[1], wd) < TOL
+    # and the shards of a frame add up to the frame (what the all-reduce relies on), at full size
+    full = _render_d(env, sc, 512 * 512, 3, (7, 7, 7))
+    parts = sum(_render_d(env, sc, 512 * 512, 3, (7, 7, 7), rank=r, count=4) for r in range(4))
+    assert product.rel_l2(parts[0], full[0]) < 1e-5 and product.rel_l2(parts[1], full[1]) < 1e-4
+
+
+def test_config2_full_size_shard(env, orc):
+    """512 x 512, spp 32, PathTracer(3) renderC on shard 9 of 64; the oracle's same lanes come from its interior term
+    (render_d's primal: the same estimator evaluated in D mode, equal to rounding)"""
+    torch, _, cabi = env
+    spec = scenes.cbox_scene(512, 512, 32, 0, 0, param=None)
+    sc = product.build_scene(spec)
+    ref = orc.OracleScene(spec, [0])
+    out = torch.empty((512 * 512, 3), dtype=torch.float32, device="cuda")
+    a = cabi.make_args(max_depth=3, seeds=(3, 0, 0), shard_rank=9, shard_count=64)
+    cabi.check(cabi.lib().psdr_hip_render_c(sc._hip_handle(), C.byref(a), out.data_ptr(), None))
+    wimg, _ = ref.render_d(max_depth=3, seeds=(3, 0, 0), terms=orc.TERM_INTERIOR, shard_rank=9, shard_count=64)
+    assert product.rel_l2(out.cpu().numpy(), wimg) < TOL
+
+
+def test_config4_lane_arithmetic_shard(env, orc):
+    """2048 x 2048, spp = sppe = sppse = 64: 268 435 456 lanes per sampler (beyond 2^28, lane * 3 beyond 2^31).  Rank 3 of 8 owns
+    the chunks k % 8 == 3; every 128-th of those (k % 1024 == 3 + 8 * 77) is rendered by both sides."""
+    spec = scenes.cbox_scene(2048, 2048, 64, 64, 64, param="light_x")
+    sc = product.build_scene(spec)
+    ref = orc.OracleScene(spec, [0])
+    rank, count = 3 + 8 * 77, 1024
+    got = _render_d(env, sc, 2048 * 2048, 3, (11, 12, 13), rank=rank, count=count)
+    wimg, wd = ref.render_d(max_depth=3, seeds=(11, 12, 13), shard_rank=rank, shard_count=count)
+    assert np.isfinite(got).all() and np.abs(wimg).max() > 0
+    assert product.rel_l2(got[0], wimg) < TOL and product.rel_l2(got[1], wd) < TOL
+    # the last chunk of the frame lands on the last pixels
+    last = (2048 * 2048 * 64) // 256 - 1
+    tail = _render_d(env, sc, 2048 * 2048, 3, (11, 12, 13), rank=last % count, count=count, terms=orc.TERM_INTERIOR)
+    wtail, _ = ref.render_d(max_depth=3, seeds=(11, 12, 13), terms=orc.TERM_INTERIOR, shard_rank=last % count, shard_count=count)
+    assert np.array_equal(np.nonzero(tail[0].sum(axis=1))[0][-1:], np.nonzero(wtail.sum(axis=1))[0][-1:])
+    assert product.rel_l2(tail[0], wtail) < TOL
+
+
+def test_config5_full_mesh(env, orc):
+    """the 81 920-triangle noisy icosphere + floor under the 1024 x 512 sun map (tests/scenes.py::config5_scene), DiffuseBSDF albedo
+    parameter, guiding grid [2000, 5, 5, 32], PathTracer(3), all three terms: the BVH path on the full-size scene"""
+    torch, psdr, cabi = env
+    spec = scenes.config5_scene(128, 128, 4, 4, 4, level=6, env_res=(1024, 512))
+    sc = product.build_scene(spec)
+    ref = orc.OracleScene(spec, [0])
+    assert ref.num_triangles == 81920 + 2 + 12
+    integ = psdr.PathTracer(3)
+    reso = [2000, 5, 5, 32]
+    integ.preprocess_secondary_edges(sc, 0, reso, 1, 0)
+    g = ref.guiding_build(0, reso, nrounds=1, seed=0, max_depth=3)
+    mass = np.asarray(integ._guiding_mass(0)).reshape(-1)
+    assert product.rel_l2(mass, g.mass()) < TOL
+    img, dimg = psdr.render_d_fwd(integ, sc, 0, seed=1)
+    wimg, wd = ref.render_d(max_depth=3, seeds=(1, 1, 1), guiding=g)
+    assert product.rel_l2(img.cpu().numpy(), wimg) < TOL and product.rel_l2(dimg.cpu().numpy(), wd) < TOL
+    # closest hits on the full mesh: bit-exact against the oracle's brute-force definition on random rays
+    rng = np.random.default_rng(5)
+    n = 20000
+    o = rng.uniform([-100, 0, -200], [650, 500, 650], size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    to, td = torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda()
+    tri = torch.empty(n, dtype=torch.int32, device="cuda")
+    uv = torch.empty((n, 2), dtype=torch.float32, device="cuda")
+    t = torch.empty(n, dtype=torch.float32, device="cuda")
+    cabi.check(cabi.lib().psdr_hip_trace(sc._hip_handle(), n, to.data_ptr(), td.data_ptr(), tri.data_ptr(), uv.data_ptr(), t.data_ptr(), None))
+    wtri, wuv, wt = ref.trace(o, d, use_bvh=True)
+    btri, buv, bt = ref.trace(o[:3000], d[:3000], use_bvh=False)       # the definition: every triangle, smallest (t, id)
+    assert np.array_equal(wtri[:3000], btri) and np.array_equal(wt[:3000], bt)
+    assert np.array_equal(tri.cpu().numpy(), wtri)
+    hit = wtri >= 0
+    assert hit.mean() > 0.5
+    assert np.array_equal(uv.cpu().numpy()[hit], wuv[hit]) and np.array_equal(t.cpu().numpy()[hit], wt[hit])

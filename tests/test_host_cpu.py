@@ -414,7 +414,7 @@ def test_exr_piz_tutorial_envmap(psdr):
     smooth 1024x512 radiance image; statistics pinned as a regression (sum of all values is order independent enough in f64)"""
     from psdr_jit_amd import exr
     import psdr_jit_amd
-    path = os.path.join(os.path.dirname(psdr_jit_amd.__file__), "data", "envmap", "ballroom_1k.exr")
+    path = os.path.join(os.path.dirname(scenes.DATA), "envmap", "ballroom_1k.exr")
     img = exr.read_rgb(path)
     assert img.shape == (512, 1024, 3) and img.dtype == np.float32 and np.isfinite(img).all() and img.min() >= 0
     assert abs(float(img.max()) - 141.5) < 1e-3
@@ -486,3 +486,40 @@ def test_host_snapshot_of_the_ggx_family(psdr):
     n_own = len([k for k in sc.param_map if k.startswith("BSDF[") and not k.startswith("BSDF[id=")])
     assert len(rows) == n_own + 1 and tuple(rows[0])[:3] == (5, n_own, 16) and rows[n_own][0] == 2
     assert type(sc.param_map["BSDF[id=tex]"].nested_bsdf).__name__ == "RoughConductorBSDF"
+
+
+def test_scene_is_freed_when_dropped(psdr):
+    """A populated Scene (sensor, BSDFs, meshes, normal map with a nested BSDF) must be collectable: the param_map wrappers the Python
+    layer keeps in the scene's __dict__ reference the scene through a visible attribute, not through pybind11's hidden keep-alive."""
+    import gc
+    import weakref
+    sc = product.build_scene(scenes.normalmap_scene(16, 16, 1, 0, 0), host_only=True)
+    mesh = sc.param_map["Mesh[0]"]
+    r = weakref.ref(sc)
+    del sc
+    gc.collect()
+    assert r() is not None and mesh.num_vertices > 0       # a live wrapper keeps its scene (no dangling pointer)
+    del mesh
+    gc.collect()
+    assert r() is None
+    sc = product.build_scene(scenes.cbox_scene(16, 16, 1, 1, 1), host_only=True)
+    r = weakref.ref(sc)
+    del sc
+    gc.collect()
+    assert r() is None
+
+
+def test_roughconductor_constructor_overloads(psdr):
+    """(alpha, eta, k[, specular]) vs (alpha_u, alpha_v, eta, k[, specular]): told apart by count and Bitmap types, never guessed"""
+    one = lambda b, n: np.asarray(b._get(n, False)).reshape(-1)
+    b = psdr.RoughConductorBSDF(0.1, [1.5, 1.6, 1.7], [2.0, 2.1, 2.2], [1.0, 0.9, 0.8])
+    assert np.allclose(one(b, "alpha_u"), 0.1) and np.allclose(one(b, "alpha_v"), 0.1) and np.allclose(one(b, "eta"), [1.5, 1.6, 1.7])
+    assert np.allclose(one(b, "k"), [2.0, 2.1, 2.2]) and np.allclose(one(b, "specular_reflectance"), [1.0, 0.9, 0.8])
+    b = psdr.RoughConductorBSDF(0.1, 0.2, [1.5, 1.6, 1.7], [2.0, 2.1, 2.2], [1.0, 0.9, 0.8])
+    assert np.allclose(one(b, "alpha_u"), 0.1) and np.allclose(one(b, "alpha_v"), 0.2) and np.allclose(one(b, "k"), [2.0, 2.1, 2.2])
+    b = psdr.RoughConductorBSDF(psdr.Bitmap1fD(0.1), psdr.Bitmap1fD(0.3), psdr.Bitmap3fD([1.5, 1.6, 1.7]), psdr.Bitmap3fD([2.0, 2.1, 2.2]))
+    assert np.allclose(one(b, "alpha_v"), 0.3) and np.allclose(one(b, "eta"), [1.5, 1.6, 1.7])
+    b = psdr.RoughConductorBSDF(psdr.Bitmap1fD(0.01), psdr.Bitmap3fD([0.155475, 0.116753, 0.138334]), psdr.Bitmap3fD([4.83181, 3.12296, 2.1486]))
+    assert np.allclose(one(b, "alpha_v"), 0.01) and np.allclose(one(b, "k"), [4.83181, 3.12296, 2.1486])
+    with pytest.raises(ValueError):
+        psdr.RoughConductorBSDF(0.1, 1.5, 2.0, [1.0, 1.0, 1.0])          # scalar eta or alpha_v?

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 rocpd databases under gpurun_out/prof_* into the text summaries that are
 committed under profiles/ (kernel-trace stats + per-kernel PMC averages) and into
-profiles/hbm_traffic.json, which bench.py reads for roofline.traffic.
+profiles/counters.json, which bench.py reads for roofline.traffic / roofline.issue (PMC counters cannot be
+collected from inside the benchmarked process; the JSON names the summary file it was made from).
 
     python tools/prof_summary.py <round-tag>          # e.g. r01
 
@@ -76,22 +77,53 @@ def pmc(tag):
             if f is not None and w is not None:
                 t = 2.0 * f * 1024 + w * 1024
                 fh.write("    %-28s %18.0f   bytes/launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024\n" % ("HBM traffic", t))
-                key = {"k_interior<true, true, false>": "k_interior<AD>", "k_primary_edges<true, false>": "k_primary_edges",
-                       "k_paths<true, true, false, 0>": "k_interior<AD>", "k_paths<false, true, false, 1>": "k_primary_edges",
-                       "k_secondary_edges<true, false>": "k_secondary_edges", "k_secondary_edges<true, false, false>": "k_secondary_edges",
-                       # scene classes (int template parameter since r01i): class 1 = the LDS kernels bench.py runs
-                       "k_paths<true, 1, false, 0>": "k_interior<AD>", "k_paths<false, 1, false, 1>": "k_primary_edges",
-                       "k_secondary_edges<1, false, false>": "k_secondary_edges"}.get(k, k)
-                traffic[key] = t
+                traffic[k] = t
             tc, ai = cs.get("SQ_THREAD_CYCLES_VALU", (None, 0))[0], cs.get("SQ_ACTIVE_INST_VALU", (None, 0))[0]
             if tc is not None and ai:
                 fh.write("    %-28s %18.4f   SQ_THREAD_CYCLES_VALU / (64*SQ_ACTIVE_INST_VALU)\n" % ("VALU lane utilisation", tc / (64.0 * ai)))
             h, m = cs.get("TCC_HIT_sum", (None, 0))[0], cs.get("TCC_MISS_sum", (None, 0))[0]
             if h is not None and m is not None and h + m > 0:
                 fh.write("    %-28s %18.4f   TCC_HIT/(TCC_HIT+TCC_MISS)\n" % ("L2 hit rate", h / (h + m)))
-    if not PREFIX:          # only the bench.py profile (tools/profile.sh) feeds bench.py's roofline.traffic
-        with open(os.path.join(PROF, "hbm_traffic.json"), "w") as fh:
-            json.dump(traffic, fh, indent=1)
+    if not PREFIX:          # only the bench.py profile (tools/profile.sh) feeds bench.py's roofline.traffic / roofline.issue
+        write_counters_json(tag, per, traffic)
+
+
+def bench_name(k):
+    """kernel template instantiation -> the name bench.py prints (un-instrumented forward kernels only)"""
+    import re
+    m = re.match(r"k_paths<(\w+), (\d+), (\w+), (\d+)>", k)
+    if m and m.group(3) == "false":
+        return "k_primary_edges" if m.group(4) == "1" else ("k_interior<AD>" if m.group(1) == "true" else "k_interior")
+    m = re.match(r"k_secondary_edges<(\d+), (\w+), (\w+)>", k)
+    if m and m.group(2) == "false" and m.group(3) == "false":
+        return "k_secondary_edges"
+    return None
+
+
+def write_counters_json(tag, per, traffic):
+    db = db_of("prof_kt")
+    avg_us = {}
+    if db is not None:
+        for name, avg in db.execute("select name, average from top_kernels"):
+            avg_us[short(name)] = avg
+    out = {"source": "profiles/%s_pmc_summary.txt + profiles/%s_kernel_trace_stats.txt (rocprofv3 --pmc / --kernel-trace --stats passes of "
+                     "`python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-parity`, tools/profile.sh)" % (tag, tag), "kernels": {}}
+    for k, cs in per.items():
+        b = bench_name(k)
+        if b is None:
+            continue
+        rec = {"instantiation": k}
+        if k in traffic:
+            rec["hbm_bytes_per_launch"] = traffic[k]
+        g = lambda c: cs.get(c, (None, 0))[0]
+        iv, tc, ai, wc = g("SQ_INSTS_VALU"), g("SQ_THREAD_CYCLES_VALU"), g("SQ_ACTIVE_INST_VALU"), g("SQ_WAVE_CYCLES")
+        if iv is not None and k in avg_us:
+            slots = 1024 * 2.4e9 / 2.0 * avg_us[k] * 1e-6          # 1024 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz
+            rec["issue"] = {"SQ_INSTS_VALU": iv, "avg_launch_us": avg_us[k], "valu_issue_slots": slots, "valu_issue_frac": iv / slots,
+                            "lane_utilisation": (tc / (64.0 * ai)) if (tc is not None and ai) else None, "SQ_WAVE_CYCLES": wc}
+        out["kernels"][b] = rec
+    with open(os.path.join(PROF, "counters.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
 
 
 if __name__ == "__main__":

@@ -7,7 +7,7 @@ set -u
 REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
-BENCH="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+BENCH="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-parity"
 cd /tmp && export TMPDIR=/tmp
 python $REPO/bench.py > $OUT/bench_line.json 2> $OUT/bench_err.log
 rm -rf $OUT/prof_kt $OUT/prof_fetch $OUT/prof_write $OUT/prof_l2 $OUT/prof_sq $OUT/prof_sq2
