@@ -258,11 +258,11 @@ def main():
 
         k = args.cpu_shard
         if k <= 0:
-            # calibrate on a 1/512 shard: aim at ~3 s per run (1 warm-up + 5 timed + the one-thread runs stay within ~30 s)
+            # shard for the parity check: ~1 s of oracle time
             t = time.perf_counter()
             ref.render_d(max_depth=DEPTH, seeds=(1, 1, 1), shard_rank=0, shard_count=512)
             t512 = time.perf_counter() - t
-            k = int(min(512, max(1, round(512 * t512 / 3.0))))
+            k = int(min(512, max(1, round(512 * t512 / 1.0))))
         if not args.no_parity:
             want_img, want_d = ref.render_d(max_depth=DEPTH, seeds=(0, 0, 0), shard_rank=0, shard_count=k)
             launch(0, 7, shard_rank=0, shard_count=k)
@@ -274,24 +274,34 @@ def main():
             out["parity"] = {"rel_l2_image": rel(got[0], want_img), "rel_l2_derivative": rel(got[1], want_d), "tolerance": 1e-3,
                              "sample": "every %d-th 256-lane chunk of each sampler of this workload, seeds (0,0,0), HIP vs oracle" % k}
         if not args.no_cpu_baseline:
-            def timed(kk, runs):
+            # The sample: the same scene, resolution, depth and three terms at a REDUCED sample count per pixel (every pixel and
+            # every sampler, so the OpenMP loops stay balanced - a sparse shard leaves most threads idle); samples per second
+            # is the metric, so the figure is directly comparable.  spp is calibrated to ~3 s per run.
+            def timed(sref, runs):
                 ts = []
                 for r in range(runs + 1):                # first run = warm-up
                     t = time.perf_counter()
-                    ref.render_d(max_depth=DEPTH, seeds=(r, r, r), shard_rank=0, shard_count=kk)
+                    sref.render_d(max_depth=DEPTH, seeds=(r, r, r))
                     ts.append(time.perf_counter() - t)
                 return statistics.median(ts[1:])
-            tc = timed(k, 5)
-            k1 = min(n_chunks, k * max(1, phys // 2))    # the one-thread runs get a proportionally smaller shard
+            one = orc.OracleScene(scenes.cbox_scene(res, res, 1, 1, 1, param="light_x"), [0])
+            t = time.perf_counter()
+            one.render_d(max_depth=DEPTH, seeds=(9, 9, 9))
+            t_one = time.perf_counter() - t
+            cspp = int(min(spp, max(1, round(3.0 / max(t_one, 1e-3)))))
+            sref = orc.OracleScene(scenes.cbox_scene(res, res, cspp, cspp, cspp, param="light_x"), [0])
+            tc = timed(sref, 5)
             orc.set_num_threads(1)
-            t1 = timed(k1, 3)
+            sres = max(16, res // 8)                      # one thread: the same scene at 1/64 of the pixels, 1 sample each
+            tiny = orc.OracleScene(scenes.cbox_scene(sres, sres, 1, 1, 1, param="light_x"), [0])
+            t1 = timed(tiny, 3)
             orc.set_num_threads(phys)
             out["cpu_baseline"] = {
-                "value": round(lanes_of(k) / tc / 1e6, 4), "unit": "Msamples/s", "cores": phys, "kind": "port",
-                "one_thread": round(lanes_of(k1) / t1 / 1e6, 5), "cpu": model, "logical_cpus": logical,
-                "sample": "oracle/ (CPU restatement of the reference algorithm, g++ -O3 -march=native, OpenMP over %d physical cores) renderD on every "
-                          "%d-th 256-lane chunk of this workload (%d interior lanes + the same share of edge lanes): 1 warm-up + median of 5, %.2f s per run; "
-                          "one thread: every %d-th chunk, median of 3, %.2f s" % (phys, k, lanes_of(k), tc, k1, t1),
+                "value": round(npx * cspp / tc / 1e6, 4), "unit": "Msamples/s", "cores": phys, "kind": "port",
+                "one_thread": round(sres * sres / t1 / 1e6, 5), "cpu": model, "logical_cpus": logical,
+                "sample": "oracle/ (CPU restatement of the reference algorithm, g++ -O3 -march=native, OpenMP over %d physical cores) renderD of this "
+                          "workload at spp=sppe=sppse=%d instead of %d (all %d pixels, all three terms): 1 warm-up + median of 5, %.2f s per run; "
+                          "one thread: %dx%d pixels at 1 sample, median of 3, %.2f s" % (phys, cspp, spp, npx, tc, sres, sres, t1),
             }
 
     if rank == 0:

@@ -1,6 +1,6 @@
 """BASELINE.json's configurations AS TIMED, HIP path (through the C ABI) vs the oracle:
 
-  config 2  Cornell box 512 x 512, spp 32, PathTracer(3) renderC           - full size, one 1/64 shard of the lanes
+  config 2  Cornell box 512 x 512, spp 32, PathTracer(3) renderC           - full size, two bands of pixel rows + a lane range
   config 3  + sppe = sppse = 32, renderD w.r.t. Mesh[0] x-translation       - small at depth 3 (per term), and full size on a 1/64 shard
             (the kernels bench.py times: the LDS-class AD interior kernel and both edge kernels at depth 3)
   config 4  2048 x 2048, spp = sppe = sppse = 64 (268 M lanes per sampler)  - rank 3 of 8's lane arithmetic on 1/128 of its chunks
@@ -76,18 +76,30 @@ def test_config3_full_size_shard(env, orc):
     assert product.rel_l2(parts[0], full[0]) < 1e-5 and product.rel_l2(parts[1], full[1]) < 1e-4
 
 
-def test_config2_full_size_shard(env, orc):
-    """512 x 512, spp 32, PathTracer(3) renderC on shard 9 of 64; the oracle's same lanes come from its interior term
-    (render_d's primal: the same estimator evaluated in D mode, equal to rounding)"""
+def test_config2_full_size_rows(env, orc):
+    """512 x 512, spp 32, PathTracer(3) renderC at full size; the oracle renders the lanes of pixel rows 200-207 (131 072 lanes,
+    a contiguous lane range of its C-mode renderer) and a second band at the bottom of the frame"""
     torch, _, cabi = env
     spec = scenes.cbox_scene(512, 512, 32, 0, 0, param=None)
     sc = product.build_scene(spec)
     ref = orc.OracleScene(spec, [0])
     out = torch.empty((512 * 512, 3), dtype=torch.float32, device="cuda")
-    a = cabi.make_args(max_depth=3, seeds=(3, 0, 0), shard_rank=9, shard_count=64)
+    a = cabi.make_args(max_depth=3, seeds=(3, 0, 0))
     cabi.check(cabi.lib().psdr_hip_render_c(sc._hip_handle(), C.byref(a), out.data_ptr(), None))
-    wimg, _ = ref.render_d(max_depth=3, seeds=(3, 0, 0), terms=orc.TERM_INTERIOR, shard_rank=9, shard_count=64)
-    assert product.rel_l2(out.cpu().numpy(), wimg) < TOL
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    for r0, r1 in ((200, 208), (500, 512)):
+        want = ref.render_c(max_depth=3, seed=3, lane_begin=r0 * 512 * 32, lane_end=r1 * 512 * 32)
+        assert np.abs(want[r0 * 512:r1 * 512]).max() > 0
+        assert product.rel_l2(got[r0 * 512:r1 * 512], want[r0 * 512:r1 * 512]) < TOL
+    # per-lane radiance of the same kernel on a lane range deep in the frame
+    lanes = torch.empty((65536, 3), dtype=torch.float32, device="cuda")
+    b0 = 300 * 512 * 32
+    cabi.check(cabi.lib().psdr_hip_li_lanes(sc._hip_handle(), C.byref(a), b0, b0 + 65536, lanes.data_ptr(), None))
+    want = ref.li_lanes(b0, b0 + 65536, max_depth=3, seed=3)
+    gl = lanes.cpu().numpy()
+    bad = np.abs(gl - want).max(axis=1) > 1e-4 * np.abs(want).max()
+    assert bad.mean() < 2e-4 and product.rel_l2(gl[~bad], want[~bad]) < 1e-5
 
 
 def test_config4_lane_arithmetic_shard(env, orc):
