@@ -75,6 +75,18 @@ template <int LDS> PSDR_DEV float *scratch_base(float4 *smem, const SceneTables 
     return reinterpret_cast<float *>(smem + (in_lds(LDS) ? T.blob_words : 0)) + T.stack_depth * kBlock;
 }
 
+// BVH scenes of the global-memory classes take the decoupled form (traversal refilled per ray, paths.h); brute-force scenes and the
+// LDS class keep the lock-step form
+template <bool AD, int LDS, bool COUNT, int MODE>
+PSDR_DEV void run_paths_any(SceneView<LDS> &S, const SensorDev &cam, const PathParams &P) {
+    if constexpr (!in_lds(LDS)) {
+#ifndef PSDR_NO_ASYNC        // measurement knob: the lock-step form on BVH scenes too
+        if (S.T->n_tris > kBruteForceMax) { run_paths_async<AD, LDS, COUNT, MODE>(S, cam, P); return; }
+#endif
+    }
+    run_paths<AD, LDS, COUNT, MODE>(S, cam, P);
+}
+
 // ------------------------------------------------------------------------------------------------
 // interior term (MODE 0) and primary-edge term (MODE 1): persistent lanes with path regeneration, paths.h
 template <bool AD, int LDS, bool COUNT, int MODE>
@@ -96,11 +108,11 @@ __global__ __launch_bounds__(kBlock, (AD ? (in_lds(LDS) ? 3 : PSDR_GLOBAL_AD_WAV
         __syncthreads();
         PathParams Q = P;
         Q.g_prim = acc;
-        run_paths<AD, LDS, COUNT, MODE>(S, cam, Q);
+        run_paths_any<AD, LDS, COUNT, MODE>(S, cam, Q);
         __syncthreads();
         for (int i = threadIdx.x; i < 4 * P.n_prim; i += kBlock) if (acc[i] != 0.f) atomicAdd(&P.g_prim[i], acc[i]);
     } else {
-        run_paths<AD, LDS, COUNT, MODE>(S, cam, P);
+        run_paths_any<AD, LDS, COUNT, MODE>(S, cam, P);
     }
     if (COUNT) flush_counters(S, ctr);
 }
@@ -433,6 +445,7 @@ struct psdr_hip_scene {
     std::vector<SensorDev> sensors;
     DevBuf counters;
     DevBuf queues;                       // ring of work-queue heads, one per path-kernel launch
+    DevBuf gstack;                       // traversal-stack entries beyond the LDS part (trav4.h)
     mutable unsigned queue_slot = 0;
     int n_leaves = 0, max_depth = 0, grid = 0;
     long long tex_total = 0;             // floats of all bitmap parameters (psdr_grads.g_tex)
@@ -481,13 +494,15 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
 
     BvhResult bvh;
     build_bvh(tr.p0, tr.e1, tr.e2, n, bvh);
+    Bvh4Result bvh4;
+    build_bvh4(bvh, n, bvh4);
     std::vector<int32_t> orig2slot(n);
     for (int slot = 0; slot < n; ++slot) orig2slot[bvh.order[slot]] = slot;
 
     const bool has_tan = tr.d_p0 != nullptr;
     SceneTables &T = sc->T;
     size_t w = 0;
-    T.nodes_off = (int) w; w += 4 * (size_t) bvh.n_nodes;
+    T.nodes_off = (int) w; w += 8 * (size_t) bvh4.n_nodes;      // 128-byte nodes of the 4-wide tree (bvh.h)
     T.trav_off = (int) w;  w += 3 * (size_t) n;
     T.shade_off = (int) w; w += 6 * (size_t) n;
     T.tan_off = (int) w;   w += has_tan ? 6 * (size_t) n : 0;
@@ -655,13 +670,21 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
         pe_offs.emplace_back(o1, o2);
     }
     T.blob_words = (int) w;
-    T.n_nodes = bvh.n_nodes; T.n_tris = n; T.n_meshes = s->n_meshes; T.n_bsdfs = s->n_bsdfs; T.n_emitters = s->n_emitters;
-    T.n_fcdf = s->n_face_distrb; T.has_tangent = has_tan ? 1 : 0; T.stack_depth = bvh.max_depth + 1;
+    T.n_nodes = bvh4.n_nodes; T.n_tris = n; T.n_meshes = s->n_meshes; T.n_bsdfs = s->n_bsdfs; T.n_emitters = s->n_emitters;
+    T.n_fcdf = s->n_face_distrb; T.has_tangent = has_tan ? 1 : 0;
+    T.ref_bits = bvh4.ref_bits;
+    // traversal stack: the first kStackLds entries of a lane in LDS, deeper ones in a per-lane global array (trav4.h);
+    // scenes that are traced by brute force (<= kBruteForceMax triangles) need neither
+    constexpr int kStackLds = 16;
+    const bool uses_bvh = n > kBruteForceMax;
+    T.stack_lds = uses_bvh ? std::min(kStackLds, bvh4.max_stack) : 0;
+    T.stack_depth = T.stack_lds + (uses_bvh ? kParkWords : 0);       // + the parked rays of run_paths_async (paths.h)
+    T.gstack = nullptr; T.gstack_stride = 0;
     T.emitter_sum = s->emitter_sum;
     T.width = s->width; T.height = s->height; T.spp = s->spp; T.sppe = s->sppe; T.sppse = s->sppse;
 
     std::vector<float> blob(4 * w, 0.f);
-    std::memcpy(&blob[4 * (size_t) T.nodes_off], bvh.nodes.data(), sizeof(float) * bvh.nodes.size());
+    std::memcpy(&blob[4 * (size_t) T.nodes_off], bvh4.nodes.data(), sizeof(float) * bvh4.nodes.size());
     for (int slot = 0; slot < n; ++slot) {
         const int o = bvh.order[slot];
         const float *p0 = tr.p0 + 3 * o, *e1 = tr.e1 + 3 * o, *e2 = tr.e2 + 3 * o;
@@ -759,7 +782,7 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     sc->lean = !sc->lds && T.tex == nullptr && T.mat == nullptr && T.pv == nullptr;
     sc->smem_bytes = (sc->lds ? blob_bytes : 0) + stack_bytes;
     if (sc->smem_bytes > 64 * 1024) return fail("BVH too deep for the LDS traversal stack");
-    sc->n_leaves = bvh.n_leaves; sc->max_depth = bvh.max_depth;
+    sc->n_leaves = bvh.n_leaves; sc->max_depth = bvh4.max_depth;
 
     for (int i = 0; i < s->n_sensors; ++i) {
         const psdr_sensor_rec &r = s->sensors[i];
@@ -778,6 +801,12 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount; }
     sc->grid = cus * 8;
+    if (uses_bvh && bvh4.max_stack > T.stack_lds) {
+        // stack entries beyond the LDS part: one int per entry and lane of the largest grid any kernel is launched with
+        const size_t stride = (size_t) sc->grid * kBlock;
+        if (sc->gstack.upload(nullptr, sizeof(int) * stride * (size_t) (bvh4.max_stack - T.stack_lds))) return 1;
+        T.gstack = (int *) sc->gstack.p; T.gstack_stride = (int) stride;
+    }
     *out = sc.release();
     return 0;
 }
@@ -806,6 +835,27 @@ static inline int grid_for(const psdr_hip_scene *sc, long long n) {
     if (chunks < 1) chunks = 1;
     return (int) std::min<long long>(chunks, sc->grid);
 }
+
+// Development builds can leave scene classes out (hipcc -DPSDR_CLS_MASK=4 compiles the class-2 kernels only: a third of the build
+// time); bit c = scene class c (scene_dev.h).  A scene of a class that is compiled out fails loudly.
+#ifndef PSDR_CLS_MASK
+#define PSDR_CLS_MASK 7
+#endif
+#if (PSDR_CLS_MASK) & 1
+#define ON_CLS0(...) __VA_ARGS__
+#else
+#define ON_CLS0(...) return fail("scene class 0 is compiled out of this development build")
+#endif
+#if (PSDR_CLS_MASK) & 2
+#define ON_CLS1(...) __VA_ARGS__
+#else
+#define ON_CLS1(...) return fail("scene class 1 is compiled out of this development build")
+#endif
+#if (PSDR_CLS_MASK) & 4
+#define ON_CLS2(...) __VA_ARGS__
+#else
+#define ON_CLS2(...) return fail("scene class 2 is compiled out of this development build")
+#endif
 
 #define LAUNCH(kernel, sc, n_lanes, stream, ...) \
     hipLaunchKernelGGL(kernel, dim3(grid_for(sc, n_lanes)), dim3(kBlock), (sc)->smem_bytes, (hipStream_t) (stream), __VA_ARGS__)
@@ -860,13 +910,13 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
         if (P.n_local > 0) {
             if (next_queue(P.counter)) return 1;
             if (ad) {
-                if (cls == 1) LAUNCH((k_paths<true, 1, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
-                else if (cls == 2) LAUNCH((k_paths<true, 2, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
-                else LAUNCH((k_paths<true, 0, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
+                if (cls == 1) ON_CLS1(LAUNCH((k_paths<true, 1, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
+                else if (cls == 2) ON_CLS2(LAUNCH((k_paths<true, 2, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
+                else ON_CLS0(LAUNCH((k_paths<true, 0, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
             } else {
-                if (cls == 1) LAUNCH((k_paths<false, 1, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
-                else if (cls == 2) LAUNCH((k_paths<false, 2, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
-                else LAUNCH((k_paths<false, 0, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
+                if (cls == 1) ON_CLS1(LAUNCH((k_paths<false, 1, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
+                else if (cls == 2) ON_CLS2(LAUNCH((k_paths<false, 2, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
+                else ON_CLS0(LAUNCH((k_paths<false, 0, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
             }
         }
     }
@@ -878,9 +928,9 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
             P.n_local = local_lanes(P.end, rank, count);
             if (P.n_local > 0) {
                 if (next_queue(P.counter)) return 1;
-                if (cls == 1) LAUNCH((k_paths<false, 1, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
-                else if (cls == 2) LAUNCH((k_paths<false, 2, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
-                else LAUNCH((k_paths<false, 0, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr);
+                if (cls == 1) ON_CLS1(LAUNCH((k_paths<false, 1, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
+                else if (cls == 2) ON_CLS2(LAUNCH((k_paths<false, 2, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
+                else ON_CLS0(LAUNCH((k_paths<false, 0, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
             }
         }
         if ((terms & PSDR_TERM_SECONDARY) && T.sppse > 0 && sc->E.n > 0) {
@@ -893,9 +943,9 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
             if (a->guiding) G = a->guiding->G;
             if (P.n_local > 0) {
                 if (next_queue(P.counter)) return 1;
-                if (sc->lds) LAUNCH((k_secondary_edges<1, COUNT, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr);
-                else if (sc->lean) LAUNCH((k_secondary_edges<2, COUNT, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr);
-                else LAUNCH((k_secondary_edges<0, COUNT, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr);
+                if (sc->lds) ON_CLS1(LAUNCH((k_secondary_edges<1, COUNT, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
+                else if (sc->lean) ON_CLS2(LAUNCH((k_secondary_edges<2, COUNT, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
+                else ON_CLS0(LAUNCH((k_secondary_edges<0, COUNT, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
             }
         }
     }
@@ -999,11 +1049,11 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     if (smem > 160 * 1024) return fail("scene too large for the adjoint kernel's LDS records");
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void *) k_interior_adjoint<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void *) k_interior_adjoint<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void *) k_interior_adjoint<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void *) k_secondary_edges<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void *) k_secondary_edges<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ON_CLS1(HIPCHK(hipFuncSetAttribute((const void *) k_interior_adjoint<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
+        ON_CLS0(HIPCHK(hipFuncSetAttribute((const void *) k_interior_adjoint<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
+        ON_CLS2(HIPCHK(hipFuncSetAttribute((const void *) k_interior_adjoint<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
+        ON_CLS1(HIPCHK(hipFuncSetAttribute((const void *) k_secondary_edges<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
+        ON_CLS0(HIPCHK(hipFuncSetAttribute((const void *) k_secondary_edges<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
         attr_set = true;
     }
     if ((terms & PSDR_TERM_INTERIOR) && T.spp > 0) {
@@ -1021,9 +1071,9 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
             if (next_queue(P.counter)) return 1;
             const int grid = grid_for(sc, P.n_local);
             P.hit_words = adj_hit_words(adj_depth); P.ext_words = adj_ext_words(adj_depth); P.lk_words = with_lookups ? 3 * adj_lk_entries(adj_depth) : 0;
-            if (adj_cls == 1) hipLaunchKernelGGL((k_interior_adjoint<1>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, cam, P);
-            else if (adj_cls == 2) hipLaunchKernelGGL((k_interior_adjoint<2>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, cam, P);
-            else hipLaunchKernelGGL((k_interior_adjoint<0>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, cam, P);
+            if (adj_cls == 1) ON_CLS1(hipLaunchKernelGGL((k_interior_adjoint<1>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, cam, P));
+            else if (adj_cls == 2) ON_CLS2(hipLaunchKernelGGL((k_interior_adjoint<2>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, cam, P));
+            else ON_CLS0(hipLaunchKernelGGL((k_interior_adjoint<0>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, cam, P));
         }
     }
     if (!a->pix_ids && (terms & PSDR_TERM_PRIMARY) && T.sppe > 0 && cam.n_edges > 0) {
@@ -1036,9 +1086,9 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
             if (next_queue(P.counter)) return 1;
             const int grid = grid_for(sc, P.n_local);
             const size_t sm = sc->smem_bytes + (P.lds_acc ? sizeof(float) * 4 * (size_t) cam.n_edges : 0);
-            if (cls == 1) hipLaunchKernelGGL((k_paths<false, 1, false, 1>), dim3(grid), dim3(kBlock), sm, st, sc->blob.as<float4>(), T, cam, P, (Counters *) nullptr);
-            else if (cls == 2) hipLaunchKernelGGL((k_paths<false, 2, false, 1>), dim3(grid), dim3(kBlock), sm, st, sc->blob.as<float4>(), T, cam, P, (Counters *) nullptr);
-            else hipLaunchKernelGGL((k_paths<false, 0, false, 1>), dim3(grid), dim3(kBlock), sm, st, sc->blob.as<float4>(), T, cam, P, (Counters *) nullptr);
+            if (cls == 1) ON_CLS1(hipLaunchKernelGGL((k_paths<false, 1, false, 1>), dim3(grid), dim3(kBlock), sm, st, sc->blob.as<float4>(), T, cam, P, (Counters *) nullptr));
+            else if (cls == 2) ON_CLS2(hipLaunchKernelGGL((k_paths<false, 2, false, 1>), dim3(grid), dim3(kBlock), sm, st, sc->blob.as<float4>(), T, cam, P, (Counters *) nullptr));
+            else ON_CLS0(hipLaunchKernelGGL((k_paths<false, 0, false, 1>), dim3(grid), dim3(kBlock), sm, st, sc->blob.as<float4>(), T, cam, P, (Counters *) nullptr));
         }
     }
     if (!a->pix_ids && (terms & PSDR_TERM_SECONDARY) && T.sppse > 0 && sc->E.n > 0) {
@@ -1057,8 +1107,8 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         if (P.n_local > 0) {
             if (next_queue(P.counter)) return 1;
             const int grid = grid_for(sc, P.n_local);
-            if (sc->lds) hipLaunchKernelGGL((k_secondary_edges<true, false, true>), dim3(grid), dim3(kBlock), smem_sec, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, (Counters *) nullptr);
-            else hipLaunchKernelGGL((k_secondary_edges<false, false, true>), dim3(grid), dim3(kBlock), smem_sec, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, (Counters *) nullptr);
+            if (sc->lds) ON_CLS1(hipLaunchKernelGGL((k_secondary_edges<true, false, true>), dim3(grid), dim3(kBlock), smem_sec, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, (Counters *) nullptr));
+            else ON_CLS0(hipLaunchKernelGGL((k_secondary_edges<false, false, true>), dim3(grid), dim3(kBlock), smem_sec, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, (Counters *) nullptr));
         }
     }
     HIPCHK(hipGetLastError());
@@ -1068,7 +1118,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
 static int trace_impl(const psdr_hip_scene *sc, int32_t n, const float *o, const float *d, int32_t *out_tri, float *out_uv, float *out_t, void *stream, int pairs) {
     if (!sc) return fail("null scene");
     if (n <= 0) return 0;
-    if (sc->lds) LAUNCH((k_trace<true>), sc, (long long) n, stream, sc->blob.as<float4>(), sc->T, n, o, d, out_tri, out_uv, out_t, pairs);
+    if (sc->lds) ON_CLS1(LAUNCH((k_trace<true>), sc, (long long) n, stream, sc->blob.as<float4>(), sc->T, n, o, d, out_tri, out_uv, out_t, pairs));
     else LAUNCH((k_trace<false>), sc, (long long) n, stream, sc->blob.as<float4>(), sc->T, n, o, d, out_tri, out_uv, out_t, pairs);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1123,8 +1173,8 @@ int psdr_hip_guiding_build(const psdr_hip_scene *sc, int32_t sensor_id, int32_t 
     if (mass.upload(nullptr, sizeof(float) * cells)) return 1;
     const long long nl = cells * reso[3];
     for (int r = 0; r < nrounds; ++r) {
-        if (sc->lds) LAUNCH((k_guiding_round<true>), sc, nl, st, sc->blob.as<float4>(), sc->T, sc->E, sc->sensors[sensor_id], G, reso[3], seed, r, (float *) mass.p);
-        else LAUNCH((k_guiding_round<false>), sc, nl, st, sc->blob.as<float4>(), sc->T, sc->E, sc->sensors[sensor_id], G, reso[3], seed, r, (float *) mass.p);
+        if (sc->lds) ON_CLS1(LAUNCH((k_guiding_round<true>), sc, nl, st, sc->blob.as<float4>(), sc->T, sc->E, sc->sensors[sensor_id], G, reso[3], seed, r, (float *) mass.p));
+        else ON_CLS0(LAUNCH((k_guiding_round<false>), sc, nl, st, sc->blob.as<float4>(), sc->T, sc->E, sc->sensors[sensor_id], G, reso[3], seed, r, (float *) mass.p));
     }
     HIPCHK(hipGetLastError());
     g->mass.resize(cells);

@@ -24,6 +24,9 @@ struct BvhResult {
     std::vector<float> nodes;      // 16 floats per node
     std::vector<int32_t> order;    // device triangle slot -> original triangle id
     int32_t n_nodes = 0, n_leaves = 0, max_depth = 0;
+    // the binary tree itself (node 0 = root; left < 0: leaf of `count` triangles starting at slot `first`), input of build_bvh4
+    std::vector<int32_t> tmp_left, tmp_right, tmp_first, tmp_count;
+    std::vector<float> tmp_box;    // lo.xyz, hi.xyz per node (padded)
 };
 
 namespace bvh_detail {
@@ -149,6 +152,99 @@ inline void build_bvh(const float *p0, const float *e1, const float *e2, int n, 
         }
     }
     out.n_nodes = n_inner; out.n_leaves = n_leaves; out.max_depth = max_depth;
+    out.tmp_left.resize(tmp.size()); out.tmp_right.resize(tmp.size()); out.tmp_first.resize(tmp.size()); out.tmp_count.resize(tmp.size()); out.tmp_box.resize(6 * tmp.size());
+    for (size_t i = 0; i < tmp.size(); ++i) {
+        out.tmp_left[i] = tmp[i].left; out.tmp_right[i] = tmp[i].right; out.tmp_first[i] = tmp[i].first; out.tmp_count[i] = tmp[i].left >= 0 ? 0 : tmp[i].count;
+        for (int k = 0; k < 3; ++k) { out.tmp_box[6 * i + k] = tmp[i].box.lo[k]; out.tmp_box[6 * i + 3 + k] = tmp[i].box.hi[k]; }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 4-wide BVH for the device traversal (trav4.h): the binary SAH tree above with up to two levels collapsed into one node
+// (the child with the largest surface area is opened first).  One node = 128 bytes = 8 float4 words = one L2 line:
+//   w0 lo.x[4]  w1 lo.y[4]  w2 lo.z[4]  w3 hi.x[4]  w4 hi.y[4]  w5 hi.z[4]  w6 code[4]  w7 unused
+// code of a child: inner node -> its index; leaf -> leaf_bit | (first_triangle << 2 | count - 1); an unused child slot carries
+// a box at +3e38 on every axis, which no ray can reach.  code < 2^ref_bits, so the traversal packs (coarse entry distance |
+// code) into ONE 32-bit sort key (trav4.h).  max_stack bounds the traversal stack of any ray (sum over a root-to-leaf path
+// of the siblings left behind).
+struct Bvh4Result {
+    std::vector<float> nodes;      // 32 floats per node
+    int32_t n_nodes = 0, max_depth = 0, max_stack = 0, ref_bits = 0;
+    uint32_t leaf_bit = 0;
+};
+
+inline void build_bvh4(const BvhResult &b2, int n_tris, Bvh4Result &out) {
+    const size_t nt = b2.tmp_left.size();
+    auto is_leaf = [&](int i) { return b2.tmp_left[i] < 0; };
+    auto half_area = [&](int i) {
+        const float *b = &b2.tmp_box[6 * (size_t) i];
+        const float d0 = b[3] - b[0], d1 = b[4] - b[1], d2 = b[5] - b[2];
+        return d0 * d1 + d1 * d2 + d2 * d0;
+    };
+    // payload bits: the largest leaf payload is ((n_tris - 1) << 2) | 3, inner indices are smaller than the number of binary nodes
+    uint32_t max_payload = (uint32_t) std::max<int64_t>(((int64_t) std::max(n_tris, 1) - 1) * 4 + 3, (int64_t) nt);
+    int bits = 1;
+    while ((1ull << bits) <= max_payload) ++bits;
+    out.leaf_bit = 1u << bits;
+    out.ref_bits = bits + 1;
+    struct Item { int tmp; int node4; int depth; };
+    std::vector<Item> todo;
+    std::vector<int> need;          // stack need below each emitted node (filled bottom-up afterwards)
+    std::vector<std::vector<int>> kids;   // per node4: child node4 indices (inner children only)
+    out.nodes.clear();
+    auto new_node = [&]() { out.nodes.resize(out.nodes.size() + 32, 0.f); kids.emplace_back(); return (int) (out.nodes.size() / 32) - 1; };
+    std::vector<int> n_children;
+    if (nt == 0) { out.n_nodes = 0; return; }
+    const int root = new_node();
+    n_children.push_back(0);
+    todo.push_back({0, root, 1});
+    int max_depth = 1;
+    while (!todo.empty()) {
+        const Item it = todo.back(); todo.pop_back();
+        max_depth = std::max(max_depth, it.depth);
+        std::vector<int> list;
+        if (is_leaf(it.tmp)) list.push_back(it.tmp);          // a scene of one leaf: the root holds it as its only child
+        else { list.push_back(b2.tmp_left[it.tmp]); list.push_back(b2.tmp_right[it.tmp]); }
+        while (list.size() < 4) {
+            int best = -1; float ba = -1.f;
+            for (size_t k = 0; k < list.size(); ++k) if (!is_leaf(list[k]) && half_area(list[k]) > ba) { ba = half_area(list[k]); best = (int) k; }
+            if (best < 0) break;
+            const int t = list[best];
+            list[best] = b2.tmp_left[t];
+            list.push_back(b2.tmp_right[t]);
+        }
+        n_children[it.node4] = (int) list.size();
+        for (int k = 0; k < 4; ++k) {
+            uint32_t code = 0xffffffffu;
+            float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {3e38f, 3e38f, 3e38f};
+            if (k < (int) list.size()) {
+                const int t = list[k];
+                for (int a = 0; a < 3; ++a) { lo[a] = b2.tmp_box[6 * (size_t) t + a]; hi[a] = b2.tmp_box[6 * (size_t) t + 3 + a]; }
+                if (is_leaf(t)) code = out.leaf_bit | (uint32_t) ((b2.tmp_first[t] << 2) | (b2.tmp_count[t] - 1));
+                else {
+                    const int c = new_node();          // (grows out.nodes: no pointer into it is held across this call)
+                    n_children.push_back(0);
+                    kids[it.node4].push_back(c);
+                    code = (uint32_t) c;
+                    todo.push_back({t, c, it.depth + 1});
+                }
+            }
+            float *q = &out.nodes[32 * (size_t) it.node4];
+            for (int a = 0; a < 3; ++a) { q[4 * a + k] = lo[a]; q[12 + 4 * a + k] = hi[a]; }
+            std::memcpy(&q[24 + k], &code, 4);
+        }
+    }
+    out.n_nodes = (int) (out.nodes.size() / 32);
+    out.max_depth = max_depth;
+    // stack need: children are emitted after their parent, so a reverse sweep sees every child before its parent
+    need.assign(out.n_nodes, 0);
+    for (int i = out.n_nodes - 1; i >= 0; --i) {
+        int below = 0;
+        for (int c : kids[i]) below = std::max(below, need[c]);
+        need[i] = (n_children[i] - 1) + below;
+    }
+    out.max_stack = need.empty() ? 1 : need[0] + 1;
 }
 
 } // namespace psdr

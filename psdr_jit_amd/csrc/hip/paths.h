@@ -304,4 +304,289 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// BVH scenes (more than kBruteForceMax triangles): the same per-lane arithmetic with the traversal DECOUPLED from the shading.
+//
+// In run_paths every iteration traces the two rays of all 64 lanes to completion before any lane shades: a wave waits for
+// its slowest ray at every path vertex, and with rays of 10 to 200 traversal steps most lanes idle (measured on the 82 k-
+// triangle scene of BASELINE config 5: 13 % of the lanes active per VALU instruction, 25 % on the 652-triangle tutorial box).
+// Here a lane is in one of two conditions:
+//     in flight - its rays are in the resumable traversal (trav4.h), or
+//     ready     - it has hits to consume, a new sample to fetch, and rays to generate.
+// The wave alternates between a TRAVERSAL phase that runs until kShadeMin lanes have finished their rays and a SHADING phase
+// in which only the ready lanes consume their hits, regenerate and post their next two rays, while the lanes still in flight
+// keep their place in the tree (their traversal state sits in registers, their rays in LDS).  Finished lanes are thus
+// refilled per traversal, not per path vertex.  The order of a lane's operations - and of its sampler draws - is unchanged:
+// [consume hits of vertex k] [path end -> next sample] [draw + post the rays of vertex k+1].
+#ifndef PSDR_SHADE_MIN
+#define PSDR_SHADE_MIN 44
+#endif
+constexpr int kShadeMin = PSDR_SHADE_MIN;
+
+template <bool AD, int LDS, bool COUNT, int MODE>
+PSDR_DEV void run_paths_async(SceneView<LDS> &S, const SensorDev &cam, const PathParams &P) {
+    using R = Num<AD>; using V = VecN<AD>;
+    const SceneTables &T = *S.T;
+    const int lane_id = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane_id) - 1ull;
+    const float inv_spp = T.spp > 1 ? 1.f / (float) T.spp : 1.f;
+    float *park = reinterpret_cast<float *>(S.stack) + T.stack_lds * kBlock;      // this lane's parked rays: oA dA oB dB, stride kBlock
+
+    long long q_next = 0, q_end = 0;
+    bool exhausted = false;
+
+    // per-lane path state (as in run_paths)
+    bool busy = false;
+    int depth = -1;
+    LaneRng rng; rng.state = 0; rng.inc = 1;
+    Its<AD> its;
+    its.valid = false; its.slot = -1; its.mesh = -1;
+    V thr(R(1.f)), res(R(0.f));
+    RayT<AD> ext;
+    long long lane = 0;
+    int pix_slot = -1;
+    int side = 0;
+    Vec3f Ln(0.f);
+    float edge_xdn_v = 0.f, edge_xdn_d = 0.f, edge_pdf = 1.f, edge_s = 0.f, edge_nx = 0.f, edge_ny = 0.f;
+    int edge_i = 0;
+    bool edge_valid = false;
+    static_assert(MODE == 0 || !AD, "the primary-edge paths are traced in C mode");
+
+    // what a vertex keeps between posting its rays and consuming their hits
+    bool inflight = false, has_hits = false, do_nee = false, ext_traced = false;
+    PositionSample<AD> ps;
+    V wod(R(0.f)); R dist_sqr(0.f), dist(0.f);
+    BSDFSample bs; bs.wo = Vec3f(0.f, 0.f, 1.f); bs.pdf = 1.f; bs.valid = true;
+    Trav4 tr;
+    tr.reset();
+
+    for (;;) {
+        const unsigned long long m_fly = __ballot(inflight);
+        const int n_can = __popcll(__ballot(!inflight && (has_hits || busy || (q_next < q_end) || !exhausted)));
+        if (m_fly == 0ull || n_can >= kShadeMin) {
+            const bool ready = !inflight;
+            // ---------------------------------------------------------------- consume the hits of the lane's current vertex
+            bool finished = false;
+            if (ready && has_hits) {
+                has_hits = false;
+                const Hit h = tr.hA, hx = ext_traced ? tr.result() : Hit{-1, 0.f, 0.f, 0.f};
+                RayT<AD> ray1; ray1.o = its.p; ray1.d = wod;
+                if (do_nee && h.slot >= 0) {
+                    if (COUNT) S.c_hits++;
+                    Its<AD> its1 = make_its<AD, LDS, false>(S, h, ray1, true);
+                    if constexpr (has_env(LDS)) { if (T.env_emitter >= 0 && mesh_emitter(S, its1.mesh) == T.env_emitter) its1 = make_its<AD, LDS, true>(S, h, ray1, true); }
+                    if ((detach(its1.t) > detach(dist) - kShadowEpsilon) && (mesh_emitter(S, its1.mesh) >= 0)) {
+                        const R cos_val = dot(its1.n, -wod);
+                        const R G_val = abs_(cos_val) / dist_sqr;
+                        const V emitter_val = eval_Le<AD, LDS>(S, its1, true);
+                        const V wo_local = to_local<AD>(its, wod);
+                        V bsdf_val2 = bsdf_eval<AD, LDS>(S, its, wo_local, true);
+                        bsdf_val2 = bsdf_val2 * (G_val * ps.J / R(ps.pdf));
+                        const float pdf1 = bsdf_pdf<AD, LDS>(S, its, wo_local, true) * detach(G_val);
+                        if (pdf1 != 0.f) res = res + thr * emitter_val * bsdf_val2 * R(P.mis == 0 ? 1.f : mis_weight(ps.pdf, pdf1));
+                    }
+                }
+                if (COUNT) { if (hx.slot >= 0) S.c_hits++; }
+                const Its<AD> itx = make_its<AD, LDS, true>(S, hx, ext, depth >= 0);
+                if (depth < 0) {
+                    its = itx;
+                    if (S.field >= 0) { if constexpr (has_mat(LDS)) res = first_hit_value<AD, LDS>(S, itx); }
+                    else if (!P.hide_emitters) res = eval_Le<AD, LDS>(S, itx, itx.valid);
+                    depth = 0;
+                    finished = !itx.valid || P.max_depth == 0;
+                } else {
+                    if (bs.valid && itx.valid) {
+                        V bsdf_val;
+                        float pdf0;
+                        if constexpr (AD) {
+                            V wo = (itx.p - its.p) / itx.t;
+                            const R cos_val = dot(itx.n, -wo);
+                            const R G_val = abs_(cos_val) / sqr(itx.t);
+                            pdf0 = bs.pdf * G_val.v;
+                            if (itx.t.v < kEpsilon) bsdf_val = V(R(0.f));
+                            else bsdf_val = bsdf_eval<AD, LDS>(S, its, to_local<AD>(its, wo), true) * G_val * itx.J / R(pdf0);
+                        } else {
+                            const float cos_val = dot(itx.n, -ext.d);
+                            const float G_val = fabsf(cos_val) / sqr(itx.t);
+                            pdf0 = bs.pdf * G_val;
+                            if (itx.t < kEpsilon) bsdf_val = V(0.f);
+                            else bsdf_val = bsdf_eval<AD, LDS>(S, its, bs.wo, true) / bs.pdf;
+                        }
+                        const float weight2 = P.mis == 1 ? 1.f : mis_weight(pdf0, emitter_position_pdf<AD, LDS>(S, detach(its.p), itx));
+                        thr = thr * bsdf_val;
+                        res = res + eval_Le<AD, LDS>(S, itx, true) * thr * R(weight2);
+                        its = itx;
+                        depth += 1;
+                        finished = depth >= P.max_depth;
+                    } else {
+                        depth += 1;
+                        finished = true;
+                    }
+                }
+            }
+            // ---------------------------------------------------------------- path end: accumulate, or start the second edge path
+            if (ready && busy && finished) {
+                if (MODE == 0) {
+                    const float pv[3] = {detach(res.x), detach(res.y), detach(res.z)};
+                    const float tv[3] = {tangent(res.x), tangent(res.y), tangent(res.z)};
+                    if (P.lanes_out) {
+                        const long long o = 3 * (lane - P.begin);
+                        P.lanes_out[o] = pv[0]; P.lanes_out[o + 1] = pv[1]; P.lanes_out[o + 2] = pv[2];
+                    }
+                    if (P.out) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {             // NaN/Inf scrub, integrator.cpp:126
+                            const bool okp = finite_(pv[c]);
+                            const float v = okp ? pv[c] : 0.f;
+                            if (v != 0.f) atomicAdd(&P.out[3 * (long long) pix_slot + c], v * inv_spp);
+                            if (AD) {
+                                const float d = (okp && finite_(tv[c])) ? tv[c] : 0.f;
+                                if (d != 0.f) atomicAdd(&P.dout[3 * (long long) pix_slot + c], d * inv_spp);
+                            }
+                        }
+                    }
+                    busy = false;
+                } else {
+                    if (side == 0) {
+                        Ln = detach(res);
+                        if (depth < P.max_depth) rng.advance((unsigned long long) ((P.mis == 0 ? 2 : (P.mis == 1 ? 3 : 5)) * (P.max_depth - depth)));
+                        side = 1; depth = -1; thr = V(R(1.f)); res = V(R(0.f));
+                        if constexpr (!AD) {
+                            const float4 r0 = S.ld(cam.pe_off + 3 * edge_i);
+                            const float oms = 1.0f - edge_s;
+                            const float pxv = fmaf(r0.x, oms, r0.z * edge_s), pyv = fmaf(r0.y, oms, r0.w * edge_s);
+                            ext = sample_primary_ray<false>(cam, pxv + kEdgeEpsilon * edge_nx, pyv + kEdgeEpsilon * edge_ny);
+                        }
+                    } else {
+                        const Vec3f Lp = detach(res);
+                        const Vec3f dL = (Ln - Lp) / edge_pdf;
+                        const float o3[3] = {dL.x, dL.y, dL.z};
+                        if (P.adj_w == nullptr) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                const float pv = edge_xdn_v * o3[c];
+                                float dv = edge_xdn_d * o3[c];
+                                if (!finite_(pv) || !finite_(dv)) dv = 0.f;
+                                if (T.sppe > 1) dv /= (float) T.sppe;
+                                if (dv != 0.f) atomicAdd(&P.dout[3 * (long long) pix_slot + c], dv);
+                            }
+                        } else {
+                            float kw = 0.f;
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                float k = o3[c];
+                                if (!finite_(edge_xdn_v * k) || !finite_(k)) k = 0.f;
+                                if (T.sppe > 1) k /= (float) T.sppe;
+                                kw += P.adj_w[3 * (long long) pix_slot + c] * k;
+                            }
+                            if (kw != 0.f) {
+                                const float a = (1.0f - edge_s) * kw, b = edge_s * kw;
+                                atomicAdd(&P.g_prim[4 * edge_i], edge_nx * a); atomicAdd(&P.g_prim[4 * edge_i + 1], edge_ny * a);
+                                atomicAdd(&P.g_prim[4 * edge_i + 2], edge_nx * b); atomicAdd(&P.g_prim[4 * edge_i + 3], edge_ny * b);
+                            }
+                        }
+                        busy = false;
+                    }
+                }
+            }
+            // ---------------------------------------------------------------- fetch work for the ready lanes without a path
+            if (q_next >= q_end && !exhausted) {
+                unsigned long long base = 0;
+                if (lane_id == 0) base = atomicAdd(P.counter, (unsigned long long) kFetchBatch);
+                base = __shfl(base, 0);
+                if ((long long) base >= P.n_local) exhausted = true;
+                else { q_next = (long long) base; q_end = q_next + kFetchBatch < P.n_local ? q_next + kFetchBatch : P.n_local; }
+            }
+            const unsigned long long need = __ballot(ready && !busy);
+            if (need != 0ull && q_next < q_end) {
+                const int rank = __popcll(need & lt_mask);
+                const long long item = q_next + rank;
+                const int n_need = __popcll(need);
+                if (ready && !busy && item < q_end) {
+                    const long long chunk = (item >> 8) * P.shard_count + P.shard_rank;
+                    lane = P.begin + (chunk << 8) + (item & 255);
+                    if (lane < P.end) {
+                        busy = true; depth = -1; thr = V(R(1.f)); res = V(R(0.f));
+                        if (MODE == 0) {
+                            const long long k = T.spp > 1 ? lane / T.spp : lane;
+                            const int pix = P.pix_ids ? P.pix_ids[k] : (int) k;
+                            pix_slot = (int) k;
+                            rng.seed(P.seed + (P.pix_ids ? (unsigned long long) (long long) pix : (unsigned long long) lane), (unsigned long long) lane, P.skip);
+                            const float bx = (float) (pix % T.width), by = (float) (pix / T.width);
+                            const float jx = rng.next_1d(), jy = rng.next_1d();
+                            ext = sample_primary_ray<AD>(cam, (bx + jx) / (float) T.width, (by + jy) / (float) T.height);
+                        } else {
+                            rng.seed(P.seed + (unsigned long long) lane, (unsigned long long) lane, P.skip);
+                            float s = rng.next_1d(), pdf;
+                            const int ei = sample_reuse(cam.n_edges, cam.edge_sum, [&](int i) { return S.ldf(cam.pecdf_off, i); },
+                                                        [&](int i) { return S.ldf(cam.pecdf_off, cam.n_edges + i); }, s, pdf);
+                            const float4 r0 = S.ld(cam.pe_off + 3 * ei), r1 = S.ld(cam.pe_off + 3 * ei + 1), r2 = S.ld(cam.pe_off + 3 * ei + 2);
+                            pdf /= r2.z;
+                            const float nx = r2.x, ny = r2.y;
+                            const float oms = 1.0f - s;
+                            const Dual p0x(r0.x, r1.x), p0y(r0.y, r1.y), p1x(r0.z, r1.z), p1y(r0.w, r1.w);
+                            const Dual px = fma_(p0x, oms, p1x * s), py = fma_(p0y, oms, p1y * s);
+                            const Dual x_dot_n = fma_(py, ny, px * nx);
+                            const int ix = (int) floorf(px.v * (float) T.width), iy = (int) floorf(py.v * (float) T.height);
+                            edge_valid = ix >= 0 && ix < T.width && iy >= 0 && iy < T.height;
+                            pix_slot = edge_valid ? iy * T.width + ix : -1;
+                            const RayT<false> ray_n = sample_primary_ray<false>(cam, px.v - kEdgeEpsilon * nx, py.v - kEdgeEpsilon * ny);
+                            if constexpr (!AD) ext = ray_n;
+                            side = 0;
+                            edge_xdn_v = x_dot_n.v; edge_xdn_d = x_dot_n.d; edge_pdf = pdf; edge_s = s; edge_nx = nx; edge_ny = ny; edge_i = ei;
+                            if (!edge_valid) busy = false;
+                        }
+                    }
+                }
+                q_next += n_need < (int) (q_end - q_next) ? n_need : (q_end - q_next);
+            }
+            // ---------------------------------------------------------------- draw and post the rays of the lane's next vertex
+            if (ready && busy) {
+                const bool at_vertex = depth >= 0;
+                do_nee = false;
+                wod = V(R(0.f)); dist_sqr = R(0.f); dist = R(0.f);
+                if (at_vertex && P.mis != 1) {
+                    const float sx = rng.next_1d(), sy = rng.next_1d();
+                    do_nee = mesh_emitter(S, its.mesh) < 0;
+                    if (do_nee) {
+                        ps = sample_emitter_position<AD, LDS>(S, detach(its.p), sx, sy);
+                        wod = ps.p - its.p;
+                        dist_sqr = squared_norm(wod);
+                        dist = safe_sqrt(dist_sqr);
+                        wod = wod / dist;
+                    }
+                }
+                bs.wo = Vec3f(0.f, 0.f, 1.f); bs.pdf = 1.f; bs.valid = true;
+                const bool do_bsdf = at_vertex && P.mis != 0;
+                if (at_vertex && !do_bsdf) bs.valid = false;
+                if (do_bsdf) {
+                    const float s0 = rng.next_1d(), s1 = rng.next_1d(), s2 = rng.next_1d();
+                    bs = bsdf_sample<AD, LDS>(S, its, s0, s1, s2, true);
+                    ext.o = its.p; ext.d = to_world<AD>(its, bs.wo);
+                }
+                ext_traced = bs.valid;
+                const Vec3f oA = detach(its.p), dA = detach(wod), oB = detach(ext.o), dB = detach(ext.d);
+                park[0] = oA.x; park[kBlock] = oA.y; park[2 * kBlock] = oA.z; park[3 * kBlock] = dA.x; park[4 * kBlock] = dA.y; park[5 * kBlock] = dA.z;
+                park[6 * kBlock] = oB.x; park[7 * kBlock] = oB.y; park[8 * kBlock] = oB.z; park[9 * kBlock] = dB.x; park[10 * kBlock] = dB.y; park[11 * kBlock] = dB.z;
+                tr.reset();
+                tr.pending = (do_nee ? 1 : 0) | (ext_traced ? 2 : 0);
+                inflight = true;
+            }
+            if (__ballot(busy || inflight) == 0ull && exhausted && q_next >= q_end) break;
+        }
+        // -------------------------------------------------------------------- traversal: until enough lanes have finished
+        {
+            const int n_fly = __popcll(__ballot(inflight));
+            if (n_fly > 0) {
+                const int want_new = n_fly < 2 * kShadeMin ? (n_fly + 1) / 2 : kShadeMin;
+                trav4_run<LDS, COUNT>(S, tr, n_fly - want_new, [&](int k, Vec3f &o, Vec3f &d) {
+                    const float *q = park + (k == 0 ? 0 : 6 * kBlock);
+                    o = Vec3f(q[0], q[kBlock], q[2 * kBlock]); d = Vec3f(q[3 * kBlock], q[4 * kBlock], q[5 * kBlock]);
+                });
+                if (inflight && tr.idle()) { inflight = false; has_hits = true; }
+            }
+        }
+    }
+}
+
 } // namespace psdr

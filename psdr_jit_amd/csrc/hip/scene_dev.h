@@ -17,6 +17,7 @@ constexpr float kPi = 3.14159265358979323846f, kInvPi = 0.31830988618379067154f;
 constexpr float kTraceTMax = 100000000.f;   // reference scene_optix.cpp:376
 constexpr int kBlock = 256;
 constexpr int kBruteForceMax = 64;          // scenes with at most this many triangles skip the BVH
+constexpr int kParkWords = 12;              // LDS words per lane behind the traversal stack: the two parked rays of run_paths_async (paths.h)
 
 // EnvironmentMap after configure() (psdr_envmap_rec): too large for the LDS blob, read from global memory
 struct EnvDev {
@@ -47,7 +48,10 @@ struct SceneTables {
     // float4-word offsets into the blob
     int nodes_off, trav_off, shade_off, tan_off, map_off, mesh_off, bsdf_off, emit_off, ecdf_off, fcdf_off;
     int n_nodes, n_tris, n_meshes, n_bsdfs, n_emitters, n_fcdf;
-    int has_tangent, stack_depth;
+    int has_tangent, stack_depth;   // stack_depth: LDS rows (of kBlock words) reserved per workgroup behind the blob = traversal stack + parked rays
+    int stack_lds, ref_bits;        // 4-wide BVH (trav4.h): stack entries kept in LDS, bits of a child code
+    int *gstack;                    // deeper stack entries, [entry][lane of the grid] (NULL when stack_lds covers the tree)
+    int gstack_stride;
     int filt_off, n_filt;      // filter primitives of the brute-force tracer (4 words each, see filter.h)
     float center[3], radius;   // bounding sphere of all vertices
     int env_emitter;           // index of the EnvironmentMap among the emitters, -1 = none
@@ -210,85 +214,9 @@ PSDR_DEV Hit trace(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
     return h;
 }
 
-// BVH traversal of up to two rays per lane (scenes with more than kBruteForceMax triangles).
-// "while-while" (all lanes of the wave first walk inner nodes until each holds a leaf or is done, then all leaves are
-// intersected together; mixing both in one loop body made every iteration pay for up to four triangle tests even when a
-// single lane was at a leaf) with a per-lane ray queue: a lane that finishes its first ray starts its second one in the
-// next round instead of idling until the whole wave has finished the first pass (config 5 measured 13 % of the lanes
-// active per VALU instruction with one pass per ray).  Each ray sees the same nodes, tests and (t, id) order as alone.
+// 4-wide BVH traversal of up to two rays per lane (scenes with more than kBruteForceMax triangles): trav4.h
 template <int LDS, bool COUNT>
-PSDR_DEV void bvh_trace2(SceneView<LDS> &S, const Vec3f &oA, const Vec3f &dA, bool actA, const Vec3f &oB, const Vec3f &dB, bool actB,
-                         Hit &hA, Hit &hB) {
-    const SceneTables &T = *S.T;
-    constexpr int kDone = (int) 0x80000000;
-    hA.slot = -1; hA.u = hA.v = hA.t = 0.f;
-    hB.slot = -1; hB.u = hB.v = hB.t = 0.f;
-    int pending = (actA ? 1 : 0) | (actB ? 2 : 0);
-    int cur = -1, sp = 0, ref = kDone;
-    Vec3f o(0.f), d(0.f);
-    float ix = 0.f, iy = 0.f, iz = 0.f, best_t = 0.f;
-    int best_id = 0;
-    Hit best; best.slot = -1; best.u = best.v = best.t = 0.f;
-    for (;;) {
-        if (ref == kDone) {                                   // retire the finished ray, take the next one
-            if (cur == 0) hA = best; else if (cur == 1) hB = best;
-            cur = -1;
-            if (pending != 0) {
-                cur = (pending & 1) ? 0 : 1;
-                pending &= ~(1 << cur);
-                o = cur == 0 ? oA : oB; d = cur == 0 ? dA : dB;
-                best.slot = -1; best.u = best.v = best.t = 0.f;
-                best_t = __builtin_inff(); best_id = 0x7fffffff;
-                sp = 0;
-                // NaN rays miss (reference scene_optix.cpp:348-353)
-                const bool ok = (o.x == o.x && o.y == o.y && o.z == o.z && d.x == d.x && d.y == d.y && d.z == d.z);
-                ref = ok ? 0 : kDone;
-                ix = 1.f / d.x; iy = 1.f / d.y; iz = 1.f / d.z;
-                if (COUNT) { if (ok) S.c_rays++; }
-            }
-        }
-        if (__ballot(ref != kDone || cur >= 0) == 0ull) break;
-        while (ref >= 0) {
-            const int w = T.nodes_off + 4 * ref;
-            const float4 q0 = S.ld(w), q1 = S.ld(w + 1), q2 = S.ld(w + 2), q3 = S.ld(w + 3);
-            if (COUNT) S.c_nodes++;
-            // slab tests; fminf/fmaxf drop NaNs (0 * inf), which keeps the test conservative
-            float t0, t1, tnL = 0.f, tfL = best_t, tnR = 0.f, tfR = best_t;
-            t0 = (q0.x - o.x) * ix; t1 = (q1.x - o.x) * ix; tnL = fmaxf(tnL, fminf(t0, t1)); tfL = fminf(tfL, fmaxf(t0, t1) * 1.0000004f);
-            t0 = (q0.y - o.y) * iy; t1 = (q1.y - o.y) * iy; tnL = fmaxf(tnL, fminf(t0, t1)); tfL = fminf(tfL, fmaxf(t0, t1) * 1.0000004f);
-            t0 = (q0.z - o.z) * iz; t1 = (q1.z - o.z) * iz; tnL = fmaxf(tnL, fminf(t0, t1)); tfL = fminf(tfL, fmaxf(t0, t1) * 1.0000004f);
-            t0 = (q2.x - o.x) * ix; t1 = (q3.x - o.x) * ix; tnR = fmaxf(tnR, fminf(t0, t1)); tfR = fminf(tfR, fmaxf(t0, t1) * 1.0000004f);
-            t0 = (q2.y - o.y) * iy; t1 = (q3.y - o.y) * iy; tnR = fmaxf(tnR, fminf(t0, t1)); tfR = fminf(tfR, fmaxf(t0, t1) * 1.0000004f);
-            t0 = (q2.z - o.z) * iz; t1 = (q3.z - o.z) * iz; tnR = fmaxf(tnR, fminf(t0, t1)); tfR = fminf(tfR, fmaxf(t0, t1) * 1.0000004f);
-            const bool hL = tnL <= tfL, hR = tnR <= tfR;
-            const int rL = __float_as_int(q0.w), rR = __float_as_int(q1.w);
-            if (hL && hR) {
-                const bool left_first = tnL <= tnR;
-                S.stack[sp * kBlock] = left_first ? rR : rL;
-                ++sp;
-                ref = left_first ? rL : rR;
-            } else if (hL) ref = rL;
-            else if (hR) ref = rR;
-            else if (sp == 0) ref = kDone;
-            else { --sp; ref = S.stack[sp * kBlock]; }
-        }
-        if (ref != kDone) {
-            const int code = ~ref, first = code >> 2, cnt = (code & 3) + 1;
-            for (int k = 0; k < cnt; ++k) {
-                const int w = T.trav_off + 3 * (first + k);
-                const float4 a = S.ld(w), b = S.ld(w + 1), c = S.ld(w + 2);
-                float u, v, t;
-                if (COUNT) S.c_tris++;
-                if (tri_test(a, b, c, o, d, u, v, t)) {
-                    const int id = __float_as_int(c.y);
-                    if (t < best_t || (t == best_t && id < best_id)) { best_t = t; best_id = id; best.slot = first + k; best.u = u; best.v = v; best.t = t; }
-                }
-            }
-            if (sp == 0) ref = kDone;
-            else { --sp; ref = S.stack[sp * kBlock]; }
-        }
-    }
-}
+PSDR_DEV void bvh4_trace2(SceneView<LDS> &S, const Vec3f &oA, const Vec3f &dA, bool actA, const Vec3f &oB, const Vec3f &dB, bool actB, Hit &hA, Hit &hB);
 
 template <int LDS, bool COUNT>
 PSDR_DEV Hit trace_scene(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
@@ -351,7 +279,7 @@ PSDR_DEV Hit trace_scene(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
         return best;
     }
     Hit other;
-    bvh_trace2<LDS, COUNT>(S, o, d, true, o, d, false, best, other);
+    bvh4_trace2<LDS, COUNT>(S, o, d, true, o, d, false, best, other);
     return best;
 }
 
@@ -371,7 +299,7 @@ PSDR_DEV void trace2(SceneView<LDS> &S, const Vec3f &oA_, const Vec3f &dA, bool 
         if (actB) hB = trace<LDS, COUNT>(S, oB_, dB);
         return;
     }
-    if (T.n_tris > kBruteForceMax) { bvh_trace2<LDS, COUNT>(S, oA_, dA, actA, oB_, dB, actB, hA, hB); return; }
+    if (T.n_tris > kBruteForceMax) { bvh4_trace2<LDS, COUNT>(S, oA_, dA, actA, oB_, dB, actB, hA, hB); return; }
     const float qnan = __builtin_nanf("");
     const Vec3f oA = actA ? oA_ : Vec3f(qnan), oB = actB ? oB_ : Vec3f(qnan);
     if (COUNT) { const unsigned n = (actA ? 1u : 0u) + (actB ? 1u : 0u); S.c_rays += n; S.c_tris += n * (unsigned) T.n_tris; }
@@ -468,3 +396,5 @@ PSDR_DEV void trace2(SceneView<LDS> &S, const Vec3f &oA_, const Vec3f &dA, bool 
 }
 
 } // namespace psdr
+
+#include "trav4.h"

@@ -78,7 +78,7 @@ def test_config3_full_size_shard(env, orc):
 
 def test_config2_full_size_rows(env, orc):
     """512 x 512, spp 32, PathTracer(3) renderC at full size; the oracle renders the lanes of pixel rows 200-207 (131 072 lanes,
-    a contiguous lane range of its C-mode renderer) and a second band at the bottom of the frame"""
+    a contiguous lane range of its C-mode renderer) and a second band lower in the frame"""
     torch, _, cabi = env
     spec = scenes.cbox_scene(512, 512, 32, 0, 0, param=None)
     sc = product.build_scene(spec)
@@ -88,7 +88,7 @@ def test_config2_full_size_rows(env, orc):
     cabi.check(cabi.lib().psdr_hip_render_c(sc._hip_handle(), C.byref(a), out.data_ptr(), None))
     got = out.cpu().numpy()
     assert np.isfinite(got).all()
-    for r0, r1 in ((200, 208), (500, 512)):
+    for r0, r1 in ((200, 208), (300, 306)):
         want = ref.render_c(max_depth=3, seed=3, lane_begin=r0 * 512 * 32, lane_end=r1 * 512 * 32)
         assert np.abs(want[r0 * 512:r1 * 512]).max() > 0
         assert product.rel_l2(got[r0 * 512:r1 * 512], want[r0 * 512:r1 * 512]) < TOL
