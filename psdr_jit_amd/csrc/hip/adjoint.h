@@ -24,6 +24,8 @@ inline __host__ __device__ int adj_ext_words(int depth) { return 2 * depth > 2 ?
 inline __host__ __device__ int adj_lk_entries(int depth) { return 4 * depth + 4; }
 // LDS words per lane of the interior adjoint kernel: scenes without bitmap / per-vertex parameters and without an environment map
 // make no lookups, carry no lookup record and keep more workgroups per CU (AdjointParams::lk_words)
+// the reverse sweep keeps, per lane: 3 words per vertex (slot, u, v) and 11 per bounce (light sample, shadow hit, constants, throughput)
+inline __host__ __device__ int adj_sweep_words(int depth) { return 3 * (depth + 1) + 11 * (depth > 0 ? depth : 1); }
 inline __host__ __device__ int adj_lane_words(int depth, bool with_lookups) { return adj_hit_words(depth) + adj_ext_words(depth) + (with_lookups ? 3 * adj_lk_entries(depth) : 0); }
 // the secondary-edge adjoint records three hits per lane, followed by 16 floats of camera-pose accumulators
 constexpr int kSecAdjLaneWords = 12;
@@ -57,6 +59,7 @@ struct AdjointParams {
     float *g_env_xf;                // [16] adjoint of the environment map's from_world (rows 0-2, columns 0-2 filled), or NULL
     int hit_words, ext_words, lk_words;   // sizes of the three per-lane records (lk_words = 0 when the scene cannot make lookups)
     float *g_mat;                   // [n_bsdfs*16] adjoints of the constant parameters of the GGX BSDFs (psdr_grads.g_mat), or NULL
+    int sweep;                      // 1: run_interior_adjoint_sweep (Diffuse BSDFs + area lights), 0: record and probe
 };
 
 constexpr int kMatRow = 16;
@@ -348,6 +351,390 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
         for (int i = threadIdx.x; i < T.n_bsdfs * 3; i += kBlock) if (acc_bsdf[i] != 0.f) atomicAdd(&P.g_bsdf[i], acc_bsdf[i]);
         for (int i = threadIdx.x; i < T.n_emitters * 3; i += kBlock) if (acc_emit[i] != 0.f) atomicAdd(&P.g_emitter[i], acc_emit[i]);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Reverse sweep of the interior term for scenes of Diffuse BSDFs and area lights (scene classes 1 and 2 without an environment
+// map, PathTracer) - what `drjit.backward` does through integrator.cpp:51-100 + path.cpp:35-127 - in ONE pass back over the
+// path instead of one replay per touched scene quantity.
+//
+// In D mode the radiance of a path is
+//     L = Le_0 + sum_k [ thr_k rho_k Le_hk cN_k s_Nk  +  thr_{k+1} Le_{k+1} w2_k ],     thr_{k+1} = thr_k rho_k cf_k s_fk,  thr_0 = 1
+// with rho_k the reflectance at vertex k, Le the radiance of the emitter that was hit, cN / cf / w2 DETACHED pdfs and MIS
+// weights, and both s_Nk (next-event term) and s_fk (BSDF-sampling term) of one geometric form
+//     s(x, ns; z, nz, A_z) = (w . ns) |nz . w| / r^2 . (A_z / detach(A_z)),     w = (z - x) / r,  r = |z - x|
+// x the shading point with shading normal ns; z the light sample (nz = geometric normal of the triangle the shadow ray hits)
+// resp. the next vertex.  Every vertex is glued to its triangle at fixed barycentrics (x = p0 + u e1 + v e2) except the camera
+// hit, which slides along the fixed ray (x_0 = o + t d, (u, v, t) the differentiable Moeller-Trumbore solution).
+// Pass 1 walks the path forward (the primal arithmetic of D mode) and keeps (slot, u, v) per vertex and, per bounce, the light
+// sample, the constants and thr_k; pass 2 walks back with A = d(w . L) / d thr_{k+1}, and emits per bounce the adjoints of
+// x_k, ns_k, z, nz, A_z in closed form (`seg_eval`), of rho_k and of the emitter radiance, scattered into the 22-float
+// triangle rows [p0 e1 e2 n0 n1 n2 fn area] and the colour rows that the host chains to its leaves (chain.py).
+// Cost: two shading passes and one traversal per path, whatever the number of leaves - the probe form replays the path once
+// per (touched triangle x 13 + 3) components.  The forward-mode kernels stay the checker: <w, J v> = <J^T w, v>
+// (tests/test_gpu_adjoint.py).
+struct SegGrad { Vec3f dx, dns, dz, dnz; float dA; };      // d s / d (x, ns, z, nz, A_z)
+
+// s and its gradient; sgn = -1 when a two-sided BSDF is seen from its back
+PSDR_DEV float seg_eval(const Vec3f &x, const Vec3f &ns, float sgn, const Vec3f &z, const Vec3f &nz, float area_z, SegGrad &g) {
+    const Vec3f v = z - x;
+    const float r2 = dot(v, v);
+    g.dx = g.dns = g.dz = g.dnz = Vec3f(0.f); g.dA = 0.f;
+    if (!(r2 > 0.f)) return 0.f;
+    const float ir2 = 1.f / r2, k = ir2 * ir2;
+    const float Pn = dot(v, ns) * sgn, Qs = dot(nz, v), sq = Qs < 0.f ? -1.f : 1.f, Q = Qs * sq;
+    const float s = Pn * Q * k;                                          // (w.ns) |nz.w| / r^2 = (v.ns)(|nz.v|) / r^4
+    g.dns = v * (sgn * Q * k);
+    g.dnz = v * (sq * Pn * k);
+    g.dz = (ns * (sgn * Q) + nz * (sq * Pn)) * k - v * (4.f * s * ir2);
+    g.dx = -g.dz;
+    g.dA = area_z > 0.f ? s / area_z : 0.f;
+    return s;
+}
+
+// adjoint of the Moeller-Trumbore solve (ray_tri_uvt): (ub, vb, tb) -> the triangle and the ray
+PSDR_DEV void mt_adjoint(const Vec3f &p0, const Vec3f &e1, const Vec3f &e2, const Vec3f &o, const Vec3f &d, float ub, float vb, float tb,
+                         Vec3f &p0b, Vec3f &e1b, Vec3f &e2b, Vec3f &ob, Vec3f &db) {
+    const Vec3f h = cross(d, e2);
+    const float a = dot(e1, h), f = 1.f / a;
+    const Vec3f s = o - p0, q = cross(s, e1);
+    const float U = dot(s, h), V = dot(d, q), Wq = dot(e2, q);
+    const float fb = ub * U + vb * V + tb * Wq, Ub = f * ub, Vb = f * vb, Wb = f * tb, ab = -f * f * fb;
+    Vec3f sb = h * Ub, hb = s * Ub;
+    db = q * Vb;
+    Vec3f qb = d * Vb + e2 * Wb;
+    e2b = q * Wb;
+    e1b = h * ab; hb = hb + e1 * ab;
+    sb = sb + cross(e1, qb); e1b = e1b + cross(qb, s);                   // q = s x e1
+    db = db + cross(e2, hb); e2b = e2b + cross(hb, d);                   // h = d x e2
+    ob = sb; p0b = -sb;
+}
+
+// geometry of one triangle slot at barycentrics (u, v)
+struct VtxGeom {
+    Vec3f p0, e1, e2, n0, n1, n2, fn, nb, ns, x;
+    float area, nbl, u, v;
+    int orig, mesh;
+    bool flat;
+};
+template <int LDS> PSDR_DEV VtxGeom load_vertex(const SceneView<LDS> &S, int slot, float u, float v) {
+    VtxGeom g;
+    load_geom<false, LDS>(S, slot, g.p0, g.e1, g.e2);
+    const int w = S.T->shade_off + 6 * slot;
+    const float4 s0 = S.ld(w), s1 = S.ld(w + 1), s2 = S.ld(w + 2), s3 = S.ld(w + 3);
+    g.n0 = Vec3f(s0.x, s0.y, s0.z); g.n1 = Vec3f(s1.x, s1.y, s1.z); g.n2 = Vec3f(s2.x, s2.y, s2.z); g.fn = Vec3f(s3.x, s3.y, s3.z);
+    g.area = s0.w; g.mesh = __float_as_int(s1.w); g.flat = (__float_as_int(s2.w) & 1) != 0; g.orig = __float_as_int(s3.w);
+    g.u = u; g.v = v;
+    g.x = madd3(g.e1, u, g.e2, v, g.p0);
+    g.nb = madd3(g.n1 - g.n0, u, g.n2 - g.n0, v, g.n0);
+    g.nbl = norm(g.nb);
+    g.ns = g.flat ? g.fn : g.nb / g.nbl;
+    return g;
+}
+
+template <int LDS>
+PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam, const AdjointParams &P, float *scratch) {
+    const SceneTables &T = *S.T;
+    const int lane_id = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane_id) - 1ull;
+    const float inv_spp = T.spp > 1 ? 1.f / (float) T.spp : 1.f;
+    const int D = P.max_depth;
+    float *vrec = scratch + threadIdx.x;                                  // [3 * (D + 1)] slot, u, v per vertex, stride kBlock
+    float *brec = vrec + 3 * (D + 1) * kBlock;                            // [11 * D] per bounce: 0 light slot, 1-2 its barycentrics, 3 shadow-hit slot,
+                                                                          //   4 cN, 5 cf, 6 w2, 7 flags, 8-10 thr_k
+    const int lane_words = P.hit_words + P.ext_words + P.lk_words;        // sized by the launch: >= adj_sweep_words(D)
+    float *acc_cam = scratch + lane_words * kBlock;                       // same accumulator layout as run_interior_adjoint
+    float *acc_mat = acc_cam + kAdjMisc;
+    float *acc = acc_mat + T.n_bsdfs * kMatRow;
+    const int n_acc = P.n_hot * 22 + T.n_bsdfs * 3 + T.n_emitters * 3;
+    for (int i = threadIdx.x; i < n_acc; i += kBlock) acc[i] = 0.f;
+    float *acc_bsdf = acc + P.n_hot * 22, *acc_emit = acc_bsdf + T.n_bsdfs * 3;
+    if (threadIdx.x < kAdjMisc) acc_cam[threadIdx.x] = 0.f;
+    __syncthreads();
+    S.mode = 0; S.probe_kind = 0;
+
+    auto add_row = [&](const VtxGeom &g, int comp, float val) {
+        if (val == 0.f || !finite_(val)) return;
+        const int hot = P.hot_map[g.orig];
+        if (hot >= 0 && hot < P.n_hot) atomicAdd(&acc[hot * 22 + comp], val); else atomicAdd(&P.g_tri[g.orig * 22 + comp], val);
+    };
+    auto add_vec = [&](const VtxGeom &g, int comp, const Vec3f &val) { add_row(g, comp, val.x); add_row(g, comp + 1, val.y); add_row(g, comp + 2, val.z); };
+    auto wanted = [&](const VtxGeom &g) { return P.mesh_filter == nullptr || P.mesh_filter[g.mesh] != 0; };
+    auto add_rgb = [&](float *tab, int id, const Vec3f &val) {
+        if (val.x != 0.f && finite_(val.x)) atomicAdd(&tab[3 * id], val.x);
+        if (val.y != 0.f && finite_(val.y)) atomicAdd(&tab[3 * id + 1], val.y);
+        if (val.z != 0.f && finite_(val.z)) atomicAdd(&tab[3 * id + 2], val.z);
+    };
+    // the normal blend n0 (1 - u - v) + n1 u + n2 v behind a shading normal: its adjoint from the adjoint of ns
+    auto blend_adjoint = [&](const VtxGeom &g, const Vec3f &nsb) { return (nsb - g.ns * dot(g.ns, nsb)) / g.nbl; };
+    // adjoints of a vertex glued to its triangle: position, shading normal, geometric normal, area
+    auto emit_glued = [&](const VtxGeom &g, const Vec3f &xb, const Vec3f &nsb, const Vec3f &ngb, float ab) {
+        if (!wanted(g)) return;
+        add_vec(g, 0, xb); add_vec(g, 3, xb * g.u); add_vec(g, 6, xb * g.v);
+        Vec3f fnb = ngb;
+        if (g.flat) fnb = fnb + nsb;
+        else {
+            const Vec3f nbb = blend_adjoint(g, nsb);
+            add_vec(g, 9, nbb * (1.f - g.u - g.v)); add_vec(g, 12, nbb * g.u); add_vec(g, 15, nbb * g.v);
+        }
+        add_vec(g, 18, fnb);
+        add_row(g, 21, ab);
+    };
+
+    long long q_next = 0, q_end = 0;
+    bool exhausted = false;
+    bool have = false;
+    long long lane = 0;
+    for (;;) {
+        // ---- phase 1: find samples whose camera ray hits the scene (as in run_interior_adjoint)
+        for (int round = 0; round < 8; ++round) {
+            const unsigned long long need = __ballot(!have);
+            if (__popcll(need) <= 6) break;
+            if (q_next >= q_end && !exhausted) {
+                unsigned long long base = 0;
+                if (lane_id == 0) base = atomicAdd(P.counter, (unsigned long long) kFetchBatch);
+                base = __shfl(base, 0);
+                if ((long long) base >= P.n_local) exhausted = true;
+                else { q_next = (long long) base; q_end = q_next + kFetchBatch < P.n_local ? q_next + kFetchBatch : P.n_local; }
+            }
+            if (q_next >= q_end) break;
+            const int rank = __popcll(need & lt_mask);
+            const long long item = q_next + rank;
+            Vec3f o(0.f), d(0.f);
+            bool cand = false;
+            if (!have && item < q_end) {
+                const long long chunk = (item >> 8) * P.shard_count + P.shard_rank;
+                lane = P.begin + (chunk << 8) + (item & 255);
+                if (lane < P.end) {
+                    const long long k = T.spp > 1 ? lane / T.spp : lane;
+                    const int pix = P.pix_ids ? P.pix_ids[k] : (int) k;
+                    LaneRng rng;
+                    rng.seed(P.seed + (P.pix_ids ? (unsigned long long) (long long) pix : (unsigned long long) lane), (unsigned long long) lane, P.skip);
+                    const float bx = (float) (pix % T.width), by = (float) (pix / T.width);
+                    const float jx = rng.next_1d(), jy = rng.next_1d();
+                    const RayT<false> r = sample_primary_ray<false>(cam, (bx + jx) / (float) T.width, (by + jy) / (float) T.height);
+                    o = r.o; d = r.d; cand = true;
+                }
+            }
+            Hit h; h.slot = -1;
+            if (cand) h = trace<LDS, false>(S, o, d);
+            if (cand && h.slot >= 0) { have = true; vrec[0] = __int_as_float(h.slot); }
+            const int n_need = __popcll(need);
+            q_next += n_need < (int) (q_end - q_next) ? n_need : (q_end - q_next);
+        }
+        if (__ballot(have) == 0ull) { if (exhausted && q_next >= q_end) break; continue; }
+
+        if (have) {
+            const long long kpix = T.spp > 1 ? lane / T.spp : lane;
+            const int pix = P.pix_ids ? P.pix_ids[kpix] : (int) kpix;
+            LaneRng rng;
+            rng.seed(P.seed + (P.pix_ids ? (unsigned long long) (long long) pix : (unsigned long long) lane), (unsigned long long) lane, P.skip);
+            const float bx = (float) (pix % T.width), by = (float) (pix / T.width);
+            const float jx = rng.next_1d(), jy = rng.next_1d();
+            const float sx = (bx + jx) / (float) T.width, sy = (by + jy) / (float) T.height;
+            const RayT<false> ray = sample_primary_ray<false>(cam, sx, sy);
+            float wgt[3] = {P.w[3 * kpix] * inv_spp, P.w[3 * kpix + 1] * inv_spp, P.w[3 * kpix + 2] * inv_spp};
+
+            // ------------------------------------------------------------ pass 1: forward, the primal arithmetic of D mode
+            const int slot0 = __float_as_int(vrec[0]);
+            float u0, v0, t0;
+            {
+                Vec3f a0, b0, c0;
+                load_geom<false, LDS>(S, slot0, a0, b0, c0);
+                ray_tri_uvt<float>(a0, b0, c0, ray.o, ray.d, u0, v0, t0);
+            }
+            vrec[kBlock] = u0; vrec[2 * kBlock] = v0;
+            const Vec3f x0(fmaf(ray.d.x, t0, ray.o.x), fmaf(ray.d.y, t0, ray.o.y), fmaf(ray.d.z, t0, ray.o.z));     // the camera hit slides along the ray
+            Hit hh; hh.slot = slot0; hh.u = u0; hh.v = v0; hh.t = t0;
+            Its<false> its = make_its<false, LDS, true>(S, hh, ray, false);
+            its.p = x0; its.t = t0;
+            its.wi = to_local<false>(its, -ray.d);
+            Vec3f thr(1.f), Lsum(0.f);
+            const int e0 = mesh_emitter(S, its.mesh);
+            const bool le0 = !P.hide_emitters && e0 >= 0 && its.wi.z > 0.f;
+            if (le0) { const float4 a = S.ld(T.emit_off + 2 * e0); Lsum = Vec3f(a.x, a.y, a.z); }
+            int nb = 0;                                                   // bounces recorded
+            bool active = true;
+            for (int depth = 0; depth < D && active; ++depth) {
+                float *br = brec + 11 * depth * kBlock;
+                br[8 * kBlock] = thr.x; br[9 * kBlock] = thr.y; br[10 * kBlock] = thr.z;
+                nb = depth + 1;
+                int flags = 0;              // 1 next-event term, 2 BSDF term, 4 back side of a two-sided BSDF, 8 the next vertex is a visible emitter
+                const int bid = mesh_bsdf(S, its.mesh);
+                const float4 ba = bid >= 0 ? S.ld(T.bsdf_off + 2 * bid) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const Vec3f rho(ba.x, ba.y, ba.z);
+                const bool two = bid >= 0 && (__float_as_int(ba.w) & 1) != 0;
+                const float sgn = (two && its.wi.z < 0.f) ? -1.f : 1.f;
+                if (sgn < 0.f) flags |= 4;
+                const bool front = bid >= 0 && (two ? fabsf(its.wi.z) : its.wi.z) > 0.f;
+                {   // next-event estimation (path.cpp:47-83)
+                    const float s1 = rng.next_1d(), s2 = rng.next_1d();
+                    if (mesh_emitter(S, its.mesh) < 0) {
+                        const PositionSample<false> ps = sample_emitter_position<false, LDS>(S, its.p, s1, s2);
+                        Vec3f wod = ps.p - its.p;
+                        const float dist_sqr = squared_norm(wod), dist = safe_sqrt(dist_sqr);
+                        wod = wod / dist;
+                        const Hit h1 = trace<LDS, false>(S, its.p, wod);
+                        if (h1.slot >= 0) {
+                            RayT<false> ray1; ray1.o = its.p; ray1.d = wod;
+                            const Its<false> its1 = make_its<false, LDS, false>(S, h1, ray1, true);
+                            const int eh = mesh_emitter(S, its1.mesh);
+                            if (its1.t > dist - kShadowEpsilon && eh >= 0) {
+                                const float G = fabsf(dot(its1.n, -wod)) / dist_sqr;
+                                const float woz = dot(wod, its.fn) * sgn;
+                                const float pdf1 = ((front && woz > 0.f) ? kInvPi * woz : 0.f) * G;
+                                if (front && woz > 0.f && pdf1 != 0.f) {
+                                    const float cN = kInvPi * mis_weight(ps.pdf, pdf1) / ps.pdf;
+                                    if (its1.wi.z > 0.f) {
+                                        const float4 ea = S.ld(T.emit_off + 2 * eh);
+                                        Lsum = Lsum + thr * rho * Vec3f(ea.x, ea.y, ea.z) * (woz * G * cN);
+                                        br[0] = __int_as_float(ps.slot); br[kBlock] = ps.ba; br[2 * kBlock] = ps.bb; br[3 * kBlock] = __int_as_float(h1.slot);
+                                        br[4 * kBlock] = cN;
+                                        flags |= 1;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                {   // BSDF sampling (path.cpp:86-123)
+                    const float s0 = rng.next_1d(), s1 = rng.next_1d(), s2 = rng.next_1d();
+                    const BSDFSample bs = bsdf_sample<false, LDS>(S, its, s0, s1, s2, true);
+                    Hit hx; hx.slot = -1;
+                    RayT<false> curr; curr.o = its.p; curr.d = to_world<false>(its, bs.wo);
+                    if (bs.valid) hx = trace<LDS, false>(S, curr.o, curr.d);
+                    active = bs.valid && hx.slot >= 0;
+                    if (active) {
+                        const Its<false> itx = make_its<false, LDS, true>(S, hx, curr, true);
+                        float *vr = vrec + 3 * (depth + 1) * kBlock;
+                        vr[0] = __int_as_float(hx.slot); vr[kBlock] = hx.u; vr[2 * kBlock] = hx.v;
+                        const Vec3f wo = (itx.p - its.p) / itx.t;
+                        const float G = fabsf(dot(itx.n, -wo)) / sqr(itx.t);
+                        const float pdf0 = bs.pdf * G;
+                        const float woz = dot(wo, its.fn) * sgn;
+                        const bool ok = !(itx.t < kEpsilon) && front && woz > 0.f;
+                        const float cf = ok ? kInvPi / pdf0 : 0.f;
+                        const float w2 = mis_weight(pdf0, emitter_position_pdf<false, LDS>(S, its.p, itx));
+                        thr = ok ? thr * rho * (woz * G * cf) : Vec3f(0.f);
+                        const int ex = mesh_emitter(S, itx.mesh);
+                        if (ex >= 0 && itx.wi.z > 0.f) { const float4 ea = S.ld(T.emit_off + 2 * ex); Lsum = Lsum + Vec3f(ea.x, ea.y, ea.z) * thr * w2; flags |= 8; }
+                        br[5 * kBlock] = cf; br[6 * kBlock] = w2;
+                        flags |= 2;
+                        its = itx;
+                    }
+                }
+                br[7 * kBlock] = __int_as_float(flags);
+            }
+            {   // integrator.cpp:126: a non-finite channel contributes nothing
+                const float pv[3] = {Lsum.x, Lsum.y, Lsum.z};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) if (!finite_(pv[c])) wgt[c] = 0.f;
+            }
+            const Vec3f W(wgt[0], wgt[1], wgt[2]);
+
+            // ------------------------------------------------------------ pass 2: back over the bounces
+            if (W.x != 0.f || W.y != 0.f || W.z != 0.f) {
+                if (le0 && !P.skip_emitter) add_rgb(acc_emit, e0, W);          // the emitter seen by the camera
+                Vec3f Abar(0.f);                       // d (w.L) / d thr_{k+1} from the bounces behind k
+                Vec3f xb_next(0.f), nsb_next(0.f);     // what bounce k+1 gave vertex k+1 as ITS shading point
+                Vec3f xb0(0.f), nsb0(0.f);             // the camera hit's totals
+                for (int k = nb - 1; k >= 0; --k) {
+                    const float *br = brec + 11 * k * kBlock;
+                    const int flags = __float_as_int(br[7 * kBlock]);
+                    const Vec3f thr_k(br[8 * kBlock], br[9 * kBlock], br[10 * kBlock]);
+                    const float sgn = (flags & 4) ? -1.f : 1.f;
+                    const float *vr = vrec + 3 * k * kBlock;
+                    VtxGeom gk = load_vertex(S, __float_as_int(vr[0]), vr[kBlock], vr[2 * kBlock]);
+                    if (k == 0) gk.x = x0;
+                    const int bid = mesh_bsdf(S, gk.mesh);
+                    const float4 ba = bid >= 0 ? S.ld(T.bsdf_off + 2 * bid) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const Vec3f rho(ba.x, ba.y, ba.z);
+                    Vec3f xb(0.f), nsb(0.f), rhob(0.f), A_k(0.f);
+                    SegGrad sg;
+                    if (flags & 2) {
+                        // thr_{k+1} = thr_k rho cf s_f,  L += thr_{k+1} Le_{k+1} w2
+                        const float *vn = vrec + 3 * (k + 1) * kBlock;
+                        const VtxGeom gz = load_vertex(S, __float_as_int(vn[0]), vn[kBlock], vn[2 * kBlock]);
+                        const float cf = br[5 * kBlock], w2 = br[6 * kBlock];
+                        const float sf = seg_eval(gk.x, gk.ns, sgn, gz.x, gz.fn, gz.area, sg) * cf;
+                        Vec3f At = Abar;                                             // total adjoint of thr_{k+1}
+                        if (flags & 8) {
+                            const int ex = mesh_emitter(S, gz.mesh);
+                            const float4 ea = S.ld(T.emit_off + 2 * ex);
+                            At = At + W * Vec3f(ea.x, ea.y, ea.z) * w2;
+                            if (!P.skip_emitter) add_rgb(acc_emit, ex, W * thr_k * rho * (sf * w2));
+                        }
+                        const float sb = cf * (thr_k.x * rho.x * At.x + thr_k.y * rho.y * At.y + thr_k.z * rho.z * At.z);
+                        rhob = rhob + thr_k * At * sf;
+                        A_k = A_k + rho * At * sf;
+                        xb = xb + sg.dx * sb; nsb = nsb + sg.dns * sb;
+                        // vertex k+1 is complete: end point of this segment + shading point of bounce k+1
+                        emit_glued(gz, xb_next + sg.dz * sb, nsb_next, sg.dnz * sb, sg.dA * sb);
+                    }
+                    if (flags & 1) {
+                        // L += thr_k rho Le_h cN s_N
+                        const VtxGeom gy = load_vertex(S, __float_as_int(br[0]), br[kBlock], br[2 * kBlock]);
+                        const VtxGeom gh = load_vertex(S, __float_as_int(br[3 * kBlock]), 0.f, 0.f);
+                        const float cN = br[4 * kBlock];
+                        const float sN = seg_eval(gk.x, gk.ns, sgn, gy.x, gh.fn, gy.area, sg) * cN;
+                        const int eh = mesh_emitter(S, gh.mesh);
+                        const float4 ea = S.ld(T.emit_off + 2 * eh);
+                        const Vec3f Le(ea.x, ea.y, ea.z);
+                        const Vec3f al = W * thr_k * rho * Le;
+                        const float sb = cN * (al.x + al.y + al.z);
+                        rhob = rhob + W * thr_k * Le * sN;
+                        A_k = A_k + W * rho * Le * sN;
+                        if (!P.skip_emitter) add_rgb(acc_emit, eh, W * thr_k * rho * sN);
+                        xb = xb + sg.dx * sb; nsb = nsb + sg.dns * sb;
+                        emit_glued(gy, sg.dz * sb, Vec3f(0.f), Vec3f(0.f), sg.dA * sb);       // the light sample: position and area of ITS triangle
+                        emit_glued(gh, Vec3f(0.f), Vec3f(0.f), sg.dnz * sb, 0.f);             // the normal of the triangle the shadow ray hit
+                    }
+                    if (bid >= 0 && !P.skip_bsdf) add_rgb(acc_bsdf, bid, rhob);
+                    xb_next = xb; nsb_next = nsb;
+                    Abar = A_k;
+                    if (k == 0) { xb0 = xb; nsb0 = nsb; }
+                }
+                // the camera hit: x_0 = o + t d and ns_0 = normalize(blend(u, v)) with (u, v, t) = Moeller-Trumbore(p0, e1, e2; o, d)
+                if (nb > 0) {
+                    const VtxGeom g0 = load_vertex(S, slot0, u0, v0);
+                    float ub = 0.f, vb = 0.f;
+                    const float tb = dot(ray.d, xb0);
+                    Vec3f ob = xb0, db = xb0 * t0;
+                    const bool want0 = wanted(g0);
+                    if (g0.flat) { if (want0) add_vec(g0, 18, nsb0); }
+                    else {
+                        const Vec3f nbb = blend_adjoint(g0, nsb0);
+                        ub = dot(g0.n1 - g0.n0, nbb); vb = dot(g0.n2 - g0.n0, nbb);
+                        if (want0) { add_vec(g0, 9, nbb * (1.f - u0 - v0)); add_vec(g0, 12, nbb * u0); add_vec(g0, 15, nbb * v0); }
+                    }
+                    Vec3f p0b, e1b, e2b, ob2, db2;
+                    mt_adjoint(g0.p0, g0.e1, g0.e2, ray.o, ray.d, ub, vb, tb, p0b, e1b, e2b, ob2, db2);
+                    if (want0) { add_vec(g0, 0, p0b); add_vec(g0, 3, e1b); add_vec(g0, 6, e2b); }
+                    if (P.g_cam != nullptr) {
+                        // o = to_world . (o_cam, 1), d = to_world . (d_cam, 0)  (primary_ray_pose_tangent)
+                        ob = ob + ob2; db = db + db2;
+                        const Vec3f pc = xform_pos(cam.sample_to_camera, Vec3f(sx, sy, 0.f));
+                        const Vec3f o_cam = cam.ortho ? pc : Vec3f(0.f), d_cam = cam.ortho ? Vec3f(0.f, 0.f, 1.f) : normalize(pc);
+                        const float oc[4] = {o_cam.x, o_cam.y, o_cam.z, 1.f}, dc[4] = {d_cam.x, d_cam.y, d_cam.z, 0.f};
+                        const float obv[3] = {ob.x, ob.y, ob.z}, dbv[3] = {db.x, db.y, db.z};
+#pragma unroll
+                        for (int r = 0; r < 3; ++r)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const float val = obv[r] * oc[c] + dbv[r] * dc[c];
+                                if (val != 0.f && finite_(val)) atomicAdd(&acc_cam[4 * r + c], val);
+                            }
+                    }
+                }
+            }
+            have = false;
+        }
+    }
+    __syncthreads();
+    if (P.g_cam != nullptr && threadIdx.x < 12 && acc_cam[threadIdx.x] != 0.f) atomicAdd(&P.g_cam[threadIdx.x], acc_cam[threadIdx.x]);
+    for (int i = threadIdx.x; i < P.n_hot * 22; i += kBlock) if (acc[i] != 0.f) atomicAdd(&P.g_tri[P.hot_inv[i / 22] * 22 + i % 22], acc[i]);
+    for (int i = threadIdx.x; i < T.n_bsdfs * 3; i += kBlock) if (acc_bsdf[i] != 0.f) atomicAdd(&P.g_bsdf[i], acc_bsdf[i]);
+    for (int i = threadIdx.x; i < T.n_emitters * 3; i += kBlock) if (acc_emit[i] != 0.f) atomicAdd(&P.g_emitter[i], acc_emit[i]);
 }
 
 } // namespace psdr

@@ -58,6 +58,7 @@ PSDR_DEV SceneView<LDS> make_view(const float4 *blob, const SceneTables &T, floa
     S.c_nodes = S.c_tris = S.c_rays = S.c_hits = 0u;
     S.mis = -1; S.field = -1; S.field_object = -1; S.intensity = 1.f; S.d_intensity = 0.f; S.mode = 0; S.rec = nullptr; S.rec_i = 0; S.rec_n = 0; S.ext = nullptr; S.ext_n = 0; S.probe_kind = 0; S.probe_id = 0; S.probe_comp = 0;
     S.lk = nullptr; S.lk_n = 0; S.lk_max = 0; S.ext_max = 0; S.probe_u = 0.f; S.probe_v = 0.f;
+    t4_init_lds(S);
     return S;
 }
 
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(kBlock) void k_interior_adjoint(const float4 *__res
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     SceneView<LDS> S = make_view<LDS>(blob, T, smem);
     S.mis = P.mis; S.field = P.field; S.field_object = P.field_object; S.intensity = P.intensity; S.d_intensity = P.d_intensity;
+    if constexpr (!has_mat(LDS)) { if (P.sweep) { run_interior_adjoint_sweep<LDS>(S, cam, P, scratch_base<LDS>(smem, T)); return; } }
     run_interior_adjoint<LDS>(S, cam, P, scratch_base<LDS>(smem, T));
 }
 
@@ -227,6 +229,9 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edges(const float4 *__rest
                     w3[c] = k;
                 }
                 S.mode = 2;
+                // (probe kind 99 matches nothing: the replays see zero tangents except the one the probe sets - with kind 0 the
+                // snapshot's FORWARD tangents of the triangles would leak into the adjoint of the edge point)
+                S.probe_kind = 99; S.probe_id = -1;
                 auto probe = [&](const BoundarySegSampleDirect &b) -> float {
                     S.rec_i = 0;
                     Vec3f t;
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edges(const float4 *__rest
                         const float g = probe(b0);
                         if (g != 0.f) atomicAdd(&g_tri[22 * orig + comp], g);
                     }
-                    S.probe_kind = 0;
+                    S.probe_kind = 99;
                 }
                 if (P.g_cam != nullptr)                            // the camera ray through p1 moves with the pose (path.cpp:214)
                     for (int comp = 0; comp < 12; ++comp) {
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edges(const float4 *__rest
                         if (g != 0.f) atomicAdd(&acc_cam[comp], g);
                     }
             }
-            S.mode = 0;
+            S.mode = 0; S.probe_kind = 0;
             have = false;
         }
         if (have) {
@@ -675,10 +680,10 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     T.ref_bits = bvh4.ref_bits;
     // traversal stack: the first kStackLds entries of a lane in LDS, deeper ones in a per-lane global array (trav4.h);
     // scenes that are traced by brute force (<= kBruteForceMax triangles) need neither
-    constexpr int kStackLds = 16;
+    constexpr int kStackLds = 12;
     const bool uses_bvh = n > kBruteForceMax;
     T.stack_lds = uses_bvh ? std::min(kStackLds, bvh4.max_stack) : 0;
-    T.stack_depth = T.stack_lds + (uses_bvh ? kParkWords : 0);       // + the parked rays of run_paths_async (paths.h)
+    T.stack_depth = T.stack_lds + (uses_bvh ? kTravRows : 0);        // + parked rays, best hits and the pair ring of the traversal (trav4.h)
     T.gstack = nullptr; T.gstack_stride = 0;
     T.emitter_sum = s->emitter_sum;
     T.width = s->width; T.height = s->height; T.spp = s->spp; T.sppe = s->sppe; T.sppse = s->sppse;
@@ -778,7 +783,7 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     const size_t blob_bytes = (size_t) T.blob_words * 16;
     // keeps >= 4 workgroups per CU (160 KiB LDS); the environment-map and texture code lives in the LDS=false kernels only (shade.h)
     static const bool no_lds = std::getenv("PSDR_NO_LDS") != nullptr;      // measurement knob: run small scenes through the global-memory classes
-    sc->lds = !no_lds && blob_bytes + stack_bytes <= 40 * 1024 && T.env_emitter < 0 && T.tex == nullptr && T.mat == nullptr && T.pv == nullptr;
+    sc->lds = !no_lds && !uses_bvh && blob_bytes + stack_bytes <= 40 * 1024 && T.env_emitter < 0 && T.tex == nullptr && T.mat == nullptr && T.pv == nullptr;      // (LDS class = brute-force scenes)
     sc->lean = !sc->lds && T.tex == nullptr && T.mat == nullptr && T.pv == nullptr;
     sc->smem_bytes = (sc->lds ? blob_bytes : 0) + stack_bytes;
     if (sc->smem_bytes > 64 * 1024) return fail("BVH too deep for the LDS traversal stack");
@@ -855,6 +860,22 @@ static inline int grid_for(const psdr_hip_scene *sc, long long n) {
 #define ON_CLS2(...) __VA_ARGS__
 #else
 #define ON_CLS2(...) return fail("scene class 2 is compiled out of this development build")
+#endif
+
+#if (PSDR_CLS_MASK) & 1
+#define IF_CLS0(...) __VA_ARGS__
+#else
+#define IF_CLS0(...) (void) 0
+#endif
+#if (PSDR_CLS_MASK) & 2
+#define IF_CLS1(...) __VA_ARGS__
+#else
+#define IF_CLS1(...) (void) 0
+#endif
+#if (PSDR_CLS_MASK) & 4
+#define IF_CLS2(...) __VA_ARGS__
+#else
+#define IF_CLS2(...) (void) 0
 #endif
 
 #define LAUNCH(kernel, sc, n_lanes, stream, ...) \
@@ -1036,7 +1057,11 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     // the number of hot triangle rows is what is left of the 160 KB
     const size_t smem_base = adj_cls == 1 ? sc->smem_bytes : sc->smem_bytes - (sc->lds ? (size_t) T.blob_words * 16 : 0);
     const int adj_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth);
-    const size_t fixed_bytes = sizeof(float) * ((size_t) adj_lane_words(adj_depth, with_lookups) * kBlock + kAdjMisc + (size_t) T.n_bsdfs * kMatRow
+    // Diffuse BSDFs + area lights under PathTracer: the reverse sweep (adjoint.h); everything else: record and probe
+    static const bool no_sweep = std::getenv("PSDR_ADJ_PROBE") != nullptr;         // measurement knob: force the probe form
+    const bool sweep = !no_sweep && adj_cls != 0 && T.env_emitter < 0 && a->direct_mode == 0 && a->field_mode == 0 && !with_lookups;
+    const int lane_words = sweep ? adj_sweep_words(adj_depth) : adj_lane_words(adj_depth, with_lookups);
+    const size_t fixed_bytes = sizeof(float) * ((size_t) lane_words * kBlock + kAdjMisc + (size_t) T.n_bsdfs * kMatRow
                                                 + (size_t) T.n_bsdfs * 3 + (size_t) T.n_emitters * 3);
     if (smem_base + fixed_bytes > 160 * 1024) return fail("path depth / scene too large for the adjoint kernel's LDS records");
     // two workgroups per CU (80 KB each) when the fixed part allows it - one wave per SIMD cannot hide the global-memory latency of
@@ -1044,16 +1069,16 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     const size_t budget = (smem_base + fixed_bytes + 64 * 22 * sizeof(float) <= 80 * 1024) ? 80 * 1024 : 160 * 1024;
     const int n_hot_used = (int) std::min<size_t>((size_t) sc->n_hot, (budget - smem_base - fixed_bytes) / (22 * sizeof(float)));
     const size_t n_acc = (size_t) n_hot_used * 22 + (size_t) T.n_bsdfs * 3 + (size_t) T.n_emitters * 3;
-    const size_t adj_bytes = sizeof(float) * ((size_t) adj_lane_words(adj_depth, with_lookups) * kBlock + kAdjMisc + (size_t) T.n_bsdfs * kMatRow + (lds_acc ? n_acc : 0));
+    const size_t adj_bytes = sizeof(float) * ((size_t) lane_words * kBlock + kAdjMisc + (size_t) T.n_bsdfs * kMatRow + (lds_acc ? n_acc : 0));
     const size_t smem = smem_base + adj_bytes;
     if (smem > 160 * 1024) return fail("scene too large for the adjoint kernel's LDS records");
     static bool attr_set = false;
     if (!attr_set) {
-        ON_CLS1(HIPCHK(hipFuncSetAttribute((const void *) k_interior_adjoint<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
-        ON_CLS0(HIPCHK(hipFuncSetAttribute((const void *) k_interior_adjoint<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
-        ON_CLS2(HIPCHK(hipFuncSetAttribute((const void *) k_interior_adjoint<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
-        ON_CLS1(HIPCHK(hipFuncSetAttribute((const void *) k_secondary_edges<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
-        ON_CLS0(HIPCHK(hipFuncSetAttribute((const void *) k_secondary_edges<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
+        IF_CLS1(HIPCHK(hipFuncSetAttribute((const void *) k_interior_adjoint<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
+        IF_CLS0(HIPCHK(hipFuncSetAttribute((const void *) k_interior_adjoint<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
+        IF_CLS2(HIPCHK(hipFuncSetAttribute((const void *) k_interior_adjoint<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
+        IF_CLS1(HIPCHK(hipFuncSetAttribute((const void *) k_secondary_edges<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
+        IF_CLS0(HIPCHK(hipFuncSetAttribute((const void *) k_secondary_edges<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
         attr_set = true;
     }
     if ((terms & PSDR_TERM_INTERIOR) && T.spp > 0) {
@@ -1071,6 +1096,8 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
             if (next_queue(P.counter)) return 1;
             const int grid = grid_for(sc, P.n_local);
             P.hit_words = adj_hit_words(adj_depth); P.ext_words = adj_ext_words(adj_depth); P.lk_words = with_lookups ? 3 * adj_lk_entries(adj_depth) : 0;
+            P.sweep = sweep ? 1 : 0;
+            if (sweep) { P.hit_words = lane_words; P.ext_words = 0; P.lk_words = 0; }
             if (adj_cls == 1) ON_CLS1(hipLaunchKernelGGL((k_interior_adjoint<1>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, cam, P));
             else if (adj_cls == 2) ON_CLS2(hipLaunchKernelGGL((k_interior_adjoint<2>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, cam, P));
             else ON_CLS0(hipLaunchKernelGGL((k_interior_adjoint<0>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, cam, P));

@@ -330,7 +330,6 @@ PSDR_DEV void run_paths_async(SceneView<LDS> &S, const SensorDev &cam, const Pat
     const int lane_id = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane_id) - 1ull;
     const float inv_spp = T.spp > 1 ? 1.f / (float) T.spp : 1.f;
-    float *park = reinterpret_cast<float *>(S.stack) + T.stack_lds * kBlock;      // this lane's parked rays: oA dA oB dB, stride kBlock
 
     long long q_next = 0, q_end = 0;
     bool exhausted = false;
@@ -369,7 +368,7 @@ PSDR_DEV void run_paths_async(SceneView<LDS> &S, const SensorDev &cam, const Pat
             bool finished = false;
             if (ready && has_hits) {
                 has_hits = false;
-                const Hit h = tr.hA, hx = ext_traced ? tr.result() : Hit{-1, 0.f, 0.f, 0.f};
+                const Hit h = tr.hA, hx = tr.hB;
                 RayT<AD> ray1; ray1.o = its.p; ray1.d = wod;
                 if (do_nee && h.slot >= 0) {
                     if (COUNT) S.c_hits++;
@@ -565,11 +564,7 @@ PSDR_DEV void run_paths_async(SceneView<LDS> &S, const SensorDev &cam, const Pat
                     ext.o = its.p; ext.d = to_world<AD>(its, bs.wo);
                 }
                 ext_traced = bs.valid;
-                const Vec3f oA = detach(its.p), dA = detach(wod), oB = detach(ext.o), dB = detach(ext.d);
-                park[0] = oA.x; park[kBlock] = oA.y; park[2 * kBlock] = oA.z; park[3 * kBlock] = dA.x; park[4 * kBlock] = dA.y; park[5 * kBlock] = dA.z;
-                park[6 * kBlock] = oB.x; park[7 * kBlock] = oB.y; park[8 * kBlock] = oB.z; park[9 * kBlock] = dB.x; park[10 * kBlock] = dB.y; park[11 * kBlock] = dB.z;
-                tr.reset();
-                tr.pending = (do_nee ? 1 : 0) | (ext_traced ? 2 : 0);
+                t4_post(S, tr, detach(its.p), detach(wod), do_nee, detach(ext.o), detach(ext.d), ext_traced);
                 inflight = true;
             }
             if (__ballot(busy || inflight) == 0ull && exhausted && q_next >= q_end) break;
@@ -579,10 +574,7 @@ PSDR_DEV void run_paths_async(SceneView<LDS> &S, const SensorDev &cam, const Pat
             const int n_fly = __popcll(__ballot(inflight));
             if (n_fly > 0) {
                 const int want_new = n_fly < 2 * kShadeMin ? (n_fly + 1) / 2 : kShadeMin;
-                trav4_run<LDS, COUNT>(S, tr, n_fly - want_new, [&](int k, Vec3f &o, Vec3f &d) {
-                    const float *q = park + (k == 0 ? 0 : 6 * kBlock);
-                    o = Vec3f(q[0], q[kBlock], q[2 * kBlock]); d = Vec3f(q[3 * kBlock], q[4 * kBlock], q[5 * kBlock]);
-                });
+                trav4_run<LDS, COUNT>(S, tr, n_fly - want_new);
                 if (inflight && tr.idle()) { inflight = false; has_hits = true; }
             }
         }

@@ -17,7 +17,8 @@ constexpr float kPi = 3.14159265358979323846f, kInvPi = 0.31830988618379067154f;
 constexpr float kTraceTMax = 100000000.f;   // reference scene_optix.cpp:376
 constexpr int kBlock = 256;
 constexpr int kBruteForceMax = 64;          // scenes with at most this many triangles skip the BVH
-constexpr int kParkWords = 12;              // LDS words per lane behind the traversal stack: the two parked rays of run_paths_async (paths.h)
+constexpr int kParkWords = 12;              // LDS words per lane behind the traversal stack: the lane's two parked rays (trav4.h)
+constexpr int kTravRows = 26;               // LDS rows (of kBlock words) behind the stack of a BVH scene: parked rays, best hits, pair ring, ring heads (trav4.h)
 
 // EnvironmentMap after configure() (psdr_envmap_rec): too large for the LDS blob, read from global memory
 struct EnvDev {
@@ -178,6 +179,7 @@ struct Hit { int slot; float u, v, t; };   // slot = device triangle slot (BVH l
 
 // Möller–Trumbore exactly as the reference's own ray_intersect_triangle (include/psdr/utils.h:82-93)
 PSDR_DEV bool tri_test(const float4 &a, const float4 &b, const float4 &c, const Vec3f &o, const Vec3f &d, float &u, float &v, float &t) {
+#pragma clang fp contract(off)
     Vec3f p0(a.x, a.y, a.z), e1(a.w, b.x, b.y), e2(b.z, b.w, c.x);
     Vec3f h = cross(d, e2);
     float det = dot(e1, h);
@@ -220,6 +222,7 @@ PSDR_DEV void bvh4_trace2(SceneView<LDS> &S, const Vec3f &oA, const Vec3f &dA, b
 
 template <int LDS, bool COUNT>
 PSDR_DEV Hit trace_scene(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
+#pragma clang fp contract(off)
     Hit best; best.slot = -1; best.u = best.v = 0.f; best.t = 0.f;
     if (!(o.x == o.x && o.y == o.y && o.z == o.z && d.x == d.x && d.y == d.y && d.z == d.z)) return best;
     const SceneTables &T = *S.T;
@@ -278,8 +281,10 @@ PSDR_DEV Hit trace_scene(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
         }
         return best;
     }
-    Hit other;
-    bvh4_trace2<LDS, COUNT>(S, o, d, true, o, d, false, best, other);
+    if constexpr (!in_lds(LDS)) {          // (the LDS class holds brute-force scenes only: its kernels carry no tree code)
+        Hit other;
+        bvh4_trace2<LDS, COUNT>(S, o, d, true, o, d, false, best, other);
+    }
     return best;
 }
 
@@ -291,6 +296,7 @@ PSDR_DEV Hit trace_scene(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
 template <int LDS, bool COUNT>
 PSDR_DEV void trace2(SceneView<LDS> &S, const Vec3f &oA_, const Vec3f &dA, bool actA, const Vec3f &oB_, const Vec3f &dB, bool actB,
                      Hit &hA, Hit &hB) {
+#pragma clang fp contract(off)
     hA.slot = -1; hA.u = hA.v = hA.t = 0.f;
     hB.slot = -1; hB.u = hB.v = hB.t = 0.f;
     const SceneTables &T = *S.T;
@@ -299,7 +305,7 @@ PSDR_DEV void trace2(SceneView<LDS> &S, const Vec3f &oA_, const Vec3f &dA, bool 
         if (actB) hB = trace<LDS, COUNT>(S, oB_, dB);
         return;
     }
-    if (T.n_tris > kBruteForceMax) { bvh4_trace2<LDS, COUNT>(S, oA_, dA, actA, oB_, dB, actB, hA, hB); return; }
+    if constexpr (!in_lds(LDS)) { if (T.n_tris > kBruteForceMax) { bvh4_trace2<LDS, COUNT>(S, oA_, dA, actA, oB_, dB, actB, hA, hB); return; } }
     const float qnan = __builtin_nanf("");
     const Vec3f oA = actA ? oA_ : Vec3f(qnan), oB = actB ? oB_ : Vec3f(qnan);
     if (COUNT) { const unsigned n = (actA ? 1u : 0u) + (actB ? 1u : 0u); S.c_rays += n; S.c_tris += n * (unsigned) T.n_tris; }

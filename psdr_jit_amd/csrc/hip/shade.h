@@ -311,7 +311,7 @@ template <bool AD, int LDS> PSDR_DEV VecN<AD> eval_Le(const SceneView<LDS> &S, c
     else return Vec3f(a.x, a.y, a.z);
 }
 
-template <bool AD> struct PositionSample { VecN<AD> p, n; Num<AD> J; float pdf; int slot; };
+template <bool AD> struct PositionSample { VecN<AD> p, n; Num<AD> J; float pdf; int slot; float ba, bb; };   // (ba, bb): barycentrics of p on triangle `slot`
 
 // Scene::sample_emitter_position -> AreaLight::sample_position -> Mesh::__sample_position
 // reference scene.cpp:987-1013, mesh.cpp:413-454, warp.h:79-82
@@ -333,7 +333,7 @@ template <bool AD, int LDS> PSDR_DEV PositionSample<AD> sample_emitter_position(
         else { r.p = p; r.n = nn; }
         r.J = Num<AD>(1.f);
         r.pdf = pdf_env * epdf;
-        r.slot = -1;
+        r.slot = -1; r.ba = 0.f; r.bb = 0.f;
         return r;
     }
     const int mesh = __float_as_int(S.ld(T.emit_off + 2 * ei + 1).w);
@@ -359,7 +359,7 @@ template <bool AD, int LDS> PSDR_DEV PositionSample<AD> sample_emitter_position(
         } else r.n = promote(Vec3f(s3.x, s3.y, s3.z));
     } else r.n = Vec3f(s3.x, s3.y, s3.z);
     r.pdf = m.inv_total_area * epdf;
-    r.slot = slot;
+    r.slot = slot; r.ba = a; r.bb = b;
     return r;
 }
 

@@ -70,3 +70,70 @@ def test_adjoint_dot_product(env, param, terms):
     assert abs(lhs - rhs) <= 2e-4 * scale, (param, terms, lhs, rhs, scale)
     if terms & 1 and param in ("albedo", "radiance"):
         assert abs(lhs) > 1e-6          # the test is not vacuous
+
+
+def _dot_product_case(env, spec, depth, terms, seeds=(7, 8, 9), with_camera=False):
+    """<w, J v> against <J^T w, v> for the forward tangent the spec carries"""
+    torch, psdr, cabi = env
+    sc = product.build_scene(spec)
+    snap = sc._snapshot()
+    cam = sc.param_map["Sensor[0]"]
+    d_tri = np.asarray(snap["d_triangles"], np.float64)
+    d_sec = np.asarray(snap["d_sec_edges"], np.float64)[:, :6]
+    d_prim = np.asarray(cam._primary_edges(True), np.float64)[:, :4]
+    d_bsdf = np.array([b.d_reflectance for b in spec.bsdfs], np.float64)
+    d_em = np.array([e.d_radiance for e in spec.emitters], np.float64)
+    n = spec.width * spec.height
+    buf = torch.empty((2, n, 3), dtype=torch.float32, device="cuda")
+    a = cabi.make_args(max_depth=depth, seeds=seeds, terms=terms)
+    cabi.check(cabi.lib().psdr_hip_render_d_fwd(sc._hip_handle(), C.byref(a), buf[0].data_ptr(), buf[1].data_ptr(), None))
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    w = (torch.rand((n, 3), generator=gen) + 0.5).to("cuda")
+    lhs = float((buf[1].double() * w.double()).sum())
+    dev = "cuda"
+    g_tri = torch.zeros((d_tri.shape[0], 22), dtype=torch.float32, device=dev)
+    g_bsdf = torch.zeros((max(1, len(spec.bsdfs)), 3), dtype=torch.float32, device=dev)
+    g_em = torch.zeros((max(1, len(spec.emitters)), 3), dtype=torch.float32, device=dev)
+    g_sec = torch.zeros((max(1, d_sec.shape[0]), 6), dtype=torch.float32, device=dev)
+    g_prim = torch.zeros((max(1, d_prim.shape[0]), 4), dtype=torch.float32, device=dev)
+    g_cam = torch.zeros(16, dtype=torch.float32, device=dev)
+    g = cabi.Grads(g_tri.data_ptr(), g_bsdf.data_ptr(), g_em.data_ptr(), g_sec.data_ptr(), g_prim.data_ptr())
+    if with_camera:
+        g.g_camera = g_cam.data_ptr()
+    cabi.check(cabi.lib().psdr_hip_render_d_bwd(sc._hip_handle(), C.byref(a), w.data_ptr(), C.byref(g), None))
+    torch.cuda.synchronize()
+    rhs = (g_tri.cpu().numpy().astype(np.float64) * d_tri).sum() + (g_bsdf.cpu().numpy().astype(np.float64)[:len(spec.bsdfs)] * d_bsdf).sum()
+    rhs += (g_em.cpu().numpy().astype(np.float64)[:len(spec.emitters)] * d_em).sum()
+    rhs += (g_sec.cpu().numpy().astype(np.float64)[:d_sec.shape[0]] * d_sec).sum() + (g_prim.cpu().numpy().astype(np.float64)[:d_prim.shape[0]] * d_prim).sum()
+    if with_camera:
+        d_tw = np.asarray(cam._get("to_world_left", True), np.float64).reshape(4, 4) if hasattr(cam, "_get") else np.zeros((4, 4))
+        rhs += (g_cam.cpu().numpy().astype(np.float64).reshape(4, 4)[:3] * d_tw[:3]).sum()
+    scale = float((buf[1].double().abs() * w.double()).sum()) + 1e-12
+    return lhs, rhs, scale
+
+
+@pytest.mark.parametrize("param", ["light_x", "box_x", "albedo"])
+def test_interior_sweep_deep_paths(env, param):
+    """the reverse sweep of the interior term (adjoint.h) at depth 5: every bounce's position, normal, area, colour adjoints"""
+    lhs, rhs, scale = _dot_product_case(env, scenes.cbox_scene(40, 40, 8, 0, 0, param=param), depth=5, terms=1)
+    assert abs(lhs - rhs) <= 2e-4 * scale and abs(lhs) > 1e-6, (param, lhs, rhs, scale)
+
+
+def test_interior_sweep_smooth_meshes(env):
+    """tutorial sphere box (class 2: BVH scene, interpolated vertex normals): the light and the small sphere move - positions,
+    areas and the blended shading normals of a finely tessellated mesh"""
+    lhs, rhs, scale = _dot_product_case(env, scenes.sphere_scene(48, 48, 8, 0, 0), depth=3, terms=1)
+    assert abs(lhs - rhs) <= 3e-4 * scale and abs(lhs) > 1e-6, (lhs, rhs, scale)
+    lhs, rhs, scale = _dot_product_case(env, scenes.sphere_scene(40, 40, 4, 4, 4), depth=2, terms=7)
+    assert abs(lhs - rhs) <= 3e-4 * scale, (lhs, rhs, scale)
+
+
+def test_interior_sweep_two_sided_and_flat(env):
+    """two-sided Diffuse BSDFs seen from the back and flat-shaded meshes (the shading normal is the face normal)"""
+    spec = scenes.cbox_scene(40, 40, 8, 0, 0, param="box_x")
+    for b in spec.bsdfs:
+        b.two_sided = True
+    for m in spec.meshes[1:3]:
+        m.use_face_normals = True
+    lhs, rhs, scale = _dot_product_case(env, spec, depth=3, terms=1)
+    assert abs(lhs - rhs) <= 2e-4 * scale and abs(lhs) > 1e-6, (lhs, rhs, scale)
