@@ -1,0 +1,54 @@
+"""The multi-GPU path with the HIP kernels on BOTH ranks: two processes (torch.distributed, gloo rendezvous on 127.0.0.1) share the
+one GPU of the test box, each renders its lane shard with the product, the partial [image | derivative] buffers and the parameter
+adjoints are all-reduced, and the result must equal the single-process render.  (tests/test_distributed_cpu.py covers the
+collective glue on CPU; an 8-GPU RCCL run is the driver's to make.)"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _torchrun(script_args, env_extra=None, timeout=600):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(env_extra or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + script_args
+    return subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
+
+
+def test_two_ranks_forward_and_backward_equal_one_process():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X (no CPU fallback exists)")
+    r = _torchrun([os.path.join("tools", "check_2rank_backward.py")])
+    assert r.returncode == 0 and "2-rank backward OK" in r.stdout, r.stdout[-3000:]
+
+
+def test_bench_two_ranks_config4_strong_scaling_line():
+    """bench.py --gpus 2 as the driver launches it (here: gloo, both ranks on the one GPU): config 4, strong scaling, one JSON line"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X (no CPU fallback exists)")
+    r = _torchrun(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"], {"PSDR_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stdout[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "config 4" in d["config"]["workload"] and "2048x2048" in d["config"]["workload"]
+    assert d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and d["unit"] == "Msamples/s"
+    assert "roofline" not in d and "cpu_baseline" not in d        # N = 1 only
