@@ -5,10 +5,12 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg.  The shipped product
  * (psdr_jit_amd/, include/psdr_hip.h) never includes, links or calls anything in oracle/.
  *
- * PARITY UNPINNED: the reference cannot be compiled or imported in this environment (its drjit
- * submodule is empty and un-pinned, it needs CUDA+OptiX, and it ships no tests, golden images or
- * known-answer vectors).  This restatement follows the reference sources cited next to every
- * function and is pinned only by analytic known-answer tests (tests/test_oracle_kat.py).
+ * PARITY: the reference cannot be compiled or imported in this environment (its drjit submodule is
+ * empty and un-pinned, it needs CUDA+OptiX, and it ships no tests).  This restatement follows the
+ * reference sources cited next to every function and is pinned against the reference's only held
+ * outputs - the figures and log lines embedded in its tutorial notebooks, extracted into
+ * tests/golden/notebooks/ (tests/test_oracle_notebooks.py) - and by analytic known-answer tests
+ * (tests/test_oracle_kat.py).  One figure is met only loosely, see DESIGN.md section 2.
  *
  * C ABI so that tests can drive it through ctypes.  All matrices are row-major float[16].
  * "d_*" members are the forward-mode tangent of the member they shadow with respect to ONE scalar

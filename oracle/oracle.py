@@ -4,7 +4,8 @@ ctypes driver for oracle/_build/liboracle.so (the CPU restatement of psdr-jit's
 PathTracer.renderC / renderD hot path, see oracle/oracle.h).  Imported only by tests/,
 __graft_entry__.smoke() and bench.py's cpu_baseline leg — never by the product package.
 
-PARITY UNPINNED: the reference cannot be built or imported here; see oracle/README.md.
+Pinned against the figures and log lines the reference's tutorial notebooks embed (tests/test_oracle_notebooks.py); the reference
+itself cannot be built or imported here, see oracle/README.md.
 """
 import ctypes as C
 import os

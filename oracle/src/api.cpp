@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see num.h header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see num.h header).
 //
 // api.cpp — C ABI of the oracle (oracle.h): the render drivers
 // (reference src/integrator/integrator.cpp:12-198, src/integrator/path.cpp:130-168,274-294)

@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see num.h header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see num.h header).
 //
 // envmap.h — EnvironmentMap emitter (reference src/emitter/envmap.cpp:17-173), the lat-long Bitmap lookup it uses
 // (src/core/bitmap.cpp:47-128, envmap_mode), HyperCubeDistribution<2> (src/core/cube_distrb.cpp:9-64) and

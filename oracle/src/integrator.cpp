@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see num.h header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see num.h header).
 //
 // integrator.cpp — one-lane restatement of the reference hot path.  Every function names the
 // reference file:line it follows.  `ad=false` is the reference's C instantiation, `ad=true` the

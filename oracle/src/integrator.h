@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see num.h header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see num.h header).
 //
 // integrator.h — per-sample restatement of the hot path: Scene::ray_intersect, emitter/BSDF
 // sampling, PathTracer::__Li, the primary- and secondary-edge estimators.

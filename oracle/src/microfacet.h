@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see num.h header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see num.h header).
 //
 // microfacet.h — Microfacet BSDF (reference src/bsdf/microfacet.cpp:18-134: Lambertian diffuse + GGX specular with the
 // Schlick-style 2^(...) Fresnel) and its GGXDistribution (src/bsdf/ggx.cpp:8-107, visible-normal sampling).

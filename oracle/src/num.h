@@ -1,7 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the shipped product; only tests/,
 // __graft_entry__.smoke() and bench.py's cpu_baseline leg may build or call this code.
-// PARITY UNPINNED: the reference (andyyankai/psdr-jit) cannot be built or imported here
-// (drjit/OptiX/CUDA absent, no tests or golden vectors upstream) — see oracle/README.md.
+// PARITY: the reference (andyyankai/psdr-jit) cannot be built or imported here (drjit/OptiX/CUDA absent, no
+// tests upstream); pinned against the outputs its tutorial notebooks embed - see oracle/README.md.
 //
 // num.h — scalar number types for the CPU restatement.
 //   Real<ad>  = float (ad=false, the reference's "C" arrays) or Dual (ad=true, the

@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see num.h header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see num.h header).
 //
 // sampler.h — per-lane random number stream.
 // Follows reference src/core/sampler.cpp:6-42 and include/psdr/core/sampler.h:8-40.

@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see num.h header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see num.h header).
 //
 // scene.cpp — Scene::configure restated (reference src/scene/scene.cpp:311-601,
 // src/shape/mesh.cpp:23-62,102-150,317-400, src/sensor/perspective.cpp:10-152,

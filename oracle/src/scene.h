@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see num.h header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see num.h header).
 //
 // scene.h — the configured scene: what Scene::configure() (reference src/scene/scene.cpp:311-601)
 // leaves behind, restated as plain host arrays of (value, tangent) pairs.

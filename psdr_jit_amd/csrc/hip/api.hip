@@ -452,6 +452,7 @@ struct psdr_hip_scene {
     DevBuf queues;                       // ring of work-queue heads, one per path-kernel launch
     DevBuf gstack;                       // traversal-stack entries beyond the LDS part (trav4.h)
     mutable unsigned queue_slot = 0;
+    mutable bool adj_attr_set = false;   // the adjoint kernels' dynamic-LDS limit has been raised on this scene's device
     int n_leaves = 0, max_depth = 0, grid = 0;
     long long tex_total = 0;             // floats of all bitmap parameters (psdr_grads.g_tex)
     DevBuf hot_map, hot_inv;             // adjoint accumulators kept in LDS: emitter triangles first, then by area (adjoint.h)
@@ -1072,14 +1073,13 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     const size_t adj_bytes = sizeof(float) * ((size_t) lane_words * kBlock + kAdjMisc + (size_t) T.n_bsdfs * kMatRow + (lds_acc ? n_acc : 0));
     const size_t smem = smem_base + adj_bytes;
     if (smem > 160 * 1024) return fail("scene too large for the adjoint kernel's LDS records");
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!sc->adj_attr_set) {         // (per scene = per device and context; a process-wide flag would skip the second device)
         IF_CLS1(HIPCHK(hipFuncSetAttribute((const void *) k_interior_adjoint<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
         IF_CLS0(HIPCHK(hipFuncSetAttribute((const void *) k_interior_adjoint<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
         IF_CLS2(HIPCHK(hipFuncSetAttribute((const void *) k_interior_adjoint<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
         IF_CLS1(HIPCHK(hipFuncSetAttribute((const void *) k_secondary_edges<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
         IF_CLS0(HIPCHK(hipFuncSetAttribute((const void *) k_secondary_edges<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
-        attr_set = true;
+        sc->adj_attr_set = true;
     }
     if ((terms & PSDR_TERM_INTERIOR) && T.spp > 0) {
         AdjointParams P{};
