@@ -649,7 +649,7 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     }
     std::vector<FilterPrim> filt;
     build_filter_prims(tr.p0, tr.e1, tr.e2, bvh.order.data(), n, filt);
-    T.filt_off = (int) w;  w += 4 * filt.size();
+    T.filt_off = (int) w;  w += 6 * filt.size();
     T.n_filt = (int) filt.size();
     {   // bounding sphere of the scene (for the absolute slack of the quad filter)
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
@@ -681,10 +681,14 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     T.ref_bits = bvh4.ref_bits;
     // traversal stack: the first kStackLds entries of a lane in LDS, deeper ones in a per-lane global array (trav4.h);
     // scenes that are traced by brute force (<= kBruteForceMax triangles) need neither
-    constexpr int kStackLds = 12;
+    static const int kStackLds = std::getenv("PSDR_STACK_LDS") ? std::atoi(std::getenv("PSDR_STACK_LDS")) : 12;
     const bool uses_bvh = n > kBruteForceMax;
     T.stack_lds = uses_bvh ? std::min(kStackLds, bvh4.max_stack) : 0;
-    T.stack_depth = T.stack_lds + (uses_bvh ? kTravRows : 0);        // + parked rays, best hits and the pair ring of the traversal (trav4.h)
+#ifdef PSDR_NO_ASYNC
+    T.stack_depth = (uses_bvh ? T.stack_lds + kTravRows : 0) + kColdRows;
+#else
+    T.stack_depth = uses_bvh ? T.stack_lds + kTravRows : kColdRows;   // BVH: + parked rays, best hits and the pair ring of the traversal (trav4.h); brute force: cold path state (paths.h)
+#endif
     T.gstack = nullptr; T.gstack_stride = 0;
     T.emitter_sum = s->emitter_sum;
     T.width = s->width; T.height = s->height; T.spp = s->spp; T.sppe = s->sppe; T.sppse = s->sppse;
@@ -721,13 +725,31 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
         }
     }
     for (int i = 0; i < n; ++i) blob[4 * (size_t) T.map_off + i] = ibits(orig2slot[i]);
+    T.filt_kmax = 0.f;
+    T.filt_hasb[0] = T.filt_hasb[1] = 0u;
     for (size_t i = 0; i < filt.size(); ++i) {
+        // dot-product form of the filter (scene_dev.h::trace2): with oc = o - centre, m = oc x d and p = p0 - centre
+        //   u-numerator = m.e2 + d.(p x e2)   v-numerator = d.(e1 x p) - m.e1   -det = d.(e1 x e2)   t-numerator = oc.(e1 x e2) - p.(e1 x e2)
         const FilterPrim &f = filt[i];
-        const size_t fw = T.filt_off + 4 * i;
-        put4(blob, fw, f.p0[0], f.p0[1], f.p0[2], f.e1[0]);
-        put4(blob, fw + 1, f.e1[1], f.e1[2], f.e2[0], f.e2[1]);
-        put4(blob, fw + 2, f.e2[2], f.umax, f.vmax, f.smax);
-        put4(blob, fw + 3, f.da, f.db, ibits(f.slot_a | ((f.slot_b < 0 ? 0xff : f.slot_b) << 8)), f.k16);
+        const size_t fw = T.filt_off + 6 * i;
+        {
+            const size_t base = i & ~(size_t) 31, cnt = std::min<size_t>(32, filt.size() - base);
+            if (f.slot_b >= 0) T.filt_hasb[i >> 5] |= 1u << (cnt - 1 - (i - base));
+        }
+        const double p[3] = {(double) f.p0[0] - (double) T.center[0], (double) f.p0[1] - (double) T.center[1], (double) f.p0[2] - (double) T.center[2]};
+        const double e1[3] = {f.e1[0], f.e1[1], f.e1[2]}, e2[3] = {f.e2[0], f.e2[1], f.e2[2]};
+        auto crs = [](const double *a, const double *b, double *c) { c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0]; };
+        double A[3], B[3], N[3];
+        crs(p, e2, A); crs(e1, p, B); crs(e1, e2, N);
+        const double npn = -(p[0] * N[0] + p[1] * N[1] + p[2] * N[2]);
+        const double K = std::max({std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]), std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]), (double) f.k16 * 32768.0});
+        T.filt_kmax = std::max(T.filt_kmax, (float) (K * 1.0001));
+        put4(blob, fw, f.e2[0], f.e2[1], f.e2[2], (float) A[0]);
+        put4(blob, fw + 1, (float) A[1], (float) A[2], f.e1[0], f.e1[1]);
+        put4(blob, fw + 2, f.e1[2], (float) B[0], (float) B[1], (float) B[2]);
+        put4(blob, fw + 3, (float) N[0], (float) N[1], (float) N[2], (float) npn);
+        put4(blob, fw + 4, f.umax, f.vmax, f.smax, f.da);
+        put4(blob, fw + 5, f.db, f.da + f.db, (float) (K * (1.0001 / 32768.0)), ibits(f.slot_a | ((f.slot_b < 0 ? 0xff : f.slot_b) << 8)));
     }
     for (int i = 0; i < s->n_meshes; ++i) {
         const psdr_mesh_rec &m = s->meshes[i];

@@ -23,17 +23,26 @@ struct FilterPrim {
     float umax, vmax, smax;
     float da, db;              // diagonal: sel = db * u - da * v  (>= 0: triangle A's side)
     int32_t slot_a, slot_b;    // device triangle slots; slot_b = -1 for a single triangle
-    float k16;                 // 2^-15 * (largest extent of the quad); 0 for a single triangle
+    float k16;                 // 2^-15 * (largest extent of the quad); 0 for a single triangle (api.hip takes max(|e1|, |e2|) then)
 };
-// Why k16: a single triangle's filter computes bit for bit the numerators of the exact test, so a margin relative
-// to |det| covers the two roundings that separate them.  A quad's filter works in another basis of the same plane;
-// its numerators are sums of products of size |s| |e| (s = origin - corner) whose ABSOLUTE rounding error does not
-// shrink with |det|, so for grazing and in-plane rays a relative margin is not conservative.  With g = 8 * 2^-24
-// per numerator, the window functions being convex combinations (weights <= 2) of the triangle's three barycentric
-// numerators scaled by the area ratio (<= ~2), the slack needed is <= (6 * 2 + 1) g |s| K ~ 6.2e-6 |s| K; the
-// filter uses 2^-15 K (S + K) = 3.1e-5 K (S + K) with S >= |s| (distance of the ray origin to the scene's bounding
-// sphere centre + its radius) and K times that for the t numerator.
-
+// Device form (api.hip uploads it, scene_dev.h::trace2 / trace_scene evaluate it).  With c = the centre of the scene's
+// bounding sphere, oc = o - c, m = oc x d (per ray) and p = p0 - c, N = e1 x e2 (per primitive) the Moeller-Trumbore
+// numerators are plain dot products of ray constants with primitive constants:
+//     s.(d x e2) = m.e2 + d.(p x e2)        d.(s x e1) = d.(e1 x p) - m.e1
+//     e1.(d x e2) = -d.N                    e2.(s x e1) = oc.N - p.N
+// six words per primitive: {e2, A.x} {A.yz, e1.xy} {e1.z, B} {N, -p.N} {umax, vmax, smax, da} {db, da + db, k15, slots},
+// A = p x e2 and B = e1 x p rounded from double.
+//
+// Slack.  These sums cancel: the terms are of size |oc| K and |p| K (K = the primitive's largest extent) while the result
+// is of size |s| K, so the ABSOLUTE rounding error of a numerator is <= ~11 * 2^-24 (|oc| + |p|) K (six products and
+// sums, the rounding of m and of the stored constants), whatever |det| is; the exact test's own numerators carry
+// <= ~4 * 2^-24 |s| K.  Quads add the error of working in another basis of the same plane, (6 * 2 + 1) * 8 * 2^-24 |s| K
+// (window functions = convex combinations, weights <= 2, of the triangle's three barycentric numerators scaled by the
+// area ratio <= ~2).  Every window test therefore gets the slack  k15 (S + Kmax),  k15 = 2^-15 K,  S = |oc| + R >= |oc| +
+// |p| (R = the bounding sphere's radius), Kmax = the largest K of the scene - 2^-15 = 512 * 2^-24 covers all of the above
+// four times over - plus 2^-18 |det| for the rounding of 1/det and of the products with it; the t numerator (terms of
+// size (|oc| + |p|) K^2) gets Kmax times that.  The window only has to be conservative: a wider one costs exact tests,
+// never hits (tests: test_trace_matches_oracle, 300 k rays incl. edge-to-edge and vertex-to-vertex ones, bit-exact).
 // p0/e1/e2: [n,3] rows in ORIGINAL triangle order; order[slot] = original index of the triangle in device slot `slot`
 inline void build_filter_prims(const float *p0, const float *e1, const float *e2, const int *order, int n, std::vector<FilterPrim> &out) {
     out.clear();

@@ -66,14 +66,17 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
     its.valid = false; its.slot = -1; its.mesh = -1;
     V thr(R(1.f)), res(R(0.f));
     RayT<AD> ext;                         // pending extension ray
-    long long lane = 0;                   // sample index of the current work item
-    int pix_slot = -1;
-    // MODE 1 extras
-    int side = 0;
-    Vec3f Ln(0.f);
-    float edge_xdn_v = 0.f, edge_xdn_d = 0.f, edge_pdf = 1.f, edge_s = 0.f, edge_nx = 0.f, edge_ny = 0.f;
-    int edge_i = 0;
-    bool edge_valid = false;
+    int side = 0;                         // MODE 1: which of the two paths of the edge sample
+    // What a lane only touches when it takes a work item and when its path ends - the pixel, the sample index, the edge sample
+    // and the first path's radiance - waits in the lane's LDS column (kColdRows rows behind the blob): registers are what this
+    // kernel runs out of, and a value parked here costs two LDS instructions per path instead of scratch traffic per vertex.
+    lds_float_t *cold = (lds_float_t *) (reinterpret_cast<float *>(S.stack) + (T.stack_depth - kColdRows) * kBlock);
+    enum { kLnX = 0, kLnY, kLnZ, kXdnV, kXdnD, kPdf, kEdgeS, kNx, kNy, kEdgeI, kPix, kLaneLo = 0, kLaneHi = 1 };
+    auto cold_f = [&](int r) -> float { return cold[r * kBlock]; };
+    auto cold_i = [&](int r) -> int { return __float_as_int(cold[r * kBlock]); };
+    auto park_f = [&](int r, float v) { cold[r * kBlock] = v; };
+    auto park_i = [&](int r, int v) { cold[r * kBlock] = __int_as_float(v); };
+    static_assert(kColdRows >= 11, "scene_dev.h::kColdRows");
     static_assert(MODE == 0 || !AD, "the primary-edge paths are traced in C mode");
 
     for (;;) {
@@ -95,13 +98,14 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
             const int n_need = __popcll(need);
             if (!busy && item < q_end) {
                 const long long chunk = (item >> 8) * P.shard_count + P.shard_rank;
-                lane = P.begin + (chunk << 8) + (item & 255);
+                const long long lane = P.begin + (chunk << 8) + (item & 255);
                 if (lane < P.end) {
                     busy = true; depth = -1; thr = V(R(1.f)); res = V(R(0.f));
                     if (MODE == 0) {
                         const long long k = T.spp > 1 ? lane / T.spp : lane;
                         const int pix = P.pix_ids ? P.pix_ids[k] : (int) k;
-                        pix_slot = (int) k;
+                        park_i(kPix, (int) k);
+                        if (P.lanes_out) { park_i(kLaneLo, (int) (unsigned) ((lane - P.begin) & 0xffffffffll)); park_i(kLaneHi, (int) ((lane - P.begin) >> 32)); }
                         rng.seed(P.seed + (P.pix_ids ? (unsigned long long) (long long) pix : (unsigned long long) lane), (unsigned long long) lane, P.skip);
                         const float bx = (float) (pix % T.width), by = (float) (pix / T.width);
                         const float jx = rng.next_1d(), jy = rng.next_1d();
@@ -120,14 +124,14 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
                         const Dual px = fma_(p0x, oms, p1x * s), py = fma_(p0y, oms, p1y * s);
                         const Dual x_dot_n = fma_(py, ny, px * nx);
                         const int ix = (int) floorf(px.v * (float) T.width), iy = (int) floorf(py.v * (float) T.height);
-                        edge_valid = ix >= 0 && ix < T.width && iy >= 0 && iy < T.height;
-                        pix_slot = edge_valid ? iy * T.width + ix : -1;
+                        const bool edge_valid = ix >= 0 && ix < T.width && iy >= 0 && iy < T.height;
+                        park_i(kPix, edge_valid ? iy * T.width + ix : -1);
                         const RayT<false> ray_p = sample_primary_ray<false>(cam, px.v + kEdgeEpsilon * nx, py.v + kEdgeEpsilon * ny);
                         const RayT<false> ray_n = sample_primary_ray<false>(cam, px.v - kEdgeEpsilon * nx, py.v - kEdgeEpsilon * ny);
                         (void) ray_p;      // rebuilt from (edge_i, edge_s) when the first path has ended
                         if constexpr (!AD) ext = ray_n;
                         side = 0;
-                        edge_xdn_v = x_dot_n.v; edge_xdn_d = x_dot_n.d; edge_pdf = pdf; edge_s = s; edge_nx = nx; edge_ny = ny; edge_i = ei;
+                        park_f(kXdnV, x_dot_n.v); park_f(kXdnD, x_dot_n.d); park_f(kPdf, pdf); park_f(kEdgeS, s); park_f(kNx, nx); park_f(kNy, ny); park_i(kEdgeI, ei);
                         if (!edge_valid) busy = false;       // Li(..., valid=false) contributes nothing
                     }
                 }
@@ -237,8 +241,9 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
             if (MODE == 0) {
                 const float pv[3] = {detach(res.x), detach(res.y), detach(res.z)};
                 const float tv[3] = {tangent(res.x), tangent(res.y), tangent(res.z)};
+                const int pix_slot = cold_i(kPix);
                 if (P.lanes_out) {
-                    const long long o = 3 * (lane - P.begin);
+                    const long long o = 3 * (((long long) cold_i(kLaneHi) << 32) | (long long) (unsigned) cold_i(kLaneLo));
                     P.lanes_out[o] = pv[0]; P.lanes_out[o + 1] = pv[1]; P.lanes_out[o + 2] = pv[2];
                 }
                 if (P.out) {
@@ -256,12 +261,14 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
                 busy = false;
             } else {
                 if (side == 0) {
-                    Ln = detach(res);
+                    { const Vec3f Ln = detach(res); park_f(kLnX, Ln.x); park_f(kLnY, Ln.y); park_f(kLnZ, Ln.z); }
                     // the reference's Li always draws 5 numbers per depth level; skip what this path left
                     if (depth < P.max_depth) rng.advance((unsigned long long) ((P.mis == 0 ? 2 : (P.mis == 1 ? 3 : 5)) * (P.max_depth - depth)));
                     side = 1; depth = -1; thr = V(R(1.f)); res = V(R(0.f));
                     if constexpr (!AD) {
                         // ray_p = sample_primary_ray(p + EdgeEpsilon * n): the same arithmetic as at the start of the work item
+                        const int edge_i = cold_i(kEdgeI);
+                        const float edge_s = cold_f(kEdgeS), edge_nx = cold_f(kNx), edge_ny = cold_f(kNy);
                         const float4 r0 = S.ld(cam.pe_off + 3 * edge_i);
                         const float oms = 1.0f - edge_s;
                         const float pxv = fmaf(r0.x, oms, r0.z * edge_s), pyv = fmaf(r0.y, oms, r0.w * edge_s);
@@ -269,7 +276,9 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
                     }
                 } else {
                     // value = x_dot_n * (Ln - Lp) / pdf, scrub, / sppe; only the tangent survives (integrator.cpp:187-192)
-                    const Vec3f Lp = detach(res);
+                    const Vec3f Lp = detach(res), Ln(cold_f(kLnX), cold_f(kLnY), cold_f(kLnZ));
+                    const float edge_xdn_v = cold_f(kXdnV), edge_xdn_d = cold_f(kXdnD), edge_pdf = cold_f(kPdf);
+                    const int pix_slot = cold_i(kPix);
                     const Vec3f dL = (Ln - Lp) / edge_pdf;
                     const float o3[3] = {dL.x, dL.y, dL.z};
                     if (P.adj_w == nullptr) {
@@ -292,6 +301,8 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
                             kw += P.adj_w[3 * (long long) pix_slot + c] * k;
                         }
                         if (kw != 0.f) {
+                            const int edge_i = cold_i(kEdgeI);
+                            const float edge_s = cold_f(kEdgeS), edge_nx = cold_f(kNx), edge_ny = cold_f(kNy);
                             const float a = (1.0f - edge_s) * kw, b = edge_s * kw;
                             atomicAdd(&P.g_prim[4 * edge_i], edge_nx * a); atomicAdd(&P.g_prim[4 * edge_i + 1], edge_ny * a);
                             atomicAdd(&P.g_prim[4 * edge_i + 2], edge_nx * b); atomicAdd(&P.g_prim[4 * edge_i + 3], edge_ny * b);
@@ -364,6 +375,11 @@ PSDR_DEV void run_paths_async(SceneView<LDS> &S, const SensorDev &cam, const Pat
         const int n_can = __popcll(__ballot(!inflight && (has_hits || busy || (q_next < q_end) || !exhausted)));
         if (m_fly == 0ull || n_can >= kShadeMin) {
             const bool ready = !inflight;
+#if PSDR_DIAG == 4
+            if (COUNT) S.c_hits++;
+#elif PSDR_DIAG == 5
+            if (COUNT) { if (ready && (has_hits || busy)) S.c_hits++; }
+#endif
             // ---------------------------------------------------------------- consume the hits of the lane's current vertex
             bool finished = false;
             if (ready && has_hits) {
@@ -371,7 +387,9 @@ PSDR_DEV void run_paths_async(SceneView<LDS> &S, const SensorDev &cam, const Pat
                 const Hit h = tr.hA, hx = tr.hB;
                 RayT<AD> ray1; ray1.o = its.p; ray1.d = wod;
                 if (do_nee && h.slot >= 0) {
+#if !PSDR_DIAG
                     if (COUNT) S.c_hits++;
+#endif
                     Its<AD> its1 = make_its<AD, LDS, false>(S, h, ray1, true);
                     if constexpr (has_env(LDS)) { if (T.env_emitter >= 0 && mesh_emitter(S, its1.mesh) == T.env_emitter) its1 = make_its<AD, LDS, true>(S, h, ray1, true); }
                     if ((detach(its1.t) > detach(dist) - kShadowEpsilon) && (mesh_emitter(S, its1.mesh) >= 0)) {
@@ -385,7 +403,9 @@ PSDR_DEV void run_paths_async(SceneView<LDS> &S, const SensorDev &cam, const Pat
                         if (pdf1 != 0.f) res = res + thr * emitter_val * bsdf_val2 * R(P.mis == 0 ? 1.f : mis_weight(ps.pdf, pdf1));
                     }
                 }
+#if !PSDR_DIAG
                 if (COUNT) { if (hx.slot >= 0) S.c_hits++; }
+#endif
                 const Its<AD> itx = make_its<AD, LDS, true>(S, hx, ext, depth >= 0);
                 if (depth < 0) {
                     its = itx;

@@ -18,6 +18,7 @@ constexpr float kTraceTMax = 100000000.f;   // reference scene_optix.cpp:376
 constexpr int kBlock = 256;
 constexpr int kBruteForceMax = 64;          // scenes with at most this many triangles skip the BVH
 constexpr int kParkWords = 12;              // LDS words per lane behind the traversal stack: the lane's two parked rays (trav4.h)
+constexpr int kColdRows = 11;               // LDS rows of a brute-force scene: per-lane state that only the start and the end of a path touch (paths.h::run_paths)
 constexpr int kTravRows = 26;               // LDS rows (of kBlock words) behind the stack of a BVH scene: parked rays, best hits, pair ring, ring heads (trav4.h)
 
 // EnvironmentMap after configure() (psdr_envmap_rec): too large for the LDS blob, read from global memory
@@ -53,8 +54,10 @@ struct SceneTables {
     int stack_lds, ref_bits;        // 4-wide BVH (trav4.h): stack entries kept in LDS, bits of a child code
     int *gstack;                    // deeper stack entries, [entry][lane of the grid] (NULL when stack_lds covers the tree)
     int gstack_stride;
-    int filt_off, n_filt;      // filter primitives of the brute-force tracer (4 words each, see filter.h)
+    int filt_off, n_filt;      // filter primitives of the brute-force tracer (6 words each, see filter.h)
     float center[3], radius;   // bounding sphere of all vertices
+    float filt_kmax;           // largest extent of a filter primitive
+    unsigned filt_hasb[2];     // per chunk of 32 filter primitives: bit (count - 1 - k) set when primitive k is a quad (has a second triangle)
     int env_emitter;           // index of the EnvironmentMap among the emitters, -1 = none
     const TexDev *tex;         // [n_bsdfs] or NULL when no BSDF is textured
     const MatDev *mat;         // [n_bsdfs] or NULL when every BSDF is Diffuse
@@ -175,7 +178,15 @@ template <int LDS> struct SceneView {
 typedef float f2 __attribute__((ext_vector_type(2)));
 PSDR_DEV f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-struct Hit { int slot; float u, v, t; };   // slot = device triangle slot (BVH leaf order), -1 = miss
+struct Hit { int slot; float u, v, t; };
+
+// m = 2 m + bit: the lane mask of a comparison (one __builtin_amdgcn_ballot_w64 per v_cmp) enters as the carry-in of
+// v_addc_co_u32 - one VALU instruction per mask update instead of v_cndmask + v_lshl_or
+PSDR_DEV unsigned mask_shift_in(unsigned m, unsigned long long lanes) {
+    unsigned r; unsigned long long carry_out;
+    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(r), "=s"(carry_out) : "v"(m), "s"(lanes));
+    return r;
+}   // slot = device triangle slot (BVH leaf order), -1 = miss
 
 // Möller–Trumbore exactly as the reference's own ray_intersect_triangle (include/psdr/utils.h:82-93)
 PSDR_DEV bool tri_test(const float4 &a, const float4 &b, const float4 &c, const Vec3f &o, const Vec3f &d, float &u, float &v, float &t) {
@@ -235,49 +246,43 @@ PSDR_DEV Hit trace_scene(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
         // exact tri_test then runs on the few surviving triangles of each lane.  See trace2 below for the two phases;
         // this is its one-ray form.  Same tri_test, same (t, id) order => same hit as the BVH path.
         if (COUNT) { S.c_rays++; S.c_tris += (unsigned) T.n_tris; }
-        unsigned m0 = 0u, m1 = 0u;
-        const float s_ray = norm(o - Vec3f(T.center[0], T.center[1], T.center[2])) + T.radius;
-        {
-            const float4 *prim = S.G + T.filt_off;
-            float4 a = prim[0], b = prim[1], c = prim[2], g = prim[3];
-            for (int k = 0; k < T.n_filt; ++k) {
-                const int kn = (k + 1 < T.n_filt) ? k + 1 : k;
-                const float4 na = prim[4 * kn], nb = prim[4 * kn + 1], nc = prim[4 * kn + 2], ng = prim[4 * kn + 3];
-                const Vec3f p0(a.x, a.y, a.z), e1(a.w, b.x, b.y), e2(b.z, b.w, c.x);
-                const Vec3f h = cross(d, e2);
-                const float det = dot(e1, h);
-                const Vec3f s = o - p0;
-                const float un = dot(s, h);
-                const Vec3f q = cross(s, e1);
-                const float vn = dot(d, q), tn = dot(e2, q);
-                const unsigned db = __float_as_uint(det), sg = db & 0x80000000u;
-                const float ad = __uint_as_float(db & 0x7fffffffu);
-                const float ua = __uint_as_float(__float_as_uint(un) ^ sg), va = __uint_as_float(__float_as_uint(vn) ^ sg);
-                const float ta = __uint_as_float(__float_as_uint(tn) ^ sg);
-                const float hi_u = fmaf(c.y, ad, -ua), hi_v = fmaf(c.z, ad, -va), hi_s = fmaf(c.w, ad, -(ua + va));
-                const float m = __builtin_fminf(__builtin_fminf(__builtin_fminf(ua, va), __builtin_fminf(hi_u, hi_v)), hi_s);
-                const float kq = g.w * 32768.f, slack = g.w * (s_ray + kq);          // absolute slack of a quad (filter.h)
-                const bool pass = __builtin_fminf(fmaf(ad, 3.8146973e-06f, m) + slack, fmaf(slack, kq, ta)) >= 0.f;
-                const float sel = fmaf(g.y, ua, -(g.x * va)), band = fmaf(ad, 1e-3f, slack) * (g.x + g.y);
-                const int sab = __float_as_int(g.z), sa = sab & 0xff, sb = (sab >> 8) & 0xff;
-                const unsigned a_lo = sa < 32 ? 1u << sa : 0u, a_hi = sa >= 32 ? 1u << (sa - 32) : 0u;
-                const unsigned b_lo = sb < 32 ? 1u << sb : 0u, b_hi = (sb >= 32 && sb < 64) ? 1u << (sb - 32) : 0u;
-                const bool in_a = pass & (sel >= -band), in_b = pass & (sel <= band);
-                m0 |= (in_a ? a_lo : 0u) | (in_b ? b_lo : 0u);
-                m1 |= (in_a ? a_hi : 0u) | (in_b ? b_hi : 0u);
-                a = na; b = nb; c = nc; g = ng;
+        const Vec3f oc = o - Vec3f(T.center[0], T.center[1], T.center[2]);
+        const Vec3f m = cross(oc, d);
+        const float s_ray = norm(oc) + T.radius + T.filt_kmax, s_t = s_ray * T.filt_kmax;
+        for (int base = 0; base < T.n_filt; base += 32) {
+            const int cnt = T.n_filt - base < 32 ? T.n_filt - base : 32;
+            unsigned ma = 0u, mb = 0u;
+            const float4 *prim = S.G + T.filt_off + 6 * base;
+            for (int k = 0; k < cnt; ++k) {
+                const float4 w0 = prim[6 * k], w1 = prim[6 * k + 1], w2 = prim[6 * k + 2], w3 = prim[6 * k + 3], w4 = prim[6 * k + 4], w5 = prim[6 * k + 5];
+                const float un = fmaf(d.z, w1.y, fmaf(d.y, w1.x, fmaf(d.x, w0.w, fmaf(m.z, w0.z, fmaf(m.y, w0.y, m.x * w0.x)))));
+                const float me1 = fmaf(m.z, w2.x, fmaf(m.y, w1.w, m.x * w1.z));
+                const float vn = fmaf(d.z, w2.w, fmaf(d.y, w2.z, fmaf(d.x, w2.y, -me1)));
+                const float dn = fmaf(d.z, w3.z, fmaf(d.y, w3.y, d.x * w3.x));                   // = -det
+                const float tn = fmaf(oc.z, w3.z, fmaf(oc.y, w3.y, fmaf(oc.x, w3.x, w3.w)));
+                const float sn = __builtin_copysignf(1.f, dn);
+                const float ad = dn * sn, ua = -(un * sn), va = -(vn * sn), ta = -(tn * sn);
+                const float hi_u = fmaf(w4.x, ad, -ua), hi_v = fmaf(w4.y, ad, -va), hi_s = fmaf(w4.z, ad, -(ua + va));
+                const float slack = w5.z * s_ray, margin = fmaf(ad, 3.8146973e-06f, slack), st = w5.z * s_t;
+                const float sel = fmaf(w5.x, ua, -(w4.w * va)), band = fmaf(ad, 1e-3f, slack) * w5.y;
+                const float mn = __builtin_fminf(__builtin_fminf(__builtin_fminf(ua, va), hi_u), __builtin_fminf(hi_v, hi_s));
+                const unsigned long long pass = __builtin_amdgcn_ballot_w64(mn >= -margin) & __builtin_amdgcn_ballot_w64(ta >= -st);
+                ma = mask_shift_in(ma, pass & __builtin_amdgcn_ballot_w64(sel >= -band));
+                mb = mask_shift_in(mb, pass & __builtin_amdgcn_ballot_w64(sel <= band));
             }
-        }
-        for (;;) {
-            const bool more = (m0 | m1) != 0u;
-            if (__ballot(more) == 0ull) break;
-            int k = 0;
-            if (m0 != 0u) { k = __builtin_ctz(m0); m0 &= m0 - 1u; } else if (m1 != 0u) { k = 32 + __builtin_ctz(m1); m1 &= m1 - 1u; }
-            const float4 a = S.ld(T.trav_off + 3 * k), b = S.ld(T.trav_off + 3 * k + 1), c = S.ld(T.trav_off + 3 * k + 2);
-            float u, v, t;
-            const bool ok = more & tri_test(a, b, c, o, d, u, v, t);
-            const int id = __float_as_int(c.y);
-            if (ok & ((t < best_t) | ((t == best_t) & (id < best_id)))) { best_t = t; best_id = id; best.slot = k; best.u = u; best.v = v; best.t = t; }
+            mb &= T.filt_hasb[base >> 5];
+            for (;;) {
+                const bool more = (ma | mb) != 0u;
+                if (__ballot(more) == 0ull) break;
+                int pos = 0, sh = 0;
+                if (ma != 0u) { pos = __builtin_ctz(ma); ma &= ma - 1u; } else if (mb != 0u) { pos = __builtin_ctz(mb); mb &= mb - 1u; sh = 8; }
+                const int k = (S.ldi(T.filt_off, 24 * (base + cnt - 1 - pos) + 23) >> sh) & 0xff;
+                const float4 a = S.ld(T.trav_off + 3 * k), b = S.ld(T.trav_off + 3 * k + 1), c = S.ld(T.trav_off + 3 * k + 2);
+                float u, v, t;
+                const bool ok = more & tri_test(a, b, c, o, d, u, v, t);
+                const int id = __float_as_int(c.y);
+                if (ok & ((t < best_t) | ((t == best_t) & (id < best_id)))) { best_t = t; best_id = id; best.slot = k; best.u = u; best.v = v; best.t = t; }
+            }
         }
         return best;
     }
@@ -312,92 +317,91 @@ PSDR_DEV void trace2(SceneView<LDS> &S, const Vec3f &oA_, const Vec3f &dA, bool 
     // Both rays ride in the two halves of packed-f32 registers (element-wise identical to the scalar instructions).
     //
     // Two phases.  The exact test spends more than half of its issue cycles on the IEEE division and on eight
-    // compares (measured on gfx950: v_mul/v_add/v_fmac 2 cycles per wave64, v_fma 3, v_cmp 4.3, v_rcp 8.2, the
-    // division sequence 44).  Phase 1 therefore only FILTERS: the Moeller-Trumbore numerators and the determinant,
-    // then one sign-folded min3 test that is conservative (it accepts everything tri_test accepts, with a 2^-18
-    // relative margin that covers the rounding of 1/det and of the three products) and a per-lane bit mask of the
-    // survivors.  Phase 2 runs the exact tri_test - same arithmetic, same (t, id) order as ever - on the 1-5
-    // surviving triangles of each lane.  The hits are bit-equal to the single-phase loop.
-    const f2 ox = {oA.x, oB.x}, oy = {oA.y, oB.y}, oz = {oA.z, oB.z};
-    const f2 dx = {dA.x, dB.x}, dy = {dA.y, dB.y}, dz = {dA.z, dB.z};
-    unsigned mA0 = 0u, mA1 = 0u, mB0 = 0u, mB1 = 0u;
+    // compares (measured on gfx950, tools/ubench/pkrate.hip: v_mul/v_add/v_fmac 2.6 cycles per wave64, v_fma 3.3,
+    // v_cmp / v_min3 / anything reading an SGPR 4.3, a packed instruction 4.4-5.4, v_rcp 8.3, the division
+    // sequence 44).  Phase 1 therefore only FILTERS, and in a form that is nothing but dot products of per-ray
+    // constants with per-primitive constants the host precomputes (filter.h): with oc = o - centre, m = oc x d,
+    //     u-numerator = m.e2 + d.(p x e2)      v-numerator = d.(e1 x p) - m.e1
+    //     -det        = d.N                    t-numerator = oc.N - p.N            (p = p0 - centre, N = e1 x e2)
+    // 18 packed multiply-adds for two rays instead of the 27 of the cross-product form.  The sign of det is folded
+    // into the numerators and one min3 pair tests the window; every test carries an absolute slack
+    // 2^-15 K (|oc| + R + K) that covers the roundings of both forms (filter.h), so the filter accepts everything
+    // tri_test accepts.  The survivors are one bit per primitive and side of the quad's diagonal, shifted into a
+    // per-lane mask by v_addc_co_u32 (the comparison's lane mask is the carry-in).  Phase 2 runs the exact tri_test -
+    // same arithmetic, same (t, id) order as ever - on the 1-5 surviving triangles of each lane.
     const Vec3f ctr(T.center[0], T.center[1], T.center[2]);
-    const f2 s_ray = {norm(oA - ctr) + T.radius, norm(oB - ctr) + T.radius};
-    {
-        // filter primitives (filter.h): {p0.xyz, e1.x} {e1.yz, e2.xy} {e2.z, umax, vmax, smax} {da, db, slot_a, slot_b}
-        const float4 *prim = S.G + T.filt_off;
-        float4 a = prim[0], b = prim[1], c = prim[2], g = prim[3];
-        for (int k = 0; k < T.n_filt; ++k) {
-            const int kn = (k + 1 < T.n_filt) ? k + 1 : k;
-            const float4 na = prim[4 * kn], nb = prim[4 * kn + 1], nc = prim[4 * kn + 2], ng = prim[4 * kn + 3];
-            const f2 e1x = a.w, e1y = b.x, e1z = b.y, e2x = b.z, e2y = b.w, e2z = c.x;
-            const f2 hx = pk_fma(dy, e2z, -(dz * e2y)), hy = pk_fma(dz, e2x, -(dx * e2z)), hz = pk_fma(dx, e2y, -(dy * e2x));
-            const f2 det = pk_fma(e1z, hz, pk_fma(e1y, hy, e1x * hx));
-            const f2 sx = ox - (f2) a.x, sy = oy - (f2) a.y, sz = oz - (f2) a.z;
-            const f2 un = pk_fma(sz, hz, pk_fma(sy, hy, sx * hx));
-            const f2 qx = pk_fma(sy, e1z, -(sz * e1y)), qy = pk_fma(sz, e1x, -(sx * e1z)), qz = pk_fma(sx, e1y, -(sy * e1x));
-            const f2 vn = pk_fma(dz, qz, pk_fma(dy, qy, dx * qx));
-            const f2 tn = pk_fma(e2z, qz, pk_fma(e2y, qy, e2x * qx));
-            // fold the sign of det into the numerators: u = ua/ad, v = va/ad, t = ta/ad with ad = |det|
-            f2 ua, va, ta, ad;
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const unsigned db = __float_as_uint(det[r]), sg = db & 0x80000000u;
-                ad[r] = __uint_as_float(db & 0x7fffffffu);
-                ua[r] = __uint_as_float(__float_as_uint(un[r]) ^ sg);
-                va[r] = __uint_as_float(__float_as_uint(vn[r]) ^ sg);
-                ta[r] = __uint_as_float(__float_as_uint(tn[r]) ^ sg);
-            }
-            const f2 hi_u = pk_fma((f2) c.y, ad, -ua), hi_v = pk_fma((f2) c.z, ad, -va), hi_s = pk_fma((f2) c.w, ad, -(ua + va));
-            const float kq = g.w * 32768.f;
-            const f2 slack = (f2) g.w * (s_ray + (f2) kq);                    // absolute slack of a quad (filter.h)
-            const f2 margin = pk_fma(ad, (f2) 3.8146973e-06f, slack);         // 2^-18 |det| + slack
-            const f2 tlo = pk_fma(slack, (f2) kq, ta);
-            const f2 sel = pk_fma((f2) g.y, ua, -((f2) g.x * va));            // side of the quad's diagonal
-            const f2 band = pk_fma(ad, (f2) 1e-3f, slack) * (f2) (g.x + g.y);
-            const int sab = __float_as_int(g.z), sa = sab & 0xff, sb = (sab >> 8) & 0xff;
-            const unsigned a_lo = sa < 32 ? 1u << sa : 0u, a_hi = sa >= 32 ? 1u << (sa - 32) : 0u;
-            const unsigned b_lo = sb < 32 ? 1u << sb : 0u, b_hi = (sb >= 32 && sb < 64) ? 1u << (sb - 32) : 0u;
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const float m = __builtin_fminf(__builtin_fminf(__builtin_fminf(ua[r], va[r]), __builtin_fminf(hi_u[r], hi_v[r])), hi_s[r]);
-                const bool pass = __builtin_fminf(m + margin[r], tlo[r]) >= 0.f;
-                const bool in_a = pass & (sel[r] >= -band[r]), in_b = pass & (sel[r] <= band[r]);
-                const unsigned lo = (in_a ? a_lo : 0u) | (in_b ? b_lo : 0u), hi = (in_a ? a_hi : 0u) | (in_b ? b_hi : 0u);
-                if (r == 0) { mA0 |= lo; mA1 |= hi; } else { mB0 |= lo; mB1 |= hi; }
-            }
-            a = na; b = nb; c = nc; g = ng;
-        }
-    }
+    const Vec3f ocA = oA - ctr, ocB = oB - ctr;
+    const f2 ox = {ocA.x, ocB.x}, oy = {ocA.y, ocB.y}, oz = {ocA.z, ocB.z};
+    const f2 dx = {dA.x, dB.x}, dy = {dA.y, dB.y}, dz = {dA.z, dB.z};
+    const f2 mx = pk_fma(oy, dz, -(oz * dy)), my = pk_fma(oz, dx, -(ox * dz)), mz = pk_fma(ox, dy, -(oy * dx));
+    const float kmax = T.filt_kmax;
+    const f2 s_ray = {norm(ocA) + T.radius + kmax, norm(ocB) + T.radius + kmax};
     float btA = __builtin_inff(), btB = __builtin_inff();
     int bidA = 0x7fffffff, bidB = 0x7fffffff;
-    for (;;) {
-        const bool moreA = (mA0 | mA1) != 0u, moreB = (mB0 | mB1) != 0u;
-        if (__ballot(moreA || moreB) == 0ull) break;
-        int kA = 0, kB = 0;
-        if (mA0 != 0u) { kA = __builtin_ctz(mA0); mA0 &= mA0 - 1u; } else if (mA1 != 0u) { kA = 32 + __builtin_ctz(mA1); mA1 &= mA1 - 1u; }
-        if (mB0 != 0u) { kB = __builtin_ctz(mB0); mB0 &= mB0 - 1u; } else if (mB1 != 0u) { kB = 32 + __builtin_ctz(mB1); mB1 &= mB1 - 1u; }
-        const float4 aA = S.ld(T.trav_off + 3 * kA), bA = S.ld(T.trav_off + 3 * kA + 1), cA = S.ld(T.trav_off + 3 * kA + 2);
-        const float4 aB = S.ld(T.trav_off + 3 * kB), bB = S.ld(T.trav_off + 3 * kB + 1), cB = S.ld(T.trav_off + 3 * kB + 2);
-        const f2 p0x = {aA.x, aB.x}, p0y = {aA.y, aB.y}, p0z = {aA.z, aB.z};
-        const f2 e1x = {aA.w, aB.w}, e1y = {bA.x, bB.x}, e1z = {bA.y, bB.y};
-        const f2 e2x = {bA.z, bB.z}, e2y = {bA.w, bB.w}, e2z = {cA.x, cB.x};
-        const f2 hx = pk_fma(dy, e2z, -(dz * e2y)), hy = pk_fma(dz, e2x, -(dx * e2z)), hz = pk_fma(dx, e2y, -(dy * e2x));
-        const f2 det = pk_fma(e1z, hz, pk_fma(e1y, hy, e1x * hx));
-        f2 f; f.x = 1.f / det.x; f.y = 1.f / det.y;
-        const f2 sx = ox - p0x, sy = oy - p0y, sz = oz - p0z;
-        const f2 u = f * pk_fma(sz, hz, pk_fma(sy, hy, sx * hx));
-        const f2 qx = pk_fma(sy, e1z, -(sz * e1y)), qy = pk_fma(sz, e1x, -(sx * e1z)), qz = pk_fma(sx, e1y, -(sy * e1x));
-        const f2 v = f * pk_fma(dz, qz, pk_fma(dy, qy, dx * qx));
-        const f2 t = f * pk_fma(e2z, qz, pk_fma(e2y, qy, e2x * qx));
-        const f2 uv = u + v;
-        const int idA = __float_as_int(cA.y), idB = __float_as_int(cB.y);
-        const bool okA = moreA & (u.x >= 0.f) & (v.x >= 0.f) & (uv.x <= 1.f) & (t.x > kRayEpsilon) & (t.x < kTraceTMax);
-        const bool okB = moreB & (u.y >= 0.f) & (v.y >= 0.f) & (uv.y <= 1.f) & (t.y > kRayEpsilon) & (t.y < kTraceTMax);
-        const bool betA = okA & ((t.x < btA) | ((t.x == btA) & (idA < bidA)));
-        const bool betB = okB & ((t.y < btB) | ((t.y == btB) & (idB < bidB)));
-        if (betA) { btA = t.x; bidA = idA; hA.slot = kA; hA.u = u.x; hA.v = v.x; hA.t = t.x; }
-        if (betB) { btB = t.y; bidB = idB; hB.slot = kB; hB.u = u.y; hB.v = v.y; hB.t = t.y; }
+    for (int base = 0; base < T.n_filt; base += 32) {
+        const int cnt = T.n_filt - base < 32 ? T.n_filt - base : 32;
+        unsigned aA = 0u, bA = 0u, aB = 0u, bB = 0u;
+        {
+            // filter primitives (filter.h): {e2, A.x} {A.yz, e1.xy} {e1.z, B} {N, -p.N} {umax, vmax, smax, da} {db, da + db, 2^-15 K, slots}
+            const float4 *prim = S.G + T.filt_off + 6 * base;
+            for (int k = 0; k < cnt; ++k) {
+                const float4 w0 = prim[6 * k], w1 = prim[6 * k + 1], w2 = prim[6 * k + 2], w3 = prim[6 * k + 3], w4 = prim[6 * k + 4], w5 = prim[6 * k + 5];
+                const f2 un = pk_fma(dz, (f2) w1.y, pk_fma(dy, (f2) w1.x, pk_fma(dx, (f2) w0.w, pk_fma(mz, (f2) w0.z, pk_fma(my, (f2) w0.y, mx * (f2) w0.x)))));
+                const f2 me1 = pk_fma(mz, (f2) w2.x, pk_fma(my, (f2) w1.w, mx * (f2) w1.z));
+                const f2 vn = pk_fma(dz, (f2) w2.w, pk_fma(dy, (f2) w2.z, pk_fma(dx, (f2) w2.y, -me1)));
+                const f2 dn = pk_fma(dz, (f2) w3.z, pk_fma(dy, (f2) w3.y, dx * (f2) w3.x));          // = -det
+                const f2 tn = pk_fma(oz, (f2) w3.z, pk_fma(oy, (f2) w3.y, pk_fma(ox, (f2) w3.x, (f2) w3.w)));
+                // fold the sign of det into the numerators: u = ua/ad, v = va/ad, t = ta/ad with ad = |det|
+                const f2 sn = {__builtin_copysignf(1.f, dn.x), __builtin_copysignf(1.f, dn.y)};
+                const f2 ad = dn * sn, ua = -(un * sn), va = -(vn * sn), ta = -(tn * sn);
+                const f2 hi_u = pk_fma((f2) w4.x, ad, -ua), hi_v = pk_fma((f2) w4.y, ad, -va), hi_s = pk_fma((f2) w4.z, ad, -(ua + va));
+                const f2 slack = (f2) w5.z * s_ray;                                // absolute slack (filter.h)
+                const f2 margin = pk_fma(ad, (f2) 3.8146973e-06f, slack);         // 2^-18 |det| + slack
+                const f2 st = slack * (f2) kmax;
+                const f2 sel = pk_fma((f2) w5.x, ua, -((f2) w4.w * va));          // side of the quad's diagonal
+                const f2 band = pk_fma(ad, (f2) 1e-3f, slack) * (f2) w5.y;
+                const float mnA = __builtin_fminf(__builtin_fminf(__builtin_fminf(ua.x, va.x), hi_u.x), __builtin_fminf(hi_v.x, hi_s.x));
+                const float mnB = __builtin_fminf(__builtin_fminf(__builtin_fminf(ua.y, va.y), hi_u.y), __builtin_fminf(hi_v.y, hi_s.y));
+                const unsigned long long passA = __builtin_amdgcn_ballot_w64(mnA >= -margin.x) & __builtin_amdgcn_ballot_w64(ta.x >= -st.x);
+                const unsigned long long passB = __builtin_amdgcn_ballot_w64(mnB >= -margin.y) & __builtin_amdgcn_ballot_w64(ta.y >= -st.y);
+                aA = mask_shift_in(aA, passA & __builtin_amdgcn_ballot_w64(sel.x >= -band.x));
+                bA = mask_shift_in(bA, passA & __builtin_amdgcn_ballot_w64(sel.x <= band.x));
+                aB = mask_shift_in(aB, passB & __builtin_amdgcn_ballot_w64(sel.y >= -band.y));
+                bB = mask_shift_in(bB, passB & __builtin_amdgcn_ballot_w64(sel.y <= band.y));
+            }
+        }
+        bA &= T.filt_hasb[base >> 5]; bB &= T.filt_hasb[base >> 5];
+        for (;;) {
+            const bool moreA = (aA | bA) != 0u, moreB = (aB | bB) != 0u;
+            if (__ballot(moreA || moreB) == 0ull) break;
+            int pA = 0, pB = 0, shA = 0, shB = 0;
+            if (aA != 0u) { pA = __builtin_ctz(aA); aA &= aA - 1u; } else if (bA != 0u) { pA = __builtin_ctz(bA); bA &= bA - 1u; shA = 8; }
+            if (aB != 0u) { pB = __builtin_ctz(aB); aB &= aB - 1u; } else if (bB != 0u) { pB = __builtin_ctz(bB); bB &= bB - 1u; shB = 8; }
+            const int kA = (S.ldi(T.filt_off, 24 * (base + cnt - 1 - pA) + 23) >> shA) & 0xff;
+            const int kB = (S.ldi(T.filt_off, 24 * (base + cnt - 1 - pB) + 23) >> shB) & 0xff;
+            const float4 aA4 = S.ld(T.trav_off + 3 * kA), bA4 = S.ld(T.trav_off + 3 * kA + 1), cA4 = S.ld(T.trav_off + 3 * kA + 2);
+            const float4 aB4 = S.ld(T.trav_off + 3 * kB), bB4 = S.ld(T.trav_off + 3 * kB + 1), cB4 = S.ld(T.trav_off + 3 * kB + 2);
+            const f2 rox = {oA.x, oB.x}, roy = {oA.y, oB.y}, roz = {oA.z, oB.z};
+            const f2 p0x = {aA4.x, aB4.x}, p0y = {aA4.y, aB4.y}, p0z = {aA4.z, aB4.z};
+            const f2 e1x = {aA4.w, aB4.w}, e1y = {bA4.x, bB4.x}, e1z = {bA4.y, bB4.y};
+            const f2 e2x = {bA4.z, bB4.z}, e2y = {bA4.w, bB4.w}, e2z = {cA4.x, cB4.x};
+            const f2 hx = pk_fma(dy, e2z, -(dz * e2y)), hy = pk_fma(dz, e2x, -(dx * e2z)), hz = pk_fma(dx, e2y, -(dy * e2x));
+            const f2 det = pk_fma(e1z, hz, pk_fma(e1y, hy, e1x * hx));
+            f2 f; f.x = 1.f / det.x; f.y = 1.f / det.y;
+            const f2 sx = rox - p0x, sy = roy - p0y, sz = roz - p0z;
+            const f2 u = f * pk_fma(sz, hz, pk_fma(sy, hy, sx * hx));
+            const f2 qx = pk_fma(sy, e1z, -(sz * e1y)), qy = pk_fma(sz, e1x, -(sx * e1z)), qz = pk_fma(sx, e1y, -(sy * e1x));
+            const f2 v = f * pk_fma(dz, qz, pk_fma(dy, qy, dx * qx));
+            const f2 t = f * pk_fma(e2z, qz, pk_fma(e2y, qy, e2x * qx));
+            const f2 uv = u + v;
+            const int idA = __float_as_int(cA4.y), idB = __float_as_int(cB4.y);
+            const bool okA = moreA & (u.x >= 0.f) & (v.x >= 0.f) & (uv.x <= 1.f) & (t.x > kRayEpsilon) & (t.x < kTraceTMax);
+            const bool okB = moreB & (u.y >= 0.f) & (v.y >= 0.f) & (uv.y <= 1.f) & (t.y > kRayEpsilon) & (t.y < kTraceTMax);
+            const bool betA = okA & ((t.x < btA) | ((t.x == btA) & (idA < bidA)));
+            const bool betB = okB & ((t.y < btB) | ((t.y == btB) & (idB < bidB)));
+            if (betA) { btA = t.x; bidA = idA; hA.slot = kA; hA.u = u.x; hA.v = v.x; hA.t = t.x; }
+            if (betB) { btB = t.y; bidB = idB; hB.slot = kB; hB.u = u.y; hB.v = v.y; hB.t = t.y; }
+        }
     }
 }
 

@@ -187,6 +187,9 @@ template <int LDS> PSDR_DEV void t4_enqueue(const SceneView<LDS> &S, const T4Lds
 template <int LDS, bool COUNT> PSDR_DEV void t4_test_pairs(SceneView<LDS> &S, const T4Lds<LDS> &L, unsigned from, int n) {
     const SceneTables &T = *S.T;
     const int rank = __popcll(__ballot(true) & ((1ull << (threadIdx.x & 63)) - 1ull));
+#if PSDR_DIAG == 2
+    if (COUNT) S.c_hits++;
+#endif
     if (rank < n) {
         const unsigned e = L.ring[(from + (unsigned) rank) & (kQueueCap - 1)];
         const int owner = (int) (e & 63u), slot = (int) (e >> 7);
@@ -228,6 +231,9 @@ PSDR_DEV void trav4_run(SceneView<LDS> &S, Trav4 &tr, int max_busy) {
     const int n_lanes = __popcll(__ballot(true));
     for (;;) {
         const unsigned tested = L.heads[1];
+#if PSDR_DIAG == 3
+        if (COUNT) S.c_hits++;
+#endif
         if (tr.code == kT4Done) {
             if (tr.cur >= 0 && tr.last_pair <= tested) {       // the ray's stack is empty and its last pair has been tested
                 const Hit h = t4_result(S, L, tr);
@@ -245,6 +251,9 @@ PSDR_DEV void trav4_run(SceneView<LDS> &S, Trav4 &tr, int max_busy) {
         for (;;) {
             if (tr.code < leaf_bit) t4_node<LDS, COUNT>(S, L, tr, cmask);
             else if (tr.code != kT4Done) t4_enqueue(S, L, tr, cmask, leaf_bit);
+#if PSDR_DIAG == 1
+            if (COUNT) S.c_hits++;
+#endif
             const int waiting = (int) (L.heads[0] - tested);
             if (waiting >= n_lanes || __ballot(tr.code != kT4Done) == 0ull) break;
         }

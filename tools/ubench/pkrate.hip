@@ -11,7 +11,7 @@ __global__ void __launch_bounds__(256) k(float *out, float s0, float s1, int ite
     for (int i = 0; i < 8; ++i) a[i] = f2{x + i, x - i};
     f2 b = {1.0001f, 0.9999f}, c = {1e-6f, -1e-6f};
     f2 sg = {s0, s1};
-    unsigned long long mask = __builtin_amdgcn_read_exec() ^ (unsigned long long) iters;
+    unsigned long long mask = __builtin_amdgcn_read_exec() ^ (unsigned long long) iters, dummy = 0;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -37,6 +37,15 @@ __global__ void __launch_bounds__(256) k(float *out, float s0, float s1, int ite
                 if (MODE == 18) { asm volatile("v_mov_b32 %0, %1" : "+v"(a[i].x) : "v"(b.x)); }
                 if (MODE == 19) { asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i].x) : "v"(b.x), "v"(c.x)); }
                 if (MODE == 20) { asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[i].x)); }
+                if (MODE == 21) { asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i].x) : "s"(s0), "v"(c.x)); }
+                if (MODE == 22) { asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[i].x) : "s"(s0)); }
+                if (MODE == 23) { asm volatile("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(a[i].x), "=s"(dummy) : "s"(mask)); }
+                if (MODE == 24) { asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x6c" : "+v"(a[i].x) : "v"(b.x), "s"(s0)); }
+                if (MODE == 25) { asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i].x) : "v"(b.x), "v"(c.x)); }
+                if (MODE == 26) { asm volatile("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(dummy) : "v"(a[i].x), "v"(b.x)); }
+                if (MODE == 27) { asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i].x) : "v"(b.x)); }
+                if (MODE == 28) { asm volatile("v_fmac_f32 %0, %1, %2\n\tv_fmac_f32 %3, %1, %4" : "+v"(a[i].x), "+v"(a[i].y) : "s"(s0), "v"(c.x), "v"(c.y)); }
+                if (MODE == 29) { asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(a[i]) : "s"(sg), "v"(c)); }
                 if (MODE == 12) { asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i].x) : "v"(b.x)); }
             }
         }
@@ -85,6 +94,15 @@ int main() {
         run<18>("v_mov_b32", w);
         run<19>("v_fmac_f32", w);
         run<20>("v_sqrt_f32", w);
+        run<21>("v_fmac_f32 sgpr src0 (VOP2)", w);
+        run<22>("v_mul_f32 sgpr src0 (VOP2)", w);
+        run<23>("v_addc_co_u32_e64 sgpr carry", w);
+        run<24>("v_bitop3_b32 sgpr", w);
+        run<25>("v_and_or_b32", w);
+        run<26>("v_cmp_le_f32_e64 -> sgpr pair", w);
+        run<27>("v_min_f32", w);
+        run<28>("2 x v_fmac_f32 sgpr (per pair)", w);
+        run<29>("v_pk_fma_f32 sgpr acc form", w);
     }
     return 0;
 }
