@@ -232,6 +232,12 @@ int psdr_hip_env_sample(const psdr_hip_scene *scene, int32_t n, const float *ref
 int psdr_hip_env_pdf(const psdr_hip_scene *scene, int32_t n, const float *ref_p, const float *p, const float *nrm,
                      float *out_pdf, void *stream);
 
+/* EnvironmentMap::configure, the cell masses of its HyperCubeDistribution2f (reference src/emitter/envmap.cpp:17-44,
+ * src/core/cube_distrb.cpp:22-29: luminance x sin(theta) at the centre of each of the 2(W-1) x 2(H-1) cells, which the
+ * reference evaluates on the device in every Scene::configure).  HOST arrays: texels[height*width*3] ->
+ * mass[2(width-1) * 2(height-1)], cell index = cx * 2(height-1) + cy.  The prefix sums stay with the caller. */
+int psdr_hip_env_cell_masses(const float *texels, int32_t width, int32_t height, float *mass);
+
 /* Integrator::renderC: out_rgb is [n_pixels*3] float32, pixel-interleaved, pixel = y*W + x */
 int psdr_hip_render_c(const psdr_hip_scene *scene, const psdr_render_args *args, float *out_rgb, void *stream);
 /* Integrator::renderD + forward derivative: out_rgb = image, out_drgb = d image / d theta */

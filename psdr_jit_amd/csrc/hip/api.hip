@@ -444,6 +444,7 @@ struct psdr_hip_scene {
     DevBuf blob;
     bool lds = false;                    // scene class 1: staged in LDS (scene_dev.h)
     bool lean = false;                   // scene class 2: global memory, Diffuse BSDFs + area lights + environment map only
+    bool lds_mat = false;                // scene class 3: staged in LDS, any BSDF / bitmap parameter, no environment map (forward kernels)
     size_t smem_bytes = 0;
     SecEdgeTables E{};
     std::vector<std::unique_ptr<DevBuf>> bufs;
@@ -808,7 +809,10 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     static const bool no_lds = std::getenv("PSDR_NO_LDS") != nullptr;      // measurement knob: run small scenes through the global-memory classes
     sc->lds = !no_lds && !uses_bvh && blob_bytes + stack_bytes <= 40 * 1024 && T.env_emitter < 0 && T.tex == nullptr && T.mat == nullptr && T.pv == nullptr;      // (LDS class = brute-force scenes)
     sc->lean = !sc->lds && T.tex == nullptr && T.mat == nullptr && T.pv == nullptr;
-    sc->smem_bytes = (sc->lds ? blob_bytes : 0) + stack_bytes;
+    // class 3: the same staging for small scenes WITH materials / bitmap parameters (the material and texture tables stay in global
+    // memory; the triangle, BSDF, emitter and edge tables are what every path vertex reads)
+    sc->lds_mat = !no_lds && !sc->lds && !uses_bvh && blob_bytes + stack_bytes <= 40 * 1024 && T.env_emitter < 0 && T.pv == nullptr;
+    sc->smem_bytes = ((sc->lds || sc->lds_mat) ? blob_bytes : 0) + stack_bytes;
     if (sc->smem_bytes > 64 * 1024) return fail("BVH too deep for the LDS traversal stack");
     sc->n_leaves = bvh.n_leaves; sc->max_depth = bvh4.max_depth;
 
@@ -867,7 +871,7 @@ static inline int grid_for(const psdr_hip_scene *sc, long long n) {
 // Development builds can leave scene classes out (hipcc -DPSDR_CLS_MASK=4 compiles the class-2 kernels only: a third of the build
 // time); bit c = scene class c (scene_dev.h).  A scene of a class that is compiled out fails loudly.
 #ifndef PSDR_CLS_MASK
-#define PSDR_CLS_MASK 7
+#define PSDR_CLS_MASK 15
 #endif
 #if (PSDR_CLS_MASK) & 1
 #define ON_CLS0(...) __VA_ARGS__
@@ -883,6 +887,12 @@ static inline int grid_for(const psdr_hip_scene *sc, long long n) {
 #define ON_CLS2(...) __VA_ARGS__
 #else
 #define ON_CLS2(...) return fail("scene class 2 is compiled out of this development build")
+#endif
+
+#if (PSDR_CLS_MASK) & 8
+#define ON_CLS3(...) __VA_ARGS__
+#else
+#define ON_CLS3(...) return fail("scene class 3 is compiled out of this development build")
 #endif
 
 #if (PSDR_CLS_MASK) & 1
@@ -935,7 +945,8 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
     if (rank < 0 || rank >= count) return fail("bad shard rank");
     // the first-hit integrators (field_mode) live in the LDS=false instantiations only
     const bool use_lds = sc->lds && a->field_mode == 0;
-    const int cls = use_lds ? 1 : ((sc->lean && a->field_mode == 0) ? 2 : 0);        // scene class of the kernels (scene_dev.h)
+    // scene class of the kernels (scene_dev.h); class 3 has the plain forward instantiations only (the counted ones run class 0)
+    const int cls = use_lds ? 1 : ((sc->lean && a->field_mode == 0) ? 2 : ((sc->lds_mat && a->field_mode == 0 && !COUNT) ? 3 : 0));
     const int fh_field = a->field_mode - 1;
     if (a->field_mode < 0 || a->field_mode > 9) return fail("bad field_mode");
 
@@ -956,10 +967,12 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
             if (ad) {
                 if (cls == 1) ON_CLS1(LAUNCH((k_paths<true, 1, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
                 else if (cls == 2) ON_CLS2(LAUNCH((k_paths<true, 2, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
+                else if (cls == 3) ON_CLS3(LAUNCH((k_paths<true, 3, false, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
                 else ON_CLS0(LAUNCH((k_paths<true, 0, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
             } else {
                 if (cls == 1) ON_CLS1(LAUNCH((k_paths<false, 1, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
                 else if (cls == 2) ON_CLS2(LAUNCH((k_paths<false, 2, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
+                else if (cls == 3) ON_CLS3(LAUNCH((k_paths<false, 3, false, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
                 else ON_CLS0(LAUNCH((k_paths<false, 0, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
             }
         }
@@ -974,6 +987,7 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
                 if (next_queue(P.counter)) return 1;
                 if (cls == 1) ON_CLS1(LAUNCH((k_paths<false, 1, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
                 else if (cls == 2) ON_CLS2(LAUNCH((k_paths<false, 2, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
+                else if (cls == 3) ON_CLS3(LAUNCH((k_paths<false, 3, false, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
                 else ON_CLS0(LAUNCH((k_paths<false, 0, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
             }
         }
@@ -989,6 +1003,7 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
                 if (next_queue(P.counter)) return 1;
                 if (sc->lds) ON_CLS1(LAUNCH((k_secondary_edges<1, COUNT, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
                 else if (sc->lean) ON_CLS2(LAUNCH((k_secondary_edges<2, COUNT, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
+                else if (cls == 3) ON_CLS3(LAUNCH((k_secondary_edges<3, false, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
                 else ON_CLS0(LAUNCH((k_secondary_edges<0, COUNT, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
             }
         }
@@ -1047,7 +1062,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     if (rank < 0 || rank >= count) return fail("bad shard rank");
     // the first-hit integrators (field_mode) live in the LDS=false instantiations only
     const bool use_lds = sc->lds && a->field_mode == 0;
-    const int cls = use_lds ? 1 : ((sc->lean && a->field_mode == 0) ? 2 : 0);        // scene class of the kernels (scene_dev.h)
+    const int cls = use_lds ? 1 : ((sc->lean && a->field_mode == 0) ? 2 : 0);        // scene class of the kernels (scene_dev.h); the reverse mode has no class 3
     const int fh_field = a->field_mode - 1;
     if (a->field_mode < 0 || a->field_mode > 9) return fail("bad field_mode");
     SensorDev cam = sc->sensors[a->sensor_id];
@@ -1078,7 +1093,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     const int adj_cls = (use_lds && !adj_global) ? 1 : ((sc->lean || use_lds) && a->field_mode == 0 ? 2 : 0);
     // LDS: [blob (class 1)] [stacks] [per-lane records] [camera / env / material accumulators] [hot triangle rows, colours, emitters];
     // the number of hot triangle rows is what is left of the 160 KB
-    const size_t smem_base = adj_cls == 1 ? sc->smem_bytes : sc->smem_bytes - (sc->lds ? (size_t) T.blob_words * 16 : 0);
+    const size_t smem_base = adj_cls == 1 ? sc->smem_bytes : sc->smem_bytes - ((sc->lds || sc->lds_mat) ? (size_t) T.blob_words * 16 : 0);
     const int adj_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth);
     // Diffuse BSDFs + area lights under PathTracer: the reverse sweep (adjoint.h); everything else: record and probe
     static const bool no_sweep = std::getenv("PSDR_ADJ_PROBE") != nullptr;         // measurement knob: force the probe form
@@ -1186,6 +1201,25 @@ int psdr_hip_env_pdf(const psdr_hip_scene *sc, int32_t n, const float *ref_p, co
     if (n <= 0) return 0;
     hipLaunchKernelGGL(k_env_pdf, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t) stream, sc->T, n, ref_p, p, nrm, out_pdf);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+// cell masses of the environment map's sampling distribution: one thread per cell, the same envmath.h::cell_mass the host half's
+// test hook evaluates (bit-equal); 2 M cells of a 1024 x 512 map take ~0.1 ms instead of 80 ms on the host cores
+__global__ void k_env_cell_mass(const float *__restrict__ texels, int W, int H, int w2, int h2, int n, float *__restrict__ mass) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) mass[i] = env::cell_mass(texels, W, H, w2, h2, i);
+}
+int psdr_hip_env_cell_masses(const float *texels, int32_t width, int32_t height, float *mass) {
+    if (!texels || !mass) return fail("null texel / mass buffer");
+    if (width < 2 || height < 2) return fail("EnvironmentMap: the bitmap needs at least 2 x 2 texels");
+    const int w2 = (width - 1) << 1, h2 = (height - 1) << 1;
+    const long long n = (long long) w2 * h2;
+    if (n > 0x7fffffffll) return fail("EnvironmentMap: too many cells");
+    DevBuf tex, out;
+    if (tex.upload(texels, sizeof(float) * 3 * (size_t) width * height) || out.upload(nullptr, sizeof(float) * (size_t) n)) return 1;
+    hipLaunchKernelGGL(k_env_cell_mass, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) nullptr, tex.as<float>(), width, height, w2, h2, (int) n, (float *) out.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(mass, out.p, sizeof(float) * (size_t) n, hipMemcpyDeviceToHost));
     return 0;
 }
 int psdr_hip_ray_intersect(const psdr_hip_scene *sc, int32_t n, const float *o, const float *d, float *out, void *stream) {

@@ -97,9 +97,9 @@ struct Counters { unsigned long long rays, nodes, tris, hits; };
 //   1  small scene staged in LDS: Diffuse BSDFs and area lights only (all Cornell boxes)
 //   2  global memory, lean: Diffuse BSDFs, area lights and the environment map - the BVH scenes of the tutorials and of
 //      BASELINE config 5 do not pay registers for material code they do not use
-constexpr bool in_lds(int cls) { return cls == 1; }
-constexpr bool has_env(int cls) { return cls != 1; }
-constexpr bool has_mat(int cls) { return cls == 0; }
+constexpr bool in_lds(int cls) { return cls == 1 || cls == 3; }
+constexpr bool has_env(int cls) { return cls == 0 || cls == 2; }
+constexpr bool has_mat(int cls) { return cls == 0 || cls == 3; }
 
 constexpr int kEnvLookup = -1;         // id of an environment-map lookup in the lookup record (BSDF ids are >= 0)
 // a per-vertex BSDF interpolation at triangle slot s is recorded as id = kPvLookup - s, with the barycentrics as (u, v)

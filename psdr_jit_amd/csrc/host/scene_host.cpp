@@ -48,19 +48,25 @@ void Distrb::init(const std::vector<float> &p) {
 
 // ------------------------------------------------------------------------------------------------
 // EnvironmentMap::configure, reference src/emitter/envmap.cpp:17-44
-void EnvironmentMap::configure() {
+void EnvironmentMap::configure(bool on_device) {
     m_sampling_weight = 0.0f;
     PSDR_ASSERT(width > 1 && height > 1);
     PSDR_ASSERT_MSG(data.size() == (size_t) 3 * width * height, "Bitmap: invalid data size!");
     const int w2 = (width - 1) << 1, h2 = (height - 1) << 1;
     reso[0] = w2; reso[1] = h2;
     // the cell distribution depends on the texels only: rebuilt when they changed (2 M cells for a 1024 x 512 map; the reference
-    // recomputes it on the device in every Scene::configure), independent cells in parallel on the host cores
+    // recomputes it on the device in every Scene::configure).  Scene::configure evaluates the masses on the device
+    // (psdr_hip_env_cell_masses, one thread per cell); the host loop serves configure_host(), the device-less half the host tests
+    // drive - the same envmath.h::cell_mass, bit-equal results.  The double-precision prefix sums stay on the host.
     if (m_cells_dirty || (int) cell_distrb.pmf.size() != w2 * h2) {
         std::vector<float> mass((size_t) w2 * h2);
         const int n_cells = w2 * h2;
+        if (on_device) {
+            hip_check(psdr_hip_env_cell_masses(data.data(), width, height, mass.data()));
+        } else {
 #pragma omp parallel for schedule(static)
-        for (int idx = 0; idx < n_cells; ++idx) mass[idx] = psdr::env::cell_mass(data.data(), width, height, w2, h2, idx);
+            for (int idx = 0; idx < n_cells; ++idx) mass[idx] = psdr::env::cell_mass(data.data(), width, height, w2, h2, idx);
+        }
         cell_distrb.init(mass);
         m_cells_dirty = false;
     }
@@ -525,7 +531,9 @@ bool Scene::is_ready() const {
 void Scene::configure(const std::vector<int> &active_sensor) {
     using namespace std::chrono;
     const auto start_time = high_resolution_clock::now();
-    configure_host(active_sensor);
+    m_device_config = true;           // (device-side steps of the host half: the environment map's cell masses)
+    try { configure_host(active_sensor); } catch (...) { m_device_config = false; throw; }
+    m_device_config = false;
     upload();
     if (m_opts.log_level > 0) {
         std::ostringstream oss;
@@ -640,7 +648,7 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
         double total_weight = 0.0;
         for (Emitter *e : m_emitters) {
             if (EnvironmentMap *env = dynamic_cast<EnvironmentMap *>(e)) {
-                env->configure();
+                env->configure(m_device_config);
             } else {
                 AreaLight *al = static_cast<AreaLight *>(e);
                 PSDR_ASSERT(al->m_mesh != nullptr && al->m_mesh->m_ready);

@@ -154,7 +154,7 @@ struct EnvironmentMap : Emitter {
     std::string type_name() const override { return "EnvironmentMap"; }
     std::string to_string() const override;
     void set_transform(const M16 &mat) { to_world_left = mat; m_ready = false; }      // envmap.h:19-22
-    void configure();                                                                  // envmap.cpp:17-44
+    void configure(bool on_device = false);                                            // envmap.cpp:17-44 (on_device: cell masses by psdr_hip_env_cell_masses)
     int width = 0, height = 0;
     std::vector<float> data, d_data;                                                   // [height*width*3] row-major rgb (+ forward tangent, may be empty)
     float scale = 1.f, d_scale = 0.f;
@@ -287,6 +287,7 @@ struct Scene : Object {
     } snap;
     psdr_hip_scene *m_hip = nullptr;
     bool m_configured = false, m_host_ready = false;
+    bool m_device_config = false;      // configure_host() runs inside configure(): its device-side steps are allowed
 private:
     void rebuild_param_map();
     void release_device();

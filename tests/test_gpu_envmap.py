@@ -395,3 +395,30 @@ def test_ggx_bitmap_parameters(psdr, orc, kind, param):
         assert np.abs(wd).max() > 0 and product.rel_l2(dimg.cpu().numpy(), wd) < TOL
     c = psdr.PathTracer(3).renderC(sc, 0, seed=2).cpu().numpy()
     assert product.rel_l2(c, ref.render_c(max_depth=3, seed=2)) < TOL
+
+
+def test_env_cell_masses_on_the_device_equal_the_oracle(psdr, orc):
+    """Scene::configure evaluates the cell masses of the environment map on the device (psdr_hip_env_cell_masses, envmap.cpp:17-44,
+    cube_distrb.cpp:22-29): bit-equal to the oracle's and to the host half's (configure_host), through the C ABI and through Scene"""
+    import ctypes as C
+    from psdr_jit_amd import cabi
+    spec = scenes.envmap_scene(32, 32, 1, 0, 0, param=None)
+    ref = orc.OracleScene(spec, [0])
+    _, reso, cell_sum, pmf, cmf = ref.envmap_info()
+    dev = product.build_scene(spec)._snapshot()                       # Scene::configure: device masses
+    host = product.build_scene(spec, host_only=True)._snapshot()      # configure_host: the host loop
+    for snap in (dev, host):
+        assert tuple(snap["env_reso"]) == reso
+        assert np.array_equal(np.asarray(snap["env_cell_pmf"]).ravel(), pmf) and np.array_equal(np.asarray(snap["env_cell_cmf"]).ravel(), cmf)
+        assert float(snap["env_cell_sum"]) == cell_sum
+    # the entry point alone, on a larger and rougher map, against the oracle's configure of the same texels
+    W, H = 256, 128
+    tex = (scenes.synthetic_envmap(W, H) * (0.5 + np.random.default_rng(3).random((H, W, 1), dtype=np.float32))).astype(np.float32)
+    _, reso2, _, pmf2, _ = orc.OracleScene(scenes.envmap_scene(16, 16, 1, 0, 0, param=None, env=tex), [0]).envmap_info()
+    w2, h2 = 2 * (W - 1), 2 * (H - 1)
+    assert reso2 == (w2, h2)
+    mass = np.empty(w2 * h2, np.float32)
+    cabi.check(cabi.lib().psdr_hip_env_cell_masses(tex.ctypes.data_as(C.c_void_p), C.c_int32(W), C.c_int32(H), mass.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(mass, pmf2)
+    with pytest.raises(Exception):
+        cabi.check(cabi.lib().psdr_hip_env_cell_masses(tex.ctypes.data_as(C.c_void_p), C.c_int32(1), C.c_int32(H), mass.ctypes.data_as(C.c_void_p)))
