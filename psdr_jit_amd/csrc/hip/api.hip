@@ -1093,7 +1093,16 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     const int adj_cls = (use_lds && !adj_global) ? 1 : ((sc->lean || use_lds) && a->field_mode == 0 ? 2 : 0);
     // LDS: [blob (class 1)] [stacks] [per-lane records] [camera / env / material accumulators] [hot triangle rows, colours, emitters];
     // the number of hot triangle rows is what is left of the 160 KB
-    const size_t smem_base = adj_cls == 1 ? sc->smem_bytes : sc->smem_bytes - ((sc->lds || sc->lds_mat) ? (size_t) T.blob_words * 16 : 0);
+    // (the cold path-state rows of brute-force scenes belong to run_paths, i.e. to k_paths: the adjoint kernels get tables without them)
+#ifdef PSDR_NO_ASYNC
+    const int cold_rows = kColdRows;
+#else
+    const int cold_rows = T.n_tris > kBruteForceMax ? 0 : kColdRows;
+#endif
+    const size_t cold_bytes = (size_t) cold_rows * kBlock * sizeof(int);
+    SceneTables Ta = T;
+    Ta.stack_depth -= cold_rows;
+    const size_t smem_base = (adj_cls == 1 ? sc->smem_bytes : sc->smem_bytes - ((sc->lds || sc->lds_mat) ? (size_t) T.blob_words * 16 : 0)) - cold_bytes;
     const int adj_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth);
     // Diffuse BSDFs + area lights under PathTracer: the reverse sweep (adjoint.h); everything else: record and probe
     static const bool no_sweep = std::getenv("PSDR_ADJ_PROBE") != nullptr;         // measurement knob: force the probe form
@@ -1135,9 +1144,9 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
             P.hit_words = adj_hit_words(adj_depth); P.ext_words = adj_ext_words(adj_depth); P.lk_words = with_lookups ? 3 * adj_lk_entries(adj_depth) : 0;
             P.sweep = sweep ? 1 : 0;
             if (sweep) { P.hit_words = lane_words; P.ext_words = 0; P.lk_words = 0; }
-            if (adj_cls == 1) ON_CLS1(hipLaunchKernelGGL((k_interior_adjoint<1>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, cam, P));
-            else if (adj_cls == 2) ON_CLS2(hipLaunchKernelGGL((k_interior_adjoint<2>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, cam, P));
-            else ON_CLS0(hipLaunchKernelGGL((k_interior_adjoint<0>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), T, cam, P));
+            if (adj_cls == 1) ON_CLS1(hipLaunchKernelGGL((k_interior_adjoint<1>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), Ta, cam, P));
+            else if (adj_cls == 2) ON_CLS2(hipLaunchKernelGGL((k_interior_adjoint<2>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), Ta, cam, P));
+            else ON_CLS0(hipLaunchKernelGGL((k_interior_adjoint<0>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), Ta, cam, P));
         }
     }
     if (!a->pix_ids && (terms & PSDR_TERM_PRIMARY) && T.sppe > 0 && cam.n_edges > 0) {
@@ -1164,15 +1173,15 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         P.g_cam = g->g_camera;
         const size_t sec_acc = sizeof(float) * (6 * (size_t) sc->E.n + 22 * (size_t) T.n_tris);
         P.lds_acc = (sec_acc <= 48 * 1024) ? 1 : 0;
-        const size_t smem_sec = sc->smem_bytes + sizeof(float) * (size_t) kSecAdjScratch + (P.lds_acc ? sec_acc : 0);
+        const size_t smem_sec = sc->smem_bytes - cold_bytes + sizeof(float) * (size_t) kSecAdjScratch + (P.lds_acc ? sec_acc : 0);
         GuidingDev G{};
         const int use_g = a->guiding ? 1 : 0;
         if (a->guiding) G = a->guiding->G;
         if (P.n_local > 0) {
             if (next_queue(P.counter)) return 1;
             const int grid = grid_for(sc, P.n_local);
-            if (sc->lds) ON_CLS1(hipLaunchKernelGGL((k_secondary_edges<true, false, true>), dim3(grid), dim3(kBlock), smem_sec, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, (Counters *) nullptr));
-            else ON_CLS0(hipLaunchKernelGGL((k_secondary_edges<false, false, true>), dim3(grid), dim3(kBlock), smem_sec, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, (Counters *) nullptr));
+            if (sc->lds) ON_CLS1(hipLaunchKernelGGL((k_secondary_edges<true, false, true>), dim3(grid), dim3(kBlock), smem_sec, st, sc->blob.as<float4>(), Ta, sc->E, cam, P, G, use_g, (Counters *) nullptr));
+            else ON_CLS0(hipLaunchKernelGGL((k_secondary_edges<false, false, true>), dim3(grid), dim3(kBlock), smem_sec, st, sc->blob.as<float4>(), Ta, sc->E, cam, P, G, use_g, (Counters *) nullptr));
         }
     }
     HIPCHK(hipGetLastError());

@@ -584,7 +584,9 @@ PSDR_DEV void run_paths_async(SceneView<LDS> &S, const SensorDev &cam, const Pat
                     ext.o = its.p; ext.d = to_world<AD>(its, bs.wo);
                 }
                 ext_traced = bs.valid;
-                t4_post(S, tr, detach(its.p), detach(wod), do_nee, detach(ext.o), detach(ext.d), ext_traced);
+                // the emitter sample only counts when the shadow ray's closest hit lies at the sample (t > dist - ShadowEpsilon): any hit
+                // clearly in front of it settles that, so the shadow ray stops at the first such hit instead of looking for the closest
+                t4_post(S, tr, detach(its.p), detach(wod), do_nee, detach(ext.o), detach(ext.d), ext_traced, do_nee ? (detach(dist) - kShadowEpsilon) * 0.9999f : -__builtin_inff());
                 inflight = true;
             }
             if (__ballot(busy || inflight) == 0ull && exhausted && q_next >= q_end) break;

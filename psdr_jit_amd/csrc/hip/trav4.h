@@ -62,8 +62,9 @@ struct Trav4 {
     int cur;                    // 0 / 1: which of the lane's two rays is being traced, -1 none
     int pending;                // bit k: ray k still waits
     unsigned last_pair;         // sequence number (+1) of the last pair this ray enqueued
+    float anyhit;               // ray 0 only: a hit closer than this ends the ray (shadow rays: any occluder will do), -inf = closest hit wanted
     Hit hA, hB;                 // results
-    PSDR_DEV void reset() { code = kT4Done; sp = 0; cur = -1; pending = 0; last_pair = 0u; hA.slot = -1; hA.u = hA.v = hA.t = 0.f; hB = hA; o = Vec3f(0.f); d = Vec3f(0.f); inv = Vec3f(0.f); }
+    PSDR_DEV void reset() { code = kT4Done; sp = 0; cur = -1; pending = 0; last_pair = 0u; anyhit = -__builtin_inff(); hA.slot = -1; hA.u = hA.v = hA.t = 0.f; hB = hA; o = Vec3f(0.f); d = Vec3f(0.f); inv = Vec3f(0.f); }
     PSDR_DEV bool idle() const { return cur < 0 && pending == 0; }
 };
 
@@ -138,6 +139,7 @@ template <int LDS, bool COUNT> PSDR_DEV void t4_node(SceneView<LDS> &S, const T4
     const float4 lx = S.ld(w), ly = S.ld(w + 1), lz = S.ld(w + 2), hx = S.ld(w + 3), hy = S.ld(w + 4), hz = S.ld(w + 5), cd = S.ld(w + 6);
     if (COUNT) S.c_nodes++;
     const float bt = __uint_as_float((unsigned) (L.best[threadIdx.x & 63] >> 32));      // closest hit so far (tested pairs only)
+    if (tr.cur == 0 && bt < tr.anyhit) { tr.sp = 0; tr.code = kT4Done; return; }        // shadow ray: an occluder has been found
     const float ox = tr.o.x, oy = tr.o.y, oz = tr.o.z, ix = tr.inv.x, iy = tr.inv.y, iz = tr.inv.z;
     unsigned key[4];
     const float lox[4] = {lx.x, lx.y, lx.z, lx.w}, loy[4] = {ly.x, ly.y, ly.z, ly.w}, loz[4] = {lz.x, lz.y, lz.z, lz.w};
@@ -283,13 +285,14 @@ template <int LDS> PSDR_DEV void t4_init_lds(const SceneView<LDS> &S) {
 }
 
 // posts the two rays of this lane (run by the lane itself: the parked copy is what the testers of the wave read)
-template <int LDS> PSDR_DEV void t4_post(const SceneView<LDS> &S, Trav4 &tr, const Vec3f &oA, const Vec3f &dA, bool actA, const Vec3f &oB, const Vec3f &dB, bool actB) {
+template <int LDS> PSDR_DEV void t4_post(const SceneView<LDS> &S, Trav4 &tr, const Vec3f &oA, const Vec3f &dA, bool actA, const Vec3f &oB, const Vec3f &dB, bool actB, float anyhit_a = -__builtin_inff()) {
     const T4Lds<LDS> L(S);
     lds_float_t *p = L.park;
     p[0] = oA.x; p[kBlock] = oA.y; p[2 * kBlock] = oA.z; p[3 * kBlock] = dA.x; p[4 * kBlock] = dA.y; p[5 * kBlock] = dA.z;
     p[6 * kBlock] = oB.x; p[7 * kBlock] = oB.y; p[8 * kBlock] = oB.z; p[9 * kBlock] = dB.x; p[10 * kBlock] = dB.y; p[11 * kBlock] = dB.z;
     tr.reset();
     tr.pending = (actA ? 1 : 0) | (actB ? 2 : 0);
+    tr.anyhit = anyhit_a;
 }
 
 // two rays per lane, run to completion: the synchronous form behind trace() / trace2() (secondary-edge, guiding, adjoint
