@@ -60,6 +60,8 @@ struct AdjointParams {
     int hit_words, ext_words, lk_words;   // sizes of the three per-lane records (lk_words = 0 when the scene cannot make lookups)
     float *g_mat;                   // [n_bsdfs*16] adjoints of the constant parameters of the GGX BSDFs (psdr_grads.g_mat), or NULL
     int sweep;                      // 1: run_interior_adjoint_sweep (Diffuse BSDFs + area lights), 0: record and probe
+    float *rec_global;              // NULL: the per-lane records live in LDS; else [workgroup][word][lane of the workgroup] in global memory
+                                    //   (paths too deep for 160 KB of LDS: any depth works, at global-memory latency)
 };
 
 constexpr int kMatRow = 16;
@@ -80,10 +82,11 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
     const int lane_id = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane_id) - 1ull;
     const float inv_spp = T.spp > 1 ? 1.f / (float) T.spp : 1.f;
-    float *rec = scratch + threadIdx.x;
-    int *ext = reinterpret_cast<int *>(scratch + P.hit_words * kBlock) + threadIdx.x;
-    float *lk = scratch + (P.hit_words + P.ext_words) * kBlock + threadIdx.x;
-    float *acc_cam = scratch + (P.hit_words + P.ext_words + P.lk_words) * kBlock;        // 16 floats, always in LDS: every path adds to the same 12 entries
+    float *recs = P.rec_global ? P.rec_global + (size_t) blockIdx.x * (size_t) (P.hit_words + P.ext_words + P.lk_words) * kBlock : scratch;
+    float *rec = recs + threadIdx.x;
+    int *ext = reinterpret_cast<int *>(recs + P.hit_words * kBlock) + threadIdx.x;
+    float *lk = recs + (P.hit_words + P.ext_words) * kBlock + threadIdx.x;
+    float *acc_cam = P.rec_global ? scratch : scratch + (P.hit_words + P.ext_words + P.lk_words) * kBlock;        // 16 floats, always in LDS: every path adds to the same 12 entries
     float *acc_mat = acc_cam + kAdjMisc;                               // [n_bsdfs * kMatRow], always in LDS like the camera block
     float *acc = acc_mat + T.n_bsdfs * kMatRow;
     const int n_acc = P.n_hot * 22 + T.n_bsdfs * 3 + T.n_emitters * 3;
@@ -439,11 +442,11 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
     const unsigned long long lt_mask = (1ull << lane_id) - 1ull;
     const float inv_spp = T.spp > 1 ? 1.f / (float) T.spp : 1.f;
     const int D = P.max_depth;
-    float *vrec = scratch + threadIdx.x;                                  // [3 * (D + 1)] slot, u, v per vertex, stride kBlock
+    const int lane_words = P.hit_words + P.ext_words + P.lk_words;        // sized by the launch: >= adj_sweep_words(D)
+    float *vrec = (P.rec_global ? P.rec_global + (size_t) blockIdx.x * (size_t) lane_words * kBlock : scratch) + threadIdx.x;    // [3 * (D + 1)] slot, u, v per vertex, stride kBlock
     float *brec = vrec + 3 * (D + 1) * kBlock;                            // [11 * D] per bounce: 0 light slot, 1-2 its barycentrics, 3 shadow-hit slot,
                                                                           //   4 cN, 5 cf, 6 w2, 7 flags, 8-10 thr_k
-    const int lane_words = P.hit_words + P.ext_words + P.lk_words;        // sized by the launch: >= adj_sweep_words(D)
-    float *acc_cam = scratch + lane_words * kBlock;                       // same accumulator layout as run_interior_adjoint
+    float *acc_cam = P.rec_global ? scratch : scratch + lane_words * kBlock;      // same accumulator layout as run_interior_adjoint
     float *acc_mat = acc_cam + kAdjMisc;
     float *acc = acc_mat + T.n_bsdfs * kMatRow;
     const int n_acc = P.n_hot * 22 + T.n_bsdfs * 3 + T.n_emitters * 3;

@@ -452,6 +452,8 @@ struct psdr_hip_scene {
     DevBuf counters;
     DevBuf queues;                       // ring of work-queue heads, one per path-kernel launch
     DevBuf gstack;                       // traversal-stack entries beyond the LDS part (trav4.h)
+    mutable DevBuf adj_rec;              // per-lane records of the interior adjoint when they do not fit LDS (deep paths), grown on demand
+    mutable size_t adj_rec_bytes = 0;
     mutable unsigned queue_slot = 0;
     mutable bool adj_attr_set = false;   // the adjoint kernels' dynamic-LDS limit has been raised on this scene's device
     int n_leaves = 0, max_depth = 0, grid = 0;
@@ -1108,15 +1110,18 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     static const bool no_sweep = std::getenv("PSDR_ADJ_PROBE") != nullptr;         // measurement knob: force the probe form
     const bool sweep = !no_sweep && adj_cls != 0 && T.env_emitter < 0 && a->direct_mode == 0 && a->field_mode == 0 && !with_lookups;
     const int lane_words = sweep ? adj_sweep_words(adj_depth) : adj_lane_words(adj_depth, with_lookups);
-    const size_t fixed_bytes = sizeof(float) * ((size_t) lane_words * kBlock + kAdjMisc + (size_t) T.n_bsdfs * kMatRow
-                                                + (size_t) T.n_bsdfs * 3 + (size_t) T.n_emitters * 3);
-    if (smem_base + fixed_bytes > 160 * 1024) return fail("path depth / scene too large for the adjoint kernel's LDS records");
+    // the per-lane records (hits, light samples, lookups of one path: 14 D + 3 words for the sweep) live in LDS when they fit beside
+    // the accumulators, else in a global array of the scene (any depth works, at global-memory latency)
+    const size_t acc_fixed = sizeof(float) * ((size_t) kAdjMisc + (size_t) T.n_bsdfs * kMatRow + (size_t) T.n_bsdfs * 3 + (size_t) T.n_emitters * 3);
+    const bool rec_in_lds = smem_base + sizeof(float) * (size_t) lane_words * kBlock + acc_fixed + 64 * 22 * sizeof(float) <= 160 * 1024;
+    const size_t fixed_bytes = acc_fixed + (rec_in_lds ? sizeof(float) * (size_t) lane_words * kBlock : 0);
+    if (smem_base + fixed_bytes > 160 * 1024) return fail("scene too large for the adjoint kernel's LDS accumulators");
     // two workgroups per CU (80 KB each) when the fixed part allows it - one wave per SIMD cannot hide the global-memory latency of
     // the replays -, with at least 64 hot rows (emitters + the largest triangles)
     const size_t budget = (smem_base + fixed_bytes + 64 * 22 * sizeof(float) <= 80 * 1024) ? 80 * 1024 : 160 * 1024;
     const int n_hot_used = (int) std::min<size_t>((size_t) sc->n_hot, (budget - smem_base - fixed_bytes) / (22 * sizeof(float)));
     const size_t n_acc = (size_t) n_hot_used * 22 + (size_t) T.n_bsdfs * 3 + (size_t) T.n_emitters * 3;
-    const size_t adj_bytes = sizeof(float) * ((size_t) lane_words * kBlock + kAdjMisc + (size_t) T.n_bsdfs * kMatRow + (lds_acc ? n_acc : 0));
+    const size_t adj_bytes = sizeof(float) * ((rec_in_lds ? (size_t) lane_words * kBlock : 0) + kAdjMisc + (size_t) T.n_bsdfs * kMatRow + (lds_acc ? n_acc : 0));
     const size_t smem = smem_base + adj_bytes;
     if (smem > 160 * 1024) return fail("scene too large for the adjoint kernel's LDS records");
     if (!sc->adj_attr_set) {         // (per scene = per device and context; a process-wide flag would skip the second device)
@@ -1144,6 +1149,16 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
             P.hit_words = adj_hit_words(adj_depth); P.ext_words = adj_ext_words(adj_depth); P.lk_words = with_lookups ? 3 * adj_lk_entries(adj_depth) : 0;
             P.sweep = sweep ? 1 : 0;
             if (sweep) { P.hit_words = lane_words; P.ext_words = 0; P.lk_words = 0; }
+            P.rec_global = nullptr;
+            if (!rec_in_lds) {
+                const size_t need = sizeof(float) * (size_t) grid * (size_t) lane_words * kBlock;
+                if (need > sc->adj_rec_bytes) {
+                    if (sc->adj_rec.p) { HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipFree(sc->adj_rec.p)); sc->adj_rec.p = nullptr; sc->adj_rec_bytes = 0; }
+                    if (sc->adj_rec.upload(nullptr, need)) return 1;
+                    sc->adj_rec_bytes = need;
+                }
+                P.rec_global = (float *) sc->adj_rec.p;
+            }
             if (adj_cls == 1) ON_CLS1(hipLaunchKernelGGL((k_interior_adjoint<1>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), Ta, cam, P));
             else if (adj_cls == 2) ON_CLS2(hipLaunchKernelGGL((k_interior_adjoint<2>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), Ta, cam, P));
             else ON_CLS0(hipLaunchKernelGGL((k_interior_adjoint<0>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), Ta, cam, P));

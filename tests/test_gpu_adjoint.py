@@ -137,3 +137,13 @@ def test_interior_sweep_two_sided_and_flat(env):
         m.use_face_normals = True
     lhs, rhs, scale = _dot_product_case(env, spec, depth=3, terms=1)
     assert abs(lhs - rhs) <= 2e-4 * scale and abs(lhs) > 1e-6, (lhs, rhs, scale)
+
+
+def test_reverse_mode_beyond_the_lds_records(env):
+    """paths too deep for per-lane records in LDS (160 KB per workgroup: ~10 bounces with the scene blob beside them) keep their
+    records in global memory: depth 24 through the reverse sweep (Diffuse box) and depth 12 through record-and-probe (GGX box),
+    against the forward tangents of the same kernels"""
+    lhs, rhs, scale = _dot_product_case(env, scenes.cbox_scene(32, 32, 4, 0, 0, param="box_x"), depth=24, terms=1)
+    assert abs(lhs - rhs) <= 3e-4 * scale and abs(lhs) > 1e-6, (lhs, rhs, scale)
+    lhs, rhs, scale = _dot_product_case(env, scenes.microfacet_cbox_scene(24, 24, 2, 0, 0, param="box_x"), depth=12, terms=1)
+    assert abs(lhs - rhs) <= 5e-4 * scale and abs(lhs) > 1e-6, (lhs, rhs, scale)
