@@ -468,6 +468,60 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
         if (val.y != 0.f && finite_(val.y)) atomicAdd(&tab[3 * id + 1], val.y);
         if (val.z != 0.f && finite_(val.z)) atomicAdd(&tab[3 * id + 2], val.z);
     };
+    // Environment map (class 2): radiance along a world direction, and what the adjoint Lb = d (w.L) / d Le of one lookup gives -
+    // the four texels of its footprint, the scale, from_world - and, returned, d (w.L) / d dir.  The Jacobian with respect to the
+    // local direction comes from three forward evaluations of the lookup with unit tangents (atan2 / acos / bilinear: shade.h).
+    auto env_radiance = [&](const Vec3f &dir) -> Vec3f {
+        if constexpr (has_env(LDS)) return env_eval_direction<false, LDS>(S, T.env, dir);
+        else return Vec3f(0.f);
+    };
+    auto env_adjoint = [&](const Vec3f &dir, const Vec3f &Lb) -> Vec3f {
+        Vec3f dirb(0.f);
+        if constexpr (has_env(LDS)) {
+            const EnvDev &E = T.env;
+            if (!(finite_(Lb.x) && finite_(Lb.y) && finite_(Lb.z)) || (Lb.x == 0.f && Lb.y == 0.f && Lb.z == 0.f)) return dirb;
+            const Vec3f v = xform_dir(E.from_world, dir);
+            float vb[3], uu = 0.f, ww = 0.f, rgb0[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const VecN<true> vd(Dual(v.x, j == 0 ? 1.f : 0.f), Dual(v.y, j == 1 ? 1.f : 0.f), Dual(v.z, j == 2 ? 1.f : 0.f));
+                Dual u = env_atan2(vd.x, -vd.z) * Dual(env::kInvTwoPi), w = env_safe_acos(vd.y) * Dual(env::kInvPi);
+                u = u - env_floor(u); w = w - env_floor(w);
+                Dual rgb[3];
+                env::bitmap_eval_fn<Dual>([&](int i, int c) { return Dual(E.radiance[3 * i + c], 0.f); }, E.width, E.height, u, w, rgb);
+                vb[j] = E.scale * (Lb.x * rgb[0].d + Lb.y * rgb[1].d + Lb.z * rgb[2].d);
+                if (j == 0) { uu = u.v; ww = w.v; rgb0[0] = rgb[0].v; rgb0[1] = rgb[1].v; rgb0[2] = rgb[2].v; }
+            }
+            const float lb[3] = {Lb.x, Lb.y, Lb.z}, dv[3] = {dir.x, dir.y, dir.z};
+            if (P.g_env != nullptr) {
+                int idx[4]; float wt[4];
+                env::bitmap_footprint_env(E.width, E.height, uu, ww, idx, wt);
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (lb[c] != 0.f) for (int k = 0; k < 4; ++k) atomicAdd(&P.g_env[3ll * idx[k] + c], lb[c] * E.scale * wt[k]);
+            }
+            if (P.g_env_scale != nullptr) { const float sb = lb[0] * rgb0[0] + lb[1] * rgb0[1] + lb[2] * rgb0[2]; if (sb != 0.f && finite_(sb)) atomicAdd(&acc_cam[12], sb); }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                if (!finite_(vb[r])) vb[r] = 0.f;
+                if (P.g_env_xf != nullptr)
+                    for (int c = 0; c < 3; ++c) { const float val = vb[r] * dv[c]; if (val != 0.f) atomicAdd(&acc_cam[16 + 4 * r + c], val); }
+            }
+            dirb = Vec3f(E.from_world.m[0] * vb[0] + E.from_world.m[4] * vb[1] + E.from_world.m[8] * vb[2],
+                         E.from_world.m[1] * vb[0] + E.from_world.m[5] * vb[1] + E.from_world.m[9] * vb[2],
+                         E.from_world.m[2] * vb[0] + E.from_world.m[6] * vb[1] + E.from_world.m[10] * vb[2]);
+        }
+        return dirb;
+    };
+    const int env_id = has_env(LDS) ? T.env_emitter : -1;
+    // adjoint of x through dir = (z - x) / |z - x| (z fixed)
+    auto dir_to_x = [&](const Vec3f &x, const Vec3f &z, const Vec3f &dirb) -> Vec3f {
+        const Vec3f v = z - x;
+        const float r = norm(v);
+        if (!(r > 0.f)) return Vec3f(0.f);
+        const Vec3f d = v / r;
+        return (d * dot(d, dirb) - dirb) / r;
+    };
     // the normal blend n0 (1 - u - v) + n1 u + n2 v behind a shading normal: its adjoint from the adjoint of ns
     auto blend_adjoint = [&](const VtxGeom &g, const Vec3f &nsb) { return (nsb - g.ns * dot(g.ns, nsb)) / g.nbl; };
     // adjoints of a vertex glued to its triangle: position, shading normal, geometric normal, area
@@ -554,8 +608,8 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
             its.wi = to_local<false>(its, -ray.d);
             Vec3f thr(1.f), Lsum(0.f);
             const int e0 = mesh_emitter(S, its.mesh);
-            const bool le0 = !P.hide_emitters && e0 >= 0 && its.wi.z > 0.f;
-            if (le0) { const float4 a = S.ld(T.emit_off + 2 * e0); Lsum = Vec3f(a.x, a.y, a.z); }
+            const bool le0 = !P.hide_emitters && e0 >= 0 && (e0 == env_id || its.wi.z > 0.f);
+            if (le0) { if (e0 == env_id) Lsum = env_radiance(ray.d); else { const float4 a = S.ld(T.emit_off + 2 * e0); Lsum = Vec3f(a.x, a.y, a.z); } }
             int nb = 0;                                                   // bounces recorded
             bool active = true;
             for (int depth = 0; depth < D && active; ++depth) {
@@ -588,7 +642,14 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
                                 const float pdf1 = ((front && woz > 0.f) ? kInvPi * woz : 0.f) * G;
                                 if (front && woz > 0.f && pdf1 != 0.f) {
                                     const float cN = kInvPi * mis_weight(ps.pdf, pdf1) / ps.pdf;
-                                    if (its1.wi.z > 0.f) {
+                                    if (eh == env_id) {
+                                        // the sample lies on the scene box (a fixed point: the record keeps it instead of a triangle),
+                                        // the radiance is looked up along the shadow ray
+                                        Lsum = Lsum + thr * rho * env_radiance(wod) * (woz * G * cN);
+                                        br[0] = ps.p.x; br[kBlock] = ps.p.y; br[2 * kBlock] = ps.p.z; br[3 * kBlock] = __int_as_float(h1.slot);
+                                        br[4 * kBlock] = cN;
+                                        flags |= 1 | 16;
+                                    } else if (its1.wi.z > 0.f) {
                                         const float4 ea = S.ld(T.emit_off + 2 * eh);
                                         Lsum = Lsum + thr * rho * Vec3f(ea.x, ea.y, ea.z) * (woz * G * cN);
                                         br[0] = __int_as_float(ps.slot); br[kBlock] = ps.ba; br[2 * kBlock] = ps.bb; br[3 * kBlock] = __int_as_float(h1.slot);
@@ -620,7 +681,8 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
                         const float w2 = mis_weight(pdf0, emitter_position_pdf<false, LDS>(S, its.p, itx));
                         thr = ok ? thr * rho * (woz * G * cf) : Vec3f(0.f);
                         const int ex = mesh_emitter(S, itx.mesh);
-                        if (ex >= 0 && itx.wi.z > 0.f) { const float4 ea = S.ld(T.emit_off + 2 * ex); Lsum = Lsum + Vec3f(ea.x, ea.y, ea.z) * thr * w2; flags |= 8; }
+                        if (ex >= 0 && ex == env_id) { Lsum = Lsum + env_radiance(wo) * thr * w2; flags |= 8; }
+                        else if (ex >= 0 && itx.wi.z > 0.f) { const float4 ea = S.ld(T.emit_off + 2 * ex); Lsum = Lsum + Vec3f(ea.x, ea.y, ea.z) * thr * w2; flags |= 8; }
                         br[5 * kBlock] = cf; br[6 * kBlock] = w2;
                         flags |= 2;
                         its = itx;
@@ -637,7 +699,9 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
 
             // ------------------------------------------------------------ pass 2: back over the bounces
             if (W.x != 0.f || W.y != 0.f || W.z != 0.f) {
-                if (le0 && !P.skip_emitter) add_rgb(acc_emit, e0, W);          // the emitter seen by the camera
+                Vec3f cam_dirb(0.f);                    // adjoint of the camera ray's direction from an environment lookup along it
+                if (le0 && e0 == env_id) cam_dirb = env_adjoint(ray.d, W);
+                else if (le0 && !P.skip_emitter) add_rgb(acc_emit, e0, W);          // the emitter seen by the camera
                 Vec3f Abar(0.f);                       // d (w.L) / d thr_{k+1} from the bounces behind k
                 Vec3f xb_next(0.f), nsb_next(0.f);     // what bounce k+1 gave vertex k+1 as ITS shading point
                 Vec3f xb0(0.f), nsb0(0.f);             // the camera hit's totals
@@ -663,9 +727,15 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
                         Vec3f At = Abar;                                             // total adjoint of thr_{k+1}
                         if (flags & 8) {
                             const int ex = mesh_emitter(S, gz.mesh);
-                            const float4 ea = S.ld(T.emit_off + 2 * ex);
-                            At = At + W * Vec3f(ea.x, ea.y, ea.z) * w2;
-                            if (!P.skip_emitter) add_rgb(acc_emit, ex, W * thr_k * rho * (sf * w2));
+                            if (ex == env_id) {
+                                const Vec3f dir = normalize(gz.x - gk.x);
+                                At = At + W * env_radiance(dir) * w2;
+                                xb = xb + dir_to_x(gk.x, gz.x, env_adjoint(dir, W * thr_k * rho * (sf * w2)));
+                            } else {
+                                const float4 ea = S.ld(T.emit_off + 2 * ex);
+                                At = At + W * Vec3f(ea.x, ea.y, ea.z) * w2;
+                                if (!P.skip_emitter) add_rgb(acc_emit, ex, W * thr_k * rho * (sf * w2));
+                            }
                         }
                         const float sb = cf * (thr_k.x * rho.x * At.x + thr_k.y * rho.y * At.y + thr_k.z * rho.z * At.z);
                         rhob = rhob + thr_k * At * sf;
@@ -674,7 +744,21 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
                         // vertex k+1 is complete: end point of this segment + shading point of bounce k+1
                         emit_glued(gz, xb_next + sg.dz * sb, nsb_next, sg.dnz * sb, sg.dA * sb);
                     }
-                    if (flags & 1) {
+                    if ((flags & 1) && (flags & 16)) {
+                        // next-event sample on the environment map: L += thr_k rho Le(dir) cN s_N with a fixed sample point y on the scene box
+                        const Vec3f y(br[0], br[kBlock], br[2 * kBlock]);
+                        const VtxGeom gh = load_vertex(S, __float_as_int(br[3 * kBlock]), 0.f, 0.f);
+                        const float cN = br[4 * kBlock];
+                        const float sN = seg_eval(gk.x, gk.ns, sgn, y, gh.fn, 1.f, sg) * cN;
+                        const Vec3f dir = normalize(y - gk.x);
+                        const Vec3f Le = env_radiance(dir);
+                        const Vec3f al = W * thr_k * rho * Le;
+                        const float sb = cN * (al.x + al.y + al.z);
+                        rhob = rhob + W * thr_k * Le * sN;
+                        A_k = A_k + W * rho * Le * sN;
+                        xb = xb + sg.dx * sb + dir_to_x(gk.x, y, env_adjoint(dir, W * thr_k * rho * sN));
+                        nsb = nsb + sg.dns * sb;
+                    } else if (flags & 1) {
                         // L += thr_k rho Le_h cN s_N
                         const VtxGeom gy = load_vertex(S, __float_as_int(br[0]), br[kBlock], br[2 * kBlock]);
                         const VtxGeom gh = load_vertex(S, __float_as_int(br[3 * kBlock]), 0.f, 0.f);
@@ -698,7 +782,7 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
                     if (k == 0) { xb0 = xb; nsb0 = nsb; }
                 }
                 // the camera hit: x_0 = o + t d and ns_0 = normalize(blend(u, v)) with (u, v, t) = Moeller-Trumbore(p0, e1, e2; o, d)
-                if (nb > 0) {
+                if (nb > 0 || le0) {
                     const VtxGeom g0 = load_vertex(S, slot0, u0, v0);
                     float ub = 0.f, vb = 0.f;
                     const float tb = dot(ray.d, xb0);
@@ -715,7 +799,7 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
                     if (want0) { add_vec(g0, 0, p0b); add_vec(g0, 3, e1b); add_vec(g0, 6, e2b); }
                     if (P.g_cam != nullptr) {
                         // o = to_world . (o_cam, 1), d = to_world . (d_cam, 0)  (primary_ray_pose_tangent)
-                        ob = ob + ob2; db = db + db2;
+                        ob = ob + ob2; db = db + db2 + cam_dirb;
                         const Vec3f pc = xform_pos(cam.sample_to_camera, Vec3f(sx, sy, 0.f));
                         const Vec3f o_cam = cam.ortho ? pc : Vec3f(0.f), d_cam = cam.ortho ? Vec3f(0.f, 0.f, 1.f) : normalize(pc);
                         const float oc[4] = {o_cam.x, o_cam.y, o_cam.z, 1.f}, dc[4] = {d_cam.x, d_cam.y, d_cam.z, 0.f};
@@ -735,6 +819,8 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
     }
     __syncthreads();
     if (P.g_cam != nullptr && threadIdx.x < 12 && acc_cam[threadIdx.x] != 0.f) atomicAdd(&P.g_cam[threadIdx.x], acc_cam[threadIdx.x]);
+    if (P.g_env_scale != nullptr && threadIdx.x == 12 && acc_cam[12] != 0.f) atomicAdd(P.g_env_scale, acc_cam[12]);
+    if (P.g_env_xf != nullptr && threadIdx.x >= 16 && threadIdx.x < 27 && acc_cam[threadIdx.x] != 0.f) atomicAdd(&P.g_env_xf[threadIdx.x - 16], acc_cam[threadIdx.x]);
     for (int i = threadIdx.x; i < P.n_hot * 22; i += kBlock) if (acc[i] != 0.f) atomicAdd(&P.g_tri[P.hot_inv[i / 22] * 22 + i % 22], acc[i]);
     for (int i = threadIdx.x; i < T.n_bsdfs * 3; i += kBlock) if (acc_bsdf[i] != 0.f) atomicAdd(&P.g_bsdf[i], acc_bsdf[i]);
     for (int i = threadIdx.x; i < T.n_emitters * 3; i += kBlock) if (acc_emit[i] != 0.f) atomicAdd(&P.g_emitter[i], acc_emit[i]);

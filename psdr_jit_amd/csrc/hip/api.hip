@@ -1106,9 +1106,9 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     Ta.stack_depth -= cold_rows;
     const size_t smem_base = (adj_cls == 1 ? sc->smem_bytes : sc->smem_bytes - ((sc->lds || sc->lds_mat) ? (size_t) T.blob_words * 16 : 0)) - cold_bytes;
     const int adj_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth);
-    // Diffuse BSDFs + area lights under PathTracer: the reverse sweep (adjoint.h); everything else: record and probe
+    // Diffuse BSDFs + area lights / an environment map under PathTracer: the reverse sweep (adjoint.h); everything else: record and probe
     static const bool no_sweep = std::getenv("PSDR_ADJ_PROBE") != nullptr;         // measurement knob: force the probe form
-    const bool sweep = !no_sweep && adj_cls != 0 && T.env_emitter < 0 && a->direct_mode == 0 && a->field_mode == 0 && !with_lookups;
+    const bool sweep = !no_sweep && adj_cls != 0 && a->direct_mode == 0 && a->field_mode == 0 && T.tex == nullptr && T.pv == nullptr && (T.env_emitter < 0 || adj_cls == 2);
     const int lane_words = sweep ? adj_sweep_words(adj_depth) : adj_lane_words(adj_depth, with_lookups);
     // the per-lane records (hits, light samples, lookups of one path: 14 D + 3 words for the sweep) live in LDS when they fit beside
     // the accumulators, else in a global array of the scene (any depth works, at global-memory latency)

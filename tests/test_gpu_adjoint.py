@@ -147,3 +147,11 @@ def test_reverse_mode_beyond_the_lds_records(env):
     assert abs(lhs - rhs) <= 3e-4 * scale and abs(lhs) > 1e-6, (lhs, rhs, scale)
     lhs, rhs, scale = _dot_product_case(env, scenes.microfacet_cbox_scene(24, 24, 2, 0, 0, param="box_x"), depth=12, terms=1)
     assert abs(lhs - rhs) <= 5e-4 * scale and abs(lhs) > 1e-6, (lhs, rhs, scale)
+
+
+@pytest.mark.parametrize("param,balls", [("box_x", False), ("albedo", False), ("albedo", True)])
+def test_interior_sweep_environment_map(env, param, balls):
+    """Diffuse scenes lit by an environment map (class 2): next-event samples on the scene box and BSDF rays that leave the scene
+    look the radiance up along their direction - the sweep carries that direction's adjoint back to the shading point"""
+    lhs, rhs, scale = _dot_product_case(env, scenes.envmap_scene(40, 40, 8, 0, 0, param=param, area_light=True, balls=balls), depth=3, terms=1)
+    assert abs(lhs - rhs) <= 3e-4 * scale and abs(lhs) > 1e-6, (param, lhs, rhs, scale)

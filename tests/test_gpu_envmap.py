@@ -422,3 +422,52 @@ def test_env_cell_masses_on_the_device_equal_the_oracle(psdr, orc):
     assert np.array_equal(mass, pmf2)
     with pytest.raises(Exception):
         cabi.check(cabi.lib().psdr_hip_env_cell_masses(tex.ctypes.data_as(C.c_void_p), C.c_int32(1), C.c_int32(H), mass.ctypes.data_as(C.c_void_p)))
+
+
+def test_envmap_reverse_sweep(psdr, orc):
+    """Diffuse scene under an environment map (scene class 2): the interior term's reverse mode is the adjoint sweep (adjoint.h) -
+    loss.backward() into the map's texels, scale and rotation, the box translation, the albedo and the camera pose equals forward mode"""
+    import torch
+    rng = np.random.default_rng(5)
+    spec = scenes.envmap_scene(40, 40, 8, 0, 0, param=None)
+    env0 = scenes.synthetic_envmap(64, 32)
+    rad = torch.tensor(env0, requires_grad=True)
+    scale = psdr.FloatD(1.25).requires_grad_()
+    albedo = torch.tensor([0.5, 0.4, 0.6], requires_grad=True)
+    P = psdr.FloatD(0.).requires_grad_()
+    C = psdr.FloatD(0.).requires_grad_()
+    sc = psdr.Scene()
+    sc.opts.spp, sc.opts.sppe, sc.opts.sppse = 8, 0, 0
+    sc.opts.width = sc.opts.height = 40
+    sc.opts.log_level = 0
+    cam = psdr.PerspectiveCamera(60, 0.000001, 10000000.)
+    base = torch.tensor(np.asarray(spec.cameras[0].to_world_raw, np.float32))
+    shift = torch.zeros(4, 4); shift[0, 3] = 1.0
+    cam.to_world = psdr.Matrix4fD(base + shift * C * 50.)
+    sc.add_Sensor(cam)
+    sc.add_BSDF(psdr.DiffuseBSDF(albedo), "cat")
+    sc.add_BSDF(psdr.DiffuseBSDF([0.8, 0.8, 0.8]), "white")
+    eye = psdr.Matrix4fC(np.eye(4, dtype=np.float32).tolist())
+    sc.add_Mesh(os.path.join(scenes.DATA, "cbox_smallbox.obj"), eye, "cat", None)
+    sc.add_Mesh(os.path.join(scenes.DATA, "cbox_largebox.obj"), eye, "cat", None)
+    sc.add_Mesh(os.path.join(scenes.DATA, "cbox_floor.obj"), eye, "white", None)
+    ang = psdr.FloatD(0.3).requires_grad_()
+    ca, sa = torch.cos(ang), torch.sin(ang)
+    e = psdr.EnvironmentMap(rad)
+    e.scale = scale
+    e.set_transform(psdr.Matrix4fD([[ca, 0., sa, 0.], [0., 1., 0., 0.], [-sa, 0., ca, 0.], [0., 0., 0., 1.]]))
+    sc.add_EnvironmentMap(e)
+    sc.configure()
+    sc.param_map["Mesh[0]"].set_transform(psdr.Matrix4fD([[1., 0., 0., P * 100.], [0., 1., 0., 0.], [0., 0., 1., 0.], [0., 0., 0., 1.]]))
+    sc.configure([0])
+    img = psdr.PathTracer(3).renderD(sc, 0, seed=5)
+    w = torch.linspace(0.5, 1.5, img.numel(), device=img.device).reshape(img.shape)
+    v_rad = torch.tensor(rng.standard_normal(env0.shape).astype(np.float32))
+    want = {"radiance": float((psdr.forward_grad(img, rad, direction=v_rad) * w).sum()), "scale": float((psdr.forward_grad(img, scale) * w).sum()),
+            "angle": float((psdr.forward_grad(img, ang) * w).sum()), "box": float((psdr.forward_grad(img, P) * w).sum()),
+            "albedo": float((psdr.forward_grad(img, albedo, direction=torch.ones(3)) * w).sum()), "camera": float((psdr.forward_grad(img, C) * w).sum())}
+    (img * w).sum().backward()
+    got = {"radiance": float((rad.grad * v_rad).sum()), "scale": float(scale.grad), "angle": float(ang.grad), "box": float(P.grad),
+           "albedo": float(albedo.grad.sum()), "camera": float(C.grad)}
+    for name in want:
+        assert abs(want[name]) > 1e-3 and abs(got[name] - want[name]) < 3e-3 * max(1.0, abs(want[name])), (name, got[name], want[name])
