@@ -18,7 +18,7 @@ HIP_LIB = os.path.join(LIBDIR, "libpsdr_hip.so")
 CORE_LIB = os.path.join(HERE, "_psdr_core" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
 
 HIP_SRCS = [os.path.join(CSRC, "hip", f) for f in ("api.hip",)]
-HIP_DEPS = [os.path.join(CSRC, "hip", f) for f in ("dmath.h", "sampler.h", "scene_dev.h", "shade.h", "edges.h", "paths.h", "adjoint.h", "bvh.h", "filter.h", "microfacet.h", "trav4.h")] + \
+HIP_DEPS = [os.path.join(CSRC, "hip", f) for f in ("dmath.h", "sampler.h", "scene_dev.h", "shade.h", "edges.h", "paths.h", "adjoint.h", "adjoint_mat.h", "bvh.h", "filter.h", "microfacet.h", "trav4.h")] + \
            [os.path.join(ROOT, "include", "psdr_hip.h"), os.path.join(CSRC, "common", "envmath.h")]
 HOST_SRCS = [os.path.join(CSRC, "host", f) for f in ("scene_host.cpp", "bindings.cpp", "exr_piz.cpp")]
 HOST_DEPS = [os.path.join(CSRC, "host", f) for f in ("scene_host.h", "hnum.h", "exr_piz.h")] + [os.path.join(ROOT, "include", "psdr_hip.h"), os.path.join(CSRC, "common", "envmath.h")]

@@ -1,0 +1,506 @@
+// adjoint_mat.h - the reverse sweep of the interior term (adjoint.h::run_interior_adjoint_sweep) for scenes with isotropic GGX
+// BSDFs (psdr.MicrofacetBSDF with constant parameters, beside Diffuse ones): scene class 0.
+//
+// Same structure - pass 1 walks the path forward with the primal arithmetic of D mode and records (slot, u, v) per vertex and the
+// constants of each bounce, pass 2 walks back - but the BSDF is a function F(wi, wo) of BOTH directions in the shading frame
+// (microfacet.cpp:22-62), so a segment factors into F and the geometry term g = |nz.w| / r^2 . A / detach(A):
+//     L += thr_k . F(wi_k, w) . Le . g cN          thr_{k+1} = thr_k . F(wi_k, w) . g cf
+// with w = (z - x_k) / r and wi_k = (x_{k-1} - x_k) / r' (the camera ray at the first vertex; scene.cpp:686-690 rebuilds it from the
+// positions).  The adjoint of F comes from forward evaluations of microfacet_eval<Dual> with unit tangents (six direction components,
+// specular, roughness, diffuse); it goes to w and wi as vectors - and through them to x_k, z and x_{k-1} - and to ns by the rotation
+// of the frame (an isotropic lobe does not see the tangents), and to the BSDF's parameters (g_mat rows, g_bsdf).
+#pragma once
+#include "adjoint.h"
+
+namespace psdr {
+
+struct GeoGrad { Vec3f dx, dz, dnz; float dA; };      // d g / d (x, z, nz, A_z)
+// g = |nz.w| / r^2 and its gradient
+PSDR_DEV float geo_eval(const Vec3f &x, const Vec3f &z, const Vec3f &nz, float area_z, GeoGrad &g) {
+    const Vec3f v = z - x;
+    const float r2 = dot(v, v);
+    g.dx = g.dz = g.dnz = Vec3f(0.f); g.dA = 0.f;
+    if (!(r2 > 0.f)) return 0.f;
+    const float ir = 1.f / sqrtf(r2), ir3 = ir * ir * ir;
+    const float Qs = dot(nz, v), sq = Qs < 0.f ? -1.f : 1.f, Q = Qs * sq;
+    const float G = Q * ir3;
+    g.dnz = v * (sq * ir3);
+    g.dz = nz * (sq * ir3) - v * (3.f * G * ir * ir);
+    g.dx = -g.dz;
+    g.dA = area_z > 0.f ? G / area_z : 0.f;
+    return G;
+}
+
+// F(wi, wo) of BSDF `bid` in local coordinates (Diffuse or Microfacet with constant parameters) and, when `Fb` is given, the adjoints
+// of the six direction components; the parameter adjoints are added to acc_bsdf (colour / diffuse reflectance) and acc_mat (g_mat row:
+// specular rgb, roughness)
+template <int LDS>
+PSDR_DEV Vec3f bsdf_value_and_adjoint(const SceneView<LDS> &S, int bid, const Vec3f &wi, const Vec3f &wo, const Vec3f *Fb, float *wib, float *wob,
+                                      float *acc_bsdf, float *acc_mat, bool params) {
+    if (wib) { wib[0] = wib[1] = wib[2] = 0.f; wob[0] = wob[1] = wob[2] = 0.f; }
+    if (bid < 0) return Vec3f(0.f);
+    const float4 a = S.ld(S.T->bsdf_off + 2 * bid);
+    const int fl = __float_as_int(a.w);
+    const bool two = (fl & 1) != 0;
+    auto add = [](float *p, float v) { if (v != 0.f && finite_(v)) atomicAdd(p, v); };
+    if constexpr (has_mat(LDS)) {
+        if (fl & 4) {
+            const MatDev md = S.T->mat[bid];
+            const Vec3f F = microfacet_eval<float>(Vec3f(md.specular[0], md.specular[1], md.specular[2]), Vec3f(a.x, a.y, a.z), md.roughness, two, wi, wo, true);
+            if (Fb == nullptr) return F;
+            if (!(finite_(Fb->x) && finite_(Fb->y) && finite_(Fb->z)) || (Fb->x == 0.f && Fb->y == 0.f && Fb->z == 0.f)) return F;
+            for (int j = 0; j < 9; ++j) {
+                const float one = 1.f;
+                const Vec3d wiD(Dual(wi.x, j == 0 ? one : 0.f), Dual(wi.y, j == 1 ? one : 0.f), Dual(wi.z, j == 2 ? one : 0.f));
+                const Vec3d woD(Dual(wo.x, j == 3 ? one : 0.f), Dual(wo.y, j == 4 ? one : 0.f), Dual(wo.z, j == 5 ? one : 0.f));
+                const float ts = j == 6 ? one : 0.f, tr = j == 7 ? one : 0.f, td = j == 8 ? one : 0.f;
+                if (j >= 6 && !params) break;
+                const Vec3d spec(Dual(md.specular[0], ts), Dual(md.specular[1], ts), Dual(md.specular[2], ts));
+                const Vec3d diff(Dual(a.x, td), Dual(a.y, td), Dual(a.z, td));
+                const Vec3d r = microfacet_eval<Dual>(spec, diff, Dual(md.roughness, tr), two, wiD, woD, true);
+                const float dx = Fb->x * r.x.d, dy = Fb->y * r.y.d, dz = Fb->z * r.z.d;
+                if (j < 3) wib[j] = dx + dy + dz;
+                else if (j < 6) wob[j - 3] = dx + dy + dz;
+                else if (j == 6) { if (acc_mat) { add(&acc_mat[bid * kMatRow], dx); add(&acc_mat[bid * kMatRow + 1], dy); add(&acc_mat[bid * kMatRow + 2], dz); } }
+                else if (j == 7) { if (acc_mat) add(&acc_mat[bid * kMatRow + 3], dx + dy + dz); }
+                else { if (acc_bsdf) { add(&acc_bsdf[3 * bid], dx); add(&acc_bsdf[3 * bid + 1], dy); add(&acc_bsdf[3 * bid + 2], dz); } }
+            }
+            for (int j = 0; j < 3; ++j) { if (!finite_(wib[j])) wib[j] = 0.f; if (!finite_(wob[j])) wob[j] = 0.f; }
+            return F;
+        }
+    }
+    // Diffuse (diffuse.cpp:30-41): rho / pi . wo.z on the lit side
+    float wiz = wi.z, woz = wo.z, sg = 1.f;
+    if (two) { sg = wiz < 0.f ? -1.f : 1.f; woz = woz * sg; wiz = fabsf(wiz); }
+    if (!(wiz > 0.f && woz > 0.f)) return Vec3f(0.f);
+    const Vec3f rho(a.x, a.y, a.z);
+    const Vec3f F = rho * (kInvPi * woz);
+    if (Fb != nullptr && finite_(Fb->x) && finite_(Fb->y) && finite_(Fb->z)) {
+        wob[2] = sg * kInvPi * (Fb->x * rho.x + Fb->y * rho.y + Fb->z * rho.z);
+        if (params && acc_bsdf) { add(&acc_bsdf[3 * bid], Fb->x * kInvPi * woz); add(&acc_bsdf[3 * bid + 1], Fb->y * kInvPi * woz); add(&acc_bsdf[3 * bid + 2], Fb->z * kInvPi * woz); }
+    }
+    return F;
+}
+
+template <int LDS>
+PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev &cam, const AdjointParams &P, float *scratch) {
+    const SceneTables &T = *S.T;
+    const int lane_id = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane_id) - 1ull;
+    const float inv_spp = T.spp > 1 ? 1.f / (float) T.spp : 1.f;
+    const int D = P.max_depth;
+    const int lane_words = P.hit_words + P.ext_words + P.lk_words;        // sized by the launch: >= adj_sweep_words(D)
+    float *vrec = (P.rec_global ? P.rec_global + (size_t) blockIdx.x * (size_t) lane_words * kBlock : scratch) + threadIdx.x;    // [3 * (D + 1)] slot, u, v per vertex, stride kBlock
+    float *brec = vrec + 3 * (D + 1) * kBlock;                            // [11 * D] per bounce: 0 light slot, 1-2 its barycentrics, 3 shadow-hit slot,
+                                                                          //   4 cN, 5 cf, 6 w2, 7 flags, 8-10 thr_k
+    float *acc_cam = P.rec_global ? scratch : scratch + lane_words * kBlock;      // same accumulator layout as run_interior_adjoint
+    float *acc_mat = acc_cam + kAdjMisc;
+    float *acc = acc_mat + T.n_bsdfs * kMatRow;
+    const int n_acc = P.n_hot * 22 + T.n_bsdfs * 3 + T.n_emitters * 3;
+    for (int i = threadIdx.x; i < n_acc; i += kBlock) acc[i] = 0.f;
+    float *acc_bsdf = acc + P.n_hot * 22, *acc_emit = acc_bsdf + T.n_bsdfs * 3;
+    if (threadIdx.x < kAdjMisc) acc_cam[threadIdx.x] = 0.f;
+    for (int i = threadIdx.x; i < T.n_bsdfs * kMatRow; i += kBlock) acc_mat[i] = 0.f;
+    __syncthreads();
+    S.mode = 0; S.probe_kind = 0;
+
+    auto add_row = [&](const VtxGeom &g, int comp, float val) {
+        if (val == 0.f || !finite_(val)) return;
+        const int hot = P.hot_map[g.orig];
+        if (hot >= 0 && hot < P.n_hot) atomicAdd(&acc[hot * 22 + comp], val); else atomicAdd(&P.g_tri[g.orig * 22 + comp], val);
+    };
+    auto add_vec = [&](const VtxGeom &g, int comp, const Vec3f &val) { add_row(g, comp, val.x); add_row(g, comp + 1, val.y); add_row(g, comp + 2, val.z); };
+    auto wanted = [&](const VtxGeom &g) { return P.mesh_filter == nullptr || P.mesh_filter[g.mesh] != 0; };
+    auto add_rgb = [&](float *tab, int id, const Vec3f &val) {
+        if (val.x != 0.f && finite_(val.x)) atomicAdd(&tab[3 * id], val.x);
+        if (val.y != 0.f && finite_(val.y)) atomicAdd(&tab[3 * id + 1], val.y);
+        if (val.z != 0.f && finite_(val.z)) atomicAdd(&tab[3 * id + 2], val.z);
+    };
+    // Environment map (class 2): radiance along a world direction, and what the adjoint Lb = d (w.L) / d Le of one lookup gives -
+    // the four texels of its footprint, the scale, from_world - and, returned, d (w.L) / d dir.  The Jacobian with respect to the
+    // local direction comes from three forward evaluations of the lookup with unit tangents (atan2 / acos / bilinear: shade.h).
+    auto env_radiance = [&](const Vec3f &dir) -> Vec3f {
+        if constexpr (has_env(LDS)) return env_eval_direction<false, LDS>(S, T.env, dir);
+        else return Vec3f(0.f);
+    };
+    auto env_adjoint = [&](const Vec3f &dir, const Vec3f &Lb) -> Vec3f {
+        Vec3f dirb(0.f);
+        if constexpr (has_env(LDS)) {
+            const EnvDev &E = T.env;
+            if (!(finite_(Lb.x) && finite_(Lb.y) && finite_(Lb.z)) || (Lb.x == 0.f && Lb.y == 0.f && Lb.z == 0.f)) return dirb;
+            const Vec3f v = xform_dir(E.from_world, dir);
+            float vb[3], uu = 0.f, ww = 0.f, rgb0[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const VecN<true> vd(Dual(v.x, j == 0 ? 1.f : 0.f), Dual(v.y, j == 1 ? 1.f : 0.f), Dual(v.z, j == 2 ? 1.f : 0.f));
+                Dual u = env_atan2(vd.x, -vd.z) * Dual(env::kInvTwoPi), w = env_safe_acos(vd.y) * Dual(env::kInvPi);
+                u = u - env_floor(u); w = w - env_floor(w);
+                Dual rgb[3];
+                env::bitmap_eval_fn<Dual>([&](int i, int c) { return Dual(E.radiance[3 * i + c], 0.f); }, E.width, E.height, u, w, rgb);
+                vb[j] = E.scale * (Lb.x * rgb[0].d + Lb.y * rgb[1].d + Lb.z * rgb[2].d);
+                if (j == 0) { uu = u.v; ww = w.v; rgb0[0] = rgb[0].v; rgb0[1] = rgb[1].v; rgb0[2] = rgb[2].v; }
+            }
+            const float lb[3] = {Lb.x, Lb.y, Lb.z}, dv[3] = {dir.x, dir.y, dir.z};
+            if (P.g_env != nullptr) {
+                int idx[4]; float wt[4];
+                env::bitmap_footprint_env(E.width, E.height, uu, ww, idx, wt);
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (lb[c] != 0.f) for (int k = 0; k < 4; ++k) atomicAdd(&P.g_env[3ll * idx[k] + c], lb[c] * E.scale * wt[k]);
+            }
+            if (P.g_env_scale != nullptr) { const float sb = lb[0] * rgb0[0] + lb[1] * rgb0[1] + lb[2] * rgb0[2]; if (sb != 0.f && finite_(sb)) atomicAdd(&acc_cam[12], sb); }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                if (!finite_(vb[r])) vb[r] = 0.f;
+                if (P.g_env_xf != nullptr)
+                    for (int c = 0; c < 3; ++c) { const float val = vb[r] * dv[c]; if (val != 0.f) atomicAdd(&acc_cam[16 + 4 * r + c], val); }
+            }
+            dirb = Vec3f(E.from_world.m[0] * vb[0] + E.from_world.m[4] * vb[1] + E.from_world.m[8] * vb[2],
+                         E.from_world.m[1] * vb[0] + E.from_world.m[5] * vb[1] + E.from_world.m[9] * vb[2],
+                         E.from_world.m[2] * vb[0] + E.from_world.m[6] * vb[1] + E.from_world.m[10] * vb[2]);
+        }
+        return dirb;
+    };
+    const int env_id = has_env(LDS) ? T.env_emitter : -1;
+    // adjoint of x through dir = (z - x) / |z - x| (z fixed)
+    auto dir_to_x = [&](const Vec3f &x, const Vec3f &z, const Vec3f &dirb) -> Vec3f {
+        const Vec3f v = z - x;
+        const float r = norm(v);
+        if (!(r > 0.f)) return Vec3f(0.f);
+        const Vec3f d = v / r;
+        return (d * dot(d, dirb) - dirb) / r;
+    };
+    // the normal blend n0 (1 - u - v) + n1 u + n2 v behind a shading normal: its adjoint from the adjoint of ns
+    auto blend_adjoint = [&](const VtxGeom &g, const Vec3f &nsb) { return (nsb - g.ns * dot(g.ns, nsb)) / g.nbl; };
+    // adjoints of a vertex glued to its triangle: position, shading normal, geometric normal, area
+    auto emit_glued = [&](const VtxGeom &g, const Vec3f &xb, const Vec3f &nsb, const Vec3f &ngb, float ab) {
+        if (!wanted(g)) return;
+        add_vec(g, 0, xb); add_vec(g, 3, xb * g.u); add_vec(g, 6, xb * g.v);
+        Vec3f fnb = ngb;
+        if (g.flat) fnb = fnb + nsb;
+        else {
+            const Vec3f nbb = blend_adjoint(g, nsb);
+            add_vec(g, 9, nbb * (1.f - g.u - g.v)); add_vec(g, 12, nbb * g.u); add_vec(g, 15, nbb * g.v);
+        }
+        add_vec(g, 18, fnb);
+        add_row(g, 21, ab);
+    };
+
+    long long q_next = 0, q_end = 0;
+    bool exhausted = false;
+    bool have = false;
+    long long lane = 0;
+    for (;;) {
+        // ---- phase 1: find samples whose camera ray hits the scene (as in run_interior_adjoint)
+        for (int round = 0; round < 8; ++round) {
+            const unsigned long long need = __ballot(!have);
+            if (__popcll(need) <= 6) break;
+            if (q_next >= q_end && !exhausted) {
+                unsigned long long base = 0;
+                if (lane_id == 0) base = atomicAdd(P.counter, (unsigned long long) kFetchBatch);
+                base = __shfl(base, 0);
+                if ((long long) base >= P.n_local) exhausted = true;
+                else { q_next = (long long) base; q_end = q_next + kFetchBatch < P.n_local ? q_next + kFetchBatch : P.n_local; }
+            }
+            if (q_next >= q_end) break;
+            const int rank = __popcll(need & lt_mask);
+            const long long item = q_next + rank;
+            Vec3f o(0.f), d(0.f);
+            bool cand = false;
+            if (!have && item < q_end) {
+                const long long chunk = (item >> 8) * P.shard_count + P.shard_rank;
+                lane = P.begin + (chunk << 8) + (item & 255);
+                if (lane < P.end) {
+                    const long long k = T.spp > 1 ? lane / T.spp : lane;
+                    const int pix = P.pix_ids ? P.pix_ids[k] : (int) k;
+                    LaneRng rng;
+                    rng.seed(P.seed + (P.pix_ids ? (unsigned long long) (long long) pix : (unsigned long long) lane), (unsigned long long) lane, P.skip);
+                    const float bx = (float) (pix % T.width), by = (float) (pix / T.width);
+                    const float jx = rng.next_1d(), jy = rng.next_1d();
+                    const RayT<false> r = sample_primary_ray<false>(cam, (bx + jx) / (float) T.width, (by + jy) / (float) T.height);
+                    o = r.o; d = r.d; cand = true;
+                }
+            }
+            Hit h; h.slot = -1;
+            if (cand) h = trace<LDS, false>(S, o, d);
+            if (cand && h.slot >= 0) { have = true; vrec[0] = __int_as_float(h.slot); }
+            const int n_need = __popcll(need);
+            q_next += n_need < (int) (q_end - q_next) ? n_need : (q_end - q_next);
+        }
+        if (__ballot(have) == 0ull) { if (exhausted && q_next >= q_end) break; continue; }
+
+        if (have) {
+            const long long kpix = T.spp > 1 ? lane / T.spp : lane;
+            const int pix = P.pix_ids ? P.pix_ids[kpix] : (int) kpix;
+            LaneRng rng;
+            rng.seed(P.seed + (P.pix_ids ? (unsigned long long) (long long) pix : (unsigned long long) lane), (unsigned long long) lane, P.skip);
+            const float bx = (float) (pix % T.width), by = (float) (pix / T.width);
+            const float jx = rng.next_1d(), jy = rng.next_1d();
+            const float sx = (bx + jx) / (float) T.width, sy = (by + jy) / (float) T.height;
+            const RayT<false> ray = sample_primary_ray<false>(cam, sx, sy);
+            float wgt[3] = {P.w[3 * kpix] * inv_spp, P.w[3 * kpix + 1] * inv_spp, P.w[3 * kpix + 2] * inv_spp};
+
+            // ------------------------------------------------------------ pass 1: forward, the primal arithmetic of D mode
+            const int slot0 = __float_as_int(vrec[0]);
+            float u0, v0, t0;
+            {
+                Vec3f a0, b0, c0;
+                load_geom<false, LDS>(S, slot0, a0, b0, c0);
+                ray_tri_uvt<float>(a0, b0, c0, ray.o, ray.d, u0, v0, t0);
+            }
+            vrec[kBlock] = u0; vrec[2 * kBlock] = v0;
+            const Vec3f x0(fmaf(ray.d.x, t0, ray.o.x), fmaf(ray.d.y, t0, ray.o.y), fmaf(ray.d.z, t0, ray.o.z));     // the camera hit slides along the ray
+            Hit hh; hh.slot = slot0; hh.u = u0; hh.v = v0; hh.t = t0;
+            Its<false> its = make_its<false, LDS, true>(S, hh, ray, false);
+            its.p = x0; its.t = t0;
+            its.wi = to_local<false>(its, -ray.d);
+            Vec3f thr(1.f), Lsum(0.f);
+            const int e0 = mesh_emitter(S, its.mesh);
+            const bool le0 = !P.hide_emitters && e0 >= 0 && (e0 == env_id || its.wi.z > 0.f);
+            if (le0) { if (e0 == env_id) Lsum = env_radiance(ray.d); else { const float4 a = S.ld(T.emit_off + 2 * e0); Lsum = Vec3f(a.x, a.y, a.z); } }
+            int nb = 0;                                                   // bounces recorded
+            bool active = true;
+            auto nonzero = [](const Vec3f &v) { return v.x != 0.f || v.y != 0.f || v.z != 0.f; };
+            for (int depth = 0; depth < D && active; ++depth) {
+                float *br = brec + 11 * depth * kBlock;
+                br[8 * kBlock] = thr.x; br[9 * kBlock] = thr.y; br[10 * kBlock] = thr.z;
+                nb = depth + 1;
+                int flags = 0;              // 1 next-event term, 2 BSDF term, 8 the next vertex is a visible emitter, 16 the light sample is on the environment map
+                {   // next-event estimation (path.cpp:47-83): L += thr . F(wi, w) . Le . g cN, g = |nz.w| / r^2 . A / detach(A), cN = mis / pdf
+                    const float s1 = rng.next_1d(), s2 = rng.next_1d();
+                    if (mesh_emitter(S, its.mesh) < 0) {
+                        const PositionSample<false> ps = sample_emitter_position<false, LDS>(S, its.p, s1, s2);
+                        Vec3f wod = ps.p - its.p;
+                        const float dist_sqr = squared_norm(wod), dist = safe_sqrt(dist_sqr);
+                        wod = wod / dist;
+                        const Hit h1 = trace<LDS, false>(S, its.p, wod);
+                        if (h1.slot >= 0) {
+                            RayT<false> ray1; ray1.o = its.p; ray1.d = wod;
+                            const Its<false> its1 = make_its<false, LDS, false>(S, h1, ray1, true);
+                            const int eh = mesh_emitter(S, its1.mesh);
+                            if (its1.t > dist - kShadowEpsilon && eh >= 0) {
+                                const float G = fabsf(dot(its1.n, -wod)) / dist_sqr;
+                                const Vec3f wo_l = to_local<false>(its, wod);
+                                const Vec3f F = bsdf_eval<false, LDS>(S, its, wo_l, true);
+                                const float pdf1 = bsdf_pdf<false, LDS>(S, its, wo_l, true) * G;
+                                Vec3f Le(0.f);
+                                if (eh == env_id) Le = env_radiance(wod);
+                                else if (its1.wi.z > 0.f) { const float4 ea = S.ld(T.emit_off + 2 * eh); Le = Vec3f(ea.x, ea.y, ea.z); }
+                                if (pdf1 != 0.f && nonzero(Le) && nonzero(F)) {
+                                    const float cN = mis_weight(ps.pdf, pdf1) / ps.pdf;
+                                    Lsum = Lsum + thr * F * Le * (G * cN);
+                                    if (eh == env_id) { br[0] = ps.p.x; br[kBlock] = ps.p.y; br[2 * kBlock] = ps.p.z; flags |= 16; }
+                                    else { br[0] = __int_as_float(ps.slot); br[kBlock] = ps.ba; br[2 * kBlock] = ps.bb; }
+                                    br[3 * kBlock] = __int_as_float(h1.slot);
+                                    br[4 * kBlock] = cN;
+                                    flags |= 1;
+                                }
+                            }
+                        }
+                    }
+                }
+                {   // BSDF sampling (path.cpp:86-123): thr' = thr . F(wi, w) . g cf, cf = 1 / pdf0
+                    const float s0 = rng.next_1d(), s1 = rng.next_1d(), s2 = rng.next_1d();
+                    const BSDFSample bs = bsdf_sample<false, LDS>(S, its, s0, s1, s2, true);
+                    Hit hx; hx.slot = -1;
+                    RayT<false> curr; curr.o = its.p; curr.d = to_world<false>(its, bs.wo);
+                    if (bs.valid) hx = trace<LDS, false>(S, curr.o, curr.d);
+                    active = bs.valid && hx.slot >= 0;
+                    if (active) {
+                        const Its<false> itx = make_its<false, LDS, true>(S, hx, curr, true);
+                        float *vr = vrec + 3 * (depth + 1) * kBlock;
+                        vr[0] = __int_as_float(hx.slot); vr[kBlock] = hx.u; vr[2 * kBlock] = hx.v;
+                        const Vec3f wo = (itx.p - its.p) / itx.t;
+                        const float G = fabsf(dot(itx.n, -wo)) / sqr(itx.t);
+                        const float pdf0 = bs.pdf * G;
+                        const Vec3f F = (itx.t < kEpsilon) ? Vec3f(0.f) : bsdf_eval<false, LDS>(S, its, to_local<false>(its, wo), true);
+                        const float cf = 1.f / pdf0;
+                        const float w2 = mis_weight(pdf0, emitter_position_pdf<false, LDS>(S, its.p, itx));
+                        thr = thr * F * (G * cf);
+                        const int ex = mesh_emitter(S, itx.mesh);
+                        Vec3f Le(0.f);
+                        if (ex >= 0 && ex == env_id) Le = env_radiance(wo);
+                        else if (ex >= 0 && itx.wi.z > 0.f) { const float4 ea = S.ld(T.emit_off + 2 * ex); Le = Vec3f(ea.x, ea.y, ea.z); }
+                        if (nonzero(Le)) { Lsum = Lsum + Le * thr * w2; flags |= 8; }
+                        br[5 * kBlock] = cf; br[6 * kBlock] = w2;
+                        flags |= 2;
+                        its = itx;
+                    }
+                }
+                br[7 * kBlock] = __int_as_float(flags);
+            }
+            {   // integrator.cpp:126: a non-finite channel contributes nothing
+                const float pv[3] = {Lsum.x, Lsum.y, Lsum.z};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) if (!finite_(pv[c])) wgt[c] = 0.f;
+            }
+            const Vec3f W(wgt[0], wgt[1], wgt[2]);
+
+            // ------------------------------------------------------------ pass 2: back over the bounces
+            if (W.x != 0.f || W.y != 0.f || W.z != 0.f) {
+                Vec3f cam_dirb(0.f);                    // adjoint of the camera ray's direction from an environment lookup along it
+                if (le0 && e0 == env_id) cam_dirb = env_adjoint(ray.d, W);
+                else if (le0 && !P.skip_emitter) add_rgb(acc_emit, e0, W);          // the emitter seen by the camera
+                Vec3f Abar(0.f);                       // d (w.L) / d thr_{k+1} from the bounces behind k
+                Vec3f xb_next(0.f), nsb_next(0.f);     // what bounce k+1 gave vertex k+1 as ITS shading point
+                Vec3f pb_a(0.f), pb_b(0.f);            // what the incident directions of bounces k+1 / k+2 gave the vertex before them
+                Vec3f xb0(0.f), nsb0(0.f);             // the camera hit's totals
+                Vec3f dcam_b(0.f);                     // adjoint of the camera ray's direction as the incident direction of bounce 0
+                for (int k = nb - 1; k >= 0; --k) {
+                    const float *br = brec + 11 * k * kBlock;
+                    const int flags = __float_as_int(br[7 * kBlock]);
+                    const Vec3f thr_k(br[8 * kBlock], br[9 * kBlock], br[10 * kBlock]);
+                    const float *vr = vrec + 3 * k * kBlock;
+                    VtxGeom gk = load_vertex(S, __float_as_int(vr[0]), vr[kBlock], vr[2 * kBlock]);
+                    if (k == 0) gk.x = x0;
+                    const int bid = mesh_bsdf(S, gk.mesh);
+                    // the incident direction: the camera ray at the first vertex, (x_{k-1} - x_k) / r behind it (scene.cpp:686-690)
+                    Vec3f wi_w = -ray.d;
+                    float rin = 1.f;
+                    if (k > 0) {
+                        const float *vp = vrec + 3 * (k - 1) * kBlock;
+                        VtxGeom gp = load_vertex(S, __float_as_int(vp[0]), vp[kBlock], vp[2 * kBlock]);
+                        if (k == 1) gp.x = x0;
+                        const Vec3f vin = gp.x - gk.x;
+                        rin = norm(vin);
+                        wi_w = vin / rin;
+                    }
+                    Vec3f fs, ft;
+                    coordinate_system(gk.ns, fs, ft);            // any frame around ns serves an isotropic BSDF
+                    const Vec3f wi_l(dot(wi_w, fs), dot(wi_w, ft), dot(wi_w, gk.ns));
+                    Vec3f xb(0.f), nsb(0.f), A_k(0.f), wib_w(0.f);
+                    // F and, for its adjoint Fb, the adjoints of the outgoing direction (returned), of the incident direction and of ns
+                    // (accumulated), and of the BSDF's parameters (accumulated in LDS)
+                    auto bsdf_primal = [&](const Vec3f &w) -> Vec3f {
+                        const Vec3f wo_l(dot(w, fs), dot(w, ft), dot(w, gk.ns));
+                        return bsdf_value_and_adjoint<LDS>(S, bid, wi_l, wo_l, nullptr, nullptr, nullptr, nullptr, nullptr, false);
+                    };
+                    auto bsdf_back = [&](const Vec3f &w, const Vec3f &Fb) -> Vec3f {
+                        const Vec3f wo_l(dot(w, fs), dot(w, ft), dot(w, gk.ns));
+                        float wib_l[3], wob_l[3];
+                        bsdf_value_and_adjoint<LDS>(S, bid, wi_l, wo_l, &Fb, wib_l, wob_l, P.skip_bsdf ? nullptr : acc_bsdf, acc_mat, true);
+                        wib_w = wib_w + fs * wib_l[0] + ft * wib_l[1] + gk.ns * wib_l[2];
+                        // turning ns (the tangents follow) changes the local components of both directions
+                        const float ex = -wi_l.z * wib_l[0] + wi_l.x * wib_l[2] - wo_l.z * wob_l[0] + wo_l.x * wob_l[2];
+                        const float ey = -wi_l.z * wib_l[1] + wi_l.y * wib_l[2] - wo_l.z * wob_l[1] + wo_l.y * wob_l[2];
+                        nsb = nsb + fs * ex + ft * ey;
+                        return fs * wob_l[0] + ft * wob_l[1] + gk.ns * wob_l[2];
+                    };
+                    GeoGrad gg;
+                    if (flags & 2) {
+                        // thr_{k+1} = thr_k . F_f . g_f cf,  L += thr_{k+1} Le_{k+1} w2
+                        const float *vn = vrec + 3 * (k + 1) * kBlock;
+                        const VtxGeom gz = load_vertex(S, __float_as_int(vn[0]), vn[kBlock], vn[2 * kBlock]);
+                        const float cf = br[5 * kBlock], w2 = br[6 * kBlock];
+                        const float gf = geo_eval(gk.x, gz.x, gz.fn, gz.area, gg) * cf;
+                        const Vec3f w = normalize(gz.x - gk.x);
+                        const Vec3f Ff = bsdf_primal(w);
+                        Vec3f At = Abar;                                             // total adjoint of thr_{k+1}
+                        if (flags & 8) {
+                            const int ex = mesh_emitter(S, gz.mesh);
+                            if (ex == env_id) {
+                                At = At + W * env_radiance(w) * w2;
+                                xb = xb + dir_to_x(gk.x, gz.x, env_adjoint(w, W * thr_k * Ff * (gf * w2)));
+                            } else {
+                                const float4 ea = S.ld(T.emit_off + 2 * ex);
+                                At = At + W * Vec3f(ea.x, ea.y, ea.z) * w2;
+                                if (!P.skip_emitter) add_rgb(acc_emit, ex, W * thr_k * Ff * (gf * w2));
+                            }
+                        }
+                        const Vec3f tf = thr_k * Ff * At;
+                        const float gb = cf * (tf.x + tf.y + tf.z);
+                        A_k = A_k + Ff * At * gf;
+                        const Vec3f wob = bsdf_back(w, thr_k * At * gf);
+                        const Vec3f wx = dir_to_x(gk.x, gz.x, wob);                  // through w = (z - x) / r
+                        xb = xb + gg.dx * gb + wx; 
+                        // vertex k+1 is complete: end point of this segment + shading point of bounce k+1 + origin of bounce k+2's incident direction
+                        emit_glued(gz, xb_next + pb_b + gg.dz * gb - wx, nsb_next, gg.dnz * gb, gg.dA * gb);
+                    }
+                    if (flags & 1) {
+                        // L += thr_k . F_N . Le . g_N cN
+                        const bool on_env = (flags & 16) != 0;
+                        const VtxGeom gh = load_vertex(S, __float_as_int(br[3 * kBlock]), 0.f, 0.f);
+                        VtxGeom gy = gh;
+                        Vec3f y;
+                        float area_y = 1.f;
+                        if (on_env) y = Vec3f(br[0], br[kBlock], br[2 * kBlock]);
+                        else { gy = load_vertex(S, __float_as_int(br[0]), br[kBlock], br[2 * kBlock]); y = gy.x; area_y = gy.area; }
+                        const float cN = br[4 * kBlock];
+                        const float gN = geo_eval(gk.x, y, gh.fn, area_y, gg) * cN;
+                        const Vec3f w = normalize(y - gk.x);
+                        const Vec3f FN = bsdf_primal(w);
+                        Vec3f Le;
+                        const int eh = mesh_emitter(S, gh.mesh);
+                        if (on_env) Le = env_radiance(w); else { const float4 ea = S.ld(T.emit_off + 2 * eh); Le = Vec3f(ea.x, ea.y, ea.z); }
+                        const Vec3f al = W * thr_k * FN * Le;
+                        const float gb = cN * (al.x + al.y + al.z);
+                        A_k = A_k + W * FN * Le * gN;
+                        if (on_env) xb = xb + dir_to_x(gk.x, y, env_adjoint(w, W * thr_k * FN * gN));
+                        else if (!P.skip_emitter) add_rgb(acc_emit, eh, W * thr_k * FN * gN);
+                        const Vec3f wob = bsdf_back(w, W * thr_k * Le * gN);
+                        const Vec3f wx = dir_to_x(gk.x, y, wob);
+                        xb = xb + gg.dx * gb + wx;
+                        if (!on_env) {
+                            emit_glued(gy, gg.dz * gb - wx, Vec3f(0.f), Vec3f(0.f), gg.dA * gb);     // the light sample: position and area of ITS triangle
+                            emit_glued(gh, Vec3f(0.f), Vec3f(0.f), gg.dnz * gb, 0.f);                // the normal of the triangle the shadow ray hit
+                        }
+                    }
+                    // the incident direction's adjoint: to the camera ray at the first vertex, else to x_{k-1} and x_k
+                    Vec3f pb(0.f);
+                    if (k == 0) dcam_b = dcam_b - wib_w;
+                    else { pb = (wib_w - wi_w * dot(wi_w, wib_w)) / rin; xb = xb - pb; }
+                    xb_next = xb; nsb_next = nsb;
+                    Abar = A_k;
+                    pb_b = pb_a; pb_a = pb;
+                    if (k == 0) { xb0 = xb + pb_b; nsb0 = nsb; }
+                }
+                // the camera hit: x_0 = o + t d and ns_0 = normalize(blend(u, v)) with (u, v, t) = Moeller-Trumbore(p0, e1, e2; o, d)
+                if (nb > 0 || le0) {
+                    const VtxGeom g0 = load_vertex(S, slot0, u0, v0);
+                    float ub = 0.f, vb = 0.f;
+                    const float tb = dot(ray.d, xb0);
+                    Vec3f ob = xb0, db = xb0 * t0 + dcam_b;
+                    const bool want0 = wanted(g0);
+                    if (g0.flat) { if (want0) add_vec(g0, 18, nsb0); }
+                    else {
+                        const Vec3f nbb = blend_adjoint(g0, nsb0);
+                        ub = dot(g0.n1 - g0.n0, nbb); vb = dot(g0.n2 - g0.n0, nbb);
+                        if (want0) { add_vec(g0, 9, nbb * (1.f - u0 - v0)); add_vec(g0, 12, nbb * u0); add_vec(g0, 15, nbb * v0); }
+                    }
+                    Vec3f p0b, e1b, e2b, ob2, db2;
+                    mt_adjoint(g0.p0, g0.e1, g0.e2, ray.o, ray.d, ub, vb, tb, p0b, e1b, e2b, ob2, db2);
+                    if (want0) { add_vec(g0, 0, p0b); add_vec(g0, 3, e1b); add_vec(g0, 6, e2b); }
+                    if (P.g_cam != nullptr) {
+                        // o = to_world . (o_cam, 1), d = to_world . (d_cam, 0)  (primary_ray_pose_tangent)
+                        ob = ob + ob2; db = db + db2 + cam_dirb;
+                        const Vec3f pc = xform_pos(cam.sample_to_camera, Vec3f(sx, sy, 0.f));
+                        const Vec3f o_cam = cam.ortho ? pc : Vec3f(0.f), d_cam = cam.ortho ? Vec3f(0.f, 0.f, 1.f) : normalize(pc);
+                        const float oc[4] = {o_cam.x, o_cam.y, o_cam.z, 1.f}, dc[4] = {d_cam.x, d_cam.y, d_cam.z, 0.f};
+                        const float obv[3] = {ob.x, ob.y, ob.z}, dbv[3] = {db.x, db.y, db.z};
+#pragma unroll
+                        for (int r = 0; r < 3; ++r)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const float val = obv[r] * oc[c] + dbv[r] * dc[c];
+                                if (val != 0.f && finite_(val)) atomicAdd(&acc_cam[4 * r + c], val);
+                            }
+                    }
+                }
+            }
+            have = false;
+        }
+    }
+    __syncthreads();
+    if (P.g_cam != nullptr && threadIdx.x < 12 && acc_cam[threadIdx.x] != 0.f) atomicAdd(&P.g_cam[threadIdx.x], acc_cam[threadIdx.x]);
+    if (P.g_env_scale != nullptr && threadIdx.x == 12 && acc_cam[12] != 0.f) atomicAdd(P.g_env_scale, acc_cam[12]);
+    if (P.g_env_xf != nullptr && threadIdx.x >= 16 && threadIdx.x < 27 && acc_cam[threadIdx.x] != 0.f) atomicAdd(&P.g_env_xf[threadIdx.x - 16], acc_cam[threadIdx.x]);
+    for (int i = threadIdx.x; i < P.n_hot * 22; i += kBlock) if (acc[i] != 0.f) atomicAdd(&P.g_tri[P.hot_inv[i / 22] * 22 + i % 22], acc[i]);
+    for (int i = threadIdx.x; i < T.n_bsdfs * 3; i += kBlock) if (acc_bsdf[i] != 0.f) atomicAdd(&P.g_bsdf[i], acc_bsdf[i]);
+    if (P.g_mat != nullptr)
+        for (int i = threadIdx.x; i < T.n_bsdfs * kMatRow; i += kBlock) if (acc_mat[i] != 0.f) atomicAdd(&P.g_mat[i], acc_mat[i]);
+    for (int i = threadIdx.x; i < T.n_emitters * 3; i += kBlock) if (acc_emit[i] != 0.f) atomicAdd(&P.g_emitter[i], acc_emit[i]);
+}
+
+
+
+} // namespace psdr

@@ -72,7 +72,7 @@ def test_adjoint_dot_product(env, param, terms):
         assert abs(lhs) > 1e-6          # the test is not vacuous
 
 
-def _dot_product_case(env, spec, depth, terms, seeds=(7, 8, 9), with_camera=False):
+def _dot_product_case(env, spec, depth, terms, seeds=(7, 8, 9), with_camera=False, with_mat=False):
     """<w, J v> against <J^T w, v> for the forward tangent the spec carries"""
     torch, psdr, cabi = env
     sc = product.build_scene(spec)
@@ -100,6 +100,9 @@ def _dot_product_case(env, spec, depth, terms, seeds=(7, 8, 9), with_camera=Fals
     g = cabi.Grads(g_tri.data_ptr(), g_bsdf.data_ptr(), g_em.data_ptr(), g_sec.data_ptr(), g_prim.data_ptr())
     if with_camera:
         g.g_camera = g_cam.data_ptr()
+    g_mat = torch.zeros((max(1, len(spec.bsdfs)), 16), dtype=torch.float32, device=dev)
+    if with_mat:
+        g.g_mat = g_mat.data_ptr()
     cabi.check(cabi.lib().psdr_hip_render_d_bwd(sc._hip_handle(), C.byref(a), w.data_ptr(), C.byref(g), None))
     torch.cuda.synchronize()
     rhs = (g_tri.cpu().numpy().astype(np.float64) * d_tri).sum() + (g_bsdf.cpu().numpy().astype(np.float64)[:len(spec.bsdfs)] * d_bsdf).sum()
@@ -108,6 +111,11 @@ def _dot_product_case(env, spec, depth, terms, seeds=(7, 8, 9), with_camera=Fals
     if with_camera:
         d_tw = np.asarray(cam._get("to_world_left", True), np.float64).reshape(4, 4) if hasattr(cam, "_get") else np.zeros((4, 4))
         rhs += (g_cam.cpu().numpy().astype(np.float64).reshape(4, 4)[:3] * d_tw[:3]).sum()
+    if with_mat:          # g_mat row of a Microfacet BSDF: specular rgb, roughness
+        gm = g_mat.cpu().numpy().astype(np.float64)
+        for i, b in enumerate(spec.bsdfs):
+            if getattr(b, "type", 0) == 1:
+                rhs += (gm[i, 0:3] * np.asarray(getattr(b, "d_specular", (0, 0, 0)), np.float64)).sum() + gm[i, 3] * float(getattr(b, "d_roughness", 0.0))
     scale = float((buf[1].double().abs() * w.double()).sum()) + 1e-12
     return lhs, rhs, scale
 
@@ -155,3 +163,12 @@ def test_interior_sweep_environment_map(env, param, balls):
     look the radiance up along their direction - the sweep carries that direction's adjoint back to the shading point"""
     lhs, rhs, scale = _dot_product_case(env, scenes.envmap_scene(40, 40, 8, 0, 0, param=param, area_light=True, balls=balls), depth=3, terms=1)
     assert abs(lhs - rhs) <= 3e-4 * scale and abs(lhs) > 1e-6, (param, lhs, rhs, scale)
+
+
+@pytest.mark.parametrize("param,two_sided", [("box_x", False), ("diffuse", False), ("roughness", False), ("specular", False), ("box_x", True), ("roughness", True)])
+def test_interior_sweep_microfacet(env, param, two_sided):
+    """Cornell box with Microfacet (GGX) boxes: the material sweep (adjoint_mat.h) - the lobe depends on both directions, so a bounce
+    also reaches the vertex before it; geometry, diffuse reflectance, specular and roughness adjoints against forward mode"""
+    spec = scenes.microfacet_cbox_scene(40, 40, 8, 0, 0, param=param, two_sided=two_sided)
+    lhs, rhs, scale = _dot_product_case(env, spec, depth=3, terms=1, with_mat=True)
+    assert abs(lhs - rhs) <= 5e-4 * scale and abs(lhs) > 1e-6, (param, two_sided, lhs, rhs, scale)
