@@ -475,6 +475,15 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
         if constexpr (has_env(LDS)) return env_eval_direction<false, LDS>(S, T.env, dir);
         else return Vec3f(0.f);
     };
+    // the direction an environment lookup uses for a ray from x that ended on the bounding cube at (slot, u, v): the hit point's local
+    // incident direction taken back to the world through the cube face's frame (intersection.h / envmap.cpp:47-56) - bit for bit what
+    // the forward pass looks up, so that both passes land in the same texel cell of the (piecewise bilinear) map
+    auto env_dir_at = [&](int slot, float u, float v, const Vec3f &x) -> Vec3f {
+        Hit h; h.slot = slot; h.u = u; h.v = v; h.t = 0.f;
+        RayT<false> r; r.o = x; r.d = Vec3f(0.f, 0.f, 1.f);
+        const Its<false> i1 = make_its<false, LDS, true>(S, h, r, true);
+        return -to_world<false>(i1, i1.wi);
+    };
     auto env_adjoint = [&](const Vec3f &dir, const Vec3f &Lb) -> Vec3f {
         Vec3f dirb(0.f);
         if constexpr (has_env(LDS)) {
@@ -609,7 +618,8 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
             Vec3f thr(1.f), Lsum(0.f);
             const int e0 = mesh_emitter(S, its.mesh);
             const bool le0 = !P.hide_emitters && e0 >= 0 && (e0 == env_id || its.wi.z > 0.f);
-            if (le0) { if (e0 == env_id) Lsum = env_radiance(ray.d); else { const float4 a = S.ld(T.emit_off + 2 * e0); Lsum = Vec3f(a.x, a.y, a.z); } }
+            const Vec3f dir0 = -to_world<false>(its, its.wi);          // (= ray.d through the frame of the first hit, as eval_Le rebuilds it)
+            if (le0) { if (e0 == env_id) Lsum = env_radiance(dir0); else { const float4 a = S.ld(T.emit_off + 2 * e0); Lsum = Vec3f(a.x, a.y, a.z); } }
             int nb = 0;                                                   // bounces recorded
             bool active = true;
             for (int depth = 0; depth < D && active; ++depth) {
@@ -645,8 +655,8 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
                                     if (eh == env_id) {
                                         // the sample lies on the scene box (a fixed point: the record keeps it instead of a triangle),
                                         // the radiance is looked up along the shadow ray
-                                        Lsum = Lsum + thr * rho * env_radiance(wod) * (woz * G * cN);
-                                        br[0] = ps.p.x; br[kBlock] = ps.p.y; br[2 * kBlock] = ps.p.z; br[3 * kBlock] = __int_as_float(h1.slot);
+                                        Lsum = Lsum + thr * rho * env_radiance(env_dir_at(h1.slot, h1.u, h1.v, its.p)) * (woz * G * cN);
+                                        br[0] = h1.u; br[kBlock] = h1.v; br[2 * kBlock] = 0.f; br[3 * kBlock] = __int_as_float(h1.slot);
                                         br[4 * kBlock] = cN;
                                         flags |= 1 | 16;
                                     } else if (its1.wi.z > 0.f) {
@@ -681,7 +691,7 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
                         const float w2 = mis_weight(pdf0, emitter_position_pdf<false, LDS>(S, its.p, itx));
                         thr = ok ? thr * rho * (woz * G * cf) : Vec3f(0.f);
                         const int ex = mesh_emitter(S, itx.mesh);
-                        if (ex >= 0 && ex == env_id) { Lsum = Lsum + env_radiance(wo) * thr * w2; flags |= 8; }
+                        if (ex >= 0 && ex == env_id) { Lsum = Lsum + env_radiance(env_dir_at(hx.slot, hx.u, hx.v, its.p)) * thr * w2; flags |= 8; }
                         else if (ex >= 0 && itx.wi.z > 0.f) { const float4 ea = S.ld(T.emit_off + 2 * ex); Lsum = Lsum + Vec3f(ea.x, ea.y, ea.z) * thr * w2; flags |= 8; }
                         br[5 * kBlock] = cf; br[6 * kBlock] = w2;
                         flags |= 2;
@@ -700,7 +710,7 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
             // ------------------------------------------------------------ pass 2: back over the bounces
             if (W.x != 0.f || W.y != 0.f || W.z != 0.f) {
                 Vec3f cam_dirb(0.f);                    // adjoint of the camera ray's direction from an environment lookup along it
-                if (le0 && e0 == env_id) cam_dirb = env_adjoint(ray.d, W);
+                if (le0 && e0 == env_id) cam_dirb = env_adjoint(dir0, W);
                 else if (le0 && !P.skip_emitter) add_rgb(acc_emit, e0, W);          // the emitter seen by the camera
                 Vec3f Abar(0.f);                       // d (w.L) / d thr_{k+1} from the bounces behind k
                 Vec3f xb_next(0.f), nsb_next(0.f);     // what bounce k+1 gave vertex k+1 as ITS shading point
@@ -728,7 +738,7 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
                         if (flags & 8) {
                             const int ex = mesh_emitter(S, gz.mesh);
                             if (ex == env_id) {
-                                const Vec3f dir = normalize(gz.x - gk.x);
+                                const Vec3f dir = env_dir_at(__float_as_int(vn[0]), vn[kBlock], vn[2 * kBlock], gk.x);
                                 At = At + W * env_radiance(dir) * w2;
                                 xb = xb + dir_to_x(gk.x, gz.x, env_adjoint(dir, W * thr_k * rho * (sf * w2)));
                             } else {
@@ -746,11 +756,11 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
                     }
                     if ((flags & 1) && (flags & 16)) {
                         // next-event sample on the environment map: L += thr_k rho Le(dir) cN s_N with a fixed sample point y on the scene box
-                        const Vec3f y(br[0], br[kBlock], br[2 * kBlock]);
-                        const VtxGeom gh = load_vertex(S, __float_as_int(br[3 * kBlock]), 0.f, 0.f);
+                        const VtxGeom gh = load_vertex(S, __float_as_int(br[3 * kBlock]), br[0], br[kBlock]);       // the shadow ray's hit on the cube
+                        const Vec3f y = gh.x;
                         const float cN = br[4 * kBlock];
                         const float sN = seg_eval(gk.x, gk.ns, sgn, y, gh.fn, 1.f, sg) * cN;
-                        const Vec3f dir = normalize(y - gk.x);
+                        const Vec3f dir = env_dir_at(__float_as_int(br[3 * kBlock]), br[0], br[kBlock], gk.x);
                         const Vec3f Le = env_radiance(dir);
                         const Vec3f al = W * thr_k * rho * Le;
                         const float sb = cN * (al.x + al.y + al.z);

@@ -31,22 +31,59 @@ PSDR_DEV float geo_eval(const Vec3f &x, const Vec3f &z, const Vec3f &nz, float a
     return G;
 }
 
-// F(wi, wo) of BSDF `bid` in local coordinates (Diffuse or Microfacet with constant parameters) and, when `Fb` is given, the adjoints
-// of the six direction components; the parameter adjoints are added to acc_bsdf (colour / diffuse reflectance) and acc_mat (g_mat row:
-// specular rgb, roughness)
+// F(wi, wo) of BSDF `bid` in local coordinates (Diffuse or Microfacet; constant or bitmap parameters looked up at (tu, tv)) and, when
+// `Fb` is given, the adjoints of the six direction components.  The parameter adjoints are added to acc_bsdf (constant colour /
+// diffuse reflectance) and acc_mat (g_mat row: constant specular rgb, roughness) or, for a bitmap parameter, scattered over the four
+// texels of the lookup (g_tex, TexDev::g_off) and - uvb given - chained to the texture coordinates (the camera vertex: its
+// barycentrics are differentiable).
 template <int LDS>
-PSDR_DEV Vec3f bsdf_value_and_adjoint(const SceneView<LDS> &S, int bid, const Vec3f &wi, const Vec3f &wo, const Vec3f *Fb, float *wib, float *wob,
-                                      float *acc_bsdf, float *acc_mat, bool params) {
+PSDR_DEV Vec3f bsdf_value_and_adjoint(const SceneView<LDS> &S, int bid, const Vec3f &wi, const Vec3f &wo, float tu, float tv, const Vec3f *Fb,
+                                      float *wib, float *wob, float *acc_bsdf, float *acc_mat, float *g_tex, float *uvb) {
     if (wib) { wib[0] = wib[1] = wib[2] = 0.f; wob[0] = wob[1] = wob[2] = 0.f; }
     if (bid < 0) return Vec3f(0.f);
     const float4 a = S.ld(S.T->bsdf_off + 2 * bid);
     const int fl = __float_as_int(a.w);
     const bool two = (fl & 1) != 0;
     auto add = [](float *p, float v) { if (v != 0.f && finite_(v)) atomicAdd(p, v); };
+    Vec3f diff(a.x, a.y, a.z);
+    // adjoint pb[CH] of the value looked up in texture slot `slot`: texels by the footprint, (tu, tv) by two forward evaluations
+    auto tex_value = [&](int slot, auto ch, float *out) {
+        if constexpr (has_mat(LDS)) {
+            constexpr int CH = decltype(ch)::value;
+            const TexDev td = S.T->tex[3 * bid + slot];
+            env::bitmap_eval_tex<float, CH>([&](int i, int c) { return td.data[CH * i + c]; }, td.w, td.h, tu, tv, true, out);
+        }
+    };
+    auto tex_back = [&](int slot, auto ch, const float *pb) {
+        if constexpr (has_mat(LDS)) {
+            constexpr int CH = decltype(ch)::value;
+            const TexDev td = S.T->tex[3 * bid + slot];
+            if (g_tex != nullptr) {
+                int idx[4]; float wt[4];
+                env::bitmap_footprint(td.w, td.h, tu, tv, true, idx, wt);
+                for (int c = 0; c < CH; ++c)
+                    if (pb[c] != 0.f && finite_(pb[c])) for (int k = 0; k < 4; ++k) atomicAdd(&g_tex[td.g_off + (long long) CH * idx[k] + c], pb[c] * wt[k]);
+            }
+            if (uvb != nullptr) {
+                for (int ax = 0; ax < 2; ++ax) {
+                    Dual o[CH];
+                    env::bitmap_eval_tex<Dual, CH>([&](int i, int c) { return Dual(td.data[CH * i + c], 0.f); }, td.w, td.h, Dual(tu, ax == 0 ? 1.f : 0.f), Dual(tv, ax == 1 ? 1.f : 0.f), true, o);
+                    float g = 0.f;
+                    for (int c = 0; c < CH; ++c) g += pb[c] * o[c].d;
+                    if (finite_(g)) uvb[ax] += g;
+                }
+            }
+        }
+    };
     if constexpr (has_mat(LDS)) {
+        if (fl & 2) { float o[3]; tex_value(0, std::integral_constant<int, 3>(), o); diff = Vec3f(o[0], o[1], o[2]); }
         if (fl & 4) {
             const MatDev md = S.T->mat[bid];
-            const Vec3f F = microfacet_eval<float>(Vec3f(md.specular[0], md.specular[1], md.specular[2]), Vec3f(a.x, a.y, a.z), md.roughness, two, wi, wo, true);
+            Vec3f spec(md.specular[0], md.specular[1], md.specular[2]);
+            float rough = md.roughness;
+            if (fl & 32) { float o[3]; tex_value(1, std::integral_constant<int, 3>(), o); spec = Vec3f(o[0], o[1], o[2]); }
+            if (fl & 64) { float o[1]; tex_value(2, std::integral_constant<int, 1>(), o); rough = o[0]; }
+            const Vec3f F = microfacet_eval<float>(spec, diff, rough, two, wi, wo, true);
             if (Fb == nullptr) return F;
             if (!(finite_(Fb->x) && finite_(Fb->y) && finite_(Fb->z)) || (Fb->x == 0.f && Fb->y == 0.f && Fb->z == 0.f)) return F;
             for (int j = 0; j < 9; ++j) {
@@ -54,16 +91,23 @@ PSDR_DEV Vec3f bsdf_value_and_adjoint(const SceneView<LDS> &S, int bid, const Ve
                 const Vec3d wiD(Dual(wi.x, j == 0 ? one : 0.f), Dual(wi.y, j == 1 ? one : 0.f), Dual(wi.z, j == 2 ? one : 0.f));
                 const Vec3d woD(Dual(wo.x, j == 3 ? one : 0.f), Dual(wo.y, j == 4 ? one : 0.f), Dual(wo.z, j == 5 ? one : 0.f));
                 const float ts = j == 6 ? one : 0.f, tr = j == 7 ? one : 0.f, td = j == 8 ? one : 0.f;
-                if (j >= 6 && !params) break;
-                const Vec3d spec(Dual(md.specular[0], ts), Dual(md.specular[1], ts), Dual(md.specular[2], ts));
-                const Vec3d diff(Dual(a.x, td), Dual(a.y, td), Dual(a.z, td));
-                const Vec3d r = microfacet_eval<Dual>(spec, diff, Dual(md.roughness, tr), two, wiD, woD, true);
-                const float dx = Fb->x * r.x.d, dy = Fb->y * r.y.d, dz = Fb->z * r.z.d;
-                if (j < 3) wib[j] = dx + dy + dz;
-                else if (j < 6) wob[j - 3] = dx + dy + dz;
-                else if (j == 6) { if (acc_mat) { add(&acc_mat[bid * kMatRow], dx); add(&acc_mat[bid * kMatRow + 1], dy); add(&acc_mat[bid * kMatRow + 2], dz); } }
-                else if (j == 7) { if (acc_mat) add(&acc_mat[bid * kMatRow + 3], dx + dy + dz); }
-                else { if (acc_bsdf) { add(&acc_bsdf[3 * bid], dx); add(&acc_bsdf[3 * bid + 1], dy); add(&acc_bsdf[3 * bid + 2], dz); } }
+                const Vec3d specD(Dual(spec.x, ts), Dual(spec.y, ts), Dual(spec.z, ts));
+                const Vec3d diffD(Dual(diff.x, td), Dual(diff.y, td), Dual(diff.z, td));
+                const Vec3d r = microfacet_eval<Dual>(specD, diffD, Dual(rough, tr), two, wiD, woD, true);
+                const float pb[3] = {Fb->x * r.x.d, Fb->y * r.y.d, Fb->z * r.z.d};
+                if (j < 3) wib[j] = pb[0] + pb[1] + pb[2];
+                else if (j < 6) wob[j - 3] = pb[0] + pb[1] + pb[2];
+                else if (j == 6) {
+                    if (fl & 32) tex_back(1, std::integral_constant<int, 3>(), pb);
+                    else if (acc_mat) { add(&acc_mat[bid * kMatRow], pb[0]); add(&acc_mat[bid * kMatRow + 1], pb[1]); add(&acc_mat[bid * kMatRow + 2], pb[2]); }
+                } else if (j == 7) {
+                    const float rb[1] = {pb[0] + pb[1] + pb[2]};
+                    if (fl & 64) tex_back(2, std::integral_constant<int, 1>(), rb);
+                    else if (acc_mat) add(&acc_mat[bid * kMatRow + 3], rb[0]);
+                } else {
+                    if (fl & 2) tex_back(0, std::integral_constant<int, 3>(), pb);
+                    else if (acc_bsdf) { add(&acc_bsdf[3 * bid], pb[0]); add(&acc_bsdf[3 * bid + 1], pb[1]); add(&acc_bsdf[3 * bid + 2], pb[2]); }
+                }
             }
             for (int j = 0; j < 3; ++j) { if (!finite_(wib[j])) wib[j] = 0.f; if (!finite_(wob[j])) wob[j] = 0.f; }
             return F;
@@ -73,11 +117,12 @@ PSDR_DEV Vec3f bsdf_value_and_adjoint(const SceneView<LDS> &S, int bid, const Ve
     float wiz = wi.z, woz = wo.z, sg = 1.f;
     if (two) { sg = wiz < 0.f ? -1.f : 1.f; woz = woz * sg; wiz = fabsf(wiz); }
     if (!(wiz > 0.f && woz > 0.f)) return Vec3f(0.f);
-    const Vec3f rho(a.x, a.y, a.z);
-    const Vec3f F = rho * (kInvPi * woz);
+    const Vec3f F = diff * (kInvPi * woz);
     if (Fb != nullptr && finite_(Fb->x) && finite_(Fb->y) && finite_(Fb->z)) {
-        wob[2] = sg * kInvPi * (Fb->x * rho.x + Fb->y * rho.y + Fb->z * rho.z);
-        if (params && acc_bsdf) { add(&acc_bsdf[3 * bid], Fb->x * kInvPi * woz); add(&acc_bsdf[3 * bid + 1], Fb->y * kInvPi * woz); add(&acc_bsdf[3 * bid + 2], Fb->z * kInvPi * woz); }
+        wob[2] = sg * kInvPi * (Fb->x * diff.x + Fb->y * diff.y + Fb->z * diff.z);
+        const float pb[3] = {Fb->x * kInvPi * woz, Fb->y * kInvPi * woz, Fb->z * kInvPi * woz};
+        if (fl & 2) tex_back(0, std::integral_constant<int, 3>(), pb);
+        else if (acc_bsdf) { add(&acc_bsdf[3 * bid], pb[0]); add(&acc_bsdf[3 * bid + 1], pb[1]); add(&acc_bsdf[3 * bid + 2], pb[2]); }
     }
     return F;
 }
@@ -122,6 +167,15 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
     auto env_radiance = [&](const Vec3f &dir) -> Vec3f {
         if constexpr (has_env(LDS)) return env_eval_direction<false, LDS>(S, T.env, dir);
         else return Vec3f(0.f);
+    };
+    // the direction an environment lookup uses for a ray from x that ended on the bounding cube at (slot, u, v): the hit point's local
+    // incident direction taken back to the world through the cube face's frame (intersection.h / envmap.cpp:47-56) - bit for bit what
+    // the forward pass looks up, so that both passes land in the same texel cell of the (piecewise bilinear) map
+    auto env_dir_at = [&](int slot, float u, float v, const Vec3f &x) -> Vec3f {
+        Hit h; h.slot = slot; h.u = u; h.v = v; h.t = 0.f;
+        RayT<false> r; r.o = x; r.d = Vec3f(0.f, 0.f, 1.f);
+        const Its<false> i1 = make_its<false, LDS, true>(S, h, r, true);
+        return -to_world<false>(i1, i1.wi);
     };
     auto env_adjoint = [&](const Vec3f &dir, const Vec3f &Lb) -> Vec3f {
         Vec3f dirb(0.f);
@@ -257,7 +311,8 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
             Vec3f thr(1.f), Lsum(0.f);
             const int e0 = mesh_emitter(S, its.mesh);
             const bool le0 = !P.hide_emitters && e0 >= 0 && (e0 == env_id || its.wi.z > 0.f);
-            if (le0) { if (e0 == env_id) Lsum = env_radiance(ray.d); else { const float4 a = S.ld(T.emit_off + 2 * e0); Lsum = Vec3f(a.x, a.y, a.z); } }
+            const Vec3f dir0 = -to_world<false>(its, its.wi);          // (= ray.d through the frame of the first hit, as eval_Le rebuilds it)
+            if (le0) { if (e0 == env_id) Lsum = env_radiance(dir0); else { const float4 a = S.ld(T.emit_off + 2 * e0); Lsum = Vec3f(a.x, a.y, a.z); } }
             int nb = 0;                                                   // bounces recorded
             bool active = true;
             auto nonzero = [](const Vec3f &v) { return v.x != 0.f || v.y != 0.f || v.z != 0.f; };
@@ -284,12 +339,12 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                                 const Vec3f F = bsdf_eval<false, LDS>(S, its, wo_l, true);
                                 const float pdf1 = bsdf_pdf<false, LDS>(S, its, wo_l, true) * G;
                                 Vec3f Le(0.f);
-                                if (eh == env_id) Le = env_radiance(wod);
+                                if (eh == env_id) Le = env_radiance(env_dir_at(h1.slot, h1.u, h1.v, its.p));
                                 else if (its1.wi.z > 0.f) { const float4 ea = S.ld(T.emit_off + 2 * eh); Le = Vec3f(ea.x, ea.y, ea.z); }
                                 if (pdf1 != 0.f && nonzero(Le) && nonzero(F)) {
                                     const float cN = mis_weight(ps.pdf, pdf1) / ps.pdf;
                                     Lsum = Lsum + thr * F * Le * (G * cN);
-                                    if (eh == env_id) { br[0] = ps.p.x; br[kBlock] = ps.p.y; br[2 * kBlock] = ps.p.z; flags |= 16; }
+                                    if (eh == env_id) { br[0] = h1.u; br[kBlock] = h1.v; br[2 * kBlock] = 0.f; flags |= 16; }
                                     else { br[0] = __int_as_float(ps.slot); br[kBlock] = ps.ba; br[2 * kBlock] = ps.bb; }
                                     br[3 * kBlock] = __int_as_float(h1.slot);
                                     br[4 * kBlock] = cN;
@@ -319,7 +374,7 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                         thr = thr * F * (G * cf);
                         const int ex = mesh_emitter(S, itx.mesh);
                         Vec3f Le(0.f);
-                        if (ex >= 0 && ex == env_id) Le = env_radiance(wo);
+                        if (ex >= 0 && ex == env_id) Le = env_radiance(env_dir_at(hx.slot, hx.u, hx.v, its.p));
                         else if (ex >= 0 && itx.wi.z > 0.f) { const float4 ea = S.ld(T.emit_off + 2 * ex); Le = Vec3f(ea.x, ea.y, ea.z); }
                         if (nonzero(Le)) { Lsum = Lsum + Le * thr * w2; flags |= 8; }
                         br[5 * kBlock] = cf; br[6 * kBlock] = w2;
@@ -339,13 +394,14 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
             // ------------------------------------------------------------ pass 2: back over the bounces
             if (W.x != 0.f || W.y != 0.f || W.z != 0.f) {
                 Vec3f cam_dirb(0.f);                    // adjoint of the camera ray's direction from an environment lookup along it
-                if (le0 && e0 == env_id) cam_dirb = env_adjoint(ray.d, W);
+                if (le0 && e0 == env_id) cam_dirb = env_adjoint(dir0, W);
                 else if (le0 && !P.skip_emitter) add_rgb(acc_emit, e0, W);          // the emitter seen by the camera
                 Vec3f Abar(0.f);                       // d (w.L) / d thr_{k+1} from the bounces behind k
                 Vec3f xb_next(0.f), nsb_next(0.f);     // what bounce k+1 gave vertex k+1 as ITS shading point
                 Vec3f pb_a(0.f), pb_b(0.f);            // what the incident directions of bounces k+1 / k+2 gave the vertex before them
                 Vec3f xb0(0.f), nsb0(0.f);             // the camera hit's totals
                 Vec3f dcam_b(0.f);                     // adjoint of the camera ray's direction as the incident direction of bounce 0
+                float ub_tex = 0.f, vb_tex = 0.f;      // adjoints of the camera hit's barycentrics through its texture coordinates
                 for (int k = nb - 1; k >= 0; --k) {
                     const float *br = brec + 11 * k * kBlock;
                     const int flags = __float_as_int(br[7 * kBlock]);
@@ -371,14 +427,23 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                     Vec3f xb(0.f), nsb(0.f), A_k(0.f), wib_w(0.f);
                     // F and, for its adjoint Fb, the adjoints of the outgoing direction (returned), of the incident direction and of ns
                     // (accumulated), and of the BSDF's parameters (accumulated in LDS)
+                    // texture coordinates of the vertex (scene.cpp:715/779): uv0 + (uv1 - uv0) u + (uv2 - uv0) v
+                    float tu = 0.f, tv = 0.f, du0x = 0.f, du0y = 0.f, du1x = 0.f, du1y = 0.f, uvb[2] = {0.f, 0.f};
+                    if (T.tex != nullptr) {
+                        const int wsh = T.shade_off + 6 * __float_as_int(vr[0]);
+                        const float4 s4 = S.ld(wsh + 4), s5 = S.ld(wsh + 5);
+                        du0x = s4.z - s4.x; du0y = s4.w - s4.y; du1x = s5.x - s4.x; du1y = s5.y - s4.y;
+                        const float bu = k == 0 ? u0 : vr[kBlock], bv = k == 0 ? v0 : vr[2 * kBlock];
+                        tu = fmaf(du0x, bu, fmaf(du1x, bv, s4.x)); tv = fmaf(du0y, bu, fmaf(du1y, bv, s4.y));
+                    }
                     auto bsdf_primal = [&](const Vec3f &w) -> Vec3f {
                         const Vec3f wo_l(dot(w, fs), dot(w, ft), dot(w, gk.ns));
-                        return bsdf_value_and_adjoint<LDS>(S, bid, wi_l, wo_l, nullptr, nullptr, nullptr, nullptr, nullptr, false);
+                        return bsdf_value_and_adjoint<LDS>(S, bid, wi_l, wo_l, tu, tv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
                     };
                     auto bsdf_back = [&](const Vec3f &w, const Vec3f &Fb) -> Vec3f {
                         const Vec3f wo_l(dot(w, fs), dot(w, ft), dot(w, gk.ns));
                         float wib_l[3], wob_l[3];
-                        bsdf_value_and_adjoint<LDS>(S, bid, wi_l, wo_l, &Fb, wib_l, wob_l, P.skip_bsdf ? nullptr : acc_bsdf, acc_mat, true);
+                        bsdf_value_and_adjoint<LDS>(S, bid, wi_l, wo_l, tu, tv, &Fb, wib_l, wob_l, P.skip_bsdf ? nullptr : acc_bsdf, acc_mat, P.g_tex, (k == 0 && T.tex != nullptr) ? uvb : nullptr);
                         wib_w = wib_w + fs * wib_l[0] + ft * wib_l[1] + gk.ns * wib_l[2];
                         // turning ns (the tangents follow) changes the local components of both directions
                         const float ex = -wi_l.z * wib_l[0] + wi_l.x * wib_l[2] - wo_l.z * wob_l[0] + wo_l.x * wob_l[2];
@@ -399,8 +464,9 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                         if (flags & 8) {
                             const int ex = mesh_emitter(S, gz.mesh);
                             if (ex == env_id) {
-                                At = At + W * env_radiance(w) * w2;
-                                xb = xb + dir_to_x(gk.x, gz.x, env_adjoint(w, W * thr_k * Ff * (gf * w2)));
+                                const Vec3f dir = env_dir_at(__float_as_int(vn[0]), vn[kBlock], vn[2 * kBlock], gk.x);
+                                At = At + W * env_radiance(dir) * w2;
+                                xb = xb + dir_to_x(gk.x, gz.x, env_adjoint(dir, W * thr_k * Ff * (gf * w2)));
                             } else {
                                 const float4 ea = S.ld(T.emit_off + 2 * ex);
                                 At = At + W * Vec3f(ea.x, ea.y, ea.z) * w2;
@@ -419,11 +485,11 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                     if (flags & 1) {
                         // L += thr_k . F_N . Le . g_N cN
                         const bool on_env = (flags & 16) != 0;
-                        const VtxGeom gh = load_vertex(S, __float_as_int(br[3 * kBlock]), 0.f, 0.f);
+                        const VtxGeom gh = load_vertex(S, __float_as_int(br[3 * kBlock]), on_env ? br[0] : 0.f, on_env ? br[kBlock] : 0.f);
                         VtxGeom gy = gh;
                         Vec3f y;
                         float area_y = 1.f;
-                        if (on_env) y = Vec3f(br[0], br[kBlock], br[2 * kBlock]);
+                        if (on_env) y = gh.x;                  // the shadow ray's hit on the cube
                         else { gy = load_vertex(S, __float_as_int(br[0]), br[kBlock], br[2 * kBlock]); y = gy.x; area_y = gy.area; }
                         const float cN = br[4 * kBlock];
                         const float gN = geo_eval(gk.x, y, gh.fn, area_y, gg) * cN;
@@ -431,11 +497,12 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                         const Vec3f FN = bsdf_primal(w);
                         Vec3f Le;
                         const int eh = mesh_emitter(S, gh.mesh);
-                        if (on_env) Le = env_radiance(w); else { const float4 ea = S.ld(T.emit_off + 2 * eh); Le = Vec3f(ea.x, ea.y, ea.z); }
+                        const Vec3f edir = on_env ? env_dir_at(__float_as_int(br[3 * kBlock]), br[0], br[kBlock], gk.x) : w;
+                        if (on_env) Le = env_radiance(edir); else { const float4 ea = S.ld(T.emit_off + 2 * eh); Le = Vec3f(ea.x, ea.y, ea.z); }
                         const Vec3f al = W * thr_k * FN * Le;
                         const float gb = cN * (al.x + al.y + al.z);
                         A_k = A_k + W * FN * Le * gN;
-                        if (on_env) xb = xb + dir_to_x(gk.x, y, env_adjoint(w, W * thr_k * FN * gN));
+                        if (on_env) xb = xb + dir_to_x(gk.x, y, env_adjoint(edir, W * thr_k * FN * gN));
                         else if (!P.skip_emitter) add_rgb(acc_emit, eh, W * thr_k * FN * gN);
                         const Vec3f wob = bsdf_back(w, W * thr_k * Le * gN);
                         const Vec3f wx = dir_to_x(gk.x, y, wob);
@@ -452,19 +519,19 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                     xb_next = xb; nsb_next = nsb;
                     Abar = A_k;
                     pb_b = pb_a; pb_a = pb;
-                    if (k == 0) { xb0 = xb + pb_b; nsb0 = nsb; }
+                    if (k == 0) { xb0 = xb + pb_b; nsb0 = nsb; ub_tex = uvb[0] * du0x + uvb[1] * du0y; vb_tex = uvb[0] * du1x + uvb[1] * du1y; }
                 }
                 // the camera hit: x_0 = o + t d and ns_0 = normalize(blend(u, v)) with (u, v, t) = Moeller-Trumbore(p0, e1, e2; o, d)
                 if (nb > 0 || le0) {
                     const VtxGeom g0 = load_vertex(S, slot0, u0, v0);
-                    float ub = 0.f, vb = 0.f;
+                    float ub = ub_tex, vb = vb_tex;
                     const float tb = dot(ray.d, xb0);
                     Vec3f ob = xb0, db = xb0 * t0 + dcam_b;
                     const bool want0 = wanted(g0);
                     if (g0.flat) { if (want0) add_vec(g0, 18, nsb0); }
                     else {
                         const Vec3f nbb = blend_adjoint(g0, nsb0);
-                        ub = dot(g0.n1 - g0.n0, nbb); vb = dot(g0.n2 - g0.n0, nbb);
+                        ub += dot(g0.n1 - g0.n0, nbb); vb += dot(g0.n2 - g0.n0, nbb);
                         if (want0) { add_vec(g0, 9, nbb * (1.f - u0 - v0)); add_vec(g0, 12, nbb * u0); add_vec(g0, 15, nbb * v0); }
                     }
                     Vec3f p0b, e1b, e2b, ob2, db2;

@@ -5,6 +5,8 @@ scene parameter, J v = d(image) from psdr_hip_render_d_fwd and J^T w the buffers
 The forward side is itself pinned against the CPU oracle (test_gpu_parity.py)."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -103,6 +105,13 @@ def _dot_product_case(env, spec, depth, terms, seeds=(7, 8, 9), with_camera=Fals
     g_mat = torch.zeros((max(1, len(spec.bsdfs)), 16), dtype=torch.float32, device=dev)
     if with_mat:
         g.g_mat = g_mat.data_ptr()
+    # bitmap parameters: the texel adjoints, laid out as psdr_hip_scene_tex_layout reports
+    n_b = int(np.asarray(snap["bsdf_type"]).shape[0]) if "bsdf_type" in snap else len(spec.bsdfs)
+    offs = (C.c_int64 * (3 * max(1, n_b)))(); total = C.c_int64(0)
+    cabi.check(cabi.lib().psdr_hip_scene_tex_layout(C.c_void_p(sc._hip_handle()), offs, C.byref(total)))
+    g_tex = torch.zeros(max(1, total.value), dtype=torch.float32, device=dev)
+    if total.value > 0:
+        g.g_tex = g_tex.data_ptr()
     cabi.check(cabi.lib().psdr_hip_render_d_bwd(sc._hip_handle(), C.byref(a), w.data_ptr(), C.byref(g), None))
     torch.cuda.synchronize()
     rhs = (g_tri.cpu().numpy().astype(np.float64) * d_tri).sum() + (g_bsdf.cpu().numpy().astype(np.float64)[:len(spec.bsdfs)] * d_bsdf).sum()
@@ -111,6 +120,14 @@ def _dot_product_case(env, spec, depth, terms, seeds=(7, 8, 9), with_camera=Fals
     if with_camera:
         d_tw = np.asarray(cam._get("to_world_left", True), np.float64).reshape(4, 4) if hasattr(cam, "_get") else np.zeros((4, 4))
         rhs += (g_cam.cpu().numpy().astype(np.float64).reshape(4, 4)[:3] * d_tw[:3]).sum()
+    if total.value > 0:    # d texel / dP of the spec's bitmaps (reflectance / diffuse, specular, roughness)
+        gt = g_tex.cpu().numpy().astype(np.float64)
+        for i, b in enumerate(spec.bsdfs):
+            for k, (name, dname) in enumerate((("texture", "d_texture"), ("spec_texture", "d_spec_texture"), ("rough_texture", "d_rough_texture"))):
+                t, dt = getattr(b, name, None), getattr(b, dname, None)
+                if t is not None and dt is not None and offs[3 * i + k] >= 0:
+                    dt = np.asarray(dt, np.float64).ravel()
+                    rhs += (gt[offs[3 * i + k]:offs[3 * i + k] + dt.size] * dt).sum()
     if with_mat:          # g_mat row of a Microfacet BSDF: specular rgb, roughness
         gm = g_mat.cpu().numpy().astype(np.float64)
         for i, b in enumerate(spec.bsdfs):
@@ -172,3 +189,25 @@ def test_interior_sweep_microfacet(env, param, two_sided):
     spec = scenes.microfacet_cbox_scene(40, 40, 8, 0, 0, param=param, two_sided=two_sided)
     lhs, rhs, scale = _dot_product_case(env, spec, depth=3, terms=1, with_mat=True)
     assert abs(lhs - rhs) <= 5e-4 * scale and abs(lhs) > 1e-6, (param, two_sided, lhs, rhs, scale)
+
+
+@pytest.mark.parametrize("scene,param", [("diffuse", "box_x"), ("diffuse", "texture"), ("microfacet", "box_x"), ("microfacet", "diffuse"),
+                                         ("microfacet", "specular"), ("microfacet", "roughness")])
+def test_interior_sweep_bitmap_parameters(env, scene, param):
+    """bitmap parameters in the material sweep: the adjoint of a looked-up value is scattered over the four texels of its footprint,
+    and at the camera vertex - whose barycentrics are differentiable - chained to the texture coordinates"""
+    spec = scenes.textured_scene(40, 40, 8, 0, 0, param=param) if scene == "diffuse" else scenes.textured_microfacet_scene(40, 40, 8, 0, 0, param=param)
+    lhs, rhs, scale = _dot_product_case(env, spec, depth=3, terms=1, with_mat=True)
+    assert abs(lhs - rhs) <= 5e-4 * scale and abs(lhs) > 1e-6, (scene, param, lhs, rhs, scale)
+
+
+def test_sweeps_under_a_high_resolution_hdr_map(env):
+    """ballroom_1k.exr (1024 x 512, values up to 140): the lookup is piecewise bilinear, so the reverse pass must land in the texel cell the
+    forward pass used - it rebuilds the lookup direction through the cube face's frame exactly as Intersection / EnvironmentMap::eval do.
+    Diffuse boxes (class 2 sweep) and the notebook's glossy bunny (material sweep)"""
+    from psdr_jit_amd import exr
+    hdr = np.ascontiguousarray(exr.read_rgb(os.path.join(scenes.DATA, "..", "envmap", "ballroom_1k.exr")))
+    lhs, rhs, scale = _dot_product_case(env, scenes.envmap_scene(96, 96, 16, 0, 0, param="box_x", env=hdr), depth=3, terms=1, seeds=(3, 3, 3))
+    assert abs(lhs - rhs) <= 1e-5 * scale and abs(lhs) > 1e-6, (lhs, rhs, scale)
+    lhs, rhs, scale = _dot_product_case(env, scenes.envmap_tutorial_scene(96, 96, 16, 0, 0, param="bunny_x", env_stride=1), depth=2, terms=1, seeds=(3, 3, 3), with_mat=True)
+    assert abs(lhs - rhs) <= 1e-5 * scale and abs(lhs) > 1e-6, (lhs, rhs, scale)
