@@ -31,7 +31,21 @@ PSDR_DEV float geo_eval(const Vec3f &x, const Vec3f &z, const Vec3f &nz, float a
     return G;
 }
 
-// F(wi, wo) of BSDF `bid` in local coordinates (Diffuse or Microfacet; constant or bitmap parameters looked up at (tu, tv)) and, when
+// the tangent vectors of a vertex's shading frame as make_its builds them (scene.cpp:724-766): from the uv parameterisation
+// (dp_du = (e1 dv1 - e2 dv0) / det, Gram-Schmidt against ns) when it is non-degenerate, else Duff et al.'s frame of ns
+template <typename R>
+PSDR_DEV void vertex_frame(const Vec3<R> &ns, const Vec3<R> &e1, const Vec3<R> &e2, float du0x, float du0y, float du1x, float du1y, Vec3<R> &fs, Vec3<R> &ft) {
+    coordinate_system(ns, fs, ft);
+    const float det = fma_(du0x, du1y, -(du0y * du1x));
+    if (det != 0.f) {
+        const float inv_det = 1.f / det;
+        const Vec3<R> dp_du = (e1 * R(du1y) - e2 * R(du0y)) * R(inv_det);
+        fs = normalize(dp_du - ns * dot(ns, dp_du));
+        ft = cross(ns, fs);
+    }
+}
+
+// F(wi, wo) of BSDF `bid` in local coordinates (Diffuse, Microfacet or RoughConductor; constant or bitmap parameters looked up at (tu, tv)) and, when
 // `Fb` is given, the adjoints of the six direction components.  The parameter adjoints are added to acc_bsdf (constant colour /
 // diffuse reflectance) and acc_mat (g_mat row: constant specular rgb, roughness) or, for a bitmap parameter, scattered over the four
 // texels of the lookup (g_tex, TexDev::g_off) and - uvb given - chained to the texture coordinates (the camera vertex: its
@@ -107,6 +121,33 @@ PSDR_DEV Vec3f bsdf_value_and_adjoint(const SceneView<LDS> &S, int bid, const Ve
                 } else {
                     if (fl & 2) tex_back(0, std::integral_constant<int, 3>(), pb);
                     else if (acc_bsdf) { add(&acc_bsdf[3 * bid], pb[0]); add(&acc_bsdf[3 * bid + 1], pb[1]); add(&acc_bsdf[3 * bid + 2], pb[2]); }
+                }
+            }
+            for (int j = 0; j < 3; ++j) { if (!finite_(wib[j])) wib[j] = 0.f; if (!finite_(wob[j])) wob[j] = 0.f; }
+            return F;
+        }
+    }
+    if constexpr (has_mat(LDS)) {
+        if (fl & 8) {          // RoughConductor with constant parameters (roughconductor.cpp:30-68): g_mat row = [alpha_u, alpha_v, eta rgb, k rgb, specular rgb]
+            const MatDev md = S.T->mat[bid];
+            const Vec3f eta(md.eta[0], md.eta[1], md.eta[2]), kk(md.k[0], md.k[1], md.k[2]), spec(md.specular[0], md.specular[1], md.specular[2]);
+            const Vec3f F = conductor_eval<float>(md.alpha_u, md.alpha_v, eta, kk, spec, two, wi, wo, true);
+            if (Fb == nullptr) return F;
+            if (!(finite_(Fb->x) && finite_(Fb->y) && finite_(Fb->z)) || (Fb->x == 0.f && Fb->y == 0.f && Fb->z == 0.f)) return F;
+            for (int j = 0; j < 11; ++j) {
+                const float one = 1.f;
+                const Vec3d wiD(Dual(wi.x, j == 0 ? one : 0.f), Dual(wi.y, j == 1 ? one : 0.f), Dual(wi.z, j == 2 ? one : 0.f));
+                const Vec3d woD(Dual(wo.x, j == 3 ? one : 0.f), Dual(wo.y, j == 4 ? one : 0.f), Dual(wo.z, j == 5 ? one : 0.f));
+                const float te = j == 8 ? one : 0.f, tk = j == 9 ? one : 0.f, ts = j == 10 ? one : 0.f;
+                const Vec3d etaD(Dual(eta.x, te), Dual(eta.y, te), Dual(eta.z, te)), kD(Dual(kk.x, tk), Dual(kk.y, tk), Dual(kk.z, tk));
+                const Vec3d specD(Dual(spec.x, ts), Dual(spec.y, ts), Dual(spec.z, ts));
+                const Vec3d r = conductor_eval<Dual>(Dual(md.alpha_u, j == 6 ? one : 0.f), Dual(md.alpha_v, j == 7 ? one : 0.f), etaD, kD, specD, two, wiD, woD, true);
+                const float pb[3] = {Fb->x * r.x.d, Fb->y * r.y.d, Fb->z * r.z.d};
+                if (j < 3) wib[j] = pb[0] + pb[1] + pb[2];
+                else if (j < 6) wob[j - 3] = pb[0] + pb[1] + pb[2];
+                else if (acc_mat) {
+                    if (j < 8) add(&acc_mat[bid * kMatRow + (j - 6)], pb[0] + pb[1] + pb[2]);
+                    else { const int o = j == 8 ? 2 : (j == 9 ? 5 : 8); add(&acc_mat[bid * kMatRow + o], pb[0]); add(&acc_mat[bid * kMatRow + o + 1], pb[1]); add(&acc_mat[bid * kMatRow + o + 2], pb[2]); }
                 }
             }
             for (int j = 0; j < 3; ++j) { if (!finite_(wib[j])) wib[j] = 0.f; if (!finite_(wob[j])) wob[j] = 0.f; }
@@ -421,9 +462,17 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                         rin = norm(vin);
                         wi_w = vin / rin;
                     }
+                    // the vertex's shading frame as the forward pass builds it (an anisotropic lobe sees the tangents)
                     Vec3f fs, ft;
-                    coordinate_system(gk.ns, fs, ft);            // any frame around ns serves an isotropic BSDF
+                    float fu0x, fu0y, fu1x, fu1y;
+                    {
+                        const int wsh = T.shade_off + 6 * __float_as_int(vr[0]);
+                        const float4 s4 = S.ld(wsh + 4), s5 = S.ld(wsh + 5);
+                        fu0x = s4.z - s4.x; fu0y = s4.w - s4.y; fu1x = s5.x - s4.x; fu1y = s5.y - s4.y;
+                    }
+                    vertex_frame<float>(gk.ns, gk.e1, gk.e2, fu0x, fu0y, fu1x, fu1y, fs, ft);
                     const Vec3f wi_l(dot(wi_w, fs), dot(wi_w, ft), dot(wi_w, gk.ns));
+                    Vec3f fsb(0.f), ftb(0.f);                    // adjoints of the two tangent vectors
                     Vec3f xb(0.f), nsb(0.f), A_k(0.f), wib_w(0.f);
                     // F and, for its adjoint Fb, the adjoints of the outgoing direction (returned), of the incident direction and of ns
                     // (accumulated), and of the BSDF's parameters (accumulated in LDS)
@@ -445,10 +494,10 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                         float wib_l[3], wob_l[3];
                         bsdf_value_and_adjoint<LDS>(S, bid, wi_l, wo_l, tu, tv, &Fb, wib_l, wob_l, P.skip_bsdf ? nullptr : acc_bsdf, acc_mat, P.g_tex, (k == 0 && T.tex != nullptr) ? uvb : nullptr);
                         wib_w = wib_w + fs * wib_l[0] + ft * wib_l[1] + gk.ns * wib_l[2];
-                        // turning ns (the tangents follow) changes the local components of both directions
-                        const float ex = -wi_l.z * wib_l[0] + wi_l.x * wib_l[2] - wo_l.z * wob_l[0] + wo_l.x * wob_l[2];
-                        const float ey = -wi_l.z * wib_l[1] + wi_l.y * wib_l[2] - wo_l.z * wob_l[1] + wo_l.y * wob_l[2];
-                        nsb = nsb + fs * ex + ft * ey;
+                        // local components = dot products with the frame vectors: their adjoints (the tangents' go through vertex_frame below)
+                        fsb = fsb + wi_w * wib_l[0] + w * wob_l[0];
+                        ftb = ftb + wi_w * wib_l[1] + w * wob_l[1];
+                        nsb = nsb + wi_w * wib_l[2] + w * wob_l[2];
                         return fs * wob_l[0] + ft * wob_l[1] + gk.ns * wob_l[2];
                     };
                     GeoGrad gg;
@@ -511,6 +560,25 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                             emit_glued(gy, gg.dz * gb - wx, Vec3f(0.f), Vec3f(0.f), gg.dA * gb);     // the light sample: position and area of ITS triangle
                             emit_glued(gh, Vec3f(0.f), Vec3f(0.f), gg.dnz * gb, 0.f);                // the normal of the triangle the shadow ray hit
                         }
+                    }
+                    // the tangents are functions of ns and, with a uv parameterisation, of the triangle's edges: J^T (fsb, ftb) by forward
+                    // evaluations of vertex_frame with unit tangents
+                    Vec3f e1b_f(0.f), e2b_f(0.f);
+                    if (fsb.x != 0.f || fsb.y != 0.f || fsb.z != 0.f || ftb.x != 0.f || ftb.y != 0.f || ftb.z != 0.f) {
+                        const bool uvf = fma_(fu0x, fu1y, -(fu0y * fu1x)) != 0.f;
+                        float gj[9];
+                        for (int j = 0; j < (uvf ? 9 : 3); ++j) {
+                            const Vec3d nsD(Dual(gk.ns.x, j == 0 ? 1.f : 0.f), Dual(gk.ns.y, j == 1 ? 1.f : 0.f), Dual(gk.ns.z, j == 2 ? 1.f : 0.f));
+                            const Vec3d e1D(Dual(gk.e1.x, j == 3 ? 1.f : 0.f), Dual(gk.e1.y, j == 4 ? 1.f : 0.f), Dual(gk.e1.z, j == 5 ? 1.f : 0.f));
+                            const Vec3d e2D(Dual(gk.e2.x, j == 6 ? 1.f : 0.f), Dual(gk.e2.y, j == 7 ? 1.f : 0.f), Dual(gk.e2.z, j == 8 ? 1.f : 0.f));
+                            Vec3d fsD, ftD;
+                            vertex_frame<Dual>(nsD, e1D, e2D, fu0x, fu0y, fu1x, fu1y, fsD, ftD);
+                            const float g = fsb.x * fsD.x.d + fsb.y * fsD.y.d + fsb.z * fsD.z.d + ftb.x * ftD.x.d + ftb.y * ftD.y.d + ftb.z * ftD.z.d;
+                            gj[j] = finite_(g) ? g : 0.f;
+                        }
+                        nsb = nsb + Vec3f(gj[0], gj[1], gj[2]);
+                        if (uvf) { e1b_f = Vec3f(gj[3], gj[4], gj[5]); e2b_f = Vec3f(gj[6], gj[7], gj[8]); }
+                        if (wanted(gk) && uvf) { add_vec(gk, 3, e1b_f); add_vec(gk, 6, e2b_f); }
                     }
                     // the incident direction's adjoint: to the camera ray at the first vertex, else to x_{k-1} and x_k
                     Vec3f pb(0.f);
