@@ -43,11 +43,37 @@ def _run(cmd):
     return r.stdout
 
 
+N_KERNEL_UNITS = 5      # api.hip's PSDR_TU1..5: the heavy kernel templates of each scene class
+
+
 def build_hip(force=False, extra_flags=()):
+    """api.hip is compiled as six translation units in parallel - the host code with the small kernels (-DPSDR_SPLIT) and five units
+    that only instantiate the heavy kernel templates of one scene class (-DPSDR_TU=k) - and linked into one library: ~4 minutes of
+    wall time instead of ~10 for the single unit (PSDR_BUILD_JOBS=1 compiles them one after the other)."""
     os.makedirs(LIBDIR, exist_ok=True)
     if force or _stale(HIP_LIB, HIP_SRCS + HIP_DEPS):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        _run([hipcc] + HIP_FLAGS + list(extra_flags) + HIP_SRCS + ["-o", HIP_LIB])
+        objdir = os.path.join(LIBDIR, "obj")
+        os.makedirs(objdir, exist_ok=True)
+        flags = [f for f in HIP_FLAGS if f != "-shared"] + list(extra_flags)
+        units = [("main", ["-DPSDR_SPLIT"])] + [("tu%d" % k, ["-DPSDR_TU=%d" % k]) for k in range(1, N_KERNEL_UNITS + 1)]
+        jobs = max(1, int(os.environ.get("PSDR_BUILD_JOBS", str(min(len(units), os.cpu_count() or 1)))))
+        objs, pending, running = [], list(units), []
+        while pending or running:
+            while pending and len(running) < jobs:
+                name, defs = pending.pop(0)
+                obj = os.path.join(objdir, "api_%s.o" % name)
+                objs.append(obj)
+                cmd = [hipcc] + flags + defs + ["-c"] + HIP_SRCS + ["-o", obj]
+                running.append((subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True), cmd))
+            proc, cmd = running.pop(0)
+            out, _ = proc.communicate()
+            if proc.returncode != 0:
+                for q, _c in running:
+                    q.kill()
+                sys.stderr.write(out)
+                raise RuntimeError("build failed: " + " ".join(cmd))
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", HIP_LIB])
     return HIP_LIB
 
 

@@ -398,6 +398,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(const float4 *__restrict__
 }
 
 // EnvironmentMap::sample_position / sample_position_pdf alone (parity aids)
+#ifndef PSDR_TU        // (plain kernels: the main unit only)
 __global__ void k_env_sample(const SceneTables T, int n, const float *__restrict__ ref_p, const float *__restrict__ s2,
                              float *__restrict__ out_p, float *__restrict__ out_n, float *__restrict__ out_pdf) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -422,6 +423,39 @@ __global__ void k_sampler_floats(unsigned long long seed_value, unsigned long lo
         for (int i = 0; i < n; ++i) out[i] = r.next_1d();
     }
 }
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// Split build (psdr_jit_amd/build.py): the heavy kernel templates of each scene class are instantiated in translation units of
+// their own - this file compiled with -DPSDR_TU=1..5, kernels only - and compiled in parallel; the main unit (-DPSDR_SPLIT: host
+// code + the small kernels) declares those instantiations extern.  Without either macro the file is one self-contained unit
+// (development builds, -DPSDR_CLS_MASK).
+#define PSDR_INST_PATHS(PFX, AD_, C_, CNT_, M_) PFX template __global__ void k_paths<AD_, C_, CNT_, M_>(const float4 *, const SceneTables, const SensorDev, const PathParams, Counters *);
+#define PSDR_INST_ADJ(PFX, C_) PFX template __global__ void k_interior_adjoint<C_>(const float4 *, const SceneTables, const SensorDev, const AdjointParams);
+#define PSDR_INST_SEC(PFX, C_, CNT_, ADJ_) PFX template __global__ void k_secondary_edges<C_, CNT_, ADJ_>(const float4 *, const SceneTables, const SecEdgeTables, const SensorDev, const PathParams, const GuidingDev, const int, Counters *);
+#define PSDR_INST_PATHS6(PFX, C_) PSDR_INST_PATHS(PFX, true, C_, false, 0) PSDR_INST_PATHS(PFX, false, C_, false, 0) PSDR_INST_PATHS(PFX, false, C_, false, 1) \
+                                  PSDR_INST_PATHS(PFX, true, C_, true, 0) PSDR_INST_PATHS(PFX, false, C_, true, 0) PSDR_INST_PATHS(PFX, false, C_, true, 1)
+#define PSDR_TU1(PFX) PSDR_INST_PATHS6(PFX, 0)
+#define PSDR_TU2(PFX) PSDR_INST_ADJ(PFX, 0) PSDR_INST_SEC(PFX, 0, false, false) PSDR_INST_SEC(PFX, 0, true, false) PSDR_INST_SEC(PFX, 0, false, true)
+#define PSDR_TU3(PFX) PSDR_INST_PATHS6(PFX, 1) PSDR_INST_ADJ(PFX, 1) PSDR_INST_SEC(PFX, 1, false, false) PSDR_INST_SEC(PFX, 1, true, false) PSDR_INST_SEC(PFX, 1, false, true)
+#define PSDR_TU4(PFX) PSDR_INST_PATHS6(PFX, 2) PSDR_INST_ADJ(PFX, 2) PSDR_INST_SEC(PFX, 2, false, false) PSDR_INST_SEC(PFX, 2, true, false)
+#define PSDR_TU5(PFX) PSDR_INST_PATHS(PFX, true, 3, false, 0) PSDR_INST_PATHS(PFX, false, 3, false, 0) PSDR_INST_PATHS(PFX, false, 3, false, 1) PSDR_INST_SEC(PFX, 3, false, false)
+#if defined(PSDR_TU)
+#if PSDR_TU == 1
+PSDR_TU1()
+#elif PSDR_TU == 2
+PSDR_TU2()
+#elif PSDR_TU == 3
+PSDR_TU3()
+#elif PSDR_TU == 4
+PSDR_TU4()
+#elif PSDR_TU == 5
+PSDR_TU5()
+#endif
+#else
+#if defined(PSDR_SPLIT)
+PSDR_TU1(extern) PSDR_TU2(extern) PSDR_TU3(extern) PSDR_TU4(extern) PSDR_TU5(extern)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -1323,3 +1357,5 @@ int psdr_hip_sampler_floats(uint64_t seed_value, uint64_t lane, uint64_t skip, i
 }
 
 } // extern "C"
+
+#endif   // !PSDR_TU
