@@ -154,6 +154,27 @@ PSDR_DEV Vec3f bsdf_value_and_adjoint(const SceneView<LDS> &S, int bid, const Ve
             return F;
         }
     }
+    if constexpr (has_mat(LDS)) {
+        if (fl & 16) {         // RoughDielectric with constant parameters (roughdielectric.cpp): g_mat row = [alpha_u, alpha_v, eta]; 1 / eta moves with eta
+            const MatDev md = S.T->mat[bid];
+            const Vec3f F = dielectric_eval<float>(md.alpha_u, md.alpha_v, md.eta[0], md.eta[1], two, wi, wo, true);
+            if (Fb == nullptr) return F;
+            if (!(finite_(Fb->x) && finite_(Fb->y) && finite_(Fb->z)) || (Fb->x == 0.f && Fb->y == 0.f && Fb->z == 0.f)) return F;
+            for (int j = 0; j < 9; ++j) {
+                const float one = 1.f;
+                const Vec3d wiD(Dual(wi.x, j == 0 ? one : 0.f), Dual(wi.y, j == 1 ? one : 0.f), Dual(wi.z, j == 2 ? one : 0.f));
+                const Vec3d woD(Dual(wo.x, j == 3 ? one : 0.f), Dual(wo.y, j == 4 ? one : 0.f), Dual(wo.z, j == 5 ? one : 0.f));
+                const Vec3d r = dielectric_eval<Dual>(Dual(md.alpha_u, j == 6 ? one : 0.f), Dual(md.alpha_v, j == 7 ? one : 0.f), Dual(md.eta[0], j == 8 ? one : 0.f),
+                                                      Dual(md.eta[1], j == 8 ? -1.f / (md.eta[0] * md.eta[0]) : 0.f), two, wiD, woD, true);
+                const float pb = Fb->x * r.x.d + Fb->y * r.y.d + Fb->z * r.z.d;
+                if (j < 3) wib[j] = pb;
+                else if (j < 6) wob[j - 3] = pb;
+                else if (acc_mat) add(&acc_mat[bid * kMatRow + (j - 6)], pb);
+            }
+            for (int j = 0; j < 3; ++j) { if (!finite_(wib[j])) wib[j] = 0.f; if (!finite_(wob[j])) wob[j] = 0.f; }
+            return F;
+        }
+    }
     // Diffuse (diffuse.cpp:30-41): rho / pi . wo.z on the lit side
     float wiz = wi.z, woz = wo.z, sg = 1.f;
     if (two) { sg = wiz < 0.f ? -1.f : 1.f; woz = woz * sg; wiz = fabsf(wiz); }
@@ -382,9 +403,11 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                                 Vec3f Le(0.f);
                                 if (eh == env_id) Le = env_radiance(env_dir_at(h1.slot, h1.u, h1.v, its.p));
                                 else if (its1.wi.z > 0.f) { const float4 ea = S.ld(T.emit_off + 2 * eh); Le = Vec3f(ea.x, ea.y, ea.z); }
+                                // (path.cpp:76-82 adds the product whenever pdf1 != 0: a non-finite factor beside a zero one poisons the
+                                // sample there, and integrator.cpp:126 then drops it - the same must happen here)
+                                const float cN = mis_weight(ps.pdf, pdf1) / ps.pdf;
+                                if (pdf1 != 0.f) Lsum = Lsum + thr * F * Le * (G * cN);
                                 if (pdf1 != 0.f && nonzero(Le) && nonzero(F)) {
-                                    const float cN = mis_weight(ps.pdf, pdf1) / ps.pdf;
-                                    Lsum = Lsum + thr * F * Le * (G * cN);
                                     if (eh == env_id) { br[0] = h1.u; br[kBlock] = h1.v; br[2 * kBlock] = 0.f; flags |= 16; }
                                     else { br[0] = __int_as_float(ps.slot); br[kBlock] = ps.ba; br[2 * kBlock] = ps.bb; }
                                     br[3 * kBlock] = __int_as_float(h1.slot);
@@ -417,7 +440,8 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                         Vec3f Le(0.f);
                         if (ex >= 0 && ex == env_id) Le = env_radiance(env_dir_at(hx.slot, hx.u, hx.v, its.p));
                         else if (ex >= 0 && itx.wi.z > 0.f) { const float4 ea = S.ld(T.emit_off + 2 * ex); Le = Vec3f(ea.x, ea.y, ea.z); }
-                        if (nonzero(Le)) { Lsum = Lsum + Le * thr * w2; flags |= 8; }
+                        Lsum = Lsum + Le * thr * w2;         // (always, as path.cpp:118 does: a zero-pdf sample makes thr and w2 non-finite and the sample is dropped)
+                        if (nonzero(Le)) flags |= 8;
                         br[5 * kBlock] = cf; br[6 * kBlock] = w2;
                         flags |= 2;
                         its = itx;

@@ -133,6 +133,8 @@ def _dot_product_case(env, spec, depth, terms, seeds=(7, 8, 9), with_camera=Fals
         for i, b in enumerate(spec.bsdfs):
             if getattr(b, "type", 0) == 1:
                 rhs += (gm[i, 0:3] * np.asarray(getattr(b, "d_specular", (0, 0, 0)), np.float64)).sum() + gm[i, 3] * float(getattr(b, "d_roughness", 0.0))
+            if getattr(b, "type", 0) == 3:      # RoughDielectric: alpha_u, alpha_v, eta (1 / eta moves with it)
+                rhs += gm[i, 0] * float(getattr(b, "d_alpha_u", 0.0)) + gm[i, 1] * float(getattr(b, "d_alpha_v", 0.0)) + gm[i, 2] * float(np.asarray(getattr(b, "d_eta", (0, 0, 0)))[0])
             if getattr(b, "type", 0) == 2:      # RoughConductor: alpha_u, alpha_v, eta rgb, k rgb, specular rgb
                 rhs += gm[i, 0] * float(getattr(b, "d_alpha_u", 0.0)) + gm[i, 1] * float(getattr(b, "d_alpha_v", 0.0))
                 rhs += (gm[i, 2:5] * np.asarray(getattr(b, "d_eta", (0, 0, 0)), np.float64)).sum() + (gm[i, 5:8] * np.asarray(getattr(b, "d_k", (0, 0, 0)), np.float64)).sum()
@@ -222,4 +224,12 @@ def test_interior_sweep_roughconductor(env, param):
     """anisotropic GGX conductors in the material sweep: the lobe sees the tangent vectors of the shading frame, whose adjoints go
     back through the frame construction (uv parameterisation or Duff et al.) to the shading normal and the triangle's edges"""
     lhs, rhs, scale = _dot_product_case(env, scenes.conductor_cbox_scene(40, 40, 8, 0, 0, param=param), depth=3, terms=1, with_mat=True)
+    assert abs(lhs - rhs) <= 5e-4 * scale and abs(lhs) > 1e-6, (param, lhs, rhs, scale)
+
+
+@pytest.mark.parametrize("param", ["box_x", "alpha", "eta"])
+def test_interior_sweep_roughdielectric(env, param):
+    """rough glass in the material sweep: paths refract into and out of the closed small box; the lobe's adjoint covers reflection and
+    transmission, eta carries 1 / eta with it"""
+    lhs, rhs, scale = _dot_product_case(env, scenes.dielectric_cbox_scene(40, 40, 8, 0, 0, param=param), depth=4, terms=1, with_mat=True)
     assert abs(lhs - rhs) <= 5e-4 * scale and abs(lhs) > 1e-6, (param, lhs, rhs, scale)
