@@ -100,6 +100,7 @@ PSDR_DEV Vec3f bsdf_value_and_adjoint(const SceneView<LDS> &S, int bid, const Ve
             const Vec3f F = microfacet_eval<float>(spec, diff, rough, two, wi, wo, true);
             if (Fb == nullptr) return F;
             if (!(finite_(Fb->x) && finite_(Fb->y) && finite_(Fb->z)) || (Fb->x == 0.f && Fb->y == 0.f && Fb->z == 0.f)) return F;
+#pragma unroll
             for (int j = 0; j < 9; ++j) {
                 const float one = 1.f;
                 const Vec3d wiD(Dual(wi.x, j == 0 ? one : 0.f), Dual(wi.y, j == 1 ? one : 0.f), Dual(wi.z, j == 2 ? one : 0.f));
@@ -134,6 +135,7 @@ PSDR_DEV Vec3f bsdf_value_and_adjoint(const SceneView<LDS> &S, int bid, const Ve
             const Vec3f F = conductor_eval<float>(md.alpha_u, md.alpha_v, eta, kk, spec, two, wi, wo, true);
             if (Fb == nullptr) return F;
             if (!(finite_(Fb->x) && finite_(Fb->y) && finite_(Fb->z)) || (Fb->x == 0.f && Fb->y == 0.f && Fb->z == 0.f)) return F;
+#pragma unroll
             for (int j = 0; j < 11; ++j) {
                 const float one = 1.f;
                 const Vec3d wiD(Dual(wi.x, j == 0 ? one : 0.f), Dual(wi.y, j == 1 ? one : 0.f), Dual(wi.z, j == 2 ? one : 0.f));
@@ -160,6 +162,7 @@ PSDR_DEV Vec3f bsdf_value_and_adjoint(const SceneView<LDS> &S, int bid, const Ve
             const Vec3f F = dielectric_eval<float>(md.alpha_u, md.alpha_v, md.eta[0], md.eta[1], two, wi, wo, true);
             if (Fb == nullptr) return F;
             if (!(finite_(Fb->x) && finite_(Fb->y) && finite_(Fb->z)) || (Fb->x == 0.f && Fb->y == 0.f && Fb->z == 0.f)) return F;
+#pragma unroll
             for (int j = 0; j < 9; ++j) {
                 const float one = 1.f;
                 const Vec3d wiD(Dual(wi.x, j == 0 ? one : 0.f), Dual(wi.y, j == 1 ? one : 0.f), Dual(wi.z, j == 2 ? one : 0.f));
@@ -496,7 +499,12 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                     }
                     vertex_frame<float>(gk.ns, gk.e1, gk.e2, fu0x, fu0y, fu1x, fu1y, fs, ft);
                     const Vec3f wi_l(dot(wi_w, fs), dot(wi_w, ft), dot(wi_w, gk.ns));
-                    Vec3f fsb(0.f), ftb(0.f);                    // adjoints of the two tangent vectors
+                    Vec3f fsb(0.f), ftb(0.f);                    // adjoints of the two tangent vectors (anisotropic lobes only)
+                    bool aniso = false;
+                    if (bid >= 0) {
+                        const int bfl = __float_as_int(S.ld(T.bsdf_off + 2 * bid).w);
+                        if (bfl & (8 | 16)) { const MatDev md = T.mat[bid]; aniso = md.alpha_u != md.alpha_v; }
+                    }
                     Vec3f xb(0.f), nsb(0.f), A_k(0.f), wib_w(0.f);
                     // F and, for its adjoint Fb, the adjoints of the outgoing direction (returned), of the incident direction and of ns
                     // (accumulated), and of the BSDF's parameters (accumulated in LDS)
@@ -518,10 +526,18 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                         float wib_l[3], wob_l[3];
                         bsdf_value_and_adjoint<LDS>(S, bid, wi_l, wo_l, tu, tv, &Fb, wib_l, wob_l, P.skip_bsdf ? nullptr : acc_bsdf, acc_mat, P.g_tex, (k == 0 && T.tex != nullptr) ? uvb : nullptr);
                         wib_w = wib_w + fs * wib_l[0] + ft * wib_l[1] + gk.ns * wib_l[2];
-                        // local components = dot products with the frame vectors: their adjoints (the tangents' go through vertex_frame below)
-                        fsb = fsb + wi_w * wib_l[0] + w * wob_l[0];
-                        ftb = ftb + wi_w * wib_l[1] + w * wob_l[1];
-                        nsb = nsb + wi_w * wib_l[2] + w * wob_l[2];
+                        if (aniso) {
+                            // local components = dot products with the frame vectors: their adjoints (the tangents' go through vertex_frame below)
+                            fsb = fsb + wi_w * wib_l[0] + w * wob_l[0];
+                            ftb = ftb + wi_w * wib_l[1] + w * wob_l[1];
+                            nsb = nsb + wi_w * wib_l[2] + w * wob_l[2];
+                        } else {
+                            // an isotropic lobe does not see the tangents: turning ns (the tangents follow) changes the local components of both
+                            // directions by d u_l = (-e_x u_z, -e_y u_z, e_x u_x + e_y u_y)
+                            const float ex = -wi_l.z * wib_l[0] + wi_l.x * wib_l[2] - wo_l.z * wob_l[0] + wo_l.x * wob_l[2];
+                            const float ey = -wi_l.z * wib_l[1] + wi_l.y * wib_l[2] - wo_l.z * wob_l[1] + wo_l.y * wob_l[2];
+                            nsb = nsb + fs * ex + ft * ey;
+                        }
                         return fs * wob_l[0] + ft * wob_l[1] + gk.ns * wob_l[2];
                     };
                     GeoGrad gg;
@@ -591,7 +607,10 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                     if (fsb.x != 0.f || fsb.y != 0.f || fsb.z != 0.f || ftb.x != 0.f || ftb.y != 0.f || ftb.z != 0.f) {
                         const bool uvf = fma_(fu0x, fu1y, -(fu0y * fu1x)) != 0.f;
                         float gj[9];
-                        for (int j = 0; j < (uvf ? 9 : 3); ++j) {
+                        for (int j = 0; j < 9; ++j) gj[j] = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 9; ++j) {
+                            if (j >= 3 && !uvf) continue;
                             const Vec3d nsD(Dual(gk.ns.x, j == 0 ? 1.f : 0.f), Dual(gk.ns.y, j == 1 ? 1.f : 0.f), Dual(gk.ns.z, j == 2 ? 1.f : 0.f));
                             const Vec3d e1D(Dual(gk.e1.x, j == 3 ? 1.f : 0.f), Dual(gk.e1.y, j == 4 ? 1.f : 0.f), Dual(gk.e1.z, j == 5 ? 1.f : 0.f));
                             const Vec3d e2D(Dual(gk.e2.x, j == 6 ? 1.f : 0.f), Dual(gk.e2.y, j == 7 ? 1.f : 0.f), Dual(gk.e2.z, j == 8 ? 1.f : 0.f));

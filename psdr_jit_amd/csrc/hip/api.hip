@@ -127,8 +127,17 @@ __global__ __launch_bounds__(kBlock) void k_interior_adjoint(const float4 *__res
     SceneView<LDS> S = make_view<LDS>(blob, T, smem);
     S.mis = P.mis; S.field = P.field; S.field_object = P.field_object; S.intensity = P.intensity; S.d_intensity = P.d_intensity;
     if constexpr (!has_mat(LDS)) { if (P.sweep) { run_interior_adjoint_sweep<LDS>(S, cam, P, scratch_base<LDS>(smem, T)); return; } }
-    if constexpr (has_mat(LDS) && has_env(LDS)) { if (P.sweep == 2) { run_interior_adjoint_sweep_mat<LDS>(S, cam, P, scratch_base<LDS>(smem, T)); return; } }
     run_interior_adjoint<LDS>(S, cam, P, scratch_base<LDS>(smem, T));
+}
+
+// the material sweep (adjoint_mat.h) in a kernel of its own: its registers are not shared with the record-and-probe form
+template <int LDS>
+__global__ __launch_bounds__(kBlock) void k_interior_adjoint_mat(const float4 *__restrict__ blob, const SceneTables T, const SensorDev cam,
+                                                                 const AdjointParams P) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    SceneView<LDS> S = make_view<LDS>(blob, T, smem);
+    S.mis = P.mis; S.field = P.field; S.field_object = P.field_object; S.intensity = P.intensity; S.d_intensity = P.d_intensity;
+    run_interior_adjoint_sweep_mat<LDS>(S, cam, P, scratch_base<LDS>(smem, T));
 }
 
 struct GuidingDev {          // HyperCubeDistribution<3>, reference src/core/cube_distrb.cpp:10-64
@@ -432,11 +441,12 @@ __global__ void k_sampler_floats(unsigned long long seed_value, unsigned long lo
 // (development builds, -DPSDR_CLS_MASK).
 #define PSDR_INST_PATHS(PFX, AD_, C_, CNT_, M_) PFX template __global__ void k_paths<AD_, C_, CNT_, M_>(const float4 *, const SceneTables, const SensorDev, const PathParams, Counters *);
 #define PSDR_INST_ADJ(PFX, C_) PFX template __global__ void k_interior_adjoint<C_>(const float4 *, const SceneTables, const SensorDev, const AdjointParams);
+#define PSDR_INST_ADJM(PFX, C_) PFX template __global__ void k_interior_adjoint_mat<C_>(const float4 *, const SceneTables, const SensorDev, const AdjointParams);
 #define PSDR_INST_SEC(PFX, C_, CNT_, ADJ_) PFX template __global__ void k_secondary_edges<C_, CNT_, ADJ_>(const float4 *, const SceneTables, const SecEdgeTables, const SensorDev, const PathParams, const GuidingDev, const int, Counters *);
 #define PSDR_INST_PATHS6(PFX, C_) PSDR_INST_PATHS(PFX, true, C_, false, 0) PSDR_INST_PATHS(PFX, false, C_, false, 0) PSDR_INST_PATHS(PFX, false, C_, false, 1) \
                                   PSDR_INST_PATHS(PFX, true, C_, true, 0) PSDR_INST_PATHS(PFX, false, C_, true, 0) PSDR_INST_PATHS(PFX, false, C_, true, 1)
 #define PSDR_TU1(PFX) PSDR_INST_PATHS6(PFX, 0)
-#define PSDR_TU2(PFX) PSDR_INST_ADJ(PFX, 0) PSDR_INST_SEC(PFX, 0, false, false) PSDR_INST_SEC(PFX, 0, true, false) PSDR_INST_SEC(PFX, 0, false, true)
+#define PSDR_TU2(PFX) PSDR_INST_ADJ(PFX, 0) PSDR_INST_ADJM(PFX, 0) PSDR_INST_SEC(PFX, 0, false, false) PSDR_INST_SEC(PFX, 0, true, false) PSDR_INST_SEC(PFX, 0, false, true)
 #define PSDR_TU3(PFX) PSDR_INST_PATHS6(PFX, 1) PSDR_INST_ADJ(PFX, 1) PSDR_INST_SEC(PFX, 1, false, false) PSDR_INST_SEC(PFX, 1, true, false) PSDR_INST_SEC(PFX, 1, false, true)
 #define PSDR_TU4(PFX) PSDR_INST_PATHS6(PFX, 2) PSDR_INST_ADJ(PFX, 2) PSDR_INST_SEC(PFX, 2, false, false) PSDR_INST_SEC(PFX, 2, true, false)
 #define PSDR_TU5(PFX) PSDR_INST_PATHS(PFX, true, 3, false, 0) PSDR_INST_PATHS(PFX, false, 3, false, 0) PSDR_INST_PATHS(PFX, false, 3, false, 1) PSDR_INST_SEC(PFX, 3, false, false)
@@ -1167,6 +1177,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     if (!sc->adj_attr_set) {         // (per scene = per device and context; a process-wide flag would skip the second device)
         IF_CLS1(HIPCHK(hipFuncSetAttribute((const void *) k_interior_adjoint<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
         IF_CLS0(HIPCHK(hipFuncSetAttribute((const void *) k_interior_adjoint<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
+        IF_CLS0(HIPCHK(hipFuncSetAttribute((const void *) k_interior_adjoint_mat<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
         IF_CLS2(HIPCHK(hipFuncSetAttribute((const void *) k_interior_adjoint<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
         IF_CLS1(HIPCHK(hipFuncSetAttribute((const void *) k_secondary_edges<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
         IF_CLS0(HIPCHK(hipFuncSetAttribute((const void *) k_secondary_edges<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
@@ -1201,6 +1212,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
             }
             if (adj_cls == 1) ON_CLS1(hipLaunchKernelGGL((k_interior_adjoint<1>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), Ta, cam, P));
             else if (adj_cls == 2) ON_CLS2(hipLaunchKernelGGL((k_interior_adjoint<2>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), Ta, cam, P));
+            else if (sweep_mat) ON_CLS0(hipLaunchKernelGGL((k_interior_adjoint_mat<0>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), Ta, cam, P));
             else ON_CLS0(hipLaunchKernelGGL((k_interior_adjoint<0>), dim3(grid), dim3(kBlock), smem, st, sc->blob.as<float4>(), Ta, cam, P));
         }
     }
