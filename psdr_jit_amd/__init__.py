@@ -880,8 +880,17 @@ class _RenderDFn(_torch.autograd.Function):
                 return fresh[key]
             return _torch.as_tensor(_np.asarray(obj._get(name, False), dtype=_np.float64))
 
-        with _torch.enable_grad():          # autograd runs backward() with grad mode off
-            tri, sec, prim, refl, rad, cam_tw = chain.snapshot_tensors(scene, st["sensor_id"], leaf_of)
+        # the host chain below works on small float64 CPU tensors: on a many-core host torch's intra-op pool costs more than it
+        # computes (measured on the 2 x 64-core box: 9 ms with <= 4 threads, 10-70 ms with the default 128)
+        n_threads = _torch.get_num_threads()
+        if n_threads > 4:
+            _torch.set_num_threads(4)
+        try:
+            with _torch.enable_grad():          # autograd runs backward() with grad mode off
+                tri, sec, prim, refl, rad, cam_tw = chain.snapshot_tensors(scene, st["sensor_id"], leaf_of)
+        except BaseException:
+            _torch.set_num_threads(n_threads)
+            raise
         g_camera = g_cam.to("cpu", _torch.float64).reshape(4, 4) if g_cam is not None else _torch.zeros((4, 4), dtype=_torch.float64)
         outs, gos = [], []
         for o, go in ((tri, g_tri), (sec, g_sec), (prim, g_prim), (refl, g_bsdf), (rad, g_em), (cam_tw, g_camera)):
@@ -892,10 +901,16 @@ class _RenderDFn(_torch.autograd.Function):
         wanted = [(i, fresh.get((id(obj), name))) for i, ((obj, name, t), need) in enumerate(zip(leaves, needs)) if need]
         wanted = [(i, f) for i, f in wanted if f is not None]
         if outs and wanted:
-            res = _torch.autograd.grad(outs, [f for _, f in wanted], gos, allow_unused=True)
+            try:
+                res = _torch.autograd.grad(outs, [f for _, f in wanted], gos, allow_unused=True)
+            finally:
+                if n_threads > 4:
+                    _torch.set_num_threads(n_threads)
             for (i, f), r in zip(wanted, res):
                 t = leaves[i][2]
                 grads[i] = _torch.zeros_like(t) if r is None else r.reshape(t.shape).to(t.device, t.dtype)
+        elif n_threads > 4:
+            _torch.set_num_threads(n_threads)
         for i in tex_leaves:          # the leaf IS the texel array: its gradient is its block of g_tex
             obj, name, t = leaves[i]
             b = _bsdf_index(scene, obj)
