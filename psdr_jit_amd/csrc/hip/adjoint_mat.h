@@ -52,7 +52,8 @@ PSDR_DEV void vertex_frame(const Vec3<R> &ns, const Vec3<R> &e1, const Vec3<R> &
 // barycentrics are differentiable).
 template <int LDS>
 PSDR_DEV Vec3f bsdf_value_and_adjoint(const SceneView<LDS> &S, int bid, const Vec3f &wi, const Vec3f &wo, float tu, float tv, const Vec3f *Fb,
-                                      float *wib, float *wob, float *acc_bsdf, float *acc_mat, float *g_tex, float *uvb) {
+                                      float *wib, float *wob, float *acc_bsdf, float *acc_mat, float *g_tex, float *uvb,
+                                      int slot = -1, float bu = 0.f, float bv = 0.f, float *bcb = nullptr) {
     if (wib) { wib[0] = wib[1] = wib[2] = 0.f; wob[0] = wob[1] = wob[2] = 0.f; }
     if (bid < 0) return Vec3f(0.f);
     const float4 a = S.ld(S.T->bsdf_off + 2 * bid);
@@ -129,6 +130,52 @@ PSDR_DEV Vec3f bsdf_value_and_adjoint(const SceneView<LDS> &S, int bid, const Ve
         }
     }
     if constexpr (has_mat(LDS)) {
+        if (fl & 128) {        // MicrofacetPerVertex (microfacet_pv.cpp): the three parameters interpolated over the hit triangle's vertices
+            const PvDev pv = S.T->pv[bid];
+            const int *fi = S.T->tri_fi + 3 * slot;
+            auto lerp = [&](const float *val, int stride, int c, float *du, float *dv) {
+                const float v0 = val[stride * fi[0] + c], v1 = val[stride * fi[1] + c], v2 = val[stride * fi[2] + c];
+                *du = v1 - v0; *dv = v2 - v0;
+                return fma_(v1 - v0, bu, fma_(v2 - v0, bv, v0));
+            };
+            float dsu[3], dsv[3], ddu[3], ddv[3], dru, drv;
+            const Vec3f spec(lerp(pv.spec, 3, 0, &dsu[0], &dsv[0]), lerp(pv.spec, 3, 1, &dsu[1], &dsv[1]), lerp(pv.spec, 3, 2, &dsu[2], &dsv[2]));
+            const Vec3f dif(lerp(pv.diff, 3, 0, &ddu[0], &ddv[0]), lerp(pv.diff, 3, 1, &ddu[1], &ddv[1]), lerp(pv.diff, 3, 2, &ddu[2], &ddv[2]));
+            const float rough = lerp(pv.rough, 1, 0, &dru, &drv);
+            const Vec3f F = microfacet_pv_eval<float>(spec, dif, rough, two, wi, wo, true);
+            if (Fb == nullptr) return F;
+            if (!(finite_(Fb->x) && finite_(Fb->y) && finite_(Fb->z)) || (Fb->x == 0.f && Fb->y == 0.f && Fb->z == 0.f)) return F;
+            const float wv[3] = {1.f - bu - bv, bu, bv};
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const float one = 1.f;
+                const Vec3d wiD(Dual(wi.x, j == 0 ? one : 0.f), Dual(wi.y, j == 1 ? one : 0.f), Dual(wi.z, j == 2 ? one : 0.f));
+                const Vec3d woD(Dual(wo.x, j == 3 ? one : 0.f), Dual(wo.y, j == 4 ? one : 0.f), Dual(wo.z, j == 5 ? one : 0.f));
+                const float ts = j == 6 ? one : 0.f, tr = j == 7 ? one : 0.f, td = j == 8 ? one : 0.f;
+                const Vec3d specD(Dual(spec.x, ts), Dual(spec.y, ts), Dual(spec.z, ts)), diffD(Dual(dif.x, td), Dual(dif.y, td), Dual(dif.z, td));
+                const Vec3d r = microfacet_pv_eval<Dual>(specD, diffD, Dual(rough, tr), two, wiD, woD, true);
+                const float pb[3] = {Fb->x * r.x.d, Fb->y * r.y.d, Fb->z * r.z.d};
+                if (j < 3) wib[j] = pb[0] + pb[1] + pb[2];
+                else if (j < 6) wob[j - 3] = pb[0] + pb[1] + pb[2];
+                else {
+                    // value adjoints: to the three vertices with the barycentric weights (g_tex blocks: diffuse, specular, roughness), and at the
+                    // camera vertex to the barycentrics
+                    const int tslot = j == 8 ? 0 : (j == 6 ? 1 : 2), ch = j == 7 ? 1 : 3;
+                    const float rb = pb[0] + pb[1] + pb[2];
+                    for (int c = 0; c < ch; ++c) {
+                        const float val = ch == 1 ? rb : pb[c];
+                        if (val == 0.f || !finite_(val)) continue;
+                        if (g_tex != nullptr) for (int q = 0; q < 3; ++q) atomicAdd(&g_tex[pv.g_off[tslot] + (long long) ch * fi[q] + c], val * wv[q]);
+                        if (bcb != nullptr) {
+                            const float du = j == 8 ? ddu[c] : (j == 6 ? dsu[c] : dru), dv = j == 8 ? ddv[c] : (j == 6 ? dsv[c] : drv);
+                            bcb[0] += val * du; bcb[1] += val * dv;
+                        }
+                    }
+                }
+            }
+            for (int j = 0; j < 3; ++j) { if (!finite_(wib[j])) wib[j] = 0.f; if (!finite_(wob[j])) wob[j] = 0.f; }
+            return F;
+        }
         if (fl & 8) {          // RoughConductor with constant parameters (roughconductor.cpp:30-68): g_mat row = [alpha_u, alpha_v, eta rgb, k rgb, specular rgb]
             const MatDev md = S.T->mat[bid];
             const Vec3f eta(md.eta[0], md.eta[1], md.eta[2]), kk(md.k[0], md.k[1], md.k[2]), spec(md.specular[0], md.specular[1], md.specular[2]);
@@ -509,7 +556,8 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                     // F and, for its adjoint Fb, the adjoints of the outgoing direction (returned), of the incident direction and of ns
                     // (accumulated), and of the BSDF's parameters (accumulated in LDS)
                     // texture coordinates of the vertex (scene.cpp:715/779): uv0 + (uv1 - uv0) u + (uv2 - uv0) v
-                    float tu = 0.f, tv = 0.f, du0x = 0.f, du0y = 0.f, du1x = 0.f, du1y = 0.f, uvb[2] = {0.f, 0.f};
+                    float tu = 0.f, tv = 0.f, du0x = 0.f, du0y = 0.f, du1x = 0.f, du1y = 0.f, uvb[2] = {0.f, 0.f}, bcb[2] = {0.f, 0.f};
+                    const float bary_u = k == 0 ? u0 : vr[kBlock], bary_v = k == 0 ? v0 : vr[2 * kBlock];
                     if (T.tex != nullptr) {
                         const int wsh = T.shade_off + 6 * __float_as_int(vr[0]);
                         const float4 s4 = S.ld(wsh + 4), s5 = S.ld(wsh + 5);
@@ -519,12 +567,13 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                     }
                     auto bsdf_primal = [&](const Vec3f &w) -> Vec3f {
                         const Vec3f wo_l(dot(w, fs), dot(w, ft), dot(w, gk.ns));
-                        return bsdf_value_and_adjoint<LDS>(S, bid, wi_l, wo_l, tu, tv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+                        return bsdf_value_and_adjoint<LDS>(S, bid, wi_l, wo_l, tu, tv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, __float_as_int(vr[0]), bary_u, bary_v, nullptr);
                     };
                     auto bsdf_back = [&](const Vec3f &w, const Vec3f &Fb) -> Vec3f {
                         const Vec3f wo_l(dot(w, fs), dot(w, ft), dot(w, gk.ns));
                         float wib_l[3], wob_l[3];
-                        bsdf_value_and_adjoint<LDS>(S, bid, wi_l, wo_l, tu, tv, &Fb, wib_l, wob_l, P.skip_bsdf ? nullptr : acc_bsdf, acc_mat, P.g_tex, (k == 0 && T.tex != nullptr) ? uvb : nullptr);
+                        bsdf_value_and_adjoint<LDS>(S, bid, wi_l, wo_l, tu, tv, &Fb, wib_l, wob_l, P.skip_bsdf ? nullptr : acc_bsdf, acc_mat, P.g_tex, (k == 0 && T.tex != nullptr) ? uvb : nullptr,
+                                                    __float_as_int(vr[0]), bary_u, bary_v, k == 0 ? bcb : nullptr);
                         wib_w = wib_w + fs * wib_l[0] + ft * wib_l[1] + gk.ns * wib_l[2];
                         if (aniso) {
                             // local components = dot products with the frame vectors: their adjoints (the tangents' go through vertex_frame below)
@@ -630,7 +679,7 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                     xb_next = xb; nsb_next = nsb;
                     Abar = A_k;
                     pb_b = pb_a; pb_a = pb;
-                    if (k == 0) { xb0 = xb + pb_b; nsb0 = nsb; ub_tex = uvb[0] * du0x + uvb[1] * du0y; vb_tex = uvb[0] * du1x + uvb[1] * du1y; }
+                    if (k == 0) { xb0 = xb + pb_b; nsb0 = nsb; ub_tex = uvb[0] * du0x + uvb[1] * du0y + bcb[0]; vb_tex = uvb[0] * du1x + uvb[1] * du1y + bcb[1]; }
                 }
                 // the camera hit: x_0 = o + t d and ns_0 = normalize(blend(u, v)) with (u, v, t) = Moeller-Trumbore(p0, e1, e2; o, d)
                 if (nb > 0 || le0) {

@@ -123,7 +123,9 @@ def _dot_product_case(env, spec, depth, terms, seeds=(7, 8, 9), with_camera=Fals
     if total.value > 0:    # d texel / dP of the spec's bitmaps (reflectance / diffuse, specular, roughness)
         gt = g_tex.cpu().numpy().astype(np.float64)
         for i, b in enumerate(spec.bsdfs):
-            for k, (name, dname) in enumerate((("texture", "d_texture"), ("spec_texture", "d_spec_texture"), ("rough_texture", "d_rough_texture"))):
+            pv = getattr(b, "type", 0) == 4      # per-vertex arrays use the same three blocks: diffuse, specular, roughness
+            for k, (name, dname) in enumerate((("pv_diffuse", "d_pv_diffuse"), ("pv_specular", "d_pv_specular"), ("pv_roughness", "d_pv_roughness")) if pv else
+                                              (("texture", "d_texture"), ("spec_texture", "d_spec_texture"), ("rough_texture", "d_rough_texture"))):
                 t, dt = getattr(b, name, None), getattr(b, dname, None)
                 if t is not None and dt is not None and offs[3 * i + k] >= 0:
                     dt = np.asarray(dt, np.float64).ravel()
@@ -232,4 +234,12 @@ def test_interior_sweep_roughdielectric(env, param):
     """rough glass in the material sweep: paths refract into and out of the closed small box; the lobe's adjoint covers reflection and
     transmission, eta carries 1 / eta with it"""
     lhs, rhs, scale = _dot_product_case(env, scenes.dielectric_cbox_scene(40, 40, 8, 0, 0, param=param), depth=4, terms=1, with_mat=True)
+    assert abs(lhs - rhs) <= 5e-4 * scale and abs(lhs) > 1e-6, (param, lhs, rhs, scale)
+
+
+@pytest.mark.parametrize("param", ["ball_x", "diffuse", "specular", "roughness"])
+def test_interior_sweep_per_vertex_parameters(env, param):
+    """MicrofacetBSDFPerVertex in the material sweep: the adjoint of an interpolated value goes to the triangle's three vertices with
+    the barycentric weights, and at the camera vertex to the barycentrics themselves"""
+    lhs, rhs, scale = _dot_product_case(env, scenes.pervertex_scene(40, 40, 8, 0, 0, param=param), depth=3, terms=1, with_mat=True)
     assert abs(lhs - rhs) <= 5e-4 * scale and abs(lhs) > 1e-6, (param, lhs, rhs, scale)
