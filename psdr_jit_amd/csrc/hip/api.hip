@@ -229,6 +229,63 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edges(const float4 *__rest
             BoundarySegSampleDirect b0 = bss;
             b0.p0 = promote(detach(bss.p0));
             Vec3f v;
+            if (P.sec_closed) {
+                // closed form: the tangent is value0 . n.(e1 du + e2 dv) with (u, v) = Moeller-Trumbore(emitter triangle; x1, sd), sd = normalize(p0 - x1)
+                // and x1 = the camera ray's hit sliding along that ray - two adjoint solves instead of 21-33 replays
+                S.mode = 0; S.probe_kind = 99; S.probe_id = -1;         // (zero tangents everywhere: only the primal factors are wanted)
+                SecAdjInfo I;
+                const int idx = eval_boundary_segment<true, LDS, false>(S, cam, b0, v, -1, &I);
+                if (idx >= 0) {
+                    const float v0c[3] = {I.value0.x, I.value0.y, I.value0.z};
+                    float gsum = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        float k = P.adj_w[3 * (long long) idx + c];
+                        if (pdf0 > kEpsilon) k /= pdf0;
+                        if (T.sppse > 1) k /= (float) T.sppse;
+                        if (finite_(v0c[c])) gsum += k * v0c[c];
+                    }
+                    if (gsum != 0.f && finite_(gsum)) {
+                        auto add3 = [&](float *tab, int row, const Vec3f &val) {
+                            if (val.x != 0.f && finite_(val.x)) atomicAdd(&tab[row], val.x);
+                            if (val.y != 0.f && finite_(val.y)) atomicAdd(&tab[row + 1], val.y);
+                            if (val.z != 0.f && finite_(val.z)) atomicAdd(&tab[row + 2], val.z);
+                        };
+                        Vec3f a2, b2, c2, a1, b1, c1;
+                        load_geom<false, LDS>(S, I.slot2, a2, b2, c2);
+                        load_geom<false, LDS>(S, I.slot1, a1, b1, c1);
+                        Vec3f p0b, e1b, e2b, ob, db;
+                        mt_adjoint(a2, b2, c2, I.x1, I.sd, gsum * dot(I.n, b2), gsum * dot(I.n, c2), 0.f, p0b, e1b, e2b, ob, db);
+                        const int orig2 = __float_as_int(S.ld(T.shade_off + 6 * I.slot2 + 3).w), orig1 = __float_as_int(S.ld(T.shade_off + 6 * I.slot1 + 3).w);
+                        add3(g_tri, 22 * orig2, p0b); add3(g_tri, 22 * orig2 + 3, e1b); add3(g_tri, 22 * orig2 + 6, e2b);
+                        const Vec3f q = detach(bss.p0) - I.x1;
+                        const Vec3f qb = (db - I.sd * dot(I.sd, db)) / norm(q);          // through sd = normalize(p0 - x1)
+                        add3(g_sec, 6 * bss.edge_id, qb); add3(g_sec, 6 * bss.edge_id + 3, qb * bss.s1);
+                        const Vec3f xb = ob - qb;                                         // the camera hit x1 = o + t d
+                        Vec3f p0c, e1c, e2c, oc2, dc2;
+                        mt_adjoint(a1, b1, c1, I.cam_o, I.cam_d, 0.f, 0.f, dot(I.cam_d, xb), p0c, e1c, e2c, oc2, dc2);
+                        add3(g_tri, 22 * orig1, p0c); add3(g_tri, 22 * orig1 + 3, e1c); add3(g_tri, 22 * orig1 + 6, e2c);
+                        if (P.g_cam != nullptr) {
+                            const float t1 = dot(I.x1 - I.cam_o, I.cam_d);
+                            const Vec3f obt = xb + oc2, dbt = xb * t1 + dc2;
+                            const Vec3f pc = xform_pos(cam.sample_to_camera, Vec3f(I.qx, I.qy, 0.f));
+                            const Vec3f o_cam = cam.ortho ? pc : Vec3f(0.f), d_cam = cam.ortho ? Vec3f(0.f, 0.f, 1.f) : normalize(pc);
+                            const float occ[4] = {o_cam.x, o_cam.y, o_cam.z, 1.f}, dcc[4] = {d_cam.x, d_cam.y, d_cam.z, 0.f};
+                            const float obv[3] = {obt.x, obt.y, obt.z}, dbv[3] = {dbt.x, dbt.y, dbt.z};
+#pragma unroll
+                            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) {
+                                    const float val = obv[r] * occ[c] + dbv[r] * dcc[c];
+                                    if (val != 0.f && finite_(val)) atomicAdd(&acc_cam[4 * r + c], val);
+                                }
+                        }
+                    }
+                }
+                S.mode = 0; S.probe_kind = 0;
+                have = false;
+                continue;
+            }
             const int idx = eval_boundary_segment<true, LDS, false>(S, cam, b0, v);
             if (idx >= 0) {
                 float w3[3];
@@ -1238,6 +1295,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         P.begin = 0; P.end = npx_full * T.sppse; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
         P.adj_w = d_rgb; P.g_sec = g->g_sec_edges; P.g_tri = g->g_triangles; P.n_sec = sc->E.n;
         P.g_cam = g->g_camera;
+        P.sec_closed = no_sweep ? 0 : 1;
         const size_t sec_acc = sizeof(float) * (6 * (size_t) sc->E.n + 22 * (size_t) T.n_tris);
         P.lds_acc = (sec_acc <= 48 * 1024) ? 1 : 0;
         const size_t smem_sec = sc->smem_bytes - cold_bytes + sizeof(float) * (size_t) kSecAdjScratch + (P.lds_acc ? sec_acc : 0);

@@ -108,8 +108,12 @@ template <int LDS> PSDR_DEV BoundarySegSampleDirect sample_boundary_segment_dire
 // PathTracer::eval_secondary_edge<ad>, reference path.cpp:171-270.
 // AD=true : returns the pixel index (or -1) and the tangent of the estimator in `value`.
 // AD=false: guiding pass, `value` = value0 without the normal velocity (path.cpp:267-268), returns -1.
+// what the closed-form reverse mode of the term needs from one evaluation (api.hip::k_secondary_edges<.., ADJ>): the detached factor, the
+// normal the velocity is projected on, the two triangles and the camera ray
+struct SecAdjInfo { Vec3f value0, n, x1, cam_o, cam_d, sd; int slot2, slot1; float qx, qy; };
+
 template <bool AD, int LDS, bool COUNT>
-PSDR_DEV int eval_boundary_segment(SceneView<LDS> &S, const SensorDev &cam, const BoundarySegSampleDirect &bss, Vec3f &value, int cam_comp = -1);
+PSDR_DEV int eval_boundary_segment(SceneView<LDS> &S, const SensorDev &cam, const BoundarySegSampleDirect &bss, Vec3f &value, int cam_comp = -1, SecAdjInfo *info = nullptr);
 
 template <bool AD, int LDS, bool COUNT>
 PSDR_DEV int eval_secondary_edge(SceneView<LDS> &S, const SecEdgeTables &E, const SensorDev &cam, const Vec3f &s3, Vec3f &value) {
@@ -121,7 +125,7 @@ PSDR_DEV int eval_secondary_edge(SceneView<LDS> &S, const SecEdgeTables &E, cons
 
 // the traced part of eval_secondary_edge (path.cpp:176-270) for an already sampled, valid boundary segment
 template <bool AD, int LDS, bool COUNT>
-PSDR_DEV int eval_boundary_segment(SceneView<LDS> &S, const SensorDev &cam, const BoundarySegSampleDirect &bss, Vec3f &value, int cam_comp) {
+PSDR_DEV int eval_boundary_segment(SceneView<LDS> &S, const SensorDev &cam, const BoundarySegSampleDirect &bss, Vec3f &value, int cam_comp, SecAdjInfo *info) {
     value = Vec3f(0.f);
     const SceneTables &T = *S.T;
     const Vec3f _p0 = detach(bss.p0), _p2 = bss.p2, _dir = normalize(_p2 - _p0);
@@ -165,6 +169,10 @@ PSDR_DEV int eval_boundary_segment(SceneView<LDS> &S, const SensorDev &cam, cons
         Vec3d v0, e1, e2;
         load_geom<true, LDS>(S, its2.slot, v0, e1, e2);
         const Vec3d sd = normalize(bss.p0 - its1.p);
+        if (info != nullptr) {
+            info->value0 = value0; info->n = n; info->x1 = detach(its1.p); info->cam_o = detach(camera_ray.o); info->cam_d = detach(camera_ray.d);
+            info->sd = detach(sd); info->slot2 = its2.slot; info->slot1 = its1.slot; info->qx = sds.qx; info->qy = sds.qy;
+        }
         Dual u, v, t;
         ray_tri_uvt<Dual>(v0, e1, e2, its1.p, sd, u, v, t);
         // u2 = bilinear(detach(v0), detach(e1), detach(e2), uv): only the barycentrics carry a tangent

@@ -36,6 +36,7 @@ struct PathParams {
     float *g_cam;                    // [16] adjoint of the sensor's to_world through the camera ray of the secondary-edge term, or NULL
     int lds_acc, n_prim, n_sec;      // 1: the kernel accumulates the adjoint tables in LDS first (same-address atomics)
     int mis;                         // -1: PathTracer; 0/1/2: DirectIntegrator(mis), reference direct.cpp:34-132 (max_depth = 1)
+    int sec_closed;                  // reverse mode of the secondary-edge term: 1 = closed form (two adjoint Moeller-Trumbore solves), 0 = record and probe
     int field, field_object;         // >= 0: first-hit integrator (shade.h first_hit_value), max_depth = 0
     float intensity, d_intensity;
 };
