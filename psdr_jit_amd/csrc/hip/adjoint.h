@@ -60,6 +60,7 @@ struct AdjointParams {
     int hit_words, ext_words, lk_words;   // sizes of the three per-lane records (lk_words = 0 when the scene cannot make lookups)
     float *g_mat;                   // [n_bsdfs*16] adjoints of the constant parameters of the GGX BSDFs (psdr_grads.g_mat), or NULL
     int sweep;                      // 1: run_interior_adjoint_sweep (Diffuse BSDFs + area lights), 0: record and probe
+    int env_lds;                    // > 0: the sweeps accumulate the environment map's texel adjoints in LDS first (= 3 * width * height floats: a small map)
     float *rec_global;              // NULL: the per-lane records live in LDS; else [workgroup][word][lane of the workgroup] in global memory
                                     //   (paths too deep for 160 KB of LDS: any depth works, at global-memory latency)
 };
@@ -449,9 +450,10 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
     float *acc_cam = P.rec_global ? scratch : scratch + lane_words * kBlock;      // same accumulator layout as run_interior_adjoint
     float *acc_mat = acc_cam + kAdjMisc;
     float *acc = acc_mat + T.n_bsdfs * kMatRow;
-    const int n_acc = P.n_hot * 22 + T.n_bsdfs * 3 + T.n_emitters * 3;
+    const int n_acc = P.n_hot * 22 + T.n_bsdfs * 3 + T.n_emitters * 3 + P.env_lds;
     for (int i = threadIdx.x; i < n_acc; i += kBlock) acc[i] = 0.f;
     float *acc_bsdf = acc + P.n_hot * 22, *acc_emit = acc_bsdf + T.n_bsdfs * 3;
+    float *acc_env = acc_emit + T.n_emitters * 3;        // [env_lds] texel adjoints of a small environment map (every sample of a wave hits the same few texels)
     if (threadIdx.x < kAdjMisc) acc_cam[threadIdx.x] = 0.f;
     __syncthreads();
     S.mode = 0; S.probe_kind = 0;
@@ -507,7 +509,10 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
                 env::bitmap_footprint_env(E.width, E.height, uu, ww, idx, wt);
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    if (lb[c] != 0.f) for (int k = 0; k < 4; ++k) atomicAdd(&P.g_env[3ll * idx[k] + c], lb[c] * E.scale * wt[k]);
+                    if (lb[c] != 0.f) for (int k = 0; k < 4; ++k) {
+                        if (P.env_lds) atomicAdd(&acc_env[3 * idx[k] + c], lb[c] * E.scale * wt[k]);
+                        else atomicAdd(&P.g_env[3ll * idx[k] + c], lb[c] * E.scale * wt[k]);
+                    }
             }
             if (P.g_env_scale != nullptr) { const float sb = lb[0] * rgb0[0] + lb[1] * rgb0[1] + lb[2] * rgb0[2]; if (sb != 0.f && finite_(sb)) atomicAdd(&acc_cam[12], sb); }
 #pragma unroll
@@ -834,6 +839,7 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
     for (int i = threadIdx.x; i < P.n_hot * 22; i += kBlock) if (acc[i] != 0.f) atomicAdd(&P.g_tri[P.hot_inv[i / 22] * 22 + i % 22], acc[i]);
     for (int i = threadIdx.x; i < T.n_bsdfs * 3; i += kBlock) if (acc_bsdf[i] != 0.f) atomicAdd(&P.g_bsdf[i], acc_bsdf[i]);
     for (int i = threadIdx.x; i < T.n_emitters * 3; i += kBlock) if (acc_emit[i] != 0.f) atomicAdd(&P.g_emitter[i], acc_emit[i]);
+    for (int i = threadIdx.x; i < P.env_lds; i += kBlock) if (acc_env[i] != 0.f) atomicAdd(&P.g_env[i], acc_env[i]);
 }
 
 } // namespace psdr

@@ -1219,7 +1219,12 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     const int lane_words = (sweep || sweep_mat) ? adj_sweep_words(adj_depth) : adj_lane_words(adj_depth, with_lookups);
     // the per-lane records (hits, light samples, lookups of one path: 14 D + 3 words for the sweep) live in LDS when they fit beside
     // the accumulators, else in a global array of the scene (any depth works, at global-memory latency)
-    const size_t acc_fixed = sizeof(float) * ((size_t) kAdjMisc + (size_t) T.n_bsdfs * kMatRow + (size_t) T.n_bsdfs * 3 + (size_t) T.n_emitters * 3);
+    // a small environment map (<= 32 KB of texel adjoints, e.g. 64 x 32) accumulates in LDS: all samples of a wave look up the same few
+    // texels, and same-address atomics in global memory serialise (sweeps only)
+    size_t env_lds = 0;
+    if ((sweep || sweep_mat) && T.env_emitter >= 0 && g->g_env != nullptr && (size_t) T.env.width * T.env.height * 3 * sizeof(float) <= 32 * 1024)
+        env_lds = (size_t) T.env.width * T.env.height * 3;
+    const size_t acc_fixed = sizeof(float) * ((size_t) kAdjMisc + (size_t) T.n_bsdfs * kMatRow + (size_t) T.n_bsdfs * 3 + (size_t) T.n_emitters * 3 + env_lds);
     const bool rec_in_lds = smem_base + sizeof(float) * (size_t) lane_words * kBlock + acc_fixed + 64 * 22 * sizeof(float) <= 160 * 1024;
     const size_t fixed_bytes = acc_fixed + (rec_in_lds ? sizeof(float) * (size_t) lane_words * kBlock : 0);
     if (smem_base + fixed_bytes > 160 * 1024) return fail("scene too large for the adjoint kernel's LDS accumulators");
@@ -1227,7 +1232,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     // the replays -, with at least 64 hot rows (emitters + the largest triangles)
     const size_t budget = (smem_base + fixed_bytes + 64 * 22 * sizeof(float) <= 80 * 1024) ? 80 * 1024 : 160 * 1024;
     const int n_hot_used = (int) std::min<size_t>((size_t) sc->n_hot, (budget - smem_base - fixed_bytes) / (22 * sizeof(float)));
-    const size_t n_acc = (size_t) n_hot_used * 22 + (size_t) T.n_bsdfs * 3 + (size_t) T.n_emitters * 3;
+    const size_t n_acc = (size_t) n_hot_used * 22 + (size_t) T.n_bsdfs * 3 + (size_t) T.n_emitters * 3 + env_lds;
     const size_t adj_bytes = sizeof(float) * ((rec_in_lds ? (size_t) lane_words * kBlock : 0) + kAdjMisc + (size_t) T.n_bsdfs * kMatRow + (lds_acc ? n_acc : 0));
     const size_t smem = smem_base + adj_bytes;
     if (smem > 160 * 1024) return fail("scene too large for the adjoint kernel's LDS records");
@@ -1257,6 +1262,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
             P.hit_words = adj_hit_words(adj_depth); P.ext_words = adj_ext_words(adj_depth); P.lk_words = with_lookups ? 3 * adj_lk_entries(adj_depth) : 0;
             P.sweep = sweep ? 1 : (sweep_mat ? 2 : 0);
             if (sweep || sweep_mat) { P.hit_words = lane_words; P.ext_words = 0; P.lk_words = 0; }
+            P.env_lds = (int) env_lds;
             P.rec_global = nullptr;
             if (!rec_in_lds) {
                 const size_t need = sizeof(float) * (size_t) grid * (size_t) lane_words * kBlock;
