@@ -646,7 +646,7 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
                         Vec3f wod = ps.p - its.p;
                         const float dist_sqr = squared_norm(wod), dist = safe_sqrt(dist_sqr);
                         wod = wod / dist;
-                        const Hit h1 = trace<LDS, false>(S, its.p, wod);
+                        const Hit h1 = trace<LDS, false>(S, its.p, wod, (dist - kShadowEpsilon) * 0.9999f);     // (any occluder settles the shadow test)
                         if (h1.slot >= 0) {
                             RayT<false> ray1; ray1.o = its.p; ray1.d = wod;
                             const Its<false> its1 = make_its<false, LDS, false>(S, h1, ray1, true);

@@ -205,10 +205,11 @@ PSDR_DEV bool tri_test(const float4 &a, const float4 &b, const float4 &c, const 
 
 // Closest hit in (RayEpsilon, 1e8), ties -> smallest original triangle id
 // (replaces jit_optix_ray_trace, reference scene_optix.cpp:343-410; NaN rays miss, :348-353).
-template <int LDS, bool COUNT> PSDR_DEV Hit trace_scene(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d);
+template <int LDS, bool COUNT> PSDR_DEV Hit trace_scene(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d, float anyhit = -__builtin_inff());
 
 template <int LDS, bool COUNT>
-PSDR_DEV Hit trace(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
+// anyhit: a hit closer than this ends the search (shadow rays of the reverse sweeps, BVH scenes only; -inf = closest hit)
+PSDR_DEV Hit trace(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d, float anyhit = -__builtin_inff()) {
     if (S.mode == 2) {                       // replay: pop the hit the recording run found for this ray
         Hit h; h.slot = -1; h.u = h.v = h.t = 0.f;
         if (S.rec_i < S.rec_n) {
@@ -218,7 +219,7 @@ PSDR_DEV Hit trace(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
         ++S.rec_i;
         return h;
     }
-    const Hit h = trace_scene<LDS, COUNT>(S, o, d);
+    const Hit h = trace_scene<LDS, COUNT>(S, o, d, anyhit);
     if (S.mode == 1) {
         float *r = S.rec + 4 * S.rec_n * kBlock;
         r[0] = __int_as_float(h.slot); r[kBlock] = h.u; r[2 * kBlock] = h.v; r[3 * kBlock] = h.t;
@@ -229,10 +230,10 @@ PSDR_DEV Hit trace(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
 
 // 4-wide BVH traversal of up to two rays per lane (scenes with more than kBruteForceMax triangles): trav4.h
 template <int LDS, bool COUNT>
-PSDR_DEV void bvh4_trace2(SceneView<LDS> &S, const Vec3f &oA, const Vec3f &dA, bool actA, const Vec3f &oB, const Vec3f &dB, bool actB, Hit &hA, Hit &hB);
+PSDR_DEV void bvh4_trace2(SceneView<LDS> &S, const Vec3f &oA, const Vec3f &dA, bool actA, const Vec3f &oB, const Vec3f &dB, bool actB, Hit &hA, Hit &hB, float anyhit_a = -__builtin_inff());
 
 template <int LDS, bool COUNT>
-PSDR_DEV Hit trace_scene(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
+PSDR_DEV Hit trace_scene(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d, float anyhit) {
 #pragma clang fp contract(off)
     Hit best; best.slot = -1; best.u = best.v = 0.f; best.t = 0.f;
     if (!(o.x == o.x && o.y == o.y && o.z == o.z && d.x == d.x && d.y == d.y && d.z == d.z)) return best;
@@ -288,7 +289,7 @@ PSDR_DEV Hit trace_scene(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d) {
     }
     if constexpr (!in_lds(LDS)) {          // (the LDS class holds brute-force scenes only: its kernels carry no tree code)
         Hit other;
-        bvh4_trace2<LDS, COUNT>(S, o, d, true, o, d, false, best, other);
+        bvh4_trace2<LDS, COUNT>(S, o, d, true, o, d, false, best, other, anyhit);
     }
     return best;
 }

@@ -298,9 +298,9 @@ template <int LDS> PSDR_DEV void t4_post(const SceneView<LDS> &S, Trav4 &tr, con
 // two rays per lane, run to completion: the synchronous form behind trace() / trace2() (secondary-edge, guiding, adjoint
 // recording and ray-batch kernels)
 template <int LDS, bool COUNT>
-PSDR_DEV void bvh4_trace2(SceneView<LDS> &S, const Vec3f &oA, const Vec3f &dA, bool actA, const Vec3f &oB, const Vec3f &dB, bool actB, Hit &hA, Hit &hB) {
+PSDR_DEV void bvh4_trace2(SceneView<LDS> &S, const Vec3f &oA, const Vec3f &dA, bool actA, const Vec3f &oB, const Vec3f &dB, bool actB, Hit &hA, Hit &hB, float anyhit_a) {
     Trav4 tr;
-    t4_post(S, tr, oA, dA, actA, oB, dB, actB);
+    t4_post(S, tr, oA, dA, actA, oB, dB, actB, anyhit_a);
     trav4_run<LDS, COUNT>(S, tr, 0);
     hA = tr.hA;
     hB = tr.hB;
