@@ -290,7 +290,12 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
         const Its<false> i1 = make_its<false, LDS, true>(S, h, r, true);
         return -to_world<false>(i1, i1.wi);
     };
-    auto env_adjoint = [&](const Vec3f &dir, const Vec3f &Lb) -> Vec3f {
+    // the camera ray's own lookup (every background pixel makes one, and the samples of a wave share texels) is scattered by the whole
+    // wave after the path work: one atomic per distinct texel and wave instead of one per lane
+    bool pend_env = false;
+    int pe_idx[4] = {0, 0, 0, 0};
+    float pe_val[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto env_adjoint = [&](const Vec3f &dir, const Vec3f &Lb, bool defer = false) -> Vec3f {
         Vec3f dirb(0.f);
         if constexpr (has_env(LDS)) {
             const EnvDev &E = T.env;
@@ -315,6 +320,7 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                 for (int c = 0; c < 3; ++c)
                     if (lb[c] != 0.f) for (int k = 0; k < 4; ++k) {
                         if (P.env_lds) atomicAdd(&acc_env[3 * idx[k] + c], lb[c] * E.scale * wt[k]);
+                        else if (defer) { pend_env = true; pe_idx[k] = idx[k]; pe_val[3 * k + c] = lb[c] * E.scale * wt[k]; }
                         else atomicAdd(&P.g_env[3ll * idx[k] + c], lb[c] * E.scale * wt[k]);
                     }
             }
@@ -513,7 +519,7 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
             // ------------------------------------------------------------ pass 2: back over the bounces
             if (W.x != 0.f || W.y != 0.f || W.z != 0.f) {
                 Vec3f cam_dirb(0.f);                    // adjoint of the camera ray's direction from an environment lookup along it
-                if (le0 && e0 == env_id) cam_dirb = env_adjoint(dir0, W);
+                if (le0 && e0 == env_id) cam_dirb = env_adjoint(dir0, W, true);
                 else if (le0 && !P.skip_emitter) add_rgb(acc_emit, e0, W);          // the emitter seen by the camera
                 Vec3f Abar(0.f);                       // d (w.L) / d thr_{k+1} from the bounces behind k
                 Vec3f xb_next(0.f), nsb_next(0.f);     // what bounce k+1 gave vertex k+1 as ITS shading point
@@ -719,6 +725,36 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                 }
             }
             have = false;
+        }
+        // every lane of the wave is here: the pending camera lookups, one atomic per distinct texel
+        if (__ballot(pend_env) != 0ull) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int key = pend_env ? pe_idx[k] : -1;
+                for (int it = 0; it < 8; ++it) {
+                    const unsigned long long m = __ballot(key >= 0);
+                    if (m == 0ull) break;
+                    const int leader = (int) __builtin_ctzll(m);
+                    const int lk = __shfl(key, leader);
+                    const bool same = key == lk;
+                    float s0 = same ? pe_val[3 * k] : 0.f, s1 = same ? pe_val[3 * k + 1] : 0.f, s2 = same ? pe_val[3 * k + 2] : 0.f;
+                    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+                    if (lane_id == leader) {
+                        if (s0 != 0.f) atomicAdd(&P.g_env[3ll * lk], s0);
+                        if (s1 != 0.f) atomicAdd(&P.g_env[3ll * lk + 1], s1);
+                        if (s2 != 0.f) atomicAdd(&P.g_env[3ll * lk + 2], s2);
+                    }
+                    if (same) key = -1;
+                }
+                if (key >= 0) {           // more than eight distinct texels in the wave: the rest go one by one
+                    if (pe_val[3 * k] != 0.f) atomicAdd(&P.g_env[3ll * key], pe_val[3 * k]);
+                    if (pe_val[3 * k + 1] != 0.f) atomicAdd(&P.g_env[3ll * key + 1], pe_val[3 * k + 1]);
+                    if (pe_val[3 * k + 2] != 0.f) atomicAdd(&P.g_env[3ll * key + 2], pe_val[3 * k + 2]);
+                }
+            }
+            pend_env = false;
+#pragma unroll
+            for (int q = 0; q < 12; ++q) pe_val[q] = 0.f;
         }
     }
     __syncthreads();
