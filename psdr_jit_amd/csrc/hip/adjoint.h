@@ -646,8 +646,9 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
                 if (sgn < 0.f) flags |= 4;
                 const bool front = bid >= 0 && (two ? fabsf(its.wi.z) : its.wi.z) > 0.f;
                 {   // next-event estimation (path.cpp:47-83)
-                    const float s1 = rng.next_1d(), s2 = rng.next_1d();
-                    if (mesh_emitter(S, its.mesh) < 0) {
+                    // (DirectIntegrator(1) neither draws nor uses the emitter sample, direct.cpp:34-132)
+                    const float s1 = P.mis != 1 ? rng.next_1d() : 0.f, s2 = P.mis != 1 ? rng.next_1d() : 0.f;
+                    if (P.mis != 1 && mesh_emitter(S, its.mesh) < 0) {
                         const PositionSample<false> ps = sample_emitter_position<false, LDS>(S, its.p, s1, s2);
                         Vec3f wod = ps.p - its.p;
                         const float dist_sqr = squared_norm(wod), dist = safe_sqrt(dist_sqr);
@@ -662,7 +663,7 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
                                 const float woz = dot(wod, its.fn) * sgn;
                                 const float pdf1 = ((front && woz > 0.f) ? kInvPi * woz : 0.f) * G;
                                 if (front && woz > 0.f && pdf1 != 0.f) {
-                                    const float cN = kInvPi * mis_weight(ps.pdf, pdf1) / ps.pdf;
+                                    const float cN = kInvPi * (P.mis == 0 ? 1.f : mis_weight(ps.pdf, pdf1)) / ps.pdf;
                                     if (eh == env_id) {
                                         // the sample lies on the scene box (a fixed point: the record keeps it instead of a triangle),
                                         // the radiance is looked up along the shadow ray
@@ -683,8 +684,11 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
                     }
                 }
                 {   // BSDF sampling (path.cpp:86-123)
-                    const float s0 = rng.next_1d(), s1 = rng.next_1d(), s2 = rng.next_1d();
-                    const BSDFSample bs = bsdf_sample<false, LDS>(S, its, s0, s1, s2, true);
+                    // (DirectIntegrator(0) stops after the emitter sample: no BSDF draw)
+                    const bool do_bsdf = P.mis != 0;
+                    const float s0 = do_bsdf ? rng.next_1d() : 0.f, s1 = do_bsdf ? rng.next_1d() : 0.f, s2 = do_bsdf ? rng.next_1d() : 0.f;
+                    BSDFSample bs = bsdf_sample<false, LDS>(S, its, s0, s1, s2, do_bsdf);
+                    if (!do_bsdf) bs.valid = false;
                     Hit hx; hx.slot = -1;
                     RayT<false> curr; curr.o = its.p; curr.d = to_world<false>(its, bs.wo);
                     if (bs.valid) hx = trace<LDS, false>(S, curr.o, curr.d);
@@ -699,7 +703,7 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
                         const float woz = dot(wo, its.fn) * sgn;
                         const bool ok = !(itx.t < kEpsilon) && front && woz > 0.f;
                         const float cf = ok ? kInvPi / pdf0 : 0.f;
-                        const float w2 = mis_weight(pdf0, emitter_position_pdf<false, LDS>(S, its.p, itx));
+                        const float w2 = P.mis == 1 ? 1.f : mis_weight(pdf0, emitter_position_pdf<false, LDS>(S, its.p, itx));
                         thr = ok ? thr * rho * (woz * G * cf) : Vec3f(0.f);
                         const int ex = mesh_emitter(S, itx.mesh);
                         if (ex >= 0 && ex == env_id) { Lsum = Lsum + env_radiance(env_dir_at(hx.slot, hx.u, hx.v, its.p)) * thr * w2; flags |= 8; }

@@ -444,8 +444,9 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                 nb = depth + 1;
                 int flags = 0;              // 1 next-event term, 2 BSDF term, 8 the next vertex is a visible emitter, 16 the light sample is on the environment map
                 {   // next-event estimation (path.cpp:47-83): L += thr . F(wi, w) . Le . g cN, g = |nz.w| / r^2 . A / detach(A), cN = mis / pdf
-                    const float s1 = rng.next_1d(), s2 = rng.next_1d();
-                    if (mesh_emitter(S, its.mesh) < 0) {
+                    // (DirectIntegrator(1) neither draws nor uses the emitter sample, direct.cpp:34-132)
+                    const float s1 = P.mis != 1 ? rng.next_1d() : 0.f, s2 = P.mis != 1 ? rng.next_1d() : 0.f;
+                    if (P.mis != 1 && mesh_emitter(S, its.mesh) < 0) {
                         const PositionSample<false> ps = sample_emitter_position<false, LDS>(S, its.p, s1, s2);
                         Vec3f wod = ps.p - its.p;
                         const float dist_sqr = squared_norm(wod), dist = safe_sqrt(dist_sqr);
@@ -465,7 +466,7 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                                 else if (its1.wi.z > 0.f) { const float4 ea = S.ld(T.emit_off + 2 * eh); Le = Vec3f(ea.x, ea.y, ea.z); }
                                 // (path.cpp:76-82 adds the product whenever pdf1 != 0: a non-finite factor beside a zero one poisons the
                                 // sample there, and integrator.cpp:126 then drops it - the same must happen here)
-                                const float cN = mis_weight(ps.pdf, pdf1) / ps.pdf;
+                                const float cN = (P.mis == 0 ? 1.f : mis_weight(ps.pdf, pdf1)) / ps.pdf;
                                 if (pdf1 != 0.f) Lsum = Lsum + thr * F * Le * (G * cN);
                                 if (pdf1 != 0.f && nonzero(Le) && nonzero(F)) {
                                     if (eh == env_id) { br[0] = h1.u; br[kBlock] = h1.v; br[2 * kBlock] = 0.f; flags |= 16; }
@@ -479,8 +480,11 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                     }
                 }
                 {   // BSDF sampling (path.cpp:86-123): thr' = thr . F(wi, w) . g cf, cf = 1 / pdf0
-                    const float s0 = rng.next_1d(), s1 = rng.next_1d(), s2 = rng.next_1d();
-                    const BSDFSample bs = bsdf_sample<false, LDS>(S, its, s0, s1, s2, true);
+                    // (DirectIntegrator(0) stops after the emitter sample: no BSDF draw)
+                    const bool do_bsdf = P.mis != 0;
+                    const float s0 = do_bsdf ? rng.next_1d() : 0.f, s1 = do_bsdf ? rng.next_1d() : 0.f, s2 = do_bsdf ? rng.next_1d() : 0.f;
+                    BSDFSample bs = bsdf_sample<false, LDS>(S, its, s0, s1, s2, do_bsdf);
+                    if (!do_bsdf) bs.valid = false;
                     Hit hx; hx.slot = -1;
                     RayT<false> curr; curr.o = its.p; curr.d = to_world<false>(its, bs.wo);
                     if (bs.valid) hx = trace<LDS, false>(S, curr.o, curr.d);
@@ -494,7 +498,7 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                         const float pdf0 = bs.pdf * G;
                         const Vec3f F = (itx.t < kEpsilon) ? Vec3f(0.f) : bsdf_eval<false, LDS>(S, its, to_local<false>(its, wo), true);
                         const float cf = 1.f / pdf0;
-                        const float w2 = mis_weight(pdf0, emitter_position_pdf<false, LDS>(S, its.p, itx));
+                        const float w2 = P.mis == 1 ? 1.f : mis_weight(pdf0, emitter_position_pdf<false, LDS>(S, its.p, itx));
                         thr = thr * F * (G * cf);
                         const int ex = mesh_emitter(S, itx.mesh);
                         Vec3f Le(0.f);

@@ -1213,9 +1213,9 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     const int adj_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth);
     // Diffuse BSDFs + area lights / an environment map under PathTracer: the reverse sweep (adjoint.h); everything else: record and probe
     static const bool no_sweep = std::getenv("PSDR_ADJ_PROBE") != nullptr;         // measurement knob: force the probe form
-    const bool sweep = !no_sweep && adj_cls != 0 && a->direct_mode == 0 && a->field_mode == 0 && T.tex == nullptr && T.pv == nullptr && (T.env_emitter < 0 || adj_cls == 2);
+    const bool sweep = !no_sweep && adj_cls != 0 && a->field_mode == 0 && T.tex == nullptr && T.pv == nullptr && (T.env_emitter < 0 || adj_cls == 2);
     // GGX scenes (class 0): the material sweep, when every BSDF is Diffuse or a constant-parameter Microfacet
-    const bool sweep_mat = !no_sweep && !sweep && adj_cls == 0 && a->direct_mode == 0 && a->field_mode == 0 && sc->simple_mats && (T.mat != nullptr || T.tex != nullptr || T.pv != nullptr);
+    const bool sweep_mat = !no_sweep && !sweep && adj_cls == 0 && a->field_mode == 0 && sc->simple_mats && (T.mat != nullptr || T.tex != nullptr || T.pv != nullptr);
     const int lane_words = (sweep || sweep_mat) ? adj_sweep_words(adj_depth) : adj_lane_words(adj_depth, with_lookups);
     // the per-lane records (hits, light samples, lookups of one path: 14 D + 3 words for the sweep) live in LDS when they fit beside
     // the accumulators, else in a global array of the scene (any depth works, at global-memory latency)
