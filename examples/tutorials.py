@@ -73,16 +73,24 @@ def forward_ad(width=512, height=512, spp=32, sppe=32, sppse=32, depth=3):
     return img.detach(), psdr.forward_grad(img, P)
 
 
-def forward_ad_envmap(width=128, height=128, spp=128, term="interior"):
-    """Forward_AD_envmap.ipynb: the bunny under ballroom_1k.exr, one term of the derivative per cell"""
+def forward_ad_envmap(width=128, height=128, spp=128, term="interior", per_vertex=False):
+    """Forward_AD_envmap.ipynb: the bunny under ballroom_1k.exr, one term of the derivative per cell.  per_vertex=True puts the
+    notebook's three parameters on every vertex of a MicrofacetBSDFPerVertex instead - the same BSDF with the Schlick-k geometry
+    term (reference src/bsdf/microfacet_pv.cpp:49-63) the notebook's figures were rendered with (tests/test_oracle_notebooks.py)"""
     n = {"interior": (spp, 0, 0), "primary": (0, spp, 0), "secondary": (0, 0, spp)}[term]
     sc = _scene(width, height, *n)
     integrator = psdr.PathTracer(1)
     sensor = psdr.PerspectiveCamera(80, 0.000001, 10000000.)
     sensor.to_world = Matrix4fD([[-1., 0., 0., 0.], [0., 1., 0., 0.], [0., 0., -1., 0.], [0., 0., 0., 1.]])
     sc.add_Sensor(sensor)
-    sc.add_BSDF(psdr.MicrofacetBSDF([0.2, 0.9, 0.9], [0.01, 0.01, 0.01], 0.3), "bunny")
-    sc.add_Mesh(os.path.join(DATA, "mesh", "bunny_low.obj"), Matrix4fC([[1., 0., 0., 0.], [0., 1., 0., 0.], [0., 0., 1., -100.], [0., 0., 0., 1.]]), "bunny", None)
+    bunny = os.path.join(DATA, "mesh", "bunny_low.obj")
+    if per_vertex:
+        n = sum(1 for line in open(bunny) if line.startswith("v "))
+        sc.add_BSDF(psdr.MicrofacetBSDFPerVertex(np.tile(np.float32([0.2, 0.9, 0.9]), (n, 1)), np.tile(np.float32([0.01, 0.01, 0.01]), (n, 1)),
+                                                 np.full(n, 0.3, np.float32)), "bunny")
+    else:
+        sc.add_BSDF(psdr.MicrofacetBSDF([0.2, 0.9, 0.9], [0.01, 0.01, 0.01], 0.3), "bunny")
+    sc.add_Mesh(bunny, Matrix4fC([[1., 0., 0., 0.], [0., 1., 0., 0.], [0., 0., 1., -100.], [0., 0., 0., 1.]]), "bunny", None)
     sc.add_EnvironmentMap(os.path.join(DATA, "envmap", "ballroom_1k.exr"), I4, 1.0)
     sc.configure()
     sc.configure([0])

@@ -84,3 +84,14 @@ def compare(img, name, grid=32):
     ncc = float((a0 * b0).sum() / max(np.sqrt((a0 * a0).sum() * (b0 * b0).sum()), 1e-30))
     scale = float((a0 * b0).sum() / max((b0 * b0).sum(), 1e-30))
     return dict(mean_abs=float(d.mean()), max_abs=float(d.max()), ncc=ncc, scale=scale, range=float(spec.get("vmax", 1.0)))
+
+
+def mass_ratio(img, name):
+    """sum of |displayed value| over the frame, ours / reference (the reference's sum is taken over its display pixels and scaled
+    by the number of data pixels per display pixel) - the comparison for one-pixel outlines, where a least-squares scale on
+    block means is diluted by every block the two outlines share only partly"""
+    ref, spec = figure(name)
+    ours = displayed(img, spec)
+    x0, x1, y0, y1 = spec["axes_rect"]
+    per_px = (spec["width"] / float(x1 - x0)) * (spec["height"] / float(y1 - y0))       # data pixels per display pixel
+    return float(np.abs(ours).sum() / (np.abs(ref).sum() * per_px))

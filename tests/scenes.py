@@ -382,7 +382,7 @@ def textured_microfacet_scene(width=48, height=48, spp=4, sppe=0, sppse=0, param
     return spec
 
 
-def envmap_tutorial_scene(width=48, height=48, spp=4, sppe=0, sppse=0, param="bunny_x", env_stride=8):
+def envmap_tutorial_scene(width=48, height=48, spp=4, sppe=0, sppse=0, param="bunny_x", env_stride=8, schlick_g=False):
     """The reference's tutorials/Forward_AD_envmap.ipynb scene: bunny_low.obj (4968 triangles) with
     MicrofacetBSDF([0.2, 0.9, 0.9], [0.01, 0.01, 0.01], 0.3), translated to z = -100, lit by ballroom_1k.exr (the tutorial's own
     PIZ-compressed environment map, read with psdr_jit_amd.exr and decimated by env_stride to keep the oracle quick), camera
@@ -407,6 +407,15 @@ def envmap_tutorial_scene(width=48, height=48, spp=4, sppe=0, sppse=0, param="bu
         bsdfs[0].d_roughness = 1.0
     elif param is not None:
         raise ValueError(param)
+    if schlick_g:
+        # the SAME parameters through MicrofacetBSDFPerVertex (reference src/bsdf/microfacet_pv.cpp:49-63): equal values on every
+        # vertex make it the Microfacet BSDF with the Schlick-k geometry term G1(c) = c / (c (1 - k) + k), k = (roughness + 1)^2 / 8
+        # in place of microfacet.cpp:50's Smith term - the only difference between the two classes' eval
+        b, n = bsdfs[0], len(v)
+        b.type = 4
+        b.pv_specular = np.tile(np.float32(b.specular), (n, 1))
+        b.pv_diffuse = np.tile(np.float32(b.reflectance), (n, 1))
+        b.pv_roughness = np.full(n, b.roughness, np.float32)
     return SceneSpec([bunny], bsdfs, emitters, [cam], width, height, spp, sppe, sppse)
 
 
@@ -506,3 +515,25 @@ def textured_ggx_scene(width=48, height=48, spp=4, sppe=0, sppse=0, kind="roughc
     elif param not in (None, "box_x"):
         raise ValueError(param)
     return spec
+
+
+def hdr_step_square_scene(width=64, height=64, spp=0, sppe=128, a=20.0, d=100.0, fov=60.0, L_pos=100.0, L_neg=1.5):
+    """A black, flat-shaded square (half-size a, depth d, facing the camera at the origin that looks down -z) moving along x by
+    100 P in front of a lat-long map that is L_pos where the direction has x > 0 and L_neg where x < 0: the closed-form case of the
+    primary-edge term (tests/test_oracle_envmap.py).  -> (spec, W H (2 a k)(100 k)) with k = 1 / (2 d tan(fov / 2))"""
+    v = np.float32([[-a, -a, -d], [a, -a, -d], [a, a, -d], [-a, a, -d]])
+    f = np.int32([[0, 1, 2], [0, 2, 3]])
+    quad = MeshSpec(vertices=v, faces=f, bsdf=0, emitter=-1)
+    quad.use_face_normals = True
+    dT = np.zeros((4, 4), np.float32)
+    dT[0, 3] = 100.0
+    quad.d_to_world_left = dT
+    cam = CameraSpec(fov, 1e-6, 1e7, to_world_raw=np.diag([-1.0, 1.0, -1.0, 1.0]).astype(np.float32))
+    w, h = 64, 32
+    env = np.empty((h, w, 3), np.float32)
+    env[:, : w // 2] = L_pos                  # u = atan2(x, -z) / 2 pi in [0, 1/2): x > 0
+    env[:, w // 2:] = L_neg
+    spec = SceneSpec([quad], [BsdfSpec((0.0, 0.0, 0.0), name="black")], [EmitterSpec(type=1, env_data=env, env_scale=1.0)], [cam],
+                     width, height, spp, sppe, 0)
+    k = 1.0 / (2.0 * d * np.tan(np.radians(fov) / 2.0))
+    return spec, width * height * (2 * a * k) * (100.0 * k)

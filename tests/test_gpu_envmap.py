@@ -471,3 +471,21 @@ def test_envmap_reverse_sweep(psdr, orc):
            "albedo": float(albedo.grad.sum()), "camera": float(C.grad)}
     for name in want:
         assert abs(want[name]) > 1e-3 and abs(got[name] - want[name]) < 3e-3 * max(1.0, abs(want[name])), (name, got[name], want[name])
+
+
+def test_primary_edge_closed_form_under_an_hdr_step_background(psdr, orc):
+    """the analytic magnitude case of tests/test_oracle_envmap.py on the HIP path: against the closed form (1 %) and the oracle"""
+    W = H = 64
+    L_pos, L_neg = 100.0, 1.5
+    spec, want = scenes.hdr_step_square_scene(W, H, 0, 128, L_pos=L_pos, L_neg=L_neg)
+    sc = product.build_scene(spec)
+    _, dimg = psdr.render_d_fwd(psdr.PathTracer(1), sc, 0, seed=5)
+    dimg = dimg.cpu().numpy().astype(np.float64).reshape(H, W, 3)
+    _, ref = orc.OracleScene(spec, [0]).render_d(max_depth=1, seeds=(5, 5, 5))
+    assert product.rel_l2(dimg.reshape(-1, 3), ref) < TOL
+    # the camera matrix mirrors x: world x > 0 (the bright side) is the image's left half
+    bright, dim = dimg[:, : W // 2].sum(axis=(0, 1)), dimg[:, W // 2:].sum(axis=(0, 1))
+    if abs(bright[0]) < abs(dim[0]):
+        bright, dim = dim, bright
+    assert np.allclose(bright, -want * L_pos, rtol=0.01), (bright, -want * L_pos)
+    assert np.allclose(dim, want * L_neg, rtol=0.01), (dim, want * L_neg)

@@ -63,8 +63,12 @@ def test_secondary_edge_guiding(tut):
 
 
 def test_different_integrator(tut):
+    """the one-pixel outline is compared by mass (tests/test_oracle_notebooks.py::test_different_integrator_figure)"""
     img, d = tut.different_integrator("silhouette 1")
-    _check(d, "different_integrator_cell6", 32, 0.95, 0.8, 1.1)
+    d = d.cpu().numpy()
+    m = nr.compare(d, "different_integrator_cell6", 32)
+    mass = nr.mass_ratio(d, "different_integrator_cell6")
+    assert m["ncc"] > 0.95 and abs(mass - 1.0) < 0.05, (m, mass)
 
 
 def test_batch_render(tut):
@@ -74,20 +78,33 @@ def test_batch_render(tut):
 
 
 def test_forward_ad_envmap(tut):
+    """Same assertions as the oracle's pin (test_oracle_notebooks.py::test_envmap_figures, which names the root cause of the 0.80):
+    today's Microfacet::__eval (Smith geometry term) reads 0.80 x the figure's primary-edge outline, the notebook's parameters
+    through MicrofacetBSDFPerVertex (the Schlick-k term the figures were rendered with) 0.96 x - on the HIP path too."""
     from test_oracle_notebooks import envelope
     out = {}
-    for term in ("interior", "primary", "secondary"):
-        img, d = tut.forward_ad_envmap(term=term)
-        out[term] = d.cpu().numpy()
-        if term == "interior":
-            _check(img, "Forward_AD_envmap_cell6", 32, 0.985, 0.96, 1.04)
-    ncc, scale = envelope(out["interior"], "Forward_AD_envmap_cell8", 16)
+    for pv in (False, True):
+        for term in ("interior", "primary", "secondary"):
+            if pv and term == "secondary":
+                continue
+            img, d = tut.forward_ad_envmap(term=term, per_vertex=pv)
+            out[pv, term] = d.cpu().numpy()
+            if term == "interior":
+                out[pv, "primal"] = img.cpu().numpy()
+    _check(out[False, "primal"], "Forward_AD_envmap_cell6", 32, 0.985, 0.96, 1.04)
+    ncc, scale = envelope(out[False, "interior"], "Forward_AD_envmap_cell8", 16)
     assert ncc > 0.97 and 0.85 < scale < 1.1, (ncc, scale)
-    m = nr.compare(out["primary"], "Forward_AD_envmap_cell10", 32)
-    ncc, scale = envelope(out["primary"], "Forward_AD_envmap_cell10", 16)
-    assert m["ncc"] > 0.9 and ncc > 0.9 and 0.6 < scale < 1.1, (m, ncc, scale)
+    m = nr.compare(out[False, "primary"], "Forward_AD_envmap_cell10", 8)
+    assert m["ncc"] > 0.96 and 0.74 < m["scale"] < 0.86, m
+    _check(out[True, "primal"], "Forward_AD_envmap_cell6", 32, 0.995, 0.98, 1.02)
+    ncc, scale = envelope(out[True, "interior"], "Forward_AD_envmap_cell8", 16)
+    assert ncc > 0.97 and 0.8 < scale < 1.1, (ncc, scale)
+    m = nr.compare(out[True, "primary"], "Forward_AD_envmap_cell10", 8)
+    assert m["ncc"] > 0.985 and abs(m["scale"] - 1.0) < 0.1, m
+    m = nr.compare(out[True, "primary"], "Forward_AD_envmap_cell10", 32)
+    assert m["ncc"] > 0.97 and abs(m["scale"] - 1.0) < 0.1, m
     ref, spec = nr.figure("Forward_AD_envmap_cell12")
-    ours = nr.displayed(out["secondary"], spec)
+    ours = nr.displayed(out[False, "secondary"], spec)
     n_ours = int((np.abs(ours) > 1.0).sum())
     n_ref = (np.abs(ref) > 1.0).sum() * (128.0 / ref.shape[0]) * (128.0 / ref.shape[1])
     assert 0.5 * n_ref < n_ours < 2.0 * n_ref, (n_ours, n_ref)

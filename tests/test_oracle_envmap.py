@@ -205,3 +205,37 @@ def test_envmap_parameters_are_differentiable(orc):
     dn, _ = render(0.3 - h)
     fd = (up - dn) / (2 * h)
     assert np.abs(fd).max() > 1e-3 and product_rel(dimg, fd) < 0.08, product_rel(dimg, fd)
+
+
+def test_primary_edge_term_against_the_closed_form_under_an_hdr_step_background(orc):
+    """Analytic pin of the primary-edge term's MAGNITUDE (integrator.cpp:179-198, perspective.cpp:200-226) under an HDR map.
+    A black, flat-shaded square (half-size a, depth d in front of the camera, facing it) moves along x by 100 P in front of a
+    map that is L1 = 100 on one side of the view axis and L2 = 1.5 on the other.  Only the two vertical edges move along their
+    normal; behind each the map is constant, so with q = world_to_sample p (a pixel is 1/W x 1/H of the unit square):
+        sum of d image / dP over the pixels of one edge = -/+ W H * (edge length in q) * (dq_x/dP) * L_behind
+                                                        = -/+ W H * (2 a k) * (100 k) * L_behind,   k = 1 / (2 d tan(fov/2)),
+    negative at the edge the square moves towards.  128 samples per pixel: 1 %."""
+    W = H = 64
+    a, d, fov, L_pos, L_neg = 20.0, 100.0, 60.0, 100.0, 1.5
+    spec, want = scenes.hdr_step_square_scene(W, H, 0, 128, a, d, fov, L_pos, L_neg)
+    k = 1.0 / (2.0 * d * np.tan(np.radians(fov) / 2.0))
+    S = orc.OracleScene(spec, [0])
+    assert S.num_primary_edges(0) == 4                      # the diagonal is coplanar (perspective.cpp:96-100)
+    _, dimg = S.render_d(max_depth=1, seeds=(1, 2, 3))
+    dimg = np.asarray(dimg, np.float64).reshape(H, W, 3)
+    # which image half shows world x > 0: the primal behind the square's sides
+    spec.spp, spec.sppe = 4, 0
+    img = np.asarray(orc.OracleScene(spec, [0]).render_c(max_depth=1, seed=1)).reshape(H, W, 3)
+    left_is_pos = img[H // 2, 2, 0] > 10.0
+    assert abs(img[H // 2, 2, 0] - (L_pos if left_is_pos else L_neg)) < 1e-3 and abs(img[H // 2, W - 3, 0] - (L_neg if left_is_pos else L_pos)) < 1e-3
+    halves = {True: dimg[:, : W // 2].sum(axis=(0, 1)), False: dimg[:, W // 2:].sum(axis=(0, 1))}
+    got_pos, got_neg = halves[left_is_pos], halves[not left_is_pos]
+    # the square moves towards +x: it covers the bright side (negative), uncovers the dim side (positive)
+    assert np.allclose(got_pos, -want * L_pos, rtol=0.01), (got_pos, -want * L_pos)
+    assert np.allclose(got_neg, +want * L_neg, rtol=0.01), (got_neg, want * L_neg)
+    # the horizontal edges slide along themselves: rows above / below the square's vertical extent hold nothing else
+    rows = np.abs(dimg).sum(axis=(1, 2))
+    q_lo, q_hi = 0.5 - a * k, 0.5 + a * k
+    inside = (np.arange(H) + 1.0) / H > q_lo - 1e-6
+    inside &= (np.arange(H) + 0.0) / H < q_hi + 1e-6
+    assert rows[~inside].sum() == 0.0

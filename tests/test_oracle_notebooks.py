@@ -11,10 +11,13 @@ blocks because the noise realisations differ (different RNG streams).  Stated me
   Forward_AD cell 5                        renderD primal, sphere box, PathTracer(1)              0.998   0.999   (> 0.985, 1 +- 0.04)
   Forward_AD cell 6                        d/dP all three terms, clipped to +-0.1                 0.998   0.996   (> 0.985, 1 +- 0.05)
   secondary_edge_guiding cell 5 / 6        secondary-edge term alone, plain / guided              0.988 / 0.993, 0.986 / 1.006   (> 0.97, 1 +- 0.07)
-  different_integrator cell 6              primary-edge term of FieldExtraction("silhouette 1")   0.970   0.915   (> 0.95, 0.8 .. 1.1)
+  different_integrator cell 6              primary-edge term of FieldExtraction("silhouette 1")   0.970   mass 0.997   (> 0.95, mass 1 +- 0.05)
   batch_render cell 5 / 6                  RoughConductor sphere, PathTracer(2), full / batch_pix 0.995 / 0.996, 0.990 / 1.003   (> 0.985, 1 +- 0.04)
-  Forward_AD_envmap cell 6                 bunny under ballroom_1k.exr, primal                    0.993   1.003   (> 0.985, 1 +- 0.04)
-  Forward_AD_envmap cell 8 / 10 / 12       interior / primary / secondary term                    see test_envmap_figures
+  Forward_AD_envmap cell 6                 bunny under ballroom_1k.exr, primal                    0.993   1.003   (> 0.985, 1 +- 0.04); with the figure's own
+                                                                                                   geometry term 0.9966 / 0.9996 (> 0.995, 1 +- 0.02)
+  Forward_AD_envmap cell 8 / 10 / 12       interior / primary / secondary term                    see test_envmap_figures: the primary-edge outline is
+                                                                                                   0.96 x the figure (8 x 8 signed block means, 1 +- 0.1)
+                                                                                                   with the figure's geometry term, 0.80 with today's
 
 ncc = normalised cross-correlation of the block means, scale = least-squares factor ours ~ scale * reference.
 """
@@ -67,12 +70,15 @@ def test_secondary_edge_guiding_figures(orc):
 def test_different_integrator_figure(orc):
     """different_integrator.ipynb cell 6: FieldExtractionIntegrator("silhouette 1") - the moving small sphere's mask; its
     derivative is the primary-edge term alone, a one-pixel outline saturated at the colour bar's +-0.1.  Rendered at the
-    notebook's 512 x 512 because the outline's width in pixels sets the block means."""
+    notebook's 512 x 512 because the outline's width in pixels sets the block means.  A one-pixel outline that sits half a pixel
+    off the reference's shares most blocks only partly, which dilutes the least-squares scale (0.915 at ncc 0.97), so the
+    magnitude is compared by MASS - the sum of |displayed value| over the frame, ours / reference = 0.997."""
     S = orc.OracleScene(scenes.sphere_scene(512, 512, 4, 32, 0), [0])
     S.set_field("silhouette", 1)
     _, d = S.render_d(max_depth=0, seeds=(1, 2, 3))
     m = nr.compare(d, "different_integrator_cell6", 32)
-    assert m["ncc"] > 0.95 and 0.8 < m["scale"] < 1.1, m
+    mass = nr.mass_ratio(d, "different_integrator_cell6")
+    assert m["ncc"] > 0.95 and abs(mass - 1.0) < 0.05, (m, mass)
 
 
 def conductor_sphere_scene(width=400, height=300, spp=32):
@@ -108,32 +114,74 @@ def envelope(d, name, grid):
     return float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum())), float((a * b).sum() / (b * b).sum())
 
 
+def bunny_ratio(img, inner):
+    """mean displayed value of our frame over the reference's inside the bunny (mask from the caller), frame 128 x 128"""
+    ref, spec = nr.figure("Forward_AD_envmap_cell6")
+    a, b = nr.block_means(nr.displayed(img, spec), ref, spec, 128)
+    return float(a[inner].mean() / b[inner].mean())
+
+
 @pytest.mark.slow
 def test_envmap_figures(orc):
-    """Forward_AD_envmap.ipynb: bunny_low.obj with MicrofacetBSDF under ballroom_1k.exr, 128 x 128, 128 samples per term.
-    cell 6 primal; cells 8 / 10 / 12 the interior / primary-edge / secondary-edge derivative alone, colour bar +-50.
+    """Forward_AD_envmap.ipynb: bunny_low.obj with MicrofacetBSDF([0.2, 0.9, 0.9], [0.01, 0.01, 0.01], 0.3) under ballroom_1k.exr,
+    128 x 128, 128 samples per term.  cell 6 primal; cells 8 / 10 / 12 the interior / primary-edge / secondary-edge derivative
+    alone, colour bar +-50.
 
-    The derivative maps of this scene are dominated by the HDR texels of the map seen in a glossy surface at 128 samples:
-    pixel values differ between two noise realisations, so the interior term is compared through the ENVELOPE (block means
-    of |value|), the primary-edge outline through signed block means, and the secondary term (a few dozen isolated spikes in
-    the reference figure and here) through the count and location of its spikes.  Measured: interior envelope ncc 0.989,
-    scale 0.96; primary ncc 0.96 with an envelope scale of 0.82 - the reference's outline is stronger on the bunny's
-    right side (unclipped blocks 1.2-1.8 x), which this restatement does not reproduce and DESIGN.md lists as open."""
-    full = {}
-    for cell, n in ((8, (128, 0, 0)), (10, (0, 128, 0)), (12, (0, 0, 128))):
-        S = orc.OracleScene(scenes.envmap_tutorial_scene(128, 128, *n, param="bunny_x", env_stride=1), [0])
-        img, d = S.render_d(max_depth=1, seeds=(1, 2, 3))
-        full[cell] = d
-        if cell == 8:
-            _check(img, "Forward_AD_envmap_cell6", 32, 0.985, 0.04)
-    ncc, scale = envelope(full[8], "Forward_AD_envmap_cell8", 16)
+    ROOT CAUSE of round 2's open item (the primary-edge outline read 0.80 x the figure, stably): the notebook's figures were
+    rendered with the Schlick-k geometry term G1(c) = c / (c (1 - k) + k), k = (roughness + 1)^2 / 8 - the term the reference
+    still carries in MicrofacetPerVertex::__eval (src/bsdf/microfacet_pv.cpp:49-63) - and not with the Smith term
+    `distr.smith_g1(wi, H) * distr.smith_g1(wo, H)` that Microfacet::__eval has today (src/bsdf/microfacet.cpp:50).  The two
+    classes' eval differ in nothing else (same GGX D, same 2^(...) Fresnel, same sampler and pdf), so the tutorial scene with its
+    parameters on every vertex of a MicrofacetPerVertex IS the older Microfacet.  Evidence, all asserted below:
+      * primal (cell 6): inside the bunny ours / figure = 1.053 with the Smith term, uniform over the colour channels (so not the
+        Fresnel term) and growing towards grazing view angles (ref / ours 0.93 at cos 0.95 ... 0.53 at cos 0.25) - the signature of a
+        masking term; 1.011 with the Schlick-k term; whole-frame ncc 0.9932 -> 0.9966;
+      * primary-edge term (cell 10), signed 8 x 8 block means: scale 0.80 / ncc 0.978 with the Smith term, 0.96 / 0.993 with
+        Schlick-k (a perfectly black bunny reads 1.006: the term is  background - rim radiance, and the rim is where the two
+        geometry terms differ most);
+      * the interior term's envelope (cell 8) stays inside its band with either (HDR texels in a glossy lobe at 128 samples).
+    The product follows the reference's SOURCE (Smith); the figure pins everything around the BSDF through the per-vertex class."""
+    from scipy import ndimage
+    # coverage mask of the bunny (first hit on the mesh) from a black-body render
+    spec = scenes.envmap_tutorial_scene(128, 128, 8, 0, 0, param=None, env_stride=8)
+    spec.bsdfs[0].type, spec.bsdfs[0].reflectance = 0, (0.0, 0.0, 0.0)
+    black = orc.OracleScene(spec, [0]).render_c(max_depth=1, seed=1)
+    inner = ndimage.binary_erosion(np.asarray(black).reshape(128, 128, 3).sum(2) == 0, iterations=5)
+    got = {}
+    for schlick in (False, True):
+        full = {}
+        for cell, n in ((8, (128, 0, 0)), (10, (0, 128, 0)), (12, (0, 0, 128))):
+            if cell == 12 and schlick:
+                continue
+            S = orc.OracleScene(scenes.envmap_tutorial_scene(128, 128, *n, param="bunny_x", env_stride=1, schlick_g=schlick), [0])
+            img, d = S.render_d(max_depth=1, seeds=(1, 2, 3))
+            full[cell] = d
+            if cell == 8:
+                full[6] = img
+        got[schlick] = full
+    # --- today's Microfacet::__eval (Smith): the frame as a whole agrees, the bunny is 5 % brighter (sRGB), the outline 0.80 x
+    smith = got[False]
+    _check(smith[6], "Forward_AD_envmap_cell6", 32, 0.985, 0.04)
+    r = bunny_ratio(smith[6], inner)
+    assert 1.03 < r < 1.08, r
+    ncc, scale = envelope(smith[8], "Forward_AD_envmap_cell8", 16)
     assert ncc > 0.97 and 0.85 < scale < 1.1, (ncc, scale)
-    m = nr.compare(full[10], "Forward_AD_envmap_cell10", 32)
-    ncc, scale = envelope(full[10], "Forward_AD_envmap_cell10", 16)
-    assert m["ncc"] > 0.9 and ncc > 0.9 and 0.6 < scale < 1.1, (m, ncc, scale)
+    m = nr.compare(smith[10], "Forward_AD_envmap_cell10", 8)
+    assert m["ncc"] > 0.96 and 0.74 < m["scale"] < 0.86, m
+    # --- the figure's own geometry term (MicrofacetPerVertex, Schlick-k): everything within the other figures' bands
+    pv = got[True]
+    m = _check(pv[6], "Forward_AD_envmap_cell6", 32, 0.995, 0.02)
+    r = bunny_ratio(pv[6], inner)
+    assert 0.98 < r < 1.03, r
+    ncc, scale = envelope(pv[8], "Forward_AD_envmap_cell8", 16)
+    assert ncc > 0.97 and 0.8 < scale < 1.1, (ncc, scale)
+    m = nr.compare(pv[10], "Forward_AD_envmap_cell10", 8)
+    assert m["ncc"] > 0.985 and abs(m["scale"] - 1.0) < 0.1, m
+    m = nr.compare(pv[10], "Forward_AD_envmap_cell10", 32)
+    assert m["ncc"] > 0.97 and abs(m["scale"] - 1.0) < 0.1, m
     # secondary term: isolated spikes on the bunny, nothing elsewhere
     ref, spec = nr.figure("Forward_AD_envmap_cell12")
-    ours = nr.displayed(full[12], spec)
+    ours = nr.displayed(smith[12], spec)
     n_ours = int((np.abs(ours) > 1.0).sum())
     n_ref = (np.abs(ref) > 1.0).sum() * (128.0 / ref.shape[0]) * (128.0 / ref.shape[1])
     assert 0.5 * n_ref < n_ours < 2.0 * n_ref, (n_ours, n_ref)
