@@ -8,6 +8,8 @@ Workloads (BASELINE.json `configs`):
            256-lane chunks are dealt round-robin to the ranks (interleaved pixel tiles), ONE RCCL all-reduce of the
            stacked [image | derivative] buffer (96 MiB) assembles it.  `--config 4 --gpus 1` runs it on one GPU.
   --weak   (N > 1): last round's mode - config 3 with spp = 32 * N, per-GPU work fixed.
+  config 5 (`--config 5`, N = 1; N > 1 shards it like config 4): the BVH path - envmap-lit 81 920-triangle mesh (examples/synth.py), 1024 x 1024,
+           spp = sppe = sppse = 64, renderD w.r.t. the DiffuseBSDF albedo, secondary-edge guiding grid [2000, 5, 5, 32].
 
 A "step" = one full renderD: image + d(image)/d(theta) = interior path tracer with its forward tangent +
 primary-edge + secondary-edge boundary integrals (3 kernels) and, for N > 1, the all-reduce.  The scene is built
@@ -15,13 +17,20 @@ through the package's public Python surface (the reference README's calls) and i
 region; the boundary hands over device pointers only (no PCIe term).  Work is never skipped: every step renders all
 lanes with fresh seeds.
 
-Prints ONE JSON line (rank 0).  Extra objects (N = 1, rank 0):
+Prints ONE JSON line (rank 0).  Extra objects (N = 1, rank 0; each can be switched off, none is inside the timed region):
   roofline     - the dominant kernel against the ceiling that binds it.  The scene is LDS / SGPR resident and the
                  compulsory HBM traffic is the two output images, so the bound is fp32 VALU issue: achieved =
                  SURVEY §8(d) flops (60 / node visit + 45 / triangle test + 250 / shaded hit, counted by the
                  instrumented build in this run) / the kernel's HIP-event duration measured in this run.  `traffic`
                  and `issue` are rocprofv3 PMC figures of the same command; they cannot be collected from inside the
                  process, so they are read from the committed summary named in `counters_source` (null if absent).
+  backward     - reverse mode on the same workload: ms per psdr_hip_render_d_bwd (adjoints of every triangle row, BSDF colour, emitter,
+                 edge row: nothing filtered), all three terms and each alone, HIP events on the launch stream.
+  config5      - (default run only) the BVH path at BASELINE config 5's full size: ms per renderD, per-kernel HIP-event times, counted
+                 nodes / triangles per ray, the dominant kernel against the L2 ceiling (34.5 TB/s) with the HBM rate and L2 hit rate
+                 of the committed rocprofv3 passes; `--config 5` makes it the headline workload instead.
+  rccl         - PSDR_BENCH_FORCE_DIST=1 runs the N > 1 code path (process group with device_id, device-pointer all-reduce, teardown)
+                 at whatever world size the launcher gives, also 1 (the preflight of tests/test_gpu_distributed.py).
   parity       - relative L2 of this run's GPU image / derivative against the oracle on the same shard and seeds.
   cpu_baseline - the CPU restatement (oracle/, test infrastructure), built -O3 -march=native on this host, 1 warm-up +
                  median of 5 on a bounded shard of the same workload, all physical cores and one thread.
@@ -40,8 +49,10 @@ for p in (ROOT, os.path.join(ROOT, "examples")):
         sys.path.insert(0, p)
 
 DEPTH = 3
-CONFIGS = {3: dict(res=512, spp=32), 4: dict(res=2048, spp=64)}
+CONFIGS = {3: dict(res=512, spp=32), 4: dict(res=2048, spp=64), 5: dict(res=1024, spp=64)}
+GUIDING = [2000, 5, 5, 32]     # config 5: preprocess_secondary_edges grid (tutorials/secondary_edge_guiding.ipynb)
 VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: fp32 vector peak
+L2_PEAK_TBPS = 34.5            # MI355X_MICROARCH.md: aggregate L2 bandwidth (8 XCDs x 4 MiB)
 COUNTERS = os.path.join(ROOT, "profiles", "counters.json")      # written by tools/prof_summary.py from the rocprofv3 --pmc passes
 
 
@@ -97,7 +108,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, choices=(3, 4), default=0, help="BASELINE config (default: 3 at N = 1, 4 at N > 1)")
+    ap.add_argument("--config", type=int, choices=(3, 4, 5), default=0, help="BASELINE config (default: 3 at N = 1, 4 at N > 1)")
+    ap.add_argument("--res", type=int, default=0, help="override the configuration's resolution (measurement aid; the line names it)")
+    ap.add_argument("--spp", type=int, default=0, help="override the configuration's sample counts (measurement aid; the line names it)")
+    ap.add_argument("--no-backward", action="store_true")
+    ap.add_argument("--no-config5", action="store_true")
     ap.add_argument("--weak", action="store_true", help="N > 1: config 3 with spp = 32 * N (weak scaling)")
     ap.add_argument("--cpu-shard", type=int, default=0, help="the CPU baseline renders every k-th 256-lane chunk (0 = calibrate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -121,8 +136,11 @@ def main():
     backend = os.environ.get("PSDR_BENCH_BACKEND", "nccl")
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    force_dist = os.environ.get("PSDR_BENCH_FORCE_DIST", "0") == "1"
+    use_dist = world > 1 or force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
         else:
@@ -131,7 +149,7 @@ def main():
     import __graft_entry__
     if rank == 0:
         __graft_entry__.build()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     import psdr_jit_amd as psdr
     from psdr_jit_amd import cabi
@@ -139,14 +157,23 @@ def main():
     n = world
     weak = args.weak and n > 1
     cfg = args.config or (3 if (n == 1 or weak) else 4)
-    res = CONFIGS[cfg]["res"]
-    spp = CONFIGS[cfg]["spp"] * (n if weak else 1)
-    sc, P = readme_scene(psdr, res, spp)                # host configure + filter primitives + upload (not timed)
-    integ = psdr.PathTracer(DEPTH)
-    # forward tangent of the parameter: d to_world_left / dP of Mesh[0]; one untimed call installs it in the device scene
-    leaf = sc.param_map["Mesh[0]"].to_world_left
-    d_leaf = np.zeros((4, 4), np.float32)
-    d_leaf[0, 3] = 100.0
+    res = args.res or CONFIGS[cfg]["res"]
+    spp = (args.spp or CONFIGS[cfg]["spp"]) * (n if weak else 1)
+    guiding = None
+    if cfg == 5:
+        import synth
+        sc, leaf = synth.config5_scene(psdr, res, spp)   # BVH build + upload + environment cell masses (not timed)
+        d_leaf = np.ones(3, np.float32)
+        integ = psdr.PathTracer(DEPTH)
+        integ.preprocess_secondary_edges(sc, 0, GUIDING, 1, 0)
+        guiding = integ._guiding_handle(0) or None       # psdr_render_args.guiding: the grid the integrator holds for sensor 0
+    else:
+        sc, P = readme_scene(psdr, res, spp)            # host configure + filter primitives + upload (not timed)
+        integ = psdr.PathTracer(DEPTH)
+        # forward tangent of the parameter: d to_world_left / dP of Mesh[0]; one untimed call installs it in the device scene
+        leaf = sc.param_map["Mesh[0]"].to_world_left
+        d_leaf = np.zeros((4, 4), np.float32)
+        d_leaf[0, 3] = 100.0
     psdr.render_d_fwd(integ, sc, 0, seed=12345, tangents={leaf: d_leaf})
     handle = sc._hip_handle()
     L = cabi.lib()
@@ -155,16 +182,16 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def launch(seed, terms=7, shard_rank=rank, shard_count=world, zero=True, out=buf):
-        a = cabi.make_args(max_depth=DEPTH, seeds=(seed, seed, seed), terms=terms, shard_rank=shard_rank, shard_count=shard_count, zero_output=zero)
+        a = cabi.make_args(max_depth=DEPTH, seeds=(seed, seed, seed), terms=terms, shard_rank=shard_rank, shard_count=shard_count, zero_output=zero, guiding=guiding)
         cabi.check(L.psdr_hip_render_d_fwd(handle, C.byref(a), out[0].data_ptr(), out[1].data_ptr(), stream))
 
     def step(i):
         launch(i)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -176,7 +203,7 @@ def main():
         step(i)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -185,61 +212,184 @@ def main():
     value = samples_per_step / (dt / args.steps) / 1e6
 
     out = {
-        "metric": "Msamples/s (spp x pixels/s) renderD, Cornell box depth=3",
+        "metric": "Msamples/s (spp x pixels/s) renderD, %s depth=3" % ("envmap-lit 82k-triangle mesh" if cfg == 5 else "Cornell box"),
         "value": round(value, 3), "unit": "Msamples/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE config %d%s: README Cornell box (36 triangles) %dx%d PathTracer(%d) renderD d/d(Mesh[0] x-translation), "
-                               "spp=sppe=sppse=%d" % (cfg, " weak-scaled" if weak else "", res, res, DEPTH, spp),
+        "config": {"workload": ("BASELINE config 5: envmap-lit 81 920-triangle mesh + floor, %dx%d PathTracer(%d) renderD d/d(albedo), spp=sppe=sppse=%d, "
+                                "guiding grid %s" % (res, res, DEPTH, spp, GUIDING)) if cfg == 5 else
+                               ("BASELINE config %d%s: README Cornell box (36 triangles) %dx%d PathTracer(%d) renderD d/d(Mesh[0] x-translation), "
+                                "spp=sppe=sppse=%d" % (cfg, " weak-scaled" if weak else "", res, res, DEPTH, spp)),
                    "rays_per_step": int(npx * spp * (1 + 2 * DEPTH) + npx * spp * 2 * (1 + 2 * DEPTH) + npx * spp * 3),
                    "parallelism": "256-lane chunks dealt round-robin to %d GPU(s)%s" % (n, " + one all_reduce(sum) of [image | derivative]" if n > 1 else "")},
     }
 
-    # ---------------------------------------------------------------- roofline of the dominant kernel (rank 0, N = 1)
-    if rank == 0 and n == 1 and not args.no_roofline:
+    counters = None
+    if os.path.exists(COUNTERS):
+        try:
+            counters = json.load(open(COUNTERS))
+        except Exception:
+            counters = None
+
+    def per_kernel(do_launch, h, bufs, gd, reps):
+        """HIP-event time of each term's kernel launched alone (torch's current stream = the launch stream) + the counted build's
+        rays / node visits / triangle tests / shaded hits for the same launch"""
         names = {1: "k_interior<AD>", 2: "k_primary_edges", 4: "k_secondary_edges"}
         per = {}
         for terms in (1, 2, 4):
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # torch's current stream = the launch stream
-            launch(77, terms)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            do_launch(77, terms)
             torch.cuda.synchronize()
-            reps = max(5, args.steps // 2)
             ev0.record()
             for i in range(reps):
-                launch(i, terms, zero=False)
+                do_launch(i, terms, zero=False)
             ev1.record()
             torch.cuda.synchronize()
             ms = ev0.elapsed_time(ev1) / reps
             c = cabi.Counters()
-            a = cabi.make_args(max_depth=DEPTH, seeds=(0, 0, 0), terms=terms)
-            cabi.check(L.psdr_hip_render_d_fwd_counted(handle, C.byref(a), buf[0].data_ptr(), buf[1].data_ptr(), C.byref(c), stream))
+            a = cabi.make_args(max_depth=DEPTH, seeds=(0, 0, 0), terms=terms, guiding=gd)
+            cabi.check(L.psdr_hip_render_d_fwd_counted(h, C.byref(a), bufs[0].data_ptr(), bufs[1].data_ptr(), C.byref(c), stream))
             per[terms] = {"kernel": names[terms], "ms": ms, "rays": c.rays, "nodes": c.nodes_visited, "tris": c.tris_tested, "hits": c.shaded_hits}
+        return per
+
+    def kernel_rows(per):
+        return [{"kernel": r["kernel"], "avg_launch_ms": round(r["ms"], 4), "rays": r["rays"],
+                 "Mrays_per_s": round(r["rays"] / (r["ms"] * 1e-3) / 1e6, 1)} for r in per.values()]
+
+    def bvh_roofline(per, h, section):
+        """The dominant kernel of a BVH scene against the L2 ceiling: algorithmic bytes = node bytes x node visits + 48 x triangle
+        tests (with the node size of this build's tree), counted in this run, / the kernel's HIP-event time of this
+        run.  HBM bytes per launch and the L2 hit rate come from the committed rocprofv3 --pmc passes of the same command."""
+        nn, nl, md, nb = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        cabi.check(L.psdr_hip_scene_stats(C.c_void_p(h), C.byref(nn), C.byref(nl), C.byref(md), C.byref(nb)))
+        node_bytes = int(L.psdr_hip_bvh_node_bytes())
         dom = max(per.values(), key=lambda r: r["ms"])
-        flops_alg = 60.0 * dom["nodes"] + 45.0 * dom["tris"] + 250.0 * dom["hits"]
-        bytes_alg = 64.0 * dom["nodes"] + 48.0 * dom["tris"]
         sec = dom["ms"] * 1e-3
-        achieved = flops_alg / sec / 1e12
-        counters = None
-        if os.path.exists(COUNTERS):
-            try:
-                counters = json.load(open(COUNTERS))
-            except Exception:
-                counters = None
-        krec = (counters or {}).get("kernels", {}).get(dom["kernel"], {})
-        out["roofline"] = {
-            "bound": "valu", "kernel": dom["kernel"], "achieved": round(achieved, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / VALU_PEAK_TFLOPS, 4),
-            "traffic": krec.get("hbm_bytes_per_launch"), "counters_source": (counters or {}).get("source"),
-            "issue": krec.get("issue"),
-            "note": "SURVEY 8(d) flops (60/node + 45/triangle + 250/shaded hit, counted in this run) / HIP-event time of this run; "
-                    "compulsory HBM bytes per launch = the two output images (%.1f MB), so HBM is not the ceiling" % (2 * npx * 12 / 1e6),
-            "avg_launch_ms": round(dom["ms"], 4), "rays": dom["rays"], "nodes_per_ray": round(dom["nodes"] / max(dom["rays"], 1), 2),
-            "tris_per_ray": round(dom["tris"] / max(dom["rays"], 1), 2), "flops_per_launch": flops_alg,
-            "scene_bytes": {"algorithmic_per_launch": bytes_alg, "rate_GBps": round(bytes_alg / sec / 1e9, 1),
-                            "served_by": "wave-uniform scalar loads / LDS (one fetch serves 64 lanes): not HBM traffic"},
-            "kernels": [{"kernel": r["kernel"], "avg_launch_ms": round(r["ms"], 4), "rays": r["rays"],
-                         "Mrays_per_s": round(r["rays"] / (r["ms"] * 1e-3) / 1e6, 1)} for r in per.values()],
+        bytes_alg = float(node_bytes) * dom["nodes"] + 48.0 * dom["tris"]
+        flops_alg = 60.0 * dom["nodes"] + 45.0 * dom["tris"] + 250.0 * dom["hits"]
+        krec = ((counters or {}).get(section) or {}).get("kernels", {}).get(dom["kernel"], {})
+        hbm = krec.get("hbm_bytes_per_launch")
+        return {
+            "bound": "l2", "kernel": dom["kernel"], "achieved": round(bytes_alg / sec / 1e12, 3), "peak": L2_PEAK_TBPS, "unit": "TB/s",
+            "frac": round(bytes_alg / sec / 1e12 / L2_PEAK_TBPS, 4),
+            "traffic": hbm, "hbm_GBps": (round(hbm / (krec.get("avg_launch_us", 0) * 1e-6) / 1e9, 1) if hbm and krec.get("avg_launch_us") else None),
+            "l2_hit_rate": krec.get("l2_hit_rate"), "counters_source": ((counters or {}).get(section) or {}).get("source"),
+            "counters_workload": ((counters or {}).get(section) or {}).get("workload"), "issue": krec.get("issue"),
+            "note": "algorithmic bytes (%d B per node visit + 48 B per triangle test, counted in this run) / HIP-event time of this run against the "
+                    "aggregate L2 bandwidth; valu_frac = SURVEY 8(d) flops / time / %.1f TFLOP/s" % (node_bytes, VALU_PEAK_TFLOPS),
+            "avg_launch_ms": round(dom["ms"], 4), "rays": dom["rays"], "Grays_per_s": round(dom["rays"] / sec / 1e9, 3),
+            "nodes_per_ray": round(dom["nodes"] / max(dom["rays"], 1), 2), "tris_per_ray": round(dom["tris"] / max(dom["rays"], 1), 2),
+            "bytes_per_launch": bytes_alg, "valu_frac": round(flops_alg / sec / 1e12 / VALU_PEAK_TFLOPS, 4),
+            "bvh": {"nodes": nn.value, "leaves": nl.value, "depth": md.value, "node_bytes": node_bytes},
+            "kernels": kernel_rows(per),
         }
+
+    # ---------------------------------------------------------------- roofline of the dominant kernel (rank 0, N = 1)
+    if rank == 0 and n == 1 and not args.no_roofline:
+        per = per_kernel(launch, handle, buf, guiding, max(3 if cfg == 5 else 5, args.steps // 2))
+        if cfg == 5:
+            out["roofline"] = bvh_roofline(per, handle, "config5")
+        else:
+            dom = max(per.values(), key=lambda r: r["ms"])
+            flops_alg = 60.0 * dom["nodes"] + 45.0 * dom["tris"] + 250.0 * dom["hits"]
+            bytes_alg = 64.0 * dom["nodes"] + 48.0 * dom["tris"]
+            sec = dom["ms"] * 1e-3
+            achieved = flops_alg / sec / 1e12
+            krec = (counters or {}).get("kernels", {}).get(dom["kernel"], {})
+            out["roofline"] = {
+                "bound": "valu", "kernel": dom["kernel"], "achieved": round(achieved, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / VALU_PEAK_TFLOPS, 4),
+                "traffic": krec.get("hbm_bytes_per_launch"), "counters_source": (counters or {}).get("source"),
+                "issue": krec.get("issue"),
+                "note": "SURVEY 8(d) flops (60/node + 45/triangle + 250/shaded hit, counted in this run) / HIP-event time of this run; "
+                        "compulsory HBM bytes per launch = the two output images (%.1f MB), so HBM is not the ceiling" % (2 * npx * 12 / 1e6),
+                "avg_launch_ms": round(dom["ms"], 4), "rays": dom["rays"], "nodes_per_ray": round(dom["nodes"] / max(dom["rays"], 1), 2),
+                "tris_per_ray": round(dom["tris"] / max(dom["rays"], 1), 2), "flops_per_launch": flops_alg,
+                "scene_bytes": {"algorithmic_per_launch": bytes_alg, "rate_GBps": round(bytes_alg / sec / 1e9, 1),
+                                "served_by": "wave-uniform scalar loads / LDS (one fetch serves 64 lanes): not HBM traffic"},
+                "kernels": kernel_rows(per),
+            }
+
+    # ---------------------------------------------------------------- reverse mode on the same workload (rank 0, N = 1)
+    def backward_leg(scene, h, gd, n_pixels, reps):
+        """ms per psdr_hip_render_d_bwd with adjoints of EVERYTHING in the snapshot wanted (no mesh filter, colours and emitters
+        included) - what loss.backward() costs before the host chain rule; all three terms and each term alone"""
+        snap = scene._snapshot()
+        cam = scene.param_map["Sensor[0]"]
+        n_tri, n_sec = int(snap["triangles"].shape[0]), int(snap["sec_edges"].shape[0])
+        n_prim = int(np.asarray(cam._primary_edge_ids()).reshape(-1, 3).shape[0])
+        pm = scene.param_map
+        nb_ = sum(1 for k in pm if k.startswith("BSDF[") and not k.startswith("BSDF[id="))
+        ne_ = sum(1 for k in pm if k.startswith("Emitter[") and not k.startswith("Emitter[id="))
+        g_tri = torch.zeros((n_tri, 22), device="cuda")
+        g_b, g_e = torch.zeros((max(1, nb_), 3), device="cuda"), torch.zeros((max(1, ne_), 3), device="cuda")
+        g_s, g_p = torch.zeros((max(1, n_sec), 6), device="cuda"), torch.zeros((max(1, n_prim), 4), device="cuda")
+        w = torch.ones((n_pixels, 3), device="cuda")            # d loss / d image
+        g = cabi.Grads(g_tri.data_ptr(), g_b.data_ptr(), g_e.data_ptr(), g_s.data_ptr(), g_p.data_ptr())
+        res_ = {}
+        for terms, name in ((7, "all"), (1, "interior"), (2, "primary_edges"), (4, "secondary_edges")):
+            def bwd(seed):
+                a = cabi.make_args(max_depth=DEPTH, seeds=(seed, seed, seed), terms=terms, guiding=gd)
+                cabi.check(L.psdr_hip_render_d_bwd(h, C.byref(a), w.data_ptr(), C.byref(g), stream))
+            bwd(99)
+            torch.cuda.synchronize()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for i in range(reps):
+                bwd(i)
+            ev1.record()
+            torch.cuda.synchronize()
+            res_[name] = round(ev0.elapsed_time(ev1) / reps, 4)
+        return {"ms": res_["all"], "ms_per_term": {k: v for k, v in res_.items() if k != "all"},
+                "adjoints": "triangle rows [%d, 22], BSDF colours [%d, 3], emitters [%d, 3], secondary-edge rows [%d, 6], primary-edge rows [%d, 4]; "
+                            "nothing filtered" % (n_tri, nb_, ne_, n_sec, n_prim),
+                "timing": "HIP events on the launch stream around %d psdr_hip_render_d_bwd calls (fresh seeds), d loss / d image = 1" % reps}
+
+    if rank == 0 and n == 1 and not args.no_backward:
+        b = backward_leg(sc, handle, guiding, npx, max(3, args.steps // 4))
+        b["forward_ms"] = round(ms_per_step, 4)
+        out["backward"] = b
+
+    # ---------------------------------------------------------------- the BVH path at BASELINE config 5's size (default run only)
+    if rank == 0 and n == 1 and cfg == 3 and not args.no_config5 and not (args.res or args.spp):
+        import synth
+        c5 = CONFIGS[5]
+        sc5, leaf5 = synth.config5_scene(psdr, c5["res"], c5["spp"])
+        integ5 = psdr.PathTracer(DEPTH)
+        t_g = time.perf_counter()
+        integ5.preprocess_secondary_edges(sc5, 0, GUIDING, 1, 0)
+        torch.cuda.synchronize()
+        t_g = time.perf_counter() - t_g
+        gd5 = integ5._guiding_handle(0) or None
+        psdr.render_d_fwd(integ5, sc5, 0, seed=12345, tangents={leaf5: np.ones(3, np.float32)})
+        h5 = sc5._hip_handle()
+        buf5 = torch.empty((2, c5["res"] * c5["res"], 3), dtype=torch.float32, device="cuda")
+
+        def launch5(seed, terms=7, zero=True):
+            a = cabi.make_args(max_depth=DEPTH, seeds=(seed, seed, seed), terms=terms, zero_output=zero, guiding=gd5)
+            cabi.check(L.psdr_hip_render_d_fwd(h5, C.byref(a), buf5[0].data_ptr(), buf5[1].data_ptr(), stream))
+        launch5(1000)
+        torch.cuda.synchronize()
+        steps5 = 3
+        t5 = time.perf_counter()
+        for i in range(steps5):
+            launch5(i)
+        torch.cuda.synchronize()
+        t5 = (time.perf_counter() - t5) / steps5
+        r5 = bvh_roofline(per_kernel(launch5, h5, buf5, gd5, 2), h5, "config5")
+        out["config5"] = {
+            "workload": "BASELINE config 5 on one GPU: envmap-lit 81 920-triangle mesh + floor (examples/synth.py), 1024 x 512 map, %dx%d PathTracer(%d) renderD "
+                        "d/d(albedo), spp=sppe=sppse=%d, guiding grid %s" % (c5["res"], c5["res"], DEPTH, c5["spp"], GUIDING),
+            "ms_per_step": round(t5 * 1e3, 3), "value": round(c5["res"] * c5["res"] * c5["spp"] / t5 / 1e6, 2), "unit": "Msamples/s", "steps": steps5,
+            "guiding_build_ms": round(t_g * 1e3, 2), "finite": bool(torch.isfinite(buf5).all()), "roofline": r5,
+        }
+        if not args.no_backward:
+            out["config5"]["backward"] = backward_leg(sc5, h5, gd5, c5["res"] * c5["res"], 2)
+        del buf5, sc5
+
+    if use_dist:
+        out["rccl"] = {"backend": backend, "ranks": world, "all_reduce_bytes": int(buf.numel() * 4),
+                       "note": "process group bound with device_id, one all_reduce(sum) of the device buffer per step, destroy_process_group at exit"}
 
     # ---------------------------------------------------------------- the oracle legs (rank 0, N = 1): parity + CPU baseline
     if rank == 0 and n == 1 and not (args.no_cpu_baseline and args.no_parity):
@@ -247,8 +397,11 @@ def main():
         from oracle import oracle as orc
         import scenes                                    # the oracle's neutral description of the same README scene
         orc.build(native=True)                           # -O3 -march=native on this host (bit-identical to the default build)
-        spec = scenes.cbox_scene(res, res, spp, spp, spp, param="light_x")
+        def spec_of(r, k):
+            return scenes.config5_scene(r, r, k, k, k) if cfg == 5 else scenes.cbox_scene(r, r, k, k, k, param="light_x")
+        spec = spec_of(res, spp)
         ref = orc.OracleScene(spec, [0])
+        g_ref = ref.guiding_build(0, GUIDING, nrounds=1, seed=0, max_depth=DEPTH) if cfg == 5 else None
         model, phys, logical = host_cpu()
         orc.set_num_threads(phys)
         n_chunks = (npx * spp + 255) // 256
@@ -260,11 +413,11 @@ def main():
         if k <= 0:
             # shard for the parity check: ~1 s of oracle time
             t = time.perf_counter()
-            ref.render_d(max_depth=DEPTH, seeds=(1, 1, 1), shard_rank=0, shard_count=512)
+            ref.render_d(max_depth=DEPTH, seeds=(1, 1, 1), shard_rank=0, shard_count=512, guiding=g_ref)
             t512 = time.perf_counter() - t
             k = int(min(512, max(1, round(512 * t512 / 1.0))))
         if not args.no_parity:
-            want_img, want_d = ref.render_d(max_depth=DEPTH, seeds=(0, 0, 0), shard_rank=0, shard_count=k)
+            want_img, want_d = ref.render_d(max_depth=DEPTH, seeds=(0, 0, 0), shard_rank=0, shard_count=k, guiding=g_ref)
             launch(0, 7, shard_rank=0, shard_count=k)
             torch.cuda.synchronize()
             got = buf.cpu().numpy()
@@ -281,19 +434,20 @@ def main():
                 ts = []
                 for r in range(runs + 1):                # first run = warm-up
                     t = time.perf_counter()
-                    sref.render_d(max_depth=DEPTH, seeds=(r, r, r))
+                    sref.render_d(max_depth=DEPTH, seeds=(r, r, r), guiding=sref_g.get(id(sref)))
                     ts.append(time.perf_counter() - t)
                 return statistics.median(ts[1:])
-            one = orc.OracleScene(scenes.cbox_scene(res, res, 1, 1, 1, param="light_x"), [0])
+            sref_g = {}
+            one = orc.OracleScene(spec_of(res, 1), [0])
             t = time.perf_counter()
             one.render_d(max_depth=DEPTH, seeds=(9, 9, 9))
             t_one = time.perf_counter() - t
             cspp = int(min(spp, max(1, round(3.0 / max(t_one, 1e-3)))))
-            sref = orc.OracleScene(scenes.cbox_scene(res, res, cspp, cspp, cspp, param="light_x"), [0])
+            sref = orc.OracleScene(spec_of(res, cspp), [0])
             tc = timed(sref, 5)
             orc.set_num_threads(1)
             sres = max(16, res // 8)                      # one thread: the same scene at 1/64 of the pixels, 1 sample each
-            tiny = orc.OracleScene(scenes.cbox_scene(sres, sres, 1, 1, 1, param="light_x"), [0])
+            tiny = orc.OracleScene(spec_of(sres, 1), [0])
             t1 = timed(tiny, 3)
             orc.set_num_threads(phys)
             out["cpu_baseline"] = {
@@ -306,7 +460,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -202,6 +202,10 @@ typedef struct psdr_counters {
     uint64_t rays, nodes_visited, tris_tested, shaded_hits;
 } psdr_counters;
 
+/* Threading / streams: every entry point that launches kernels takes the stream to launch on.  Calls on one stream are ordered by
+ * the stream.  The launches of ONE scene share device scratch (work-queue ring, traversal-stack overflow, adjoint records), so calls
+ * on the same scene from different streams or host threads are serialised by the library: a call first makes its stream wait for
+ * the completion event of the scene's previous call (no host synchronisation).  Different scenes run concurrently. */
 const char *psdr_hip_last_error(void);
 int psdr_hip_abi_version(void);
 int psdr_hip_device_count(void);
@@ -212,6 +216,9 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *snapshot, psdr_hip_scene **
 int psdr_hip_scene_destroy(psdr_hip_scene *scene);
 /* BVH statistics for DESIGN/bench: nodes, leaves, max depth, bytes resident in LDS per workgroup */
 int psdr_hip_scene_stats(const psdr_hip_scene *scene, int32_t *n_nodes, int32_t *n_leaves, int32_t *max_depth, int32_t *lds_bytes);
+/* bytes of one node of the 4-wide BVH this build walks (64: quantised child boxes, csrc/hip/bvh.h) - the unit of the algorithmic
+ * bytes bench.py prices a node visit at */
+int psdr_hip_bvh_node_bytes(void);
 
 /* Scene::ray_intersect<false> for a batch of rays (reference src/scene/scene.cpp:612-806; bound to Python as
  * Scene.unit_ray_intersect, src/psdr.cpp:404).  Device arrays o[n*3], d[n*3] -> out[n*24]:

@@ -768,6 +768,23 @@ def _mesh_index(scene, mesh):
     raise RuntimeError("mesh is not part of the scene")
 
 
+class _intra_op_threads:
+    """caps torch's intra-op thread pool for a block of small CPU tensor work and restores it on every way out"""
+
+    def __init__(self, cap):
+        self.cap = cap
+
+    def __enter__(self):
+        self.n = _torch.get_num_threads()
+        if self.n > self.cap:
+            _torch.set_num_threads(self.cap)
+
+    def __exit__(self, *exc):
+        if self.n > self.cap:
+            _torch.set_num_threads(self.n)
+        return False
+
+
 class _RenderDFn(_torch.autograd.Function):
     """Autograd node of renderD.  forward = primal image; backward = the reverse-mode kernels
     (psdr_hip_render_d_bwd: adjoints of the configured snapshot) followed by the host chain rule of
@@ -882,35 +899,23 @@ class _RenderDFn(_torch.autograd.Function):
 
         # the host chain below works on small float64 CPU tensors: on a many-core host torch's intra-op pool costs more than it
         # computes (measured on the 2 x 64-core box: 9 ms with <= 4 threads, 10-70 ms with the default 128)
-        n_threads = _torch.get_num_threads()
-        if n_threads > 4:
-            _torch.set_num_threads(4)
-        try:
+        grads = [None] * len(leaves)
+        with _intra_op_threads(4):
             with _torch.enable_grad():          # autograd runs backward() with grad mode off
                 tri, sec, prim, refl, rad, cam_tw = chain.snapshot_tensors(scene, st["sensor_id"], leaf_of)
-        except BaseException:
-            _torch.set_num_threads(n_threads)
-            raise
-        g_camera = g_cam.to("cpu", _torch.float64).reshape(4, 4) if g_cam is not None else _torch.zeros((4, 4), dtype=_torch.float64)
-        outs, gos = [], []
-        for o, go in ((tri, g_tri), (sec, g_sec), (prim, g_prim), (refl, g_bsdf), (rad, g_em), (cam_tw, g_camera)):
-            if o.requires_grad and o.numel() > 0:
-                outs.append(o)
-                gos.append(go.reshape(o.shape))
-        grads = [None] * len(leaves)
-        wanted = [(i, fresh.get((id(obj), name))) for i, ((obj, name, t), need) in enumerate(zip(leaves, needs)) if need]
-        wanted = [(i, f) for i, f in wanted if f is not None]
-        if outs and wanted:
-            try:
+            g_camera = g_cam.to("cpu", _torch.float64).reshape(4, 4) if g_cam is not None else _torch.zeros((4, 4), dtype=_torch.float64)
+            outs, gos = [], []
+            for o, go in ((tri, g_tri), (sec, g_sec), (prim, g_prim), (refl, g_bsdf), (rad, g_em), (cam_tw, g_camera)):
+                if o.requires_grad and o.numel() > 0:
+                    outs.append(o)
+                    gos.append(go.reshape(o.shape))
+            wanted = [(i, fresh.get((id(obj), name))) for i, ((obj, name, t), need) in enumerate(zip(leaves, needs)) if need]
+            wanted = [(i, f) for i, f in wanted if f is not None]
+            if outs and wanted:
                 res = _torch.autograd.grad(outs, [f for _, f in wanted], gos, allow_unused=True)
-            finally:
-                if n_threads > 4:
-                    _torch.set_num_threads(n_threads)
-            for (i, f), r in zip(wanted, res):
-                t = leaves[i][2]
-                grads[i] = _torch.zeros_like(t) if r is None else r.reshape(t.shape).to(t.device, t.dtype)
-        elif n_threads > 4:
-            _torch.set_num_threads(n_threads)
+                for (i, f), r in zip(wanted, res):
+                    t = leaves[i][2]
+                    grads[i] = _torch.zeros_like(t) if r is None else r.reshape(t.shape).to(t.device, t.dtype)
         for i in tex_leaves:          # the leaf IS the texel array: its gradient is its block of g_tex
             obj, name, t = leaves[i]
             b = _bsdf_index(scene, obj)

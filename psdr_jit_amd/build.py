@@ -3,9 +3,13 @@
   psdr_jit_amd/lib/libpsdr_hip.so   hipcc --offload-arch=gfx950: the kernels + C ABI (include/psdr_hip.h)
   psdr_jit_amd/_psdr_core*.so        g++ + pybind11: host scene model, links the C ABI
 
-hipcc cross-compiles gfx950 without a GPU.  Rebuilds only when a source is newer than the target.
+hipcc cross-compiles gfx950 without a GPU.  A library is rebuilt when the SHA-256 over its sources, headers and compiler flags
+differs from the signature stored beside it (lib/*.sig) - not by modification times, which do not survive the copy to the GPU
+box - and build_all() checks that the loaded library reports the ABI version of include/psdr_hip.h.
 """
+import hashlib
 import os
+import re
 import subprocess
 import sys
 import sysconfig
@@ -28,11 +32,31 @@ HOST_DEPS = [os.path.join(CSRC, "host", f) for f in ("scene_host.h", "hnum.h", "
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-slp-vectorize"]
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
+def _signature(files, flags):
+    h = hashlib.sha256()
+    for f in sorted(files):
+        h.update(os.path.relpath(f, ROOT).encode())
+        with open(f, "rb") as fh:
+            h.update(hashlib.sha256(fh.read()).digest())
+    h.update(("\0".join(flags)).encode())
+    return h.hexdigest()
+
+
+def _sig_path(target):
+    return os.path.join(LIBDIR, os.path.basename(target) + ".sig")
+
+
+def _stale(target, deps, flags=()):
+    """True when `target` is missing or was built from other sources / with other flags than `deps` / `flags`"""
+    if not os.path.exists(target) or not os.path.exists(_sig_path(target)):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(_sig_path(target)) as fh:
+        return fh.read().strip() != _signature(deps, flags)
+
+
+def _stamp(target, deps, flags=()):
+    with open(_sig_path(target), "w") as fh:
+        fh.write(_signature(deps, flags) + "\n")
 
 
 def _run(cmd):
@@ -51,14 +75,18 @@ def build_hip(force=False, extra_flags=()):
     that only instantiate the heavy kernel templates of one scene class (-DPSDR_TU=k) - and linked into one library: ~4 minutes of
     wall time instead of ~10 for the single unit (PSDR_BUILD_JOBS=1 compiles them one after the other)."""
     os.makedirs(LIBDIR, exist_ok=True)
-    if force or _stale(HIP_LIB, HIP_SRCS + HIP_DEPS):
+    flags = [f for f in HIP_FLAGS if f != "-shared"] + list(extra_flags)
+    if force or _stale(HIP_LIB, HIP_SRCS + HIP_DEPS, flags):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         objdir = os.path.join(LIBDIR, "obj")
         os.makedirs(objdir, exist_ok=True)
-        flags = [f for f in HIP_FLAGS if f != "-shared"] + list(extra_flags)
         units = [("main", ["-DPSDR_SPLIT"])] + [("tu%d" % k, ["-DPSDR_TU=%d" % k]) for k in range(1, N_KERNEL_UNITS + 1)]
         jobs = max(1, int(os.environ.get("PSDR_BUILD_JOBS", str(min(len(units), os.cpu_count() or 1)))))
         objs, pending, running = [], list(units), []
+        for name, _d in units:                           # objects of an earlier (possibly failed, possibly differently flagged) build never get linked
+            obj = os.path.join(objdir, "api_%s.o" % name)
+            if os.path.exists(obj):
+                os.remove(obj)
         while pending or running:
             while pending and len(running) < jobs:
                 name, defs = pending.pop(0)
@@ -71,25 +99,54 @@ def build_hip(force=False, extra_flags=()):
             if proc.returncode != 0:
                 for q, _c in running:
                     q.kill()
+                    q.wait()
+                for o in objs:
+                    if os.path.exists(o):
+                        os.remove(o)
                 sys.stderr.write(out)
                 raise RuntimeError("build failed: " + " ".join(cmd))
-        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", HIP_LIB])
+        arch = [f for f in flags if f.startswith("--offload-arch")]
+        _run([hipcc] + arch + ["-shared", "-fPIC"] + objs + ["-o", HIP_LIB])
+        _stamp(HIP_LIB, HIP_SRCS + HIP_DEPS, flags)
     return HIP_LIB
 
 
-def build_core(force=False):
-    build_hip()
-    if force or _stale(CORE_LIB, HOST_SRCS + HOST_DEPS + [HIP_LIB]):
+CORE_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-fopenmp"]
+
+
+def build_core(force=False, hip_flags=()):
+    build_hip(extra_flags=hip_flags)
+    deps = HOST_SRCS + HOST_DEPS
+    if force or _stale(CORE_LIB, deps, CORE_FLAGS):
         import pybind11
         inc = ["-I" + sysconfig.get_paths()["include"], "-I" + pybind11.get_include()]
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-fopenmp"] + inc + HOST_SRCS +
-             ["-o", CORE_LIB, "-L" + LIBDIR, "-lpsdr_hip", "-Wl,-rpath,$ORIGIN/lib"])
+        _run(["g++"] + CORE_FLAGS + inc + HOST_SRCS + ["-o", CORE_LIB, "-L" + LIBDIR, "-lpsdr_hip", "-Wl,-rpath,$ORIGIN/lib"])
+        _stamp(CORE_LIB, deps, CORE_FLAGS)
     return CORE_LIB
 
 
-def build_all(force=False):
-    build_hip(force)
-    build_core(force)
+def header_abi_version():
+    with open(os.path.join(ROOT, "include", "psdr_hip.h")) as fh:
+        m = re.search(r"#define\s+PSDR_HIP_ABI_VERSION\s+(\d+)", fh.read())
+    return int(m.group(1))
+
+
+def check_abi():
+    """the library that will be loaded is the one this tree's header describes"""
+    import ctypes
+    L = ctypes.CDLL(HIP_LIB)
+    got, want = int(L.psdr_hip_abi_version()), header_abi_version()
+    if got != want:
+        raise RuntimeError("libpsdr_hip.so reports ABI version %d, include/psdr_hip.h says %d: stale binary" % (got, want))
+
+
+def build_all(force=False, hip_flags=None):
+    """hip_flags: extra hipcc flags (development builds, e.g. -DPSDR_CLS_MASK=4); default: $PSDR_HIP_FLAGS split on blanks"""
+    if hip_flags is None:
+        hip_flags = tuple(os.environ.get("PSDR_HIP_FLAGS", "").split())
+    build_hip(force, extra_flags=hip_flags)
+    build_core(force, hip_flags=hip_flags)
+    check_abi()
     return HIP_LIB, CORE_LIB
 
 

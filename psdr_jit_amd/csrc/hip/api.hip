@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -565,6 +566,15 @@ struct psdr_hip_scene {
     DevBuf hot_map, hot_inv;             // adjoint accumulators kept in LDS: emitter triangles first, then by area (adjoint.h)
     int n_hot = 0;
     std::vector<long long> tex_layout;   // [3*n_bsdfs] offsets into g_tex, -1 = constant
+    // The launches of one scene share mutable device scratch - the work-queue ring, the counters, the traversal-stack overflow
+    // `gstack` (indexed by workgroup and thread only) and the adjoint records `adj_rec` (re-allocated when they grow) - while the C
+    // ABI takes a stream per call.  They are therefore SERIALISED ACROSS STREAMS (ScratchGuard below): a call on another stream than
+    // the scene's previous one first makes its stream wait for that call's completion event; calls on one stream order themselves.
+    mutable std::mutex mu;
+    mutable hipEvent_t ev = nullptr;
+    mutable hipStream_t last_stream = nullptr;
+    mutable bool have_last = false;
+    ~psdr_hip_scene() { if (ev) (void) hipEventDestroy(ev); }
     const float *up(const float *src, size_t n, int &rc) {
         if (!src) return nullptr;
         bufs.emplace_back(new DevBuf());
@@ -578,6 +588,23 @@ struct psdr_hip_scene {
         return bufs.back()->as<uint8_t>();
     }
 };
+
+// one in-flight user of a scene's scratch buffers per stream order (see psdr_hip_scene::mu)
+struct ScratchGuard {
+    const psdr_hip_scene *sc;
+    hipStream_t st;
+    hipError_t err = hipSuccess;
+    ScratchGuard(const psdr_hip_scene *s, void *stream) : sc(s), st((hipStream_t) stream) {
+        sc->mu.lock();
+        if (!sc->ev) err = hipEventCreateWithFlags(&sc->ev, hipEventDisableTiming);
+        if (err == hipSuccess && sc->have_last && sc->last_stream != st) err = hipStreamWaitEvent(st, sc->ev, 0);
+    }
+    ~ScratchGuard() {
+        if (sc->ev && hipEventRecord(sc->ev, st) == hipSuccess) { sc->last_stream = st; sc->have_last = true; }
+        sc->mu.unlock();
+    }
+};
+#define SCRATCH_GUARD(sc, stream) ScratchGuard guard_((sc), (stream)); if (guard_.err != hipSuccess) return fail(std::string("scene scratch serialisation: ") + hipGetErrorString(guard_.err))
 
 struct psdr_hip_guiding {
     GuidingDev G{};
@@ -615,7 +642,7 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     const bool has_tan = tr.d_p0 != nullptr;
     SceneTables &T = sc->T;
     size_t w = 0;
-    T.nodes_off = (int) w; w += 8 * (size_t) bvh4.n_nodes;      // 128-byte nodes of the 4-wide tree (bvh.h)
+    T.nodes_off = (int) w; w += (size_t) (kNodeFloats / 4) * (size_t) bvh4.n_nodes;      // nodes of the 4-wide tree (bvh.h: 64 bytes each)
     T.trav_off = (int) w;  w += 3 * (size_t) n;
     T.shade_off = (int) w; w += 6 * (size_t) n;
     T.tan_off = (int) w;   w += has_tan ? 6 * (size_t) n : 0;
@@ -788,7 +815,7 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     T.ref_bits = bvh4.ref_bits;
     // traversal stack: the first kStackLds entries of a lane in LDS, deeper ones in a per-lane global array (trav4.h);
     // scenes that are traced by brute force (<= kBruteForceMax triangles) need neither
-    static const int kStackLds = std::getenv("PSDR_STACK_LDS") ? std::atoi(std::getenv("PSDR_STACK_LDS")) : 12;
+    static const int kStackLds = std::getenv("PSDR_STACK_LDS") ? std::atoi(std::getenv("PSDR_STACK_LDS")) : 8;      // 8 + kTravRows = 40 KB per workgroup: four workgroups per CU
     const bool uses_bvh = n > kBruteForceMax;
     T.stack_lds = uses_bvh ? std::min(kStackLds, bvh4.max_stack) : 0;
 #ifdef PSDR_NO_ASYNC
@@ -951,6 +978,7 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
 }
 
 int psdr_hip_scene_destroy(psdr_hip_scene *scene) { delete scene; return 0; }
+int psdr_hip_bvh_node_bytes(void) { return kNodeFloats * 4; }
 
 int psdr_hip_scene_stats(const psdr_hip_scene *sc, int32_t *n_nodes, int32_t *n_leaves, int32_t *max_depth, int32_t *lds_bytes) {
     if (!sc) return fail("null scene");
@@ -1036,6 +1064,7 @@ template <bool COUNT>
 static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool ad, float *out, float *dout, float *lanes_out,
                        long long lane_b, long long lane_e, psdr_counters *counters, void *stream) {
     if (check_args(sc, a)) return 1;
+    SCRATCH_GUARD(sc, stream);
     const SceneTables &T = sc->T;
     hipStream_t st = (hipStream_t) stream;
     const long long npx = a->pix_ids ? a->n_pix : (long long) T.width * T.height;
@@ -1159,6 +1188,7 @@ int psdr_hip_scene_tex_layout(const psdr_hip_scene *sc, int64_t *offsets, int64_
 int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, const float *d_rgb, const psdr_grads *g, void *stream) {
     if (check_args(sc, a)) return 1;
     if (!d_rgb || !g || !g->g_triangles || !g->g_bsdf || !g->g_emitter) return fail("null gradient buffer");
+    SCRATCH_GUARD(sc, stream);
     // batch rendering (integrator.cpp:139-176): d_rgb is [n_pix*3]; only the interior term exists for a pixel list (as in the forward path)
     const SceneTables &T = sc->T;
     hipStream_t st = (hipStream_t) stream;
@@ -1267,6 +1297,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
             if (!rec_in_lds) {
                 const size_t need = sizeof(float) * (size_t) grid * (size_t) lane_words * kBlock;
                 if (need > sc->adj_rec_bytes) {
+                    // (every earlier user of the records was ordered before this stream by the guard: its completion is this stream's)
                     if (sc->adj_rec.p) { HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipFree(sc->adj_rec.p)); sc->adj_rec.p = nullptr; sc->adj_rec_bytes = 0; }
                     if (sc->adj_rec.upload(nullptr, need)) return 1;
                     sc->adj_rec_bytes = need;
@@ -1322,6 +1353,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
 static int trace_impl(const psdr_hip_scene *sc, int32_t n, const float *o, const float *d, int32_t *out_tri, float *out_uv, float *out_t, void *stream, int pairs) {
     if (!sc) return fail("null scene");
     if (n <= 0) return 0;
+    SCRATCH_GUARD(sc, stream);
     if (sc->lds) ON_CLS1(LAUNCH((k_trace<true>), sc, (long long) n, stream, sc->blob.as<float4>(), sc->T, n, o, d, out_tri, out_uv, out_t, pairs));
     else LAUNCH((k_trace<false>), sc, (long long) n, stream, sc->blob.as<float4>(), sc->T, n, o, d, out_tri, out_uv, out_t, pairs);
     HIPCHK(hipGetLastError());
@@ -1366,6 +1398,7 @@ int psdr_hip_ray_intersect(const psdr_hip_scene *sc, int32_t n, const float *o, 
     if (!sc) return fail("null scene");
     if (n <= 0) return 0;
     if (!o || !d || !out) return fail("null ray / output buffer");
+    SCRATCH_GUARD(sc, stream);
     if (sc->lds) LAUNCH((k_intersect<true>), sc, (long long) n, stream, sc->blob.as<float4>(), sc->T, n, o, d, out);
     else LAUNCH((k_intersect<false>), sc, (long long) n, stream, sc->blob.as<float4>(), sc->T, n, o, d, out);
     HIPCHK(hipGetLastError());
@@ -1391,6 +1424,7 @@ int psdr_hip_guiding_build(const psdr_hip_scene *sc, int32_t sensor_id, int32_t 
     GuidingDev &G = g->G;
     for (int k = 0; k < 3; ++k) { G.reso[k] = reso[k]; G.unit[k] = 1.f / (float) reso[k]; }
     G.num_cells = (int) cells;
+    SCRATCH_GUARD(sc, stream);
     hipStream_t st = (hipStream_t) stream;
     DevBuf mass;
     if (mass.upload(nullptr, sizeof(float) * cells)) return 1;

@@ -48,7 +48,8 @@ inline int32_t float_bits(int32_t v) { return v; }
 inline void build_bvh(const float *p0, const float *e1, const float *e2, int n, BvhResult &out) {
     using namespace bvh_detail;
     constexpr int kBins = 16;
-    static const int kLeafMax = std::getenv("PSDR_BVH_LEAF") ? std::max(1, std::min(4, std::atoi(std::getenv("PSDR_BVH_LEAF")))) : 2;     // triangles per leaf (1..4); measured with the triangle ring: 1: +15 %, 2: -1.5 %, 4: 0
+    // triangles per leaf: 1 or 2 (measured with the triangle ring: 1: +15 %, 2: -1.5 %, 4: 0; the pair ring of trav4.h is sized for leaves of <= 2)
+    static const int kLeafMax = std::getenv("PSDR_BVH_LEAF") ? std::max(1, std::min(2, std::atoi(std::getenv("PSDR_BVH_LEAF")))) : 2;
     std::vector<Box> tb(n);
     std::vector<float> ctr(3 * (size_t) n);
     out.order.resize(n);
@@ -162,14 +163,27 @@ inline void build_bvh(const float *p0, const float *e1, const float *e2, int n, 
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // 4-wide BVH for the device traversal (trav4.h): the binary SAH tree above with up to two levels collapsed into one node
-// (the child with the largest surface area is opened first).  One node = 128 bytes = 8 float4 words = one L2 line:
-//   w0 lo.x[4]  w1 lo.y[4]  w2 lo.z[4]  w3 hi.x[4]  w4 hi.y[4]  w5 hi.z[4]  w6 code[4]  w7 unused
-// code of a child: inner node -> its index; leaf -> leaf_bit | (first_triangle << 2 | count - 1); an unused child slot carries
-// a box at +3e38 on every axis, which no ray can reach.  code < 2^ref_bits, so the traversal packs (coarse entry distance |
-// code) into ONE 32-bit sort key (trav4.h).  max_stack bounds the traversal stack of any ray (sum over a root-to-leaf path
-// of the siblings left behind).
+// (the child with the largest surface area is opened first).
+//
+// One node = 64 bytes = 4 float4 words (round 3; two nodes per 128-byte L2 line, four 16-byte loads per step):
+//   w0  origin.xyz (the lower corner of the union of the children's boxes), bits(ex | ey << 8 | ez << 16): biased exponents,
+//       the grid step along axis a is 2^(e_a - 127)
+//   w1  lo.x[4] lo.y[4] lo.z[4] hi.x[4]      one byte per child: lo = origin + step * q rounded DOWN, hi rounded UP - the
+//   w2  hi.y[4] hi.z[4] code[0] code[1]      quantised box contains the (padded) float box, so the traversal visits a superset
+//   w3  code[2] code[3] 0 0                  and the hit, defined by the exact triangle test alone, is unchanged
+// With -DPSDR_NODE128 (measurement knob) the node is round 2's 128 bytes = 8 words: lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4]
+// code[4] unused, boxes as floats.
+// code of a child: inner node -> its index; leaf -> leaf_bit | (first_triangle << 2 | count - 1); an unused child slot has code
+// 0xffffffff (and an inverted / unreachable box).  code < 2^ref_bits, so the traversal packs (coarse entry distance | code) into
+// ONE 32-bit sort key (trav4.h).  max_stack bounds the traversal stack of any ray (sum over a root-to-leaf path of the siblings
+// left behind).
+#ifdef PSDR_NODE128
+constexpr int kNodeFloats = 32;
+#else
+constexpr int kNodeFloats = 16;
+#endif
 struct Bvh4Result {
-    std::vector<float> nodes;      // 32 floats per node
+    std::vector<float> nodes;      // kNodeFloats per node
     int32_t n_nodes = 0, max_depth = 0, max_stack = 0, ref_bits = 0;
     uint32_t leaf_bit = 0;
 };
@@ -193,7 +207,7 @@ inline void build_bvh4(const BvhResult &b2, int n_tris, Bvh4Result &out) {
     std::vector<int> need;          // stack need below each emitted node (filled bottom-up afterwards)
     std::vector<std::vector<int>> kids;   // per node4: child node4 indices (inner children only)
     out.nodes.clear();
-    auto new_node = [&]() { out.nodes.resize(out.nodes.size() + 32, 0.f); kids.emplace_back(); return (int) (out.nodes.size() / 32) - 1; };
+    auto new_node = [&]() { out.nodes.resize(out.nodes.size() + kNodeFloats, 0.f); kids.emplace_back(); return (int) (out.nodes.size() / kNodeFloats) - 1; };
     std::vector<int> n_children;
     if (nt == 0) { out.n_nodes = 0; return; }
     const int root = new_node();
@@ -215,6 +229,8 @@ inline void build_bvh4(const BvhResult &b2, int n_tris, Bvh4Result &out) {
             list.push_back(b2.tmp_right[t]);
         }
         n_children[it.node4] = (int) list.size();
+        uint32_t codes[4];
+        float los[4][3], his[4][3];
         for (int k = 0; k < 4; ++k) {
             uint32_t code = 0xffffffffu;
             float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {3e38f, 3e38f, 3e38f};
@@ -230,12 +246,56 @@ inline void build_bvh4(const BvhResult &b2, int n_tris, Bvh4Result &out) {
                     todo.push_back({t, c, it.depth + 1});
                 }
             }
-            float *q = &out.nodes[32 * (size_t) it.node4];
-            for (int a = 0; a < 3; ++a) { q[4 * a + k] = lo[a]; q[12 + 4 * a + k] = hi[a]; }
-            std::memcpy(&q[24 + k], &code, 4);
+            codes[k] = code;
+            for (int a = 0; a < 3; ++a) { los[k][a] = lo[a]; his[k][a] = hi[a]; }
         }
+        float *q = &out.nodes[(size_t) kNodeFloats * (size_t) it.node4];
+#ifdef PSDR_NODE128
+        for (int k = 0; k < 4; ++k) {
+            for (int a = 0; a < 3; ++a) { q[4 * a + k] = los[k][a]; q[12 + 4 * a + k] = his[k][a]; }
+            std::memcpy(&q[24 + k], &codes[k], 4);
+        }
+#else
+        {
+            const int nc = (int) list.size();
+            double org[3], ext[3];
+            for (int a = 0; a < 3; ++a) {
+                double mn = los[0][a], mx = his[0][a];
+                for (int k = 1; k < nc; ++k) { mn = std::min(mn, (double) los[k][a]); mx = std::max(mx, (double) his[k][a]); }
+                org[a] = mn; ext[a] = mx - mn;
+            }
+            uint32_t exps = 0, qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+            for (int a = 0; a < 3; ++a) {
+                // smallest power of two with extent / step <= 255 (checked on the rounded-up upper bounds below)
+                int e = ext[a] > 0.0 ? (int) std::ceil(std::log2(ext[a] / 255.0)) : 0;
+                e = std::max(-126, std::min(127, e));
+                for (;;) {
+                    const double step = std::ldexp(1.0, e);
+                    bool ok = true;
+                    for (int k = 0; k < nc && ok; ++k) ok = std::ceil(((double) his[k][a] - org[a]) / step) <= 255.0;
+                    if (ok || e >= 127) break;
+                    ++e;
+                }
+                const double step = std::ldexp(1.0, e);
+                exps |= (uint32_t) (e + 127) << (8 * a);
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t l = 255u, h = 0u;          // unused child: inverted box (and code 0xffffffff, which the traversal checks)
+                    if (k < nc) {
+                        l = (uint32_t) std::max(0.0, std::min(255.0, std::floor(((double) los[k][a] - org[a]) / step)));
+                        h = (uint32_t) std::max(0.0, std::min(255.0, std::ceil(((double) his[k][a] - org[a]) / step)));
+                    }
+                    qlo[a] |= l << (8 * k); qhi[a] |= h << (8 * k);
+                }
+            }
+            const float o3[3] = {(float) org[0], (float) org[1], (float) org[2]};     // exact: org is one of the float bounds
+            q[0] = o3[0]; q[1] = o3[1]; q[2] = o3[2]; std::memcpy(&q[3], &exps, 4);
+            std::memcpy(&q[4], &qlo[0], 4); std::memcpy(&q[5], &qlo[1], 4); std::memcpy(&q[6], &qlo[2], 4); std::memcpy(&q[7], &qhi[0], 4);
+            std::memcpy(&q[8], &qhi[1], 4); std::memcpy(&q[9], &qhi[2], 4); std::memcpy(&q[10], &codes[0], 4); std::memcpy(&q[11], &codes[1], 4);
+            std::memcpy(&q[12], &codes[2], 4); std::memcpy(&q[13], &codes[3], 4);
+        }
+#endif
     }
-    out.n_nodes = (int) (out.nodes.size() / 32);
+    out.n_nodes = (int) (out.nodes.size() / kNodeFloats);
     out.max_depth = max_depth;
     // stack need: children are emitted after their parent, so a reverse sweep sees every child before its parent
     need.assign(out.n_nodes, 0);

@@ -323,12 +323,13 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
 // its slowest ray at every path vertex, and with rays of 10 to 200 traversal steps most lanes idle (measured on the 82 k-
 // triangle scene of BASELINE config 5: 13 % of the lanes active per VALU instruction, 25 % on the 652-triangle tutorial box).
 // Here a lane is in one of two conditions:
-//     in flight - its rays are in the resumable traversal (trav4.h), or
+//     in flight - its vertex's rays are in the wave's ray queue / being walked (trav4.h), or
 //     ready     - it has hits to consume, a new sample to fetch, and rays to generate.
-// The wave alternates between a TRAVERSAL phase that runs until kShadeMin lanes have finished their rays and a SHADING phase
-// in which only the ready lanes consume their hits, regenerate and post their next two rays, while the lanes still in flight
-// keep their place in the tree (their traversal state sits in registers, their rays in LDS).  Finished lanes are thus
-// refilled per traversal, not per path vertex.  The order of a lane's operations - and of its sampler draws - is unchanged:
+// The wave alternates between a TRAVERSAL phase that runs until kShadeMin lanes have their rays back and a SHADING phase
+// in which only the ready lanes consume their hits, regenerate and post their next two rays.  In the traversal phase every lane
+// is a WORKER that pulls rays from the wave's queue - its own or anybody's (round 3; round 2 traced a lane's two rays in that
+// lane, one after the other, and a lane whose rays were finished idled until the shading phase) - and a walk in progress stays in
+// the worker's registers across shading phases.  The order of a lane's operations - and of its sampler draws - is unchanged:
 // [consume hits of vertex k] [path end -> next sample] [draw + post the rays of vertex k+1].
 #ifndef PSDR_SHADE_MIN
 #define PSDR_SHADE_MIN 44
@@ -368,8 +369,9 @@ PSDR_DEV void run_paths_async(SceneView<LDS> &S, const SensorDev &cam, const Pat
     PositionSample<AD> ps;
     V wod(R(0.f)); R dist_sqr(0.f), dist(0.f);
     BSDFSample bs; bs.wo = Vec3f(0.f, 0.f, 1.f); bs.pdf = 1.f; bs.valid = true;
-    Trav4 tr;
+    Trav4 tr;                             // this lane as a traversal WORKER: the ray it walks may belong to any lane of the wave (trav4.h)
     tr.reset();
+    int posted = 0;                       // this lane as an OWNER: which of its vertex's two rays are in the wave's queue
 
     for (;;) {
         const unsigned long long m_fly = __ballot(inflight);
@@ -385,7 +387,11 @@ PSDR_DEV void run_paths_async(SceneView<LDS> &S, const SensorDev &cam, const Pat
             bool finished = false;
             if (ready && has_hits) {
                 has_hits = false;
-                const Hit h = tr.hA, hx = tr.hB;
+                Hit h, hx;
+                h.slot = -1; h.u = h.v = h.t = 0.f; hx = h;
+                if (posted & 1) h = t4_result(S, 0);
+                if (posted & 2) hx = t4_result(S, 1);
+                posted = 0;
                 RayT<AD> ray1; ray1.o = its.p; ray1.d = wod;
                 if (do_nee && h.slot >= 0) {
 #if !PSDR_DIAG
@@ -587,7 +593,7 @@ PSDR_DEV void run_paths_async(SceneView<LDS> &S, const SensorDev &cam, const Pat
                 ext_traced = bs.valid;
                 // the emitter sample only counts when the shadow ray's closest hit lies at the sample (t > dist - ShadowEpsilon): any hit
                 // clearly in front of it settles that, so the shadow ray stops at the first such hit instead of looking for the closest
-                t4_post(S, tr, detach(its.p), detach(wod), do_nee, detach(ext.o), detach(ext.d), ext_traced, do_nee ? (detach(dist) - kShadowEpsilon) * 0.9999f : -__builtin_inff());
+                posted = t4_post(S, detach(its.p), detach(wod), do_nee, detach(ext.o), detach(ext.d), ext_traced, do_nee ? (detach(dist) - kShadowEpsilon) * 0.9999f : -__builtin_inff());
                 inflight = true;
             }
             if (__ballot(busy || inflight) == 0ull && exhausted && q_next >= q_end) break;
@@ -597,8 +603,8 @@ PSDR_DEV void run_paths_async(SceneView<LDS> &S, const SensorDev &cam, const Pat
             const int n_fly = __popcll(__ballot(inflight));
             if (n_fly > 0) {
                 const int want_new = n_fly < 2 * kShadeMin ? (n_fly + 1) / 2 : kShadeMin;
-                trav4_run<LDS, COUNT>(S, tr, n_fly - want_new);
-                if (inflight && tr.idle()) { inflight = false; has_hits = true; }
+                const bool mine_done = trav4_run<LDS, COUNT>(S, tr, inflight ? posted : 0, n_fly - want_new);
+                if (inflight && mine_done) { inflight = false; has_hits = true; }
             }
         }
     }

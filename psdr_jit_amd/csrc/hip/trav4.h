@@ -5,49 +5,54 @@
 // triangle, smallest t in (RayEpsilon, 1e8), ties to the smallest original triangle id.  The boxes are padded and
 // the slab test is conservative, so the tree only decides which triangles are looked at.
 //
-// One step = one 128-byte node: four slab tests, then the (up to four) children that are hit are ordered with a
-// five-comparator sorting network on ONE 32-bit key per child,
+// LANES ARE TRAVERSAL WORKERS, RAYS ARE WORK ITEMS (round 3).  A lane that owns a path vertex POSTS its (up to two) rays - the
+// next-event ray and the extension ray - into LDS: the ray itself, an empty best-hit record and an entry in the wave's RAY
+// QUEUE.  Any lane of the wave without a ray in hand pulls the next ray from that queue, walks it, and when the walk ends
+// publishes the ray as finished and pulls another one - it neither waits for its own path's other ray nor for the shading of
+// the paths that are already complete (round 2 traced a lane's two rays one after the other IN that lane: a third of the lanes
+// of the node loop sat on finished rays, waiting for the shading threshold).  An owner's vertex is complete when both of its rays
+// are; `trav4_run` returns when at most a wanted number of owners is still incomplete, and the path kernels (paths.h,
+// run_paths_async) shade the complete ones while the workers keep their place in the tree.
+//
+// One step = one node (64 bytes, bvh.h: the children's boxes quantised to 8 bits inside the node's own box): four 16-byte loads,
+// four slab tests, then the (up to four) children that are hit are ordered with a five-comparator sorting network on ONE 32-bit
+// key per child,
 //        key = (bits of the entry distance, low `ref_bits` bits cleared) | child code,
-// (entry distances are >= 0, so their float bits order like unsigned integers; a missed child is 0xffffffff).  The
-// nearest child is visited next, the others go on the per-lane stack with the far ones below, and a popped key is
-// dropped when its (rounded-down) entry distance lies behind the closest hit found meanwhile.
+// (entry distances are >= 0, so their float bits order like unsigned integers; a missed child is 0xffffffff).  The nearest child
+// is visited next, the others go on the worker's stack with the far ones below, and a popped key is dropped when its
+// (rounded-down) entry distance lies behind the closest hit found meanwhile.
 //
-// The traversal is RESUMABLE: its state lives in `Trav4`, and `trav4_run` returns when a wanted number of lanes of
-// the wave has finished its rays.  The path kernels (paths.h, run_paths_async) use this to shade the finished lanes and
-// hand them new rays while the other lanes keep their place in the tree - finished lanes no longer wait for the
-// slowest ray of the wave (config 5 ran with 13 % of the lanes active per VALU instruction when they did).
-// Each lane owns a queue of up to two rays (the next-event ray and the extension ray of one path vertex).
+// THE WAVE TESTS THE TRIANGLES.  A worker that reaches a leaf only ENQUEUES (triangle, ray) pairs in a per-wave LDS ring and goes
+// on to its next node; whenever the ring holds a wave's worth of pairs every lane tests ONE pair - anybody's: the ray comes from
+// its parked copy, the result goes back with one 64-bit LDS atomic min on (bits of t << 32 | original triangle id), which IS the
+// (t, id) order that defines the hit, and the lane that holds the minimum after the batch writes (slot, u, v).  A ray is finished
+// when its walk has ended and its last pair has been tested.
 //
-// Stack: the first T.stack_lds entries of a lane are in LDS (stride kBlock, conflict-free), deeper entries - rare -
+// Stack: the first T.stack_lds entries of a worker are in LDS (stride kBlock, conflict-free), deeper entries - rare -
 // in a per-lane global array (T.gstack), so the LDS footprint does not grow with the depth of the tree.
 #pragma once
 #include "scene_dev.h"
 
 namespace psdr {
 
-constexpr unsigned kT4Done = 0xffffffffu;      // Trav4::code: no node in hand, the current ray is finished (or there is none)
-constexpr unsigned kT4Miss = 0xffffffffu;      // sort key of a child the ray does not enter
+constexpr unsigned kT4Done = 0xffffffffu;      // Trav4::code: no node in hand (walk finished, or no ray)
+constexpr unsigned kT4Miss = 0xffffffffu;      // sort key of a child the ray does not enter / code of an unused child slot
 
-// ---- wave-level triangle queue -------------------------------------------------------------------------------------------
-// A ray visits ~3 leaves of up to four triangles, and the exact triangle test (a division, five comparisons) is more than half
-// of the traversal's arithmetic.  Tested inside the per-lane loop, the lanes that hold a leaf make every other lane wait
-// (and wait themselves while the others walk inner nodes).  So a lane that reaches a leaf only ENQUEUES (triangle, lane)
-// pairs in a per-wave LDS ring and goes on to its next node; whenever the ring holds a wave's worth of pairs all lanes
-// test one pair each - any lane tests any lane's triangle: the ray comes from the owner's parked ray in LDS, the result goes
-// back with one 64-bit LDS atomic min on (bits of t, original triangle id), which is exactly the (t, id) order that defines
-// the hit.  The owner's node tests read the t half for culling.  When a ray's stack is empty and its last pair has been
-// tested, the owner rebuilds (slot, u, v) of the winning triangle with one more exact test.
-//
-// LDS rows (of kBlock words) behind the traversal stack, per workgroup (scene_dev.h::kTravRows):
-//   kParkWords rows  parked rays   [word][lane]           oA dA oB dB of every lane (written by whoever posts the rays)
-//   2 rows           best          [wave][lane] x u64     (t bits << 32 | original id) of the ray the lane is tracing
-//   kQueueRows rows  pair ring     [wave][kQueueCap]      (slot << 7 | ray << 6 | owner lane)
-//   1 row            ring heads    [wave][2]              pairs enqueued / pairs tested so far
-//   3 rows           hit           [word][lane]           slot, u, v of the pair that currently holds `best`
-constexpr int kQueueCap = 512;                 // power of two >= 63 left over + 64 lanes x 4 triangles
-constexpr int kQueueRows = (4 * kQueueCap + kBlock - 1) / kBlock;
-constexpr int kHitRows = 3;                    // (slot, u, v) of the best hit so far, written by the lane that found it
-static_assert(kTravRows == kParkWords + 2 + kQueueRows + 1 + kHitRows, "scene_dev.h::kTravRows");
+// LDS rows (of kBlock words) behind the traversal stack, per workgroup of four waves (scene_dev.h::kTravRows):
+//   kParkWords rows  parked rays   [word][lane]            oA dA oB dB + the any-hit distance of ray A, written by the owner
+//   4 rows           best          [wave][kRayCap] x u64   (t bits << 32 | original id) per ray
+//   6 rows           hit           [word][wave][kRayCap]   slot, u, v of the pair that currently holds `best`
+//   2 rows           fin           [wave][kRayCap]         0 = walk not finished; else 1 + sequence number after the ray's last pair
+//   kPairRows rows   pair ring     [wave][kPairCap]        (slot << 7 | ray)
+//   2 rows           ray queue     [wave][kRayCap]         rays posted and not yet taken by a worker
+//   1 row            heads         [wave][4]               pairs enqueued, pairs tested, rays posted, rays taken
+constexpr int kRayCap = 128;                   // rays of a wave: two per lane; ray id = k * 64 + owner lane (k = 0: next-event ray, 1: extension ray)
+constexpr int kPairCap = 256;                  // power of two >= 63 left over + 64 workers x 2 triangles per leaf (bvh.h: leaves of <= 2)
+constexpr int kPairRows = (4 * kPairCap + kBlock - 1) / kBlock;
+constexpr int kRowBest = kParkWords, kRowHit = kRowBest + 4, kRowFin = kRowHit + 6, kRowPair = kRowFin + 2, kRowRq = kRowPair + kPairRows, kRowHeads = kRowRq + 2;
+static_assert(kTravRows == kRowHeads + 1, "scene_dev.h::kTravRows");
+static_assert(kParkWords == 13, "scene_dev.h::kParkWords");
+enum { kHdPairEnq = 0, kHdPairTested = 1, kHdRayTail = 2, kHdRayHead = 3 };
 
 typedef __attribute__((address_space(3))) int lds_int_t;
 typedef __attribute__((address_space(3))) unsigned lds_uint_t;
@@ -55,17 +60,23 @@ typedef __attribute__((address_space(3))) float lds_float_t;
 typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
 typedef __attribute__((address_space(1))) int glb_int_t;
 
+// Lanes of a wave talk to each other through LDS (owner -> worker -> tester -> owner).  The hardware executes a wave's LDS
+// instructions in order; this keeps the COMPILER from moving or forwarding accesses across the points where another lane's
+// write has to be seen.
+PSDR_DEV void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// a worker's traversal state (registers)
 struct Trav4 {
-    Vec3f o, d, inv;            // the ray being traced
+    Vec3f o, d, inv;            // the ray in hand
     unsigned code;              // node / leaf in hand, kT4Done = none
     int sp;                     // stack pointer
-    int cur;                    // 0 / 1: which of the lane's two rays is being traced, -1 none
-    int pending;                // bit k: ray k still waits
-    unsigned last_pair;         // sequence number (+1) of the last pair this ray enqueued
-    float anyhit;               // ray 0 only: a hit closer than this ends the ray (shadow rays: any occluder will do), -inf = closest hit wanted
-    Hit hA, hB;                 // results
-    PSDR_DEV void reset() { code = kT4Done; sp = 0; cur = -1; pending = 0; last_pair = 0u; anyhit = -__builtin_inff(); hA.slot = -1; hA.u = hA.v = hA.t = 0.f; hB = hA; o = Vec3f(0.f); d = Vec3f(0.f); inv = Vec3f(0.f); }
-    PSDR_DEV bool idle() const { return cur < 0 && pending == 0; }
+    int rid;                    // ray in hand, -1 none
+    unsigned last_pair;         // sequence number after the last pair this ray enqueued
+    float anyhit;               // a hit closer than this ends the walk (shadow rays: any occluder will do), -inf = closest hit wanted
+    PSDR_DEV void reset() { code = kT4Done; sp = 0; rid = -1; last_pair = 0u; anyhit = -__builtin_inff(); o = Vec3f(0.f); d = Vec3f(0.f); inv = Vec3f(0.f); }
 };
 
 // per-lane / per-wave views of the LDS rows above
@@ -73,10 +84,12 @@ template <int LDS> struct T4Lds {
     lds_int_t *stack;           // this lane's stack, stride kBlock
     lds_float_t *park;          // this lane's parked rays, stride kBlock
     lds_float_t *park0;         // lane 0 of this WAVE (owner lane l: park0 + l)
-    lds_u64_t *best;            // this wave's 64 entries
-    lds_uint_t *ring;           // this wave's kQueueCap pairs
-    lds_uint_t *heads;          // this wave's {enqueued, tested}
-    lds_float_t *hit0;          // (slot, u, v) rows, lane 0 of this wave
+    lds_u64_t *best;            // this wave's kRayCap entries
+    lds_float_t *hit0;          // this wave's slot[kRayCap]; u at + 2 rows, v at + 4 rows
+    lds_uint_t *fin;            // this wave's kRayCap entries
+    lds_uint_t *ring;           // this wave's kPairCap pairs
+    lds_uint_t *rq;             // this wave's kRayCap queue slots
+    lds_uint_t *heads;          // this wave's four counters
     PSDR_DEV explicit T4Lds(const SceneView<LDS> &S) {
         const int rows = S.T->stack_lds;
         lds_int_t *base = (lds_int_t *) (S.stack - threadIdx.x);          // row 0 of the workgroup's stack area
@@ -84,12 +97,15 @@ template <int LDS> struct T4Lds {
         stack = base + threadIdx.x;
         park = (lds_float_t *) (base + rows * kBlock + threadIdx.x);
         park0 = (lds_float_t *) (base + rows * kBlock + (wave << 6));
-        best = (lds_u64_t *) (base + (rows + kParkWords) * kBlock) + (wave << 6);
-        ring = (lds_uint_t *) (base + (rows + kParkWords + 2) * kBlock) + wave * kQueueCap;
-        heads = (lds_uint_t *) (base + (rows + kParkWords + 2 + kQueueRows) * kBlock) + 2 * wave;
-        hit0 = (lds_float_t *) (base + (rows + kParkWords + 2 + kQueueRows + 1) * kBlock + (wave << 6));
+        best = (lds_u64_t *) (base + (rows + kRowBest) * kBlock) + wave * kRayCap;
+        hit0 = (lds_float_t *) (base + (rows + kRowHit) * kBlock + wave * kRayCap);
+        fin = (lds_uint_t *) (base + (rows + kRowFin) * kBlock) + wave * kRayCap;
+        ring = (lds_uint_t *) (base + (rows + kRowPair) * kBlock) + wave * kPairCap;
+        rq = (lds_uint_t *) (base + (rows + kRowRq) * kBlock) + wave * kRayCap;
+        heads = (lds_uint_t *) (base + (rows + kRowHeads) * kBlock) + 4 * wave;
     }
 };
+constexpr int kHitStride = 2 * kBlock;         // words between the slot / u / v arrays of `hit0`
 
 template <int LDS> PSDR_DEV void t4_push(const SceneView<LDS> &S, const T4Lds<LDS> &L, int &sp, unsigned key) {
     const SceneTables &T = *S.T;
@@ -106,7 +122,7 @@ template <int LDS> PSDR_DEV unsigned t4_pop(const SceneView<LDS> &S, const T4Lds
     return key;
 }
 
-// next node of this lane's ray: pop until an entry is not behind the closest hit; kT4Done when the stack is empty
+// next node of this worker's ray: pop until an entry is not behind the closest hit; kT4Done when the stack is empty
 template <int LDS> PSDR_DEV unsigned t4_next(const SceneView<LDS> &S, const T4Lds<LDS> &L, Trav4 &tr, unsigned cmask, float best_t) {
     while (tr.sp > 0) {
         const unsigned key = t4_pop(S, L, tr.sp);
@@ -117,31 +133,38 @@ template <int LDS> PSDR_DEV unsigned t4_next(const SceneView<LDS> &S, const T4Ld
 
 constexpr unsigned long long kT4NoHit = (0x7f800000ull << 32) | 0x7fffffffull;      // t = +inf, id = INT_MAX
 
-// start ray `k` of the lane from its parked copy: NaN rays miss (reference scene_optix.cpp:348-353)
-template <int LDS, bool COUNT> PSDR_DEV void t4_start(SceneView<LDS> &S, const T4Lds<LDS> &L, Trav4 &tr, int k) {
-    const lds_float_t *q = L.park + (k == 0 ? 0 : 6 * kBlock);
+PSDR_DEV float t4_best_t(const lds_u64_t *best, int rid) {
+    return __uint_as_float((unsigned) (__hip_atomic_load(&best[rid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32));
+}
+
+// a worker takes ray `rid` from its parked copy: NaN rays miss (reference scene_optix.cpp:348-353)
+template <int LDS, bool COUNT> PSDR_DEV void t4_start(SceneView<LDS> &S, const T4Lds<LDS> &L, Trav4 &tr, int rid) {
+    const int owner = rid & 63;
+    const lds_float_t *q = L.park0 + owner + ((rid & 64) ? 6 * kBlock : 0);
     const Vec3f o(q[0], q[kBlock], q[2 * kBlock]), d(q[3 * kBlock], q[4 * kBlock], q[5 * kBlock]);
-    tr.cur = k;
+    tr.rid = rid;
     tr.o = o; tr.d = d;
     tr.inv = Vec3f(1.f / d.x, 1.f / d.y, 1.f / d.z);
     tr.sp = 0;
     tr.last_pair = 0u;
-    L.best[threadIdx.x & 63] = kT4NoHit;
+    tr.anyhit = (rid & 64) ? -__builtin_inff() : L.park0[owner + 12 * kBlock];
     const bool ok = (o.x == o.x && o.y == o.y && o.z == o.z && d.x == d.x && d.y == d.y && d.z == d.z);
     tr.code = ok ? 0u : kT4Done;       // node 0 = root
     if (COUNT) { if (ok) S.c_rays++; }
 }
 
-// one inner node for the lanes whose code is an inner node
+// one inner node for the workers whose code is an inner node
 template <int LDS, bool COUNT> PSDR_DEV void t4_node(SceneView<LDS> &S, const T4Lds<LDS> &L, Trav4 &tr, unsigned cmask) {
     const SceneTables &T = *S.T;
-    const int w = T.nodes_off + 8 * (int) tr.code;
-    const float4 lx = S.ld(w), ly = S.ld(w + 1), lz = S.ld(w + 2), hx = S.ld(w + 3), hy = S.ld(w + 4), hz = S.ld(w + 5), cd = S.ld(w + 6);
     if (COUNT) S.c_nodes++;
-    const float bt = __uint_as_float((unsigned) (L.best[threadIdx.x & 63] >> 32));      // closest hit so far (tested pairs only)
-    if (tr.cur == 0 && bt < tr.anyhit) { tr.sp = 0; tr.code = kT4Done; return; }        // shadow ray: an occluder has been found
+    const float bt = t4_best_t(L.best, tr.rid);                               // closest hit so far (tested pairs only)
+    if (bt < tr.anyhit) { tr.sp = 0; tr.code = kT4Done; return; }              // shadow ray: an occluder has been found
     const float ox = tr.o.x, oy = tr.o.y, oz = tr.o.z, ix = tr.inv.x, iy = tr.inv.y, iz = tr.inv.z;
     unsigned key[4];
+#ifdef PSDR_NODE128
+    // round 2's node: 128 bytes, the children's boxes as floats (measurement knob; bvh.h emits the matching layout)
+    const int w = T.nodes_off + 8 * (int) tr.code;
+    const float4 lx = S.ld(w), ly = S.ld(w + 1), lz = S.ld(w + 2), hx = S.ld(w + 3), hy = S.ld(w + 4), hz = S.ld(w + 5), cd = S.ld(w + 6);
     const float lox[4] = {lx.x, lx.y, lx.z, lx.w}, loy[4] = {ly.x, ly.y, ly.z, ly.w}, loz[4] = {lz.x, lz.y, lz.z, lz.w};
     const float hix[4] = {hx.x, hx.y, hx.z, hx.w}, hiy[4] = {hy.x, hy.y, hy.z, hy.w}, hiz[4] = {hz.x, hz.y, hz.z, hz.w};
     const unsigned cds[4] = {__float_as_uint(cd.x), __float_as_uint(cd.y), __float_as_uint(cd.z), __float_as_uint(cd.w)};
@@ -156,6 +179,34 @@ template <int LDS, bool COUNT> PSDR_DEV void t4_node(SceneView<LDS> &S, const T4
         const bool hit = tn <= fminf(tf, bt);
         key[k] = hit ? ((__float_as_uint(tn) & ~cmask) | cds[k]) : kT4Miss;
     }
+#else
+    // 64-byte node (bvh.h): {origin.xyz, exponents} {lo.x[4] lo.y[4] lo.z[4] hi.x[4]} {hi.y[4] hi.z[4] code0 code1} {code2 code3 - -};
+    // child k's bounds are bytes k of the six words: lo = origin + 2^e q_lo (rounded down), hi = origin + 2^e q_hi (rounded up).
+    // Along one axis  (origin + s q - o) * inv = q * (s inv) + (origin - o) inv: one convert and one fma per bound, as many
+    // VALU instructions as the subtract and multiply of the float node, for four loads instead of seven.  The roundings of the
+    // factored form (a few ulps of |origin - o| |inv|) stay far inside the builder's padding of every box (1e-4 of the coordinate
+    // magnitude, bvh.h).
+    const int w = T.nodes_off + 4 * (int) tr.code;
+    const float4 n0 = S.ld(w), n1 = S.ld(w + 1), n2 = S.ld(w + 2), n3 = S.ld(w + 3);
+    const unsigned ex = __float_as_uint(n0.w);
+    const float sx = __uint_as_float((ex & 0xffu) << 23), sy = __uint_as_float(((ex >> 8) & 0xffu) << 23), sz = __uint_as_float(((ex >> 16) & 0xffu) << 23);
+    const float ax0 = (n0.x - ox) * ix, ay0 = (n0.y - oy) * iy, az0 = (n0.z - oz) * iz;
+    const float bxs = sx * ix, bys = sy * iy, bzs = sz * iz;
+    const unsigned qlx = __float_as_uint(n1.x), qly = __float_as_uint(n1.y), qlz = __float_as_uint(n1.z);
+    const unsigned qhx = __float_as_uint(n1.w), qhy = __float_as_uint(n2.x), qhz = __float_as_uint(n2.y);
+    const unsigned cds[4] = {__float_as_uint(n2.z), __float_as_uint(n2.w), __float_as_uint(n3.x), __float_as_uint(n3.y)};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float ax = fmaf((float) ((qlx >> (8 * k)) & 0xffu), bxs, ax0), bx = fmaf((float) ((qhx >> (8 * k)) & 0xffu), bxs, ax0);
+        const float ay = fmaf((float) ((qly >> (8 * k)) & 0xffu), bys, ay0), by = fmaf((float) ((qhy >> (8 * k)) & 0xffu), bys, ay0);
+        const float az = fmaf((float) ((qlz >> (8 * k)) & 0xffu), bzs, az0), bz = fmaf((float) ((qhz >> (8 * k)) & 0xffu), bzs, az0);
+        // slab test; fminf / fmaxf drop NaNs (0 * inf), which keeps the test conservative; the far side gets one ulp-scale of slack
+        const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
+        const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000004f;
+        const bool hit = (tn <= fminf(tf, bt)) && (cds[k] != kT4Miss);
+        key[k] = hit ? ((__float_as_uint(tn) & ~cmask) | cds[k]) : kT4Miss;
+    }
+#endif
     // sorting network on four keys: (0,1) (2,3) (0,2) (1,3) (1,2)
     unsigned a = min(key[0], key[1]), b = max(key[0], key[1]), c = min(key[2], key[3]), e = max(key[2], key[3]);
     const unsigned k0 = min(a, c), m1 = max(a, c), m2 = min(b, e), k3 = max(b, e);
@@ -166,7 +217,7 @@ template <int LDS, bool COUNT> PSDR_DEV void t4_node(SceneView<LDS> &S, const T4
     tr.code = k0 != kT4Miss ? (k0 & cmask) : t4_next(S, L, tr, cmask, bt);
 }
 
-// the leaf in hand (called by the lanes that hold one, together): its triangles join the wave's pair ring
+// the leaf in hand (called by the workers that hold one, together): its triangles join the wave's pair ring
 template <int LDS> PSDR_DEV void t4_enqueue(const SceneView<LDS> &S, const T4Lds<LDS> &L, Trav4 &tr, unsigned cmask, unsigned leaf_bit) {
     const int lane_id = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane_id) - 1ull;
@@ -175,14 +226,13 @@ template <int LDS> PSDR_DEV void t4_enqueue(const SceneView<LDS> &S, const T4Lds
     const unsigned long long b1 = __ballot(true), b2 = __ballot(cnt > 1), b3 = __ballot(cnt > 2), b4 = __ballot(cnt > 3);
     const int before = __popcll(b1 & lt_mask) + __popcll(b2 & lt_mask) + __popcll(b3 & lt_mask) + __popcll(b4 & lt_mask);
     const int total = __popcll(b1) + __popcll(b2) + __popcll(b3) + __popcll(b4);
-    const unsigned base = L.heads[0];                 // wave-synchronous: every participating lane reads the old head ...
-    __builtin_amdgcn_wave_barrier();
-    if (lane_id == (int) __builtin_ctzll(b1)) L.heads[0] = base + (unsigned) total;      // ... before the first of them advances it
+    const unsigned base = L.heads[kHdPairEnq];        // every participating lane reads the old head ...
+    wave_sync();
+    if (lane_id == (int) __builtin_ctzll(b1)) L.heads[kHdPairEnq] = base + (unsigned) total;      // ... before the first of them advances it
     const unsigned mine = base + (unsigned) before;
-    for (int k = 0; k < cnt; ++k) L.ring[(mine + k) & (kQueueCap - 1)] = ((unsigned) (first + k) << 7) | ((unsigned) tr.cur << 6) | (unsigned) lane_id;
+    for (int k = 0; k < cnt; ++k) L.ring[(mine + k) & (kPairCap - 1)] = ((unsigned) (first + k) << 7) | (unsigned) tr.rid;
     tr.last_pair = mine + (unsigned) cnt;
-    const float bt = __uint_as_float((unsigned) (L.best[lane_id] >> 32));
-    tr.code = t4_next(S, L, tr, cmask, bt);
+    tr.code = t4_next(S, L, tr, cmask, t4_best_t(L.best, tr.rid));
 }
 
 // all participating lanes test one pair each, `n` pairs starting at sequence number `from`
@@ -192,107 +242,151 @@ template <int LDS, bool COUNT> PSDR_DEV void t4_test_pairs(SceneView<LDS> &S, co
 #if PSDR_DIAG == 2
     if (COUNT) S.c_hits++;
 #endif
+    unsigned long long key = 0ull;
+    int rid = 0, slot = 0;
+    float u = 0.f, v = 0.f;
+    bool hit = false;
     if (rank < n) {
-        const unsigned e = L.ring[(from + (unsigned) rank) & (kQueueCap - 1)];
-        const int owner = (int) (e & 63u), slot = (int) (e >> 7);
-        const lds_float_t *q = L.park0 + owner + ((e & 64u) ? 6 * kBlock : 0);
+        const unsigned e = L.ring[(from + (unsigned) rank) & (kPairCap - 1)];
+        rid = (int) (e & 127u); slot = (int) (e >> 7);
+        const lds_float_t *q = L.park0 + (rid & 63) + ((rid & 64) ? 6 * kBlock : 0);
         const Vec3f o(q[0], q[kBlock], q[2 * kBlock]), d(q[3 * kBlock], q[4 * kBlock], q[5 * kBlock]);
         const int w = T.trav_off + 3 * slot;
         const float4 a = S.ld(w), b = S.ld(w + 1), c = S.ld(w + 2);
-        float u, v, t;
+        float t;
         if (COUNT) S.c_tris++;
-        if (tri_test(a, b, c, o, d, u, v, t)) {
-            const unsigned long long key = ((unsigned long long) __float_as_uint(t) << 32) | (unsigned long long) (unsigned) __float_as_int(c.y);
-            __hip_atomic_fetch_min(&L.best[owner], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            // whoever holds the minimum after this batch's atomics describes the hit (keys are unique: one pair per triangle and ray)
-            if (L.best[owner] == key) { L.hit0[owner] = __int_as_float(slot); L.hit0[kBlock + owner] = u; L.hit0[2 * kBlock + owner] = v; }
+        hit = tri_test(a, b, c, o, d, u, v, t);
+        if (hit) {
+            key = ((unsigned long long) __float_as_uint(t) << 32) | (unsigned long long) (unsigned) __float_as_int(c.y);
+            __hip_atomic_fetch_min(&L.best[rid], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+    }
+    // whoever holds the minimum after ALL of this batch's atomics describes the hit (keys are unique: one pair per triangle and ray)
+    wave_sync();
+    if (hit && __hip_atomic_load(&L.best[rid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == key) {
+        L.hit0[rid] = __int_as_float(slot); L.hit0[kHitStride + rid] = u; L.hit0[2 * kHitStride + rid] = v;
     }
 }
 
-// the finished ray's hit
-template <int LDS> PSDR_DEV Hit t4_result(const SceneView<LDS> &S, const T4Lds<LDS> &L, const Trav4 &tr) {
+// the finished ray's hit (read by its owner)
+template <int LDS> PSDR_DEV Hit t4_result(const SceneView<LDS> &S, int k) {
+    const T4Lds<LDS> L(S);
     Hit h; h.slot = -1; h.u = h.v = h.t = 0.f;
-    const int lane_id = threadIdx.x & 63;
-    const unsigned long long key = L.best[lane_id];
+    const int rid = (k << 6) | (threadIdx.x & 63);
+    const unsigned long long key = __hip_atomic_load(&L.best[rid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if ((unsigned) (key & 0xffffffffull) != 0x7fffffffu) {
-        h.slot = __float_as_int(L.hit0[lane_id]); h.u = L.hit0[kBlock + lane_id]; h.v = L.hit0[2 * kBlock + lane_id];
+        h.slot = __float_as_int(L.hit0[rid]); h.u = L.hit0[kHitStride + rid]; h.v = L.hit0[2 * kHitStride + rid];
         h.t = __uint_as_float((unsigned) (key >> 32));
     }
     return h;
 }
 
-// Runs the lanes' ray queues (rays parked in LDS by the caller, tr.pending says which).  Returns as soon as at most `max_busy`
-// lanes still have rays to trace (0: run to completion).  May be called under a partial exec mask: only the active lanes take
-// part (and are counted).  Results: tr.hA / tr.hB.
+// Works on the wave's ray queue until at most `max_busy` OWNERS still wait for a posted ray (0: until every posted ray is
+// finished).  `posted`: bit k set = this lane posted ray k with t4_post and has not consumed it yet.  May be called under a partial
+// exec mask: only the active lanes work (and are counted).  Returns true for a lane whose posted rays are all finished (their hits:
+// t4_result); the workers' walks in progress stay in `tr` for the next call.
 template <int LDS, bool COUNT>
-PSDR_DEV void trav4_run(SceneView<LDS> &S, Trav4 &tr, int max_busy) {
+PSDR_DEV bool trav4_run(SceneView<LDS> &S, Trav4 &tr, int posted, int max_busy) {
     const SceneTables &T = *S.T;
     const T4Lds<LDS> L(S);
     const unsigned cmask = (1u << T.ref_bits) - 1u, leaf_bit = 1u << (T.ref_bits - 1);
-    const int n_lanes = __popcll(__ballot(true));
+    const int lane_id = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane_id) - 1ull, m_all = __ballot(true);
+    const int n_lanes = __popcll(m_all), first = (int) __builtin_ctzll(m_all);
+    bool done = true;
     for (;;) {
-        const unsigned tested = L.heads[1];
+        wave_sync();
+        const unsigned tested = L.heads[kHdPairTested];
 #if PSDR_DIAG == 3
         if (COUNT) S.c_hits++;
 #endif
-        if (tr.code == kT4Done) {
-            if (tr.cur >= 0 && tr.last_pair <= tested) {       // the ray's stack is empty and its last pair has been tested
-                const Hit h = t4_result(S, L, tr);
-                if (tr.cur == 0) tr.hA = h; else tr.hB = h;
-                tr.cur = -1;
-            }
-            if (tr.cur < 0 && tr.pending != 0) {               // next ray of this lane's queue
-                const int k = (tr.pending & 1) ? 0 : 1;
-                tr.pending &= ~(1 << k);
-                t4_start<LDS, COUNT>(S, L, tr, k);
-            }
+        // a worker whose walk has ended hands the ray back (finished once the pairs up to last_pair are tested) ...
+        if (tr.rid >= 0 && tr.code == kT4Done) { L.fin[tr.rid] = tr.last_pair + 1u; tr.rid = -1; }
+        // ... and the workers without a ray take the next ones of the queue
+        const unsigned long long m_idle = __ballot(tr.rid < 0);
+        const unsigned rq_tail = L.heads[kHdRayTail], rq_head = L.heads[kHdRayHead];
+        int avail = (int) (rq_tail - rq_head);            // rays waiting in the queue (after the refill: still waiting)
+        if (m_idle != 0ull && avail > 0) {
+            const int rank = __popcll(m_idle & lt_mask), n_idle = __popcll(m_idle), n_take = n_idle < avail ? n_idle : avail;
+            if (tr.rid < 0 && rank < avail) t4_start<LDS, COUNT>(S, L, tr, (int) L.rq[(rq_head + (unsigned) rank) & (kRayCap - 1)]);
+            wave_sync();
+            if (lane_id == first) L.heads[kHdRayHead] = rq_head + (unsigned) n_take;
+            avail -= n_take;
         }
-        if (__popcll(__ballot(!tr.idle())) <= max_busy) break;
+        wave_sync();
+        // owners: are my posted rays finished?  (fin = 1 + the sequence number after the ray's last pair)
+        bool wait_pairs = false;
+        done = true;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (posted & (1 << k)) {
+                const unsigned f = L.fin[(k << 6) | lane_id];
+                if (f == 0u) done = false;
+                else if ((int) (f - 1u - tested) > 0) { done = false; wait_pairs = true; }
+            }
+        if (__popcll(__ballot(!done)) <= max_busy) break;
         // traversal burst: until the ring holds a wave's worth of pairs, or nobody has a node in hand
-        for (;;) {
-            if (tr.code < leaf_bit) t4_node<LDS, COUNT>(S, L, tr, cmask);
-            else if (tr.code != kT4Done) t4_enqueue(S, L, tr, cmask, leaf_bit);
+        const unsigned long long m_walk = __ballot(tr.code != kT4Done);
+        if (m_walk != 0ull) {
+            for (;;) {
+                if (tr.code < leaf_bit) t4_node<LDS, COUNT>(S, L, tr, cmask);
+                else if (tr.code != kT4Done) t4_enqueue(S, L, tr, cmask, leaf_bit);
 #if PSDR_DIAG == 1
-            if (COUNT) S.c_hits++;
+                if (COUNT) S.c_hits++;
 #endif
-            const int waiting = (int) (L.heads[0] - tested);
-            if (waiting >= n_lanes || __ballot(tr.code != kT4Done) == 0ull) break;
+                wave_sync();
+                const int waiting = (int) (L.heads[kHdPairEnq] - tested);
+                if (waiting >= n_lanes || __ballot(tr.code != kT4Done) == 0ull) break;
+                // workers that ran out of nodes idle until the burst ends: end it early when many do and rays are waiting
+                if (avail > n_lanes / 4 && __popcll(__ballot(tr.code == kT4Done)) >= n_lanes / 4) break;
+            }
         }
-        // test the waiting pairs, a wave's worth at a time; the partial last batch only when a finished ray is waiting for it
+        // test the waiting pairs, a wave's worth at a time; the partial last batch only when a finished walk is waiting for it
         {
             unsigned from = tested;
-            const unsigned head = L.heads[0];
+            const unsigned head = L.heads[kHdPairEnq];
             while ((int) (head - from) >= n_lanes) { t4_test_pairs<LDS, COUNT>(S, L, from, n_lanes); from += (unsigned) n_lanes; }
-            if (head != from && __ballot(tr.code == kT4Done && tr.cur >= 0 && (int) (tr.last_pair - from) > 0) != 0ull) {
+            if (head != from && (__ballot(wait_pairs) != 0ull || (m_walk == 0ull && avail <= 0))) {
                 t4_test_pairs<LDS, COUNT>(S, L, from, (int) (head - from));
                 from = head;
             }
-            __builtin_amdgcn_wave_barrier();
-            if ((threadIdx.x & 63) == (int) __builtin_ctzll(__ballot(true))) L.heads[1] = from;
-            __builtin_amdgcn_wave_barrier();
+            wave_sync();
+            if (lane_id == first) L.heads[kHdPairTested] = from;
         }
     }
+    return done;
 }
 
 // called once per kernel by every thread of the workgroup (make_view): the ring heads start at zero
 template <int LDS> PSDR_DEV void t4_init_lds(const SceneView<LDS> &S) {
     if (S.T->stack_lds > 0) {
         lds_int_t *base = (lds_int_t *) (S.stack - threadIdx.x);
-        base[(S.T->stack_lds + kParkWords + 2 + kQueueRows) * kBlock + threadIdx.x] = 0;
+        base[(S.T->stack_lds + kRowHeads) * kBlock + threadIdx.x] = 0;
         __syncthreads();
     }
 }
 
-// posts the two rays of this lane (run by the lane itself: the parked copy is what the testers of the wave read)
-template <int LDS> PSDR_DEV void t4_post(const SceneView<LDS> &S, Trav4 &tr, const Vec3f &oA, const Vec3f &dA, bool actA, const Vec3f &oB, const Vec3f &dB, bool actB, float anyhit_a = -__builtin_inff()) {
+// The owner posts its two rays (called by the owners together): parked copies, empty hit records, entries in the wave's ray queue.
+// -> bit mask of the rays posted, to be handed to trav4_run until the hits have been read with t4_result.
+template <int LDS> PSDR_DEV int t4_post(const SceneView<LDS> &S, const Vec3f &oA, const Vec3f &dA, bool actA, const Vec3f &oB, const Vec3f &dB, bool actB, float anyhit_a = -__builtin_inff()) {
     const T4Lds<LDS> L(S);
+    const int lane_id = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane_id) - 1ull;
     lds_float_t *p = L.park;
     p[0] = oA.x; p[kBlock] = oA.y; p[2 * kBlock] = oA.z; p[3 * kBlock] = dA.x; p[4 * kBlock] = dA.y; p[5 * kBlock] = dA.z;
     p[6 * kBlock] = oB.x; p[7 * kBlock] = oB.y; p[8 * kBlock] = oB.z; p[9 * kBlock] = dB.x; p[10 * kBlock] = dB.y; p[11 * kBlock] = dB.z;
-    tr.reset();
-    tr.pending = (actA ? 1 : 0) | (actB ? 2 : 0);
-    tr.anyhit = anyhit_a;
+    p[12 * kBlock] = anyhit_a;
+    L.best[lane_id] = kT4NoHit; L.best[64 + lane_id] = kT4NoHit;
+    L.fin[lane_id] = 0u; L.fin[64 + lane_id] = 0u;
+    const unsigned long long mA = __ballot(actA), mB = __ballot(actB), m_all = __ballot(true);
+    const int before = __popcll(mA & lt_mask) + __popcll(mB & lt_mask), total = __popcll(mA) + __popcll(mB);
+    const unsigned tail = L.heads[kHdRayTail];
+    wave_sync();
+    if (actA) L.rq[(tail + (unsigned) before) & (kRayCap - 1)] = (unsigned) lane_id;
+    if (actB) L.rq[(tail + (unsigned) before + (actA ? 1u : 0u)) & (kRayCap - 1)] = 64u + (unsigned) lane_id;
+    if (lane_id == (int) __builtin_ctzll(m_all)) L.heads[kHdRayTail] = tail + (unsigned) total;
+    wave_sync();
+    return (actA ? 1 : 0) | (actB ? 2 : 0);
 }
 
 // two rays per lane, run to completion: the synchronous form behind trace() / trace2() (secondary-edge, guiding, adjoint
@@ -300,10 +394,12 @@ template <int LDS> PSDR_DEV void t4_post(const SceneView<LDS> &S, Trav4 &tr, con
 template <int LDS, bool COUNT>
 PSDR_DEV void bvh4_trace2(SceneView<LDS> &S, const Vec3f &oA, const Vec3f &dA, bool actA, const Vec3f &oB, const Vec3f &dB, bool actB, Hit &hA, Hit &hB, float anyhit_a) {
     Trav4 tr;
-    t4_post(S, tr, oA, dA, actA, oB, dB, actB, anyhit_a);
-    trav4_run<LDS, COUNT>(S, tr, 0);
-    hA = tr.hA;
-    hB = tr.hB;
+    tr.reset();
+    const int posted = t4_post(S, oA, dA, actA, oB, dB, actB, anyhit_a);
+    trav4_run<LDS, COUNT>(S, tr, posted, 0);
+    hA.slot = -1; hA.u = hA.v = hA.t = 0.f; hB = hA;
+    if (actA) hA = t4_result(S, 0);
+    if (actB) hB = t4_result(S, 1);
 }
 
 } // namespace psdr

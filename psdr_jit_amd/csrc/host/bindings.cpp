@@ -498,6 +498,7 @@ PYBIND11_MODULE(_psdr_core, m) {
         .def(py::init<int>(), "max_depth"_a = 1)
         .def("preprocess_secondary_edges", &PathTracer::preprocess_secondary_edges, "scene"_a, "sensor_id"_a, "resolution"_a, "nrounds"_a = 1, "seed"_a = 0)
         .def("_guiding_mass", [](const PathTracer &p, int sid) { auto v = p.guiding_mass(sid); return from_vec(v, 1); })
+        .def("_guiding_handle", [](const PathTracer &p, int sid) { return reinterpret_cast<uintptr_t>(p.guiding(sid)); })    // psdr_render_args.guiding for direct C-ABI calls
         .def_readwrite("hide_emitters", &PathTracer::m_hide_emitters)
         .def_readonly("max_depth", &PathTracer::m_max_depth);
     py::class_<FieldExtractionIntegrator, Integrator>(m, "FieldExtractionIntegrator", py::dynamic_attr())

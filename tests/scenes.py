@@ -5,10 +5,14 @@ cells 2-5, 652 triangles).  Geometry comes from the OBJ data files under example
 The OBJ reader here is the tests' own (fan triangulation = what an ear-clipping triangulator
 yields for convex polygons, which is what the reference gets from tinyobj)."""
 import os
+import sys
 
 import numpy as np
 
 from oracle.oracle import BsdfSpec, CameraSpec, EmitterSpec, MeshSpec, SceneSpec
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+from synth import icosphere, synthetic_envmap                # noqa: E402,F401  (file-less inputs shared with bench.py's config-5 leg)
 
 DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "data", "cbox")
 
@@ -132,21 +136,6 @@ def sphere_scene(width=512, height=512, spp=32, sppe=32, sppse=32):
     return SceneSpec(meshes, bsdfs, emitters, [cam], width, height, spp, sppe, sppse)
 
 
-def synthetic_envmap(width=64, height=32, sun=True):
-    """Lat-long radiance image [H, W, 3] by a fixed formula (BASELINE config 5 / SURVEY §8d): a constant sky
-    (0.6, 0.7, 0.9) plus, when `sun`, one Gaussian sun of peak (40, 36, 30) at (u, v) = (0.30, 0.25), sigma 0.04."""
-    u = (np.arange(width, dtype=np.float64) + 0.5) / width
-    v = (np.arange(height, dtype=np.float64) + 0.5) / height
-    uu, vv = np.meshgrid(u, v)
-    img = np.empty((height, width, 3), dtype=np.float64)
-    img[...] = (0.6, 0.7, 0.9)
-    if sun:
-        du = np.minimum(np.abs(uu - 0.30), 1.0 - np.abs(uu - 0.30))
-        g = np.exp(-(du * du + (vv - 0.25) ** 2) / (2 * 0.04 ** 2))
-        img += g[..., None] * np.array([40.0, 36.0, 30.0])
-    return img.astype(np.float32)
-
-
 def envmap_scene(width=64, height=64, spp=4, sppe=0, sppse=0, param="albedo", env=None, area_light=False, floor_only=False, balls=False):
     """Cornell-box furniture (floor + the two boxes) under an environment map - the Forward_AD_envmap layout in
     small.  param: 'albedo' (d box reflectance / dP = (1,1,1)), 'box_x' (small box translated by 100*P in x), None."""
@@ -177,33 +166,6 @@ def _rot_x(a):
     c, s = np.cos(a), np.sin(a)
     m[1, 1], m[1, 2], m[2, 1], m[2, 2] = c, -s, s, c
     return m
-
-
-def icosphere(level=3, radius=1.0, noise=0.0, seed=0):
-    """Icosphere with 20*4^level triangles; `noise` scales a seeded radial perturbation (BASELINE config 5's
-    ~100k-triangle mesh: level 6 = 81920 triangles, numpy.random.default_rng(0))."""
-    t = (1.0 + 5.0 ** 0.5) / 2.0
-    v = [[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t], [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]]
-    f = [[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2], [10, 7, 6], [7, 1, 8],
-         [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5], [2, 4, 11], [6, 2, 10], [8, 6, 7], [9, 8, 1]]
-    v = [np.asarray(p, np.float64) / np.linalg.norm(p) for p in v]
-    for _ in range(level):
-        cache, nf = {}, []
-        def mid(a, b):
-            key = (a, b) if a < b else (b, a)
-            if key not in cache:
-                m = v[a] + v[b]
-                v.append(m / np.linalg.norm(m))
-                cache[key] = len(v) - 1
-            return cache[key]
-        for a, b, c in f:
-            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
-            nf += [[a, ab, ca], [b, bc, ab], [c, ca, bc], [ab, bc, ca]]
-        f = nf
-    v = np.asarray(v)
-    if noise > 0:
-        v = v * (1.0 + noise * np.random.default_rng(seed).standard_normal(len(v)))[:, None]
-    return (v * radius).astype(np.float32), np.asarray(f, dtype=np.int32)
 
 
 def config5_scene(width=128, height=128, spp=4, sppe=4, sppse=4, level=6, env_res=(1024, 512), param="albedo"):

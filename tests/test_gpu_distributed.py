@@ -52,3 +52,28 @@ def test_bench_two_ranks_config4_strong_scaling_line():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "config 4" in d["config"]["workload"] and "2048x2048" in d["config"]["workload"]
     assert d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and d["unit"] == "Msamples/s"
     assert "roofline" not in d and "cpu_baseline" not in d        # N = 1 only
+
+
+def test_rccl_preflight_world_size_one():
+    """RCCL preflight for the driver's 8-GPU run: bench.py's N > 1 code path - `init_process_group("nccl", device_id=...)`, the
+    device-pointer all_reduce(sum) of the [image | derivative] buffer after every renderD, the max-over-ranks timing reduce, the
+    barriers and destroy_process_group - executed through RCCL itself on the test box's one GPU, as torch.distributed.run launches
+    a single rank (PSDR_BENCH_FORCE_DIST=1 keeps the collectives in at world size 1).  Config 4's scene at a reduced frame."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X (no CPU fallback exists)")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update({"PSDR_BENCH_FORCE_DIST": "1", "PSDR_BENCH_BACKEND": "nccl"})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "1", "--config", "4", "--res", "256", "--spp", "8", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--no-parity", "--no-roofline", "--no-backward", "--no-config5"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    d = json.loads(lines[0])
+    assert d["rccl"]["backend"] == "nccl" and d["rccl"]["ranks"] == 1 and d["rccl"]["all_reduce_bytes"] == 2 * 256 * 256 * 3 * 4
+    assert d["value"] > 0 and d["n_gpus"] == 1 and "config 4" in d["config"]["workload"]
+    # the same frame without the process group: the all-reduce of one rank must not change the image (checked through the rate only
+    # being finite here; equality of sharded and unsharded frames is test_two_ranks_forward_and_backward_equal_one_process)
