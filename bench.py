@@ -33,7 +33,8 @@ Prints ONE JSON line (rank 0).  Extra objects (N = 1, rank 0; each can be switch
                  at whatever world size the launcher gives, also 1 (the preflight of tests/test_gpu_distributed.py).
   parity       - relative L2 of this run's GPU image / derivative against the oracle on the same shard and seeds.
   cpu_baseline - the CPU restatement (oracle/, test infrastructure), built -O3 -march=native on this host, 1 warm-up +
-                 median of 5 on a bounded shard of the same workload, all physical cores and one thread.
+                 median of 5 on the same frame at a reduced sample count, on the cores this process may use (affinity mask and
+                 cgroup CPU quota, `cores`), and the same frame on one thread.
 """
 import argparse
 import ctypes as C
@@ -101,6 +102,33 @@ def host_cpu():
     except OSError:
         pass
     return model, (len(cores) or os.cpu_count() or 1), (os.cpu_count() or 1)
+
+
+def usable_cpus(phys):
+    """How many cores this PROCESS may really keep busy: the physical cores of the host, cut down to its affinity mask and to the
+    CPU quota of its cgroup (a container sees every core of the host in /proc/cpuinfo but is throttled to cpu.max - 128 OpenMP threads
+    on a 16-CPU quota ran at 7 % parallel efficiency in round 2's baseline).  -> (threads to use, quota in CPUs or None)"""
+    n = phys
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                      # cgroup v2
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())                # cgroup v1
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota)))
+    return max(1, n), quota
 
 
 def main():
@@ -403,7 +431,8 @@ def main():
         ref = orc.OracleScene(spec, [0])
         g_ref = ref.guiding_build(0, GUIDING, nrounds=1, seed=0, max_depth=DEPTH) if cfg == 5 else None
         model, phys, logical = host_cpu()
-        orc.set_num_threads(phys)
+        n_thr, quota = usable_cpus(phys)
+        orc.set_num_threads(n_thr)
         n_chunks = (npx * spp + 255) // 256
 
         def lanes_of(k):
@@ -429,33 +458,31 @@ def main():
         if not args.no_cpu_baseline:
             # The sample: the same scene, resolution, depth and three terms at a REDUCED sample count per pixel (every pixel and
             # every sampler, so the OpenMP loops stay balanced - a sparse shard leaves most threads idle); samples per second
-            # is the metric, so the figure is directly comparable.  spp is calibrated to ~3 s per run.
-            def timed(sref, runs):
+            # is the metric, so the figure is directly comparable.  Threads = the cores this process may use (usable_cpus);
+            # the one-thread figure is the SAME frame at one sample per pixel.
+            def timed(sref, runs, warm=1):
                 ts = []
-                for r in range(runs + 1):                # first run = warm-up
+                for r in range(runs + warm):                # first run = warm-up
                     t = time.perf_counter()
-                    sref.render_d(max_depth=DEPTH, seeds=(r, r, r), guiding=sref_g.get(id(sref)))
+                    sref.render_d(max_depth=DEPTH, seeds=(r, r, r))
                     ts.append(time.perf_counter() - t)
-                return statistics.median(ts[1:])
-            sref_g = {}
+                return statistics.median(ts[warm:])
             one = orc.OracleScene(spec_of(res, 1), [0])
-            t = time.perf_counter()
-            one.render_d(max_depth=DEPTH, seeds=(9, 9, 9))
-            t_one = time.perf_counter() - t
+            t_one = timed(one, 1)                         # all usable threads, 1 sample per pixel: calibrates the sample count
             cspp = int(min(spp, max(1, round(3.0 / max(t_one, 1e-3)))))
             sref = orc.OracleScene(spec_of(res, cspp), [0])
             tc = timed(sref, 5)
             orc.set_num_threads(1)
-            sres = max(16, res // 8)                      # one thread: the same scene at 1/64 of the pixels, 1 sample each
-            tiny = orc.OracleScene(spec_of(sres, 1), [0])
-            t1 = timed(tiny, 3)
-            orc.set_num_threads(phys)
+            t1 = timed(one, 1) if t_one * n_thr < 20.0 else None       # (skipped where one thread would need more than ~20 s per frame)
+            orc.set_num_threads(n_thr)
             out["cpu_baseline"] = {
-                "value": round(npx * cspp / tc / 1e6, 4), "unit": "Msamples/s", "cores": phys, "kind": "port",
-                "one_thread": round(sres * sres / t1 / 1e6, 5), "cpu": model, "logical_cpus": logical,
-                "sample": "oracle/ (CPU restatement of the reference algorithm, g++ -O3 -march=native, OpenMP over %d physical cores) renderD of this "
-                          "workload at spp=sppe=sppse=%d instead of %d (all %d pixels, all three terms): 1 warm-up + median of 5, %.2f s per run; "
-                          "one thread: %dx%d pixels at 1 sample, median of 3, %.2f s" % (phys, cspp, spp, npx, tc, sres, sres, t1),
+                "value": round(npx * cspp / tc / 1e6, 4), "unit": "Msamples/s", "cores": n_thr, "kind": "port",
+                "one_thread": round(npx / t1 / 1e6, 5) if t1 else None, "parallel_efficiency": round((npx * cspp / tc) / (npx / t1) / n_thr, 3) if t1 else None,
+                "cpu": model, "physical_cores": phys, "logical_cpus": logical, "cgroup_cpu_quota": quota,
+                "sample": "oracle/ (CPU restatement of the reference algorithm, g++ -O3 -march=native, OpenMP) renderD of this workload at spp=sppe=sppse=%d "
+                          "instead of %d (all %d pixels, all three terms) on %d threads = the cores this process may use (host: %d physical cores, cgroup "
+                          "CPU quota %s): 1 warm-up + median of 5, %.2f s per run; one thread: the same frame at 1 sample per pixel, %s"
+                          % (cspp, spp, npx, n_thr, phys, ("%.1f" % quota) if quota else "none", tc, ("%.2f s" % t1) if t1 else "not timed"),
             }
 
     if rank == 0:

@@ -150,7 +150,7 @@ struct GuidingDev {          // HyperCubeDistribution<3>, reference src/core/cub
 
 PSDR_DEV float guiding_sample_reuse(const GuidingDev &G, Vec3f &s) {
     float pdf;
-    const int idx = sample_reuse(G.num_cells, G.sum, [&](int i) { return G.pmf[i]; }, [&](int i) { return G.cmf[i]; }, s.z, pdf);
+    const int idx = sample_reuse<true>(G.num_cells, G.sum, [&](int i) { return G.pmf[i]; }, [&](int i) { return G.cmf[i]; }, s.z, pdf);
     const int c0 = idx / (G.reso[1] * G.reso[2]);
     const int rem = idx - c0 * (G.reso[1] * G.reso[2]);
     const int c1 = rem / G.reso[2], c2 = rem - c1 * G.reso[2];

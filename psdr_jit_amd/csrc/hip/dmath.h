@@ -14,6 +14,26 @@
 
 namespace psdr {
 
+// WEIGHT ARITHMETIC (round 3).  An IEEE-rounded fp32 division is a ten-instruction, ~44-cycle sequence on gfx950 (v_div_scale x 2, v_rcp,
+// four fma, v_div_fmas, v_div_fixup) and the primary-edge kernel of the README box carried 111 of them.  Two kinds of numbers flow
+// through a path:
+//   * GEOMETRY - hit points, directions, sample positions, everything a later ray, a comparison or a table index is computed from.
+//     It stays correctly rounded (plain `/`, __builtin_sqrtf): one ulp in a direction moves the next hit, once in ~10^5 paths across an
+//     edge, and the path - not its last bits - differs from the oracle's.  Measured with v_rcp / v_sqrt everywhere: renderD 7.58 -> 7.02 ms,
+//     but 4 samples in a million take another path and the frame's relative L2 against the oracle goes from 1e-8 to 7e-4 (small test
+//     frames: 1e-2).  Not taken.
+//   * WEIGHTS - geometry terms, pdfs, MIS weights, throughput, radiance and EVERY TANGENT: they are multiplied into the result and
+//     never decide anything.  They divide by multiplying with v_rcp_f32 (1 ulp): fdiv / frcp / div_ below, the tangent half of the Dual
+//     operators.  Special values keep their IEEE meaning (x / 0 = +-inf, 0 / 0 = NaN, x / inf = 0).
+// -DPSDR_EXACT_DIV restores the correctly rounded forms everywhere (measurement knob).
+#ifdef PSDR_EXACT_DIV
+__device__ __forceinline__ float frcp(float a) { return 1.f / a; }
+__device__ __forceinline__ float fdiv(float a, float b) { return a / b; }
+#else
+__device__ __forceinline__ float frcp(float a) { return __builtin_amdgcn_rcpf(a); }
+__device__ __forceinline__ float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+#endif
+
 struct Dual {
     float v, d;
     PSDR_DEV Dual() : v(0.f), d(0.f) {}
@@ -34,9 +54,9 @@ PSDR_DEV Dual operator+(const Dual &a, const Dual &b) { return Dual(a.v + b.v, a
 PSDR_DEV Dual operator-(const Dual &a, const Dual &b) { return Dual(a.v - b.v, a.d - b.d); }
 PSDR_DEV Dual operator-(const Dual &a) { return Dual(-a.v, -a.d); }
 PSDR_DEV Dual operator*(const Dual &a, const Dual &b) { return Dual(a.v * b.v, a.d * b.v + a.v * b.d); }
-PSDR_DEV Dual operator/(const Dual &a, const Dual &b) {
-    float q = a.v / b.v;
-    return Dual(q, (a.d - q * b.d) / b.v);
+PSDR_DEV Dual operator/(const Dual &a, const Dual &b) {      // value: geometry (correctly rounded); tangent: weight arithmetic
+    const float q = a.v / b.v;
+    return Dual(q, (a.d - q * b.d) * frcp(b.v));
 }
 PSDR_DEV Dual operator*(const Dual &a, float b) { return Dual(a.v * b, a.d * b); }
 PSDR_DEV Dual operator*(float a, const Dual &b) { return Dual(a * b.v, a * b.d); }
@@ -44,7 +64,7 @@ PSDR_DEV Dual operator+(const Dual &a, float b) { return Dual(a.v + b, a.d); }
 PSDR_DEV Dual operator+(float a, const Dual &b) { return Dual(a + b.v, b.d); }
 PSDR_DEV Dual operator-(const Dual &a, float b) { return Dual(a.v - b, a.d); }
 PSDR_DEV Dual operator-(float a, const Dual &b) { return Dual(a - b.v, -b.d); }
-PSDR_DEV Dual operator/(const Dual &a, float b) { return Dual(a.v / b, a.d / b); }
+PSDR_DEV Dual operator/(const Dual &a, float b) { return Dual(a.v / b, a.d * frcp(b)); }
 PSDR_DEV Dual operator/(float a, const Dual &b) { return Dual(a) / b; }
 
 PSDR_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -55,14 +75,19 @@ PSDR_DEV Dual fma_(const Dual &a, float b, const Dual &c) { return Dual(__builti
 PSDR_DEV float sqrt_(float a) { return __builtin_sqrtf(a); }
 PSDR_DEV Dual sqrt_(const Dual &a) {
     float s = __builtin_sqrtf(a.v);
-    return Dual(s, a.d / (2.f * s));
+    return Dual(s, a.d * frcp(2.f * s));
 }
 PSDR_DEV float safe_sqrt(float a) { return __builtin_sqrtf(a > 0.f ? a : 0.f); }
 PSDR_DEV Dual safe_sqrt(const Dual &a) { return (a.v > 0.f) ? sqrt_(a) : Dual(0.f, 0.f); }
 PSDR_DEV float abs_(float a) { return __builtin_fabsf(a); }
 PSDR_DEV Dual abs_(const Dual &a) { return a.v < 0.f ? -a : a; }
 PSDR_DEV float rcp_(float a) { return 1.f / a; }
+// a / b of the WEIGHT arithmetic for either number type (plain `/` is the correctly rounded division of the geometry)
+PSDR_DEV float div_(float a, float b) { return fdiv(a, b); }
 PSDR_DEV Dual rcp_(const Dual &a) { return Dual(1.f) / a; }
+PSDR_DEV Dual div_(const Dual &a, const Dual &b) { const float r = frcp(b.v), q = a.v * r; return Dual(q, (a.d - q * b.d) * r); }
+PSDR_DEV Dual div_(const Dual &a, float b) { const float r = frcp(b); return Dual(a.v * r, a.d * r); }
+PSDR_DEV Dual div_(float a, const Dual &b) { return div_(Dual(a), b); }
 PSDR_DEV float sqr(float a) { return a * a; }
 PSDR_DEV Dual sqr(const Dual &a) { return a * a; }
 PSDR_DEV bool signbit_(float x) { return (__float_as_uint(x) >> 31) != 0u; }
@@ -108,6 +133,10 @@ PSDR_DEV Vec3d cross(const Vec3d &a, const Vec3f &b) { return cross(a, promote(b
 template <typename T> PSDR_DEV T squared_norm(const Vec3<T> &a) { return dot(a, a); }
 template <typename T> PSDR_DEV T norm(const Vec3<T> &a) { return sqrt_(dot(a, a)); }
 template <typename T> PSDR_DEV Vec3<T> normalize(const Vec3<T> &a) { return a * rcp_(sqrt_(dot(a, a))); }
+// v / s of the weight arithmetic
+PSDR_DEV Vec3<float> vdiv_(const Vec3<float> &a, float b) { const float r = frcp(b); return Vec3<float>(a.x * r, a.y * r, a.z * r); }
+PSDR_DEV Vec3<Dual> vdiv_(const Vec3<Dual> &a, const Dual &b) { const Dual r = div_(Dual(1.f), b); return Vec3<Dual>(a.x * r, a.y * r, a.z * r); }
+PSDR_DEV Vec3<Dual> vdiv_(const Vec3<Dual> &a, float b) { const float r = frcp(b); return Vec3<Dual>(a.x * r, a.y * r, a.z * r); }
 template <typename T> PSDR_DEV Vec3<T> madd3(const Vec3<T> &e1, const T &s, const Vec3<T> &e2, const T &t, const Vec3<T> &p0) {
     // reference utils.h:64-67 bilinear(): fmadd(e1, s, fmadd(e2, t, p0))
     return Vec3<T>(fma_(e1.x, s, fma_(e2.x, t, p0.x)), fma_(e1.y, s, fma_(e2.y, t, p0.y)), fma_(e1.z, s, fma_(e2.z, t, p0.z)));

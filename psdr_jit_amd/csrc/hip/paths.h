@@ -80,6 +80,14 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
     static_assert(kColdRows >= 11, "scene_dev.h::kColdRows");
     static_assert(MODE == 0 || !AD, "the primary-edge paths are traced in C mode");
 
+#if PSDR_DIAG == 6
+    // phase timers (wave cycles, every lane adds the same delta): c_rays = fetch + regeneration, c_nodes = drawing the vertex's
+    // two rays, c_tris = trace2, c_hits = consuming the hits + path end
+    unsigned long long t_ph = __builtin_readcyclecounter();
+#define PSDR_PHASE(field) do { if (COUNT) { const unsigned long long t_now = __builtin_readcyclecounter(); S.field += (unsigned) (t_now - t_ph); t_ph = t_now; } } while (0)
+#else
+#define PSDR_PHASE(field) do { } while (0)
+#endif
     for (;;) {
         // ------------------------------------------------------------------ fetch work for idle lanes
         if (q_next >= q_end && !exhausted) {
@@ -118,7 +126,7 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
                         const int ei = sample_reuse(cam.n_edges, cam.edge_sum, [&](int i) { return S.ldf(cam.pecdf_off, i); },
                                                     [&](int i) { return S.ldf(cam.pecdf_off, cam.n_edges + i); }, s, pdf);
                         const float4 r0 = S.ld(cam.pe_off + 3 * ei), r1 = S.ld(cam.pe_off + 3 * ei + 1), r2 = S.ld(cam.pe_off + 3 * ei + 2);
-                        pdf /= r2.z;
+                        pdf = fdiv(pdf, r2.z);
                         const float nx = r2.x, ny = r2.y;
                         const float oms = 1.0f - s;
                         const Dual p0x(r0.x, r1.x), p0y(r0.y, r1.y), p1x(r0.z, r1.z), p1y(r0.w, r1.w);
@@ -139,6 +147,7 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
             }
             q_next += n_need < (int) (q_end - q_next) ? n_need : (q_end - q_next);
         }
+        PSDR_PHASE(c_rays);
         if (__ballot(busy) == 0ull) { if (exhausted && q_next >= q_end) break; continue; }
 
         // ------------------------------------------------------------------ [A] next-event estimation (path.cpp:47-83)
@@ -171,9 +180,11 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
             ext.o = its.p; ext.d = to_world<AD>(its, bs.wo);
         }
         Hit h, hx;
+        PSDR_PHASE(c_nodes);
         // an invalid BSDF sample (e.g. on the BSDF-less bounding cube of the environment map: wo = 0) ends the path whatever
         // its ray hits; a zero-direction ray would wander through every BVH node that contains its origin
         trace2<LDS, COUNT>(S, detach(ray1.o), detach(ray1.d), do_nee, detach(ext.o), detach(ext.d), busy && bs.valid, h, hx);
+        PSDR_PHASE(c_tris);
         {
             if (do_nee && h.slot >= 0) {
                 if (COUNT) S.c_hits++;
@@ -183,11 +194,11 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
                 if constexpr (has_env(LDS)) { if (T.env_emitter >= 0 && mesh_emitter(S, its1.mesh) == T.env_emitter) its1 = make_its<AD, LDS, true>(S, h, ray1, true); }
                 if ((detach(its1.t) > detach(dist) - kShadowEpsilon) && (mesh_emitter(S, its1.mesh) >= 0)) {
                     const R cos_val = dot(its1.n, -wod);
-                    const R G_val = abs_(cos_val) / dist_sqr;
+                    const R G_val = div_(abs_(cos_val), dist_sqr);
                     const V emitter_val = eval_Le<AD, LDS>(S, its1, true);
                     const V wo_local = to_local<AD>(its, wod);
                     V bsdf_val2 = bsdf_eval<AD, LDS>(S, its, wo_local, true);
-                    bsdf_val2 = bsdf_val2 * (G_val * ps.J / R(ps.pdf));
+                    bsdf_val2 = bsdf_val2 * div_(G_val * ps.J, R(ps.pdf));
                     const float pdf1 = bsdf_pdf<AD, LDS>(S, its, wo_local, true) * detach(G_val);
                     if (pdf1 != 0.f) res = res + thr * emitter_val * bsdf_val2 * R(P.mis == 0 ? 1.f : mis_weight(ps.pdf, pdf1));
                 }
@@ -213,16 +224,16 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
                     if constexpr (AD) {
                         V wo = (itx.p - its.p) / itx.t;
                         const R cos_val = dot(itx.n, -wo);
-                        const R G_val = abs_(cos_val) / sqr(itx.t);
+                        const R G_val = div_(abs_(cos_val), sqr(itx.t));
                         pdf0 = bs.pdf * G_val.v;
                         if (itx.t.v < kEpsilon) bsdf_val = V(R(0.f));
-                        else bsdf_val = bsdf_eval<AD, LDS>(S, its, to_local<AD>(its, wo), true) * G_val * itx.J / R(pdf0);
+                        else bsdf_val = bsdf_eval<AD, LDS>(S, its, to_local<AD>(its, wo), true) * div_(G_val * itx.J, R(pdf0));
                     } else {
                         const float cos_val = dot(itx.n, -ext.d);
-                        const float G_val = fabsf(cos_val) / sqr(itx.t);
+                        const float G_val = fdiv(fabsf(cos_val), sqr(itx.t));
                         pdf0 = bs.pdf * G_val;
                         if (itx.t < kEpsilon) bsdf_val = V(0.f);
-                        else bsdf_val = bsdf_eval<AD, LDS>(S, its, bs.wo, true) / bs.pdf;
+                        else bsdf_val = vdiv_(bsdf_eval<AD, LDS>(S, its, bs.wo, true), bs.pdf);
                     }
                     const float weight2 = P.mis == 1 ? 1.f : mis_weight(pdf0, emitter_position_pdf<AD, LDS>(S, detach(its.p), itx));
                     thr = thr * bsdf_val;
@@ -280,7 +291,7 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
                     const Vec3f Lp = detach(res), Ln(cold_f(kLnX), cold_f(kLnY), cold_f(kLnZ));
                     const float edge_xdn_v = cold_f(kXdnV), edge_xdn_d = cold_f(kXdnD), edge_pdf = cold_f(kPdf);
                     const int pix_slot = cold_i(kPix);
-                    const Vec3f dL = (Ln - Lp) / edge_pdf;
+                    const Vec3f dL = vdiv_(Ln - Lp, edge_pdf);
                     const float o3[3] = {dL.x, dL.y, dL.z};
                     if (P.adj_w == nullptr) {
 #pragma unroll
@@ -313,7 +324,9 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
                 }
             }
         }
+        PSDR_PHASE(c_hits);
     }
+#undef PSDR_PHASE
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -373,7 +386,13 @@ PSDR_DEV void run_paths_async(SceneView<LDS> &S, const SensorDev &cam, const Pat
     tr.reset();
     int posted = 0;                       // this lane as an OWNER: which of its vertex's two rays are in the wave's queue
 
+#if PSDR_DIAG == 8
+    unsigned long long t_sh = 0ull;
+#endif
     for (;;) {
+#if PSDR_DIAG == 8
+        if (COUNT) t_sh = __builtin_readcyclecounter();
+#endif
         const unsigned long long m_fly = __ballot(inflight);
         const int n_can = __popcll(__ballot(!inflight && (has_hits || busy || (q_next < q_end) || !exhausted)));
         if (m_fly == 0ull || n_can >= kShadeMin) {
@@ -401,11 +420,11 @@ PSDR_DEV void run_paths_async(SceneView<LDS> &S, const SensorDev &cam, const Pat
                     if constexpr (has_env(LDS)) { if (T.env_emitter >= 0 && mesh_emitter(S, its1.mesh) == T.env_emitter) its1 = make_its<AD, LDS, true>(S, h, ray1, true); }
                     if ((detach(its1.t) > detach(dist) - kShadowEpsilon) && (mesh_emitter(S, its1.mesh) >= 0)) {
                         const R cos_val = dot(its1.n, -wod);
-                        const R G_val = abs_(cos_val) / dist_sqr;
+                        const R G_val = div_(abs_(cos_val), dist_sqr);
                         const V emitter_val = eval_Le<AD, LDS>(S, its1, true);
                         const V wo_local = to_local<AD>(its, wod);
                         V bsdf_val2 = bsdf_eval<AD, LDS>(S, its, wo_local, true);
-                        bsdf_val2 = bsdf_val2 * (G_val * ps.J / R(ps.pdf));
+                        bsdf_val2 = bsdf_val2 * div_(G_val * ps.J, R(ps.pdf));
                         const float pdf1 = bsdf_pdf<AD, LDS>(S, its, wo_local, true) * detach(G_val);
                         if (pdf1 != 0.f) res = res + thr * emitter_val * bsdf_val2 * R(P.mis == 0 ? 1.f : mis_weight(ps.pdf, pdf1));
                     }
@@ -427,16 +446,16 @@ PSDR_DEV void run_paths_async(SceneView<LDS> &S, const SensorDev &cam, const Pat
                         if constexpr (AD) {
                             V wo = (itx.p - its.p) / itx.t;
                             const R cos_val = dot(itx.n, -wo);
-                            const R G_val = abs_(cos_val) / sqr(itx.t);
+                            const R G_val = div_(abs_(cos_val), sqr(itx.t));
                             pdf0 = bs.pdf * G_val.v;
                             if (itx.t.v < kEpsilon) bsdf_val = V(R(0.f));
-                            else bsdf_val = bsdf_eval<AD, LDS>(S, its, to_local<AD>(its, wo), true) * G_val * itx.J / R(pdf0);
+                            else bsdf_val = bsdf_eval<AD, LDS>(S, its, to_local<AD>(its, wo), true) * div_(G_val * itx.J, R(pdf0));
                         } else {
                             const float cos_val = dot(itx.n, -ext.d);
-                            const float G_val = fabsf(cos_val) / sqr(itx.t);
+                            const float G_val = fdiv(fabsf(cos_val), sqr(itx.t));
                             pdf0 = bs.pdf * G_val;
                             if (itx.t < kEpsilon) bsdf_val = V(0.f);
-                            else bsdf_val = bsdf_eval<AD, LDS>(S, its, bs.wo, true) / bs.pdf;
+                            else bsdf_val = vdiv_(bsdf_eval<AD, LDS>(S, its, bs.wo, true), bs.pdf);
                         }
                         const float weight2 = P.mis == 1 ? 1.f : mis_weight(pdf0, emitter_position_pdf<AD, LDS>(S, detach(its.p), itx));
                         thr = thr * bsdf_val;
@@ -485,7 +504,7 @@ PSDR_DEV void run_paths_async(SceneView<LDS> &S, const SensorDev &cam, const Pat
                         }
                     } else {
                         const Vec3f Lp = detach(res);
-                        const Vec3f dL = (Ln - Lp) / edge_pdf;
+                        const Vec3f dL = vdiv_(Ln - Lp, edge_pdf);
                         const float o3[3] = {dL.x, dL.y, dL.z};
                         if (P.adj_w == nullptr) {
 #pragma unroll
@@ -547,7 +566,7 @@ PSDR_DEV void run_paths_async(SceneView<LDS> &S, const SensorDev &cam, const Pat
                             const int ei = sample_reuse(cam.n_edges, cam.edge_sum, [&](int i) { return S.ldf(cam.pecdf_off, i); },
                                                         [&](int i) { return S.ldf(cam.pecdf_off, cam.n_edges + i); }, s, pdf);
                             const float4 r0 = S.ld(cam.pe_off + 3 * ei), r1 = S.ld(cam.pe_off + 3 * ei + 1), r2 = S.ld(cam.pe_off + 3 * ei + 2);
-                            pdf /= r2.z;
+                            pdf = fdiv(pdf, r2.z);
                             const float nx = r2.x, ny = r2.y;
                             const float oms = 1.0f - s;
                             const Dual p0x(r0.x, r1.x), p0y(r0.y, r1.y), p1x(r0.z, r1.z), p1y(r0.w, r1.w);
@@ -598,6 +617,9 @@ PSDR_DEV void run_paths_async(SceneView<LDS> &S, const SensorDev &cam, const Pat
             }
             if (__ballot(busy || inflight) == 0ull && exhausted && q_next >= q_end) break;
         }
+#if PSDR_DIAG == 8
+        if (COUNT) S.c_rays += (unsigned) (__builtin_readcyclecounter() - t_sh);
+#endif
         // -------------------------------------------------------------------- traversal: until enough lanes have finished
         {
             const int n_fly = __popcll(__ballot(inflight));

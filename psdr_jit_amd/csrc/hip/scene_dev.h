@@ -314,7 +314,20 @@ PSDR_DEV void trace2(SceneView<LDS> &S, const Vec3f &oA_, const Vec3f &dA, bool 
     if constexpr (!in_lds(LDS)) { if (T.n_tris > kBruteForceMax) { bvh4_trace2<LDS, COUNT>(S, oA_, dA, actA, oB_, dB, actB, hA, hB); return; } }
     const float qnan = __builtin_nanf("");
     const Vec3f oA = actA ? oA_ : Vec3f(qnan), oB = actB ? oB_ : Vec3f(qnan);
+#if PSDR_DIAG != 6 && PSDR_DIAG != 7 && PSDR_DIAG != 9
     if (COUNT) { const unsigned n = (actA ? 1u : 0u) + (actB ? 1u : 0u); S.c_rays += n; S.c_tris += n * (unsigned) T.n_tris; }
+#endif
+#if PSDR_DIAG == 7
+    // phase timers inside the brute-force tracer (wave cycles): c_rays = set-up, c_nodes = filter loop, c_tris = exact rounds, c_hits = number of exact rounds
+    unsigned long long t_ph = __builtin_readcyclecounter();
+#define PSDR_TPHASE(field) do { if (COUNT) { const unsigned long long t_now = __builtin_readcyclecounter(); S.field += (unsigned) (t_now - t_ph); t_ph = t_now; } } while (0)
+#else
+#define PSDR_TPHASE(field) do { } while (0)
+#endif
+#if PSDR_DIAG == 9
+    // candidate statistics: c_rays = candidates (triangles handed to the exact test), c_nodes = active rays, c_tris = exact rounds (x 64), c_hits = calls (x 64)
+    if (COUNT) { S.c_nodes += (actA ? 1u : 0u) + (actB ? 1u : 0u); S.c_hits++; }
+#endif
     // Both rays ride in the two halves of packed-f32 registers (element-wise identical to the scalar instructions).
     //
     // Two phases.  The exact test spends more than half of its issue cycles on the IEEE division and on eight
@@ -339,6 +352,7 @@ PSDR_DEV void trace2(SceneView<LDS> &S, const Vec3f &oA_, const Vec3f &dA, bool 
     const f2 s_ray = {norm(ocA) + T.radius + kmax, norm(ocB) + T.radius + kmax};
     float btA = __builtin_inff(), btB = __builtin_inff();
     int bidA = 0x7fffffff, bidB = 0x7fffffff;
+    PSDR_TPHASE(c_rays);
     for (int base = 0; base < T.n_filt; base += 32) {
         const int cnt = T.n_filt - base < 32 ? T.n_filt - base : 32;
         unsigned aA = 0u, bA = 0u, aB = 0u, bB = 0u;
@@ -372,9 +386,18 @@ PSDR_DEV void trace2(SceneView<LDS> &S, const Vec3f &oA_, const Vec3f &dA, bool 
             }
         }
         bA &= T.filt_hasb[base >> 5]; bB &= T.filt_hasb[base >> 5];
+        PSDR_TPHASE(c_nodes);
+#if PSDR_DIAG == 9
+        if (COUNT) S.c_rays += (unsigned) (__builtin_popcount(aA) + __builtin_popcount(bA) + __builtin_popcount(aB) + __builtin_popcount(bB));
+#endif
         for (;;) {
             const bool moreA = (aA | bA) != 0u, moreB = (aB | bB) != 0u;
             if (__ballot(moreA || moreB) == 0ull) break;
+#if PSDR_DIAG == 7
+            if (COUNT) S.c_hits++;
+#elif PSDR_DIAG == 9
+            if (COUNT) S.c_tris++;
+#endif
             int pA = 0, pB = 0, shA = 0, shB = 0;
             if (aA != 0u) { pA = __builtin_ctz(aA); aA &= aA - 1u; } else if (bA != 0u) { pA = __builtin_ctz(bA); bA &= bA - 1u; shA = 8; }
             if (aB != 0u) { pB = __builtin_ctz(aB); aB &= aB - 1u; } else if (bB != 0u) { pB = __builtin_ctz(bB); bB &= bB - 1u; shB = 8; }
@@ -403,7 +426,9 @@ PSDR_DEV void trace2(SceneView<LDS> &S, const Vec3f &oA_, const Vec3f &dA, bool 
             if (betA) { btA = t.x; bidA = idA; hA.slot = kA; hA.u = u.x; hA.v = v.x; hA.t = t.x; }
             if (betB) { btB = t.y; bidB = idB; hB.slot = kB; hB.u = u.y; hB.v = v.y; hB.t = t.y; }
         }
+        PSDR_TPHASE(c_tris);
     }
+#undef PSDR_TPHASE
 }
 
 } // namespace psdr

@@ -184,7 +184,9 @@ template <int LDS> PSDR_DEV int mesh_emitter(const SceneView<LDS> &S, int mesh) 
 template <int LDS> PSDR_DEV int mesh_bsdf(const SceneView<LDS> &S, int mesh) { return __float_as_int(S.ld(S.T->mesh_off + 2 * mesh).x); }
 
 // DiscreteDistribution::sample_reuse, reference src/core/pmf.cpp:26-45 (size 1 leaves the sample untouched)
-template <typename PmfFn, typename CmfFn>
+// EXACT: a correctly rounded pdf as well (the environment-map sampler, which psdr_hip_env_sample exposes for bit-exact comparison);
+// everywhere else the pdf is weight arithmetic (dmath.h)
+template <bool EXACT = false, typename PmfFn, typename CmfFn>
 PSDR_DEV int sample_reuse(int size, float sum, PmfFn pmf, CmfFn cmf, float &s, float &pdf) {
     if (size == 1) { pdf = 1.f; return 0; }
     s *= sum;
@@ -193,9 +195,9 @@ PSDR_DEV int sample_reuse(int size, float sum, PmfFn pmf, CmfFn cmf, float &s, f
     const int idx = lo;
     if (idx > 0) s -= cmf(idx - 1);
     const float p = pmf(idx);
-    if (p > 0.f) s /= p;
+    if (p > 0.f) s /= p;                                 // (the re-used sample places the next point: geometry)
     s = fminf(fmaxf(s, 0.f), 1.f);
-    pdf = p / sum;
+    pdf = EXACT ? p / sum : fdiv(p, sum);
     return idx;
 }
 
@@ -252,7 +254,7 @@ template <bool AD, int LDS> PSDR_DEV VecN<AD> env_eval_direction(const SceneView
 PSDR_DEV float env_position_pdf(const EnvDev &E, const Vec3f &ref_p, const Vec3f &p, const Vec3f &n) {
     Vec3f d = p - ref_p;
     const float dist2 = squared_norm(d);
-    d = d / safe_sqrt(dist2);
+    { const float len = __builtin_sqrtf(dist2 > 0.f ? dist2 : 0.f); d = Vec3f(d.x / len, d.y / len, d.z / len); }      // (correctly rounded: psdr_hip_env_pdf is compared bit for bit)
     const float G = fabsf(dot(d, n)) / dist2;
     d = xform_dir(E.from_world, d);
     const float factor = G * (1.f / sqrtf(fmaxf(fma_(d.x, d.x, d.z * d.z), kEpsilon * kEpsilon))) * (.5f / (kPi * kPi));
@@ -268,7 +270,7 @@ PSDR_DEV float env_position_pdf(const EnvDev &E, const Vec3f &ref_p, const Vec3f
 // cube_distrb.cpp:42-49), carried to the scene box (utils.h:145-164); everything detached
 PSDR_DEV void env_sample_position(const EnvDev &E, const Vec3f &ref_p, float sx, float sy, Vec3f &p_out, Vec3f &n_out, float &pdf_out) {
     float pdf;
-    const int idx = sample_reuse(E.num_cells, E.cell_sum, [&](int i) { return E.cell_pmf[i]; }, [&](int i) { return E.cell_cmf[i]; }, sy, pdf);
+    const int idx = sample_reuse<true>(E.num_cells, E.cell_sum, [&](int i) { return E.cell_pmf[i]; }, [&](int i) { return E.cell_cmf[i]; }, sy, pdf);
     const int cx = idx / E.reso1, cy = idx - cx * E.reso1;
     sx = (sx + (float) cx) * (1.f / (float) E.reso0);
     sy = (sy + (float) cy) * (1.f / (float) E.reso1);
@@ -315,12 +317,14 @@ template <bool AD> struct PositionSample { VecN<AD> p, n; Num<AD> J; float pdf; 
 
 // Scene::sample_emitter_position -> AreaLight::sample_position -> Mesh::__sample_position
 // reference scene.cpp:987-1013, mesh.cpp:413-454, warp.h:79-82
-template <bool AD, int LDS> PSDR_DEV PositionSample<AD> sample_emitter_position(const SceneView<LDS> &S, const Vec3f &ref_p, float sx, float sy) {
+// EXACT: correctly rounded pdfs - the secondary-edge term's values fill the guiding grid, whose running sums are SAMPLED from: there a
+// weight becomes geometry (edges.h)
+template <bool AD, int LDS, bool EXACT = false> PSDR_DEV PositionSample<AD> sample_emitter_position(const SceneView<LDS> &S, const Vec3f &ref_p, float sx, float sy) {
     const SceneTables &T = *S.T;
     float epdf = 1.f;
     int ei = 0;
     if (T.n_emitters > 1) {
-        ei = sample_reuse(T.n_emitters, T.emitter_sum,
+        ei = sample_reuse<EXACT>(T.n_emitters, T.emitter_sum,
                           [&](int i) { return S.ldf(T.ecdf_off, i); },
                           [&](int i) { return S.ldf(T.ecdf_off, T.n_emitters + i); }, sy, epdf);
     }
@@ -339,7 +343,7 @@ template <bool AD, int LDS> PSDR_DEV PositionSample<AD> sample_emitter_position(
     const int mesh = __float_as_int(S.ld(T.emit_off + 2 * ei + 1).w);
     const MeshRec m = load_mesh(S, mesh);
     float fpdf;
-    const int fi = sample_reuse(m.n_faces, m.distrb_sum,
+    const int fi = sample_reuse<EXACT>(m.n_faces, m.distrb_sum,
                                 [&](int i) { return S.ldf(T.fcdf_off, m.distrb_offset + i); },
                                 [&](int i) { return S.ldf(T.fcdf_off, T.n_fcdf + m.distrb_offset + i); }, sx, fpdf);
     const float tt = safe_sqrt(1.f - sx);
@@ -780,7 +784,7 @@ template <bool AD, int LDS> PSDR_DEV VecN<AD> first_hit_value(const SceneView<LD
     }
 }
 
-PSDR_DEV float mis_weight(float p1, float p2) { const float w1 = p1 * p1, w2 = p2 * p2; return w1 / (w1 + w2); }   // reference utils.h:277-281
+PSDR_DEV float mis_weight(float p1, float p2) { const float w1 = p1 * p1, w2 = p2 * p2; return fdiv(w1, w1 + w2); }   // reference utils.h:277-281
 
 // ---------------------------------------------------------------- PathTracer::__Li, reference src/integrator/path.cpp:35-127
 // Consumes exactly 5*max_depth draws of `rng` whatever the path does (the reference draws for masked lanes too).
@@ -814,11 +818,11 @@ PSDR_DEV VecN<AD> Li(SceneView<LDS> &S, LaneRng &rng, const RayT<AD> &ray_in, bo
                 bool active_direct = its1.valid && (detach(its1.t) > detach(dist) - kShadowEpsilon) && (mesh_emitter(S, its1.mesh) >= 0);
                 if (active_direct) {
                     const R cos_val = dot(its1.n, -wod);
-                    const R G_val = abs_(cos_val) / dist_sqr;
+                    const R G_val = div_(abs_(cos_val), dist_sqr);
                     const V emitter_val = eval_Le<AD, LDS>(S, its1, true);
                     const V wo_local = to_local<AD>(its, wod);
                     V bsdf_val2 = bsdf_eval<AD, LDS>(S, its, wo_local, true);
-                    bsdf_val2 = bsdf_val2 * (G_val * ps.J / R(ps.pdf));
+                    bsdf_val2 = bsdf_val2 * div_(G_val * ps.J, R(ps.pdf));
                     const float pdf1 = bsdf_pdf<AD, LDS>(S, its, wo_local, true) * detach(G_val);
                     if (pdf1 != 0.f) {
                         const float weight1 = mis == 0 ? 1.f : mis_weight(ps.pdf, pdf1);
@@ -840,16 +844,16 @@ PSDR_DEV VecN<AD> Li(SceneView<LDS> &S, LaneRng &rng, const RayT<AD> &ray_in, bo
             if constexpr (AD) {
                 V wo = (its1.p - its.p) / its1.t;
                 const R cos_val = dot(its1.n, -wo);
-                const R G_val = abs_(cos_val) / sqr(its1.t);
+                const R G_val = div_(abs_(cos_val), sqr(its1.t));
                 pdf0 = bs.pdf * G_val.v;
                 if (its1.t.v < kEpsilon) bsdf_val = V(R(0.f));
-                else bsdf_val = bsdf_eval<AD, LDS>(S, its, to_local<AD>(its, wo), true) * G_val * its1.J / R(pdf0);
+                else bsdf_val = bsdf_eval<AD, LDS>(S, its, to_local<AD>(its, wo), true) * div_(G_val * its1.J, R(pdf0));
             } else {
                 const float cos_val = dot(its1.n, -curr.d);
-                const float G_val = fabsf(cos_val) / sqr(its1.t);
+                const float G_val = fdiv(fabsf(cos_val), sqr(its1.t));
                 pdf0 = bs.pdf * G_val;
                 if (its1.t < kEpsilon) bsdf_val = V(0.f);
-                else bsdf_val = bsdf_eval<AD, LDS>(S, its, bs.wo, true) / bs.pdf;
+                else bsdf_val = vdiv_(bsdf_eval<AD, LDS>(S, its, bs.wo, true), bs.pdf);
             }
             const float weight2 = mis == 1 ? 1.f : mis_weight(pdf0, emitter_position_pdf<AD, LDS>(S, detach(its.p), its1));
             throughput = throughput * bsdf_val;

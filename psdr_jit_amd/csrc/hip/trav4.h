@@ -150,13 +150,17 @@ template <int LDS, bool COUNT> PSDR_DEV void t4_start(SceneView<LDS> &S, const T
     tr.anyhit = (rid & 64) ? -__builtin_inff() : L.park0[owner + 12 * kBlock];
     const bool ok = (o.x == o.x && o.y == o.y && o.z == o.z && d.x == d.x && d.y == d.y && d.z == d.z);
     tr.code = ok ? 0u : kT4Done;       // node 0 = root
+#if PSDR_DIAG != 8
     if (COUNT) { if (ok) S.c_rays++; }
+#endif
 }
 
 // one inner node for the workers whose code is an inner node
 template <int LDS, bool COUNT> PSDR_DEV void t4_node(SceneView<LDS> &S, const T4Lds<LDS> &L, Trav4 &tr, unsigned cmask) {
     const SceneTables &T = *S.T;
+#if PSDR_DIAG != 8
     if (COUNT) S.c_nodes++;
+#endif
     const float bt = t4_best_t(L.best, tr.rid);                               // closest hit so far (tested pairs only)
     if (bt < tr.anyhit) { tr.sp = 0; tr.code = kT4Done; return; }              // shadow ray: an occluder has been found
     const float ox = tr.o.x, oy = tr.o.y, oz = tr.o.z, ix = tr.inv.x, iy = tr.inv.y, iz = tr.inv.z;
@@ -254,7 +258,9 @@ template <int LDS, bool COUNT> PSDR_DEV void t4_test_pairs(SceneView<LDS> &S, co
         const int w = T.trav_off + 3 * slot;
         const float4 a = S.ld(w), b = S.ld(w + 1), c = S.ld(w + 2);
         float t;
+#if PSDR_DIAG != 8
         if (COUNT) S.c_tris++;
+#endif
         hit = tri_test(a, b, c, o, d, u, v, t);
         if (hit) {
             key = ((unsigned long long) __float_as_uint(t) << 32) | (unsigned long long) (unsigned) __float_as_int(c.y);
@@ -294,6 +300,13 @@ PSDR_DEV bool trav4_run(SceneView<LDS> &S, Trav4 &tr, int posted, int max_busy) 
     const unsigned long long lt_mask = (1ull << lane_id) - 1ull, m_all = __ballot(true);
     const int n_lanes = __popcll(m_all), first = (int) __builtin_ctzll(m_all);
     bool done = true;
+#if PSDR_DIAG == 8
+    // phase timers (wave cycles): c_nodes = node bursts, c_tris = pair tests, c_hits = ray hand-over and bookkeeping (c_rays: the shading phase, paths.h)
+    unsigned long long t_ph = __builtin_readcyclecounter();
+#define PSDR_T4PHASE(field) do { if (COUNT) { const unsigned long long t_now = __builtin_readcyclecounter(); S.field += (unsigned) (t_now - t_ph); t_ph = t_now; } } while (0)
+#else
+#define PSDR_T4PHASE(field) do { } while (0)
+#endif
     for (;;) {
         wave_sync();
         const unsigned tested = L.heads[kHdPairTested];
@@ -324,6 +337,7 @@ PSDR_DEV bool trav4_run(SceneView<LDS> &S, Trav4 &tr, int posted, int max_busy) 
                 if (f == 0u) done = false;
                 else if ((int) (f - 1u - tested) > 0) { done = false; wait_pairs = true; }
             }
+        PSDR_T4PHASE(c_hits);
         if (__popcll(__ballot(!done)) <= max_busy) break;
         // traversal burst: until the ring holds a wave's worth of pairs, or nobody has a node in hand
         const unsigned long long m_walk = __ballot(tr.code != kT4Done);
@@ -341,6 +355,7 @@ PSDR_DEV bool trav4_run(SceneView<LDS> &S, Trav4 &tr, int posted, int max_busy) 
                 if (avail > n_lanes / 4 && __popcll(__ballot(tr.code == kT4Done)) >= n_lanes / 4) break;
             }
         }
+        PSDR_T4PHASE(c_nodes);
         // test the waiting pairs, a wave's worth at a time; the partial last batch only when a finished walk is waiting for it
         {
             unsigned from = tested;
@@ -353,7 +368,9 @@ PSDR_DEV bool trav4_run(SceneView<LDS> &S, Trav4 &tr, int posted, int max_busy) 
             wave_sync();
             if (lane_id == first) L.heads[kHdPairTested] = from;
         }
+        PSDR_T4PHASE(c_tris);
     }
+#undef PSDR_T4PHASE
     return done;
 }
 
