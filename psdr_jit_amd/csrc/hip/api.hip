@@ -143,6 +143,8 @@ __global__ __launch_bounds__(kBlock) void k_interior_adjoint_mat(const float4 *_
 
 struct GuidingDev {          // HyperCubeDistribution<3>, reference src/core/cube_distrb.cpp:10-64
     const float *pmf, *cmf;
+    const int *guide;        // search bounds per sample bucket (shade.h::sample_reuse_guided), [guide_n + 1]; guide_n = 0: none
+    int guide_n;
     float sum;
     int reso[3], num_cells;
     float unit[3];
@@ -150,7 +152,7 @@ struct GuidingDev {          // HyperCubeDistribution<3>, reference src/core/cub
 
 PSDR_DEV float guiding_sample_reuse(const GuidingDev &G, Vec3f &s) {
     float pdf;
-    const int idx = sample_reuse<true>(G.num_cells, G.sum, [&](int i) { return G.pmf[i]; }, [&](int i) { return G.cmf[i]; }, s.z, pdf);
+    const int idx = sample_reuse_guided<true>(G.guide, G.guide_n, G.num_cells, G.sum, [&](int i) { return G.pmf[i]; }, [&](int i) { return G.cmf[i]; }, s.z, pdf);
     const int c0 = idx / (G.reso[1] * G.reso[2]);
     const int rem = idx - c0 * (G.reso[1] * G.reso[2]);
     const int c1 = rem / G.reso[2], c2 = rem - c1 * G.reso[2];
@@ -608,9 +610,24 @@ struct ScratchGuard {
 
 struct psdr_hip_guiding {
     GuidingDev G{};
-    DevBuf pmf, cmf;
+    DevBuf pmf, cmf, guide;
     std::vector<float> mass;
 };
+
+// Guide table of a discrete distribution (shade.h::sample_reuse_guided): entry k = the index DiscreteDistribution::sample_reuse finds for the
+// sample k / n_buckets, in the kernels' own float arithmetic (s * sum, then the first i < size - 1 whose running sum is not < s, else size - 1).
+// n_buckets: the power of two nearest to size / 16 (at least 1); tables below 256 entries are not worth one (-> empty).
+static void build_cdf_guide(const float *cmf, int size, float sum, std::vector<int> &guide) {
+    guide.clear();
+    if (size < 256) return;
+    int nb = 1;
+    while (nb * 32 <= size) nb <<= 1;
+    guide.resize((size_t) nb + 1);
+    for (int k = 0; k <= nb; ++k) {
+        const float s = ((float) k / (float) nb) * sum;
+        guide[k] = (int) (std::partition_point(cmf, cmf + (size - 1), [s](float c) { return c < s; }) - cmf);
+    }
+}
 
 static inline void put4(std::vector<float> &b, size_t word, float x, float y, float z, float w) { float *q = &b[4 * word]; q[0] = x; q[1] = y; q[2] = z; q[3] = w; }
 static inline float ibits(int32_t v) { float f; std::memcpy(&f, &v, 4); return f; }
@@ -664,6 +681,16 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
         ED.cell_pmf = sc->up(er->cell_pmf, cells, rc);
         ED.cell_cmf = sc->up(er->cell_cmf, cells, rc);
         ED.d_radiance = sc->up(er->d_radiance, (size_t) 3 * er->width * er->height, rc);
+        ED.cell_guide = nullptr; ED.guide_n = 0;
+        {
+            std::vector<int> guide;
+            build_cdf_guide(er->cell_cmf, (int) cells, er->cell_sum, guide);
+            if (!guide.empty()) {
+                sc->bufs.emplace_back(new DevBuf());
+                rc |= sc->bufs.back()->upload(guide.data(), guide.size() * sizeof(int));
+                ED.cell_guide = sc->bufs.back()->as<int>(); ED.guide_n = (int) guide.size() - 1;
+            }
+        }
         if (rc) return 1;
         ED.width = er->width; ED.height = er->height; ED.reso0 = er->reso[0]; ED.reso1 = er->reso[1]; ED.num_cells = (int) cells;
         ED.scale = er->scale; ED.cell_sum = er->cell_sum;
@@ -1447,6 +1474,15 @@ int psdr_hip_guiding_build(const psdr_hip_scene *sc, int32_t sensor_id, int32_t 
     G.sum = sum;
     if (g->pmf.upload(g->mass.data(), sizeof(float) * cells) || g->cmf.upload(cmf.data(), sizeof(float) * cells)) return 1;
     G.pmf = g->pmf.as<float>(); G.cmf = g->cmf.as<float>();
+    {
+        std::vector<int> guide;
+        build_cdf_guide(cmf.data(), (int) cells, sum, guide);
+        G.guide = nullptr; G.guide_n = 0;
+        if (!guide.empty()) {
+            if (g->guide.upload(guide.data(), guide.size() * sizeof(int))) return 1;
+            G.guide = g->guide.as<int>(); G.guide_n = (int) guide.size() - 1;
+        }
+    }
     *out = g.release();
     return 0;
 }

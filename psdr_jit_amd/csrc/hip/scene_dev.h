@@ -25,6 +25,8 @@ constexpr int kTravRows = 32;               // LDS rows (of kBlock words) behind
 struct EnvDev {
     const float *radiance;          // [height*width*3]
     const float *cell_pmf, *cell_cmf;
+    const int *cell_guide;          // search bounds of the cell distribution per bucket of the sample (shade.h::sample_reuse_guided), [guide_n + 1]
+    int guide_n;                    // number of buckets (a power of two), 0 = no table
     int width, height, reso0, reso1, num_cells;
     float scale, cell_sum;
     const float *d_radiance;        // forward tangent of the texels, or NULL

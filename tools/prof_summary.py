@@ -4,7 +4,9 @@ committed under profiles/ (kernel-trace stats + per-kernel PMC averages) and int
 profiles/counters.json, which bench.py reads for roofline.traffic / roofline.issue (PMC counters cannot be
 collected from inside the benchmarked process; the JSON names the summary file it was made from).
 
-    python tools/prof_summary.py <round-tag>          # e.g. r01
+    python tools/prof_summary.py <round-tag>                                  # e.g. r01: the bench.py passes of tools/profile.sh
+    python tools/prof_summary.py <tag> <dir prefix> [section] [workload]       # the passes of tools/profile_cmd.sh <prefix> ...; a section
+                                                                               # name (e.g. config5) adds them to counters.json under that key
 
 HBM bytes per launch follow MI355X_MICROARCH.md §HBM: separate --pmc passes for FETCH_SIZE and
 WRITE_SIZE (KiB); on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x, so it is doubled:
@@ -27,6 +29,8 @@ def short(name):
 
 
 PREFIX = ""
+SECTION = None
+WORKLOAD = None
 
 
 def db_of(d):
@@ -45,7 +49,7 @@ def kernel_stats(tag):
                      "avg(scratch_size) from kernels group by name").fetchall()
     det = {r[0]: r[1:] for r in det}
     with open(os.path.join(PROF, "%s_kernel_trace_stats.txt" % tag), "w") as fh:
-        fh.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline   (MI355X, gfx950)\n")
+        fh.write("# rocprofv3 --kernel-trace --stats   (MI355X, gfx950; command: tools/profile.sh, passes %s*)\n" % (PREFIX or "prof_"))
         fh.write("# durations in us; grid = work-items\n")
         fh.write("%-46s %6s %12s %10s %10s %10s %6s %9s %6s %8s %5s %5s\n" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct", "grid", "wg", "lds_B", "vgpr", "sgpr"))
         for name, calls, total, avg, pct in rows:
@@ -84,8 +88,10 @@ def pmc(tag):
             h, m = cs.get("TCC_HIT_sum", (None, 0))[0], cs.get("TCC_MISS_sum", (None, 0))[0]
             if h is not None and m is not None and h + m > 0:
                 fh.write("    %-28s %18.4f   TCC_HIT/(TCC_HIT+TCC_MISS)\n" % ("L2 hit rate", h / (h + m)))
-    if not PREFIX:          # only the bench.py profile (tools/profile.sh) feeds bench.py's roofline.traffic / roofline.issue
+    if not PREFIX:          # the bench.py profile (tools/profile.sh) feeds bench.py's roofline.traffic / roofline.issue ...
         write_counters_json(tag, per, traffic)
+    elif SECTION:           # ... and a named section (config5) its config-5 object
+        write_counters_json(tag, per, traffic, SECTION, WORKLOAD)
 
 
 def bench_name(k):
@@ -100,14 +106,15 @@ def bench_name(k):
     return None
 
 
-def write_counters_json(tag, per, traffic):
+def write_counters_json(tag, per, traffic, section=None, workload=None):
     db = db_of("prof_kt")
     avg_us = {}
     if db is not None:
         for name, avg in db.execute("select name, average from top_kernels"):
             avg_us[short(name)] = avg
-    out = {"source": "profiles/%s_pmc_summary.txt + profiles/%s_kernel_trace_stats.txt (rocprofv3 --pmc / --kernel-trace --stats passes of "
-                     "`python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-parity`, tools/profile.sh)" % (tag, tag), "kernels": {}}
+    out = {"source": "profiles/%s_pmc_summary.txt + profiles/%s_kernel_trace_stats.txt (rocprofv3 --pmc / --kernel-trace --stats passes, tools/profile.sh)" % (tag, tag), "kernels": {}}
+    if workload:
+        out["workload"] = workload
     for k, cs in per.items():
         b = bench_name(k)
         if b is None:
@@ -117,12 +124,34 @@ def write_counters_json(tag, per, traffic):
             rec["hbm_bytes_per_launch"] = traffic[k]
         g = lambda c: cs.get(c, (None, 0))[0]
         iv, tc, ai, wc = g("SQ_INSTS_VALU"), g("SQ_THREAD_CYCLES_VALU"), g("SQ_ACTIVE_INST_VALU"), g("SQ_WAVE_CYCLES")
+        h, m = g("TCC_HIT_sum"), g("TCC_MISS_sum")
+        if h is not None and m is not None and h + m > 0:
+            rec["l2_hit_rate"] = h / (h + m)
+        if k in avg_us:
+            rec["avg_launch_us"] = avg_us[k]
         if iv is not None and k in avg_us:
             slots = 1024 * 2.4e9 / 2.0 * avg_us[k] * 1e-6          # 1024 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz
             rec["issue"] = {"SQ_INSTS_VALU": iv, "avg_launch_us": avg_us[k], "valu_issue_slots": slots, "valu_issue_frac": iv / slots,
-                            "lane_utilisation": (tc / (64.0 * ai)) if (tc is not None and ai) else None, "SQ_WAVE_CYCLES": wc}
+                            "lane_utilisation": (tc / (64.0 * ai)) if (tc is not None and ai) else None, "SQ_WAVE_CYCLES": wc,
+                            "SQ_WAIT_ANY": g("SQ_WAIT_ANY")}
         out["kernels"][b] = rec
-    with open(os.path.join(PROF, "counters.json"), "w") as fh:
+    path = os.path.join(PROF, "counters.json")
+    if section:
+        try:
+            whole = json.load(open(path))
+        except Exception:
+            whole = {}
+        whole[section] = out
+        out = whole
+    else:
+        try:                                   # keep the named sections of an earlier run until they are rewritten
+            old = json.load(open(path))
+            for key, val in old.items():
+                if key not in ("source", "kernels", "workload"):
+                    out[key] = val
+        except Exception:
+            pass
+    with open(path, "w") as fh:
         json.dump(out, fh, indent=1)
 
 
@@ -130,6 +159,8 @@ if __name__ == "__main__":
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     if len(sys.argv) > 2:
         PREFIX = sys.argv[2]
+    SECTION = sys.argv[3] if len(sys.argv) > 3 else None
+    WORKLOAD = sys.argv[4] if len(sys.argv) > 4 else None
     os.makedirs(PROF, exist_ok=True)
     kernel_stats(tag)
     pmc(tag)
