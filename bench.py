@@ -58,7 +58,7 @@ COUNTERS = os.path.join(ROOT, "profiles", "counters.json")      # written by too
 
 
 def readme_scene(psdr, res, spp):
-    """The reference README's Cornell box (README.md:54-90) through the public API: 8 OBJ meshes, 5 Diffuse BSDFs, one area
+    """The reference README's Cornell box (README.md:54-90) through the public API: 8 meshes (generated from coordinates), 5 Diffuse BSDFs, one area
     light, camera fov 60 at (208, 273, -800), Mesh[0] translated by 100 * P in x."""
     from psdr_jit_amd import FloatD, Matrix4fC, Matrix4fD
     sc = psdr.Scene()
@@ -70,12 +70,13 @@ def readme_scene(psdr, res, spp):
     sc.add_Sensor(sensor)
     for name, rgb in (("light", [0.0, 0.0, 0.0]), ("cat", [0.5, 0.5, 0.5]), ("white", [0.95, 0.95, 0.95]), ("green", [0.20, 0.90, 0.20]), ("red", [0.90, 0.20, 0.20])):
         sc.add_BSDF(psdr.DiffuseBSDF(rgb), name)
-    data = os.path.join(ROOT, "examples", "data", "cbox")
+    import synth
+    obj = synth.write_cornell_box()                  # the eight meshes from coordinates (examples/synth.py), written as OBJ text to a temporary directory
     eye = [[1., 0., 0., 0.], [0., 1., 0., 0.], [0., 0., 1., 0.], [0., 0., 0., 1.]]
-    sc.add_Mesh(os.path.join(data, "cbox_luminaire.obj"), Matrix4fC([[1., 0., 0., 0.], [0., 1., 0., -0.5], [0., 0., 1., 0.], [0., 0., 0., 1.]]), "light",
+    sc.add_Mesh(obj["luminaire"], Matrix4fC([[1., 0., 0., 0.], [0., 1., 0., -0.5], [0., 0., 1., 0.], [0., 0., 0., 1.]]), "light",
                 psdr.AreaLight([20.0, 20.0, 8.0]))
     for f, b in (("smallbox", "cat"), ("largebox", "cat"), ("floor", "white"), ("ceiling", "white"), ("back", "white"), ("greenwall", "green"), ("redwall", "red")):
-        sc.add_Mesh(os.path.join(data, "cbox_%s.obj" % f), Matrix4fC(eye), b, None)
+        sc.add_Mesh(obj[f], Matrix4fC(eye), b, None)
     P = FloatD(0.).requires_grad_()
     sc.param_map["Mesh[0]"].set_transform(Matrix4fD([[1., 0., 0., P * 100], [0., 1., 0., 0.], [0., 0., 1., 0.], [0., 0., 0., 1.]]))
     sc.configure()

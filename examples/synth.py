@@ -72,8 +72,79 @@ def config5_scene(psdr, res=1024, spp=64, level=6, env_res=(1024, 512)):
     blob.load_raw(v, f, np.zeros((0, 2), np.float32), np.zeros((0, 3), np.int32))
     blob.to_world = Matrix4fC([[1., 0., 0., 278.], [0., 1., 0., 160.], [0., 0., 1., 280.], [0., 0., 0., 1.]])
     sc.add_Mesh(blob, "blob", None)
-    sc.add_Mesh(os.path.join(DATA, "cbox", "cbox_floor.obj"), Matrix4fC([[1., 0., 0., 0.], [0., 1., 0., 0.], [0., 0., 1., 0.], [0., 0., 0., 1.]]), "white", None)
+    sc.add_Mesh(write_cornell_box()["floor"], Matrix4fC([[1., 0., 0., 0.], [0., 1., 0., 0.], [0., 0., 1., 0.], [0., 0., 0., 1.]]), "white", None)
     sc.add_EnvironmentMap(psdr.EnvironmentMap(synthetic_envmap(env_res[0], env_res[1])))
     sc.configure()
     sc.configure([0])
     return sc, sc.param_map["BSDF[0]"].reflectance
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The README's Cornell box from coordinates: the eight meshes of the reference README example as literal vertex / texture-
+# coordinate / face lists - the classic Cornell-box measurements (552.8 x 548.8 x 559.2 room, the two blocks, the 130 x 105 luminaire)
+# in the decimal spelling psdr-jit's tutorial data uses, so that float parsing gives the same bits.  bench.py and tests/scenes.py build
+# the C3 / C4 workload from write_cornell_box(), not from files shipped with the reference.
+CORNELL_BOX = {
+    "luminaire": {
+        "v": ["343 540.79999 227", "343 540.79999 332", "213 540.79999 332", "213 540.79999 227"],
+        "f": ["1 2 3 4"],
+    },
+    "smallbox": {
+        "v": ["130.000000 165.000000 65.000000", "82.000000 165.000000 225.000000", "240.000000 165.000000 272.000000", "290.000000 165.000000 114.000000", "290.000000 0.000000 114.000000", "240.000000 0.000000 272.000000", "130.000000 0.000000 65.000000", "82.000000 0.000000 225.000000"],
+        "f": ["1 2 3", "1 3 4", "5 4 3", "5 3 6", "7 1 4", "7 4 5", "8 2 1", "8 1 7", "6 3 2", "6 2 8", "5 6 8", "5 8 7"],
+    },
+    "largebox": {
+        "v": ["423.000000 329.999969 247.000061", "265.000000 329.999939 296.000061", "314.000000 329.999939 456.000061", "472.000000 329.999939 406.000061", "423.000000 -0.000040 247.000000", "472.000000 -0.000066 406.000000", "314.000000 -0.000074 456.000000", "265.000000 -0.000048 296.000000"],
+        "vt": ["0.994838 0.753967", "0.663615 0.753540", "0.663030 0.500000", "0.994838 0.501892", "0.335054 0.500000", "0.335054 0.000000", "0.668172 0.000000", "0.668172 0.500000", "1.000000 0.000000", "1.000000 0.500000", "0.335054 0.000000", "0.335054 0.500000", "0.000000 0.500000", "0.000000 0.000000", "0.000000 1.000000", "0.331223 0.500000", "0.331223 1.000000", "0.663030 0.752075", "0.331223 0.753998", "0.331808 0.500458", "0.663030 0.500000"],
+        "f": ["1/1 2/2 3/3", "1/1 3/3 4/4", "5/5 1/6 4/7", "5/5 4/7 6/8", "6/8 4/7 3/9", "6/8 3/9 7/10", "7/11 3/12 2/13", "7/11 2/13 8/14", "8/15 2/13 1/16", "8/15 1/16 5/17", "6/18 7/19 8/20", "6/18 8/20 5/21"],
+    },
+    "floor": {
+        "v": ["552.79999 0 0", "0 0 0", "0 0 559.20001", "549.59998 0 559.20001", "130 0 65", "82 0 225", "240 0 272", "290 0 114", "423 0 247", "265 0 296", "314 0 456", "472 0 406"],
+        "f": ["1 2 3 4"],
+    },
+    "ceiling": {
+        "v": ["556 548.79999 0", "556 548.79999 559.20001", "0 548.79999 559.20001", "0 548.79999 0"],
+        "f": ["1 2 3 4"],
+    },
+    "back": {
+        "v": ["549.599976 -0.000091 559.200012", "0.000000 -0.000091 559.200012", "0.000000 548.799927 559.200073", "556.000000 548.799927 559.200073"],
+        "vt": ["0.987061 0.011536", "0.987061 1.000000", "0.000000 1.000000", "0.000000 0.000000"],
+        "f": ["1/1 2/2 3/3 4/4"],
+    },
+    "greenwall": {
+        "v": ["0 0 559.20001", "0 0 0", "0 548.79999 0", "0 548.79999 559.20001"],
+        "f": ["1 2 3 4"],
+    },
+    "redwall": {
+        "v": ["552.79999 0 0", "549.59998 0 559.20001", "556 548.79999 559.20001", "556 548.79999 0"],
+        "f": ["1 2 3 4"],
+    },
+}
+
+
+def cornell_box_obj(name):
+    """Wavefront OBJ text of one mesh of the README scene (luminaire, smallbox, largebox, floor, ceiling, back, greenwall, redwall)"""
+    m = CORNELL_BOX[name]
+    lines = ["o cbox_%s" % name] + ["v " + s for s in m["v"]] + ["vt " + s for s in m.get("vt", [])] + ["f " + s for s in m["f"]]
+    return "\n".join(lines) + "\n"
+
+
+_cbox_dir = None
+
+
+def write_cornell_box(dirpath=None):
+    """Writes the eight meshes as cbox_<name>.obj (into a fresh temporary directory by default, once per process) -> {name: path}"""
+    global _cbox_dir
+    import tempfile
+    if dirpath is None:
+        if _cbox_dir is None or not os.path.isdir(_cbox_dir):
+            _cbox_dir = tempfile.mkdtemp(prefix="psdr_cbox_")
+        dirpath = _cbox_dir
+    os.makedirs(dirpath, exist_ok=True)
+    paths = {}
+    for name in CORNELL_BOX:
+        paths[name] = os.path.join(dirpath, "cbox_%s.obj" % name)
+        if not os.path.exists(paths[name]):
+            with open(paths[name], "w") as fh:
+                fh.write(cornell_box_obj(name))
+    return paths

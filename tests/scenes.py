@@ -12,7 +12,8 @@ import numpy as np
 from oracle.oracle import BsdfSpec, CameraSpec, EmitterSpec, MeshSpec, SceneSpec
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
-from synth import icosphere, synthetic_envmap                # noqa: E402,F401  (file-less inputs shared with bench.py's config-5 leg)
+import synth                                                # noqa: E402  (file-less inputs shared with bench.py)
+from synth import icosphere, synthetic_envmap                # noqa: E402,F401
 
 DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "data", "cbox")
 
@@ -50,6 +51,9 @@ def translate(x, y, z):
 
 def _mesh(name, bsdf, emitter=-1, raw=None):
     path = os.path.join(DATA, name)
+    stem = name[len("cbox_"):-len(".obj")] if name.startswith("cbox_") and name.endswith(".obj") else None
+    if stem in synth.CORNELL_BOX:                 # the README's eight meshes come from coordinates (examples/synth.py), not from shipped files
+        path = synth.write_cornell_box()[stem]
     v, f, uv, fuv = load_obj(path)
     m = MeshSpec(vertices=v, faces=f, uvs=uv, face_uvs=fuv, bsdf=bsdf, emitter=emitter, path=path)
     if raw is not None:

@@ -523,3 +523,19 @@ def test_roughconductor_constructor_overloads(psdr):
     assert np.allclose(one(b, "alpha_v"), 0.01) and np.allclose(one(b, "k"), [4.83181, 3.12296, 2.1486])
     with pytest.raises(ValueError):
         psdr.RoughConductorBSDF(0.1, 1.5, 2.0, [1.0, 1.0, 1.0])          # scalar eta or alpha_v?
+
+
+def test_cornell_box_from_coordinates_equals_the_tutorial_files():
+    """bench.py and tests/scenes.py build the README scene from examples/synth.py's coordinate lists; they parse to the arrays of
+    the Cornell-box files of the reference's tutorials (kept under examples/data for the tutorials' other scenes)"""
+    import synth
+    paths = synth.write_cornell_box()
+    assert sorted(paths) == sorted(["luminaire", "smallbox", "largebox", "floor", "ceiling", "back", "greenwall", "redwall"])
+    n_tri = 0
+    for name, path in paths.items():
+        a = scenes.load_obj(path)
+        b = scenes.load_obj(os.path.join(ROOT, "examples", "data", "cbox", "cbox_%s.obj" % name))
+        for x, y in zip(a, b):
+            assert (x is None and y is None) or np.array_equal(x, y), name
+        n_tri += a[1].shape[0]
+    assert n_tri == 36
