@@ -81,7 +81,7 @@ struct Trav4 {
 
 // per-lane / per-wave views of the LDS rows above
 template <int LDS> struct T4Lds {
-    lds_int_t *stack;           // this lane's stack, stride kBlock
+    lds_int_t *stack0;          // row 0 of the workgroup's stack area (lane t: stack0 + t, stride kBlock; wave-uniform)
     lds_float_t *park;          // this lane's parked rays, stride kBlock
     lds_float_t *park0;         // lane 0 of this WAVE (owner lane l: park0 + l)
     lds_u64_t *best;            // this wave's kRayCap entries
@@ -94,7 +94,7 @@ template <int LDS> struct T4Lds {
         const int rows = S.T->stack_lds;
         lds_int_t *base = (lds_int_t *) (S.stack - threadIdx.x);          // row 0 of the workgroup's stack area
         const int wave = threadIdx.x >> 6;
-        stack = base + threadIdx.x;
+        stack0 = base;
         park = (lds_float_t *) (base + rows * kBlock + threadIdx.x);
         park0 = (lds_float_t *) (base + rows * kBlock + (wave << 6));
         best = (lds_u64_t *) (base + (rows + kRowBest) * kBlock) + wave * kRayCap;
@@ -107,9 +107,16 @@ template <int LDS> struct T4Lds {
 };
 constexpr int kHitStride = 2 * kBlock;         // words between the slot / u / v arrays of `hit0`
 
+// This lane's stack base, recomputed from the thread index where it is used: kept in a register across the whole kernel it is one of the
+// values the allocator spills, and a push then starts with a scratch load and a full s_waitcnt vmcnt(0) (three per node step, seen in the ISA)
+template <int LDS> PSDR_DEV lds_int_t *t4_stack_base(const T4Lds<LDS> &L) {
+    unsigned tid;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(tid) : "v"(threadIdx.x));
+    return L.stack0 + tid;
+}
 template <int LDS> PSDR_DEV void t4_push(const SceneView<LDS> &S, const T4Lds<LDS> &L, int &sp, unsigned key) {
     const SceneTables &T = *S.T;
-    if (sp < T.stack_lds) L.stack[sp * kBlock] = (int) key;
+    if (sp < T.stack_lds) t4_stack_base(L)[sp * kBlock] = (int) key;
     else ((glb_int_t *) T.gstack)[(size_t) (sp - T.stack_lds) * T.gstack_stride + (size_t) blockIdx.x * kBlock + threadIdx.x] = (int) key;
     ++sp;
 }
@@ -117,7 +124,7 @@ template <int LDS> PSDR_DEV unsigned t4_pop(const SceneView<LDS> &S, const T4Lds
     const SceneTables &T = *S.T;
     --sp;
     unsigned key;
-    if (sp < T.stack_lds) key = (unsigned) L.stack[sp * kBlock];
+    if (sp < T.stack_lds) key = (unsigned) t4_stack_base(L)[sp * kBlock];
     else key = (unsigned) ((glb_int_t *) T.gstack)[(size_t) (sp - T.stack_lds) * T.gstack_stride + (size_t) blockIdx.x * kBlock + threadIdx.x];
     return key;
 }
@@ -207,7 +214,7 @@ template <int LDS, bool COUNT> PSDR_DEV void t4_node(SceneView<LDS> &S, const T4
         // slab test; fminf / fmaxf drop NaNs (0 * inf), which keeps the test conservative; the far side gets one ulp-scale of slack
         const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
         const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000004f;
-        const bool hit = (tn <= fminf(tf, bt)) && (cds[k] != kT4Miss);
+        const bool hit = (tn <= fminf(tf, bt)) & (cds[k] != kT4Miss);      // `&`: with `&&` the compiler sinks the load of the child's code into a branch - a second memory round trip per node
         key[k] = hit ? ((__float_as_uint(tn) & ~cmask) | cds[k]) : kT4Miss;
     }
 #endif
