@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PSDR_HIP_ABI_VERSION 10
+#define PSDR_HIP_ABI_VERSION 11
 
 /* TriangleInfo SoA, reference include/psdr/types.h:162-175 (+ Scene::m_triangle_uv,
  * m_triangle_face_normals, scene.cpp:528-542).  Arrays of n_triangles rows. */
@@ -88,6 +88,12 @@ typedef struct psdr_bsdf_rec {       /* Diffuse, reference src/bsdf/diffuse.cpp 
      * nested_bsdf = index in psdr_scene_snapshot.bsdfs of the BSDF it perturbs (any type but NormalMap; the host may append the
      * nested BSDF as an extra entry no mesh refers to) */
     int32_t nested_bsdf;
+    /* uv transform of the three bitmap slots above (0 tex_data, 1 spec_tex_data, 2 rough_tex_data): Bitmap::m_rot, m_scale,
+     * m_trans.x, m_trans.y (include/psdr/core/bitmap.h:37-39, applied by src/core/bitmap.cpp:64-86; the reference binds them as
+     * rotate / scale / translate, src/psdr.cpp:204-206, 217-219) and their forward tangents.  Identity = {0, 1, 0, 0}.
+     * Reverse mode: the adjoint of a transform component is <adj_image, d_image> of one psdr_hip_render_d_fwd launch with
+     * that component's tangent set to one (four scalars per bitmap: forward mode is the cheap direction). */
+    float tex_xf[3][4], d_tex_xf[3][4];
 } psdr_bsdf_rec;
 
 typedef struct psdr_emitter_rec {    /* AreaLight (src/emitter/area.cpp) or EnvironmentMap (src/emitter/envmap.cpp) */
@@ -113,6 +119,9 @@ typedef struct psdr_envmap_rec {
     const float *d_radiance;
     float d_scale;
     float d_to_world[16], d_from_world[16];
+    /* uv transform of m_radiance (as psdr_bsdf_rec.tex_xf: rotate, scale, translate.x, translate.y) and its forward tangent;
+     * cell_pmf / cell_cmf are the masses of the transformed map (envmap.cpp:28-31 evaluates m_radiance through Bitmap::eval) */
+    float radiance_xf[4], d_radiance_xf[4];
 } psdr_envmap_rec;
 
 /* SecondaryEdgeInfo SoA, reference include/psdr/edge/edge.h:49-68 */
@@ -244,6 +253,9 @@ int psdr_hip_env_pdf(const psdr_hip_scene *scene, int32_t n, const float *ref_p,
  * reference evaluates on the device in every Scene::configure).  HOST arrays: texels[height*width*3] ->
  * mass[2(width-1) * 2(height-1)], cell index = cx * 2(height-1) + cy.  The prefix sums stay with the caller. */
 int psdr_hip_env_cell_masses(const float *texels, int32_t width, int32_t height, float *mass);
+/* the same with m_radiance's uv transform uv_xf[4] = rotate, scale, translate.x, translate.y (psdr_envmap_rec.radiance_xf;
+ * NULL = identity): envmap.cpp:28-31 looks the cell centres up through Bitmap::eval, bitmap.cpp:64-86 */
+int psdr_hip_env_cell_masses_xf(const float *texels, int32_t width, int32_t height, const float *uv_xf, float *mass);
 
 /* Integrator::renderC: out_rgb is [n_pixels*3] float32, pixel-interleaved, pixel = y*W + x */
 int psdr_hip_render_c(const psdr_hip_scene *scene, const psdr_render_args *args, float *out_rgb, void *stream);

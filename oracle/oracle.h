@@ -65,6 +65,9 @@ typedef struct orc_bsdf {            /* Diffuse, include/psdr/bsdf/diffuse.h */
     /* type 5 = NormalMap (src/bsdf/normalmap.cpp): reflectance / tex_data = the normal map (rgb in [0,1]), nested_bsdf = index of the
      * BSDF it perturbs (any type but NormalMap) */
     int nested_bsdf;
+    /* uv transform of the bitmap slots tex / spec_tex / rough_tex: Bitmap::m_rot, m_scale, m_trans.x, m_trans.y
+     * (include/psdr/core/bitmap.h:37-39, src/core/bitmap.cpp:64-86) and their tangents; identity = {0, 1, 0, 0} */
+    float tex_xf[3][4], d_tex_xf[3][4];
 } orc_bsdf;
 
 typedef struct orc_emitter {         /* AreaLight (include/psdr/emitter/area.h) or EnvironmentMap (emitter/envmap.h) */
@@ -78,6 +81,7 @@ typedef struct orc_emitter {         /* AreaLight (include/psdr/emitter/area.h) 
     const float *d_env_data;
     float d_env_scale;
     float d_env_to_world_left[16];
+    float env_uv_xf[4], d_env_uv_xf[4];   /* m_radiance's rotate, scale, translate.x, translate.y (as orc_bsdf.tex_xf) */
 } orc_emitter;
 
 typedef struct orc_camera {          /* PerspectiveCamera(fov_x, near, far) */

@@ -96,6 +96,10 @@ class BsdfSpec:
     d_pv_diffuse: Optional[np.ndarray] = None
     d_pv_roughness: Optional[np.ndarray] = None
     nested: int = -1                            # type 5 = NormalMapBSDF: index of the nested BSDF; `reflectance` / `texture` = the normal map
+    # uv transform of the bitmaps `texture`, `spec_texture`, `rough_texture`: [3][rotate, scale, translate.x, translate.y] (Bitmap::m_rot,
+    # m_scale, m_trans, reference bitmap.h:37-39) and its tangent; None = identity / zero
+    tex_xf: Optional[np.ndarray] = None
+    d_tex_xf: Optional[np.ndarray] = None
 
 
 @dataclass
@@ -112,6 +116,8 @@ class EmitterSpec:
     d_env_data: Optional[np.ndarray] = None        # tangents of the texels / scale / to_world_left
     d_env_scale: float = 0.0
     d_env_to_world_left: np.ndarray = field(default_factory=lambda: np.zeros((4, 4), dtype=np.float32))
+    env_uv_xf: tuple = (0.0, 1.0, 0.0, 0.0)        # m_radiance's rotate, scale, translate.x, translate.y (+ tangent)
+    d_env_uv_xf: tuple = (0.0, 0.0, 0.0, 0.0)
 
 
 @dataclass
@@ -165,13 +171,14 @@ class _Bsdf(C.Structure):
                 ("rough_tex_width", C.c_int), ("rough_tex_height", C.c_int), ("rough_tex_data", C.POINTER(C.c_float)), ("d_rough_tex_data", C.POINTER(C.c_float)),
                 ("pv_count", C.c_int), ("pv_specular", C.POINTER(C.c_float)), ("pv_diffuse", C.POINTER(C.c_float)), ("pv_roughness", C.POINTER(C.c_float)),
                 ("d_pv_specular", C.POINTER(C.c_float)), ("d_pv_diffuse", C.POINTER(C.c_float)), ("d_pv_roughness", C.POINTER(C.c_float)),
-                ("nested_bsdf", C.c_int)]
+                ("nested_bsdf", C.c_int), ("tex_xf", (C.c_float * 4) * 3), ("d_tex_xf", (C.c_float * 4) * 3)]
 
 
 class _Emitter(C.Structure):
     _fields_ = [("radiance", _F3), ("d_radiance", _F3), ("type", C.c_int), ("env_width", C.c_int), ("env_height", C.c_int),
                 ("env_data", C.POINTER(C.c_float)), ("env_scale", C.c_float), ("env_to_world_left", _F16), ("env_to_world_raw", _F16),
-                ("d_env_data", C.POINTER(C.c_float)), ("d_env_scale", C.c_float), ("d_env_to_world_left", _F16)]
+                ("d_env_data", C.POINTER(C.c_float)), ("d_env_scale", C.c_float), ("d_env_to_world_left", _F16),
+                ("env_uv_xf", C.c_float * 4), ("d_env_uv_xf", C.c_float * 4)]
 
 
 class _Camera(C.Structure):
@@ -304,6 +311,11 @@ class OracleScene:
         for i, b in enumerate(spec.bsdfs):
             bsdfs[i].type = int(getattr(b, "type", 0))
             bsdfs[i].nested_bsdf = int(getattr(b, "nested", -1))
+            xf = np.asarray(getattr(b, "tex_xf", None) if getattr(b, "tex_xf", None) is not None else [[0, 1, 0, 0]] * 3, dtype=np.float32).reshape(3, 4)
+            dxf = np.asarray(getattr(b, "d_tex_xf", None) if getattr(b, "d_tex_xf", None) is not None else np.zeros((3, 4)), dtype=np.float32).reshape(3, 4)
+            for k in range(3):
+                for q in range(4):
+                    bsdfs[i].tex_xf[k][q], bsdfs[i].d_tex_xf[k][q] = float(xf[k, q]), float(dxf[k, q])
             bsdfs[i].specular = _F3(*getattr(b, "specular", (0.04, 0.04, 0.04)))
             bsdfs[i].d_specular = _F3(*getattr(b, "d_specular", (0.0, 0.0, 0.0)))
             bsdfs[i].roughness = float(getattr(b, "roughness", 0.5))
@@ -358,6 +370,8 @@ class OracleScene:
             emitters[i].env_to_world_left, emitters[i].env_to_world_raw = _m16(e.env_to_world_left), _m16(e.env_to_world_raw)
             emitters[i].env_scale = float(e.env_scale)
             emitters[i].d_env_scale = float(getattr(e, "d_env_scale", 0.0))
+            emitters[i].env_uv_xf = (C.c_float * 4)(*[float(q) for q in getattr(e, "env_uv_xf", (0.0, 1.0, 0.0, 0.0))])
+            emitters[i].d_env_uv_xf = (C.c_float * 4)(*[float(q) for q in getattr(e, "d_env_uv_xf", (0.0, 0.0, 0.0, 0.0))])
             emitters[i].d_env_to_world_left = _m16(getattr(e, "d_env_to_world_left", np.zeros((4, 4), np.float32)))
             if e.type == 1 and getattr(e, "d_env_data", None) is not None:
                 dimg = np.ascontiguousarray(np.asarray(e.d_env_data, dtype=np.float32))

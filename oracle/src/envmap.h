@@ -75,18 +75,30 @@ inline Dual floor_(const Dual &x) { return Dual(std::floor(x.v), 0.f); }
 
 // ---------------------------------------------------------------- Bitmap3fD (lat-long, envmap_mode) and the cell grid
 
-// Bitmap<3>::eval<ad>(uv, flip_v = false, envmap_mode = true) with the default m_rot = 0, m_scale = 1, m_trans = 0
-// (bitmap.cpp:47-128); the texel values carry no tangent (the lookup position does).
+// Bitmap::eval's uv transform, bitmap.cpp:64-74 (ad) = :76-86 (detached): m_rot, m_scale, m_trans (bitmap.h:37-39) are differentiable
+// members; xf = {rotate, scale, translate.x, translate.y} as (value, tangent), R = float drops the tangents (detach)
+template <typename R> inline R xf_part(const Dual &q) { if constexpr (std::is_same<R, Dual>::value) return q; else return q.v; }
+template <typename R> inline void uv_transform_ref(const Dual xf[4], bool flip_v, R u, R v, R &x, R &y) {
+    float sv, cv;
+    sincos_cephes(xf[0].v, sv, cv);
+    R sr, cr;
+    if constexpr (std::is_same<R, Dual>::value) { sr = Dual(sv, cv * xf[0].d); cr = Dual(cv, -(sv * xf[0].d)); } else { sr = sv; cr = cv; }
+    const R scale = xf_part<R>(xf[1]);
+    x = (u - R(0.5f)) * cr + (v - R(0.5f)) * sr;
+    y = -(u - R(0.5f)) * sr + (v - R(0.5f)) * cr;
+    x = x + R(0.5f); y = y + R(0.5f);
+    if (flip_v) y = -y;                                                           // flip the v coordinates to match common practices
+    x = x * scale; y = y * scale;
+    const R off = R(-.5f) + scale * R(0.5f);                                      // -.5f + m_scale / 2
+    x = x - off; y = y + off;
+    x = x + xf_part<R>(xf[2]); y = y + xf_part<R>(xf[3]);
+}
+
+// Bitmap<3>::eval<ad>(uv, flip_v = false, envmap_mode = true) (bitmap.cpp:47-128)
 template <typename R> V3<R> envmap_bitmap_eval(const EnvmapC &E, R u, R v) {
     const int W = E.width, H = E.height;
-    float sr, cr;
-    sincos_cephes(0.f, sr, cr);                                                   // cos(m_rot), sin(m_rot)
-    R x = (u - R(0.5f)) * R(cr) + (v - R(0.5f)) * R(sr);
-    R y = -(u - R(0.5f)) * R(sr) + (v - R(0.5f)) * R(cr);
-    x = x + R(0.5f); y = y + R(0.5f);
-    x = x * R(1.f); y = y * R(1.f);                                               // uv *= m_scale
-    x = x - R(-.5f + 1.f / 2); y = y + R(-.5f + 1.f / 2);
-    x = x + R(0.f); y = y + R(0.f);                                               // uv += m_trans
+    R x, y;
+    uv_transform_ref<R>(E.uv_xf, false, u, v, x, y);
     x = x - R((float) (0.5 / W));                                                 // :83
     x = x - floor_(x); y = y - floor_(y);
     x = x * R((float) W); y = y * R((float) (H - 1));
@@ -115,17 +127,10 @@ template <typename R> V3<R> envmap_bitmap_eval(const EnvmapC &E, R u, R v) {
 // Bitmap<CH>::eval<ad>(uv, flip_v = true, envmap_mode = false) for a resolution above 1x1 (bitmap.cpp:60-128): the texture
 // lookup of Diffuse::m_reflectance (diffuse.cpp:38) and of Microfacet's three parameters (microfacet.cpp:38-45).
 // Texels carry the tangent d_data.
-template <bool ad> void tex_eval(const float *data, const float *d_data, int W, int H, int CH, const V2<Real<ad>> &uv, Real<ad> *out) {
+template <bool ad> void tex_eval(const float *data, const float *d_data, int W, int H, int CH, const V2<Real<ad>> &uv, Real<ad> *out, const Dual xf[4]) {
     using R = Real<ad>;
-    float sr, cr;
-    sincos_cephes(0.f, sr, cr);
-    R x = (uv.x - R(0.5f)) * R(cr) + (uv.y - R(0.5f)) * R(sr);
-    R y = -(uv.x - R(0.5f)) * R(sr) + (uv.y - R(0.5f)) * R(cr);
-    x = x + R(0.5f); y = y + R(0.5f);
-    y = -y;                                                                       // flip_v
-    x = x * R(1.f); y = y * R(1.f);
-    x = x - R(-.5f + 1.f / 2); y = y + R(-.5f + 1.f / 2);
-    x = x + R(0.f); y = y + R(0.f);
+    R x, y;
+    uv_transform_ref<R>(xf, true, uv.x, uv.y, x, y);                              // flip_v
     x = x - floor_(x); y = y - floor_(y);
     x = x * R((float) (W - 1)); y = y * R((float) (H - 1));
     int px = (int) std::floor(detach(x)), py = (int) std::floor(detach(y));
@@ -148,20 +153,20 @@ template <bool ad> V3<Real<ad>> bsdf_reflectance(const BsdfC &b, const V2<Real<a
         if constexpr (ad) return b.reflectance; else return detach(b.reflectance);
     }
     R out[3];
-    tex_eval<ad>(b.tex.data(), b.d_tex.data(), b.tex_w, b.tex_h, 3, uv, out);
+    tex_eval<ad>(b.tex.data(), b.d_tex.data(), b.tex_w, b.tex_h, 3, uv, out, b.uv_xf[0]);
     return V3<R>(out[0], out[1], out[2]);
 }
 // Microfacet: m_specularReflectance / m_roughness as bitmaps (value, tangent); the caller detaches in C mode
 template <bool ad> V3d bsdf_specular(const BsdfC &b, const V2<Real<ad>> &uv) {
     if (b.spec_w == 0) return b.specular;
     Dual out[3];
-    tex_eval<true>(b.spec_tex.data(), b.d_spec_tex.data(), b.spec_w, b.spec_h, 3, V2d(Dual(uv.x), Dual(uv.y)), out);
+    tex_eval<true>(b.spec_tex.data(), b.d_spec_tex.data(), b.spec_w, b.spec_h, 3, V2d(Dual(uv.x), Dual(uv.y)), out, b.uv_xf[1]);
     return V3d(out[0], out[1], out[2]);
 }
 template <bool ad> Dual bsdf_roughness(const BsdfC &b, const V2<Real<ad>> &uv) {
     if (b.rough_w == 0) return b.roughness;
     Dual out[1];
-    tex_eval<true>(b.rough_tex.data(), b.d_rough_tex.data(), b.rough_w, b.rough_h, 1, V2d(Dual(uv.x), Dual(uv.y)), out);
+    tex_eval<true>(b.rough_tex.data(), b.d_rough_tex.data(), b.rough_w, b.rough_h, 1, V2d(Dual(uv.x), Dual(uv.y)), out, b.uv_xf[2]);
     return out[0];
 }
 

@@ -220,6 +220,7 @@ Scene *configure_scene(const orc_scene_desc &d, const int *active, int n_active)
         }
         take(b.spec_tex_data, b.d_spec_tex_data, b.spec_tex_width, b.spec_tex_height, 3, bc.spec_w, bc.spec_h, bc.spec_tex, bc.d_spec_tex);
         take(b.rough_tex_data, b.d_rough_tex_data, b.rough_tex_width, b.rough_tex_height, 1, bc.rough_w, bc.rough_h, bc.rough_tex, bc.d_rough_tex);
+        for (int k = 0; k < 3; ++k) for (int q = 0; q < 4; ++q) bc.uv_xf[k][q] = Dual(b.tex_xf[k][q], b.d_tex_xf[k][q]);
         sc->bsdfs.push_back(bc);
     }
     for (int i = 0; i < d.n_emitters; ++i) {
@@ -237,6 +238,7 @@ Scene *configure_scene(const orc_scene_desc &d, const int *active, int n_active)
             E.data.assign(e.env_data, e.env_data + (size_t) 3 * E.width * E.height);
             if (e.d_env_data) E.d_data.assign(e.d_env_data, e.d_env_data + (size_t) 3 * E.width * E.height);
             E.scale = Dual(e.env_scale, e.d_env_scale);
+            for (int q = 0; q < 4; ++q) E.uv_xf[q] = Dual(e.env_uv_xf[q], e.d_env_uv_xf[q]);
             const float zero16[16] = {0};
             E.to_world = make_m4d(e.env_to_world_left, e.d_env_to_world_left) * make_m4d(e.env_to_world_raw, zero16);      // envmap.cpp:41
         }

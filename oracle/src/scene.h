@@ -86,6 +86,8 @@ struct BsdfC { int type; V3d reflectance; bool two_sided; int tex_w = 0, tex_h =
                std::vector<float> spec_tex, d_spec_tex, rough_tex, d_rough_tex;
                // type 4 = MicrofacetPerVertex: [n*3], [n*3], [n] values per (mesh-local) vertex, with optional tangents
                std::vector<float> pv_spec, pv_diff, pv_rough, d_pv_spec, d_pv_diff, d_pv_rough;
+               // uv transform of the three bitmap slots (tex, spec_tex, rough_tex): Bitmap::m_rot, m_scale, m_trans.x, m_trans.y (bitmap.h:37-39)
+               Dual uv_xf[3][4] = {{Dual(0.f), Dual(1.f), Dual(0.f), Dual(0.f)}, {Dual(0.f), Dual(1.f), Dual(0.f), Dual(0.f)}, {Dual(0.f), Dual(1.f), Dual(0.f), Dual(0.f)}};
                int nested = -1; };                // type 5 = NormalMap: index of the nested BSDF; reflectance / tex = the normal map   // type 2 = RoughConductor (specular = specular_reflectance)   // tex: Bitmap3fD texels when textured
 // type 0 = AreaLight (area.h), 1 = EnvironmentMap (envmap.h); an envmap's mesh is the bounding cube scene.cpp:442-480 adds
 struct EmitterC { V3d radiance; int mesh = -1; float sampling_weight = 1.f; int type = 0; };
@@ -94,6 +96,7 @@ struct EnvmapC {
     int width = 0, height = 0;               // m_radiance.m_resolution
     std::vector<float> data, d_data;         // [height*width*3], row-major rgb (+ optional tangent of the texels)
     Dual scale = Dual(1.f);                  // m_scale (FloatD)
+    Dual uv_xf[4] = {Dual(0.f), Dual(1.f), Dual(0.f), Dual(0.f)};   // m_radiance.m_rot, m_scale, m_trans (bitmap.h:37-39)
     M4d to_world, from_world;                // envmap.cpp:41-42
     V3f lower, upper;                        // scene AABB + margin (scene.cpp:436-440)
     // HyperCubeDistribution2f m_cell_distrb

@@ -163,12 +163,19 @@ class Bitmap3fD:
     def resolution(self):
         return (self.data.shape[1], self.data.shape[0])
 
+    # m_rot, m_scale, m_trans (reference bitmap.h:37-39; bound as rotate / scale / translate, psdr.cpp:217-219)
+    rotate, scale, translate = 0.0, 1.0, (0.0, 0.0)
+
 
 def _bitmap_eval(self, uv, flip_v=True, envmap_mode=False):
-    """Bitmap::eval(uv[N, 2]) (reference bitmap.cpp:47-128, default translate / rotate / scale) -> [N, channels] numpy array"""
+    """Bitmap::eval(uv[N, 2]) (reference bitmap.cpp:47-128) -> [N, channels] numpy array"""
     from .host_utils import bitmap_eval
     uv = uv.detach().cpu().numpy() if isinstance(uv, _torch.Tensor) else uv
-    return bitmap_eval(self.data, uv, flip_v, envmap_mode)
+    xf = [float(_np.asarray(q.detach().cpu() if isinstance(q, _torch.Tensor) else q).reshape(-1)[k]) for q, k in
+          ((self.rotate, 0), (self.scale, 0), (self.translate, 0), (self.translate, 1))]
+    return bitmap_eval(self.data, uv, flip_v, envmap_mode, xf)
+
+
 
 
 Bitmap3fD.eval = _bitmap_eval
@@ -191,6 +198,8 @@ class Bitmap1fD:
     @property
     def resolution(self):
         return (self.data.shape[1], self.data.shape[0])
+
+    rotate, scale, translate = 0.0, 1.0, (0.0, 0.0)       # psdr.cpp:204-206
 
 
 Bitmap1fD.eval = _bitmap_eval
@@ -239,6 +248,95 @@ NormalMapBSDF.normal_map = _make_param_property("normal_map", _refl_shape)
 AreaLight.radiance = _make_param_property("radiance", _v3)
 
 
+# ------------------------------------------------------------------ uv transform of a bitmap parameter
+# The reference's Bitmap1fD / Bitmap3fD carry three differentiable members besides their texels - translate (Vector2fD), rotate and
+# scale (FloatD), psdr.cpp:204-206, 217-219, applied to every lookup by bitmap.cpp:64-86.  Here a bitmap parameter of a BSDF (or the
+# environment map's radiance) is a tensor property, so its transform is reached through obj.uv_transform(name):
+#     t = scene.param_map["BSDF[0]"].uv_transform("reflectance");  t.rotate = torch.tensor(0.3, requires_grad=True)
+# (the reference spelling: scene.param_map["BSDF[0]"].reflectance.rotate = FloatD(0.3)).  The three members travel to the host
+# object as one leaf [rotate, scale, translate.x, translate.y] named "<parameter>@uv".
+_UV_SLOT = {"reflectance": 0, "diffuseReflectance": 0, "specularReflectance": 1, "roughness": 2, "normal_map": 0,
+            "eta": 0, "k": 1, "alpha_u": 2, "alpha_v": 2}
+_UV_SUFFIX = "@uv"
+
+
+def _uv_push(obj, name, v, d):
+    """[rotate, scale, tx, ty] (+ tangent) of bitmap parameter `name` -> host object"""
+    v = _np.ascontiguousarray(_np.asarray(v, dtype=_np.float32).reshape(4))
+    d = _np.ascontiguousarray(_np.asarray(d, dtype=_np.float32).reshape(4))
+    if isinstance(obj, EnvironmentMap):
+        obj._set("radiance_uv_xf", v, d)
+    else:
+        obj._set_uv_xf(_UV_SLOT[name], v, d)
+
+
+class BitmapTransform:
+    """rotate / scale / translate of one bitmap parameter (reference Bitmap::m_rot / m_scale / m_trans)"""
+
+    def __init__(self, obj, name):
+        if isinstance(obj, EnvironmentMap):
+            if name != "radiance":
+                raise RuntimeError("EnvironmentMap: the bitmap parameter is 'radiance'")
+        elif name not in _UV_SLOT or not hasattr(type(obj), name):
+            raise RuntimeError("%s has no bitmap parameter %r" % (type(obj).__name__, name))
+        self.__dict__["_obj"], self.__dict__["_name"] = obj, name
+        parts = obj.__dict__.setdefault("_psdr_uv_parts", {})
+        if name not in parts:
+            cur = self._host()
+            parts[name] = {"rotate": float(cur[0]), "scale": float(cur[1]), "translate": (float(cur[2]), float(cur[3]))}
+
+    def _host(self):
+        o = self._obj
+        return _np.asarray(o._get("radiance_uv_xf", False) if isinstance(o, EnvironmentMap) else o._get_uv_xf(_UV_SLOT[self._name], False))
+
+    def __getattr__(self, key):
+        if key in ("rotate", "scale", "translate"):
+            return self._obj.__dict__["_psdr_uv_parts"][self._name][key]
+        raise AttributeError(key)
+
+    def __setattr__(self, key, value):
+        if key not in ("rotate", "scale", "translate"):
+            raise AttributeError("a bitmap transform has rotate, scale and translate")
+        parts = self._obj.__dict__["_psdr_uv_parts"][self._name]
+        parts[key] = value
+        seq = (parts["rotate"], parts["scale"], parts["translate"])
+        if any(isinstance(q, _torch.Tensor) for q in seq):
+            ref = next(q for q in seq if isinstance(q, _torch.Tensor))
+            flat = [(q.to(ref.device, _torch.float32) if isinstance(q, _torch.Tensor) else _torch.as_tensor(q, dtype=_torch.float32, device=ref.device)).reshape(-1) for q in seq]
+            t = _torch.cat(flat)
+            if t.numel() != 4:
+                raise RuntimeError("bitmap transform: rotate and scale are scalars, translate has two components")
+            _params(self._obj)[self._name + _UV_SUFFIX] = t
+            v = t.detach().cpu().numpy()
+        else:
+            _params(self._obj).pop(self._name + _UV_SUFFIX, None)
+            v = _np.concatenate([_np.asarray(q, dtype=_np.float32).reshape(-1) for q in seq])
+        _uv_push(self._obj, self._name, v, _np.zeros(4, _np.float32))
+
+
+def _uv_transform(self, name="radiance"):
+    return BitmapTransform(self, name)
+
+
+for _cls in (DiffuseBSDF, MicrofacetBSDF, RoughConductorBSDF, RoughDielectricBSDF, NormalMapBSDF, EnvironmentMap):
+    _cls.uv_transform = _uv_transform
+
+
+def _copy_uv_parts(src, dst):
+    """the Python half of a bitmap transform follows the host object's copy (the host copy carries the values)"""
+    if src is not None and "_psdr_uv_parts" in src.__dict__:
+        dst.__dict__["_psdr_uv_parts"] = {k: dict(v) for k, v in src.__dict__["_psdr_uv_parts"].items()}
+
+
+def _adopt_bitmap_transform(obj, name, bitmap):
+    """a Bitmap1fD / Bitmap3fD handed to a constructor brings its rotate / scale / translate along"""
+    if isinstance(bitmap, (Bitmap3fD, Bitmap1fD)) and bitmap.data.size > 3:
+        for key in ("rotate", "scale", "translate"):
+            val = getattr(bitmap, key)
+            if isinstance(val, _torch.Tensor) or val != getattr(type(bitmap), key):
+                setattr(obj.uv_transform(name), key, val)
+
+
 def _set_transform(self, mat, set_left=True):
     """Mesh/Sensor.set_transform (reference mesh.h:26-33, sensor.h:34-40)."""
     name = "to_world_left" if set_left else "to_world_right"
@@ -264,12 +362,14 @@ def _diffuse_init(self, reflectance=None):
     if reflectance is None:
         _DiffuseBSDF_init(self)
         return
+    src = reflectance
     if isinstance(reflectance, Bitmap3fD):
         reflectance = reflectance.data.reshape(3) if reflectance.data.size == 3 else reflectance.data
     shp = tuple(reflectance.shape) if hasattr(reflectance, "shape") else _np.shape(reflectance)
     if len(shp) == 3:                       # a reflectance texture
         _DiffuseBSDF_init(self)
         self.reflectance = reflectance
+        _adopt_bitmap_transform(self, "reflectance", src)
         return
     v, t = _split(reflectance, (-1,))
     _DiffuseBSDF_init(self, v)
@@ -288,6 +388,7 @@ def _microfacet_init(self, specular=None, diffuse=None, roughness=None):
     if specular is None:
         return
     for name, val, n in (("specularReflectance", specular, 3), ("diffuseReflectance", diffuse, 3), ("roughness", roughness, 1)):
+        _adopt_bitmap_transform(self, name, val)
         if isinstance(val, (Bitmap3fD, Bitmap1fD)):
             val = val.data.reshape(n) if val.data.size == n else val.data
         shp = tuple(val.shape) if hasattr(val, "shape") else _np.shape(val)
@@ -355,9 +456,11 @@ def _normalmap_init(self, normal_map=None):
     perturbs is assigned through `nested_bsdf`"""
     _NormalMapBSDF_init(self)
     if normal_map is not None:
+        src = normal_map
         if isinstance(normal_map, Bitmap3fD):
             normal_map = normal_map.data.reshape(3) if normal_map.data.size == 3 else normal_map.data
         self.normal_map = normal_map
+        _adopt_bitmap_transform(self, "normal_map", src)
 
 
 def _nm_get_nested(self):
@@ -366,6 +469,7 @@ def _nm_get_nested(self):
         src = self.__dict__.get("_psdr_nested_src")
         if src is not None and "_psdr_params" in src.__dict__ and "_psdr_params" not in n.__dict__:
             n.__dict__["_psdr_params"] = dict(src.__dict__["_psdr_params"])
+            _copy_uv_parts(src, n)
     return n
 
 
@@ -419,6 +523,7 @@ def _keep(scene, key, src):
     scene.__dict__.setdefault("_psdr_objs", {})[key] = obj
     if src is not None and "_psdr_params" in src.__dict__:
         obj.__dict__["_psdr_params"] = dict(src.__dict__["_psdr_params"])
+    _copy_uv_parts(src, obj)
     return obj
 
 
@@ -441,6 +546,7 @@ def _add_BSDF(self, bsdf, name, twoSide=False):
             self.__dict__.setdefault("_psdr_objs", {})["BSDF[id=%s].nested" % name] = nested
             if src is not None and "_psdr_params" in src.__dict__:
                 nested.__dict__["_psdr_params"] = dict(src.__dict__["_psdr_params"])
+            _copy_uv_parts(src, nested)
 
 
 def _add_normalmap_BSDF(self, bsdf1, bsdf2, name, twoSide=False):
@@ -448,6 +554,7 @@ def _add_normalmap_BSDF(self, bsdf1, bsdf2, name, twoSide=False):
     nm = NormalMapBSDF(bsdf1.normal_map)
     if "_psdr_params" in bsdf1.__dict__:
         nm.__dict__["_psdr_params"] = dict(bsdf1.__dict__["_psdr_params"])
+    _copy_uv_parts(bsdf1, nm)
     nm.nested_bsdf = bsdf2
     _add_BSDF(self, nm, name, twoSide)
 
@@ -678,6 +785,10 @@ def _sync_params(scene, tangents=None, integ=None):
     """Push current tensor values (and optional tangents {id(tensor): array}) into the host objects."""
     for obj, name, t in _leaves(scene, integ):
         v = t.detach().to("cpu", _torch.float32).numpy()
+        if name.endswith(_UV_SUFFIX):                        # [rotate, scale, translate] of a bitmap parameter
+            d = tangents[id(t)] if tangents is not None and id(t) in tangents else _np.zeros(4, _np.float32)
+            _uv_push(obj, name[:-len(_UV_SUFFIX)], v, d)
+            continue
         shape = (4, 4) if name.startswith("to_world") else ((obj.num_vertices, 3) if name == "vertex_positions" else (-1,))
         if isinstance(obj, (_core.BSDF, _core.Emitter)) and t.dim() >= 2 and not name.startswith("to_world"):
             shape = tuple(t.shape)                           # a bitmap parameter keeps its [H, W(, 3)] shape
@@ -855,7 +966,7 @@ class _RenderDFn(_torch.autograd.Function):
         mat_leaves = [i for i, ((obj, name, t), need) in enumerate(zip(leaves, needs))
                       if need and t.dim() < 2 and name in mat_rows.get(type(obj).__name__, {})]
         g_mat = _torch.zeros(16 * max(1, nb + n_hidden), dtype=_torch.float32, device=dev) if mat_leaves else None
-        env_leaves = [i for i, ((obj, name, t), need) in enumerate(zip(leaves, needs)) if need and isinstance(obj, EnvironmentMap)]
+        env_leaves = [i for i, ((obj, name, t), need) in enumerate(zip(leaves, needs)) if need and isinstance(obj, EnvironmentMap) and not name.endswith(_UV_SUFFIX)]
         g_env = g_env_scale = g_env_xf = None
         for i in env_leaves:
             obj, name, t = leaves[i]
@@ -950,6 +1061,21 @@ class _RenderDFn(_torch.autograd.Function):
                     fw = _torch.linalg.inv(L @ raw)
                     (gl,) = _torch.autograd.grad(fw, L, g_env_xf.to("cpu", _torch.float64).reshape(4, 4))
                 grads[i] = gl.reshape(t.shape).to(t.device, t.dtype)
+        # rotate / scale / translate of a bitmap: four scalars per bitmap, taken in FORWARD mode - one replay of the recorded render per
+        # component with its unit tangent, dotted with the adjoint image (include/psdr_hip.h, psdr_bsdf_rec.tex_xf)
+        uv_leaves = [i for i, ((obj, name, t), need) in enumerate(zip(leaves, needs)) if need and name.endswith(_UV_SUFFIX)]
+        if uv_leaves:
+            for i in uv_leaves:
+                t = leaves[i][2]
+                g = _torch.zeros(4, dtype=_torch.float64)
+                for j in range(4):
+                    e = _np.zeros(4, _np.float32)
+                    e[j] = 1.0
+                    dimg = _replay_forward(integ, scene, st, {id(t): e})
+                    g[j] = (g_img.to(_torch.float64) * dimg.to(g_img.device, _torch.float64).reshape(g_img.shape)).sum().item()
+                grads[i] = g.reshape(t.shape).to(t.device, t.dtype)
+            _sync_params(scene, None, integ)
+            scene._configure(st["active"])
         return (None,) + tuple(grads)
 
 

@@ -54,9 +54,10 @@ def _stale(target, deps, flags=()):
         return fh.read().strip() != _signature(deps, flags)
 
 
-def _stamp(target, deps, flags=()):
+def _stamp(target, sig):
+    """`sig`: the signature taken BEFORE the compilers read the sources (an edit made while they run must leave the target stale)"""
     with open(_sig_path(target), "w") as fh:
-        fh.write(_signature(deps, flags) + "\n")
+        fh.write(sig + "\n")
 
 
 def _run(cmd):
@@ -77,6 +78,7 @@ def build_hip(force=False, extra_flags=()):
     os.makedirs(LIBDIR, exist_ok=True)
     flags = [f for f in HIP_FLAGS if f != "-shared"] + list(extra_flags)
     if force or _stale(HIP_LIB, HIP_SRCS + HIP_DEPS, flags):
+        sig = _signature(HIP_SRCS + HIP_DEPS, flags)
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         objdir = os.path.join(LIBDIR, "obj")
         os.makedirs(objdir, exist_ok=True)
@@ -107,7 +109,7 @@ def build_hip(force=False, extra_flags=()):
                 raise RuntimeError("build failed: " + " ".join(cmd))
         arch = [f for f in flags if f.startswith("--offload-arch")]
         _run([hipcc] + arch + ["-shared", "-fPIC"] + objs + ["-o", HIP_LIB])
-        _stamp(HIP_LIB, HIP_SRCS + HIP_DEPS, flags)
+        _stamp(HIP_LIB, sig)
     return HIP_LIB
 
 
@@ -118,10 +120,11 @@ def build_core(force=False, hip_flags=()):
     build_hip(extra_flags=hip_flags)
     deps = HOST_SRCS + HOST_DEPS
     if force or _stale(CORE_LIB, deps, CORE_FLAGS):
+        sig = _signature(deps, CORE_FLAGS)
         import pybind11
         inc = ["-I" + sysconfig.get_paths()["include"], "-I" + pybind11.get_include()]
         _run(["g++"] + CORE_FLAGS + inc + HOST_SRCS + ["-o", CORE_LIB, "-L" + LIBDIR, "-lpsdr_hip", "-Wl,-rpath,$ORIGIN/lib"])
-        _stamp(CORE_LIB, deps, CORE_FLAGS)
+        _stamp(CORE_LIB, sig)
     return CORE_LIB
 
 

@@ -87,20 +87,36 @@ PSDR_HD float safe_acos_f(float x) { return acos_f(fminf(fmaxf(x, -1.f), 1.f)); 
 PSDR_HD float e_fma(float a, float b, float c) { return fmaf(a, b, c); }
 PSDR_HD float e_floor(float a) { return floorf(a); }
 PSDR_HD float e_value(float a) { return a; }
+PSDR_HD void e_sincos(float a, float &s, float &c) { sincos_f(a, s, c); }
 
-// Bitmap<3>::eval<ad>(uv, flip_v = false, envmap_mode = true) with m_rot = 0, m_scale = 1, m_trans = 0
-// (bitmap.cpp:47-128).  data: [H*W*3] row-major rgb; the texels carry no tangent, the position does.
+// Bitmap::m_rot, m_scale, m_trans (bitmap.h:37-39, bound as rotate / scale / translate, psdr.cpp:204-206, 217-219): the uv transform
+// every lookup applies (bitmap.cpp:64-86).  R = float, or the device's (value, tangent) type - the three are differentiable members.
+template <typename R> struct UvXf {
+    R rot, scale, tx, ty;
+    PSDR_HD UvXf() : rot(0.f), scale(1.f), tx(0.f), ty(0.f) {}
+    PSDR_HD UvXf(R r, R s, R x, R y) : rot(r), scale(s), tx(x), ty(y) {}
+    PSDR_HD explicit UvXf(const float *p) : rot(p[0]), scale(p[1]), tx(p[2]), ty(p[3]) {}
+};
+// bitmap.cpp:64-86 (ad) = :76-86 (detached): rotate about the centre, flip v, scale about the centre, translate
+template <typename R> PSDR_HD void uv_transform(const UvXf<R> &xf, bool flip_v, R u, R v, R &x, R &y) {
+    R sr, cr;
+    e_sincos(xf.rot, sr, cr);                                                     // cos(m_rot), sin(m_rot)
+    x = (u - R(0.5f)) * cr + (v - R(0.5f)) * sr;
+    y = -(u - R(0.5f)) * sr + (v - R(0.5f)) * cr;
+    x = x + R(0.5f); y = y + R(0.5f);
+    if (flip_v) y = -y;
+    x = x * xf.scale; y = y * xf.scale;
+    const R off = R(-.5f) + xf.scale * R(0.5f);                                   // -.5f + m_scale / 2
+    x = x - off; y = y + off;
+    x = x + xf.tx; y = y + xf.ty;
+}
+
+// Bitmap<3>::eval<ad>(uv, flip_v = false, envmap_mode = true) (bitmap.cpp:47-128).  data: [H*W*3] row-major rgb.
 // texel(i, c) returns channel c of texel i as an R (so that (value, tangent) texels can be supplied)
 template <typename R, typename TexelFn>
-PSDR_HD void bitmap_eval_fn(TexelFn texel, int W, int H, R u, R v, R out[3]) {
-    float sr, cr;
-    sincos_f(0.f, sr, cr);                                                        // cos(m_rot), sin(m_rot)
-    R x = (u - R(0.5f)) * R(cr) + (v - R(0.5f)) * R(sr);
-    R y = -(u - R(0.5f)) * R(sr) + (v - R(0.5f)) * R(cr);
-    x = x + R(0.5f); y = y + R(0.5f);
-    x = x * R(1.f); y = y * R(1.f);
-    x = x - R(-.5f + 1.f / 2); y = y + R(-.5f + 1.f / 2);
-    x = x + R(0.f); y = y + R(0.f);
+PSDR_HD void bitmap_eval_fn(TexelFn texel, int W, int H, R u, R v, R out[3], const UvXf<R> &xf = UvXf<R>()) {
+    R x, y;
+    uv_transform<R>(xf, false, u, v, x, y);
     x = x - R((float) (0.5 / W));
     x = x - e_floor(x); y = y - e_floor(y);
     x = x * R((float) W); y = y * R((float) (H - 1));
@@ -119,19 +135,13 @@ PSDR_HD void bitmap_eval_fn(TexelFn texel, int W, int H, R u, R v, R out[3]) {
     }
 }
 template <typename R>
-PSDR_HD void bitmap_eval(const float *data, int W, int H, R u, R v, R out[3]) {
-    bitmap_eval_fn<R>([&](int i, int c) { return R(data[3 * i + c]); }, W, H, u, v, out);
+PSDR_HD void bitmap_eval(const float *data, int W, int H, R u, R v, R out[3], const UvXf<R> &xf = UvXf<R>()) {
+    bitmap_eval_fn<R>([&](int i, int c) { return R(data[3 * i + c]); }, W, H, u, v, out, xf);
 }
 // the four texels and weights bitmap_eval reads at (u, v) (envmap mode): d out[c] / d texel[idx[k]][c] = w[k]
-PSDR_HD void bitmap_footprint_env(int W, int H, float u, float v, int idx[4], float w[4]) {
-    float sr, cr;
-    sincos_f(0.f, sr, cr);
-    float x = (u - 0.5f) * cr + (v - 0.5f) * sr;
-    float y = -(u - 0.5f) * sr + (v - 0.5f) * cr;
-    x = x + 0.5f; y = y + 0.5f;
-    x = x * 1.f; y = y * 1.f;
-    x = x - (-.5f + 1.f / 2); y = y + (-.5f + 1.f / 2);
-    x = x + 0.f; y = y + 0.f;
+PSDR_HD void bitmap_footprint_env(int W, int H, float u, float v, int idx[4], float w[4], const UvXf<float> &xf = UvXf<float>()) {
+    float x, y;
+    uv_transform<float>(xf, false, u, v, x, y);
     x = x - (float) (0.5 / W);
     x = x - floorf(x); y = y - floorf(y);
     x = x * (float) W; y = y * (float) (H - 1);
@@ -146,20 +156,13 @@ PSDR_HD void bitmap_footprint_env(int W, int H, float u, float v, int idx[4], fl
     w[0] = w0y * w0x; w[1] = w0y * w1x; w[2] = w1y * w0x; w[3] = w1y * w1x;
 }
 
-// Bitmap<CH>::eval<ad>(uv, flip_v, envmap_mode = false) with m_rot = 0, m_scale = 1, m_trans = 0 (bitmap.cpp:47-128):
-// the texture lookup of Diffuse::m_reflectance (diffuse.cpp:38, flip_v = true).  texel(i, c) returns channel c of
-// texel i as an R (so that a (value, tangent) texel can be supplied).
+// Bitmap<CH>::eval<ad>(uv, flip_v, envmap_mode = false) (bitmap.cpp:47-128): the texture lookup of Diffuse::m_reflectance
+// (diffuse.cpp:38, flip_v = true).  texel(i, c) returns channel c of texel i as an R (so that a (value, tangent) texel can
+// be supplied).
 template <typename R, int CH = 3, typename TexelFn>
-PSDR_HD void bitmap_eval_tex(TexelFn texel, int W, int H, R u, R v, bool flip_v, R *out) {
-    float sr, cr;
-    sincos_f(0.f, sr, cr);
-    R x = (u - R(0.5f)) * R(cr) + (v - R(0.5f)) * R(sr);
-    R y = -(u - R(0.5f)) * R(sr) + (v - R(0.5f)) * R(cr);
-    x = x + R(0.5f); y = y + R(0.5f);
-    if (flip_v) y = -y;
-    x = x * R(1.f); y = y * R(1.f);
-    x = x - R(-.5f + 1.f / 2); y = y + R(-.5f + 1.f / 2);
-    x = x + R(0.f); y = y + R(0.f);
+PSDR_HD void bitmap_eval_tex(TexelFn texel, int W, int H, R u, R v, bool flip_v, R *out, const UvXf<R> &xf = UvXf<R>()) {
+    R x, y;
+    uv_transform<R>(xf, flip_v, u, v, x, y);
     x = x - e_floor(x); y = y - e_floor(y);
     x = x * R((float) (W - 1)); y = y * R((float) (H - 1));
     int px = (int) floorf(e_value(x)), py = (int) floorf(e_value(y));
@@ -175,16 +178,9 @@ PSDR_HD void bitmap_eval_tex(TexelFn texel, int W, int H, R u, R v, bool flip_v,
 }
 
 // the four texels and bilinear weights bitmap_eval_tex reads at (u, v): d out[c] / d texel[idx[k]][c] = w[k]
-PSDR_HD void bitmap_footprint(int W, int H, float u, float v, bool flip_v, int idx[4], float w[4]) {
-    float sr, cr;
-    sincos_f(0.f, sr, cr);
-    float x = (u - 0.5f) * cr + (v - 0.5f) * sr;
-    float y = -(u - 0.5f) * sr + (v - 0.5f) * cr;
-    x = x + 0.5f; y = y + 0.5f;
-    if (flip_v) y = -y;
-    x = x * 1.f; y = y * 1.f;
-    x = x - (-.5f + 1.f / 2); y = y + (-.5f + 1.f / 2);
-    x = x + 0.f; y = y + 0.f;
+PSDR_HD void bitmap_footprint(int W, int H, float u, float v, bool flip_v, int idx[4], float w[4], const UvXf<float> &xf = UvXf<float>()) {
+    float x, y;
+    uv_transform<float>(xf, flip_v, u, v, x, y);
     x = x - floorf(x); y = y - floorf(y);
     x = x * (float) (W - 1); y = y * (float) (H - 1);
     int px = (int) floorf(x), py = (int) floorf(y);
@@ -196,12 +192,12 @@ PSDR_HD void bitmap_footprint(int W, int H, float u, float v, bool flip_v, int i
 }
 
 // mass of cell idx of HyperCubeDistribution2f (envmap.cpp:28-31, cube_distrb.cpp:22-29): luminance * sin(theta)
-PSDR_HD float cell_mass(const float *data, int W, int H, int w2, int h2, int idx) {
+PSDR_HD float cell_mass(const float *data, int W, int H, int w2, int h2, int idx, const UvXf<float> &xf = UvXf<float>()) {
     const int cx = idx / h2, cy = idx - cx * h2;
     const float ux = 1.f / (float) w2, uy = 1.f / (float) h2;
     const float u = ((float) cx + .5f) * ux, v = ((float) cy + .5f) * uy;
     float val[3];
-    bitmap_eval<float>(data, W, H, u, v, val);
+    bitmap_eval<float>(data, W, H, u, v, val, xf);
     const float theta = ((float) (idx % h2) + .5f) * (kPi / (float) h2);
     float s, c;
     sincos_f(theta, s, c);

@@ -304,7 +304,7 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                                 // gval = d L / d rgb[c] of this lookup (before the scale): texels by the footprint, and
                                 // d L / d scale = sum_c gval_c . rgb[c] / scale
                                 const EnvDev &E = T.env;
-                                env::bitmap_footprint_env(E.width, E.height, S.probe_u, S.probe_v, idx, wt);
+                                env::bitmap_footprint_env(E.width, E.height, S.probe_u, S.probe_v, idx, wt, env::UvXf<float>(E.xf));
                                 if (gval != 0.f && finite_(gval)) {
                                     float rgb_c = 0.f;
                                     for (int k = 0; k < 4; ++k) {
@@ -327,7 +327,7 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                             } else {
                                 const int tslot = st_comp < 3 ? 0 : (st_comp < 6 ? 1 : 2), ch = tslot == 2 ? 1 : 3, c = st_comp - 3 * tslot;
                                 const TexDev td = T.tex[3 * st_id + tslot];
-                                env::bitmap_footprint(td.w, td.h, S.probe_u, S.probe_v, true, idx, wt);
+                                env::bitmap_footprint(td.w, td.h, S.probe_u, S.probe_v, true, idx, wt, env::UvXf<float>(td.xf));
                                 if (gval != 0.f && finite_(gval))
                                     for (int k = 0; k < 4; ++k) atomicAdd(&P.g_tex[td.g_off + (long long) ch * idx[k] + c], gval * wt[k]);
                             }
@@ -504,14 +504,14 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
                 Dual u = env_atan2(vd.x, -vd.z) * Dual(env::kInvTwoPi), w = env_safe_acos(vd.y) * Dual(env::kInvPi);
                 u = u - env_floor(u); w = w - env_floor(w);
                 Dual rgb[3];
-                env::bitmap_eval_fn<Dual>([&](int i, int c) { return Dual(E.radiance[3 * i + c], 0.f); }, E.width, E.height, u, w, rgb);
+                env::bitmap_eval_fn<Dual>([&](int i, int c) { return Dual(E.radiance[3 * i + c], 0.f); }, E.width, E.height, u, w, rgb, uv_xf_d(E.xf, E.xf, false));
                 vb[j] = E.scale * (Lb.x * rgb[0].d + Lb.y * rgb[1].d + Lb.z * rgb[2].d);
                 if (j == 0) { uu = u.v; ww = w.v; rgb0[0] = rgb[0].v; rgb0[1] = rgb[1].v; rgb0[2] = rgb[2].v; }
             }
             const float lb[3] = {Lb.x, Lb.y, Lb.z}, dv[3] = {dir.x, dir.y, dir.z};
             if (P.g_env != nullptr) {
                 int idx[4]; float wt[4];
-                env::bitmap_footprint_env(E.width, E.height, uu, ww, idx, wt);
+                env::bitmap_footprint_env(E.width, E.height, uu, ww, idx, wt, env::UvXf<float>(E.xf));
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
                     if (lb[c] != 0.f) for (int k = 0; k < 4; ++k) {

@@ -66,7 +66,7 @@ PSDR_DEV Vec3f bsdf_value_and_adjoint(const SceneView<LDS> &S, int bid, const Ve
         if constexpr (has_mat(LDS)) {
             constexpr int CH = decltype(ch)::value;
             const TexDev td = S.T->tex[3 * bid + slot];
-            env::bitmap_eval_tex<float, CH>([&](int i, int c) { return td.data[CH * i + c]; }, td.w, td.h, tu, tv, true, out);
+            env::bitmap_eval_tex<float, CH>([&](int i, int c) { return td.data[CH * i + c]; }, td.w, td.h, tu, tv, true, out, env::UvXf<float>(td.xf));
         }
     };
     auto tex_back = [&](int slot, auto ch, const float *pb) {
@@ -75,14 +75,14 @@ PSDR_DEV Vec3f bsdf_value_and_adjoint(const SceneView<LDS> &S, int bid, const Ve
             const TexDev td = S.T->tex[3 * bid + slot];
             if (g_tex != nullptr) {
                 int idx[4]; float wt[4];
-                env::bitmap_footprint(td.w, td.h, tu, tv, true, idx, wt);
+                env::bitmap_footprint(td.w, td.h, tu, tv, true, idx, wt, env::UvXf<float>(td.xf));
                 for (int c = 0; c < CH; ++c)
                     if (pb[c] != 0.f && finite_(pb[c])) for (int k = 0; k < 4; ++k) atomicAdd(&g_tex[td.g_off + (long long) CH * idx[k] + c], pb[c] * wt[k]);
             }
             if (uvb != nullptr) {
                 for (int ax = 0; ax < 2; ++ax) {
                     Dual o[CH];
-                    env::bitmap_eval_tex<Dual, CH>([&](int i, int c) { return Dual(td.data[CH * i + c], 0.f); }, td.w, td.h, Dual(tu, ax == 0 ? 1.f : 0.f), Dual(tv, ax == 1 ? 1.f : 0.f), true, o);
+                    env::bitmap_eval_tex<Dual, CH>([&](int i, int c) { return Dual(td.data[CH * i + c], 0.f); }, td.w, td.h, Dual(tu, ax == 0 ? 1.f : 0.f), Dual(tv, ax == 1 ? 1.f : 0.f), true, o, uv_xf_d(td.xf, td.xf, false));
                     float g = 0.f;
                     for (int c = 0; c < CH; ++c) g += pb[c] * o[c].d;
                     if (finite_(g)) uvb[ax] += g;
@@ -308,14 +308,14 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                 Dual u = env_atan2(vd.x, -vd.z) * Dual(env::kInvTwoPi), w = env_safe_acos(vd.y) * Dual(env::kInvPi);
                 u = u - env_floor(u); w = w - env_floor(w);
                 Dual rgb[3];
-                env::bitmap_eval_fn<Dual>([&](int i, int c) { return Dual(E.radiance[3 * i + c], 0.f); }, E.width, E.height, u, w, rgb);
+                env::bitmap_eval_fn<Dual>([&](int i, int c) { return Dual(E.radiance[3 * i + c], 0.f); }, E.width, E.height, u, w, rgb, uv_xf_d(E.xf, E.xf, false));
                 vb[j] = E.scale * (Lb.x * rgb[0].d + Lb.y * rgb[1].d + Lb.z * rgb[2].d);
                 if (j == 0) { uu = u.v; ww = w.v; rgb0[0] = rgb[0].v; rgb0[1] = rgb[1].v; rgb0[2] = rgb[2].v; }
             }
             const float lb[3] = {Lb.x, Lb.y, Lb.z}, dv[3] = {dir.x, dir.y, dir.z};
             if (P.g_env != nullptr) {
                 int idx[4]; float wt[4];
-                env::bitmap_footprint_env(E.width, E.height, uu, ww, idx, wt);
+                env::bitmap_footprint_env(E.width, E.height, uu, ww, idx, wt, env::UvXf<float>(E.xf));
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
                     if (lb[c] != 0.f) for (int k = 0; k < 4; ++k) {

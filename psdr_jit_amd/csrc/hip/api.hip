@@ -697,13 +697,14 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
         std::memcpy(ED.to_world.m, er->to_world, 64); std::memcpy(ED.from_world.m, er->from_world, 64);
         std::memcpy(ED.d_from_world.m, er->d_from_world, 64); ED.d_scale = er->d_scale;
         for (int k = 0; k < 3; ++k) { ED.lower[k] = er->lower[k]; ED.upper[k] = er->upper[k]; }
+        for (int k = 0; k < 4; ++k) { ED.xf[k] = er->radiance_xf[k]; ED.d_xf[k] = er->d_radiance_xf[k]; }
     }
     T.tex = nullptr;
     {   // bitmap parameters: three slots per BSDF - [0] reflectance / diffuse reflectance (rgb), [1] specular (rgb), [2] roughness (1 channel)
         bool any_tex = false;
         for (int i = 0; i < s->n_bsdfs; ++i) any_tex |= s->bsdfs[i].tex_data != nullptr || s->bsdfs[i].spec_tex_data != nullptr || s->bsdfs[i].rough_tex_data != nullptr;
         if (any_tex) {
-            std::vector<TexDev> td((size_t) 3 * s->n_bsdfs, TexDev{nullptr, nullptr, 0, 0, -1});
+            std::vector<TexDev> td((size_t) 3 * s->n_bsdfs, TexDev{nullptr, nullptr, 0, 0, -1, {0.f, 1.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}});
             sc->tex_total = 0;
             int rc = 0;
             for (int i = 0; i < s->n_bsdfs; ++i) {
@@ -719,6 +720,7 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
                     td[3 * i + k].d_data = sc->up(dsrc[k], nt, rc);
                     td[3 * i + k].w = tw[k]; td[3 * i + k].h = th[k];
                     td[3 * i + k].g_off = sc->tex_total; sc->tex_total += (long long) nt;
+                    for (int q = 0; q < 4; ++q) { td[3 * i + k].xf[q] = b.tex_xf[k][q]; td[3 * i + k].d_xf[q] = b.d_tex_xf[k][q]; }
                 }
             }
             sc->bufs.emplace_back(new DevBuf());
@@ -1073,8 +1075,15 @@ static inline int grid_for(const psdr_hip_scene *sc, long long n) {
 #define IF_CLS2(...) (void) 0
 #endif
 
-#define LAUNCH(kernel, sc, n_lanes, stream, ...) \
-    hipLaunchKernelGGL(kernel, dim3(grid_for(sc, n_lanes)), dim3(kBlock), (sc)->smem_bytes, (hipStream_t) (stream), __VA_ARGS__)
+// dynamic LDS of a kernel of scene class `cls` (0 global tables, 1 LDS blob, 2 lean BVH, 3 LDS blob with materials): the traversal stack / cold rows,
+// plus the blob only for the classes that stage it - a class-0 kernel launched on a scene that ALSO has an LDS class (reverse mode,
+// counted runs, ray batches, field integrators on Microfacet / bitmap boxes) must not reserve the blob's bytes it never fills
+static size_t smem_for(const psdr_hip_scene *sc, int cls) {
+    const size_t blob = (sc->lds || sc->lds_mat) ? (size_t) sc->T.blob_words * 16 : 0;
+    return (cls == 1 || cls == 3) ? sc->smem_bytes : sc->smem_bytes - blob;
+}
+#define LAUNCH(cls_, kernel, sc, n_lanes, stream, ...) \
+    hipLaunchKernelGGL(kernel, dim3(grid_for(sc, n_lanes)), dim3(kBlock), smem_for(sc, cls_), (hipStream_t) (stream), __VA_ARGS__)
 
 static int check_args(const psdr_hip_scene *sc, const psdr_render_args *a) {
     if (!sc || !a) return fail("null argument");
@@ -1128,15 +1137,15 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
         if (P.n_local > 0) {
             if (next_queue(P.counter)) return 1;
             if (ad) {
-                if (cls == 1) ON_CLS1(LAUNCH((k_paths<true, 1, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
-                else if (cls == 2) ON_CLS2(LAUNCH((k_paths<true, 2, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
-                else if (cls == 3) ON_CLS3(LAUNCH((k_paths<true, 3, false, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
-                else ON_CLS0(LAUNCH((k_paths<true, 0, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
+                if (cls == 1) ON_CLS1(LAUNCH(1, (k_paths<true, 1, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
+                else if (cls == 2) ON_CLS2(LAUNCH(2, (k_paths<true, 2, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
+                else if (cls == 3) ON_CLS3(LAUNCH(3, (k_paths<true, 3, false, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
+                else ON_CLS0(LAUNCH(0, (k_paths<true, 0, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
             } else {
-                if (cls == 1) ON_CLS1(LAUNCH((k_paths<false, 1, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
-                else if (cls == 2) ON_CLS2(LAUNCH((k_paths<false, 2, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
-                else if (cls == 3) ON_CLS3(LAUNCH((k_paths<false, 3, false, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
-                else ON_CLS0(LAUNCH((k_paths<false, 0, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
+                if (cls == 1) ON_CLS1(LAUNCH(1, (k_paths<false, 1, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
+                else if (cls == 2) ON_CLS2(LAUNCH(2, (k_paths<false, 2, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
+                else if (cls == 3) ON_CLS3(LAUNCH(3, (k_paths<false, 3, false, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
+                else ON_CLS0(LAUNCH(0, (k_paths<false, 0, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
             }
         }
     }
@@ -1148,10 +1157,10 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
             P.n_local = local_lanes(P.end, rank, count);
             if (P.n_local > 0) {
                 if (next_queue(P.counter)) return 1;
-                if (cls == 1) ON_CLS1(LAUNCH((k_paths<false, 1, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
-                else if (cls == 2) ON_CLS2(LAUNCH((k_paths<false, 2, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
-                else if (cls == 3) ON_CLS3(LAUNCH((k_paths<false, 3, false, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
-                else ON_CLS0(LAUNCH((k_paths<false, 0, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
+                if (cls == 1) ON_CLS1(LAUNCH(1, (k_paths<false, 1, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
+                else if (cls == 2) ON_CLS2(LAUNCH(2, (k_paths<false, 2, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
+                else if (cls == 3) ON_CLS3(LAUNCH(3, (k_paths<false, 3, false, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
+                else ON_CLS0(LAUNCH(0, (k_paths<false, 0, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
             }
         }
         if ((terms & PSDR_TERM_SECONDARY) && T.sppse > 0 && sc->E.n > 0) {
@@ -1164,10 +1173,10 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
             if (a->guiding) G = a->guiding->G;
             if (P.n_local > 0) {
                 if (next_queue(P.counter)) return 1;
-                if (sc->lds) ON_CLS1(LAUNCH((k_secondary_edges<1, COUNT, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
-                else if (sc->lean) ON_CLS2(LAUNCH((k_secondary_edges<2, COUNT, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
-                else if (cls == 3) ON_CLS3(LAUNCH((k_secondary_edges<3, false, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
-                else ON_CLS0(LAUNCH((k_secondary_edges<0, COUNT, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
+                if (sc->lds) ON_CLS1(LAUNCH(1, (k_secondary_edges<1, COUNT, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
+                else if (sc->lean) ON_CLS2(LAUNCH(2, (k_secondary_edges<2, COUNT, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
+                else if (cls == 3) ON_CLS3(LAUNCH(3, (k_secondary_edges<3, false, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
+                else ON_CLS0(LAUNCH(0, (k_secondary_edges<0, COUNT, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
             }
         }
     }
@@ -1346,7 +1355,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         if (P.n_local > 0) {
             if (next_queue(P.counter)) return 1;
             const int grid = grid_for(sc, P.n_local);
-            const size_t sm = sc->smem_bytes + (P.lds_acc ? sizeof(float) * 4 * (size_t) cam.n_edges : 0);
+            const size_t sm = smem_for(sc, cls) + (P.lds_acc ? sizeof(float) * 4 * (size_t) cam.n_edges : 0);
             if (cls == 1) ON_CLS1(hipLaunchKernelGGL((k_paths<false, 1, false, 1>), dim3(grid), dim3(kBlock), sm, st, sc->blob.as<float4>(), T, cam, P, (Counters *) nullptr));
             else if (cls == 2) ON_CLS2(hipLaunchKernelGGL((k_paths<false, 2, false, 1>), dim3(grid), dim3(kBlock), sm, st, sc->blob.as<float4>(), T, cam, P, (Counters *) nullptr));
             else ON_CLS0(hipLaunchKernelGGL((k_paths<false, 0, false, 1>), dim3(grid), dim3(kBlock), sm, st, sc->blob.as<float4>(), T, cam, P, (Counters *) nullptr));
@@ -1362,7 +1371,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         P.sec_closed = no_sweep ? 0 : 1;
         const size_t sec_acc = sizeof(float) * (6 * (size_t) sc->E.n + 22 * (size_t) T.n_tris);
         P.lds_acc = (sec_acc <= 48 * 1024) ? 1 : 0;
-        const size_t smem_sec = sc->smem_bytes - cold_bytes + sizeof(float) * (size_t) kSecAdjScratch + (P.lds_acc ? sec_acc : 0);
+        const size_t smem_sec = smem_for(sc, sc->lds ? 1 : 0) - cold_bytes + sizeof(float) * (size_t) kSecAdjScratch + (P.lds_acc ? sec_acc : 0);
         GuidingDev G{};
         const int use_g = a->guiding ? 1 : 0;
         if (a->guiding) G = a->guiding->G;
@@ -1381,8 +1390,8 @@ static int trace_impl(const psdr_hip_scene *sc, int32_t n, const float *o, const
     if (!sc) return fail("null scene");
     if (n <= 0) return 0;
     SCRATCH_GUARD(sc, stream);
-    if (sc->lds) ON_CLS1(LAUNCH((k_trace<true>), sc, (long long) n, stream, sc->blob.as<float4>(), sc->T, n, o, d, out_tri, out_uv, out_t, pairs));
-    else LAUNCH((k_trace<false>), sc, (long long) n, stream, sc->blob.as<float4>(), sc->T, n, o, d, out_tri, out_uv, out_t, pairs);
+    if (sc->lds) ON_CLS1(LAUNCH(1, (k_trace<true>), sc, (long long) n, stream, sc->blob.as<float4>(), sc->T, n, o, d, out_tri, out_uv, out_t, pairs));
+    else LAUNCH(0, (k_trace<false>), sc, (long long) n, stream, sc->blob.as<float4>(), sc->T, n, o, d, out_tri, out_uv, out_t, pairs);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1404,11 +1413,14 @@ int psdr_hip_env_pdf(const psdr_hip_scene *sc, int32_t n, const float *ref_p, co
 }
 // cell masses of the environment map's sampling distribution: one thread per cell, the same envmath.h::cell_mass the host half's
 // test hook evaluates (bit-equal); 2 M cells of a 1024 x 512 map take ~0.1 ms instead of 80 ms on the host cores
-__global__ void k_env_cell_mass(const float *__restrict__ texels, int W, int H, int w2, int h2, int n, float *__restrict__ mass) {
+__global__ void k_env_cell_mass(const float *__restrict__ texels, int W, int H, int w2, int h2, int n, float *__restrict__ mass, env::UvXf<float> xf) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) mass[i] = env::cell_mass(texels, W, H, w2, h2, i);
+    if (i < n) mass[i] = env::cell_mass(texels, W, H, w2, h2, i, xf);
 }
 int psdr_hip_env_cell_masses(const float *texels, int32_t width, int32_t height, float *mass) {
+    return psdr_hip_env_cell_masses_xf(texels, width, height, nullptr, mass);
+}
+int psdr_hip_env_cell_masses_xf(const float *texels, int32_t width, int32_t height, const float *uv_xf, float *mass) {
     if (!texels || !mass) return fail("null texel / mass buffer");
     if (width < 2 || height < 2) return fail("EnvironmentMap: the bitmap needs at least 2 x 2 texels");
     const int w2 = (width - 1) << 1, h2 = (height - 1) << 1;
@@ -1416,7 +1428,7 @@ int psdr_hip_env_cell_masses(const float *texels, int32_t width, int32_t height,
     if (n > 0x7fffffffll) return fail("EnvironmentMap: too many cells");
     DevBuf tex, out;
     if (tex.upload(texels, sizeof(float) * 3 * (size_t) width * height) || out.upload(nullptr, sizeof(float) * (size_t) n)) return 1;
-    hipLaunchKernelGGL(k_env_cell_mass, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) nullptr, tex.as<float>(), width, height, w2, h2, (int) n, (float *) out.p);
+    hipLaunchKernelGGL(k_env_cell_mass, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) nullptr, tex.as<float>(), width, height, w2, h2, (int) n, (float *) out.p, uv_xf ? env::UvXf<float>(uv_xf) : env::UvXf<float>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(mass, out.p, sizeof(float) * (size_t) n, hipMemcpyDeviceToHost));
     return 0;
@@ -1426,8 +1438,8 @@ int psdr_hip_ray_intersect(const psdr_hip_scene *sc, int32_t n, const float *o, 
     if (n <= 0) return 0;
     if (!o || !d || !out) return fail("null ray / output buffer");
     SCRATCH_GUARD(sc, stream);
-    if (sc->lds) LAUNCH((k_intersect<true>), sc, (long long) n, stream, sc->blob.as<float4>(), sc->T, n, o, d, out);
-    else LAUNCH((k_intersect<false>), sc, (long long) n, stream, sc->blob.as<float4>(), sc->T, n, o, d, out);
+    if (sc->lds) LAUNCH(1, (k_intersect<true>), sc, (long long) n, stream, sc->blob.as<float4>(), sc->T, n, o, d, out);
+    else LAUNCH(0, (k_intersect<false>), sc, (long long) n, stream, sc->blob.as<float4>(), sc->T, n, o, d, out);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1457,8 +1469,8 @@ int psdr_hip_guiding_build(const psdr_hip_scene *sc, int32_t sensor_id, int32_t 
     if (mass.upload(nullptr, sizeof(float) * cells)) return 1;
     const long long nl = cells * reso[3];
     for (int r = 0; r < nrounds; ++r) {
-        if (sc->lds) ON_CLS1(LAUNCH((k_guiding_round<true>), sc, nl, st, sc->blob.as<float4>(), sc->T, sc->E, sc->sensors[sensor_id], G, reso[3], seed, r, (float *) mass.p));
-        else ON_CLS0(LAUNCH((k_guiding_round<false>), sc, nl, st, sc->blob.as<float4>(), sc->T, sc->E, sc->sensors[sensor_id], G, reso[3], seed, r, (float *) mass.p));
+        if (sc->lds) ON_CLS1(LAUNCH(1, (k_guiding_round<true>), sc, nl, st, sc->blob.as<float4>(), sc->T, sc->E, sc->sensors[sensor_id], G, reso[3], seed, r, (float *) mass.p));
+        else ON_CLS0(LAUNCH(0, (k_guiding_round<false>), sc, nl, st, sc->blob.as<float4>(), sc->T, sc->E, sc->sensors[sensor_id], G, reso[3], seed, r, (float *) mass.p));
     }
     HIPCHK(hipGetLastError());
     g->mass.resize(cells);

@@ -33,11 +33,15 @@ struct EnvDev {
     float d_scale;
     Mat4<float> to_world, from_world, d_from_world;
     float lower[3], upper[3];
+    float xf[4], d_xf[4];           // m_radiance's uv transform (rotate, scale, translate.x, translate.y; bitmap.h:37-39) and its forward tangent
 };
 
 // one bitmap parameter of a BSDF (global memory; w == 0: constant).  SceneTables::tex holds three per BSDF:
 // [0] reflectance / diffuse reflectance (rgb), [1] specular reflectance (rgb), [2] roughness (one channel)
-struct TexDev { const float *data, *d_data; int w, h; long long g_off; };    // g_off: offset of its texel adjoints in psdr_grads.g_tex
+struct TexDev {
+    const float *data, *d_data; int w, h; long long g_off;     // g_off: offset of its texel adjoints in psdr_grads.g_tex
+    float xf[4], d_xf[4];                                      // the bitmap's uv transform (rotate, scale, translate.x, translate.y; bitmap.h:37-39) and its forward tangent
+};
 
 // MicrofacetPerVertex (microfacet_pv.cpp): per-vertex parameter arrays of one BSDF in global memory (n == 0: not per-vertex)
 struct PvDev { const float *spec, *d_spec, *diff, *d_diff, *rough, *d_rough; int n; long long g_off[3]; };   // g_off: diffuse / specular / roughness adjoints in psdr_grads.g_tex

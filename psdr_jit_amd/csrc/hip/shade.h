@@ -233,6 +233,14 @@ PSDR_DEV int sample_reuse_guided(const int *guide, int guide_n, int size, float 
 PSDR_DEV Dual e_fma(const Dual &a, const Dual &b, const Dual &c) { return fma_(a, b, c); }
 PSDR_DEV Dual e_floor(const Dual &a) { return Dual(floorf(a.v), 0.f); }
 PSDR_DEV float e_value(const Dual &a) { return a.v; }
+PSDR_DEV void e_sincos(const Dual &a, Dual &s, Dual &c) { float sv, cv; env::sincos_f(a.v, sv, cv); s = Dual(sv, cv * a.d); c = Dual(cv, -(sv * a.d)); }
+// a bitmap's uv transform (bitmap.h:37-39) as (value, tangent): the forward tangents of rotate / scale / translate in a render; none in the
+// replays and sweeps of reverse mode (psdr_hip.h: their adjoints are taken in forward mode)
+PSDR_DEV env::UvXf<Dual> uv_xf_d(const float *xf, const float *d_xf, bool tan) {
+    return env::UvXf<Dual>(Dual(xf[0], tan ? d_xf[0] : 0.f), Dual(xf[1], tan ? d_xf[1] : 0.f), Dual(xf[2], tan ? d_xf[2] : 0.f), Dual(xf[3], tan ? d_xf[3] : 0.f));
+}
+template <int LDS> PSDR_DEV env::UvXf<Dual> tex_xf_d(const SceneView<LDS> &S, const TexDev &td) { return uv_xf_d(td.xf, td.d_xf, S.mode == 0 && S.probe_kind == 0); }
+template <int LDS> PSDR_DEV env::UvXf<Dual> env_xf_d(const SceneView<LDS> &S, const EnvDev &E) { return uv_xf_d(E.xf, E.d_xf, S.mode == 0 && S.probe_kind == 0); }
 PSDR_DEV float env_atan2(float y, float x) { return env::atan2_f(y, x); }
 PSDR_DEV Dual env_atan2(const Dual &y, const Dual &x) { return Dual(env::atan2_f(y.v, x.v), fmaf(x.v, y.d, -(y.v * x.d)) / fmaf(x.v, x.v, y.v * y.v)); }
 PSDR_DEV float env_safe_acos(float x) { return env::safe_acos_f(x); }
@@ -266,13 +274,13 @@ template <bool AD, int LDS> PSDR_DEV VecN<AD> env_eval_direction(const SceneView
     R rgb[3];
     if constexpr (AD) {
         const bool tt = S.mode == 0 && E.d_radiance != nullptr;
-        env::bitmap_eval_fn<Dual>([&](int i, int c) { return Dual(E.radiance[3 * i + c], tt ? E.d_radiance[3 * i + c] : 0.f); }, E.width, E.height, u, w, rgb);
+        env::bitmap_eval_fn<Dual>([&](int i, int c) { return Dual(E.radiance[3 * i + c], tt ? E.d_radiance[3 * i + c] : 0.f); }, E.width, E.height, u, w, rgb, env_xf_d(S, E));
         S.note_lookup(kEnvLookup, u.v, w.v);
         const int hot = S.lookup_hot(kEnvLookup, u.v, w.v, 0, 3);
         if (hot >= 0) rgb[hot].d += 1.f;
         return VecN<AD>(rgb[0], rgb[1], rgb[2]) * Dual(E.scale, S.mode == 0 ? E.d_scale : 0.f);
     } else {
-        env::bitmap_eval<R>(E.radiance, E.width, E.height, u, w, rgb);
+        env::bitmap_eval<R>(E.radiance, E.width, E.height, u, w, rgb, env::UvXf<float>(E.xf));
         return VecN<AD>(rgb[0], rgb[1], rgb[2]) * R(E.scale);
     }
 }
@@ -415,7 +423,7 @@ template <bool AD, int LDS> PSDR_DEV float pv_roughness(const SceneView<LDS> &S,
 template <bool AD, int LDS> PSDR_DEV float roughness_lookup(const SceneView<LDS> &S, int id, const Its<AD> &its) {
     const TexDev td = S.T->tex[3 * id + 2];
     float o[1];
-    env::bitmap_eval_tex<float, 1>([&](int i, int) { return td.data[i]; }, td.w, td.h, detach(its.tu), detach(its.tv), true, o);
+    env::bitmap_eval_tex<float, 1>([&](int i, int) { return td.data[i]; }, td.w, td.h, detach(its.tu), detach(its.tv), true, o, env::UvXf<float>(td.xf));
     return o[0];
 }
 // bitmap parameter `slot` (0..2) of BSDF `id` at its.uv as (value, tangent): forward texel tangents in a render, the probe's unit
@@ -424,7 +432,7 @@ template <int CH, bool AD, int LDS> PSDR_DEV void param_lookup(const SceneView<L
     const TexDev td = S.T->tex[3 * id + slot];
     const bool tt = AD && S.mode == 0 && td.d_data != nullptr;
     const Dual tu = Dual(its.tu), tv = Dual(its.tv);
-    env::bitmap_eval_tex<Dual, CH>([&](int i, int c) { return Dual(td.data[CH * i + c], tt ? td.d_data[CH * i + c] : 0.f); }, td.w, td.h, tu, tv, true, out);
+    env::bitmap_eval_tex<Dual, CH>([&](int i, int c) { return Dual(td.data[CH * i + c], tt ? td.d_data[CH * i + c] : 0.f); }, td.w, td.h, tu, tv, true, out, tex_xf_d(S, td));
     if constexpr (AD) {
         S.note_lookup(id, tu.v, tv.v);
         const int hot = S.lookup_hot(id, tu.v, tv.v, 3 * slot, CH);
@@ -458,7 +466,7 @@ template <bool AD, int LDS> PSDR_DEV VecN<AD> bsdf_eval_id(const SceneView<LDS> 
                     const TexDev td = S.T->tex[3 * id + slot];
                     constexpr int CH = decltype(ch)::value;
                     const bool tt = tan && td.d_data != nullptr;
-                    env::bitmap_eval_tex<Dual, CH>([&](int i, int c) { return Dual(td.data[CH * i + c], tt ? td.d_data[CH * i + c] : 0.f); }, td.w, td.h, tu, tv, true, out);
+                    env::bitmap_eval_tex<Dual, CH>([&](int i, int c) { return Dual(td.data[CH * i + c], tt ? td.d_data[CH * i + c] : 0.f); }, td.w, td.h, tu, tv, true, out, tex_xf_d(S, td));
                     if constexpr (AD) {                    // reverse mode: note the lookup / carry the probe's unit tangent (scene_dev.h)
                         S.note_lookup(id, tu.v, tv.v);
                         const int hot = S.lookup_hot(id, tu.v, tv.v, 3 * slot, CH);
@@ -546,12 +554,12 @@ template <bool AD, int LDS> PSDR_DEV VecN<AD> bsdf_eval_id(const SceneView<LDS> 
             if constexpr (AD) {
                 const bool tan = td.d_data != nullptr && S.mode == 0;      // (reverse mode: the texel adjoints come from the lookup probes)
                 env::bitmap_eval_tex<Dual>([&](int i, int c) { return Dual(td.data[3 * i + c], tan ? td.d_data[3 * i + c] : 0.f); },
-                                           td.w, td.h, its.tu, its.tv, true, rgb);
+                                           td.w, td.h, its.tu, its.tv, true, rgb, tex_xf_d(S, td));
                 S.note_lookup(bid_, its.tu.v, its.tv.v);
                 const int hot = S.lookup_hot(bid_, its.tu.v, its.tv.v, 0, 3);
                 if (hot >= 0) rgb[hot].d += 1.f;
             } else {
-                env::bitmap_eval_tex<float>([&](int i, int c) { return td.data[3 * i + c]; }, td.w, td.h, its.tu, its.tv, true, rgb);
+                env::bitmap_eval_tex<float>([&](int i, int c) { return td.data[3 * i + c]; }, td.w, td.h, its.tu, its.tv, true, rgb, env::UvXf<float>(td.xf));
             }
             refl = V(rgb[0], rgb[1], rgb[2]);
         }
@@ -692,12 +700,12 @@ template <bool AD, int LDS> PSDR_DEV NmFrame<Num<AD>> nm_frame(const SceneView<L
         R rgb[3];
         if constexpr (AD) {
             const bool tan = td.d_data != nullptr && S.mode == 0;
-            env::bitmap_eval_tex<Dual>([&](int i, int ch) { return Dual(td.data[3 * i + ch], tan ? td.d_data[3 * i + ch] : 0.f); }, td.w, td.h, its.tu, its.tv, true, rgb);
+            env::bitmap_eval_tex<Dual>([&](int i, int ch) { return Dual(td.data[3 * i + ch], tan ? td.d_data[3 * i + ch] : 0.f); }, td.w, td.h, its.tu, its.tv, true, rgb, tex_xf_d(S, td));
             S.note_lookup(bid, its.tu.v, its.tv.v);
             const int hot = S.lookup_hot(bid, its.tu.v, its.tv.v, 0, 3);
             if (hot >= 0) rgb[hot].d += 1.f;
         } else {
-            env::bitmap_eval_tex<float>([&](int i, int ch) { return td.data[3 * i + ch]; }, td.w, td.h, its.tu, its.tv, true, rgb);
+            env::bitmap_eval_tex<float>([&](int i, int ch) { return td.data[3 * i + ch]; }, td.w, td.h, its.tu, its.tv, true, rgb, env::UvXf<float>(td.xf));
         }
         c = V(rgb[0], rgb[1], rgb[2]);
     } else {

@@ -203,17 +203,23 @@ template <int LDS, bool COUNT> PSDR_DEV void t4_node(SceneView<LDS> &S, const T4
     const float sx = __uint_as_float((ex & 0xffu) << 23), sy = __uint_as_float(((ex >> 8) & 0xffu) << 23), sz = __uint_as_float(((ex >> 16) & 0xffu) << 23);
     const float ax0 = (n0.x - ox) * ix, ay0 = (n0.y - oy) * iy, az0 = (n0.z - oz) * iz;
     const float bxs = sx * ix, bys = sy * iy, bzs = sz * iz;
-    const unsigned qlx = __float_as_uint(n1.x), qly = __float_as_uint(n1.y), qlz = __float_as_uint(n1.z);
-    const unsigned qhx = __float_as_uint(n1.w), qhy = __float_as_uint(n2.x), qhz = __float_as_uint(n2.y);
+    // the planes a ray enters / leaves a box through are known from the signs of its direction: pick the byte words once per node
+    // (lo or hi per axis) instead of ordering every child's two plane distances with a min and a max (six instructions per child)
+    const bool ngx = ix < 0.f, ngy = iy < 0.f, ngz = iz < 0.f;
+    const unsigned wlx = __float_as_uint(n1.x), wly = __float_as_uint(n1.y), wlz = __float_as_uint(n1.z);
+    const unsigned whx = __float_as_uint(n1.w), why = __float_as_uint(n2.x), whz = __float_as_uint(n2.y);
+    const unsigned qnx = ngx ? whx : wlx, qny = ngy ? why : wly, qnz = ngz ? whz : wlz;
+    const unsigned qfx = ngx ? wlx : whx, qfy = ngy ? wly : why, qfz = ngz ? wlz : whz;
     const unsigned cds[4] = {__float_as_uint(n2.z), __float_as_uint(n2.w), __float_as_uint(n3.x), __float_as_uint(n3.y)};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float ax = fmaf((float) ((qlx >> (8 * k)) & 0xffu), bxs, ax0), bx = fmaf((float) ((qhx >> (8 * k)) & 0xffu), bxs, ax0);
-        const float ay = fmaf((float) ((qly >> (8 * k)) & 0xffu), bys, ay0), by = fmaf((float) ((qhy >> (8 * k)) & 0xffu), bys, ay0);
-        const float az = fmaf((float) ((qlz >> (8 * k)) & 0xffu), bzs, az0), bz = fmaf((float) ((qhz >> (8 * k)) & 0xffu), bzs, az0);
-        // slab test; fminf / fmaxf drop NaNs (0 * inf), which keeps the test conservative; the far side gets one ulp-scale of slack
-        const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
-        const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000004f;
+        const float ax = fmaf((float) ((qnx >> (8 * k)) & 0xffu), bxs, ax0), bx = fmaf((float) ((qfx >> (8 * k)) & 0xffu), bxs, ax0);
+        const float ay = fmaf((float) ((qny >> (8 * k)) & 0xffu), bys, ay0), by = fmaf((float) ((qfy >> (8 * k)) & 0xffu), bys, ay0);
+        const float az = fmaf((float) ((qnz >> (8 * k)) & 0xffu), bzs, az0), bz = fmaf((float) ((qfz >> (8 * k)) & 0xffu), bzs, az0);
+        // slab test; fminf / fmaxf drop NaNs (0 * inf, inf - inf for a direction component of zero), which keeps the test conservative; the far
+        // side gets one ulp-scale of slack
+        const float tn = fmaxf(fmaxf(ax, ay), fmaxf(az, 0.f));
+        const float tf = fminf(fminf(bx, by), bz) * 1.0000004f;
         const bool hit = (tn <= fminf(tf, bt)) & (cds[k] != kT4Miss);      // `&`: with `&&` the compiler sinks the load of the child's code into a branch - a second memory round trip per node
         key[k] = hit ? ((__float_as_uint(tn) & ~cmask) | cds[k]) : kT4Miss;
     }
@@ -350,8 +356,10 @@ PSDR_DEV bool trav4_run(SceneView<LDS> &S, Trav4 &tr, int posted, int max_busy) 
         const unsigned long long m_walk = __ballot(tr.code != kT4Done);
         if (m_walk != 0ull) {
             for (;;) {
+                // node step, THEN the leaves - also the ones this step arrived at: a worker whose nearest child is a leaf enqueues it and pops its next
+                // node in the same iteration instead of sitting out the next node step (round 3; a ray meets ~6 leaves on ~19 nodes)
                 if (tr.code < leaf_bit) t4_node<LDS, COUNT>(S, L, tr, cmask);
-                else if (tr.code != kT4Done) t4_enqueue(S, L, tr, cmask, leaf_bit);
+                if (tr.code >= leaf_bit && tr.code != kT4Done) t4_enqueue(S, L, tr, cmask, leaf_bit);
 #if PSDR_DIAG == 1
                 if (COUNT) S.c_hits++;
 #endif

@@ -67,7 +67,17 @@ PYBIND11_MODULE(_psdr_core, m) {
             return oss.str();
         });
 
-    py::class_<BSDF, Object>(m, "BSDF", py::dynamic_attr()).def_readwrite("twoSide", &BSDF::m_twoSide).def("anisotropic", &BSDF::anisotropic);
+    py::class_<BSDF, Object>(m, "BSDF", py::dynamic_attr()).def_readwrite("twoSide", &BSDF::m_twoSide).def("anisotropic", &BSDF::anisotropic)
+        // Bitmap::m_rot / m_scale / m_trans of bitmap slot 0..2 as [rotate, scale, translate.x, translate.y] (reference psdr.cpp:204-206, 217-219)
+        .def("_get_uv_xf", [](const BSDF &b, int slot, bool tangent) {
+            if (slot < 0 || slot > 2) throw Exception("BSDF: bitmap slot out of range");
+            farr a(4);
+            std::memcpy(a.mutable_data(), tangent ? b.d_uv_xf[slot] : b.uv_xf[slot], 16);
+            return a; })
+        .def("_set_uv_xf", [](BSDF &b, int slot, const farr &v, const farr &t) {
+            if (slot < 0 || slot > 2 || v.size() != 4) throw Exception("BSDF: a uv transform is [rotate, scale, translate.x, translate.y] of bitmap slot 0..2");
+            std::memcpy(b.uv_xf[slot], v.data(), 16);
+            if (t.size() == 4) std::memcpy(b.d_uv_xf[slot], t.data(), 16); else std::memset(b.d_uv_xf[slot], 0, 16); });
     py::class_<Diffuse, BSDF>(m, "DiffuseBSDF", py::dynamic_attr())
         .def(py::init<>())
         .def(py::init([](const farr &r) { return new Diffuse(to_a3(r)); }))
@@ -328,6 +338,7 @@ PYBIND11_MODULE(_psdr_core, m) {
                 return a;
             }
             if (name == "scale") { farr a(1); a.mutable_data()[0] = tangent ? e.d_scale : e.scale; return a; }
+            if (name == "radiance_uv_xf") { farr a(4); std::memcpy(a.mutable_data(), tangent ? e.d_uv_xf : e.uv_xf, 16); return a; }
             farr a({4, 4});
             if (name == "to_world_left") std::memcpy(a.mutable_data(), (tangent ? e.d_to_world_left : e.to_world_left).data(), 64);
             else if (tangent) std::memset(a.mutable_data(), 0, 64);
@@ -342,6 +353,11 @@ PYBIND11_MODULE(_psdr_core, m) {
                 if (!same) { e.data.assign(v.data(), v.data() + v.size()); e.m_cells_dirty = true; }      // (a tangent-only update keeps the cell distribution)
                 if (t.size() == v.size()) e.d_data.assign(t.data(), t.data() + t.size()); else e.d_data.clear();
             } else if (name == "scale") { e.scale = v.data()[0]; e.d_scale = t.size() ? t.data()[0] : 0.f; }
+            else if (name == "radiance_uv_xf") {          // m_radiance.rotate / scale / translate: the cell masses are those of the transformed map
+                if (v.size() != 4) throw Exception("EnvironmentMap: a uv transform is [rotate, scale, translate.x, translate.y]");
+                if (std::memcmp(e.uv_xf, v.data(), 16) != 0) { std::memcpy(e.uv_xf, v.data(), 16); e.m_cells_dirty = true; }
+                if (t.size() == 4) std::memcpy(e.d_uv_xf, t.data(), 16); else std::memset(e.d_uv_xf, 0, 16);
+            }
             else if (name == "to_world_left") { e.to_world_left = to_m16(v); e.d_to_world_left = t.size() == 16 ? to_m16(t) : zeros16(); }
             else e.to_world_raw = to_m16(v);
             e.m_ready = false; });

@@ -62,10 +62,10 @@ void EnvironmentMap::configure(bool on_device) {
         std::vector<float> mass((size_t) w2 * h2);
         const int n_cells = w2 * h2;
         if (on_device) {
-            hip_check(psdr_hip_env_cell_masses(data.data(), width, height, mass.data()));
+            hip_check(psdr_hip_env_cell_masses_xf(data.data(), width, height, uv_xf, mass.data()));
         } else {
 #pragma omp parallel for schedule(static)
-            for (int idx = 0; idx < n_cells; ++idx) mass[idx] = psdr::env::cell_mass(data.data(), width, height, w2, h2, idx);
+            for (int idx = 0; idx < n_cells; ++idx) mass[idx] = psdr::env::cell_mass(data.data(), width, height, w2, h2, idx, psdr::env::UvXf<float>(uv_xf));
         }
         cell_distrb.init(mass);
         m_cells_dirty = false;
@@ -676,6 +676,7 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
                 for (int k = 0; k < 3; ++k) { er.lower[k] = env->lower[k]; er.upper[k] = env->upper[k]; }
                 er.reso[0] = env->reso[0]; er.reso[1] = env->reso[1];
                 er.cell_pmf = env->cell_distrb.pmf.data(); er.cell_cmf = env->cell_distrb.cmf.data(); er.cell_sum = env->cell_distrb.sum;
+                for (int k = 0; k < 4; ++k) { er.radiance_xf[k] = env->uv_xf[k]; er.d_radiance_xf[k] = env->d_uv_xf[k]; }
                 S.has_envmap = true;
             } else {
                 AreaLight *al = static_cast<AreaLight *>(e);
@@ -685,7 +686,7 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
             S.emitters.push_back(r);
         }
     }
-    auto rec_of = [&](const BSDF *b, std::vector<psdr_bsdf_rec> &dst) {
+    auto rec_of_type = [&](const BSDF *b, std::vector<psdr_bsdf_rec> &dst) {
         if (const NormalMap *nm = dynamic_cast<const NormalMap *>(b)) {
             psdr_bsdf_rec r{};
             r.type = 5; r.two_sided = nm->m_twoSide ? 1 : 0; r.nested_bsdf = -1;       // patched below
@@ -785,6 +786,11 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
             r.d_tex_data = d->d_tex.size() == d->tex.size() ? d->d_tex.data() : nullptr;
         }
         dst.push_back(r);
+    };
+    auto rec_of = [&](const BSDF *b, std::vector<psdr_bsdf_rec> &dst) {
+        rec_of_type(b, dst);
+        std::memcpy(dst.back().tex_xf, b->uv_xf, sizeof(b->uv_xf));
+        std::memcpy(dst.back().d_tex_xf, b->d_uv_xf, sizeof(b->d_uv_xf));
     };
     for (BSDF *b : m_bsdfs) rec_of(b, S.bsdfs);
     // the BSDF a NormalMap perturbs travels as an extra entry behind the scene's own (no mesh refers to it)

@@ -59,6 +59,9 @@ struct Distrb {
 struct BSDF : Object {
     bool m_twoSide = false;
     virtual bool anisotropic() const = 0;
+    // uv transform of the BSDF's (up to three) bitmap parameters, slot order of psdr_bsdf_rec (0 reflectance / diffuse / eta / normal map,
+    // 1 specular / k, 2 roughness / alpha): Bitmap::m_rot, m_scale, m_trans.x, m_trans.y (reference bitmap.h:37-39) + forward tangents
+    float uv_xf[3][4] = {{0, 1, 0, 0}, {0, 1, 0, 0}, {0, 1, 0, 0}}, d_uv_xf[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 };
 struct Diffuse : BSDF {
     Diffuse() : reflectance{0.5f, 0.5f, 0.5f}, d_reflectance{0, 0, 0} {}
@@ -158,6 +161,7 @@ struct EnvironmentMap : Emitter {
     int width = 0, height = 0;
     std::vector<float> data, d_data;                                                   // [height*width*3] row-major rgb (+ forward tangent, may be empty)
     float scale = 1.f, d_scale = 0.f;
+    float uv_xf[4] = {0, 1, 0, 0}, d_uv_xf[4] = {0, 0, 0, 0};                          // m_radiance's m_rot, m_scale, m_trans (bitmap.h:37-39) + forward tangent
     M16 to_world_raw = identity16(), to_world_left = identity16(), d_to_world_left = zeros16();
     // configured state
     float to_world[16], from_world[16], d_to_world[16], d_from_world[16];

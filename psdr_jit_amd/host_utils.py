@@ -94,8 +94,8 @@ class DiscreteDistribution:
         return idx, self.m_pmf[idx] / np.float32(self.m_sum)
 
 
-def bitmap_eval(data, uv, flip_v=True, envmap_mode=False):
-    """Bitmap<C>::eval(uv, flip_v, envmap_mode) with the default translate / rotate / scale (bitmap.cpp:47-128).
+def bitmap_eval(data, uv, flip_v=True, envmap_mode=False, uv_xf=(0.0, 1.0, 0.0, 0.0)):
+    """Bitmap<C>::eval(uv, flip_v, envmap_mode) (bitmap.cpp:47-128); uv_xf = (rotate, scale, translate.x, translate.y).
     data: [H, W, C] or [H, W]; uv: [N, 2]; returns [N, C]."""
     a = np.asarray(data, dtype=np.float32)
     if a.ndim == 2:
@@ -106,9 +106,15 @@ def bitmap_eval(data, uv, flip_v=True, envmap_mode=False):
         return np.tile(a.reshape(1, C), (uv.shape[0], 1))
     if W < 2 or H < 2:
         raise RuntimeError("Bitmap: invalid resolution!")
-    x, y = uv[:, 0].copy(), uv[:, 1].copy()
+    f = np.float32
+    rot, scl, tx, ty = (f(q) for q in uv_xf)
+    sr, cr = f(np.sin(rot)), f(np.cos(rot))
+    u0, v0 = uv[:, 0] - f(0.5), uv[:, 1] - f(0.5)
+    x, y = u0 * cr + v0 * sr + f(0.5), -u0 * sr + v0 * cr + f(0.5)
     if flip_v:
         y = -y
+    off = f(-0.5) + scl * f(0.5)
+    x, y = x * scl - off + tx, y * scl + off + ty
     if envmap_mode:
         x = x - np.float32(0.5 / W)
     x, y = x - np.floor(x), y - np.floor(y)

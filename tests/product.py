@@ -38,6 +38,15 @@ def build_scene(spec, configure=True, active=(0,), host_only=False, log_level=0)
         bs.twoSide = bool(b.two_sided)
         return bs
 
+    def put_xf(bs, b):
+        # rotate / scale / translate of the three bitmap slots (BsdfSpec.tex_xf) and their forward tangents
+        if getattr(b, "tex_xf", None) is None and getattr(b, "d_tex_xf", None) is None:
+            return
+        xf = np.asarray(b.tex_xf if getattr(b, "tex_xf", None) is not None else [[0, 1, 0, 0]] * 3, np.float32).reshape(3, 4)
+        dxf = np.asarray(b.d_tex_xf if getattr(b, "d_tex_xf", None) is not None else np.zeros((3, 4)), np.float32).reshape(3, 4)
+        for k in range(3):
+            bs._set_uv_xf(k, np.ascontiguousarray(xf[k]), np.ascontiguousarray(dxf[k]))
+
     for i, b in enumerate(spec.bsdfs):
         if getattr(b, "type", 0) == 5:              # NormalMapBSDF over spec.bsdfs[b.nested] (which the scene also holds as its own entry)
             nm = psdr.NormalMapBSDF(list(b.reflectance))
@@ -47,6 +56,7 @@ def build_scene(spec, configure=True, active=(0,), host_only=False, log_level=0)
                 dtex = np.ascontiguousarray(np.asarray(b.d_texture, np.float32)) if getattr(b, "d_texture", None) is not None else np.zeros_like(tex)
                 nm._set("normal_map", tex, dtex)
             nm.nested_bsdf = plain_bsdf(spec.bsdfs[b.nested])
+            put_xf(nm, b)
             sc.add_BSDF(nm, b.name or ("bsdf%d" % i), b.two_sided)
             continue
         if getattr(b, "type", 0) == 1:
@@ -60,6 +70,7 @@ def build_scene(spec, configure=True, active=(0,), host_only=False, log_level=0)
                     tex = np.ascontiguousarray(np.asarray(t, np.float32))
                     dt = getattr(b, "d_" + attr, None)
                     bs._set(name, tex, np.ascontiguousarray(np.asarray(dt, np.float32)) if dt is not None else np.zeros_like(tex))
+            put_xf(bs, b)
             sc.add_BSDF(bs, b.name or ("bsdf%d" % i), b.two_sided)
             continue
         if getattr(b, "type", 0) == 2:
@@ -75,6 +86,7 @@ def build_scene(spec, configure=True, active=(0,), host_only=False, log_level=0)
                     tex = np.ascontiguousarray(np.asarray(t, np.float32))
                     dt = getattr(b, "d_" + attr, None)
                     bs._set(name, tex, np.ascontiguousarray(np.asarray(dt, np.float32)) if dt is not None else np.zeros_like(tex))
+            put_xf(bs, b)
             sc.add_BSDF(bs, b.name or ("bsdf%d" % i), b.two_sided)
             continue
         if getattr(b, "type", 0) == 4:
@@ -83,6 +95,7 @@ def build_scene(spec, configure=True, active=(0,), host_only=False, log_level=0)
             for attr, name, w in (("pv_specular", "specularReflectance", 3), ("pv_diffuse", "diffuseReflectance", 3), ("pv_roughness", "roughness", 1)):
                 d = getattr(b, "d_" + attr, None)
                 bs._set(name, f2(getattr(b, attr), w), f2(d, w) if d is not None else np.zeros_like(f2(getattr(b, attr), w)))
+            put_xf(bs, b)
             sc.add_BSDF(bs, b.name or ("bsdf%d" % i), b.two_sided)
             continue
         if getattr(b, "type", 0) == 3:
@@ -94,6 +107,7 @@ def build_scene(spec, configure=True, active=(0,), host_only=False, log_level=0)
                 tex = np.ascontiguousarray(np.asarray(b.rough_texture, np.float32))
                 dt = getattr(b, "d_rough_texture", None)
                 bs._set("alpha_u", tex, np.ascontiguousarray(np.asarray(dt, np.float32)) if dt is not None else np.zeros_like(tex))
+            put_xf(bs, b)
             sc.add_BSDF(bs, b.name or ("bsdf%d" % i), b.two_sided)
             continue
         bs = psdr.DiffuseBSDF(list(b.reflectance))
@@ -102,6 +116,7 @@ def build_scene(spec, configure=True, active=(0,), host_only=False, log_level=0)
             tex = np.ascontiguousarray(np.asarray(b.texture, np.float32))
             dtex = np.ascontiguousarray(np.asarray(b.d_texture, np.float32)) if getattr(b, "d_texture", None) is not None else np.zeros_like(tex)
             bs._set("reflectance", tex, dtex)
+        put_xf(bs, b)
         sc.add_BSDF(bs, b.name or ("bsdf%d" % i), b.two_sided)
     def add_envs_before(k):
         # emitters are numbered in the order they are added: keep the spec's numbering
@@ -115,6 +130,7 @@ def build_scene(spec, configure=True, active=(0,), host_only=False, log_level=0)
                 if getattr(e, "d_env_data", None) is not None:
                     env._set("radiance", np.ascontiguousarray(np.asarray(e.env_data, np.float32)), np.ascontiguousarray(np.asarray(e.d_env_data, np.float32)))
                 env._set("scale", np.asarray([e.env_scale], np.float32), np.asarray([getattr(e, "d_env_scale", 0.0)], np.float32))
+                env._set("radiance_uv_xf", np.asarray(getattr(e, "env_uv_xf", (0, 1, 0, 0)), np.float32), np.asarray(getattr(e, "d_env_uv_xf", (0, 0, 0, 0)), np.float32))
                 env._set("to_world_left", np.asarray(e.env_to_world_left, np.float32), np.asarray(getattr(e, "d_env_to_world_left", np.zeros((4, 4))), np.float32))
                 sc.add_EnvironmentMap(env)
                 added_env.add(i)

@@ -489,3 +489,122 @@ def test_primary_edge_closed_form_under_an_hdr_step_background(psdr, orc):
         bright, dim = dim, bright
     assert np.allclose(bright, -want * L_pos, rtol=0.01), (bright, -want * L_pos)
     assert np.allclose(dim, want * L_neg, rtol=0.01), (dim, want * L_neg)
+
+
+# ---------------------------------------------------------------- Bitmap::m_rot / m_scale / m_trans (bitmap.cpp:64-86, psdr.cpp:204-206, 217-219)
+XF = [[0.4, 1.6, 0.21, -0.13], [-0.7, 0.8, 0.05, 0.3], [1.1, 2.3, -0.4, 0.15]]
+
+
+@pytest.mark.parametrize("comp", [-1, 0, 1, 2, 3])
+def test_bitmap_uv_transform_diffuse(psdr, orc, comp):
+    """textured DiffuseBSDF under a uv transform: image and the forward tangent of rotate / scale / translate.x / translate.y against the
+    oracle (whose tangents are checked against finite differences in tests/test_oracle_envmap.py); edge terms on (box_x moves too for comp -1)"""
+    tex = scenes.checker_texture(33, 17, 5)
+    spec = scenes.textured_scene(48, 48, 8, 8, 8, texture=tex, param="box_x" if comp < 0 else None, env=True)
+    spec.bsdfs[0].tex_xf = [XF[0], [0, 1, 0, 0], [0, 1, 0, 0]]
+    if comp >= 0:
+        d = np.zeros((3, 4)); d[0, comp] = 1.0
+        spec.bsdfs[0].d_tex_xf = d
+    sc = product.build_scene(spec)
+    ref = orc.OracleScene(spec, [0])
+    img, dimg = psdr.render_d_fwd(psdr.PathTracer(2), sc, 0, seed=4)
+    wimg, wd = ref.render_d(max_depth=2, seeds=(4, 4, 4))
+    assert product.rel_l2(img.cpu().numpy(), wimg) < TOL
+    assert np.abs(wd).max() > 0 and product.rel_l2(dimg.cpu().numpy(), wd) < TOL
+    c = psdr.PathTracer(3).renderC(sc, 0, seed=2).cpu().numpy()
+    assert product.rel_l2(c, ref.render_c(max_depth=3, seed=2)) < TOL
+    # the transform matters: the untransformed texture gives another image
+    spec.bsdfs[0].tex_xf = None
+    assert product.rel_l2(c, orc.OracleScene(spec, [0]).render_c(max_depth=3, seed=2)) > 0.02
+
+
+@pytest.mark.parametrize("slot,comp", [(0, 0), (1, 1), (2, 2), (1, 3), (2, 0)])
+def test_bitmap_uv_transform_microfacet_slots(psdr, orc, slot, comp):
+    """MicrofacetBSDF with three bitmaps, each under its own transform (diffuse, specular, roughness): one component's tangent at a time"""
+    spec = scenes.textured_microfacet_scene(48, 48, 8, 8, 8)
+    spec.bsdfs[0].tex_xf = XF
+    d = np.zeros((3, 4)); d[slot, comp] = 1.0
+    spec.bsdfs[0].d_tex_xf = d
+    sc = product.build_scene(spec)
+    ref = orc.OracleScene(spec, [0])
+    img, dimg = psdr.render_d_fwd(psdr.PathTracer(2), sc, 0, seed=4)
+    wimg, wd = ref.render_d(max_depth=2, seeds=(4, 4, 4))
+    assert product.rel_l2(img.cpu().numpy(), wimg) < TOL
+    assert np.abs(wd).max() > 0 and product.rel_l2(dimg.cpu().numpy(), wd) < TOL
+
+
+@pytest.mark.parametrize("kind", ["roughconductor", "roughdielectric", "normalmap"])
+def test_bitmap_uv_transform_other_bsdfs(psdr, orc, kind):
+    """eta / k / alpha maps of RoughConductor, the alpha map of RoughDielectric and a normal map under uv transforms"""
+    spec = scenes.normalmap_scene(48, 48, 8, 8, 8) if kind == "normalmap" else scenes.textured_ggx_scene(48, 48, 8, 8, 8, kind=kind)
+    spec.bsdfs[0].tex_xf = XF
+    d = np.zeros((3, 4))
+    d[0 if kind != "roughdielectric" else 2, 0] = 1.0; d[2, 2] = 0.5
+    spec.bsdfs[0].d_tex_xf = d
+    sc = product.build_scene(spec)
+    ref = orc.OracleScene(spec, [0])
+    img, dimg = psdr.render_d_fwd(psdr.PathTracer(2), sc, 0, seed=4)
+    wimg, wd = ref.render_d(max_depth=2, seeds=(4, 4, 4))
+    assert product.rel_l2(img.cpu().numpy(), wimg) < TOL
+    assert np.abs(wd).max() > 0 and product.rel_l2(dimg.cpu().numpy(), wd) < TOL
+
+
+@pytest.mark.parametrize("comp", [-1, 0, 2])
+def test_envmap_radiance_uv_transform(psdr, orc, comp):
+    """m_radiance.rotate / scale / translate of the EnvironmentMap: lookups, the cell distribution EnvironmentMap::configure builds from
+    the transformed map (device cell masses == the oracle's), emitter sampling and pdf, and the forward tangent of the transform"""
+    spec = scenes.envmap_scene(48, 48, 8, 8, 8, param="box_x" if comp < 0 else None)
+    spec.emitters[0].env_uv_xf = (0.3, 1.0, 0.27, 0.0)
+    if comp >= 0:
+        d = [0.0] * 4; d[comp] = 1.0
+        spec.emitters[0].d_env_uv_xf = tuple(d)
+    sc = product.build_scene(spec)
+    ref = orc.OracleScene(spec, [0])
+    img, dimg = psdr.render_d_fwd(psdr.PathTracer(2), sc, 0, seed=4)
+    wimg, wd = ref.render_d(max_depth=2, seeds=(4, 4, 4))
+    assert product.rel_l2(img.cpu().numpy(), wimg) < TOL
+    assert np.abs(wd).max() > 0 and product.rel_l2(dimg.cpu().numpy(), wd) < TOL
+    spec.emitters[0].env_uv_xf = (0.0, 1.0, 0.0, 0.0)
+    assert product.rel_l2(img.cpu().numpy(), orc.OracleScene(spec, [0]).render_d(max_depth=2, seeds=(4, 4, 4))[0]) > 0.02
+
+
+def test_bitmap_transform_api_and_reverse_mode(psdr, orc):
+    """obj.uv_transform(name).rotate / scale / translate (the reference's bitmap.rotate / scale / translate members): assignment reaches the
+    renderer, tensors are leaves; backward() == the forward-mode derivative of each component dotted with the adjoint image"""
+    import torch
+    tex = scenes.checker_texture(33, 17, 5)
+    spec = scenes.textured_scene(40, 40, 8, 0, 0, texture=tex, env=True)
+    sc = product.build_scene(spec)
+    bs = sc.param_map["BSDF[0]"]
+    rot = torch.tensor(0.4, requires_grad=True)
+    scl = torch.tensor(1.6, requires_grad=True)
+    tr = torch.tensor([0.21, -0.13], requires_grad=True)
+    t = bs.uv_transform("reflectance")
+    t.rotate, t.scale, t.translate = rot, scl, tr
+    assert bs.uv_transform("reflectance").rotate is rot
+    sc.configure([0])
+    integ = psdr.PathTracer(2)
+    img = integ.renderD(sc, 0, seed=5)
+    spec.bsdfs[0].tex_xf = [XF[0], [0, 1, 0, 0], [0, 1, 0, 0]]
+    want = orc.OracleScene(spec, [0]).render_d(max_depth=2, seeds=(5, 5, 5))[0]
+    assert product.rel_l2(img.detach().cpu().numpy(), want) < TOL
+    w = torch.linspace(0.5, 1.5, img.numel(), device=img.device).reshape(img.shape)
+    (img * w).sum().backward()
+    got = [float(rot.grad), float(scl.grad), float(tr.grad[0]), float(tr.grad[1])]
+    for comp in range(4):
+        d = np.zeros((3, 4)); d[0, comp] = 1.0
+        spec.bsdfs[0].d_tex_xf = d
+        wd = orc.OracleScene(spec, [0]).render_d(max_depth=2, seeds=(5, 5, 5))[1]
+        ref = float((wd.astype(np.float64) * w.cpu().numpy().reshape(wd.shape)).sum())
+        assert abs(got[comp] - ref) < 2e-3 * max(1.0, abs(ref)), (comp, got[comp], ref)
+    # plain numbers again: the leaf goes away, the values stay
+    t.rotate, t.scale, t.translate = 0.0, 1.0, (0.0, 0.0)
+    sc.configure([0])
+    spec.bsdfs[0].tex_xf = None
+    c = integ.renderC(sc, 0, seed=2).cpu().numpy()
+    assert product.rel_l2(c, orc.OracleScene(spec, [0]).render_c(max_depth=2, seed=2)) < TOL
+    # a Bitmap3fD handed to a constructor brings its transform along
+    bm = psdr.Bitmap3fD(tex.shape[1], tex.shape[0], tex.reshape(-1, 3))
+    bm.rotate, bm.translate = 0.25, (0.1, 0.2)
+    b2 = psdr.DiffuseBSDF(bm)
+    assert np.allclose(np.asarray(b2._get_uv_xf(0, False)), [0.25, 1.0, 0.1, 0.2])

@@ -239,3 +239,95 @@ def test_primary_edge_term_against_the_closed_form_under_an_hdr_step_background(
     inside = (np.arange(H) + 1.0) / H > q_lo - 1e-6
     inside &= (np.arange(H) + 0.0) / H < q_hi + 1e-6
     assert rows[~inside].sum() == 0.0
+
+
+# ---------------------------------------------------------------- Bitmap::m_rot / m_scale / m_trans (bitmap.cpp:64-86)
+def periodic_texture(n=33):
+    """smooth texture whose last row / column repeats the first: the wrap `uv - floor(uv)` of a transformed lookup is continuous"""
+    t = np.arange(n) / (n - 1.0)
+    uu, vv = np.meshgrid(t, t)
+    two_pi = 2.0 * np.pi
+    return np.stack([0.5 + 0.3 * np.sin(two_pi * uu) * np.cos(two_pi * vv), 0.5 + 0.35 * np.cos(two_pi * (uu + vv)),
+                     0.4 + 0.25 * np.sin(two_pi * 2 * uu) + 0.1 * np.cos(two_pi * vv)], axis=-1).astype(np.float32)
+
+
+def test_bitmap_uv_transform_matches_the_analytic_lookup(orc):
+    """A floor seen from straight above under a constant map shows rho(T(uv)) L, T = rotate about the centre, flip v, scale about
+    the centre, translate (bitmap.cpp:64-74), for a texture given in closed form; the identity transform is the old lookup."""
+    n = 129
+    tex = periodic_texture(n)
+    res = 24
+    rot, scl, tx, ty = 0.4, 1.6, 0.21, -0.13
+    spec = scenes.textured_scene(res, res, 256, 0, 0, texture=tex, box=False)
+    spec.bsdfs[0].tex_xf = [[rot, scl, tx, ty], [0, 1, 0, 0], [0, 1, 0, 0]]
+    spec.cameras[0].to_world_raw = scenes.translate(280.0, 700.0, 280.0) @ scenes._rot_x(np.radians(90.0))
+    img = orc.OracleScene(spec, [0]).render_c(max_depth=1, seed=5).reshape(res, res, 3)
+    spec_u = scenes.textured_scene(res, res, 256, 0, 0, texture=np.full((4, 4, 3), 1.0, np.float32), box=False)
+    spec_u.cameras[0].to_world_raw = spec.cameras[0].to_world_raw
+    white = orc.OracleScene(spec_u, [0]).render_c(max_depth=1, seed=5).reshape(res, res, 3)          # the same paths on a white floor
+    # the uv of every pixel centre is not known in closed form here (camera orientation): recover it from a ramp texture
+    spec_r = scenes.textured_scene(res, res, 256, 0, 0, texture=scenes.ramp_texture(), box=False)
+    spec_r.cameras[0].to_world_raw = spec.cameras[0].to_world_raw
+    ramp = orc.OracleScene(spec_r, [0]).render_c(max_depth=1, seed=5).reshape(res, res, 3)
+    ok = white[..., 0] > 1e-3
+    u = (ramp[..., 0] / np.where(ok, white[..., 0], 1.0) - 0.2) / 0.6          # ramp: r = 0.2 + 0.6 u, g = 0.8 - 0.5 v'  (v' = the flipped, wrapped v)
+    vf = (0.8 - ramp[..., 1] / np.where(ok, white[..., 1], 1.0)) / 0.5
+    v = np.where(vf > 0, 1.0 - vf, 0.0)                                         # flip_v: v' = -v - floor(-v) = 1 - v on (0, 1)
+    x = (u - 0.5) * np.cos(rot) + (v - 0.5) * np.sin(rot) + 0.5
+    y = -(-(u - 0.5) * np.sin(rot) + (v - 0.5) * np.cos(rot) + 0.5)
+    off = -0.5 + scl / 2
+    x, y = x * scl - off + tx, y * scl + off + ty
+    two_pi = 2.0 * np.pi
+    want = np.stack([0.5 + 0.3 * np.sin(two_pi * x) * np.cos(two_pi * y), 0.5 + 0.35 * np.cos(two_pi * (x + y)),
+                     0.4 + 0.25 * np.sin(two_pi * 2 * x) + 0.1 * np.cos(two_pi * y)], axis=-1) * white
+    inner = ok & (u > 0.05) & (u < 0.95) & (v > 0.05) & (v < 0.95)
+    assert inner.sum() > 100
+    # the pixel footprint averages the texture over ~1/24 of the floor: compare the means and the per-pixel values loosely
+    err = np.abs(img[inner] - want[inner]).mean() / np.abs(want[inner]).mean()
+    assert err < 0.06, err
+    # identity transform given explicitly == no transform given
+    spec_i = scenes.textured_scene(res, res, 8, 0, 0, texture=tex, box=True)
+    a = orc.OracleScene(spec_i, [0]).render_c(max_depth=2, seed=2)
+    spec_i.bsdfs[0].tex_xf = [[0, 1, 0, 0]] * 3
+    b = orc.OracleScene(spec_i, [0]).render_c(max_depth=2, seed=2)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("comp", [0, 1, 2, 3])
+def test_bitmap_uv_transform_tangents_match_finite_differences(orc, comp):
+    """forward tangents of rotate / scale / translate.x / translate.y (the differentiable members m_rot, m_scale, m_trans,
+    bitmap.h:37-39) against central differences of renderC with common random numbers; depth 2 with the box: the lookups of
+    the second bounce carry the tangent too"""
+    tex = periodic_texture(33)
+    base = np.array([0.4, 1.6, 0.21, -0.13])
+    h = 2e-3
+
+    def make(delta, d):
+        spec = scenes.textured_scene(24, 24, 64, 0, 0, texture=tex, box=True)
+        xf = base.copy(); xf[comp] += delta
+        spec.bsdfs[0].tex_xf = [xf.tolist(), [0, 1, 0, 0], [0, 1, 0, 0]]
+        dx = np.zeros((3, 4)); dx[0, comp] = d
+        spec.bsdfs[0].d_tex_xf = dx
+        return orc.OracleScene(spec, [0])
+
+    img, dimg = make(0.0, 1.0).render_d(max_depth=2, seeds=(3, 3, 3))
+    fd = (make(+h, 0.0).render_c(max_depth=2, seed=3) - make(-h, 0.0).render_c(max_depth=2, seed=3)) / (2 * h)
+    assert np.abs(fd).max() > 0.05
+    rel = np.linalg.norm(dimg - fd) / np.linalg.norm(fd)
+    assert rel < 0.03, rel            # bilinear interpolation: the tangent is piecewise constant, the difference quotient crosses texel borders
+
+
+def test_envmap_radiance_translate_is_a_roll_of_the_texels(orc):
+    """m_radiance.translate.x = k / W shifts the lat-long lookup (bitmap.cpp:74, envmap_mode :83-87) by k texels - the image, and the
+    cell masses EnvironmentMap::configure builds through the same Bitmap::eval (envmap.cpp:28-31), are those of the rolled map"""
+    env = scenes.synthetic_envmap(64, 32)
+    k = 8
+    spec_t = scenes.envmap_scene(24, 24, 16, 0, 0, param=None, env=env)
+    spec_t.emitters[0].env_uv_xf = (0.0, 1.0, k / 64.0, 0.0)
+    spec_r = scenes.envmap_scene(24, 24, 16, 0, 0, param=None, env=np.ascontiguousarray(np.roll(env, -k, axis=1)))
+    a = orc.OracleScene(spec_t, [0]).render_c(max_depth=2, seed=3)
+    b = orc.OracleScene(spec_r, [0]).render_c(max_depth=2, seed=3)
+    assert np.linalg.norm(a - b) / np.linalg.norm(b) < 2e-3           # (u + k/W rounds differently from an index shift: a few samples change cells)
+    # the translated map is not the original one
+    c = orc.OracleScene(scenes.envmap_scene(24, 24, 16, 0, 0, param=None, env=env), [0]).render_c(max_depth=2, seed=3)
+    assert np.linalg.norm(a - c) / np.linalg.norm(c) > 0.05
