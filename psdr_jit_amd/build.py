@@ -68,11 +68,12 @@ def _run(cmd):
     return r.stdout
 
 
-N_KERNEL_UNITS = 5      # api.hip's PSDR_TU1..5: the heavy kernel templates of each scene class
+N_KERNEL_UNITS = 6      # api.hip's PSDR_TU1..6: the heavy kernel templates of each scene class
+UNIT_CLASS_BIT = {1: 1, 2: 1, 6: 1, 3: 2, 4: 4, 5: 8}      # the PSDR_CLS_MASK bit of the scene class a unit instantiates
 
 
 def build_hip(force=False, extra_flags=()):
-    """api.hip is compiled as six translation units in parallel - the host code with the small kernels (-DPSDR_SPLIT) and five units
+    """api.hip is compiled as seven translation units in parallel - the host code with the small kernels (-DPSDR_SPLIT) and six units
     that only instantiate the heavy kernel templates of one scene class (-DPSDR_TU=k) - and linked into one library: ~4 minutes of
     wall time instead of ~10 for the single unit (PSDR_BUILD_JOBS=1 compiles them one after the other)."""
     os.makedirs(LIBDIR, exist_ok=True)
@@ -82,7 +83,12 @@ def build_hip(force=False, extra_flags=()):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         objdir = os.path.join(LIBDIR, "obj")
         os.makedirs(objdir, exist_ok=True)
-        units = [("main", ["-DPSDR_SPLIT"])] + [("tu%d" % k, ["-DPSDR_TU=%d" % k]) for k in range(1, N_KERNEL_UNITS + 1)]
+        # development builds (-DPSDR_CLS_MASK=m: the host code launches the kernels of those scene classes only) skip the other classes' units
+        mask = 15
+        for f in flags:
+            if f.startswith("-DPSDR_CLS_MASK="):
+                mask = int(f.split("=")[1])
+        units = [("main", ["-DPSDR_SPLIT"])] + [("tu%d" % k, ["-DPSDR_TU=%d" % k]) for k in (1, 6, 2, 4, 5, 3) if UNIT_CLASS_BIT[k] & mask]
         jobs = max(1, int(os.environ.get("PSDR_BUILD_JOBS", str(min(len(units), os.cpu_count() or 1)))))
         objs, pending, running = [], list(units), []
         for name, _d in units:                           # objects of an earlier (possibly failed, possibly differently flagged) build never get linked

@@ -496,7 +496,7 @@ __global__ void k_sampler_floats(unsigned long long seed_value, unsigned long lo
 
 // ------------------------------------------------------------------------------------------------
 // Split build (psdr_jit_amd/build.py): the heavy kernel templates of each scene class are instantiated in translation units of
-// their own - this file compiled with -DPSDR_TU=1..5, kernels only - and compiled in parallel; the main unit (-DPSDR_SPLIT: host
+// their own - this file compiled with -DPSDR_TU=1..6, kernels only - and compiled in parallel; the main unit (-DPSDR_SPLIT: host
 // code + the small kernels) declares those instantiations extern.  Without either macro the file is one self-contained unit
 // (development builds, -DPSDR_CLS_MASK).
 #define PSDR_INST_PATHS(PFX, AD_, C_, CNT_, M_) PFX template __global__ void k_paths<AD_, C_, CNT_, M_>(const float4 *, const SceneTables, const SensorDev, const PathParams, Counters *);
@@ -505,7 +505,8 @@ __global__ void k_sampler_floats(unsigned long long seed_value, unsigned long lo
 #define PSDR_INST_SEC(PFX, C_, CNT_, ADJ_) PFX template __global__ void k_secondary_edges<C_, CNT_, ADJ_>(const float4 *, const SceneTables, const SecEdgeTables, const SensorDev, const PathParams, const GuidingDev, const int, Counters *);
 #define PSDR_INST_PATHS6(PFX, C_) PSDR_INST_PATHS(PFX, true, C_, false, 0) PSDR_INST_PATHS(PFX, false, C_, false, 0) PSDR_INST_PATHS(PFX, false, C_, false, 1) \
                                   PSDR_INST_PATHS(PFX, true, C_, true, 0) PSDR_INST_PATHS(PFX, false, C_, true, 0) PSDR_INST_PATHS(PFX, false, C_, true, 1)
-#define PSDR_TU1(PFX) PSDR_INST_PATHS6(PFX, 0)
+#define PSDR_TU1(PFX) PSDR_INST_PATHS(PFX, true, 0, false, 0) PSDR_INST_PATHS(PFX, false, 0, false, 0) PSDR_INST_PATHS(PFX, false, 0, false, 1)
+#define PSDR_TU6(PFX) PSDR_INST_PATHS(PFX, true, 0, true, 0) PSDR_INST_PATHS(PFX, false, 0, true, 0) PSDR_INST_PATHS(PFX, false, 0, true, 1)
 #define PSDR_TU2(PFX) PSDR_INST_ADJ(PFX, 0) PSDR_INST_ADJM(PFX, 0) PSDR_INST_SEC(PFX, 0, false, false) PSDR_INST_SEC(PFX, 0, true, false) PSDR_INST_SEC(PFX, 0, false, true)
 #define PSDR_TU3(PFX) PSDR_INST_PATHS6(PFX, 1) PSDR_INST_ADJ(PFX, 1) PSDR_INST_SEC(PFX, 1, false, false) PSDR_INST_SEC(PFX, 1, true, false) PSDR_INST_SEC(PFX, 1, false, true)
 #define PSDR_TU4(PFX) PSDR_INST_PATHS6(PFX, 2) PSDR_INST_ADJ(PFX, 2) PSDR_INST_SEC(PFX, 2, false, false) PSDR_INST_SEC(PFX, 2, true, false)
@@ -521,10 +522,12 @@ PSDR_TU3()
 PSDR_TU4()
 #elif PSDR_TU == 5
 PSDR_TU5()
+#elif PSDR_TU == 6
+PSDR_TU6()
 #endif
 #else
 #if defined(PSDR_SPLIT)
-PSDR_TU1(extern) PSDR_TU2(extern) PSDR_TU3(extern) PSDR_TU4(extern) PSDR_TU5(extern)
+PSDR_TU1(extern) PSDR_TU2(extern) PSDR_TU3(extern) PSDR_TU4(extern) PSDR_TU5(extern) PSDR_TU6(extern)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -617,11 +620,13 @@ struct psdr_hip_guiding {
 // Guide table of a discrete distribution (shade.h::sample_reuse_guided): entry k = the index DiscreteDistribution::sample_reuse finds for the
 // sample k / n_buckets, in the kernels' own float arithmetic (s * sum, then the first i < size - 1 whose running sum is not < s, else size - 1).
 // n_buckets: the power of two nearest to size / 16 (at least 1); tables below 256 entries are not worth one (-> empty).
-static void build_cdf_guide(const float *cmf, int size, float sum, std::vector<int> &guide) {
+// per_bucket: entries left to the binary search (32: one or two cache lines of the large environment / guiding tables; the edge
+// distributions - tens of thousands of entries, read by every edge sample - get 4)
+static void build_cdf_guide(const float *cmf, int size, float sum, std::vector<int> &guide, int per_bucket = 32) {
     guide.clear();
     if (size < 256) return;
     int nb = 1;
-    while (nb * 32 <= size) nb <<= 1;
+    while (nb * per_bucket <= size) nb <<= 1;
     guide.resize((size_t) nb + 1);
     for (int k = 0; k <= nb; ++k) {
         const float s = ((float) k / (float) nb) * sum;
@@ -829,6 +834,16 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     const psdr_sec_edges &se = s->sec_edges;
     SecEdgeTables &E = sc->E;
     E.n = se.n_edges; E.sum = se.sum;
+    E.guide = nullptr; E.guide_n = 0;
+    if (se.n_edges > 0 && se.cmf) {              // every sample of the secondary-edge term starts with this search (17 dependent loads for config 5's 122 885 edges)
+        std::vector<int> guide;
+        build_cdf_guide(se.cmf, se.n_edges, se.sum, guide, 4);
+        if (!guide.empty()) {
+            sc->bufs.emplace_back(new DevBuf());
+            if (sc->bufs.back()->upload(guide.data(), guide.size() * sizeof(int))) return 1;
+            E.guide = sc->bufs.back()->as<int>(); E.guide_n = (int) guide.size() - 1;
+        }
+    }
     E.off = (int) w;       w += 6 * (size_t) std::max(0, se.n_edges);
     E.cdf_off = (int) w;   w += words_for_floats(2 * (size_t) std::max(1, se.n_edges));
     std::vector<std::pair<int, int>> pe_offs;
@@ -988,6 +1003,16 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
         for (int k = 0; k < 3; ++k) { d.cam_pos[k] = r.cam_pos[k]; d.cam_dir[k] = r.cam_dir[k]; }
         d.inv_area = r.inv_area; d.n_edges = r.n_edges; d.edge_sum = r.edge_sum; d.ortho = r.orthographic;
         d.pe_off = pe_offs[i].first; d.pecdf_off = pe_offs[i].second;
+        d.pe_guide = nullptr; d.pe_guide_n = 0;
+        if (r.n_edges > 0 && r.edge_cmf) {       // a sample of the primary-edge term starts with this search (15 dependent loads for config 5's 26 592 edges)
+            std::vector<int> guide;
+            build_cdf_guide(r.edge_cmf, r.n_edges, r.edge_sum, guide, 4);
+            if (!guide.empty()) {
+                sc->bufs.emplace_back(new DevBuf());
+                if (sc->bufs.back()->upload(guide.data(), guide.size() * sizeof(int))) return 1;
+                d.pe_guide = sc->bufs.back()->as<int>(); d.pe_guide_n = (int) guide.size() - 1;
+            }
+        }
         sc->sensors.push_back(d);
     }
     if (sc->counters.upload(nullptr, sizeof(Counters))) return 1;
@@ -1470,7 +1495,7 @@ int psdr_hip_guiding_build(const psdr_hip_scene *sc, int32_t sensor_id, int32_t 
     const long long nl = cells * reso[3];
     for (int r = 0; r < nrounds; ++r) {
         if (sc->lds) ON_CLS1(LAUNCH(1, (k_guiding_round<true>), sc, nl, st, sc->blob.as<float4>(), sc->T, sc->E, sc->sensors[sensor_id], G, reso[3], seed, r, (float *) mass.p));
-        else ON_CLS0(LAUNCH(0, (k_guiding_round<false>), sc, nl, st, sc->blob.as<float4>(), sc->T, sc->E, sc->sensors[sensor_id], G, reso[3], seed, r, (float *) mass.p));
+        else LAUNCH(0, (k_guiding_round<false>), sc, nl, st, sc->blob.as<float4>(), sc->T, sc->E, sc->sensors[sensor_id], G, reso[3], seed, r, (float *) mass.p);      // (a plain kernel of the main unit: present in every development build)
     }
     HIPCHK(hipGetLastError());
     g->mass.resize(cells);

@@ -80,7 +80,7 @@ PSDR_DEV float sign1(float x) { return signbit_(x) ? -1.f : 1.f; }              
 template <int LDS> PSDR_DEV BoundarySegSampleDirect sample_boundary_segment_direct(const SceneView<LDS> &S, const SecEdgeTables &E, Vec3f s3) {
     BoundarySegSampleDirect r;
     float sample1 = s3.x, pdf0;
-    const int ei = sample_reuse<true>(E.n, E.sum, [&](int i) { return S.ldf(E.cdf_off, i); }, [&](int i) { return S.ldf(E.cdf_off, E.n + i); }, sample1, pdf0);
+    const int ei = sample_reuse_guided<true>(E.guide, E.guide_n, E.n, E.sum, [&](int i) { return S.ldf(E.cdf_off, i); }, [&](int i) { return S.ldf(E.cdf_off, E.n + i); }, sample1, pdf0);
     const int w = E.off + 6 * ei;
     const float4 q0 = S.ld(w), q1 = S.ld(w + 1), q2 = S.ld(w + 2), q3 = S.ld(w + 3), q4 = S.ld(w + 4), q5 = S.ld(w + 5);
     const Vec3f p0(q0.x, q0.y, q0.z), e1(q0.w, q1.x, q1.y), n0(q1.z, q1.w, q2.x), n1(q2.y, q2.z, q2.w), p2(q3.x, q3.y, q3.z);

@@ -123,7 +123,7 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
                         // PerspectiveCamera::sample_primary_edge, reference perspective.cpp:200-226
                         rng.seed(P.seed + (unsigned long long) lane, (unsigned long long) lane, P.skip);
                         float s = rng.next_1d(), pdf;
-                        const int ei = sample_reuse(cam.n_edges, cam.edge_sum, [&](int i) { return S.ldf(cam.pecdf_off, i); },
+                        const int ei = sample_reuse_guided(cam.pe_guide, cam.pe_guide_n, cam.n_edges, cam.edge_sum, [&](int i) { return S.ldf(cam.pecdf_off, i); },
                                                     [&](int i) { return S.ldf(cam.pecdf_off, cam.n_edges + i); }, s, pdf);
                         const float4 r0 = S.ld(cam.pe_off + 3 * ei), r1 = S.ld(cam.pe_off + 3 * ei + 1), r2 = S.ld(cam.pe_off + 3 * ei + 2);
                         pdf = fdiv(pdf, r2.z);
@@ -563,7 +563,7 @@ PSDR_DEV void run_paths_async(SceneView<LDS> &S, const SensorDev &cam, const Pat
                         } else {
                             rng.seed(P.seed + (unsigned long long) lane, (unsigned long long) lane, P.skip);
                             float s = rng.next_1d(), pdf;
-                            const int ei = sample_reuse(cam.n_edges, cam.edge_sum, [&](int i) { return S.ldf(cam.pecdf_off, i); },
+                            const int ei = sample_reuse_guided(cam.pe_guide, cam.pe_guide_n, cam.n_edges, cam.edge_sum, [&](int i) { return S.ldf(cam.pecdf_off, i); },
                                                         [&](int i) { return S.ldf(cam.pecdf_off, cam.n_edges + i); }, s, pdf);
                             const float4 r0 = S.ld(cam.pe_off + 3 * ei), r1 = S.ld(cam.pe_off + 3 * ei + 1), r2 = S.ld(cam.pe_off + 3 * ei + 2);
                             pdf = fdiv(pdf, r2.z);

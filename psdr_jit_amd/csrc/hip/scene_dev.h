@@ -82,6 +82,8 @@ struct SceneTables {
 struct SecEdgeTables {
     int off, cdf_off, n;
     float sum;
+    const int *guide;          // search bounds of the edge distribution per bucket of the sample (shade.h::sample_reuse_guided), [guide_n + 1]; guide_n = 0: none
+    int guide_n;
 };
 
 // Primary-edge table of one sensor inside the blob: 3 words per edge {p0.xy, p1.xy} {d_p0.xy, d_p1.xy} {n.xy, length, 0},
@@ -93,6 +95,8 @@ struct SensorDev {
     int n_edges, pe_off, pecdf_off;
     float edge_sum;
     int ortho;                 // OrthographicCamera
+    const int *pe_guide;       // search bounds of the primary-edge distribution (as SecEdgeTables::guide)
+    int pe_guide_n;
 };
 
 struct Counters { unsigned long long rays, nodes, tris, hits; };

@@ -35,6 +35,13 @@
 
 namespace psdr {
 
+// measurement knobs (tools/variants.py): leaf-enqueue rounds per burst iteration; a burst ends early when 1 / PSDR_BURST_DIV of the workers idle and as many rays wait
+#ifndef PSDR_ENQ_ROUNDS
+#define PSDR_ENQ_ROUNDS 1
+#endif
+#ifndef PSDR_BURST_DIV
+#define PSDR_BURST_DIV 4
+#endif
 constexpr unsigned kT4Done = 0xffffffffu;      // Trav4::code: no node in hand (walk finished, or no ray)
 constexpr unsigned kT4Miss = 0xffffffffu;      // sort key of a child the ray does not enter / code of an unused child slot
 
@@ -239,15 +246,16 @@ template <int LDS> PSDR_DEV void t4_enqueue(const SceneView<LDS> &S, const T4Lds
     const int lane_id = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane_id) - 1ull;
     const int payload = (int) (tr.code & (leaf_bit - 1u)), first = payload >> 2, cnt = (payload & 3) + 1;
-    // exclusive prefix sum of cnt (1..4) over the participating lanes
-    const unsigned long long b1 = __ballot(true), b2 = __ballot(cnt > 1), b3 = __ballot(cnt > 2), b4 = __ballot(cnt > 3);
-    const int before = __popcll(b1 & lt_mask) + __popcll(b2 & lt_mask) + __popcll(b3 & lt_mask) + __popcll(b4 & lt_mask);
-    const int total = __popcll(b1) + __popcll(b2) + __popcll(b3) + __popcll(b4);
+    // exclusive prefix sum of cnt over the participating lanes: a leaf holds one or two triangles (bvh.h::build_bvh, kLeafMax)
+    const unsigned long long b1 = __ballot(true), b2 = __ballot(cnt > 1);
+    const int before = __popcll(b1 & lt_mask) + __popcll(b2 & lt_mask);
+    const int total = __popcll(b1) + __popcll(b2);
     const unsigned base = L.heads[kHdPairEnq];        // every participating lane reads the old head ...
     wave_sync();
     if (lane_id == (int) __builtin_ctzll(b1)) L.heads[kHdPairEnq] = base + (unsigned) total;      // ... before the first of them advances it
     const unsigned mine = base + (unsigned) before;
-    for (int k = 0; k < cnt; ++k) L.ring[(mine + k) & (kPairCap - 1)] = ((unsigned) (first + k) << 7) | (unsigned) tr.rid;
+    L.ring[mine & (kPairCap - 1)] = ((unsigned) first << 7) | (unsigned) tr.rid;
+    if (cnt > 1) L.ring[(mine + 1u) & (kPairCap - 1)] = ((unsigned) (first + 1) << 7) | (unsigned) tr.rid;
     tr.last_pair = mine + (unsigned) cnt;
     tr.code = t4_next(S, L, tr, cmask, t4_best_t(L.best, tr.rid));
 }
@@ -359,7 +367,9 @@ PSDR_DEV bool trav4_run(SceneView<LDS> &S, Trav4 &tr, int posted, int max_busy) 
                 // node step, THEN the leaves - also the ones this step arrived at: a worker whose nearest child is a leaf enqueues it and pops its next
                 // node in the same iteration instead of sitting out the next node step (round 3; a ray meets ~6 leaves on ~19 nodes)
                 if (tr.code < leaf_bit) t4_node<LDS, COUNT>(S, L, tr, cmask);
-                if (tr.code >= leaf_bit && tr.code != kT4Done) t4_enqueue(S, L, tr, cmask, leaf_bit);
+#pragma unroll
+                for (int er = 0; er < PSDR_ENQ_ROUNDS; ++er)
+                    if (tr.code >= leaf_bit && tr.code != kT4Done) t4_enqueue(S, L, tr, cmask, leaf_bit);
 #if PSDR_DIAG == 1
                 if (COUNT) S.c_hits++;
 #endif
@@ -367,7 +377,7 @@ PSDR_DEV bool trav4_run(SceneView<LDS> &S, Trav4 &tr, int posted, int max_busy) 
                 const int waiting = (int) (L.heads[kHdPairEnq] - tested);
                 if (waiting >= n_lanes || __ballot(tr.code != kT4Done) == 0ull) break;
                 // workers that ran out of nodes idle until the burst ends: end it early when many do and rays are waiting
-                if (avail > n_lanes / 4 && __popcll(__ballot(tr.code == kT4Done)) >= n_lanes / 4) break;
+                if (avail > n_lanes / PSDR_BURST_DIV && __popcll(__ballot(tr.code == kT4Done)) >= n_lanes / PSDR_BURST_DIV) break;
             }
         }
         PSDR_T4PHASE(c_nodes);
@@ -411,11 +421,19 @@ template <int LDS> PSDR_DEV int t4_post(const SceneView<LDS> &S, const Vec3f &oA
     L.best[lane_id] = kT4NoHit; L.best[64 + lane_id] = kT4NoHit;
     L.fin[lane_id] = 0u; L.fin[64 + lane_id] = 0u;
     const unsigned long long mA = __ballot(actA), mB = __ballot(actB), m_all = __ballot(true);
-    const int before = __popcll(mA & lt_mask) + __popcll(mB & lt_mask), total = __popcll(mA) + __popcll(mB);
+    // queue order: all extension rays (closest hit wanted: the long walks), then the next-event rays (they stop at the first occluder) - the
+    // workers take rays in this order, so the long ones start first and the short ones fill the end of the traversal phase
+    const int nB = __popcll(mB), total = __popcll(mA) + nB;
     const unsigned tail = L.heads[kHdRayTail];
     wave_sync();
+#ifdef PSDR_RQ_INTERLEAVED
+    const int before = __popcll(mA & lt_mask) + __popcll(mB & lt_mask);
     if (actA) L.rq[(tail + (unsigned) before) & (kRayCap - 1)] = (unsigned) lane_id;
     if (actB) L.rq[(tail + (unsigned) before + (actA ? 1u : 0u)) & (kRayCap - 1)] = 64u + (unsigned) lane_id;
+#else
+    if (actB) L.rq[(tail + (unsigned) __popcll(mB & lt_mask)) & (kRayCap - 1)] = 64u + (unsigned) lane_id;
+    if (actA) L.rq[(tail + (unsigned) (nB + __popcll(mA & lt_mask))) & (kRayCap - 1)] = (unsigned) lane_id;
+#endif
     if (lane_id == (int) __builtin_ctzll(m_all)) L.heads[kHdRayTail] = tail + (unsigned) total;
     wave_sync();
     return (actA ? 1 : 0) | (actB ? 2 : 0);
