@@ -42,6 +42,9 @@ namespace psdr {
 #ifndef PSDR_BURST_DIV
 #define PSDR_BURST_DIV 4
 #endif
+#ifndef PSDR_PAIR_MIN          // a burst ends when the ring holds this many pairs, and that many are worth a (partial) test round; 64 = a wave's worth
+#define PSDR_PAIR_MIN 48         // (config 5: 32: 260.5, 48: 258.9, 64: 264.4 ms - earlier hits cull more; 128 - two rounds back to back, half the outer iterations - 285 vs 264 ms on config 5: the hits arrive later and cull less)
+#endif
 constexpr unsigned kT4Done = 0xffffffffu;      // Trav4::code: no node in hand (walk finished, or no ray)
 constexpr unsigned kT4Miss = 0xffffffffu;      // sort key of a child the ray does not enter / code of an unused child slot
 
@@ -375,7 +378,7 @@ PSDR_DEV bool trav4_run(SceneView<LDS> &S, Trav4 &tr, int posted, int max_busy) 
 #endif
                 wave_sync();
                 const int waiting = (int) (L.heads[kHdPairEnq] - tested);
-                if (waiting >= n_lanes || __ballot(tr.code != kT4Done) == 0ull) break;
+                if (waiting >= (PSDR_PAIR_MIN < n_lanes ? PSDR_PAIR_MIN : n_lanes) || __ballot(tr.code != kT4Done) == 0ull) break;
                 // workers that ran out of nodes idle until the burst ends: end it early when many do and rays are waiting
                 if (avail > n_lanes / PSDR_BURST_DIV && __popcll(__ballot(tr.code == kT4Done)) >= n_lanes / PSDR_BURST_DIV) break;
             }
@@ -386,7 +389,7 @@ PSDR_DEV bool trav4_run(SceneView<LDS> &S, Trav4 &tr, int posted, int max_busy) 
             unsigned from = tested;
             const unsigned head = L.heads[kHdPairEnq];
             while ((int) (head - from) >= n_lanes) { t4_test_pairs<LDS, COUNT>(S, L, from, n_lanes); from += (unsigned) n_lanes; }
-            if (head != from && (__ballot(wait_pairs) != 0ull || (m_walk == 0ull && avail <= 0))) {
+            if (head != from && ((int) (head - from) >= PSDR_PAIR_MIN || __ballot(wait_pairs) != 0ull || (m_walk == 0ull && avail <= 0))) {
                 t4_test_pairs<LDS, COUNT>(S, L, from, (int) (head - from));
                 from = head;
             }
