@@ -99,7 +99,16 @@ template <bool AD, int LDS, bool COUNT, int MODE>
 #ifndef PSDR_GLOBAL_AD_WAVES
 #define PSDR_GLOBAL_AD_WAVES 3
 #endif
-__global__ __launch_bounds__(kBlock, (AD ? (in_lds(LDS) ? 3 : PSDR_GLOBAL_AD_WAVES) : (in_lds(LDS) ? 4 : PSDR_GLOBAL_C_WAVES))) void k_paths(const float4 *__restrict__ blob, const SceneTables T, const SensorDev cam,
+#ifndef PSDR_LDS_AD_WAVES       // classes 1 / 3 (scene in LDS), AD kernel: 2 / 3 / 4 waves per SIMD measured on C3 1.67 / 1.79 / 2.11 ms (the tangents spill at 168 registers)
+#define PSDR_LDS_AD_WAVES 2
+#endif
+#ifndef PSDR_LDS_C_WAVES
+#define PSDR_LDS_C_WAVES 4
+#endif
+#ifndef PSDR_LEAN_AD_WAVES       // class 2 (BVH scenes): 1 / 2 / 3 / 4 waves per SIMD measured on config 5's interior kernel 47.9 / 31.6 / 34.5 / 37.1 ms, sphere box 13.2 / 7.6 / 8.2 / 8.8 ms -
+#define PSDR_LEAN_AD_WAVES 2     // the (value, tangent) path state spills less at 256 registers than it gains from a third wave; the C-mode kernels want their four (3: +16 %, 2: +60 %)
+#endif
+__global__ __launch_bounds__(kBlock, (AD ? (in_lds(LDS) ? PSDR_LDS_AD_WAVES : (LDS == 2 ? PSDR_LEAN_AD_WAVES : PSDR_GLOBAL_AD_WAVES)) : (in_lds(LDS) ? PSDR_LDS_C_WAVES : PSDR_GLOBAL_C_WAVES))) void k_paths(const float4 *__restrict__ blob, const SceneTables T, const SensorDev cam,
                                                   const PathParams P, Counters *ctr) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     SceneView<LDS> S = make_view<LDS>(blob, T, smem);
@@ -167,8 +176,15 @@ PSDR_DEV float guiding_sample_reuse(const GuidingDev &G, Vec3f &s) {
 // sample_boundary_segment_direct (silhouette condition + light facing), and only those trace rays.  Each lane
 // therefore keeps drawing candidates (RNG seed + three draws + the validity test, no ray) until the wave holds
 // enough valid ones, and the traced part (3 rays) runs with nearly all lanes active (stage r01a: 17 %).
+// waves per SIMD of the secondary-edge kernel (forward): its candidate rounds are chains of dependent loads, so it wants occupancy - measured on
+// config 5 (class 2) 2 / 3 / 4 waves: 48.6 / 38.3 / 33.2 ms (the compiler's own choice was 2), on C3 (class 1) 3 / 4 / 5: 0.79 / 0.72 / 0.76 ms;
+// the material classes and the reverse-mode instantiation keep the compiler's choice (1 = no constraint)
+#ifndef PSDR_SEC_WAVES
+#define PSDR_SEC_WAVES 4
+#endif
 template <int LDS, bool COUNT, bool ADJ>
-__global__ __launch_bounds__(kBlock) void k_secondary_edges(const float4 *__restrict__ blob, const SceneTables T, const SecEdgeTables E,
+__global__ __launch_bounds__(kBlock, ((!ADJ && (LDS == 1 || LDS == 2)) ? PSDR_SEC_WAVES : 1)) void k_secondary_edges(
+                                                            const float4 *__restrict__ blob, const SceneTables T, const SecEdgeTables E,
                                                             const SensorDev cam, const PathParams P, const GuidingDev G, const int use_guiding,
                                                             Counters *ctr) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
