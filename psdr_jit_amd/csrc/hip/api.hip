@@ -130,8 +130,14 @@ __global__ __launch_bounds__(kBlock, (AD ? (in_lds(LDS) ? PSDR_LDS_AD_WAVES : (L
 }
 
 // reverse mode of the interior term (adjoint.h)
+#ifndef PSDR_ADJ_WAVES          // measurement knob: waves per SIMD of the interior adjoint kernel (1 = the compiler's choice)
+#define PSDR_ADJ_WAVES 1
+#endif
+#ifndef PSDR_SEC_ADJ_WAVES
+#define PSDR_SEC_ADJ_WAVES 1
+#endif
 template <int LDS>
-__global__ __launch_bounds__(kBlock) void k_interior_adjoint(const float4 *__restrict__ blob, const SceneTables T, const SensorDev cam,
+__global__ __launch_bounds__(kBlock, PSDR_ADJ_WAVES) void k_interior_adjoint(const float4 *__restrict__ blob, const SceneTables T, const SensorDev cam,
                                                              const AdjointParams P) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     SceneView<LDS> S = make_view<LDS>(blob, T, smem);
@@ -183,7 +189,7 @@ PSDR_DEV float guiding_sample_reuse(const GuidingDev &G, Vec3f &s) {
 #define PSDR_SEC_WAVES 4
 #endif
 template <int LDS, bool COUNT, bool ADJ>
-__global__ __launch_bounds__(kBlock, ((!ADJ && (LDS == 1 || LDS == 2)) ? PSDR_SEC_WAVES : 1)) void k_secondary_edges(
+__global__ __launch_bounds__(kBlock, (ADJ ? PSDR_SEC_ADJ_WAVES : ((LDS == 1 || LDS == 2) ? PSDR_SEC_WAVES : 1))) void k_secondary_edges(
                                                             const float4 *__restrict__ blob, const SceneTables T, const SecEdgeTables E,
                                                             const SensorDev cam, const PathParams P, const GuidingDev G, const int use_guiding,
                                                             Counters *ctr) {
@@ -525,7 +531,7 @@ __global__ void k_sampler_floats(unsigned long long seed_value, unsigned long lo
 #define PSDR_TU6(PFX) PSDR_INST_PATHS(PFX, true, 0, true, 0) PSDR_INST_PATHS(PFX, false, 0, true, 0) PSDR_INST_PATHS(PFX, false, 0, true, 1)
 #define PSDR_TU2(PFX) PSDR_INST_ADJ(PFX, 0) PSDR_INST_ADJM(PFX, 0) PSDR_INST_SEC(PFX, 0, false, false) PSDR_INST_SEC(PFX, 0, true, false) PSDR_INST_SEC(PFX, 0, false, true)
 #define PSDR_TU3(PFX) PSDR_INST_PATHS6(PFX, 1) PSDR_INST_ADJ(PFX, 1) PSDR_INST_SEC(PFX, 1, false, false) PSDR_INST_SEC(PFX, 1, true, false) PSDR_INST_SEC(PFX, 1, false, true)
-#define PSDR_TU4(PFX) PSDR_INST_PATHS6(PFX, 2) PSDR_INST_ADJ(PFX, 2) PSDR_INST_SEC(PFX, 2, false, false) PSDR_INST_SEC(PFX, 2, true, false)
+#define PSDR_TU4(PFX) PSDR_INST_PATHS6(PFX, 2) PSDR_INST_ADJ(PFX, 2) PSDR_INST_SEC(PFX, 2, false, false) PSDR_INST_SEC(PFX, 2, true, false) PSDR_INST_SEC(PFX, 2, false, true)
 #define PSDR_TU5(PFX) PSDR_INST_PATHS(PFX, true, 3, false, 0) PSDR_INST_PATHS(PFX, false, 3, false, 0) PSDR_INST_PATHS(PFX, false, 3, false, 1) PSDR_INST_SEC(PFX, 3, false, false)
 #if defined(PSDR_TU)
 #if PSDR_TU == 1
@@ -1350,6 +1356,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         IF_CLS2(HIPCHK(hipFuncSetAttribute((const void *) k_interior_adjoint<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
         IF_CLS1(HIPCHK(hipFuncSetAttribute((const void *) k_secondary_edges<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
         IF_CLS0(HIPCHK(hipFuncSetAttribute((const void *) k_secondary_edges<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
+        IF_CLS2(HIPCHK(hipFuncSetAttribute((const void *) k_secondary_edges<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
         sc->adj_attr_set = true;
     }
     if ((terms & PSDR_TERM_INTERIOR) && T.spp > 0) {
@@ -1420,6 +1427,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
             if (next_queue(P.counter)) return 1;
             const int grid = grid_for(sc, P.n_local);
             if (sc->lds) ON_CLS1(hipLaunchKernelGGL((k_secondary_edges<true, false, true>), dim3(grid), dim3(kBlock), smem_sec, st, sc->blob.as<float4>(), Ta, sc->E, cam, P, G, use_g, (Counters *) nullptr));
+            else if (sc->lean && a->field_mode == 0) ON_CLS2(hipLaunchKernelGGL((k_secondary_edges<2, false, true>), dim3(grid), dim3(kBlock), smem_sec, st, sc->blob.as<float4>(), Ta, sc->E, cam, P, G, use_g, (Counters *) nullptr));      // (the lean instantiation, as the forward pass)
             else ON_CLS0(hipLaunchKernelGGL((k_secondary_edges<false, false, true>), dim3(grid), dim3(kBlock), smem_sec, st, sc->blob.as<float4>(), Ta, sc->E, cam, P, G, use_g, (Counters *) nullptr));
         }
     }

@@ -1,5 +1,5 @@
 """Per-term renderD timings of a named test scene (tests/scenes.py) at the C3 settings: 512x512, spp = sppe = sppse = 32, depth 3.
-    python tools/bench_scene.py sphere|cbox|envballs|microfacet|conductor"""
+    python tools/bench_scene.py sphere|cbox|envballs|microfacet|conductor|bunny"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -13,7 +13,9 @@ spec = {"sphere": lambda: scenes.sphere_scene(res, res, spp, spp, spp),
         "cbox": lambda: scenes.cbox_scene(res, res, spp, spp, spp),
         "envballs": lambda: scenes.envmap_scene(res, res, spp, spp, spp, param="albedo", balls=True),
         "microfacet": lambda: scenes.microfacet_cbox_scene(res, res, spp, spp, spp),
-        "conductor": lambda: scenes.conductor_cbox_scene(res, res, spp, spp, spp)}[name]()
+        "conductor": lambda: scenes.conductor_cbox_scene(res, res, spp, spp, spp),
+        # scene class 0 (global memory, materials + environment map): the envmap notebook's glossy bunny under the full-size ballroom map
+        "bunny": lambda: scenes.envmap_tutorial_scene(res, res, spp, spp, spp, param="bunny_x", env_stride=1)}[name]()
 sc = product.build_scene(spec)
 integ = psdr.PathTracer(3)
 for terms, label in ((1, "interior"), (2, "primary"), (4, "secondary"), (7, "all")):
