@@ -96,8 +96,8 @@ template <bool AD, int LDS, bool COUNT, int MODE>
 #ifndef PSDR_GLOBAL_C_WAVES
 #define PSDR_GLOBAL_C_WAVES 4
 #endif
-#ifndef PSDR_GLOBAL_AD_WAVES
-#define PSDR_GLOBAL_AD_WAVES 3
+#ifndef PSDR_GLOBAL_AD_WAVES     // class 0: 2 / 3 waves measured on the envmap notebook's glossy bunny (512², 32 spp): interior 4.93 / 5.53 ms
+#define PSDR_GLOBAL_AD_WAVES 2
 #endif
 #ifndef PSDR_LDS_AD_WAVES       // classes 1 / 3 (scene in LDS), AD kernel: 2 / 3 / 4 waves per SIMD measured on C3 1.67 / 1.79 / 2.11 ms (the tangents spill at 168 registers)
 #define PSDR_LDS_AD_WAVES 2
@@ -183,13 +183,14 @@ PSDR_DEV float guiding_sample_reuse(const GuidingDev &G, Vec3f &s) {
 // therefore keeps drawing candidates (RNG seed + three draws + the validity test, no ray) until the wave holds
 // enough valid ones, and the traced part (3 rays) runs with nearly all lanes active (stage r01a: 17 %).
 // waves per SIMD of the secondary-edge kernel (forward): its candidate rounds are chains of dependent loads, so it wants occupancy - measured on
-// config 5 (class 2) 2 / 3 / 4 waves: 48.6 / 38.3 / 33.2 ms (the compiler's own choice was 2), on C3 (class 1) 3 / 4 / 5: 0.79 / 0.72 / 0.76 ms;
-// the material classes and the reverse-mode instantiation keep the compiler's choice (1 = no constraint)
+// config 5 (class 2) 2 / 3 / 4 waves: 48.6 / 38.3 / 33.2 ms (the compiler's own choice was 2), on C3 (class 1) 3 / 4 / 5: 0.79 / 0.72 / 0.76 ms, on the
+// Microfacet box (class 3) 0.83 -> 0.75 ms, on the glossy bunny under the ballroom map (class 0) 1.85 -> 1.52 ms; the reverse-mode instantiation keeps
+// the compiler's choice (1 = no constraint; 2-4 measured: +1-3 %)
 #ifndef PSDR_SEC_WAVES
 #define PSDR_SEC_WAVES 4
 #endif
 template <int LDS, bool COUNT, bool ADJ>
-__global__ __launch_bounds__(kBlock, (ADJ ? PSDR_SEC_ADJ_WAVES : ((LDS == 1 || LDS == 2) ? PSDR_SEC_WAVES : 1))) void k_secondary_edges(
+__global__ __launch_bounds__(kBlock, (ADJ ? PSDR_SEC_ADJ_WAVES : PSDR_SEC_WAVES)) void k_secondary_edges(
                                                             const float4 *__restrict__ blob, const SceneTables T, const SecEdgeTables E,
                                                             const SensorDev cam, const PathParams P, const GuidingDev G, const int use_guiding,
                                                             Counters *ctr) {
