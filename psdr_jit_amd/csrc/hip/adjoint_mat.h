@@ -51,9 +51,9 @@ PSDR_DEV void vertex_frame(const Vec3<R> &ns, const Vec3<R> &e1, const Vec3<R> &
 // texels of the lookup (g_tex, TexDev::g_off) and - uvb given - chained to the texture coordinates (the camera vertex: its
 // barycentrics are differentiable).
 template <int LDS>
-PSDR_DEV Vec3f bsdf_value_and_adjoint(const SceneView<LDS> &S, int bid, const Vec3f &wi, const Vec3f &wo, float tu, float tv, const Vec3f *Fb,
-                                      float *wib, float *wob, float *acc_bsdf, float *acc_mat, float *g_tex, float *uvb,
-                                      int slot = -1, float bu = 0.f, float bv = 0.f, float *bcb = nullptr) {
+PSDR_DEV Vec3f bsdf_plain_value_and_adjoint(const SceneView<LDS> &S, int bid, const Vec3f &wi, const Vec3f &wo, float tu, float tv, const Vec3f *Fb,
+                                            float *wib, float *wob, float *acc_bsdf, float *acc_mat, float *g_tex, float *uvb,
+                                            int slot = -1, float bu = 0.f, float bv = 0.f, float *bcb = nullptr) {
     if (wib) { wib[0] = wib[1] = wib[2] = 0.f; wob[0] = wob[1] = wob[2] = 0.f; }
     if (bid < 0) return Vec3f(0.f);
     const float4 a = S.ld(S.T->bsdf_off + 2 * bid);
@@ -237,6 +237,115 @@ PSDR_DEV Vec3f bsdf_value_and_adjoint(const SceneView<LDS> &S, int bid, const Ve
         else if (acc_bsdf) { add(&acc_bsdf[3 * bid], pb[0]); add(&acc_bsdf[3 * bid + 1], pb[1]); add(&acc_bsdf[3 * bid + 2], pb[2]); }
     }
     return F;
+}
+
+// NormalMap (normalmap.cpp:45-83; shade.h::normalmap_eval): what the map does to the two directions, as a function of (wi, wo, map value c, dp_du) -
+// the directions in the perturbed frame, the reflected incident direction in it, the two weights
+template <typename R>
+PSDR_DEV void nm_geometry(const Vec3<R> &wi, const Vec3<R> &wo, const Vec3<R> &c, const Vec3<R> &dpdu, Vec3<R> &pwi, Vec3<R> &pwo, Vec3<R> &rwi, R &lp, R &g1, bool &refl) {
+    const Vec3<R> wp = normalize(Vec3<R>(fma_(c.x, R(2.f), R(-1.f)), fma_(c.y, R(2.f), R(-1.f)), fma_(c.z, R(2.f), R(-1.f))));
+    const Vec3<R> s = normalize(dpdu - wp * dot(wp, dpdu));
+    const NmFrame<R> pf(wp, s);
+    pwi = pf.to_local(wi); pwo = pf.to_local(wo);
+    g1 = nm_G1(wp, wo); lp = nm_lambda_p(wp, wi);
+    const Vec3<R> wt = nm_wt(wp);
+    refl = detach(dot(wi, wt)) > 0.f;
+    const Vec3<R> wi_r = normalize(wi - wt * (R(2.0f) * dot(wi, wt)));
+    rwi = pf.to_local(wi_r);
+}
+
+// F(wi, wo) and its adjoints for any BSDF of the material sweep.  A NormalMap (round 3) is its nested BSDF seen through the map:
+//     F = N(pwi, pwo) lp g1 + [wi.wt > 0] N(rwi, pwo) (1 - lp) g1,
+// so the nested BSDF's own adjoint routine gives the adjoints of its parameters and of (pwi, pwo, rwi); the 11 quantities nm_geometry returns
+// are differentiated with respect to its 12 inputs by forward evaluations, which chains those - and the adjoints of the two weights - to wi, wo,
+// the map value (constant: the NormalMap's g_bsdf row; bitmap: the four texels of the lookup and, at the camera vertex, the texture
+// coordinates) and dp_du (`dpb`: the caller takes it to the triangle's edges).  dpdu / dpb: the vertex's dp_du (make_its), needed by NormalMaps only.
+template <int LDS>
+PSDR_DEV Vec3f bsdf_value_and_adjoint(const SceneView<LDS> &S, int bid, const Vec3f &wi_, const Vec3f &wo_, float tu, float tv, const Vec3f *Fb,
+                                      float *wib, float *wob, float *acc_bsdf, float *acc_mat, float *g_tex, float *uvb,
+                                      int slot = -1, float bu = 0.f, float bv = 0.f, float *bcb = nullptr, const Vec3f *dpdu = nullptr, float *dpb = nullptr) {
+    if constexpr (has_mat(LDS)) {
+        if (bid >= 0 && (__float_as_int(S.ld(S.T->bsdf_off + 2 * bid).w) & 256)) {
+            if (wib) { wib[0] = wib[1] = wib[2] = 0.f; wob[0] = wob[1] = wob[2] = 0.f; }
+            if (dpb) { dpb[0] = dpb[1] = dpb[2] = 0.f; }
+            const float4 a = S.ld(S.T->bsdf_off + 2 * bid);
+            const int fl = __float_as_int(a.w);
+            const int nested = __float_as_int(S.ld(S.T->bsdf_off + 2 * bid + 1).w);
+            Vec3f wi = wi_, wo = wo_;
+            float sgn = 1.f;
+            if (fl & 1) { sgn = wi.z < 0.f ? -1.f : 1.f; wo.z = wo.z * sgn; wi.z = fabsf(wi.z); }       // (mulsign / abs of the two-sided form)
+            if (!(wi.z > 0.f && wo.z > 0.f)) return Vec3f(0.f);
+            Vec3f c(a.x, a.y, a.z);
+            const TexDev td = (fl & 2) ? S.T->tex[3 * bid] : TexDev{};
+            if (fl & 2) {
+                float o[3];
+                env::bitmap_eval_tex<float, 3>([&](int i, int ch) { return td.data[3 * i + ch]; }, td.w, td.h, tu, tv, true, o, env::UvXf<float>(td.xf));
+                c = Vec3f(o[0], o[1], o[2]);
+            }
+            const Vec3f dp = dpdu ? *dpdu : Vec3f(0.f);
+            Vec3f pwi, pwo, rwi;
+            float lp, g1;
+            bool refl;
+            nm_geometry<float>(wi, wo, c, dp, pwi, pwo, rwi, lp, g1, refl);
+            const Vec3f N1 = bsdf_plain_value_and_adjoint<LDS>(S, nested, pwi, pwo, tu, tv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, slot, bu, bv, nullptr);
+            Vec3f N2(0.f);
+            if (refl) N2 = bsdf_plain_value_and_adjoint<LDS>(S, nested, rwi, pwo, tu, tv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, slot, bu, bv, nullptr);
+            const Vec3f F = N1 * (lp * g1) + N2 * ((1.f - lp) * g1);
+            if (Fb == nullptr) return F;
+            if (!(finite_(Fb->x) && finite_(Fb->y) && finite_(Fb->z)) || (Fb->x == 0.f && Fb->y == 0.f && Fb->z == 0.f)) return F;
+            // the nested BSDF's adjoints (its parameters accumulate inside) for the two evaluations
+            float pwib[3], pwob[3], rwib[3] = {0.f, 0.f, 0.f}, pwob2[3] = {0.f, 0.f, 0.f};
+            const Vec3f Nb1 = *Fb * (lp * g1);
+            bsdf_plain_value_and_adjoint<LDS>(S, nested, pwi, pwo, tu, tv, &Nb1, pwib, pwob, acc_bsdf, acc_mat, g_tex, uvb, slot, bu, bv, bcb);
+            if (refl) {
+                const Vec3f Nb2 = *Fb * ((1.f - lp) * g1);
+                bsdf_plain_value_and_adjoint<LDS>(S, nested, rwi, pwo, tu, tv, &Nb2, rwib, pwob2, acc_bsdf, acc_mat, g_tex, uvb, slot, bu, bv, bcb);
+            }
+            const Vec3f dN = N1 - N2, mix = N1 * lp + N2 * (1.f - lp);
+            const float lpb = g1 * (Fb->x * dN.x + Fb->y * dN.y + Fb->z * dN.z), g1b = Fb->x * mix.x + Fb->y * mix.y + Fb->z * mix.z;
+            float inb[12];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                const float one = 1.f;
+                const Vec3d wiD(Dual(wi.x, j == 0 ? one : 0.f), Dual(wi.y, j == 1 ? one : 0.f), Dual(wi.z, j == 2 ? one : 0.f));
+                const Vec3d woD(Dual(wo.x, j == 3 ? one : 0.f), Dual(wo.y, j == 4 ? one : 0.f), Dual(wo.z, j == 5 ? one : 0.f));
+                const Vec3d cD(Dual(c.x, j == 6 ? one : 0.f), Dual(c.y, j == 7 ? one : 0.f), Dual(c.z, j == 8 ? one : 0.f));
+                const Vec3d dD(Dual(dp.x, j == 9 ? one : 0.f), Dual(dp.y, j == 10 ? one : 0.f), Dual(dp.z, j == 11 ? one : 0.f));
+                Vec3d pwiD, pwoD, rwiD;
+                Dual lpD, g1D;
+                bool r2;
+                nm_geometry<Dual>(wiD, woD, cD, dD, pwiD, pwoD, rwiD, lpD, g1D, r2);
+                float g = pwib[0] * pwiD.x.d + pwib[1] * pwiD.y.d + pwib[2] * pwiD.z.d
+                        + (pwob[0] + pwob2[0]) * pwoD.x.d + (pwob[1] + pwob2[1]) * pwoD.y.d + (pwob[2] + pwob2[2]) * pwoD.z.d
+                        + lpb * lpD.d + g1b * g1D.d;
+                if (refl) g += rwib[0] * rwiD.x.d + rwib[1] * rwiD.y.d + rwib[2] * rwiD.z.d;
+                inb[j] = finite_(g) ? g : 0.f;
+            }
+            if (wib) { wib[0] = inb[0]; wib[1] = inb[1]; wib[2] = inb[2] * sgn; wob[0] = inb[3]; wob[1] = inb[4]; wob[2] = inb[5] * sgn; }
+            // the map value: a constant's adjoint is the NormalMap's g_bsdf row, a bitmap's goes to the four texels of the lookup and to the texture coordinates
+            if (fl & 2) {
+                if (g_tex != nullptr) {
+                    int idx[4]; float wt4[4];
+                    env::bitmap_footprint(td.w, td.h, tu, tv, true, idx, wt4, env::UvXf<float>(td.xf));
+                    for (int ch = 0; ch < 3; ++ch)
+                        if (inb[6 + ch] != 0.f) for (int k = 0; k < 4; ++k) atomicAdd(&g_tex[td.g_off + 3ll * idx[k] + ch], inb[6 + ch] * wt4[k]);
+                }
+                if (uvb != nullptr) {
+                    for (int ax = 0; ax < 2; ++ax) {
+                        Dual o[3];
+                        env::bitmap_eval_tex<Dual, 3>([&](int i, int ch) { return Dual(td.data[3 * i + ch], 0.f); }, td.w, td.h, Dual(tu, ax == 0 ? 1.f : 0.f), Dual(tv, ax == 1 ? 1.f : 0.f), true, o, uv_xf_d(td.xf, td.xf, false));
+                        const float g = inb[6] * o[0].d + inb[7] * o[1].d + inb[8] * o[2].d;
+                        if (finite_(g)) uvb[ax] += g;
+                    }
+                }
+            } else if (acc_bsdf) {
+                for (int ch = 0; ch < 3; ++ch) if (inb[6 + ch] != 0.f) atomicAdd(&acc_bsdf[3 * bid + ch], inb[6 + ch]);
+            }
+            if (dpb) { dpb[0] = inb[9]; dpb[1] = inb[10]; dpb[2] = inb[11]; }
+            return F;
+        }
+    }
+    return bsdf_plain_value_and_adjoint<LDS>(S, bid, wi_, wo_, tu, tv, Fb, wib, wob, acc_bsdf, acc_mat, g_tex, uvb, slot, bu, bv, bcb);
 }
 
 template <int LDS>
@@ -565,7 +674,13 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                     if (bid >= 0) {
                         const int bfl = __float_as_int(S.ld(T.bsdf_off + 2 * bid).w);
                         if (bfl & (8 | 16)) { const MatDev md = T.mat[bid]; aniso = md.alpha_u != md.alpha_v; }
+                        if (bfl & 256) aniso = true;             // a NormalMap sees the frame through dp_du (a world-space vector beside the local map normal, normalmap.cpp:62)
                     }
+                    // its.dp_du of the vertex (make_its; scene.cpp:724-766) and its adjoint: NormalMaps only
+                    Vec3f dpdu_k(0.f), dpdu_b(0.f);
+                    const float det_uv = fma_(fu0x, fu1y, -(fu0y * fu1x));
+                    const float inv_det_uv = det_uv != 0.f ? 1.f / det_uv : 0.f;
+                    if (det_uv != 0.f) dpdu_k = (gk.e1 * fu1y - gk.e2 * fu0y) * inv_det_uv;
                     Vec3f xb(0.f), nsb(0.f), A_k(0.f), wib_w(0.f);
                     // F and, for its adjoint Fb, the adjoints of the outgoing direction (returned), of the incident direction and of ns
                     // (accumulated), and of the BSDF's parameters (accumulated in LDS)
@@ -581,13 +696,14 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                     }
                     auto bsdf_primal = [&](const Vec3f &w) -> Vec3f {
                         const Vec3f wo_l(dot(w, fs), dot(w, ft), dot(w, gk.ns));
-                        return bsdf_value_and_adjoint<LDS>(S, bid, wi_l, wo_l, tu, tv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, __float_as_int(vr[0]), bary_u, bary_v, nullptr);
+                        return bsdf_value_and_adjoint<LDS>(S, bid, wi_l, wo_l, tu, tv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, __float_as_int(vr[0]), bary_u, bary_v, nullptr, &dpdu_k, nullptr);
                     };
                     auto bsdf_back = [&](const Vec3f &w, const Vec3f &Fb) -> Vec3f {
                         const Vec3f wo_l(dot(w, fs), dot(w, ft), dot(w, gk.ns));
-                        float wib_l[3], wob_l[3];
+                        float wib_l[3], wob_l[3], dpb_l[3] = {0.f, 0.f, 0.f};
                         bsdf_value_and_adjoint<LDS>(S, bid, wi_l, wo_l, tu, tv, &Fb, wib_l, wob_l, P.skip_bsdf ? nullptr : acc_bsdf, acc_mat, P.g_tex, (k == 0 && T.tex != nullptr) ? uvb : nullptr,
-                                                    __float_as_int(vr[0]), bary_u, bary_v, k == 0 ? bcb : nullptr);
+                                                    __float_as_int(vr[0]), bary_u, bary_v, k == 0 ? bcb : nullptr, &dpdu_k, dpb_l);
+                        dpdu_b = dpdu_b + Vec3f(dpb_l[0], dpb_l[1], dpb_l[2]);
                         wib_w = wib_w + fs * wib_l[0] + ft * wib_l[1] + gk.ns * wib_l[2];
                         if (aniso) {
                             // local components = dot products with the frame vectors: their adjoints (the tangents' go through vertex_frame below)
@@ -685,6 +801,11 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                         nsb = nsb + Vec3f(gj[0], gj[1], gj[2]);
                         if (uvf) { e1b_f = Vec3f(gj[3], gj[4], gj[5]); e2b_f = Vec3f(gj[6], gj[7], gj[8]); }
                         if (wanted(gk) && uvf) { add_vec(gk, 3, e1b_f); add_vec(gk, 6, e2b_f); }
+                    }
+                    // dp_du = (e1 dv1 - e2 dv0) / det: a NormalMap's adjoint of it goes to the triangle's edges
+                    if (det_uv != 0.f && wanted(gk) && (dpdu_b.x != 0.f || dpdu_b.y != 0.f || dpdu_b.z != 0.f)) {
+                        add_vec(gk, 3, dpdu_b * (fu1y * inv_det_uv));
+                        add_vec(gk, 6, dpdu_b * (-fu0y * inv_det_uv));
                     }
                     // the incident direction's adjoint: to the camera ray at the first vertex, else to x_{k-1} and x_k
                     Vec3f pb(0.f);

@@ -576,6 +576,7 @@ struct psdr_hip_scene {
     DevBuf blob;
     bool lds = false;                    // scene class 1: staged in LDS (scene_dev.h)
     bool lean = false;                   // scene class 2: global memory, Diffuse BSDFs + area lights + environment map only
+    bool has_nmap = false;               // a NormalMap BSDF is present (material sweep even without a material table)
     bool simple_mats = true;             // every BSDF is Diffuse, Microfacet (constants or bitmaps) or a constant RoughConductor (the material sweep of adjoint_mat.h applies)
     bool lds_mat = false;                // scene class 3: staged in LDS, any BSDF / bitmap parameter, no environment map (forward kernels)
     size_t smem_bytes = 0;
@@ -961,7 +962,9 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
         const psdr_bsdf_rec &b = s->bsdfs[i];
         if (b.type < 0 || b.type > 5) return fail("Unknown BSDF type!");
         if (b.type == 5 && (b.nested_bsdf < 0 || b.nested_bsdf >= s->n_bsdfs || s->bsdfs[b.nested_bsdf].type == 5)) return fail("NormalMap: invalid nested BSDF");
-        if (!(b.type == 0 || b.type == 1 || b.type == 4 || ((b.type == 2 || b.type == 3) && !b.tex_data && !b.spec_tex_data && !b.rough_tex_data))) sc->simple_mats = false;
+        // (a NormalMap, type 5, is its nested BSDF seen through the map: the nested record is an entry of its own and decides)
+        if (!(b.type == 0 || b.type == 1 || b.type == 4 || b.type == 5 || ((b.type == 2 || b.type == 3) && !b.tex_data && !b.spec_tex_data && !b.rough_tex_data))) sc->simple_mats = false;
+        if (b.type == 5) sc->has_nmap = true;
         put4(blob, T.bsdf_off + 2 * (size_t) i, b.reflectance[0], b.reflectance[1], b.reflectance[2], ibits((b.two_sided ? 1 : 0) | (b.tex_data ? 2 : 0) | (b.type == 1 ? 4 : 0) | (b.type == 2 ? 8 : 0) | (b.type == 3 ? 16 : 0) | (b.spec_tex_data ? 32 : 0) | (b.rough_tex_data ? 64 : 0) | (b.type == 4 ? 128 : 0) | (b.type == 5 ? 256 : 0)));
         put4(blob, T.bsdf_off + 2 * (size_t) i + 1, b.d_reflectance[0], b.d_reflectance[1], b.d_reflectance[2], ibits(b.type == 5 ? b.nested_bsdf : -1));
     }
@@ -1329,7 +1332,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     static const bool no_sweep = std::getenv("PSDR_ADJ_PROBE") != nullptr;         // measurement knob: force the probe form
     const bool sweep = !no_sweep && adj_cls != 0 && a->field_mode == 0 && T.tex == nullptr && T.pv == nullptr && (T.env_emitter < 0 || adj_cls == 2);
     // GGX scenes (class 0): the material sweep, when every BSDF is Diffuse or a constant-parameter Microfacet
-    const bool sweep_mat = !no_sweep && !sweep && adj_cls == 0 && a->field_mode == 0 && sc->simple_mats && (T.mat != nullptr || T.tex != nullptr || T.pv != nullptr);
+    const bool sweep_mat = !no_sweep && !sweep && adj_cls == 0 && a->field_mode == 0 && sc->simple_mats && (T.mat != nullptr || T.tex != nullptr || T.pv != nullptr || sc->has_nmap);
     const int lane_words = (sweep || sweep_mat) ? adj_sweep_words(adj_depth) : adj_lane_words(adj_depth, with_lookups);
     // the per-lane records (hits, light samples, lookups of one path: 14 D + 3 words for the sweep) live in LDS when they fit beside
     // the accumulators, else in a global array of the scene (any depth works, at global-memory latency)

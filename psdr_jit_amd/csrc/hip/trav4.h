@@ -246,10 +246,12 @@ template <int LDS, bool COUNT> PSDR_DEV void t4_node(SceneView<LDS> &S, const T4
 
 // the leaf in hand (called by the workers that hold one, together): its triangles join the wave's pair ring
 template <int LDS> PSDR_DEV void t4_enqueue(const SceneView<LDS> &S, const T4Lds<LDS> &L, Trav4 &tr, unsigned cmask, unsigned leaf_bit) {
+    const int payload = (int) (tr.code & (leaf_bit - 1u)), first = payload >> 2, cnt = (payload & 3) + 1;        // a leaf holds one or two triangles (bvh.h::build_bvh, kLeafMax)
+#ifdef PSDR_ENQ_BALLOT
+    // (round 2/3 form: exclusive prefix sum of cnt over the participating lanes - two ballots, four popcounts, a head read, a fence and a head write for the ~8 lanes
+    // of 64 that hold a leaf in a burst iteration)
     const int lane_id = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane_id) - 1ull;
-    const int payload = (int) (tr.code & (leaf_bit - 1u)), first = payload >> 2, cnt = (payload & 3) + 1;
-    // exclusive prefix sum of cnt over the participating lanes: a leaf holds one or two triangles (bvh.h::build_bvh, kLeafMax)
     const unsigned long long b1 = __ballot(true), b2 = __ballot(cnt > 1);
     const int before = __popcll(b1 & lt_mask) + __popcll(b2 & lt_mask);
     const int total = __popcll(b1) + __popcll(b2);
@@ -257,6 +259,11 @@ template <int LDS> PSDR_DEV void t4_enqueue(const SceneView<LDS> &S, const T4Lds
     wave_sync();
     if (lane_id == (int) __builtin_ctzll(b1)) L.heads[kHdPairEnq] = base + (unsigned) total;      // ... before the first of them advances it
     const unsigned mine = base + (unsigned) before;
+#else
+    // each leaf-holding lane reserves its ring slots with ONE LDS atomic on the wave's head (few lanes take part, so the same-address serialisation is short);
+    // the order of the pairs in the ring is free: a ray is finished when the test counter has passed its last pair
+    const unsigned mine = __hip_atomic_fetch_add(&L.heads[kHdPairEnq], (unsigned) cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
     L.ring[mine & (kPairCap - 1)] = ((unsigned) first << 7) | (unsigned) tr.rid;
     if (cnt > 1) L.ring[(mine + 1u) & (kPairCap - 1)] = ((unsigned) (first + 1) << 7) | (unsigned) tr.rid;
     tr.last_pair = mine + (unsigned) cnt;
