@@ -178,8 +178,14 @@ PSDR_DEV Vec3f bsdf_plain_value_and_adjoint(const SceneView<LDS> &S, int bid, co
         }
         if (fl & 8) {          // RoughConductor with constant parameters (roughconductor.cpp:30-68): g_mat row = [alpha_u, alpha_v, eta rgb, k rgb, specular rgb]
             const MatDev md = S.T->mat[bid];
-            const Vec3f eta(md.eta[0], md.eta[1], md.eta[2]), kk(md.k[0], md.k[1], md.k[2]), spec(md.specular[0], md.specular[1], md.specular[2]);
-            const Vec3f F = conductor_eval<float>(md.alpha_u, md.alpha_v, eta, kk, spec, two, wi, wo, true);
+            Vec3f eta(md.eta[0], md.eta[1], md.eta[2]), kk(md.k[0], md.k[1], md.k[2]);
+            const Vec3f spec(md.specular[0], md.specular[1], md.specular[2]);
+            float cau = md.alpha_u, cav = md.alpha_v;
+            // bitmap parameters (round 3; shade.h::bsdf_eval_id): slot 0 eta, slot 1 k, slot 2 alpha (one map for both axes)
+            if (fl & 2) { float o[3]; tex_value(0, std::integral_constant<int, 3>(), o); eta = Vec3f(o[0], o[1], o[2]); }
+            if (fl & 32) { float o[3]; tex_value(1, std::integral_constant<int, 3>(), o); kk = Vec3f(o[0], o[1], o[2]); }
+            if (fl & 64) { float o[1]; tex_value(2, std::integral_constant<int, 1>(), o); cau = o[0]; cav = o[0]; }
+            const Vec3f F = conductor_eval<float>(cau, cav, eta, kk, spec, two, wi, wo, true);
             if (Fb == nullptr) return F;
             if (!(finite_(Fb->x) && finite_(Fb->y) && finite_(Fb->z)) || (Fb->x == 0.f && Fb->y == 0.f && Fb->z == 0.f)) return F;
 #pragma unroll
@@ -190,10 +196,13 @@ PSDR_DEV Vec3f bsdf_plain_value_and_adjoint(const SceneView<LDS> &S, int bid, co
                 const float te = j == 8 ? one : 0.f, tk = j == 9 ? one : 0.f, ts = j == 10 ? one : 0.f;
                 const Vec3d etaD(Dual(eta.x, te), Dual(eta.y, te), Dual(eta.z, te)), kD(Dual(kk.x, tk), Dual(kk.y, tk), Dual(kk.z, tk));
                 const Vec3d specD(Dual(spec.x, ts), Dual(spec.y, ts), Dual(spec.z, ts));
-                const Vec3d r = conductor_eval<Dual>(Dual(md.alpha_u, j == 6 ? one : 0.f), Dual(md.alpha_v, j == 7 ? one : 0.f), etaD, kD, specD, two, wiD, woD, true);
+                const Vec3d r = conductor_eval<Dual>(Dual(cau, j == 6 ? one : 0.f), Dual(cav, j == 7 ? one : 0.f), etaD, kD, specD, two, wiD, woD, true);
                 const float pb[3] = {Fb->x * r.x.d, Fb->y * r.y.d, Fb->z * r.z.d};
                 if (j < 3) wib[j] = pb[0] + pb[1] + pb[2];
                 else if (j < 6) wob[j - 3] = pb[0] + pb[1] + pb[2];
+                else if (j < 8 && (fl & 64)) { const float rb[1] = {pb[0] + pb[1] + pb[2]}; tex_back(2, std::integral_constant<int, 1>(), rb); }      // the alpha map feeds both axes
+                else if (j == 8 && (fl & 2)) tex_back(0, std::integral_constant<int, 3>(), pb);
+                else if (j == 9 && (fl & 32)) tex_back(1, std::integral_constant<int, 3>(), pb);
                 else if (acc_mat) {
                     if (j < 8) add(&acc_mat[bid * kMatRow + (j - 6)], pb[0] + pb[1] + pb[2]);
                     else { const int o = j == 8 ? 2 : (j == 9 ? 5 : 8); add(&acc_mat[bid * kMatRow + o], pb[0]); add(&acc_mat[bid * kMatRow + o + 1], pb[1]); add(&acc_mat[bid * kMatRow + o + 2], pb[2]); }
@@ -206,7 +215,9 @@ PSDR_DEV Vec3f bsdf_plain_value_and_adjoint(const SceneView<LDS> &S, int bid, co
     if constexpr (has_mat(LDS)) {
         if (fl & 16) {         // RoughDielectric with constant parameters (roughdielectric.cpp): g_mat row = [alpha_u, alpha_v, eta]; 1 / eta moves with eta
             const MatDev md = S.T->mat[bid];
-            const Vec3f F = dielectric_eval<float>(md.alpha_u, md.alpha_v, md.eta[0], md.eta[1], two, wi, wo, true);
+            float cau = md.alpha_u, cav = md.alpha_v;
+            if (fl & 64) { float o[1]; tex_value(2, std::integral_constant<int, 1>(), o); cau = o[0]; cav = o[0]; }      // alpha bitmap (slot 2, both axes)
+            const Vec3f F = dielectric_eval<float>(cau, cav, md.eta[0], md.eta[1], two, wi, wo, true);
             if (Fb == nullptr) return F;
             if (!(finite_(Fb->x) && finite_(Fb->y) && finite_(Fb->z)) || (Fb->x == 0.f && Fb->y == 0.f && Fb->z == 0.f)) return F;
 #pragma unroll
@@ -214,11 +225,12 @@ PSDR_DEV Vec3f bsdf_plain_value_and_adjoint(const SceneView<LDS> &S, int bid, co
                 const float one = 1.f;
                 const Vec3d wiD(Dual(wi.x, j == 0 ? one : 0.f), Dual(wi.y, j == 1 ? one : 0.f), Dual(wi.z, j == 2 ? one : 0.f));
                 const Vec3d woD(Dual(wo.x, j == 3 ? one : 0.f), Dual(wo.y, j == 4 ? one : 0.f), Dual(wo.z, j == 5 ? one : 0.f));
-                const Vec3d r = dielectric_eval<Dual>(Dual(md.alpha_u, j == 6 ? one : 0.f), Dual(md.alpha_v, j == 7 ? one : 0.f), Dual(md.eta[0], j == 8 ? one : 0.f),
+                const Vec3d r = dielectric_eval<Dual>(Dual(cau, j == 6 ? one : 0.f), Dual(cav, j == 7 ? one : 0.f), Dual(md.eta[0], j == 8 ? one : 0.f),
                                                       Dual(md.eta[1], j == 8 ? -1.f / (md.eta[0] * md.eta[0]) : 0.f), two, wiD, woD, true);
                 const float pb = Fb->x * r.x.d + Fb->y * r.y.d + Fb->z * r.z.d;
                 if (j < 3) wib[j] = pb;
                 else if (j < 6) wob[j - 3] = pb;
+                else if (j < 8 && (fl & 64)) { const float rb[1] = {pb}; tex_back(2, std::integral_constant<int, 1>(), rb); }
                 else if (acc_mat) add(&acc_mat[bid * kMatRow + (j - 6)], pb);
             }
             for (int j = 0; j < 3; ++j) { if (!finite_(wib[j])) wib[j] = 0.f; if (!finite_(wob[j])) wob[j] = 0.f; }

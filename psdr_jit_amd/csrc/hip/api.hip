@@ -963,7 +963,8 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
         if (b.type < 0 || b.type > 5) return fail("Unknown BSDF type!");
         if (b.type == 5 && (b.nested_bsdf < 0 || b.nested_bsdf >= s->n_bsdfs || s->bsdfs[b.nested_bsdf].type == 5)) return fail("NormalMap: invalid nested BSDF");
         // (a NormalMap, type 5, is its nested BSDF seen through the map: the nested record is an entry of its own and decides)
-        if (!(b.type == 0 || b.type == 1 || b.type == 4 || b.type == 5 || ((b.type == 2 || b.type == 3) && !b.tex_data && !b.spec_tex_data && !b.rough_tex_data))) sc->simple_mats = false;
+        // (round 3: the bitmap parameters of RoughConductor / RoughDielectric joined the sweep - every BSDF type qualifies now)
+        if (!(b.type >= 0 && b.type <= 5)) sc->simple_mats = false;
         if (b.type == 5) sc->has_nmap = true;
         put4(blob, T.bsdf_off + 2 * (size_t) i, b.reflectance[0], b.reflectance[1], b.reflectance[2], ibits((b.two_sided ? 1 : 0) | (b.tex_data ? 2 : 0) | (b.type == 1 ? 4 : 0) | (b.type == 2 ? 8 : 0) | (b.type == 3 ? 16 : 0) | (b.spec_tex_data ? 32 : 0) | (b.rough_tex_data ? 64 : 0) | (b.type == 4 ? 128 : 0) | (b.type == 5 ? 256 : 0)));
         put4(blob, T.bsdf_off + 2 * (size_t) i + 1, b.d_reflectance[0], b.d_reflectance[1], b.d_reflectance[2], ibits(b.type == 5 ? b.nested_bsdf : -1));

@@ -291,3 +291,13 @@ def test_normalmap_sweep_equals_the_probe_form(env, monkeypatch):
     dt = time.time() - t0
     assert abs(lhs - rhs) <= 5e-4 * scale and abs(lhs) > 1e-6, (lhs, rhs, scale)
     assert dt < 5.0, dt
+
+
+@pytest.mark.parametrize("kind,param", [("roughconductor", "eta"), ("roughconductor", "k"), ("roughconductor", "alpha"), ("roughconductor", "box_x"),
+                                        ("roughdielectric", "alpha"), ("roughdielectric", "box_x")])
+def test_interior_sweep_ggx_bitmaps(env, kind, param):
+    """eta / k / alpha bitmaps of RoughConductor and the alpha bitmap of RoughDielectric in the material sweep (round 3; record-and-probe before): the
+    looked-up values' adjoints go to the four texels of each footprint (one alpha map feeds both axes), geometry through the lobe as with constants"""
+    spec = scenes.textured_ggx_scene(40, 40, 8, 0, 0, kind=kind, param=param)
+    lhs, rhs, scale = _dot_product_case(env, spec, depth=3 if kind == "roughconductor" else 4, terms=1, with_mat=True)
+    assert abs(lhs - rhs) <= 5e-4 * scale and abs(lhs) > 1e-6, (kind, param, lhs, rhs, scale)
