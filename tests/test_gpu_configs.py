@@ -5,7 +5,7 @@
             (the kernels bench.py times: the LDS-class AD interior kernel and both edge kernels at depth 3)
   config 4  2048 x 2048, spp = sppe = sppse = 64 (268 M lanes per sampler)  - rank 3 of 8's lane arithmetic on 1/128 of its chunks
   config 5  82 k-triangle mesh under a 1024 x 512 environment map, albedo parameter, guiding grid [2000, 5, 5, 32], PathTracer(3)
-            - the full mesh and map at 128 x 128 x 4 spp
+            - the full mesh and map at 128 x 128 x 4 spp, and at full size (1024 x 1024 x 64) on a 1/1021 shard + shards add up to the frame
 
 A shard = the 256-lane chunks k with k % count == rank of each of the three samplers (what a rank of the multi-GPU path
 renders); oracle and kernels enumerate the same lanes, so the comparison is exact up to float summation order.
@@ -156,3 +156,29 @@ def test_config5_full_mesh(env, orc):
     hit = wtri >= 0
     assert hit.mean() > 0.5
     assert np.array_equal(uv.cpu().numpy()[hit], wuv[hit]) and np.array_equal(t.cpu().numpy()[hit], wt[hit])
+
+
+def test_config5_full_size_shard(env, orc):
+    """config 5 AS TIMED (bench.py --config 5): 1024 x 1024, spp = sppe = sppse = 64, the full mesh, map and guiding grid.  Shard 777 of
+    1021 of every sampler (~65 700 lanes each; a prime count, so the 256-lane chunks = groups of four pixels scatter over the whole frame) against the oracle, and the four quarter
+    shards of the frame against the frame (size-independent: what the multi-GPU all-reduce relies on, on the BVH path)."""
+    torch, psdr, cabi = env
+    spec = scenes.config5_scene(1024, 1024, 64, 64, 64, level=6, env_res=(1024, 512))
+    sc = product.build_scene(spec)
+    ref = orc.OracleScene(spec, [0])
+    integ = psdr.PathTracer(3)
+    reso = [2000, 5, 5, 32]
+    integ.preprocess_secondary_edges(sc, 0, reso, 1, 0)
+    g = ref.guiding_build(0, reso, nrounds=1, seed=0, max_depth=3)
+    gh = integ._guiding_handle(0)
+    n_pix = 1024 * 1024
+    got = _render_d(env, sc, n_pix, 3, (21, 22, 23), rank=777, count=1021, guiding=gh)
+    wimg, wd = ref.render_d(max_depth=3, seeds=(21, 22, 23), guiding=g, shard_rank=777, shard_count=1021)
+    assert np.isfinite(got).all() and np.abs(wimg).max() > 0 and np.abs(wd).max() > 0
+    assert product.rel_l2(got[0], wimg) < TOL and product.rel_l2(got[1], wd) < TOL
+    full = _render_d(env, sc, n_pix, 3, (21, 22, 23), guiding=gh)
+    assert np.isfinite(full).all()
+    parts = sum(_render_d(env, sc, n_pix, 3, (21, 22, 23), rank=r, count=4, guiding=gh) for r in range(4))
+    assert product.rel_l2(parts[0], full[0]) < 1e-5 and product.rel_l2(parts[1], full[1]) < 1e-4
+    # every pixel of the full-size frame received radiance (sky or surface) and the albedo derivative is confined to the blob and its surroundings
+    assert (full[0].sum(axis=1) > 0).mean() > 0.999
