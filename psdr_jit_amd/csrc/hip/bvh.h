@@ -7,7 +7,7 @@
 //   q2 = right.lo.xyz, 0                   q3 = right.hi.xyz, 0
 // ref >= 0 : index of an inner node;  ref < 0 : leaf, ~ref = (first_triangle << 2) | (count - 1),
 // 1..4 triangles, triangles re-ordered so that a leaf's triangles are contiguous.
-// Binned SAH (16 bins); boxes are padded so the slab test can never reject a ray that the
+// Binned SAH (64 bins); boxes are padded so the slab test can never reject a ray that the
 // triangle test accepts (hit selection must not depend on the traversal order).
 #pragma once
 #include <algorithm>
@@ -47,7 +47,12 @@ inline int32_t float_bits(int32_t v) { return v; }
 
 inline void build_bvh(const float *p0, const float *e1, const float *e2, int n, BvhResult &out) {
     using namespace bvh_detail;
-    constexpr int kBins = 16;
+    // measurement knobs (tools/bvh_knobs.sh): bins of the binned SAH, exact sweep SAH (every split of the centroid order of every axis) for ranges of
+    // at most PSDR_BVH_SWEEP triangles, split cost in leaves (area x ceil(count / kLeafMax)) instead of triangles
+    constexpr int kMaxBins = 64;
+    static const int kBins = std::getenv("PSDR_BVH_BINS") ? std::max(4, std::min(kMaxBins, std::atoi(std::getenv("PSDR_BVH_BINS")))) : 64;       // config 5: 16 / 32 / 64 bins: 237.9 / 236.7 / 233.8 ms, 18.34 / 18.23 / 17.94 nodes per ray
+    static const int kSweep = std::getenv("PSDR_BVH_SWEEP") ? std::atoi(std::getenv("PSDR_BVH_SWEEP")) : 0;
+    static const bool kLeafCost = std::getenv("PSDR_BVH_LEAFCOST") != nullptr;
     // triangles per leaf: 1 or 2 (measured with the triangle ring: 1: +15 %, 2: -1.5 %, 4: 0; the pair ring of trav4.h is sized for leaves of <= 2)
     static const int kLeafMax = std::getenv("PSDR_BVH_LEAF") ? std::max(1, std::min(2, std::atoi(std::getenv("PSDR_BVH_LEAF")))) : 2;
     std::vector<Box> tb(n);
@@ -89,23 +94,49 @@ inline void build_bvh(const float *p0, const float *e1, const float *e2, int n, 
             int widest = 0;
             for (int k = 1; k < 3; ++k) if (cb.hi[k] - cb.lo[k] > cb.hi[widest] - cb.lo[widest]) widest = k;
             static const bool all_axes = std::getenv("PSDR_BVH_WIDEST_AXIS") == nullptr;
-            for (int axis = 0; axis < 3; ++axis) {
+            auto units = [&](int c) { return kLeafCost ? (float) ((c + kLeafMax - 1) / kLeafMax) : (float) c; };
+            bool swept = false;
+            if (j.count <= kSweep) {
+                // exact sweep: the triangles in centroid order along each axis, every prefix / suffix split priced
+                std::vector<int> ord(out.order.begin() + j.first, out.order.begin() + j.first + j.count);
+                std::vector<Box> suf(j.count);
+                int best_k = -1, sweep_axis = -1;
+                auto sort_by = [&](int axis) { std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return ctr[3 * (size_t) a + axis] < ctr[3 * (size_t) b + axis]; }); };
+                for (int axis = 0; axis < 3; ++axis) {
+                    std::copy(out.order.begin() + j.first, out.order.begin() + j.first + j.count, ord.begin());
+                    sort_by(axis);
+                    Box acc;
+                    for (int i = j.count - 1; i > 0; --i) { acc.grow(tb[ord[i]]); suf[i] = acc; }
+                    acc = Box();
+                    for (int i = 0; i < j.count - 1; ++i) {
+                        acc.grow(tb[ord[i]]);
+                        const float cost = acc.half_area() * units(i + 1) + suf[i + 1].half_area() * units(j.count - i - 1);
+                        if (cost < best) { best = cost; best_k = i + 1; sweep_axis = axis; }
+                    }
+                }
+                if (best_k > 0) {
+                    std::copy(out.order.begin() + j.first, out.order.begin() + j.first + j.count, ord.begin());
+                    sort_by(sweep_axis);
+                    std::copy(ord.begin(), ord.end(), out.order.begin() + j.first); mid = j.first + best_k; swept = true;
+                }
+            }
+            for (int axis = 0; axis < 3 && !swept; ++axis) {
                 if (!all_axes && axis != widest) continue;
                 if (!(cb.hi[axis] - cb.lo[axis] > 0.f)) continue;
-                Box bb[kBins]; int bc[kBins] = {0};
+                Box bb[kMaxBins]; int bc[kMaxBins] = {0};
                 for (int i = j.first; i < j.first + j.count; ++i) { int t = out.order[i]; int b = bin_of(t, axis); bb[b].grow(tb[t]); bc[b]++; }
-                Box r[kBins]; int rc[kBins];
+                Box r[kMaxBins]; int rc[kMaxBins];
                 Box acc; int cnt = 0;
                 for (int b = kBins - 1; b > 0; --b) { acc.grow(bb[b]); cnt += bc[b]; r[b] = acc; rc[b] = cnt; }
                 acc = Box(); cnt = 0;
                 for (int b = 0; b < kBins - 1; ++b) {
                     acc.grow(bb[b]); cnt += bc[b];
                     if (cnt == 0 || rc[b + 1] == 0) continue;
-                    float cost = acc.half_area() * cnt + r[b + 1].half_area() * rc[b + 1];
+                    float cost = acc.half_area() * units(cnt) + r[b + 1].half_area() * units(rc[b + 1]);
                     if (cost < best) { best = cost; best_split = b; best_axis = axis; }
                 }
             }
-            if (best_axis >= 0) {
+            if (best_axis >= 0 && !swept) {
                 auto it = std::stable_partition(out.order.begin() + j.first, out.order.begin() + j.first + j.count,
                                                 [&](int t) { return bin_of(t, best_axis) <= best_split; });
                 mid = (int) (it - out.order.begin());
