@@ -45,6 +45,25 @@ namespace psdr {
 #ifndef PSDR_PAIR_MIN          // a burst ends when the ring holds this many pairs, and that many are worth a (partial) test round; 64 = a wave's worth
 #define PSDR_PAIR_MIN 48         // (config 5: 32: 260.5, 48: 258.9, 64: 264.4 ms - earlier hits cull more; 128 - two rounds back to back, half the outer iterations - 285 vs 264 ms on config 5: the hits arrive later and cull less)
 #endif
+#ifndef PSDR_STEAL             // 1: workers without a ray take over the bottom stack entry (the far subtree) of a walk in progress once the wave's ray queue is empty
+#define PSDR_STEAL 1
+#endif
+#ifndef PSDR_STEAL_MIN         // a walk gives an entry away when its stack holds at least this many
+#define PSDR_STEAL_MIN 1
+#endif
+#ifndef PSDR_STEAL_IDLE        // a steal round is worth its instructions when at least this many workers idle
+#define PSDR_STEAL_IDLE 8
+#endif
+#ifndef PSDR_STEAL_TOP         // ray kinds (bit 0: next-event, bit 1: extension) that give their TOP stack entry (the next-nearest subtree) instead of the bottom one
+#define PSDR_STEAL_TOP 3
+#endif
+#ifndef PSDR_STEAL_ROUNDS      // steal rounds per hand-over (a walk gives one entry per round)
+#define PSDR_STEAL_ROUNDS 1
+#endif
+#ifndef PSDR_STEAL_KINDS       // 3: any ray, 2: extension rays only (closest hit wanted), 1: next-event rays only
+#define PSDR_STEAL_KINDS 3
+#endif
+constexpr unsigned kFinBusy = 0x80000000u, kFinShared = 0x40000000u, kFinCount = 0x3fffffffu;      // `fin` while a ray is posted / walked: busy flag | walked by more than one worker at some point | walkers
 constexpr unsigned kT4Done = 0xffffffffu;      // Trav4::code: no node in hand (walk finished, or no ray)
 constexpr unsigned kT4Miss = 0xffffffffu;      // sort key of a child the ray does not enter / code of an unused child slot
 
@@ -83,10 +102,11 @@ struct Trav4 {
     Vec3f o, d, inv;            // the ray in hand
     unsigned code;              // node / leaf in hand, kT4Done = none
     int sp;                     // stack pointer
+    int sb;                     // stack bottom: the entries below were given to other workers (PSDR_STEAL); the stack is [sb, sp)
     int rid;                    // ray in hand, -1 none
     unsigned last_pair;         // sequence number after the last pair this ray enqueued
     float anyhit;               // a hit closer than this ends the walk (shadow rays: any occluder will do), -inf = closest hit wanted
-    PSDR_DEV void reset() { code = kT4Done; sp = 0; rid = -1; last_pair = 0u; anyhit = -__builtin_inff(); o = Vec3f(0.f); d = Vec3f(0.f); inv = Vec3f(0.f); }
+    PSDR_DEV void reset() { code = kT4Done; sp = 0; sb = 0; rid = -1; last_pair = 0u; anyhit = -__builtin_inff(); o = Vec3f(0.f); d = Vec3f(0.f); inv = Vec3f(0.f); }
 };
 
 // per-lane / per-wave views of the LDS rows above
@@ -141,7 +161,7 @@ template <int LDS> PSDR_DEV unsigned t4_pop(const SceneView<LDS> &S, const T4Lds
 
 // next node of this worker's ray: pop until an entry is not behind the closest hit; kT4Done when the stack is empty
 template <int LDS> PSDR_DEV unsigned t4_next(const SceneView<LDS> &S, const T4Lds<LDS> &L, Trav4 &tr, unsigned cmask, float best_t) {
-    while (tr.sp > 0) {
+    while (tr.sp > tr.sb) {
         const unsigned key = t4_pop(S, L, tr.sp);
         if (__uint_as_float(key & ~cmask) <= best_t) return key & cmask;
     }
@@ -162,8 +182,9 @@ template <int LDS, bool COUNT> PSDR_DEV void t4_start(SceneView<LDS> &S, const T
     tr.rid = rid;
     tr.o = o; tr.d = d;
     tr.inv = Vec3f(1.f / d.x, 1.f / d.y, 1.f / d.z);
-    tr.sp = 0;
+    tr.sp = 0; tr.sb = 0;
     tr.last_pair = 0u;
+    L.fin[rid] = kFinBusy | 1u;            // one walker
     tr.anyhit = (rid & 64) ? -__builtin_inff() : L.park0[owner + 12 * kBlock];
     const bool ok = (o.x == o.x && o.y == o.y && o.z == o.z && d.x == d.x && d.y == d.y && d.z == d.z);
     tr.code = ok ? 0u : kT4Done;       // node 0 = root
@@ -179,7 +200,7 @@ template <int LDS, bool COUNT> PSDR_DEV void t4_node(SceneView<LDS> &S, const T4
     if (COUNT) S.c_nodes++;
 #endif
     const float bt = t4_best_t(L.best, tr.rid);                               // closest hit so far (tested pairs only)
-    if (bt < tr.anyhit) { tr.sp = 0; tr.code = kT4Done; return; }              // shadow ray: an occluder has been found
+    if (bt < tr.anyhit) { tr.sp = tr.sb; tr.code = kT4Done; return; }              // shadow ray: an occluder has been found
     const float ox = tr.o.x, oy = tr.o.y, oz = tr.o.z, ix = tr.inv.x, iy = tr.inv.y, iz = tr.inv.z;
     unsigned key[4];
 #ifdef PSDR_NODE128
@@ -345,7 +366,12 @@ PSDR_DEV bool trav4_run(SceneView<LDS> &S, Trav4 &tr, int posted, int max_busy) 
         if (COUNT) S.c_hits++;
 #endif
         // a worker whose walk has ended hands the ray back (finished once the pairs up to last_pair are tested) ...
-        if (tr.rid >= 0 && tr.code == kT4Done) { L.fin[tr.rid] = tr.last_pair + 1u; tr.rid = -1; }
+        // (a ray may have several walkers, PSDR_STEAL: the last one to end publishes it; a shared ray waits for every pair enqueued so far, its own are among them)
+        if (tr.rid >= 0 && tr.code == kT4Done) {
+            const unsigned old = __hip_atomic_fetch_add(&L.fin[tr.rid], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((old & kFinCount) == 1u) L.fin[tr.rid] = ((old & kFinShared) ? L.heads[kHdPairEnq] : tr.last_pair) + 1u;
+            tr.rid = -1;
+        }
         // ... and the workers without a ray take the next ones of the queue
         const unsigned long long m_idle = __ballot(tr.rid < 0);
         const unsigned rq_tail = L.heads[kHdRayTail], rq_head = L.heads[kHdRayHead];
@@ -357,15 +383,64 @@ PSDR_DEV bool trav4_run(SceneView<LDS> &S, Trav4 &tr, int posted, int max_busy) 
             if (lane_id == first) L.heads[kHdRayHead] = rq_head + (unsigned) n_take;
             avail -= n_take;
         }
+#if PSDR_STEAL
+        // ... and when the queue is empty, the workers still without a ray take over the BOTTOM stack entry - the far subtree - of a walk in progress: the wave
+        // issues the node steps anyway, so an idle lane walks for free what its owner would reach last (or never, if a hit culls it: then the thief is culled
+        // as well at its next step).  The hit is the minimum over all tested pairs of the ray, whoever enqueued them.  Mailbox = the (empty) ray queue.
+        if (avail <= 0) {
+#pragma unroll
+          for (int round = 0; round < PSDR_STEAL_ROUNDS; ++round) {
+            if (round > 0) wave_sync();
+            const unsigned long long m_idle2 = __ballot(tr.rid < 0);
+            if (__popcll(m_idle2) >= PSDR_STEAL_IDLE) {
+                const bool give = tr.rid >= 0 && tr.code != kT4Done && tr.sp - tr.sb >= PSDR_STEAL_MIN && (((PSDR_STEAL_TOP >> (tr.rid >> 6)) & 1) || tr.sb < T.stack_lds) && ((PSDR_STEAL_KINDS >> (tr.rid >> 6)) & 1);
+                const unsigned long long m_give = __ballot(give);
+                if (m_give != 0ull) {
+                    const int n_idle = __popcll(m_idle2), n_give = __popcll(m_give), n = n_idle < n_give ? n_idle : n_give;
+                    if (give) {
+                        const int r = __popcll(m_give & lt_mask);
+                        if (r < n) {
+                            unsigned key;
+                            if ((PSDR_STEAL_TOP >> (tr.rid >> 6)) & 1) key = t4_pop(S, L, tr.sp);
+                            else { key = (unsigned) t4_stack_base(L)[tr.sb * kBlock]; ++tr.sb; }
+                            L.rq[(rq_tail + (unsigned) r) & (kRayCap - 1)] = key;
+                            L.rq[(rq_tail + 64u + (unsigned) r) & (kRayCap - 1)] = (unsigned) tr.rid;
+                            __hip_atomic_fetch_add(&L.fin[tr.rid], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_or(&L.fin[tr.rid], kFinShared, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                    wave_sync();
+                    if (tr.rid < 0) {
+                        const int r = __popcll(m_idle2 & lt_mask);
+                        if (r < n) {
+                            const unsigned key = L.rq[(rq_tail + (unsigned) r) & (kRayCap - 1)];
+                            const int rid = (int) L.rq[(rq_tail + 64u + (unsigned) r) & (kRayCap - 1)];
+                            const int owner = rid & 63;
+                            const lds_float_t *q = L.park0 + owner + ((rid & 64) ? 6 * kBlock : 0);
+                            const Vec3f o(q[0], q[kBlock], q[2 * kBlock]), d(q[3 * kBlock], q[4 * kBlock], q[5 * kBlock]);
+                            tr.rid = rid;
+                            tr.o = o; tr.d = d;
+                            tr.inv = Vec3f(1.f / d.x, 1.f / d.y, 1.f / d.z);
+                            tr.sp = 0; tr.sb = 0;
+                            tr.last_pair = 0u;
+                            tr.anyhit = (rid & 64) ? -__builtin_inff() : L.park0[owner + 12 * kBlock];
+                            tr.code = (__uint_as_float(key & ~cmask) <= t4_best_t(L.best, rid)) ? (key & cmask) : kT4Done;
+                        }
+                    }
+                }
+            }
+          }
+        }
+#endif
         wave_sync();
-        // owners: are my posted rays finished?  (fin = 1 + the sequence number after the ray's last pair)
+        // owners: are my posted rays finished?  (fin = kFinBusy | ... while posted or walked, then 1 + the sequence number after the ray's last pair)
         bool wait_pairs = false;
         done = true;
 #pragma unroll
         for (int k = 0; k < 2; ++k)
             if (posted & (1 << k)) {
                 const unsigned f = L.fin[(k << 6) | lane_id];
-                if (f == 0u) done = false;
+                if (f & kFinBusy) done = false;
                 else if ((int) (f - 1u - tested) > 0) { done = false; wait_pairs = true; }
             }
         PSDR_T4PHASE(c_hits);
@@ -429,7 +504,7 @@ template <int LDS> PSDR_DEV int t4_post(const SceneView<LDS> &S, const Vec3f &oA
     p[6 * kBlock] = oB.x; p[7 * kBlock] = oB.y; p[8 * kBlock] = oB.z; p[9 * kBlock] = dB.x; p[10 * kBlock] = dB.y; p[11 * kBlock] = dB.z;
     p[12 * kBlock] = anyhit_a;
     L.best[lane_id] = kT4NoHit; L.best[64 + lane_id] = kT4NoHit;
-    L.fin[lane_id] = 0u; L.fin[64 + lane_id] = 0u;
+    L.fin[lane_id] = kFinBusy; L.fin[64 + lane_id] = kFinBusy;
     const unsigned long long mA = __ballot(actA), mB = __ballot(actB), m_all = __ballot(true);
     // queue order: all extension rays (closest hit wanted: the long walks), then the next-event rays (they stop at the first occluder) - the
     // workers take rays in this order, so the long ones start first and the short ones fill the end of the traversal phase
