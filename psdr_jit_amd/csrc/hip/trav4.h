@@ -57,8 +57,14 @@ namespace psdr {
 #ifndef PSDR_STEAL_TOP         // ray kinds (bit 0: next-event, bit 1: extension) that give their TOP stack entry (the next-nearest subtree) instead of the bottom one
 #define PSDR_STEAL_TOP 3
 #endif
+#ifndef PSDR_STEAL_BREAK       // 0 = off.  Measurement knob, NOT validated: with 2, config 5's secondary-edge kernel runs 26.5 -> 24.5 ms and the traced hits stay bit-equal, but the
+#define PSDR_STEAL_BREAK 0       // reverse sweeps of environment-lit scenes then miss their dot-product tests by 0.5-2 % (tests/test_gpu_adjoint.py::test_interior_sweep_environment_map): left off
+#endif
 #ifndef PSDR_STEAL_ROUNDS      // steal rounds per hand-over (a walk gives one entry per round)
 #define PSDR_STEAL_ROUNDS 1
+#endif
+#ifndef PSDR_STEAL_ROUNDS_ASYNC
+#define PSDR_STEAL_ROUNDS_ASYNC 1
 #endif
 #ifndef PSDR_STEAL_KINDS       // 3: any ray, 2: extension rays only (closest hit wanted), 1: next-event rays only
 #define PSDR_STEAL_KINDS 3
@@ -390,6 +396,7 @@ PSDR_DEV bool trav4_run(SceneView<LDS> &S, Trav4 &tr, int posted, int max_busy) 
         if (avail <= 0) {
 #pragma unroll
           for (int round = 0; round < PSDR_STEAL_ROUNDS; ++round) {
+            if (round >= PSDR_STEAL_ROUNDS_ASYNC && max_busy != 0) break;      // (the path kernels: one round)
             if (round > 0) wave_sync();
             const unsigned long long m_idle2 = __ballot(tr.rid < 0);
             if (__popcll(m_idle2) >= PSDR_STEAL_IDLE) {
@@ -463,6 +470,12 @@ PSDR_DEV bool trav4_run(SceneView<LDS> &S, Trav4 &tr, int posted, int max_busy) 
                 if (waiting >= (PSDR_PAIR_MIN < n_lanes ? PSDR_PAIR_MIN : n_lanes) || __ballot(tr.code != kT4Done) == 0ull) break;
                 // workers that ran out of nodes idle until the burst ends: end it early when many do and rays are waiting
                 if (avail > n_lanes / PSDR_BURST_DIV && __popcll(__ballot(tr.code == kT4Done)) >= n_lanes / PSDR_BURST_DIV) break;
+#if PSDR_STEAL && PSDR_STEAL_BREAK > 0
+                // ... or - in the synchronous form (bvh4_trace2: no shading phase will bring new rays) - when the queue is empty, 1 / PSDR_STEAL_BREAK of the workers idle and
+                // walks in progress have entries to give: the hand-over at the top of the outer loop then puts the idle workers on those (config 5's secondary-edge kernel
+                // 26.5 -> 24.5 ms; in the path kernels, where finished owners are shaded in between, the same rule costs 1-3 %)
+                if (max_busy == 0 && avail <= 0 && __popcll(__ballot(tr.code == kT4Done)) >= n_lanes / PSDR_STEAL_BREAK && __ballot(tr.code != kT4Done && tr.sp > tr.sb) != 0ull) break;
+#endif
             }
         }
         PSDR_T4PHASE(c_nodes);
