@@ -451,6 +451,10 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
     float *acc_mat = acc_cam + kAdjMisc;
     float *acc = acc_mat + T.n_bsdfs * kMatRow;
     const int n_acc = P.n_hot * 22 + T.n_bsdfs * 3 + T.n_emitters * 3 + P.env_lds;
+#ifdef PSDR_LDS_POISON
+    // (diagnostic) the per-lane records start as garbage: a record word that is read before this path wrote it shows up in the result
+    if (!P.rec_global) { for (int i = threadIdx.x; i < lane_words * kBlock; i += kBlock) scratch[i] = PSDR_LDS_POISON; __syncthreads(); }
+#endif
     for (int i = threadIdx.x; i < n_acc; i += kBlock) acc[i] = 0.f;
     float *acc_bsdf = acc + P.n_hot * 22, *acc_emit = acc_bsdf + T.n_bsdfs * 3;
     float *acc_env = acc_emit + T.n_emitters * 3;        // [env_lds] texel adjoints of a small environment map (every sample of a wave hits the same few texels)
