@@ -279,6 +279,11 @@ class BitmapTransform:
                 raise RuntimeError("EnvironmentMap: the bitmap parameter is 'radiance'")
         elif name not in _UV_SLOT or not hasattr(type(obj), name):
             raise RuntimeError("%s has no bitmap parameter %r" % (type(obj).__name__, name))
+        if name == "alpha_v":
+            # ONE roughness map serves both axes here (the kernels look alpha up once, slot 2: shade.h "alpha (both axes)"), so the two names
+            # are one transform: uv_transform("alpha_v") IS uv_transform("alpha_u") - reading either shows what was set through the other.
+            # (The reference keeps m_rot / m_scale / m_trans per Bitmap, bitmap.h:37-39; two different alpha maps are not representable here.)
+            name = "alpha_u"
         self.__dict__["_obj"], self.__dict__["_name"] = obj, name
         parts = obj.__dict__.setdefault("_psdr_uv_parts", {})
         if name not in parts:

@@ -22,8 +22,9 @@ HIP_LIB = os.path.join(LIBDIR, "libpsdr_hip.so")
 CORE_LIB = os.path.join(HERE, "_psdr_core" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
 
 HIP_SRCS = [os.path.join(CSRC, "hip", f) for f in ("api.hip",)]
+BUILD_DEPS = [os.path.join(HERE, "isa_lint.py")]          # part of the recipe: a change of the lint re-builds (and re-lints) the library
 HIP_DEPS = [os.path.join(CSRC, "hip", f) for f in ("dmath.h", "sampler.h", "scene_dev.h", "shade.h", "edges.h", "paths.h", "adjoint.h", "adjoint_mat.h", "bvh.h", "filter.h", "microfacet.h", "trav4.h")] + \
-           [os.path.join(ROOT, "include", "psdr_hip.h"), os.path.join(CSRC, "common", "envmath.h")]
+           [os.path.join(ROOT, "include", "psdr_hip.h"), os.path.join(CSRC, "common", "envmath.h")] + BUILD_DEPS
 HOST_SRCS = [os.path.join(CSRC, "host", f) for f in ("scene_host.cpp", "bindings.cpp", "exr_piz.cpp")]
 HOST_DEPS = [os.path.join(CSRC, "host", f) for f in ("scene_host.h", "hnum.h", "exr_piz.h")] + [os.path.join(ROOT, "include", "psdr_hip.h"), os.path.join(CSRC, "common", "envmath.h")]
 
@@ -72,51 +73,113 @@ N_KERNEL_UNITS = 6      # api.hip's PSDR_TU1..6: the heavy kernel templates of e
 UNIT_CLASS_BIT = {1: 1, 2: 1, 6: 1, 3: 2, 4: 4, 5: 8}      # the PSDR_CLS_MASK bit of the scene class a unit instantiates
 
 
-def build_hip(force=False, extra_flags=()):
+def build_hip(force=False, extra_flags=(), target=None):
     """api.hip is compiled as seven translation units in parallel - the host code with the small kernels (-DPSDR_SPLIT) and six units
     that only instantiate the heavy kernel templates of one scene class (-DPSDR_TU=k) - and linked into one library: ~4 minutes of
     wall time instead of ~10 for the single unit (PSDR_BUILD_JOBS=1 compiles them one after the other)."""
     os.makedirs(LIBDIR, exist_ok=True)
     flags = [f for f in HIP_FLAGS if f != "-shared"] + list(extra_flags)
+    if target is not None:
+        # a development variant (tools/variants.py): its own library and object directory, so that several can be built side by side
+        return _compile_hip(flags, target, os.path.join(os.path.dirname(target), "obj"))
     if force or _stale(HIP_LIB, HIP_SRCS + HIP_DEPS, flags):
-        sig = _signature(HIP_SRCS + HIP_DEPS, flags)
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        objdir = os.path.join(LIBDIR, "obj")
-        os.makedirs(objdir, exist_ok=True)
-        # development builds (-DPSDR_CLS_MASK=m: the host code launches the kernels of those scene classes only) skip the other classes' units
-        mask = 15
-        for f in flags:
-            if f.startswith("-DPSDR_CLS_MASK="):
-                mask = int(f.split("=")[1])
-        units = [("main", ["-DPSDR_SPLIT"])] + [("tu%d" % k, ["-DPSDR_TU=%d" % k]) for k in (1, 6, 2, 4, 5, 3) if UNIT_CLASS_BIT[k] & mask]
-        jobs = max(1, int(os.environ.get("PSDR_BUILD_JOBS", str(min(len(units), os.cpu_count() or 1)))))
-        objs, pending, running = [], list(units), []
-        for name, _d in units:                           # objects of an earlier (possibly failed, possibly differently flagged) build never get linked
-            obj = os.path.join(objdir, "api_%s.o" % name)
-            if os.path.exists(obj):
-                os.remove(obj)
-        while pending or running:
-            while pending and len(running) < jobs:
-                name, defs = pending.pop(0)
-                obj = os.path.join(objdir, "api_%s.o" % name)
-                objs.append(obj)
-                cmd = [hipcc] + flags + defs + ["-c"] + HIP_SRCS + ["-o", obj]
-                running.append((subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True), cmd))
-            proc, cmd = running.pop(0)
-            out, _ = proc.communicate()
-            if proc.returncode != 0:
-                for q, _c in running:
-                    q.kill()
-                    q.wait()
-                for o in objs:
-                    if os.path.exists(o):
-                        os.remove(o)
-                sys.stderr.write(out)
-                raise RuntimeError("build failed: " + " ".join(cmd))
-        arch = [f for f in flags if f.startswith("--offload-arch")]
-        _run([hipcc] + arch + ["-shared", "-fPIC"] + objs + ["-o", HIP_LIB])
-        _stamp(HIP_LIB, sig)
+        _compile_hip(flags, HIP_LIB, os.path.join(LIBDIR, "obj"))
     return HIP_LIB
+
+
+# The allocator of clang 22 / ROCm 7.2 can place vector instructions it inserts at the head of a join block (re-materialised constants,
+# split copies, reloads) in FRONT of the `s_or_b64 exec` that switches the other branch's lanes back on - those lanes then go on with a stale
+# register.  It happens when its scalar phase has left copies in front of the exec restore; it cost round 3 its open item (the class-2
+# reverse sweep, 0.5-2.5 % off in builds whose only difference was an unrelated knob; DESIGN.md section 4).  isa_lint.py finds the pattern
+# in the ISA; a unit that shows it is compiled again with the scalar allocator that does not split live ranges (-sgpr-regalloc=basic: the
+# copies become SGPR spills, which the compiler does recognise as block prologue; measured +4 % kernel time, so it is not the default),
+# and a unit that still shows it fails the build.
+LINT_FALLBACK_FLAGS = ["-mllvm", "-sgpr-regalloc=basic"]
+
+
+def _load_lint():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_psdr_isa_lint", os.path.join(HERE, "isa_lint.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _lint_units(hipcc, flags, units, objdir):
+    lint = _load_lint()
+    report = os.path.join(objdir, "lint.txt")
+    if os.environ.get("PSDR_BUILD_NO_LINT"):          # development only: keeps a flagged unit as the compiler made it (to show what the lint is for, tools/variants.py)
+        with open(report, "w") as fh:
+            fh.write("lint skipped (PSDR_BUILD_NO_LINT)\n")
+        return
+    if not lint.available():
+        sys.stderr.write("psdr_jit_amd.build: llvm-objdump not found, the ISA lint of the kernels is skipped\n")
+        return
+    lines = []
+    for name, defs in units:
+        obj = os.path.join(objdir, "api_%s.o" % name)
+        found = lint.lint(obj)
+        if found:
+            lines.append("%s: %d join block(s) with vector instructions ahead of the exec restore (%s ...): compiled again with %s" %
+                         (name, len(found), found[0][0][:60], " ".join(LINT_FALLBACK_FLAGS)))
+            _run([hipcc] + flags + LINT_FALLBACK_FLAGS + defs + ["-c"] + HIP_SRCS + ["-o", obj])
+            again = lint.lint(obj)
+            if again:
+                raise RuntimeError("build failed: unit %s still has vector instructions ahead of an exec restore with %s:\n%s" %
+                                   (name, " ".join(LINT_FALLBACK_FLAGS), "\n".join("%s +0x%x: %s" % (n, o, "; ".join(x[:4])) for n, o, x in again)))
+        else:
+            lines.append("%s: clean" % name)
+    with open(report, "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    for l in lines:
+        if not l.endswith("clean"):
+            sys.stderr.write("psdr_jit_amd.build: " + l + "\n")
+
+
+def _compile_hip(flags, target, objdir):
+    """compiles and links api.hip with `flags` into `target`; objects go to `objdir`"""
+    sig = _signature(HIP_SRCS + HIP_DEPS, flags)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(objdir, exist_ok=True)
+    # development builds (-DPSDR_CLS_MASK=m: the host code launches the kernels of those scene classes only) skip the other classes' units
+    mask = 15
+    for f in flags:
+        if f.startswith("-DPSDR_CLS_MASK="):
+            mask = int(f.split("=")[1])
+    units = [("main", ["-DPSDR_SPLIT"])] + [("tu%d" % k, ["-DPSDR_TU=%d" % k]) for k in (1, 6, 2, 4, 5, 3) if UNIT_CLASS_BIT[k] & mask]
+    jobs = max(1, int(os.environ.get("PSDR_BUILD_JOBS", str(min(len(units), os.cpu_count() or 1)))))
+    objs, pending, running = [], list(units), []
+    for name, _d in units:                           # objects of an earlier (possibly failed, possibly differently flagged) build never get linked
+        obj = os.path.join(objdir, "api_%s.o" % name)
+        if os.path.exists(obj):
+            os.remove(obj)
+    while pending or running:
+        while pending and len(running) < jobs:
+            name, defs = pending.pop(0)
+            obj = os.path.join(objdir, "api_%s.o" % name)
+            objs.append(obj)
+            cmd = [hipcc] + flags + defs + ["-c"] + HIP_SRCS + ["-o", obj]
+            running.append((subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True), cmd))
+        proc, cmd = running.pop(0)
+        out, _ = proc.communicate()
+        if proc.returncode != 0:
+            for q, _c in running:
+                q.kill()
+                q.wait()
+            for o in objs:
+                if os.path.exists(o):
+                    os.remove(o)
+            sys.stderr.write(out)
+            raise RuntimeError("build failed: " + " ".join(cmd))
+    _lint_units(hipcc, flags, units, objdir)
+    arch = [f for f in flags if f.startswith("--offload-arch")]
+    _run([hipcc] + arch + ["-shared", "-fPIC"] + objs + ["-o", target])
+    if target == HIP_LIB:
+        _stamp(HIP_LIB, sig)
+    else:
+        with open(target + ".sig", "w") as fh:
+            fh.write(sig + "\n")
+    return target
 
 
 CORE_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-fopenmp"]

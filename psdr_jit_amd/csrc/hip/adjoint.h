@@ -226,7 +226,11 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                     }
                     // stage 3: the bitmap lookups the path made - components 0..2 the diffuse / reflectance map, 3..5 the
                     // specular map, 6 the roughness map of the BSDF; only the maps that exist are probed
-                    while (st_i < n_lk) {
+                    // (only IN stage 3: stage 6 counts hits with the same st_i, and without the guard its second call came back from
+                    // here with a lookup's id - the y / z components and every hit but the camera's lost their normal adjoints whenever
+                    // the path had made lookups, i.e. with g_env / g_env_from_world / g_tex requested; found by the sweep-vs-probe
+                    // cross-check of tools/sweep_check.py in round 4)
+                    while (st_stage == 3 && st_i < n_lk) {
                         const int id = __float_as_int(lk[3 * st_i * kBlock]);
                         // an environment-map lookup has the three radiance components; a BSDF the maps it owns
                         const int fl = id == kEnvLookup ? (P.g_env != nullptr ? 2 : 0) : (id <= kPvLookup ? (P.g_tex != nullptr ? (2 | 32 | 64) : 0)
@@ -725,6 +729,18 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
                 for (int c = 0; c < 3; ++c) if (!finite_(pv[c])) wgt[c] = 0.f;
             }
             const Vec3f W(wgt[0], wgt[1], wgt[2]);
+#if PSDR_SWEEP_DUMP == 1
+            // (diagnostic) per-lane record of the sweep in the buffer behind P.g_tex: 64 floats per sample
+            float *dbg = P.g_tex ? P.g_tex + 64 * lane : nullptr;
+            if (dbg) {
+                dbg[0] = (float) nb; dbg[1] = Lsum.x; dbg[2] = Lsum.y; dbg[3] = Lsum.z; dbg[4] = W.x; dbg[5] = W.y; dbg[6] = W.z; dbg[7] = le0 ? 1.f : 0.f;
+                for (int k = 0; k < nb && k < 3; ++k) {
+                    const float *br = brec + 11 * k * kBlock;
+                    dbg[8 + 8 * k] = (float) __float_as_int(br[7 * kBlock]); dbg[9 + 8 * k] = br[8 * kBlock]; dbg[10 + 8 * k] = br[9 * kBlock]; dbg[11 + 8 * k] = br[10 * kBlock];
+                    dbg[12 + 8 * k] = br[4 * kBlock]; dbg[13 + 8 * k] = br[5 * kBlock]; dbg[14 + 8 * k] = br[6 * kBlock]; dbg[15 + 8 * k] = (float) __float_as_int(vrec[3 * k * kBlock]);
+                }
+            }
+#endif
 
             // ------------------------------------------------------------ pass 2: back over the bounces
             if (W.x != 0.f || W.y != 0.f || W.z != 0.f) {
@@ -787,6 +803,13 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
                         A_k = A_k + W * rho * Le * sN;
                         xb = xb + sg.dx * sb + dir_to_x(gk.x, y, env_adjoint(dir, W * thr_k * rho * sN));
                         nsb = nsb + sg.dns * sb;
+#if PSDR_SWEEP_DUMP == 2
+                        // (diagnostic, round 4) the environment lookup of this bounce's next-event sample: the build that kept the compiler defect visible -
+                        // Le.x came back as the sky's 0.6 instead of the sun's 14.3 for the same direction
+                        if (P.g_tex && k < 4) { float *q = P.g_tex + 64 * lane + 8 * k; q[0] = Le.x; q[1] = sN; q[2] = dir.x; q[3] = dir.y; q[4] = dir.z; q[5] = cN; q[6] = gk.x.x; q[7] = y.x; }
+#elif PSDR_SWEEP_DUMP == 3
+                        if (P.g_tex && k < 4) { float *q = P.g_tex + 64 * lane + 8 * k; q[0] = Le.x; q[1] = sN; }
+#endif
                     } else if (flags & 1) {
                         // L += thr_k rho Le_h cN s_N
                         const VtxGeom gy = load_vertex(S, __float_as_int(br[0]), br[kBlock], br[2 * kBlock]);
@@ -806,6 +829,9 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
                         emit_glued(gh, Vec3f(0.f), Vec3f(0.f), sg.dnz * sb, 0.f);             // the normal of the triangle the shadow ray hit
                     }
                     if (bid >= 0 && !P.skip_bsdf) add_rgb(acc_bsdf, bid, rhob);
+#if PSDR_SWEEP_DUMP == 1
+                    if (dbg && k < 3) { dbg[32 + 8 * k] = rhob.x; dbg[33 + 8 * k] = rhob.y; dbg[34 + 8 * k] = rhob.z; dbg[35 + 8 * k] = A_k.x; dbg[36 + 8 * k] = A_k.y; dbg[37 + 8 * k] = A_k.z; dbg[38 + 8 * k] = (float) bid; dbg[39 + 8 * k] = (float) flags; }
+#endif
                     xb_next = xb; nsb_next = nsb;
                     Abar = A_k;
                     if (k == 0) { xb0 = xb; nsb0 = nsb; }

@@ -547,6 +547,8 @@ PSDR_TU4()
 PSDR_TU5()
 #elif PSDR_TU == 6
 PSDR_TU6()
+#elif PSDR_TU == 7          // (tools/isa_adj.sh: the class-2 interior adjoint kernel alone, for ISA listings)
+PSDR_INST_ADJ(, 2)
 #endif
 #else
 #if defined(PSDR_SPLIT)
@@ -1330,7 +1332,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     const size_t smem_base = (adj_cls == 1 ? sc->smem_bytes : sc->smem_bytes - ((sc->lds || sc->lds_mat) ? (size_t) T.blob_words * 16 : 0)) - cold_bytes;
     const int adj_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth);
     // Diffuse BSDFs + area lights / an environment map under PathTracer: the reverse sweep (adjoint.h); everything else: record and probe
-    static const bool no_sweep = std::getenv("PSDR_ADJ_PROBE") != nullptr;         // measurement knob: force the probe form
+    const bool no_sweep = std::getenv("PSDR_ADJ_PROBE") != nullptr;                // measurement / test knob, read per call: force the probe form
     const bool sweep = !no_sweep && adj_cls != 0 && a->field_mode == 0 && T.tex == nullptr && T.pv == nullptr && (T.env_emitter < 0 || adj_cls == 2);
     // GGX scenes (class 0): the material sweep, when every BSDF is Diffuse or a constant-parameter Microfacet
     const bool sweep_mat = !no_sweep && !sweep && adj_cls == 0 && a->field_mode == 0 && sc->simple_mats && (T.mat != nullptr || T.tex != nullptr || T.pv != nullptr || sc->has_nmap);
@@ -1371,6 +1373,9 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         P.w = d_rgb; P.g_tri = g->g_triangles; P.g_bsdf = g->g_bsdf; P.g_emitter = g->g_emitter; P.hot_map = sc->hot_map.as<int>(); P.hot_inv = sc->hot_inv.as<int>(); P.n_hot = n_hot_used;
         P.mesh_filter = g->mesh_filter; P.skip_bsdf = g->skip_bsdf; P.skip_emitter = g->skip_emitter;
         P.g_tex = sc->tex_total > 0 ? g->g_tex : nullptr;
+#ifdef PSDR_SWEEP_DUMP
+        P.g_tex = g->g_tex;        // (diagnostic build: the sweep's per-lane dump goes there)
+#endif
         P.g_cam = g->g_camera;
         P.g_mat = sc->T.mat != nullptr ? g->g_mat : nullptr;
         P.g_env_xf = sc->T.env_emitter >= 0 ? g->g_env_from_world : nullptr;

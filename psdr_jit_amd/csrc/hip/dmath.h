@@ -24,7 +24,8 @@ namespace psdr {
 //     frames: 1e-2).  Not taken.
 //   * WEIGHTS - geometry terms, pdfs, MIS weights, throughput, radiance and EVERY TANGENT: they are multiplied into the result and
 //     never decide anything.  They divide by multiplying with v_rcp_f32 (1 ulp): fdiv / frcp / div_ below, the tangent half of the Dual
-//     operators.  Special values keep their IEEE meaning (x / 0 = +-inf, 0 / 0 = NaN, x / inf = 0).
+//     operators.  x / 0 = +-inf, 0 / 0 = NaN, x / inf = 0 as in IEEE; NOT as in IEEE: v_rcp_f32 flushes a denormal divisor (x / 1e-40 = inf)
+//     and returns 0 for a divisor above 2^126 - callers whose divisor can get there rescale first (shade.h::mis_weight).
 // -DPSDR_EXACT_DIV restores the correctly rounded forms everywhere (measurement knob).
 #ifdef PSDR_EXACT_DIV
 __device__ __forceinline__ float frcp(float a) { return 1.f / a; }

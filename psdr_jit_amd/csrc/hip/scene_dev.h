@@ -193,9 +193,17 @@ struct Hit { int slot; float u, v, t; };
 // m = 2 m + bit: the lane mask of a comparison (one __builtin_amdgcn_ballot_w64 per v_cmp) enters as the carry-in of
 // v_addc_co_u32 - one VALU instruction per mask update instead of v_cndmask + v_lshl_or
 PSDR_DEV unsigned mask_shift_in(unsigned m, unsigned long long lanes) {
+#if PSDR_MASK_SHIFT == 2
+    return (m << 1) | (unsigned) ((lanes >> (threadIdx.x & 63)) & 1ull);
+#elif PSDR_MASK_SHIFT == 1
+    unsigned r; unsigned long long carry_out;
+    asm volatile("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(r), "=s"(carry_out) : "v"(m), "s"(lanes));
+    return r;
+#else
     unsigned r; unsigned long long carry_out;
     asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(r), "=s"(carry_out) : "v"(m), "s"(lanes));
     return r;
+#endif
 }   // slot = device triangle slot (BVH leaf order), -1 = miss
 
 // Möller–Trumbore exactly as the reference's own ray_intersect_triangle (include/psdr/utils.h:82-93)

@@ -819,7 +819,13 @@ template <bool AD, int LDS> PSDR_DEV VecN<AD> first_hit_value(const SceneView<LD
     }
 }
 
-PSDR_DEV float mis_weight(float p1, float p2) { const float w1 = p1 * p1, w2 = p2 * p2; return fdiv(w1, w1 + w2); }   // reference utils.h:277-281
+// reference utils.h:277-281.  The squares of two small pdfs can sum to a denormal, which v_rcp_f32 flushes (-> inf, and a weight that should be
+// <= 1 turns into inf / NaN and the sample is dropped): such sums are scaled into the normal range first (2^64 on both sides, exact)
+PSDR_DEV float mis_weight(float p1, float p2) {
+    const float w1 = p1 * p1, w2 = p2 * p2, den = w1 + w2;
+    const float s = den < 7.8886091e-31f ? 18446744073709551616.f : 1.f;          // 2^-100, 2^64
+    return fdiv(w1 * s, den * s);
+}
 
 // ---------------------------------------------------------------- PathTracer::__Li, reference src/integrator/path.cpp:35-127
 // Consumes exactly 5*max_depth draws of `rng` whatever the path does (the reference draws for masked lanes too).

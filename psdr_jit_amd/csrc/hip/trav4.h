@@ -70,6 +70,9 @@ namespace psdr {
 #define PSDR_STEAL_KINDS 3
 #endif
 constexpr unsigned kFinBusy = 0x80000000u, kFinShared = 0x40000000u, kFinCount = 0x3fffffffu;      // `fin` while a ray is posted / walked: busy flag | walked by more than one worker at some point | walkers
+// BOUND: once a ray is finished the same word holds 1 + the wave's pair sequence number (heads[kHdPairEnq], zeroed per kernel launch), and bit 31 of THAT would read as
+// "busy" for ever: a persistent wave may enqueue fewer than 2^31 (triangle, ray) pairs per launch.  Config 5 at full size reaches ~1e6 per wave (8.9 pairs per ray,
+// ~1.2e5 rays per wave); a launch that could come near the bound has to be split by the caller (shard_count), nothing here wraps the counter.
 constexpr unsigned kT4Done = 0xffffffffu;      // Trav4::code: no node in hand (walk finished, or no ray)
 constexpr unsigned kT4Miss = 0xffffffffu;      // sort key of a child the ray does not enter / code of an unused child slot
 

@@ -1,0 +1,138 @@
+"""ISA lint for libpsdr_hip.so and its objects: vector instructions ahead of the lane re-enable of a control-flow join.
+Part of the build recipe (build.py lints every translation unit and re-compiles a flagged one with the scalar allocator that does not
+produce the pattern) and of the CPU test suite (tests/test_isa_lint.py).
+
+The compiler bug this looks for (ROCm 7.2 / clang 22, AMDGPU split register allocation; DESIGN.md section 4, "the class-2 sweep's open
+item, closed"): the exec restore of a join block (`s_or_b64 exec, exec, s[a:b]`, SI_END_CF) is meant to be the block's first instruction,
+and everything the VGPR allocator inserts at a block head (re-materialised constants, split copies, reloads from AGPRs or scratch) is
+meant to go AFTER it.  When the SGPR allocation phase has put scalar copies in front of the restore, `SIInstrInfo::isBasicBlockPrologue`
+stops at those copies and the vector instructions land BEFORE the restore: they run for the lanes of the fall-through branch only, and the
+lanes that rejoin at this block keep whatever the register held before - a wrong value in a lane-dependent subset of the wave.
+
+    python psdr_jit_amd/isa_lint.py [libpsdr_hip.so | api_tu4.o ...]      # exit code 1 when a kernel shows the pattern
+
+A join block is recognised as the target of an `s_cbranch_execz` (the branch that skips a region when no lane wants it: when it is taken
+exec is zero, so nothing of the program's own can sit between that label and the restore - a vector instruction there would do nothing on
+the skipping path) or as the fall-through of an `s_cbranch_execnz` (the exit of a divergent loop, entered with exec == 0).  From the label the scan walks forward until the first instruction that writes exec, branches, or starts the next
+block; if that instruction is `s_or_b64 exec, exec, <sgpr pair>` and a vector instruction (v_*, ds_*, flat_/global_/scratch_/buffer_*)
+came before it, the block is reported.  v_readlane / v_writelane (SGPR spill code, which the compiler does recognise as block prologue)
+do not depend on exec and are ignored."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def available():
+    return os.path.exists(OBJDUMP)
+
+INS = re.compile(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):\s*[0-9A-Fa-f ]+(?:<([^>]+)>)?\s*$")
+FUNC = re.compile(r"^([0-9a-f]+) <(.+)>:$")
+
+
+def code_objects(lib, tmp):
+    """the gfx950 code objects bundled in a host shared library (one per translation unit)"""
+    import shutil
+    local = os.path.join(tmp, "lib.so")          # (the bundles are extracted beside the file that is read)
+    shutil.copy2(lib, local)
+    out = subprocess.run([OBJDUMP, "--offloading", local], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
+    objs = sorted(f for f in os.listdir(tmp) if "amdgcn" in f)
+    if not objs:
+        raise RuntimeError("no device code objects found in %s:\n%s" % (lib, out))
+    return [os.path.join(tmp, f) for f in objs]
+
+
+def is_vector(op):
+    return op.startswith(("v_", "ds_", "global_", "flat_", "scratch_", "buffer_", "tbuffer_", "image_"))
+
+
+def is_lane_op(op):
+    return op.startswith(("v_readlane", "v_writelane", "v_readfirstlane"))
+
+
+def is_allocator_kind(op):
+    return op.startswith(("v_mov_b32", "v_mov_b64", "v_accvgpr_read", "v_accvgpr_write", "v_accvgpr_mov", "scratch_load", "scratch_store"))
+
+
+def writes_exec(op, args):
+    if "saveexec" in op or op.startswith("v_cmpx"):
+        return True
+    dst = args.split(",")[0].strip()
+    return op.startswith("s_") and dst in ("exec", "exec_lo", "exec_hi")
+
+
+def lint_object(path):
+    dis = subprocess.run([OBJDUMP, "-d", path], stdout=subprocess.PIPE, text=True).stdout.split("\n")
+    findings = []
+    funcs = []          # (name, [(addr, op, args)])
+    cur = None
+    for line in dis:
+        m = FUNC.match(line)
+        if m:
+            cur = (m.group(2), int(m.group(1), 16), [])
+            funcs.append(cur)
+            continue
+        m = INS.match(line)
+        if m and cur is not None:
+            cur[2].append((int(m.group(3), 16), m.group(1), m.group(2), m.group(4)))
+    for name, base, ins in funcs:
+        if not any(op == "s_endpgm" for _a, op, _g, _t in ins):
+            continue
+        targets, skip_targets = set(), set()
+        for addr, op, args, tgt in ins:
+            if op.startswith(("s_cbranch", "s_branch")) and tgt and "+0x" in tgt:
+                targets.add(base + int(tgt.rsplit("+0x", 1)[1], 16))
+                if op == "s_cbranch_execz":
+                    skip_targets.add(base + int(tgt.rsplit("+0x", 1)[1], 16))
+        # ... and the exit of a divergent loop: the block that follows the back edge `s_cbranch_execnz` is entered with exec == 0
+        for k, (addr, op, args, tgt) in enumerate(ins[:-1]):
+            if op == "s_cbranch_execnz":
+                skip_targets.add(ins[k + 1][0])
+        index = {a: i for i, (a, _o, _g, _t) in enumerate(ins)}
+        for t in sorted(skip_targets):
+            i = index.get(t)
+            if i is None:
+                continue
+            seen = []
+            while i < len(ins):
+                addr, op, args, _tgt = ins[i]
+                if i != index[t] and addr in targets:
+                    break
+                if op == "s_or_b64" and args.replace(" ", "").startswith("exec,exec,s["):
+                    if seen:
+                        findings.append((name, t - base, seen))
+                    break
+                if writes_exec(op, args) or op.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc", "s_swappc")):
+                    break
+                if is_vector(op) and not is_lane_op(op):
+                    seen.append("%s %s" % (op, args))
+                i += 1
+    return findings
+
+
+def lint(lib):
+    with tempfile.TemporaryDirectory() as tmp:
+        res = []
+        for obj in code_objects(lib, tmp):
+            res += lint_object(obj)
+    return res
+
+
+if __name__ == "__main__":
+    libs = sys.argv[1:] or [os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpsdr_hip.so")]
+    bad = 0
+    for lib in libs:
+        f = lint(lib)
+        print("%s: %d block(s) with vector instructions ahead of the exec restore" % (lib, len(f)))
+        by_kernel = {}
+        for name, off, seen in f:
+            by_kernel.setdefault(name, []).append((off, seen))
+        for name, lst in by_kernel.items():
+            print("  %s" % name)
+            for off, seen in lst[:12]:
+                print("    +0x%x: %s" % (off, "; ".join(seen[:6]) + (" ..." if len(seen) > 6 else "")))
+        bad += len(f)
+    sys.exit(1 if bad else 0)

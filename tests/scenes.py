@@ -160,6 +160,22 @@ def envmap_scene(width=64, height=64, spp=4, sppe=0, sppse=0, param="albedo", en
         dT = np.zeros((4, 4), dtype=np.float32)
         dT[0, 3] = 100.0
         meshes[0].d_to_world_left = dT
+    elif param == "box_rot" and not floor_only:
+        # the first mesh turns about the vertical axis through (185, 0, 169): positions AND the interpolated vertex normals carry a tangent
+        dT = np.zeros((4, 4), dtype=np.float32)
+        dT[0, 2], dT[2, 0] = 1.0, -1.0
+        dT[0, 3], dT[2, 3] = -169.0, 185.0
+        meshes[0].d_to_world_left = dT
+    elif param in ("box_rot_x", "box_rot_z") and not floor_only:
+        # ... about a horizontal axis through (185, 80, 169)
+        dT = np.zeros((4, 4), dtype=np.float32)
+        if param == "box_rot_x":
+            dT[1, 2], dT[2, 1] = -1.0, 1.0
+            dT[1, 3], dT[2, 3] = 169.0, -80.0
+        else:
+            dT[0, 1], dT[1, 0] = -1.0, 1.0
+            dT[0, 3], dT[1, 3] = 80.0, -185.0
+        meshes[0].d_to_world_left = dT
     elif param is not None:
         raise ValueError(param)
     return SceneSpec(meshes, bsdfs, emitters, [cam], width, height, spp, sppe, sppse)

@@ -1,0 +1,8 @@
+#!/bin/bash
+O=gpurun_out/ub6; mkdir -p $O
+for v in "$@"; do
+  timeout 600 python tools/variants.py run $v python tools/adj_dump.py 2 99 20 19 $O/$v.r2.npy > $O/$v.r2.log 2>&1
+  timeout 600 python tools/variants.py run $v python tools/adj_dump.py 2 732 13 12 $O/$v.r18.npy > $O/$v.r18.log 2>&1
+done
+python tools/variants.py restore
+for v in "$@"; do echo "=== $v"; cat $O/$v.r2.log $O/$v.r18.log; done
