@@ -74,8 +74,9 @@ def test_adjoint_dot_product(env, param, terms):
         assert abs(lhs) > 1e-6          # the test is not vacuous
 
 
-def _dot_product_case(env, spec, depth, terms, seeds=(7, 8, 9), with_camera=False, with_mat=False, direct_mis=-1):
-    """<w, J v> against <J^T w, v> for the forward tangent the spec carries"""
+def _dot_product_case(env, spec, depth, terms, seeds=(7, 8, 9), with_camera=False, with_mat=False, direct_mis=-1, oracle=None):
+    """<w, J v> against <J^T w, v> for the forward tangent the spec carries; J v from HIP forward mode or, oracle = the oracle module, from the CPU oracle's
+    forward mode (then no HIP forward kernel takes part in the check)"""
     torch, psdr, cabi = env
     sc = product.build_scene(spec)
     snap = sc._snapshot()
@@ -91,6 +92,10 @@ def _dot_product_case(env, spec, depth, terms, seeds=(7, 8, 9), with_camera=Fals
     cabi.check(cabi.lib().psdr_hip_render_d_fwd(sc._hip_handle(), C.byref(a), buf[0].data_ptr(), buf[1].data_ptr(), None))
     gen = torch.Generator(device="cpu").manual_seed(3)
     w = (torch.rand((n, 3), generator=gen) + 0.5).to("cuda")
+    if oracle is not None:
+        assert direct_mis == -1
+        _img, d_img = oracle.OracleScene(spec, [0]).render_d(max_depth=depth, seeds=seeds, terms=terms)
+        buf[1].copy_(torch.from_numpy(d_img).to("cuda"))
     lhs = float((buf[1].double() * w.double()).sum())
     dev = "cuda"
     g_tri = torch.zeros((d_tri.shape[0], 22), dtype=torch.float32, device=dev)
@@ -348,6 +353,24 @@ def test_environment_sweep_equals_the_probe_form(env, monkeypatch, balls):
         q["tri"][-12:] = 0.0          # the rows of the map's bounding box, appended last by Scene::configure (scene.cpp:434-485): fixed geometry, read by nobody - the
                                       # sweep glues its vertices to their triangles, the probe form differentiates the box hit as a ray-plane solve
     _assert_same_buffers(sw, pr, 3e-4, "envmap balls=%s" % balls)
+
+
+@pytest.mark.parametrize("family", ["diffuse_env", "diffuse_env_rot", "microfacet", "normalmap", "cbox"])
+def test_reverse_sweeps_against_the_oracle(env, orc, family):
+    """every sweep family against the ORACLE's forward mode (no HIP forward kernel in the loop, no finite differences): class-2 sweep under an environment map (translation and
+    rotation of a smooth mesh), the material sweep of a Microfacet box, the normal-map sweep, the class-1 sweep of the README box"""
+    if family == "diffuse_env":
+        spec, kw = scenes.envmap_scene(40, 40, 8, 0, 0, param="box_x", area_light=True, balls=True), {}
+    elif family == "diffuse_env_rot":
+        spec, kw = scenes.envmap_scene(40, 40, 8, 0, 0, param="box_rot_x", area_light=True, balls=True), {}
+    elif family == "microfacet":
+        spec, kw = scenes.microfacet_cbox_scene(40, 40, 8, 0, 0, param="roughness"), {"with_mat": True}
+    elif family == "normalmap":
+        spec, kw = scenes.normalmap_scene(40, 40, 8, 0, 0, param="box_x", nested="microfacet", nmap="bumpy"), {"with_mat": True}
+    else:
+        spec, kw = scenes.cbox_scene(40, 40, 8, 0, 0, param="box_x"), {}
+    lhs, rhs, scale = _dot_product_case(env, spec, depth=3, terms=1, oracle=orc, **kw)
+    assert abs(lhs - rhs) <= 1e-3 * scale and abs(lhs) > 1e-6, (family, lhs, rhs, scale)
 
 
 @pytest.mark.parametrize("axis", ["box_rot", "box_rot_x", "box_rot_z"])
