@@ -147,6 +147,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--dry", action="store_true", help="check that --gpus N can run on this node (visible devices, launcher environment), print the verdict, render nothing")
     args = ap.parse_args()
 
     import numpy as np
@@ -156,10 +157,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    launch_line = "python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus %d" % (args.gpus, args.gpus)
+    if args.dry:
+        # the 1 -> 8 curve is the driver's to run; this says beforehand whether the node can: one rank per GPU needs N visible devices
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        ok = have >= args.gpus
+        print(json.dumps({"dry": True, "gpus_requested": args.gpus, "devices_visible": have, "ok": ok,
+                          "launch": launch_line if args.gpus > 1 else "python bench.py",
+                          "message": "ok" if ok else "bench.py --gpus %d needs %d visible GPUs (one rank per GPU over RCCL), this node shows %d" % (args.gpus, args.gpus, have)}))
+        raise SystemExit(0 if ok else 1)
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+        raise SystemExit("launch with: %s   (WORLD_SIZE is %d)" % (launch_line, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    if world > 1 and os.environ.get("PSDR_BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py --gpus %d: one rank per GPU over RCCL needs %d visible GPUs, this node shows %d (PSDR_BENCH_BACKEND=gloo shares devices, for tests only)" %
+                         (world, world, torch.cuda.device_count()))
     # one rank per GPU over RCCL.  (PSDR_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a box with fewer GPUs
     # than ranks - ranks then share devices; never used for reported numbers.)
     backend = os.environ.get("PSDR_BENCH_BACKEND", "nccl")
@@ -237,6 +250,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
+    # N > 1 (outside the timed region): what a step consists of on every rank - HIP events on the launch stream around the render and around the
+    # all-reduce of three extra steps - so that a scaling curve can be attributed (a slow rank, a slow collective, or launch skew)
+    breakdown = None
+    if use_dist:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        acc = [0.0, 0.0]
+        reps = 3
+        for i in range(reps):
+            sync()
+            ev[0].record()
+            launch(5000 + i)
+            ev[1].record()
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            ev[2].record()
+            torch.cuda.synchronize()
+            acc[0] += ev[0].elapsed_time(ev[1]); acc[1] += ev[1].elapsed_time(ev[2])
+        mine = torch.tensor([acc[0] / reps, acc[1] / reps], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        breakdown = {"render_ms_per_rank": [round(float(t[0]), 3) for t in allr], "allreduce_ms_per_rank": [round(float(t[1]), 3) for t in allr],
+                     "all_reduce_bytes": int(buf.numel() * 4),
+                     "note": "HIP events on the launch stream, mean of %d steps outside the timed region; a rank's all-reduce time includes its wait for the slowest rank's render; "
+                             "the interior tiles of the ranks are disjoint, the edge terms scatter over the frame - the whole [image | derivative] buffer is summed" % reps}
     samples_per_step = float(npx) * spp                  # spp x pixels of the whole job
     value = samples_per_step / (dt / args.steps) / 1e6
 
@@ -252,6 +288,9 @@ def main():
                    "rays_per_step": int(npx * spp * (1 + 2 * DEPTH) + npx * spp * 2 * (1 + 2 * DEPTH) + npx * spp * 3),
                    "parallelism": "256-lane chunks dealt round-robin to %d GPU(s)%s" % (n, " + one all_reduce(sum) of [image | derivative]" if n > 1 else "")},
     }
+
+    if breakdown is not None:
+        out["scale_breakdown"] = breakdown
 
     counters = None
     if os.path.exists(COUNTERS):

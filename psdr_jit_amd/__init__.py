@@ -701,6 +701,99 @@ class IntersectionC:
 IntersectionD = IntersectionC
 
 
+class InteractionC:
+    """reference interaction.h / psdr.cpp:223-233: the base of IntersectionC - wi, p, t and is_valid()"""
+
+    def __init__(self, wi, p, t, valid):
+        self.wi, self.p, self.t, self._valid = wi, p, t, valid
+
+    def is_valid(self):
+        return self._valid
+
+
+InteractionD = InteractionC
+
+
+class SampleRecordC:
+    """reference records.h / psdr.cpp:251-257: pdf, is_valid"""
+
+    def __init__(self, pdf, is_valid):
+        self.pdf, self.is_valid = pdf, is_valid
+
+
+class PositionSampleC(SampleRecordC):
+    """reference records.h / psdr.cpp:259-265: p, J (+ pdf, is_valid); what Mesh.sample_position returns.  C: numpy arrays, D: torch tensors"""
+
+    def __init__(self, p, J, pdf, is_valid, n=None):
+        SampleRecordC.__init__(self, pdf, is_valid)
+        self.p, self.J, self.n = p, J, n
+
+
+SampleRecordD, PositionSampleD = SampleRecordC, PositionSampleC
+
+
+def _mesh_sample_position(self, sample2, active=True):
+    """Mesh.sample_position(sample2, active) (reference psdr.cpp:321-322, mesh.cpp:403-454): a face by area (DiscreteDistribution::sample_reuse on
+    sample2.x), a point on it by warp::square_to_uniform_triangle; pdf = 1 / total area.  A numpy sample2 gives the C instantiation (numpy float32
+    arrays, J = 1), a torch tensor the D one: torch float64 tensors whose graph reaches sample2 and the mesh's leaves (vertex_positions, to_world*),
+    J = area / detach(area).  Host-side numpy / torch - scripts call it on a handful of samples; the kernels sample emitters themselves (shade.h)."""
+    from . import chain as _chain
+    if self.num_faces <= 0 or _np.asarray(self.vertex_positions_T).size == 0:
+        raise PsdrException("Mesh::sample_position: the mesh is not configured")
+    is_d = isinstance(sample2, _torch.Tensor)
+    F = _torch.as_tensor(_np.asarray(self.face_indices, dtype=_np.int64))
+    if is_d:
+        def leaf(name):
+            t = _params(self).get(name)
+            return t.to(_torch.float64) if t is not None else _chain._t(self._get(name, False))
+        M = leaf("to_world_left").reshape(4, 4) @ leaf("to_world").reshape(4, 4) @ leaf("to_world_right").reshape(4, 4)
+        Vw = _chain._xform_pos(M, leaf("vertex_positions").reshape(-1, 3))
+        s2 = sample2.to(_torch.float64).reshape(-1, 2)
+    else:
+        Vw = _chain._t(self.vertex_positions_T).reshape(-1, 3)
+        s2 = _torch.as_tensor(_np.asarray(sample2, dtype=_np.float32).reshape(-1, 2)).to(_torch.float64)
+    rows = _chain._process_mesh(Vw, F)
+    area = rows[:, 21]
+    dist = DiscreteDistribution()
+    dist.init(area.detach().cpu().numpy().astype(_np.float32))
+    sx = s2[:, 0].detach().cpu().numpy().astype(_np.float32)
+    if dist.m_size == 1:
+        idx, reused = _np.zeros(sx.size, _np.int64), s2[:, 0]
+    else:
+        # sample_reuse (pmf.cpp:26-45): the index, and the sample stretched back over its bucket
+        t = sx * _np.float32(dist.m_sum)
+        idx = _np.searchsorted(dist.m_cmf[:dist.m_size - 1], t, side="left").astype(_np.int64)
+        lo = _np.where(idx > 0, dist.m_cmf[_np.maximum(idx - 1, 0)], _np.float32(0.0)).astype(_np.float32)
+        reused = (s2[:, 0] * float(dist.m_sum) - _torch.as_tensor(lo.astype(_np.float64))) / _torch.as_tensor(dist.m_pmf[idx].astype(_np.float64))
+    it = _torch.as_tensor(idx)
+    tt = _torch.sqrt(_torch.clamp(1.0 - reused, min=0.0))                      # warp.h:79-82
+    u, v = 1.0 - tt, tt * s2[:, 1]
+    p = rows[it, 0:3] + rows[it, 3:6] * u[:, None] + rows[it, 6:9] * v[:, None]
+    a = area[it]
+    ok = _torch.as_tensor(_np.broadcast_to(_np.asarray(active, dtype=bool), (s2.shape[0],)).copy())
+    inv_total = 1.0 / float(area.detach().sum())
+    if is_d:
+        return PositionSampleD(p, a / a.detach(), _torch.full((s2.shape[0],), inv_total, dtype=_torch.float64), ok, n=rows[it, 18:21])
+    f = lambda x: x.detach().cpu().numpy().astype(_np.float32)
+    return PositionSampleC(f(p), _np.ones(s2.shape[0], _np.float32), _np.full(s2.shape[0], inv_total, _np.float32), ok.numpy(), n=f(rows[it, 18:21]))
+
+
+Mesh.sample_position = _mesh_sample_position
+
+
+def _get_valid_edge_indices(self):
+    # Mesh::m_valid_edge_indices (mesh.h:110, bound read-write at psdr.cpp:335): a member the reference declares and never fills or reads -
+    # kept so that scripts touching it keep running; empty [0, 2] until a script stores something
+    return self.__dict__.get("_psdr_valid_edge_indices", _np.zeros((0, 2), _np.int32))
+
+
+def _set_valid_edge_indices(self, value):
+    self.__dict__["_psdr_valid_edge_indices"] = _np.asarray(value, dtype=_np.int32).reshape(-1, 2)
+
+
+Mesh.valid_edge_indices = property(_get_valid_edge_indices, _set_valid_edge_indices)
+
+
 def _unit_ray_intersect(self, ray, active=None):
     """Scene.unit_ray_intersect (reference psdr.cpp:404, scene.cpp:809-...): closest hits of a batch of rays on the GPU.
     The AD variant returns the same detached record (derivatives of intersections are taken inside renderD)."""

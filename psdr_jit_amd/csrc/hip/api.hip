@@ -1,12 +1,16 @@
 // api.hip — gfx950 kernels and the C ABI of libpsdr_hip.so (include/psdr_hip.h).
 //
 // Kernel structure (one thread = one sample lane of the reference's wavefront arrays):
-//   * persistent workgroups of 256 threads (4 wave64) stride over 256-lane chunks of the lane range;
+//   * persistent workgroups of 256 threads (4 wave64): every wave pulls batches of 256 work items from a global queue and hands
+//     them to whichever of its lanes have finished their path (ballot / popcount regeneration, paths.h), so the lanes of a wave
+//     belong to different pixels at different bounces;
 //   * at start each workgroup stages the scene blob into LDS (small scenes) with 16-byte loads;
-//   * each lane re-derives its RNG state (sampler.h), traces/shades its whole path in registers with
-//     an LDS traversal stack (scene_dev.h, shade.h), then lanes of one pixel are combined with a
-//     wave-level segmented scan so that ONE lane per pixel issues the float atomics
-//     (the reference issues 3 atomics per lane: scatter_reduce, integrator.cpp:127-129).
+//   * each lane re-derives its RNG state (sampler.h) and traces / shades its whole path in registers (brute-force scenes) or as a
+//     traversal worker on the wave's shared ray queue (BVH scenes, trav4.h);
+//   * a finished path adds its value (and tangent) to its pixel with one float atomic per channel, as the reference does
+//     (scatter_reduce, integrator.cpp:127-129).  Round 1 combined the lanes of a pixel with a segmented scan first; with persistent
+//     regeneration the finishing lanes of a wave rarely share a pixel, and the atomics are not what the kernels wait for: the C3
+//     interior kernel takes 1.698 ms with them and 1.685 ms with the adds compiled out (round 4, -0.8 %), so nothing is aggregated.
 // There is no host synchronisation inside a render call (the reference syncs before each of its 7+
 // OptiX launches, scene_optix.cpp:345).
 #include <hip/hip_runtime.h>
@@ -136,6 +140,9 @@ __global__ __launch_bounds__(kBlock, (AD ? (in_lds(LDS) ? PSDR_LDS_AD_WAVES : (L
 #ifndef PSDR_SEC_ADJ_WAVES
 #define PSDR_SEC_ADJ_WAVES 1
 #endif
+#ifndef PSDR_SEC_HOT_MAX        // triangle rows the secondary-edge adjoint keeps in LDS on large scenes (9 floats each)
+#define PSDR_SEC_HOT_MAX 256
+#endif
 template <int LDS>
 __global__ __launch_bounds__(kBlock, PSDR_ADJ_WAVES) void k_interior_adjoint(const float4 *__restrict__ blob, const SceneTables T, const SensorDev cam,
                                                              const AdjointParams P) {
@@ -204,9 +211,10 @@ __global__ __launch_bounds__(kBlock, (ADJ ? PSDR_SEC_ADJ_WAVES : PSDR_SEC_WAVES)
     BoundarySegSampleDirect bss;
     bss.valid = false;
     float pdf0 = 1.f;
-    if constexpr (ADJ) if (P.lds_acc) {
+    if constexpr (ADJ) if (P.lds_acc || P.n_hot > 0) {
         float *acc = scratch_base<LDS>(smem, T) + kSecAdjScratch;
-        for (int i = threadIdx.x; i < 6 * P.n_sec + 22 * T.n_tris; i += kBlock) acc[i] = 0.f;
+        const int n_acc = P.lds_acc ? 6 * P.n_sec + 22 * T.n_tris : 9 * P.n_hot;
+        for (int i = threadIdx.x; i < n_acc; i += kBlock) acc[i] = 0.f;
         __syncthreads();
     }
     // camera-pose adjoint: 12 entries every sample adds to - kept in LDS (behind the 3 recorded hits of this kernel)
@@ -277,20 +285,26 @@ __global__ __launch_bounds__(kBlock, (ADJ ? PSDR_SEC_ADJ_WAVES : PSDR_SEC_WAVES)
                             if (val.y != 0.f && finite_(val.y)) atomicAdd(&tab[row + 1], val.y);
                             if (val.z != 0.f && finite_(val.z)) atomicAdd(&tab[row + 2], val.z);
                         };
+                        // triangle rows: hot ones per workgroup in LDS (config 5: 93 -> ... ms; 51 of the 93 were the scatter, most of it the 108 floats of the scene box)
+                        float *hot_acc = scratch_base<LDS>(smem, T) + kSecAdjScratch;
+                        auto add_tri = [&](int orig, int comp, const Vec3f &val) {
+                            const int hot = (!P.lds_acc && P.n_hot > 0) ? P.hot_map[orig] : -1;
+                            if (hot >= 0 && hot < P.n_hot) add3(hot_acc, 9 * hot + comp, val); else add3(g_tri, 22 * orig + comp, val);
+                        };
                         Vec3f a2, b2, c2, a1, b1, c1;
                         load_geom<false, LDS>(S, I.slot2, a2, b2, c2);
                         load_geom<false, LDS>(S, I.slot1, a1, b1, c1);
                         Vec3f p0b, e1b, e2b, ob, db;
                         mt_adjoint(a2, b2, c2, I.x1, I.sd, gsum * dot(I.n, b2), gsum * dot(I.n, c2), 0.f, p0b, e1b, e2b, ob, db);
                         const int orig2 = __float_as_int(S.ld(T.shade_off + 6 * I.slot2 + 3).w), orig1 = __float_as_int(S.ld(T.shade_off + 6 * I.slot1 + 3).w);
-                        add3(g_tri, 22 * orig2, p0b); add3(g_tri, 22 * orig2 + 3, e1b); add3(g_tri, 22 * orig2 + 6, e2b);
+                        add_tri(orig2, 0, p0b); add_tri(orig2, 3, e1b); add_tri(orig2, 6, e2b);
                         const Vec3f q = detach(bss.p0) - I.x1;
                         const Vec3f qb = (db - I.sd * dot(I.sd, db)) / norm(q);          // through sd = normalize(p0 - x1)
                         add3(g_sec, 6 * bss.edge_id, qb); add3(g_sec, 6 * bss.edge_id + 3, qb * bss.s1);
                         const Vec3f xb = ob - qb;                                         // the camera hit x1 = o + t d
                         Vec3f p0c, e1c, e2c, oc2, dc2;
                         mt_adjoint(a1, b1, c1, I.cam_o, I.cam_d, 0.f, 0.f, dot(I.cam_d, xb), p0c, e1c, e2c, oc2, dc2);
-                        add3(g_tri, 22 * orig1, p0c); add3(g_tri, 22 * orig1 + 3, e1c); add3(g_tri, 22 * orig1 + 6, e2c);
+                        add_tri(orig1, 0, p0c); add_tri(orig1, 3, e1c); add_tri(orig1, 6, e2c);
                         if (P.g_cam != nullptr) {
                             const float t1 = dot(I.x1 - I.cam_o, I.cam_d);
                             const Vec3f obt = xb + oc2, dbt = xb * t1 + dc2;
@@ -395,6 +409,10 @@ __global__ __launch_bounds__(kBlock, (ADJ ? PSDR_SEC_ADJ_WAVES : PSDR_SEC_WAVES)
         __syncthreads();
         for (int i = threadIdx.x; i < 6 * P.n_sec; i += kBlock) if (acc[i] != 0.f) atomicAdd(&P.g_sec[i], acc[i]);
         for (int i = threadIdx.x; i < 22 * T.n_tris; i += kBlock) if (acc[6 * P.n_sec + i] != 0.f) atomicAdd(&P.g_tri[i], acc[6 * P.n_sec + i]);
+    } else if (P.n_hot > 0) {
+        float *acc = scratch_base<LDS>(smem, T) + kSecAdjScratch;
+        __syncthreads();
+        for (int i = threadIdx.x; i < 9 * P.n_hot; i += kBlock) if (acc[i] != 0.f) atomicAdd(&P.g_tri[22 * P.hot_inv[i / 9] + i % 9], acc[i]);
     }
     if (COUNT) flush_counters(S, ctr);
 }
@@ -1429,7 +1447,11 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         P.sec_closed = no_sweep ? 0 : 1;
         const size_t sec_acc = sizeof(float) * (6 * (size_t) sc->E.n + 22 * (size_t) T.n_tris);
         P.lds_acc = (sec_acc <= 48 * 1024) ? 1 : 0;
-        const size_t smem_sec = smem_for(sc, sc->lds ? 1 : 0) - cold_bytes + sizeof(float) * (size_t) kSecAdjScratch + (P.lds_acc ? sec_acc : 0);
+        // tables too large for LDS: the hot triangle rows still accumulate there (closed form only: it writes p0, e1, e2 = 9 floats per row)
+        constexpr int kSecHotMax = PSDR_SEC_HOT_MAX;
+        P.n_hot = (!P.lds_acc && P.sec_closed) ? std::min(sc->n_hot, kSecHotMax) : 0;
+        P.hot_map = sc->hot_map.as<int>(); P.hot_inv = sc->hot_inv.as<int>();
+        const size_t smem_sec = smem_for(sc, sc->lds ? 1 : 0) - cold_bytes + sizeof(float) * (size_t) kSecAdjScratch + (P.lds_acc ? sec_acc : sizeof(float) * 9 * (size_t) P.n_hot);
         GuidingDev G{};
         const int use_g = a->guiding ? 1 : 0;
         if (a->guiding) G = a->guiding->G;

@@ -37,6 +37,10 @@ struct PathParams {
     int lds_acc, n_prim, n_sec;      // 1: the kernel accumulates the adjoint tables in LDS first (same-address atomics)
     int mis;                         // -1: PathTracer; 0/1/2: DirectIntegrator(mis), reference direct.cpp:34-132 (max_depth = 1)
     int sec_closed;                  // reverse mode of the secondary-edge term: 1 = closed form (two adjoint Moeller-Trumbore solves), 0 = record and probe
+    // closed form on scenes whose tables do not fit LDS (lds_acc == 0): the rows of the scene's hot triangles (emitter meshes first - EVERY sample adds to the
+    // emitter triangle its boundary ray ends on, under an environment map one of the 12 of the scene box -, then by area; adjoint.h) accumulate per workgroup
+    const int *hot_map, *hot_inv;    // [n_tris] original triangle id -> hot index or -1; [n_hot] back
+    int n_hot;                       // rows kept in LDS (9 floats each: p0, e1, e2), 0 = none
     int field, field_object;         // >= 0: first-hit integrator (shade.h first_hit_value), max_depth = 0
     float intensity, d_intensity;
 };

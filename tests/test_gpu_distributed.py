@@ -52,6 +52,20 @@ def test_bench_two_ranks_config4_strong_scaling_line():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "config 4" in d["config"]["workload"] and "2048x2048" in d["config"]["workload"]
     assert d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and d["unit"] == "Msamples/s"
     assert "roofline" not in d and "cpu_baseline" not in d        # N = 1 only
+    # what the line offers for reading a scaling curve: per-rank render and all-reduce times (HIP events, outside the timed region)
+    sb = d["scale_breakdown"]
+    assert len(sb["render_ms_per_rank"]) == 2 and len(sb["allreduce_ms_per_rank"]) == 2 and min(sb["render_ms_per_rank"]) > 0
+    assert sb["all_reduce_bytes"] == 2 * 2048 * 2048 * 3 * 4
+
+
+def test_bench_dry_run_says_whether_the_node_can_run_n_ranks():
+    """`bench.py --gpus N --dry`: visible devices against the ranks asked for, with the launch line - no rendering"""
+    for n, want in ((1, 0), (64, 1)):
+        r = subprocess.run([sys.executable, "bench.py", "--gpus", str(n), "--dry"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+        assert r.returncode == want and d["dry"] and d["ok"] == (want == 0) and d["gpus_requested"] == n, r.stdout[-1000:]
+        if want:
+            assert "needs 64 visible GPUs" in d["message"]
 
 
 def test_rccl_preflight_world_size_one():
@@ -74,6 +88,7 @@ def test_rccl_preflight_world_size_one():
     assert len(lines) == 1, r.stdout[-3000:]
     d = json.loads(lines[0])
     assert d["rccl"]["backend"] == "nccl" and d["rccl"]["ranks"] == 1 and d["rccl"]["all_reduce_bytes"] == 2 * 256 * 256 * 3 * 4
+    assert len(d["scale_breakdown"]["render_ms_per_rank"]) == 1 and d["scale_breakdown"]["allreduce_ms_per_rank"][0] >= 0.0
     assert d["value"] > 0 and d["n_gpus"] == 1 and "config 4" in d["config"]["workload"]
     # the same frame without the process group: the all-reduce of one rank must not change the image (checked through the rate only
     # being finite here; equality of sharded and unsharded frames is test_two_ranks_forward_and_backward_equal_one_process)

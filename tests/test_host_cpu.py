@@ -539,3 +539,44 @@ def test_cornell_box_from_coordinates_equals_the_tutorial_files():
             assert (x is None and y is None) or np.array_equal(x, y), name
         n_tri += a[1].shape[0]
     assert n_tri == 36
+
+
+def test_mesh_sample_position_and_the_record_classes(psdr):
+    """Mesh.sample_position (reference psdr.cpp:321-322, mesh.cpp:403-454) in its C (numpy) and D (torch) instantiation, Mesh.valid_edge_indices, the record classes"""
+    import torch
+    spec = scenes.cbox_scene(16, 16, 1, 0, 0, param=None)
+    sc = product.build_scene(spec, host_only=True)
+    mesh = sc.param_map["Mesh[0]"]
+    rng = np.random.default_rng(3)
+    s2 = rng.random((4096, 2), dtype=np.float32)
+    ps = mesh.sample_position(s2)
+    assert isinstance(ps, psdr.PositionSampleC) and isinstance(ps, psdr.SampleRecordC)
+    V = np.asarray(mesh.vertex_positions_T, np.float64)
+    F = np.asarray(mesh.face_indices)
+    e1, e2 = V[F[:, 1]] - V[F[:, 0]], V[F[:, 2]] - V[F[:, 0]]
+    area = 0.5 * np.linalg.norm(np.cross(e1, e2), axis=1)
+    assert ps.p.shape == (4096, 3) and ps.is_valid.all() and np.allclose(ps.J, 1.0) and np.allclose(ps.pdf, 1.0 / area.sum(), rtol=1e-6)
+    # every point lies on a face of the mesh, and the faces are hit in proportion to their areas
+    N = np.cross(e1, e2); N /= np.linalg.norm(N, axis=1, keepdims=True)
+    d = np.abs(np.einsum("pfk,fk->pf", ps.p[:, None, :].astype(np.float64) - V[F[:, 0]][None], N)).min(axis=1)
+    assert d.max() < 1e-3 * np.abs(V).max()
+    cen = (area[:, None] * (V[F[:, 0]] + (e1 + e2) / 3.0)).sum(axis=0) / area.sum()
+    assert np.abs(ps.p.mean(axis=0) - cen).max() < 0.03 * np.ptp(V, axis=0).max()
+    # the first sample coordinate picks the face by the running sum of the areas: u -> 0 lands on face 0, u -> 1 on the last face
+    lo, hi = mesh.sample_position(np.array([[1e-6, 0.5]], np.float32)), mesh.sample_position(np.array([[1 - 1e-6, 0.5]], np.float32))
+    inside = lambda p, f: abs(np.dot(p - V[F[f, 0]], N[f])) < 1e-3
+    assert inside(lo.p[0].astype(np.float64), 0) and inside(hi.p[0].astype(np.float64), len(F) - 1)
+    # D: the graph reaches the sample and the mesh's leaves
+    P = torch.tensor(0.0, requires_grad=True)
+    mesh.set_transform(psdr.Matrix4fD([[1., 0., 0., P * 10.], [0., 1., 0., 0.], [0., 0., 1., 0.], [0., 0., 0., 1.]]))
+    st = torch.tensor(s2[:8], requires_grad=True)
+    pd = mesh.sample_position(st)
+    assert isinstance(pd, psdr.PositionSampleD) and pd.p.dtype == torch.float64 and torch.allclose(pd.J, torch.ones_like(pd.J))
+    g_P, g_s = torch.autograd.grad(pd.p[:, 0].sum(), [P, st])
+    assert abs(float(g_P) - 80.0) < 1e-6 and g_s.abs().sum() > 0
+    # the member the reference binds read-write and never uses
+    assert mesh.valid_edge_indices.shape == (0, 2)
+    mesh.valid_edge_indices = [[0, 1], [2, 3]]
+    assert mesh.valid_edge_indices.tolist() == [[0, 1], [2, 3]]
+    its = psdr.InteractionC(np.zeros((1, 3)), np.zeros((1, 3)), np.ones(1), np.array([True]))
+    assert its.is_valid()[0] and psdr.InteractionD is psdr.InteractionC

@@ -1,5 +1,6 @@
 """Reverse mode alone, for the profiler: N calls of psdr_hip_render_d_bwd (all three terms, every adjoint, nothing filtered) on the
-bench workload - `c3` (README box, 512^2, 32/32/32, depth 3) or `c5` (BASELINE config 5's scene at [res] x [spp], default 512^2 x 16) - so
+bench workload - `c3` (README box, 512^2, 32/32/32, depth 3) or `c5` (BASELINE config 5's scene with its guiding grid [2000, 5, 5, 32] at [res] x [spp], default
+the timed size 1024^2 x 64: what bench.py's `config5.backward` times) - so
 that every kernel in a rocprofv3 trace of this command belongs to the backward pass.
 
     python tools/bwd_only.py c3 [calls]          python tools/bwd_only.py c5 [calls] [res] [spp]
@@ -22,10 +23,16 @@ if what == "c3":
     res, spp = 512, 32
     spec = scenes.cbox_scene(res, res, spp, spp, spp, param="light_x")
 else:
-    res = int(sys.argv[3]) if len(sys.argv) > 3 else 512
-    spp = int(sys.argv[4]) if len(sys.argv) > 4 else 16
+    res = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+    spp = int(sys.argv[4]) if len(sys.argv) > 4 else 64
     spec = scenes.config5_scene(res, res, spp, spp, spp, level=6, env_res=(1024, 512))
 sc = product.build_scene(spec)
+guiding = None
+if what != "c3":
+    import psdr_jit_amd as psdr
+    integ = psdr.PathTracer(3)
+    integ.preprocess_secondary_edges(sc, 0, [2000, 5, 5, 32], 1, 0)
+    guiding = integ._guiding_handle(0) or None
 snap = sc._snapshot(); cam = sc.param_map["Sensor[0]"]
 n = res * res
 z = lambda *s: torch.zeros(s, device="cuda")
@@ -42,11 +49,11 @@ if envs:
     keep += [g_env, g_scale, g_xf, g_cam]
 w = torch.ones((n, 3), device="cuda")
 L = cabi.lib()
-a = cabi.make_args(max_depth=3, seeds=(1, 2, 3), terms=7)
+a = cabi.make_args(max_depth=3, seeds=(1, 2, 3), terms=7, guiding=guiding)
 cabi.check(L.psdr_hip_render_d_bwd(sc._hip_handle(), C.byref(a), w.data_ptr(), C.byref(g), None)); torch.cuda.synchronize()
 t = time.perf_counter()
 for i in range(calls):
-    a = cabi.make_args(max_depth=3, seeds=(i, i, i), terms=7)
+    a = cabi.make_args(max_depth=3, seeds=(i, i, i), terms=7, guiding=guiding)
     cabi.check(L.psdr_hip_render_d_bwd(sc._hip_handle(), C.byref(a), w.data_ptr(), C.byref(g), None))
 torch.cuda.synchronize()
 print("%s backward (%d x %d, %d samples per pixel and term, depth 3, %d triangles): %.2f ms per call" % (what, res, res, spp, n_tri, (time.perf_counter() - t) / calls * 1e3))

@@ -6,7 +6,7 @@
 #   (default dirs prof_*)  bench.py's timed loop alone: the C3 forward kernels
 #   bwd_     reverse mode on C3 alone (tools/bwd_only.py c3)
 #   c5_      BASELINE config 5 at full size (bench.py --config 5: 1024 x 1024, 64 / 64 / 64, guiding grid)
-#   c5bwd_   reverse mode on config 5's scene (512 x 512 x 16)
+#   c5bwd_   reverse mode on config 5 at full size with its guiding grid (tools/bwd_only.py c5: 1024 x 1024 x 64)
 #   sph_     the sphere tutorial box at depth 3 (tools/bench_scene.py sphere)
 set -u
 REPO=$(pwd)
@@ -25,7 +25,7 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ
 cd $REPO
 bash tools/profile_cmd.sh bwd python tools/bwd_only.py c3 5
 bash tools/profile_cmd.sh c5 python bench.py --config 5 --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-backward --no-roofline
-bash tools/profile_cmd.sh c5bwd python tools/bwd_only.py c5 3
+bash tools/profile_cmd.sh c5bwd python tools/bwd_only.py c5 2 1024 64
 bash tools/profile_cmd.sh sph python tools/bench_scene.py sphere
 # the databases travel back through gpurun_out (64 MiB): keep the *_results.db files only
 find $OUT -name "*.csv" -size +2M -delete 2> /dev/null
