@@ -1,5 +1,6 @@
 """BASELINE.json's configurations AS TIMED, HIP path (through the C ABI) vs the oracle:
 
+  config 1  Cornell box 128 x 128, spp 4, PathTracer(1) renderC              - the whole frame
   config 2  Cornell box 512 x 512, spp 32, PathTracer(3) renderC           - full size, two bands of pixel rows + a lane range
   config 3  + sppe = sppse = 32, renderD w.r.t. Mesh[0] x-translation       - small at depth 3 (per term), and full size on a 1/64 shard
             (the kernels bench.py times: the LDS-class AD interior kernel and both edge kernels at depth 3)
@@ -135,6 +136,18 @@ def test_config3_full_size_shard(env, orc):
     full = _render_d(env, sc, 512 * 512, 3, (7, 7, 7))
     parts = sum(_render_d(env, sc, 512 * 512, 3, (7, 7, 7), rank=r, count=4) for r in range(4))
     assert product.rel_l2(parts[0], full[0]) < 1e-5 and product.rel_l2(parts[1], full[1]) < 1e-4
+
+
+def test_config1_exact_size(env, orc):
+    """config 1 as BASELINE.json writes it - Cornell box 128 x 128, spp = 4, PathTracer(1), renderC ("plumbing"; the reference runs it on drjit's LLVM CPU backend): the
+    whole frame against the oracle, through the Python surface the reference's README uses"""
+    torch, psdr, cabi = env
+    spec = scenes.cbox_scene(128, 128, 4, 0, 0, param=None)
+    sc = product.build_scene(spec)
+    img = psdr.PathTracer(1).renderC(sc, 0, seed=0).cpu().numpy()
+    want = orc.OracleScene(spec, [0]).render_c(max_depth=1, seed=0)
+    assert img.shape == (128 * 128, 3) and np.isfinite(img).all() and np.abs(want).max() > 0
+    assert product.rel_l2(img, want) < TOL
 
 
 def test_config2_full_size_rows(env, orc):
