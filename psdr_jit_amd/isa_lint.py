@@ -14,7 +14,8 @@ lanes that rejoin at this block keep whatever the register held before - a wrong
 A join block is recognised as the target of an `s_cbranch_execz` (the branch that skips a region when no lane wants it: when it is taken
 exec is zero, so nothing of the program's own can sit between that label and the restore - a vector instruction there would do nothing on
 the skipping path) or as the fall-through of an `s_cbranch_execnz` (the exit of a divergent loop, entered with exec == 0).  From the label the scan walks forward until the first instruction that writes exec, branches, or starts the next
-block; if that instruction is `s_or_b64 exec, exec, <sgpr pair>` and a vector instruction (v_*, ds_*, flat_/global_/scratch_/buffer_*)
+block; if that instruction is `s_or_b64 exec, exec, <sgpr pair>` (or the `s_or_saveexec_b64` / `s_andn2_saveexec_b64` that flips a flow block to the lanes of the
+other branch) and a vector instruction (v_*, ds_*, flat_/global_/scratch_/buffer_*)
 came before it, the block is reported.  v_readlane / v_writelane (SGPR spill code, which the compiler does recognise as block prologue)
 do not depend on exec and are ignored."""
 import os
@@ -101,7 +102,8 @@ def lint_object(path):
                 addr, op, args, _tgt = ins[i]
                 if i != index[t] and addr in targets:
                     break
-                if op == "s_or_b64" and args.replace(" ", "").startswith("exec,exec,s["):
+                # the lane re-enable of a join (SI_END_CF) or the flip to the other branch's lanes at the head of a flow block (SI_ELSE)
+                if (op == "s_or_b64" and args.replace(" ", "").startswith("exec,exec,s[")) or op in ("s_or_saveexec_b64", "s_andn2_saveexec_b64"):
                     if seen:
                         findings.append((name, t - base, seen))
                     break

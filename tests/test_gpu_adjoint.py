@@ -341,6 +341,39 @@ def test_normalmap_sweep_equals_the_probe_form(env, monkeypatch):
     _assert_same_buffers(sw, pr, 5e-4, "normalmap")
 
 
+_FAMILIES = {
+    "cbox": lambda: scenes.cbox_scene(40, 40, 8, 0, 0, param="box_x"),
+    "cbox_camera": lambda: scenes.cbox_scene(40, 40, 8, 0, 0, param="camera_x"),
+    "sphere": lambda: scenes.sphere_scene(40, 40, 8, 0, 0),
+    "microfacet": lambda: scenes.microfacet_cbox_scene(40, 40, 8, 0, 0, param="roughness"),
+    "microfacet_two_sided": lambda: scenes.microfacet_cbox_scene(40, 40, 8, 0, 0, param="box_x", two_sided=True),
+    "conductor": lambda: scenes.conductor_cbox_scene(40, 40, 8, 0, 0, param="alpha"),
+    "dielectric": lambda: scenes.dielectric_cbox_scene(40, 40, 8, 0, 0, param="alpha"),
+    "textured_env": lambda: scenes.textured_scene(40, 40, 8, 0, 0, param="box_x"),
+    "textured_microfacet": lambda: scenes.textured_microfacet_scene(40, 40, 8, 0, 0, param="roughness"),
+    "pervertex": lambda: scenes.pervertex_scene(40, 40, 8, 0, 0, param="ball_x"),
+    "normalmap_diffuse": lambda: scenes.normalmap_scene(40, 40, 8, 0, 0, param="box_x", nested="diffuse", nmap="bumpy"),
+    "textured_conductor": lambda: scenes.textured_ggx_scene(40, 40, 8, 0, 0, kind="roughconductor", param="alpha"),
+    "textured_dielectric": lambda: scenes.textured_ggx_scene(40, 40, 8, 0, 0, kind="roughdielectric", param="alpha"),
+    "envmap_tutorial": lambda: scenes.envmap_tutorial_scene(40, 40, 8, 0, 0, param="bunny_x"),
+    "ortho": lambda: scenes.ortho_cbox_scene(40, 40, 8, 0, 0, param="box_x"),
+}
+
+
+@pytest.mark.parametrize("family", list(_FAMILIES))
+def test_every_reverse_form_against_the_probe_form(env, monkeypatch, family):
+    """whatever reverse form the launch picks for a scene (class-1 / class-2 sweep, material sweep, or record-and-probe itself) against record-and-probe forced, every buffer
+    the call can fill (triangle rows, colours, emitters, GGX constants, texels / per-vertex values, camera pose, environment texels / scale / rotation) - the cross-check that
+    found the probe form's stage-3 defect in round 4, over every scene family of the suite"""
+    spec = _FAMILIES[family]()
+    sw = _all_adjoint_buffers(env, spec, 3, monkeypatch, probe=False)
+    pr = _all_adjoint_buffers(env, spec, 3, monkeypatch, probe=True)
+    if any(getattr(e, "type", 0) == 1 for e in spec.emitters):
+        for q in (sw, pr):
+            q["tri"][-12:] = 0.0          # rows of the environment map's bounding box (see test_environment_sweep_equals_the_probe_form)
+    _assert_same_buffers(sw, pr, 5e-4, family)
+
+
 @pytest.mark.parametrize("balls", [False, True])
 def test_environment_sweep_equals_the_probe_form(env, monkeypatch, balls):
     """class-2 reverse sweep against record-and-probe with EVERY optional buffer requested (texels, scale and rotation of the map, camera pose): round 4 found

@@ -55,17 +55,22 @@ GOOD = """
 """
 
 
+ELSE_FLIP = BAD.replace("kernel_a", "kernel_c").replace("s_or_b64 exec, exec, s[0:1]                                // 000000001020: 87FE007E",
+                                                            "s_or_saveexec_b64 s[0:1], s[0:1]                           // 000000001020: BE802500")
+
+
 def test_lint_flags_a_constant_written_before_the_lane_restore(tmp_path, monkeypatch):
     """the shape found in the failing build, and its harmless sibling (SGPR reload in front of the restore, constant behind it)"""
     class Fake:
         def __init__(self, text):
             self.stdout = text
-    for text, want in ((BAD, 1), (GOOD, 0)):
+    assert "s_or_saveexec_b64" in ELSE_FLIP
+    for text, want in ((BAD, 1), (GOOD, 0), (ELSE_FLIP, 1)):
         monkeypatch.setattr(isa_lint.subprocess, "run", lambda *a, _t=text, **k: Fake(_t))
         got = isa_lint.lint_object("unused")
         assert len(got) == want, (got, want)
         if want:
-            assert got[0][0] == "kernel_a" and got[0][1] == 0x14 and "0x40490fdb" in got[0][2][0]
+            assert got[0][0] in ("kernel_a", "kernel_c") and got[0][1] == 0x14 and "0x40490fdb" in got[0][2][0]
 
 
 def test_shipped_library_is_clean():
