@@ -388,6 +388,37 @@ def test_environment_sweep_equals_the_probe_form(env, monkeypatch, balls):
     _assert_same_buffers(sw, pr, 3e-4, "envmap balls=%s" % balls)
 
 
+@pytest.mark.parametrize("family", ["cbox_camera", "cbox_radiance", "conductor", "dielectric", "textured_env", "textured_microfacet", "pervertex", "textured_conductor", "envmap_tutorial", "ortho", "sphere"])
+def test_reverse_mode_against_the_oracle_more_families(env, orc, family):
+    """the remaining scene families of the suite, reverse mode against the oracle's forward mode (interior term, depth 3): camera pose, emitter radiance, GGX conductors and
+    dielectrics (constants and bitmaps), textures under an environment map, per-vertex parameters, the tutorial's glossy mesh under its map, the orthographic camera, the BVH box"""
+    kw = {}
+    if family == "cbox_camera":
+        spec, kw = scenes.cbox_scene(40, 40, 8, 0, 0, param="camera_x"), {"with_camera": True}
+    elif family == "cbox_radiance":
+        spec = scenes.cbox_scene(40, 40, 8, 0, 0, param="radiance")
+    elif family == "conductor":
+        spec, kw = scenes.conductor_cbox_scene(40, 40, 8, 0, 0, param="eta"), {"with_mat": True}
+    elif family == "dielectric":
+        spec, kw = scenes.dielectric_cbox_scene(40, 40, 8, 0, 0, param="alpha"), {"with_mat": True}
+    elif family == "textured_env":
+        spec = scenes.textured_scene(40, 40, 8, 0, 0, param="texture")
+    elif family == "textured_microfacet":
+        spec, kw = scenes.textured_microfacet_scene(40, 40, 8, 0, 0, param="roughness"), {"with_mat": True}
+    elif family == "pervertex":
+        spec, kw = scenes.pervertex_scene(40, 40, 8, 0, 0, param="roughness"), {"with_mat": True}
+    elif family == "textured_conductor":
+        spec, kw = scenes.textured_ggx_scene(40, 40, 8, 0, 0, kind="roughconductor", param="alpha"), {"with_mat": True}
+    elif family == "envmap_tutorial":
+        spec, kw = scenes.envmap_tutorial_scene(40, 40, 8, 0, 0, param="bunny_x"), {"with_mat": True}
+    elif family == "ortho":
+        spec = scenes.ortho_cbox_scene(40, 40, 8, 0, 0, param="box_x")
+    else:
+        spec = scenes.sphere_scene(40, 40, 8, 0, 0)
+    lhs, rhs, scale = _dot_product_case(env, spec, depth=3, terms=1, oracle=orc, **kw)
+    assert abs(lhs - rhs) <= 1e-3 * scale and abs(lhs) > 1e-6, (family, lhs, rhs, scale)
+
+
 @pytest.mark.parametrize("family", ["diffuse_env", "diffuse_env_rot", "microfacet", "normalmap", "cbox"])
 def test_reverse_sweeps_against_the_oracle(env, orc, family):
     """every sweep family against the ORACLE's forward mode (no HIP forward kernel in the loop, no finite differences): class-2 sweep under an environment map (translation and
