@@ -653,53 +653,57 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
                 const float sgn = (two && its.wi.z < 0.f) ? -1.f : 1.f;
                 if (sgn < 0.f) flags |= 4;
                 const bool front = bid >= 0 && (two ? fabsf(its.wi.z) : its.wi.z) > 0.f;
-                {   // next-event estimation (path.cpp:47-83)
-                    // (DirectIntegrator(1) neither draws nor uses the emitter sample, direct.cpp:34-132)
-                    const float s1 = P.mis != 1 ? rng.next_1d() : 0.f, s2 = P.mis != 1 ? rng.next_1d() : 0.f;
-                    if (P.mis != 1 && mesh_emitter(S, its.mesh) < 0) {
-                        const PositionSample<false> ps = sample_emitter_position<false, LDS>(S, its.p, s1, s2);
-                        Vec3f wod = ps.p - its.p;
-                        const float dist_sqr = squared_norm(wod), dist = safe_sqrt(dist_sqr);
-                        wod = wod / dist;
-                        const Hit h1 = trace<LDS, false>(S, its.p, wod, (dist - kShadowEpsilon) * 0.9999f);     // (any occluder settles the shadow test)
-                        if (h1.slot >= 0) {
-                            RayT<false> ray1; ray1.o = its.p; ray1.d = wod;
-                            const Its<false> its1 = make_its<false, LDS, false>(S, h1, ray1, true);
-                            const int eh = mesh_emitter(S, its1.mesh);
-                            if (its1.t > dist - kShadowEpsilon && eh >= 0) {
-                                const float G = fabsf(dot(its1.n, -wod)) / dist_sqr;
-                                const float woz = dot(wod, its.fn) * sgn;
-                                const float pdf1 = ((front && woz > 0.f) ? kInvPi * woz : 0.f) * G;
-                                if (front && woz > 0.f && pdf1 != 0.f) {
-                                    const float cN = kInvPi * (P.mis == 0 ? 1.f : mis_weight(ps.pdf, pdf1)) / ps.pdf;
-                                    if (eh == env_id) {
-                                        // the sample lies on the scene box (a fixed point: the record keeps it instead of a triangle),
-                                        // the radiance is looked up along the shadow ray
-                                        Lsum = Lsum + thr * rho * env_radiance(env_dir_at(h1.slot, h1.u, h1.v, its.p)) * (woz * G * cN);
-                                        br[0] = h1.u; br[kBlock] = h1.v; br[2 * kBlock] = 0.f; br[3 * kBlock] = __int_as_float(h1.slot);
-                                        br[4 * kBlock] = cN;
-                                        flags |= 1 | 16;
-                                    } else if (its1.wi.z > 0.f) {
-                                        const float4 ea = S.ld(T.emit_off + 2 * eh);
-                                        Lsum = Lsum + thr * rho * Vec3f(ea.x, ea.y, ea.z) * (woz * G * cN);
-                                        br[0] = __int_as_float(ps.slot); br[kBlock] = ps.ba; br[2 * kBlock] = ps.bb; br[3 * kBlock] = __int_as_float(h1.slot);
-                                        br[4 * kBlock] = cN;
-                                        flags |= 1;
-                                    }
-                                }
+                // The vertex's two rays - the shadow ray of the emitter sample (path.cpp:47-83) and the extension ray of the BSDF sample (path.cpp:86-123) - are drawn
+                // first (the sampler order is the forward pass's: two numbers, then three) and traced by ONE trace2 call, as run_paths does: on a BVH scene one post + one
+                // run of the wave's queue with twice the rays in flight instead of two runs to completion (round 4: config 5's interior adjoint 51.5 -> 45.5 ms, C3's 2.2 -> 2.1 ms)
+                // (DirectIntegrator(1) neither draws nor uses the emitter sample, DirectIntegrator(0) stops after it: direct.cpp:34-132)
+                const float sn1 = P.mis != 1 ? rng.next_1d() : 0.f, sn2 = P.mis != 1 ? rng.next_1d() : 0.f;
+                const bool do_nee = P.mis != 1 && mesh_emitter(S, its.mesh) < 0;
+                PositionSample<false> ps;
+                ps.p = Vec3f(0.f); ps.n = Vec3f(0.f); ps.J = 1.f; ps.pdf = 1.f; ps.slot = -1; ps.ba = ps.bb = 0.f;
+                Vec3f wod(0.f);
+                float dist_sqr = 0.f, dist = 0.f;
+                if (do_nee) {
+                    ps = sample_emitter_position<false, LDS>(S, its.p, sn1, sn2);
+                    wod = ps.p - its.p;
+                    dist_sqr = squared_norm(wod); dist = safe_sqrt(dist_sqr);
+                    wod = wod / dist;
+                }
+                const bool do_bsdf = P.mis != 0;
+                const float sb0 = do_bsdf ? rng.next_1d() : 0.f, sb1 = do_bsdf ? rng.next_1d() : 0.f, sb2 = do_bsdf ? rng.next_1d() : 0.f;
+                BSDFSample bs = bsdf_sample<false, LDS>(S, its, sb0, sb1, sb2, do_bsdf);
+                if (!do_bsdf) bs.valid = false;
+                RayT<false> curr; curr.o = its.p; curr.d = to_world<false>(its, bs.wo);
+                Hit h1, hx;
+                trace2<LDS, false>(S, its.p, wod, do_nee, curr.o, curr.d, bs.valid, h1, hx, do_nee ? (dist - kShadowEpsilon) * 0.9999f : -__builtin_inff());     // (any occluder settles the shadow test)
+                if (do_nee && h1.slot >= 0) {   // next-event estimation
+                    RayT<false> ray1; ray1.o = its.p; ray1.d = wod;
+                    const Its<false> its1 = make_its<false, LDS, false>(S, h1, ray1, true);
+                    const int eh = mesh_emitter(S, its1.mesh);
+                    if (its1.t > dist - kShadowEpsilon && eh >= 0) {
+                        const float G = fabsf(dot(its1.n, -wod)) / dist_sqr;
+                        const float woz = dot(wod, its.fn) * sgn;
+                        const float pdf1 = ((front && woz > 0.f) ? kInvPi * woz : 0.f) * G;
+                        if (front && woz > 0.f && pdf1 != 0.f) {
+                            const float cN = kInvPi * (P.mis == 0 ? 1.f : mis_weight(ps.pdf, pdf1)) / ps.pdf;
+                            if (eh == env_id) {
+                                // the sample lies on the scene box (a fixed point: the record keeps it instead of a triangle),
+                                // the radiance is looked up along the shadow ray
+                                Lsum = Lsum + thr * rho * env_radiance(env_dir_at(h1.slot, h1.u, h1.v, its.p)) * (woz * G * cN);
+                                br[0] = h1.u; br[kBlock] = h1.v; br[2 * kBlock] = 0.f; br[3 * kBlock] = __int_as_float(h1.slot);
+                                br[4 * kBlock] = cN;
+                                flags |= 1 | 16;
+                            } else if (its1.wi.z > 0.f) {
+                                const float4 ea = S.ld(T.emit_off + 2 * eh);
+                                Lsum = Lsum + thr * rho * Vec3f(ea.x, ea.y, ea.z) * (woz * G * cN);
+                                br[0] = __int_as_float(ps.slot); br[kBlock] = ps.ba; br[2 * kBlock] = ps.bb; br[3 * kBlock] = __int_as_float(h1.slot);
+                                br[4 * kBlock] = cN;
+                                flags |= 1;
                             }
                         }
                     }
                 }
-                {   // BSDF sampling (path.cpp:86-123)
-                    // (DirectIntegrator(0) stops after the emitter sample: no BSDF draw)
-                    const bool do_bsdf = P.mis != 0;
-                    const float s0 = do_bsdf ? rng.next_1d() : 0.f, s1 = do_bsdf ? rng.next_1d() : 0.f, s2 = do_bsdf ? rng.next_1d() : 0.f;
-                    BSDFSample bs = bsdf_sample<false, LDS>(S, its, s0, s1, s2, do_bsdf);
-                    if (!do_bsdf) bs.valid = false;
-                    Hit hx; hx.slot = -1;
-                    RayT<false> curr; curr.o = its.p; curr.d = to_world<false>(its, bs.wo);
-                    if (bs.valid) hx = trace<LDS, false>(S, curr.o, curr.d);
+                {   // BSDF sampling
                     active = bs.valid && hx.slot >= 0;
                     if (active) {
                         const Its<false> itx = make_its<false, LDS, true>(S, hx, curr, true);

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kBlock, (ADJ ? PSDR_SEC_ADJ_WAVES : PSDR_SEC_WAVES)
                             if (val.y != 0.f && finite_(val.y)) atomicAdd(&tab[row + 1], val.y);
                             if (val.z != 0.f && finite_(val.z)) atomicAdd(&tab[row + 2], val.z);
                         };
-                        // triangle rows: hot ones per workgroup in LDS (config 5: 93 -> ... ms; 51 of the 93 were the scatter, most of it the 108 floats of the scene box)
+                        // triangle rows: hot ones per workgroup in LDS (config 5: 93 -> 42 ms; 51 of the 93 were the scatter, most of it the 108 floats of the scene box)
                         float *hot_acc = scratch_base<LDS>(smem, T) + kSecAdjScratch;
                         auto add_tri = [&](int orig, int comp, const Vec3f &val) {
                             const int hot = (!P.lds_acc && P.n_hot > 0) ? P.hot_map[orig] : -1;

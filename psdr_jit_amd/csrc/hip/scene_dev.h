@@ -319,17 +319,17 @@ PSDR_DEV Hit trace_scene(SceneView<LDS> &S, const Vec3f &o, const Vec3f &d, floa
 // which fails every comparison.  BVH scenes and the record/replay modes trace the rays one after the other.
 template <int LDS, bool COUNT>
 PSDR_DEV void trace2(SceneView<LDS> &S, const Vec3f &oA_, const Vec3f &dA, bool actA, const Vec3f &oB_, const Vec3f &dB, bool actB,
-                     Hit &hA, Hit &hB) {
+                     Hit &hA, Hit &hB, float anyhit_a = -__builtin_inff()) {        // anyhit_a: ray A may stop at a hit closer than this (BVH scenes only; trace())
 #pragma clang fp contract(off)
     hA.slot = -1; hA.u = hA.v = hA.t = 0.f;
     hB.slot = -1; hB.u = hB.v = hB.t = 0.f;
     const SceneTables &T = *S.T;
     if (S.mode != 0) {
-        if (actA) hA = trace<LDS, COUNT>(S, oA_, dA);
+        if (actA) hA = trace<LDS, COUNT>(S, oA_, dA, anyhit_a);
         if (actB) hB = trace<LDS, COUNT>(S, oB_, dB);
         return;
     }
-    if constexpr (!in_lds(LDS)) { if (T.n_tris > kBruteForceMax) { bvh4_trace2<LDS, COUNT>(S, oA_, dA, actA, oB_, dB, actB, hA, hB); return; } }
+    if constexpr (!in_lds(LDS)) { if (T.n_tris > kBruteForceMax) { bvh4_trace2<LDS, COUNT>(S, oA_, dA, actA, oB_, dB, actB, hA, hB, anyhit_a); return; } }
     const float qnan = __builtin_nanf("");
     const Vec3f oA = actA ? oA_ : Vec3f(qnan), oB = actB ? oB_ : Vec3f(qnan);
 #if PSDR_DIAG != 6 && PSDR_DIAG != 7 && PSDR_DIAG != 9
