@@ -564,15 +564,29 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                 br[8 * kBlock] = thr.x; br[9 * kBlock] = thr.y; br[10 * kBlock] = thr.z;
                 nb = depth + 1;
                 int flags = 0;              // 1 next-event term, 2 BSDF term, 8 the next vertex is a visible emitter, 16 the light sample is on the environment map
+                // the vertex's two rays are drawn first (sampler order of the forward pass: two numbers, then three) and traced by ONE trace2 call (adjoint.h, round 4)
+                // (DirectIntegrator(1) neither draws nor uses the emitter sample, DirectIntegrator(0) stops after it: direct.cpp:34-132)
+                const float sn1 = P.mis != 1 ? rng.next_1d() : 0.f, sn2 = P.mis != 1 ? rng.next_1d() : 0.f;
+                const bool do_nee = P.mis != 1 && mesh_emitter(S, its.mesh) < 0;
+                PositionSample<false> ps;
+                ps.p = Vec3f(0.f); ps.n = Vec3f(0.f); ps.J = 1.f; ps.pdf = 1.f; ps.slot = -1; ps.ba = ps.bb = 0.f;
+                Vec3f wod(0.f);
+                float dist_sqr = 0.f, dist = 0.f;
+                if (do_nee) {
+                    ps = sample_emitter_position<false, LDS>(S, its.p, sn1, sn2);
+                    wod = ps.p - its.p;
+                    dist_sqr = squared_norm(wod); dist = safe_sqrt(dist_sqr);
+                    wod = wod / dist;
+                }
+                const bool do_bsdf = P.mis != 0;
+                const float sb0 = do_bsdf ? rng.next_1d() : 0.f, sb1 = do_bsdf ? rng.next_1d() : 0.f, sb2 = do_bsdf ? rng.next_1d() : 0.f;
+                BSDFSample bs = bsdf_sample<false, LDS>(S, its, sb0, sb1, sb2, do_bsdf);
+                if (!do_bsdf) bs.valid = false;
+                RayT<false> curr; curr.o = its.p; curr.d = to_world<false>(its, bs.wo);
+                Hit h1, hx;
+                trace2<LDS, false>(S, its.p, wod, do_nee, curr.o, curr.d, bs.valid, h1, hx, do_nee ? (dist - kShadowEpsilon) * 0.9999f : -__builtin_inff());     // (any occluder settles the shadow test)
                 {   // next-event estimation (path.cpp:47-83): L += thr . F(wi, w) . Le . g cN, g = |nz.w| / r^2 . A / detach(A), cN = mis / pdf
-                    // (DirectIntegrator(1) neither draws nor uses the emitter sample, direct.cpp:34-132)
-                    const float s1 = P.mis != 1 ? rng.next_1d() : 0.f, s2 = P.mis != 1 ? rng.next_1d() : 0.f;
-                    if (P.mis != 1 && mesh_emitter(S, its.mesh) < 0) {
-                        const PositionSample<false> ps = sample_emitter_position<false, LDS>(S, its.p, s1, s2);
-                        Vec3f wod = ps.p - its.p;
-                        const float dist_sqr = squared_norm(wod), dist = safe_sqrt(dist_sqr);
-                        wod = wod / dist;
-                        const Hit h1 = trace<LDS, false>(S, its.p, wod, (dist - kShadowEpsilon) * 0.9999f);     // (any occluder settles the shadow test)
+                    if (do_nee) {
                         if (h1.slot >= 0) {
                             RayT<false> ray1; ray1.o = its.p; ray1.d = wod;
                             const Its<false> its1 = make_its<false, LDS, false>(S, h1, ray1, true);
@@ -601,14 +615,6 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                     }
                 }
                 {   // BSDF sampling (path.cpp:86-123): thr' = thr . F(wi, w) . g cf, cf = 1 / pdf0
-                    // (DirectIntegrator(0) stops after the emitter sample: no BSDF draw)
-                    const bool do_bsdf = P.mis != 0;
-                    const float s0 = do_bsdf ? rng.next_1d() : 0.f, s1 = do_bsdf ? rng.next_1d() : 0.f, s2 = do_bsdf ? rng.next_1d() : 0.f;
-                    BSDFSample bs = bsdf_sample<false, LDS>(S, its, s0, s1, s2, do_bsdf);
-                    if (!do_bsdf) bs.valid = false;
-                    Hit hx; hx.slot = -1;
-                    RayT<false> curr; curr.o = its.p; curr.d = to_world<false>(its, bs.wo);
-                    if (bs.valid) hx = trace<LDS, false>(S, curr.o, curr.d);
                     active = bs.valid && hx.slot >= 0;
                     if (active) {
                         const Its<false> itx = make_its<false, LDS, true>(S, hx, curr, true);
