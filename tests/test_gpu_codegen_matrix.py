@@ -28,8 +28,9 @@ VARIANTS = {
     "m_break_dump": ["-DPSDR_CLS_MASK=4", "-DPSDR_STEAL_BREAK=2", "-DPSDR_SWEEP_DUMP=3"],   # the diagnostic build that kept the defect visible
     "m_waves2": ["-DPSDR_CLS_MASK=4", "-DPSDR_ADJ_WAVES=2"],                        # 128 registers per lane less: another allocation altogether
     "m_o2": ["-DPSDR_CLS_MASK=4", "-O2"],
-    "m_nosteal": ["-DPSDR_CLS_MASK=4", "-DPSDR_STEAL=0"],                           # at this commit's sources the unit that shows the pattern again (an AGPR spill store in front
-                                                                                    # of an exec restore): the build recipe compiles it a second time (lint.txt of the variant says so)
+    "m_nosteal": ["-DPSDR_CLS_MASK=4", "-DPSDR_STEAL=0"],                           # showed the pattern at the commit that closed the item (an AGPR spill store in front of an exec
+                                                                                    # restore; profiles/r04_sweep_defect_evidence.txt section 6) - which build shows it moves with every
+                                                                                    # edit of the kernels; a variant's obj/lint.txt says whether the recipe compiled a unit twice
 }
 
 

@@ -82,3 +82,36 @@ def test_shipped_library_is_clean():
     from psdr_jit_amd import build
     findings = isa_lint.lint(build.HIP_LIB)
     assert not findings, "\n".join("%s +0x%x: %s" % (n, o, "; ".join(s[:4])) for n, o, s in findings)
+
+
+def test_build_recipe_compiles_a_flagged_unit_again_and_fails_if_that_does_not_help(tmp_path, monkeypatch):
+    """build.py::_lint_units - a unit the lint flags is compiled a second time with the scalar allocator that does not split live ranges; still flagged = build failure"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_psdr_build_t", os.path.join(ROOT, "psdr_jit_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    calls, verdicts = [], {}
+
+    class FakeLint:
+        @staticmethod
+        def available():
+            return True
+
+        @staticmethod
+        def lint(obj):
+            return verdicts[os.path.basename(obj)].pop(0)
+
+    monkeypatch.setattr(b, "_load_lint", lambda: FakeLint)
+    monkeypatch.setattr(b, "_run", lambda cmd: calls.append(cmd) or "")
+    monkeypatch.delenv("PSDR_BUILD_NO_LINT", raising=False)
+    finding = [("k_interior_adjoint<2>", 0x133c0, ["v_mov_b32_e32 v110, 0x40490fdb"])]
+    units = [("main", ["-DPSDR_SPLIT"]), ("tu4", ["-DPSDR_TU=4"])]
+    verdicts.update({"api_main.o": [[]], "api_tu4.o": [finding, []]})
+    b._lint_units("hipcc", ["--offload-arch=gfx950", "-O3"], units, str(tmp_path))
+    assert len(calls) == 1 and "-DPSDR_TU=4" in calls[0] and calls[0][-1].endswith("api_tu4.o")
+    assert all(f in calls[0] for f in b.LINT_FALLBACK_FLAGS) and "-sgpr-regalloc=basic" in " ".join(b.LINT_FALLBACK_FLAGS)
+    report = open(os.path.join(str(tmp_path), "lint.txt")).read()
+    assert "main: clean" in report and "tu4: 1 join block" in report
+    verdicts.update({"api_main.o": [[]], "api_tu4.o": [finding, finding]})
+    with pytest.raises(RuntimeError, match="still has vector instructions ahead of an exec restore"):
+        b._lint_units("hipcc", ["--offload-arch=gfx950", "-O3"], units, str(tmp_path))
