@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PSDR_HIP_ABI_VERSION 11
+#define PSDR_HIP_ABI_VERSION 12
 
 /* TriangleInfo SoA, reference include/psdr/types.h:162-175 (+ Scene::m_triangle_uv,
  * m_triangle_face_normals, scene.cpp:528-542).  Arrays of n_triangles rows. */
@@ -91,8 +91,7 @@ typedef struct psdr_bsdf_rec {       /* Diffuse, reference src/bsdf/diffuse.cpp 
     /* uv transform of the three bitmap slots above (0 tex_data, 1 spec_tex_data, 2 rough_tex_data): Bitmap::m_rot, m_scale,
      * m_trans.x, m_trans.y (include/psdr/core/bitmap.h:37-39, applied by src/core/bitmap.cpp:64-86; the reference binds them as
      * rotate / scale / translate, src/psdr.cpp:204-206, 217-219) and their forward tangents.  Identity = {0, 1, 0, 0}.
-     * Reverse mode: the adjoint of a transform component is <adj_image, d_image> of one psdr_hip_render_d_fwd launch with
-     * that component's tangent set to one (four scalars per bitmap: forward mode is the cheap direction). */
+     * Reverse mode: psdr_grads.g_uv_xf (ABI 12; until then four psdr_hip_render_d_fwd launches per bitmap). */
     float tex_xf[3][4], d_tex_xf[3][4];
 } psdr_bsdf_rec;
 
@@ -293,6 +292,13 @@ typedef struct psdr_grads {
     float *g_mat;
     /* adjoint of the environment map's from_world (DEVICE [16], row major; the 3x3 block that maps world directions), or NULL */
     float *g_env_from_world;
+    /* adjoints of the bitmaps' uv transforms (psdr_bsdf_rec.tex_xf, psdr_emitter_rec's radiance transform): DEVICE
+     * [(3*n_bsdfs + 1)*4], row 3*b + k = [rotate, scale, translate.x, translate.y] of bitmap k of BSDF b, last row = the environment
+     * map's; or NULL = not wanted.  Every lookup of the interior term adds its share in the same pass that fills g_tex / g_env:
+     * give g_tex beside it for the rows of BSDF bitmaps and g_env for the environment map's row (the record-and-probe form visits a
+     * lookup only for a buffer that is wanted).  The edge terms do not see the transforms (their values are
+     * detached, src/integrator/integrator.cpp:179-198, path.cpp:171-270). */
+    float *g_uv_xf;
 } psdr_grads;
 /* offsets[3*n_bsdfs] (HOST): float offset of the texel block of BSDF b's bitmap k (0 reflectance / diffuse reflectance rgb,
  * 1 specular reflectance rgb, 2 roughness; RoughConductor: eta, k, alpha; NormalMap: the map; MicrofacetPerVertex: the per-vertex

@@ -1051,8 +1051,11 @@ class _RenderDFn(_torch.autograd.Function):
         mesh_filter = _torch.from_numpy(want_mesh).to(dev)
         # bitmap parameters (a leaf of 2 or 3 dimensions on a BSDF) and per-vertex values: their adjoints come back in one flat buffer
         tex_leaves = [i for i, ((obj, name, t), need) in enumerate(zip(leaves, needs)) if need and isinstance(obj, _core.BSDF) and (t.dim() >= 2 or isinstance(obj, MicrofacetBSDFPerVertex))]
+        # rotate / scale / translate of a bitmap: four scalars per bitmap, filled by the same pass (psdr_grads.g_uv_xf beside g_tex / g_env)
+        uv_leaves = [i for i, ((obj, name, t), need) in enumerate(zip(leaves, needs)) if need and name.endswith(_UV_SUFFIX)]
+        g_uv = _torch.zeros(4 * (3 * (nb + n_hidden) + 1), dtype=_torch.float32, device=dev) if uv_leaves else None
         g_tex = None
-        if tex_leaves:
+        if tex_leaves or any(isinstance(leaves[i][0], _core.BSDF) for i in uv_leaves):
             tex_off, tex_total = _core._tex_layout(scene)
             g_tex = _torch.zeros(max(1, int(tex_total)), dtype=_torch.float32, device=dev)
         g_cam = _torch.zeros(16, dtype=_torch.float32, device=dev) if want_cam else None
@@ -1074,6 +1077,8 @@ class _RenderDFn(_torch.autograd.Function):
                 g_env_scale = _torch.zeros(1, dtype=_torch.float32, device=dev)
             else:               # to_world_left: through the adjoint of from_world = (to_world_left . to_world_raw)^-1
                 g_env_xf = _torch.zeros(16, dtype=_torch.float32, device=dev)
+        if g_env is None and any(isinstance(leaves[i][0], EnvironmentMap) for i in uv_leaves):
+            g_env = _torch.zeros(int(_np.prod(leaves[uv_leaves[0]][0]._get("radiance", False).shape)), dtype=_torch.float32, device=dev)
         if g_env_scale is not None and g_env is None:        # the scale adjoint is assembled from the texel probes
             g_env = _torch.zeros(int(_np.prod(leaves[env_leaves[0]][0]._get("radiance", False).shape)), dtype=_torch.float32, device=dev)
         _core._render_d_bwd(integ, scene, st["sensor_id"], seeds, skips, g_img.data_ptr(), ptr[0], ptr[1], ptr[2], ptr[3], ptr[4],
@@ -1081,9 +1086,10 @@ class _RenderDFn(_torch.autograd.Function):
                             g_tex.data_ptr() if g_tex is not None else 0, g_cam.data_ptr() if g_cam is not None else 0,
                             g_env.data_ptr() if g_env is not None else 0, g_env_scale.data_ptr() if g_env_scale is not None else 0,
                             g_mat.data_ptr() if g_mat is not None else 0, g_env_xf.data_ptr() if g_env_xf is not None else 0,
-                            bpix.data_ptr() if bpix is not None else 0, int(bpix.numel()) if bpix is not None else 0)
+                            bpix.data_ptr() if bpix is not None else 0, int(bpix.numel()) if bpix is not None else 0,
+                            g_uv.data_ptr() if g_uv is not None else 0)
         _all_reduce(flat, world > 1)
-        for extra in (g_env, g_env_scale, g_mat, g_env_xf):
+        for extra in (g_env, g_env_scale, g_mat, g_env_xf, g_uv):
             if extra is not None:
                 _all_reduce(extra, world > 1)
         if g_cam is not None:
@@ -1159,21 +1165,10 @@ class _RenderDFn(_torch.autograd.Function):
                     fw = _torch.linalg.inv(L @ raw)
                     (gl,) = _torch.autograd.grad(fw, L, g_env_xf.to("cpu", _torch.float64).reshape(4, 4))
                 grads[i] = gl.reshape(t.shape).to(t.device, t.dtype)
-        # rotate / scale / translate of a bitmap: four scalars per bitmap, taken in FORWARD mode - one replay of the recorded render per
-        # component with its unit tangent, dotted with the adjoint image (include/psdr_hip.h, psdr_bsdf_rec.tex_xf)
-        uv_leaves = [i for i, ((obj, name, t), need) in enumerate(zip(leaves, needs)) if need and name.endswith(_UV_SUFFIX)]
-        if uv_leaves:
-            for i in uv_leaves:
-                t = leaves[i][2]
-                g = _torch.zeros(4, dtype=_torch.float64)
-                for j in range(4):
-                    e = _np.zeros(4, _np.float32)
-                    e[j] = 1.0
-                    dimg = _replay_forward(integ, scene, st, {id(t): e})
-                    g[j] = (g_img.to(_torch.float64) * dimg.to(g_img.device, _torch.float64).reshape(g_img.shape)).sum().item()
-                grads[i] = g.reshape(t.shape).to(t.device, t.dtype)
-            _sync_params(scene, None, integ)
-            scene._configure(st["active"])
+        for i in uv_leaves:           # [rotate, scale, translate.x, translate.y]: the bitmap's row of g_uv_xf (the last row is the environment map's)
+            obj, name, t = leaves[i]
+            row = 3 * (nb + n_hidden) if isinstance(obj, EnvironmentMap) else 3 * _bsdf_index(scene, obj) + _UV_SLOT[name[:-len(_UV_SUFFIX)]]
+            grads[i] = g_uv[4 * row:4 * row + 4].reshape(t.shape).to(t.device, t.dtype)
         return (None,) + tuple(grads)
 
 

@@ -28,7 +28,7 @@ class RenderArgs(C.Structure):
 class Grads(C.Structure):
     _fields_ = [("g_triangles", C.c_void_p), ("g_bsdf", C.c_void_p), ("g_emitter", C.c_void_p), ("g_sec_edges", C.c_void_p),
                 ("g_prim_edges", C.c_void_p), ("mesh_filter", C.c_void_p), ("skip_bsdf", C.c_int32), ("skip_emitter", C.c_int32),
-                ("g_tex", C.c_void_p), ("g_camera", C.c_void_p), ("g_env", C.c_void_p), ("g_env_scale", C.c_void_p), ("g_mat", C.c_void_p), ("g_env_from_world", C.c_void_p)]
+                ("g_tex", C.c_void_p), ("g_camera", C.c_void_p), ("g_env", C.c_void_p), ("g_env_scale", C.c_void_p), ("g_mat", C.c_void_p), ("g_env_from_world", C.c_void_p), ("g_uv_xf", C.c_void_p)]
 
 
 class Counters(C.Structure):

@@ -57,6 +57,7 @@ struct AdjointParams {
     float *g_cam;                   // [16] adjoint of the sensor's to_world (row major, rows 0-2 filled), or NULL
     float *g_env, *g_env_scale;     // texel adjoints [H*W*3] and scale adjoint [1] of the environment map, or NULL
     float *g_env_xf;                // [16] adjoint of the environment map's from_world (rows 0-2, columns 0-2 filled), or NULL
+    float *g_uv_xf;                 // [(3 * n_bsdfs + 1) * 4] adjoints of the bitmaps' uv transforms (psdr_grads.g_uv_xf), or NULL
     int hit_words, ext_words, lk_words;   // sizes of the three per-lane records (lk_words = 0 when the scene cannot make lookups)
     float *g_mat;                   // [n_bsdfs*16] adjoints of the constant parameters of the GGX BSDFs (psdr_grads.g_mat), or NULL
     int sweep;                      // 1: run_interior_adjoint_sweep (Diffuse BSDFs + area lights), 0: record and probe
@@ -65,7 +66,8 @@ struct AdjointParams {
                                     //   (paths too deep for 160 KB of LDS: any depth works, at global-memory latency)
 };
 
-constexpr int kMatRow = 16;
+constexpr int kMatOut = 16;         // a BSDF's row of psdr_grads.g_mat
+constexpr int kMatRow = 28;         // ... and of its LDS accumulator: the g_mat row, then [rot, scale, tx, ty] of its three bitmaps (g_uv_xf)
 constexpr int kAdjMisc = 32;        // LDS accumulators every path adds to: camera pose, environment scale and transform
 // number of constant material parameters a BSDF record's flags announce (Microfacet 4 - fewer with maps -, RoughConductor 11, RoughDielectric 3)
 PSDR_DEV int mat_param_count(int fl) { return (fl & 4) ? 4 : ((fl & 8) ? 11 : ((fl & 16) ? 3 : 0)); }
@@ -94,7 +96,7 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
     const bool use_lds = true;                                         // colours and emitters always accumulate in LDS
     for (int i = threadIdx.x; i < n_acc; i += kBlock) acc[i] = 0.f;
     float *acc_bsdf = acc + P.n_hot * 22, *acc_emit = acc_bsdf + T.n_bsdfs * 3;
-    if (threadIdx.x < kAdjMisc) acc_cam[threadIdx.x] = 0.f;    // [0..11] camera pose, [12] environment-map scale, [16..31] environment from_world
+    if (threadIdx.x < kAdjMisc) acc_cam[threadIdx.x] = 0.f;    // [0..11] camera pose, [12] environment-map scale, [16..26] environment from_world, [28..31] the map's uv transform
     for (int i = threadIdx.x; i < T.n_bsdfs * kMatRow; i += kBlock) acc_mat[i] = 0.f;
     __syncthreads();
     S.rec = rec; S.ext = ext; S.lk = lk; S.ext_max = P.ext_words; S.lk_max = P.lk_words / 3;
@@ -316,6 +318,7 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                                         rgb_c += wt[k] * E.radiance[3ll * idx[k] + st_comp];
                                     }
                                     if (P.g_env_scale != nullptr && E.scale != 0.f) atomicAdd(&acc_cam[12], gval * rgb_c / E.scale);
+                                    if (P.g_uv_xf != nullptr) { float ob[3] = {0.f, 0.f, 0.f}; ob[st_comp] = gval; env_xf_adjoint(E, S.probe_u, S.probe_v, ob, &acc_cam[28]); }
                                 }
                             } else if (!has_mat(LDS)) {
                             } else if (st_id <= kPvLookup) {
@@ -332,8 +335,14 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                                 const int tslot = st_comp < 3 ? 0 : (st_comp < 6 ? 1 : 2), ch = tslot == 2 ? 1 : 3, c = st_comp - 3 * tslot;
                                 const TexDev td = T.tex[3 * st_id + tslot];
                                 env::bitmap_footprint(td.w, td.h, S.probe_u, S.probe_v, true, idx, wt, env::UvXf<float>(td.xf));
-                                if (gval != 0.f && finite_(gval))
+                                if (gval != 0.f && finite_(gval)) {
                                     for (int k = 0; k < 4; ++k) atomicAdd(&P.g_tex[td.g_off + (long long) ch * idx[k] + c], gval * wt[k]);
+                                    if (P.g_uv_xf != nullptr) {
+                                        float ob[3] = {0.f, 0.f, 0.f}; ob[c] = gval;
+                                        if (ch == 3) tex_xf_adjoint<3>(td, S.probe_u, S.probe_v, ob, &acc_mat[st_id * kMatRow + kMatOut + 4 * tslot]);
+                                        else tex_xf_adjoint<1>(td, S.probe_u, S.probe_v, ob, &acc_mat[st_id * kMatRow + kMatOut + 4 * tslot]);
+                                    }
+                                }
                             }
                         }
                         ++st_comp;
@@ -352,7 +361,11 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
     if (P.g_env_scale != nullptr && threadIdx.x == 12 && acc_cam[12] != 0.f) atomicAdd(P.g_env_scale, acc_cam[12]);
     if (P.g_env_xf != nullptr && threadIdx.x >= 16 && threadIdx.x < 27 && acc_cam[threadIdx.x] != 0.f) atomicAdd(&P.g_env_xf[threadIdx.x - 16], acc_cam[threadIdx.x]);
     if (P.g_mat != nullptr)
-        for (int i = threadIdx.x; i < T.n_bsdfs * kMatRow; i += kBlock) if (acc_mat[i] != 0.f) atomicAdd(&P.g_mat[i], acc_mat[i]);
+        for (int i = threadIdx.x; i < T.n_bsdfs * kMatOut; i += kBlock) { const float v = acc_mat[(i / kMatOut) * kMatRow + i % kMatOut]; if (v != 0.f) atomicAdd(&P.g_mat[i], v); }
+    if (P.g_uv_xf != nullptr) {          // uv transforms: three bitmaps per BSDF, then the environment map's
+        for (int i = threadIdx.x; i < T.n_bsdfs * 12; i += kBlock) { const float v = acc_mat[(i / 12) * kMatRow + kMatOut + i % 12]; if (v != 0.f) atomicAdd(&P.g_uv_xf[i], v); }
+        if (threadIdx.x >= 28 && threadIdx.x < 32 && acc_cam[threadIdx.x] != 0.f) atomicAdd(&P.g_uv_xf[12 * T.n_bsdfs + threadIdx.x - 28], acc_cam[threadIdx.x]);
+    }
     if (use_lds) {
         __syncthreads();
         for (int i = threadIdx.x; i < P.n_hot * 22; i += kBlock) if (acc[i] != 0.f) atomicAdd(&P.g_tri[P.hot_inv[i / 22] * 22 + i % 22], acc[i]);
@@ -529,6 +542,7 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
                     }
             }
             if (P.g_env_scale != nullptr) { const float sb = lb[0] * rgb0[0] + lb[1] * rgb0[1] + lb[2] * rgb0[2]; if (sb != 0.f && finite_(sb)) atomicAdd(&acc_cam[12], sb); }
+            if (P.g_uv_xf != nullptr) { const float ob[3] = {lb[0] * E.scale, lb[1] * E.scale, lb[2] * E.scale}; env_xf_adjoint(E, uu, ww, ob, &acc_cam[28]); }
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 if (!finite_(vb[r])) vb[r] = 0.f;
@@ -910,6 +924,7 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
     if (P.g_cam != nullptr && threadIdx.x < 12 && acc_cam[threadIdx.x] != 0.f) atomicAdd(&P.g_cam[threadIdx.x], acc_cam[threadIdx.x]);
     if (P.g_env_scale != nullptr && threadIdx.x == 12 && acc_cam[12] != 0.f) atomicAdd(P.g_env_scale, acc_cam[12]);
     if (P.g_env_xf != nullptr && threadIdx.x >= 16 && threadIdx.x < 27 && acc_cam[threadIdx.x] != 0.f) atomicAdd(&P.g_env_xf[threadIdx.x - 16], acc_cam[threadIdx.x]);
+    if (P.g_uv_xf != nullptr && threadIdx.x >= 28 && threadIdx.x < 32 && acc_cam[threadIdx.x] != 0.f) atomicAdd(&P.g_uv_xf[12 * T.n_bsdfs + threadIdx.x - 28], acc_cam[threadIdx.x]);
     for (int i = threadIdx.x; i < P.n_hot * 22; i += kBlock) if (acc[i] != 0.f) atomicAdd(&P.g_tri[P.hot_inv[i / 22] * 22 + i % 22], acc[i]);
     for (int i = threadIdx.x; i < T.n_bsdfs * 3; i += kBlock) if (acc_bsdf[i] != 0.f) atomicAdd(&P.g_bsdf[i], acc_bsdf[i]);
     for (int i = threadIdx.x; i < T.n_emitters * 3; i += kBlock) if (acc_emit[i] != 0.f) atomicAdd(&P.g_emitter[i], acc_emit[i]);

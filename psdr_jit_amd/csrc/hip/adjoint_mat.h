@@ -79,6 +79,7 @@ PSDR_DEV Vec3f bsdf_plain_value_and_adjoint(const SceneView<LDS> &S, int bid, co
                 for (int c = 0; c < CH; ++c)
                     if (pb[c] != 0.f && finite_(pb[c])) for (int k = 0; k < 4; ++k) atomicAdd(&g_tex[td.g_off + (long long) CH * idx[k] + c], pb[c] * wt[k]);
             }
+            if (S.uv_adj && acc_mat != nullptr) tex_xf_adjoint<CH>(td, tu, tv, pb, &acc_mat[bid * kMatRow + kMatOut + 4 * slot]);
             if (uvb != nullptr) {
                 for (int ax = 0; ax < 2; ++ax) {
                     Dual o[CH];
@@ -342,6 +343,7 @@ PSDR_DEV Vec3f bsdf_value_and_adjoint(const SceneView<LDS> &S, int bid, const Ve
                     for (int ch = 0; ch < 3; ++ch)
                         if (inb[6 + ch] != 0.f) for (int k = 0; k < 4; ++k) atomicAdd(&g_tex[td.g_off + 3ll * idx[k] + ch], inb[6 + ch] * wt4[k]);
                 }
+                if (S.uv_adj && acc_mat != nullptr) tex_xf_adjoint<3>(td, tu, tv, &inb[6], &acc_mat[bid * kMatRow + kMatOut]);
                 if (uvb != nullptr) {
                     for (int ax = 0; ax < 2; ++ax) {
                         Dual o[3];
@@ -446,6 +448,7 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                     }
             }
             if (P.g_env_scale != nullptr) { const float sb = lb[0] * rgb0[0] + lb[1] * rgb0[1] + lb[2] * rgb0[2]; if (sb != 0.f && finite_(sb)) atomicAdd(&acc_cam[12], sb); }
+            if (P.g_uv_xf != nullptr) { const float ob[3] = {lb[0] * E.scale, lb[1] * E.scale, lb[2] * E.scale}; env_xf_adjoint(E, uu, ww, ob, &acc_cam[28]); }
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 if (!finite_(vb[r])) vb[r] = 0.f;
@@ -553,9 +556,19 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
             its.wi = to_local<false>(its, -ray.d);
             Vec3f thr(1.f), Lsum(0.f);
             const int e0 = mesh_emitter(S, its.mesh);
-            const bool le0 = !P.hide_emitters && e0 >= 0 && (e0 == env_id || its.wi.z > 0.f);
+            // the first-hit integrators (field.cpp:49-121, collocated.cpp:24-55): the sample's value is a function of this vertex alone
+            const bool fh = P.field >= 0, fh_bsdf = P.field == 6 || P.field >= 8;
+            bool fh_ok = false;
+            const bool le0 = !fh && !P.hide_emitters && e0 >= 0 && (e0 == env_id || its.wi.z > 0.f);
             const Vec3f dir0 = -to_world<false>(its, its.wi);          // (= ray.d through the frame of the first hit, as eval_Le rebuilds it)
             if (le0) { if (e0 == env_id) Lsum = env_radiance(dir0); else { const float4 a = S.ld(T.emit_off + 2 * e0); Lsum = Vec3f(a.x, a.y, a.z); } }
+            if (fh) {
+                if constexpr (has_mat(LDS)) {
+                    fh_ok = !(T.env_emitter >= 0 && P.field != 8) || mesh_bsdf(S, its.mesh) >= 0;
+                    if (P.field_object >= 0) fh_ok = fh_ok && its.mesh == P.field_object;
+                    Lsum = first_hit_value<false, LDS>(S, its);
+                }
+            }
             int nb = 0;                                                   // bounces recorded
             bool active = true;
             auto nonzero = [](const Vec3f &v) { return v.x != 0.f || v.y != 0.f || v.z != 0.f; };
@@ -648,7 +661,7 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
             const Vec3f W(wgt[0], wgt[1], wgt[2]);
 
             // ------------------------------------------------------------ pass 2: back over the bounces
-            if (W.x != 0.f || W.y != 0.f || W.z != 0.f) {
+            if ((W.x != 0.f || W.y != 0.f || W.z != 0.f) && (!fh || fh_ok)) {
                 Vec3f cam_dirb(0.f);                    // adjoint of the camera ray's direction from an environment lookup along it
                 if (le0 && e0 == env_id) cam_dirb = env_adjoint(dir0, W, true);
                 else if (le0 && !P.skip_emitter) add_rgb(acc_emit, e0, W);          // the emitter seen by the camera
@@ -658,10 +671,12 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                 Vec3f xb0(0.f), nsb0(0.f);             // the camera hit's totals
                 Vec3f dcam_b(0.f);                     // adjoint of the camera ray's direction as the incident direction of bounce 0
                 float ub_tex = 0.f, vb_tex = 0.f;      // adjoints of the camera hit's barycentrics through its texture coordinates
-                for (int k = nb - 1; k >= 0; --k) {
+                float tb_field = 0.f;                  // adjoint of the camera hit's distance as a first-hit integrator's own argument
+                // (a first-hit integrator has no bounces: its BSDF forms run the vertex part of iteration 0, the others only the camera-hit block)
+                for (int k = fh ? (fh_bsdf ? 0 : -1) : nb - 1; k >= 0; --k) {
                     const float *br = brec + 11 * k * kBlock;
-                    const int flags = __float_as_int(br[7 * kBlock]);
-                    const Vec3f thr_k(br[8 * kBlock], br[9 * kBlock], br[10 * kBlock]);
+                    const int flags = fh ? 0 : __float_as_int(br[7 * kBlock]);
+                    const Vec3f thr_k = fh ? Vec3f(1.f) : Vec3f(br[8 * kBlock], br[9 * kBlock], br[10 * kBlock]);
                     const float *vr = vrec + 3 * k * kBlock;
                     VtxGeom gk = load_vertex(S, __float_as_int(vr[0]), vr[kBlock], vr[2 * kBlock]);
                     if (k == 0) gk.x = x0;
@@ -798,6 +813,16 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                             emit_glued(gh, Vec3f(0.f), Vec3f(0.f), gg.dnz * gb, 0.f);                // the normal of the triangle the shadow ray hit
                         }
                     }
+                    if (fh && fh_bsdf && bid >= 0) {
+                        // field 6: F(wi, wi); CollocatedIntegrator: F(wi, wi) . intensity / t^2 - both directions are the camera ray's
+                        float scale = 1.f;
+                        if (P.field >= 8) {
+                            const Vec3f wf = W * bsdf_primal(wi_w);
+                            scale = P.intensity / sqr(t0);
+                            tb_field = -2.f * (wf.x + wf.y + wf.z) * scale / t0;
+                        }
+                        dcam_b = dcam_b - bsdf_back(wi_w, W * scale);
+                    }
                     // the tangents are functions of ns and, with a uv parameterisation, of the triangle's edges: J^T (fsb, ftb) by forward
                     // evaluations of vertex_frame with unit tangents
                     Vec3f e1b_f(0.f), e2b_f(0.f);
@@ -835,10 +860,22 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                     if (k == 0) { xb0 = xb + pb_b; nsb0 = nsb; ub_tex = uvb[0] * du0x + uvb[1] * du0y + bcb[0]; vb_tex = uvb[0] * du1x + uvb[1] * du1y + bcb[1]; }
                 }
                 // the camera hit: x_0 = o + t d and ns_0 = normalize(blend(u, v)) with (u, v, t) = Moeller-Trumbore(p0, e1, e2; o, d)
-                if (nb > 0 || le0) {
+                if (nb > 0 || le0 || fh) {
                     const VtxGeom g0 = load_vertex(S, slot0, u0, v0);
+                    if (fh) {
+                        // field.cpp:60-106: 1 position, 2 depth (three equal channels), 3 geometric normal, 4 shading normal, 5 texture coordinates
+                        if (P.field == 1) xb0 = xb0 + W;
+                        else if (P.field == 2) tb_field = W.x + W.y + W.z;
+                        else if (P.field == 3) { if (wanted(g0)) add_vec(g0, 18, W); }
+                        else if (P.field == 4) nsb0 = nsb0 + W;
+                        else if (P.field == 5) {
+                            const float4 s4 = S.ld(T.shade_off + 6 * slot0 + 4), s5 = S.ld(T.shade_off + 6 * slot0 + 5);
+                            ub_tex += W.x * (s4.z - s4.x) + W.y * (s4.w - s4.y);
+                            vb_tex += W.x * (s5.x - s4.x) + W.y * (s5.y - s4.y);
+                        }
+                    }
                     float ub = ub_tex, vb = vb_tex;
-                    const float tb = dot(ray.d, xb0);
+                    const float tb = dot(ray.d, xb0) + tb_field;
                     Vec3f ob = xb0, db = xb0 * t0 + dcam_b;
                     const bool want0 = wanted(g0);
                     if (g0.flat) { if (want0) add_vec(g0, 18, nsb0); }
@@ -907,7 +944,11 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
     for (int i = threadIdx.x; i < P.n_hot * 22; i += kBlock) if (acc[i] != 0.f) atomicAdd(&P.g_tri[P.hot_inv[i / 22] * 22 + i % 22], acc[i]);
     for (int i = threadIdx.x; i < T.n_bsdfs * 3; i += kBlock) if (acc_bsdf[i] != 0.f) atomicAdd(&P.g_bsdf[i], acc_bsdf[i]);
     if (P.g_mat != nullptr)
-        for (int i = threadIdx.x; i < T.n_bsdfs * kMatRow; i += kBlock) if (acc_mat[i] != 0.f) atomicAdd(&P.g_mat[i], acc_mat[i]);
+        for (int i = threadIdx.x; i < T.n_bsdfs * kMatOut; i += kBlock) { const float v = acc_mat[(i / kMatOut) * kMatRow + i % kMatOut]; if (v != 0.f) atomicAdd(&P.g_mat[i], v); }
+    if (P.g_uv_xf != nullptr) {          // uv transforms: three bitmaps per BSDF, then the environment map's
+        for (int i = threadIdx.x; i < T.n_bsdfs * 12; i += kBlock) { const float v = acc_mat[(i / 12) * kMatRow + kMatOut + i % 12]; if (v != 0.f) atomicAdd(&P.g_uv_xf[i], v); }
+        if (threadIdx.x >= 28 && threadIdx.x < 32 && acc_cam[threadIdx.x] != 0.f) atomicAdd(&P.g_uv_xf[12 * T.n_bsdfs + threadIdx.x - 28], acc_cam[threadIdx.x]);
+    }
     for (int i = threadIdx.x; i < T.n_emitters * 3; i += kBlock) if (acc_emit[i] != 0.f) atomicAdd(&P.g_emitter[i], acc_emit[i]);
     for (int i = threadIdx.x; i < P.env_lds; i += kBlock) if (acc_env[i] != 0.f) atomicAdd(&P.g_env[i], acc_env[i]);
 }

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kBlock) void k_interior_adjoint_mat(const float4 *_
                                                                  const AdjointParams P) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     SceneView<LDS> S = make_view<LDS>(blob, T, smem);
-    S.mis = P.mis; S.field = P.field; S.field_object = P.field_object; S.intensity = P.intensity; S.d_intensity = P.d_intensity;
+    S.mis = P.mis; S.field = P.field; S.field_object = P.field_object; S.intensity = P.intensity; S.d_intensity = P.d_intensity; S.uv_adj = P.g_uv_xf != nullptr;
     run_interior_adjoint_sweep_mat<LDS>(S, cam, P, scratch_base<LDS>(smem, T));
 }
 
@@ -1322,7 +1322,8 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         if (g->g_env && T.env_emitter >= 0) HIPCHK(hipMemsetAsync(g->g_env, 0, sizeof(float) * 3 * (size_t) T.env.width * T.env.height, st));
         if (g->g_env_scale) HIPCHK(hipMemsetAsync(g->g_env_scale, 0, sizeof(float), st));
         if (g->g_env_from_world) HIPCHK(hipMemsetAsync(g->g_env_from_world, 0, sizeof(float) * 16, st));
-        if (g->g_mat) HIPCHK(hipMemsetAsync(g->g_mat, 0, sizeof(float) * kMatRow * (size_t) std::max(1, T.n_bsdfs), st));
+        if (g->g_mat) HIPCHK(hipMemsetAsync(g->g_mat, 0, sizeof(float) * kMatOut * (size_t) std::max(1, T.n_bsdfs), st));
+        if (g->g_uv_xf) HIPCHK(hipMemsetAsync(g->g_uv_xf, 0, sizeof(float) * 4 * (3 * (size_t) T.n_bsdfs + 1), st));
         if (g->g_sec_edges && sc->E.n > 0) HIPCHK(hipMemsetAsync(g->g_sec_edges, 0, sizeof(float) * 6 * (size_t) sc->E.n, st));
         if (g->g_prim_edges && cam.n_edges > 0) HIPCHK(hipMemsetAsync(g->g_prim_edges, 0, sizeof(float) * 4 * (size_t) cam.n_edges, st));
     }
@@ -1353,7 +1354,8 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     const bool no_sweep = std::getenv("PSDR_ADJ_PROBE") != nullptr;                // measurement / test knob, read per call: force the probe form
     const bool sweep = !no_sweep && adj_cls != 0 && a->field_mode == 0 && T.tex == nullptr && T.pv == nullptr && (T.env_emitter < 0 || adj_cls == 2);
     // GGX scenes (class 0): the material sweep, when every BSDF is Diffuse or a constant-parameter Microfacet
-    const bool sweep_mat = !no_sweep && !sweep && adj_cls == 0 && a->field_mode == 0 && sc->simple_mats && (T.mat != nullptr || T.tex != nullptr || T.pv != nullptr || sc->has_nmap);
+    // ... and the first-hit integrators on such scenes (the sweep's camera-hit block with the integrator's own adjoint; field 0 and 7 are constants)
+    const bool sweep_mat = !no_sweep && !sweep && adj_cls == 0 && sc->simple_mats && (a->field_mode > 0 || T.mat != nullptr || T.tex != nullptr || T.pv != nullptr || sc->has_nmap);
     const int lane_words = (sweep || sweep_mat) ? adj_sweep_words(adj_depth) : adj_lane_words(adj_depth, with_lookups);
     // the per-lane records (hits, light samples, lookups of one path: 14 D + 3 words for the sweep) live in LDS when they fit beside
     // the accumulators, else in a global array of the scene (any depth works, at global-memory latency)
@@ -1397,6 +1399,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         P.g_cam = g->g_camera;
         P.g_mat = sc->T.mat != nullptr ? g->g_mat : nullptr;
         P.g_env_xf = sc->T.env_emitter >= 0 ? g->g_env_from_world : nullptr;
+        P.g_uv_xf = g->g_uv_xf;
         P.g_env = sc->T.env_emitter >= 0 ? g->g_env : nullptr; P.g_env_scale = sc->T.env_emitter >= 0 ? g->g_env_scale : nullptr;
         if (P.n_local > 0) {
             if (next_queue(P.counter)) return 1;

@@ -129,6 +129,7 @@ template <int LDS> struct SceneView {
     // instead of traversing again, so a probe costs shading only.
     int mis;                   // Li variant: -1 PathTracer, 0/1/2 DirectIntegrator(mis) (set by the kernels from their parameters)
     int field, field_object;   // >= 0: first-hit integrator (FieldExtractionIntegrator / CollocatedIntegrator), shade.h first_hit_value
+    bool uv_adj = false;       // reverse mode: the adjoints of the bitmaps' uv transforms are wanted (psdr_grads.g_uv_xf)
     float intensity, d_intensity;
     int mode;                  // 0 = trace, 1 = trace + record hits, 2 = replay recorded hits
     float *rec;                // this lane's LDS record, stride kBlock: 4 words per hit (slot, u, v, t)

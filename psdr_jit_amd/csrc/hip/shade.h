@@ -235,9 +235,33 @@ PSDR_DEV Dual e_floor(const Dual &a) { return Dual(floorf(a.v), 0.f); }
 PSDR_DEV float e_value(const Dual &a) { return a.v; }
 PSDR_DEV void e_sincos(const Dual &a, Dual &s, Dual &c) { float sv, cv; env::sincos_f(a.v, sv, cv); s = Dual(sv, cv * a.d); c = Dual(cv, -(sv * a.d)); }
 // a bitmap's uv transform (bitmap.h:37-39) as (value, tangent): the forward tangents of rotate / scale / translate in a render; none in the
-// replays and sweeps of reverse mode (psdr_hip.h: their adjoints are taken in forward mode)
+// replays and sweeps of reverse mode (their adjoints: tex_xf_adjoint / env_xf_adjoint below)
 PSDR_DEV env::UvXf<Dual> uv_xf_d(const float *xf, const float *d_xf, bool tan) {
     return env::UvXf<Dual>(Dual(xf[0], tan ? d_xf[0] : 0.f), Dual(xf[1], tan ? d_xf[1] : 0.f), Dual(xf[2], tan ? d_xf[2] : 0.f), Dual(xf[3], tan ? d_xf[3] : 0.f));
+}
+// reverse mode of rotate / scale / translate (bitmap.cpp:64-86): the adjoint ob[CH] of ONE lookup's output taken to the four members by four forward
+// evaluations of that lookup with unit tangents (the lookup is a handful of multiply-adds), added to acc4 = [rot, scale, tx, ty] (an LDS accumulator)
+template <int CH> PSDR_DEV void tex_xf_adjoint(const TexDev &td, float tu, float tv, const float *ob, float *acc4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float e[4] = {j == 0 ? 1.f : 0.f, j == 1 ? 1.f : 0.f, j == 2 ? 1.f : 0.f, j == 3 ? 1.f : 0.f};
+        Dual o[CH];
+        env::bitmap_eval_tex<Dual, CH>([&](int i, int c) { return Dual(td.data[CH * i + c], 0.f); }, td.w, td.h, Dual(tu, 0.f), Dual(tv, 0.f), true, o, uv_xf_d(td.xf, e, true));
+        float g = 0.f;
+        for (int c = 0; c < CH; ++c) g += ob[c] * o[c].d;
+        if (g != 0.f && finite_(g)) atomicAdd(&acc4[j], g);
+    }
+}
+// the environment map's radiance lookup at (u, w) (envmap.cpp:47-56, envmap mode of the bitmap)
+PSDR_DEV void env_xf_adjoint(const EnvDev &E, float u, float w, const float *ob, float *acc4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float e[4] = {j == 0 ? 1.f : 0.f, j == 1 ? 1.f : 0.f, j == 2 ? 1.f : 0.f, j == 3 ? 1.f : 0.f};
+        Dual o[3];
+        env::bitmap_eval_fn<Dual>([&](int i, int c) { return Dual(E.radiance[3 * i + c], 0.f); }, E.width, E.height, Dual(u, 0.f), Dual(w, 0.f), o, uv_xf_d(E.xf, e, true));
+        const float g = ob[0] * o[0].d + ob[1] * o[1].d + ob[2] * o[2].d;
+        if (g != 0.f && finite_(g)) atomicAdd(&acc4[j], g);
+    }
 }
 template <int LDS> PSDR_DEV env::UvXf<Dual> tex_xf_d(const SceneView<LDS> &S, const TexDev &td) { return uv_xf_d(td.xf, td.d_xf, S.mode == 0 && S.probe_kind == 0); }
 template <int LDS> PSDR_DEV env::UvXf<Dual> env_xf_d(const SceneView<LDS> &S, const EnvDev &E) { return uv_xf_d(E.xf, E.d_xf, S.mode == 0 && S.probe_kind == 0); }

@@ -74,7 +74,10 @@ def test_adjoint_dot_product(env, param, terms):
         assert abs(lhs) > 1e-6          # the test is not vacuous
 
 
-def _dot_product_case(env, spec, depth, terms, seeds=(7, 8, 9), with_camera=False, with_mat=False, direct_mis=-1, oracle=None):
+_FIELD_NAMES = {0: "silhouette", 1: "position", 2: "depth", 3: "geoNormal", 4: "shNormal", 5: "uv", 6: "bsdf", 7: "segmentation", 8: "collocated"}
+
+
+def _dot_product_case(env, spec, depth, terms, seeds=(7, 8, 9), with_camera=False, with_mat=False, direct_mis=-1, oracle=None, field=-1, field_object=-1, intensity=1.0):
     """<w, J v> against <J^T w, v> for the forward tangent the spec carries; J v from HIP forward mode or, oracle = the oracle module, from the CPU oracle's
     forward mode (then no HIP forward kernel takes part in the check)"""
     torch, psdr, cabi = env
@@ -88,13 +91,16 @@ def _dot_product_case(env, spec, depth, terms, seeds=(7, 8, 9), with_camera=Fals
     d_em = np.array([e.d_radiance for e in spec.emitters], np.float64)
     n = spec.width * spec.height
     buf = torch.empty((2, n, 3), dtype=torch.float32, device="cuda")
-    a = cabi.make_args(max_depth=depth, seeds=seeds, terms=terms, direct_mis=direct_mis)
+    a = cabi.make_args(max_depth=depth, seeds=seeds, terms=terms, direct_mis=direct_mis, field=field, field_object=field_object, intensity=intensity)
     cabi.check(cabi.lib().psdr_hip_render_d_fwd(sc._hip_handle(), C.byref(a), buf[0].data_ptr(), buf[1].data_ptr(), None))
     gen = torch.Generator(device="cpu").manual_seed(3)
     w = (torch.rand((n, 3), generator=gen) + 0.5).to("cuda")
     if oracle is not None:
         assert direct_mis == -1
-        _img, d_img = oracle.OracleScene(spec, [0]).render_d(max_depth=depth, seeds=seeds, terms=terms)
+        osc = oracle.OracleScene(spec, [0])
+        if field >= 0:
+            osc.set_field(_FIELD_NAMES[field], obj=field_object, intensity=intensity)
+        _img, d_img = osc.render_d(max_depth=depth, seeds=seeds, terms=terms)
         buf[1].copy_(torch.from_numpy(d_img).to("cuda"))
     lhs = float((buf[1].double() * w.double()).sum())
     dev = "cuda"
@@ -285,7 +291,7 @@ def test_interior_sweep_normalmap(env, nested, nmap, param):
     assert abs(lhs - rhs) <= 5e-4 * scale and abs(lhs) > 1e-6, (nested, nmap, param, lhs, rhs, scale)
 
 
-def _all_adjoint_buffers(env, spec, depth, monkeypatch, probe):
+def _all_adjoint_buffers(env, spec, depth, monkeypatch, probe, field=-1, intensity=1.0):
     """every adjoint buffer of psdr_hip_render_d_bwd (interior term) from the reverse sweep or, probe=True, from record-and-probe (PSDR_ADJ_PROBE is read per call)"""
     torch, psdr, cabi = env
     if probe:
@@ -313,7 +319,7 @@ def _all_adjoint_buffers(env, spec, depth, monkeypatch, probe):
         g.g_env, g.g_env_scale, g.g_env_from_world = out["env"].data_ptr(), out["env_scale"].data_ptr(), out["env_xf"].data_ptr()
     gen = torch.Generator(device="cpu").manual_seed(11)
     w = (torch.rand((spec.width * spec.height, 3), generator=gen) + 0.5).to("cuda")
-    a = cabi.make_args(max_depth=depth, seeds=(7, 8, 9), terms=1)
+    a = cabi.make_args(max_depth=depth, seeds=(7, 8, 9), terms=1, field=field, intensity=intensity)
     cabi.check(cabi.lib().psdr_hip_render_d_bwd(sc._hip_handle(), C.byref(a), w.data_ptr(), C.byref(g), None))
     torch.cuda.synchronize()
     monkeypatch.delenv("PSDR_ADJ_PROBE", raising=False)
@@ -461,3 +467,119 @@ def test_interior_sweep_ggx_bitmaps(env, kind, param):
     spec = scenes.textured_ggx_scene(40, 40, 8, 0, 0, kind=kind, param=param)
     lhs, rhs, scale = _dot_product_case(env, spec, depth=3 if kind == "roughconductor" else 4, terms=1, with_mat=True)
     assert abs(lhs - rhs) <= 5e-4 * scale and abs(lhs) > 1e-6, (kind, param, lhs, rhs, scale)
+
+
+_FIRST_HIT_SCENES = {
+    "cbox": lambda: scenes.cbox_scene(40, 40, 8, 0, 0, param="box_x"),
+    "cbox_camera": lambda: scenes.cbox_scene(40, 40, 8, 0, 0, param="camera_x"),
+    "sphere": lambda: scenes.sphere_scene(40, 40, 8, 0, 0),
+    "microfacet": lambda: scenes.microfacet_cbox_scene(40, 40, 8, 0, 0, param="roughness"),
+    "microfacet_two_sided": lambda: scenes.microfacet_cbox_scene(40, 40, 8, 0, 0, param="box_x", two_sided=True),
+    "conductor": lambda: scenes.conductor_cbox_scene(40, 40, 8, 0, 0, param="alpha"),
+    "textured_microfacet": lambda: scenes.textured_microfacet_scene(40, 40, 8, 0, 0, param="roughness"),
+    "textured_env": lambda: scenes.textured_scene(40, 40, 8, 0, 0, param="box_x"),
+    "pervertex": lambda: scenes.pervertex_scene(40, 40, 8, 0, 0, param="ball_x"),
+    "normalmap": lambda: scenes.normalmap_scene(40, 40, 8, 0, 0, param="box_x", nested="microfacet", nmap="bumpy"),
+    "ortho": lambda: scenes.ortho_cbox_scene(40, 40, 8, 0, 0, param="box_x"),
+}
+
+
+@pytest.mark.parametrize("family", list(_FIRST_HIT_SCENES))
+def test_first_hit_integrators_sweep_equals_the_probe_form(env, monkeypatch, family):
+    """FieldExtractionIntegrator (field.cpp:49-121: position, depth, geometric / shading normal, uv, bsdf) and CollocatedIntegrator (collocated.cpp:24-55) in reverse mode: the
+    one-pass form (the material sweep's camera-hit block, round 4) against record-and-probe forced, every buffer the call can fill"""
+    spec = _FIRST_HIT_SCENES[family]()
+    seen = 0
+    for field, intensity in ((1, 1.0), (2, 1.0), (3, 1.0), (4, 1.0), (5, 1.0), (6, 1.0), (8, 2e5)):
+        sw = _all_adjoint_buffers(env, spec, 0, monkeypatch, probe=False, field=field, intensity=intensity)
+        pr = _all_adjoint_buffers(env, spec, 0, monkeypatch, probe=True, field=field, intensity=intensity)
+        live = [k for k in pr if np.abs(pr[k]).sum() > 0.0]
+        if not live:
+            assert all(np.abs(sw[k]).sum() == 0.0 for k in sw), (family, field)     # (e.g. the texture coordinates of a mesh without them)
+            continue
+        seen += 1
+        for k in sw:
+            ref = np.abs(pr[k]).sum()
+            err = np.abs(sw[k] - pr[k]).sum() / (ref + 1e-12) if ref > 0.0 else np.abs(sw[k]).sum()
+            assert err <= 5e-4, (family, field, k, err)
+    assert seen >= 5, family
+
+
+@pytest.mark.parametrize("family,kw", [("cbox", {}), ("cbox_camera", {"with_camera": True}), ("microfacet", {"with_mat": True}), ("conductor", {"with_mat": True}),
+                                       ("textured_microfacet", {"with_mat": True}), ("pervertex", {"with_mat": True}), ("normalmap", {"with_mat": True}), ("sphere", {})])
+def test_first_hit_integrators_reverse_mode_against_the_oracle(env, orc, family, kw):
+    """<w, d_img> from the ORACLE's forward mode of the first-hit integrators against <J^T w, v> from psdr_hip_render_d_bwd (interior + primary-edge terms)"""
+    for field, intensity in ((1, 1.0), (2, 1.0), (4, 1.0), (6, 1.0), (8, 2e5)):
+        spec = _FIRST_HIT_SCENES[family]()
+        spec.sppe = 4
+        lhs, rhs, scale = _dot_product_case(env, spec, depth=0, terms=3, oracle=orc, field=field, intensity=intensity, **kw)
+        assert abs(lhs - rhs) <= 1e-3 * scale, (family, field, lhs, rhs, scale)
+
+
+_UV_XF = [[0.4, 1.6, 0.21, -0.13], [-0.7, 0.8, 0.05, 0.3], [1.1, 2.3, -0.4, 0.15]]
+_UV_CASES = {
+    "diffuse_env": lambda: scenes.textured_scene(40, 40, 8, 0, 0, texture=scenes.checker_texture(33, 17, 5), param=None, env=True),
+    "microfacet": lambda: scenes.textured_microfacet_scene(40, 40, 8, 0, 0),
+    "roughconductor": lambda: scenes.textured_ggx_scene(40, 40, 8, 0, 0, kind="roughconductor"),
+    "roughdielectric": lambda: scenes.textured_ggx_scene(40, 40, 8, 0, 0, kind="roughdielectric"),
+    "normalmap": lambda: scenes.normalmap_scene(40, 40, 8, 0, 0),
+    "envmap": lambda: scenes.envmap_scene(40, 40, 8, 0, 0, param=None),
+    "envmap_balls": lambda: scenes.envmap_scene(40, 40, 8, 0, 0, param=None, area_light=True, balls=True),
+}
+
+
+@pytest.mark.parametrize("probe", [False, True])
+@pytest.mark.parametrize("case", list(_UV_CASES))
+def test_uv_transform_adjoints_in_one_pass(env, orc, monkeypatch, case, probe):
+    """psdr_grads.g_uv_xf (ABI 12): the adjoints of rotate / scale / translate of every bitmap (bitmap.cpp:64-86) from the pass that fills g_tex / g_env - every
+    reverse form, <J^T w, v> against <w, J v> with J v from the ORACLE's forward mode, all components of all bitmaps of the scene carrying a tangent at once"""
+    torch, psdr, cabi = env
+    spec = _UV_CASES[case]()
+    rng = np.random.default_rng(5)
+    d_tex = rng.uniform(-1.0, 1.0, size=(len(spec.bsdfs), 3, 4))
+    for i, b in enumerate(spec.bsdfs):
+        if any(getattr(b, k, None) is not None for k in ("texture", "spec_texture", "rough_texture")):
+            b.tex_xf, b.d_tex_xf = _UV_XF, d_tex[i]
+        else:
+            d_tex[i] = 0.0
+    d_env = np.zeros(4)
+    for e in spec.emitters:
+        if getattr(e, "type", 0) == 1:
+            d_env = rng.uniform(-1.0, 1.0, size=4)
+            e.env_uv_xf, e.d_env_uv_xf = (0.3, 1.2, 0.27, -0.1), tuple(float(q) for q in d_env)
+    assert np.abs(d_tex).sum() + np.abs(d_env).sum() > 0
+    _img, d_img = orc.OracleScene(spec, [0]).render_d(max_depth=3, seeds=(7, 8, 9), terms=1)
+    n = spec.width * spec.height
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    w = (torch.rand((n, 3), generator=gen) + 0.5).to("cuda")
+    lhs = float((torch.from_numpy(d_img).to("cuda").double() * w.double()).sum())
+    scale = float((torch.from_numpy(d_img).to("cuda").double().abs() * w.double()).sum()) + 1e-12
+    if probe:
+        monkeypatch.setenv("PSDR_ADJ_PROBE", "1")
+    else:
+        monkeypatch.delenv("PSDR_ADJ_PROBE", raising=False)
+    sc = product.build_scene(spec)
+    snap = sc._snapshot()
+    n_tris = np.asarray(snap["d_triangles"]).shape[0]
+    n_b = len(snap["bsdf_rows"]) if "bsdf_rows" in snap else len(spec.bsdfs)
+    z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device="cuda")
+    keep = [z(n_tris, 22), z(max(1, n_b), 3), z(max(1, len(spec.emitters)), 3), z(1, 6), z(1, 4)]
+    g = cabi.Grads(*[t.data_ptr() for t in keep])
+    offs = (C.c_int64 * (3 * max(1, n_b)))(); total = C.c_int64(0)
+    cabi.check(cabi.lib().psdr_hip_scene_tex_layout(C.c_void_p(sc._hip_handle()), offs, C.byref(total)))
+    g_tex, g_uv = z(max(1, total.value)), z(3 * n_b + 1, 4)
+    if total.value > 0:
+        g.g_tex = g_tex.data_ptr()
+    g.g_uv_xf = g_uv.data_ptr()
+    env_em = [e for e in spec.emitters if getattr(e, "type", 0) == 1]
+    if env_em:
+        H, W = env_em[0].env_data.shape[:2]
+        g_env = z(H * W * 3)
+        g.g_env = g_env.data_ptr()
+    a = cabi.make_args(max_depth=3, seeds=(7, 8, 9), terms=1)
+    cabi.check(cabi.lib().psdr_hip_render_d_bwd(sc._hip_handle(), C.byref(a), w.data_ptr(), C.byref(g), None))
+    torch.cuda.synchronize()
+    monkeypatch.delenv("PSDR_ADJ_PROBE", raising=False)
+    gu = g_uv.cpu().numpy().astype(np.float64)
+    rhs = float((gu[:3 * len(spec.bsdfs)].reshape(len(spec.bsdfs), 3, 4) * d_tex).sum() + (gu[3 * n_b] * d_env).sum())
+    assert abs(lhs) > 1e-3 * scale and abs(lhs - rhs) <= 1e-3 * scale, (case, probe, lhs, rhs, scale)
