@@ -468,8 +468,7 @@ PYBIND11_MODULE(_psdr_core, m) {
         a.shard_rank = rank; a.shard_count = count; a.zero_output = 1; a.terms = terms; a.guiding = it.guiding(sensor_id);
         a.direct_mode = it.direct_mis() + 1;
         a.pix_ids = reinterpret_cast<const int32_t *>(pix_ids); a.n_pix = pix_ids ? n_pix : 0;       // batch rendering: interior term only
-        a.field_mode = it.field() + 1; a.field_object = -1; a.intensity = it.intensity(false);
-        if (!it.field_object().empty()) throw Exception("reverse mode: FieldExtractionIntegrator with an object filter is not supported");
+        a.field_mode = it.field() + 1; a.field_object = field_object_index(scene, it); a.intensity = it.intensity(false);
         psdr_grads g{reinterpret_cast<float *>(g_tri), reinterpret_cast<float *>(g_bsdf), reinterpret_cast<float *>(g_emitter),
                      reinterpret_cast<float *>(g_sec), reinterpret_cast<float *>(g_prim),
                      reinterpret_cast<const uint8_t *>(mesh_filter), skip_bsdf ? 1 : 0, skip_emitter ? 1 : 0, reinterpret_cast<float *>(g_tex), reinterpret_cast<float *>(g_cam),

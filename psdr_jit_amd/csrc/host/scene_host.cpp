@@ -880,6 +880,18 @@ void Scene::upload() {
 
 // ------------------------------------------------------------------------------------------------
 // Integrator::renderC / renderD, reference src/integrator/integrator.cpp:12-100
+// FieldExtractionIntegrator's object filter as a mesh index (-1 = none).  Mesh::get_obj_mask, reference mesh.h:49-63: a mesh with an id is matched by
+// name, the others by index
+int field_object_index(const Scene &scene, const Integrator &it) {
+    const std::string obj = it.field_object();
+    if (obj.empty()) return -1;
+    int by_index = -1;
+    try { by_index = std::stoi(obj); } catch (...) { by_index = -1; }
+    for (const Mesh *m : scene.m_meshes)
+        if (!m->m_id.empty() ? (m->m_id == obj) : (m->m_mesh_id == by_index)) return m->m_mesh_id;
+    return 1 << 30;        // nothing matches: an empty field
+}
+
 static void fill_args(psdr_render_args &a, const Scene &scene, const Integrator &it, int sensor_id, uintptr_t pix_ids, int n_pix, int rank, int count) {
     std::memset(&a, 0, sizeof(a));
     a.sensor_id = sensor_id; a.max_depth = it.max_depth(); a.hide_emitters = it.hide_emitters() ? 1 : 0;
@@ -889,17 +901,8 @@ static void fill_args(psdr_render_args &a, const Scene &scene, const Integrator 
     a.guiding = it.guiding(sensor_id);
     a.direct_mode = it.direct_mis() + 1;
     a.field_mode = it.field() + 1;
-    a.field_object = -1;
+    a.field_object = field_object_index(scene, it);
     a.intensity = it.intensity(false); a.d_intensity = it.intensity(true);
-    const std::string obj = it.field_object();
-    if (!obj.empty()) {          // Mesh::get_obj_mask, reference mesh.h:49-63: a mesh with an id is matched by name, the others by index
-        int by_index = -1;
-        try { by_index = std::stoi(obj); } catch (...) { by_index = -1; }
-        for (const Mesh *m : scene.m_meshes) {
-            if (!m->m_id.empty() ? (m->m_id == obj) : (m->m_mesh_id == by_index)) { a.field_object = m->m_mesh_id; break; }
-        }
-        if (a.field_object < 0) a.field_object = 1 << 30;        // nothing matches: an empty field
-    }
 }
 
 void Integrator::renderC(const Scene &scene, int sensor_id, int seed, uintptr_t pix_ids, int n_pix, uintptr_t out, uintptr_t stream, int rank, int count) const {

@@ -361,4 +361,6 @@ struct CollocatedIntegrator : Integrator {
     float m_intensity, d_intensity = 0.f;
 };
 
+int field_object_index(const Scene &scene, const Integrator &it);      // scene_host.cpp: FieldExtractionIntegrator's object filter as a mesh index
+
 } // namespace psdr_host

@@ -337,6 +337,16 @@ def test_field_extraction_and_collocated_integrators(psdr, orc):
     (im * w).sum().backward()
     want = float((d * w).sum())
     assert abs(want) > 1e-3 and abs(float(P.grad) - want) < 2e-3 * max(1.0, abs(want))
+    # ... and with an object filter (Mesh::get_obj_mask, mesh.h:49-63): the small box alone, which is the mesh that moves
+    P = psdr.FloatD(0.).requires_grad_()
+    sc3 = _readme_scene(psdr, P)
+    im = psdr.FieldExtractionIntegrator("position 0").renderD(sc3, 0, seed=2)
+    d = psdr.forward_grad(im, P)
+    (im * w).sum().backward()
+    want = float((d * w).sum())
+    assert abs(want) > 1e-3 and abs(float(P.grad) - want) < 2e-3 * max(1.0, abs(want))
+    whole = psdr.FieldExtractionIntegrator("position").renderD(sc3, 0, seed=2)
+    assert float((whole.detach() - im.detach()).abs().sum()) > 1.0          # the filter removed the rest of the room
 
 
 def test_scene_without_emitters(psdr):
