@@ -33,7 +33,8 @@ constexpr int kSecAdjScratch = kSecAdjLaneWords * kBlock + 16;
 
 struct AdjointParams {
     int max_depth, hide_emitters;
-    unsigned long long seed, skip;
+    unsigned long long seed;
+    SkipAhead skip;                  // the sampler's draws so far, as pcg32's skip-ahead map (sampler.h)
     const int *pix_ids;
     long long begin, end;
     int shard_rank, shard_count;

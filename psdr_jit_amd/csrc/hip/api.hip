@@ -529,7 +529,7 @@ __global__ void k_env_pdf(const SceneTables T, int n, const float *__restrict__ 
 
 __global__ void k_sampler_floats(unsigned long long seed_value, unsigned long long lane, unsigned long long skip, int n, float *out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        LaneRng r; r.seed(seed_value, lane, skip);
+        LaneRng r; r.seed(seed_value, lane, skip_ahead(skip));        // (the kernels' form of the skip-ahead: sampler.h)
         for (int i = 0; i < n; ++i) out[i] = r.next_1d();
     }
 }
@@ -1201,7 +1201,7 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
     };
     if ((terms & PSDR_TERM_INTERIOR) && T.spp > 0) {
         PathParams P{};
-        P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[0].seed; P.skip = a->samplers[0].skip;
+        P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[0].seed; P.skip = skip_ahead(a->samplers[0].skip);
         P.pix_ids = a->pix_ids; P.begin = 0; P.end = npx * T.spp; P.shard_rank = rank; P.shard_count = count;
         P.out = out; P.dout = dout; P.lanes_out = lanes_out;
         if (lanes_out) { P.begin = lane_b; P.end = lane_e; P.shard_rank = 0; P.shard_count = 1; }
@@ -1224,7 +1224,7 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
     if (ad && !a->pix_ids && !lanes_out) {
         if ((terms & PSDR_TERM_PRIMARY) && T.sppe > 0 && cam.n_edges > 0) {
             PathParams P{};
-            P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[1].seed; P.skip = a->samplers[1].skip;
+            P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[1].seed; P.skip = skip_ahead(a->samplers[1].skip);
             P.begin = 0; P.end = npx * T.sppe; P.shard_rank = rank; P.shard_count = count; P.dout = dout;
             P.n_local = local_lanes(P.end, rank, count);
             if (P.n_local > 0) {
@@ -1237,7 +1237,7 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
         }
         if ((terms & PSDR_TERM_SECONDARY) && T.sppse > 0 && sc->E.n > 0) {
             PathParams P{};
-            P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[2].seed; P.skip = a->samplers[2].skip;
+            P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[2].seed; P.skip = skip_ahead(a->samplers[2].skip);
             P.begin = 0; P.end = npx * T.sppse; P.shard_rank = rank; P.shard_count = count; P.dout = dout;
             P.n_local = local_lanes(P.end, rank, count);
             GuidingDev G{};
@@ -1388,7 +1388,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     }
     if ((terms & PSDR_TERM_INTERIOR) && T.spp > 0) {
         AdjointParams P{};
-        P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[0].seed; P.skip = a->samplers[0].skip;
+        P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[0].seed; P.skip = skip_ahead(a->samplers[0].skip);
         P.pix_ids = a->pix_ids; P.begin = 0; P.end = npx * T.spp; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
         P.w = d_rgb; P.g_tri = g->g_triangles; P.g_bsdf = g->g_bsdf; P.g_emitter = g->g_emitter; P.hot_map = sc->hot_map.as<int>(); P.hot_inv = sc->hot_inv.as<int>(); P.n_hot = n_hot_used;
         P.mesh_filter = g->mesh_filter; P.skip_bsdf = g->skip_bsdf; P.skip_emitter = g->skip_emitter;
@@ -1428,7 +1428,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     if (!a->pix_ids && (terms & PSDR_TERM_PRIMARY) && T.sppe > 0 && cam.n_edges > 0) {
         if (!g->g_prim_edges) return fail("g_prim_edges is required when the primary-edge term is requested");
         PathParams P{};
-        P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[1].seed; P.skip = a->samplers[1].skip;
+        P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[1].seed; P.skip = skip_ahead(a->samplers[1].skip);
         P.begin = 0; P.end = npx_full * T.sppe; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
         P.adj_w = d_rgb; P.g_prim = g->g_prim_edges; P.n_prim = cam.n_edges; P.lds_acc = (cam.n_edges <= 2048) ? 1 : 0;
         if (P.n_local > 0) {
@@ -1443,7 +1443,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     if (!a->pix_ids && (terms & PSDR_TERM_SECONDARY) && T.sppse > 0 && sc->E.n > 0) {
         if (!g->g_sec_edges) return fail("g_sec_edges is required when the secondary-edge term is requested");
         PathParams P{};
-        P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[2].seed; P.skip = a->samplers[2].skip;
+        P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[2].seed; P.skip = skip_ahead(a->samplers[2].skip);
         P.begin = 0; P.end = npx_full * T.sppse; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
         P.adj_w = d_rgb; P.g_sec = g->g_sec_edges; P.g_tri = g->g_triangles; P.n_sec = sc->E.n;
         P.g_cam = g->g_camera;

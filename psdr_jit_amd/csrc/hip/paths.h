@@ -21,7 +21,8 @@ namespace psdr {
 
 struct PathParams {
     int max_depth, hide_emitters;
-    unsigned long long seed, skip;
+    unsigned long long seed;
+    SkipAhead skip;                  // the sampler's draws so far, as pcg32's skip-ahead map (sampler.h)
     const int *pix_ids;
     long long begin, end;            // lane range of the sampler
     int shard_rank, shard_count;     // 256-lane chunks k with k % count == rank

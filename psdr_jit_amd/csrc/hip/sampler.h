@@ -35,6 +35,25 @@ PSDR_RNG_HD uint64_t tea64(uint64_t v0, uint64_t v1) {
     return v0 + (v1 << 32);
 }
 
+// pcg32's skip-ahead by `delta` draws is the affine map state -> mult * state + plus, and plus is LINEAR in the stream's increment
+// (every term of the doubling recurrence below carries one factor inc): plus = inc * g with g the same recurrence run for inc = 1.
+// (mult, g) depend on delta only, so the host runs the O(log delta) loop once per launch and every work item applies the map with two
+// 64-bit multiplications - the same numbers mod 2^64 as the per-lane loop (a continuing sampler, e.g. iteration 1000 of an optimisation,
+// otherwise pays ~35 instructions x log2(delta) per work item: tools/time_skip.py).
+struct SkipAhead {
+    uint64_t mult, g;
+};
+PSDR_RNG_HD SkipAhead skip_ahead(uint64_t delta) {
+    uint64_t cur_mult = kPcgMult, cur_plus = 1u, acc_mult = 1u, acc_plus = 0u;
+    while (delta > 0) {
+        if (delta & 1) { acc_mult *= cur_mult; acc_plus = acc_plus * cur_mult + cur_plus; }
+        cur_plus = (cur_mult + 1) * cur_plus;
+        cur_mult *= cur_mult;
+        delta >>= 1;
+    }
+    return SkipAhead{acc_mult, acc_plus};
+}
+
 struct LaneRng {
     uint64_t state, inc;
 
@@ -70,6 +89,11 @@ struct LaneRng {
         state += initstate;
         next_u32();
         if (skip) advance(skip);
+    }
+    // ... with the skip-ahead as its precomputed map (the kernels' form)
+    PSDR_RNG_HD void seed(uint64_t seed_value, uint64_t lane, const SkipAhead &sk) {
+        seed(seed_value, lane, (uint64_t) 0);
+        if (sk.mult != 1u || sk.g != 0u) state = sk.mult * state + sk.g * inc;      // (a launch-wide constant: a scalar branch)
     }
 };
 

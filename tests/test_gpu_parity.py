@@ -57,6 +57,10 @@ def test_sampler_bit_exact(torch_cuda, psdr, orc):
     buf = torch_cuda.zeros(20, dtype=torch_cuda.float32, device="cuda")
     cabi.check(L.psdr_hip_sampler_floats(999, 123456, 17, 20, buf.data_ptr(), None))
     assert np.array_equal(buf.cpu().numpy(), orc.sampler_floats(999, 123456, 20, skip=17))
+    # the kernels apply the skip-ahead as a precomputed affine map (sampler.h::skip_ahead): far into a run, lanes beyond 2^32, a skip beyond 2^40
+    for seed_value, lane, skip in ((5, 7, 31 * 1000), (2 ** 33 + 11, 2 ** 32 + 99, 31 * 10 ** 6), (12345678901234, 268435455, 2 ** 40 + 12345), (0, 0, 2 ** 63 + 5)):
+        cabi.check(L.psdr_hip_sampler_floats(seed_value, lane, skip, 20, buf.data_ptr(), None))
+        assert np.array_equal(buf.cpu().numpy(), orc.sampler_floats(seed_value, lane, 20, skip=skip)), (seed_value, lane, skip)
 
 
 @pytest.mark.parametrize("scene_name", ["cbox", "sphere"])
