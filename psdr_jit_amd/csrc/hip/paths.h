@@ -46,7 +46,11 @@ struct PathParams {
     float intensity, d_intensity;
 };
 
-constexpr int kFetchBatch = 256;
+#ifndef PSDR_FETCH_BATCH
+#define PSDR_FETCH_BATCH 256
+#endif
+constexpr int kFetchBatch = PSDR_FETCH_BATCH;      // work items a wave takes from the launch's queue per atomic
+static_assert(kFetchBatch % 64 == 0, "PSDR_FETCH_BATCH");
 #ifndef PSDR_REGEN_MIN
 #define PSDR_REGEN_MIN 1
 #endif
