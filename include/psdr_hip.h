@@ -224,6 +224,12 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *snapshot, psdr_hip_scene **
 int psdr_hip_scene_destroy(psdr_hip_scene *scene);
 /* BVH statistics for DESIGN/bench: nodes, leaves, max depth, bytes resident in LDS per workgroup */
 int psdr_hip_scene_stats(const psdr_hip_scene *scene, int32_t *n_nodes, int32_t *n_leaves, int32_t *max_depth, int32_t *lds_bytes);
+/* The live-pixel mask of a sensor (HOST bits[(width*height + 31) / 32], bit y*width + x; either pointer may be NULL): a pixel is dead when
+ * no ray through its square can reach a triangle - the conservative screen-space coverage of the scene, built at scene creation.  The
+ * interior term of every sample of a dead pixel is exactly zero (Integrator::__render, src/integrator/integrator.cpp:103-131: the
+ * camera ray misses), and psdr_hip_render_c / _d_fwd skip such samples before seeding them.  All ones: no mask (environment-lit
+ * scenes, a triangle across the camera plane, 2^31 lanes or more, PSDR_NO_LIVE_MASK=1 in the environment). */
+int psdr_hip_scene_live_pixels(const psdr_hip_scene *scene, int32_t sensor_id, uint32_t *bits, int64_t *n_live);
 /* bytes of one node of the 4-wide BVH this build walks (64: quantised child boxes, csrc/hip/bvh.h) - the unit of the algorithmic
  * bytes bench.py prices a node visit at */
 int psdr_hip_bvh_node_bytes(void);

@@ -7,7 +7,7 @@ from . import build as _build
 
 SYMBOLS = [
     "psdr_hip_last_error", "psdr_hip_abi_version", "psdr_hip_device_count", "psdr_hip_set_device",
-    "psdr_hip_scene_create", "psdr_hip_scene_destroy", "psdr_hip_scene_stats", "psdr_hip_bvh_node_bytes", "psdr_hip_scene_tex_layout", "psdr_hip_trace", "psdr_hip_trace_pairs", "psdr_hip_ray_intersect", "psdr_hip_env_sample", "psdr_hip_env_pdf", "psdr_hip_env_cell_masses", "psdr_hip_env_cell_masses_xf",
+    "psdr_hip_scene_create", "psdr_hip_scene_destroy", "psdr_hip_scene_stats", "psdr_hip_scene_live_pixels", "psdr_hip_bvh_node_bytes", "psdr_hip_scene_tex_layout", "psdr_hip_trace", "psdr_hip_trace_pairs", "psdr_hip_ray_intersect", "psdr_hip_env_sample", "psdr_hip_env_pdf", "psdr_hip_env_cell_masses", "psdr_hip_env_cell_masses_xf",
     "psdr_hip_render_c", "psdr_hip_render_d_fwd", "psdr_hip_render_d_bwd", "psdr_hip_render_c_counted", "psdr_hip_render_d_fwd_counted",
     "psdr_hip_li_lanes", "psdr_hip_guiding_build", "psdr_hip_guiding_mass", "psdr_hip_guiding_num_cells",
     "psdr_hip_guiding_destroy", "psdr_hip_tea64", "psdr_hip_sampler_floats",
@@ -59,6 +59,7 @@ def lib():
         L.psdr_hip_render_d_fwd_counted.argtypes = [C.c_void_p, C.POINTER(RenderArgs), C.c_void_p, C.c_void_p, C.POINTER(Counters), C.c_void_p]
         L.psdr_hip_li_lanes.argtypes = [C.c_void_p, C.POINTER(RenderArgs), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
         L.psdr_hip_scene_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.psdr_hip_scene_live_pixels.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int64)]
         _lib = L
     return _lib
 

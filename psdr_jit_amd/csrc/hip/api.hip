@@ -612,6 +612,7 @@ struct psdr_hip_scene {
     mutable bool adj_attr_set = false;   // the adjoint kernels' dynamic-LDS limit has been raised on this scene's device
     int n_leaves = 0, max_depth = 0, grid = 0;
     long long tex_total = 0;             // floats of all bitmap parameters (psdr_grads.g_tex)
+    std::vector<std::vector<unsigned>> live_host;      // per sensor: the live-pixel mask (empty = every pixel is live), kept for psdr_hip_scene_live_pixels
     DevBuf hot_map, hot_inv;             // adjoint accumulators kept in LDS: emitter triangles first, then by area (adjoint.h)
     int n_hot = 0;
     std::vector<long long> tex_layout;   // [3*n_bsdfs] offsets into g_tex, -1 = constant
@@ -685,6 +686,52 @@ static inline size_t words_for_floats(size_t n) { return (n + 3) / 4; }
 extern "C" {
 
 const char *psdr_hip_last_error(void) { return g_err.c_str(); }
+// Conservative screen-space coverage of the scene for one sensor: bit (y * width + x) = some triangle's projection (world_to_sample, a projective map: the
+// image of a triangle in front of the camera is the triangle of its projected vertices) comes within a quarter of a pixel of the pixel's square.  Row by row:
+// the x-extent of the triangle inside the (padded) row slab.  false = no mask (a triangle crosses the camera plane: its image is not a triangle).
+static bool build_live_mask(const psdr_triangles &tr, const float *w2s, int W, int H, std::vector<unsigned> &mask) {
+    const double pad = 0.25;
+    mask.assign(((size_t) W * H + 31) / 32, 0u);
+    for (int t = 0; t < tr.n_triangles; ++t) {
+        double X[3], Y[3];
+        int behind = 0;
+        for (int v = 0; v < 3; ++v) {
+            double p[3];
+            for (int c = 0; c < 3; ++c) p[c] = (double) tr.p0[3 * t + c] + (v == 1 ? (double) tr.e1[3 * t + c] : (v == 2 ? (double) tr.e2[3 * t + c] : 0.0));
+            if (!(std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]))) return false;
+            const double x = w2s[0] * p[0] + w2s[1] * p[1] + w2s[2] * p[2] + w2s[3], y = w2s[4] * p[0] + w2s[5] * p[1] + w2s[6] * p[2] + w2s[7];
+            const double w = w2s[12] * p[0] + w2s[13] * p[1] + w2s[14] * p[2] + w2s[15];
+            if (!(w > 1e-9)) { ++behind; continue; }
+            X[v] = x / w * W; Y[v] = y / w * H;
+        }
+        if (behind == 3) continue;              // behind the camera: no forward ray reaches it
+        if (behind != 0) return false;
+        const double ymin = std::min(Y[0], std::min(Y[1], Y[2])) - pad, ymax = std::max(Y[0], std::max(Y[1], Y[2])) + pad;
+        if (!(ymax >= 0.0 && ymin < (double) H)) continue;
+        const int r0 = (int) std::max(0.0, std::floor(ymin)), r1 = (int) std::min((double) (H - 1), std::floor(ymax));
+        for (int row = r0; row <= r1; ++row) {
+            const double lo = row - pad, hi = row + 1 + pad;
+            double xmin = 1e300, xmax = -1e300;
+            for (int v = 0; v < 3; ++v) {
+                if (Y[v] >= lo && Y[v] <= hi) { xmin = std::min(xmin, X[v]); xmax = std::max(xmax, X[v]); }
+                const int u = (v + 1) % 3;
+                const double dy = Y[u] - Y[v];
+                if (dy != 0.0)
+                    for (double yc : {lo, hi}) {
+                        const double s = (yc - Y[v]) / dy;
+                        if (s >= 0.0 && s <= 1.0) { const double xc = X[v] + s * (X[u] - X[v]); xmin = std::min(xmin, xc); xmax = std::max(xmax, xc); }
+                    }
+            }
+            if (xmin > xmax) continue;
+            xmin -= pad; xmax += pad;
+            if (!(xmax >= 0.0 && xmin < (double) W)) continue;
+            const int c0 = (int) std::max(0.0, std::floor(xmin)), c1 = (int) std::min((double) (W - 1), std::floor(xmax));
+            for (int c = c0; c <= c1; ++c) { const size_t b = (size_t) row * W + c; mask[b >> 5] |= 1u << (b & 31); }
+        }
+    }
+    return true;
+}
+
 int psdr_hip_abi_version(void) { return PSDR_HIP_ABI_VERSION; }
 int psdr_hip_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 int psdr_hip_set_device(int device) { HIPCHK(hipSetDevice(device)); return 0; }
@@ -1044,6 +1091,17 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
     for (int i = 0; i < s->n_sensors; ++i) {
         const psdr_sensor_rec &r = s->sensors[i];
         SensorDev d{};
+        d.live = nullptr;
+        {
+            std::vector<unsigned> live;
+            static const bool no_live = std::getenv("PSDR_NO_LIVE_MASK") != nullptr;       // measurement knob
+            if (!no_live && T.env_emitter < 0 && (long long) s->width * s->height * std::max(1, s->spp) < (1ll << 31) && build_live_mask(s->tris, r.world_to_sample, s->width, s->height, live)) {
+                sc->bufs.emplace_back(new DevBuf());
+                if (sc->bufs.back()->upload(live.data(), live.size() * sizeof(unsigned))) return 1;
+                d.live = sc->bufs.back()->as<unsigned>();
+            } else live.clear();
+            sc->live_host.push_back(live);
+        }
         std::memcpy(d.sample_to_camera.m, r.sample_to_camera, 64); std::memcpy(d.to_world.m, r.to_world, 64);
         std::memcpy(d.d_to_world.m, r.d_to_world, 64); std::memcpy(d.world_to_sample.m, r.world_to_sample, 64);
         std::memcpy(d.d_world_to_sample.m, r.d_world_to_sample, 64);
@@ -1087,6 +1145,22 @@ int psdr_hip_scene_stats(const psdr_hip_scene *sc, int32_t *n_nodes, int32_t *n_
     if (n_leaves) *n_leaves = sc->n_leaves;
     if (max_depth) *max_depth = sc->max_depth;
     if (lds_bytes) *lds_bytes = (int32_t) sc->smem_bytes * (sc->lds ? 1 : -1);
+    return 0;
+}
+
+int psdr_hip_scene_live_pixels(const psdr_hip_scene *sc, int32_t sensor_id, uint32_t *bits, int64_t *n_live) {
+    if (!sc) return fail("null scene");
+    if (sensor_id < 0 || sensor_id >= (int) sc->live_host.size()) return fail("Invalid sensor id!");
+    const std::vector<unsigned> &m = sc->live_host[sensor_id];
+    const long long npx = (long long) sc->T.width * sc->T.height;
+    long long count = 0;
+    for (long long i = 0; i < (npx + 31) / 32; ++i) {
+        unsigned w = m.empty() ? 0xffffffffu : m[(size_t) i];
+        if (i == (npx + 31) / 32 - 1 && (npx & 31)) w &= (1u << (npx & 31)) - 1u;
+        if (bits) bits[i] = w;
+        count += __builtin_popcount(w);
+    }
+    if (n_live) *n_live = count;
     return 0;
 }
 

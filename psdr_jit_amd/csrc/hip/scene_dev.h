@@ -97,6 +97,10 @@ struct SensorDev {
     int ortho;                 // OrthographicCamera
     const int *pe_guide;       // search bounds of the primary-edge distribution (as SecEdgeTables::guide)
     int pe_guide_n;
+    // one bit per pixel: 0 = no ray through the pixel's footprint can hit a triangle (the conservative screen-space coverage of the scene, api.hip::build_live_mask);
+    // a sample of such a pixel contributes exactly zero to the interior term, so the kernels skip it before they seed it.  NULL = every pixel is live
+    // (environment-lit scenes: the bounding cube fills the frame; a triangle that crosses the camera plane; more than 2^31 lanes)
+    const unsigned *live;
 };
 
 struct Counters { unsigned long long rays, nodes, tris, hits; };

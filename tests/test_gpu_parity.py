@@ -251,3 +251,45 @@ def test_counters_match_oracle_scale(torch_cuda, psdr):
     plain = torch_cuda.empty_like(out)
     cabi.check(cabi.lib().psdr_hip_render_c(sc._hip_handle(), C.byref(a), plain.data_ptr(), None))
     assert torch_cuda.allclose(out, plain, rtol=1e-5, atol=1e-6)
+
+
+def test_live_pixel_mask_is_conservative_and_exact(psdr, orc):
+    """psdr_hip_scene_live_pixels: the interior term skips the samples of pixels no ray can leave towards a triangle (SensorDev::live, api.hip::build_live_mask).
+    Conservative: every pixel in which some sample of a first-hit image lands on the scene is live - cameras and scenes of several kinds; not trivial: the README
+    frame is mostly dead; exact: the frame equals the oracle's (which knows no mask) - and environment-lit scenes carry no mask."""
+    import ctypes as C
+    import torch
+    from psdr_jit_amd import cabi
+    L = cabi.lib()
+    cases = [("cbox", scenes.cbox_scene(96, 80, 8, 0, 0, param="box_x"), 3), ("sphere", scenes.sphere_scene(64, 64, 8, 0, 0), 2),
+             ("ortho", scenes.ortho_cbox_scene(72, 72, 8, 0, 0, param="box_x"), 2), ("microfacet", scenes.microfacet_cbox_scene(64, 48, 8, 0, 0, param="box_x"), 2),
+             ("pervertex", scenes.pervertex_scene(64, 64, 8, 0, 0, param="ball_x"), 2)]
+    fractions = {}
+    for name, spec, depth in cases:
+        sc = product.build_scene(spec)
+        n = spec.width * spec.height
+        bits = np.zeros((n + 31) // 32, np.uint32)
+        n_live = C.c_int64(0)
+        cabi.check(L.psdr_hip_scene_live_pixels(C.c_void_p(sc._hip_handle()), 0, bits.ctypes.data, C.byref(n_live)))
+        live = ((bits[np.arange(n) >> 5] >> (np.arange(n) & 31).astype(np.uint32)) & 1).astype(bool)
+        assert int(live.sum()) == n_live.value
+        fractions[name] = n_live.value / n
+        # the silhouette field (1 where a camera ray hits anything), 8 samples per pixel: no hit outside the mask
+        a = cabi.make_args(max_depth=0, seeds=(3, 3, 3), terms=1, field=0)
+        img = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+        cabi.check(L.psdr_hip_render_c(C.c_void_p(sc._hip_handle()), C.byref(a), img.data_ptr(), None))
+        hit = img.cpu().numpy()[:, 0] > 0
+        assert hit.sum() > 0 and not np.any(hit & ~live), (name, int((hit & ~live).sum()))
+        assert live.sum() <= 2.5 * hit.sum() + 4 * (spec.width + spec.height), (name, int(live.sum()), int(hit.sum()))        # ... and not much more than the hits
+        # PathTracer frames equal the oracle's
+        a = cabi.make_args(max_depth=depth, seeds=(5, 5, 5), terms=1)
+        buf = torch.zeros((2, n, 3), dtype=torch.float32, device="cuda")
+        cabi.check(L.psdr_hip_render_d_fwd(C.c_void_p(sc._hip_handle()), C.byref(a), buf[0].data_ptr(), buf[1].data_ptr(), None))
+        wimg, wd = orc.OracleScene(spec, [0]).render_d(max_depth=depth, seeds=(5, 5, 5), terms=1)
+        assert product.rel_l2(buf[0].cpu().numpy(), wimg) < TOL and product.rel_l2(buf[1].cpu().numpy(), wd) < TOL, name
+    assert fractions["cbox"] < 0.9 or fractions["sphere"] < 0.9, fractions
+    spec = scenes.envmap_scene(48, 48, 4, 0, 0)
+    sc = product.build_scene(spec)
+    n_live = C.c_int64(0)
+    cabi.check(L.psdr_hip_scene_live_pixels(C.c_void_p(sc._hip_handle()), 0, None, C.byref(n_live)))
+    assert n_live.value == 48 * 48
