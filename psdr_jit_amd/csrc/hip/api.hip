@@ -726,7 +726,13 @@ static bool build_live_mask(const psdr_triangles &tr, const float *w2s, int W, i
             xmin -= pad; xmax += pad;
             if (!(xmax >= 0.0 && xmin < (double) W)) continue;
             const int c0 = (int) std::max(0.0, std::floor(xmin)), c1 = (int) std::min((double) (W - 1), std::floor(xmax));
-            for (int c = c0; c <= c1; ++c) { const size_t b = (size_t) row * W + c; mask[b >> 5] |= 1u << (b & 31); }
+            // bits [b0, b1] of the mask, a word at a time (a wall of the Cornell box at 2048 x 2048 is four million pixels per triangle)
+            const size_t b0 = (size_t) row * W + c0, b1 = (size_t) row * W + c1;
+            for (size_t wi = b0 >> 5; wi <= (b1 >> 5); ++wi) {
+                const unsigned lo_bit = wi == (b0 >> 5) ? (unsigned) (b0 & 31) : 0u, hi_bit = wi == (b1 >> 5) ? (unsigned) (b1 & 31) : 31u;
+                const unsigned m_hi = hi_bit == 31u ? 0xffffffffu : ((1u << (hi_bit + 1u)) - 1u);
+                mask[wi] |= m_hi & ~((1u << lo_bit) - 1u);
+            }
         }
     }
     return true;
