@@ -228,7 +228,8 @@ int psdr_hip_scene_stats(const psdr_hip_scene *scene, int32_t *n_nodes, int32_t 
  * no ray through its square can reach a triangle - the conservative screen-space coverage of the scene, built at scene creation.  The
  * interior term of every sample of a dead pixel is exactly zero (Integrator::__render, src/integrator/integrator.cpp:103-131: the
  * camera ray misses), and psdr_hip_render_c / _d_fwd skip such samples before seeding them.  All ones: no mask (environment-lit
- * scenes, a triangle across the camera plane, 2^31 lanes or more, PSDR_NO_LIVE_MASK=1 in the environment). */
+ * scenes, a triangle across the camera plane, 2^31 lanes or more, less than a quarter of the frame dead, PSDR_NO_LIVE_MASK=1 in the
+ * environment). */
 int psdr_hip_scene_live_pixels(const psdr_hip_scene *scene, int32_t sensor_id, uint32_t *bits, int64_t *n_live);
 /* bytes of one node of the 4-wide BVH this build walks (64: quantised child boxes, csrc/hip/bvh.h) - the unit of the algorithmic
  * bytes bench.py prices a node visit at */

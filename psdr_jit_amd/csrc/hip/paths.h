@@ -70,6 +70,40 @@ PSDR_DEV int nth_set_bit(unsigned long long m, int r) {
     return pos;
 }
 
+// LIVE PIXELS ONLY (round 4).  64 % of the README frame is background: a sample there is seeded, its camera ray traced, and nothing comes of it.  Pixels no ray
+// can leave towards a triangle are known to the host (SensorDev::live); the wave looks at the next 64 queue positions at once - every lane one position -, and the
+// lanes that want a work item take the live ones in order.  Dead positions cost a bit test.  -> this lane's item (q_end: none), n_taken = queue positions used up
+PSDR_DEV long long take_live_items(const SceneTables &T, const SensorDev &cam, const PathParams &P, bool wants, long long q_next, long long q_end, int lane_id,
+                                   unsigned long long lt_mask, int &n_taken) {
+    long long item = q_end;
+    n_taken = 0;
+#pragma nounroll
+    for (int win = 0; win < 3; ++win) {
+        const unsigned long long want = __ballot(wants && item >= q_end);
+        const long long w0 = q_next + n_taken;
+        if (want == 0ull || w0 >= q_end) break;
+        const int wlen = q_end - w0 < 64 ? (int) (q_end - w0) : 64;
+        bool live = false;
+        if (lane_id < wlen) {
+            const long long it = w0 + lane_id;
+            const long long chunk = (it >> 8) * P.shard_count + P.shard_rank;
+            const long long lane = P.begin + (chunk << 8) + (it & 255);
+            if (lane < P.end) {
+                const unsigned k = T.spp > 1 ? (unsigned) lane / (unsigned) T.spp : (unsigned) lane;      // (fewer than 2^31 lanes: the host gives no mask otherwise)
+                const int pix = P.pix_ids ? P.pix_ids[k] : (int) k;
+                live = ((cam.live[pix >> 5] >> (pix & 31)) & 1u) != 0u;
+            }
+        }
+        const unsigned long long lv = __ballot(live);
+        const int n_live = __popcll(lv), n_want = __popcll(want);
+        if (wants && item >= q_end) { const int r = __popcll(want & lt_mask); if (r < n_live) item = w0 + nth_set_bit(lv, r); }
+        // the window is used up to its last taken position (all of it when every live position found a lane)
+        n_taken += n_live <= n_want ? wlen : nth_set_bit(lv, n_want - 1) + 1;
+        if (n_live >= n_want) break;
+    }
+    return item;
+}
+
 template <bool AD, int LDS, bool COUNT, int MODE>
 PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParams &P) {
     using R = Num<AD>; using V = VecN<AD>;
@@ -129,34 +163,8 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
             long long item = q_end;                       // the work item this lane starts (q_end: none)
             int n_taken;                                  // queue positions consumed
             if (MODE == 0 && !COUNT && cam.live != nullptr && P.lanes_out == nullptr) {      // (the counted builds and the per-lane output see every sample)
-                // LIVE PIXELS ONLY (round 4).  70 % of the README frame is background: a sample there is seeded, its camera ray traced, and nothing comes of
-                // it.  Pixels no ray can leave towards a triangle are known to the host (SensorDev::live); the wave looks at the next 64 queue positions at
-                // once - every lane one position -, and the idle lanes take the live ones in order.  Dead positions cost a bit test.
-                n_taken = 0;
-#pragma nounroll
-                for (int win = 0; win < 3; ++win) {
-                    const unsigned long long want = __ballot(!busy && item >= q_end);
-                    const long long w0 = q_next + n_taken;
-                    if (want == 0ull || w0 >= q_end) break;
-                    const int wlen = q_end - w0 < 64 ? (int) (q_end - w0) : 64;
-                    bool live = false;
-                    if (lane_id < wlen) {
-                        const long long it = w0 + lane_id;
-                        const long long chunk = (it >> 8) * P.shard_count + P.shard_rank;
-                        const long long lane = P.begin + (chunk << 8) + (it & 255);
-                        if (lane < P.end) {
-                            const unsigned k = T.spp > 1 ? (unsigned) lane / (unsigned) T.spp : (unsigned) lane;      // (fewer than 2^31 lanes: the host gives no mask otherwise)
-                            const int pix = P.pix_ids ? P.pix_ids[k] : (int) k;
-                            live = ((cam.live[pix >> 5] >> (pix & 31)) & 1u) != 0u;
-                        }
-                    }
-                    const unsigned long long lv = __ballot(live);
-                    const int n_live = __popcll(lv), n_want = __popcll(want);
-                    if (!busy && item >= q_end) { const int r = __popcll(want & lt_mask); if (r < n_live) item = w0 + nth_set_bit(lv, r); }
-                    // the window is used up to its last taken position (all of it when every live position found a lane)
-                    n_taken += n_live <= n_want ? wlen : nth_set_bit(lv, n_want - 1) + 1;
-                    if (n_live >= n_want) break;
-                }
+                // LIVE PIXELS ONLY (round 4): take_live_items above
+                item = take_live_items(T, cam, P, !busy, q_next, q_end, lane_id, lt_mask, n_taken);
             } else {
                 item = q_next + __popcll(need & lt_mask);
                 n_taken = n_need < (int) (q_end - q_next) ? n_need : (int) (q_end - q_next);
@@ -600,9 +608,11 @@ PSDR_DEV void run_paths_async(SceneView<LDS> &S, const SensorDev &cam, const Pat
             }
             const unsigned long long need = __ballot(ready && !busy);
             if (need != 0ull && q_next < q_end) {
-                const int rank = __popcll(need & lt_mask);
-                const long long item = q_next + rank;
                 const int n_need = __popcll(need);
+                long long item;
+                int n_taken;
+                if (MODE == 0 && !COUNT && cam.live != nullptr && P.lanes_out == nullptr) item = take_live_items(T, cam, P, ready && !busy, q_next, q_end, lane_id, lt_mask, n_taken);
+                else { item = q_next + __popcll(need & lt_mask); n_taken = n_need < (int) (q_end - q_next) ? n_need : (int) (q_end - q_next); }
                 if (ready && !busy && item < q_end) {
                     const long long chunk = (item >> 8) * P.shard_count + P.shard_rank;
                     lane = P.begin + (chunk << 8) + (item & 255);
@@ -639,7 +649,7 @@ PSDR_DEV void run_paths_async(SceneView<LDS> &S, const SensorDev &cam, const Pat
                         }
                     }
                 }
-                q_next += n_need < (int) (q_end - q_next) ? n_need : (q_end - q_next);
+                q_next += n_taken;
             }
             // ---------------------------------------------------------------- draw and post the rays of the lane's next vertex
             if (ready && busy) {
