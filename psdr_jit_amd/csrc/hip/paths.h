@@ -73,7 +73,8 @@ PSDR_DEV int nth_set_bit(unsigned long long m, int r) {
 // LIVE PIXELS ONLY (round 4).  64 % of the README frame is background: a sample there is seeded, its camera ray traced, and nothing comes of it.  Pixels no ray
 // can leave towards a triangle are known to the host (SensorDev::live); the wave looks at the next 64 queue positions at once - every lane one position -, and the
 // lanes that want a work item take the live ones in order.  Dead positions cost a bit test.  -> this lane's item (q_end: none), n_taken = queue positions used up
-PSDR_DEV long long take_live_items(const SceneTables &T, const SensorDev &cam, const PathParams &P, bool wants, long long q_next, long long q_end, int lane_id,
+template <typename Params>
+PSDR_DEV long long take_live_items(const SceneTables &T, const SensorDev &cam, const Params &P, bool wants, long long q_next, long long q_end, int lane_id,
                                    unsigned long long lt_mask, int &n_taken) {
     long long item = q_end;
     n_taken = 0;
