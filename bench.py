@@ -14,8 +14,12 @@ Workloads (BASELINE.json `configs`):
 A "step" = one full renderD: image + d(image)/d(theta) = interior path tracer with its forward tangent +
 primary-edge + secondary-edge boundary integrals (3 kernels) and, for N > 1, the all-reduce.  The scene is built
 through the package's public Python surface (the reference README's calls) and is resident in HBM before the timed
-region; the boundary hands over device pointers only (no PCIe term).  Work is never skipped: every step renders all
-lanes with fresh seeds.
+region; the boundary hands over device pointers only (no PCIe term).  Every step renders the whole frame with fresh
+seeds; nothing is cached between steps.  (Since round 4 the interior term passes over the samples of pixels no ray can
+leave towards a triangle - a conservative coverage mask of the scene, built at scene creation; the value of such a sample is
+zero in the reference as well, the frame is checked against the CPU restatement in the run (`parity`), and
+PSDR_NO_LIVE_MASK=1 switches the mask off: 7.21 instead of 7.08 ms.  The samples still count in `value`, as they do for the
+reference, which launches them.)
 
 Prints ONE JSON line (rank 0).  Extra objects (N = 1, rank 0; each can be switched off, none is inside the timed region):
   roofline     - the dominant kernel against the ceiling that binds it.  The scene is LDS / SGPR resident and the
