@@ -295,6 +295,14 @@ def main():
 
     if breakdown is not None:
         out["scale_breakdown"] = breakdown
+    try:        # the live-pixel mask of the timed scene (psdr_hip_scene_live_pixels): which part of the frame the interior term passes over
+        n_live = C.c_int64(0)
+        cabi.check(cabi.lib().psdr_hip_scene_live_pixels(C.c_void_p(handle), 0, None, C.byref(n_live)))
+        out["live_pixels"] = {"fraction": round(n_live.value / float(npx), 4),
+                              "note": "interior-term samples of the other pixels are provably zero and are passed over before seeding (they count in `value`, as for the reference, "
+                                      "which launches them); PSDR_NO_LIVE_MASK=1 renders them"}
+    except Exception as e:      # (never in the way of the line)
+        out["live_pixels"] = {"error": str(e)[:200]}
 
     counters = None
     if os.path.exists(COUNTERS):
