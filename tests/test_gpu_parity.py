@@ -288,6 +288,21 @@ def test_live_pixel_mask_is_conservative_and_exact(psdr, orc):
         wimg, wd = orc.OracleScene(spec, [0]).render_d(max_depth=depth, seeds=(5, 5, 5), terms=1)
         assert product.rel_l2(buf[0].cpu().numpy(), wimg) < TOL and product.rel_l2(buf[1].cpu().numpy(), wd) < TOL, name
     assert fractions["cbox"] < 0.9 or fractions["sphere"] < 0.9, fractions
+    # a camera INSIDE the room: walls, floor and ceiling cross the camera plane (their images are not triangles) - no mask, and the frame still equals the oracle's;
+    # a camera far away and off to the side: the room is a small part of the frame
+    for name, move in (("inside", scenes.translate(278.0, 273.0, 150.0)), ("far", scenes.translate(-900.0, 273.0, -2500.0))):
+        spec = scenes.cbox_scene(64, 64, 4, 0, 0, param="box_x")
+        spec.cameras[0].to_world_raw = np.asarray(move, np.float32)
+        sc = product.build_scene(spec)
+        n = 64 * 64
+        n_live = C.c_int64(0)
+        cabi.check(L.psdr_hip_scene_live_pixels(C.c_void_p(sc._hip_handle()), 0, None, C.byref(n_live)))
+        assert (n_live.value == n) if name == "inside" else (0 < n_live.value < n // 2), (name, n_live.value)
+        a = cabi.make_args(max_depth=2, seeds=(9, 9, 9), terms=1)
+        buf = torch.zeros((2, n, 3), dtype=torch.float32, device="cuda")
+        cabi.check(L.psdr_hip_render_d_fwd(C.c_void_p(sc._hip_handle()), C.byref(a), buf[0].data_ptr(), buf[1].data_ptr(), None))
+        wimg, wd = orc.OracleScene(spec, [0]).render_d(max_depth=2, seeds=(9, 9, 9), terms=1)
+        assert np.abs(wimg).sum() > 0 and product.rel_l2(buf[0].cpu().numpy(), wimg) < TOL and product.rel_l2(buf[1].cpu().numpy(), wd) < TOL, name
     spec = scenes.envmap_scene(48, 48, 4, 0, 0)
     sc = product.build_scene(spec)
     n_live = C.c_int64(0)
