@@ -1137,7 +1137,11 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
 
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount; }
-    sc->grid = cus * 8;
+    {   // workgroups per launch: a multiple of what fits on the device (persistent workgroups pull work until the launch's queue is empty; the ones that start late find it empty)
+        // (measured, tools/ab_env.sh: brute-force scenes 4 per CU - what is resident at most - C3 forward -0.5 %, its backward pass 8.28 -> 8.06 ms; BVH scenes 8: config 5 218.7 ms, with 4 220.1)
+        static const int per_cu_env = std::getenv("PSDR_GRID_PER_CU") ? std::max(1, std::atoi(std::getenv("PSDR_GRID_PER_CU"))) : 0;      // measurement knob
+        sc->grid = cus * (per_cu_env > 0 ? per_cu_env : (sc->T.n_tris > kBruteForceMax ? 8 : 4));
+    }
     if (uses_bvh && bvh4.max_stack > T.stack_lds) {
         // stack entries beyond the LDS part: one int per entry and lane of the largest grid any kernel is launched with
         const size_t stride = (size_t) sc->grid * kBlock;
