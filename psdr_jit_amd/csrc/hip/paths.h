@@ -92,7 +92,7 @@ PSDR_DEV long long take_live_items(const SceneTables &T, const SensorDev &cam, c
             if (lane < P.end) {
                 const unsigned k = T.spp > 1 ? (unsigned) lane / (unsigned) T.spp : (unsigned) lane;      // (fewer than 2^31 lanes: the host gives no mask otherwise)
                 const int pix = P.pix_ids ? P.pix_ids[k] : (int) k;
-                live = ((cam.live[pix >> 5] >> (pix & 31)) & 1u) != 0u;
+                live = (unsigned) pix >= (unsigned) (T.width * T.height) || ((cam.live[pix >> 5] >> (pix & 31)) & 1u) != 0u;      // (a pixel id outside the frame - batch rendering - is left to the path code)
             }
         }
         const unsigned long long lv = __ballot(live);
