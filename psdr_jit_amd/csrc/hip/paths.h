@@ -90,7 +90,7 @@ PSDR_DEV long long take_live_items(const SceneTables &T, const SensorDev &cam, c
             const long long chunk = (it >> 8) * P.shard_count + P.shard_rank;
             const long long lane = P.begin + (chunk << 8) + (it & 255);
             if (lane < P.end) {
-                const unsigned k = T.spp > 1 ? (unsigned) lane / (unsigned) T.spp : (unsigned) lane;      // (fewer than 2^31 lanes: the host gives no mask otherwise)
+                const unsigned k = T.spp > 1 ? (unsigned) lane / (unsigned) T.spp : (unsigned) lane;      // (fewer than 2^31 lanes: the callers check P.end)
                 const int pix = P.pix_ids ? P.pix_ids[k] : (int) k;
                 live = (unsigned) pix >= (unsigned) (T.width * T.height) || ((cam.live[pix >> 5] >> (pix & 31)) & 1u) != 0u;      // (a pixel id outside the frame - batch rendering - is left to the path code)
             }
@@ -163,7 +163,7 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
             const int n_need = __popcll(need);
             long long item = q_end;                       // the work item this lane starts (q_end: none)
             int n_taken;                                  // queue positions consumed
-            if (MODE == 0 && !COUNT && cam.live != nullptr && P.lanes_out == nullptr) {      // (the counted builds and the per-lane output see every sample)
+            if (MODE == 0 && !COUNT && cam.live != nullptr && P.lanes_out == nullptr && P.end < (1ll << 31)) {      // (the counted builds and the per-lane output see every sample)
                 // LIVE PIXELS ONLY (round 4): take_live_items above
                 item = take_live_items(T, cam, P, !busy, q_next, q_end, lane_id, lt_mask, n_taken);
             } else {
@@ -612,7 +612,7 @@ PSDR_DEV void run_paths_async(SceneView<LDS> &S, const SensorDev &cam, const Pat
                 const int n_need = __popcll(need);
                 long long item;
                 int n_taken;
-                if (MODE == 0 && !COUNT && cam.live != nullptr && P.lanes_out == nullptr) item = take_live_items(T, cam, P, ready && !busy, q_next, q_end, lane_id, lt_mask, n_taken);
+                if (MODE == 0 && !COUNT && cam.live != nullptr && P.lanes_out == nullptr && P.end < (1ll << 31)) item = take_live_items(T, cam, P, ready && !busy, q_next, q_end, lane_id, lt_mask, n_taken);
                 else { item = q_next + __popcll(need & lt_mask); n_taken = n_need < (int) (q_end - q_next) ? n_need : (int) (q_end - q_next); }
                 if (ready && !busy && item < q_end) {
                     const long long chunk = (item >> 8) * P.shard_count + P.shard_rank;
