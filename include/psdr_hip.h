@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PSDR_HIP_ABI_VERSION 12
+#define PSDR_HIP_ABI_VERSION 13
 
 /* TriangleInfo SoA, reference include/psdr/types.h:162-175 (+ Scene::m_triangle_uv,
  * m_triangle_face_normals, scene.cpp:528-542).  Arrays of n_triangles rows. */
@@ -222,6 +222,36 @@ int psdr_hip_set_device(int device);
 /* replaces Scene_OptiX::configure (GAS build) + the jit uploads of Scene::configure */
 int psdr_hip_scene_create(const psdr_scene_snapshot *snapshot, psdr_hip_scene **out);
 int psdr_hip_scene_destroy(psdr_hip_scene *scene);
+/* Scene::configure() AGAIN on a scene that already has a device copy (the reference's per-step pattern, README.md:87-106: set_transform ->
+ * configure -> renderD -> backward; the reference re-uploads every array and rebuilds its OptiX GAS each time, src/scene/scene.cpp:311-599,
+ * src/scene/scene_optix.cpp:265-332).  The new snapshot replaces the old one inside the same handle (guiding grids built from the old state
+ * are the caller's to rebuild, as PathTracer::preprocess_secondary_edges is in the reference):
+ *   - same triangle count: the tree and the triangle order are kept.  Moved triangles -> the 4-wide tree is refitted on the device (bottom-up, the
+ *     builder's own box padding and quantisation), and built again only when the refitted tree's SAH cost exceeds 1.4 x the cost it was built with;
+ *   - another triangle count: the tree is built again (host threads).
+ * `same`: PSDR_SAME_* bits by which the caller vouches that a part of the snapshot holds the values of the previous create / update of this handle -
+ * such a part is neither rewritten nor sent.  0 is always correct (everything is rewritten; the tree is still kept and refitted).  The call waits for
+ * the scene's pending render calls and returns when the device copy is complete; `info` (may be NULL) says what was done. */
+#define PSDR_SAME_TRIANGLES     1u   /* every array of psdr_triangles except the d_ (tangent) arrays */
+#define PSDR_SAME_TRI_TANGENTS  2u   /* the d_ arrays of psdr_triangles */
+#define PSDR_SAME_SEC_EDGES     4u   /* psdr_sec_edges, tangents included */
+#define PSDR_SAME_PRIM_EDGES    8u   /* the primary-edge arrays of every sensor, tangents included */
+#define PSDR_SAME_ENV_TEXELS   16u   /* psdr_envmap_rec.radiance, cell_pmf, cell_cmf (not its transform, scale or tangents) */
+#define PSDR_SAME_ENV_TANGENT  32u   /* psdr_envmap_rec.d_radiance */
+#define PSDR_SAME_BITMAPS      64u   /* the texel / per-vertex arrays of every psdr_bsdf_rec and their tangents (not the constants or uv transforms) */
+typedef struct psdr_update_info {
+    int32_t tree;                    /* 0 kept as it was, 1 refitted on the device, 2 built */
+    int32_t reallocated;             /* device allocations whose size changed */
+    int64_t bytes_uploaded;
+    double sah_cost, sah_cost_built; /* SAH cost of the tree now / when it was built (sum over child boxes of half-area x triangles-or-1, over the root's half-area) */
+    double ms_tree, ms_fill, ms_upload, ms_total;   /* host wall clock: tree build / refit, writing the host copy, copies issued, whole call */
+} psdr_update_info;
+int psdr_hip_scene_update(psdr_hip_scene *scene, const psdr_scene_snapshot *snapshot, uint32_t same, psdr_update_info *info);
+/* what the last create / update of this handle did */
+int psdr_hip_scene_last_update(const psdr_hip_scene *scene, psdr_update_info *info);
+/* test aid (synchronises, downloads the tree): number of places where the device tree is NOT a bounding hierarchy of the device triangles - a child
+ * box that does not contain the padded box of a triangle below it, a triangle slot under no or several leaves.  0 for brute-force scenes. */
+int psdr_hip_scene_check_tree(const psdr_hip_scene *scene, int64_t *violations);
 /* BVH statistics for DESIGN/bench: nodes, leaves, max depth, bytes resident in LDS per workgroup */
 int psdr_hip_scene_stats(const psdr_hip_scene *scene, int32_t *n_nodes, int32_t *n_leaves, int32_t *max_depth, int32_t *lds_bytes);
 /* The live-pixel mask of a sensor (HOST bits[(width*height + 31) / 32], bit y*width + x; either pointer may be NULL): a pixel is dead when

@@ -1014,9 +1014,7 @@ class _RenderDFn(_torch.autograd.Function):
         want_cam = any(need and isinstance(obj, Sensor) for (obj, name, t), need in zip(leaves, needs))
         dev = grad_img.device
         g_img = grad_img.contiguous().to(_torch.float32)
-        snap = scene._snapshot()
-        n_tris = int(snap["triangles"].shape[0])
-        n_sec = int(snap["sec_edges"].shape[0])
+        n_tris, n_sec = (int(x) for x in scene._snapshot_counts())
         cam = scene.param_map["Sensor[%d]" % st["sensor_id"]]
         n_prim = int(_np.asarray(cam._primary_edge_ids()).reshape(-1, 3).shape[0])
         pm = scene.param_map

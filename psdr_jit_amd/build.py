@@ -21,10 +21,15 @@ LIBDIR = os.path.join(HERE, "lib")
 HIP_LIB = os.path.join(LIBDIR, "libpsdr_hip.so")
 CORE_LIB = os.path.join(HERE, "_psdr_core" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
 
-HIP_SRCS = [os.path.join(CSRC, "hip", f) for f in ("api.hip",)]
+API_SRC = os.path.join(CSRC, "hip", "api.hip")                  # the render entry points and every kernel (compiled as seven units, see _compile_hip)
+SCENE_SRC = os.path.join(CSRC, "hip", "scene_build.hip")        # psdr_hip_scene_create / _update: tree build and refit, blob layout, uploads
+HIP_SRCS = [API_SRC, SCENE_SRC]
 BUILD_DEPS = [os.path.join(HERE, "isa_lint.py")]          # part of the recipe: a change of the lint re-builds (and re-lints) the library
-HIP_DEPS = [os.path.join(CSRC, "hip", f) for f in ("dmath.h", "sampler.h", "scene_dev.h", "shade.h", "edges.h", "paths.h", "adjoint.h", "adjoint_mat.h", "bvh.h", "filter.h", "microfacet.h", "trav4.h")] + \
-           [os.path.join(ROOT, "include", "psdr_hip.h"), os.path.join(CSRC, "common", "envmath.h")] + BUILD_DEPS
+_H = lambda *names: [os.path.join(CSRC, "hip", f) for f in names]
+COMMON_DEPS = _H("scene_obj.h", "scene_dev.h", "dmath.h", "trav4.h") + [os.path.join(ROOT, "include", "psdr_hip.h")]
+API_DEPS = COMMON_DEPS + _H("sampler.h", "shade.h", "edges.h", "paths.h", "adjoint.h", "adjoint_mat.h", "microfacet.h") + [os.path.join(CSRC, "common", "envmath.h")] + BUILD_DEPS
+SCENE_DEPS = COMMON_DEPS + _H("bvh.h", "filter.h") + BUILD_DEPS
+HIP_DEPS = sorted(set(API_DEPS + SCENE_DEPS))
 HOST_SRCS = [os.path.join(CSRC, "host", f) for f in ("scene_host.cpp", "bindings.cpp", "exr_piz.cpp")]
 HOST_DEPS = [os.path.join(CSRC, "host", f) for f in ("scene_host.h", "hnum.h", "exr_piz.h")] + [os.path.join(ROOT, "include", "psdr_hip.h"), os.path.join(CSRC, "common", "envmath.h")]
 
@@ -75,8 +80,8 @@ UNIT_CLASS_BIT = {1: 1, 2: 1, 6: 1, 3: 2, 4: 4, 5: 8}      # the PSDR_CLS_MASK b
 
 def build_hip(force=False, extra_flags=(), target=None):
     """api.hip is compiled as seven translation units in parallel - the host code with the small kernels (-DPSDR_SPLIT) and six units
-    that only instantiate the heavy kernel templates of one scene class (-DPSDR_TU=k) - and linked into one library: ~4 minutes of
-    wall time instead of ~10 for the single unit (PSDR_BUILD_JOBS=1 compiles them one after the other)."""
+    that only instantiate the heavy kernel templates of one scene class (-DPSDR_TU=k) -, scene_build.hip as an eighth, and all are linked
+    into one library: ~4 minutes of wall time instead of ~10 for the single unit (PSDR_BUILD_JOBS=1 compiles them one after the other)."""
     os.makedirs(LIBDIR, exist_ok=True)
     flags = [f for f in HIP_FLAGS if f != "-shared"] + list(extra_flags)
     if target is not None:
@@ -113,16 +118,17 @@ def _lint_units(hipcc, flags, units, objdir):
             fh.write("lint skipped (PSDR_BUILD_NO_LINT)\n")
         return
     if not lint.available():
-        sys.stderr.write("psdr_jit_amd.build: llvm-objdump not found, the ISA lint of the kernels is skipped\n")
-        return
+        # the lint is the only guard against the allocator defect described above: a build that cannot run it does not ship silently
+        raise RuntimeError("build failed: llvm-objdump not found (looked in $HIPCC's directory, $ROCM_PATH, /opt/rocm and PATH), the ISA lint of the kernels "
+                           "cannot run; PSDR_BUILD_NO_LINT=1 builds without it (development only)")
     lines = []
-    for name, defs in units:
+    for name, src, defs, _deps in units:
         obj = os.path.join(objdir, "api_%s.o" % name)
         found = lint.lint(obj)
         if found:
             lines.append("%s: %d join block(s) with vector instructions ahead of the exec restore (%s ...): compiled again with %s" %
                          (name, len(found), found[0][0][:60], " ".join(LINT_FALLBACK_FLAGS)))
-            _run([hipcc] + flags + LINT_FALLBACK_FLAGS + defs + ["-c"] + HIP_SRCS + ["-o", obj])
+            _run([hipcc] + flags + LINT_FALLBACK_FLAGS + defs + ["-c", src, "-o", obj])
             again = lint.lint(obj)
             if again:
                 raise RuntimeError("build failed: unit %s still has vector instructions ahead of an exec restore with %s:\n%s" %
@@ -146,19 +152,32 @@ def _compile_hip(flags, target, objdir):
     for f in flags:
         if f.startswith("-DPSDR_CLS_MASK="):
             mask = int(f.split("=")[1])
-    units = [("main", ["-DPSDR_SPLIT"])] + [("tu%d" % k, ["-DPSDR_TU=%d" % k]) for k in (1, 6, 2, 4, 5, 3) if UNIT_CLASS_BIT[k] & mask]
+    units = [("main", API_SRC, ["-DPSDR_SPLIT"], API_DEPS)] + [("tu%d" % k, API_SRC, ["-DPSDR_TU=%d" % k], API_DEPS) for k in (1, 6, 2, 4, 5, 3) if UNIT_CLASS_BIT[k] & mask] + \
+            [("scene", SCENE_SRC, [], SCENE_DEPS)]
     jobs = max(1, int(os.environ.get("PSDR_BUILD_JOBS", str(min(len(units), os.cpu_count() or 1)))))
-    objs, pending, running = [], list(units), []
-    for name, _d in units:                           # objects of an earlier (possibly failed, possibly differently flagged) build never get linked
+    objs, pending, running = [], [], []
+    # an object is compiled again only when ITS sources, headers or flags changed (signature beside it): editing the scene-build unit or
+    # bvh.h leaves the six kernel units - minutes of compile time - alone
+    usigs = {}
+    for name, src, defs, deps in units:
         obj = os.path.join(objdir, "api_%s.o" % name)
-        if os.path.exists(obj):
-            os.remove(obj)
+        objs.append(obj)
+        usigs[name] = _signature([src] + deps, flags + defs)
+        fresh = False
+        if os.path.exists(obj) and os.path.exists(obj + ".sig"):
+            with open(obj + ".sig") as fh:
+                fresh = fh.read().strip() == usigs[name]
+        if not fresh:
+            for f in (obj, obj + ".sig"):
+                if os.path.exists(f):
+                    os.remove(f)            # objects of an earlier (possibly failed, possibly differently flagged) build never get linked
+            pending.append((name, src, defs, deps))
+    built = [u[0] for u in pending]
     while pending or running:
         while pending and len(running) < jobs:
-            name, defs = pending.pop(0)
+            name, src, defs, _deps = pending.pop(0)
             obj = os.path.join(objdir, "api_%s.o" % name)
-            objs.append(obj)
-            cmd = [hipcc] + flags + defs + ["-c"] + HIP_SRCS + ["-o", obj]
+            cmd = [hipcc] + flags + defs + ["-c", src, "-o", obj]
             running.append((subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True), cmd))
         proc, cmd = running.pop(0)
         out, _ = proc.communicate()
@@ -166,12 +185,16 @@ def _compile_hip(flags, target, objdir):
             for q, _c in running:
                 q.kill()
                 q.wait()
-            for o in objs:
+            for name in built:
+                o = os.path.join(objdir, "api_%s.o" % name)
                 if os.path.exists(o):
                     os.remove(o)
             sys.stderr.write(out)
             raise RuntimeError("build failed: " + " ".join(cmd))
     _lint_units(hipcc, flags, units, objdir)
+    for name in built:                           # stamped after the lint: a unit the lint compiled again keeps its signature (same sources, the fallback flags are the recipe's)
+        with open(os.path.join(objdir, "api_%s.o.sig" % name), "w") as fh:
+            fh.write(usigs[name] + "\n")
     arch = [f for f in flags if f.startswith("--offload-arch")]
     _run([hipcc] + arch + ["-shared", "-fPIC"] + objs + ["-o", target])
     if target == HIP_LIB:

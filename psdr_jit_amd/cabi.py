@@ -7,7 +7,7 @@ from . import build as _build
 
 SYMBOLS = [
     "psdr_hip_last_error", "psdr_hip_abi_version", "psdr_hip_device_count", "psdr_hip_set_device",
-    "psdr_hip_scene_create", "psdr_hip_scene_destroy", "psdr_hip_scene_stats", "psdr_hip_scene_live_pixels", "psdr_hip_bvh_node_bytes", "psdr_hip_scene_tex_layout", "psdr_hip_trace", "psdr_hip_trace_pairs", "psdr_hip_ray_intersect", "psdr_hip_env_sample", "psdr_hip_env_pdf", "psdr_hip_env_cell_masses", "psdr_hip_env_cell_masses_xf",
+    "psdr_hip_scene_create", "psdr_hip_scene_update", "psdr_hip_scene_last_update", "psdr_hip_scene_check_tree", "psdr_hip_scene_destroy", "psdr_hip_scene_stats", "psdr_hip_scene_live_pixels", "psdr_hip_bvh_node_bytes", "psdr_hip_scene_tex_layout", "psdr_hip_trace", "psdr_hip_trace_pairs", "psdr_hip_ray_intersect", "psdr_hip_env_sample", "psdr_hip_env_pdf", "psdr_hip_env_cell_masses", "psdr_hip_env_cell_masses_xf",
     "psdr_hip_render_c", "psdr_hip_render_d_fwd", "psdr_hip_render_d_bwd", "psdr_hip_render_c_counted", "psdr_hip_render_d_fwd_counted",
     "psdr_hip_li_lanes", "psdr_hip_guiding_build", "psdr_hip_guiding_mass", "psdr_hip_guiding_num_cells",
     "psdr_hip_guiding_destroy", "psdr_hip_tea64", "psdr_hip_sampler_floats",
@@ -35,6 +35,11 @@ class Counters(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("shaded_hits", C.c_uint64)]
 
 
+class UpdateInfo(C.Structure):      # psdr_update_info
+    _fields_ = [("tree", C.c_int32), ("reallocated", C.c_int32), ("bytes_uploaded", C.c_int64), ("sah_cost", C.c_double), ("sah_cost_built", C.c_double),
+                ("ms_tree", C.c_double), ("ms_fill", C.c_double), ("ms_upload", C.c_double), ("ms_total", C.c_double)]
+
+
 _lib = None
 
 
@@ -59,6 +64,8 @@ def lib():
         L.psdr_hip_render_d_fwd_counted.argtypes = [C.c_void_p, C.POINTER(RenderArgs), C.c_void_p, C.c_void_p, C.POINTER(Counters), C.c_void_p]
         L.psdr_hip_li_lanes.argtypes = [C.c_void_p, C.POINTER(RenderArgs), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
         L.psdr_hip_scene_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.psdr_hip_scene_last_update.argtypes = [C.c_void_p, C.POINTER(UpdateInfo)]
+        L.psdr_hip_scene_check_tree.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.psdr_hip_scene_live_pixels.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int64)]
         _lib = L
     return _lib

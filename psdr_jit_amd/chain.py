@@ -83,12 +83,18 @@ def snapshot_tensors(scene, sensor_id, leaf_of):
         M = leaf_of(m, "to_world_left").reshape(4, 4) @ leaf_of(m, "to_world").reshape(4, 4) @ leaf_of(m, "to_world_right").reshape(4, 4)
         Vw = _xform_pos(M, V)
         Vws.append(Vw)
+        n_edges = m.num_edges() if (scene.opts.sppse > 0 and m.enable_edges) else 0
+        if not Vw.requires_grad:
+            # a mesh none of whose parameters is wanted: its rows carry no gradient, only their count matters (config 5: the floor beside the 81 920-triangle blob)
+            tri_rows.append(torch.zeros((m.num_faces, 22), dtype=F64))
+            if n_edges:
+                sec_rows.append(torch.zeros((n_edges, 6), dtype=F64))
+            continue
         F = torch.as_tensor(np.asarray(m.face_indices, dtype=np.int64))
         tri_rows.append(_process_mesh(Vw, F))
-        if scene.opts.sppse > 0 and m.enable_edges:
+        if n_edges:
             E = torch.as_tensor(np.asarray(m.edge_indices(), dtype=np.int64))
-            if E.numel():
-                sec_rows.append(torch.cat([Vw[E[:, 0]], Vw[E[:, 1]] - Vw[E[:, 0]]], dim=1))
+            sec_rows.append(torch.cat([Vw[E[:, 0]], Vw[E[:, 1]] - Vw[E[:, 0]]], dim=1))
     tri = torch.cat(tri_rows, dim=0)
     sec = torch.cat(sec_rows, dim=0) if sec_rows else torch.zeros((0, 6), dtype=F64)
     cam = pm["Sensor[%d]" % sensor_id]
@@ -99,12 +105,15 @@ def snapshot_tensors(scene, sensor_id, leaf_of):
         fov, near, far = cam._camera_params()
         aspect = float(scene.opts.width) / float(scene.opts.height)
         w2s = _camera_to_sample(fov, near, far, aspect, bool(cam.orthographic)) @ torch.linalg.inv(tw)
-        q0, q1 = [], []
-        for mid, v0, v1 in ids.tolist():
-            q0.append(Vws[mid][v0])
-            q1.append(Vws[mid][v1])
-        q0 = _xform_pos(w2s, torch.stack(q0))
-        q1 = _xform_pos(w2s, torch.stack(q1))
+        # end points of the kept edges, gathered per mesh (config 5 keeps 26 592 edges: one gather per mesh, not one per edge)
+        q0 = torch.zeros((ids.shape[0], 3), dtype=F64)
+        q1 = torch.zeros((ids.shape[0], 3), dtype=F64)
+        for mid in torch.unique(ids[:, 0]).tolist():
+            rows = torch.nonzero(ids[:, 0] == mid).reshape(-1)
+            q0 = q0.index_add(0, rows, Vws[mid][ids[rows, 1]])
+            q1 = q1.index_add(0, rows, Vws[mid][ids[rows, 2]])
+        q0 = _xform_pos(w2s, q0)
+        q1 = _xform_pos(w2s, q1)
         prim = torch.cat([q0[:, :2], q1[:, :2]], dim=1)
     else:
         prim = torch.zeros((0, 4), dtype=F64)

@@ -22,8 +22,7 @@
 #include <vector>
 
 #include "../../../include/psdr_hip.h"
-#include "bvh.h"
-#include "filter.h"
+#include "scene_obj.h"
 #include "edges.h"
 #include "paths.h"
 #include "adjoint.h"
@@ -33,9 +32,8 @@ using namespace psdr;
 
 // ------------------------------------------------------------------------------------------------
 // error plumbing
-static thread_local std::string g_err;
-static int fail(const std::string &msg) { g_err = msg; return 1; }
-#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+// (psdr::api_fail and HIPCHK: scene_obj.h; the message store itself is in the host part of this file)
+[[maybe_unused]] static int fail(const std::string &msg) { return psdr::api_fail(msg); }
 
 // ------------------------------------------------------------------------------------------------
 // device helpers shared by the kernels
@@ -574,87 +572,9 @@ PSDR_TU1(extern) PSDR_TU2(extern) PSDR_TU3(extern) PSDR_TU4(extern) PSDR_TU5(ext
 #endif
 
 // ------------------------------------------------------------------------------------------------
-// host side
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void) hipFree(p); }
-    DevBuf() = default;
-    DevBuf(const DevBuf &) = delete;
-    int upload(const void *src, size_t bytes) {
-        if (bytes == 0) bytes = 16;
-        HIPCHK(hipMalloc(&p, bytes));
-        if (src) HIPCHK(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice)); else HIPCHK(hipMemset(p, 0, bytes));
-        return 0;
-    }
-    template <typename T> const T *as() const { return reinterpret_cast<const T *>(p); }
-};
-
-constexpr unsigned kQueueRing = 1024;
-
-struct psdr_hip_scene {
-    SceneTables T{};
-    DevBuf blob;
-    bool lds = false;                    // scene class 1: staged in LDS (scene_dev.h)
-    bool lean = false;                   // scene class 2: global memory, Diffuse BSDFs + area lights + environment map only
-    bool has_nmap = false;               // a NormalMap BSDF is present (material sweep even without a material table)
-    bool simple_mats = true;             // every BSDF is Diffuse, Microfacet (constants or bitmaps) or a constant RoughConductor (the material sweep of adjoint_mat.h applies)
-    bool lds_mat = false;                // scene class 3: staged in LDS, any BSDF / bitmap parameter, no environment map (forward kernels)
-    size_t smem_bytes = 0;
-    SecEdgeTables E{};
-    std::vector<std::unique_ptr<DevBuf>> bufs;
-    std::vector<SensorDev> sensors;
-    DevBuf counters;
-    DevBuf queues;                       // ring of work-queue heads, one per path-kernel launch
-    DevBuf gstack;                       // traversal-stack entries beyond the LDS part (trav4.h)
-    mutable DevBuf adj_rec;              // per-lane records of the interior adjoint when they do not fit LDS (deep paths), grown on demand
-    mutable size_t adj_rec_bytes = 0;
-    mutable unsigned queue_slot = 0;
-    mutable bool adj_attr_set = false;   // the adjoint kernels' dynamic-LDS limit has been raised on this scene's device
-    int n_leaves = 0, max_depth = 0, grid = 0;
-    long long tex_total = 0;             // floats of all bitmap parameters (psdr_grads.g_tex)
-    std::vector<std::vector<unsigned>> live_host;      // per sensor: the live-pixel mask (empty = every pixel is live), kept for psdr_hip_scene_live_pixels
-    DevBuf hot_map, hot_inv;             // adjoint accumulators kept in LDS: emitter triangles first, then by area (adjoint.h)
-    int n_hot = 0;
-    std::vector<long long> tex_layout;   // [3*n_bsdfs] offsets into g_tex, -1 = constant
-    // The launches of one scene share mutable device scratch - the work-queue ring, the counters, the traversal-stack overflow
-    // `gstack` (indexed by workgroup and thread only) and the adjoint records `adj_rec` (re-allocated when they grow) - while the C
-    // ABI takes a stream per call.  They are therefore SERIALISED ACROSS STREAMS (ScratchGuard below): a call on another stream than
-    // the scene's previous one first makes its stream wait for that call's completion event; calls on one stream order themselves.
-    mutable std::mutex mu;
-    mutable hipEvent_t ev = nullptr;
-    mutable hipStream_t last_stream = nullptr;
-    mutable bool have_last = false;
-    ~psdr_hip_scene() { if (ev) (void) hipEventDestroy(ev); }
-    const float *up(const float *src, size_t n, int &rc) {
-        if (!src) return nullptr;
-        bufs.emplace_back(new DevBuf());
-        rc |= bufs.back()->upload(src, n * sizeof(float));
-        return bufs.back()->as<float>();
-    }
-    const uint8_t *up8(const uint8_t *src, size_t n, int &rc) {
-        if (!src) return nullptr;
-        bufs.emplace_back(new DevBuf());
-        rc |= bufs.back()->upload(src, n);
-        return bufs.back()->as<uint8_t>();
-    }
-};
-
-// one in-flight user of a scene's scratch buffers per stream order (see psdr_hip_scene::mu)
-struct ScratchGuard {
-    const psdr_hip_scene *sc;
-    hipStream_t st;
-    hipError_t err = hipSuccess;
-    ScratchGuard(const psdr_hip_scene *s, void *stream) : sc(s), st((hipStream_t) stream) {
-        sc->mu.lock();
-        if (!sc->ev) err = hipEventCreateWithFlags(&sc->ev, hipEventDisableTiming);
-        if (err == hipSuccess && sc->have_last && sc->last_stream != st) err = hipStreamWaitEvent(st, sc->ev, 0);
-    }
-    ~ScratchGuard() {
-        if (sc->ev && hipEventRecord(sc->ev, st) == hipSuccess) { sc->last_stream = st; sc->have_last = true; }
-        sc->mu.unlock();
-    }
-};
-#define SCRATCH_GUARD(sc, stream) ScratchGuard guard_((sc), (stream)); if (guard_.err != hipSuccess) return fail(std::string("scene scratch serialisation: ") + hipGetErrorString(guard_.err))
+// host side (the scene object, its creation and its updates: scene_obj.h, scene_build.hip)
+static thread_local std::string g_err;
+namespace psdr { int api_fail(const std::string &msg) { g_err = msg; return 1; } }
 
 struct psdr_hip_guiding {
     GuidingDev G{};
@@ -662,523 +582,13 @@ struct psdr_hip_guiding {
     std::vector<float> mass;
 };
 
-// Guide table of a discrete distribution (shade.h::sample_reuse_guided): entry k = the index DiscreteDistribution::sample_reuse finds for the
-// sample k / n_buckets, in the kernels' own float arithmetic (s * sum, then the first i < size - 1 whose running sum is not < s, else size - 1).
-// n_buckets: the power of two nearest to size / 16 (at least 1); tables below 256 entries are not worth one (-> empty).
-// per_bucket: entries left to the binary search (32: one or two cache lines of the large environment / guiding tables; the edge
-// distributions - tens of thousands of entries, read by every edge sample - get 4)
-static void build_cdf_guide(const float *cmf, int size, float sum, std::vector<int> &guide, int per_bucket = 32) {
-    guide.clear();
-    if (size < 256) return;
-    int nb = 1;
-    while (nb * per_bucket <= size) nb <<= 1;
-    guide.resize((size_t) nb + 1);
-    for (int k = 0; k <= nb; ++k) {
-        const float s = ((float) k / (float) nb) * sum;
-        guide[k] = (int) (std::partition_point(cmf, cmf + (size - 1), [s](float c) { return c < s; }) - cmf);
-    }
-}
-
-static inline void put4(std::vector<float> &b, size_t word, float x, float y, float z, float w) { float *q = &b[4 * word]; q[0] = x; q[1] = y; q[2] = z; q[3] = w; }
-static inline float ibits(int32_t v) { float f; std::memcpy(&f, &v, 4); return f; }
-static inline size_t words_for_floats(size_t n) { return (n + 3) / 4; }
 
 extern "C" {
 
 const char *psdr_hip_last_error(void) { return g_err.c_str(); }
-// Conservative screen-space coverage of the scene for one sensor: bit (y * width + x) = some triangle's projection (world_to_sample, a projective map: the
-// image of a triangle in front of the camera is the triangle of its projected vertices) comes within a quarter of a pixel of the pixel's square.  Row by row:
-// the x-extent of the triangle inside the (padded) row slab.  false = no mask (a triangle crosses the camera plane: its image is not a triangle).
-static bool build_live_mask(const psdr_triangles &tr, const float *w2s, int W, int H, std::vector<unsigned> &mask) {
-    const double pad = 0.25;
-    mask.assign(((size_t) W * H + 31) / 32, 0u);
-    for (int t = 0; t < tr.n_triangles; ++t) {
-        double X[3], Y[3];
-        int behind = 0;
-        for (int v = 0; v < 3; ++v) {
-            double p[3];
-            for (int c = 0; c < 3; ++c) p[c] = (double) tr.p0[3 * t + c] + (v == 1 ? (double) tr.e1[3 * t + c] : (v == 2 ? (double) tr.e2[3 * t + c] : 0.0));
-            if (!(std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]))) return false;
-            const double x = w2s[0] * p[0] + w2s[1] * p[1] + w2s[2] * p[2] + w2s[3], y = w2s[4] * p[0] + w2s[5] * p[1] + w2s[6] * p[2] + w2s[7];
-            const double w = w2s[12] * p[0] + w2s[13] * p[1] + w2s[14] * p[2] + w2s[15];
-            if (!(w > 1e-9)) { ++behind; continue; }
-            X[v] = x / w * W; Y[v] = y / w * H;
-        }
-        if (behind == 3) continue;              // behind the camera: no forward ray reaches it
-        if (behind != 0) return false;
-        const double ymin = std::min(Y[0], std::min(Y[1], Y[2])) - pad, ymax = std::max(Y[0], std::max(Y[1], Y[2])) + pad;
-        if (!(ymax >= 0.0 && ymin < (double) H)) continue;
-        const int r0 = (int) std::max(0.0, std::floor(ymin)), r1 = (int) std::min((double) (H - 1), std::floor(ymax));
-        for (int row = r0; row <= r1; ++row) {
-            const double lo = row - pad, hi = row + 1 + pad;
-            double xmin = 1e300, xmax = -1e300;
-            for (int v = 0; v < 3; ++v) {
-                if (Y[v] >= lo && Y[v] <= hi) { xmin = std::min(xmin, X[v]); xmax = std::max(xmax, X[v]); }
-                const int u = (v + 1) % 3;
-                const double dy = Y[u] - Y[v];
-                if (dy != 0.0)
-                    for (double yc : {lo, hi}) {
-                        const double s = (yc - Y[v]) / dy;
-                        if (s >= 0.0 && s <= 1.0) { const double xc = X[v] + s * (X[u] - X[v]); xmin = std::min(xmin, xc); xmax = std::max(xmax, xc); }
-                    }
-            }
-            if (xmin > xmax) continue;
-            xmin -= pad; xmax += pad;
-            if (!(xmax >= 0.0 && xmin < (double) W)) continue;
-            const int c0 = (int) std::max(0.0, std::floor(xmin)), c1 = (int) std::min((double) (W - 1), std::floor(xmax));
-            // bits [b0, b1] of the mask, a word at a time (a wall of the Cornell box at 2048 x 2048 is four million pixels per triangle)
-            const size_t b0 = (size_t) row * W + c0, b1 = (size_t) row * W + c1;
-            for (size_t wi = b0 >> 5; wi <= (b1 >> 5); ++wi) {
-                const unsigned lo_bit = wi == (b0 >> 5) ? (unsigned) (b0 & 31) : 0u, hi_bit = wi == (b1 >> 5) ? (unsigned) (b1 & 31) : 31u;
-                const unsigned m_hi = hi_bit == 31u ? 0xffffffffu : ((1u << (hi_bit + 1u)) - 1u);
-                mask[wi] |= m_hi & ~((1u << lo_bit) - 1u);
-            }
-        }
-    }
-    return true;
-}
-
 int psdr_hip_abi_version(void) { return PSDR_HIP_ABI_VERSION; }
 int psdr_hip_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 int psdr_hip_set_device(int device) { HIPCHK(hipSetDevice(device)); return 0; }
-
-int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
-    if (!s || !out) return fail("psdr_hip_scene_create: null argument");
-    if (s->abi_version != PSDR_HIP_ABI_VERSION) return fail("psdr_hip_scene_create: ABI version mismatch");
-    const psdr_triangles &tr = s->tris;
-    const int n = tr.n_triangles;
-    if (n <= 0) return fail("Missing meshes!");
-    if (s->n_sensors <= 0) return fail("Missing sensor!");
-    auto sc = std::make_unique<psdr_hip_scene>();
-
-    BvhResult bvh;
-    build_bvh(tr.p0, tr.e1, tr.e2, n, bvh);
-    Bvh4Result bvh4;
-    build_bvh4(bvh, n, bvh4);
-    std::vector<int32_t> orig2slot(n);
-    for (int slot = 0; slot < n; ++slot) orig2slot[bvh.order[slot]] = slot;
-
-    const bool has_tan = tr.d_p0 != nullptr;
-    SceneTables &T = sc->T;
-    size_t w = 0;
-    T.nodes_off = (int) w; w += (size_t) (kNodeFloats / 4) * (size_t) bvh4.n_nodes;      // nodes of the 4-wide tree (bvh.h: 64 bytes each)
-    T.trav_off = (int) w;  w += 3 * (size_t) n;
-    T.shade_off = (int) w; w += 6 * (size_t) n;
-    T.tan_off = (int) w;   w += has_tan ? 6 * (size_t) n : 0;
-    T.map_off = (int) w;   w += words_for_floats(n);
-    T.mesh_off = (int) w;  w += 2 * (size_t) s->n_meshes;
-    T.bsdf_off = (int) w;  w += 2 * (size_t) std::max(1, s->n_bsdfs);
-    T.emit_off = (int) w;  w += 2 * (size_t) std::max(1, s->n_emitters);
-    T.ecdf_off = (int) w;  w += words_for_floats(2 * (size_t) std::max(1, s->n_emitters));
-    T.fcdf_off = (int) w;  w += words_for_floats(2 * (size_t) std::max(1, s->n_face_distrb));
-    T.env_emitter = -1;
-    for (int i = 0; i < s->n_emitters; ++i) if (s->emitters[i].type == 1) T.env_emitter = i;
-    if (T.env_emitter >= 0) {
-        const psdr_envmap_rec *er = s->envmap;
-        if (!er || !er->radiance || !er->cell_pmf || !er->cell_cmf || er->width < 2 || er->height < 2) return fail("EnvironmentMap emitter without a configured psdr_envmap_rec");
-        EnvDev &ED = T.env;
-        int rc = 0;
-        const size_t cells = (size_t) er->reso[0] * er->reso[1];
-        ED.radiance = sc->up(er->radiance, (size_t) 3 * er->width * er->height, rc);
-        ED.cell_pmf = sc->up(er->cell_pmf, cells, rc);
-        ED.cell_cmf = sc->up(er->cell_cmf, cells, rc);
-        ED.d_radiance = sc->up(er->d_radiance, (size_t) 3 * er->width * er->height, rc);
-        ED.cell_guide = nullptr; ED.guide_n = 0;
-        {
-            std::vector<int> guide;
-            build_cdf_guide(er->cell_cmf, (int) cells, er->cell_sum, guide);
-            if (!guide.empty()) {
-                sc->bufs.emplace_back(new DevBuf());
-                rc |= sc->bufs.back()->upload(guide.data(), guide.size() * sizeof(int));
-                ED.cell_guide = sc->bufs.back()->as<int>(); ED.guide_n = (int) guide.size() - 1;
-            }
-        }
-        if (rc) return 1;
-        ED.width = er->width; ED.height = er->height; ED.reso0 = er->reso[0]; ED.reso1 = er->reso[1]; ED.num_cells = (int) cells;
-        ED.scale = er->scale; ED.cell_sum = er->cell_sum;
-        std::memcpy(ED.to_world.m, er->to_world, 64); std::memcpy(ED.from_world.m, er->from_world, 64);
-        std::memcpy(ED.d_from_world.m, er->d_from_world, 64); ED.d_scale = er->d_scale;
-        for (int k = 0; k < 3; ++k) { ED.lower[k] = er->lower[k]; ED.upper[k] = er->upper[k]; }
-        for (int k = 0; k < 4; ++k) { ED.xf[k] = er->radiance_xf[k]; ED.d_xf[k] = er->d_radiance_xf[k]; }
-    }
-    T.tex = nullptr;
-    {   // bitmap parameters: three slots per BSDF - [0] reflectance / diffuse reflectance (rgb), [1] specular (rgb), [2] roughness (1 channel)
-        bool any_tex = false;
-        for (int i = 0; i < s->n_bsdfs; ++i) any_tex |= s->bsdfs[i].tex_data != nullptr || s->bsdfs[i].spec_tex_data != nullptr || s->bsdfs[i].rough_tex_data != nullptr;
-        if (any_tex) {
-            std::vector<TexDev> td((size_t) 3 * s->n_bsdfs, TexDev{nullptr, nullptr, 0, 0, -1, {0.f, 1.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}});
-            sc->tex_total = 0;
-            int rc = 0;
-            for (int i = 0; i < s->n_bsdfs; ++i) {
-                const psdr_bsdf_rec &b = s->bsdfs[i];
-                const float *src[3] = {b.tex_data, b.spec_tex_data, b.rough_tex_data}, *dsrc[3] = {b.d_tex_data, b.d_spec_tex_data, b.d_rough_tex_data};
-                const int tw[3] = {b.tex_width, b.spec_tex_width, b.rough_tex_width}, th[3] = {b.tex_height, b.spec_tex_height, b.rough_tex_height};
-                for (int k = 0; k < 3; ++k) {
-                    if (!src[k]) continue;
-                    if (k > 0 && b.type != 1 && b.type != 2 && !(b.type == 3 && k == 2)) return fail("this BSDF type has no second / third bitmap parameter");
-                    if (tw[k] < 2 || th[k] < 2) return fail("Bitmap: invalid resolution!");
-                    const size_t nt = (size_t) (k == 2 ? 1 : 3) * tw[k] * th[k];
-                    td[3 * i + k].data = sc->up(src[k], nt, rc);
-                    td[3 * i + k].d_data = sc->up(dsrc[k], nt, rc);
-                    td[3 * i + k].w = tw[k]; td[3 * i + k].h = th[k];
-                    td[3 * i + k].g_off = sc->tex_total; sc->tex_total += (long long) nt;
-                    for (int q = 0; q < 4; ++q) { td[3 * i + k].xf[q] = b.tex_xf[k][q]; td[3 * i + k].d_xf[q] = b.d_tex_xf[k][q]; }
-                }
-            }
-            sc->bufs.emplace_back(new DevBuf());
-            rc |= sc->bufs.back()->upload(td.data(), td.size() * sizeof(TexDev));
-            if (rc) return 1;
-            T.tex = sc->bufs.back()->as<TexDev>();
-            sc->tex_layout.resize(td.size());
-            for (size_t i = 0; i < td.size(); ++i) sc->tex_layout[i] = td[i].g_off;
-        }
-    }
-    T.mat = nullptr;
-    {
-        bool any = false;
-        for (int i = 0; i < s->n_bsdfs; ++i) {
-            if (s->bsdfs[i].type < 0 || s->bsdfs[i].type > 5) return fail("Unknown BSDF type!");
-            any |= s->bsdfs[i].type != 0;
-        }
-        if (any) {
-            std::vector<MatDev> md((size_t) s->n_bsdfs);
-            for (int i = 0; i < s->n_bsdfs; ++i) {
-                const psdr_bsdf_rec &b = s->bsdfs[i];
-                for (int k = 0; k < 3; ++k) { md[i].specular[k] = b.specular[k]; md[i].d_specular[k] = b.d_specular[k]; }
-                md[i].roughness = b.roughness; md[i].d_roughness = b.d_roughness;
-                md[i].alpha_u = b.alpha_u; md[i].alpha_v = b.alpha_v; md[i].d_alpha_u = b.d_alpha_u; md[i].d_alpha_v = b.d_alpha_v;
-                for (int k = 0; k < 3; ++k) { md[i].eta[k] = b.eta[k]; md[i].d_eta[k] = b.d_eta[k]; md[i].k[k] = b.k[k]; md[i].d_k[k] = b.d_k[k]; }
-            }
-            sc->bufs.emplace_back(new DevBuf());
-            if (sc->bufs.back()->upload(md.data(), md.size() * sizeof(MatDev))) return 1;
-            T.mat = sc->bufs.back()->as<MatDev>();
-        }
-    }
-    T.pv = nullptr; T.tri_fi = nullptr;
-    {   // MicrofacetPerVertex: parameter arrays per BSDF + the mesh-local vertex ids of every triangle slot
-        bool any_pv = false;
-        for (int i = 0; i < s->n_bsdfs; ++i) any_pv |= s->bsdfs[i].type == 4;
-        if (any_pv) {
-            if (!tr.face_indices) return fail("MicrofacetPerVertex needs psdr_triangles.face_indices");
-            std::vector<PvDev> pd((size_t) s->n_bsdfs, PvDev{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, {-1, -1, -1}});
-            if (sc->tex_layout.size() < (size_t) 3 * s->n_bsdfs) sc->tex_layout.resize((size_t) 3 * s->n_bsdfs, -1);
-            int rc = 0;
-            for (int i = 0; i < s->n_bsdfs; ++i) {
-                const psdr_bsdf_rec &b = s->bsdfs[i];
-                if (b.type != 4) continue;
-                if (b.pv_count <= 0 || !b.pv_specular || !b.pv_diffuse || !b.pv_roughness) return fail("MicrofacetPerVertex: missing per-vertex data");
-                const size_t nv = (size_t) b.pv_count;
-                pd[i].spec = sc->up(b.pv_specular, 3 * nv, rc); pd[i].d_spec = sc->up(b.d_pv_specular, 3 * nv, rc);
-                pd[i].diff = sc->up(b.pv_diffuse, 3 * nv, rc); pd[i].d_diff = sc->up(b.d_pv_diffuse, 3 * nv, rc);
-                pd[i].rough = sc->up(b.pv_roughness, nv, rc); pd[i].d_rough = sc->up(b.d_pv_roughness, nv, rc);
-                pd[i].n = b.pv_count;
-                // adjoint blocks in psdr_grads.g_tex, numbered like Microfacet's maps: 0 diffuse, 1 specular, 2 roughness
-                const size_t sizes[3] = {3 * nv, 3 * nv, nv};
-                for (int k = 0; k < 3; ++k) { pd[i].g_off[k] = sc->tex_total; sc->tex_layout[3 * (size_t) i + k] = sc->tex_total; sc->tex_total += (long long) sizes[k]; }
-            }
-            // every mesh that uses a per-vertex BSDF must index inside its arrays
-            for (int i = 0; i < n; ++i) {
-                const int bid = s->meshes[tr.mesh_id[i]].bsdf_id;
-                if (bid >= 0 && s->bsdfs[bid].type == 4)
-                    for (int k = 0; k < 3; ++k)
-                        if (tr.face_indices[3 * i + k] < 0 || tr.face_indices[3 * i + k] >= s->bsdfs[bid].pv_count) return fail("MicrofacetPerVertex: fewer values than mesh vertices");
-            }
-            std::vector<int> fi((size_t) 3 * n);
-            for (int slot = 0; slot < n; ++slot)
-                for (int k = 0; k < 3; ++k) fi[3 * (size_t) slot + k] = tr.face_indices[3 * (size_t) bvh.order[slot] + k];
-            sc->bufs.emplace_back(new DevBuf());
-            rc |= sc->bufs.back()->upload(fi.data(), fi.size() * sizeof(int));
-            T.tri_fi = sc->bufs.back()->as<int>();
-            sc->bufs.emplace_back(new DevBuf());
-            rc |= sc->bufs.back()->upload(pd.data(), pd.size() * sizeof(PvDev));
-            if (rc) return 1;
-            T.pv = sc->bufs.back()->as<PvDev>();
-        }
-    }
-    {   // hot triangles of the reverse-mode accumulators: emitter meshes first, then by area, at most kHotMax
-        constexpr int kHotMax = 720;                                   // 720 x 22 floats = 62 KB of LDS
-        std::vector<int> ord((size_t) n);
-        std::vector<float> key((size_t) n);
-        for (int i = 0; i < n; ++i) {
-            ord[i] = i;
-            const float *a1 = tr.e1 + 3 * (size_t) i, *a2 = tr.e2 + 3 * (size_t) i;
-            const float cx = a1[1] * a2[2] - a1[2] * a2[1], cy = a1[2] * a2[0] - a1[0] * a2[2], cz = a1[0] * a2[1] - a1[1] * a2[0];
-            const bool emit = s->meshes[tr.mesh_id[i]].emitter_id >= 0;
-            key[i] = std::sqrt(cx * cx + cy * cy + cz * cz) * (emit ? 1e30f : 1.f);
-        }
-        std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return key[x] > key[y]; });
-        sc->n_hot = std::min(n, kHotMax);
-        std::vector<int> hmap((size_t) std::max(1, n), -1), hinv((size_t) std::max(1, sc->n_hot), 0);
-        for (int h = 0; h < sc->n_hot; ++h) { hmap[ord[h]] = h; hinv[h] = ord[h]; }
-        if (sc->hot_map.upload(hmap.data(), hmap.size() * sizeof(int)) || sc->hot_inv.upload(hinv.data(), hinv.size() * sizeof(int))) return 1;
-    }
-    std::vector<FilterPrim> filt;
-    build_filter_prims(tr.p0, tr.e1, tr.e2, bvh.order.data(), n, filt);
-    T.filt_off = (int) w;  w += 6 * filt.size();
-    T.n_filt = (int) filt.size();
-    {   // bounding sphere of the scene (for the absolute slack of the quad filter)
-        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-        for (int i = 0; i < n; ++i)
-            for (int v = 0; v < 3; ++v)
-                for (int k = 0; k < 3; ++k) {
-                    const double x = (double) tr.p0[3 * i + k] + (v == 1 ? (double) tr.e1[3 * i + k] : v == 2 ? (double) tr.e2[3 * i + k] : 0.0);
-                    lo[k] = std::min(lo[k], x); hi[k] = std::max(hi[k], x);
-                }
-        double r2 = 0.0;
-        for (int k = 0; k < 3; ++k) { T.center[k] = n > 0 ? (float) (0.5 * (lo[k] + hi[k])) : 0.f; r2 += n > 0 ? 0.25 * (hi[k] - lo[k]) * (hi[k] - lo[k]) : 0.0; }
-        T.radius = (float) (std::sqrt(r2) * 1.0001);
-    }
-    const psdr_sec_edges &se = s->sec_edges;
-    SecEdgeTables &E = sc->E;
-    E.n = se.n_edges; E.sum = se.sum;
-    E.guide = nullptr; E.guide_n = 0;
-    if (se.n_edges > 0 && se.cmf) {              // every sample of the secondary-edge term starts with this search (17 dependent loads for config 5's 122 885 edges)
-        std::vector<int> guide;
-        build_cdf_guide(se.cmf, se.n_edges, se.sum, guide, 4);
-        if (!guide.empty()) {
-            sc->bufs.emplace_back(new DevBuf());
-            if (sc->bufs.back()->upload(guide.data(), guide.size() * sizeof(int))) return 1;
-            E.guide = sc->bufs.back()->as<int>(); E.guide_n = (int) guide.size() - 1;
-        }
-    }
-    E.off = (int) w;       w += 6 * (size_t) std::max(0, se.n_edges);
-    E.cdf_off = (int) w;   w += words_for_floats(2 * (size_t) std::max(1, se.n_edges));
-    std::vector<std::pair<int, int>> pe_offs;
-    for (int i = 0; i < s->n_sensors; ++i) {
-        const int ne = std::max(0, s->sensors[i].n_edges);
-        const int o1 = (int) w; w += 3 * (size_t) ne;
-        const int o2 = (int) w; w += words_for_floats(2 * (size_t) std::max(1, ne));
-        pe_offs.emplace_back(o1, o2);
-    }
-    T.blob_words = (int) w;
-    T.n_nodes = bvh4.n_nodes; T.n_tris = n; T.n_meshes = s->n_meshes; T.n_bsdfs = s->n_bsdfs; T.n_emitters = s->n_emitters;
-    T.n_fcdf = s->n_face_distrb; T.has_tangent = has_tan ? 1 : 0;
-    T.ref_bits = bvh4.ref_bits;
-    // traversal stack: the first kStackLds entries of a lane in LDS, deeper ones in a per-lane global array (trav4.h);
-    // scenes that are traced by brute force (<= kBruteForceMax triangles) need neither
-    static const int kStackLds = std::getenv("PSDR_STACK_LDS") ? std::atoi(std::getenv("PSDR_STACK_LDS")) : 8;      // 8 + kTravRows = 40 KB per workgroup: four workgroups per CU
-    const bool uses_bvh = n > kBruteForceMax;
-    T.stack_lds = uses_bvh ? std::min(kStackLds, bvh4.max_stack) : 0;
-#ifdef PSDR_NO_ASYNC
-    T.stack_depth = (uses_bvh ? T.stack_lds + kTravRows : 0) + kColdRows;
-#else
-    T.stack_depth = uses_bvh ? T.stack_lds + kTravRows : kColdRows;   // BVH: + parked rays, best hits and the pair ring of the traversal (trav4.h); brute force: cold path state (paths.h)
-#endif
-    T.gstack = nullptr; T.gstack_stride = 0;
-    T.emitter_sum = s->emitter_sum;
-    T.width = s->width; T.height = s->height; T.spp = s->spp; T.sppe = s->sppe; T.sppse = s->sppse;
-
-    std::vector<float> blob(4 * w, 0.f);
-    std::memcpy(&blob[4 * (size_t) T.nodes_off], bvh4.nodes.data(), sizeof(float) * bvh4.nodes.size());
-    for (int slot = 0; slot < n; ++slot) {
-        const int o = bvh.order[slot];
-        const float *p0 = tr.p0 + 3 * o, *e1 = tr.e1 + 3 * o, *e2 = tr.e2 + 3 * o;
-        put4(blob, T.trav_off + 3 * (size_t) slot, p0[0], p0[1], p0[2], e1[0]);
-        put4(blob, T.trav_off + 3 * (size_t) slot + 1, e1[1], e1[2], e2[0], e2[1]);
-        put4(blob, T.trav_off + 3 * (size_t) slot + 2, e2[2], ibits(o), 0.f, 0.f);
-        const float *n0 = tr.n0 + 3 * o, *n1 = tr.n1 + 3 * o, *n2 = tr.n2 + 3 * o, *fn = tr.face_normal + 3 * o;
-        const size_t sw = T.shade_off + 6 * (size_t) slot;
-        put4(blob, sw, n0[0], n0[1], n0[2], tr.face_area[o]);
-        put4(blob, sw + 1, n1[0], n1[1], n1[2], ibits(tr.mesh_id[o]));
-        put4(blob, sw + 2, n2[0], n2[1], n2[2], ibits(tr.use_face_normal && tr.use_face_normal[o] ? 1 : 0));
-        put4(blob, sw + 3, fn[0], fn[1], fn[2], ibits(o));
-        if (tr.uv) {
-            const float *uv = tr.uv + 6 * o;
-            put4(blob, sw + 4, uv[0], uv[1], uv[2], uv[3]);
-            put4(blob, sw + 5, uv[4], uv[5], 0.f, 0.f);
-        }
-        if (has_tan) {
-            const float *a = tr.d_p0 + 3 * o, *b = tr.d_e1 + 3 * o, *c = tr.d_e2 + 3 * o, *d0 = tr.d_n0 + 3 * o, *d1 = tr.d_n1 + 3 * o,
-                        *d2 = tr.d_n2 + 3 * o, *df = tr.d_face_normal + 3 * o;
-            const size_t tw = T.tan_off + 6 * (size_t) slot;
-            put4(blob, tw, a[0], a[1], a[2], b[0]);
-            put4(blob, tw + 1, b[1], b[2], c[0], c[1]);
-            put4(blob, tw + 2, c[2], d0[0], d0[1], d0[2]);
-            put4(blob, tw + 3, d1[0], d1[1], d1[2], d2[0]);
-            put4(blob, tw + 4, d2[1], d2[2], df[0], df[1]);
-            put4(blob, tw + 5, df[2], tr.d_face_area[o], 0.f, 0.f);
-        }
-    }
-    for (int i = 0; i < n; ++i) blob[4 * (size_t) T.map_off + i] = ibits(orig2slot[i]);
-    T.filt_kmax = 0.f;
-    T.filt_hasb[0] = T.filt_hasb[1] = 0u;
-    for (size_t i = 0; i < filt.size(); ++i) {
-        // dot-product form of the filter (scene_dev.h::trace2): with oc = o - centre, m = oc x d and p = p0 - centre
-        //   u-numerator = m.e2 + d.(p x e2)   v-numerator = d.(e1 x p) - m.e1   -det = d.(e1 x e2)   t-numerator = oc.(e1 x e2) - p.(e1 x e2)
-        const FilterPrim &f = filt[i];
-        const size_t fw = T.filt_off + 6 * i;
-        {
-            const size_t base = i & ~(size_t) 31, cnt = std::min<size_t>(32, filt.size() - base);
-            if (f.slot_b >= 0) T.filt_hasb[i >> 5] |= 1u << (cnt - 1 - (i - base));
-        }
-        const double p[3] = {(double) f.p0[0] - (double) T.center[0], (double) f.p0[1] - (double) T.center[1], (double) f.p0[2] - (double) T.center[2]};
-        const double e1[3] = {f.e1[0], f.e1[1], f.e1[2]}, e2[3] = {f.e2[0], f.e2[1], f.e2[2]};
-        auto crs = [](const double *a, const double *b, double *c) { c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0]; };
-        double A[3], B[3], N[3];
-        crs(p, e2, A); crs(e1, p, B); crs(e1, e2, N);
-        const double npn = -(p[0] * N[0] + p[1] * N[1] + p[2] * N[2]);
-        const double K = std::max({std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]), std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]), (double) f.k16 * 32768.0});
-        T.filt_kmax = std::max(T.filt_kmax, (float) (K * 1.0001));
-        put4(blob, fw, f.e2[0], f.e2[1], f.e2[2], (float) A[0]);
-        put4(blob, fw + 1, (float) A[1], (float) A[2], f.e1[0], f.e1[1]);
-        put4(blob, fw + 2, f.e1[2], (float) B[0], (float) B[1], (float) B[2]);
-        put4(blob, fw + 3, (float) N[0], (float) N[1], (float) N[2], (float) npn);
-        put4(blob, fw + 4, f.umax, f.vmax, f.smax, f.da);
-        put4(blob, fw + 5, f.db, f.da + f.db, (float) (K * (1.0001 / 32768.0)), ibits(f.slot_a | ((f.slot_b < 0 ? 0xff : f.slot_b) << 8)));
-    }
-    for (int i = 0; i < s->n_meshes; ++i) {
-        const psdr_mesh_rec &m = s->meshes[i];
-        put4(blob, T.mesh_off + 2 * (size_t) i, ibits(m.bsdf_id), ibits(m.emitter_id), ibits(m.face_offset), ibits(m.n_faces));
-        put4(blob, T.mesh_off + 2 * (size_t) i + 1, m.inv_total_area, ibits(m.distrb_offset), m.distrb_sum, 0.f);
-    }
-    for (int i = 0; i < s->n_bsdfs; ++i) {
-        const psdr_bsdf_rec &b = s->bsdfs[i];
-        if (b.type < 0 || b.type > 5) return fail("Unknown BSDF type!");
-        if (b.type == 5 && (b.nested_bsdf < 0 || b.nested_bsdf >= s->n_bsdfs || s->bsdfs[b.nested_bsdf].type == 5)) return fail("NormalMap: invalid nested BSDF");
-        // (a NormalMap, type 5, is its nested BSDF seen through the map: the nested record is an entry of its own and decides)
-        // (round 3: the bitmap parameters of RoughConductor / RoughDielectric joined the sweep - every BSDF type qualifies now)
-        if (!(b.type >= 0 && b.type <= 5)) sc->simple_mats = false;
-        if (b.type == 5) sc->has_nmap = true;
-        put4(blob, T.bsdf_off + 2 * (size_t) i, b.reflectance[0], b.reflectance[1], b.reflectance[2], ibits((b.two_sided ? 1 : 0) | (b.tex_data ? 2 : 0) | (b.type == 1 ? 4 : 0) | (b.type == 2 ? 8 : 0) | (b.type == 3 ? 16 : 0) | (b.spec_tex_data ? 32 : 0) | (b.rough_tex_data ? 64 : 0) | (b.type == 4 ? 128 : 0) | (b.type == 5 ? 256 : 0)));
-        put4(blob, T.bsdf_off + 2 * (size_t) i + 1, b.d_reflectance[0], b.d_reflectance[1], b.d_reflectance[2], ibits(b.type == 5 ? b.nested_bsdf : -1));
-    }
-    for (int i = 0; i < s->n_emitters; ++i) {
-        const psdr_emitter_rec &e = s->emitters[i];
-        put4(blob, T.emit_off + 2 * (size_t) i, e.radiance[0], e.radiance[1], e.radiance[2], e.sampling_weight);
-        put4(blob, T.emit_off + 2 * (size_t) i + 1, e.d_radiance[0], e.d_radiance[1], e.d_radiance[2], ibits(e.mesh_id));
-        blob[4 * (size_t) T.ecdf_off + i] = s->emitter_pmf ? s->emitter_pmf[i] : 1.f;
-        blob[4 * (size_t) T.ecdf_off + s->n_emitters + i] = s->emitter_cmf ? s->emitter_cmf[i] : 1.f;
-    }
-    for (int i = 0; i < s->n_face_distrb; ++i) {
-        blob[4 * (size_t) T.fcdf_off + i] = s->face_pmf[i];
-        blob[4 * (size_t) T.fcdf_off + s->n_face_distrb + i] = s->face_cmf[i];
-    }
-    for (int i = 0; i < se.n_edges; ++i) {
-        const float *p0 = se.p0 + 3 * i, *e1 = se.e1 + 3 * i, *n0 = se.n0 + 3 * i, *n1 = se.n1 + 3 * i, *p2 = se.p2 + 3 * i;
-        const float z3[3] = {0.f, 0.f, 0.f};
-        const float *dp0 = se.d_p0 ? se.d_p0 + 3 * i : z3, *de1 = se.d_e1 ? se.d_e1 + 3 * i : z3;
-        const size_t ew = E.off + 6 * (size_t) i;
-        put4(blob, ew, p0[0], p0[1], p0[2], e1[0]);
-        put4(blob, ew + 1, e1[1], e1[2], n0[0], n0[1]);
-        put4(blob, ew + 2, n0[2], n1[0], n1[1], n1[2]);
-        put4(blob, ew + 3, p2[0], p2[1], p2[2], ibits(se.is_boundary[i] ? 1 : 0));
-        put4(blob, ew + 4, dp0[0], dp0[1], dp0[2], de1[0]);
-        put4(blob, ew + 5, de1[1], de1[2], 0.f, 0.f);
-        blob[4 * (size_t) E.cdf_off + i] = se.pmf[i];
-        blob[4 * (size_t) E.cdf_off + se.n_edges + i] = se.cmf[i];
-    }
-    for (int k = 0; k < s->n_sensors; ++k) {
-        const psdr_sensor_rec &r = s->sensors[k];
-        for (int i = 0; i < r.n_edges; ++i) {
-            const size_t pw = pe_offs[k].first + 3 * (size_t) i;
-            put4(blob, pw, r.edge_p0[2 * i], r.edge_p0[2 * i + 1], r.edge_p1[2 * i], r.edge_p1[2 * i + 1]);
-            put4(blob, pw + 1, r.d_edge_p0 ? r.d_edge_p0[2 * i] : 0.f, r.d_edge_p0 ? r.d_edge_p0[2 * i + 1] : 0.f,
-                 r.d_edge_p1 ? r.d_edge_p1[2 * i] : 0.f, r.d_edge_p1 ? r.d_edge_p1[2 * i + 1] : 0.f);
-            put4(blob, pw + 2, r.edge_normal[2 * i], r.edge_normal[2 * i + 1], r.edge_length[i], 0.f);
-            blob[4 * (size_t) pe_offs[k].second + i] = r.edge_pmf[i];
-            blob[4 * (size_t) pe_offs[k].second + r.n_edges + i] = r.edge_cmf[i];
-        }
-    }
-    if (sc->blob.upload(blob.data(), blob.size() * sizeof(float))) return 1;
-
-    const size_t stack_bytes = (size_t) T.stack_depth * kBlock * sizeof(int);
-    const size_t blob_bytes = (size_t) T.blob_words * 16;
-    // keeps >= 4 workgroups per CU (160 KiB LDS); the environment-map and texture code lives in the LDS=false kernels only (shade.h)
-    static const bool no_lds = std::getenv("PSDR_NO_LDS") != nullptr;      // measurement knob: run small scenes through the global-memory classes
-    sc->lds = !no_lds && !uses_bvh && blob_bytes + stack_bytes <= 40 * 1024 && T.env_emitter < 0 && T.tex == nullptr && T.mat == nullptr && T.pv == nullptr;      // (LDS class = brute-force scenes)
-    sc->lean = !sc->lds && T.tex == nullptr && T.mat == nullptr && T.pv == nullptr;
-    // class 3: the same staging for small scenes WITH materials / bitmap parameters (the material and texture tables stay in global
-    // memory; the triangle, BSDF, emitter and edge tables are what every path vertex reads)
-    sc->lds_mat = !no_lds && !sc->lds && !uses_bvh && blob_bytes + stack_bytes <= 40 * 1024 && T.env_emitter < 0 && T.pv == nullptr;
-    sc->smem_bytes = ((sc->lds || sc->lds_mat) ? blob_bytes : 0) + stack_bytes;
-    if (sc->smem_bytes > 64 * 1024) return fail("BVH too deep for the LDS traversal stack");
-    sc->n_leaves = bvh.n_leaves; sc->max_depth = bvh4.max_depth;
-
-    for (int i = 0; i < s->n_sensors; ++i) {
-        const psdr_sensor_rec &r = s->sensors[i];
-        SensorDev d{};
-        d.live = nullptr;
-        {
-            std::vector<unsigned> live;
-            static const bool no_live = std::getenv("PSDR_NO_LIVE_MASK") != nullptr;       // measurement knob
-            bool use = !no_live && T.env_emitter < 0 && (long long) s->width * s->height * std::max(1, s->spp) < (1ll << 31) && build_live_mask(s->tris, r.world_to_sample, s->width, s->height, live);
-            if (use) {       // worth a window of bit tests per regeneration only when a good part of the frame is dead (the sphere box, all of it live: +1.7 % with the mask)
-                long long n_set = 0;
-                for (unsigned w : live) n_set += __builtin_popcount(w);
-                use = n_set * 4 <= (long long) s->width * s->height * 3;
-            }
-            if (use) {
-                sc->bufs.emplace_back(new DevBuf());
-                if (sc->bufs.back()->upload(live.data(), live.size() * sizeof(unsigned))) return 1;
-                d.live = sc->bufs.back()->as<unsigned>();
-            } else live.clear();
-            sc->live_host.push_back(live);
-        }
-        std::memcpy(d.sample_to_camera.m, r.sample_to_camera, 64); std::memcpy(d.to_world.m, r.to_world, 64);
-        std::memcpy(d.d_to_world.m, r.d_to_world, 64); std::memcpy(d.world_to_sample.m, r.world_to_sample, 64);
-        std::memcpy(d.d_world_to_sample.m, r.d_world_to_sample, 64);
-        for (int k = 0; k < 3; ++k) { d.cam_pos[k] = r.cam_pos[k]; d.cam_dir[k] = r.cam_dir[k]; }
-        d.inv_area = r.inv_area; d.n_edges = r.n_edges; d.edge_sum = r.edge_sum; d.ortho = r.orthographic;
-        d.pe_off = pe_offs[i].first; d.pecdf_off = pe_offs[i].second;
-        d.pe_guide = nullptr; d.pe_guide_n = 0;
-        if (r.n_edges > 0 && r.edge_cmf) {       // a sample of the primary-edge term starts with this search (15 dependent loads for config 5's 26 592 edges)
-            std::vector<int> guide;
-            build_cdf_guide(r.edge_cmf, r.n_edges, r.edge_sum, guide, 4);
-            if (!guide.empty()) {
-                sc->bufs.emplace_back(new DevBuf());
-                if (sc->bufs.back()->upload(guide.data(), guide.size() * sizeof(int))) return 1;
-                d.pe_guide = sc->bufs.back()->as<int>(); d.pe_guide_n = (int) guide.size() - 1;
-            }
-        }
-        sc->sensors.push_back(d);
-    }
-    if (sc->counters.upload(nullptr, sizeof(Counters))) return 1;
-    if (sc->queues.upload(nullptr, sizeof(unsigned long long) * kQueueRing)) return 1;
-
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount; }
-    {   // workgroups per launch: a multiple of what fits on the device (persistent workgroups pull work until the launch's queue is empty; the ones that start late find it empty)
-        // (measured, tools/ab_env.sh: brute-force scenes 4 per CU - what is resident at most - C3 forward -0.5 %, its backward pass 8.28 -> 8.06 ms; BVH scenes 8: config 5 218.7 ms, with 4 220.1)
-        static const int per_cu_env = std::getenv("PSDR_GRID_PER_CU") ? std::max(1, std::atoi(std::getenv("PSDR_GRID_PER_CU"))) : 0;      // measurement knob
-        sc->grid = cus * (per_cu_env > 0 ? per_cu_env : (sc->T.n_tris > kBruteForceMax ? 8 : 4));
-    }
-    if (uses_bvh && bvh4.max_stack > T.stack_lds) {
-        // stack entries beyond the LDS part: one int per entry and lane of the largest grid any kernel is launched with
-        const size_t stride = (size_t) sc->grid * kBlock;
-        if (sc->gstack.upload(nullptr, sizeof(int) * stride * (size_t) (bvh4.max_stack - T.stack_lds))) return 1;
-        T.gstack = (int *) sc->gstack.p; T.gstack_stride = (int) stride;
-    }
-    *out = sc.release();
-    return 0;
-}
-
-int psdr_hip_scene_destroy(psdr_hip_scene *scene) { delete scene; return 0; }
-int psdr_hip_bvh_node_bytes(void) { return kNodeFloats * 4; }
-
-int psdr_hip_scene_stats(const psdr_hip_scene *sc, int32_t *n_nodes, int32_t *n_leaves, int32_t *max_depth, int32_t *lds_bytes) {
-    if (!sc) return fail("null scene");
-    if (n_nodes) *n_nodes = sc->T.n_nodes;
-    if (n_leaves) *n_leaves = sc->n_leaves;
-    if (max_depth) *max_depth = sc->max_depth;
-    if (lds_bytes) *lds_bytes = (int32_t) sc->smem_bytes * (sc->lds ? 1 : -1);
-    return 0;
-}
-
-int psdr_hip_scene_live_pixels(const psdr_hip_scene *sc, int32_t sensor_id, uint32_t *bits, int64_t *n_live) {
-    if (!sc) return fail("null scene");
-    if (sensor_id < 0 || sensor_id >= (int) sc->live_host.size()) return fail("Invalid sensor id!");
-    const std::vector<unsigned> &m = sc->live_host[sensor_id];
-    const long long npx = (long long) sc->T.width * sc->T.height;
-    long long count = 0;
-    for (long long i = 0; i < (npx + 31) / 32; ++i) {
-        unsigned w = m.empty() ? 0xffffffffu : m[(size_t) i];
-        if (i == (npx + 31) / 32 - 1 && (npx & 31)) w &= (1u << (npx & 31)) - 1u;
-        if (bits) bits[i] = w;
-        count += __builtin_popcount(w);
-    }
-    if (n_live) *n_live = count;
-    return 0;
-}
 
 } // extern "C"
 

@@ -1,33 +1,153 @@
-// bvh.h — host-side builder of the software BVH that replaces the OptiX GAS
-// (reference src/scene/scene_optix.cpp:265-332 builds a geometry acceleration structure with
-// optixAccelBuild; MI355X has no ray-tracing unit, so traversal is a HIP loop over this tree).
+// bvh.h — the software BVH that replaces the OptiX GAS (reference src/scene/scene_optix.cpp:265-332 builds a geometry acceleration
+// structure with optixAccelBuild in every Scene::configure; MI355X has no ray-tracing unit, so traversal is a HIP loop over this tree,
+// trav4.h).  Host side: the builder (binned SAH over all three axes, multi-threaded) and the collapse into 4-wide nodes.  Shared with
+// the device: the box of a triangle and the quantisation of a node's child boxes, so that the REFIT kernels of scene_build.hip
+// (vertices moved, topology unchanged: psdr_hip_scene_update) write the very bytes the builder would write for the same tree.
 //
-// Layout (one 64-byte node = 4 x float4, fetched with four ds_read_b128 / one 64 B global line):
-//   q0 = left.lo.xyz , bits(left_ref)      q1 = left.hi.xyz , bits(right_ref)
-//   q2 = right.lo.xyz, 0                   q3 = right.hi.xyz, 0
-// ref >= 0 : index of an inner node;  ref < 0 : leaf, ~ref = (first_triangle << 2) | (count - 1),
-// 1..4 triangles, triangles re-ordered so that a leaf's triangles are contiguous.
-// Binned SAH (64 bins); boxes are padded so the slab test can never reject a ray that the
-// triangle test accepts (hit selection must not depend on the traversal order).
+// Boxes are padded so the slab test can never reject a ray that the triangle test accepts (hit selection must not depend on the
+// traversal order): the hit is defined by the exact triangle test alone (trav4.h), the tree only decides which triangles are looked at.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
+#include <thread>
 #include <vector>
+#if defined(__linux__)
+#include <sched.h>
+#endif
+
+#if defined(__HIPCC__)
+#define PSDR_BVH_HD __host__ __device__
+#else
+#define PSDR_BVH_HD
+#endif
 
 namespace psdr {
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// shared by the host builder and the device refit
+//
+// padded box of the triangle (p0, p0 + e1, p0 + e2): 1e-4 of the coordinate magnitude (at least 1e-4) on every side
+PSDR_BVH_HD inline void bvh_tri_box(const float *p0, const float *e1, const float *e2, float *lo, float *hi) {
+    for (int k = 0; k < 3; ++k) {
+        const float a = p0[k], b = a + e1[k], c = a + e2[k];
+        float l = a < b ? a : b; l = l < c ? l : c;
+        float h = a > b ? a : b; h = h > c ? h : c;
+        const float al = l < 0.f ? -l : l, ah = h < 0.f ? -h : h;
+        float m = al > ah ? al : ah; m = m > 1.f ? m : 1.f;
+        const float pad = 1e-4f * m;
+        lo[k] = l - pad; hi[k] = h + pad;
+    }
+}
+
+// 4-wide node = 64 bytes = 4 float4 words (two nodes per 128-byte L2 line, four 16-byte loads per step):
+//   w0  origin.xyz (the lower corner of the union of the children's boxes), bits(ex | ey << 8 | ez << 16): biased exponents,
+//       the grid step along axis a is 2^(e_a - 127)
+//   w1  lo.x[4] lo.y[4] lo.z[4] hi.x[4]      one byte per child: lo = origin + step * q rounded DOWN, hi rounded UP - the
+//   w2  hi.y[4] hi.z[4] code[0] code[1]      quantised box contains the (padded) float box, so the traversal visits a superset
+//   w3  code[2] code[3] 0 0                  and the hit, defined by the exact triangle test alone, is unchanged
+// code of a child: inner node -> its index; leaf -> leaf_bit | (first_triangle << 2 | count - 1); an unused child slot has code
+// 0xffffffff (and an inverted / unreachable box).  code < 2^ref_bits, so the traversal packs (coarse entry distance | code) into
+// ONE 32-bit sort key (trav4.h).
+//
+// bvh_quantise: words 0..9 of the node from the float boxes of its nc (1..4) children; the codes (words 10..13) are the builder's.
+// smallest power-of-two step with (hi - origin) / step <= 255 after rounding up, per axis; all in double, exact for float inputs.
+PSDR_BVH_HD inline void bvh_quantise(const float los[4][3], const float his[4][3], int nc, float *q) {
+    uint32_t exps = 0, qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+    float o3[3];
+    for (int a = 0; a < 3; ++a) {
+        double mn = los[0][a], mx = his[0][a];
+        for (int k = 1; k < nc; ++k) { mn = mn < (double) los[k][a] ? mn : (double) los[k][a]; mx = mx > (double) his[k][a] ? mx : (double) his[k][a]; }
+        const double org = mn, ext = mx - mn;
+        int e = 0;
+        if (ext > 0.0) {
+            // ceil(log2(ext / 255)) without a logarithm: x = m 2^k, m in [0.5, 1)
+            int k2 = 0;
+            const double m = frexp(ext / 255.0, &k2);
+            e = (m == 0.5) ? k2 - 1 : k2;
+        }
+        e = e < -126 ? -126 : (e > 127 ? 127 : e);
+        for (;;) {
+            const double step = ldexp(1.0, e);
+            bool ok = true;
+            for (int k = 0; k < nc && ok; ++k) ok = ceil(((double) his[k][a] - org) / step) <= 255.0;
+            if (ok || e >= 127) break;
+            ++e;
+        }
+        const double step = ldexp(1.0, e);
+        exps |= (uint32_t) (e + 127) << (8 * a);
+        for (int k = 0; k < 4; ++k) {
+            uint32_t l = 255u, h = 0u;          // unused child: inverted box (and code 0xffffffff, which the traversal checks)
+            if (k < nc) {
+                double fl = floor(((double) los[k][a] - org) / step), ch = ceil(((double) his[k][a] - org) / step);
+                fl = fl < 0.0 ? 0.0 : (fl > 255.0 ? 255.0 : fl); ch = ch < 0.0 ? 0.0 : (ch > 255.0 ? 255.0 : ch);
+                l = (uint32_t) fl; h = (uint32_t) ch;
+            }
+            qlo[a] |= l << (8 * k); qhi[a] |= h << (8 * k);
+        }
+        o3[a] = (float) org;                   // exact: org is one of the float bounds
+    }
+    uint32_t *u = reinterpret_cast<uint32_t *>(q);
+    q[0] = o3[0]; q[1] = o3[1]; q[2] = o3[2]; u[3] = exps;
+    u[4] = qlo[0]; u[5] = qlo[1]; u[6] = qlo[2]; u[7] = qhi[0];
+    u[8] = qhi[1]; u[9] = qhi[2];
+}
+
+PSDR_BVH_HD inline float bvh_half_area(const float *lo, const float *hi) {
+    const float d0 = hi[0] - lo[0], d1 = hi[1] - lo[1], d2 = hi[2] - lo[2];
+    return d0 * d1 + d1 * d2 + d2 * d0;
+}
+
+constexpr int kNodeFloats = 16;
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// host builder
 struct BvhResult {
-    std::vector<float> nodes;      // 16 floats per node
     std::vector<int32_t> order;    // device triangle slot -> original triangle id
-    int32_t n_nodes = 0, n_leaves = 0, max_depth = 0;
-    // the binary tree itself (node 0 = root; left < 0: leaf of `count` triangles starting at slot `first`), input of build_bvh4
+    int32_t n_leaves = 0, max_depth = 0;
+    // the binary tree (node 0 = root; left < 0: leaf of `count` (1 or 2) triangles starting at slot `first`), input of build_bvh4
     std::vector<int32_t> tmp_left, tmp_right, tmp_first, tmp_count;
     std::vector<float> tmp_box;    // lo.xyz, hi.xyz per node (padded)
 };
+
+// threads the host-side builders may keep busy: the affinity mask, cut down to the cgroup's CPU quota (a container sees every core of the
+// host but is throttled to cpu.max) and to 32; PSDR_HOST_THREADS overrides
+inline int bvh_host_threads() {
+    static const int n = [] {
+        if (const char *e = std::getenv("PSDR_HOST_THREADS")) return std::max(1, std::atoi(e));
+        int t = (int) std::thread::hardware_concurrency();
+        if (t <= 0) t = 1;
+#if defined(__linux__)
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) t = std::min(t, std::max(1, CPU_COUNT(&set)));
+        if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64]; long long per = 0;
+            if (std::fscanf(f, "%63s %lld", q, &per) == 2 && std::strcmp(q, "max") != 0 && per > 0) t = std::min(t, std::max(1, (int) (std::atoll(q) / per)));
+            std::fclose(f);
+        }
+#endif
+        return std::min(t, 32);
+    }();
+    return n;
+}
+
+// fn(begin, end) over [0, n) in contiguous chunks on up to `threads` threads (the calling thread takes the first chunk)
+template <typename F> inline void bvh_parallel_for(size_t n, int threads, size_t min_chunk, F fn) {
+    const size_t parts = std::max<size_t>(1, std::min<size_t>((size_t) std::max(1, threads), n / std::max<size_t>(1, min_chunk)));
+    if (parts <= 1) { fn((size_t) 0, n); return; }
+    std::vector<std::thread> th;
+    th.reserve(parts - 1);
+    for (size_t p = 1; p < parts; ++p) th.emplace_back([=] { fn(n * p / parts, n * (p + 1) / parts); });
+    fn((size_t) 0, n / parts);
+    for (std::thread &t : th) t.join();
+}
 
 namespace bvh_detail {
 struct Box {
@@ -42,48 +162,46 @@ struct Box {
     }
 };
 struct TmpNode { Box box; int left = -1, right = -1, first = 0, count = 0; };
-inline int32_t float_bits(int32_t v) { return v; }
+constexpr int kBins = 64;          // config 5: 16 / 32 / 64 bins: 237.9 / 236.7 / 233.8 ms per renderD, 18.34 / 18.23 / 17.94 nodes per ray (round 3)
+constexpr int kLeafMax = 2;        // triangles per leaf (measured with the triangle ring: 1: +15 %, 2: -1.5 %, 4: 0; the pair ring of trav4.h is sized for leaves of <= 2)
 } // namespace bvh_detail
 
-inline void build_bvh(const float *p0, const float *e1, const float *e2, int n, BvhResult &out) {
+// Binned SAH over all three axes (64 bins; the cheapest left area x count + right area x count split wins), leaves of at most two triangles.
+// The tree is a function of the triangles alone: every split is decided from order-independent sums (box unions, counts) and carried out by a
+// stable partition, so `threads` changes the time, not the result (the numbering of the binary nodes differs; build_bvh4 walks the structure).
+// Work is handed out per subtree: a job splits its range and queues the two halves until a range is small enough to finish in place.
+inline void build_bvh(const float *p0, const float *e1, const float *e2, int n, BvhResult &out, int threads = 0) {
     using namespace bvh_detail;
-    // measurement knobs (tools/bvh_knobs.sh): bins of the binned SAH, exact sweep SAH (every split of the centroid order of every axis) for ranges of
-    // at most PSDR_BVH_SWEEP triangles, split cost in leaves (area x ceil(count / kLeafMax)) instead of triangles
-    constexpr int kMaxBins = 64;
-    static const int kBins = std::getenv("PSDR_BVH_BINS") ? std::max(4, std::min(kMaxBins, std::atoi(std::getenv("PSDR_BVH_BINS")))) : 64;       // config 5: 16 / 32 / 64 bins: 237.9 / 236.7 / 233.8 ms, 18.34 / 18.23 / 17.94 nodes per ray
-    static const int kSweep = std::getenv("PSDR_BVH_SWEEP") ? std::atoi(std::getenv("PSDR_BVH_SWEEP")) : 0;
-    static const bool kLeafCost = std::getenv("PSDR_BVH_LEAFCOST") != nullptr;
-    // triangles per leaf: 1 or 2 (measured with the triangle ring: 1: +15 %, 2: -1.5 %, 4: 0; the pair ring of trav4.h is sized for leaves of <= 2)
-    static const int kLeafMax = std::getenv("PSDR_BVH_LEAF") ? std::max(1, std::min(2, std::atoi(std::getenv("PSDR_BVH_LEAF")))) : 2;
-    std::vector<Box> tb(n);
+    if (threads <= 0) threads = bvh_host_threads();
+    std::vector<Box> tb((size_t) n);
     std::vector<float> ctr(3 * (size_t) n);
-    out.order.resize(n);
-    for (int i = 0; i < n; ++i) {
-        out.order[i] = i;
-        float a[3], b[3], c[3];
-        for (int k = 0; k < 3; ++k) { a[k] = p0[3 * i + k]; b[k] = a[k] + e1[3 * i + k]; c[k] = a[k] + e2[3 * i + k]; }
-        tb[i].grow(a); tb[i].grow(b); tb[i].grow(c);
-        for (int k = 0; k < 3; ++k) {
-            ctr[3 * (size_t) i + k] = 0.5f * (tb[i].lo[k] + tb[i].hi[k]);
-            float pad = 1e-4f * std::max(1.f, std::max(std::fabs(tb[i].lo[k]), std::fabs(tb[i].hi[k])));
-            tb[i].lo[k] -= pad; tb[i].hi[k] += pad;
+    out.order.resize((size_t) n);
+    bvh_parallel_for((size_t) n, threads, 4096, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            out.order[i] = (int32_t) i;
+            // centroid of the UNPADDED box, then the padded box (bvh_tri_box)
+            float lo[3], hi[3];
+            for (int k = 0; k < 3; ++k) {
+                const float a = p0[3 * i + k], bb = a + e1[3 * i + k], c = a + e2[3 * i + k];
+                lo[k] = std::min(a, std::min(bb, c)); hi[k] = std::max(a, std::max(bb, c));
+                ctr[3 * i + k] = 0.5f * (lo[k] + hi[k]);
+            }
+            bvh_tri_box(p0 + 3 * i, e1 + 3 * i, e2 + 3 * i, tb[i].lo, tb[i].hi);
         }
-    }
-    std::vector<TmpNode> tmp;
-    tmp.reserve(2 * (size_t) n + 2);
+    });
+    const size_t cap = 2 * (size_t) std::max(n, 1) + 2;
+    std::vector<TmpNode> tmp(cap);
+    std::atomic<int> n_tmp{1};
+    std::atomic<int> max_depth{1};
     struct Job { int node, first, count, depth; };
-    std::vector<Job> stack;
-    tmp.emplace_back();
-    stack.push_back({0, 0, n, 1});
-    int max_depth = 1;
-    while (!stack.empty()) {
-        Job j = stack.back(); stack.pop_back();
-        max_depth = std::max(max_depth, j.depth);
+
+    // one node: its box, and either a leaf or a split of out.order[first, first + count) -> true: children allocated (left, right ranges in l / r)
+    auto split = [&](const Job &j, Job &l, Job &r) -> bool {
         Box box, cb;
         for (int i = j.first; i < j.first + j.count; ++i) { box.grow(tb[out.order[i]]); cb.grow(&ctr[3 * (size_t) out.order[i]]); }
         TmpNode nd; nd.box = box; nd.first = j.first; nd.count = j.count;
+        bool inner = false;
         if (j.count > kLeafMax || (j.node == 0 && j.count > 1)) {
-            // binned SAH over all three axes: the cheapest (left area x count + right area x count) split wins
             int mid = -1, best_axis = -1, best_split = -1;
             float best = std::numeric_limits<float>::max();
             auto bin_of = [&](int t, int axis) {
@@ -91,102 +209,96 @@ inline void build_bvh(const float *p0, const float *e1, const float *e2, int n, 
                 int b = (int) ((ctr[3 * (size_t) t + axis] - cb.lo[axis]) * (kBins / ext));
                 return std::min(std::max(b, 0), kBins - 1);
             };
-            int widest = 0;
-            for (int k = 1; k < 3; ++k) if (cb.hi[k] - cb.lo[k] > cb.hi[widest] - cb.lo[widest]) widest = k;
-            static const bool all_axes = std::getenv("PSDR_BVH_WIDEST_AXIS") == nullptr;
-            auto units = [&](int c) { return kLeafCost ? (float) ((c + kLeafMax - 1) / kLeafMax) : (float) c; };
-            bool swept = false;
-            if (j.count <= kSweep) {
-                // exact sweep: the triangles in centroid order along each axis, every prefix / suffix split priced
-                std::vector<int> ord(out.order.begin() + j.first, out.order.begin() + j.first + j.count);
-                std::vector<Box> suf(j.count);
-                int best_k = -1, sweep_axis = -1;
-                auto sort_by = [&](int axis) { std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return ctr[3 * (size_t) a + axis] < ctr[3 * (size_t) b + axis]; }); };
-                for (int axis = 0; axis < 3; ++axis) {
-                    std::copy(out.order.begin() + j.first, out.order.begin() + j.first + j.count, ord.begin());
-                    sort_by(axis);
-                    Box acc;
-                    for (int i = j.count - 1; i > 0; --i) { acc.grow(tb[ord[i]]); suf[i] = acc; }
-                    acc = Box();
-                    for (int i = 0; i < j.count - 1; ++i) {
-                        acc.grow(tb[ord[i]]);
-                        const float cost = acc.half_area() * units(i + 1) + suf[i + 1].half_area() * units(j.count - i - 1);
-                        if (cost < best) { best = cost; best_k = i + 1; sweep_axis = axis; }
-                    }
-                }
-                if (best_k > 0) {
-                    std::copy(out.order.begin() + j.first, out.order.begin() + j.first + j.count, ord.begin());
-                    sort_by(sweep_axis);
-                    std::copy(ord.begin(), ord.end(), out.order.begin() + j.first); mid = j.first + best_k; swept = true;
-                }
-            }
-            for (int axis = 0; axis < 3 && !swept; ++axis) {
-                if (!all_axes && axis != widest) continue;
+            for (int axis = 0; axis < 3; ++axis) {
                 if (!(cb.hi[axis] - cb.lo[axis] > 0.f)) continue;
-                Box bb[kMaxBins]; int bc[kMaxBins] = {0};
-                for (int i = j.first; i < j.first + j.count; ++i) { int t = out.order[i]; int b = bin_of(t, axis); bb[b].grow(tb[t]); bc[b]++; }
-                Box r[kMaxBins]; int rc[kMaxBins];
+                Box bb[kBins]; int bc[kBins] = {0};
+                for (int i = j.first; i < j.first + j.count; ++i) { const int t = out.order[i]; const int b = bin_of(t, axis); bb[b].grow(tb[t]); bc[b]++; }
+                Box rb[kBins]; int rc[kBins];
                 Box acc; int cnt = 0;
-                for (int b = kBins - 1; b > 0; --b) { acc.grow(bb[b]); cnt += bc[b]; r[b] = acc; rc[b] = cnt; }
+                for (int b = kBins - 1; b > 0; --b) { acc.grow(bb[b]); cnt += bc[b]; rb[b] = acc; rc[b] = cnt; }
                 acc = Box(); cnt = 0;
                 for (int b = 0; b < kBins - 1; ++b) {
                     acc.grow(bb[b]); cnt += bc[b];
                     if (cnt == 0 || rc[b + 1] == 0) continue;
-                    float cost = acc.half_area() * units(cnt) + r[b + 1].half_area() * units(rc[b + 1]);
+                    const float cost = acc.half_area() * (float) cnt + rb[b + 1].half_area() * (float) rc[b + 1];
                     if (cost < best) { best = cost; best_split = b; best_axis = axis; }
                 }
             }
-            if (best_axis >= 0 && !swept) {
+            if (best_axis >= 0) {
                 auto it = std::stable_partition(out.order.begin() + j.first, out.order.begin() + j.first + j.count,
                                                 [&](int t) { return bin_of(t, best_axis) <= best_split; });
                 mid = (int) (it - out.order.begin());
             }
-            if (mid <= j.first || mid >= j.first + j.count) {   // degenerate: split by index
-                mid = j.first + j.count / 2;
-            }
-            nd.left = (int) tmp.size(); tmp.emplace_back();
-            nd.right = (int) tmp.size(); tmp.emplace_back();
-            nd.count = 0;
-            stack.push_back({nd.left, j.first, mid - j.first, j.depth + 1});
-            stack.push_back({nd.right, mid, j.first + j.count - mid, j.depth + 1});
+            if (mid <= j.first || mid >= j.first + j.count) mid = j.first + j.count / 2;       // degenerate: split by index
+            const int at = n_tmp.fetch_add(2);
+            nd.left = at; nd.right = at + 1; nd.count = 0;
+            l = {nd.left, j.first, mid - j.first, j.depth + 1};
+            r = {nd.right, mid, j.first + j.count - mid, j.depth + 1};
+            inner = true;
         }
-        tmp[j.node] = nd;
-    }
-    // emit two-box nodes; inner tmp nodes get device indices in DFS order
-    std::vector<int> dev_index(tmp.size(), -1);
-    int n_inner = 0, n_leaves = 0;
-    for (size_t i = 0; i < tmp.size(); ++i) { if (tmp[i].left >= 0) dev_index[i] = n_inner++; else n_leaves++; }
-    bool single_leaf_root = (tmp[0].left < 0);
-    if (single_leaf_root) n_inner = 1;
-    out.nodes.assign(16 * (size_t) n_inner, 0.f);
-    auto ref_of = [&](int ti) -> int32_t {
-        const TmpNode &t = tmp[ti];
-        if (t.left >= 0) return dev_index[ti];
-        return ~((t.first << 2) | (t.count - 1));
+        tmp[(size_t) j.node] = nd;
+        int d = max_depth.load();
+        while (j.depth > d && !max_depth.compare_exchange_weak(d, j.depth)) {}
+        return inner;
     };
-    auto put = [&](float *q, const Box &b, int32_t ref_lo_slot, int32_t ref_hi_slot, bool with_refs) {
-        q[0] = b.lo[0]; q[1] = b.lo[1]; q[2] = b.lo[2];
-        q[4] = b.hi[0]; q[5] = b.hi[1]; q[6] = b.hi[2];
-        if (with_refs) { std::memcpy(&q[3], &ref_lo_slot, 4); std::memcpy(&q[7], &ref_hi_slot, 4); }
+    // a whole subtree on the calling thread
+    auto finish = [&](const Job &root) {
+        std::vector<Job> st;
+        st.push_back(root);
+        while (!st.empty()) {
+            const Job j = st.back(); st.pop_back();
+            Job l, r;
+            if (split(j, l, r)) { st.push_back(l); st.push_back(r); }
+        }
     };
-    if (single_leaf_root) {
-        float *q = &out.nodes[0];
-        Box empty;   // lo > hi: never hit
-        int32_t lref = n > 0 ? ref_of(0) : ~0, rref = lref;
-        put(q, n > 0 ? tmp[0].box : empty, lref, rref, true);
-        put(q + 8, empty, 0, 0, false);
+    if (threads <= 1 || n < 8192) {
+        finish({0, 0, n, 1});
     } else {
-        for (size_t i = 0; i < tmp.size(); ++i) {
-            if (tmp[i].left < 0) continue;
-            float *q = &out.nodes[16 * (size_t) dev_index[i]];
-            put(q, tmp[tmp[i].left].box, ref_of(tmp[i].left), ref_of(tmp[i].right), true);
-            put(q + 8, tmp[tmp[i].right].box, 0, 0, false);
-        }
+        const int small = std::max(2048, n / (8 * threads));         // ranges of at most this many triangles are finished in place
+        std::mutex mu;
+        std::condition_variable cv;
+        std::vector<Job> queue;
+        int pending = 1;                                             // jobs queued or being worked on
+        queue.push_back({0, 0, n, 1});
+        auto worker = [&] {
+            for (;;) {
+                Job j;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return !queue.empty() || pending == 0; });
+                    if (queue.empty()) return;
+                    // largest range first: the long jobs start early
+                    size_t best = 0;
+                    for (size_t i = 1; i < queue.size(); ++i) if (queue[i].count > queue[best].count) best = i;
+                    j = queue[best]; queue[best] = queue.back(); queue.pop_back();
+                }
+                if (j.count <= small) finish(j);
+                else {
+                    Job l, r;
+                    if (split(j, l, r)) {
+                        std::lock_guard<std::mutex> lk(mu);
+                        queue.push_back(l); queue.push_back(r); pending += 2;
+                    }
+                }
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    --pending;
+                }
+                cv.notify_all();
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < threads; ++t) th.emplace_back(worker);
+        worker();
+        for (std::thread &t : th) t.join();
     }
-    out.n_nodes = n_inner; out.n_leaves = n_leaves; out.max_depth = max_depth;
-    out.tmp_left.resize(tmp.size()); out.tmp_right.resize(tmp.size()); out.tmp_first.resize(tmp.size()); out.tmp_count.resize(tmp.size()); out.tmp_box.resize(6 * tmp.size());
-    for (size_t i = 0; i < tmp.size(); ++i) {
+    const size_t nt = (size_t) n_tmp.load();
+    out.max_depth = max_depth.load();
+    out.n_leaves = 0;
+    out.tmp_left.resize(nt); out.tmp_right.resize(nt); out.tmp_first.resize(nt); out.tmp_count.resize(nt); out.tmp_box.resize(6 * nt);
+    for (size_t i = 0; i < nt; ++i) {
         out.tmp_left[i] = tmp[i].left; out.tmp_right[i] = tmp[i].right; out.tmp_first[i] = tmp[i].first; out.tmp_count[i] = tmp[i].left >= 0 ? 0 : tmp[i].count;
+        if (tmp[i].left < 0) out.n_leaves++;
         for (int k = 0; k < 3; ++k) { out.tmp_box[6 * i + k] = tmp[i].box.lo[k]; out.tmp_box[6 * i + 3 + k] = tmp[i].box.hi[k]; }
     }
 }
@@ -194,146 +306,98 @@ inline void build_bvh(const float *p0, const float *e1, const float *e2, int n, 
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // 4-wide BVH for the device traversal (trav4.h): the binary SAH tree above with up to two levels collapsed into one node
-// (the child with the largest surface area is opened first).
-//
-// One node = 64 bytes = 4 float4 words (round 3; two nodes per 128-byte L2 line, four 16-byte loads per step):
-//   w0  origin.xyz (the lower corner of the union of the children's boxes), bits(ex | ey << 8 | ez << 16): biased exponents,
-//       the grid step along axis a is 2^(e_a - 127)
-//   w1  lo.x[4] lo.y[4] lo.z[4] hi.x[4]      one byte per child: lo = origin + step * q rounded DOWN, hi rounded UP - the
-//   w2  hi.y[4] hi.z[4] code[0] code[1]      quantised box contains the (padded) float box, so the traversal visits a superset
-//   w3  code[2] code[3] 0 0                  and the hit, defined by the exact triangle test alone, is unchanged
-// With -DPSDR_NODE128 (measurement knob) the node is round 2's 128 bytes = 8 words: lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4]
-// code[4] unused, boxes as floats.
-// code of a child: inner node -> its index; leaf -> leaf_bit | (first_triangle << 2 | count - 1); an unused child slot has code
-// 0xffffffff (and an inverted / unreachable box).  code < 2^ref_bits, so the traversal packs (coarse entry distance | code) into
-// ONE 32-bit sort key (trav4.h).  max_stack bounds the traversal stack of any ray (sum over a root-to-leaf path of the siblings
-// left behind).
-#ifdef PSDR_NODE128
-constexpr int kNodeFloats = 32;
-#else
-constexpr int kNodeFloats = 16;
-#endif
+// (the child with the largest surface area is opened first).  max_stack bounds the traversal stack of any ray (sum over a
+// root-to-leaf path of the siblings left behind).  `height[i]` = levels of inner nodes below node i (0: all children are leaves): a
+// refit processes the nodes by increasing height.  `cost` = the tree's SAH cost, sum over all child boxes of
+// half_area(child) x (triangles of a leaf | 1 for an inner node) / half_area(root box) - what a refit re-evaluates to decide whether
+// the tree still fits the geometry (bvh4_cost_term).
 struct Bvh4Result {
     std::vector<float> nodes;      // kNodeFloats per node
+    std::vector<int32_t> height;   // per node
     int32_t n_nodes = 0, max_depth = 0, max_stack = 0, ref_bits = 0;
     uint32_t leaf_bit = 0;
+    double cost = 0.0;
 };
 
 inline void build_bvh4(const BvhResult &b2, int n_tris, Bvh4Result &out) {
     const size_t nt = b2.tmp_left.size();
     auto is_leaf = [&](int i) { return b2.tmp_left[i] < 0; };
-    auto half_area = [&](int i) {
-        const float *b = &b2.tmp_box[6 * (size_t) i];
-        const float d0 = b[3] - b[0], d1 = b[4] - b[1], d2 = b[5] - b[2];
-        return d0 * d1 + d1 * d2 + d2 * d0;
-    };
+    auto half_area = [&](int i) { const float *b = &b2.tmp_box[6 * (size_t) i]; return bvh_half_area(b, b + 3); };
     // payload bits: the largest leaf payload is ((n_tris - 1) << 2) | 3, inner indices are smaller than the number of binary nodes
     uint32_t max_payload = (uint32_t) std::max<int64_t>(((int64_t) std::max(n_tris, 1) - 1) * 4 + 3, (int64_t) nt);
     int bits = 1;
     while ((1ull << bits) <= max_payload) ++bits;
     out.leaf_bit = 1u << bits;
     out.ref_bits = bits + 1;
+    out.nodes.clear(); out.height.clear(); out.cost = 0.0;
+    if (nt == 0) { out.n_nodes = 0; return; }
     struct Item { int tmp; int node4; int depth; };
     std::vector<Item> todo;
-    std::vector<int> need;          // stack need below each emitted node (filled bottom-up afterwards)
-    std::vector<std::vector<int>> kids;   // per node4: child node4 indices (inner children only)
-    out.nodes.clear();
-    auto new_node = [&]() { out.nodes.resize(out.nodes.size() + kNodeFloats, 0.f); kids.emplace_back(); return (int) (out.nodes.size() / kNodeFloats) - 1; };
-    std::vector<int> n_children;
-    if (nt == 0) { out.n_nodes = 0; return; }
+    std::vector<int32_t> kid;            // per node4: up to four inner children (-1 = none)
+    std::vector<int32_t> n_children;
+    out.nodes.reserve((size_t) kNodeFloats * (nt / 2 + 2));
+    auto new_node = [&]() {
+        out.nodes.resize(out.nodes.size() + kNodeFloats, 0.f);
+        kid.resize(kid.size() + 4, -1); n_children.push_back(0);
+        return (int) (out.nodes.size() / kNodeFloats) - 1;
+    };
     const int root = new_node();
-    n_children.push_back(0);
     todo.push_back({0, root, 1});
     int max_depth = 1;
+    const double root_area = std::max((double) half_area(0), 1e-300);
     while (!todo.empty()) {
         const Item it = todo.back(); todo.pop_back();
         max_depth = std::max(max_depth, it.depth);
-        std::vector<int> list;
-        if (is_leaf(it.tmp)) list.push_back(it.tmp);          // a scene of one leaf: the root holds it as its only child
-        else { list.push_back(b2.tmp_left[it.tmp]); list.push_back(b2.tmp_right[it.tmp]); }
-        while (list.size() < 4) {
+        int list[4], nl = 0;
+        if (is_leaf(it.tmp)) list[nl++] = it.tmp;          // a scene of one leaf: the root holds it as its only child
+        else { list[nl++] = b2.tmp_left[it.tmp]; list[nl++] = b2.tmp_right[it.tmp]; }
+        while (nl < 4) {
             int best = -1; float ba = -1.f;
-            for (size_t k = 0; k < list.size(); ++k) if (!is_leaf(list[k]) && half_area(list[k]) > ba) { ba = half_area(list[k]); best = (int) k; }
+            for (int k = 0; k < nl; ++k) if (!is_leaf(list[k]) && half_area(list[k]) > ba) { ba = half_area(list[k]); best = k; }
             if (best < 0) break;
             const int t = list[best];
             list[best] = b2.tmp_left[t];
-            list.push_back(b2.tmp_right[t]);
+            list[nl++] = b2.tmp_right[t];
         }
-        n_children[it.node4] = (int) list.size();
+        n_children[it.node4] = nl;
         uint32_t codes[4];
         float los[4][3], his[4][3];
         for (int k = 0; k < 4; ++k) {
             uint32_t code = 0xffffffffu;
-            float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {3e38f, 3e38f, 3e38f};
-            if (k < (int) list.size()) {
+            for (int a = 0; a < 3; ++a) { los[k][a] = 3e38f; his[k][a] = 3e38f; }
+            if (k < nl) {
                 const int t = list[k];
-                for (int a = 0; a < 3; ++a) { lo[a] = b2.tmp_box[6 * (size_t) t + a]; hi[a] = b2.tmp_box[6 * (size_t) t + 3 + a]; }
-                if (is_leaf(t)) code = out.leaf_bit | (uint32_t) ((b2.tmp_first[t] << 2) | (b2.tmp_count[t] - 1));
-                else {
+                for (int a = 0; a < 3; ++a) { los[k][a] = b2.tmp_box[6 * (size_t) t + a]; his[k][a] = b2.tmp_box[6 * (size_t) t + 3 + a]; }
+                if (is_leaf(t)) {
+                    code = out.leaf_bit | (uint32_t) ((b2.tmp_first[t] << 2) | (b2.tmp_count[t] - 1));
+                    out.cost += (double) half_area(t) * b2.tmp_count[t] / root_area;
+                } else {
                     const int c = new_node();          // (grows out.nodes: no pointer into it is held across this call)
-                    n_children.push_back(0);
-                    kids[it.node4].push_back(c);
+                    kid[4 * (size_t) it.node4 + k] = c;
                     code = (uint32_t) c;
                     todo.push_back({t, c, it.depth + 1});
+                    out.cost += (double) half_area(t) / root_area;
                 }
             }
             codes[k] = code;
-            for (int a = 0; a < 3; ++a) { los[k][a] = lo[a]; his[k][a] = hi[a]; }
         }
         float *q = &out.nodes[(size_t) kNodeFloats * (size_t) it.node4];
-#ifdef PSDR_NODE128
-        for (int k = 0; k < 4; ++k) {
-            for (int a = 0; a < 3; ++a) { q[4 * a + k] = los[k][a]; q[12 + 4 * a + k] = his[k][a]; }
-            std::memcpy(&q[24 + k], &codes[k], 4);
-        }
-#else
-        {
-            const int nc = (int) list.size();
-            double org[3], ext[3];
-            for (int a = 0; a < 3; ++a) {
-                double mn = los[0][a], mx = his[0][a];
-                for (int k = 1; k < nc; ++k) { mn = std::min(mn, (double) los[k][a]); mx = std::max(mx, (double) his[k][a]); }
-                org[a] = mn; ext[a] = mx - mn;
-            }
-            uint32_t exps = 0, qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
-            for (int a = 0; a < 3; ++a) {
-                // smallest power of two with extent / step <= 255 (checked on the rounded-up upper bounds below)
-                int e = ext[a] > 0.0 ? (int) std::ceil(std::log2(ext[a] / 255.0)) : 0;
-                e = std::max(-126, std::min(127, e));
-                for (;;) {
-                    const double step = std::ldexp(1.0, e);
-                    bool ok = true;
-                    for (int k = 0; k < nc && ok; ++k) ok = std::ceil(((double) his[k][a] - org[a]) / step) <= 255.0;
-                    if (ok || e >= 127) break;
-                    ++e;
-                }
-                const double step = std::ldexp(1.0, e);
-                exps |= (uint32_t) (e + 127) << (8 * a);
-                for (int k = 0; k < 4; ++k) {
-                    uint32_t l = 255u, h = 0u;          // unused child: inverted box (and code 0xffffffff, which the traversal checks)
-                    if (k < nc) {
-                        l = (uint32_t) std::max(0.0, std::min(255.0, std::floor(((double) los[k][a] - org[a]) / step)));
-                        h = (uint32_t) std::max(0.0, std::min(255.0, std::ceil(((double) his[k][a] - org[a]) / step)));
-                    }
-                    qlo[a] |= l << (8 * k); qhi[a] |= h << (8 * k);
-                }
-            }
-            const float o3[3] = {(float) org[0], (float) org[1], (float) org[2]};     // exact: org is one of the float bounds
-            q[0] = o3[0]; q[1] = o3[1]; q[2] = o3[2]; std::memcpy(&q[3], &exps, 4);
-            std::memcpy(&q[4], &qlo[0], 4); std::memcpy(&q[5], &qlo[1], 4); std::memcpy(&q[6], &qlo[2], 4); std::memcpy(&q[7], &qhi[0], 4);
-            std::memcpy(&q[8], &qhi[1], 4); std::memcpy(&q[9], &qhi[2], 4); std::memcpy(&q[10], &codes[0], 4); std::memcpy(&q[11], &codes[1], 4);
-            std::memcpy(&q[12], &codes[2], 4); std::memcpy(&q[13], &codes[3], 4);
-        }
-#endif
+        bvh_quantise(los, his, nl, q);
+        std::memcpy(&q[10], &codes[0], 16);
     }
     out.n_nodes = (int) (out.nodes.size() / kNodeFloats);
     out.max_depth = max_depth;
-    // stack need: children are emitted after their parent, so a reverse sweep sees every child before its parent
-    need.assign(out.n_nodes, 0);
+    // stack need and height: children are emitted after their parent, so a reverse sweep sees every child before its parent
+    std::vector<int> need((size_t) out.n_nodes, 0);
+    out.height.assign((size_t) out.n_nodes, 0);
     for (int i = out.n_nodes - 1; i >= 0; --i) {
-        int below = 0;
-        for (int c : kids[i]) below = std::max(below, need[c]);
+        int below = 0, h = 0;
+        for (int k = 0; k < 4; ++k) {
+            const int c = kid[4 * (size_t) i + k];
+            if (c >= 0) { below = std::max(below, need[c]); h = std::max(h, out.height[c] + 1); }
+        }
         need[i] = (n_children[i] - 1) + below;
+        out.height[i] = h;
     }
     out.max_stack = need.empty() ? 1 : need[0] + 1;
 }

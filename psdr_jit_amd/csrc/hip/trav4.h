@@ -212,25 +212,6 @@ template <int LDS, bool COUNT> PSDR_DEV void t4_node(SceneView<LDS> &S, const T4
     if (bt < tr.anyhit) { tr.sp = tr.sb; tr.code = kT4Done; return; }              // shadow ray: an occluder has been found
     const float ox = tr.o.x, oy = tr.o.y, oz = tr.o.z, ix = tr.inv.x, iy = tr.inv.y, iz = tr.inv.z;
     unsigned key[4];
-#ifdef PSDR_NODE128
-    // round 2's node: 128 bytes, the children's boxes as floats (measurement knob; bvh.h emits the matching layout)
-    const int w = T.nodes_off + 8 * (int) tr.code;
-    const float4 lx = S.ld(w), ly = S.ld(w + 1), lz = S.ld(w + 2), hx = S.ld(w + 3), hy = S.ld(w + 4), hz = S.ld(w + 5), cd = S.ld(w + 6);
-    const float lox[4] = {lx.x, lx.y, lx.z, lx.w}, loy[4] = {ly.x, ly.y, ly.z, ly.w}, loz[4] = {lz.x, lz.y, lz.z, lz.w};
-    const float hix[4] = {hx.x, hx.y, hx.z, hx.w}, hiy[4] = {hy.x, hy.y, hy.z, hy.w}, hiz[4] = {hz.x, hz.y, hz.z, hz.w};
-    const unsigned cds[4] = {__float_as_uint(cd.x), __float_as_uint(cd.y), __float_as_uint(cd.z), __float_as_uint(cd.w)};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        // slab test; fminf / fmaxf drop NaNs (0 * inf), which keeps the test conservative; the far side gets one ulp-scale of slack
-        const float ax = (lox[k] - ox) * ix, bx = (hix[k] - ox) * ix;
-        const float ay = (loy[k] - oy) * iy, by = (hiy[k] - oy) * iy;
-        const float az = (loz[k] - oz) * iz, bz = (hiz[k] - oz) * iz;
-        const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
-        const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000004f;
-        const bool hit = tn <= fminf(tf, bt);
-        key[k] = hit ? ((__float_as_uint(tn) & ~cmask) | cds[k]) : kT4Miss;
-    }
-#else
     // 64-byte node (bvh.h): {origin.xyz, exponents} {lo.x[4] lo.y[4] lo.z[4] hi.x[4]} {hi.y[4] hi.z[4] code0 code1} {code2 code3 - -};
     // child k's bounds are bytes k of the six words: lo = origin + 2^e q_lo (rounded down), hi = origin + 2^e q_hi (rounded up).
     // Along one axis  (origin + s q - o) * inv = q * (s inv) + (origin - o) inv: one convert and one fma per bound, as many
@@ -263,7 +244,6 @@ template <int LDS, bool COUNT> PSDR_DEV void t4_node(SceneView<LDS> &S, const T4
         const bool hit = (tn <= fminf(tf, bt)) & (cds[k] != kT4Miss);      // `&`: with `&&` the compiler sinks the load of the child's code into a branch - a second memory round trip per node
         key[k] = hit ? ((__float_as_uint(tn) & ~cmask) | cds[k]) : kT4Miss;
     }
-#endif
     // sorting network on four keys: (0,1) (2,3) (0,2) (1,3) (1,2)
     unsigned a = min(key[0], key[1]), b = max(key[0], key[1]), c = min(key[2], key[3]), e = max(key[2], key[3]);
     const unsigned k0 = min(a, c), m1 = max(a, c), m2 = min(b, e), k3 = max(b, e);

@@ -316,6 +316,7 @@ PYBIND11_MODULE(_psdr_core, m) {
         .def_property_readonly("face_uv_indices", [](const Mesh &me) { return from_ivec(me.face_uv_indices, 3); })
         .def_readwrite("use_face_normal", &Mesh::m_use_face_normals)
         .def_readwrite("enable_edges", &Mesh::m_enable_edges)
+        .def("num_edges", [](const Mesh &me) { return (int64_t) me.edges.size(); })
         .def("edge_indices", [](const Mesh &me) {
             iarr a({(ssize_t) me.edges.size(), (ssize_t) 5});
             int *o = a.mutable_data();
@@ -402,7 +403,18 @@ PYBIND11_MODULE(_psdr_core, m) {
             int32_t n = 0, l = 0, d = 0, b = 0;
             if (!s.m_hip || psdr_hip_scene_stats(s.m_hip, &n, &l, &d, &b)) throw Exception("scene not configured");
             return py::make_tuple(n, l, d, b); })
+        // (triangles, secondary edges) of the configured snapshot: what reverse mode sizes its adjoint buffers with
+        .def("_snapshot_counts", [](const Scene &s) { return py::make_tuple((int64_t) s.snap.area.size(), (int64_t) s.snap.n_sec_edges); })
         .def("_hip_handle", [](const Scene &s) { return (uintptr_t) s.m_hip; })
+        // what the last configure() did to the device copy (psdr_update_info, include/psdr_hip.h)
+        .def("_last_update", [](const Scene &s) {
+            py::dict d;
+            const psdr_update_info &u = s.m_last_update;
+            d["tree"] = u.tree == 2 ? "built" : (u.tree == 1 ? "refitted" : "kept");
+            d["reallocated"] = u.reallocated; d["bytes_uploaded"] = u.bytes_uploaded; d["sah_cost"] = u.sah_cost; d["sah_cost_built"] = u.sah_cost_built;
+            d["ms_host"] = s.m_ms_host; d["ms_tree"] = u.ms_tree; d["ms_fill"] = u.ms_fill; d["ms_upload"] = u.ms_upload; d["ms_total"] = u.ms_total;
+            return d; })
+        .def_readwrite("_always_rebuild", &Scene::m_always_rebuild)
         .def("_snapshot", [](const Scene &s) {
             // configured host arrays in the oracle's row formats (tests compare them with the CPU restatement)
             const Scene::Snapshot &S = s.snap;

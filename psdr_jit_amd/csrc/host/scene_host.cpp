@@ -208,6 +208,7 @@ void Mesh::load_raw(const std::vector<float> &v, const std::vector<int> &f, cons
     face_indices = f;
     for (int idx : f) PSDR_ASSERT(idx >= 0 && idx < m_num_vertices);
     edges.clear();
+    ++m_topo_version;
     if (m_enable_edges) build_edges();
     if (verbose) std::cout << "Loaded " << m_num_vertices << " vertices, " << m_num_faces << " faces, " << edges.size() << " edges. " << std::endl;
     m_ready = false;
@@ -230,20 +231,39 @@ void Mesh::build_edges() {
     for (const auto &kv : em) edges.push_back({kv.first.first, kv.first.second, kv.second[1], kv.second.size() >= 3 ? kv.second[2] : -1, kv.second[0]});
 }
 
+// per vertex, its (corner i, face f) incidences in the order the reference's three scatter passes visit them (mesh.cpp:34-41: corner 0 of every face,
+// then corner 1, then corner 2), so that the per-vertex sums below add in that very order whatever the thread count
+void Mesh::build_vertex_faces() {
+    const int nv = m_num_vertices, nf = m_num_faces;
+    vf_begin.assign((size_t) nv + 1, 0);
+    for (int i = 0; i < 3 * nf; ++i) vf_begin[(size_t) face_indices[i] + 1]++;
+    for (int v = 0; v < nv; ++v) vf_begin[(size_t) v + 1] += vf_begin[(size_t) v];
+    vf_item.resize((size_t) 3 * nf);
+    std::vector<int> at(vf_begin.begin(), vf_begin.end() - 1);
+    for (int i = 0; i < 3; ++i)
+        for (int f = 0; f < nf; ++f) vf_item[(size_t) at[(size_t) face_indices[3 * f + i]]++] = f;      // (ascending in i * nf + f by construction)
+    vf_topo = m_topo_version;
+}
+
 // process_mesh<true>, reference src/shape/mesh.cpp:23-62; rows of 22 floats: p0 e1 e2 n0 n1 n2 fn area
-static void process_mesh(const std::vector<D3> &V, const std::vector<int> &F, int nf, std::vector<float> &tri, std::vector<float> &d_tri,
-                         std::vector<float> *vertex_normals_out) {
+// (vf_begin / vf_item: Mesh::build_vertex_faces; the loops are independent per face / per vertex and run on the OpenMP team)
+static void process_mesh(const std::vector<D3> &V, const std::vector<int> &F, int nf, const std::vector<int> &vf_begin, const std::vector<int> &vf_item,
+                         std::vector<float> &tri, std::vector<float> &d_tri, std::vector<float> *vertex_normals_out) {
     const size_t nv = V.size();
     std::vector<D3> vn(nv), fnrm(nf);
-    std::vector<DF> vw(nv), farea(nf);
+    std::vector<DF> farea(nf);
+#pragma omp parallel for schedule(static) if (nf > 4096)
     for (int f = 0; f < nf; ++f) {
         const D3 p0 = V[F[3 * f]], e1 = V[F[3 * f + 1]] - p0, e2 = V[F[3 * f + 2]] - p0;
         fnrm[f] = dcross(e1, e2);
         farea[f] = dnorm(fnrm[f]);
     }
-    for (int i = 0; i < 3; ++i)
-        for (int f = 0; f < nf; ++f) { const int v = F[3 * f + i]; vn[v] = vn[v] + fnrm[f]; vw[v] = vw[v] + farea[f]; }
-    for (size_t v = 0; v < nv; ++v) vn[v] = dnormalize(vn[v] / vw[v]);
+#pragma omp parallel for schedule(static) if (nv > 4096)
+    for (long long v = 0; v < (long long) nv; ++v) {
+        D3 acc; DF w;
+        for (int k = vf_begin[(size_t) v]; k < vf_begin[(size_t) v + 1]; ++k) { const int f = vf_item[(size_t) k]; acc = acc + fnrm[f]; w = w + farea[f]; }
+        vn[(size_t) v] = dnormalize(acc / w);
+    }
     if (vertex_normals_out) {
         vertex_normals_out->resize(3 * nv);
         for (size_t v = 0; v < nv; ++v) { (*vertex_normals_out)[3 * v] = vn[v].x.v; (*vertex_normals_out)[3 * v + 1] = vn[v].y.v; (*vertex_normals_out)[3 * v + 2] = vn[v].z.v; }
@@ -254,6 +274,7 @@ static void process_mesh(const std::vector<D3> &V, const std::vector<int> &F, in
         tri[22 * row + col] = a.x.v; tri[22 * row + col + 1] = a.y.v; tri[22 * row + col + 2] = a.z.v;
         d_tri[22 * row + col] = a.x.d; d_tri[22 * row + col + 1] = a.y.d; d_tri[22 * row + col + 2] = a.z.d;
     };
+#pragma omp parallel for schedule(static) if (nf > 4096)
     for (int f = 0; f < nf; ++f) {
         const D3 p0 = V[F[3 * f]], e1 = V[F[3 * f + 1]] - p0, e2 = V[F[3 * f + 2]] - p0;
         put(f, 0, p0); put(f, 3, e1); put(f, 6, e2);
@@ -269,26 +290,47 @@ void Mesh::configure() {
     if (m_bsdf != nullptr) PSDR_ASSERT(!m_bsdf->anisotropic() || !m_use_face_normals);
     PSDR_ASSERT_MSG(m_num_faces > 0, "Mesh has no faces!");
     if (d_vertex_positions_raw.size() != vertex_positions_raw.size()) d_vertex_positions_raw.assign(vertex_positions_raw.size(), 0.f);
+    // the same inputs as last time: nothing to do (values: raw vertices, the three to_world factors, the topology; tangents: theirs)
+    const M16 *mv[3] = {&to_world_left, &to_world_raw, &to_world_right}, *md[3] = {&d_to_world_left, &d_to_world_raw, &d_to_world_right};
+    bool same_values = cfg_valid && cfg_topo == m_topo_version && cfg_raw == vertex_positions_raw, same_tangents = cfg_valid && cfg_d_raw == d_vertex_positions_raw;
+    const bool same_raw = same_values, same_d_raw = same_tangents;
+    for (int k = 0; k < 3; ++k) { same_values = same_values && cfg_m[k] == *mv[k]; same_tangents = same_tangents && cfg_dm[k] == *md[k]; }
+    if (same_values && same_tangents) { m_ready = true; return; }
+    if (vf_topo != m_topo_version || vf_begin.size() != (size_t) m_num_vertices + 1) build_vertex_faces();
     std::vector<D3> raw(m_num_vertices), world(m_num_vertices);
     for (int v = 0; v < m_num_vertices; ++v)
         raw[v] = {DF(vertex_positions_raw[3 * v], d_vertex_positions_raw[3 * v]), DF(vertex_positions_raw[3 * v + 1], d_vertex_positions_raw[3 * v + 1]),
                   DF(vertex_positions_raw[3 * v + 2], d_vertex_positions_raw[3 * v + 2])};
     std::vector<float> dummy1, dummy2;
-    process_mesh(raw, face_indices, m_num_faces, dummy1, dummy2, &vertex_normals_raw);
+    if (!raw_normals_valid || !same_raw || !same_d_raw) {       // (a function of the raw vertices alone)
+        process_mesh(raw, face_indices, m_num_faces, vf_begin, vf_item, dummy1, dummy2, &vertex_normals_raw);
+        raw_normals_valid = true;
+    }
     const DM4 tw = to_world();
     vertex_positions.resize(3 * (size_t) m_num_vertices); d_vertex_positions.resize(3 * (size_t) m_num_vertices);
+#pragma omp parallel for schedule(static) if (m_num_vertices > 4096)
     for (int v = 0; v < m_num_vertices; ++v) {
         world[v] = xform_pos(tw, raw[v]);
         vertex_positions[3 * v] = world[v].x.v; vertex_positions[3 * v + 1] = world[v].y.v; vertex_positions[3 * v + 2] = world[v].z.v;
         d_vertex_positions[3 * v] = world[v].x.d; d_vertex_positions[3 * v + 1] = world[v].y.d; d_vertex_positions[3 * v + 2] = world[v].z.d;
     }
-    process_mesh(world, face_indices, m_num_faces, tri, d_tri, nullptr);
-    std::vector<float> areas(m_num_faces);
-    for (int f = 0; f < m_num_faces; ++f) areas[f] = tri[22 * (size_t) f + 21];
-    m_total_area = sum_f32(areas);
-    m_inv_total_area = 1.f / m_total_area;
-    face_distrb.init(areas);
+    for (int k = 0; k < 3; ++k) { m_lower[k] = std::numeric_limits<float>::max(); m_upper[k] = -std::numeric_limits<float>::max(); }
+    for (int v = 0; v < m_num_vertices; ++v)
+        for (int k = 0; k < 3; ++k) { m_lower[k] = std::min(m_lower[k], vertex_positions[3 * v + k]); m_upper[k] = std::max(m_upper[k], vertex_positions[3 * v + k]); }
+    process_mesh(world, face_indices, m_num_faces, vf_begin, vf_item, tri, d_tri, nullptr);
+    if (!same_values) {           // (areas are values: the face distribution follows them)
+        std::vector<float> areas(m_num_faces);
+        for (int f = 0; f < m_num_faces; ++f) areas[f] = tri[22 * (size_t) f + 21];
+        m_total_area = sum_f32(areas);
+        m_inv_total_area = 1.f / m_total_area;
+        face_distrb.init(areas);
+    }
     if (m_enable_edges && edges.empty()) build_edges();
+    if (!same_values) ++m_geo_version;
+    ++m_tan_version;
+    cfg_raw = vertex_positions_raw; cfg_d_raw = d_vertex_positions_raw; cfg_topo = m_topo_version;
+    for (int k = 0; k < 3; ++k) { cfg_m[k] = *mv[k]; cfg_dm[k] = *md[k]; }
+    cfg_valid = true;
     m_ready = true;
 }
 
@@ -362,8 +404,12 @@ void PerspectiveCamera::configure(const Scene &scene, bool keep_edges) {
     const D3 cpos = {DF(pos.x.v), DF(pos.y.v), DF(pos.z.v)};
     for (const Mesh *mesh : scene.m_meshes) {
         if (!mesh->m_enable_edges) continue;
-        int kept = 0;
-        for (const MeshEdge &e : mesh->edges) {
+        // pass 1 (parallel): which edges are kept; pass 2 (parallel): their rows at the positions an in-order walk would give them
+        const int ne = (int) mesh->edges.size();
+        std::vector<uint8_t> keep_flag((size_t) ne, 0);
+#pragma omp parallel for schedule(static) if (ne > 4096)
+        for (int i = 0; i < ne; ++i) {
+            const MeshEdge &e = mesh->edges[(size_t) i];
             const bool valid = e.f1 >= 0;
             const float *t0 = &mesh->tri[22 * (size_t) e.f0];
             const D3 e0 = dnormalize(cpos - fvec(t0)), n0 = fvec(t0 + 18);
@@ -380,20 +426,30 @@ void PerspectiveCamera::configure(const Scene &scene, bool keep_edges) {
             if (mesh->m_use_face_normals) keep = !(valid && ((fdot(e0, n0) < Epsilon && fdot(e1, n1) < Epsilon) || fdot(n0, n1) > 1.f - Epsilon));
             else keep = !valid || ((fdot(e0, n0) > Epsilon) != (fdot(e1, n1) > Epsilon));
             if (mesh->m_has_uv) keep = keep || uv_mask;
-            if (!keep) continue;
-            ++kept;
+            keep_flag[(size_t) i] = keep ? 1 : 0;
+        }
+        std::vector<int> kept_ids;
+        for (int i = 0; i < ne; ++i) if (keep_flag[(size_t) i]) kept_ids.push_back(i);
+        const int kept = (int) kept_ids.size();
+        PSDR_ASSERT_MSG(kept > 0, "slices(info) > 0");
+        const size_t base = pe.length.size();
+        for (std::vector<float> *v : {&pe.p0, &pe.p1, &pe.d_p0, &pe.d_p1, &pe.normal}) v->resize(2 * (base + (size_t) kept));
+        pe.length.resize(base + (size_t) kept); pe.ids.resize(3 * (base + (size_t) kept));
+#pragma omp parallel for schedule(static) if (kept > 4096)
+        for (int j = 0; j < kept; ++j) {
+            const MeshEdge &e = mesh->edges[(size_t) kept_ids[(size_t) j]];
+            const size_t r = base + (size_t) j;
             const D3 q0 = xform_pos(w2s, dvec(&mesh->vertex_positions[3 * e.v0], &mesh->d_vertex_positions[3 * e.v0])),
                      q1 = xform_pos(w2s, dvec(&mesh->vertex_positions[3 * e.v1], &mesh->d_vertex_positions[3 * e.v1]));
             float ex = q1.x.v - q0.x.v, ey = q1.y.v - q0.y.v;
             const float len = std::sqrt(std::fmaf(ey, ey, ex * ex));
             ex /= len; ey /= len;
-            pe.p0.push_back(q0.x.v); pe.p0.push_back(q0.y.v); pe.p1.push_back(q1.x.v); pe.p1.push_back(q1.y.v);
-            pe.d_p0.push_back(q0.x.d); pe.d_p0.push_back(q0.y.d); pe.d_p1.push_back(q1.x.d); pe.d_p1.push_back(q1.y.d);
-            pe.normal.push_back(-ey); pe.normal.push_back(ex);
-            pe.length.push_back(len);
-            pe.ids.push_back(mesh->m_mesh_id); pe.ids.push_back(e.v0); pe.ids.push_back(e.v1);
+            pe.p0[2 * r] = q0.x.v; pe.p0[2 * r + 1] = q0.y.v; pe.p1[2 * r] = q1.x.v; pe.p1[2 * r + 1] = q1.y.v;
+            pe.d_p0[2 * r] = q0.x.d; pe.d_p0[2 * r + 1] = q0.y.d; pe.d_p1[2 * r] = q1.x.d; pe.d_p1[2 * r + 1] = q1.y.d;
+            pe.normal[2 * r] = -ey; pe.normal[2 * r + 1] = ex;
+            pe.length[r] = len;
+            pe.ids[3 * r] = mesh->m_mesh_id; pe.ids[3 * r + 1] = e.v0; pe.ids[3 * r + 2] = e.v1;
         }
-        PSDR_ASSERT_MSG(kept > 0, "slices(info) > 0");
     }
     if (!pe.length.empty() && keep_edges) {
         pe.distrb.init(pe.length);
@@ -534,6 +590,7 @@ void Scene::configure(const std::vector<int> &active_sensor) {
     m_device_config = true;           // (device-side steps of the host half: the environment map's cell masses)
     try { configure_host(active_sensor); } catch (...) { m_device_config = false; throw; }
     m_device_config = false;
+    m_ms_host = duration_cast<duration<double, std::milli>>(high_resolution_clock::now() - start_time).count();
     upload();
     if (m_opts.log_level > 0) {
         std::ostringstream oss;
@@ -562,12 +619,42 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
     for (int id : active_sensor) PSDR_ASSERT_MSG(id >= 0 && id < m_num_sensors, "Invalid sensor id!");
 
     Snapshot &S = snap;
-    S = Snapshot();
+    // the small per-object records are rebuilt every time; the per-triangle and per-edge arrays keep their rows unless their mesh changed
+    S.meshes.clear(); S.bsdfs.clear(); S.emitters.clear(); S.face_pmf.clear(); S.face_cmf.clear(); S.envmap = psdr_envmap_rec{}; S.has_envmap = false;
+    S.emitters_distrb = Distrb();
+    uint32_t same = PSDR_SAME_TRIANGLES | PSDR_SAME_TRI_TANGENTS | PSDR_SAME_SEC_EDGES | PSDR_SAME_PRIM_EDGES | PSDR_SAME_ENV_TEXELS | PSDR_SAME_ENV_TANGENT | PSDR_SAME_BITMAPS;
     // m_upper starts at numeric_limits<float>::min(), the smallest positive float, as in the reference (scene.cpp:357-358)
     for (int k = 0; k < 3; ++k) { m_lower[k] = std::numeric_limits<float>::max(); m_upper[k] = std::numeric_limits<float>::min(); }
+    for (Mesh *mesh : m_meshes) mesh->configure();          // (does nothing for a mesh whose inputs are those of its previous run)
+    auto key_of = [](const Mesh *m) { return MeshKey{m, m->m_topo_version, m->m_num_faces, m->m_bsdf_id, m->m_emitter_id, m->m_has_uv, m->m_use_face_normals, m->m_enable_edges}; };
+    // rows [face_offset, face_offset + n_faces) of the triangle arrays for one mesh: the values and / or the tangents
+    auto write_rows = [&](const Mesh *mesh, size_t face_offset, bool values, bool tangents) {
+        const int nf = mesh->m_num_faces;
+        auto put3 = [](std::vector<float> &dst, size_t row, const float *src) { dst[3 * row] = src[0]; dst[3 * row + 1] = src[1]; dst[3 * row + 2] = src[2]; };
+#pragma omp parallel for schedule(static) if (nf > 4096)
+        for (int f = 0; f < nf; ++f) {
+            const size_t row = face_offset + (size_t) f;
+            const float *t = &mesh->tri[22 * (size_t) f], *d = &mesh->d_tri[22 * (size_t) f];
+            if (values) {
+                put3(S.p0, row, t); put3(S.e1, row, t + 3); put3(S.e2, row, t + 6); put3(S.n0, row, t + 9); put3(S.n1, row, t + 12); put3(S.n2, row, t + 15); put3(S.fn, row, t + 18); S.area[row] = t[21];
+                for (int k = 0; k < 3; ++k) {
+                    if (mesh->m_has_uv) { const int ui = mesh->face_uv_indices[3 * f + k]; S.uv[6 * row + 2 * k] = mesh->vertex_uv[2 * ui]; S.uv[6 * row + 2 * k + 1] = mesh->vertex_uv[2 * ui + 1]; }
+                    else { S.uv[6 * row + 2 * k] = 0.f; S.uv[6 * row + 2 * k + 1] = 0.f; }
+                    S.face_indices[3 * row + k] = mesh->face_indices[3 * f + k];
+                }
+                S.mesh_id[row] = mesh->m_mesh_id;
+                S.flat[row] = mesh->m_use_face_normals ? 1 : 0;
+            }
+            if (tangents) { put3(S.d_p0, row, d); put3(S.d_e1, row, d + 3); put3(S.d_e2, row, d + 6); put3(S.d_n0, row, d + 9); put3(S.d_n1, row, d + 12); put3(S.d_n2, row, d + 15); put3(S.d_fn, row, d + 18); S.d_area[row] = d[21]; }
+        }
+    };
+    auto resize_rows = [&](size_t n) {
+        for (std::vector<float> *v : {&S.p0, &S.e1, &S.e2, &S.n0, &S.n1, &S.n2, &S.fn, &S.d_p0, &S.d_e1, &S.d_e2, &S.d_n0, &S.d_n1, &S.d_n2, &S.d_fn}) v->resize(3 * n);
+        S.area.resize(n); S.d_area.resize(n); S.uv.resize(6 * n); S.mesh_id.resize(n); S.face_indices.resize(3 * n); S.flat.resize(n);
+    };
+    // the mesh records, the face distributions of the emitters' meshes and the scene box (cheap: per mesh, not per triangle)
     int face_offset = 0;
-    auto append_mesh = [&](Mesh *mesh) {
-        mesh->configure();
+    auto append_record = [&](const Mesh *mesh) {
         psdr_mesh_rec r{};
         r.bsdf_id = mesh->m_bsdf_id; r.emitter_id = mesh->m_emitter_id; r.face_offset = face_offset; r.n_faces = mesh->m_num_faces;
         r.inv_total_area = mesh->m_inv_total_area; r.distrb_offset = 0; r.distrb_sum = mesh->face_distrb.sum;
@@ -577,31 +664,52 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
             S.face_cmf.insert(S.face_cmf.end(), mesh->face_distrb.cmf.begin(), mesh->face_distrb.cmf.end());
         }
         S.meshes.push_back(r);
-        for (int f = 0; f < mesh->m_num_faces; ++f) {
-            const float *t = &mesh->tri[22 * (size_t) f], *d = &mesh->d_tri[22 * (size_t) f];
-            auto app = [](std::vector<float> &dst, const float *src) { dst.push_back(src[0]); dst.push_back(src[1]); dst.push_back(src[2]); };
-            app(S.p0, t); app(S.e1, t + 3); app(S.e2, t + 6); app(S.n0, t + 9); app(S.n1, t + 12); app(S.n2, t + 15); app(S.fn, t + 18); S.area.push_back(t[21]);
-            app(S.d_p0, d); app(S.d_e1, d + 3); app(S.d_e2, d + 6); app(S.d_n0, d + 9); app(S.d_n1, d + 12); app(S.d_n2, d + 15); app(S.d_fn, d + 18); S.d_area.push_back(d[21]);
-            for (int k = 0; k < 3; ++k) {
-                if (mesh->m_has_uv) { const int ui = mesh->face_uv_indices[3 * f + k]; S.uv.push_back(mesh->vertex_uv[2 * ui]); S.uv.push_back(mesh->vertex_uv[2 * ui + 1]); }
-                else { S.uv.push_back(0.f); S.uv.push_back(0.f); }
-            }
-            S.mesh_id.push_back(mesh->m_mesh_id);
-            for (int k = 0; k < 3; ++k) S.face_indices.push_back(mesh->face_indices[3 * f + k]);
-            S.flat.push_back(mesh->m_use_face_normals ? 1 : 0);
-        }
         face_offset += mesh->m_num_faces;
-        for (int v = 0; v < mesh->m_num_vertices; ++v)
-            for (int k = 0; k < 3; ++k) { m_lower[k] = std::min(m_lower[k], mesh->vertex_positions[3 * v + k]); m_upper[k] = std::max(m_upper[k], mesh->vertex_positions[3 * v + k]); }
+        for (int k = 0; k < 3; ++k) { m_lower[k] = std::min(m_lower[k], mesh->m_lower[k]); m_upper[k] = std::max(m_upper[k], mesh->m_upper[k]); }
     };
-    for (Mesh *mesh : m_meshes) append_mesh(mesh);
+    {
+        std::vector<MeshKey> keys;
+        size_t total = 0;
+        for (const Mesh *mesh : m_meshes) { keys.push_back(key_of(mesh)); total += (size_t) mesh->m_num_faces; }
+        const bool same_layout = keys == m_snap_keys && S.area.size() == total && m_seen_geo.size() == m_meshes.size();
+        if (!same_layout) {
+            resize_rows(total);
+            m_seen_geo.assign(m_meshes.size(), ~0ull); m_seen_tan.assign(m_meshes.size(), ~0ull);
+            m_snap_keys = keys;
+            ++m_layout_version;
+        }
+        for (size_t i = 0; i < m_meshes.size(); ++i) {
+            const Mesh *mesh = m_meshes[i];
+            const bool values = m_seen_geo[i] != mesh->m_geo_version, tangents = m_seen_tan[i] != mesh->m_tan_version;
+            if (values || tangents) write_rows(mesh, (size_t) face_offset, values, tangents);
+            if (values) same &= ~PSDR_SAME_TRIANGLES;
+            if (tangents) same &= ~PSDR_SAME_TRI_TANGENTS;
+            m_seen_geo[i] = mesh->m_geo_version; m_seen_tan[i] = mesh->m_tan_version;
+            append_record(mesh);
+        }
+    }
+    uint64_t geo_sum = 0, tan_sum = 0;           // (versions only grow: equal sums = no mesh changed)
+    for (const Mesh *mesh : m_meshes) { geo_sum += mesh->m_geo_version; tan_sum += mesh->m_tan_version; }
 
     // sensors: only the active ones keep their primary-edge list (scene.cpp:381-416)
     std::vector<size_t> num_edges;
     for (int sid = 0; sid < m_num_sensors; ++sid) {
         const bool active = std::find(active_sensor.begin(), active_sensor.end(), sid) != active_sensor.end();
         PerspectiveCamera *cam = static_cast<PerspectiveCamera *>(m_sensors[sid]);
-        cam->configure(*this, active);
+        {
+            // the sensor's own members, the render options and the state of the meshes it projects: the same as in its previous run -> nothing to do
+            std::vector<float> key;
+            for (const M16 *m : {&cam->to_world_left, &cam->to_world_raw, &cam->to_world_right, &cam->d_to_world_left, &cam->d_to_world_raw, &cam->d_to_world_right}) key.insert(key.end(), m->begin(), m->end());
+            const double extra[] = {(double) cam->m_fov_x, (double) cam->m_near_clip, (double) cam->m_far_clip, cam->m_orthographic ? 1.0 : 0.0, (double) m_opts.width, (double) m_opts.height,
+                                    (double) m_opts.sppe, active ? 1.0 : 0.0, (double) (geo_sum & 0xffffffffull), (double) (geo_sum >> 32), (double) (tan_sum & 0xffffffffull), (double) (tan_sum >> 32),
+                                    (double) (m_layout_version & 0xffffffull)};
+            for (double x : extra) key.push_back((float) x);
+            if (key != cam->cfg_key || m_opts.sppe <= 0) {
+                cam->configure(*this, active);
+                cam->cfg_key = key;
+                cam->m_edges_version++;
+            }
+        }
         if (!cam->m_orthographic)      // only PerspectiveCamera positions extend the scene box (scene.cpp:383-387, 410-414)
             for (int k = 0; k < 3; ++k) { m_lower[k] = std::min(m_lower[k], cam->rec.cam_pos[k]); m_upper[k] = std::max(m_upper[k], cam->rec.cam_pos[k]); }
         if (m_opts.sppe > 0 && (active || active_sensor.empty())) num_edges.push_back(cam->m_enable_edges ? cam->m_edges.length.size() : 1);
@@ -638,16 +746,25 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
         m_meshes.push_back(bound);
         ++m_num_meshes;
         m_has_bound_mesh = true;
-        append_mesh(bound);
+        bound->configure();
+        resize_rows(S.area.size() + (size_t) bound->m_num_faces);
+        write_rows(bound, (size_t) face_offset, true, true);
+        append_record(bound);
+        m_snap_keys.push_back(key_of(bound)); m_seen_geo.push_back(bound->m_geo_version); m_seen_tan.push_back(bound->m_tan_version);
+        geo_sum += bound->m_geo_version; tan_sum += bound->m_tan_version;
+        ++m_layout_version;
+        same &= ~(PSDR_SAME_TRIANGLES | PSDR_SAME_TRI_TANGENTS);
         if (m_opts.log_level > 0) log("Bounding mesh added for environmental lighting.");
     }
 
     // emitters (area.cpp:9-14, envmap.cpp:17-44, scene.cpp:488-515)
+    bool env_cells_rebuilt = false;
     if (!m_emitters.empty()) {
         std::vector<float> weights;
         double total_weight = 0.0;
         for (Emitter *e : m_emitters) {
             if (EnvironmentMap *env = dynamic_cast<EnvironmentMap *>(e)) {
+                env_cells_rebuilt = env_cells_rebuilt || env->m_cells_dirty || env->cell_distrb.pmf.empty();
                 env->configure(m_device_config);
             } else {
                 AreaLight *al = static_cast<AreaLight *>(e);
@@ -802,33 +919,90 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
         }
 
     // secondary edges (mesh.cpp:355-369, scene.cpp:546-571): every mesh edge is kept
-    if (m_opts.sppse > 0) {
+    const bool sec_same = m_opts.sppse > 0 && m_sec_sppse > 0 && m_sec_geo == geo_sum && m_sec_tan == tan_sum && m_sec_layout == m_layout_version;
+    if (!sec_same) {
+        same &= ~PSDR_SAME_SEC_EDGES;
+        for (std::vector<float> *v : {&S.se_p0, &S.se_e1, &S.se_n0, &S.se_n1, &S.se_p2, &S.se_d_p0, &S.se_d_e1}) v->clear();
+        S.se_boundary.clear(); S.n_sec_edges = 0; S.sec_edge_distrb = Distrb();
+        m_sec_geo = geo_sum; m_sec_tan = tan_sum; m_sec_sppse = m_opts.sppse; m_sec_layout = m_layout_version;
+    }
+    if (m_opts.sppse > 0 && !sec_same) {
         std::vector<float> pmf;
-        int fo = 0;
+        size_t total_edges = 0;
+        for (const Mesh *mesh : m_meshes) if (mesh->m_enable_edges) total_edges += mesh->edges.size();
+        for (std::vector<float> *v : {&S.se_p0, &S.se_e1, &S.se_n0, &S.se_n1, &S.se_p2, &S.se_d_p0, &S.se_d_e1}) v->resize(3 * total_edges);
+        S.se_boundary.resize(total_edges); pmf.resize(total_edges);
+        size_t base = 0;
         for (const Mesh *mesh : m_meshes) {
-            if (mesh->m_enable_edges) {
-                for (const MeshEdge &e : mesh->edges) {
-                    const float *P = mesh->vertex_positions.data(), *dP = mesh->d_vertex_positions.data();
-                    float e1[3], de1[3];
-                    for (int k = 0; k < 3; ++k) {
-                        e1[k] = P[3 * e.v1 + k] - P[3 * e.v0 + k]; de1[k] = dP[3 * e.v1 + k] - dP[3 * e.v0 + k];
-                        S.se_p0.push_back(P[3 * e.v0 + k]); S.se_d_p0.push_back(dP[3 * e.v0 + k]);
-                        S.se_p2.push_back(P[3 * e.opp + k]);
-                        S.se_n0.push_back(mesh->tri[22 * (size_t) e.f0 + 18 + k]);
-                        S.se_n1.push_back(e.f1 >= 0 ? mesh->tri[22 * (size_t) e.f1 + 18 + k] : 0.f);
-                    }
-                    for (int k = 0; k < 3; ++k) { S.se_e1.push_back(e1[k]); S.se_d_e1.push_back(de1[k]); }
-                    S.se_boundary.push_back(e.f1 < 0 ? 1 : 0);
-                    pmf.push_back(std::sqrt(std::fmaf(e1[2], e1[2], std::fmaf(e1[1], e1[1], e1[0] * e1[0]))));
+            if (!mesh->m_enable_edges) continue;
+            const int ne = (int) mesh->edges.size();
+            const float *P = mesh->vertex_positions.data(), *dP = mesh->d_vertex_positions.data();
+#pragma omp parallel for schedule(static) if (ne > 4096)
+            for (int i = 0; i < ne; ++i) {
+                const MeshEdge &e = mesh->edges[(size_t) i];
+                const size_t r = base + (size_t) i;
+                float e1[3];
+                for (int k = 0; k < 3; ++k) {
+                    e1[k] = P[3 * e.v1 + k] - P[3 * e.v0 + k];
+                    S.se_e1[3 * r + k] = e1[k]; S.se_d_e1[3 * r + k] = dP[3 * e.v1 + k] - dP[3 * e.v0 + k];
+                    S.se_p0[3 * r + k] = P[3 * e.v0 + k]; S.se_d_p0[3 * r + k] = dP[3 * e.v0 + k];
+                    S.se_p2[3 * r + k] = P[3 * e.opp + k];
+                    S.se_n0[3 * r + k] = mesh->tri[22 * (size_t) e.f0 + 18 + k];
+                    S.se_n1[3 * r + k] = e.f1 >= 0 ? mesh->tri[22 * (size_t) e.f1 + 18 + k] : 0.f;
                 }
+                S.se_boundary[r] = e.f1 < 0 ? 1 : 0;
+                pmf[r] = std::sqrt(std::fmaf(e1[2], e1[2], std::fmaf(e1[1], e1[1], e1[0] * e1[0])));
             }
-            fo += mesh->m_num_faces;
+            base += (size_t) ne;
         }
         S.n_sec_edges = (int) pmf.size();
         if (!pmf.empty()) S.sec_edge_distrb.init(pmf);
         if (m_opts.log_level > 0) { std::ostringstream oss; oss << S.n_sec_edges << " secondary edges initialized."; log(oss.str()); }
     }
 
+    // primary edges: unchanged when no sensor ran its configure
+    if (m_seen_edges.size() != m_sensors.size()) { m_seen_edges.assign(m_sensors.size(), ~0ull); }
+    for (size_t i = 0; i < m_sensors.size(); ++i) {
+        if (m_seen_edges[i] != m_sensors[i]->m_edges_version) same &= ~PSDR_SAME_PRIM_EDGES;
+        m_seen_edges[i] = m_sensors[i]->m_edges_version;
+    }
+    // bitmap parameters and the environment map's tangent: by content (FNV-style hash of the arrays the records point to)
+    {
+        auto hash = [](uint64_t h, const float *p, size_t n) {
+            const size_t n8 = n / 2;
+            const uint64_t *q = reinterpret_cast<const uint64_t *>(p);
+            uint64_t a = h ^ (n * 0x9e3779b97f4a7c15ull), b = 0x2545f4914f6cdd1dull, c = 0x9e3779b97f4a7c15ull, d = 0xc2b2ae3d27d4eb4full;
+            size_t i = 0;
+            for (; i + 4 <= n8; i += 4) {         // four independent lanes: the loop runs at memory speed
+                uint64_t w0, w1, w2, w3;
+                std::memcpy(&w0, q + i, 8); std::memcpy(&w1, q + i + 1, 8); std::memcpy(&w2, q + i + 2, 8); std::memcpy(&w3, q + i + 3, 8);
+                a = (a ^ w0) * 0x100000001b3ull; b = (b ^ w1) * 0x100000001b3ull; c = (c ^ w2) * 0x100000001b3ull; d = (d ^ w3) * 0x100000001b3ull;
+            }
+            for (; i < n8; ++i) { uint64_t w0; std::memcpy(&w0, q + i, 8); a = (a ^ w0) * 0x100000001b3ull; }
+            if (n & 1) { uint32_t w0; std::memcpy(&w0, p + n - 1, 4); a = (a ^ w0) * 0x100000001b3ull; }
+            uint64_t r = a;
+            r = (r ^ (b >> 7)) * 0x100000001b3ull; r = (r ^ (c >> 11)) * 0x100000001b3ull; r = (r ^ (d >> 13)) * 0x100000001b3ull;
+            return r;
+        };
+        uint64_t hb = 0xcbf29ce484222325ull;
+        for (const psdr_bsdf_rec &b : S.bsdfs) {
+            const float *ptrs[6] = {b.tex_data, b.d_tex_data, b.spec_tex_data, b.d_spec_tex_data, b.rough_tex_data, b.d_rough_tex_data};
+            const size_t lens[6] = {(size_t) 3 * b.tex_width * b.tex_height, (size_t) 3 * b.tex_width * b.tex_height, (size_t) 3 * b.spec_tex_width * b.spec_tex_height,
+                                    (size_t) 3 * b.spec_tex_width * b.spec_tex_height, (size_t) b.rough_tex_width * b.rough_tex_height, (size_t) b.rough_tex_width * b.rough_tex_height};
+            for (int k = 0; k < 6; ++k) hb = ptrs[k] ? hash(hb, ptrs[k], lens[k]) : hb * 31 + 7;
+            const float *pv[6] = {b.pv_specular, b.d_pv_specular, b.pv_diffuse, b.d_pv_diffuse, b.pv_roughness, b.d_pv_roughness};
+            const size_t pl[6] = {(size_t) 3 * b.pv_count, (size_t) 3 * b.pv_count, (size_t) 3 * b.pv_count, (size_t) 3 * b.pv_count, (size_t) b.pv_count, (size_t) b.pv_count};
+            for (int k = 0; k < 6; ++k) hb = pv[k] ? hash(hb, pv[k], pl[k]) : hb * 31 + 11;
+        }
+        if (hb != m_bitmap_hash) same &= ~PSDR_SAME_BITMAPS;
+        m_bitmap_hash = hb;
+        uint64_t he = 0xcbf29ce484222325ull;
+        if (S.has_envmap && S.envmap.d_radiance) he = hash(he, S.envmap.d_radiance, (size_t) 3 * S.envmap.width * S.envmap.height);
+        if (he != m_env_tan_hash) same &= ~PSDR_SAME_ENV_TANGENT;
+        m_env_tan_hash = he;
+    }
+    if (env_cells_rebuilt) same &= ~PSDR_SAME_ENV_TEXELS;
+    m_same &= same;              // (several configure_host() calls may pass before the next upload)
     m_host_ready = true;
 }
 
@@ -873,8 +1047,16 @@ void Scene::upload() {
         S.sensors.push_back(r);
     }
     sn.n_sensors = (int) S.sensors.size(); sn.sensors = S.sensors.data();
-    release_device();
-    hip_check(psdr_hip_scene_create(&sn, &m_hip));
+    // the device copy: created once, then updated in place - only what changed since the previous upload is rewritten and sent, the tree is kept
+    // (refitted on the device when triangles moved); psdr_hip_scene_update, include/psdr_hip.h
+    if (m_hip != nullptr && m_always_rebuild) release_device();
+    if (m_hip == nullptr) {
+        hip_check(psdr_hip_scene_create(&sn, &m_hip));
+        hip_check(psdr_hip_scene_last_update(m_hip, &m_last_update));
+    } else {
+        hip_check(psdr_hip_scene_update(m_hip, &sn, m_same, &m_last_update));
+    }
+    m_same = PSDR_SAME_TRIANGLES | PSDR_SAME_TRI_TANGENTS | PSDR_SAME_SEC_EDGES | PSDR_SAME_PRIM_EDGES | PSDR_SAME_ENV_TEXELS | PSDR_SAME_ENV_TANGENT | PSDR_SAME_BITMAPS;
     m_configured = true;
 }
 

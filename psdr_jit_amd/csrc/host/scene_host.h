@@ -208,8 +208,22 @@ struct Mesh : Object, Transformable {
     Distrb face_distrb;
     // per-face TriangleInfo rows (value, tangent), 22 floats each: p0 e1 e2 n0 n1 n2 fn area
     std::vector<float> tri, d_tri;
+    // configure() compares its inputs with the ones of its previous run and does nothing when they are the same (the reference recomputes and
+    // re-uploads every mesh in every Scene::configure, src/scene/scene.cpp:346-371).  What it found: m_geo_version counts the runs in which a value
+    // input (raw vertices, a to_world factor, the topology) differed, m_tan_version the runs in which a value or a tangent input differed -
+    // Scene::configure_host rewrites the snapshot rows of a mesh, and tells the device library what is unchanged, from these.
+    uint64_t m_topo_version = 1;               // bumped by load / load_raw (faces, uv indices, vertex count)
+    uint64_t m_geo_version = 0, m_tan_version = 0;
+    float m_lower[3] = {0, 0, 0}, m_upper[3] = {0, 0, 0};       // box of the world-space vertices
 private:
     void build_edges();
+    void build_vertex_faces();
+    std::vector<float> cfg_raw, cfg_d_raw;     // inputs of the previous configure()
+    M16 cfg_m[3], cfg_dm[3];
+    uint64_t cfg_topo = 0;
+    bool cfg_valid = false, raw_normals_valid = false;
+    std::vector<int> vf_begin, vf_item;        // per vertex: its (corner, face) incidences as corner * num_faces + face, ascending = the order process_mesh sums them in
+    uint64_t vf_topo = 0;
 };
 
 struct PrimaryEdges {
@@ -223,6 +237,10 @@ struct Sensor : Object, Transformable {
     virtual void configure(const Scene &scene, bool keep_edges) = 0;
     bool m_enable_edges = false;
     PrimaryEdges m_edges;
+    // inputs of the previous configure(): the sensor's own members, the render options and the versions of the scene's meshes it was run against
+    // (Scene::configure_host skips a sensor whose inputs are the same; m_edges_version counts the runs that rebuilt the primary edges)
+    std::vector<float> cfg_key;
+    uint64_t m_edges_version = 0;
 };
 struct PerspectiveCamera : Sensor {
     PerspectiveCamera(float fov_x, float near_, float far_) : m_fov_x(fov_x), m_near_clip(near_), m_far_clip(far_) {}
@@ -292,9 +310,24 @@ struct Scene : Object {
     psdr_hip_scene *m_hip = nullptr;
     bool m_configured = false, m_host_ready = false;
     bool m_device_config = false;      // configure_host() runs inside configure(): its device-side steps are allowed
+    // Incremental configure.  configure_host() rewrites only the snapshot rows whose inputs changed and accumulates in m_same the PSDR_SAME_* bits
+    // (include/psdr_hip.h) that still hold relative to the snapshot the device has; upload() hands them to psdr_hip_scene_update and resets them.
+    uint32_t m_same = 0;
+    psdr_update_info m_last_update{};
+    double m_ms_host = 0.0;            // wall clock of the host half (configure_host) of the last configure()
+    bool m_always_rebuild = false;     // test / measurement aid: destroy and create the device scene in every configure() (what rounds 1-4 did)
 private:
     void rebuild_param_map();
     void release_device();
+    struct MeshKey { const Mesh *mesh; uint64_t topo; int nf, bsdf, emitter; bool uv, flat, edges; bool operator==(const MeshKey &o) const { return mesh == o.mesh && topo == o.topo && nf == o.nf && bsdf == o.bsdf && emitter == o.emitter && uv == o.uv && flat == o.flat && edges == o.edges; } };
+    std::vector<MeshKey> m_snap_keys;                      // the meshes the snapshot's rows were laid out for
+    std::vector<uint64_t> m_seen_geo, m_seen_tan;          // per mesh: the versions its snapshot rows hold
+    uint64_t m_layout_version = 0;                         // counts the configure_host() runs that laid the triangle rows out anew (another mesh list, topology or flag)
+    uint64_t m_sec_layout = ~0ull;
+    uint64_t m_sec_geo = ~0ull, m_sec_tan = ~0ull;         // sum of the mesh versions the secondary-edge arrays were built from
+    int m_sec_sppse = -1;
+    uint64_t m_bitmap_hash = 0, m_env_tan_hash = 0;
+    std::vector<uint64_t> m_seen_edges;                    // per sensor: Sensor::m_edges_version at the last upload-relevant configure
 };
 
 struct Integrator : Object {

@@ -24,11 +24,28 @@ import subprocess
 import sys
 import tempfile
 
-OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+def _find_objdump():
+    """llvm-objdump of the toolchain that compiles the kernels: beside $HIPCC, under $ROCM_PATH, under /opt/rocm, then on PATH"""
+    import shutil
+    cands = []
+    hipcc = os.environ.get("HIPCC")
+    if hipcc:
+        root = os.path.dirname(os.path.dirname(os.path.realpath(hipcc)))
+        cands += [os.path.join(root, "lib", "llvm", "bin", "llvm-objdump"), os.path.join(root, "llvm", "bin", "llvm-objdump")]
+    for root in (os.environ.get("ROCM_PATH"), "/opt/rocm"):
+        if root:
+            cands += [os.path.join(root, "lib", "llvm", "bin", "llvm-objdump"), os.path.join(root, "llvm", "bin", "llvm-objdump")]
+    for c in cands:
+        if os.path.exists(c):
+            return c
+    return shutil.which("llvm-objdump")
+
+
+OBJDUMP = _find_objdump()
 
 
 def available():
-    return os.path.exists(OBJDUMP)
+    return OBJDUMP is not None and os.path.exists(OBJDUMP)
 
 INS = re.compile(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):\s*[0-9A-Fa-f ]+(?:<([^>]+)>)?\s*$")
 FUNC = re.compile(r"^([0-9a-f]+) <(.+)>:$")

@@ -75,7 +75,7 @@ def test_lint_flags_a_constant_written_before_the_lane_restore(tmp_path, monkeyp
 
 def test_shipped_library_is_clean():
     """every gfx950 kernel of the library the GPU tests load: no allocator-inserted vector instruction in front of an exec restore"""
-    if not os.path.exists(isa_lint.OBJDUMP):
+    if not isa_lint.available():
         pytest.skip("llvm-objdump is not installed")
     import __graft_entry__
     __graft_entry__.build()
@@ -105,7 +105,7 @@ def test_build_recipe_compiles_a_flagged_unit_again_and_fails_if_that_does_not_h
     monkeypatch.setattr(b, "_run", lambda cmd: calls.append(cmd) or "")
     monkeypatch.delenv("PSDR_BUILD_NO_LINT", raising=False)
     finding = [("k_interior_adjoint<2>", 0x133c0, ["v_mov_b32_e32 v110, 0x40490fdb"])]
-    units = [("main", ["-DPSDR_SPLIT"]), ("tu4", ["-DPSDR_TU=4"])]
+    units = [("main", b.API_SRC, ["-DPSDR_SPLIT"], b.API_DEPS), ("tu4", b.API_SRC, ["-DPSDR_TU=4"], b.API_DEPS)]
     verdicts.update({"api_main.o": [[]], "api_tu4.o": [finding, []]})
     b._lint_units("hipcc", ["--offload-arch=gfx950", "-O3"], units, str(tmp_path))
     assert len(calls) == 1 and "-DPSDR_TU=4" in calls[0] and calls[0][-1].endswith("api_tu4.o")
@@ -115,3 +115,16 @@ def test_build_recipe_compiles_a_flagged_unit_again_and_fails_if_that_does_not_h
     verdicts.update({"api_main.o": [[]], "api_tu4.o": [finding, finding]})
     with pytest.raises(RuntimeError, match="still has vector instructions ahead of an exec restore"):
         b._lint_units("hipcc", ["--offload-arch=gfx950", "-O3"], units, str(tmp_path))
+
+    # a toolchain without llvm-objdump: the lint cannot run, and the build says so instead of shipping unchecked kernels
+    class NoLint(FakeLint):
+        @staticmethod
+        def available():
+            return False
+
+    monkeypatch.setattr(b, "_load_lint", lambda: NoLint)
+    with pytest.raises(RuntimeError, match="llvm-objdump not found"):
+        b._lint_units("hipcc", ["--offload-arch=gfx950", "-O3"], units, str(tmp_path))
+    monkeypatch.setenv("PSDR_BUILD_NO_LINT", "1")           # the explicit development switch still builds
+    b._lint_units("hipcc", ["--offload-arch=gfx950", "-O3"], units, str(tmp_path))
+    assert "lint skipped" in open(os.path.join(str(tmp_path), "lint.txt")).read()
