@@ -33,6 +33,8 @@ Prints ONE JSON line (rank 0).  Extra objects (N = 1, rank 0; each can be switch
   config5      - (default run only) the BVH path at BASELINE config 5's full size: ms per renderD, per-kernel HIP-event times, counted
                  nodes / triangles per ray, the dominant kernel against the L2 ceiling (34.5 TB/s) with the HBM rate and L2 hit rate
                  of the committed rocprofv3 passes; `--config 5` makes it the headline workload instead.
+  api          - (N = 1) through the public Python surface (tools/configure_timing.py): api_call_ms = renderD + forward_grad as a user calls them, configure_ms per kind
+                 of change (nothing / a colour / moved vertices / the rebuild of rounds 1-4), step_ms = configure + renderD + backward; the same inside `config5`.
   rccl         - PSDR_BENCH_FORCE_DIST=1 runs the N > 1 code path (process group with device_id, device-pointer all-reduce, teardown)
                  at whatever world size the launcher gives, also 1 (the preflight of tests/test_gpu_distributed.py).
   parity       - relative L2 of this run's GPU image / derivative against the oracle on the same shard and seeds.
@@ -146,6 +148,7 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="override the configuration's sample counts (measurement aid; the line names it)")
     ap.add_argument("--no-backward", action="store_true")
     ap.add_argument("--no-config5", action="store_true")
+    ap.add_argument("--no-api", action="store_true", help="skip the legs through the public Python surface (api_call_ms, configure_ms, step_ms)")
     ap.add_argument("--weak", action="store_true", help="N > 1: config 3 with spp = 32 * N (weak scaling)")
     ap.add_argument("--cpu-shard", type=int, default=0, help="the CPU baseline renders every k-th 256-lane chunk (0 = calibrate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -298,6 +301,10 @@ def main():
     try:        # the live-pixel mask of the timed scene (psdr_hip_scene_live_pixels): which part of the frame the interior term passes over
         n_live = C.c_int64(0)
         cabi.check(cabi.lib().psdr_hip_scene_live_pixels(C.c_void_p(handle), 0, None, C.byref(n_live)))
+        # `value` counts every sample the reference would launch; `value_traced` only the interior samples this build traces (live pixels x spp) - the
+        # like-for-like figure against builds without the mask (PSDR_NO_LIVE_MASK=1) and against rounds 1-3
+        out["traced_samples_per_step"] = int(n_live.value * spp)
+        out["value_traced"] = round(n_live.value * spp / (dt / args.steps) / 1e6, 3)
         out["live_pixels"] = {"fraction": round(n_live.value / float(npx), 4),
                               "note": "interior-term samples of the other pixels are provably zero and are passed over before seeding (they count in `value`, as for the reference, "
                                       "which launches them); PSDR_NO_LIVE_MASK=1 renders them"}
@@ -465,6 +472,13 @@ def main():
         }
         if not args.no_backward:
             out["config5"]["backward"] = backward_leg(sc5, h5, gd5, c5["res"] * c5["res"], 2)
+        if not args.no_api:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import configure_timing
+                out["config5"]["api"] = configure_timing.measure(psdr, sc5, "BSDF[0]", reps=5, depth=DEPTH, heavy_reps=2)
+            except Exception as e:
+                out["config5"]["api"] = {"error": repr(e)[:300]}
         del buf5, sc5
 
     if use_dist:
@@ -536,6 +550,22 @@ def main():
                           "CPU quota %s): 1 warm-up + median of 5, %.2f s per run; one thread: the same frame at 1 sample per pixel, %s"
                           % (cspp, spp, npx, n_thr, phys, ("%.1f" % quota) if quota else "none", tc, ("%.2f s" % t1) if t1 else "not timed"),
             }
+
+    # ---------------------------------------------------------------- the calls a user makes (rank 0, N = 1; last: these legs reconfigure the scene)
+    if rank == 0 and n == 1 and not args.no_api and cfg != 5:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import configure_timing
+            sc.param_map["Mesh[0]"].set_transform(psdr.Matrix4fC([[1., 0., 0., 0.], [0., 1., 0., 0.], [0., 0., 1., 0.], [0., 0., 0., 1.]]))
+            api = configure_timing.measure(psdr, sc, "BSDF[1]", reps=7, depth=DEPTH)
+            api["note"] = ("through the public Python surface, device synchronised around every call, median after one warm-up: api_call_ms = PathTracer(3).renderD(sc, 0) + "
+                           "forward_grad(img, P) (SURVEY 8(d): wall time of one renderD call with its derivative); configure_ms = Scene.configure() after no change / a colour / "
+                           "a translation of Mesh[0] (`rebuild`: the device scene destroyed and created as rounds 1-4 did); step_ms = configure + renderD + loss + backward "
+                           "(reverse_*) or + forward_grad (forward_vertices)")
+            api["api_call_over_ms_per_step"] = round(api["api_call_ms"] / ms_per_step, 3)
+            out["api"] = api
+        except Exception as e:      # (never in the way of the line)
+            out["api"] = {"error": repr(e)[:300]}
 
     if rank == 0:
         print(json.dumps(out))

@@ -1009,6 +1009,7 @@ class _RenderDFn(_torch.autograd.Function):
         from . import chain
         st = ctx.state
         integ, scene = st["integrator"], st["scene"]
+        scene.__dict__["_psdr_fwd_hint"] = None          # this scene's images go to reverse mode: renderD makes no forward-mode launch ahead of time
         leaves = st["leaves"]
         needs = ctx.needs_input_grad[1:]
         want_cam = any(need and isinstance(obj, Sensor) for (obj, name, t), need in zip(leaves, needs))
@@ -1183,37 +1184,12 @@ def _replay_forward(integ, scene, st, tangents):
     return dimg
 
 
-def _renderD(self, scene, sensor_id=0, seed=-1, batch_pix=-1, terms=TERM_ALL):
-    """Integrator.renderD (reference integrator.cpp:51-100).  Returns the image as a tensor attached
-    to the autograd graph of the scene's torch parameters."""
-    leaves = _leaves(scene, self)
-    for _name, _t in self.__dict__.get("_psdr_params", {}).items():       # the integrator's own tensor parameters (m_intensity)
-        _v = _t.detach().to("cpu", _torch.float32).numpy().reshape(-1)
-        self._set(_name, _v, _zeros_like(_v))
-    state = {"integrator": self, "scene": scene, "sensor_id": sensor_id, "batch_pix": batch_pix, "terms": terms,
-             "active": scene.__dict__.get("_psdr_active", []), "leaves": leaves, "seed": seed,
-             "samplers": [scene._sampler_state(k) for k in range(3)]}      # the streams this call starts from
-    tens = [t for (_, _, t) in leaves]
-    if any(t.requires_grad for t in tens):
-        # the derivative is computed later (forward_grad / backward) from the recorded sampler state: now only the primal
-        # image is needed, and both edge terms have zero primal - launch the interior term, advance all three samplers
-        img, _ = _render_d_raw(self, scene, sensor_id, seed, batch_pix, (terms & TERM_INTERIOR) | ((terms & 7) << 4))
-        state["img"] = img
-        return _RenderDFn.apply(state, *tens)
-    img, dimg = _render_d_raw(self, scene, sensor_id, seed, batch_pix, terms)
-    return img
-
-
-def forward_grad(img, param, direction=None):
-    """d img / d param along `direction` (default: ones) — the torch spelling of
-    drjit.set_grad(P, 1); drjit.forward_to(img); drjit.grad(img) (reference README.md:102-104)."""
-    fn = img.grad_fn
-    if fn is None or not hasattr(fn, "state"):
-        raise RuntimeError("forward_grad: img does not come from renderD with differentiable scene parameters")
-    st = fn.state
+def _jvp_tangents(leaves, param, direction=None):
+    """{id(leaf tensor): d leaf / d param . direction} for the scene's torch parameters (direction default: ones): the tangents
+    drjit.set_grad(param, direction); drjit.forward_to(...) would carry into the scene (reference README.md:102-104)"""
     tangents = {}
     v = _torch.ones_like(param) if direction is None else direction
-    for (obj, name, t) in st["leaves"]:
+    for (obj, name, t) in leaves:
         if not t.requires_grad:
             continue
         if t is param:
@@ -1226,9 +1202,64 @@ def forward_grad(img, param, direction=None):
         (jv,) = _torch.autograd.grad(g, w, v, allow_unused=True)
         if jv is not None:
             tangents[id(t)] = jv.detach().cpu().numpy()
-    dimg = _replay_forward(st["integrator"], st["scene"], st, tangents)
-    _sync_params(st["scene"], None, st["integrator"])
-    st["scene"]._configure(st["active"])
+    return tangents
+
+
+def _renderD(self, scene, sensor_id=0, seed=-1, batch_pix=-1, terms=TERM_ALL):
+    """Integrator.renderD (reference integrator.cpp:51-100).  Returns the image as a tensor attached
+    to the autograd graph of the scene's torch parameters."""
+    import weakref
+    leaves = _leaves(scene, self)
+    for _name, _t in self.__dict__.get("_psdr_params", {}).items():       # the integrator's own tensor parameters (m_intensity)
+        _v = _t.detach().to("cpu", _torch.float32).numpy().reshape(-1)
+        self._set(_name, _v, _zeros_like(_v))
+    state = {"integrator": self, "scene": scene, "sensor_id": sensor_id, "batch_pix": batch_pix, "terms": terms,
+             "active": scene.__dict__.get("_psdr_active", []), "leaves": leaves, "seed": seed,
+             "samplers": [scene._sampler_state(k) for k in range(3)]}      # the streams this call starts from
+    tens = [t for (_, _, t) in leaves]
+    if any(t.requires_grad for t in tens):
+        # The derivative is computed later (forward_grad / backward) from the recorded sampler state: in general only the primal image is
+        # needed now, and both edge terms have zero primal - launch the interior term, advance all three samplers.
+        # When the previous image of this scene went to forward_grad(img, P) for a P that is still alive, this call is expected to go the
+        # same way (an optimisation loop repeats its step): the tangents of P are installed and the ONE launch that forward mode needs is
+        # made now - image and derivative from the same pass, as the reference gets them from one recorded renderD - instead of a primal pass
+        # here and a full replay in forward_grad.  A wrong guess costs the edge terms of one call, never a result: forward_grad and backward
+        # check what they find.
+        hint = scene.__dict__.get("_psdr_fwd_hint")
+        param = hint["param"]() if hint else None
+        if param is not None and param.requires_grad and (terms & 7) != 0:
+            tangents = _jvp_tangents(leaves, param)
+            if tangents:
+                _sync_params(scene, tangents, self)
+                scene._configure(state["active"])
+                img, dimg = _render_d_raw(self, scene, sensor_id, seed, batch_pix, terms)
+                _sync_params(scene, None, self)
+                scene._configure(state["active"])
+                state["img"], state["dimg"], state["dimg_param"] = img, dimg, weakref.ref(param)
+                return _RenderDFn.apply(state, *tens)
+        img, _ = _render_d_raw(self, scene, sensor_id, seed, batch_pix, (terms & TERM_INTERIOR) | ((terms & 7) << 4))
+        state["img"] = img
+        return _RenderDFn.apply(state, *tens)
+    img, dimg = _render_d_raw(self, scene, sensor_id, seed, batch_pix, terms)
+    return img
+
+
+def forward_grad(img, param, direction=None):
+    """d img / d param along `direction` (default: ones) — the torch spelling of
+    drjit.set_grad(P, 1); drjit.forward_to(img); drjit.grad(img) (reference README.md:102-104)."""
+    import weakref
+    fn = img.grad_fn
+    if fn is None or not hasattr(fn, "state"):
+        raise RuntimeError("forward_grad: img does not come from renderD with differentiable scene parameters")
+    st = fn.state
+    scene = st["scene"]
+    scene.__dict__["_psdr_fwd_hint"] = {"param": weakref.ref(param)}       # (the next renderD of this scene: see _renderD)
+    if direction is None and st.get("dimg") is not None and st["dimg_param"]() is param:
+        return st["dimg"]                                                   # renderD made the forward-mode launch already
+    tangents = _jvp_tangents(st["leaves"], param, direction)
+    dimg = _replay_forward(st["integrator"], scene, st, tangents)
+    _sync_params(scene, None, st["integrator"])
+    scene._configure(st["active"])
     return dimg
 
 

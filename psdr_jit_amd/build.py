@@ -28,10 +28,10 @@ BUILD_DEPS = [os.path.join(HERE, "isa_lint.py")]          # part of the recipe: 
 _H = lambda *names: [os.path.join(CSRC, "hip", f) for f in names]
 COMMON_DEPS = _H("scene_obj.h", "scene_dev.h", "dmath.h", "trav4.h") + [os.path.join(ROOT, "include", "psdr_hip.h")]
 API_DEPS = COMMON_DEPS + _H("sampler.h", "shade.h", "edges.h", "paths.h", "adjoint.h", "adjoint_mat.h", "microfacet.h") + [os.path.join(CSRC, "common", "envmath.h")] + BUILD_DEPS
-SCENE_DEPS = COMMON_DEPS + _H("bvh.h", "filter.h") + BUILD_DEPS
+SCENE_DEPS = COMMON_DEPS + _H("bvh.h", "filter.h") + [os.path.join(CSRC, "common", "threads.h")] + BUILD_DEPS
 HIP_DEPS = sorted(set(API_DEPS + SCENE_DEPS))
 HOST_SRCS = [os.path.join(CSRC, "host", f) for f in ("scene_host.cpp", "bindings.cpp", "exr_piz.cpp")]
-HOST_DEPS = [os.path.join(CSRC, "host", f) for f in ("scene_host.h", "hnum.h", "exr_piz.h")] + [os.path.join(ROOT, "include", "psdr_hip.h"), os.path.join(CSRC, "common", "envmath.h")]
+HOST_DEPS = [os.path.join(CSRC, "host", f) for f in ("scene_host.h", "hnum.h", "exr_piz.h")] + [os.path.join(ROOT, "include", "psdr_hip.h"), os.path.join(CSRC, "common", "envmath.h"), os.path.join(CSRC, "common", "threads.h")]
 
 # -ffp-contract=off: every fused multiply-add in the kernels is an explicit fma so that the
 # arithmetic matches the scalar CPU restatement the parity tests compare against.
@@ -205,7 +205,7 @@ def _compile_hip(flags, target, objdir):
     return target
 
 
-CORE_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-fopenmp"]
+CORE_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-pthread"]
 
 
 def build_core(force=False, hip_flags=()):

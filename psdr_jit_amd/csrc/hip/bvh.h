@@ -19,9 +19,8 @@
 #include <mutex>
 #include <thread>
 #include <vector>
-#if defined(__linux__)
-#include <sched.h>
-#endif
+
+#include "../common/threads.h"
 
 #if defined(__HIPCC__)
 #define PSDR_BVH_HD __host__ __device__
@@ -117,38 +116,6 @@ struct BvhResult {
     std::vector<float> tmp_box;    // lo.xyz, hi.xyz per node (padded)
 };
 
-// threads the host-side builders may keep busy: the affinity mask, cut down to the cgroup's CPU quota (a container sees every core of the
-// host but is throttled to cpu.max) and to 32; PSDR_HOST_THREADS overrides
-inline int bvh_host_threads() {
-    static const int n = [] {
-        if (const char *e = std::getenv("PSDR_HOST_THREADS")) return std::max(1, std::atoi(e));
-        int t = (int) std::thread::hardware_concurrency();
-        if (t <= 0) t = 1;
-#if defined(__linux__)
-        cpu_set_t set;
-        if (sched_getaffinity(0, sizeof(set), &set) == 0) t = std::min(t, std::max(1, CPU_COUNT(&set)));
-        if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
-            char q[64]; long long per = 0;
-            if (std::fscanf(f, "%63s %lld", q, &per) == 2 && std::strcmp(q, "max") != 0 && per > 0) t = std::min(t, std::max(1, (int) (std::atoll(q) / per)));
-            std::fclose(f);
-        }
-#endif
-        return std::min(t, 32);
-    }();
-    return n;
-}
-
-// fn(begin, end) over [0, n) in contiguous chunks on up to `threads` threads (the calling thread takes the first chunk)
-template <typename F> inline void bvh_parallel_for(size_t n, int threads, size_t min_chunk, F fn) {
-    const size_t parts = std::max<size_t>(1, std::min<size_t>((size_t) std::max(1, threads), n / std::max<size_t>(1, min_chunk)));
-    if (parts <= 1) { fn((size_t) 0, n); return; }
-    std::vector<std::thread> th;
-    th.reserve(parts - 1);
-    for (size_t p = 1; p < parts; ++p) th.emplace_back([=] { fn(n * p / parts, n * (p + 1) / parts); });
-    fn((size_t) 0, n / parts);
-    for (std::thread &t : th) t.join();
-}
-
 namespace bvh_detail {
 struct Box {
     float lo[3], hi[3];
@@ -172,11 +139,11 @@ constexpr int kLeafMax = 2;        // triangles per leaf (measured with the tria
 // Work is handed out per subtree: a job splits its range and queues the two halves until a range is small enough to finish in place.
 inline void build_bvh(const float *p0, const float *e1, const float *e2, int n, BvhResult &out, int threads = 0) {
     using namespace bvh_detail;
-    if (threads <= 0) threads = bvh_host_threads();
+    if (threads <= 0) threads = host_threads();
     std::vector<Box> tb((size_t) n);
     std::vector<float> ctr(3 * (size_t) n);
     out.order.resize((size_t) n);
-    bvh_parallel_for((size_t) n, threads, 4096, [&](size_t b, size_t e) {
+    parallel_for((size_t) n, 4096, [&](size_t b, size_t e) {
         for (size_t i = b; i < e; ++i) {
             out.order[i] = (int32_t) i;
             // centroid of the UNPADDED box, then the padded box (bvh_tri_box)
@@ -188,7 +155,7 @@ inline void build_bvh(const float *p0, const float *e1, const float *e2, int n, 
             }
             bvh_tri_box(p0 + 3 * i, e1 + 3 * i, e2 + 3 * i, tb[i].lo, tb[i].hi);
         }
-    });
+    }, threads);
     const size_t cap = 2 * (size_t) std::max(n, 1) + 2;
     std::vector<TmpNode> tmp(cap);
     std::atomic<int> n_tmp{1};

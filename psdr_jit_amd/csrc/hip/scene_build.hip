@@ -315,7 +315,6 @@ static int scene_sync(psdr_hip_scene *sc, const psdr_scene_snapshot *s, unsigned
     float *H = (float *) sc->hblob.p;
     std::vector<WordRange> dirty;
     auto mark = [&](size_t b, size_t e) { if (e > b) dirty.push_back({b, e}); };
-    const int host_threads = bvh_host_threads();
 
     if (build) {
         std::memcpy(H + 4 * (size_t) T.nodes_off, new_nodes.data(), sizeof(float) * new_nodes.size());
@@ -327,7 +326,7 @@ static int scene_sync(psdr_hip_scene *sc, const psdr_scene_snapshot *s, unsigned
     }
     const bool write_geo = geo || blob_moved || T.trav_off != Told.trav_off || T.shade_off != Told.shade_off;
     if (write_geo) {
-        bvh_parallel_for((size_t) n, host_threads, 8192, [&](size_t b0, size_t e0) {
+        parallel_for((size_t) n, 8192, [&](size_t b0, size_t e0) {
             for (size_t slot = b0; slot < e0; ++slot) {
                 const size_t o = (size_t) order[slot];
                 const float *p0 = tr.p0 + 3 * o, *e1 = tr.e1 + 3 * o, *e2 = tr.e2 + 3 * o;
@@ -350,7 +349,7 @@ static int scene_sync(psdr_hip_scene *sc, const psdr_scene_snapshot *s, unsigned
         mark((size_t) T.trav_off, (size_t) T.trav_off + 9 * (size_t) n);
     }
     if (has_tan && (!same_tan || blob_moved || T.tan_off != Told.tan_off || !Told.has_tangent)) {
-        bvh_parallel_for((size_t) n, host_threads, 8192, [&](size_t b0, size_t e0) {
+        parallel_for((size_t) n, 8192, [&](size_t b0, size_t e0) {
             for (size_t slot = b0; slot < e0; ++slot) {
                 const size_t o = (size_t) order[slot];
                 const float *a = tr.d_p0 + 3 * o, *b = tr.d_e1 + 3 * o, *c = tr.d_e2 + 3 * o, *d0 = tr.d_n0 + 3 * o, *d1 = tr.d_n1 + 3 * o,
@@ -438,7 +437,7 @@ static int scene_sync(psdr_hip_scene *sc, const psdr_scene_snapshot *s, unsigned
     // ---- secondary edges
     const bool write_sec = !same_sec || blob_moved || E.off != Eold.off || E.cdf_off != Eold.cdf_off || E.n != Eold.n;
     if (write_sec && se.n_edges > 0) {
-        bvh_parallel_for((size_t) se.n_edges, host_threads, 8192, [&](size_t b0, size_t e0) {
+        parallel_for((size_t) se.n_edges, 8192, [&](size_t b0, size_t e0) {
             const float z3[3] = {0.f, 0.f, 0.f};
             for (size_t i = b0; i < e0; ++i) {
                 const float *p0 = se.p0 + 3 * i, *e1 = se.e1 + 3 * i, *n0 = se.n0 + 3 * i, *n1 = se.n1 + 3 * i, *p2 = se.p2 + 3 * i;

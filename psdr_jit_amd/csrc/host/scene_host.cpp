@@ -2,6 +2,7 @@
 // the render drivers that call libpsdr_hip.so.  Reference sites are cited per function.
 #include "scene_host.h"
 #include "../common/envmath.h"
+#include "../common/threads.h"
 
 #include <algorithm>
 #include <chrono>
@@ -64,8 +65,9 @@ void EnvironmentMap::configure(bool on_device) {
         if (on_device) {
             hip_check(psdr_hip_env_cell_masses_xf(data.data(), width, height, uv_xf, mass.data()));
         } else {
-#pragma omp parallel for schedule(static)
-            for (int idx = 0; idx < n_cells; ++idx) mass[idx] = psdr::env::cell_mass(data.data(), width, height, w2, h2, idx, psdr::env::UvXf<float>(uv_xf));
+            psdr::parallel_for((size_t) n_cells, 16384, [&](size_t b, size_t e) {
+                for (size_t idx = b; idx < e; ++idx) mass[idx] = psdr::env::cell_mass(data.data(), width, height, w2, h2, (int) idx, psdr::env::UvXf<float>(uv_xf));
+            });
         }
         cell_distrb.init(mass);
         m_cells_dirty = false;
@@ -252,18 +254,20 @@ static void process_mesh(const std::vector<D3> &V, const std::vector<int> &F, in
     const size_t nv = V.size();
     std::vector<D3> vn(nv), fnrm(nf);
     std::vector<DF> farea(nf);
-#pragma omp parallel for schedule(static) if (nf > 4096)
-    for (int f = 0; f < nf; ++f) {
-        const D3 p0 = V[F[3 * f]], e1 = V[F[3 * f + 1]] - p0, e2 = V[F[3 * f + 2]] - p0;
-        fnrm[f] = dcross(e1, e2);
-        farea[f] = dnorm(fnrm[f]);
-    }
-#pragma omp parallel for schedule(static) if (nv > 4096)
-    for (long long v = 0; v < (long long) nv; ++v) {
-        D3 acc; DF w;
-        for (int k = vf_begin[(size_t) v]; k < vf_begin[(size_t) v + 1]; ++k) { const int f = vf_item[(size_t) k]; acc = acc + fnrm[f]; w = w + farea[f]; }
-        vn[(size_t) v] = dnormalize(acc / w);
-    }
+    psdr::parallel_for((size_t) nf, 4096, [&](size_t b, size_t e) {
+        for (size_t f = b; f < e; ++f) {
+            const D3 p0 = V[F[3 * f]], e1 = V[F[3 * f + 1]] - p0, e2 = V[F[3 * f + 2]] - p0;
+            fnrm[f] = dcross(e1, e2);
+            farea[f] = dnorm(fnrm[f]);
+        }
+    });
+    psdr::parallel_for(nv, 4096, [&](size_t b, size_t e) {
+        for (size_t v = b; v < e; ++v) {
+            D3 acc; DF w;
+            for (int k = vf_begin[v]; k < vf_begin[v + 1]; ++k) { const int f = vf_item[(size_t) k]; acc = acc + fnrm[f]; w = w + farea[f]; }
+            vn[v] = dnormalize(acc / w);
+        }
+    });
     if (vertex_normals_out) {
         vertex_normals_out->resize(3 * nv);
         for (size_t v = 0; v < nv; ++v) { (*vertex_normals_out)[3 * v] = vn[v].x.v; (*vertex_normals_out)[3 * v + 1] = vn[v].y.v; (*vertex_normals_out)[3 * v + 2] = vn[v].z.v; }
@@ -274,15 +278,16 @@ static void process_mesh(const std::vector<D3> &V, const std::vector<int> &F, in
         tri[22 * row + col] = a.x.v; tri[22 * row + col + 1] = a.y.v; tri[22 * row + col + 2] = a.z.v;
         d_tri[22 * row + col] = a.x.d; d_tri[22 * row + col + 1] = a.y.d; d_tri[22 * row + col + 2] = a.z.d;
     };
-#pragma omp parallel for schedule(static) if (nf > 4096)
-    for (int f = 0; f < nf; ++f) {
-        const D3 p0 = V[F[3 * f]], e1 = V[F[3 * f + 1]] - p0, e2 = V[F[3 * f + 2]] - p0;
-        put(f, 0, p0); put(f, 3, e1); put(f, 6, e2);
-        put(f, 9, vn[F[3 * f]]); put(f, 12, vn[F[3 * f + 1]]); put(f, 15, vn[F[3 * f + 2]]);
-        put(f, 18, fnrm[f] / farea[f]);
-        const DF a = farea[f] * DF(0.5f);
-        tri[22 * (size_t) f + 21] = a.v; d_tri[22 * (size_t) f + 21] = a.d;
-    }
+    psdr::parallel_for((size_t) nf, 4096, [&](size_t b, size_t e) {
+        for (size_t f = b; f < e; ++f) {
+            const D3 p0 = V[F[3 * f]], e1 = V[F[3 * f + 1]] - p0, e2 = V[F[3 * f + 2]] - p0;
+            put(f, 0, p0); put(f, 3, e1); put(f, 6, e2);
+            put(f, 9, vn[F[3 * f]]); put(f, 12, vn[F[3 * f + 1]]); put(f, 15, vn[F[3 * f + 2]]);
+            put(f, 18, fnrm[f] / farea[f]);
+            const DF a = farea[f] * DF(0.5f);
+            tri[22 * f + 21] = a.v; d_tri[22 * f + 21] = a.d;
+        }
+    });
 }
 
 // Mesh::configure, reference src/shape/mesh.cpp:317-382
@@ -308,12 +313,13 @@ void Mesh::configure() {
     }
     const DM4 tw = to_world();
     vertex_positions.resize(3 * (size_t) m_num_vertices); d_vertex_positions.resize(3 * (size_t) m_num_vertices);
-#pragma omp parallel for schedule(static) if (m_num_vertices > 4096)
-    for (int v = 0; v < m_num_vertices; ++v) {
-        world[v] = xform_pos(tw, raw[v]);
-        vertex_positions[3 * v] = world[v].x.v; vertex_positions[3 * v + 1] = world[v].y.v; vertex_positions[3 * v + 2] = world[v].z.v;
-        d_vertex_positions[3 * v] = world[v].x.d; d_vertex_positions[3 * v + 1] = world[v].y.d; d_vertex_positions[3 * v + 2] = world[v].z.d;
-    }
+    psdr::parallel_for((size_t) m_num_vertices, 4096, [&](size_t b, size_t e) {
+        for (size_t v = b; v < e; ++v) {
+            world[v] = xform_pos(tw, raw[v]);
+            vertex_positions[3 * v] = world[v].x.v; vertex_positions[3 * v + 1] = world[v].y.v; vertex_positions[3 * v + 2] = world[v].z.v;
+            d_vertex_positions[3 * v] = world[v].x.d; d_vertex_positions[3 * v + 1] = world[v].y.d; d_vertex_positions[3 * v + 2] = world[v].z.d;
+        }
+    });
     for (int k = 0; k < 3; ++k) { m_lower[k] = std::numeric_limits<float>::max(); m_upper[k] = -std::numeric_limits<float>::max(); }
     for (int v = 0; v < m_num_vertices; ++v)
         for (int k = 0; k < 3; ++k) { m_lower[k] = std::min(m_lower[k], vertex_positions[3 * v + k]); m_upper[k] = std::max(m_upper[k], vertex_positions[3 * v + k]); }
@@ -407,9 +413,9 @@ void PerspectiveCamera::configure(const Scene &scene, bool keep_edges) {
         // pass 1 (parallel): which edges are kept; pass 2 (parallel): their rows at the positions an in-order walk would give them
         const int ne = (int) mesh->edges.size();
         std::vector<uint8_t> keep_flag((size_t) ne, 0);
-#pragma omp parallel for schedule(static) if (ne > 4096)
-        for (int i = 0; i < ne; ++i) {
-            const MeshEdge &e = mesh->edges[(size_t) i];
+        psdr::parallel_for((size_t) ne, 4096, [&](size_t eb, size_t ee) {
+          for (size_t i = eb; i < ee; ++i) {
+            const MeshEdge &e = mesh->edges[i];
             const bool valid = e.f1 >= 0;
             const float *t0 = &mesh->tri[22 * (size_t) e.f0];
             const D3 e0 = dnormalize(cpos - fvec(t0)), n0 = fvec(t0 + 18);
@@ -426,8 +432,9 @@ void PerspectiveCamera::configure(const Scene &scene, bool keep_edges) {
             if (mesh->m_use_face_normals) keep = !(valid && ((fdot(e0, n0) < Epsilon && fdot(e1, n1) < Epsilon) || fdot(n0, n1) > 1.f - Epsilon));
             else keep = !valid || ((fdot(e0, n0) > Epsilon) != (fdot(e1, n1) > Epsilon));
             if (mesh->m_has_uv) keep = keep || uv_mask;
-            keep_flag[(size_t) i] = keep ? 1 : 0;
-        }
+            keep_flag[i] = keep ? 1 : 0;
+          }
+        });
         std::vector<int> kept_ids;
         for (int i = 0; i < ne; ++i) if (keep_flag[(size_t) i]) kept_ids.push_back(i);
         const int kept = (int) kept_ids.size();
@@ -435,10 +442,10 @@ void PerspectiveCamera::configure(const Scene &scene, bool keep_edges) {
         const size_t base = pe.length.size();
         for (std::vector<float> *v : {&pe.p0, &pe.p1, &pe.d_p0, &pe.d_p1, &pe.normal}) v->resize(2 * (base + (size_t) kept));
         pe.length.resize(base + (size_t) kept); pe.ids.resize(3 * (base + (size_t) kept));
-#pragma omp parallel for schedule(static) if (kept > 4096)
-        for (int j = 0; j < kept; ++j) {
-            const MeshEdge &e = mesh->edges[(size_t) kept_ids[(size_t) j]];
-            const size_t r = base + (size_t) j;
+        psdr::parallel_for((size_t) kept, 4096, [&](size_t jb, size_t je) {
+          for (size_t j = jb; j < je; ++j) {
+            const MeshEdge &e = mesh->edges[(size_t) kept_ids[j]];
+            const size_t r = base + j;
             const D3 q0 = xform_pos(w2s, dvec(&mesh->vertex_positions[3 * e.v0], &mesh->d_vertex_positions[3 * e.v0])),
                      q1 = xform_pos(w2s, dvec(&mesh->vertex_positions[3 * e.v1], &mesh->d_vertex_positions[3 * e.v1]));
             float ex = q1.x.v - q0.x.v, ey = q1.y.v - q0.y.v;
@@ -449,7 +456,8 @@ void PerspectiveCamera::configure(const Scene &scene, bool keep_edges) {
             pe.normal[2 * r] = -ey; pe.normal[2 * r + 1] = ex;
             pe.length[r] = len;
             pe.ids[3 * r] = mesh->m_mesh_id; pe.ids[3 * r + 1] = e.v0; pe.ids[3 * r + 2] = e.v1;
-        }
+          }
+        });
     }
     if (!pe.length.empty() && keep_edges) {
         pe.distrb.init(pe.length);
@@ -631,9 +639,9 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
     auto write_rows = [&](const Mesh *mesh, size_t face_offset, bool values, bool tangents) {
         const int nf = mesh->m_num_faces;
         auto put3 = [](std::vector<float> &dst, size_t row, const float *src) { dst[3 * row] = src[0]; dst[3 * row + 1] = src[1]; dst[3 * row + 2] = src[2]; };
-#pragma omp parallel for schedule(static) if (nf > 4096)
-        for (int f = 0; f < nf; ++f) {
-            const size_t row = face_offset + (size_t) f;
+        psdr::parallel_for((size_t) nf, 4096, [&](size_t fb, size_t fe) {
+          for (size_t f = fb; f < fe; ++f) {
+            const size_t row = face_offset + f;
             const float *t = &mesh->tri[22 * (size_t) f], *d = &mesh->d_tri[22 * (size_t) f];
             if (values) {
                 put3(S.p0, row, t); put3(S.e1, row, t + 3); put3(S.e2, row, t + 6); put3(S.n0, row, t + 9); put3(S.n1, row, t + 12); put3(S.n2, row, t + 15); put3(S.fn, row, t + 18); S.area[row] = t[21];
@@ -646,7 +654,8 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
                 S.flat[row] = mesh->m_use_face_normals ? 1 : 0;
             }
             if (tangents) { put3(S.d_p0, row, d); put3(S.d_e1, row, d + 3); put3(S.d_e2, row, d + 6); put3(S.d_n0, row, d + 9); put3(S.d_n1, row, d + 12); put3(S.d_n2, row, d + 15); put3(S.d_fn, row, d + 18); S.d_area[row] = d[21]; }
-        }
+          }
+        });
     };
     auto resize_rows = [&](size_t n) {
         for (std::vector<float> *v : {&S.p0, &S.e1, &S.e2, &S.n0, &S.n1, &S.n2, &S.fn, &S.d_p0, &S.d_e1, &S.d_e2, &S.d_n0, &S.d_n1, &S.d_n2, &S.d_fn}) v->resize(3 * n);
@@ -937,10 +946,10 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
             if (!mesh->m_enable_edges) continue;
             const int ne = (int) mesh->edges.size();
             const float *P = mesh->vertex_positions.data(), *dP = mesh->d_vertex_positions.data();
-#pragma omp parallel for schedule(static) if (ne > 4096)
-            for (int i = 0; i < ne; ++i) {
-                const MeshEdge &e = mesh->edges[(size_t) i];
-                const size_t r = base + (size_t) i;
+            psdr::parallel_for((size_t) ne, 4096, [&](size_t eb, size_t ee) {
+              for (size_t i = eb; i < ee; ++i) {
+                const MeshEdge &e = mesh->edges[i];
+                const size_t r = base + i;
                 float e1[3];
                 for (int k = 0; k < 3; ++k) {
                     e1[k] = P[3 * e.v1 + k] - P[3 * e.v0 + k];
@@ -952,7 +961,8 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
                 }
                 S.se_boundary[r] = e.f1 < 0 ? 1 : 0;
                 pmf[r] = std::sqrt(std::fmaf(e1[2], e1[2], std::fmaf(e1[1], e1[1], e1[0] * e1[0])));
-            }
+              }
+            });
             base += (size_t) ne;
         }
         S.n_sec_edges = (int) pmf.size();

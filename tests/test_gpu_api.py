@@ -73,6 +73,54 @@ def test_readme_example_forward_and_reverse(psdr, orc):
     assert abs(float(P.grad) - want) < 1e-3 * max(1.0, abs(want))
 
 
+def test_renderd_makes_the_forward_mode_launch_when_the_previous_image_went_to_forward_grad(psdr, orc):
+    """An optimisation loop repeats renderD -> forward_grad(img, P): from the second iteration on renderD installs P's tangents and makes the one launch
+    forward mode needs (image and derivative of the same pass); forward_grad then returns what renderD kept.  Same numbers as the replay, with fixed seeds
+    and with continuing samplers (seed = -1); a reverse-mode call on such an image still works and switches the prediction off"""
+    import torch
+    P = psdr.FloatD(0.).requires_grad_()
+    sc = _readme_scene(psdr, P)
+    integrator = psdr.PathTracer(2)
+    spec = scenes.cbox_scene(48, 48, 8, 8, 8, param="light_x")
+    ref = orc.OracleScene(spec, [0])
+    for it, seed in enumerate((5, 6, 7)):
+        img = integrator.renderD(sc, 0, seed=seed)
+        predicted = img.grad_fn.state.get("dimg") is not None
+        assert predicted == (it > 0)
+        dimg = psdr.forward_grad(img, P)
+        wimg, wd = ref.render_d(max_depth=2, seeds=(seed, seed, seed))
+        assert product.rel_l2(img.detach().cpu().numpy(), wimg) < 1e-3 and product.rel_l2(dimg.cpu().numpy(), wd) < 1e-3
+    # continuing samplers: the predicted call advances the three streams exactly like the unpredicted one (one renderD each)
+    before = [sc._sampler_state(k) for k in range(3)]
+    img = integrator.renderD(sc, 0)
+    assert img.grad_fn.state.get("dimg") is not None
+    after = [sc._sampler_state(k) for k in range(3)]
+    d1 = psdr.forward_grad(img, P)
+    assert [sc._sampler_state(k) for k in range(3)] == after and after != before
+    # another parameter than the predicted one: the replay path, same image
+    refl = torch.tensor([0.90, 0.20, 0.20], requires_grad=True)
+    sc.param_map["BSDF[id=red]"].reflectance = refl
+    sc.configure([0])
+    img = integrator.renderD(sc, 0, seed=9)
+    d_r = psdr.forward_grad(img, refl, direction=torch.tensor([1.0, 1.0, 1.0]))
+    d_p = psdr.forward_grad(img, P)
+    spec_a = scenes.cbox_scene(48, 48, 8, 8, 8, param="albedo")
+    _, wd_a = orc.OracleScene(spec_a, [0]).render_d(max_depth=2, seeds=(9, 9, 9))
+    _, wd_p = ref.render_d(max_depth=2, seeds=(9, 9, 9))
+    assert product.rel_l2(d_r.cpu().numpy(), wd_a) < 1e-3 and product.rel_l2(d_p.cpu().numpy(), wd_p) < 1e-3
+    # reverse mode on a predicted image
+    img = integrator.renderD(sc, 0, seed=11)
+    assert img.grad_fn.state.get("dimg") is not None
+    w = torch.linspace(0.5, 1.5, img.numel(), device=img.device).reshape(img.shape)
+    P.grad = None
+    (img * w).sum().backward()
+    _, wd11 = ref.render_d(max_depth=2, seeds=(11, 11, 11))
+    want = float((torch.from_numpy(wd11).to(img.device) * w).sum())
+    assert abs(float(P.grad) - want) < 1e-3 * max(1.0, abs(want))
+    img = integrator.renderD(sc, 0, seed=12)
+    assert img.grad_fn.state.get("dimg") is None          # (the last image went to backward)
+
+
 def test_renderc_and_sampler_continuation(psdr, orc):
     import torch
     sc = _readme_scene(psdr, torch.tensor(0.0))
