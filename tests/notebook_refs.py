@@ -95,3 +95,66 @@ def mass_ratio(img, name):
     x0, x1, y0, y1 = spec["axes_rect"]
     per_px = (spec["width"] / float(x1 - x0)) * (spec["height"] / float(y1 - y0))       # data pixels per display pixel
     return float(np.abs(ours).sum() / (np.abs(ref).sum() * per_px))
+
+
+def channel_scales(img, name, grid=32, sat=0.8):
+    """least-squares scale per colour channel of an sRGB figure, ours ~ scale_c * ref per channel (block means, each side's mean removed), over the blocks
+    that are not saturated in the figure and do not touch a saturated block: a light source that clips to 1.0 turns a sub-pixel registration offset of the figure's
+    axes into +-0.07 on its two rows of blocks, which is all the blue channel of a dim scene has to fit"""
+    ref, spec = figure(name)
+    a, b = block_means(displayed(img, spec), ref, spec, grid)
+    hot = b.max(axis=2) > sat
+    near = hot.copy()
+    near[1:, :] |= hot[:-1, :]; near[:-1, :] |= hot[1:, :]; near[:, 1:] |= hot[:, :-1]; near[:, :-1] |= hot[:, 1:]
+    keep = ~near
+    out = []
+    for c in range(3):
+        a0, b0 = a[..., c][keep], b[..., c][keep]
+        a0, b0 = a0 - a0.mean(), b0 - b0.mean()
+        out.append(float((a0 * b0).sum() / max((b0 * b0).sum(), 1e-30)))
+    return out
+
+
+# The bands the notebook pins assert (tests/test_oracle_notebooks.py on the oracle, tests/test_gpu_notebooks.py on the HIP path), from the seed-to-seed spread of each
+# statistic over 8 oracle renders (tools/notebook_bands.py): |scale - 1| < |mean - 1| + 3 sqrt(2) sigma - the figure is one noisy realisation too - rounded up by about a
+# half for other resolutions and seeds.  Measured (mean +- sigma over seeds) -> 3-sigma band -> asserted:
+#   figure                          ncc                 scale               3-sigma band      per-channel scale (r, g, b; blocks next to a saturated light left out)
+#   Forward_AD_cell5 @32            0.9977 +- 0.00003   0.9987 +- 0.0002    0.0020            1.0035 1.0025 1.0038 +- 0.0002 -> 0.0048
+#   Forward_AD_cell6 @32            0.9981 +- 0.0001    0.9966 +- 0.0007    0.0063
+#   Forward_AD_cell6 @64            0.9954 +- 0.0001    0.9954 +- 0.0007    0.0076
+#   secondary_edge_guiding_cell5    0.9879 +- 0.0014    1.0061 +- 0.0127    0.0599            (4 samples per pixel, unguided: the figure's own noise is the band)
+#   secondary_edge_guiding_cell6    0.9936 +- 0.0002    1.0092 +- 0.0027    0.0207
+#   batch_render_cell5 @32          0.9947 +- 0.0001    0.9897 +- 0.0005    0.0124            1.0082 1.0043 1.0041 +- 0.0011 -> 0.0127
+#   batch_render_cell6 @25          0.9959 +- 0.0005    1.0021 +- 0.0013    0.0075            0.9987 1.0021 1.0016 +- 0.0017 -> 0.0088
+#   different_integrator_cell6      0.9701 +- 0.0003    mass 0.9972 +- 0.0011 -> 0.0074
+# (batch_render_cell5's whole-frame scale of 0.990 is the luminaire: its two rows of blocks read -0.07 / +0.08 in all three channels, a registration offset of a fraction of a
+#  display pixel between the figure's axes and the data grid; with those blocks left out the three channels read 1.004-1.008.)
+BANDS = {
+    "Forward_AD_cell5": dict(grid=32, ncc=0.9965, scale=0.004, channel=0.008),
+    "Forward_AD_cell6": dict(grid=32, ncc=0.9965, scale=0.010),
+    "Forward_AD_cell6@64": dict(grid=64, ncc=0.993, scale=0.012),
+    "secondary_edge_guiding_cell5": dict(grid=32, ncc=0.975, scale=0.07),
+    "secondary_edge_guiding_cell6": dict(grid=32, ncc=0.990, scale=0.03),
+    "batch_render_cell5": dict(grid=32, ncc=0.9925, scale=0.018, channel=0.020),
+    "batch_render_cell6": dict(grid=25, ncc=0.991, scale=0.012, channel=0.015),
+    "different_integrator_cell6": dict(grid=32, ncc=0.965, mass=0.012),
+}
+
+
+def check_band(img, key):
+    """asserts BANDS[key] for `img` against the figure key names (key may carry an @grid suffix); -> the measured statistics"""
+    name = key.split("@")[0]
+    band = BANDS[key]
+    img = np.asarray(img.detach().cpu().numpy() if hasattr(img, "detach") else img)
+    m = compare(img, name, band["grid"])
+    assert m["ncc"] > band["ncc"], (key, m, band)
+    if "scale" in band:
+        assert abs(m["scale"] - 1.0) < band["scale"], (key, m, band)
+    if "channel" in band:
+        ch = channel_scales(img, name, band["grid"])
+        m["channel_scales"] = ch
+        assert max(abs(c - 1.0) for c in ch) < band["channel"], (key, ch, band)
+    if "mass" in band:
+        m["mass"] = mass_ratio(img, name)
+        assert abs(m["mass"] - 1.0) < band["mass"], (key, m, band)
+    return m

@@ -35,8 +35,9 @@ def _check(img, name, grid, ncc, scale_lo, scale_hi):
 def test_forward_ad(tut):
     """Forward_AD.ipynb cells 5-6 (512 x 512, 32 / 32 / 32, PathTracer(1)): the figure whose run the notebook times at 1.258 s"""
     img, d = tut.forward_ad(depth=1)
-    _check(img, "Forward_AD_cell5", 32, 0.985, 0.96, 1.04)
-    _check(d, "Forward_AD_cell6", 32, 0.985, 0.95, 1.05)
+    nr.check_band(img, "Forward_AD_cell5")             # (tests/notebook_refs.py::BANDS: three sigma of the statistics' seed-to-seed spread, tools/notebook_bands.py)
+    nr.check_band(d, "Forward_AD_cell6")
+    nr.check_band(d, "Forward_AD_cell6@64")
     # at the display's own resolution (367 pixels) the derivative map still correlates pixel by pixel
     m = nr.compare(d.cpu().numpy(), "Forward_AD_cell6", 128)
     assert m["ncc"] > 0.9, m
@@ -58,23 +59,21 @@ def test_logged_scene_box_and_edge_counts(tut):
 
 def test_secondary_edge_guiding(tut):
     plain, guided = tut.secondary_edge_guiding()
-    _check(plain, "secondary_edge_guiding_cell5", 32, 0.97, 0.93, 1.07)
-    _check(guided, "secondary_edge_guiding_cell6", 32, 0.97, 0.93, 1.07)
+    nr.check_band(plain, "secondary_edge_guiding_cell5")
+    nr.check_band(guided, "secondary_edge_guiding_cell6")
 
 
 def test_different_integrator(tut):
     """the one-pixel outline is compared by mass (tests/test_oracle_notebooks.py::test_different_integrator_figure)"""
     img, d = tut.different_integrator("silhouette 1")
     d = d.cpu().numpy()
-    m = nr.compare(d, "different_integrator_cell6", 32)
-    mass = nr.mass_ratio(d, "different_integrator_cell6")
-    assert m["ncc"] > 0.95 and abs(mass - 1.0) < 0.05, (m, mass)
+    nr.check_band(d, "different_integrator_cell6")
 
 
 def test_batch_render(tut):
     full, part, pix = tut.batch_render()
-    _check(full, "batch_render_cell5", 32, 0.985, 0.96, 1.04)
-    _check(part, "batch_render_cell6", 25, 0.985, 0.96, 1.04)
+    nr.check_band(full, "batch_render_cell5")
+    nr.check_band(part, "batch_render_cell6")
 
 
 def test_forward_ad_envmap(tut):
