@@ -132,8 +132,13 @@ __global__ __launch_bounds__(kBlock, (AD ? (in_lds(LDS) ? PSDR_LDS_AD_WAVES : (L
 }
 
 // reverse mode of the interior term (adjoint.h)
-#ifndef PSDR_ADJ_WAVES          // measurement knob: waves per SIMD of the interior adjoint kernel (1 = the compiler's choice)
-#define PSDR_ADJ_WAVES 1
+#ifndef PSDR_ADJ_REC_LDS        // measurement knob: 1 = the per-lane records stay in LDS whenever they fit 160 KB (rounds 2-4)
+#define PSDR_ADJ_REC_LDS 0
+#endif
+// waves per SIMD of the interior adjoint kernels.  Class 2 (BVH scenes): 2 - with the per-lane records in global memory two workgroups fit a CU (40 KB of traversal
+// rows + the hot accumulators <= 80 KB), and at <= 256 registers both run: config 5's interior adjoint 46.0 -> 29.3 ms.  The other classes keep the compiler's choice.
+#ifndef PSDR_ADJ_WAVES
+#define PSDR_ADJ_WAVES(cls) ((cls) == 2 ? 2 : 1)
 #endif
 #ifndef PSDR_SEC_ADJ_WAVES
 #define PSDR_SEC_ADJ_WAVES 1
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(kBlock, (AD ? (in_lds(LDS) ? PSDR_LDS_AD_WAVES : (L
 #define PSDR_SEC_HOT_MAX 256
 #endif
 template <int LDS>
-__global__ __launch_bounds__(kBlock, PSDR_ADJ_WAVES) void k_interior_adjoint(const float4 *__restrict__ blob, const SceneTables T, const SensorDev cam,
+__global__ __launch_bounds__(kBlock, PSDR_ADJ_WAVES(LDS)) void k_interior_adjoint(const float4 *__restrict__ blob, const SceneTables T, const SensorDev cam,
                                                              const AdjointParams P) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     SceneView<LDS> S = make_view<LDS>(blob, T, smem);
@@ -548,7 +553,8 @@ __global__ void k_sampler_floats(unsigned long long seed_value, unsigned long lo
 #define PSDR_TU6(PFX) PSDR_INST_PATHS(PFX, true, 0, true, 0) PSDR_INST_PATHS(PFX, false, 0, true, 0) PSDR_INST_PATHS(PFX, false, 0, true, 1)
 #define PSDR_TU2(PFX) PSDR_INST_ADJ(PFX, 0) PSDR_INST_ADJM(PFX, 0) PSDR_INST_SEC(PFX, 0, false, false) PSDR_INST_SEC(PFX, 0, true, false) PSDR_INST_SEC(PFX, 0, false, true)
 #define PSDR_TU3(PFX) PSDR_INST_PATHS6(PFX, 1) PSDR_INST_ADJ(PFX, 1) PSDR_INST_SEC(PFX, 1, false, false) PSDR_INST_SEC(PFX, 1, true, false) PSDR_INST_SEC(PFX, 1, false, true)
-#define PSDR_TU4(PFX) PSDR_INST_PATHS6(PFX, 2) PSDR_INST_ADJ(PFX, 2) PSDR_INST_SEC(PFX, 2, false, false) PSDR_INST_SEC(PFX, 2, true, false) PSDR_INST_SEC(PFX, 2, false, true)
+#define PSDR_TU4(PFX) PSDR_INST_PATHS6(PFX, 2) PSDR_INST_SEC(PFX, 2, false, false) PSDR_INST_SEC(PFX, 2, true, false) PSDR_INST_SEC(PFX, 2, false, true)
+#define PSDR_TU7(PFX) PSDR_INST_ADJ(PFX, 2)          // a unit of its own: when the ISA lint sends it to the second allocator (build.py), the class-2 path kernels do not pay for it
 #define PSDR_TU5(PFX) PSDR_INST_PATHS(PFX, true, 3, false, 0) PSDR_INST_PATHS(PFX, false, 3, false, 0) PSDR_INST_PATHS(PFX, false, 3, false, 1) PSDR_INST_SEC(PFX, 3, false, false)
 #if defined(PSDR_TU)
 #if PSDR_TU == 1
@@ -563,12 +569,12 @@ PSDR_TU4()
 PSDR_TU5()
 #elif PSDR_TU == 6
 PSDR_TU6()
-#elif PSDR_TU == 7          // (tools/isa_adj.sh: the class-2 interior adjoint kernel alone, for ISA listings)
-PSDR_INST_ADJ(, 2)
+#elif PSDR_TU == 7
+PSDR_TU7()
 #endif
 #else
 #if defined(PSDR_SPLIT)
-PSDR_TU1(extern) PSDR_TU2(extern) PSDR_TU3(extern) PSDR_TU4(extern) PSDR_TU5(extern) PSDR_TU6(extern)
+PSDR_TU1(extern) PSDR_TU2(extern) PSDR_TU3(extern) PSDR_TU4(extern) PSDR_TU5(extern) PSDR_TU6(extern) PSDR_TU7(extern)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -699,6 +705,21 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
         HIPCHK(hipMemsetAsync(q, 0, sizeof(unsigned long long), st));
         return 0;
     };
+    // The three terms of a renderD are independent launches that add into the same two images: each is a grid of persistent workgroups that drains its own queue,
+    // and the last workgroups of one launch leave most of the device idle while they finish.  With the edge terms on two side streams of the scene (forked from the
+    // caller's stream after the clears, joined before the call returns) the next term's workgroups take the slots as they free up.
+    hipStream_t s_prim = st, s_sec = st;
+    // (BVH scenes only: config 5 219.3 -> 217.9 ms; the brute-force classes lose - C3 7.09 -> 7.34 ms - because a second kernel's waves beside a VALU-bound one only take issue slots)
+    const bool fork = ad && !a->pix_ids && !lanes_out && !COUNT && T.n_tris > kBruteForceMax && ((terms & (PSDR_TERM_PRIMARY | PSDR_TERM_SECONDARY)) != 0) && (terms & (terms - 1)) != 0;
+    unsigned long long *q_int = nullptr, *q_prim = nullptr, *q_sec = nullptr;
+    if (fork) {
+        if (sc->make_term_streams()) return fail("term streams: cannot create");
+        if (next_queue(q_int) || next_queue(q_prim) || next_queue(q_sec)) return 1;
+        HIPCHK(hipEventRecord(sc->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(sc->aux[0], sc->ev_fork, 0));
+        HIPCHK(hipStreamWaitEvent(sc->aux[1], sc->ev_fork, 0));
+        s_prim = sc->aux[0]; s_sec = sc->aux[1];
+    }
     if ((terms & PSDR_TERM_INTERIOR) && T.spp > 0) {
         PathParams P{};
         P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[0].seed; P.skip = skip_ahead(a->samplers[0].skip);
@@ -707,7 +728,7 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
         if (lanes_out) { P.begin = lane_b; P.end = lane_e; P.shard_rank = 0; P.shard_count = 1; }
         P.n_local = local_lanes(P.end - P.begin, P.shard_rank, P.shard_count);
         if (P.n_local > 0) {
-            if (next_queue(P.counter)) return 1;
+            if (fork) P.counter = q_int; else if (next_queue(P.counter)) return 1;
             if (ad) {
                 if (cls == 1) ON_CLS1(LAUNCH(1, (k_paths<true, 1, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
                 else if (cls == 2) ON_CLS2(LAUNCH(2, (k_paths<true, 2, COUNT, 0>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
@@ -728,11 +749,11 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
             P.begin = 0; P.end = npx * T.sppe; P.shard_rank = rank; P.shard_count = count; P.dout = dout;
             P.n_local = local_lanes(P.end, rank, count);
             if (P.n_local > 0) {
-                if (next_queue(P.counter)) return 1;
-                if (cls == 1) ON_CLS1(LAUNCH(1, (k_paths<false, 1, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
-                else if (cls == 2) ON_CLS2(LAUNCH(2, (k_paths<false, 2, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
-                else if (cls == 3) ON_CLS3(LAUNCH(3, (k_paths<false, 3, false, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
-                else ON_CLS0(LAUNCH(0, (k_paths<false, 0, COUNT, 1>), sc, P.n_local, st, sc->blob.as<float4>(), T, cam, P, ctr));
+                if (fork) P.counter = q_prim; else if (next_queue(P.counter)) return 1;
+                if (cls == 1) ON_CLS1(LAUNCH(1, (k_paths<false, 1, COUNT, 1>), sc, P.n_local, s_prim, sc->blob.as<float4>(), T, cam, P, ctr));
+                else if (cls == 2) ON_CLS2(LAUNCH(2, (k_paths<false, 2, COUNT, 1>), sc, P.n_local, s_prim, sc->blob.as<float4>(), T, cam, P, ctr));
+                else if (cls == 3) ON_CLS3(LAUNCH(3, (k_paths<false, 3, false, 1>), sc, P.n_local, s_prim, sc->blob.as<float4>(), T, cam, P, ctr));
+                else ON_CLS0(LAUNCH(0, (k_paths<false, 0, COUNT, 1>), sc, P.n_local, s_prim, sc->blob.as<float4>(), T, cam, P, ctr));
             }
         }
         if ((terms & PSDR_TERM_SECONDARY) && T.sppse > 0 && sc->E.n > 0) {
@@ -744,13 +765,19 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
             const int use_g = a->guiding ? 1 : 0;
             if (a->guiding) G = a->guiding->G;
             if (P.n_local > 0) {
-                if (next_queue(P.counter)) return 1;
-                if (sc->lds) ON_CLS1(LAUNCH(1, (k_secondary_edges<1, COUNT, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
-                else if (sc->lean) ON_CLS2(LAUNCH(2, (k_secondary_edges<2, COUNT, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
-                else if (cls == 3) ON_CLS3(LAUNCH(3, (k_secondary_edges<3, false, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
-                else ON_CLS0(LAUNCH(0, (k_secondary_edges<0, COUNT, false>), sc, P.n_local, st, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
+                if (fork) P.counter = q_sec; else if (next_queue(P.counter)) return 1;
+                if (sc->lds) ON_CLS1(LAUNCH(1, (k_secondary_edges<1, COUNT, false>), sc, P.n_local, s_sec, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
+                else if (sc->lean) ON_CLS2(LAUNCH(2, (k_secondary_edges<2, COUNT, false>), sc, P.n_local, s_sec, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
+                else if (cls == 3) ON_CLS3(LAUNCH(3, (k_secondary_edges<3, false, false>), sc, P.n_local, s_sec, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
+                else ON_CLS0(LAUNCH(0, (k_secondary_edges<0, COUNT, false>), sc, P.n_local, s_sec, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
             }
         }
+    }
+    if (fork) {
+        HIPCHK(hipEventRecord(sc->ev_join[0], sc->aux[0]));
+        HIPCHK(hipEventRecord(sc->ev_join[1], sc->aux[1]));
+        HIPCHK(hipStreamWaitEvent(st, sc->ev_join[0], 0));
+        HIPCHK(hipStreamWaitEvent(st, sc->ev_join[1], 0));
     }
     HIPCHK(hipGetLastError());
     if (COUNT && counters) {
@@ -835,7 +862,11 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     const bool lds_acc = true;
     const bool with_lookups = T.tex != nullptr || T.pv != nullptr || T.env_emitter >= 0;
     // PSDR_ADJ_GLOBAL=1: run the interior adjoint of an LDS-class scene from global memory (no blob copy in LDS: more workgroups per CU)
+#ifdef PSDR_DEV_KNOBS
     static const bool adj_global = std::getenv("PSDR_ADJ_GLOBAL") != nullptr;
+#else
+    constexpr bool adj_global = false;
+#endif
     const int adj_cls = (use_lds && !adj_global) ? 1 : ((sc->lean || use_lds) && a->field_mode == 0 ? 2 : 0);
     // LDS: [blob (class 1)] [stacks] [per-lane records] [camera / env / material accumulators] [hot triangle rows, colours, emitters];
     // the number of hot triangle rows is what is left of the 160 KB
@@ -855,6 +886,13 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     const bool sweep = !no_sweep && adj_cls != 0 && a->field_mode == 0 && T.tex == nullptr && T.pv == nullptr && (T.env_emitter < 0 || adj_cls == 2);
     // GGX scenes (class 0): the material sweep, when every BSDF is Diffuse or a constant-parameter Microfacet
     // ... and the first-hit integrators on such scenes (the sweep's camera-hit block with the integrator's own adjoint; field 0 and 7 are constants)
+    // the record-and-probe form fills g_uv_xf only while it visits a bitmap / environment lookup for g_tex / g_env: a caller that wants the uv-transform adjoints
+    // without those buffers would get zeros from this form and numbers from the sweeps - refuse instead
+    if (g->g_uv_xf && (no_sweep || a->field_mode == 0) && !sweep) {
+        const bool sweep_mat_ = !no_sweep && adj_cls == 0 && sc->simple_mats;
+        if (!sweep_mat_ && ((sc->tex_total > 0 && !g->g_tex) || (T.env_emitter >= 0 && !g->g_env)))
+            return fail("g_uv_xf in the record-and-probe form needs g_tex (BSDF bitmaps) / g_env (environment map) beside it");
+    }
     const bool sweep_mat = !no_sweep && !sweep && adj_cls == 0 && sc->simple_mats && (a->field_mode > 0 || T.mat != nullptr || T.tex != nullptr || T.pv != nullptr || sc->has_nmap);
     const int lane_words = (sweep || sweep_mat) ? adj_sweep_words(adj_depth) : adj_lane_words(adj_depth, with_lookups);
     // the per-lane records (hits, light samples, lookups of one path: 14 D + 3 words for the sweep) live in LDS when they fit beside
@@ -865,7 +903,11 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     if ((sweep || sweep_mat) && T.env_emitter >= 0 && g->g_env != nullptr && (size_t) T.env.width * T.env.height * 3 * sizeof(float) <= 32 * 1024)
         env_lds = (size_t) T.env.width * T.env.height * 3;
     const size_t acc_fixed = sizeof(float) * ((size_t) kAdjMisc + (size_t) T.n_bsdfs * kMatRow + (size_t) T.n_bsdfs * 3 + (size_t) T.n_emitters * 3 + env_lds);
-    const bool rec_in_lds = smem_base + sizeof(float) * (size_t) lane_words * kBlock + acc_fixed + 64 * 22 * sizeof(float) <= 160 * 1024;
+    // ... unless they are what keeps a SECOND workgroup off the CU: the kernels need <= 256 registers (two waves per SIMD fit), and one wave per SIMD cannot hide the
+    // latency of the sweep's traces (config 5, depth 3: 40 KB of traversal rows + 45 KB of records; round 4 measured this with a 314-register kernel, where it could not help)
+    const size_t rec_bytes = sizeof(float) * (size_t) lane_words * kBlock, min_hot = 64 * 22 * sizeof(float);
+    const bool two_wg_with_rec = smem_base + rec_bytes + acc_fixed + min_hot <= 80 * 1024, two_wg_without = smem_base + acc_fixed + min_hot <= 80 * 1024;
+    const bool rec_in_lds = (two_wg_with_rec || !two_wg_without || PSDR_ADJ_REC_LDS) && smem_base + rec_bytes + acc_fixed + min_hot <= 160 * 1024;
     const size_t fixed_bytes = acc_fixed + (rec_in_lds ? sizeof(float) * (size_t) lane_words * kBlock : 0);
     if (smem_base + fixed_bytes > 160 * 1024) return fail("scene too large for the adjoint kernel's LDS accumulators");
     // two workgroups per CU (80 KB each) when the fixed part allows it - one wave per SIMD cannot hide the global-memory latency of

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -137,7 +138,22 @@ struct psdr_hip_scene {
     mutable hipEvent_t ev = nullptr;
     mutable hipStream_t last_stream = nullptr;
     mutable bool have_last = false;
-    ~psdr_hip_scene() { if (ev) (void) hipEventDestroy(ev); }
+    // side streams for the edge terms of a renderD (api.hip::render_impl): forked from the caller's stream, joined before the call returns
+    mutable hipStream_t aux[2] = {nullptr, nullptr};
+    mutable hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    int make_term_streams() const {
+        if (aux[0]) return 0;
+        for (int k = 0; k < 2; ++k) {
+            if (hipStreamCreateWithFlags(&aux[k], hipStreamNonBlocking) != hipSuccess) return 1;
+            if (hipEventCreateWithFlags(&ev_join[k], hipEventDisableTiming) != hipSuccess) return 1;
+        }
+        return hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess;
+    }
+    ~psdr_hip_scene() {
+        if (ev) (void) hipEventDestroy(ev);
+        for (int k = 0; k < 2; ++k) { if (aux[k]) (void) hipStreamDestroy(aux[k]); if (ev_join[k]) (void) hipEventDestroy(ev_join[k]); }
+        if (ev_fork) (void) hipEventDestroy(ev_fork);
+    }
     psdr::DevBuf &buf(const std::string &key) {
         auto it = named.find(key);
         if (it == named.end()) it = named.emplace(key, std::make_unique<psdr::DevBuf>()).first;

@@ -241,6 +241,8 @@ template <int LDS, bool COUNT> PSDR_DEV void t4_node(SceneView<LDS> &S, const T4
         // side gets one ulp-scale of slack
         const float tn = fmaxf(fmaxf(ax, ay), fmaxf(az, 0.f));
         const float tf = fminf(fminf(bx, by), bz) * 1.0000004f;
+        // (the code test stays although an unused slot carries an inverted box: for a node that is tiny against its distance from the ray's origin the fma absorbs
+        //  255 steps and near == far on every axis - the box alone does not reject then)
         const bool hit = (tn <= fminf(tf, bt)) & (cds[k] != kT4Miss);      // `&`: with `&&` the compiler sinks the load of the child's code into a branch - a second memory round trip per node
         key[k] = hit ? ((__float_as_uint(tn) & ~cmask) | cds[k]) : kT4Miss;
     }

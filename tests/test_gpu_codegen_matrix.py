@@ -26,7 +26,7 @@ VARIANTS = {
     "m_default": ["-DPSDR_CLS_MASK=4"],
     "m_break": ["-DPSDR_CLS_MASK=4", "-DPSDR_STEAL_BREAK=2"],                       # returned -8.4128 / 384.59 / 303.26 before the fix
     "m_break_dump": ["-DPSDR_CLS_MASK=4", "-DPSDR_STEAL_BREAK=2", "-DPSDR_SWEEP_DUMP=3"],   # the diagnostic build that kept the defect visible
-    "m_waves2": ["-DPSDR_CLS_MASK=4", "-DPSDR_ADJ_WAVES=2"],                        # 128 registers per lane less: another allocation altogether
+    "m_waves1": ["-DPSDR_CLS_MASK=4", "-DPSDR_ADJ_WAVES(cls)=1"],                   # the class-2 adjoint kernel without its two-waves bound (rounds 2-4): 512 registers to allocate in
     "m_o2": ["-DPSDR_CLS_MASK=4", "-O2"],
     "m_nosteal": ["-DPSDR_CLS_MASK=4", "-DPSDR_STEAL=0"],                           # showed the pattern at the commit that closed the item (an AGPR spill store in front of an exec
                                                                                     # restore; profiles/r04_sweep_defect_evidence.txt section 6) - which build shows it moves with every
