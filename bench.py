@@ -234,10 +234,24 @@ def main():
         a = cabi.make_args(max_depth=DEPTH, seeds=(seed, seed, seed), terms=terms, shard_rank=shard_rank, shard_count=shard_count, zero_output=zero, guiding=guiding)
         cabi.check(L.psdr_hip_render_d_fwd(handle, C.byref(a), out[0].data_ptr(), out[1].data_ptr(), stream))
 
-    def step(i):
-        launch(i)
-        if use_dist:
+    single_collective = os.environ.get("PSDR_SINGLE_COLLECTIVE", "0") == "1"
+    edge = torch.empty((2, npx, 3), dtype=torch.float32, device="cuda") if use_dist else None
+
+    def step(i, single=None):
+        # N > 1: the form psdr_jit_amd._render_terms uses - the interior term (disjoint pixels per rank, first to finish) goes into its own all_reduce, which RCCL's
+        # stream runs under the edge kernels; only the edge terms' derivative is reduced after them.  PSDR_SINGLE_COLLECTIVE=1: rounds 1-4's one all_reduce of everything.
+        if not use_dist:
+            launch(i)
+        elif single_collective if single is None else single:
+            launch(i)
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        else:
+            launch(i, terms=1)
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+            launch(i, terms=6, out=edge)
+            dist.all_reduce(edge[1], op=dist.ReduceOp.SUM)
+            work.wait()
+            buf[1] += edge[1]
 
     def sync():
         if use_dist:
@@ -273,11 +287,23 @@ def main():
             ev[2].record()
             torch.cuda.synchronize()
             acc[0] += ev[0].elapsed_time(ev[1]); acc[1] += ev[1].elapsed_time(ev[2])
+        # the two collective forms, whole steps, wall clock between synchronisations (what the overlap hides = their difference)
+        form_ms = {}
+        for name, flag in (("split", False), ("single", True)):
+            step(6000, single=flag)
+            sync()
+            t_f = time.perf_counter()
+            for i in range(reps):
+                step(6001 + i, single=flag)
+            sync()
+            form_ms[name] = (time.perf_counter() - t_f) / reps * 1e3
         mine = torch.tensor([acc[0] / reps, acc[1] / reps], dtype=torch.float64, device="cuda")
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         breakdown = {"render_ms_per_rank": [round(float(t[0]), 3) for t in allr], "allreduce_ms_per_rank": [round(float(t[1]), 3) for t in allr],
                      "all_reduce_bytes": int(buf.numel() * 4),
+                     "step_ms_split_collectives": round(form_ms["split"], 3), "step_ms_single_collective": round(form_ms["single"], 3),
+                     "overlap_ms": round(form_ms["single"] - form_ms["split"], 3), "timed_form": "single" if single_collective else "split",
                      "note": "HIP events on the launch stream, mean of %d steps outside the timed region; a rank's all-reduce time includes its wait for the slowest rank's render; "
                              "the interior tiles of the ranks are disjoint, the edge terms scatter over the frame - the whole [image | derivative] buffer is summed" % reps}
     samples_per_step = float(npx) * spp                  # spp x pixels of the whole job
@@ -293,7 +319,8 @@ def main():
                                ("BASELINE config %d%s: README Cornell box (36 triangles) %dx%d PathTracer(%d) renderD d/d(Mesh[0] x-translation), "
                                 "spp=sppe=sppse=%d" % (cfg, " weak-scaled" if weak else "", res, res, DEPTH, spp)),
                    "rays_per_step": int(npx * spp * (1 + 2 * DEPTH) + npx * spp * 2 * (1 + 2 * DEPTH) + npx * spp * 3),
-                   "parallelism": "256-lane chunks dealt round-robin to %d GPU(s)%s" % (n, " + one all_reduce(sum) of [image | derivative]" if n > 1 else "")},
+                   "parallelism": "256-lane chunks dealt round-robin to %d GPU(s)%s" % (n, (" + one all_reduce(sum) of [image | derivative]" if single_collective else
+                                    " + all_reduce(sum) of the interior term's [image | derivative] under the edge kernels, then of the edge terms' derivative") if n > 1 else "")},
     }
 
     if breakdown is not None:

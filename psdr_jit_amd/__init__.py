@@ -943,15 +943,44 @@ def _renderC(self, scene, sensor_id=0, seed=-1, batch_pix=-1, distributed=None):
     return _all_reduce(out, world > 1)
 
 
+def _render_terms(render, n, dev, world, terms, split_ok=True):
+    """image and forward derivative of one renderD from `render(launch_terms, continue_streams, image, derivative)`, summed over the ranks.
+
+    On several ranks (torch.distributed initialised: one process per GPU, RCCL) every rank evaluates its 256-lane chunks of the three samplers.  The interior
+    term's samples belong to disjoint pixels per rank and it is the first to finish, so its [image | derivative] goes into a collective of its own as soon as
+    it is launched - RCCL's stream runs it while the edge kernels, the bulk of a renderD, are still busy - and only the edge terms' derivative is reduced after
+    them: the exposed collective moves a third of the bytes.  PSDR_SINGLE_COLLECTIVE=1 keeps rounds 1-4's form: all three terms, then one all_reduce of the
+    stacked buffer.  (device-agnostic: tests/test_distributed_cpu.py drives both forms over gloo with the oracle as `render`)"""
+    launch = terms & 7
+    split = split_ok and world > 1 and (launch & TERM_INTERIOR) and (launch & (TERM_PRIMARY | TERM_SECONDARY)) and (terms >> 4) == 0 \
+        and _os.environ.get("PSDR_SINGLE_COLLECTIVE", "0") != "1"
+    if not split:
+        buf = (_torch.empty if launch else _torch.zeros)((2, n, 3), dtype=_torch.float32, device=dev)
+        render(terms, False, buf[0], buf[1])
+        _all_reduce(buf, world > 1)      # one collective for image + derivative
+        return buf[0], buf[1]
+    import torch.distributed as dist
+    buf = _torch.empty((2, n, 3), dtype=_torch.float32, device=dev)
+    render(TERM_INTERIOR, False, buf[0], buf[1])
+    work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)          # (waits for the interior kernel only; overlaps the launches below)
+    edge = _torch.empty((2, n, 3), dtype=_torch.float32, device=dev)            # edge[0]: the edge terms' primal, identically zero (integrator.cpp:192, path.cpp:265) - not reduced
+    # the edge terms continue from the sampler state the first call left (it has seeded all three streams and advanced the interior one)
+    render(launch & (TERM_PRIMARY | TERM_SECONDARY), True, edge[0], edge[1])
+    dist.all_reduce(edge[1], op=dist.ReduceOp.SUM)
+    work.wait()
+    return buf[0], buf[1] + edge[1]
+
+
 def _render_d_raw(self, scene, sensor_id, seed, batch_pix, terms, distributed=None):
     dev = _device()
     pix = _pix(batch_pix, dev)
     n = int(pix.numel()) if pix is not None else scene.opts.width * scene.opts.height
     rank, world = _shard() if distributed in (None, True) else (0, 1)
-    buf = (_torch.empty if (terms & 7) else _torch.zeros)((2, n, 3), dtype=_torch.float32, device=dev)
-    self._renderD(scene, sensor_id, seed, pix.data_ptr() if pix is not None else 0, n, buf[0].data_ptr(), buf[1].data_ptr(), _stream_ptr(), rank, world, terms)
-    _all_reduce(buf, world > 1)      # one collective for image + derivative
-    return buf[0], buf[1]
+    pp = pix.data_ptr() if pix is not None else 0
+
+    def render(launch_terms, continue_streams, image, derivative):
+        self._renderD(scene, sensor_id, -1 if continue_streams else seed, pp, n, image.data_ptr(), derivative.data_ptr(), _stream_ptr(), rank, world, launch_terms)
+    return _render_terms(render, n, dev, world, terms, split_ok=pix is None)
 
 
 def _bsdf_index(scene, obj):

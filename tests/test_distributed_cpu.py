@@ -44,11 +44,24 @@ def _worker(rank, world, port, outdir):
     img, dimg = sc.render_d(max_depth=2, seeds=(3, 4, 5), shard_rank=r, shard_count=w)
     buf = torch.from_numpy(np.stack([img, dimg]))
     psdr._all_reduce(buf, w > 1)
+    # the product's renderD over ranks (psdr_jit_amd._render_terms) in both forms - the interior term's collective started ahead of the edge terms, and the
+    # single collective of rounds 1-4 - with the oracle standing in for the kernels: the same frame
+    def render(terms, continue_streams, image, derivative):
+        i, d = sc.render_d(max_depth=2, seeds=(3, 4, 5), shard_rank=r, shard_count=w, terms=terms)
+        image.copy_(torch.from_numpy(i)); derivative.copy_(torch.from_numpy(d))
+    forms = {}
+    for name, flag in (("split", "0"), ("single", "1")):
+        os.environ["PSDR_SINGLE_COLLECTIVE"] = flag
+        i, d = psdr._render_terms(render, 24 * 24, torch.device("cpu"), w, 7)
+        forms[name] = np.stack([i.numpy(), d.numpy()])
+    os.environ.pop("PSDR_SINGLE_COLLECTIVE", None)
     if rank == 0:
         full = np.stack(sc.render_d(max_depth=2, seeds=(3, 4, 5)))
         np.save(os.path.join(outdir, "reduced.npy"), buf.numpy())
         np.save(os.path.join(outdir, "full.npy"), full)
         np.save(os.path.join(outdir, "part0.npy"), np.stack([img, dimg]))
+        np.save(os.path.join(outdir, "split.npy"), forms["split"])
+        np.save(os.path.join(outdir, "single.npy"), forms["single"])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -60,6 +73,9 @@ def test_two_rank_shards_reduce_to_full_frame(tmp_path):
     reduced, full, part0 = (np.load(os.path.join(tmp_path, f)) for f in ("reduced.npy", "full.npy", "part0.npy"))
     assert np.allclose(reduced[0], full[0], rtol=1e-5, atol=1e-7)
     assert np.allclose(reduced[1], full[1], rtol=1e-4, atol=1e-6)
+    for form in ("split", "single"):
+        got = np.load(os.path.join(tmp_path, form + ".npy"))
+        assert np.allclose(got[0], full[0], rtol=1e-5, atol=1e-7) and np.allclose(got[1], full[1], rtol=1e-4, atol=1e-6), form
     # each rank really rendered only a part
     assert np.linalg.norm(part0[0]) < 0.9 * np.linalg.norm(full[0])
 

@@ -36,7 +36,7 @@ def test_two_ranks_forward_and_backward_equal_one_process():
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a visible MI355X (no CPU fallback exists)")
     r = _torchrun([os.path.join("tools", "check_2rank_backward.py")])
-    assert r.returncode == 0 and "2-rank backward OK" in r.stdout, r.stdout[-3000:]
+    assert r.returncode == 0 and "backward OK" in r.stdout, r.stdout[-3000:]
 
 
 def test_bench_two_ranks_config4_strong_scaling_line():
@@ -56,6 +56,9 @@ def test_bench_two_ranks_config4_strong_scaling_line():
     sb = d["scale_breakdown"]
     assert len(sb["render_ms_per_rank"]) == 2 and len(sb["allreduce_ms_per_rank"]) == 2 and min(sb["render_ms_per_rank"]) > 0
     assert sb["all_reduce_bytes"] == 2 * 2048 * 2048 * 3 * 4
+    # both collective forms were timed as whole steps (the interior term's all_reduce under the edge kernels / one all_reduce at the end)
+    assert sb["step_ms_split_collectives"] > 0 and sb["step_ms_single_collective"] > 0 and sb["timed_form"] == "split"
+    assert abs(sb["overlap_ms"] - (sb["step_ms_single_collective"] - sb["step_ms_split_collectives"])) < 1e-2
 
 
 def test_bench_dry_run_says_whether_the_node_can_run_n_ranks():
