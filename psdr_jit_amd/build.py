@@ -95,7 +95,7 @@ def build_hip(force=False, extra_flags=(), target=None):
 # The allocator of clang 22 / ROCm 7.2 can place vector instructions it inserts at the head of a join block (re-materialised constants,
 # split copies, reloads) in FRONT of the `s_or_b64 exec` that switches the other branch's lanes back on - those lanes then go on with a stale
 # register.  It happens when its scalar phase has left copies in front of the exec restore; it cost round 3 its open item (the class-2
-# reverse sweep, 0.5-2.5 % off in builds whose only difference was an unrelated knob).  isa_lint.py finds the pattern
+# reverse sweep, 0.5-2.5 % off in builds whose only difference was an unrelated knob; LABNOTES.md section 4).  isa_lint.py finds the pattern
 # in the ISA; a unit that shows it is compiled again with the scalar allocator that does not split live ranges (-sgpr-regalloc=basic: the
 # copies become SGPR spills, which the compiler does recognise as block prologue; measured +4 % kernel time, so it is not the default),
 # and a unit that still shows it fails the build.

@@ -2,7 +2,7 @@
 Part of the build recipe (build.py lints every translation unit and re-compiles a flagged one with the scalar allocator that does not
 produce the pattern) and of the CPU test suite (tests/test_isa_lint.py).
 
-The compiler bug this looks for (ROCm 7.2 / clang 22, AMDGPU split register allocation; DESIGN.md section 4, "the class-2 sweep's open
+The compiler bug this looks for (ROCm 7.2 / clang 22, AMDGPU split register allocation; LABNOTES.md section 4, "the class-2 sweep's open
 item, closed"): the exec restore of a join block (`s_or_b64 exec, exec, s[a:b]`, SI_END_CF) is meant to be the block's first instruction,
 and everything the VGPR allocator inserts at a block head (re-materialised constants, split copies, reloads from AGPRs or scratch) is
 meant to go AFTER it.  When the SGPR allocation phase has put scalar copies in front of the restore, `SIInstrInfo::isBasicBlockPrologue`

@@ -2,7 +2,7 @@
 
 Round 3 ended with `k_interior_adjoint<2>` returning -8.4128 instead of -8.2052 when an unrelated knob of trav4.h (PSDR_STEAL_BREAK) changed
 the register allocation of the kernel.  Round 4 found the cause in the compiler (vector constants re-materialised in front of a join block's
-`s_or_b64 exec`): psdr_jit_amd/isa_lint.py finds the pattern in the ISA, and the build recipe compiles a unit that shows it a
+`s_or_b64 exec`; LABNOTES.md section 4): psdr_jit_amd/isa_lint.py finds the pattern in the ISA, and the build recipe compiles a unit that shows it a
 second time with the scalar allocator that does not produce it (and fails if it still does).  This test keeps the property measurable: libpsdr_hip.so is built in several variants that
 perturb the sweep kernel's code generation - among them the two that returned wrong numbers before the fix - and each variant, in a process of
 its own (tools/sweep_check.py on a staged package copy), has to

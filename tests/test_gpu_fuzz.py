@@ -1,7 +1,7 @@
 """Randomised parity: scene family, parameter, frame size, spp, depth, terms and seeds drawn by a generator instead of picked by hand.
 
 tools/fuzz_parity.py compares renderD of the HIP path with the CPU oracle, tools/fuzz_reverse.py the reverse mode (<J^T w, v>) with the oracle's
-forward mode (<w, J v>).  Round 4 ran 1650 + 660 cases of them without a failure; the suite keeps a short fixed-seed slice of each."""
+forward mode (<w, J v>).  Round 4 ran 1650 + 660 cases of them without a failure (LABNOTES.md section 2); the suite keeps a short fixed-seed slice of each."""
 import os
 import subprocess
 import sys

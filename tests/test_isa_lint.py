@@ -3,7 +3,7 @@
 Round 3 left one open item: the class-2 reverse sweep (`k_interior_adjoint<2>`) returned gradients that were 0.5-2.5 % off when an unrelated
 line of another header changed.  Round 4 traced it to the compiler, not to the source: with scalar copies in front of `s_or_b64 exec` the
 VGPR allocation phase of clang 22 / ROCm 7.2 places re-materialised constants (here the +-pi, +-pi/2 of the environment lookup's atan2 /
-acos) BEFORE the lanes of the other branch are switched back on, so those lanes go on with a stale register.  The
+acos) BEFORE the lanes of the other branch are switched back on, so those lanes go on with a stale register (LABNOTES.md section 4).  The
 pattern is visible in the ISA without a GPU, which is what this test pins: every kernel of libpsdr_hip.so, every build."""
 import os
 import subprocess

@@ -1,7 +1,7 @@
 """finite-difference validation of the oracle's full renderD
 (interior + primary-edge + secondary-edge terms) against its own renderC with common random numbers.
 
-Setup notes (measured, see DESIGN.md "What the estimator does and does not differentiate"):
+Setup notes (measured, see LABNOTES.md "What the estimator does and does not differentiate"):
   * depth 1: the reference's secondary-edge term only covers DIRECT boundary segments (path.cpp:172-270
     never calls Li), so at depth >= 2 renderD is biased by design against a finite difference;
   * flat-shaded meshes: with interpolated shading normals the integrand n_s.w does not vanish at the
@@ -52,7 +52,7 @@ def test_primary_edge_term_matches_finite_differences_under_a_uniform_environmen
     environment map, translated in x.  The interior derivative of this scene vanishes up to shading noise, no emitter geometry moves,
     so the finite difference of renderC is the silhouette integral the primary-edge estimator samples: positive and negative sides
     within 5 % (measured 0.98 / 0.98).  (With interpolated normals the reference's estimator is 6-12 % above the finite
-    difference - DESIGN.md section 7 -; the figure Forward_AD_envmap.ipynb cell 10 shows is another 1.2 x above this
+    difference - LABNOTES.md section 7 -; the figure Forward_AD_envmap.ipynb cell 10 shows is another 1.2 x above this
     restatement, which is why that figure's band in test_oracle_notebooks.py is wide.)"""
     from oracle.oracle import BsdfSpec, EmitterSpec
     res, h = 96, 5e-4

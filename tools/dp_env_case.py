@@ -1,5 +1,5 @@
 """Diagnostic: prints (lhs, rhs, scale) of the reverse-sweep dot-product cases of environment-lit scenes (tests/test_gpu_adjoint.py::test_interior_sweep_environment_map);
-lhs = forward-mode tangents . w, rhs = adjoints . tangents.  DESIGN.md section 4, BVH third pass, open item.   python tools/dp_env_case.py"""
+lhs = forward-mode tangents . w, rhs = adjoints . tangents.  LABNOTES.md section 4, BVH third pass, open item.   python tools/dp_env_case.py"""
 import sys
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import pytest, scenes
