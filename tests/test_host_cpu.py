@@ -67,6 +67,78 @@ def test_host_snapshot_matches_oracle(psdr, orc, name, param):
         assert snap["sec_edges"].shape[0] == 990 and cam._primary_edges(False).shape[0] == 79   # Forward_AD.ipynb:139-140
 
 
+def _snap_equal(a, b):
+    sa, sb = a._snapshot(), b._snapshot()
+    assert sorted(sa.keys()) == sorted(sb.keys())
+    for k in sa:
+        if k in ("bsdf_rows", "env_reso"):
+            assert list(sa[k]) == list(sb[k]), k
+        elif k == "env_cell_sum":
+            assert float(sa[k]) == float(sb[k])
+        else:
+            assert np.array_equal(np.asarray(sa[k]), np.asarray(sb[k])), k
+    for sid in range(a.num_sensors):
+        ca, cb = a.param_map["Sensor[%d]" % sid], b.param_map["Sensor[%d]" % sid]
+        for tg in (False, True):
+            assert np.array_equal(ca._primary_edges(tg), cb._primary_edges(tg)), ("primary edges", sid, tg)
+        assert np.array_equal(np.asarray(ca._primary_edge_ids()), np.asarray(cb._primary_edge_ids()))
+
+
+@pytest.mark.parametrize("name", ["cbox", "sphere", "envmap"])
+def test_incremental_configure_equals_a_fresh_scene(psdr, name):
+    """configure_host() on a scene that has been configured before rewrites only the snapshot rows whose inputs changed (Mesh::configure skips a mesh whose inputs are
+    those of its previous run, sensors and edge lists follow the meshes' versions): after every kind of change - a tangent, a translation of one mesh, raw vertices,
+    a colour, the camera, nothing - the snapshot equals, bit for bit, the one of a scene built from scratch in that state"""
+    make = {"cbox": lambda: scenes.cbox_scene(24, 24, 4, 4, 4, param="light_x"), "sphere": lambda: scenes.sphere_scene(24, 24, 4, 4, 4),
+            "envmap": lambda: scenes.envmap_scene(24, 24, 4, 4, 4, param="box_x", area_light=True)}[name]
+    spec = make()
+    sc = product.build_scene(spec, host_only=True)
+    z44 = np.zeros((4, 4), np.float32)
+
+    def fresh():
+        f = product.build_scene(spec, host_only=True)
+        _snap_equal(sc, f)
+
+    fresh()
+    sc._configure_host([0]); fresh()                                   # nothing changed
+    m0 = spec.meshes[0]
+    # 1. a tangent only
+    d = z44.copy(); d[1, 3] = 2.5
+    m0.d_to_world_left = d
+    sc.param_map["Mesh[0]"]._set("to_world_left", np.asarray(m0.to_world_left, np.float32), d)
+    sc._configure_host([0]); fresh()
+    # 2. the mesh moves
+    t = np.asarray(m0.to_world_left, np.float32).copy(); t[0, 3] += 7.0; t[2, 3] -= 3.0
+    m0.to_world_left = t
+    sc.param_map["Mesh[0]"]._set("to_world_left", t, d)
+    sc._configure_host([0]); fresh()
+    # 3. raw vertices of another mesh (and their tangents)
+    m1 = spec.meshes[1]
+    v = np.asarray(sc.param_map["Mesh[1]"]._get("vertex_positions", False), np.float32).copy()
+    v[:, 0] = v[:, 0].mean() + 0.9 * (v[:, 0] - v[:, 0].mean())        # (inside the scene box of the first configure: the environment map's bounding cube is added once)
+    dv = np.zeros_like(v); dv[:, 0] = 1.0
+    sc.param_map["Mesh[1]"]._set("vertex_positions", v, dv)
+    m1.vertices = v; m1.d_vertices = dv; m1.path = None               # (a spec with a path would re-read the file)
+    sc._configure_host([0]); fresh()
+    m1.d_vertices = None
+    sc.param_map["Mesh[1]"]._set("vertex_positions", v, np.zeros_like(v))
+    sc._configure_host([0]); fresh()
+    # 4. a colour
+    spec.bsdfs[1].reflectance = (0.25, 0.5, 0.75); spec.bsdfs[1].d_reflectance = (0.0, 1.0, 0.0)
+    sc.param_map["BSDF[1]"]._set("reflectance", np.asarray([0.25, 0.5, 0.75], np.float32), np.asarray([0.0, 1.0, 0.0], np.float32))
+    sc._configure_host([0]); fresh()
+    # 5. the camera
+    c = spec.cameras[0]
+    tw = np.asarray(c.to_world_raw, np.float32).copy(); tw[0, 3] += 11.0
+    c.to_world_raw = tw
+    sc.param_map["Sensor[0]"]._set("to_world", tw, np.asarray(c.d_to_world_raw, np.float32))
+    sc._configure_host([0]); fresh()
+    # 6. back to no tangent on the first mesh
+    m0.d_to_world_left = z44
+    sc.param_map["Mesh[0]"]._set("to_world_left", t, z44)
+    sc._configure_host([0]); fresh()
+
+
 def test_host_envmap_configure_matches_oracle(psdr, orc):
     """EnvironmentMap::configure, the bounding cube and the emitter weights (scene.cpp:434-515) on the host"""
     spec = scenes.envmap_scene(32, 32, 4, 4, 4, param="box_x", area_light=True)
