@@ -130,12 +130,12 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
     // and the first path's radiance - waits in the lane's LDS column (kColdRows rows behind the blob): registers are what this
     // kernel runs out of, and a value parked here costs two LDS instructions per path instead of scratch traffic per vertex.
     lds_float_t *cold = (lds_float_t *) (reinterpret_cast<float *>(S.stack) + (T.stack_depth - kColdRows) * kBlock);
-    enum { kLnX = 0, kLnY, kLnZ, kXdnV, kXdnD, kPdf, kEdgeS, kNx, kNy, kEdgeI, kPix, kLaneLo = 0, kLaneHi = 1 };
+    enum { kLnX = 0, kLnY, kLnZ, kXdnV, kXdnD, kPdf, kEdgeS, kNx, kNy, kEdgeI, kPix, kHpSlot, kHpU, kHpV, kHpT, kLaneLo = 0, kLaneHi = 1 };
     auto cold_f = [&](int r) -> float { return cold[r * kBlock]; };
     auto cold_i = [&](int r) -> int { return __float_as_int(cold[r * kBlock]); };
     auto park_f = [&](int r, float v) { cold[r * kBlock] = v; };
     auto park_i = [&](int r, int v) { cold[r * kBlock] = __int_as_float(v); };
-    static_assert(kColdRows >= 11, "scene_dev.h::kColdRows");
+    static_assert(kColdRows >= 15, "scene_dev.h::kColdRows");
     static_assert(MODE == 0 || !AD, "the primary-edge paths are traced in C mode");
 
 #if PSDR_DIAG == 6
@@ -147,6 +147,10 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
 #define PSDR_PHASE(field) do { } while (0)
 #endif
     for (;;) {
+        // MODE 1: the camera ray of an edge sample's SECOND path rides in the first path's first trace (whose next-event slot is idle: no vertex yet); its hit waits in
+        // the lane's cold rows until the first path has ended.  Same rays, same sampler draws - one trace2 pass per edge sample less (8 -> 7 at depth 3).
+        RayT<AD> cam_p; cam_p.o = V(R(0.f)); cam_p.d = V(R(0.f));
+        bool trace_p = false;
         // ------------------------------------------------------------------ fetch work for idle lanes
         if (q_next >= q_end && !exhausted) {
             unsigned long long base = 0;
@@ -202,8 +206,7 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
                         park_i(kPix, edge_valid ? iy * T.width + ix : -1);
                         const RayT<false> ray_p = sample_primary_ray<false>(cam, px.v + kEdgeEpsilon * nx, py.v + kEdgeEpsilon * ny);
                         const RayT<false> ray_n = sample_primary_ray<false>(cam, px.v - kEdgeEpsilon * nx, py.v - kEdgeEpsilon * ny);
-                        (void) ray_p;      // rebuilt from (edge_i, edge_s) when the first path has ended
-                        if constexpr (!AD) ext = ray_n;
+                        if constexpr (!AD) { ext = ray_n; cam_p = ray_p; trace_p = edge_valid; }      // (ray_p is rebuilt from (edge_i, edge_s) when the first path has ended: make_its wants it)
                         side = 0;
                         park_f(kXdnV, x_dot_n.v); park_f(kXdnD, x_dot_n.d); park_f(kPdf, pdf); park_f(kEdgeS, s); park_f(kNx, nx); park_f(kNy, ny); park_i(kEdgeI, ei);
                         if (!edge_valid) busy = false;       // Li(..., valid=false) contributes nothing
@@ -248,8 +251,10 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
         PSDR_PHASE(c_nodes);
         // an invalid BSDF sample (e.g. on the BSDF-less bounding cube of the environment map: wo = 0) ends the path whatever
         // its ray hits; a zero-direction ray would wander through every BVH node that contains its origin
-        trace2<LDS, COUNT>(S, detach(ray1.o), detach(ray1.d), do_nee, detach(ext.o), detach(ext.d), busy && bs.valid, h, hx);
+        if (MODE == 1) { if (trace_p) ray1 = cam_p; }
+        trace2<LDS, COUNT>(S, detach(ray1.o), detach(ray1.d), do_nee || (MODE == 1 && trace_p), detach(ext.o), detach(ext.d), busy && bs.valid, h, hx);
         PSDR_PHASE(c_tris);
+        if (MODE == 1) { if (trace_p) { park_i(kHpSlot, h.slot); park_f(kHpU, h.u); park_f(kHpV, h.v); park_f(kHpT, h.t); } }
         {
             if (do_nee && h.slot >= 0) {
                 if (COUNT) S.c_hits++;
@@ -337,6 +342,7 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
                 }
                 busy = false;
             } else {
+                bool sample_done = side == 1;
                 if (side == 0) {
                     { const Vec3f Ln = detach(res); park_f(kLnX, Ln.x); park_f(kLnY, Ln.y); park_f(kLnZ, Ln.z); }
                     // the reference's Li always draws 5 numbers per depth level; skip what this path left
@@ -350,8 +356,17 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
                         const float oms = 1.0f - edge_s;
                         const float pxv = fmaf(r0.x, oms, r0.z * edge_s), pyv = fmaf(r0.y, oms, r0.w * edge_s);
                         ext = sample_primary_ray<false>(cam, pxv + kEdgeEpsilon * edge_nx, pyv + kEdgeEpsilon * edge_ny);
+                        // ... and its hit was found in the first path's first trace: the second path starts AT its first vertex (path.cpp:38-43)
+                        Hit hp; hp.slot = cold_i(kHpSlot); hp.u = cold_f(kHpU); hp.v = cold_f(kHpV); hp.t = cold_f(kHpT);
+                        const Its<AD> itp = make_its<AD, LDS, true>(S, hp, ext, false);
+                        its = itp;
+                        if (S.field >= 0) { if constexpr (has_mat(LDS)) res = first_hit_value<AD, LDS>(S, itp); }
+                        else if (!P.hide_emitters) res = eval_Le<AD, LDS>(S, itp, itp.valid);
+                        depth = 0;
+                        sample_done = !itp.valid || P.max_depth == 0;
                     }
-                } else {
+                }
+                if (sample_done) {
                     // value = x_dot_n * (Ln - Lp) / pdf, scrub, / sppe; only the tangent survives (integrator.cpp:187-192)
                     const Vec3f Lp = detach(res), Ln(cold_f(kLnX), cold_f(kLnY), cold_f(kLnZ));
                     const float edge_xdn_v = cold_f(kXdnV), edge_xdn_d = cold_f(kXdnD), edge_pdf = cold_f(kPdf);
@@ -414,6 +429,8 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
 #endif
 constexpr int kShadeMin = PSDR_SHADE_MIN;
 
+// (round 5, measured and not kept here: posting the second edge path's camera ray beside the first's - what run_paths does - leaves config 5's primary-edge kernel at
+//  163.6 ms (163.3 before): the four registers of the parked hit and the second make_its cost what the saved queue rounds give)
 template <bool AD, int LDS, bool COUNT, int MODE>
 PSDR_DEV void run_paths_async(SceneView<LDS> &S, const SensorDev &cam, const PathParams &P) {
     using R = Num<AD>; using V = VecN<AD>;
