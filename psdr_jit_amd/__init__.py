@@ -1129,36 +1129,33 @@ class _RenderDFn(_torch.autograd.Function):
         g_tri, g_bsdf, g_em = g[offs[0]:offs[1]].reshape(n_tris, 22), g_bsdf_all[:nb], g[offs[2]:offs[3]].reshape(-1, 3)[:ne]
         g_sec, g_prim = g[offs[3]:offs[4]].reshape(-1, 6)[:n_sec], g[offs[4]:offs[5]].reshape(-1, 4)[:n_prim]
 
-        fresh = {}
-
-        def leaf_of(obj, name):
-            t = obj.__dict__.get("_psdr_params", {}).get(name)
-            key = (id(obj), name)
-            if t is not None and t.requires_grad:
-                if key not in fresh:
-                    fresh[key] = t.detach().to("cpu", _torch.float64).clone().requires_grad_(True)
-                return fresh[key]
-            return _torch.as_tensor(_np.asarray(obj._get(name, False), dtype=_np.float64))
-
-        # the host chain below works on small float64 CPU tensors: on a many-core host torch's intra-op pool costs more than it
-        # computes (measured on the 2 x 64-core box: 9 ms with <= 4 threads, 10-70 ms with the default 128)
+        # From the adjoints of the snapshot rows to the leaves: the per-triangle / per-edge part of the chain rule runs in the host core (Scene::chain_geometry through
+        # chain.native_geometry_grads: double arithmetic on host threads; rounds 1-4 differentiated a torch restatement of configure() here, 25 ms per step on config 5),
+        # colours and radiances are rows of g_bsdf / g_emitter.
         grads = [None] * len(leaves)
-        with _intra_op_threads(4):
-            with _torch.enable_grad():          # autograd runs backward() with grad mode off
-                tri, sec, prim, refl, rad, cam_tw = chain.snapshot_tensors(scene, st["sensor_id"], leaf_of)
-            g_camera = g_cam.to("cpu", _torch.float64).reshape(4, 4) if g_cam is not None else _torch.zeros((4, 4), dtype=_torch.float64)
-            outs, gos = [], []
-            for o, go in ((tri, g_tri), (sec, g_sec), (prim, g_prim), (refl, g_bsdf), (rad, g_em), (cam_tw, g_camera)):
-                if o.requires_grad and o.numel() > 0:
-                    outs.append(o)
-                    gos.append(go.reshape(o.shape))
-            wanted = [(i, fresh.get((id(obj), name))) for i, ((obj, name, t), need) in enumerate(zip(leaves, needs)) if need]
-            wanted = [(i, f) for i, f in wanted if f is not None]
-            if outs and wanted:
-                res = _torch.autograd.grad(outs, [f for _, f in wanted], gos, allow_unused=True)
-                for (i, f), r in zip(wanted, res):
-                    t = leaves[i][2]
-                    grads[i] = _torch.zeros_like(t) if r is None else r.reshape(t.shape).to(t.device, t.dtype)
+        g_np = g.numpy()
+        geo_wanted = [(obj, name) for (obj, name, t), need in zip(leaves, needs)
+                      if need and ((isinstance(obj, Mesh) and name in ("vertex_positions", "to_world_left", "to_world", "to_world_right")) or
+                                   (isinstance(obj, Sensor) and name in ("to_world_left", "to_world", "to_world_right")))]
+        if geo_wanted:
+            geo = chain.native_geometry_grads(scene, st["sensor_id"], geo_wanted, g_np[offs[0]:offs[1]], g_np[offs[3]:offs[3] + 6 * n_sec], g_np[offs[4]:offs[4] + 4 * n_prim],
+                                              g_cam.to("cpu", _torch.float64).numpy().reshape(4, 4) if g_cam is not None else None)
+        for i, ((obj, name, t), need) in enumerate(zip(leaves, needs)):
+            if not need:
+                continue
+            if (obj, name) in [(o, n) for o, n in geo_wanted] and (id(obj), name) in geo:
+                grads[i] = _torch.as_tensor(_np.ascontiguousarray(geo[(id(obj), name)])).reshape(t.shape).to(t.device, t.dtype)
+            elif isinstance(obj, _core.BSDF) and t.dim() < 2 and name == ("diffuseReflectance" if isinstance(obj, MicrofacetBSDF) else "reflectance") \
+                    and isinstance(obj, (DiffuseBSDF, MicrofacetBSDF)):
+                b = _bsdf_index(scene, obj)
+                if b < nb:                      # (a BSDF nested in a normal map: below)
+                    row = g_bsdf[b].to(_torch.float32)
+                    grads[i] = (row if t.numel() == 3 else row.sum().reshape(1)).reshape(t.shape).to(t.device, t.dtype)
+            elif isinstance(obj, AreaLight) and name == "radiance":
+                e = [k for k in range(ne) if pm.get("Emitter[%d]" % k) is obj]
+                if e:
+                    row = g_em[e[0]].to(_torch.float32)
+                    grads[i] = (row if t.numel() == 3 else row.sum().reshape(1)).reshape(t.shape).to(t.device, t.dtype)
         for i in tex_leaves:          # the leaf IS the texel array: its gradient is its block of g_tex
             obj, name, t = leaves[i]
             b = _bsdf_index(scene, obj)

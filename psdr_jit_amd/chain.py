@@ -132,3 +132,48 @@ def snapshot_tensors(scene, sensor_id, leaf_of):
         return torch.zeros(3, dtype=F64) if type(e).__name__ == "EnvironmentMap" else leaf_of(e, "radiance").reshape(-1).expand(3)
     rad = torch.stack([_rad(pm["Emitter[%d]" % i]) for i in range(ne)]) if ne else torch.zeros((0, 3), dtype=F64)
     return tri, sec, prim, refl, rad, tw
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# The same chain rule without autograd: the per-triangle / per-edge part runs in the host core (Scene::chain_geometry, csrc/host/scene_host.cpp: double arithmetic on
+# host threads), what is left here are 4 x 4 products.  snapshot_tensors above stays as the restatement the CPU suite checks it against (tests/test_host_cpu.py).
+def _factor_grads(obj, g_M):
+    """adjoints of (to_world_left, to_world, to_world_right) from the adjoint of their product M = L . R . Rt"""
+    L, R, Rt = (np.asarray(obj._get(n, False), dtype=np.float64).reshape(4, 4) for n in ("to_world_left", "to_world", "to_world_right"))
+    return {"to_world_left": g_M @ (R @ Rt).T, "to_world": L.T @ g_M @ Rt.T, "to_world_right": (L @ R).T @ g_M}
+
+
+def native_geometry_grads(scene, sensor_id, wanted, g_tri, g_sec, g_prim, g_camera=None):
+    """wanted: [(object, parameter name)] of Mesh / Sensor parameters whose adjoint is asked for -> {(id(object), name): float64 array}.
+    g_tri [n_triangles, 22], g_sec [n_sec_edges, 6], g_prim [n_primary_edges, 4]: snapshot-row adjoints (numpy float32); g_camera [4, 4]: the interior / secondary-edge
+    terms' adjoint of the sensor's to_world (psdr_grads.g_camera) or None."""
+    pm = scene.param_map
+    mesh_ix = {}
+    for i in range(scene.num_meshes):
+        m = pm.get("Mesh[%d]" % i)
+        if m is not None:
+            mesh_ix[id(m)] = i
+    cam = pm["Sensor[%d]" % sensor_id]
+    want_mesh = sorted({mesh_ix[id(o)] for o, _ in wanted if id(o) in mesh_ix})
+    want_cam = any(o is cam for o, _ in wanted)
+    f32 = lambda a, cols: np.ascontiguousarray(np.asarray(a, dtype=np.float32).reshape(-1, cols))
+    L, R, Rt = (np.asarray(cam._get(n, False), dtype=np.float64).reshape(4, 4) for n in ("to_world_left", "to_world", "to_world_right"))
+    tw = L @ R @ Rt
+    fov, near, far = cam._camera_params()
+    C = _camera_to_sample(fov, near, far, float(scene.opts.width) / float(scene.opts.height), bool(cam.orthographic)).numpy()
+    inv = np.linalg.inv(tw)
+    meshes, g_w2s = scene._chain_geometry(sensor_id, f32(g_tri, 22), f32(g_sec, 6), f32(g_prim, 4), want_mesh, want_cam, np.ascontiguousarray(C @ inv))
+    out = {}
+    by_mesh = {int(i): (np.asarray(gm), np.asarray(gv)) for i, gm, gv in meshes}
+    for o, name in wanted:
+        if id(o) in mesh_ix:
+            gm, gv = by_mesh[mesh_ix[id(o)]]
+            out[(id(o), name)] = gv if name == "vertex_positions" else _factor_grads(o, gm)[name]
+    if want_cam:
+        g_tw = np.zeros((4, 4)) if g_camera is None else np.asarray(g_camera, dtype=np.float64).reshape(4, 4).copy()
+        g_tw += -inv.T @ (C.T @ np.asarray(g_w2s)) @ inv.T            # world_to_sample = C . tw^-1;  Y = X^-1: g_X = -Y^T g_Y Y^T
+        fg = {"to_world_left": g_tw @ (R @ Rt).T, "to_world": L.T @ g_tw @ Rt.T, "to_world_right": (L @ R).T @ g_tw}
+        for o, name in wanted:
+            if o is cam:
+                out[(id(o), name)] = fg[name]
+    return out

@@ -403,6 +403,29 @@ PYBIND11_MODULE(_psdr_core, m) {
             int32_t n = 0, l = 0, d = 0, b = 0;
             if (!s.m_hip || psdr_hip_scene_stats(s.m_hip, &n, &l, &d, &b)) throw Exception("scene not configured");
             return py::make_tuple(n, l, d, b); })
+        // Scene::chain_geometry: float32 arrays in (rows of the snapshot), per wanted mesh (index, g_to_world [4, 4], g_vertices [nv, 3]) and g_world_to_sample out
+        .def("_chain_geometry", [](const Scene &s, int sensor_id, const farr &g_tri, const farr &g_sec, const farr &g_prim, const std::vector<int> &want_mesh, bool want_camera,
+                                  const py::array_t<double, py::array::c_style | py::array::forcecast> &w2s) {
+            std::vector<uint8_t> want(s.m_meshes.size(), 0);
+            if (w2s.size() != 0 && w2s.size() != 16) throw Exception("_chain_geometry: world_to_sample is 4 x 4");
+            for (int i : want_mesh) if (i >= 0 && (size_t) i < want.size()) want[(size_t) i] = 1;
+            if ((size_t) g_tri.size() != 22 * s.snap.area.size()) throw Exception("_chain_geometry: g_tri does not match the snapshot");
+            if ((size_t) g_sec.size() < 6 * (size_t) s.snap.n_sec_edges) throw Exception("_chain_geometry: g_sec does not match the snapshot");
+            Scene::GeometryAdjoint ga;
+            {
+                py::gil_scoped_release rel;
+                ga = s.chain_geometry(sensor_id, g_tri.data(), g_sec.data(), g_prim.data(), want, want_camera, w2s.size() == 16 ? w2s.data() : nullptr);
+            }
+            py::list meshes;
+            for (const Scene::MeshAdjoint &m : ga.meshes) {
+                py::array_t<double> gm({4, 4}), gv({(ssize_t) m.g_vertices.size() / 3, (ssize_t) 3});
+                std::memcpy(gm.mutable_data(), m.g_to_world, sizeof(double) * 16);
+                if (!m.g_vertices.empty()) std::memcpy(gv.mutable_data(), m.g_vertices.data(), sizeof(double) * m.g_vertices.size());
+                meshes.append(py::make_tuple(m.mesh, gm, gv));
+            }
+            py::array_t<double> gw({4, 4});
+            std::memcpy(gw.mutable_data(), ga.g_world_to_sample, sizeof(double) * 16);
+            return py::make_tuple(meshes, gw); })
         // (triangles, secondary edges) of the configured snapshot: what reverse mode sizes its adjoint buffers with
         .def("_snapshot_counts", [](const Scene &s) { return py::make_tuple((int64_t) s.snap.area.size(), (int64_t) s.snap.n_sec_edges); })
         .def("_hip_handle", [](const Scene &s) { return (uintptr_t) s.m_hip; })

@@ -243,7 +243,7 @@ void Mesh::build_vertex_faces() {
     vf_item.resize((size_t) 3 * nf);
     std::vector<int> at(vf_begin.begin(), vf_begin.end() - 1);
     for (int i = 0; i < 3; ++i)
-        for (int f = 0; f < nf; ++f) vf_item[(size_t) at[(size_t) face_indices[3 * f + i]]++] = f;      // (ascending in i * nf + f by construction)
+        for (int f = 0; f < nf; ++f) vf_item[(size_t) at[(size_t) face_indices[3 * f + i]]++] = (f << 2) | i;      // (face, corner); ascending in i * nf + f by construction
     vf_topo = m_topo_version;
 }
 
@@ -264,7 +264,7 @@ static void process_mesh(const std::vector<D3> &V, const std::vector<int> &F, in
     psdr::parallel_for(nv, 4096, [&](size_t b, size_t e) {
         for (size_t v = b; v < e; ++v) {
             D3 acc; DF w;
-            for (int k = vf_begin[v]; k < vf_begin[v + 1]; ++k) { const int f = vf_item[(size_t) k]; acc = acc + fnrm[f]; w = w + farea[f]; }
+            for (int k = vf_begin[v]; k < vf_begin[v + 1]; ++k) { const int f = vf_item[(size_t) k] >> 2; acc = acc + fnrm[f]; w = w + farea[f]; }
             vn[v] = dnormalize(acc / w);
         }
     });
@@ -1014,6 +1014,154 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
     if (env_cells_rebuilt) same &= ~PSDR_SAME_ENV_TEXELS;
     m_same &= same;              // (several configure_host() calls may pass before the next upload)
     m_host_ready = true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Scene::chain_geometry (scene_host.h): the transpose of the value part of Mesh::configure / the edge assembly above, in double.
+namespace {
+struct V3d { double x, y, z; };
+inline V3d operator+(V3d a, V3d b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3d operator-(V3d a, V3d b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3d operator*(V3d a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+inline double dot3(V3d a, V3d b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3d cross3(V3d a, V3d b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline V3d ld3f(const float *p) { return {(double) p[0], (double) p[1], (double) p[2]}; }
+// q = (M p)_xyz / (M p)_w and its transpose: g_p, and g_M accumulated
+inline V3d xform_d(const double *M, V3d p, double *w_out) {
+    const double h[3] = {M[0] * p.x + M[1] * p.y + M[2] * p.z + M[3], M[4] * p.x + M[5] * p.y + M[6] * p.z + M[7], M[8] * p.x + M[9] * p.y + M[10] * p.z + M[11]};
+    const double w = M[12] * p.x + M[13] * p.y + M[14] * p.z + M[15];
+    *w_out = w;
+    return {h[0] / w, h[1] / w, h[2] / w};
+}
+inline V3d xform_d_T(const double *M, V3d p, V3d q, double w, V3d g_q, double *g_M) {
+    const V3d g_h = g_q * (1.0 / w);
+    const double g_w = -dot3(g_q, q) / w;
+    const double gh[3] = {g_h.x, g_h.y, g_h.z}, pp[3] = {p.x, p.y, p.z};
+    if (g_M) {
+        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) g_M[4 * r + c] += gh[r] * pp[c]; g_M[4 * r + 3] += gh[r]; }
+        for (int c = 0; c < 3; ++c) g_M[12 + c] += g_w * pp[c];
+        g_M[15] += g_w;
+    }
+    return {M[0] * gh[0] + M[4] * gh[1] + M[8] * gh[2] + M[12] * g_w, M[1] * gh[0] + M[5] * gh[1] + M[9] * gh[2] + M[13] * g_w, M[2] * gh[0] + M[6] * gh[1] + M[10] * gh[2] + M[14] * g_w};
+}
+void mul44(const double *a, const double *b, double *c) { for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { double x = 0.0; for (int k = 0; k < 4; ++k) x += a[4 * i + k] * b[4 * k + j]; c[4 * i + j] = x; } }
+} // namespace
+
+Scene::GeometryAdjoint Scene::chain_geometry(int sensor_id, const float *g_tri, const float *g_sec, const float *g_prim, const std::vector<uint8_t> &want_mesh, bool want_camera,
+                                             const double *world_to_sample) const {
+    PSDR_ASSERT_MSG(m_host_ready, "configure() first");
+    PSDR_ASSERT_MSG(sensor_id >= 0 && sensor_id < m_num_sensors, "Invalid sensor id!");
+    GeometryAdjoint out;
+    for (double &x : out.g_world_to_sample) x = 0.0;
+    const PerspectiveCamera *cam = static_cast<const PerspectiveCamera *>(m_sensors[(size_t) sensor_id]);
+    double w2s[16];
+    for (int i = 0; i < 16; ++i) w2s[i] = world_to_sample ? world_to_sample[i] : (double) cam->rec.world_to_sample[i];
+    const std::vector<int> &ids = cam->m_enable_edges ? cam->m_edges.ids : std::vector<int>();
+    size_t face_offset = 0, sec_offset = 0;
+    for (size_t mi = 0; mi < m_meshes.size(); ++mi) {
+        Mesh *mesh = m_meshes[mi];
+        const size_t nf = (size_t) mesh->m_num_faces, nv = (size_t) mesh->m_num_vertices;
+        const size_t n_edges = (m_opts.sppse > 0 && mesh->m_enable_edges) ? mesh->edges.size() : 0;
+        const bool wanted = mi < want_mesh.size() && want_mesh[mi] != 0;
+        if (wanted || want_camera) {
+            // world-space vertices in double from the leaf values, as the forward chain rule would
+            double M[16];
+            {
+                double L[16], R0[16], Rt[16], t[16];
+                for (int i = 0; i < 16; ++i) { L[i] = mesh->to_world_left[(size_t) i]; R0[i] = mesh->to_world_raw[(size_t) i]; Rt[i] = mesh->to_world_right[(size_t) i]; }
+                mul44(L, R0, t); mul44(t, Rt, M);
+            }
+            std::vector<V3d> Vw(nv);
+            std::vector<double> Ww(nv);
+            for (size_t v = 0; v < nv; ++v) Vw[v] = xform_d(M, ld3f(&mesh->vertex_positions_raw[3 * v]), &Ww[v]);
+            std::vector<V3d> gVw(nv, V3d{0.0, 0.0, 0.0});
+            if (wanted) {
+                if (!mesh->vertex_faces_current()) mesh->build_vertex_faces();
+                const std::vector<int> &F = mesh->face_indices;
+                // per face: what its rows send to its three corners and to the face normal sum; per vertex: the normalised normal's adjoint
+                std::vector<V3d> gN(nf), gc0(nf), gc1(nf), gc2(nf), vn(nv, V3d{0.0, 0.0, 0.0}), g_nv(nv, V3d{0.0, 0.0, 0.0});
+                std::vector<V3d> N(nf);
+                for (size_t f = 0; f < nf; ++f) {
+                    const V3d p0 = Vw[(size_t) F[3 * f]], e1 = Vw[(size_t) F[3 * f + 1]] - p0, e2 = Vw[(size_t) F[3 * f + 2]] - p0;
+                    N[f] = cross3(e1, e2);
+                }
+                const std::vector<int> &vb = mesh->vertex_face_begin(), &vi = mesh->vertex_face_item();
+                psdr::parallel_for(nv, 4096, [&](size_t b, size_t e) {
+                    for (size_t v = b; v < e; ++v) {
+                        V3d acc{0.0, 0.0, 0.0}, g{0.0, 0.0, 0.0};
+                        for (int k = vb[v]; k < vb[v + 1]; ++k) {
+                            const size_t f = (size_t) (vi[(size_t) k] >> 2);
+                            const int corner = vi[(size_t) k] & 3;
+                            acc = acc + N[f];
+                            g = g + ld3f(g_tri + 22 * (face_offset + f) + 9 + 3 * corner);       // the row block n0 / n1 / n2 of this corner
+                        }
+                        vn[v] = acc; g_nv[v] = g;
+                    }
+                });
+                std::vector<V3d> g_vn(nv);
+                for (size_t v = 0; v < nv; ++v) {
+                    const double len = std::sqrt(dot3(vn[v], vn[v]));
+                    if (!(len > 0.0)) { g_vn[v] = V3d{0.0, 0.0, 0.0}; continue; }
+                    const V3d n = vn[v] * (1.0 / len);
+                    g_vn[v] = (g_nv[v] - n * dot3(n, g_nv[v])) * (1.0 / len);
+                }
+                psdr::parallel_for(nf, 4096, [&](size_t b, size_t e) {
+                    for (size_t f = b; f < e; ++f) {
+                        const float *row = g_tri + 22 * (face_offset + f);
+                        const size_t i0 = (size_t) F[3 * f], i1 = (size_t) F[3 * f + 1], i2 = (size_t) F[3 * f + 2];
+                        const V3d p0 = Vw[i0], e1 = Vw[i1] - p0, e2 = Vw[i2] - p0;
+                        const double a = std::sqrt(dot3(N[f], N[f]));
+                        V3d gn = g_vn[i0] + g_vn[i1] + g_vn[i2];
+                        if (a > 0.0) {
+                            const V3d fn = N[f] * (1.0 / a), g_fn = ld3f(row + 18);
+                            gn = gn + (g_fn - fn * dot3(fn, g_fn)) * (1.0 / a) + fn * (0.5 * (double) row[21]);
+                        }
+                        const V3d g_e1 = ld3f(row + 3) + cross3(e2, gn), g_e2 = ld3f(row + 6) + cross3(gn, e1);
+                        gc0[f] = ld3f(row) - g_e1 - g_e2; gc1[f] = g_e1; gc2[f] = g_e2;
+                    }
+                });
+                for (size_t f = 0; f < nf; ++f) {
+                    gVw[(size_t) F[3 * f]] = gVw[(size_t) F[3 * f]] + gc0[f];
+                    gVw[(size_t) F[3 * f + 1]] = gVw[(size_t) F[3 * f + 1]] + gc1[f];
+                    gVw[(size_t) F[3 * f + 2]] = gVw[(size_t) F[3 * f + 2]] + gc2[f];
+                }
+                // secondary-edge rows: p0 = Vw[v0], e1 = Vw[v1] - Vw[v0]
+                for (size_t i = 0; i < n_edges; ++i) {
+                    const MeshEdge &ed = mesh->edges[i];
+                    const float *row = g_sec + 6 * (sec_offset + i);
+                    const V3d gp = ld3f(row), ge = ld3f(row + 3);
+                    gVw[(size_t) ed.v0] = gVw[(size_t) ed.v0] + gp - ge;
+                    gVw[(size_t) ed.v1] = gVw[(size_t) ed.v1] + ge;
+                }
+            }
+            // primary-edge rows of this mesh: (q0.xy, q1.xy) = world_to_sample . Vw[v0 / v1]
+            for (size_t k = 0; 3 * k + 2 < ids.size(); ++k) {
+                if ((size_t) ids[3 * k] != mi) continue;
+                for (int side = 0; side < 2; ++side) {
+                    const size_t v = (size_t) ids[3 * k + 1 + side];
+                    const V3d gq{(double) g_prim[4 * k + 2 * side], (double) g_prim[4 * k + 2 * side + 1], 0.0};
+                    double w;
+                    const V3d q = xform_d(w2s, Vw[v], &w);
+                    const V3d gp = xform_d_T(w2s, Vw[v], q, w, gq, want_camera ? out.g_world_to_sample : nullptr);
+                    if (wanted) gVw[v] = gVw[v] + gp;
+                }
+            }
+            if (wanted) {
+                MeshAdjoint ma;
+                ma.mesh = (int) mi;
+                for (double &x : ma.g_to_world) x = 0.0;
+                ma.g_vertices.assign(3 * nv, 0.0);
+                for (size_t v = 0; v < nv; ++v) {
+                    const V3d gp = xform_d_T(M, ld3f(&mesh->vertex_positions_raw[3 * v]), Vw[v], Ww[v], gVw[v], ma.g_to_world);
+                    ma.g_vertices[3 * v] = gp.x; ma.g_vertices[3 * v + 1] = gp.y; ma.g_vertices[3 * v + 2] = gp.z;
+                }
+                out.meshes.push_back(std::move(ma));
+            }
+        }
+        face_offset += nf;
+        sec_offset += n_edges;
+    }
+    return out;
 }
 
 // assemble the C-ABI snapshot and hand it to the HIP library (replaces Scene_OptiX::configure)

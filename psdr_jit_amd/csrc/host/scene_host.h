@@ -217,7 +217,12 @@ struct Mesh : Object, Transformable {
     float m_lower[3] = {0, 0, 0}, m_upper[3] = {0, 0, 0};       // box of the world-space vertices
 private:
     void build_edges();
+public:
     void build_vertex_faces();
+    const std::vector<int> &vertex_face_begin() const { return vf_begin; }
+    const std::vector<int> &vertex_face_item() const { return vf_item; }
+    bool vertex_faces_current() const { return vf_topo == m_topo_version && vf_begin.size() == (size_t) m_num_vertices + 1; }
+private:
     std::vector<float> cfg_raw, cfg_d_raw;     // inputs of the previous configure()
     M16 cfg_m[3], cfg_dm[3];
     uint64_t cfg_topo = 0;
@@ -276,6 +281,14 @@ struct Scene : Object {
     void upload();                                                      // BVH build + device upload
     bool is_ready() const;
     size_t get_num_emitters() const { return m_emitters.size(); }
+    // Reverse-mode chain rule of the differentiable part of configure() (Mesh::configure / process_mesh, the secondary-edge rows, the primary-edge projection:
+    // reference src/shape/mesh.cpp:23-62,317-369, src/sensor/perspective.cpp:130-143 - what drjit.backward walks between the configured arrays and the user's
+    // parameters): from the adjoints of the snapshot rows psdr_hip_render_d_bwd returns to the adjoints of each wanted mesh's combined to_world (4 x 4) and raw
+    // vertices and of the sensor's world_to_sample.  double arithmetic, host threads.  g_tri [n_triangles * 22], g_sec [n_sec_edges * 6], g_prim [n_primary_edges * 4].
+    struct MeshAdjoint { int mesh = -1; double g_to_world[16]; std::vector<double> g_vertices; };
+    struct GeometryAdjoint { std::vector<MeshAdjoint> meshes; double g_world_to_sample[16]; };
+    GeometryAdjoint chain_geometry(int sensor_id, const float *g_tri, const float *g_sec, const float *g_prim, const std::vector<uint8_t> &want_mesh, bool want_camera,
+                                   const double *world_to_sample = nullptr) const;      // world_to_sample: the sensor's matrix in double (default: the configured float one)
 
     int seed = 0;
     RenderOption m_opts;

@@ -139,6 +139,54 @@ def test_incremental_configure_equals_a_fresh_scene(psdr, name):
     sc._configure_host([0]); fresh()
 
 
+@pytest.mark.parametrize("name", ["cbox", "sphere"])
+def test_native_chain_rule_equals_the_autograd_restatement(psdr, name):
+    """Scene::chain_geometry (host C++: from the adjoints of the snapshot's triangle / edge rows to mesh transforms, raw vertices and the camera pose) against
+    psdr_jit_amd/chain.py::snapshot_tensors differentiated by torch.autograd, on random row adjoints"""
+    import torch
+    from psdr_jit_amd import chain
+    spec = scenes.cbox_scene(24, 24, 4, 4, 4, param="light_x") if name == "cbox" else scenes.sphere_scene(24, 24, 4, 4, 4)
+    sc = product.build_scene(spec, host_only=True)
+    rng = np.random.default_rng(3)
+    cam = sc.param_map["Sensor[0]"]
+    n_tri, n_sec = (int(x) for x in sc._snapshot_counts())
+    n_prim = np.asarray(cam._primary_edge_ids()).reshape(-1, 3).shape[0]
+    assert n_prim > 0 and n_sec > 0
+    g_tri, g_sec, g_prim = (rng.normal(size=s).astype(np.float32) for s in ((n_tri, 22), (n_sec, 6), (n_prim, 4)))
+    g_cam = rng.normal(size=(4, 4)); g_cam[3] = 0.0
+    meshes = [sc.param_map["Mesh[%d]" % i] for i in (0, 1, sc.num_meshes - 1)]
+    wanted = [(m, n) for m in meshes for n in ("vertex_positions", "to_world_left", "to_world", "to_world_right")] + [(cam, n) for n in ("to_world_left", "to_world", "to_world_right")]
+    # give the factors values other than the identity, so that their order matters
+    for k, m in enumerate(meshes):
+        r = np.eye(4, dtype=np.float32); r[0, 0], r[0, 2], r[2, 0], r[2, 2] = np.cos(0.1 * (k + 1)), np.sin(0.1 * (k + 1)), -np.sin(0.1 * (k + 1)), np.cos(0.1 * (k + 1))
+        m._set("to_world_right", r, np.zeros((4, 4), np.float32))
+        t = np.asarray(m._get("to_world_left", False), np.float32).copy(); t[1, 3] += 2.0 + k
+        m._set("to_world_left", t, np.zeros((4, 4), np.float32))
+    sc._configure_host([0])
+    n_prim = np.asarray(cam._primary_edge_ids()).reshape(-1, 3).shape[0]
+    g_prim = rng.normal(size=(n_prim, 4)).astype(np.float32)
+    got = chain.native_geometry_grads(sc, 0, wanted, g_tri, g_sec, g_prim, g_cam)
+    leaves = {}
+
+    def leaf_of(obj, pname):
+        key = (id(obj), pname)
+        if key in {(id(o), n) for o, n in wanted}:
+            if key not in leaves:
+                leaves[key] = torch.as_tensor(np.asarray(obj._get(pname, False), dtype=np.float64)).clone().requires_grad_(True)
+            return leaves[key]
+        return torch.as_tensor(np.asarray(obj._get(pname, False), dtype=np.float64))
+    tri, sec, prim, refl, rad, cam_tw = chain.snapshot_tensors(sc, 0, leaf_of)
+    outs = [tri, sec, prim, cam_tw]
+    gos = [torch.as_tensor(g_tri, dtype=torch.float64), torch.as_tensor(g_sec, dtype=torch.float64), torch.as_tensor(g_prim, dtype=torch.float64), torch.as_tensor(g_cam)]
+    keys = list(leaves)
+    res = torch.autograd.grad(outs, [leaves[k] for k in keys], gos, allow_unused=True)
+    assert len(keys) == len(wanted)
+    for k, r in zip(keys, res):
+        want = np.zeros_like(got[k]) if r is None else r.numpy().reshape(got[k].shape)
+        scale = max(1.0, float(np.abs(want).max()))
+        assert np.abs(got[k] - want).max() < 1e-9 * scale, (k, np.abs(got[k] - want).max(), scale)
+
+
 def test_host_envmap_configure_matches_oracle(psdr, orc):
     """EnvironmentMap::configure, the bounding cube and the emitter weights (scene.cpp:434-515) on the host"""
     spec = scenes.envmap_scene(32, 32, 4, 4, 4, param="box_x", area_light=True)
