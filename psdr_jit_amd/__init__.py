@@ -283,7 +283,9 @@ class BitmapTransform:
             # ONE roughness map serves both axes here (the kernels look alpha up once, slot 2: shade.h "alpha (both axes)"), so the two names
             # are one transform: uv_transform("alpha_v") IS uv_transform("alpha_u") - reading either shows what was set through the other.
             # (The reference keeps m_rot / m_scale / m_trans per Bitmap, bitmap.h:37-39; two different alpha maps are not representable here.)
+            self.__dict__["_asked"] = "alpha_v"
             name = "alpha_u"
+        self.__dict__.setdefault("_asked", name)
         self.__dict__["_obj"], self.__dict__["_name"] = obj, name
         parts = obj.__dict__.setdefault("_psdr_uv_parts", {})
         if name not in parts:
@@ -303,6 +305,16 @@ class BitmapTransform:
         if key not in ("rotate", "scale", "translate"):
             raise AttributeError("a bitmap transform has rotate, scale and translate")
         parts = self._obj.__dict__["_psdr_uv_parts"][self._name]
+        if self._name == "alpha_u":
+            # the aliased pair: a value set through one name and then changed through the other is the case the reference would keep apart
+            by = parts.setdefault("_set_by", {})
+            differs = not _np.array_equal(_np.asarray(_torch.as_tensor(parts[key]).detach().cpu()), _np.asarray(_torch.as_tensor(value).detach().cpu()))
+            if by.get(key, self._asked) != self._asked and differs:
+                import warnings
+                warnings.warn("uv_transform(%r).%s overrides the value set through uv_transform(%r): alpha_u and alpha_v share ONE roughness map and ONE "
+                              "transform here (the reference keeps a Bitmap per axis)" % (self._asked, key, by[key]), RuntimeWarning, stacklevel=2)
+            if differs or key not in by:
+                by[key] = self._asked
         parts[key] = value
         seq = (parts["rotate"], parts["scale"], parts["translate"])
         if any(isinstance(q, _torch.Tensor) for q in seq):

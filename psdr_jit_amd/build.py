@@ -74,8 +74,8 @@ def _run(cmd):
     return r.stdout
 
 
-N_KERNEL_UNITS = 7      # api.hip's PSDR_TU1..7: the heavy kernel templates of each scene class
-UNIT_CLASS_BIT = {1: 1, 2: 1, 6: 1, 3: 2, 4: 4, 7: 4, 5: 8}      # the PSDR_CLS_MASK bit of the scene class a unit instantiates
+N_KERNEL_UNITS = 8      # api.hip's PSDR_TU1..8: the heavy kernel templates of each scene class
+UNIT_CLASS_BIT = {1: 1, 2: 1, 6: 1, 8: 1, 3: 2, 4: 4, 7: 4, 5: 8}      # the PSDR_CLS_MASK bit of the scene class a unit instantiates
 
 
 def build_hip(force=False, extra_flags=(), target=None):
@@ -152,7 +152,7 @@ def _compile_hip(flags, target, objdir):
     for f in flags:
         if f.startswith("-DPSDR_CLS_MASK="):
             mask = int(f.split("=")[1])
-    units = [("main", API_SRC, ["-DPSDR_SPLIT"], API_DEPS)] + [("tu%d" % k, API_SRC, ["-DPSDR_TU=%d" % k], API_DEPS) for k in (1, 6, 2, 4, 7, 5, 3) if UNIT_CLASS_BIT[k] & mask] + \
+    units = [("main", API_SRC, ["-DPSDR_SPLIT"], API_DEPS)] + [("tu%d" % k, API_SRC, ["-DPSDR_TU=%d" % k], API_DEPS) for k in (1, 6, 8, 2, 4, 7, 5, 3) if UNIT_CLASS_BIT[k] & mask] + \
             [("scene", SCENE_SRC, [], SCENE_DEPS)]
     jobs = max(1, int(os.environ.get("PSDR_BUILD_JOBS", str(min(len(units), os.cpu_count() or 1)))))
     objs, pending, running = [], [], []

@@ -540,7 +540,7 @@ __global__ void k_sampler_floats(unsigned long long seed_value, unsigned long lo
 
 // ------------------------------------------------------------------------------------------------
 // Split build (psdr_jit_amd/build.py): the heavy kernel templates of each scene class are instantiated in translation units of
-// their own - this file compiled with -DPSDR_TU=1..6, kernels only - and compiled in parallel; the main unit (-DPSDR_SPLIT: host
+// their own - this file compiled with -DPSDR_TU=1..8, kernels only - and compiled in parallel; the main unit (-DPSDR_SPLIT: host
 // code + the small kernels) declares those instantiations extern.  Without either macro the file is one self-contained unit
 // (development builds, -DPSDR_CLS_MASK).
 #define PSDR_INST_PATHS(PFX, AD_, C_, CNT_, M_) PFX template __global__ void k_paths<AD_, C_, CNT_, M_>(const float4 *, const SceneTables, const SensorDev, const PathParams, Counters *);
@@ -551,7 +551,8 @@ __global__ void k_sampler_floats(unsigned long long seed_value, unsigned long lo
                                   PSDR_INST_PATHS(PFX, true, C_, true, 0) PSDR_INST_PATHS(PFX, false, C_, true, 0) PSDR_INST_PATHS(PFX, false, C_, true, 1)
 #define PSDR_TU1(PFX) PSDR_INST_PATHS(PFX, true, 0, false, 0) PSDR_INST_PATHS(PFX, false, 0, false, 0) PSDR_INST_PATHS(PFX, false, 0, false, 1)
 #define PSDR_TU6(PFX) PSDR_INST_PATHS(PFX, true, 0, true, 0) PSDR_INST_PATHS(PFX, false, 0, true, 0) PSDR_INST_PATHS(PFX, false, 0, true, 1)
-#define PSDR_TU2(PFX) PSDR_INST_ADJ(PFX, 0) PSDR_INST_ADJM(PFX, 0) PSDR_INST_SEC(PFX, 0, false, false) PSDR_INST_SEC(PFX, 0, true, false) PSDR_INST_SEC(PFX, 0, false, true)
+#define PSDR_TU2(PFX) PSDR_INST_ADJ(PFX, 0) PSDR_INST_SEC(PFX, 0, false, false) PSDR_INST_SEC(PFX, 0, true, false) PSDR_INST_SEC(PFX, 0, false, true)
+#define PSDR_TU8(PFX) PSDR_INST_ADJM(PFX, 0)         // the material sweep, a unit of its own for the same reason as PSDR_TU7: its not-inlined bsdf_back lambda shows the allocator defect
 #define PSDR_TU3(PFX) PSDR_INST_PATHS6(PFX, 1) PSDR_INST_ADJ(PFX, 1) PSDR_INST_SEC(PFX, 1, false, false) PSDR_INST_SEC(PFX, 1, true, false) PSDR_INST_SEC(PFX, 1, false, true)
 #define PSDR_TU4(PFX) PSDR_INST_PATHS6(PFX, 2) PSDR_INST_SEC(PFX, 2, false, false) PSDR_INST_SEC(PFX, 2, true, false) PSDR_INST_SEC(PFX, 2, false, true)
 #define PSDR_TU7(PFX) PSDR_INST_ADJ(PFX, 2)          // a unit of its own: when the ISA lint sends it to the second allocator (build.py), the class-2 path kernels do not pay for it
@@ -571,10 +572,12 @@ PSDR_TU5()
 PSDR_TU6()
 #elif PSDR_TU == 7
 PSDR_TU7()
+#elif PSDR_TU == 8
+PSDR_TU8()
 #endif
 #else
 #if defined(PSDR_SPLIT)
-PSDR_TU1(extern) PSDR_TU2(extern) PSDR_TU3(extern) PSDR_TU4(extern) PSDR_TU5(extern) PSDR_TU6(extern) PSDR_TU7(extern)
+PSDR_TU1(extern) PSDR_TU2(extern) PSDR_TU3(extern) PSDR_TU4(extern) PSDR_TU5(extern) PSDR_TU6(extern) PSDR_TU7(extern) PSDR_TU8(extern)
 #endif
 
 // ------------------------------------------------------------------------------------------------

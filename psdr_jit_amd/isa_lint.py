@@ -97,7 +97,9 @@ def lint_object(path):
         if m and cur is not None:
             cur[2].append((int(m.group(3), 16), m.group(1), m.group(2), m.group(4)))
     for name, base, ins in funcs:
-        if not any(op == "s_endpgm" for _a, op, _g, _t in ins):
+        # kernels end in s_endpgm; a device function the compiler did NOT inline (a large lambda called from several places) returns with
+        # s_setpc_b64 - it is allocated by the same allocator and shows the same defect (round 5: the material sweep's bsdf_back)
+        if not any(op in ("s_endpgm", "s_setpc_b64") for _a, op, _g, _t in ins):
             continue
         targets, skip_targets = set(), set()
         for addr, op, args, tgt in ins:
@@ -105,10 +107,40 @@ def lint_object(path):
                 targets.add(base + int(tgt.rsplit("+0x", 1)[1], 16))
                 if op == "s_cbranch_execz":
                     skip_targets.add(base + int(tgt.rsplit("+0x", 1)[1], 16))
+        # A kernel too long for the 16-bit branch offset has its far branches relaxed into
+        #     s_getpc_b64 s[a:b] ; s_add_u32 sa, sa, imm ; s_addc_u32 sb, sb, hi ; s_setpc_b64 s[a:b]
+        # (target = the address after the s_getpc + imm).  A far `s_cbranch_execz L` becomes `s_cbranch_execnz <over the jump>` + that jump, so the
+        # block behind the s_setpc is a join block exactly like an execz target - and was invisible to the scan without this.
+        far = {}            # index of the s_getpc -> target address
+        for k in range(len(ins) - 3):
+            if ins[k][1] != "s_getpc_b64" or ins[k + 3][1] != "s_setpc_b64":
+                continue
+            pair = ins[k][2].replace(" ", "")
+            lo, hi = ins[k + 1], ins[k + 2]
+            if not (lo[1] in ("s_add_u32", "s_sub_u32") and hi[1] in ("s_addc_u32", "s_subb_u32") and ins[k + 3][2].replace(" ", "") == pair):
+                continue
+            try:
+                imm_lo = int(lo[2].split(",")[2].strip(), 0)
+                imm_hi = int(hi[2].split(",")[2].strip(), 0)
+            except (ValueError, IndexError):
+                continue
+            off = (imm_hi << 32) | (imm_lo & 0xffffffff)
+            if off >= 1 << 63:
+                off -= 1 << 64
+            if lo[1] == "s_sub_u32":
+                off = -off
+            far[k] = ins[k + 1][0] + off
+            targets.add(far[k])
         # ... and the exit of a divergent loop: the block that follows the back edge `s_cbranch_execnz` is entered with exec == 0
         for k, (addr, op, args, tgt) in enumerate(ins[:-1]):
             if op == "s_cbranch_execnz":
-                skip_targets.add(ins[k + 1][0])
+                if (k + 1) in far:
+                    skip_targets.add(far[k + 1])          # the relaxed form of `s_cbranch_execz <far>`
+                else:
+                    skip_targets.add(ins[k + 1][0])
+            elif op == "s_cbranch_execz" and tgt and "+0x" in tgt:
+                # the relaxed back edge of a divergent loop: `s_cbranch_execz <exit>` + far jump to the loop head; <exit> is already a skip target
+                pass
         index = {a: i for i, (a, _o, _g, _t) in enumerate(ins)}
         for t in sorted(skip_targets):
             i = index.get(t)

@@ -505,6 +505,21 @@ def test_first_hit_integrators_sweep_equals_the_probe_form(env, monkeypatch, fam
     assert seen >= 5, family
 
 
+def test_first_hit_sweep_is_the_same_in_every_run(env, monkeypatch):
+    """Round 5: the sweep of the normal-mapped scene returned different adjoints from run to run (4 of 12 800 samples read stale registers: the not-inlined
+    bsdf_back lambda of adjoint_mat.h carried the allocator defect of LABNOTES section 4, and isa_lint.py looked at kernels only).  The persistent waves hand
+    samples to lanes in a different order every launch, so a stale register shows as run-to-run variation: ten launches, each against the probe form"""
+    spec = _FIRST_HIT_SCENES["normalmap"]()
+    for field, intensity in ((6, 1.0), (8, 2e5)):
+        pr = _all_adjoint_buffers(env, spec, 0, monkeypatch, probe=True, field=field, intensity=intensity)
+        for run in range(10):
+            sw = _all_adjoint_buffers(env, spec, 0, monkeypatch, probe=False, field=field, intensity=intensity)
+            for k in sw:
+                ref = np.abs(pr[k]).sum()
+                err = np.abs(sw[k] - pr[k]).sum() / (ref + 1e-12) if ref > 0.0 else np.abs(sw[k]).sum()
+                assert err <= 1e-5, (field, run, k, err)
+
+
 @pytest.mark.parametrize("family,kw", [("cbox", {}), ("cbox_camera", {"with_camera": True}), ("microfacet", {"with_mat": True}), ("conductor", {"with_mat": True}),
                                        ("textured_microfacet", {"with_mat": True}), ("pervertex", {"with_mat": True}), ("normalmap", {"with_mat": True}), ("sphere", {})])
 def test_first_hit_integrators_reverse_mode_against_the_oracle(env, orc, family, kw):

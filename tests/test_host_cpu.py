@@ -645,6 +645,22 @@ def test_roughconductor_constructor_overloads(psdr):
         psdr.RoughConductorBSDF(0.1, 1.5, 2.0, [1.0, 1.0, 1.0])          # scalar eta or alpha_v?
 
 
+def test_alpha_v_transform_is_the_alpha_u_transform_and_says_so(psdr):
+    """ONE roughness map serves both axes here (the reference keeps a Bitmap - and a transform - per axis, bitmap.h:37-39): a transform set through one
+    name and then changed through the other warns; the same value again, or the same name again, does not"""
+    import warnings
+    b = psdr.RoughConductorBSDF(0.1, 0.2, [1.5, 1.6, 1.7], [2.0, 2.1, 2.2], [1.0, 0.9, 0.8])
+    b.uv_transform("alpha_u").rotate = 0.3
+    assert b.uv_transform("alpha_v").rotate == 0.3
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        b.uv_transform("alpha_u").rotate = 0.4          # the same name again
+        b.uv_transform("alpha_v").rotate = 0.4          # the other name, the same value
+    with pytest.warns(RuntimeWarning, match="share ONE roughness map"):
+        b.uv_transform("alpha_v").rotate = 0.5
+    assert b.uv_transform("alpha_u").rotate == 0.5 and np.allclose(np.asarray(b._get_uv_xf(2, False))[0], 0.5)
+
+
 def test_cornell_box_from_coordinates_equals_the_tutorial_files():
     """bench.py and tests/scenes.py build the README scene from examples/synth.py's coordinate lists; they parse to the arrays of
     the Cornell-box files of the reference's tutorials (kept under examples/data for the tutorials' other scenes)"""
