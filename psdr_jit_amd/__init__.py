@@ -1121,8 +1121,10 @@ class _RenderDFn(_torch.autograd.Function):
             g_env = _torch.zeros(int(_np.prod(leaves[uv_leaves[0]][0]._get("radiance", False).shape)), dtype=_torch.float32, device=dev)
         if g_env_scale is not None and g_env is None:        # the scale adjoint is assembled from the texel probes
             g_env = _torch.zeros(int(_np.prod(leaves[env_leaves[0]][0]._get("radiance", False).shape)), dtype=_torch.float32, device=dev)
+        # the boundary terms' adjoints are rows of edges (g_sec / g_prim): nobody reads them unless a mesh or the camera is differentiated
+        bwd_terms = _derivative_terms(st["terms"], leaves, {id(t) for (_o, _n, t), need in zip(leaves, needs) if need}) & 7
         _core._render_d_bwd(integ, scene, st["sensor_id"], seeds, skips, g_img.data_ptr(), ptr[0], ptr[1], ptr[2], ptr[3], ptr[4],
-                            _stream_ptr(), rank, world, st["terms"], mesh_filter.data_ptr(), not want_bsdf, not want_em,
+                            _stream_ptr(), rank, world, bwd_terms, mesh_filter.data_ptr(), not want_bsdf, not want_em,
                             g_tex.data_ptr() if g_tex is not None else 0, g_cam.data_ptr() if g_cam is not None else 0,
                             g_env.data_ptr() if g_env is not None else 0, g_env_scale.data_ptr() if g_env_scale is not None else 0,
                             g_mat.data_ptr() if g_mat is not None else 0, g_env_xf.data_ptr() if g_env_xf is not None else 0,
@@ -1209,6 +1211,24 @@ class _RenderDFn(_torch.autograd.Function):
         return (None,) + tuple(grads)
 
 
+def _moves_edges(obj, name):
+    """Does this leaf reach the boundary terms?  Their integrand is detach(radiance difference) x the normal velocity of the edge point (reference
+    integrator.cpp:179-198, path.cpp:171-294, scene.cpp:1027-1068): the only differentiable factor is the edge's geometry - mesh vertices and transforms, the
+    camera pose - so colours, material constants, bitmaps, radiances and the environment map's texels / scale get exactly zero from both edge terms.  (The
+    map's to_world and the integrators' own parameters are kept on the full path.)"""
+    return isinstance(obj, (Mesh, Sensor)) or isinstance(obj, Integrator) or (isinstance(obj, EnvironmentMap) and name.startswith("to_world"))
+
+
+def _derivative_terms(terms, leaves, moving):
+    """the terms a derivative pass has to LAUNCH for the leaves in `moving` (ids of leaf tensors with a tangent / that need an adjoint): without a leaf that
+    moves an edge the two boundary terms contribute zeros and only their samplers advance (bits 4-6, as in renderD's primal pass) - the images, derivatives
+    and sampler streams are what the full launch gives, bit for bit, at the cost of the interior term alone (BASELINE config 5: a fifth)"""
+    if any(id(t) in moving and _moves_edges(obj, name) for (obj, name, t) in leaves):
+        return terms
+    advance = ((terms >> 4) & 7) or (terms & 7)
+    return (terms & TERM_INTERIOR) | (advance << 4)
+
+
 def _replay_forward(integ, scene, st, tangents):
     """Re-render with the sampler state of the recorded call and the given leaf tangents."""
     _sync_params(scene, tangents, integ)
@@ -1216,7 +1236,7 @@ def _replay_forward(integ, scene, st, tangents):
     after = [scene._sampler_state(k) for k in range(3)]
     for k, s in enumerate(st["samplers"]):
         scene._set_sampler_state(k, *s)
-    _, dimg = _render_d_raw(integ, scene, st["sensor_id"], st["seed"], st["batch_pix"], st["terms"])
+    _, dimg = _render_d_raw(integ, scene, st["sensor_id"], st["seed"], st["batch_pix"], _derivative_terms(st["terms"], st["leaves"], tangents))
     for k, s in enumerate(after):
         scene._set_sampler_state(k, *s)
     return dimg
@@ -1270,7 +1290,7 @@ def _renderD(self, scene, sensor_id=0, seed=-1, batch_pix=-1, terms=TERM_ALL):
             if tangents:
                 _sync_params(scene, tangents, self)
                 scene._configure(state["active"])
-                img, dimg = _render_d_raw(self, scene, sensor_id, seed, batch_pix, terms)
+                img, dimg = _render_d_raw(self, scene, sensor_id, seed, batch_pix, _derivative_terms(terms, leaves, tangents))
                 _sync_params(scene, None, self)
                 scene._configure(state["active"])
                 state["img"], state["dimg"], state["dimg_param"] = img, dimg, weakref.ref(param)

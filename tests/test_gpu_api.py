@@ -149,6 +149,60 @@ def test_albedo_gradient_through_autograd(psdr, orc):
     assert abs(float(refl.grad.sum()) - float(wd.sum())) < 1e-3 * abs(float(wd.sum()))
 
 
+def test_derivative_passes_without_a_geometry_leaf_skip_the_boundary_terms(psdr, monkeypatch):
+    """Both edge terms are detach(radiance difference) x the edge point's normal velocity (integrator.cpp:179-198, path.cpp:171-294): a colour moves no edge, so
+    forward_grad / backward w.r.t. it launch the interior term alone - and return what the full launch returns: derivative image bit for bit, the three sampler
+    streams where a full renderD leaves them, the same gradient.  A mesh transform among the differentiated leaves brings the edge terms back."""
+    import torch
+    sc = _readme_scene(psdr, torch.tensor(0.0))
+    refl = torch.tensor([0.90, 0.20, 0.20], requires_grad=True)
+    sc.param_map["BSDF[id=red]"].reflectance = refl
+    sc.configure([0])
+    integ = psdr.PathTracer(2)
+    launched = []
+    raw = psdr._render_d_raw
+    monkeypatch.setattr(psdr, "_render_d_raw", lambda integrator, scene, sensor_id, seed, batch_pix, terms, distributed=None:
+                        (launched.append(terms), raw(integrator, scene, sensor_id, seed, batch_pix, terms, distributed))[1])
+    start = [sc._sampler_state(k) for k in range(3)]
+    img = integ.renderD(sc, 0)
+    d = psdr.forward_grad(img, refl)
+    assert launched == [0x71, 0x71], launched                 # primal pass, then the replay with the colour's tangent: interior only, all three streams advance
+    after = [sc._sampler_state(k) for k in range(3)]
+    # the full launch from the same stream positions with the same tangent
+    for k, s in enumerate(start):
+        sc._set_sampler_state(k, *s)
+    img_full, d_full = psdr.render_d_fwd(integ, sc, 0, tangents={refl: np.ones(3, np.float32)})
+    assert launched[-1] == 7
+    assert [sc._sampler_state(k) for k in range(3)] == after
+    assert torch.equal(img.detach(), img_full) and torch.equal(d, d_full) and float(d.abs().sum()) > 0
+    psdr._sync_params(sc, None, integ)
+    sc.configure([0])
+    # ... a mesh translation does move edges
+    P = torch.tensor(0.0, requires_grad=True)
+    sc2 = _readme_scene(psdr, P)
+    dP = psdr.forward_grad(integ.renderD(sc2, 0), P)
+    assert launched[-1] == 7 and float(dP.abs().sum()) > 0
+    # reverse mode: the colour's gradient with and without the edge kernels
+    bwd = psdr._core._render_d_bwd
+    terms_seen = []
+    monkeypatch.setattr(psdr._core, "_render_d_bwd", lambda *a: (terms_seen.append(a[14]), bwd(*a))[1])
+    grads = []
+    for full in (False, True):
+        if full:
+            monkeypatch.setattr(psdr, "_derivative_terms", lambda terms, leaves, moving: terms)
+        img = integ.renderD(sc, 0, seed=11)
+        w = torch.linspace(0.5, 1.5, img.numel(), device=img.device).reshape(img.shape)
+        (g,) = torch.autograd.grad((img * w).sum(), refl)
+        grads.append(g.double())
+    assert terms_seen == [1, 7], terms_seen
+    assert float((grads[0] - grads[1]).abs().max()) <= 1e-5 * float(grads[1].abs().max()) and float(grads[1].abs().max()) > 0
+    monkeypatch.undo()
+    terms_seen = []
+    monkeypatch.setattr(psdr._core, "_render_d_bwd", lambda *a: (terms_seen.append(a[14]), bwd(*a))[1])
+    integ.renderD(sc2, 0, seed=11).sum().backward()
+    assert terms_seen == [7] and P.grad is not None
+
+
 def test_vertex_and_transform_gradients_reverse_matches_forward(psdr):
     """loss.backward() through the adjoint kernels + host chain == <w, forward derivative> for vertex positions
     (a many-parameter leaf only reverse mode can handle) and for the mesh transform."""
