@@ -230,8 +230,9 @@ def main():
     buf = torch.empty((2, npx, 3), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
-    def launch(seed, terms=7, shard_rank=rank, shard_count=world, zero=True, out=buf):
-        a = cabi.make_args(max_depth=DEPTH, seeds=(seed, seed, seed), terms=terms, shard_rank=shard_rank, shard_count=shard_count, zero_output=zero, guiding=guiding)
+    def launch(seed, terms=7, shard_rank=rank, shard_count=world, zero=True, out=buf, skip_static=False):
+        a = cabi.make_args(max_depth=DEPTH, seeds=(seed, seed, seed), terms=terms, shard_rank=shard_rank, shard_count=shard_count, zero_output=zero, guiding=guiding,
+                           skip_static_edges=skip_static)
         cabi.check(L.psdr_hip_render_d_fwd(handle, C.byref(a), out[0].data_ptr(), out[1].data_ptr(), stream))
 
     single_collective = os.environ.get("PSDR_SINGLE_COLLECTIVE", "0") == "1"
@@ -325,6 +326,19 @@ def main():
 
     if breakdown is not None:
         out["scale_breakdown"] = breakdown
+    if n == 1:
+        # psdr_render_args.skip_static_edges (ABI 14), what the Python surface asks for: a primary-edge sample on an edge that does not move under the installed tangent
+        # adds exactly zero to the derivative image and is not traced - the same numbers reach the image and the derivative (tests/test_gpu_configs.py).  The headline above traces
+        # every sample, as the reference does and as rounds 1-4 did.
+        launch(2000, skip_static=True)
+        sync()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            launch(i, skip_static=True)
+        sync()
+        dt1 = time.perf_counter() - t1
+        out["static_edges_skipped"] = {"ms_per_step": round(dt1 / args.steps * 1e3, 4), "value": round(samples_per_step / (dt1 / args.steps) / 1e6, 3),
+                                       "note": "the same workload with psdr_render_args.skip_static_edges = 1: identical outputs, the primary-edge samples with a zero edge velocity not traced"}
     try:        # the live-pixel mask of the timed scene (psdr_hip_scene_live_pixels): which part of the frame the interior term passes over
         n_live = C.c_int64(0)
         cabi.check(cabi.lib().psdr_hip_scene_live_pixels(C.c_void_p(handle), 0, None, C.byref(n_live)))

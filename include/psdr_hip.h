@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PSDR_HIP_ABI_VERSION 13
+#define PSDR_HIP_ABI_VERSION 14
 
 /* TriangleInfo SoA, reference include/psdr/types.h:162-175 (+ Scene::m_triangle_uv,
  * m_triangle_face_normals, scene.cpp:528-542).  Arrays of n_triangles rows. */
@@ -203,6 +203,10 @@ typedef struct psdr_render_args {
                                      7 segmentation; f = 8: CollocatedIntegrator(intensity) (src/integrator/collocated.cpp) */
     int32_t field_object;         /* mesh index the field is restricted to (field.cpp:59-66), -1 = all; only read when field_mode > 0 */
     float intensity, d_intensity; /* CollocatedIntegrator::m_intensity and its forward tangent */
+    int32_t skip_static_edges;    /* psdr_hip_render_d_fwd, primary-edge term: 1 = a sample whose edge point has a zero normal velocity under the installed
+                                     tangents (an edge of a mesh that does not move, a camera that does not move) is not traced - its contribution to out_drgb is
+                                     d(x.n) x (Ln - Lp) / pdf = exactly 0 (integrator.cpp:179-198), so the same numbers are added to the derivative image; 0 = every sample's
+                                     two paths are traced, as the reference does */
 } psdr_render_args;
 
 /* counters of the instrumented build: filled by psdr_hip_render_*_counted */
@@ -336,6 +340,9 @@ typedef struct psdr_grads {
      * lookup only for a buffer that is wanted).  The edge terms do not see the transforms (their values are
      * detached, src/integrator/integrator.cpp:179-198, path.cpp:171-270). */
     float *g_uv_xf;
+    /* primary-edge term: DEVICE [n_primary_edges(sensor)], 1 = the row of g_prim_edges is wanted; an edge sample of an unwanted row is not traced (its
+     * whole contribution is that row).  NULL = all rows.  (A caller that differentiates one mesh and not the camera wants the rows of that mesh's edges.) */
+    const uint8_t *prim_edge_filter;
 } psdr_grads;
 /* offsets[3*n_bsdfs] (HOST): float offset of the texel block of BSDF b's bitmap k (0 reflectance / diffuse reflectance rgb,
  * 1 specular reflectance rgb, 2 roughness; RoughConductor: eta, k, alpha; NormalMap: the map; MicrofacetPerVertex: the per-vertex

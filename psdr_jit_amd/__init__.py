@@ -1123,13 +1123,19 @@ class _RenderDFn(_torch.autograd.Function):
             g_env = _torch.zeros(int(_np.prod(leaves[env_leaves[0]][0]._get("radiance", False).shape)), dtype=_torch.float32, device=dev)
         # the boundary terms' adjoints are rows of edges (g_sec / g_prim): nobody reads them unless a mesh or the camera is differentiated
         bwd_terms = _derivative_terms(st["terms"], leaves, {id(t) for (_o, _n, t), need in zip(leaves, needs) if need}) & 7
+        # ... and the primary-edge samples add to the row of THEIR edge only: with some meshes differentiated and the camera (and the integrator) not, the samples
+        # on the other meshes' edges are not traced (psdr_grads.prim_edge_filter)
+        prim_filter = None
+        if (bwd_terms & TERM_PRIMARY) and n_prim > 0 and not any(need and not isinstance(obj, Mesh) and _moves_edges(obj, name) for (obj, name, t), need in zip(leaves, needs)):
+            edge_mesh = _np.asarray(cam._primary_edge_ids(), dtype=_np.int64).reshape(-1, 3)[:, 0]
+            prim_filter = _torch.from_numpy(_np.ascontiguousarray(want_mesh[edge_mesh])).to(dev)
         _core._render_d_bwd(integ, scene, st["sensor_id"], seeds, skips, g_img.data_ptr(), ptr[0], ptr[1], ptr[2], ptr[3], ptr[4],
                             _stream_ptr(), rank, world, bwd_terms, mesh_filter.data_ptr(), not want_bsdf, not want_em,
                             g_tex.data_ptr() if g_tex is not None else 0, g_cam.data_ptr() if g_cam is not None else 0,
                             g_env.data_ptr() if g_env is not None else 0, g_env_scale.data_ptr() if g_env_scale is not None else 0,
                             g_mat.data_ptr() if g_mat is not None else 0, g_env_xf.data_ptr() if g_env_xf is not None else 0,
                             bpix.data_ptr() if bpix is not None else 0, int(bpix.numel()) if bpix is not None else 0,
-                            g_uv.data_ptr() if g_uv is not None else 0)
+                            g_uv.data_ptr() if g_uv is not None else 0, prim_filter.data_ptr() if prim_filter is not None else 0)
         _all_reduce(flat, world > 1)
         for extra in (g_env, g_env_scale, g_mat, g_env_xf, g_uv):
             if extra is not None:

@@ -22,13 +22,14 @@ class RenderArgs(C.Structure):
     _fields_ = [("sensor_id", C.c_int32), ("max_depth", C.c_int32), ("hide_emitters", C.c_int32),
                 ("samplers", Sampler * 3), ("pix_ids", C.c_void_p), ("n_pix", C.c_int32), ("terms", C.c_int32),
                 ("shard_rank", C.c_int32), ("shard_count", C.c_int32), ("guiding", C.c_void_p), ("zero_output", C.c_int32), ("direct_mode", C.c_int32),
-                ("field_mode", C.c_int32), ("field_object", C.c_int32), ("intensity", C.c_float), ("d_intensity", C.c_float)]
+                ("field_mode", C.c_int32), ("field_object", C.c_int32), ("intensity", C.c_float), ("d_intensity", C.c_float), ("skip_static_edges", C.c_int32)]
 
 
 class Grads(C.Structure):
     _fields_ = [("g_triangles", C.c_void_p), ("g_bsdf", C.c_void_p), ("g_emitter", C.c_void_p), ("g_sec_edges", C.c_void_p),
                 ("g_prim_edges", C.c_void_p), ("mesh_filter", C.c_void_p), ("skip_bsdf", C.c_int32), ("skip_emitter", C.c_int32),
-                ("g_tex", C.c_void_p), ("g_camera", C.c_void_p), ("g_env", C.c_void_p), ("g_env_scale", C.c_void_p), ("g_mat", C.c_void_p), ("g_env_from_world", C.c_void_p), ("g_uv_xf", C.c_void_p)]
+                ("g_tex", C.c_void_p), ("g_camera", C.c_void_p), ("g_env", C.c_void_p), ("g_env_scale", C.c_void_p), ("g_mat", C.c_void_p), ("g_env_from_world", C.c_void_p), ("g_uv_xf", C.c_void_p),
+                ("prim_edge_filter", C.c_void_p)]
 
 
 class Counters(C.Structure):
@@ -77,7 +78,8 @@ def check(rc):
 
 
 def make_args(sensor_id=0, max_depth=1, hide_emitters=False, seeds=(0, 0, 0), skips=(0, 0, 0), pix_ids_ptr=0, n_pix=0,
-              terms=7, shard_rank=0, shard_count=1, guiding=None, zero_output=True, direct_mis=-1, field=-1, field_object=-1, intensity=1.0, d_intensity=0.0):
+              terms=7, shard_rank=0, shard_count=1, guiding=None, zero_output=True, direct_mis=-1, field=-1, field_object=-1, intensity=1.0, d_intensity=0.0,
+              skip_static_edges=False):
     a = RenderArgs()
     a.sensor_id, a.max_depth, a.hide_emitters = sensor_id, max_depth, int(hide_emitters)
     for k in range(3):
@@ -86,4 +88,5 @@ def make_args(sensor_id=0, max_depth=1, hide_emitters=False, seeds=(0, 0, 0), sk
     a.shard_rank, a.shard_count, a.guiding, a.zero_output = shard_rank, shard_count, guiding, int(zero_output)
     a.direct_mode = int(direct_mis) + 1
     a.field_mode, a.field_object, a.intensity, a.d_intensity = int(field) + 1, int(field_object), float(intensity), float(d_intensity)
+    a.skip_static_edges = int(skip_static_edges)
     return a

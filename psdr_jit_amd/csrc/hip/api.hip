@@ -750,6 +750,7 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
             PathParams P{};
             P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[1].seed; P.skip = skip_ahead(a->samplers[1].skip);
             P.begin = 0; P.end = npx * T.sppe; P.shard_rank = rank; P.shard_count = count; P.dout = dout;
+            P.skip_static = a->skip_static_edges;
             P.n_local = local_lanes(P.end, rank, count);
             if (P.n_local > 0) {
                 if (fork) P.counter = q_prim; else if (next_queue(P.counter)) return 1;
@@ -976,6 +977,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[1].seed; P.skip = skip_ahead(a->samplers[1].skip);
         P.begin = 0; P.end = npx_full * T.sppe; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
         P.adj_w = d_rgb; P.g_prim = g->g_prim_edges; P.n_prim = cam.n_edges; P.lds_acc = (cam.n_edges <= 2048) ? 1 : 0;
+        P.prim_filter = g->prim_edge_filter;
         if (P.n_local > 0) {
             if (next_queue(P.counter)) return 1;
             const int grid = grid_for(sc, P.n_local);

@@ -44,7 +44,16 @@ struct PathParams {
     int n_hot;                       // rows kept in LDS (9 floats each: p0, e1, e2), 0 = none
     int field, field_object;         // >= 0: first-hit integrator (shade.h first_hit_value), max_depth = 0
     float intensity, d_intensity;
+    // primary-edge samples that cannot contribute are not traced: forward mode - the edge point's normal velocity is zero (psdr_render_args.skip_static_edges);
+    // reverse mode - the row of g_prim the sample would add to is not wanted (psdr_grads.prim_edge_filter)
+    int skip_static;
+    const unsigned char *prim_filter;
 };
+
+// (x_dot_n.d == 0: the sample's d_out is 0 x (Ln - Lp) / pdf - zero, or a NaN that the accumulation drops)
+PSDR_DEV bool edge_sample_idle(const PathParams &P, int ei, float xdn_d) {
+    return P.adj_w == nullptr ? (P.skip_static != 0 && xdn_d == 0.f) : (P.prim_filter != nullptr && P.prim_filter[ei] == 0);
+}
 
 #ifndef PSDR_FETCH_BATCH
 #define PSDR_FETCH_BATCH 256
@@ -202,7 +211,7 @@ PSDR_DEV void run_paths(SceneView<LDS> &S, const SensorDev &cam, const PathParam
                         const Dual px = fma_(p0x, oms, p1x * s), py = fma_(p0y, oms, p1y * s);
                         const Dual x_dot_n = fma_(py, ny, px * nx);
                         const int ix = (int) floorf(px.v * (float) T.width), iy = (int) floorf(py.v * (float) T.height);
-                        const bool edge_valid = ix >= 0 && ix < T.width && iy >= 0 && iy < T.height;
+                        const bool edge_valid = ix >= 0 && ix < T.width && iy >= 0 && iy < T.height && !edge_sample_idle(P, ei, x_dot_n.d);
                         park_i(kPix, edge_valid ? iy * T.width + ix : -1);
                         const RayT<false> ray_p = sample_primary_ray<false>(cam, px.v + kEdgeEpsilon * nx, py.v + kEdgeEpsilon * ny);
                         const RayT<false> ray_n = sample_primary_ray<false>(cam, px.v - kEdgeEpsilon * nx, py.v - kEdgeEpsilon * ny);
@@ -657,7 +666,7 @@ PSDR_DEV void run_paths_async(SceneView<LDS> &S, const SensorDev &cam, const Pat
                             const Dual px = fma_(p0x, oms, p1x * s), py = fma_(p0y, oms, p1y * s);
                             const Dual x_dot_n = fma_(py, ny, px * nx);
                             const int ix = (int) floorf(px.v * (float) T.width), iy = (int) floorf(py.v * (float) T.height);
-                            edge_valid = ix >= 0 && ix < T.width && iy >= 0 && iy < T.height;
+                            edge_valid = ix >= 0 && ix < T.width && iy >= 0 && iy < T.height && !edge_sample_idle(P, ei, x_dot_n.d);
                             pix_slot = edge_valid ? iy * T.width + ix : -1;
                             const RayT<false> ray_n = sample_primary_ray<false>(cam, px.v - kEdgeEpsilon * nx, py.v - kEdgeEpsilon * ny);
                             if constexpr (!AD) ext = ray_n;

@@ -490,11 +490,12 @@ PYBIND11_MODULE(_psdr_core, m) {
         .def("_renderC", &Integrator::renderC, "scene"_a, "sensor_id"_a, "seed"_a, "pix_ids"_a, "n_pix"_a, "out"_a, "stream"_a, "shard_rank"_a, "shard_count"_a,
              py::call_guard<py::gil_scoped_release>())
         .def("_renderD", &Integrator::renderD, "scene"_a, "sensor_id"_a, "seed"_a, "pix_ids"_a, "n_pix"_a, "out"_a, "dout"_a, "stream"_a, "shard_rank"_a,
-             "shard_count"_a, "terms"_a, py::call_guard<py::gil_scoped_release>());
+             "shard_count"_a, "terms"_a, py::call_guard<py::gil_scoped_release>())
+        .def_readwrite("trace_static_edges", &Integrator::m_trace_static_edges);
 
     m.def("_render_d_bwd", [](const Integrator &it, const Scene &scene, int sensor_id, const std::vector<uint64_t> &seeds, const std::vector<uint64_t> &skips,
                               uintptr_t d_rgb, uintptr_t g_tri, uintptr_t g_bsdf, uintptr_t g_emitter, uintptr_t g_sec, uintptr_t g_prim, uintptr_t stream,
-                              int rank, int count, int terms, uintptr_t mesh_filter, bool skip_bsdf, bool skip_emitter, uintptr_t g_tex, uintptr_t g_cam, uintptr_t g_env, uintptr_t g_env_scale, uintptr_t g_mat, uintptr_t g_env_xf, uintptr_t pix_ids, int n_pix, uintptr_t g_uv_xf) {
+                              int rank, int count, int terms, uintptr_t mesh_filter, bool skip_bsdf, bool skip_emitter, uintptr_t g_tex, uintptr_t g_cam, uintptr_t g_env, uintptr_t g_env_scale, uintptr_t g_mat, uintptr_t g_env_xf, uintptr_t pix_ids, int n_pix, uintptr_t g_uv_xf, uintptr_t prim_filter) {
         if (!scene.is_ready()) throw Exception("Input scene must be configured!");
         psdr_render_args a;
         std::memset(&a, 0, sizeof(a));
@@ -507,7 +508,8 @@ PYBIND11_MODULE(_psdr_core, m) {
         psdr_grads g{reinterpret_cast<float *>(g_tri), reinterpret_cast<float *>(g_bsdf), reinterpret_cast<float *>(g_emitter),
                      reinterpret_cast<float *>(g_sec), reinterpret_cast<float *>(g_prim),
                      reinterpret_cast<const uint8_t *>(mesh_filter), skip_bsdf ? 1 : 0, skip_emitter ? 1 : 0, reinterpret_cast<float *>(g_tex), reinterpret_cast<float *>(g_cam),
-                     reinterpret_cast<float *>(g_env), reinterpret_cast<float *>(g_env_scale), reinterpret_cast<float *>(g_mat), reinterpret_cast<float *>(g_env_xf), reinterpret_cast<float *>(g_uv_xf)};
+                     reinterpret_cast<float *>(g_env), reinterpret_cast<float *>(g_env_scale), reinterpret_cast<float *>(g_mat), reinterpret_cast<float *>(g_env_xf), reinterpret_cast<float *>(g_uv_xf),
+                     reinterpret_cast<const uint8_t *>(prim_filter)};
         if (psdr_hip_render_d_bwd(scene.m_hip, &a, reinterpret_cast<const float *>(d_rgb), &g, reinterpret_cast<void *>(stream)))
             throw Exception(std::string("libpsdr_hip: ") + psdr_hip_last_error());
     });

@@ -358,6 +358,9 @@ struct Integrator : Object {
     virtual std::string field_object() const { return ""; }
     virtual float intensity(bool tangent) const { return tangent ? 0.f : 1.f; }
     int draws_per_level() const { const int m = direct_mis(); return m == 0 ? 2 : (m == 1 ? 3 : 5); }
+    // renderD, primary-edge term: false (default) = an edge sample whose edge point does not move under the installed tangents is not traced - it adds exactly
+    // zero to the derivative image (psdr_render_args.skip_static_edges); true = every sample's two paths are traced, as the reference does
+    bool m_trace_static_edges = false;
 };
 
 struct PathTracer : Integrator {

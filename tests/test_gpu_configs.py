@@ -62,6 +62,54 @@ def test_config3_depth3_small_per_term(env, orc, param):
             assert np.abs(got[1]).max() == 0.0
 
 
+@pytest.mark.parametrize("scene", ["cbox_lds", "sphere_bvh"])
+def test_primary_edge_samples_that_cannot_contribute_are_not_traced(env, scene):
+    """psdr_render_args.skip_static_edges (forward mode) and psdr_grads.prim_edge_filter (reverse mode), ABI 14: a primary-edge sample adds d(x.n) (Ln - Lp) / pdf to
+    the derivative image and to ONE row of g_prim_edges (integrator.cpp:179-198).  With a zero normal velocity of the edge point the first is exactly zero, with an
+    unwanted row nobody reads the second - such a sample's two paths are not traced: the same numbers are added to the derivative image by fewer rays, the wanted rows
+    are unchanged"""
+    torch, _, cabi = env
+    spec = scenes.cbox_scene(64, 64, 8, 8, 8, param="light_x") if scene == "cbox_lds" else scenes.sphere_scene(64, 64, 8, 8, 8)
+    sc = product.build_scene(spec)
+    cam = sc.param_map["Sensor[0]"]
+    d_prim = np.asarray(cam._primary_edges(True), np.float64)[:, :4]
+    moving = np.abs(d_prim).sum(axis=1) > 0
+    assert 0 < moving.sum() < moving.size, (moving.sum(), moving.size)        # some edges move, most do not
+    n, depth, seeds = 64 * 64, 3, (41, 42, 43)
+    imgs, rays = [], []
+    for skip in (False, True):
+        buf = torch.empty((2, n, 3), dtype=torch.float32, device="cuda")
+        a = cabi.make_args(max_depth=depth, seeds=seeds, terms=2, skip_static_edges=skip)
+        c = cabi.Counters()
+        cabi.check(cabi.lib().psdr_hip_render_d_fwd_counted(sc._hip_handle(), C.byref(a), buf[0].data_ptr(), buf[1].data_ptr(), C.byref(c), None))
+        imgs.append(buf.cpu().numpy()); rays.append(int(c.rays))
+    # (the same samples add the same numbers to a pixel; only the order of the float atomics differs from launch to launch)
+    assert np.abs(imgs[0][1]).max() > 0 and np.abs(imgs[0][1] - imgs[1][1]).max() <= 2e-6 * np.abs(imgs[0][1]).max() and np.abs(imgs[1][0]).max() == 0.0
+    assert rays[1] < 0.8 * rays[0], rays
+    # reverse mode: only the rows of the moving edges are wanted
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    w = (torch.rand((n, 3), generator=gen) + 0.5).to("cuda")
+    snap = sc._snapshot()
+    n_tris, n_sec = np.asarray(snap["d_triangles"]).shape[0], np.asarray(snap["d_sec_edges"]).shape[0]
+    rows = []
+    for filt in (None, torch.from_numpy(moving.astype(np.uint8)).to("cuda")):
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device="cuda")
+        g_tri, g_bsdf, g_em, g_sec, g_prim = z(n_tris, 22), z(max(1, len(spec.bsdfs)), 3), z(max(1, len(spec.emitters)), 3), z(max(1, n_sec), 6), z(moving.size, 4)
+        g = cabi.Grads(g_tri.data_ptr(), g_bsdf.data_ptr(), g_em.data_ptr(), g_sec.data_ptr(), g_prim.data_ptr())
+        if filt is not None:
+            g.prim_edge_filter = filt.data_ptr()
+        a = cabi.make_args(max_depth=depth, seeds=seeds, terms=2)
+        cabi.check(cabi.lib().psdr_hip_render_d_bwd(sc._hip_handle(), C.byref(a), w.data_ptr(), C.byref(g), None))
+        torch.cuda.synchronize()
+        rows.append(g_prim.cpu().numpy().astype(np.float64))
+    assert np.abs(rows[0][~moving]).max() > 0 and np.abs(rows[1][~moving]).max() == 0.0
+    assert np.abs(rows[1][moving] - rows[0][moving]).max() <= 1e-5 * np.abs(rows[0][moving]).max()
+    # <w, J v> = <J^T w, v> with the filtered rows: the unwanted rows meet zero tangents
+    lhs = float((imgs[1][1].astype(np.float64) * w.cpu().numpy().astype(np.float64)).sum())
+    rhs = float((rows[1] * d_prim).sum())
+    assert abs(lhs - rhs) <= 2e-4 * max(abs(lhs), 1e-12), (lhs, rhs)
+
+
 def _oracle_pinned_backward(env, orc_mod, sc, spec, ref, depth, seeds, rank, count, guiding=None, guiding_ref=None, tol=TOL):
     """reverse mode against the ORACLE on one shard, per term:  <w, d_img>  with d_img from the oracle's forward-mode render_d  ==  <J^T w, v>  with J^T w the buffers of
     psdr_hip_render_d_bwd on the same lanes and seeds and v the configured snapshot's tangent rows - no HIP forward kernel takes part"""
