@@ -493,8 +493,8 @@ def main():
         h5 = sc5._hip_handle()
         buf5 = torch.empty((2, c5["res"] * c5["res"], 3), dtype=torch.float32, device="cuda")
 
-        def launch5(seed, terms=7, zero=True):
-            a = cabi.make_args(max_depth=DEPTH, seeds=(seed, seed, seed), terms=terms, zero_output=zero, guiding=gd5)
+        def launch5(seed, terms=7, zero=True, skip_static=False):
+            a = cabi.make_args(max_depth=DEPTH, seeds=(seed, seed, seed), terms=terms, zero_output=zero, guiding=gd5, skip_static_edges=skip_static)
             cabi.check(L.psdr_hip_render_d_fwd(h5, C.byref(a), buf5[0].data_ptr(), buf5[1].data_ptr(), stream))
         launch5(1000)
         torch.cuda.synchronize()
@@ -511,6 +511,15 @@ def main():
             "ms_per_step": round(t5 * 1e3, 3), "value": round(c5["res"] * c5["res"] * c5["spp"] / t5 / 1e6, 2), "unit": "Msamples/s", "steps": steps5,
             "guiding_build_ms": round(t_g * 1e3, 2), "finite": bool(torch.isfinite(buf5).all()), "roofline": r5,
         }
+        # (the parameter of BASELINE config 5 is a colour: no edge moves, so with psdr_render_args.skip_static_edges the primary-edge term traces nothing)
+        launch5(2000, skip_static=True)
+        torch.cuda.synchronize()
+        t5s = time.perf_counter()
+        for i in range(steps5):
+            launch5(i, skip_static=True)
+        torch.cuda.synchronize()
+        t5s = (time.perf_counter() - t5s) / steps5
+        out["config5"]["static_edges_skipped"] = {"ms_per_step": round(t5s * 1e3, 3), "value": round(c5["res"] * c5["res"] * c5["spp"] / t5s / 1e6, 2)}
         if not args.no_backward:
             out["config5"]["backward"] = backward_leg(sc5, h5, gd5, c5["res"] * c5["res"], 2)
         if not args.no_api:
