@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="override the configuration's sample counts (measurement aid; the line names it)")
     ap.add_argument("--no-backward", action="store_true")
     ap.add_argument("--no-config5", action="store_true")
+    ap.add_argument("--no-static-skip", action="store_true", help="leave out the extra run with psdr_render_args.skip_static_edges (profiling passes: one kind of launch per kernel)")
     ap.add_argument("--no-api", action="store_true", help="skip the legs through the public Python surface (api_call_ms, configure_ms, step_ms)")
     ap.add_argument("--weak", action="store_true", help="N > 1: config 3 with spp = 32 * N (weak scaling)")
     ap.add_argument("--cpu-shard", type=int, default=0, help="the CPU baseline renders every k-th 256-lane chunk (0 = calibrate)")
@@ -223,6 +224,7 @@ def main():
         leaf = sc.param_map["Mesh[0]"].to_world_left
         d_leaf = np.zeros((4, 4), np.float32)
         d_leaf[0, 3] = 100.0
+    integ.trace_static_edges = True                   # (the untimed call that installs the tangent traces what the timed C-ABI launches trace)
     psdr.render_d_fwd(integ, sc, 0, seed=12345, tangents={leaf: d_leaf})
     handle = sc._hip_handle()
     L = cabi.lib()
@@ -326,7 +328,7 @@ def main():
 
     if breakdown is not None:
         out["scale_breakdown"] = breakdown
-    if n == 1:
+    if n == 1 and not args.no_static_skip:
         # psdr_render_args.skip_static_edges (ABI 14), what the Python surface asks for: a primary-edge sample on an edge that does not move under the installed tangent
         # adds exactly zero to the derivative image and is not traced - the same numbers reach the image and the derivative (tests/test_gpu_configs.py).  The headline above traces
         # every sample, as the reference does and as rounds 1-4 did.
@@ -489,6 +491,7 @@ def main():
         torch.cuda.synchronize()
         t_g = time.perf_counter() - t_g
         gd5 = integ5._guiding_handle(0) or None
+        integ5.trace_static_edges = True
         psdr.render_d_fwd(integ5, sc5, 0, seed=12345, tangents={leaf5: np.ones(3, np.float32)})
         h5 = sc5._hip_handle()
         buf5 = torch.empty((2, c5["res"] * c5["res"], 3), dtype=torch.float32, device="cuda")

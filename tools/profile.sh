@@ -12,7 +12,7 @@ set -u
 REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
-BENCH="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-parity --no-backward --no-config5 --no-api"
+BENCH="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-parity --no-backward --no-config5 --no-api --no-static-skip"
 cd /tmp && export TMPDIR=/tmp
 python $REPO/bench.py > $OUT/bench_line.json 2> $OUT/bench_err.log
 rm -rf $OUT/prof_kt $OUT/prof_fetch $OUT/prof_write $OUT/prof_l2 $OUT/prof_sq $OUT/prof_sq2
@@ -24,9 +24,10 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SME
 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA -d $OUT/prof_sq2 -- $BENCH > $OUT/prof_sq2.log 2>&1
 cd $REPO
 bash tools/profile_cmd.sh bwd python tools/bwd_only.py c3 5
-bash tools/profile_cmd.sh c5 python bench.py --config 5 --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-backward --no-roofline --no-api
+bash tools/profile_cmd.sh c5 python bench.py --config 5 --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-backward --no-roofline --no-api --no-static-skip
 bash tools/profile_cmd.sh c5bwd python tools/bwd_only.py c5 2 1024 64
 bash tools/profile_cmd.sh sph python tools/bench_scene.py sphere
+python tools/bench_scene.py sphere --skip > $OUT/sphere_skip.log 2>&1
 # the databases travel back through gpurun_out (64 MiB): keep the *_results.db files only
 find $OUT -name "*.csv" -size +2M -delete 2> /dev/null
 tail -1 $OUT/bench_line.json | cut -c1-400
