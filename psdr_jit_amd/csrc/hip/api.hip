@@ -661,7 +661,13 @@ static inline int grid_for(const psdr_hip_scene *sc, long long n) {
 // counted runs, ray batches, field integrators on Microfacet / bitmap boxes) must not reserve the blob's bytes it never fills
 static size_t smem_for(const psdr_hip_scene *sc, int cls) {
     const size_t blob = (sc->lds || sc->lds_mat) ? (size_t) sc->T.blob_words * 16 : 0;
+#ifdef PSDR_DEV_KNOBS
+    // (measurement: PSDR_PAD_LDS=bytes asks for more LDS per workgroup than the kernels use - fewer workgroups per CU, to see what occupancy is worth)
+    static const size_t pad = std::getenv("PSDR_PAD_LDS") ? (size_t) std::atoll(std::getenv("PSDR_PAD_LDS")) : 0;
+    return ((cls == 1 || cls == 3) ? sc->smem_bytes : sc->smem_bytes - blob) + pad;
+#else
     return (cls == 1 || cls == 3) ? sc->smem_bytes : sc->smem_bytes - blob;
+#endif
 }
 #define LAUNCH(cls_, kernel, sc, n_lanes, stream, ...) \
     hipLaunchKernelGGL(kernel, dim3(grid_for(sc, n_lanes)), dim3(kBlock), smem_for(sc, cls_), (hipStream_t) (stream), __VA_ARGS__)

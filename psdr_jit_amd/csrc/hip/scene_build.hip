@@ -292,7 +292,14 @@ static int scene_sync(psdr_hip_scene *sc, const psdr_scene_snapshot *s, unsigned
     for (int i = 0; i < s->n_emitters; ++i) if (s->emitters[i].type == 1) T.env_emitter = i;
     // traversal stack: the first kStackLds entries of a lane in LDS, deeper ones in a per-lane global array (trav4.h);
     // scenes that are traced by brute force (<= kBruteForceMax triangles) need neither
-    constexpr int kStackLds = 8;                                      // 8 + kTravRows = 40 KB per workgroup: four workgroups per CU
+#ifdef PSDR_DEV_KNOBS
+    const int kStackLds = std::getenv("PSDR_STACK_LDS") ? std::atoi(std::getenv("PSDR_STACK_LDS")) : 8;      // (measurement: what the global tail of the stack costs)
+#else
+    // 8 + kTravRows = 40 KB per workgroup: four workgroups per CU.  Round 5 measured both sides of that choice on config 5 (LABNOTES): FEWER workgroups cost a lot
+    // (3 per CU: +17 %, 2: +55 %), a FIFTH brings nothing (a 30 KB layout - no hit rows, 4 stack rows - lost exactly what its shorter stack costs at equal
+    // occupancy), and stack rows going to the global tail cost 1.2 % (6 rows), 6.8 % (4), 9.5 % (2)
+    constexpr int kStackLds = 8;
+#endif
     T.stack_lds = uses_bvh ? std::min(kStackLds, sc->tree_max_stack) : 0;
     T.stack_depth = uses_bvh ? T.stack_lds + kTravRows : kColdRows;   // BVH: + parked rays, best hits and the pair ring of the traversal (trav4.h); brute force: cold path state (paths.h)
 
