@@ -68,7 +68,8 @@ struct AdjointParams {
 };
 
 constexpr int kMatOut = 16;         // a BSDF's row of psdr_grads.g_mat
-constexpr int kMatRow = 28;         // ... and of its LDS accumulator: the g_mat row, then [rot, scale, tx, ty] of its three bitmaps (g_uv_xf)
+constexpr int kMatRow = 28;         // ... and of its LDS accumulator when uv transforms are differentiated: the g_mat row, then [rot, scale, tx, ty] of its three bitmaps (g_uv_xf);
+                                    // without g_uv_xf the accumulator's row is the g_mat row alone (`mrow` in the kernels, api.hip::adj LDS sizes)
 constexpr int kAdjMisc = 32;        // LDS accumulators every path adds to: camera pose, environment scale and transform
 // number of constant material parameters a BSDF record's flags announce (Microfacet 4 - fewer with maps -, RoughConductor 11, RoughDielectric 3)
 PSDR_DEV int mat_param_count(int fl) { return (fl & 4) ? 4 : ((fl & 8) ? 11 : ((fl & 16) ? 3 : 0)); }
@@ -83,6 +84,7 @@ PSDR_DEV void adj_add(float *lds_g, float *glob, int idx, float v, bool use_lds)
 template <int LDS>
 PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, const AdjointParams &P, float *scratch) {
     const SceneTables &T = *S.T;
+    const int mrow = S.uv_adj ? kMatRow : kMatOut;                     // LDS row of a BSDF's material adjoints (kMatRow)
     const int lane_id = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane_id) - 1ull;
     const float inv_spp = T.spp > 1 ? 1.f / (float) T.spp : 1.f;
@@ -91,14 +93,14 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
     int *ext = reinterpret_cast<int *>(recs + P.hit_words * kBlock) + threadIdx.x;
     float *lk = recs + (P.hit_words + P.ext_words) * kBlock + threadIdx.x;
     float *acc_cam = P.rec_global ? scratch : scratch + (P.hit_words + P.ext_words + P.lk_words) * kBlock;        // 16 floats, always in LDS: every path adds to the same 12 entries
-    float *acc_mat = acc_cam + kAdjMisc;                               // [n_bsdfs * kMatRow], always in LDS like the camera block
-    float *acc = acc_mat + T.n_bsdfs * kMatRow;
+    float *acc_mat = acc_cam + kAdjMisc;                               // [n_bsdfs * mrow], always in LDS like the camera block
+    float *acc = acc_mat + T.n_bsdfs * mrow;
     const int n_acc = P.n_hot * 22 + T.n_bsdfs * 3 + T.n_emitters * 3;
     const bool use_lds = true;                                         // colours and emitters always accumulate in LDS
     for (int i = threadIdx.x; i < n_acc; i += kBlock) acc[i] = 0.f;
     float *acc_bsdf = acc + P.n_hot * 22, *acc_emit = acc_bsdf + T.n_bsdfs * 3;
     if (threadIdx.x < kAdjMisc) acc_cam[threadIdx.x] = 0.f;    // [0..11] camera pose, [12] environment-map scale, [16..26] environment from_world, [28..31] the map's uv transform
-    for (int i = threadIdx.x; i < T.n_bsdfs * kMatRow; i += kBlock) acc_mat[i] = 0.f;
+    for (int i = threadIdx.x; i < T.n_bsdfs * mrow; i += kBlock) acc_mat[i] = 0.f;
     __syncthreads();
     S.rec = rec; S.ext = ext; S.lk = lk; S.ext_max = P.ext_words; S.lk_max = P.lk_words / 3;
 
@@ -288,7 +290,7 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                             if (hot >= 0 && hot < P.n_hot) adj_add<LDS>(acc, acc, hot * 22 + st_comp, gval, true);      // (the launch may use fewer hot slots than the scene has)
                             else adj_add<LDS>(acc, P.g_tri, st_orig * 22 + st_comp, gval, false);
                         }
-                        else if (st_stage == 1 && bc >= 3) adj_add<LDS>(acc_mat, acc_mat, st_id * kMatRow + bc - 3, gval, true);
+                        else if (st_stage == 1 && bc >= 3) adj_add<LDS>(acc_mat, acc_mat, st_id * mrow + bc - 3, gval, true);
                         else if (st_stage == 1) adj_add<LDS>(acc_bsdf, P.g_bsdf, st_id * 3 + bc, gval, use_lds);
                         else if (st_stage == 2) adj_add<LDS>(acc_emit, P.g_emitter, st_id * 3 + st_comp, gval, use_lds);
                         else if (st_stage == 4) { adj_add<LDS>(acc_cam, acc_cam, st_comp, gval, true); ray_p = ray; }
@@ -340,8 +342,8 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
                                     for (int k = 0; k < 4; ++k) atomicAdd(&P.g_tex[td.g_off + (long long) ch * idx[k] + c], gval * wt[k]);
                                     if (P.g_uv_xf != nullptr) {
                                         float ob[3] = {0.f, 0.f, 0.f}; ob[c] = gval;
-                                        if (ch == 3) tex_xf_adjoint<3>(td, S.probe_u, S.probe_v, ob, &acc_mat[st_id * kMatRow + kMatOut + 4 * tslot]);
-                                        else tex_xf_adjoint<1>(td, S.probe_u, S.probe_v, ob, &acc_mat[st_id * kMatRow + kMatOut + 4 * tslot]);
+                                        if (ch == 3) tex_xf_adjoint<3>(td, S.probe_u, S.probe_v, ob, &acc_mat[st_id * mrow + kMatOut + 4 * tslot]);
+                                        else tex_xf_adjoint<1>(td, S.probe_u, S.probe_v, ob, &acc_mat[st_id * mrow + kMatOut + 4 * tslot]);
                                     }
                                 }
                             }
@@ -362,9 +364,9 @@ PSDR_DEV void run_interior_adjoint(SceneView<LDS> &S, const SensorDev &cam, cons
     if (P.g_env_scale != nullptr && threadIdx.x == 12 && acc_cam[12] != 0.f) atomicAdd(P.g_env_scale, acc_cam[12]);
     if (P.g_env_xf != nullptr && threadIdx.x >= 16 && threadIdx.x < 27 && acc_cam[threadIdx.x] != 0.f) atomicAdd(&P.g_env_xf[threadIdx.x - 16], acc_cam[threadIdx.x]);
     if (P.g_mat != nullptr)
-        for (int i = threadIdx.x; i < T.n_bsdfs * kMatOut; i += kBlock) { const float v = acc_mat[(i / kMatOut) * kMatRow + i % kMatOut]; if (v != 0.f) atomicAdd(&P.g_mat[i], v); }
+        for (int i = threadIdx.x; i < T.n_bsdfs * kMatOut; i += kBlock) { const float v = acc_mat[(i / kMatOut) * mrow + i % kMatOut]; if (v != 0.f) atomicAdd(&P.g_mat[i], v); }
     if (P.g_uv_xf != nullptr) {          // uv transforms: three bitmaps per BSDF, then the environment map's
-        for (int i = threadIdx.x; i < T.n_bsdfs * 12; i += kBlock) { const float v = acc_mat[(i / 12) * kMatRow + kMatOut + i % 12]; if (v != 0.f) atomicAdd(&P.g_uv_xf[i], v); }
+        for (int i = threadIdx.x; i < T.n_bsdfs * 12; i += kBlock) { const float v = acc_mat[(i / 12) * mrow + kMatOut + i % 12]; if (v != 0.f) atomicAdd(&P.g_uv_xf[i], v); }
         if (threadIdx.x >= 28 && threadIdx.x < 32 && acc_cam[threadIdx.x] != 0.f) atomicAdd(&P.g_uv_xf[12 * T.n_bsdfs + threadIdx.x - 28], acc_cam[threadIdx.x]);
     }
     if (use_lds) {
@@ -457,6 +459,7 @@ template <int LDS> PSDR_DEV VtxGeom load_vertex(const SceneView<LDS> &S, int slo
 template <int LDS>
 PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam, const AdjointParams &P, float *scratch) {
     const SceneTables &T = *S.T;
+    const int mrow = S.uv_adj ? kMatRow : kMatOut;                     // LDS row of a BSDF's material adjoints (kMatRow)
     const int lane_id = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane_id) - 1ull;
     const float inv_spp = T.spp > 1 ? 1.f / (float) T.spp : 1.f;
@@ -467,7 +470,7 @@ PSDR_DEV void run_interior_adjoint_sweep(SceneView<LDS> &S, const SensorDev &cam
                                                                           //   4 cN, 5 cf, 6 w2, 7 flags, 8-10 thr_k
     float *acc_cam = P.rec_global ? scratch : scratch + lane_words * kBlock;      // same accumulator layout as run_interior_adjoint
     float *acc_mat = acc_cam + kAdjMisc;
-    float *acc = acc_mat + T.n_bsdfs * kMatRow;
+    float *acc = acc_mat + T.n_bsdfs * mrow;
     const int n_acc = P.n_hot * 22 + T.n_bsdfs * 3 + T.n_emitters * 3 + P.env_lds;
 #ifdef PSDR_LDS_POISON
     // (diagnostic) the per-lane records start as garbage: a record word that is read before this path wrote it shows up in the result

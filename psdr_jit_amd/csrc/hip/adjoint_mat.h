@@ -55,6 +55,7 @@ PSDR_DEV Vec3f bsdf_plain_value_and_adjoint(const SceneView<LDS> &S, int bid, co
                                             float *wib, float *wob, float *acc_bsdf, float *acc_mat, float *g_tex, float *uvb,
                                             int slot = -1, float bu = 0.f, float bv = 0.f, float *bcb = nullptr) {
     if (wib) { wib[0] = wib[1] = wib[2] = 0.f; wob[0] = wob[1] = wob[2] = 0.f; }
+    const int mrow = S.uv_adj ? kMatRow : kMatOut;                     // LDS row of a BSDF's material adjoints (kMatRow)
     if (bid < 0) return Vec3f(0.f);
     const float4 a = S.ld(S.T->bsdf_off + 2 * bid);
     const int fl = __float_as_int(a.w);
@@ -79,7 +80,7 @@ PSDR_DEV Vec3f bsdf_plain_value_and_adjoint(const SceneView<LDS> &S, int bid, co
                 for (int c = 0; c < CH; ++c)
                     if (pb[c] != 0.f && finite_(pb[c])) for (int k = 0; k < 4; ++k) atomicAdd(&g_tex[td.g_off + (long long) CH * idx[k] + c], pb[c] * wt[k]);
             }
-            if (S.uv_adj && acc_mat != nullptr) tex_xf_adjoint<CH>(td, tu, tv, pb, &acc_mat[bid * kMatRow + kMatOut + 4 * slot]);
+            if (S.uv_adj && acc_mat != nullptr) tex_xf_adjoint<CH>(td, tu, tv, pb, &acc_mat[bid * mrow + kMatOut + 4 * slot]);
             if (uvb != nullptr) {
                 for (int ax = 0; ax < 2; ++ax) {
                     Dual o[CH];
@@ -116,11 +117,11 @@ PSDR_DEV Vec3f bsdf_plain_value_and_adjoint(const SceneView<LDS> &S, int bid, co
                 else if (j < 6) wob[j - 3] = pb[0] + pb[1] + pb[2];
                 else if (j == 6) {
                     if (fl & 32) tex_back(1, std::integral_constant<int, 3>(), pb);
-                    else if (acc_mat) { add(&acc_mat[bid * kMatRow], pb[0]); add(&acc_mat[bid * kMatRow + 1], pb[1]); add(&acc_mat[bid * kMatRow + 2], pb[2]); }
+                    else if (acc_mat) { add(&acc_mat[bid * mrow], pb[0]); add(&acc_mat[bid * mrow + 1], pb[1]); add(&acc_mat[bid * mrow + 2], pb[2]); }
                 } else if (j == 7) {
                     const float rb[1] = {pb[0] + pb[1] + pb[2]};
                     if (fl & 64) tex_back(2, std::integral_constant<int, 1>(), rb);
-                    else if (acc_mat) add(&acc_mat[bid * kMatRow + 3], rb[0]);
+                    else if (acc_mat) add(&acc_mat[bid * mrow + 3], rb[0]);
                 } else {
                     if (fl & 2) tex_back(0, std::integral_constant<int, 3>(), pb);
                     else if (acc_bsdf) { add(&acc_bsdf[3 * bid], pb[0]); add(&acc_bsdf[3 * bid + 1], pb[1]); add(&acc_bsdf[3 * bid + 2], pb[2]); }
@@ -205,8 +206,8 @@ PSDR_DEV Vec3f bsdf_plain_value_and_adjoint(const SceneView<LDS> &S, int bid, co
                 else if (j == 8 && (fl & 2)) tex_back(0, std::integral_constant<int, 3>(), pb);
                 else if (j == 9 && (fl & 32)) tex_back(1, std::integral_constant<int, 3>(), pb);
                 else if (acc_mat) {
-                    if (j < 8) add(&acc_mat[bid * kMatRow + (j - 6)], pb[0] + pb[1] + pb[2]);
-                    else { const int o = j == 8 ? 2 : (j == 9 ? 5 : 8); add(&acc_mat[bid * kMatRow + o], pb[0]); add(&acc_mat[bid * kMatRow + o + 1], pb[1]); add(&acc_mat[bid * kMatRow + o + 2], pb[2]); }
+                    if (j < 8) add(&acc_mat[bid * mrow + (j - 6)], pb[0] + pb[1] + pb[2]);
+                    else { const int o = j == 8 ? 2 : (j == 9 ? 5 : 8); add(&acc_mat[bid * mrow + o], pb[0]); add(&acc_mat[bid * mrow + o + 1], pb[1]); add(&acc_mat[bid * mrow + o + 2], pb[2]); }
                 }
             }
             for (int j = 0; j < 3; ++j) { if (!finite_(wib[j])) wib[j] = 0.f; if (!finite_(wob[j])) wob[j] = 0.f; }
@@ -232,7 +233,7 @@ PSDR_DEV Vec3f bsdf_plain_value_and_adjoint(const SceneView<LDS> &S, int bid, co
                 if (j < 3) wib[j] = pb;
                 else if (j < 6) wob[j - 3] = pb;
                 else if (j < 8 && (fl & 64)) { const float rb[1] = {pb}; tex_back(2, std::integral_constant<int, 1>(), rb); }
-                else if (acc_mat) add(&acc_mat[bid * kMatRow + (j - 6)], pb);
+                else if (acc_mat) add(&acc_mat[bid * mrow + (j - 6)], pb);
             }
             for (int j = 0; j < 3; ++j) { if (!finite_(wib[j])) wib[j] = 0.f; if (!finite_(wob[j])) wob[j] = 0.f; }
             return F;
@@ -277,6 +278,7 @@ template <int LDS>
 PSDR_DEV Vec3f bsdf_value_and_adjoint(const SceneView<LDS> &S, int bid, const Vec3f &wi_, const Vec3f &wo_, float tu, float tv, const Vec3f *Fb,
                                       float *wib, float *wob, float *acc_bsdf, float *acc_mat, float *g_tex, float *uvb,
                                       int slot = -1, float bu = 0.f, float bv = 0.f, float *bcb = nullptr, const Vec3f *dpdu = nullptr, float *dpb = nullptr) {
+    const int mrow = S.uv_adj ? kMatRow : kMatOut;                     // LDS row of a BSDF's material adjoints (kMatRow)
     if constexpr (has_mat(LDS)) {
         if (bid >= 0 && (__float_as_int(S.ld(S.T->bsdf_off + 2 * bid).w) & 256)) {
             if (wib) { wib[0] = wib[1] = wib[2] = 0.f; wob[0] = wob[1] = wob[2] = 0.f; }
@@ -343,7 +345,7 @@ PSDR_DEV Vec3f bsdf_value_and_adjoint(const SceneView<LDS> &S, int bid, const Ve
                     for (int ch = 0; ch < 3; ++ch)
                         if (inb[6 + ch] != 0.f) for (int k = 0; k < 4; ++k) atomicAdd(&g_tex[td.g_off + 3ll * idx[k] + ch], inb[6 + ch] * wt4[k]);
                 }
-                if (S.uv_adj && acc_mat != nullptr) tex_xf_adjoint<3>(td, tu, tv, &inb[6], &acc_mat[bid * kMatRow + kMatOut]);
+                if (S.uv_adj && acc_mat != nullptr) tex_xf_adjoint<3>(td, tu, tv, &inb[6], &acc_mat[bid * mrow + kMatOut]);
                 if (uvb != nullptr) {
                     for (int ax = 0; ax < 2; ++ax) {
                         Dual o[3];
@@ -365,6 +367,7 @@ PSDR_DEV Vec3f bsdf_value_and_adjoint(const SceneView<LDS> &S, int bid, const Ve
 template <int LDS>
 PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev &cam, const AdjointParams &P, float *scratch) {
     const SceneTables &T = *S.T;
+    const int mrow = S.uv_adj ? kMatRow : kMatOut;                     // LDS row of a BSDF's material adjoints (kMatRow)
     const int lane_id = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane_id) - 1ull;
     const float inv_spp = T.spp > 1 ? 1.f / (float) T.spp : 1.f;
@@ -375,13 +378,13 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
                                                                           //   4 cN, 5 cf, 6 w2, 7 flags, 8-10 thr_k
     float *acc_cam = P.rec_global ? scratch : scratch + lane_words * kBlock;      // same accumulator layout as run_interior_adjoint
     float *acc_mat = acc_cam + kAdjMisc;
-    float *acc = acc_mat + T.n_bsdfs * kMatRow;
+    float *acc = acc_mat + T.n_bsdfs * mrow;
     const int n_acc = P.n_hot * 22 + T.n_bsdfs * 3 + T.n_emitters * 3 + P.env_lds;
     for (int i = threadIdx.x; i < n_acc; i += kBlock) acc[i] = 0.f;
     float *acc_bsdf = acc + P.n_hot * 22, *acc_emit = acc_bsdf + T.n_bsdfs * 3;
     float *acc_env = acc_emit + T.n_emitters * 3;        // [env_lds] texel adjoints of a small environment map (every sample of a wave hits the same few texels)
     if (threadIdx.x < kAdjMisc) acc_cam[threadIdx.x] = 0.f;
-    for (int i = threadIdx.x; i < T.n_bsdfs * kMatRow; i += kBlock) acc_mat[i] = 0.f;
+    for (int i = threadIdx.x; i < T.n_bsdfs * mrow; i += kBlock) acc_mat[i] = 0.f;
     __syncthreads();
     S.mode = 0; S.probe_kind = 0;
 
@@ -944,9 +947,9 @@ PSDR_DEV void run_interior_adjoint_sweep_mat(SceneView<LDS> &S, const SensorDev 
     for (int i = threadIdx.x; i < P.n_hot * 22; i += kBlock) if (acc[i] != 0.f) atomicAdd(&P.g_tri[P.hot_inv[i / 22] * 22 + i % 22], acc[i]);
     for (int i = threadIdx.x; i < T.n_bsdfs * 3; i += kBlock) if (acc_bsdf[i] != 0.f) atomicAdd(&P.g_bsdf[i], acc_bsdf[i]);
     if (P.g_mat != nullptr)
-        for (int i = threadIdx.x; i < T.n_bsdfs * kMatOut; i += kBlock) { const float v = acc_mat[(i / kMatOut) * kMatRow + i % kMatOut]; if (v != 0.f) atomicAdd(&P.g_mat[i], v); }
+        for (int i = threadIdx.x; i < T.n_bsdfs * kMatOut; i += kBlock) { const float v = acc_mat[(i / kMatOut) * mrow + i % kMatOut]; if (v != 0.f) atomicAdd(&P.g_mat[i], v); }
     if (P.g_uv_xf != nullptr) {          // uv transforms: three bitmaps per BSDF, then the environment map's
-        for (int i = threadIdx.x; i < T.n_bsdfs * 12; i += kBlock) { const float v = acc_mat[(i / 12) * kMatRow + kMatOut + i % 12]; if (v != 0.f) atomicAdd(&P.g_uv_xf[i], v); }
+        for (int i = threadIdx.x; i < T.n_bsdfs * 12; i += kBlock) { const float v = acc_mat[(i / 12) * mrow + kMatOut + i % 12]; if (v != 0.f) atomicAdd(&P.g_uv_xf[i], v); }
         if (threadIdx.x >= 28 && threadIdx.x < 32 && acc_cam[threadIdx.x] != 0.f) atomicAdd(&P.g_uv_xf[12 * T.n_bsdfs + threadIdx.x - 28], acc_cam[threadIdx.x]);
     }
     for (int i = threadIdx.x; i < T.n_emitters * 3; i += kBlock) if (acc_emit[i] != 0.f) atomicAdd(&P.g_emitter[i], acc_emit[i]);

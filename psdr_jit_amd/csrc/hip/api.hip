@@ -912,7 +912,8 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     size_t env_lds = 0;
     if ((sweep || sweep_mat) && T.env_emitter >= 0 && g->g_env != nullptr && (size_t) T.env.width * T.env.height * 3 * sizeof(float) <= 32 * 1024)
         env_lds = (size_t) T.env.width * T.env.height * 3;
-    const size_t acc_fixed = sizeof(float) * ((size_t) kAdjMisc + (size_t) T.n_bsdfs * kMatRow + (size_t) T.n_bsdfs * 3 + (size_t) T.n_emitters * 3 + env_lds);
+    const size_t mat_row = g->g_uv_xf ? kMatRow : kMatOut;      // (the uv transforms' twelve floats per BSDF only when they are wanted)
+    const size_t acc_fixed = sizeof(float) * ((size_t) kAdjMisc + (size_t) T.n_bsdfs * mat_row + (size_t) T.n_bsdfs * 3 + (size_t) T.n_emitters * 3 + env_lds);
     // ... unless they are what keeps a SECOND workgroup off the CU: the kernels need <= 256 registers (two waves per SIMD fit), and one wave per SIMD cannot hide the
     // latency of the sweep's traces (config 5, depth 3: 40 KB of traversal rows + 45 KB of records; round 4 measured this with a 314-register kernel, where it could not help)
     const size_t rec_bytes = sizeof(float) * (size_t) lane_words * kBlock, min_hot = 64 * 22 * sizeof(float);
@@ -925,7 +926,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     const size_t budget = (smem_base + fixed_bytes + 64 * 22 * sizeof(float) <= 80 * 1024) ? 80 * 1024 : 160 * 1024;
     const int n_hot_used = (int) std::min<size_t>((size_t) sc->n_hot, (budget - smem_base - fixed_bytes) / (22 * sizeof(float)));
     const size_t n_acc = (size_t) n_hot_used * 22 + (size_t) T.n_bsdfs * 3 + (size_t) T.n_emitters * 3 + env_lds;
-    const size_t adj_bytes = sizeof(float) * ((rec_in_lds ? (size_t) lane_words * kBlock : 0) + kAdjMisc + (size_t) T.n_bsdfs * kMatRow + (lds_acc ? n_acc : 0));
+    const size_t adj_bytes = sizeof(float) * ((rec_in_lds ? (size_t) lane_words * kBlock : 0) + kAdjMisc + (size_t) T.n_bsdfs * mat_row + (lds_acc ? n_acc : 0));
     const size_t smem = smem_base + adj_bytes;
     if (smem > 160 * 1024) return fail("scene too large for the adjoint kernel's LDS records");
     if (!sc->adj_attr_set) {         // (per scene = per device and context; a process-wide flag would skip the second device)
