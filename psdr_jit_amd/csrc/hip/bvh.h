@@ -105,6 +105,7 @@ PSDR_BVH_HD inline float bvh_half_area(const float *lo, const float *hi) {
 }
 
 constexpr int kNodeFloats = 16;
+constexpr int kBvhTopNodes = 96;        // nodes numbered breadth first from the root (= trav4.h::kTopNodes, the part of the tree a workgroup copies to LDS)
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // host builder
@@ -312,8 +313,13 @@ inline void build_bvh4(const BvhResult &b2, int n_tris, Bvh4Result &out) {
     todo.push_back({0, root, 1});
     int max_depth = 1;
     const double root_area = std::max((double) half_area(0), 1e-300);
-    while (!todo.empty()) {
-        const Item it = todo.back(); todo.pop_back();
+    // numbering: the first kBvhTopNodes nodes breadth first - the top levels, which every walk passes and trav4.h keeps in LDS -, the rest depth first (a
+    // subtree's nodes next to each other)
+    size_t head = 0;
+    while (head < todo.size()) {
+        Item it;
+        if ((int) (out.nodes.size() / kNodeFloats) < kBvhTopNodes) it = todo[head++];
+        else { it = todo.back(); todo.pop_back(); }
         max_depth = std::max(max_depth, it.depth);
         int list[4], nl = 0;
         if (is_leaf(it.tmp)) list[nl++] = it.tmp;          // a scene of one leaf: the root holds it as its only child

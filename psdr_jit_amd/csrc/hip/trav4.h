@@ -25,8 +25,9 @@
 // THE WAVE TESTS THE TRIANGLES.  A worker that reaches a leaf only ENQUEUES (triangle, ray) pairs in a per-wave LDS ring and goes
 // on to its next node; whenever the ring holds a wave's worth of pairs every lane tests ONE pair - anybody's: the ray comes from
 // its parked copy, the result goes back with one 64-bit LDS atomic min on (bits of t << 32 | original triangle id), which IS the
-// (t, id) order that defines the hit, and the lane that holds the minimum after the batch writes (slot, u, v).  A ray is finished
-// when its walk has ended and its last pair has been tested.
+// (t, id) order that defines the hit.  A ray is finished when its walk has ended and its last pair has been tested; its owner then turns the winning id back
+// into the triangle (the blob's id -> slot map) and recomputes (u, v) with the same test on the parked ray - the same bits (round 5: until then the winning lane
+// of every batch wrote (slot, u, v) to six LDS rows per workgroup; those rows now hold the TOP OF THE TREE, see kTopNodes).
 //
 // Stack: the first T.stack_lds entries of a worker are in LDS (stride kBlock, conflict-free), deeper entries - rare -
 // in a per-lane global array (T.gstack), so the LDS footprint does not grow with the depth of the tree.
@@ -44,6 +45,9 @@ namespace psdr {
 #endif
 #ifndef PSDR_PAIR_MIN          // a burst ends when the ring holds this many pairs, and that many are worth a (partial) test round; 64 = a wave's worth
 #define PSDR_PAIR_MIN 48         // (config 5: 32: 260.5, 48: 258.9, 64: 264.4 ms - earlier hits cull more; 128 - two rounds back to back, half the outer iterations - 285 vs 264 ms on config 5: the hits arrive later and cull less)
+#endif
+#ifndef PSDR_TOP_LDS           // 1: the first kTopNodes nodes of the tree are read from the workgroup's LDS copy
+#define PSDR_TOP_LDS 1
 #endif
 #ifndef PSDR_STEAL             // 1: workers without a ray take over the bottom stack entry (the far subtree) of a walk in progress once the wave's ray queue is empty
 #define PSDR_STEAL 1
@@ -79,7 +83,8 @@ constexpr unsigned kT4Miss = 0xffffffffu;      // sort key of a child the ray do
 // LDS rows (of kBlock words) behind the traversal stack, per workgroup of four waves (scene_dev.h::kTravRows):
 //   kParkWords rows  parked rays   [word][lane]            oA dA oB dB + the any-hit distance of ray A, written by the owner
 //   4 rows           best          [wave][kRayCap] x u64   (t bits << 32 | original id) per ray
-//   6 rows           hit           [word][wave][kRayCap]   slot, u, v of the pair that currently holds `best`
+//   6 rows           top           [kTopNodes][16]         the first kTopNodes nodes of the tree (bvh.h numbers the top levels first): every walk starts there, and an
+//                                                             LDS read costs the wave 8 clocks where 64 lanes on 64 different cache lines cost the L1 a tag lookup each
 //   2 rows           fin           [wave][kRayCap]         0 = walk not finished; else 1 + sequence number after the ray's last pair
 //   kPairRows rows   pair ring     [wave][kPairCap]        (slot << 7 | ray)
 //   2 rows           ray queue     [wave][kRayCap]         rays posted and not yet taken by a worker
@@ -87,7 +92,8 @@ constexpr unsigned kT4Miss = 0xffffffffu;      // sort key of a child the ray do
 constexpr int kRayCap = 128;                   // rays of a wave: two per lane; ray id = k * 64 + owner lane (k = 0: next-event ray, 1: extension ray)
 constexpr int kPairCap = 256;                  // power of two >= 63 left over + 64 workers x 2 triangles per leaf (bvh.h: leaves of <= 2)
 constexpr int kPairRows = (4 * kPairCap + kBlock - 1) / kBlock;
-constexpr int kRowBest = kParkWords, kRowHit = kRowBest + 4, kRowFin = kRowHit + 6, kRowPair = kRowFin + 2, kRowRq = kRowPair + kPairRows, kRowHeads = kRowRq + 2;
+constexpr int kRowBest = kParkWords, kRowTop = kRowBest + 4, kRowFin = kRowTop + 6, kRowPair = kRowFin + 2, kRowRq = kRowPair + kPairRows, kRowHeads = kRowRq + 2;
+constexpr int kTopNodes = 6 * kBlock / 16;       // 96 nodes of 64 bytes
 static_assert(kTravRows == kRowHeads + 1, "scene_dev.h::kTravRows");
 static_assert(kParkWords == 13, "scene_dev.h::kParkWords");
 enum { kHdPairEnq = 0, kHdPairTested = 1, kHdRayTail = 2, kHdRayHead = 3 };
@@ -97,6 +103,8 @@ typedef __attribute__((address_space(3))) unsigned lds_uint_t;
 typedef __attribute__((address_space(3))) float lds_float_t;
 typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
 typedef __attribute__((address_space(1))) int glb_int_t;
+typedef float t4_v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) t4_v4f lds_v4f_t;
 
 // Lanes of a wave talk to each other through LDS (owner -> worker -> tester -> owner).  The hardware executes a wave's LDS
 // instructions in order; this keeps the COMPILER from moving or forwarding accesses across the points where another lane's
@@ -124,7 +132,7 @@ template <int LDS> struct T4Lds {
     lds_float_t *park;          // this lane's parked rays, stride kBlock
     lds_float_t *park0;         // lane 0 of this WAVE (owner lane l: park0 + l)
     lds_u64_t *best;            // this wave's kRayCap entries
-    lds_float_t *hit0;          // this wave's slot[kRayCap]; u at + 2 rows, v at + 4 rows
+    const lds_v4f_t *top;       // the workgroup's copy of the first kTopNodes nodes
     lds_uint_t *fin;            // this wave's kRayCap entries
     lds_uint_t *ring;           // this wave's kPairCap pairs
     lds_uint_t *rq;             // this wave's kRayCap queue slots
@@ -137,14 +145,13 @@ template <int LDS> struct T4Lds {
         park = (lds_float_t *) (base + rows * kBlock + threadIdx.x);
         park0 = (lds_float_t *) (base + rows * kBlock + (wave << 6));
         best = (lds_u64_t *) (base + (rows + kRowBest) * kBlock) + wave * kRayCap;
-        hit0 = (lds_float_t *) (base + (rows + kRowHit) * kBlock + wave * kRayCap);
+        top = (const lds_v4f_t *) (base + (rows + kRowTop) * kBlock);
         fin = (lds_uint_t *) (base + (rows + kRowFin) * kBlock) + wave * kRayCap;
         ring = (lds_uint_t *) (base + (rows + kRowPair) * kBlock) + wave * kPairCap;
         rq = (lds_uint_t *) (base + (rows + kRowRq) * kBlock) + wave * kRayCap;
         heads = (lds_uint_t *) (base + (rows + kRowHeads) * kBlock) + 4 * wave;
     }
 };
-constexpr int kHitStride = 2 * kBlock;         // words between the slot / u / v arrays of `hit0`
 
 // This lane's stack base, recomputed from the thread index where it is used: kept in a register across the whole kernel it is one of the
 // values the allocator spills, and a push then starts with a scratch load and a full s_waitcnt vmcnt(0) (three per node step, seen in the ISA)
@@ -218,8 +225,18 @@ template <int LDS, bool COUNT> PSDR_DEV void t4_node(SceneView<LDS> &S, const T4
     // VALU instructions as the subtract and multiply of the float node, for four loads instead of seven.  The roundings of the
     // factored form (a few ulps of |origin - o| |inv|) stay far inside the builder's padding of every box (1e-4 of the coordinate
     // magnitude, bvh.h).
-    const int w = T.nodes_off + 4 * (int) tr.code;
-    const float4 n0 = S.ld(w), n1 = S.ld(w + 1), n2 = S.ld(w + 2), n3 = S.ld(w + 3);
+    float4 n0, n1, n2, n3;
+#if PSDR_TOP_LDS
+    if (tr.code < (unsigned) kTopNodes) {             // (the top of the tree: the workgroup's LDS copy, t4_init_lds)
+        const lds_v4f_t *q = L.top + 4 * (int) tr.code;
+        const t4_v4f q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        n0 = make_float4(q0.x, q0.y, q0.z, q0.w); n1 = make_float4(q1.x, q1.y, q1.z, q1.w); n2 = make_float4(q2.x, q2.y, q2.z, q2.w); n3 = make_float4(q3.x, q3.y, q3.z, q3.w);
+    } else
+#endif
+    {
+        const int w = T.nodes_off + 4 * (int) tr.code;
+        n0 = S.ld(w); n1 = S.ld(w + 1); n2 = S.ld(w + 2); n3 = S.ld(w + 3);
+    }
     const unsigned ex = __float_as_uint(n0.w);
     const float sx = __uint_as_float((ex & 0xffu) << 23), sy = __uint_as_float(((ex >> 8) & 0xffu) << 23), sz = __uint_as_float(((ex >> 16) & 0xffu) << 23);
     const float ax0 = (n0.x - ox) * ix, ay0 = (n0.y - oy) * iy, az0 = (n0.z - oz) * iz;
@@ -289,31 +306,21 @@ template <int LDS, bool COUNT> PSDR_DEV void t4_test_pairs(SceneView<LDS> &S, co
 #if PSDR_DIAG == 2
     if (COUNT) S.c_hits++;
 #endif
-    unsigned long long key = 0ull;
-    int rid = 0, slot = 0;
-    float u = 0.f, v = 0.f;
-    bool hit = false;
     if (rank < n) {
         const unsigned e = L.ring[(from + (unsigned) rank) & (kPairCap - 1)];
-        rid = (int) (e & 127u); slot = (int) (e >> 7);
+        const int rid = (int) (e & 127u), slot = (int) (e >> 7);
         const lds_float_t *q = L.park0 + (rid & 63) + ((rid & 64) ? 6 * kBlock : 0);
         const Vec3f o(q[0], q[kBlock], q[2 * kBlock]), d(q[3 * kBlock], q[4 * kBlock], q[5 * kBlock]);
         const int w = T.trav_off + 3 * slot;
         const float4 a = S.ld(w), b = S.ld(w + 1), c = S.ld(w + 2);
-        float t;
+        float u, v, t;
 #if PSDR_DIAG != 8
         if (COUNT) S.c_tris++;
 #endif
-        hit = tri_test(a, b, c, o, d, u, v, t);
-        if (hit) {
-            key = ((unsigned long long) __float_as_uint(t) << 32) | (unsigned long long) (unsigned) __float_as_int(c.y);
+        if (tri_test(a, b, c, o, d, u, v, t)) {
+            const unsigned long long key = ((unsigned long long) __float_as_uint(t) << 32) | (unsigned long long) (unsigned) __float_as_int(c.y);
             __hip_atomic_fetch_min(&L.best[rid], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-    }
-    // whoever holds the minimum after ALL of this batch's atomics describes the hit (keys are unique: one pair per triangle and ray)
-    wave_sync();
-    if (hit && __hip_atomic_load(&L.best[rid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == key) {
-        L.hit0[rid] = __int_as_float(slot); L.hit0[kHitStride + rid] = u; L.hit0[2 * kHitStride + rid] = v;
     }
 }
 
@@ -324,7 +331,15 @@ template <int LDS> PSDR_DEV Hit t4_result(const SceneView<LDS> &S, int k) {
     const int rid = (k << 6) | (threadIdx.x & 63);
     const unsigned long long key = __hip_atomic_load(&L.best[rid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if ((unsigned) (key & 0xffffffffull) != 0x7fffffffu) {
-        h.slot = __float_as_int(L.hit0[rid]); h.u = L.hit0[kHitStride + rid]; h.v = L.hit0[2 * kHitStride + rid];
+        // the winning pair again: id -> slot (the map the per-mesh samplers use, shade.h), the triangle's rows, the ray's parked copy, the same test
+        const SceneTables &T = *S.T;
+        h.slot = S.ldi(T.map_off, (int) (unsigned) (key & 0xffffffffull));
+        const lds_float_t *q = L.park0 + (threadIdx.x & 63) + (k ? 6 * kBlock : 0);
+        const Vec3f o(q[0], q[kBlock], q[2 * kBlock]), d(q[3 * kBlock], q[4 * kBlock], q[5 * kBlock]);
+        const int w = T.trav_off + 3 * h.slot;
+        const float4 a = S.ld(w), b = S.ld(w + 1), c = S.ld(w + 2);
+        float t;
+        (void) tri_test(a, b, c, o, d, h.u, h.v, t);
         h.t = __uint_as_float((unsigned) (key >> 32));
     }
     return h;
@@ -487,6 +502,12 @@ template <int LDS> PSDR_DEV void t4_init_lds(const SceneView<LDS> &S) {
     if (S.T->stack_lds > 0) {
         lds_int_t *base = (lds_int_t *) (S.stack - threadIdx.x);
         base[(S.T->stack_lds + kRowHeads) * kBlock + threadIdx.x] = 0;
+#if PSDR_TOP_LDS
+        // the first kTopNodes nodes, four 16-byte words each
+        lds_v4f_t *top = (lds_v4f_t *) (base + (S.T->stack_lds + kRowTop) * kBlock);
+        const int n_words = 4 * (S.T->n_nodes < kTopNodes ? S.T->n_nodes : kTopNodes);
+        for (int i = threadIdx.x; i < n_words; i += kBlock) { const float4 v = S.ld(S.T->nodes_off + i); t4_v4f w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; top[i] = w; }
+#endif
         __syncthreads();
     }
 }
