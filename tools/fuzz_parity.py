@@ -39,7 +39,7 @@ for case in range(n_cases):
     sc = product.build_scene(spec)
     ref = orc.OracleScene(spec, [0])
     buf = torch.empty((2, w * h, 3), dtype=torch.float32, device="cuda")
-    a = cabi.make_args(max_depth=depth, seeds=seeds, terms=7)
+    a = cabi.make_args(max_depth=depth, seeds=seeds, terms=7, skip_static_edges=bool(rng.integers(2)))      # (ABI 14: with or without the zero-velocity edge samples - the same image)
     cabi.check(cabi.lib().psdr_hip_render_d_fwd(sc._hip_handle(), C.byref(a), buf[0].data_ptr(), buf[1].data_ptr(), None))
     torch.cuda.synchronize()
     got = buf.cpu().numpy()
