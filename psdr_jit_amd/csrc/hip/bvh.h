@@ -46,6 +46,17 @@ PSDR_BVH_HD inline void bvh_tri_box(const float *p0, const float *e1, const floa
     }
 }
 
+// Width of the tree (children per node).  4: the shipped form.  8 (-DPSDR_BVH_WIDTH=8, measurement build): a node of 128 bytes - one line - with two words per byte plane
+// (lo.x[8] ... hi.z[8] at words 4-15) and eight codes at words 16-23; a walk then takes fewer, wider steps.
+#ifndef PSDR_BVH_WIDTH
+#define PSDR_BVH_WIDTH 4
+#endif
+constexpr int kBvhW = PSDR_BVH_WIDTH;
+static_assert(kBvhW == 4 || kBvhW == 8, "PSDR_BVH_WIDTH");
+constexpr int kNodeFloats = kBvhW == 4 ? 16 : 32;
+constexpr int kNodeCodeOff = 4 + 6 * (kBvhW / 4);        // word of the first child code (10 / 16)
+constexpr int kBvhTopNodes = 6 * 256 / kNodeFloats;      // nodes numbered breadth first from the root (= trav4.h::kTopNodes, the part of the tree a workgroup copies to LDS: six rows)
+
 // 4-wide node = 64 bytes = 4 float4 words (two nodes per 128-byte L2 line, four 16-byte loads per step):
 //   w0  origin.xyz (the lower corner of the union of the children's boxes), bits(ex | ey << 8 | ez << 16): biased exponents,
 //       the grid step along axis a is 2^(e_a - 127)
@@ -58,8 +69,9 @@ PSDR_BVH_HD inline void bvh_tri_box(const float *p0, const float *e1, const floa
 //
 // bvh_quantise: words 0..9 of the node from the float boxes of its nc (1..4) children; the codes (words 10..13) are the builder's.
 // smallest power-of-two step with (hi - origin) / step <= 255 after rounding up, per axis; all in double, exact for float inputs.
-PSDR_BVH_HD inline void bvh_quantise(const float los[4][3], const float his[4][3], int nc, float *q) {
-    uint32_t exps = 0, qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+PSDR_BVH_HD inline void bvh_quantise(const float los[kBvhW][3], const float his[kBvhW][3], int nc, float *q) {
+    constexpr int WW = kBvhW / 4;          // words per byte plane
+    uint32_t exps = 0, qlo[3][WW] = {}, qhi[3][WW] = {};
     float o3[3];
     for (int a = 0; a < 3; ++a) {
         double mn = los[0][a], mx = his[0][a];
@@ -82,21 +94,21 @@ PSDR_BVH_HD inline void bvh_quantise(const float los[4][3], const float his[4][3
         }
         const double step = ldexp(1.0, e);
         exps |= (uint32_t) (e + 127) << (8 * a);
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < kBvhW; ++k) {
             uint32_t l = 255u, h = 0u;          // unused child: inverted box (and code 0xffffffff, which the traversal checks)
             if (k < nc) {
                 double fl = floor(((double) los[k][a] - org) / step), ch = ceil(((double) his[k][a] - org) / step);
                 fl = fl < 0.0 ? 0.0 : (fl > 255.0 ? 255.0 : fl); ch = ch < 0.0 ? 0.0 : (ch > 255.0 ? 255.0 : ch);
                 l = (uint32_t) fl; h = (uint32_t) ch;
             }
-            qlo[a] |= l << (8 * k); qhi[a] |= h << (8 * k);
+            qlo[a][k >> 2] |= l << (8 * (k & 3)); qhi[a][k >> 2] |= h << (8 * (k & 3));
         }
         o3[a] = (float) org;                   // exact: org is one of the float bounds
     }
     uint32_t *u = reinterpret_cast<uint32_t *>(q);
     q[0] = o3[0]; q[1] = o3[1]; q[2] = o3[2]; u[3] = exps;
-    u[4] = qlo[0]; u[5] = qlo[1]; u[6] = qlo[2]; u[7] = qhi[0];
-    u[8] = qhi[1]; u[9] = qhi[2];
+    for (int a = 0; a < 3; ++a)
+        for (int j = 0; j < WW; ++j) { u[4 + a * WW + j] = qlo[a][j]; u[4 + (3 + a) * WW + j] = qhi[a][j]; }
 }
 
 PSDR_BVH_HD inline float bvh_half_area(const float *lo, const float *hi) {
@@ -104,8 +116,6 @@ PSDR_BVH_HD inline float bvh_half_area(const float *lo, const float *hi) {
     return d0 * d1 + d1 * d2 + d2 * d0;
 }
 
-constexpr int kNodeFloats = 16;
-constexpr int kBvhTopNodes = 96;        // nodes numbered breadth first from the root (= trav4.h::kTopNodes, the part of the tree a workgroup copies to LDS)
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // host builder
@@ -306,7 +316,7 @@ inline void build_bvh4(const BvhResult &b2, int n_tris, Bvh4Result &out) {
     out.nodes.reserve((size_t) kNodeFloats * (nt / 2 + 2));
     auto new_node = [&]() {
         out.nodes.resize(out.nodes.size() + kNodeFloats, 0.f);
-        kid.resize(kid.size() + 4, -1); n_children.push_back(0);
+        kid.resize(kid.size() + kBvhW, -1); n_children.push_back(0);
         return (int) (out.nodes.size() / kNodeFloats) - 1;
     };
     const int root = new_node();
@@ -321,10 +331,10 @@ inline void build_bvh4(const BvhResult &b2, int n_tris, Bvh4Result &out) {
         if ((int) (out.nodes.size() / kNodeFloats) < kBvhTopNodes) it = todo[head++];
         else { it = todo.back(); todo.pop_back(); }
         max_depth = std::max(max_depth, it.depth);
-        int list[4], nl = 0;
+        int list[kBvhW], nl = 0;
         if (is_leaf(it.tmp)) list[nl++] = it.tmp;          // a scene of one leaf: the root holds it as its only child
         else { list[nl++] = b2.tmp_left[it.tmp]; list[nl++] = b2.tmp_right[it.tmp]; }
-        while (nl < 4) {
+        while (nl < kBvhW) {
             int best = -1; float ba = -1.f;
             for (int k = 0; k < nl; ++k) if (!is_leaf(list[k]) && half_area(list[k]) > ba) { ba = half_area(list[k]); best = k; }
             if (best < 0) break;
@@ -333,9 +343,9 @@ inline void build_bvh4(const BvhResult &b2, int n_tris, Bvh4Result &out) {
             list[nl++] = b2.tmp_right[t];
         }
         n_children[it.node4] = nl;
-        uint32_t codes[4];
-        float los[4][3], his[4][3];
-        for (int k = 0; k < 4; ++k) {
+        uint32_t codes[kBvhW];
+        float los[kBvhW][3], his[kBvhW][3];
+        for (int k = 0; k < kBvhW; ++k) {
             uint32_t code = 0xffffffffu;
             for (int a = 0; a < 3; ++a) { los[k][a] = 3e38f; his[k][a] = 3e38f; }
             if (k < nl) {
@@ -346,7 +356,7 @@ inline void build_bvh4(const BvhResult &b2, int n_tris, Bvh4Result &out) {
                     out.cost += (double) half_area(t) * b2.tmp_count[t] / root_area;
                 } else {
                     const int c = new_node();          // (grows out.nodes: no pointer into it is held across this call)
-                    kid[4 * (size_t) it.node4 + k] = c;
+                    kid[kBvhW * (size_t) it.node4 + k] = c;
                     code = (uint32_t) c;
                     todo.push_back({t, c, it.depth + 1});
                     out.cost += (double) half_area(t) / root_area;
@@ -356,7 +366,7 @@ inline void build_bvh4(const BvhResult &b2, int n_tris, Bvh4Result &out) {
         }
         float *q = &out.nodes[(size_t) kNodeFloats * (size_t) it.node4];
         bvh_quantise(los, his, nl, q);
-        std::memcpy(&q[10], &codes[0], 16);
+        std::memcpy(&q[kNodeCodeOff], &codes[0], 4 * kBvhW);
     }
     out.n_nodes = (int) (out.nodes.size() / kNodeFloats);
     out.max_depth = max_depth;
@@ -365,8 +375,8 @@ inline void build_bvh4(const BvhResult &b2, int n_tris, Bvh4Result &out) {
     out.height.assign((size_t) out.n_nodes, 0);
     for (int i = out.n_nodes - 1; i >= 0; --i) {
         int below = 0, h = 0;
-        for (int k = 0; k < 4; ++k) {
-            const int c = kid[4 * (size_t) i + k];
+        for (int k = 0; k < kBvhW; ++k) {
+            const int c = kid[kBvhW * (size_t) i + k];
             if (c >= 0) { below = std::max(below, need[c]); h = std::max(h, out.height[c] + 1); }
         }
         need[i] = (n_children[i] - 1) + below;

@@ -97,12 +97,12 @@ __global__ void k_refit_level(float4 *__restrict__ blob, int nodes_off, int trav
     double c = 0.0;
     if (tid < count) {
         const int node = ids[tid];
-        float *q = reinterpret_cast<float *>(blob + nodes_off + 4 * (size_t) node);
-        const uint32_t *codes = reinterpret_cast<const uint32_t *>(q) + 10;
-        float los[4][3], his[4][3];
+        float *q = reinterpret_cast<float *>(blob + nodes_off + (kNodeFloats / 4) * (size_t) node);
+        const uint32_t *codes = reinterpret_cast<const uint32_t *>(q) + kNodeCodeOff;
+        float los[kBvhW][3], his[kBvhW][3];
         float ulo[3] = {3e38f, 3e38f, 3e38f}, uhi[3] = {-3e38f, -3e38f, -3e38f};
         int nc = 0;
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < kBvhW; ++k) {
             const uint32_t code = codes[k];
             if (code == 0xffffffffu) break;
             ++nc;
@@ -816,8 +816,8 @@ int psdr_hip_scene_check_tree(const psdr_hip_scene *sc, int64_t *violations) {
         const float *q = &nodes[(size_t) kNodeFloats * (size_t) i];
         const uint32_t *u = reinterpret_cast<const uint32_t *>(q);
         float ulo[3] = {3e38f, 3e38f, 3e38f}, uhi[3] = {-3e38f, -3e38f, -3e38f};
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t code = u[10 + k];
+        for (int k = 0; k < kBvhW; ++k) {
+            const uint32_t code = u[kNodeCodeOff + k];
             if (code == 0xffffffffu) continue;
             float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
             if (code & leaf_bit) {
@@ -838,8 +838,9 @@ int psdr_hip_scene_check_tree(const psdr_hip_scene *sc, int64_t *violations) {
             // the quantised box of child k as the traversal decodes it
             for (int a = 0; a < 3; ++a) {
                 const double step = std::ldexp(1.0, (int) ((u[3] >> (8 * a)) & 0xffu) - 127);
-                const uint32_t wl = u[4 + a], wh = u[7 + a];
-                const double ql = (double) q[a] + step * (double) ((wl >> (8 * k)) & 0xffu), qh = (double) q[a] + step * (double) ((wh >> (8 * k)) & 0xffu);
+                constexpr int WW = kBvhW / 4;
+                const uint32_t wl = u[4 + a * WW + (k >> 2)], wh = u[4 + (3 + a) * WW + (k >> 2)];
+                const double ql = (double) q[a] + step * (double) ((wl >> (8 * (k & 3))) & 0xffu), qh = (double) q[a] + step * (double) ((wh >> (8 * (k & 3))) & 0xffu);
                 if (!(ql <= (double) lo[a] && qh >= (double) hi[a])) ++bad;
             }
             for (int a = 0; a < 3; ++a) { ulo[a] = std::min(ulo[a], lo[a]); uhi[a] = std::max(uhi[a], hi[a]); }

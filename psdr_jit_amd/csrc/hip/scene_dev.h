@@ -19,6 +19,10 @@ constexpr int kBlock = 256;
 constexpr int kBruteForceMax = 64;          // scenes with at most this many triangles skip the BVH
 constexpr int kParkWords = 13;              // LDS words per lane behind the traversal stack: the lane's two parked rays + the any-hit distance of the first (trav4.h)
 constexpr int kColdRows = 15;               // LDS rows of a brute-force scene: per-lane state that only the start and the end of a path touch (paths.h::run_paths)
+#ifndef PSDR_BVH_WIDTH                      // children per node of the tree (bvh.h): 4 = the shipped form, 8 = measurement build
+#define PSDR_BVH_WIDTH 4
+#endif
+constexpr int kNodeW4 = PSDR_BVH_WIDTH == 4 ? 4 : 8;       // float4 words per node
 constexpr int kTravRows = 32;               // LDS rows (of kBlock words) behind the stack of a BVH scene: parked rays, per-ray best hits, the top of the tree, pair ring, ray queue, heads (trav4.h)
 
 // EnvironmentMap after configure() (psdr_envmap_rec): too large for the LDS blob, read from global memory

@@ -93,7 +93,7 @@ constexpr int kRayCap = 128;                   // rays of a wave: two per lane; 
 constexpr int kPairCap = 256;                  // power of two >= 63 left over + 64 workers x 2 triangles per leaf (bvh.h: leaves of <= 2)
 constexpr int kPairRows = (4 * kPairCap + kBlock - 1) / kBlock;
 constexpr int kRowBest = kParkWords, kRowTop = kRowBest + 4, kRowFin = kRowTop + 6, kRowPair = kRowFin + 2, kRowRq = kRowPair + kPairRows, kRowHeads = kRowRq + 2;
-constexpr int kTopNodes = 6 * kBlock / 16;       // 96 nodes of 64 bytes
+constexpr int kTopNodes = 6 * kBlock / (4 * kNodeW4);       // 96 nodes of 64 bytes (48 of 128 in the 8-wide measurement build)
 static_assert(kTravRows == kRowHeads + 1, "scene_dev.h::kTravRows");
 static_assert(kParkWords == 13, "scene_dev.h::kParkWords");
 enum { kHdPairEnq = 0, kHdPairTested = 1, kHdRayTail = 2, kHdRayHead = 3 };
@@ -225,16 +225,67 @@ template <int LDS, bool COUNT> PSDR_DEV void t4_node(SceneView<LDS> &S, const T4
     // VALU instructions as the subtract and multiply of the float node, for four loads instead of seven.  The roundings of the
     // factored form (a few ulps of |origin - o| |inv|) stay far inside the builder's padding of every box (1e-4 of the coordinate
     // magnitude, bvh.h).
+#if PSDR_BVH_WIDTH == 8
+    // 8-wide measurement build (bvh.h, PSDR_BVH_WIDTH == 8): a node is one 128-byte line - w0 origin + exponents; w1 lo.x[8] lo.y[8]; w2 lo.z[8] hi.x[8]; w3 hi.y[8] hi.z[8];
+    // w4 codes 0-3; w5 codes 4-7 - eight slab tests, a 19-comparator network (Batcher's odd-even merge sort), up to seven pushes
+    float4 n0, n1, n2, n3, n4, n5;
+#if PSDR_TOP_LDS
+    if (tr.code < (unsigned) kTopNodes) {
+        const lds_v4f_t *q = L.top + kNodeW4 * (int) tr.code;
+        const t4_v4f q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
+        n0 = make_float4(q0.x, q0.y, q0.z, q0.w); n1 = make_float4(q1.x, q1.y, q1.z, q1.w); n2 = make_float4(q2.x, q2.y, q2.z, q2.w);
+        n3 = make_float4(q3.x, q3.y, q3.z, q3.w); n4 = make_float4(q4.x, q4.y, q4.z, q4.w); n5 = make_float4(q5.x, q5.y, q5.z, q5.w);
+    } else
+#endif
+    {
+        const int w = T.nodes_off + kNodeW4 * (int) tr.code;
+        n0 = S.ld(w); n1 = S.ld(w + 1); n2 = S.ld(w + 2); n3 = S.ld(w + 3); n4 = S.ld(w + 4); n5 = S.ld(w + 5);
+    }
+    const unsigned ex = __float_as_uint(n0.w);
+    const float sx = __uint_as_float((ex & 0xffu) << 23), sy = __uint_as_float(((ex >> 8) & 0xffu) << 23), sz = __uint_as_float(((ex >> 16) & 0xffu) << 23);
+    const float ax0 = (n0.x - ox) * ix, ay0 = (n0.y - oy) * iy, az0 = (n0.z - oz) * iz;
+    const float bxs = sx * ix, bys = sy * iy, bzs = sz * iz;
+    const bool ngx = ix < 0.f, ngy = iy < 0.f, ngz = iz < 0.f;
+    const unsigned wlx[2] = {__float_as_uint(n1.x), __float_as_uint(n1.y)}, wly[2] = {__float_as_uint(n1.z), __float_as_uint(n1.w)}, wlz[2] = {__float_as_uint(n2.x), __float_as_uint(n2.y)};
+    const unsigned whx[2] = {__float_as_uint(n2.z), __float_as_uint(n2.w)}, why[2] = {__float_as_uint(n3.x), __float_as_uint(n3.y)}, whz[2] = {__float_as_uint(n3.z), __float_as_uint(n3.w)};
+    const unsigned cds[8] = {__float_as_uint(n4.x), __float_as_uint(n4.y), __float_as_uint(n4.z), __float_as_uint(n4.w), __float_as_uint(n5.x), __float_as_uint(n5.y), __float_as_uint(n5.z), __float_as_uint(n5.w)};
+    unsigned key8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int j = k >> 2, sh = 8 * (k & 3);
+        const unsigned qnx = ngx ? whx[j] : wlx[j], qny = ngy ? why[j] : wly[j], qnz = ngz ? whz[j] : wlz[j];
+        const unsigned qfx = ngx ? wlx[j] : whx[j], qfy = ngy ? wly[j] : why[j], qfz = ngz ? wlz[j] : whz[j];
+        const float ax = fmaf((float) ((qnx >> sh) & 0xffu), bxs, ax0), bx = fmaf((float) ((qfx >> sh) & 0xffu), bxs, ax0);
+        const float ay = fmaf((float) ((qny >> sh) & 0xffu), bys, ay0), by = fmaf((float) ((qfy >> sh) & 0xffu), bys, ay0);
+        const float az = fmaf((float) ((qnz >> sh) & 0xffu), bzs, az0), bz = fmaf((float) ((qfz >> sh) & 0xffu), bzs, az0);
+        const float tn = fmaxf(fmaxf(ax, ay), fmaxf(az, 0.f));
+        const float tf = fminf(fminf(bx, by), bz) * 1.0000004f;
+        const bool hit = (tn <= fminf(tf, bt)) & (cds[k] != kT4Miss);
+        key8[k] = hit ? ((__float_as_uint(tn) & ~cmask) | cds[k]) : kT4Miss;
+    }
+#define PSDR_CX(i, j) do { const unsigned lo_ = min(key8[i], key8[j]), hi_ = max(key8[i], key8[j]); key8[i] = lo_; key8[j] = hi_; } while (0)
+    PSDR_CX(0, 1); PSDR_CX(2, 3); PSDR_CX(4, 5); PSDR_CX(6, 7);
+    PSDR_CX(0, 2); PSDR_CX(1, 3); PSDR_CX(4, 6); PSDR_CX(5, 7);
+    PSDR_CX(1, 2); PSDR_CX(5, 6);
+    PSDR_CX(0, 4); PSDR_CX(1, 5); PSDR_CX(2, 6); PSDR_CX(3, 7);
+    PSDR_CX(2, 4); PSDR_CX(3, 5);
+    PSDR_CX(1, 2); PSDR_CX(3, 4); PSDR_CX(5, 6);
+#undef PSDR_CX
+#pragma unroll
+    for (int k = 7; k >= 1; --k) if (key8[k] != kT4Miss) t4_push(S, L, tr.sp, key8[k]);
+    tr.code = key8[0] != kT4Miss ? (key8[0] & cmask) : t4_next(S, L, tr, cmask, bt);
+}
+#else
     float4 n0, n1, n2, n3;
 #if PSDR_TOP_LDS
     if (tr.code < (unsigned) kTopNodes) {             // (the top of the tree: the workgroup's LDS copy, t4_init_lds)
-        const lds_v4f_t *q = L.top + 4 * (int) tr.code;
+        const lds_v4f_t *q = L.top + kNodeW4 * (int) tr.code;
         const t4_v4f q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
         n0 = make_float4(q0.x, q0.y, q0.z, q0.w); n1 = make_float4(q1.x, q1.y, q1.z, q1.w); n2 = make_float4(q2.x, q2.y, q2.z, q2.w); n3 = make_float4(q3.x, q3.y, q3.z, q3.w);
     } else
 #endif
     {
-        const int w = T.nodes_off + 4 * (int) tr.code;
+        const int w = T.nodes_off + kNodeW4 * (int) tr.code;
         n0 = S.ld(w); n1 = S.ld(w + 1); n2 = S.ld(w + 2); n3 = S.ld(w + 3);
     }
     const unsigned ex = __float_as_uint(n0.w);
@@ -272,6 +323,7 @@ template <int LDS, bool COUNT> PSDR_DEV void t4_node(SceneView<LDS> &S, const T4
     if (k1 != kT4Miss) t4_push(S, L, tr.sp, k1);
     tr.code = k0 != kT4Miss ? (k0 & cmask) : t4_next(S, L, tr, cmask, bt);
 }
+#endif
 
 // the leaf in hand (called by the workers that hold one, together): its triangles join the wave's pair ring
 template <int LDS> PSDR_DEV void t4_enqueue(const SceneView<LDS> &S, const T4Lds<LDS> &L, Trav4 &tr, unsigned cmask, unsigned leaf_bit) {
@@ -505,7 +557,7 @@ template <int LDS> PSDR_DEV void t4_init_lds(const SceneView<LDS> &S) {
 #if PSDR_TOP_LDS
         // the first kTopNodes nodes, four 16-byte words each
         lds_v4f_t *top = (lds_v4f_t *) (base + (S.T->stack_lds + kRowTop) * kBlock);
-        const int n_words = 4 * (S.T->n_nodes < kTopNodes ? S.T->n_nodes : kTopNodes);
+        const int n_words = kNodeW4 * (S.T->n_nodes < kTopNodes ? S.T->n_nodes : kTopNodes);
         for (int i = threadIdx.x; i < n_words; i += kBlock) { const float4 v = S.ld(S.T->nodes_off + i); t4_v4f w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; top[i] = w; }
 #endif
         __syncthreads();
