@@ -226,7 +226,54 @@ __global__ __launch_bounds__(kBlock, (ADJ ? PSDR_SEC_ADJ_WAVES : PSDR_SEC_WAVES)
         if (threadIdx.x < 16) acc_cam[threadIdx.x] = 0.f;
         __syncthreads();
     }
+    // Candidates: one in six passes the silhouette / light-facing test.  Brute-force scenes (whose LDS rows behind the blob this kernel does not use otherwise): every
+    // lane draws in every round, the indices of the valid ones collect in a per-wave pool in LDS, and when the pool holds a wave's worth each lane takes one and draws
+    // it again - the segment is a function of the item's index (round 5: 6 full rounds + 1 per 64 segments; the form below needs 13 rounds at half the lanes).  BVH
+    // scenes keep the older form: their rows belong to the traversal (trav4.h).
+    auto draw = [&](long long item, BoundarySegSampleDirect &out, float &pdf_out) -> bool {
+        const long long chunk = (item >> 8) * P.shard_count + P.shard_rank;
+        const long long lane = P.begin + (chunk << 8) + (item & 255);
+        if (lane >= P.end) return false;
+        LaneRng rng;
+        rng.seed(P.seed + (unsigned long long) lane, (unsigned long long) lane, P.skip);
+        Vec3f s3;
+        s3.x = rng.next_1d(); s3.y = rng.next_1d(); s3.z = rng.next_1d();
+        pdf_out = use_guiding ? guiding_sample_reuse(G, s3) : 1.f;
+        out = sample_boundary_segment_direct<LDS>(S, E, s3);
+        return out.valid;
+    };
+    constexpr int kPoolCap = 192;            // < 64 waiting + <= 64 new per round
+    const bool pooled = T.n_tris <= kBruteForceMax && T.stack_depth * kBlock >= 4 * kPoolCap && P.n_local < (1ll << 31);
+    lds_uint_t *pool = (lds_uint_t *) (S.stack - threadIdx.x) + (threadIdx.x >> 6) * kPoolCap;
+    int pool_n = 0;
     for (;;) {
+        if (pooled) {
+            while (pool_n < 64) {
+                if (q_next >= q_end && !exhausted) {
+                    unsigned long long base = 0;
+                    if (lane_id == 0) base = atomicAdd(P.counter, (unsigned long long) kFetchBatch);
+                    base = __shfl(base, 0);
+                    if ((long long) base >= P.n_local) exhausted = true;
+                    else { q_next = (long long) base; q_end = q_next + kFetchBatch < P.n_local ? q_next + kFetchBatch : P.n_local; }
+                }
+                if (q_next >= q_end) break;
+                const long long item = q_next + lane_id;
+                bool ok = false;
+                if (item < q_end) { BoundarySegSampleDirect tmp; float tpdf; ok = draw(item, tmp, tpdf); }
+                const unsigned long long m_ok = __ballot(ok);
+                if (ok) pool[pool_n + __popcll(m_ok & lt_mask)] = (unsigned) item;
+                pool_n += __popcll(m_ok);
+                const long long left = q_end - q_next;
+                q_next += left < 64 ? left : 64;
+            }
+            wave_sync();
+            const int n_take = pool_n < 64 ? pool_n : 64;
+            have = false;
+            if (lane_id < n_take) have = draw((long long) pool[pool_n - n_take + lane_id], bss, pdf0);
+            pool_n -= n_take;
+            wave_sync();
+            if (n_take == 0) { if (exhausted && q_next >= q_end) break; continue; }
+        } else {
         for (int round = 0; round < 16; ++round) {
             const unsigned long long need = __ballot(!have);
             if (__popcll(need) <= 6) break;
@@ -257,6 +304,7 @@ __global__ __launch_bounds__(kBlock, (ADJ ? PSDR_SEC_ADJ_WAVES : PSDR_SEC_WAVES)
             q_next += n_need < (int) (q_end - q_next) ? n_need : (q_end - q_next);
         }
         if (__ballot(have) == 0ull) { if (exhausted && q_next >= q_end) break; continue; }
+        }
         if constexpr (ADJ) if (have) {
             // reverse mode: record the three rays once, then probe the quantities the tangent is linear in
             float *rec = scratch_base<LDS>(smem, T) + threadIdx.x;
