@@ -767,8 +767,14 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
     // caller's stream after the clears, joined before the call returns) the next term's workgroups take the slots as they free up.
     hipStream_t s_prim = st, s_sec = st;
     // (BVH scenes only: config 5 219.3 -> 217.9 ms; the brute-force classes lose - C3 7.09 -> 7.34 ms - because a second kernel's waves beside a VALU-bound one only take issue slots)
-    const bool fork = ad && !a->pix_ids && !lanes_out && !COUNT && T.n_tris > kBruteForceMax && ((terms & (PSDR_TERM_PRIMARY | PSDR_TERM_SECONDARY)) != 0) && (terms & (terms - 1)) != 0;
+    // (PSDR_NO_FORK: measurement / test knob, read per call - the three terms one after the other on the caller's stream, so that a profiler sees each kernel's own
+    //  duration (tools/profile.sh) and a test can compare the forked call with the serial one)
+    const bool no_fork = std::getenv("PSDR_NO_FORK") != nullptr;
+    const bool fork = !no_fork && ad && !a->pix_ids && !lanes_out && !COUNT && T.n_tris > kBruteForceMax && ((terms & (PSDR_TERM_PRIMARY | PSDR_TERM_SECONDARY)) != 0) && (terms & (terms - 1)) != 0;
     unsigned long long *q_int = nullptr, *q_prim = nullptr, *q_sec = nullptr;
+    // concurrent launches must not share the global tail of the traversal stack (trav4.h indexes it by workgroup and thread only): the edge terms get slices of their own
+    SceneTables T_prim = T, T_sec = T;
+    if (fork && T.gstack != nullptr) { T_prim.gstack = T.gstack + sc->gstack_slice; T_sec.gstack = T.gstack + 2 * sc->gstack_slice; }
     if (fork) {
         if (sc->make_term_streams()) return fail("term streams: cannot create");
         if (next_queue(q_int) || next_queue(q_prim) || next_queue(q_sec)) return 1;
@@ -808,10 +814,10 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
             P.n_local = local_lanes(P.end, rank, count);
             if (P.n_local > 0) {
                 if (fork) P.counter = q_prim; else if (next_queue(P.counter)) return 1;
-                if (cls == 1) ON_CLS1(LAUNCH(1, (k_paths<false, 1, COUNT, 1>), sc, P.n_local, s_prim, sc->blob.as<float4>(), T, cam, P, ctr));
-                else if (cls == 2) ON_CLS2(LAUNCH(2, (k_paths<false, 2, COUNT, 1>), sc, P.n_local, s_prim, sc->blob.as<float4>(), T, cam, P, ctr));
-                else if (cls == 3) ON_CLS3(LAUNCH(3, (k_paths<false, 3, false, 1>), sc, P.n_local, s_prim, sc->blob.as<float4>(), T, cam, P, ctr));
-                else ON_CLS0(LAUNCH(0, (k_paths<false, 0, COUNT, 1>), sc, P.n_local, s_prim, sc->blob.as<float4>(), T, cam, P, ctr));
+                if (cls == 1) ON_CLS1(LAUNCH(1, (k_paths<false, 1, COUNT, 1>), sc, P.n_local, s_prim, sc->blob.as<float4>(), T_prim, cam, P, ctr));
+                else if (cls == 2) ON_CLS2(LAUNCH(2, (k_paths<false, 2, COUNT, 1>), sc, P.n_local, s_prim, sc->blob.as<float4>(), T_prim, cam, P, ctr));
+                else if (cls == 3) ON_CLS3(LAUNCH(3, (k_paths<false, 3, false, 1>), sc, P.n_local, s_prim, sc->blob.as<float4>(), T_prim, cam, P, ctr));
+                else ON_CLS0(LAUNCH(0, (k_paths<false, 0, COUNT, 1>), sc, P.n_local, s_prim, sc->blob.as<float4>(), T_prim, cam, P, ctr));
             }
         }
         if ((terms & PSDR_TERM_SECONDARY) && T.sppse > 0 && sc->E.n > 0) {
@@ -824,10 +830,10 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
             if (a->guiding) G = a->guiding->G;
             if (P.n_local > 0) {
                 if (fork) P.counter = q_sec; else if (next_queue(P.counter)) return 1;
-                if (sc->lds) ON_CLS1(LAUNCH(1, (k_secondary_edges<1, COUNT, false>), sc, P.n_local, s_sec, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
-                else if (sc->lean) ON_CLS2(LAUNCH(2, (k_secondary_edges<2, COUNT, false>), sc, P.n_local, s_sec, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
-                else if (cls == 3) ON_CLS3(LAUNCH(3, (k_secondary_edges<3, false, false>), sc, P.n_local, s_sec, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
-                else ON_CLS0(LAUNCH(0, (k_secondary_edges<0, COUNT, false>), sc, P.n_local, s_sec, sc->blob.as<float4>(), T, sc->E, cam, P, G, use_g, ctr));
+                if (sc->lds) ON_CLS1(LAUNCH(1, (k_secondary_edges<1, COUNT, false>), sc, P.n_local, s_sec, sc->blob.as<float4>(), T_sec, sc->E, cam, P, G, use_g, ctr));
+                else if (sc->lean) ON_CLS2(LAUNCH(2, (k_secondary_edges<2, COUNT, false>), sc, P.n_local, s_sec, sc->blob.as<float4>(), T_sec, sc->E, cam, P, G, use_g, ctr));
+                else if (cls == 3) ON_CLS3(LAUNCH(3, (k_secondary_edges<3, false, false>), sc, P.n_local, s_sec, sc->blob.as<float4>(), T_sec, sc->E, cam, P, G, use_g, ctr));
+                else ON_CLS0(LAUNCH(0, (k_secondary_edges<0, COUNT, false>), sc, P.n_local, s_sec, sc->blob.as<float4>(), T_sec, sc->E, cam, P, G, use_g, ctr));
             }
         }
     }

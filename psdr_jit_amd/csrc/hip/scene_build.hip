@@ -292,14 +292,13 @@ static int scene_sync(psdr_hip_scene *sc, const psdr_scene_snapshot *s, unsigned
     for (int i = 0; i < s->n_emitters; ++i) if (s->emitters[i].type == 1) T.env_emitter = i;
     // traversal stack: the first kStackLds entries of a lane in LDS, deeper ones in a per-lane global array (trav4.h);
     // scenes that are traced by brute force (<= kBruteForceMax triangles) need neither
-#ifdef PSDR_DEV_KNOBS
-    const int kStackLds = std::getenv("PSDR_STACK_LDS") ? std::atoi(std::getenv("PSDR_STACK_LDS")) : 8;      // (measurement: what the global tail of the stack costs)
-#else
     // 8 + kTravRows = 40 KB per workgroup: four workgroups per CU.  Round 5 measured both sides of that choice on config 5 (LABNOTES): FEWER workgroups cost a lot
     // (3 per CU: +17 %, 2: +55 %), a FIFTH brings nothing (a 30 KB layout - no hit rows, 4 stack rows - lost exactly what its shorter stack costs at equal
-    // occupancy), and stack rows going to the global tail cost 1.2 % (6 rows), 6.8 % (4), 9.5 % (2)
-    constexpr int kStackLds = 8;
-#endif
+    // occupancy), and stack rows going to the global tail cost 1.2 % (6 rows), 6.8 % (4), 9.5 % (2).
+    // PSDR_STACK_LDS = 2 ... 8 (test knob, read when a scene is created or rebuilt): fewer rows, so that small test scenes reach the global tail too
+    // (tests/test_gpu_configs.py: the forked terms of a renderD against the serial call)
+    int kStackLds = 8;
+    if (const char *e = std::getenv("PSDR_STACK_LDS")) kStackLds = std::max(2, std::min(8, std::atoi(e)));
     T.stack_lds = uses_bvh ? std::min(kStackLds, sc->tree_max_stack) : 0;
     T.stack_depth = uses_bvh ? T.stack_lds + kTravRows : kColdRows;   // BVH: + parked rays, best hits and the pair ring of the traversal (trav4.h); brute force: cold path state (paths.h)
 
@@ -748,9 +747,11 @@ static int scene_sync(psdr_hip_scene *sc, const psdr_scene_snapshot *s, unsigned
         sc->grid = cus * per_cu;
         T.gstack = nullptr; T.gstack_stride = 0;
         if (uses_bvh && sc->tree_max_stack > T.stack_lds) {
-            // stack entries beyond the LDS part: one int per entry and lane of the largest grid any kernel is launched with
+            // stack entries beyond the LDS part: one int per entry and lane of the largest grid any kernel is launched with - kTermSlices of them, because the
+            // three terms of a renderD run as concurrent launches on forked streams (api.hip::render_impl) and a slice is indexed by workgroup and thread only
             const size_t stride = (size_t) sc->grid * kBlock;
-            if (sc->gstack.ensure(sizeof(int) * stride * (size_t) (sc->tree_max_stack - T.stack_lds))) return 1;
+            sc->gstack_slice = stride * (size_t) (sc->tree_max_stack - T.stack_lds);
+            if (sc->gstack.ensure(sizeof(int) * sc->gstack_slice * (size_t) kTermSlices)) return 1;
             T.gstack = (int *) sc->gstack.p; T.gstack_stride = (int) stride;
         }
     }
@@ -775,7 +776,14 @@ int psdr_hip_scene_create(const psdr_scene_snapshot *s, psdr_hip_scene **out) {
 int psdr_hip_scene_update(psdr_hip_scene *scene, const psdr_scene_snapshot *s, uint32_t same, psdr_update_info *info) {
     if (!scene || !s) return fail("psdr_hip_scene_update: null argument");
     if (s->abi_version != PSDR_HIP_ABI_VERSION) return fail("psdr_hip_scene_update: ABI version mismatch");
-    return scene_sync(scene, s, same, false, false, info);
+    // scene_sync rewrites the handle in place (tables, offsets, named buffers, sensors) while it validates and uploads: a failure midway - a validation message, out of
+    // memory, an LDS budget - leaves old and new sections mixed.  Such a handle is POISONED: the render entry points refuse it, and the next update ignores what the
+    // caller vouches for (its `same` bits are relative to a snapshot the device never fully received) and builds everything again.
+    const bool was_poisoned = scene->poisoned;
+    const int rc = scene_sync(scene, s, was_poisoned ? 0u : same, false, was_poisoned, info);
+    scene->poisoned = rc != 0;
+    if (rc) scene->tree_tris = -1;
+    return rc;
 }
 
 int psdr_hip_scene_destroy(psdr_hip_scene *scene) { delete scene; return 0; }

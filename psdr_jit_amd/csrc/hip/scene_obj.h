@@ -69,6 +69,7 @@ struct PinnedBuf {
 };
 
 constexpr unsigned kQueueRing = 1024;
+constexpr int kTermSlices = 3;            // slices of the traversal stack's global tail: interior, primary-edge and secondary-edge launches of one renderD run concurrently
 
 // Guide table of a discrete distribution (shade.h::sample_reuse_guided): entry k = the index DiscreteDistribution::sample_reuse finds for the
 // sample k / n_buckets, in the kernels' own float arithmetic (s * sum, then the first i < size - 1 whose running sum is not < s, else size - 1).
@@ -106,7 +107,8 @@ struct psdr_hip_scene {
     std::vector<psdr::SensorDev> sensors;
     psdr::DevBuf counters;
     psdr::DevBuf queues;                 // ring of work-queue heads, one per path-kernel launch
-    psdr::DevBuf gstack;                 // traversal-stack entries beyond the LDS part (trav4.h)
+    psdr::DevBuf gstack;                 // traversal-stack entries beyond the LDS part (trav4.h): kTermSlices slices of gstack_slice ints, one per concurrently running term
+    size_t gstack_slice = 0;
     mutable psdr::DevBuf adj_rec;        // per-lane records of the interior adjoint when they do not fit LDS (deep paths), grown on demand
     mutable size_t adj_rec_bytes = 0;
     mutable unsigned queue_slot = 0;
@@ -129,9 +131,10 @@ struct psdr_hip_scene {
     double cost_built = 0.0;                           // SAH cost of the tree when it was built; a refit that exceeds kRebuildFactor x this triggers a build
     std::vector<float> sensor_w2s;                     // world_to_sample of every sensor at the last live-mask build (a mask is rebuilt when it or the triangles changed)
     psdr_update_info last_info{};
+    bool poisoned = false;                             // a psdr_hip_scene_update failed midway: no rendering until an update has gone through (scene_build.hip)
 
     // The launches of one scene share mutable device scratch - the work-queue ring, the counters, the traversal-stack overflow
-    // `gstack` (indexed by workgroup and thread only) and the adjoint records `adj_rec` (re-allocated when they grow) - while the C
+    // `gstack` (indexed by workgroup and thread only; the forked terms of ONE call get a slice each) and the adjoint records `adj_rec` (re-allocated when they grow) - while the C
     // ABI takes a stream per call.  They are therefore SERIALISED ACROSS STREAMS (ScratchGuard below): a call on another stream than
     // the scene's previous one first makes its stream wait for that call's completion event; calls on one stream order themselves.
     mutable std::mutex mu;
@@ -176,4 +179,5 @@ struct ScratchGuard {
         sc->mu.unlock();
     }
 };
-#define SCRATCH_GUARD(sc, stream) ScratchGuard guard_((sc), (stream)); if (guard_.err != hipSuccess) return psdr::api_fail(std::string("scene scratch serialisation: ") + hipGetErrorString(guard_.err))
+#define SCRATCH_GUARD(sc, stream) if ((sc)->poisoned) return psdr::api_fail("the scene's last psdr_hip_scene_update failed: update it again (everything is re-sent) before using it"); \
+    ScratchGuard guard_((sc), (stream)); if (guard_.err != hipSuccess) return psdr::api_fail(std::string("scene scratch serialisation: ") + hipGetErrorString(guard_.err))

@@ -73,6 +73,10 @@ namespace psdr {
 #ifndef PSDR_STEAL_KINDS       // 3: any ray, 2: extension rays only (closest hit wanted), 1: next-event rays only
 #define PSDR_STEAL_KINDS 3
 #endif
+// PSDR_DIAG (instrumented development builds, counted launches only): 8 = phase timers; 11 = census of the burst iterations' lane slots (c_nodes on an inner node, c_tris holding
+// a leaf - sitting the node step out -, c_rays without a ray, c_hits walk ended and waiting for the hand-over); 12 = how often the stack's global tail is in reach (c_tris lanes
+// on a node with fewer than three LDS rows left, c_rays burst iterations with at least one such lane, c_hits all lane slots)
+#define PSDR_DIAG_PLAIN (PSDR_DIAG != 8 && PSDR_DIAG != 11 && PSDR_DIAG != 12)
 constexpr unsigned kFinBusy = 0x80000000u, kFinShared = 0x40000000u, kFinCount = 0x3fffffffu;      // `fin` while a ray is posted / walked: busy flag | walked by more than one worker at some point | walkers
 // BOUND: once a ray is finished the same word holds 1 + the wave's pair sequence number (heads[kHdPairEnq], zeroed per kernel launch), and bit 31 of THAT would read as
 // "busy" for ever: a persistent wave may enqueue fewer than 2^31 (triangle, ray) pairs per launch.  Config 5 at full size reaches ~1e6 per wave (8.9 pairs per ray,
@@ -190,6 +194,17 @@ PSDR_DEV float t4_best_t(const lds_u64_t *best, int rid) {
     return __uint_as_float((unsigned) (__hip_atomic_load(&best[rid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32));
 }
 
+// 1 / d for the slab tests.  The walk only has to be conservative - the boxes are padded by 1e-4 of the coordinate magnitude (bvh.h) and the hit itself comes from
+// tri_test on the parked ray - so the hardware reciprocal (1 ulp, one instruction) does what the IEEE division (a ten-instruction sequence, three per ray) did:
+// +-0 still gives +-inf, NaN stays NaN
+PSDR_DEV Vec3f t4_inv_dir(const Vec3f &d) {
+#ifdef PSDR_T4_IEEE_INV
+    return Vec3f(1.f / d.x, 1.f / d.y, 1.f / d.z);
+#else
+    return Vec3f(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+#endif
+}
+
 // a worker takes ray `rid` from its parked copy: NaN rays miss (reference scene_optix.cpp:348-353)
 template <int LDS, bool COUNT> PSDR_DEV void t4_start(SceneView<LDS> &S, const T4Lds<LDS> &L, Trav4 &tr, int rid) {
     const int owner = rid & 63;
@@ -197,14 +212,14 @@ template <int LDS, bool COUNT> PSDR_DEV void t4_start(SceneView<LDS> &S, const T
     const Vec3f o(q[0], q[kBlock], q[2 * kBlock]), d(q[3 * kBlock], q[4 * kBlock], q[5 * kBlock]);
     tr.rid = rid;
     tr.o = o; tr.d = d;
-    tr.inv = Vec3f(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    tr.inv = t4_inv_dir(d);
     tr.sp = 0; tr.sb = 0;
     tr.last_pair = 0u;
     L.fin[rid] = kFinBusy | 1u;            // one walker
     tr.anyhit = (rid & 64) ? -__builtin_inff() : L.park0[owner + 12 * kBlock];
     const bool ok = (o.x == o.x && o.y == o.y && o.z == o.z && d.x == d.x && d.y == d.y && d.z == d.z);
     tr.code = ok ? 0u : kT4Done;       // node 0 = root
-#if PSDR_DIAG != 8
+#if PSDR_DIAG_PLAIN
     if (COUNT) { if (ok) S.c_rays++; }
 #endif
 }
@@ -287,6 +302,14 @@ template <int LDS, bool COUNT> PSDR_DEV void t4_node(SceneView<LDS> &S, const T4
     {
         const int w = T.nodes_off + kNodeW4 * (int) tr.code;
         n0 = S.ld(w); n1 = S.ld(w + 1); n2 = S.ld(w + 2); n3 = S.ld(w + 3);
+#ifdef PSDR_T_NODE_DUP
+        // measurement build (round 6): the node's four loads issued a second time - same lines, so L1 hits: what one more set of lane-loads per node step costs the
+        // kernel bounds what a cheaper fetch (a quad per node: one instruction per whole node) could give back
+        { const float4 *q = &S.B[w];
+          t4_v4f m0, m1, m2, m3;
+          asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\tglobal_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48\n\ts_waitcnt vmcnt(0)"
+                       : "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(m3) : "v"(q) : "memory"); }
+#endif
     }
     const unsigned ex = __float_as_uint(n0.w);
     const float sx = __uint_as_float((ex & 0xffu) << 23), sy = __uint_as_float(((ex >> 8) & 0xffu) << 23), sz = __uint_as_float(((ex >> 16) & 0xffu) << 23);
@@ -366,7 +389,7 @@ template <int LDS, bool COUNT> PSDR_DEV void t4_test_pairs(SceneView<LDS> &S, co
         const int w = T.trav_off + 3 * slot;
         const float4 a = S.ld(w), b = S.ld(w + 1), c = S.ld(w + 2);
         float u, v, t;
-#if PSDR_DIAG != 8
+#if PSDR_DIAG_PLAIN
         if (COUNT) S.c_tris++;
 #endif
         if (tri_test(a, b, c, o, d, u, v, t)) {
@@ -479,7 +502,7 @@ PSDR_DEV bool trav4_run(SceneView<LDS> &S, Trav4 &tr, int posted, int max_busy) 
                             const Vec3f o(q[0], q[kBlock], q[2 * kBlock]), d(q[3 * kBlock], q[4 * kBlock], q[5 * kBlock]);
                             tr.rid = rid;
                             tr.o = o; tr.d = d;
-                            tr.inv = Vec3f(1.f / d.x, 1.f / d.y, 1.f / d.z);
+                            tr.inv = t4_inv_dir(d);
                             tr.sp = 0; tr.sb = 0;
                             tr.last_pair = 0u;
                             tr.anyhit = (rid & 64) ? -__builtin_inff() : L.park0[owner + 12 * kBlock];
@@ -510,6 +533,11 @@ PSDR_DEV bool trav4_run(SceneView<LDS> &S, Trav4 &tr, int posted, int max_busy) 
             for (;;) {
                 // node step, THEN the leaves - also the ones this step arrived at: a worker whose nearest child is a leaf enqueues it and pops its next
                 // node in the same iteration instead of sitting out the next node step (round 3; a ray meets ~6 leaves on ~19 nodes)
+#if PSDR_DIAG == 11
+                if (COUNT) { if (tr.code >= leaf_bit && tr.code != kT4Done) S.c_tris++; else if (tr.rid < 0) S.c_rays++; else if (tr.code == kT4Done) S.c_hits++; }
+#elif PSDR_DIAG == 12
+                if (COUNT) { const bool deep = tr.code < leaf_bit && tr.sp + 3 > T.stack_lds; if (deep) S.c_tris++; if (__ballot(deep) != 0ull) S.c_rays++; S.c_hits++; }
+#endif
                 if (tr.code < leaf_bit) t4_node<LDS, COUNT>(S, L, tr, cmask);
 #pragma unroll
                 for (int er = 0; er < PSDR_ENQ_ROUNDS; ++er)

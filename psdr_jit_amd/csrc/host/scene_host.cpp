@@ -300,7 +300,12 @@ void Mesh::configure() {
     bool same_values = cfg_valid && cfg_topo == m_topo_version && cfg_raw == vertex_positions_raw, same_tangents = cfg_valid && cfg_d_raw == d_vertex_positions_raw;
     const bool same_raw = same_values, same_d_raw = same_tangents;
     for (int k = 0; k < 3; ++k) { same_values = same_values && cfg_m[k] == *mv[k]; same_tangents = same_tangents && cfg_dm[k] == *md[k]; }
-    if (same_values && same_tangents) { m_ready = true; return; }
+    if (same_values && same_tangents) {
+        // (a mesh loaded with enable_edges = False has no edge list; switched on between two configure() calls it needs one although no value changed)
+        if (m_enable_edges && edges.empty()) build_edges();
+        m_ready = true;
+        return;
+    }
     if (vf_topo != m_topo_version || vf_begin.size() != (size_t) m_num_vertices + 1) build_vertex_faces();
     std::vector<D3> raw(m_num_vertices), world(m_num_vertices);
     for (int v = 0; v < m_num_vertices; ++v)
@@ -710,9 +715,11 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
             std::vector<float> key;
             for (const M16 *m : {&cam->to_world_left, &cam->to_world_raw, &cam->to_world_right, &cam->d_to_world_left, &cam->d_to_world_raw, &cam->d_to_world_right}) key.insert(key.end(), m->begin(), m->end());
             const double extra[] = {(double) cam->m_fov_x, (double) cam->m_near_clip, (double) cam->m_far_clip, cam->m_orthographic ? 1.0 : 0.0, (double) m_opts.width, (double) m_opts.height,
-                                    (double) m_opts.sppe, active ? 1.0 : 0.0, (double) (geo_sum & 0xffffffffull), (double) (geo_sum >> 32), (double) (tan_sum & 0xffffffffull), (double) (tan_sum >> 32),
-                                    (double) (m_layout_version & 0xffffffull)};
+                                    (double) m_opts.sppe, active ? 1.0 : 0.0};
             for (double x : extra) key.push_back((float) x);
+            // the version sums in 16-bit pieces: each is exact as a float (a 32-bit piece is not beyond 2^24, and two sums that round to the same float would keep stale edges)
+            for (uint64_t v : {geo_sum, tan_sum, (uint64_t) m_layout_version})
+                for (int k = 0; k < 4; ++k) key.push_back((float) ((v >> (16 * k)) & 0xffffull));
             if (key != cam->cfg_key || m_opts.sppe <= 0) {
                 cam->configure(*this, active);
                 cam->cfg_key = key;
@@ -1212,7 +1219,14 @@ void Scene::upload() {
         hip_check(psdr_hip_scene_create(&sn, &m_hip));
         hip_check(psdr_hip_scene_last_update(m_hip, &m_last_update));
     } else {
-        hip_check(psdr_hip_scene_update(m_hip, &sn, m_same, &m_last_update));
+        // a failed update leaves the device scene half-written (and poisoned, scene_build.hip): the PSDR_SAME_* bits of the NEXT configure() would be relative to a
+        // snapshot the device never received, so the handle is dropped and the next upload creates the scene again
+        if (psdr_hip_scene_update(m_hip, &sn, m_same, &m_last_update)) {
+            const std::string why = psdr_hip_last_error();
+            release_device();
+            m_same = 0;
+            throw Exception("libpsdr_hip: " + why);
+        }
     }
     m_same = PSDR_SAME_TRIANGLES | PSDR_SAME_TRI_TANGENTS | PSDR_SAME_SEC_EDGES | PSDR_SAME_PRIM_EDGES | PSDR_SAME_ENV_TEXELS | PSDR_SAME_ENV_TANGENT | PSDR_SAME_BITMAPS;
     m_configured = true;

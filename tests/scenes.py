@@ -200,6 +200,10 @@ def config5_scene(width=128, height=128, spp=4, sppe=4, sppse=4, level=6, env_re
     cam = CameraSpec(60.0, 0.000001, 10000000.0, to_world_raw=translate(278.0, 400.0, -700.0) @ _rot_x(np.radians(25.0)))
     if param == "albedo":
         bsdfs[0].d_reflectance = (1.0, 1.0, 1.0)
+    elif param == "blob_x":              # the mesh itself moves: every vertex, every edge (the shape-optimisation case; both boundary terms are non-zero)
+        dT = np.zeros((4, 4), dtype=np.float32)
+        dT[0, 3] = 100.0
+        blob.d_to_world_left = dT
     elif param is not None:
         raise ValueError(param)
     return SceneSpec(meshes, bsdfs, emitters, [cam], width, height, spp, sppe, sppse)

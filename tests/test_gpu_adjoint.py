@@ -520,6 +520,66 @@ def test_first_hit_sweep_is_the_same_in_every_run(env, monkeypatch):
                 assert err <= 1e-5, (field, run, k, err)
 
 
+_EVERY_RUN = {
+    # scene, depth: one per reverse kernel family (the scene class picks the kernel, api.hip::psdr_hip_render_d_bwd)
+    "class1_lds": (lambda: scenes.cbox_scene(40, 40, 8, 8, 8, param="box_x"), 3),                            # k_interior_adjoint<1>, k_paths<false,1,.,1> with weights, k_secondary_edges<1,.,true>
+    "class2_bvh": (lambda: scenes.sphere_scene(40, 40, 8, 8, 8), 3),                                           # the class-2 unit (records in global memory) and the BVH edge kernels
+    "class2_env": (lambda: scenes.envmap_scene(40, 40, 8, 8, 8, param="box_x", area_light=True, balls=True), 3),     # ... with environment lookups on record
+    "material_sweep": (lambda: scenes.microfacet_cbox_scene(40, 40, 8, 8, 8, param="roughness"), 3),          # adjoint_mat.h (class 0 / 3)
+    "normalmap": (lambda: scenes.normalmap_scene(40, 40, 8, 8, 8, param="box_x", nested="microfacet", nmap="bumpy"), 2),
+}
+
+
+@pytest.mark.parametrize("family", list(_EVERY_RUN))
+def test_every_adjoint_kernel_is_the_same_in_every_run(env, family):
+    """The allocator defect of LABNOTES section 4 (a vector instruction ahead of a join block's exec restore) leaves lanes with stale registers; persistent waves deal the
+    samples to other lanes in every launch, so it shows as RUN-TO-RUN variation.  isa_lint.py looks for the pattern in the ISA; this is the runtime side of the same guard,
+    for every reverse kernel family and all three terms: ten launches of psdr_hip_render_d_bwd on one scene, every buffer against the first launch (float atomics reorder
+    sums: 1e-5 of a buffer's L1 norm; a stale register showed as 1e-3 and more)"""
+    torch, psdr, cabi = env
+    make, depth = _EVERY_RUN[family]
+    spec = make()
+    sc = product.build_scene(spec)
+    snap = sc._snapshot()
+    n_tris = np.asarray(snap["d_triangles"]).shape[0]
+    n_sec = np.asarray(snap["d_sec_edges"]).shape[0]
+    n_prim = np.asarray(sc.param_map["Sensor[0]"]._primary_edges(True)).shape[0]
+    n_b = len(snap["bsdf_rows"]) if "bsdf_rows" in snap else len(spec.bsdfs)
+    offs = (C.c_int64 * (3 * max(1, n_b)))(); total = C.c_int64(0)
+    cabi.check(cabi.lib().psdr_hip_scene_tex_layout(C.c_void_p(sc._hip_handle()), offs, C.byref(total)))
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    w = (torch.rand((spec.width * spec.height, 3), generator=gen) + 0.5).to("cuda")
+    env_em = [e for e in spec.emitters if getattr(e, "type", 0) == 1]
+
+    def launch(terms):
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device="cuda")
+        out = {"tri": z(n_tris, 22), "bsdf": z(max(1, n_b), 3), "emitter": z(max(1, len(spec.emitters)), 3), "sec": z(max(1, n_sec), 6), "prim": z(max(1, n_prim), 4),
+               "camera": z(16), "mat": z(max(1, n_b), 16), "tex": z(max(1, total.value))}
+        g = cabi.Grads(out["tri"].data_ptr(), out["bsdf"].data_ptr(), out["emitter"].data_ptr(), out["sec"].data_ptr(), out["prim"].data_ptr())
+        g.g_camera, g.g_mat = out["camera"].data_ptr(), out["mat"].data_ptr()
+        if total.value > 0:
+            g.g_tex = out["tex"].data_ptr()
+        if env_em:
+            H, W = env_em[0].env_data.shape[:2]
+            out["env"], out["env_scale"], out["env_xf"] = z(H * W * 3), z(1), z(16)
+            g.g_env, g.g_env_scale, g.g_env_from_world = out["env"].data_ptr(), out["env_scale"].data_ptr(), out["env_xf"].data_ptr()
+        a = cabi.make_args(max_depth=depth, seeds=(7, 8, 9), terms=terms)
+        cabi.check(cabi.lib().psdr_hip_render_d_bwd(sc._hip_handle(), C.byref(a), w.data_ptr(), C.byref(g), None))
+        torch.cuda.synchronize()
+        return {k: v.cpu().numpy().astype(np.float64) for k, v in out.items()}
+
+    for terms in (1, 2, 4):
+        first = launch(terms)
+        if terms == 1:
+            assert any(np.abs(v).sum() > 0 for v in first.values()), (family, terms)
+        for run in range(9):
+            again = launch(terms)
+            for k in first:
+                ref = np.abs(first[k]).sum()
+                err = np.abs(again[k] - first[k]).sum() / (ref + 1e-12) if ref > 0.0 else np.abs(again[k]).sum()
+                assert err <= 1e-5, (family, terms, run, k, err)
+
+
 @pytest.mark.parametrize("family,kw", [("cbox", {}), ("cbox_camera", {"with_camera": True}), ("microfacet", {"with_mat": True}), ("conductor", {"with_mat": True}),
                                        ("textured_microfacet", {"with_mat": True}), ("pervertex", {"with_mat": True}), ("normalmap", {"with_mat": True}), ("sphere", {})])
 def test_first_hit_integrators_reverse_mode_against_the_oracle(env, orc, family, kw):

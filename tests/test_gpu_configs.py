@@ -36,10 +36,10 @@ def env():
     return torch, psdr_jit_amd, cabi
 
 
-def _render_d(env, sc, n_pix, depth, seeds, rank=0, count=1, terms=7, guiding=None):
+def _render_d(env, sc, n_pix, depth, seeds, rank=0, count=1, terms=7, guiding=None, skip_static_edges=False):
     torch, _, cabi = env
     buf = torch.empty((2, n_pix, 3), dtype=torch.float32, device="cuda")
-    a = cabi.make_args(max_depth=depth, seeds=seeds, terms=terms, shard_rank=rank, shard_count=count, guiding=guiding)
+    a = cabi.make_args(max_depth=depth, seeds=seeds, terms=terms, shard_rank=rank, shard_count=count, guiding=guiding, skip_static_edges=skip_static_edges)
     cabi.check(cabi.lib().psdr_hip_render_d_fwd(sc._hip_handle(), C.byref(a), buf[0].data_ptr(), buf[1].data_ptr(), None))
     torch.cuda.synchronize()
     return buf.cpu().numpy()
@@ -110,7 +110,7 @@ def test_primary_edge_samples_that_cannot_contribute_are_not_traced(env, scene):
     assert abs(lhs - rhs) <= 2e-4 * max(abs(lhs), 1e-12), (lhs, rhs)
 
 
-def _oracle_pinned_backward(env, orc_mod, sc, spec, ref, depth, seeds, rank, count, guiding=None, guiding_ref=None, tol=TOL):
+def _oracle_pinned_backward(env, orc_mod, sc, spec, ref, depth, seeds, rank, count, guiding=None, guiding_ref=None, tol=TOL, prim_filter=False):
     """reverse mode against the ORACLE on one shard, per term:  <w, d_img>  with d_img from the oracle's forward-mode render_d  ==  <J^T w, v>  with J^T w the buffers of
     psdr_hip_render_d_bwd on the same lanes and seeds and v the configured snapshot's tangent rows - no HIP forward kernel takes part"""
     torch, _, cabi = env
@@ -135,6 +135,10 @@ def _oracle_pinned_backward(env, orc_mod, sc, spec, ref, depth, seeds, rank, cou
         g_tri, g_bsdf, g_em = z(d_tri.shape[0], 22), z(max(1, len(spec.bsdfs)), 3), z(max(1, len(spec.emitters)), 3)
         g_sec, g_prim = z(max(1, d_sec.shape[0]), 6), z(max(1, d_prim.shape[0]), 4)
         g = cabi.Grads(g_tri.data_ptr(), g_bsdf.data_ptr(), g_em.data_ptr(), g_sec.data_ptr(), g_prim.data_ptr())
+        if prim_filter:
+            # psdr_grads.prim_edge_filter: only the rows of the edges that move are wanted (what the host core asks for); the oracle still traces every sample
+            moving = torch.from_numpy((np.abs(d_prim).sum(axis=1) > 0).astype(np.uint8)).to("cuda")
+            g.prim_edge_filter = moving.data_ptr()
         a = cabi.make_args(max_depth=depth, seeds=seeds, terms=terms, shard_rank=rank, shard_count=count, guiding=guiding)
         cabi.check(cabi.lib().psdr_hip_render_d_bwd(sc._hip_handle(), C.byref(a), wg.data_ptr(), C.byref(g), None))
         torch.cuda.synchronize()
@@ -152,6 +156,9 @@ def test_config3_backward_against_the_oracle(env, orc):
     sc = product.build_scene(spec)
     ref = orc.OracleScene(spec, [0])
     res = _oracle_pinned_backward(env, orc, sc, spec, ref, 3, (7, 7, 7), 5, 64)
+    # the same with the work-elimination switch of reverse mode (rows of static edges not wanted -> their samples not traced): the oracle's number does not change
+    res_f = _oracle_pinned_backward(env, orc, sc, spec, ref, 3, (7, 7, 7), 5, 64, prim_filter=True)
+    assert abs(res_f[orc.TERM_PRIMARY][1] - res[orc.TERM_PRIMARY][1]) <= 1e-5 * res[orc.TERM_PRIMARY][2], (res, res_f)
     # (the interior term of a translated luminaire is zero in this estimator - positions on emitters are detached, path.cpp:47-83 -, on both sides; the edges carry the motion)
     assert abs(res[orc.TERM_PRIMARY][0]) > 1e-6 and abs(res[orc.TERM_SECONDARY][0]) > 1e-6 and res[orc.TERM_INTERIOR][2] < 1e-6, res
 
@@ -180,10 +187,35 @@ def test_config3_full_size_shard(env, orc):
     wimg, wd = ref.render_d(max_depth=3, seeds=(7, 7, 7), shard_rank=5, shard_count=64)
     assert np.isfinite(got).all()
     assert product.rel_l2(got[0], wimg) < TOL and product.rel_l2(got[1], wd) < TOL
+    # the work-elimination switch of forward mode against the ORACLE (which traces every sample): primary-edge samples on edges that do not move add exactly zero
+    skipped = _render_d(env, sc, 512 * 512, 3, (7, 7, 7), rank=5, count=64, skip_static_edges=True)
+    assert product.rel_l2(skipped[0], wimg) < TOL and product.rel_l2(skipped[1], wd) < TOL
     # and the shards of a frame add up to the frame (what the all-reduce relies on), at full size
     full = _render_d(env, sc, 512 * 512, 3, (7, 7, 7))
     parts = sum(_render_d(env, sc, 512 * 512, 3, (7, 7, 7), rank=r, count=4) for r in range(4))
     assert product.rel_l2(parts[0], full[0]) < 1e-5 and product.rel_l2(parts[1], full[1]) < 1e-4
+
+
+def test_forked_terms_do_not_share_the_stack_tail(env, monkeypatch):
+    """The three terms of a renderD on a BVH scene run as concurrent launches on forked streams (api.hip::render_impl).  The global tail of the traversal stack is
+    indexed by workgroup and thread only, so each forked term needs a slice of its own (round 6; until then workgroups with the same index in two launches wrote each
+    other's entries whenever a walk went deeper than the LDS rows).  PSDR_STACK_LDS=2 sends nearly every walk of the 82 k-triangle mesh to the tail; the forked call
+    must return what the three terms return one after the other (PSDR_NO_FORK), sample for sample - 4 samples per pixel, so one lost subtree is ~1e-4 of the frame"""
+    torch, psdr, cabi = env
+    monkeypatch.setenv("PSDR_STACK_LDS", "2")
+    spec = scenes.config5_scene(96, 96, 4, 4, 4, level=6, env_res=(256, 128), param="blob_x")
+    sc = product.build_scene(spec)
+    monkeypatch.delenv("PSDR_STACK_LDS")
+    nn, nl, md, lb = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    cabi.check(cabi.lib().psdr_hip_scene_stats(C.c_void_p(sc._hip_handle()), C.byref(nn), C.byref(nl), C.byref(md), C.byref(lb)))
+    assert md.value > 4
+    monkeypatch.setenv("PSDR_NO_FORK", "1")
+    serial = _render_d(env, sc, 96 * 96, 3, (5, 6, 7))
+    monkeypatch.delenv("PSDR_NO_FORK")
+    for run in range(5):
+        forked = _render_d(env, sc, 96 * 96, 3, (5, 6, 7))
+        assert np.abs(serial[1]).max() > 0
+        assert product.rel_l2(forked[0], serial[0]) < 2e-6 and product.rel_l2(forked[1], serial[1]) < 2e-5, run
 
 
 def test_config1_exact_size(env, orc):

@@ -23,7 +23,7 @@ TOL = 1e-4
 def env():
     import torch
     if not torch.cuda.is_available():
-        pytest.skip("needs a GPU")
+        pytest.fail("GPU tests need a visible MI355X (no CPU fallback exists)")
     import psdr_jit_amd as psdr
     from psdr_jit_amd import cabi
     return torch, psdr, cabi

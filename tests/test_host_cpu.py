@@ -139,6 +139,21 @@ def test_incremental_configure_equals_a_fresh_scene(psdr, name):
     sc._configure_host([0]); fresh()
 
 
+def test_enable_edges_switched_on_between_two_configures(psdr):
+    """a mesh loaded with enable_edges = False has no edge list (Mesh::load_raw builds one only when the flag is set); switched on after a configure() - nothing else
+    changed, so Mesh::configure takes its same-inputs return - it must still get its edges: the snapshot then equals that of a scene whose mesh had them from the start
+    (round 5's early return sat in front of build_edges: the sensor's reconfigure then tripped on an empty edge list, or the mesh silently had no secondary edges)"""
+    spec = scenes.cbox_scene(24, 24, 4, 4, 4, param="light_x")
+    want = product.build_scene(spec, host_only=True)
+    spec.meshes[1].enable_edges = False
+    sc = product.build_scene(spec, host_only=True)
+    assert np.asarray(sc._snapshot()["sec_edges"]).shape[0] < np.asarray(want._snapshot()["sec_edges"]).shape[0]
+    sc.param_map["Mesh[1]"].enable_edges = True
+    sc._configure_host([0])
+    spec.meshes[1].enable_edges = True
+    _snap_equal(sc, want)
+
+
 @pytest.mark.parametrize("name", ["cbox", "sphere"])
 def test_native_chain_rule_equals_the_autograd_restatement(psdr, name):
     """Scene::chain_geometry (host C++: from the adjoints of the snapshot's triangle / edge rows to mesh transforms, raw vertices and the camera pose) against

@@ -1,5 +1,5 @@
 """Per-term renderD timings of a named test scene (tests/scenes.py) at the C3 settings: 512x512, spp = sppe = sppse = 32, depth 3.
-    python tools/bench_scene.py sphere|cbox|envballs|microfacet|conductor|bunny [--skip]"""
+    python tools/bench_scene.py sphere|cbox|envballs|microfacet|conductor|bunny [--skip] [--terms-only]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -21,7 +21,8 @@ integ = psdr.PathTracer(3)
 # every primary-edge sample traced, as the reference does and as rounds 1-4 measured (Integrator.trace_static_edges; "--skip": the public surface's default, which
 # drops the samples on edges that do not move under the scene's tangent - psdr_render_args.skip_static_edges)
 integ.trace_static_edges = "--skip" not in sys.argv
-for terms, label in ((1, "interior"), (2, "primary"), (4, "secondary"), (7, "all")):
+# "--terms-only": the three terms alone, no combined call (the profiler passes: one kind of launch per kernel)
+for terms, label in ((1, "interior"), (2, "primary"), (4, "secondary")) + ((() if "--terms-only" in sys.argv else ((7, "all"),))):
     psdr.render_d_fwd(integ, sc, 0, seed=1, terms=terms); torch.cuda.synchronize()
     t0 = time.time()
     for i in range(5): psdr.render_d_fwd(integ, sc, 0, seed=i, terms=terms)

@@ -108,9 +108,17 @@ def bench_name(k):
 
 def write_counters_json(tag, per, traffic, section=None, workload=None):
     db = db_of("prof_kt")
-    avg_us = {}
+    avg_us, refused = {}, {}
     if db is not None:
+        spread = {short(r[0]): (r[1], r[2]) for r in db.execute("select name, min(duration), max(duration) from kernels group by name")}
         for name, avg in db.execute("select name, average from top_kernels"):
+            mn, mx = spread.get(short(name), (0, 0))
+            # a kernel whose launches differ by more than 10 % in one pass is not ONE kind of launch (launches that overlap on forked streams, skipping next to
+            # non-skipping ones, a warm-up of another size): its average is no per-launch duration, and nothing is derived from it
+            if mn > 0 and mx > 1.10 * mn:
+                refused[short(name)] = "min %.1f us, max %.1f us: launches of this pass differ by more than 10 %%, no per-launch duration taken" % (mn / 1e3, mx / 1e3)
+                sys.stderr.write("prof_summary: %s refused (%s)\n" % (short(name), refused[short(name)]))
+                continue
             avg_us[short(name)] = avg
     out = {"source": "profiles/%s_pmc_summary.txt + profiles/%s_kernel_trace_stats.txt (rocprofv3 --pmc / --kernel-trace --stats passes, tools/profile.sh)" % (tag, tag), "kernels": {}}
     if workload:
@@ -129,6 +137,8 @@ def write_counters_json(tag, per, traffic, section=None, workload=None):
             rec["l2_hit_rate"] = h / (h + m)
         if k in avg_us:
             rec["avg_launch_us"] = avg_us[k]
+        if k in refused:
+            rec["avg_launch_us_refused"] = refused[k]
         if iv is not None and k in avg_us:
             slots = 1024 * 2.4e9 / 2.0 * avg_us[k] * 1e-6          # 1024 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz
             rec["issue"] = {"SQ_INSTS_VALU": iv, "avg_launch_us": avg_us[k], "valu_issue_slots": slots, "valu_issue_frac": iv / slots,

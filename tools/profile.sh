@@ -7,7 +7,9 @@
 #   bwd_     reverse mode on C3 alone (tools/bwd_only.py c3)
 #   c5_      BASELINE config 5 at full size (bench.py --config 5: 1024 x 1024, 64 / 64 / 64, guiding grid)
 #   c5bwd_   reverse mode on config 5 at full size with its guiding grid (tools/bwd_only.py c5: 1024 x 1024 x 64)
-#   sph_     the sphere tutorial box at depth 3 (tools/bench_scene.py sphere)
+#   sph_     the sphere tutorial box at depth 3 (tools/bench_scene.py sphere --terms-only: one term per launch, every sample traced)
+# The config-5 and sphere passes run with PSDR_NO_FORK=1: the three terms of a renderD one after the other instead of on forked streams, so that a kernel's
+# duration in the trace is its own (overlapping launches each show the whole call's time); bench.py's own numbers are taken WITH the fork.
 set -u
 REPO=$(pwd)
 OUT=$REPO/gpurun_out
@@ -24,9 +26,9 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SME
 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA -d $OUT/prof_sq2 -- $BENCH > $OUT/prof_sq2.log 2>&1
 cd $REPO
 bash tools/profile_cmd.sh bwd python tools/bwd_only.py c3 5
-bash tools/profile_cmd.sh c5 python bench.py --config 5 --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-backward --no-roofline --no-api --no-static-skip
+PSDR_NO_FORK=1 bash tools/profile_cmd.sh c5 python bench.py --config 5 --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-backward --no-roofline --no-api --no-static-skip
 bash tools/profile_cmd.sh c5bwd python tools/bwd_only.py c5 2 1024 64
-bash tools/profile_cmd.sh sph python tools/bench_scene.py sphere
+PSDR_NO_FORK=1 bash tools/profile_cmd.sh sph python tools/bench_scene.py sphere --terms-only
 python tools/bench_scene.py sphere --skip > $OUT/sphere_skip.log 2>&1
 # the databases travel back through gpurun_out (64 MiB): keep the *_results.db files only
 find $OUT -name "*.csv" -size +2M -delete 2> /dev/null
