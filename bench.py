@@ -232,15 +232,31 @@ def main():
     buf = torch.empty((2, npx, 3), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
-    def launch(seed, terms=7, shard_rank=rank, shard_count=world, zero=True, out=buf, skip_static=False):
+    def launch(seed, terms=7, shard_rank=rank, shard_count=world, zero=True, out=buf, skip_static=False, shard_mode=0):
         a = cabi.make_args(max_depth=DEPTH, seeds=(seed, seed, seed), terms=terms, shard_rank=shard_rank, shard_count=shard_count, zero_output=zero, guiding=guiding,
-                           skip_static_edges=skip_static)
+                           skip_static_edges=skip_static, shard_mode=shard_mode)
         cabi.check(L.psdr_hip_render_d_fwd(handle, C.byref(a), out[0].data_ptr(), out[1].data_ptr(), stream))
 
     single_collective = os.environ.get("PSDR_SINGLE_COLLECTIVE", "0") == "1"
     edge = torch.empty((2, npx, 3), dtype=torch.float32, device="cuda") if use_dist else None
 
+    rows_timed = os.environ.get("PSDR_SHARD", "interleaved").lower() == "rows"       # the partition of the timed region (psdr_jit_amd._shard_mode)
+    tile = psdr._row_tile(npx, res, world, False) if use_dist else 0
+
+    def step_rows(i):
+        # PSDR_SHARD=rows, BASELINE north_star's partition: contiguous pixel-row tiles - the interior term is assembled by all_gather_into_tensor (1 / N of the bytes per
+        # rank, started under the edge kernels), the edge terms' derivative (contiguous lane runs) is summed
+        launch(i, terms=1, shard_mode=1)
+        done = psdr._gather_tiles(buf, npx, tile, world, async_op=True)
+        launch(i, terms=6, out=edge, shard_mode=1)
+        dist.all_reduce(edge[1], op=dist.ReduceOp.SUM)
+        full = done()
+        full[1] += edge[1]
+        return full
+
     def step(i, single=None):
+        if use_dist and rows_timed and single is None:
+            return step_rows(i)
         # N > 1: the form psdr_jit_amd._render_terms uses - the interior term (disjoint pixels per rank, first to finish) goes into its own all_reduce, which RCCL's
         # stream runs under the edge kernels; only the edge terms' derivative is reduced after them.  PSDR_SINGLE_COLLECTIVE=1: rounds 1-4's one all_reduce of everything.
         if not use_dist:
@@ -300,13 +316,33 @@ def main():
                 step(6001 + i, single=flag)
             sync()
             form_ms[name] = (time.perf_counter() - t_f) / reps * 1e3
-        mine = torch.tensor([acc[0] / reps, acc[1] / reps], dtype=torch.float64, device="cuda")
+        # ... and the contiguous row-tile partition (render times per rank show its balance, the step its all-gather)
+        rows_acc = 0.0
+        for i in range(reps):
+            sync()
+            ev[0].record()
+            launch(7000 + i, shard_mode=1)
+            ev[1].record()
+            torch.cuda.synchronize()
+            rows_acc += ev[0].elapsed_time(ev[1])
+        step_rows(7100)
+        sync()
+        t_f = time.perf_counter()
+        for i in range(reps):
+            step_rows(7101 + i)
+        sync()
+        form_ms["rows"] = (time.perf_counter() - t_f) / reps * 1e3
+        mine = torch.tensor([acc[0] / reps, acc[1] / reps, rows_acc / reps], dtype=torch.float64, device="cuda")
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         breakdown = {"render_ms_per_rank": [round(float(t[0]), 3) for t in allr], "allreduce_ms_per_rank": [round(float(t[1]), 3) for t in allr],
                      "all_reduce_bytes": int(buf.numel() * 4),
                      "step_ms_split_collectives": round(form_ms["split"], 3), "step_ms_single_collective": round(form_ms["single"], 3),
-                     "overlap_ms": round(form_ms["single"] - form_ms["split"], 3), "timed_form": "single" if single_collective else "split",
+                     "overlap_ms": round(form_ms["single"] - form_ms["split"], 3), "timed_form": "rows" if rows_timed else ("single" if single_collective else "split"),
+                     "row_tiles": {"render_ms_per_rank": [round(float(t[2]), 3) for t in allr], "step_ms": round(form_ms["rows"], 3), "all_gather_bytes_per_rank": int(2 * tile * 3 * 4),
+                                   "all_reduce_bytes": int(npx * 3 * 4),
+                                   "note": "PSDR_SHARD=rows: contiguous pixel-row tiles (psdr_render_args.shard_mode 1), interior term by all_gather_into_tensor, edge derivative by all_reduce; "
+                                           "render_ms_per_rank shows the balance of the tiles against the interleaved chunks above"},
                      "note": "HIP events on the launch stream, mean of %d steps outside the timed region; a rank's all-reduce time includes its wait for the slowest rank's render; "
                              "the interior tiles of the ranks are disjoint, the edge terms scatter over the frame - the whole [image | derivative] buffer is summed" % reps}
     samples_per_step = float(npx) * spp                  # spp x pixels of the whole job

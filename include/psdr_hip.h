@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PSDR_HIP_ABI_VERSION 14
+#define PSDR_HIP_ABI_VERSION 15
 
 /* TriangleInfo SoA, reference include/psdr/types.h:162-175 (+ Scene::m_triangle_uv,
  * m_triangle_face_normals, scene.cpp:528-542).  Arrays of n_triangles rows. */
@@ -176,6 +176,8 @@ typedef struct psdr_sampler {
 } psdr_sampler;
 
 #define PSDR_SHARD_CHUNK 256
+#define PSDR_SHARD_INTERLEAVED 0
+#define PSDR_SHARD_ROWS 1
 
 #define PSDR_TERM_INTERIOR  1
 #define PSDR_TERM_PRIMARY   2
@@ -207,6 +209,11 @@ typedef struct psdr_render_args {
                                      tangents (an edge of a mesh that does not move, a camera that does not move) is not traced - its contribution to out_drgb is
                                      d(x.n) x (Ln - Lp) / pdf = exactly 0 (integrator.cpp:179-198), so the same numbers are added to the derivative image; 0 = every sample's
                                      two paths are traced, as the reference does */
+    int32_t shard_mode;           /* multi-GPU partition of every sampler's lanes over shard_count ranks (ABI 15): PSDR_SHARD_INTERLEAVED (0) = the chunks k % c == r above;
+                                     PSDR_SHARD_ROWS (1) = CONTIGUOUS ranges - the interior sampler by whole pixel rows (rank r renders rows [r R, (r + 1) R), R = ceil(H / c):
+                                     one block of the image per rank, which an all-gather assembles; batch rendering: by whole pixels of the list), the two edge samplers by
+                                     equal runs of whole PSDR_SHARD_CHUNK-lane chunks.  Every lane's random stream is a function of (seed, lane), so both partitions add up to
+                                     the same frame; the reference's nearest hook is batch_pix (integrator.cpp:139-176) */
 } psdr_render_args;
 
 /* counters of the instrumented build: filled by psdr_hip_render_*_counted */

@@ -175,6 +175,7 @@ int orc_render_d(const orc_scene *s, int sensor_id, int max_depth, int hide_emit
                  const orc_sampler samplers[3], const int *pix_ids, int n_pix,
                  const orc_guiding *guiding, int terms,
                  int shard_rank, int shard_count,   /* 256-lane chunks k with k % c == r of each sampler; c<=1 = all */
+                 int shard_mode,                    /* 0: the interleaved chunks above; 1: contiguous runs (pixel-row tiles; psdr_render_args.shard_mode) */
                  float *out_rgb, float *out_drgb);
 
 /* per-lane radiance of the interior term (debug/parity aid): out [n_lanes*3] */

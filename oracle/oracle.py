@@ -230,7 +230,7 @@ def lib():
                                    C.c_int64, C.c_int64, C.c_void_p]
         L.orc_render_c.restype = C.c_int
         L.orc_render_d.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(_Sampler), C.c_void_p, C.c_int,
-                                   C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+                                   C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_render_d.restype = C.c_int
         L.orc_li_lanes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _Sampler, C.c_int64, C.c_int64, C.c_void_p]
         L.orc_li_lanes.restype = C.c_int
@@ -529,7 +529,7 @@ class OracleScene:
         return out
 
     def render_d(self, sensor=0, max_depth=1, hide_emitters=False, seeds=(0, 0, 0), skips=(0, 0, 0), pix_ids=None,
-                 guiding=None, terms=TERM_ALL, shard_rank=0, shard_count=1):
+                 guiding=None, terms=TERM_ALL, shard_rank=0, shard_count=1, shard_mode=0):
         pid = _i32(pix_ids) if pix_ids is not None else None
         n = self._npix(pix_ids)
         out = np.zeros((n, 3), dtype=np.float32)
@@ -537,7 +537,7 @@ class OracleScene:
         sm = (_Sampler * 3)(*[_Sampler(int(seeds[i]), int(skips[i])) for i in range(3)])
         rc = lib().orc_render_d(self._h, sensor, max_depth, int(hide_emitters), sm,
                                 pid.ctypes.data if pid is not None else None, n,
-                                guiding._h if guiding is not None else None, terms, shard_rank, shard_count,
+                                guiding._h if guiding is not None else None, terms, shard_rank, shard_count, shard_mode,
                                 out.ctypes.data, dout.ctypes.data)
         if rc:
             raise RuntimeError(lib().orc_last_error().decode())

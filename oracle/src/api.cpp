@@ -184,11 +184,21 @@ int orc_li_lanes(const orc_scene *s, int sensor_id, int max_depth, int hide, orc
 }
 
 // ---------------------------------------------------------------- renderD
-// multi-GPU sharding of the product: rank r of c owns the 256-lane chunks k with k % c == r
-static inline bool in_shard(int64_t lane, int rank, int count) { return count <= 1 || ((lane / 256) % count) == rank; }
+// multi-GPU sharding of the product (include/psdr_hip.h, psdr_render_args.shard_mode): 0 = rank r of c owns the 256-lane chunks k with k % c == r; 1 = contiguous runs of whole
+// `unit` lanes (a pixel row of the interior sampler, a pixel of a batch list, a 256-lane chunk of an edge sampler): rank r owns units [r U, (r + 1) U), U = ceil(units / c)
+struct Shard {
+    int rank, count, mode; int64_t per;
+    Shard(int r, int c, int m, int64_t n_lanes, int64_t unit) : rank(r), count(c), mode(m), per(0) {
+        if (count > 1 && mode == 1) { const int64_t n_units = (n_lanes + unit - 1) / unit; per = ((n_units + count - 1) / count) * unit; }
+    }
+    bool has(int64_t lane) const {
+        if (count <= 1) return true;
+        return mode == 1 ? (lane >= rank * per && lane < (rank + 1) * per) : ((lane / 256) % count) == rank;
+    }
+};
 
 int orc_render_d(const orc_scene *s, int sensor_id, int max_depth, int hide, const orc_sampler samplers[3], const int *pix_ids, int n_pix,
-                 const orc_guiding *guiding, int terms, int shard_rank, int shard_count, float *out, float *dout) {
+                 const orc_guiding *guiding, int terms, int shard_rank, int shard_count, int shard_mode, float *out, float *dout) {
     const Scene &sc = *s->sc;
     if (sensor_id < 0 || sensor_id >= (int) sc.cameras.size()) { g_err = "Invalid sensor id!"; return 1; }
     const CameraC &cam = sc.cameras[sensor_id];
@@ -201,11 +211,12 @@ int orc_render_d(const orc_scene *s, int sensor_id, int max_depth, int hide, con
     if ((terms & ORC_TERM_INTERIOR) && sc.spp > 0) {
         const int64_t lb = 0, le = npx * sc.spp;
         const int64_t px0 = 0, px1 = npx;
+        const Shard shard(shard_rank, shard_count, shard_mode, le, pix_ids ? (int64_t) sc.spp : (int64_t) sc.width * sc.spp);
 #pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads)
         for (int64_t px = px0; px < px1; ++px) {
             float acc[3] = {0, 0, 0}, dacc[3] = {0, 0, 0};
             for (int64_t lane = std::max(px * sc.spp, lb); lane < std::min((px + 1) * sc.spp, le); ++lane) {
-                if (!in_shard(lane, shard_rank, shard_count)) continue;
+                if (!shard.has(lane)) continue;
                 V3d v = interior_lane<true>(sc, cam, max_depth, hide != 0, samplers[0], pix_ids, lane);
                 for (int c = 0; c < 3; ++c) {
                     // the reference masks value where the primal is non-finite (integrator.cpp:126)
@@ -231,12 +242,13 @@ int orc_render_d(const orc_scene *s, int sensor_id, int max_depth, int hide, con
     // primary edges (integrator.cpp:179-198)
     if ((terms & ORC_TERM_PRIMARY) && sc.sppe > 0 && cam.enable_edges) {
         const int64_t lb = 0, le = npx * sc.sppe;
+        const Shard shard(shard_rank, shard_count, shard_mode, le, 256);
         for (int64_t c0 = lb; c0 < le; c0 += CH) {
             int64_t c1 = std::min(c0 + CH, le);
 #pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads)
             for (int64_t lane = c0; lane < c1; ++lane) {
                 idx[lane - c0] = -1;
-                if (!in_shard(lane, shard_rank, shard_count)) continue;
+                if (!shard.has(lane)) continue;
                 LaneSampler sm;
                 seed_lane(sm, samplers[1], nullptr, 1, lane);
                 PrimaryEdgeSample es = sample_primary_edge(sc, cam, sm.next_1d());
@@ -262,12 +274,13 @@ int orc_render_d(const orc_scene *s, int sensor_id, int max_depth, int hide, con
     // secondary edges (path.cpp:274-294)
     if ((terms & ORC_TERM_SECONDARY) && sc.field < 0 && sc.sppse > 0 && !sc.sec_edges.empty()) {
         const int64_t lb = 0, le = npx * sc.sppse;
+        const Shard shard(shard_rank, shard_count, shard_mode, le, 256);
         for (int64_t c0 = lb; c0 < le; c0 += CH) {
             int64_t c1 = std::min(c0 + CH, le);
 #pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads)
             for (int64_t lane = c0; lane < c1; ++lane) {
                 idx[lane - c0] = -1;
-                if (!in_shard(lane, shard_rank, shard_count)) continue;
+                if (!shard.has(lane)) continue;
                 LaneSampler sm;
                 seed_lane(sm, samplers[2], nullptr, 1, lane);
                 V3f s3;

@@ -943,6 +943,39 @@ def _all_reduce(t, distributed):
     return t
 
 
+def _shard_mode():
+    """the partition of every sampler's lanes over the ranks (psdr_render_args.shard_mode, include/psdr_hip.h): PSDR_SHARD=rows = contiguous runs - pixel-row tiles of the
+    interior term, which an all-gather then assembles (BASELINE north_star's partition); anything else = interleaved 256-lane chunks (balanced whatever the image)"""
+    return 1 if _os.environ.get("PSDR_SHARD", "interleaved").lower() == "rows" else 0
+
+
+def _row_tile(n, width, world, batch):
+    """pixels per rank of the contiguous partition (api.hip::shard_run): whole pixel rows of a full frame (`width` pixels each), whole pixels of a batch list"""
+    unit = 1 if batch else width
+    n_units = (n + unit - 1) // unit
+    return ((n_units + world - 1) // world) * unit
+
+
+def _gather_tiles(buf, n, tile, world, async_op=False):
+    """[2, n, 3] buffers whose rank-r rows [r tile, (r + 1) tile) are final -> the whole buffers on every rank: all_gather_into_tensor of 1 / world each (the interior
+    term under PSDR_SHARD=rows; an all_reduce would move the full buffer for data that is disjoint by construction).  async_op: returns a function that waits and
+    returns the assembled [2, n, 3] buffer"""
+    import torch.distributed as dist
+    rank = dist.get_rank()
+    pad = tile * world
+    mine = _torch.zeros((2, tile, 3), dtype=buf.dtype, device=buf.device)
+    lo, hi = min(n, rank * tile), min(n, (rank + 1) * tile)
+    mine[:, :hi - lo] = buf[:, lo:hi]
+    full = _torch.empty((2, pad, 3), dtype=buf.dtype, device=buf.device)
+    works = [dist.all_gather_into_tensor(full[k], mine[k], async_op=True) for k in range(2)]          # (image and derivative are separate slabs)
+
+    def finish():
+        for w in works:
+            w.wait()
+        return full[:, :n]
+    return finish if async_op else finish()
+
+
 # ------------------------------------------------------------------ Integrator.renderC / renderD
 def _renderC(self, scene, sensor_id=0, seed=-1, batch_pix=-1, distributed=None):
     """Integrator.renderC (reference integrator.cpp:12-48): float32 [n_pixels, 3], pixel = y*W + x."""
@@ -951,11 +984,12 @@ def _renderC(self, scene, sensor_id=0, seed=-1, batch_pix=-1, distributed=None):
     n = int(pix.numel()) if pix is not None else scene.opts.width * scene.opts.height
     rank, world = _shard() if distributed in (None, True) else (0, 1)
     out = _torch.empty((n, 3), dtype=_torch.float32, device=dev)
+    self._shard_mode = _shard_mode() if world > 1 else 0
     self._renderC(scene, sensor_id, seed, pix.data_ptr() if pix is not None else 0, n, out.data_ptr(), _stream_ptr(), rank, world)
     return _all_reduce(out, world > 1)
 
 
-def _render_terms(render, n, dev, world, terms, split_ok=True):
+def _render_terms(render, n, dev, world, terms, split_ok=True, tile=0):
     """image and forward derivative of one renderD from `render(launch_terms, continue_streams, image, derivative)`, summed over the ranks.
 
     On several ranks (torch.distributed initialised: one process per GPU, RCCL) every rank evaluates its 256-lane chunks of the three samplers.  The interior
@@ -974,6 +1008,15 @@ def _render_terms(render, n, dev, world, terms, split_ok=True):
     import torch.distributed as dist
     buf = _torch.empty((2, n, 3), dtype=_torch.float32, device=dev)
     render(TERM_INTERIOR, False, buf[0], buf[1])
+    if tile > 0:
+        # PSDR_SHARD=rows: this rank's interior samples all lie in its own tile of pixel rows, so the term is ASSEMBLED, not summed - 1 / world of the bytes per rank.
+        # (the gather is issued after the edge kernels are in the queue: torch's collectives order themselves behind the work of the current stream at call time)
+        works = _gather_tiles(buf, n, tile, world, async_op=True)               # (waits for the interior kernel only; overlaps the launches below)
+        edge = _torch.empty((2, n, 3), dtype=_torch.float32, device=dev)
+        render(launch & (TERM_PRIMARY | TERM_SECONDARY), True, edge[0], edge[1])
+        dist.all_reduce(edge[1], op=dist.ReduceOp.SUM)
+        full = works()
+        return full[0], full[1] + edge[1]
     work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)          # (waits for the interior kernel only; overlaps the launches below)
     edge = _torch.empty((2, n, 3), dtype=_torch.float32, device=dev)            # edge[0]: the edge terms' primal, identically zero (integrator.cpp:192, path.cpp:265) - not reduced
     # the edge terms continue from the sampler state the first call left (it has seeded all three streams and advanced the interior one)
@@ -989,10 +1032,12 @@ def _render_d_raw(self, scene, sensor_id, seed, batch_pix, terms, distributed=No
     n = int(pix.numel()) if pix is not None else scene.opts.width * scene.opts.height
     rank, world = _shard() if distributed in (None, True) else (0, 1)
     pp = pix.data_ptr() if pix is not None else 0
+    self._shard_mode = _shard_mode() if world > 1 else 0
+    tile = _row_tile(n, scene.opts.width, world, pix is not None) if self._shard_mode == 1 else 0
 
     def render(launch_terms, continue_streams, image, derivative):
         self._renderD(scene, sensor_id, -1 if continue_streams else seed, pp, n, image.data_ptr(), derivative.data_ptr(), _stream_ptr(), rank, world, launch_terms)
-    return _render_terms(render, n, dev, world, terms, split_ok=pix is None)
+    return _render_terms(render, n, dev, world, terms, split_ok=pix is None, tile=tile)
 
 
 def _bsdf_index(scene, obj):
@@ -1129,6 +1174,7 @@ class _RenderDFn(_torch.autograd.Function):
         if (bwd_terms & TERM_PRIMARY) and n_prim > 0 and not any(need and not isinstance(obj, Mesh) and _moves_edges(obj, name) for (obj, name, t), need in zip(leaves, needs)):
             edge_mesh = _np.asarray(cam._primary_edge_ids(), dtype=_np.int64).reshape(-1, 3)[:, 0]
             prim_filter = _torch.from_numpy(_np.ascontiguousarray(want_mesh[edge_mesh])).to(dev)
+        integ._shard_mode = _shard_mode() if world > 1 else 0            # (the partition of the forward pass: the adjoints of all ranks are summed below, whatever the partition)
         _core._render_d_bwd(integ, scene, st["sensor_id"], seeds, skips, g_img.data_ptr(), ptr[0], ptr[1], ptr[2], ptr[3], ptr[4],
                             _stream_ptr(), rank, world, bwd_terms, mesh_filter.data_ptr(), not want_bsdf, not want_em,
                             g_tex.data_ptr() if g_tex is not None else 0, g_cam.data_ptr() if g_cam is not None else 0,

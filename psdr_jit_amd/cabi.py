@@ -22,7 +22,7 @@ class RenderArgs(C.Structure):
     _fields_ = [("sensor_id", C.c_int32), ("max_depth", C.c_int32), ("hide_emitters", C.c_int32),
                 ("samplers", Sampler * 3), ("pix_ids", C.c_void_p), ("n_pix", C.c_int32), ("terms", C.c_int32),
                 ("shard_rank", C.c_int32), ("shard_count", C.c_int32), ("guiding", C.c_void_p), ("zero_output", C.c_int32), ("direct_mode", C.c_int32),
-                ("field_mode", C.c_int32), ("field_object", C.c_int32), ("intensity", C.c_float), ("d_intensity", C.c_float), ("skip_static_edges", C.c_int32)]
+                ("field_mode", C.c_int32), ("field_object", C.c_int32), ("intensity", C.c_float), ("d_intensity", C.c_float), ("skip_static_edges", C.c_int32), ("shard_mode", C.c_int32)]
 
 
 class Grads(C.Structure):
@@ -79,7 +79,7 @@ def check(rc):
 
 def make_args(sensor_id=0, max_depth=1, hide_emitters=False, seeds=(0, 0, 0), skips=(0, 0, 0), pix_ids_ptr=0, n_pix=0,
               terms=7, shard_rank=0, shard_count=1, guiding=None, zero_output=True, direct_mis=-1, field=-1, field_object=-1, intensity=1.0, d_intensity=0.0,
-              skip_static_edges=False):
+              skip_static_edges=False, shard_mode=0):
     a = RenderArgs()
     a.sensor_id, a.max_depth, a.hide_emitters = sensor_id, max_depth, int(hide_emitters)
     for k in range(3):
@@ -89,4 +89,5 @@ def make_args(sensor_id=0, max_depth=1, hide_emitters=False, seeds=(0, 0, 0), sk
     a.direct_mode = int(direct_mis) + 1
     a.field_mode, a.field_object, a.intensity, a.d_intensity = int(field) + 1, int(field_object), float(intensity), float(d_intensity)
     a.skip_static_edges = int(skip_static_edges)
+    a.shard_mode = int(shard_mode)          # 0: interleaved 256-lane chunks, 1: contiguous runs (pixel-row tiles), include/psdr_hip.h
     return a

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(kBlock, (ADJ ? PSDR_SEC_ADJ_WAVES : PSDR_SEC_WAVES)
     bool exhausted = false;
     bool have = false;
     BoundarySegSampleDirect bss;
-    bss.valid = false;
+    bss.valid = false; bss.pdf = 1.f; bss.p0 = Vec3d(Dual(0.f)); bss.edge = bss.edge2 = bss.p2 = bss.n = Vec3f(0.f); bss.emitter_slot = -1; bss.edge_id = 0; bss.s1 = 0.f;
     float pdf0 = 1.f;
     if constexpr (ADJ) if (P.lds_acc || P.n_hot > 0) {
         float *acc = scratch_base<LDS>(smem, T) + kSecAdjScratch;
@@ -226,10 +226,7 @@ __global__ __launch_bounds__(kBlock, (ADJ ? PSDR_SEC_ADJ_WAVES : PSDR_SEC_WAVES)
         if (threadIdx.x < 16) acc_cam[threadIdx.x] = 0.f;
         __syncthreads();
     }
-    // Candidates: one in six passes the silhouette / light-facing test.  Brute-force scenes (whose LDS rows behind the blob this kernel does not use otherwise): every
-    // lane draws in every round, the indices of the valid ones collect in a per-wave pool in LDS, and when the pool holds a wave's worth each lane takes one and draws
-    // it again - the segment is a function of the item's index (round 5: 6 full rounds + 1 per 64 segments; the form below needs 13 rounds at half the lanes).  BVH
-    // scenes keep the older form: their rows belong to the traversal (trav4.h).
+    // Candidates: one in six passes the silhouette / light-facing test.
     auto draw = [&](long long item, BoundarySegSampleDirect &out, float &pdf_out) -> bool {
         const long long chunk = (item >> 8) * P.shard_count + P.shard_rank;
         const long long lane = P.begin + (chunk << 8) + (item & 255);
@@ -242,26 +239,193 @@ __global__ __launch_bounds__(kBlock, (ADJ ? PSDR_SEC_ADJ_WAVES : PSDR_SEC_WAVES)
         out = sample_boundary_segment_direct<LDS>(S, E, s3);
         return out.valid;
     };
-    constexpr int kPoolCap = 192;            // < 64 waiting + <= 64 new per round
-    const bool pooled = T.n_tris <= kBruteForceMax && T.stack_depth * kBlock >= 4 * kPoolCap && P.n_local < (1ll << 31);
-    lds_uint_t *pool = (lds_uint_t *) (S.stack - threadIdx.x) + (threadIdx.x >> 6) * kPoolCap;
-    int pool_n = 0;
-    for (;;) {
-        if (pooled) {
-            while (pool_n < 64) {
-                if (q_next >= q_end && !exhausted) {
-                    unsigned long long base = 0;
-                    if (lane_id == 0) base = atomicAdd(P.counter, (unsigned long long) kFetchBatch);
-                    base = __shfl(base, 0);
-                    if ((long long) base >= P.n_local) exhausted = true;
-                    else { q_next = (long long) base; q_end = q_next + kFetchBatch < P.n_local ? q_next + kFetchBatch : P.n_local; }
+    auto refill_queue = [&]() {
+        if (q_next >= q_end && !exhausted) {
+            unsigned long long base = 0;
+            if (lane_id == 0) base = atomicAdd(P.counter, (unsigned long long) kFetchBatch);
+            base = __shfl(base, 0);
+            if ((long long) base >= P.n_local) exhausted = true;
+            else { q_next = (long long) base; q_end = q_next + kFetchBatch < P.n_local ? q_next + kFetchBatch : P.n_local; }
+        }
+    };
+    // reverse mode, closed form: the tangent is value0 . n.(e1 du + e2 dv) with (u, v) = Moeller-Trumbore(emitter triangle; x1, sd), sd = normalize(p0 - x1)
+    // and x1 = the camera ray's hit sliding along that ray - two adjoint solves instead of 21-33 replays
+    auto scatter_closed = [&](int idx, const SecAdjInfo &I, const BoundarySegSampleDirect &seg, float pdf_seg) {
+        if constexpr (ADJ) {
+            float *g_sec = P.lds_acc ? scratch_base<LDS>(smem, T) + kSecAdjScratch : P.g_sec;
+            float *g_tri = P.lds_acc ? g_sec + 6 * P.n_sec : P.g_tri;
+            const float v0c[3] = {I.value0.x, I.value0.y, I.value0.z};
+            float gsum = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float k = P.adj_w[3 * (long long) idx + c];
+                if (pdf_seg > kEpsilon) k /= pdf_seg;
+                if (T.sppse > 1) k /= (float) T.sppse;
+                if (finite_(v0c[c])) gsum += k * v0c[c];
+            }
+            if (gsum != 0.f && finite_(gsum)) {
+                auto add3 = [&](float *tab, int row, const Vec3f &val) {
+                    if (val.x != 0.f && finite_(val.x)) atomicAdd(&tab[row], val.x);
+                    if (val.y != 0.f && finite_(val.y)) atomicAdd(&tab[row + 1], val.y);
+                    if (val.z != 0.f && finite_(val.z)) atomicAdd(&tab[row + 2], val.z);
+                };
+                // triangle rows: hot ones per workgroup in LDS (config 5: 93 -> 42 ms; 51 of the 93 were the scatter, most of it the 108 floats of the scene box)
+                float *hot_acc = scratch_base<LDS>(smem, T) + kSecAdjScratch;
+                auto add_tri = [&](int orig, int comp, const Vec3f &val) {
+                    const int hot = (!P.lds_acc && P.n_hot > 0) ? P.hot_map[orig] : -1;
+                    if (hot >= 0 && hot < P.n_hot) add3(hot_acc, 9 * hot + comp, val); else add3(g_tri, 22 * orig + comp, val);
+                };
+                Vec3f a2, b2, c2, a1, b1, c1;
+                load_geom<false, LDS>(S, I.slot2, a2, b2, c2);
+                load_geom<false, LDS>(S, I.slot1, a1, b1, c1);
+                Vec3f p0b, e1b, e2b, ob, db;
+                mt_adjoint(a2, b2, c2, I.x1, I.sd, gsum * dot(I.n, b2), gsum * dot(I.n, c2), 0.f, p0b, e1b, e2b, ob, db);
+                const int orig2 = __float_as_int(S.ld(T.shade_off + 6 * I.slot2 + 3).w), orig1 = __float_as_int(S.ld(T.shade_off + 6 * I.slot1 + 3).w);
+                add_tri(orig2, 0, p0b); add_tri(orig2, 3, e1b); add_tri(orig2, 6, e2b);
+                const Vec3f q = detach(seg.p0) - I.x1;
+                const Vec3f qb = (db - I.sd * dot(I.sd, db)) / norm(q);          // through sd = normalize(p0 - x1)
+                add3(g_sec, 6 * seg.edge_id, qb); add3(g_sec, 6 * seg.edge_id + 3, qb * seg.s1);
+                const Vec3f xb = ob - qb;                                         // the camera hit x1 = o + t d
+                Vec3f p0c, e1c, e2c, oc2, dc2;
+                mt_adjoint(a1, b1, c1, I.cam_o, I.cam_d, 0.f, 0.f, dot(I.cam_d, xb), p0c, e1c, e2c, oc2, dc2);
+                add_tri(orig1, 0, p0c); add_tri(orig1, 3, e1c); add_tri(orig1, 6, e2c);
+                if (P.g_cam != nullptr) {
+                    const float t1 = dot(I.x1 - I.cam_o, I.cam_d);
+                    const Vec3f obt = xb + oc2, dbt = xb * t1 + dc2;
+                    const Vec3f pc = xform_pos(cam.sample_to_camera, Vec3f(I.qx, I.qy, 0.f));
+                    const Vec3f o_cam = cam.ortho ? pc : Vec3f(0.f), d_cam = cam.ortho ? Vec3f(0.f, 0.f, 1.f) : normalize(pc);
+                    const float occ[4] = {o_cam.x, o_cam.y, o_cam.z, 1.f}, dcc[4] = {d_cam.x, d_cam.y, d_cam.z, 0.f};
+                    const float obv[3] = {obt.x, obt.y, obt.z}, dbv[3] = {dbt.x, dbt.y, dbt.z};
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float val = obv[r] * occ[c] + dbv[r] * dcc[c];
+                            if (val != 0.f && finite_(val)) atomicAdd(&acc_cam[4 * r + c], val);
+                        }
                 }
+            }
+        }
+    };
+    // THE PIPELINED FORM (round 6; forward mode and the closed-form reverse mode).  A valid segment costs three rays, each of which can end it: the ray to its emitter
+    // sample, the opposite ray to the surface point p1 the sensor sees it on, the camera ray through p1.  Traced one ray at a time by the lanes that still hold a segment
+    // (eval_boundary_segment), the three traversals of a wave run at 58, ~40 and ~25 of 64 lanes, each with the tail of its slowest walk: lane utilisation 0.29 on the
+    // 82 k-triangle scene of config 5.  Here a lane's segment is in one of two stages - FIRST RAYS (the emitter ray, which may stop at any occluder in front of the sample,
+    // and the opposite ray, posted TOGETHER: the second one is speculative, and wasted when the first fails) and CAMERA RAY - and every call of trace2 carries the rays of
+    // ALL lanes, whatever their stage: a lane whose segment ended takes the next candidate in the same iteration.  Candidates: every lane draws in every round, the indices
+    // of the valid ones (one in six) wait in a per-wave pool in LDS (a segment is a function of its item's index); the pool sits in rows the traversal uses - stack rows of
+    // BVH scenes, the cold path-state rows of brute-force scenes - so what is left of it rides in a register across a trace (fewer than 64 entries by construction).
+    constexpr int kPoolCap = 192;            // < 64 needed + <= 64 new per round
+    const bool pooled = T.stack_depth >= kPoolCap / 64 && P.n_local < (1ll << 31);
+    // (BVH scenes.  Brute-force scenes keep round 5's form - the pool, then the three rays one after the other: their trace2 pays for a speculative second ray in full,
+    //  C3's kernel 0.60 -> 0.62 ms pipelined)
+    const bool pipelined = pooled && T.n_tris > kBruteForceMax && (!ADJ || P.sec_closed);
+    lds_uint_t *pool_base = (lds_uint_t *) (S.stack - threadIdx.x) + (threadIdx.x & ~63);
+    // entry i of this wave's pool: row i / 64 of the area, in the wave's OWN 64 columns - the rows are per-lane rows of all four waves (traversal stacks, parked rays), and
+    // another wave may be in the middle of a trace while this one collects candidates
+    auto pool_at = [&](int i) -> lds_uint_t & { return pool_base[(i >> 6) * kBlock + (i & 63)]; };
+    int pool_n = 0;
+    if (pipelined) {
+        int stage = 0;
+        unsigned spare = 0u;
+        Hit h2, h1c;
+        h2.slot = -1; h2.u = h2.v = h2.t = 0.f; h1c = h2;
+        Vec3f p1(0.f);
+        if constexpr (ADJ) { S.mode = 0; S.probe_kind = 99; S.probe_id = -1; }          // (zero tangents everywhere: only the primal factors are wanted)
+        for (;;) {
+            // ---- candidates for the lanes without a segment
+            const int n_need = __popcll(__ballot(stage == 0));
+            while (pool_n < n_need) {
+                refill_queue();
                 if (q_next >= q_end) break;
                 const long long item = q_next + lane_id;
                 bool ok = false;
                 if (item < q_end) { BoundarySegSampleDirect tmp; float tpdf; ok = draw(item, tmp, tpdf); }
                 const unsigned long long m_ok = __ballot(ok);
-                if (ok) pool[pool_n + __popcll(m_ok & lt_mask)] = (unsigned) item;
+                if (ok) pool_at(pool_n + __popcll(m_ok & lt_mask)) = (unsigned) item;
+                pool_n += __popcll(m_ok);
+                const long long left = q_end - q_next;
+                q_next += left < 64 ? left : 64;
+            }
+            wave_sync();
+            {
+                const unsigned long long m_need = __ballot(stage == 0);
+                const int n_take = pool_n < n_need ? pool_n : n_need, rank = __popcll(m_need & lt_mask);
+                if (stage == 0 && rank < n_take) {
+                    if (draw((long long) pool_at(pool_n - n_take + rank), bss, pdf0)) stage = 1;
+                    if constexpr (ADJ) bss.p0 = promote(detach(bss.p0));
+                }
+                pool_n -= n_take;
+                if (lane_id < pool_n) spare = pool_at(lane_id);
+            }
+            wave_sync();
+#ifdef PSDR_T_SEC_NOTRACE
+            stage = 0;          // measurement build: the candidate phase alone (wrong results)
+#endif
+            if (__ballot(stage != 0) == 0ull) { if (exhausted && q_next >= q_end && pool_n == 0) break; continue; }
+            // ---- the rays of every lane's stage in one call
+            const Vec3f p0v = detach(bss.p0), dirv = normalize(bss.p2 - p0v);
+            Vec3f oB = p0v, dB = -dirv;
+            SensorDirectSample sds; sds.valid = false; sds.qx = sds.qy = 0.f; sds.pixel_idx = -1; sds.sensor_val = 0.f;
+            RayT<true> camera_ray; camera_ray.o = Vec3d(Dual(0.f)); camera_ray.d = Vec3d(Dual(0.f));
+            if (stage == 2) {
+                sec_camera_sample<true>(T, cam, p1, sds, camera_ray, -1);
+                oB = detach(camera_ray.o); dB = detach(camera_ray.d);
+            }
+            Hit hA, hB;
+            // (the emitter ray only has to know whether its closest hit lies at the sample: any hit clearly in front of it settles that - as the next-event rays of the paths)
+            trace2<LDS, COUNT>(S, p0v, dirv, stage == 1, oB, dB, stage != 0, hA, hB, (norm(bss.p2 - p0v) - kShadowEpsilon) * 0.9999f);
+            if (lane_id < pool_n) pool_at(lane_id) = spare;
+            wave_sync();
+            if (stage == 1) {
+                stage = 0;
+                RayT<false> r2; r2.o = p0v; r2.d = dirv;
+                if (COUNT) { if (hA.slot >= 0) S.c_hits++; if (hB.slot >= 0) S.c_hits++; }
+                const Its<false> its2 = make_its<false, LDS, true>(S, hA, r2, false);
+                if (sec_light_hit_ok(S, its2, bss.p2) && hB.slot >= 0) {
+                    RayT<false> r1; r1.o = p0v; r1.d = -dirv;
+                    const Its<false> its1c = make_its<false, LDS, true>(S, hB, r1, false);
+                    SensorDirectSample s1; RayT<true> c1;
+                    if (its1c.valid && sec_camera_sample<true>(T, cam, its1c.p, s1, c1, -1)) { stage = 2; h2 = hA; h1c = hB; p1 = its1c.p; }
+                }
+            } else if (stage == 2) {
+                stage = 0;
+                RayT<false> r2; r2.o = p0v; r2.d = dirv;
+                RayT<false> r1; r1.o = p0v; r1.d = -dirv;
+                if (COUNT) { if (hB.slot >= 0) S.c_hits++; }
+                const Its<false> its2 = make_its<false, LDS, true>(S, h2, r2, false);
+                const Its<false> its1c = make_its<false, LDS, true>(S, h1c, r1, false);
+                const Its<true> its1 = make_its<true, LDS, true>(S, hB, camera_ray, false);
+                Vec3f v;
+                SecAdjInfo I;
+                const int idx = sec_value<true, LDS>(S, bss, its2, its1c, its1, camera_ray, sds, v, ADJ ? &I : nullptr);
+                if (idx >= 0) {
+                    if constexpr (ADJ) scatter_closed(idx, I, bss, pdf0);
+                    else {
+                        float o[3] = {v.x, v.y, v.z};
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            if (pdf0 > kEpsilon) o[c] /= pdf0;
+                            if (T.sppse > 1) o[c] /= (float) T.sppse;
+                            if (finite_(o[c]) && o[c] != 0.f) atomicAdd(&P.dout[3 * (long long) idx + c], o[c]);
+                        }
+                    }
+                }
+            }
+        }
+        if constexpr (ADJ) { S.mode = 0; S.probe_kind = 0; }
+    } else
+    for (;;) {
+        if (pooled && T.n_tris <= kBruteForceMax) {
+            // brute-force scenes (round 5): every lane draws in every round, the valid items' indices wait in the pool, a wave's worth is taken at a time
+            while (pool_n < 64) {
+                refill_queue();
+                if (q_next >= q_end) break;
+                const long long item = q_next + lane_id;
+                bool ok = false;
+                if (item < q_end) { BoundarySegSampleDirect tmp; float tpdf; ok = draw(item, tmp, tpdf); }
+                const unsigned long long m_ok = __ballot(ok);
+                if (ok) pool_at(pool_n + __popcll(m_ok & lt_mask)) = (unsigned) item;
                 pool_n += __popcll(m_ok);
                 const long long left = q_end - q_next;
                 q_next += left < 64 ? left : 64;
@@ -269,7 +433,7 @@ __global__ __launch_bounds__(kBlock, (ADJ ? PSDR_SEC_ADJ_WAVES : PSDR_SEC_WAVES)
             wave_sync();
             const int n_take = pool_n < 64 ? pool_n : 64;
             have = false;
-            if (lane_id < n_take) have = draw((long long) pool[pool_n - n_take + lane_id], bss, pdf0);
+            if (lane_id < n_take) have = draw((long long) pool_at(pool_n - n_take + lane_id), bss, pdf0);
             pool_n -= n_take;
             wave_sync();
             if (n_take == 0) { if (exhausted && q_next >= q_end) break; continue; }
@@ -277,29 +441,11 @@ __global__ __launch_bounds__(kBlock, (ADJ ? PSDR_SEC_ADJ_WAVES : PSDR_SEC_WAVES)
         for (int round = 0; round < 16; ++round) {
             const unsigned long long need = __ballot(!have);
             if (__popcll(need) <= 6) break;
-            if (q_next >= q_end && !exhausted) {
-                unsigned long long base = 0;
-                if (lane_id == 0) base = atomicAdd(P.counter, (unsigned long long) kFetchBatch);
-                base = __shfl(base, 0);
-                if ((long long) base >= P.n_local) exhausted = true;
-                else { q_next = (long long) base; q_end = q_next + kFetchBatch < P.n_local ? q_next + kFetchBatch : P.n_local; }
-            }
+            refill_queue();
             if (q_next >= q_end) break;
             const int rank = __popcll(need & lt_mask);
             const long long item = q_next + rank;
-            if (!have && item < q_end) {
-                const long long chunk = (item >> 8) * P.shard_count + P.shard_rank;
-                const long long lane = P.begin + (chunk << 8) + (item & 255);
-                if (lane < P.end) {
-                    LaneRng rng;
-                    rng.seed(P.seed + (unsigned long long) lane, (unsigned long long) lane, P.skip);
-                    Vec3f s3;
-                    s3.x = rng.next_1d(); s3.y = rng.next_1d(); s3.z = rng.next_1d();
-                    pdf0 = use_guiding ? guiding_sample_reuse(G, s3) : 1.f;
-                    bss = sample_boundary_segment_direct<LDS>(S, E, s3);
-                    have = bss.valid;
-                }
-            }
+            if (!have && item < q_end) have = draw(item, bss, pdf0);
             const int n_need = __popcll(need);
             q_next += n_need < (int) (q_end - q_next) ? n_need : (q_end - q_next);
         }
@@ -315,64 +461,10 @@ __global__ __launch_bounds__(kBlock, (ADJ ? PSDR_SEC_ADJ_WAVES : PSDR_SEC_WAVES)
             b0.p0 = promote(detach(bss.p0));
             Vec3f v;
             if (P.sec_closed) {
-                // closed form: the tangent is value0 . n.(e1 du + e2 dv) with (u, v) = Moeller-Trumbore(emitter triangle; x1, sd), sd = normalize(p0 - x1)
-                // and x1 = the camera ray's hit sliding along that ray - two adjoint solves instead of 21-33 replays
                 S.mode = 0; S.probe_kind = 99; S.probe_id = -1;         // (zero tangents everywhere: only the primal factors are wanted)
                 SecAdjInfo I;
                 const int idx = eval_boundary_segment<true, LDS, false>(S, cam, b0, v, -1, &I);
-                if (idx >= 0) {
-                    const float v0c[3] = {I.value0.x, I.value0.y, I.value0.z};
-                    float gsum = 0.f;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        float k = P.adj_w[3 * (long long) idx + c];
-                        if (pdf0 > kEpsilon) k /= pdf0;
-                        if (T.sppse > 1) k /= (float) T.sppse;
-                        if (finite_(v0c[c])) gsum += k * v0c[c];
-                    }
-                    if (gsum != 0.f && finite_(gsum)) {
-                        auto add3 = [&](float *tab, int row, const Vec3f &val) {
-                            if (val.x != 0.f && finite_(val.x)) atomicAdd(&tab[row], val.x);
-                            if (val.y != 0.f && finite_(val.y)) atomicAdd(&tab[row + 1], val.y);
-                            if (val.z != 0.f && finite_(val.z)) atomicAdd(&tab[row + 2], val.z);
-                        };
-                        // triangle rows: hot ones per workgroup in LDS (config 5: 93 -> 42 ms; 51 of the 93 were the scatter, most of it the 108 floats of the scene box)
-                        float *hot_acc = scratch_base<LDS>(smem, T) + kSecAdjScratch;
-                        auto add_tri = [&](int orig, int comp, const Vec3f &val) {
-                            const int hot = (!P.lds_acc && P.n_hot > 0) ? P.hot_map[orig] : -1;
-                            if (hot >= 0 && hot < P.n_hot) add3(hot_acc, 9 * hot + comp, val); else add3(g_tri, 22 * orig + comp, val);
-                        };
-                        Vec3f a2, b2, c2, a1, b1, c1;
-                        load_geom<false, LDS>(S, I.slot2, a2, b2, c2);
-                        load_geom<false, LDS>(S, I.slot1, a1, b1, c1);
-                        Vec3f p0b, e1b, e2b, ob, db;
-                        mt_adjoint(a2, b2, c2, I.x1, I.sd, gsum * dot(I.n, b2), gsum * dot(I.n, c2), 0.f, p0b, e1b, e2b, ob, db);
-                        const int orig2 = __float_as_int(S.ld(T.shade_off + 6 * I.slot2 + 3).w), orig1 = __float_as_int(S.ld(T.shade_off + 6 * I.slot1 + 3).w);
-                        add_tri(orig2, 0, p0b); add_tri(orig2, 3, e1b); add_tri(orig2, 6, e2b);
-                        const Vec3f q = detach(bss.p0) - I.x1;
-                        const Vec3f qb = (db - I.sd * dot(I.sd, db)) / norm(q);          // through sd = normalize(p0 - x1)
-                        add3(g_sec, 6 * bss.edge_id, qb); add3(g_sec, 6 * bss.edge_id + 3, qb * bss.s1);
-                        const Vec3f xb = ob - qb;                                         // the camera hit x1 = o + t d
-                        Vec3f p0c, e1c, e2c, oc2, dc2;
-                        mt_adjoint(a1, b1, c1, I.cam_o, I.cam_d, 0.f, 0.f, dot(I.cam_d, xb), p0c, e1c, e2c, oc2, dc2);
-                        add_tri(orig1, 0, p0c); add_tri(orig1, 3, e1c); add_tri(orig1, 6, e2c);
-                        if (P.g_cam != nullptr) {
-                            const float t1 = dot(I.x1 - I.cam_o, I.cam_d);
-                            const Vec3f obt = xb + oc2, dbt = xb * t1 + dc2;
-                            const Vec3f pc = xform_pos(cam.sample_to_camera, Vec3f(I.qx, I.qy, 0.f));
-                            const Vec3f o_cam = cam.ortho ? pc : Vec3f(0.f), d_cam = cam.ortho ? Vec3f(0.f, 0.f, 1.f) : normalize(pc);
-                            const float occ[4] = {o_cam.x, o_cam.y, o_cam.z, 1.f}, dcc[4] = {d_cam.x, d_cam.y, d_cam.z, 0.f};
-                            const float obv[3] = {obt.x, obt.y, obt.z}, dbv[3] = {dbt.x, dbt.y, dbt.z};
-#pragma unroll
-                            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                                for (int c = 0; c < 4; ++c) {
-                                    const float val = obv[r] * occ[c] + dbv[r] * dcc[c];
-                                    if (val != 0.f && finite_(val)) atomicAdd(&acc_cam[4 * r + c], val);
-                                }
-                        }
-                    }
-                }
+                if (idx >= 0) scatter_closed(idx, I, bss, pdf0);
                 S.mode = 0; S.probe_kind = 0;
                 have = false;
                 continue;
@@ -655,6 +747,19 @@ static inline long long local_lanes(long long n, int rank, int count) {
     const long long mine = chunks > rank ? (chunks - rank + count - 1) / count : 0;
     return mine * kBlock;
 }
+// psdr_render_args.shard_mode == PSDR_SHARD_ROWS: rank `rank` of `count` owns one CONTIGUOUS run of a sampler's lanes, a whole number of `unit` lanes (a pixel row of the
+// interior sampler - the rank's pixels are then one block of the image -, a pixel of a batch list, a 256-lane chunk of an edge sampler); the kernels see it as the lane range
+// [begin, end) of a single rank, the form the per-lane entry points use
+static inline void shard_run(long long n_lanes, long long unit, int rank, int count, long long &begin, long long &end) {
+    const long long n_units = (n_lanes + unit - 1) / unit, per = (n_units + count - 1) / count;
+    begin = std::min(n_lanes, (long long) rank * per * unit);
+    end = std::min(n_lanes, ((long long) rank + 1) * per * unit);
+}
+template <typename Params> static inline void set_shard(Params &P, const psdr_render_args *a, long long n_lanes, long long unit, int rank, int count) {
+    P.begin = 0; P.end = n_lanes; P.shard_rank = rank; P.shard_count = count;
+    if (count > 1 && a->shard_mode == PSDR_SHARD_ROWS) { shard_run(n_lanes, unit, rank, count, P.begin, P.end); P.shard_rank = 0; P.shard_count = 1; }
+    P.n_local = local_lanes(P.end - P.begin, P.shard_rank, P.shard_count);
+}
 static inline int grid_for(const psdr_hip_scene *sc, long long n) {
     long long chunks = (n + kBlock - 1) / kBlock;
     if (chunks < 1) chunks = 1;
@@ -750,6 +855,7 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
     const int count = a->shard_count > 1 ? a->shard_count : 1;
     const int rank = count > 1 ? a->shard_rank : 0;
     if (rank < 0 || rank >= count) return fail("bad shard rank");
+    if (a->shard_mode != PSDR_SHARD_INTERLEAVED && a->shard_mode != PSDR_SHARD_ROWS) return fail("bad shard mode");
     // the first-hit integrators (field_mode) live in the LDS=false instantiations only
     const bool use_lds = sc->lds && a->field_mode == 0;
     // scene class of the kernels (scene_dev.h); class 3 has the plain forward instantiations only (the counted ones run class 0)
@@ -786,10 +892,10 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
     if ((terms & PSDR_TERM_INTERIOR) && T.spp > 0) {
         PathParams P{};
         P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[0].seed; P.skip = skip_ahead(a->samplers[0].skip);
-        P.pix_ids = a->pix_ids; P.begin = 0; P.end = npx * T.spp; P.shard_rank = rank; P.shard_count = count;
+        P.pix_ids = a->pix_ids;
+        set_shard(P, a, npx * T.spp, a->pix_ids ? (long long) T.spp : (long long) T.width * T.spp, rank, count);
         P.out = out; P.dout = dout; P.lanes_out = lanes_out;
-        if (lanes_out) { P.begin = lane_b; P.end = lane_e; P.shard_rank = 0; P.shard_count = 1; }
-        P.n_local = local_lanes(P.end - P.begin, P.shard_rank, P.shard_count);
+        if (lanes_out) { P.begin = lane_b; P.end = lane_e; P.shard_rank = 0; P.shard_count = 1; P.n_local = local_lanes(P.end - P.begin, 0, 1); }
         if (P.n_local > 0) {
             if (fork) P.counter = q_int; else if (next_queue(P.counter)) return 1;
             if (ad) {
@@ -809,9 +915,8 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
         if ((terms & PSDR_TERM_PRIMARY) && T.sppe > 0 && cam.n_edges > 0) {
             PathParams P{};
             P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[1].seed; P.skip = skip_ahead(a->samplers[1].skip);
-            P.begin = 0; P.end = npx * T.sppe; P.shard_rank = rank; P.shard_count = count; P.dout = dout;
+            set_shard(P, a, npx * T.sppe, kBlock, rank, count); P.dout = dout;
             P.skip_static = a->skip_static_edges;
-            P.n_local = local_lanes(P.end, rank, count);
             if (P.n_local > 0) {
                 if (fork) P.counter = q_prim; else if (next_queue(P.counter)) return 1;
                 if (cls == 1) ON_CLS1(LAUNCH(1, (k_paths<false, 1, COUNT, 1>), sc, P.n_local, s_prim, sc->blob.as<float4>(), T_prim, cam, P, ctr));
@@ -823,8 +928,7 @@ static int render_impl(const psdr_hip_scene *sc, const psdr_render_args *a, bool
         if ((terms & PSDR_TERM_SECONDARY) && T.sppse > 0 && sc->E.n > 0) {
             PathParams P{};
             P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[2].seed; P.skip = skip_ahead(a->samplers[2].skip);
-            P.begin = 0; P.end = npx * T.sppse; P.shard_rank = rank; P.shard_count = count; P.dout = dout;
-            P.n_local = local_lanes(P.end, rank, count);
+            set_shard(P, a, npx * T.sppse, kBlock, rank, count); P.dout = dout;
             GuidingDev G{};
             const int use_g = a->guiding ? 1 : 0;
             if (a->guiding) G = a->guiding->G;
@@ -896,6 +1000,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     const int count = a->shard_count > 1 ? a->shard_count : 1;
     const int rank = count > 1 ? a->shard_rank : 0;
     if (rank < 0 || rank >= count) return fail("bad shard rank");
+    if (a->shard_mode != PSDR_SHARD_INTERLEAVED && a->shard_mode != PSDR_SHARD_ROWS) return fail("bad shard mode");
     // the first-hit integrators (field_mode) live in the LDS=false instantiations only
     const bool use_lds = sc->lds && a->field_mode == 0;
     const int cls = use_lds ? 1 : ((sc->lean && a->field_mode == 0) ? 2 : 0);        // scene class of the kernels (scene_dev.h); the reverse mode has no class 3
@@ -996,7 +1101,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
     if ((terms & PSDR_TERM_INTERIOR) && T.spp > 0) {
         AdjointParams P{};
         P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[0].seed; P.skip = skip_ahead(a->samplers[0].skip);
-        P.pix_ids = a->pix_ids; P.begin = 0; P.end = npx * T.spp; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
+        P.pix_ids = a->pix_ids; set_shard(P, a, npx * T.spp, a->pix_ids ? (long long) T.spp : (long long) T.width * T.spp, rank, count);
         P.w = d_rgb; P.g_tri = g->g_triangles; P.g_bsdf = g->g_bsdf; P.g_emitter = g->g_emitter; P.hot_map = sc->hot_map.as<int>(); P.hot_inv = sc->hot_inv.as<int>(); P.n_hot = n_hot_used;
         P.mesh_filter = g->mesh_filter; P.skip_bsdf = g->skip_bsdf; P.skip_emitter = g->skip_emitter;
         P.g_tex = sc->tex_total > 0 ? g->g_tex : nullptr;
@@ -1036,7 +1141,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         if (!g->g_prim_edges) return fail("g_prim_edges is required when the primary-edge term is requested");
         PathParams P{};
         P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[1].seed; P.skip = skip_ahead(a->samplers[1].skip);
-        P.begin = 0; P.end = npx_full * T.sppe; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
+        set_shard(P, a, npx_full * T.sppe, kBlock, rank, count);
         P.adj_w = d_rgb; P.g_prim = g->g_prim_edges; P.n_prim = cam.n_edges; P.lds_acc = (cam.n_edges <= 2048) ? 1 : 0;
         P.prim_filter = g->prim_edge_filter;
         if (P.n_local > 0) {
@@ -1052,7 +1157,7 @@ int psdr_hip_render_d_bwd(const psdr_hip_scene *sc, const psdr_render_args *a, c
         if (!g->g_sec_edges) return fail("g_sec_edges is required when the secondary-edge term is requested");
         PathParams P{};
         P.max_depth = fh_field >= 0 ? 0 : (a->direct_mode > 0 ? 1 : a->max_depth); P.mis = a->direct_mode - 1; P.field = fh_field; P.field_object = a->field_object; P.intensity = a->intensity; P.d_intensity = a->d_intensity; P.hide_emitters = a->hide_emitters; P.seed = a->samplers[2].seed; P.skip = skip_ahead(a->samplers[2].skip);
-        P.begin = 0; P.end = npx_full * T.sppse; P.shard_rank = rank; P.shard_count = count; P.n_local = local_lanes(P.end, rank, count);
+        set_shard(P, a, npx_full * T.sppse, kBlock, rank, count);
         P.adj_w = d_rgb; P.g_sec = g->g_sec_edges; P.g_tri = g->g_triangles; P.n_sec = sc->E.n;
         P.g_cam = g->g_camera;
         P.sec_closed = no_sweep ? 0 : 1;

@@ -123,28 +123,28 @@ PSDR_DEV int eval_secondary_edge(SceneView<LDS> &S, const SecEdgeTables &E, cons
     return eval_boundary_segment<AD, LDS, COUNT>(S, cam, bss, value);
 }
 
-// the traced part of eval_secondary_edge (path.cpp:176-270) for an already sampled, valid boundary segment
-template <bool AD, int LDS, bool COUNT>
-PSDR_DEV int eval_boundary_segment(SceneView<LDS> &S, const SensorDev &cam, const BoundarySegSampleDirect &bss, Vec3f &value, int cam_comp, SecAdjInfo *info) {
-    value = Vec3f(0.f);
-    const SceneTables &T = *S.T;
-    const Vec3f _p0 = detach(bss.p0), _p2 = bss.p2, _dir = normalize(_p2 - _p0);
+// The traced part of eval_secondary_edge (path.cpp:176-270) for an already sampled, valid boundary segment, in the three pieces between its three rays
+// (eval_boundary_segment below strings them together one ray at a time; api.hip::k_secondary_edges pipelines them - round 6):
+//   sec_light_hit_ok   the segment reaches its emitter sample (closest hit of p0 -> p2 lies at p2, on an emitter)
+//   sec_camera_sample  the opposite ray's hit p1 is seen by the sensor: sensor sample and camera ray through p1
+//   sec_value          the estimator's value from the three hits
+template <int LDS> PSDR_DEV bool sec_light_hit_ok(const SceneView<LDS> &S, const Its<false> &its2, const Vec3f &p2) {
+    return its2.valid && mesh_emitter(S, its2.mesh) >= 0 && norm(its2.p - p2) < kShadowEpsilon;
+}
 
-    RayT<false> r2; r2.o = _p0; r2.d = _dir;
-    const Its<false> its2 = ray_intersect<false, false, LDS, COUNT>(S, r2, true);
-    if (!(its2.valid && mesh_emitter(S, its2.mesh) >= 0 && norm(its2.p - _p2) < kShadowEpsilon)) return -1;
-
-    RayT<false> r1; r1.o = _p0; r1.d = -_dir;
-    const Its<false> its1c = ray_intersect<false, false, LDS, COUNT>(S, r1, true);
-    if (!its1c.valid) return -1;
-    const Vec3f _p1 = its1c.p;
-
-    const SensorDirectSample sds = sample_direct(T, cam, _p1);
-    if (!sds.valid) return -1;
-
-    RayT<AD> camera_ray = sample_primary_ray<AD>(cam, sds.qx, sds.qy);
+template <bool AD> PSDR_DEV bool sec_camera_sample(const SceneTables &T, const SensorDev &cam, const Vec3f &p1, SensorDirectSample &sds, RayT<AD> &camera_ray, int cam_comp) {
+    sds = sample_direct(T, cam, p1);
+    if (!sds.valid) return false;
+    camera_ray = sample_primary_ray<AD>(cam, sds.qx, sds.qy);
     if constexpr (AD) if (cam_comp >= 0) primary_ray_pose_tangent(cam, sds.qx, sds.qy, cam_comp, camera_ray);      // camera-pose probe
-    const Its<AD> its1 = ray_intersect<AD, false, LDS, COUNT>(S, camera_ray, true);
+    return true;
+}
+
+template <bool AD, int LDS>
+PSDR_DEV int sec_value(SceneView<LDS> &S, const BoundarySegSampleDirect &bss, const Its<false> &its2, const Its<false> &its1c, const Its<AD> &its1, const RayT<AD> &camera_ray,
+                       const SensorDirectSample &sds, Vec3f &value, SecAdjInfo *info) {
+    const Vec3f _p0 = detach(bss.p0), _p2 = bss.p2, _dir = normalize(_p2 - _p0);
+    const Vec3f _p1 = its1c.p;
     if (!(its1.valid && norm(detach(its1.p) - _p1) < kShadowEpsilon)) return -1;
     if (mesh_bsdf(S, its1.mesh) < 0) return -1;
 
@@ -185,6 +185,27 @@ PSDR_DEV int eval_boundary_segment(SceneView<LDS> &S, const SensorDev &cam, cons
         value = value0;
         return -1;
     }
+}
+
+template <bool AD, int LDS, bool COUNT>
+PSDR_DEV int eval_boundary_segment(SceneView<LDS> &S, const SensorDev &cam, const BoundarySegSampleDirect &bss, Vec3f &value, int cam_comp, SecAdjInfo *info) {
+    value = Vec3f(0.f);
+    const SceneTables &T = *S.T;
+    const Vec3f _p0 = detach(bss.p0), _p2 = bss.p2, _dir = normalize(_p2 - _p0);
+
+    RayT<false> r2; r2.o = _p0; r2.d = _dir;
+    const Its<false> its2 = ray_intersect<false, false, LDS, COUNT>(S, r2, true);
+    if (!sec_light_hit_ok(S, its2, _p2)) return -1;
+
+    RayT<false> r1; r1.o = _p0; r1.d = -_dir;
+    const Its<false> its1c = ray_intersect<false, false, LDS, COUNT>(S, r1, true);
+    if (!its1c.valid) return -1;
+
+    SensorDirectSample sds;
+    RayT<AD> camera_ray;
+    if (!sec_camera_sample<AD>(T, cam, its1c.p, sds, camera_ray, cam_comp)) return -1;
+    const Its<AD> its1 = ray_intersect<AD, false, LDS, COUNT>(S, camera_ray, true);
+    return sec_value<AD, LDS>(S, bss, its2, its1c, its1, camera_ray, sds, value, info);
 }
 
 } // namespace psdr

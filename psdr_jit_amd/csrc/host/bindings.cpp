@@ -491,7 +491,8 @@ PYBIND11_MODULE(_psdr_core, m) {
              py::call_guard<py::gil_scoped_release>())
         .def("_renderD", &Integrator::renderD, "scene"_a, "sensor_id"_a, "seed"_a, "pix_ids"_a, "n_pix"_a, "out"_a, "dout"_a, "stream"_a, "shard_rank"_a,
              "shard_count"_a, "terms"_a, py::call_guard<py::gil_scoped_release>())
-        .def_readwrite("trace_static_edges", &Integrator::m_trace_static_edges);
+        .def_readwrite("trace_static_edges", &Integrator::m_trace_static_edges)
+        .def_readwrite("_shard_mode", &Integrator::m_shard_mode);
 
     m.def("_render_d_bwd", [](const Integrator &it, const Scene &scene, int sensor_id, const std::vector<uint64_t> &seeds, const std::vector<uint64_t> &skips,
                               uintptr_t d_rgb, uintptr_t g_tri, uintptr_t g_bsdf, uintptr_t g_emitter, uintptr_t g_sec, uintptr_t g_prim, uintptr_t stream,
@@ -501,7 +502,7 @@ PYBIND11_MODULE(_psdr_core, m) {
         std::memset(&a, 0, sizeof(a));
         a.sensor_id = sensor_id; a.max_depth = it.max_depth(); a.hide_emitters = it.hide_emitters() ? 1 : 0;
         for (int k = 0; k < 3; ++k) { a.samplers[k].seed = seeds[k]; a.samplers[k].skip = skips[k]; }
-        a.shard_rank = rank; a.shard_count = count; a.zero_output = 1; a.terms = terms; a.guiding = it.guiding(sensor_id);
+        a.shard_rank = rank; a.shard_count = count; a.shard_mode = it.m_shard_mode; a.zero_output = 1; a.terms = terms; a.guiding = it.guiding(sensor_id);
         a.direct_mode = it.direct_mis() + 1;
         a.pix_ids = reinterpret_cast<const int32_t *>(pix_ids); a.n_pix = pix_ids ? n_pix : 0;       // batch rendering: interior term only
         a.field_mode = it.field() + 1; a.field_object = field_object_index(scene, it); a.intensity = it.intensity(false);

@@ -1258,6 +1258,7 @@ static void fill_args(psdr_render_args &a, const Scene &scene, const Integrator 
     a.field_object = field_object_index(scene, it);
     a.intensity = it.intensity(false); a.d_intensity = it.intensity(true);
     a.skip_static_edges = it.m_trace_static_edges ? 0 : 1;
+    a.shard_mode = it.m_shard_mode;
 }
 
 void Integrator::renderC(const Scene &scene, int sensor_id, int seed, uintptr_t pix_ids, int n_pix, uintptr_t out, uintptr_t stream, int rank, int count) const {

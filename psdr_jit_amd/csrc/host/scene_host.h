@@ -361,6 +361,7 @@ struct Integrator : Object {
     // renderD, primary-edge term: false (default) = an edge sample whose edge point does not move under the installed tangents is not traced - it adds exactly
     // zero to the derivative image (psdr_render_args.skip_static_edges); true = every sample's two paths are traced, as the reference does
     bool m_trace_static_edges = false;
+    int m_shard_mode = 0;                // psdr_render_args.shard_mode of the launches (multi-GPU: 0 interleaved 256-lane chunks, 1 contiguous runs = pixel-row tiles)
 };
 
 struct PathTracer : Integrator {

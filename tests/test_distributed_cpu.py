@@ -55,6 +55,29 @@ def _worker(rank, world, port, outdir):
         i, d = psdr._render_terms(render, 24 * 24, torch.device("cpu"), w, 7)
         forms[name] = np.stack([i.numpy(), d.numpy()])
     os.environ.pop("PSDR_SINGLE_COLLECTIVE", None)
+    # PSDR_SHARD=rows (psdr_render_args.shard_mode 1): contiguous runs - rank r renders the pixel rows [r R, (r + 1) R) of the interior term, which is then ASSEMBLED by
+    # all_gather_into_tensor (1 / world of the bytes per rank) while only the edge terms' derivative is summed.  24 rows over 2 ranks: 12 each; a 25-row frame tests the padding
+    def render_rows(terms, continue_streams, image, derivative):
+        i, d = sc.render_d(max_depth=2, seeds=(3, 4, 5), shard_rank=r, shard_count=w, shard_mode=1, terms=terms)
+        image.copy_(torch.from_numpy(i)); derivative.copy_(torch.from_numpy(d))
+    assert psdr._row_tile(24 * 24, 24, w, False) == 12 * 24
+    i, d = psdr._render_terms(render_rows, 24 * 24, torch.device("cpu"), w, 7, tile=psdr._row_tile(24 * 24, 24, w, False))
+    forms["rows"] = np.stack([i.numpy(), d.numpy()])
+    i, d = psdr._render_terms(render_rows, 24 * 24, torch.device("cpu"), w, 7)          # (the same partition through one all_reduce of everything)
+    forms["rows_reduced"] = np.stack([i.numpy(), d.numpy()])
+    rows_part = sc.render_d(max_depth=2, seeds=(3, 4, 5), shard_rank=r, shard_count=w, shard_mode=1, terms=orc.TERM_INTERIOR)[0]
+    assert np.abs(rows_part[(1 - r) * 12 * 24:(2 - r) * 12 * 24]).max() == 0.0 and np.abs(rows_part[r * 12 * 24:(r + 1) * 12 * 24]).max() > 0.0      # one block of rows per rank
+    spec25 = scenes.cbox_scene(24, 25, 4, 4, 4, param="light_x")
+    sc25 = orc.OracleScene(spec25, [0])
+    def render_rows25(terms, continue_streams, image, derivative):
+        i, d = sc25.render_d(max_depth=1, seeds=(3, 4, 5), shard_rank=r, shard_count=w, shard_mode=1, terms=terms)
+        image.copy_(torch.from_numpy(i)); derivative.copy_(torch.from_numpy(d))
+    i, d = psdr._render_terms(render_rows25, 24 * 25, torch.device("cpu"), w, 7, tile=psdr._row_tile(24 * 25, 24, w, False))
+    forms["rows25"] = np.stack([i.numpy(), d.numpy()])
+    if rank == 0:
+        np.save(os.path.join(outdir, "full25.npy"), np.stack(sc25.render_d(max_depth=1, seeds=(3, 4, 5))))
+        for k in ("rows", "rows_reduced", "rows25"):
+            np.save(os.path.join(outdir, k + ".npy"), forms[k])
     if rank == 0:
         full = np.stack(sc.render_d(max_depth=2, seeds=(3, 4, 5)))
         np.save(os.path.join(outdir, "reduced.npy"), buf.numpy())
@@ -78,6 +101,10 @@ def test_two_rank_shards_reduce_to_full_frame(tmp_path):
         assert np.allclose(got[0], full[0], rtol=1e-5, atol=1e-7) and np.allclose(got[1], full[1], rtol=1e-4, atol=1e-6), form
     # each rank really rendered only a part
     assert np.linalg.norm(part0[0]) < 0.9 * np.linalg.norm(full[0])
+    # the contiguous partition (row tiles + all-gather), assembled and reduced, and on a frame whose rows do not divide
+    for form, ref in (("rows", full), ("rows_reduced", full), ("rows25", np.load(os.path.join(tmp_path, "full25.npy")))):
+        got = np.load(os.path.join(tmp_path, form + ".npy"))
+        assert np.allclose(got[0], ref[0], rtol=1e-5, atol=1e-7) and np.allclose(got[1], ref[1], rtol=1e-4, atol=1e-6), form
 
 
 def test_shard_is_identity_without_process_group():

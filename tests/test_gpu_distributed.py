@@ -59,6 +59,10 @@ def test_bench_two_ranks_config4_strong_scaling_line():
     # both collective forms were timed as whole steps (the interior term's all_reduce under the edge kernels / one all_reduce at the end)
     assert sb["step_ms_split_collectives"] > 0 and sb["step_ms_single_collective"] > 0 and sb["timed_form"] == "split"
     assert abs(sb["overlap_ms"] - (sb["step_ms_single_collective"] - sb["step_ms_split_collectives"])) < 1e-2
+    # ... and the contiguous row-tile partition beside it (PSDR_SHARD=rows): render time per rank (the tiles' balance), the step, the bytes of its collectives
+    rt = sb["row_tiles"]
+    assert len(rt["render_ms_per_rank"]) == 2 and min(rt["render_ms_per_rank"]) > 0 and rt["step_ms"] > 0
+    assert rt["all_gather_bytes_per_rank"] == 2 * 1024 * 2048 * 3 * 4 and rt["all_reduce_bytes"] == 2048 * 2048 * 3 * 4
 
 
 def test_bench_dry_run_says_whether_the_node_can_run_n_ranks():

@@ -54,17 +54,23 @@ if "RANK" in os.environ:
     os.environ["PSDR_SINGLE_COLLECTIVE"] = "1"
     f_single = fwd_of()
     os.environ.pop("PSDR_SINGLE_COLLECTIVE")
+    # PSDR_SHARD=rows: contiguous pixel-row tiles (psdr_render_args.shard_mode 1), the interior term assembled by all_gather_into_tensor - forward and backward
+    os.environ["PSDR_SHARD"] = "rows"
+    f_rows = fwd_of()
+    img_r, gp_r, gr_r = grad_of(True)
+    os.environ.pop("PSDR_SHARD")
     dist.destroy_process_group()
     # reference: the same in one process (after the group is gone psdr shards over 1 rank)
     img1, gp1, gr1 = grad_of(False)
     f_one = fwd_of()
-    for a, b, c in zip(f_split, f_single, f_one):
-        for x, nm in ((a, "split"), (b, "single")):
+    for a, b, r, c in zip(f_split, f_single, f_rows, f_one):
+        for x, nm in ((a, "split"), (b, "single"), (r, "rows")):
             e0, e1 = np.linalg.norm(x[0] - c[0]) / np.linalg.norm(c[0]), np.linalg.norm(x[1] - c[1]) / np.linalg.norm(c[1])
             assert e0 < 1e-5 and e1 < 1e-4, (nm, e0, e1)
     if int(os.environ["RANK"]) == 0:
         print("image rel L2 %.2e   dP %.6f vs %.6f   d refl %s vs %s" % (np.linalg.norm(img - img1) / np.linalg.norm(img1), gp, gp1, gr, gr1))
         assert np.linalg.norm(img - img1) / np.linalg.norm(img1) < 1e-5 and abs(gp - gp1) < 1e-4 * max(1.0, abs(gp1)) and np.allclose(gr, gr1, rtol=1e-4)
-        print("2-rank forward (split / single collective) and backward OK")
+        assert np.linalg.norm(img_r - img1) / np.linalg.norm(img1) < 1e-5 and abs(gp_r - gp1) < 1e-4 * max(1.0, abs(gp1)) and np.allclose(gr_r, gr1, rtol=1e-4), (gp_r, gp1, gr_r, gr1)
+        print("2-rank forward (split / single collective / row tiles) and backward OK")
 else:
     print(single[1], single[2])

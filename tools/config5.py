@@ -26,6 +26,7 @@ nn, nl, md, lb = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
 cabi.check(cabi.lib().psdr_hip_scene_stats(C.c_void_p(sc._hip_handle()), C.byref(nn), C.byref(nl), C.byref(md), C.byref(lb)))
 print("triangles", sum(len(m.faces) for m in spec.meshes) + 12, "bvh nodes", nn.value, "depth", md.value, "configure %.2f s" % t_cfg)
 integ = psdr.PathTracer(a.depth)
+integ.trace_static_edges = True            # every primary-edge sample traced (the parameter is a colour: the public surface would drop them all - bench_scene.py)
 t0 = time.time(); integ.preprocess_secondary_edges(sc, 0, a.guiding, 1, 0); torch.cuda.synchronize(); print("guiding build %.3f s" % (time.time() - t0))
 for terms, name in ((1, "interior"), (2, "primary"), (4, "secondary"), (7, "all")):
     psdr.render_d_fwd(integ, sc, 0, seed=1, terms=terms); torch.cuda.synchronize()
