@@ -55,7 +55,10 @@ constexpr int kBvhW = PSDR_BVH_WIDTH;
 static_assert(kBvhW == 4 || kBvhW == 8, "PSDR_BVH_WIDTH");
 constexpr int kNodeFloats = kBvhW == 4 ? 16 : 32;
 constexpr int kNodeCodeOff = 4 + 6 * (kBvhW / 4);        // word of the first child code (10 / 16)
-constexpr int kBvhTopNodes = 6 * 256 / kNodeFloats;      // nodes numbered breadth first from the root (= trav4.h::kTopNodes, the part of the tree a workgroup copies to LDS: six rows)
+#ifndef PSDR_TOP_ROWS
+#define PSDR_TOP_ROWS 2
+#endif
+constexpr int kBvhTopNodes = PSDR_TOP_ROWS * 256 / kNodeFloats;      // nodes numbered breadth first from the root (= trav4.h::kTopNodes, the part of the tree a workgroup copies to LDS: scene_dev.h::kTopRows rows)
 
 // 4-wide node = 64 bytes = 4 float4 words (two nodes per 128-byte L2 line, four 16-byte loads per step):
 //   w0  origin.xyz (the lower corner of the union of the children's boxes), bits(ex | ey << 8 | ez << 16): biased exponents,

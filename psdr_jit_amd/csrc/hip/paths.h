@@ -718,7 +718,7 @@ PSDR_DEV void run_paths_async(SceneView<LDS> &S, const SensorDev &cam, const Pat
             const int n_fly = __popcll(__ballot(inflight));
             if (n_fly > 0) {
                 const int want_new = n_fly < 2 * kShadeMin ? (n_fly + 1) / 2 : kShadeMin;
-                const bool mine_done = trav4_run<LDS, COUNT>(S, tr, inflight ? posted : 0, n_fly - want_new);
+                const bool mine_done = trav4_run<LDS, COUNT, true>(S, tr, inflight ? posted : 0, n_fly - want_new);
                 if (inflight && mine_done) { inflight = false; has_hits = true; }
             }
         }

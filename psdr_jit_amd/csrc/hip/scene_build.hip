@@ -292,13 +292,13 @@ static int scene_sync(psdr_hip_scene *sc, const psdr_scene_snapshot *s, unsigned
     for (int i = 0; i < s->n_emitters; ++i) if (s->emitters[i].type == 1) T.env_emitter = i;
     // traversal stack: the first kStackLds entries of a lane in LDS, deeper ones in a per-lane global array (trav4.h);
     // scenes that are traced by brute force (<= kBruteForceMax triangles) need neither
-    // 8 + kTravRows = 40 KB per workgroup: four workgroups per CU.  Round 5 measured both sides of that choice on config 5 (LABNOTES): FEWER workgroups cost a lot
+    // kStackLdsMax + kTravRows = 40 KB per workgroup: four workgroups per CU (round 6: 12 stack rows + 2 rows of tree top, until then 8 + 6 - trav4.h).  Round 5 measured both sides of that choice on config 5 (LABNOTES): FEWER workgroups cost a lot
     // (3 per CU: +17 %, 2: +55 %), a FIFTH brings nothing (a 30 KB layout - no hit rows, 4 stack rows - lost exactly what its shorter stack costs at equal
     // occupancy), and stack rows going to the global tail cost 1.2 % (6 rows), 6.8 % (4), 9.5 % (2).
-    // PSDR_STACK_LDS = 2 ... 8 (test knob, read when a scene is created or rebuilt): fewer rows, so that small test scenes reach the global tail too
+    // PSDR_STACK_LDS = 2 ... kStackLdsMax (test knob, read when a scene is created or rebuilt): fewer rows, so that small test scenes reach the global tail too
     // (tests/test_gpu_configs.py: the forked terms of a renderD against the serial call)
-    int kStackLds = 8;
-    if (const char *e = std::getenv("PSDR_STACK_LDS")) kStackLds = std::max(2, std::min(8, std::atoi(e)));
+    int kStackLds = kStackLdsMax;
+    if (const char *e = std::getenv("PSDR_STACK_LDS")) kStackLds = std::max(2, std::min(kStackLdsMax, std::atoi(e)));
     T.stack_lds = uses_bvh ? std::min(kStackLds, sc->tree_max_stack) : 0;
     T.stack_depth = uses_bvh ? T.stack_lds + kTravRows : kColdRows;   // BVH: + parked rays, best hits and the pair ring of the traversal (trav4.h); brute force: cold path state (paths.h)
 

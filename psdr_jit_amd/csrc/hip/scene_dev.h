@@ -23,7 +23,12 @@ constexpr int kColdRows = 15;               // LDS rows of a brute-force scene: 
 #define PSDR_BVH_WIDTH 4
 #endif
 constexpr int kNodeW4 = PSDR_BVH_WIDTH == 4 ? 4 : 8;       // float4 words per node
-constexpr int kTravRows = 32;               // LDS rows (of kBlock words) behind the stack of a BVH scene: parked rays, per-ray best hits, the top of the tree, pair ring, ray queue, heads (trav4.h)
+#ifndef PSDR_TOP_ROWS                       // LDS rows that hold the top of the tree (trav4.h::kTopNodes = 16 nodes per row; bvh.h numbers that many nodes breadth first)
+#define PSDR_TOP_ROWS 2
+#endif
+constexpr int kTopRows = PSDR_TOP_ROWS;
+constexpr int kTravRows = 26 + kTopRows;    // LDS rows (of kBlock words) behind the stack of a BVH scene: parked rays, per-ray best hits, the top of the tree, pair ring, ray queue, heads (trav4.h)
+constexpr int kStackLdsMax = 40 - kTravRows;      // stack rows kept in LDS: what is left of 40 KB per workgroup (four workgroups per CU; scene_build.hip)
 
 // EnvironmentMap after configure() (psdr_envmap_rec): too large for the LDS blob, read from global memory
 struct EnvDev {

@@ -49,6 +49,9 @@ namespace psdr {
 #ifndef PSDR_TOP_LDS           // 1: the first kTopNodes nodes of the tree are read from the workgroup's LDS copy
 #define PSDR_TOP_LDS 1
 #endif
+#ifndef PSDR_FAST_STACK        // 1: pushes and pops without the global tail's branch in the burst iterations in which no lane is near it (wave-uniform test)
+#define PSDR_FAST_STACK 1
+#endif
 #ifndef PSDR_STEAL             // 1: workers without a ray take over the bottom stack entry (the far subtree) of a walk in progress once the wave's ray queue is empty
 #define PSDR_STEAL 1
 #endif
@@ -87,7 +90,7 @@ constexpr unsigned kT4Miss = 0xffffffffu;      // sort key of a child the ray do
 // LDS rows (of kBlock words) behind the traversal stack, per workgroup of four waves (scene_dev.h::kTravRows):
 //   kParkWords rows  parked rays   [word][lane]            oA dA oB dB + the any-hit distance of ray A, written by the owner
 //   4 rows           best          [wave][kRayCap] x u64   (t bits << 32 | original id) per ray
-//   6 rows           top           [kTopNodes][16]         the first kTopNodes nodes of the tree (bvh.h numbers the top levels first): every walk starts there, and an
+//   kTopRows rows    top           [kTopNodes][16]         the first kTopNodes nodes of the tree (bvh.h numbers the top levels first): every walk starts there, and an
 //                                                             LDS read costs the wave 8 clocks where 64 lanes on 64 different cache lines cost the L1 a tag lookup each
 //   2 rows           fin           [wave][kRayCap]         0 = walk not finished; else 1 + sequence number after the ray's last pair
 //   kPairRows rows   pair ring     [wave][kPairCap]        (slot << 7 | ray)
@@ -96,8 +99,8 @@ constexpr unsigned kT4Miss = 0xffffffffu;      // sort key of a child the ray do
 constexpr int kRayCap = 128;                   // rays of a wave: two per lane; ray id = k * 64 + owner lane (k = 0: next-event ray, 1: extension ray)
 constexpr int kPairCap = 256;                  // power of two >= 63 left over + 64 workers x 2 triangles per leaf (bvh.h: leaves of <= 2)
 constexpr int kPairRows = (4 * kPairCap + kBlock - 1) / kBlock;
-constexpr int kRowBest = kParkWords, kRowTop = kRowBest + 4, kRowFin = kRowTop + 6, kRowPair = kRowFin + 2, kRowRq = kRowPair + kPairRows, kRowHeads = kRowRq + 2;
-constexpr int kTopNodes = 6 * kBlock / (4 * kNodeW4);       // 96 nodes of 64 bytes (48 of 128 in the 8-wide measurement build)
+constexpr int kRowBest = kParkWords, kRowTop = kRowBest + 4, kRowFin = kRowTop + kTopRows, kRowPair = kRowFin + 2, kRowRq = kRowPair + kPairRows, kRowHeads = kRowRq + 2;
+constexpr int kTopNodes = kTopRows * kBlock / (4 * kNodeW4);       // 16 nodes of 64 bytes per row (8 of 128 in the 8-wide measurement build)
 static_assert(kTravRows == kRowHeads + 1, "scene_dev.h::kTravRows");
 static_assert(kParkWords == 13, "scene_dev.h::kParkWords");
 enum { kHdPairEnq = 0, kHdPairTested = 1, kHdRayTail = 2, kHdRayHead = 3 };
@@ -180,7 +183,20 @@ template <int LDS> PSDR_DEV unsigned t4_pop(const SceneView<LDS> &S, const T4Lds
 }
 
 // next node of this worker's ray: pop until an entry is not behind the closest hit; kT4Done when the stack is empty
-template <int LDS> PSDR_DEV unsigned t4_next(const SceneView<LDS> &S, const T4Lds<LDS> &L, Trav4 &tr, unsigned cmask, float best_t) {
+template <int LDS, bool FAST = false> PSDR_DEV unsigned t4_next(const SceneView<LDS> &S, const T4Lds<LDS> &L, Trav4 &tr, unsigned cmask, float best_t) {
+#if PSDR_FAST_STACK
+    if constexpr (FAST)
+    // (round 6) every stack of the lanes that pop now lies in LDS - with 12 rows that is 93 % of the burst iterations of config 5 -: the loop without the global tail's branch
+    if (__ballot(tr.sp > S.T->stack_lds) == 0ull) {
+        lds_int_t *b = t4_stack_base(L);
+        while (tr.sp > tr.sb) {
+            --tr.sp;
+            const unsigned key = (unsigned) b[tr.sp * kBlock];
+            if (__uint_as_float(key & ~cmask) <= best_t) return key & cmask;
+        }
+        return kT4Done;
+    }
+#endif
     while (tr.sp > tr.sb) {
         const unsigned key = t4_pop(S, L, tr.sp);
         if (__uint_as_float(key & ~cmask) <= best_t) return key & cmask;
@@ -225,7 +241,7 @@ template <int LDS, bool COUNT> PSDR_DEV void t4_start(SceneView<LDS> &S, const T
 }
 
 // one inner node for the workers whose code is an inner node
-template <int LDS, bool COUNT> PSDR_DEV void t4_node(SceneView<LDS> &S, const T4Lds<LDS> &L, Trav4 &tr, unsigned cmask) {
+template <int LDS, bool COUNT, bool FAST = false> PSDR_DEV void t4_node(SceneView<LDS> &S, const T4Lds<LDS> &L, Trav4 &tr, unsigned cmask) {
     const SceneTables &T = *S.T;
 #if PSDR_DIAG != 8
     if (COUNT) S.c_nodes++;
@@ -288,7 +304,7 @@ template <int LDS, bool COUNT> PSDR_DEV void t4_node(SceneView<LDS> &S, const T4
 #undef PSDR_CX
 #pragma unroll
     for (int k = 7; k >= 1; --k) if (key8[k] != kT4Miss) t4_push(S, L, tr.sp, key8[k]);
-    tr.code = key8[0] != kT4Miss ? (key8[0] & cmask) : t4_next(S, L, tr, cmask, bt);
+    tr.code = key8[0] != kT4Miss ? (key8[0] & cmask) : t4_next<LDS, FAST>(S, L, tr, cmask, bt);
 }
 #else
     float4 n0, n1, n2, n3;
@@ -341,15 +357,29 @@ template <int LDS, bool COUNT> PSDR_DEV void t4_node(SceneView<LDS> &S, const T4
     unsigned a = min(key[0], key[1]), b = max(key[0], key[1]), c = min(key[2], key[3]), e = max(key[2], key[3]);
     const unsigned k0 = min(a, c), m1 = max(a, c), m2 = min(b, e), k3 = max(b, e);
     const unsigned k1 = min(m1, m2), k2 = max(m1, m2);
-    if (k3 != kT4Miss) t4_push(S, L, tr.sp, k3);
-    if (k2 != kT4Miss) t4_push(S, L, tr.sp, k2);
-    if (k1 != kT4Miss) t4_push(S, L, tr.sp, k1);
-    tr.code = k0 != kT4Miss ? (k0 & cmask) : t4_next(S, L, tr, cmask, bt);
+#if PSDR_FAST_STACK
+    // (round 6) the pushes without a branch when no lane of this step comes within three entries of the global tail (wave-uniform test): the keys are sorted, so the far
+    // ones are the misses - all three words are written, a miss onto the slot the next valid key overwrites (LDS executes a wave's writes in order) or above the new top
+    if (FAST && __ballot(tr.sp + 3 > T.stack_lds) == 0ull) {
+        const int n_push = (k1 != kT4Miss ? 1 : 0) + (k2 != kT4Miss ? 1 : 0) + (k3 != kT4Miss ? 1 : 0);
+        lds_int_t *b = t4_stack_base(L) + tr.sp * kBlock;
+        b[(n_push > 3 ? n_push - 3 : 0) * kBlock] = (int) k3;
+        b[(n_push > 2 ? n_push - 2 : 0) * kBlock] = (int) k2;
+        b[(n_push > 1 ? n_push - 1 : 0) * kBlock] = (int) k1;
+        tr.sp += n_push;
+    } else
+#endif
+    {
+        if (k3 != kT4Miss) t4_push(S, L, tr.sp, k3);
+        if (k2 != kT4Miss) t4_push(S, L, tr.sp, k2);
+        if (k1 != kT4Miss) t4_push(S, L, tr.sp, k1);
+    }
+    tr.code = k0 != kT4Miss ? (k0 & cmask) : t4_next<LDS, FAST>(S, L, tr, cmask, bt);
 }
 #endif
 
 // the leaf in hand (called by the workers that hold one, together): its triangles join the wave's pair ring
-template <int LDS> PSDR_DEV void t4_enqueue(const SceneView<LDS> &S, const T4Lds<LDS> &L, Trav4 &tr, unsigned cmask, unsigned leaf_bit) {
+template <int LDS, bool FAST = false> PSDR_DEV void t4_enqueue(const SceneView<LDS> &S, const T4Lds<LDS> &L, Trav4 &tr, unsigned cmask, unsigned leaf_bit) {
     const int payload = (int) (tr.code & (leaf_bit - 1u)), first = payload >> 2, cnt = (payload & 3) + 1;        // a leaf holds one or two triangles (bvh.h::build_bvh, kLeafMax)
 #ifdef PSDR_ENQ_BALLOT
     // (round 2/3 form: exclusive prefix sum of cnt over the participating lanes - two ballots, four popcounts, a head read, a fence and a head write for the ~8 lanes
@@ -371,7 +401,7 @@ template <int LDS> PSDR_DEV void t4_enqueue(const SceneView<LDS> &S, const T4Lds
     L.ring[mine & (kPairCap - 1)] = ((unsigned) first << 7) | (unsigned) tr.rid;
     if (cnt > 1) L.ring[(mine + 1u) & (kPairCap - 1)] = ((unsigned) (first + 1) << 7) | (unsigned) tr.rid;
     tr.last_pair = mine + (unsigned) cnt;
-    tr.code = t4_next(S, L, tr, cmask, t4_best_t(L.best, tr.rid));
+    tr.code = t4_next<LDS, FAST>(S, L, tr, cmask, t4_best_t(L.best, tr.rid));
 }
 
 // all participating lanes test one pair each, `n` pairs starting at sequence number `from`
@@ -424,7 +454,9 @@ template <int LDS> PSDR_DEV Hit t4_result(const SceneView<LDS> &S, int k) {
 // finished).  `posted`: bit k set = this lane posted ray k with t4_post and has not consumed it yet.  May be called under a partial
 // exec mask: only the active lanes work (and are counted).  Returns true for a lane whose posted rays are all finished (their hits:
 // t4_result); the workers' walks in progress stay in `tr` for the next call.
-template <int LDS, bool COUNT>
+// FAST (round 6): the branch-free stack paths of t4_node / t4_next in the burst iterations that allow them - the path kernels (run_paths_async) gain 1.4 % from them, the
+// synchronous callers lose (config 5's secondary-edge kernel 20.2 -> 21.6 ms: its registers are what it runs out of), so they keep the plain form
+template <int LDS, bool COUNT, bool FAST = false>
 PSDR_DEV bool trav4_run(SceneView<LDS> &S, Trav4 &tr, int posted, int max_busy) {
     const SceneTables &T = *S.T;
     const T4Lds<LDS> L(S);
@@ -536,12 +568,15 @@ PSDR_DEV bool trav4_run(SceneView<LDS> &S, Trav4 &tr, int posted, int max_busy) 
 #if PSDR_DIAG == 11
                 if (COUNT) { if (tr.code >= leaf_bit && tr.code != kT4Done) S.c_tris++; else if (tr.rid < 0) S.c_rays++; else if (tr.code == kT4Done) S.c_hits++; }
 #elif PSDR_DIAG == 12
-                if (COUNT) { const bool deep = tr.code < leaf_bit && tr.sp + 3 > T.stack_lds; if (deep) S.c_tris++; if (__ballot(deep) != 0ull) S.c_rays++; S.c_hits++; }
+#ifndef PSDR_DEEP_AT
+#define PSDR_DEEP_AT T.stack_lds
 #endif
-                if (tr.code < leaf_bit) t4_node<LDS, COUNT>(S, L, tr, cmask);
+                if (COUNT) { const bool deep = tr.code < leaf_bit && tr.sp + 3 > PSDR_DEEP_AT; if (deep) S.c_tris++; if (__ballot(deep) != 0ull) S.c_rays++; S.c_hits++; }
+#endif
+                if (tr.code < leaf_bit) t4_node<LDS, COUNT, FAST>(S, L, tr, cmask);
 #pragma unroll
                 for (int er = 0; er < PSDR_ENQ_ROUNDS; ++er)
-                    if (tr.code >= leaf_bit && tr.code != kT4Done) t4_enqueue(S, L, tr, cmask, leaf_bit);
+                    if (tr.code >= leaf_bit && tr.code != kT4Done) t4_enqueue<LDS, FAST>(S, L, tr, cmask, leaf_bit);
 #if PSDR_DIAG == 1
                 if (COUNT) S.c_hits++;
 #endif
