@@ -317,21 +317,25 @@ def main():
             sync()
             form_ms[name] = (time.perf_counter() - t_f) / reps * 1e3
         # ... and the contiguous row-tile partition (render times per rank show its balance, the step its all-gather)
-        rows_acc = 0.0
-        for i in range(reps):
+        rows_acc, rows_error = 0.0, None
+        try:
+            for i in range(reps):
+                sync()
+                ev[0].record()
+                launch(7000 + i, shard_mode=1)
+                ev[1].record()
+                torch.cuda.synchronize()
+                rows_acc += ev[0].elapsed_time(ev[1])
+            step_rows(7100)
             sync()
-            ev[0].record()
-            launch(7000 + i, shard_mode=1)
-            ev[1].record()
-            torch.cuda.synchronize()
-            rows_acc += ev[0].elapsed_time(ev[1])
-        step_rows(7100)
-        sync()
-        t_f = time.perf_counter()
-        for i in range(reps):
-            step_rows(7101 + i)
-        sync()
-        form_ms["rows"] = (time.perf_counter() - t_f) / reps * 1e3
+            t_f = time.perf_counter()
+            for i in range(reps):
+                step_rows(7101 + i)
+            sync()
+            form_ms["rows"] = (time.perf_counter() - t_f) / reps * 1e3
+        except Exception as e:                      # (an extra outside the timed region must not cost the line)
+            rows_error = repr(e)[:300]
+            form_ms["rows"] = 0.0
         mine = torch.tensor([acc[0] / reps, acc[1] / reps, rows_acc / reps], dtype=torch.float64, device="cuda")
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
@@ -340,7 +344,7 @@ def main():
                      "step_ms_split_collectives": round(form_ms["split"], 3), "step_ms_single_collective": round(form_ms["single"], 3),
                      "overlap_ms": round(form_ms["single"] - form_ms["split"], 3), "timed_form": "rows" if rows_timed else ("single" if single_collective else "split"),
                      "row_tiles": {"render_ms_per_rank": [round(float(t[2]), 3) for t in allr], "step_ms": round(form_ms["rows"], 3), "all_gather_bytes_per_rank": int(2 * tile * 3 * 4),
-                                   "all_reduce_bytes": int(npx * 3 * 4),
+                                   "all_reduce_bytes": int(npx * 3 * 4), "error": rows_error,
                                    "note": "PSDR_SHARD=rows: contiguous pixel-row tiles (psdr_render_args.shard_mode 1), interior term by all_gather_into_tensor, edge derivative by all_reduce; "
                                            "render_ms_per_rank shows the balance of the tiles against the interleaved chunks above"},
                      "note": "HIP events on the launch stream, mean of %d steps outside the timed region; a rank's all-reduce time includes its wait for the slowest rank's render; "
