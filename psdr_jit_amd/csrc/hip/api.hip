@@ -359,9 +359,6 @@ __global__ __launch_bounds__(kBlock, (ADJ ? PSDR_SEC_ADJ_WAVES : PSDR_SEC_WAVES)
                 if (lane_id < pool_n) spare = pool_at(lane_id);
             }
             wave_sync();
-#ifdef PSDR_T_SEC_NOTRACE
-            stage = 0;          // measurement build: the candidate phase alone (wrong results)
-#endif
             if (__ballot(stage != 0) == 0ull) { if (exhausted && q_next >= q_end && pool_n == 0) break; continue; }
             // ---- the rays of every lane's stage in one call
             const Vec3f p0v = detach(bss.p0), dirv = normalize(bss.p2 - p0v);
