@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PSDR_HIP_ABI_VERSION 15
+#define PSDR_HIP_ABI_VERSION 16
 
 /* TriangleInfo SoA, reference include/psdr/types.h:162-175 (+ Scene::m_triangle_uv,
  * m_triangle_face_normals, scene.cpp:528-542).  Arrays of n_triangles rows. */
@@ -151,6 +151,24 @@ typedef struct psdr_sensor_rec {
     float edge_sum;
 } psdr_sensor_rec;
 
+/* What ONE mesh's rows of psdr_triangles / psdr_sec_edges are a function of (ABI 16): Mesh::configure + process_mesh, reference src/shape/mesh.cpp:23-62, 317-400, run on
+ * drjit device arrays - the reference computes these rows ON THE GPU in every Scene::configure.  With psdr_scene_snapshot.geometry set, psdr_hip_scene_update computes the
+ * rows of the meshes flagged `moved` on the device, in the host's own (value, tangent) arithmetic (csrc/host/hnum.h compiled for both sides: the same bits), from the raw vertices
+ * and the composed transform: ~1 MB travels instead of the 30 MB of rows the host would write.  The snapshot's row arrays stay valid (they are what psdr_hip_scene_create,
+ * a rebuild and the host-side consumers read); the edge CDFs and the sensors' primary edges still come from the host. */
+typedef struct psdr_mesh_geometry {
+    int32_t n_vertices, n_faces, n_edges;          /* n_edges: this mesh's rows of psdr_sec_edges (0 when its edges are disabled or sppse == 0) */
+    const float *vertices_raw, *d_vertices_raw;    /* [n_vertices*3] Mesh::m_vertex_positions_raw and its forward tangent */
+    float to_world[16], d_to_world[16];            /* m_to_world_left * m_to_world_raw * m_to_world_right, row-major, composed in (value, tangent) arithmetic by the host */
+    const int32_t *faces;                          /* [n_faces*3] mesh-local vertex ids (Mesh::m_face_indices) */
+    const int32_t *vf_begin, *vf_item;             /* [n_vertices+1], [n_faces*3]: per vertex its (face << 2 | corner) incidences in the order the reference's three scatter passes
+                                                      visit them (mesh.cpp:34-41), so that the per-vertex normal sums add in that very order */
+    const int32_t *edges;                          /* [n_edges*5] v0 v1 f0 f1 opp (Mesh::m_edge_indices; f1 = -1: boundary edge) */
+    int32_t mesh_id, use_face_normals;
+    uint64_t topology_version;                     /* changes whenever faces / vf lists / edges / the counts do: the device keeps the topology of the version it saw last */
+    int32_t moved;                                 /* 1: vertices, transform or their tangents differ from what the previous create / update carried */
+} psdr_mesh_geometry;
+
 typedef struct psdr_scene_snapshot {
     int32_t abi_version;                      /* PSDR_HIP_ABI_VERSION */
     int32_t width, height, spp, sppe, sppse;  /* RenderOption, reference include/psdr/types.h:217-228 */
@@ -165,6 +183,7 @@ typedef struct psdr_scene_snapshot {
     psdr_sec_edges sec_edges;
     int32_t n_sensors;  const psdr_sensor_rec *sensors;
     const psdr_envmap_rec *envmap;            /* Scene::m_emitter_env, NULL = none */
+    const psdr_mesh_geometry *geometry;       /* [n_meshes] or NULL: lets psdr_hip_scene_update compute moved meshes' rows on the device (BVH scenes; see psdr_mesh_geometry) */
 } psdr_scene_snapshot;
 
 /* One of Scene::m_samplers[0..2] in closed form: lane i was seeded with
@@ -263,6 +282,9 @@ int psdr_hip_scene_last_update(const psdr_hip_scene *scene, psdr_update_info *in
 /* test aid (synchronises, downloads the tree): number of places where the device tree is NOT a bounding hierarchy of the device triangles - a child
  * box that does not contain the padded box of a triangle below it, a triangle slot under no or several leaves.  0 for brute-force scenes. */
 int psdr_hip_scene_check_tree(const psdr_hip_scene *scene, int64_t *violations);
+/* test aid (synchronises, downloads the sections): 32-bit words of the device's triangle rows (traversal, shading, tangent) and secondary-edge rows that differ from the rows
+ * the host path would write from `snapshot` - 0 when the kernels that compute a moved mesh's rows on the device (psdr_mesh_geometry) produced the host's bits */
+int psdr_hip_scene_check_rows(const psdr_hip_scene *scene, const psdr_scene_snapshot *snapshot, int64_t *mismatches);
 /* BVH statistics for DESIGN/bench: nodes, leaves, max depth, bytes resident in LDS per workgroup */
 int psdr_hip_scene_stats(const psdr_hip_scene *scene, int32_t *n_nodes, int32_t *n_leaves, int32_t *max_depth, int32_t *lds_bytes);
 /* The live-pixel mask of a sensor (HOST bits[(width*height + 31) / 32], bit y*width + x; either pointer may be NULL): a pixel is dead when

@@ -26,9 +26,9 @@ SCENE_SRC = os.path.join(CSRC, "hip", "scene_build.hip")        # psdr_hip_scene
 HIP_SRCS = [API_SRC, SCENE_SRC]
 BUILD_DEPS = [os.path.join(HERE, "isa_lint.py")]          # part of the recipe: a change of the lint re-builds (and re-lints) the library
 _H = lambda *names: [os.path.join(CSRC, "hip", f) for f in names]
-COMMON_DEPS = _H("scene_obj.h", "scene_dev.h", "dmath.h", "trav4.h") + [os.path.join(ROOT, "include", "psdr_hip.h")]
+COMMON_DEPS = _H("scene_obj.h", "scene_dev.h", "dmath.h", "trav4.h") + [os.path.join(ROOT, "include", "psdr_hip.h"), os.path.join(CSRC, "common", "threads.h")]
 API_DEPS = COMMON_DEPS + _H("sampler.h", "shade.h", "edges.h", "paths.h", "adjoint.h", "adjoint_mat.h", "microfacet.h") + [os.path.join(CSRC, "common", "envmath.h")] + BUILD_DEPS
-SCENE_DEPS = COMMON_DEPS + _H("bvh.h", "filter.h") + [os.path.join(CSRC, "common", "threads.h")] + BUILD_DEPS
+SCENE_DEPS = COMMON_DEPS + _H("bvh.h", "filter.h") + [os.path.join(CSRC, "host", "hnum.h")] + BUILD_DEPS
 HIP_DEPS = sorted(set(API_DEPS + SCENE_DEPS))
 HOST_SRCS = [os.path.join(CSRC, "host", f) for f in ("scene_host.cpp", "bindings.cpp", "exr_piz.cpp")]
 HOST_DEPS = [os.path.join(CSRC, "host", f) for f in ("scene_host.h", "hnum.h", "exr_piz.h")] + [os.path.join(ROOT, "include", "psdr_hip.h"), os.path.join(CSRC, "common", "envmath.h"), os.path.join(CSRC, "common", "threads.h")]

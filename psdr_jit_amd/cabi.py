@@ -7,7 +7,7 @@ from . import build as _build
 
 SYMBOLS = [
     "psdr_hip_last_error", "psdr_hip_abi_version", "psdr_hip_device_count", "psdr_hip_set_device",
-    "psdr_hip_scene_create", "psdr_hip_scene_update", "psdr_hip_scene_last_update", "psdr_hip_scene_check_tree", "psdr_hip_scene_destroy", "psdr_hip_scene_stats", "psdr_hip_scene_live_pixels", "psdr_hip_bvh_node_bytes", "psdr_hip_scene_tex_layout", "psdr_hip_trace", "psdr_hip_trace_pairs", "psdr_hip_ray_intersect", "psdr_hip_env_sample", "psdr_hip_env_pdf", "psdr_hip_env_cell_masses", "psdr_hip_env_cell_masses_xf",
+    "psdr_hip_scene_create", "psdr_hip_scene_update", "psdr_hip_scene_last_update", "psdr_hip_scene_check_tree", "psdr_hip_scene_check_rows", "psdr_hip_scene_destroy", "psdr_hip_scene_stats", "psdr_hip_scene_live_pixels", "psdr_hip_bvh_node_bytes", "psdr_hip_scene_tex_layout", "psdr_hip_trace", "psdr_hip_trace_pairs", "psdr_hip_ray_intersect", "psdr_hip_env_sample", "psdr_hip_env_pdf", "psdr_hip_env_cell_masses", "psdr_hip_env_cell_masses_xf",
     "psdr_hip_render_c", "psdr_hip_render_d_fwd", "psdr_hip_render_d_bwd", "psdr_hip_render_c_counted", "psdr_hip_render_d_fwd_counted",
     "psdr_hip_li_lanes", "psdr_hip_guiding_build", "psdr_hip_guiding_mass", "psdr_hip_guiding_num_cells",
     "psdr_hip_guiding_destroy", "psdr_hip_tea64", "psdr_hip_sampler_floats",

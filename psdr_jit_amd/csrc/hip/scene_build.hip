@@ -20,6 +20,7 @@
 #include "scene_obj.h"
 #include "bvh.h"
 #include "filter.h"
+#include "../host/hnum.h"
 
 using namespace psdr;
 
@@ -206,6 +207,223 @@ template <typename P> static int sync_named(psdr_hip_scene *sc, const std::strin
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// GEOMETRY ON THE DEVICE (round 6; psdr_mesh_geometry, include/psdr_hip.h).  The reference's Mesh::configure / process_mesh run on drjit device arrays
+// (src/shape/mesh.cpp:23-62, 317-400); until this round a moved vertex made the HOST recompute every row of its mesh and psdr_hip_scene_update rewrite and send
+// them (34 MB for config 5).  Here the rows of the moved meshes are computed by five small kernels from the raw vertices and the composed transform, in the
+// host's own dual-number code (csrc/host/hnum.h, __host__ __device__; -ffp-contract=off and correctly rounded division / square root on both sides), so the
+// sections hold the bits the host would have written (psdr_hip_scene_check_rows compares them):
+//   k_geo_world    world[v]  = xform_pos(to_world, raw[v])                              Mesh::configure, mesh.cpp:330-340
+//   k_geo_face     fn[f]     = cross(e1, e2), area2[f] = |fn|                           process_mesh, mesh.cpp:26-33
+//   k_geo_vnormal  vn[v]     = normalize(sum fn / sum area2) over the vertex' faces in the reference's scatter order     mesh.cpp:34-44
+//   k_geo_rows     traversal / shading / tangent rows of the blob, at the slot of the triangle (leaf order)
+//   k_geo_sec      secondary-edge rows (mesh.cpp:355-369, scene.cpp:546-571); their CDF stays with the host (a sequential float prefix sum the parity tests pin)
+struct GeoMeshDev { float tw[16], d_tw[16]; int v_off, n_v, f_off, n_f, e_off, n_e, mesh_id, flat, moved, pad[3]; };
+using psdr_host::DF; using psdr_host::D3; using psdr_host::DM4;
+
+__device__ inline D3 geo_ld(const float *a, size_t i) { const float *q = a + 6 * i; return D3{DF(q[0], q[1]), DF(q[2], q[3]), DF(q[4], q[5])}; }
+__device__ inline void geo_st(float *a, size_t i, const D3 &v) { float *q = a + 6 * i; q[0] = v.x.v; q[1] = v.x.d; q[2] = v.y.v; q[3] = v.y.d; q[4] = v.z.v; q[5] = v.z.d; }
+
+__global__ void k_geo_world(const GeoMeshDev *__restrict__ M, const int *__restrict__ vmesh, const float *__restrict__ raw, const float *__restrict__ d_raw,
+                            float *__restrict__ world, int nv) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv) return;
+    const GeoMeshDev &m = M[vmesh[v]];
+    if (!m.moved) return;
+    DM4 tw;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) tw.m[i][j] = DF(m.tw[4 * i + j], m.d_tw[4 * i + j]);
+    const D3 p{DF(raw[3 * (size_t) v], d_raw[3 * (size_t) v]), DF(raw[3 * (size_t) v + 1], d_raw[3 * (size_t) v + 1]), DF(raw[3 * (size_t) v + 2], d_raw[3 * (size_t) v + 2])};
+    geo_st(world, (size_t) v, psdr_host::xform_pos(tw, p));
+}
+
+__global__ void k_geo_face(const GeoMeshDev *__restrict__ M, const int *__restrict__ fmesh, const int *__restrict__ faces, const float *__restrict__ world,
+                           float *__restrict__ fnrm, float *__restrict__ farea, int nf) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nf) return;
+    if (!M[fmesh[f]].moved) return;
+    const D3 p0 = geo_ld(world, (size_t) faces[3 * (size_t) f]), e1 = geo_ld(world, (size_t) faces[3 * (size_t) f + 1]) - p0, e2 = geo_ld(world, (size_t) faces[3 * (size_t) f + 2]) - p0;
+    const D3 n = psdr_host::dcross(e1, e2);
+    const DF a = psdr_host::dnorm(n);
+    geo_st(fnrm, (size_t) f, n);
+    farea[2 * (size_t) f] = a.v; farea[2 * (size_t) f + 1] = a.d;
+}
+
+__global__ void k_geo_vnormal(const GeoMeshDev *__restrict__ M, const int *__restrict__ vmesh, const int *__restrict__ vf_begin, const int *__restrict__ vf_item,
+                              const float *__restrict__ fnrm, const float *__restrict__ farea, float *__restrict__ vn, int nv) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv) return;
+    if (!M[vmesh[v]].moved) return;
+    D3 acc; DF w;
+    for (int k = vf_begin[v]; k < vf_begin[v + 1]; ++k) {
+        const size_t f = (size_t) (vf_item[k] >> 2);
+        acc = acc + geo_ld(fnrm, f);
+        w = w + DF(farea[2 * f], farea[2 * f + 1]);
+    }
+    geo_st(vn, (size_t) v, psdr_host::dnormalize(acc / w));
+}
+
+__device__ inline float geo_ibits(int v) { return __int_as_float(v); }
+
+__global__ void k_geo_rows(float4 *__restrict__ blob, SceneTables T, const GeoMeshDev *__restrict__ M, const int *__restrict__ fmesh, const int *__restrict__ faces,
+                           const float *__restrict__ world, const float *__restrict__ fnrm, const float *__restrict__ farea, const float *__restrict__ vn, int nf, int values, int tangents) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nf) return;
+    const GeoMeshDev &m = M[fmesh[f]];
+    if (!m.moved) return;
+    const int slot = reinterpret_cast<const int *>(blob + T.map_off)[f];
+    const int i0 = faces[3 * (size_t) f], i1 = faces[3 * (size_t) f + 1], i2 = faces[3 * (size_t) f + 2];
+    const D3 p0 = geo_ld(world, (size_t) i0), e1 = geo_ld(world, (size_t) i1) - p0, e2 = geo_ld(world, (size_t) i2) - p0;
+    const D3 n0 = geo_ld(vn, (size_t) i0), n1 = geo_ld(vn, (size_t) i1), n2 = geo_ld(vn, (size_t) i2);
+    const DF a2 = DF(farea[2 * (size_t) f], farea[2 * (size_t) f + 1]);
+    const D3 fn = geo_ld(fnrm, (size_t) f) / a2;
+    const DF area = a2 * DF(0.5f);
+    if (values) {
+        float4 *t = blob + T.trav_off + 3 * (size_t) slot;
+        t[0] = make_float4(p0.x.v, p0.y.v, p0.z.v, e1.x.v);
+        t[1] = make_float4(e1.y.v, e1.z.v, e2.x.v, e2.y.v);
+        t[2] = make_float4(e2.z.v, geo_ibits(f), 0.f, 0.f);
+        float4 *w = blob + T.shade_off + 6 * (size_t) slot;          // (words 4 and 5 - the uv of the three corners - do not depend on the vertices)
+        w[0] = make_float4(n0.x.v, n0.y.v, n0.z.v, area.v);
+        w[1] = make_float4(n1.x.v, n1.y.v, n1.z.v, geo_ibits(m.mesh_id));
+        w[2] = make_float4(n2.x.v, n2.y.v, n2.z.v, geo_ibits(m.flat ? 1 : 0));
+        w[3] = make_float4(fn.x.v, fn.y.v, fn.z.v, geo_ibits(f));
+    }
+    if (tangents && T.has_tangent) {
+        float4 *w = blob + T.tan_off + 6 * (size_t) slot;
+        w[0] = make_float4(p0.x.d, p0.y.d, p0.z.d, e1.x.d);
+        w[1] = make_float4(e1.y.d, e1.z.d, e2.x.d, e2.y.d);
+        w[2] = make_float4(e2.z.d, n0.x.d, n0.y.d, n0.z.d);
+        w[3] = make_float4(n1.x.d, n1.y.d, n1.z.d, n2.x.d);
+        w[4] = make_float4(n2.y.d, n2.z.d, fn.x.d, fn.y.d);
+        w[5] = make_float4(fn.z.d, area.d, 0.f, 0.f);
+    }
+}
+
+// edges: [ne][6] = v0 v1 opp (global vertex ids), f0 f1 (global face ids, f1 = -1: boundary), mesh index
+__global__ void k_geo_sec(float4 *__restrict__ blob, int sec_off, const GeoMeshDev *__restrict__ M, const int *__restrict__ edges, const float *__restrict__ world,
+                          const float *__restrict__ fnrm, const float *__restrict__ farea, int ne) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= ne) return;
+    const int *e = edges + 6 * (size_t) r;
+    if (!M[e[5]].moved) return;
+    const D3 a = geo_ld(world, (size_t) e[0]), b = geo_ld(world, (size_t) e[1]), c = geo_ld(world, (size_t) e[2]);
+    const float e1[3] = {b.x.v - a.x.v, b.y.v - a.y.v, b.z.v - a.z.v}, de1[3] = {b.x.d - a.x.d, b.y.d - a.y.d, b.z.d - a.z.d};
+    const D3 n0 = geo_ld(fnrm, (size_t) e[3]) / DF(farea[2 * (size_t) e[3]], farea[2 * (size_t) e[3] + 1]);
+    float n1[3] = {0.f, 0.f, 0.f};
+    if (e[4] >= 0) { const D3 q = geo_ld(fnrm, (size_t) e[4]) / DF(farea[2 * (size_t) e[4]], farea[2 * (size_t) e[4] + 1]); n1[0] = q.x.v; n1[1] = q.y.v; n1[2] = q.z.v; }
+    float4 *w = blob + sec_off + 6 * (size_t) r;
+    w[0] = make_float4(a.x.v, a.y.v, a.z.v, e1[0]);
+    w[1] = make_float4(e1[1], e1[2], n0.x.v, n0.y.v);
+    w[2] = make_float4(n0.z.v, n1[0], n1[1], n1[2]);
+    w[3] = make_float4(c.x.v, c.y.v, c.z.v, geo_ibits(e[4] < 0 ? 1 : 0));
+    w[4] = make_float4(a.x.d, a.y.d, a.z.d, de1[0]);
+    w[5] = make_float4(de1[1], de1[2], 0.f, 0.f);
+}
+
+// uploads what the kernels need (topology when a mesh's version changed, raw vertices and transforms of the moved meshes) and runs them; -> 1 on error.
+// `usable` = false (nothing done) when the snapshot's geometry does not describe the scene's triangles and edges one to one.
+static int geometry_on_device(psdr_hip_scene *sc, const psdr_scene_snapshot *s, bool values, bool tangents, bool sec_rows, psdr_update_info &info, bool &usable) {
+    usable = false;
+    const psdr_mesh_geometry *G = s->geometry;
+    if (!G) return 0;
+    const int nm = s->n_meshes;
+    size_t NV = 0, NF = 0, NE = 0;
+    for (int i = 0; i < nm; ++i) {
+        if (G[i].n_faces != s->meshes[i].n_faces || (size_t) s->meshes[i].face_offset != NF || !G[i].vertices_raw || !G[i].d_vertices_raw || !G[i].faces || !G[i].vf_begin || !G[i].vf_item) return 0;
+        if (G[i].n_edges > 0 && !G[i].edges) return 0;
+        NV += (size_t) G[i].n_vertices; NF += (size_t) G[i].n_faces; NE += (size_t) G[i].n_edges;
+    }
+    if (NF != (size_t) s->tris.n_triangles || NE != (size_t) std::max(0, s->sec_edges.n_edges) || NV == 0) return 0;
+    // ---- topology: kept while every mesh reports the version (and the counts) the device saw last
+    bool same_topo = sc->geo_versions.size() == (size_t) nm && sc->geo_counts.size() == 3 * (size_t) nm;
+    for (int i = 0; same_topo && i < nm; ++i)
+        same_topo = sc->geo_versions[(size_t) i] == G[i].topology_version && sc->geo_counts[3 * (size_t) i] == G[i].n_vertices && sc->geo_counts[3 * (size_t) i + 1] == G[i].n_faces &&
+                    sc->geo_counts[3 * (size_t) i + 2] == G[i].n_edges;
+    std::vector<GeoMeshDev> mt((size_t) nm);
+    {
+        size_t vo = 0, fo = 0, eo = 0;
+        for (int i = 0; i < nm; ++i) {
+            GeoMeshDev &m = mt[(size_t) i];
+            std::memcpy(m.tw, G[i].to_world, 64); std::memcpy(m.d_tw, G[i].d_to_world, 64);
+            m.v_off = (int) vo; m.n_v = G[i].n_vertices; m.f_off = (int) fo; m.n_f = G[i].n_faces; m.e_off = (int) eo; m.n_e = G[i].n_edges;
+            m.mesh_id = G[i].mesh_id; m.flat = G[i].use_face_normals; m.moved = (G[i].moved || !same_topo) ? 1 : 0; m.pad[0] = m.pad[1] = m.pad[2] = 0;
+            vo += (size_t) G[i].n_vertices; fo += (size_t) G[i].n_faces; eo += (size_t) G[i].n_edges;
+        }
+    }
+    auto up = [&](const char *key, const void *src, size_t bytes) -> int {
+        DevBuf &b = sc->buf(key);
+        if (b.ensure(bytes)) return 1;
+        if (src) { HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, nullptr)); info.bytes_uploaded += (int64_t) bytes; }
+        return 0;
+    };
+    if (!same_topo) {
+        std::vector<int> faces(3 * NF), vmesh(NV), fmesh(NF), vfb(NV + 1), vfi(3 * NF), edges(6 * std::max<size_t>(1, NE));
+        size_t k = 0;
+        vfb[0] = 0;
+        for (int i = 0; i < nm; ++i) {
+            const GeoMeshDev &m = mt[(size_t) i];
+            for (int v = 0; v < m.n_v; ++v) vmesh[(size_t) m.v_off + (size_t) v] = i;
+            for (int f = 0; f < m.n_f; ++f) {
+                fmesh[(size_t) m.f_off + (size_t) f] = i;
+                for (int c = 0; c < 3; ++c) {
+                    const int vi = G[i].faces[3 * (size_t) f + c];
+                    if (vi < 0 || vi >= m.n_v) return fail("psdr_mesh_geometry: face index outside the mesh's vertices");
+                    faces[3 * ((size_t) m.f_off + (size_t) f) + c] = m.v_off + vi;
+                }
+            }
+            // (vf_begin of a mesh counts from 0; items are (local face << 2 | corner): both move to the global numbering)
+            for (int v = 0; v < m.n_v; ++v) {
+                for (int q = G[i].vf_begin[v]; q < G[i].vf_begin[v + 1]; ++q) { const int it = G[i].vf_item[q]; vfi[k++] = (((it >> 2) + m.f_off) << 2) | (it & 3); }
+                vfb[(size_t) m.v_off + (size_t) v + 1] = (int) k;
+            }
+            for (int e = 0; e < m.n_e; ++e) {
+                const int *q = G[i].edges + 5 * (size_t) e;
+                int *d = &edges[6 * ((size_t) m.e_off + (size_t) e)];
+                d[0] = m.v_off + q[0]; d[1] = m.v_off + q[1]; d[2] = m.v_off + q[4]; d[3] = m.f_off + q[2]; d[4] = q[3] >= 0 ? m.f_off + q[3] : -1; d[5] = i;
+            }
+        }
+        if (k != 3 * NF) return fail("psdr_mesh_geometry: vf lists do not cover the faces");
+        if (up("geo.faces", faces.data(), faces.size() * 4) || up("geo.vmesh", vmesh.data(), vmesh.size() * 4) || up("geo.fmesh", fmesh.data(), fmesh.size() * 4) ||
+            up("geo.vf_begin", vfb.data(), vfb.size() * 4) || up("geo.vf_item", vfi.data(), vfi.size() * 4) || up("geo.edges", edges.data(), edges.size() * 4)) return 1;
+        if (up("geo.raw", nullptr, 12 * NV) || up("geo.d_raw", nullptr, 12 * NV) || up("geo.world", nullptr, 24 * NV) || up("geo.vn", nullptr, 24 * NV) ||
+            up("geo.fnrm", nullptr, 24 * NF) || up("geo.farea", nullptr, 8 * NF)) return 1;
+        HIPCHK(hipStreamSynchronize(nullptr));                     // (the staging vectors go out of scope)
+        sc->geo_versions.resize((size_t) nm); sc->geo_counts.resize(3 * (size_t) nm);
+        for (int i = 0; i < nm; ++i) {
+            sc->geo_versions[(size_t) i] = G[i].topology_version;
+            sc->geo_counts[3 * (size_t) i] = G[i].n_vertices; sc->geo_counts[3 * (size_t) i + 1] = G[i].n_faces; sc->geo_counts[3 * (size_t) i + 2] = G[i].n_edges;
+        }
+    }
+    // ---- this update's inputs: the mesh table, raw vertices and their tangents of the moved meshes
+    if (up("geo.meshes", mt.data(), mt.size() * sizeof(GeoMeshDev))) return 1;
+    float *raw = (float *) sc->buf("geo.raw").p, *d_raw = (float *) sc->buf("geo.d_raw").p;
+    bool any = false;
+    for (int i = 0; i < nm; ++i) {
+        const GeoMeshDev &m = mt[(size_t) i];
+        if (!m.moved || m.n_v == 0) continue;
+        any = true;
+        HIPCHK(hipMemcpyAsync(raw + 3 * (size_t) m.v_off, G[i].vertices_raw, 12 * (size_t) m.n_v, hipMemcpyHostToDevice, nullptr));
+        HIPCHK(hipMemcpyAsync(d_raw + 3 * (size_t) m.v_off, G[i].d_vertices_raw, 12 * (size_t) m.n_v, hipMemcpyHostToDevice, nullptr));
+        info.bytes_uploaded += (int64_t) (24 * (size_t) m.n_v);
+    }
+    usable = true;
+    if (!any) return 0;
+    const GeoMeshDev *Md = sc->buf("geo.meshes").as<GeoMeshDev>();
+    const int *vmesh = sc->buf("geo.vmesh").as<int>(), *fmesh = sc->buf("geo.fmesh").as<int>(), *faces = sc->buf("geo.faces").as<int>();
+    float *world = (float *) sc->buf("geo.world").p, *vn = (float *) sc->buf("geo.vn").p, *fnrm = (float *) sc->buf("geo.fnrm").p, *farea = (float *) sc->buf("geo.farea").p;
+    const unsigned bv = (unsigned) ((NV + 255) / 256), bf = (unsigned) ((NF + 255) / 256), be = (unsigned) ((NE + 255) / 256);
+    hipLaunchKernelGGL(k_geo_world, dim3(bv), dim3(256), 0, nullptr, Md, vmesh, raw, d_raw, world, (int) NV);
+    hipLaunchKernelGGL(k_geo_face, dim3(bf), dim3(256), 0, nullptr, Md, fmesh, faces, world, fnrm, farea, (int) NF);
+    hipLaunchKernelGGL(k_geo_vnormal, dim3(bv), dim3(256), 0, nullptr, Md, vmesh, sc->buf("geo.vf_begin").as<int>(), sc->buf("geo.vf_item").as<int>(), fnrm, farea, vn, (int) NV);
+    if (values || tangents)
+        hipLaunchKernelGGL(k_geo_rows, dim3(bf), dim3(256), 0, nullptr, (float4 *) sc->blob.p, sc->T, Md, fmesh, faces, world, fnrm, farea, vn, (int) NF, values ? 1 : 0, tangents ? 1 : 0);
+    if (sec_rows && NE > 0)
+        hipLaunchKernelGGL(k_geo_sec, dim3(be), dim3(256), 0, nullptr, (float4 *) sc->blob.p, sc->E.off, Md, sc->buf("geo.edges").as<int>(), world, fnrm, farea, (int) NE);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(nullptr));                         // (the mesh table is a local; the kernels take ~0.1 ms)
+    return 0;
+}
+
 struct WordRange { size_t b, e; };
 
 // Everything between a snapshot and a renderable device scene.  fresh: the handle is new.  same: PSDR_SAME_* bits the caller vouches for
@@ -330,7 +548,19 @@ static int scene_sync(psdr_hip_scene *sc, const psdr_scene_snapshot *s, unsigned
         for (int i = 0; i < n; ++i) H[4 * (size_t) T.map_off + (size_t) i] = ibits(sc->orig2slot[(size_t) i]);
         mark((size_t) T.map_off, (size_t) T.map_off + words_for_floats((size_t) n));
     }
-    const bool write_geo = geo || blob_moved || T.trav_off != Told.trav_off || T.shade_off != Told.shade_off;
+    // ---- moved meshes: their rows computed on the device (geometry_on_device above) when nothing else about the layout changed; the host then writes none of them
+    bool dev_geo = false;
+    {
+        const bool layout_same = !fresh && !build && !blob_moved && uses_bvh && T.trav_off == Told.trav_off && T.shade_off == Told.shade_off && T.tan_off == Told.tan_off &&
+                                 T.map_off == Told.map_off && (has_tan ? 1 : 0) == Told.has_tangent && E.off == Eold.off && E.cdf_off == Eold.cdf_off && E.n == Eold.n;
+        const bool forced_host = std::getenv("PSDR_HOST_GEOMETRY") != nullptr;         // test knob, read per call: the host writes the rows (what psdr_hip_scene_check_rows compares with)
+        if (layout_same && !forced_host && s->geometry != nullptr && (geo || !same_tan || !same_sec)) {
+            if (geometry_on_device(sc, s, geo, has_tan && !same_tan, !same_sec, info, dev_geo)) return 1;
+        }
+    }
+    // (the pinned host copy of a section the device wrote is behind the device's; it is only ever sent after the host has rewritten the whole section from the snapshot -
+    //  a change of the section itself, or a moved allocation, both of which write it first)
+    const bool write_geo = !dev_geo && (geo || blob_moved || T.trav_off != Told.trav_off || T.shade_off != Told.shade_off);
     if (write_geo) {
         parallel_for((size_t) n, 8192, [&](size_t b0, size_t e0) {
             for (size_t slot = b0; slot < e0; ++slot) {
@@ -354,7 +584,7 @@ static int scene_sync(psdr_hip_scene *sc, const psdr_scene_snapshot *s, unsigned
         });
         mark((size_t) T.trav_off, (size_t) T.trav_off + 9 * (size_t) n);
     }
-    if (has_tan && (!same_tan || blob_moved || T.tan_off != Told.tan_off || !Told.has_tangent)) {
+    if (has_tan && !dev_geo && (!same_tan || blob_moved || T.tan_off != Told.tan_off || !Told.has_tangent)) {
         parallel_for((size_t) n, 8192, [&](size_t b0, size_t e0) {
             for (size_t slot = b0; slot < e0; ++slot) {
                 const size_t o = (size_t) order[slot];
@@ -371,7 +601,11 @@ static int scene_sync(psdr_hip_scene *sc, const psdr_scene_snapshot *s, unsigned
         });
         mark((size_t) T.tan_off, (size_t) T.tan_off + 6 * (size_t) n);
     }
-    if (geo) {
+    if (geo && uses_bvh) {
+        // (the bounding sphere and the filter primitives belong to the brute-force tracer, scene_dev.h::trace2: a BVH scene has neither - and the serial pass over its
+        //  triangles' vertices was 0.5 ms of every moved-vertex update of config 5)
+        T.center[0] = T.center[1] = T.center[2] = 0.f; T.radius = 0.f; T.filt_kmax = 0.f; T.filt_hasb[0] = T.filt_hasb[1] = 0u;
+    } else if (geo) {
         // bounding sphere of the scene (for the absolute slack of the quad filter)
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
         for (int i = 0; i < n; ++i)
@@ -442,7 +676,12 @@ static int scene_sync(psdr_hip_scene *sc, const psdr_scene_snapshot *s, unsigned
 
     // ---- secondary edges
     const bool write_sec = !same_sec || blob_moved || E.off != Eold.off || E.cdf_off != Eold.cdf_off || E.n != Eold.n;
-    if (write_sec && se.n_edges > 0) {
+    if (write_sec && se.n_edges > 0 && dev_geo) {
+        // (the rows are the device's; the distribution over the edges - a sequential float prefix sum - comes from the host)
+        std::memcpy(H + 4 * (size_t) E.cdf_off, se.pmf, sizeof(float) * (size_t) se.n_edges);
+        std::memcpy(H + 4 * (size_t) E.cdf_off + (size_t) se.n_edges, se.cmf, sizeof(float) * (size_t) se.n_edges);
+        mark((size_t) E.cdf_off, sec_end);
+    } else if (write_sec && se.n_edges > 0) {
         parallel_for((size_t) se.n_edges, 8192, [&](size_t b0, size_t e0) {
             const float z3[3] = {0.f, 0.f, 0.f};
             for (size_t i = b0; i < e0; ++i) {
@@ -491,7 +730,8 @@ static int scene_sync(psdr_hip_scene *sc, const psdr_scene_snapshot *s, unsigned
         d.pe_off = pe_offs[(size_t) k].first; d.pecdf_off = pe_offs[(size_t) k].second;
         const bool write_pe = !same_prim || blob_moved || !od || od->pe_off != d.pe_off || od->pecdf_off != d.pecdf_off || od->n_edges != d.n_edges;
         if (write_pe) {
-            for (int i = 0; i < r.n_edges; ++i) {
+            parallel_for((size_t) std::max(0, r.n_edges), 8192, [&](size_t ib, size_t ie) {
+              for (size_t i = ib; i < ie; ++i) {
                 const size_t pw = (size_t) d.pe_off + 3 * (size_t) i;
                 put4(H, pw, r.edge_p0[2 * i], r.edge_p0[2 * i + 1], r.edge_p1[2 * i], r.edge_p1[2 * i + 1]);
                 put4(H, pw + 1, r.d_edge_p0 ? r.d_edge_p0[2 * i] : 0.f, r.d_edge_p0 ? r.d_edge_p0[2 * i + 1] : 0.f,
@@ -499,7 +739,8 @@ static int scene_sync(psdr_hip_scene *sc, const psdr_scene_snapshot *s, unsigned
                 put4(H, pw + 2, r.edge_normal[2 * i], r.edge_normal[2 * i + 1], r.edge_length[i], 0.f);
                 H[4 * (size_t) d.pecdf_off + (size_t) i] = r.edge_pmf[i];
                 H[4 * (size_t) d.pecdf_off + (size_t) r.n_edges + (size_t) i] = r.edge_cmf[i];
-            }
+              }
+            });
             mark((size_t) d.pe_off, (size_t) d.pecdf_off + words_for_floats(2 * (size_t) std::max(1, r.n_edges)));
             d.pe_guide = nullptr; d.pe_guide_n = 0;
             if (r.n_edges > 0 && r.edge_cmf) {       // a sample of the primary-edge term starts with this search (15 dependent loads for config 5's 26 592 edges)
@@ -801,6 +1042,58 @@ int psdr_hip_scene_stats(const psdr_hip_scene *sc, int32_t *n_nodes, int32_t *n_
 int psdr_hip_scene_last_update(const psdr_hip_scene *sc, psdr_update_info *info) {
     if (!sc || !info) return fail("null argument");
     *info = sc->last_info;
+    return 0;
+}
+
+// Test aid (synchronises, downloads the sections): the triangle rows (traversal, shading, tangent) and the secondary-edge rows of the device blob against the rows the host
+// path would write from `snapshot` - the check that the kernels of geometry_on_device produce the host's bits.  -> number of 32-bit words that differ.
+int psdr_hip_scene_check_rows(const psdr_hip_scene *sc, const psdr_scene_snapshot *s, int64_t *mismatches) {
+    if (!sc || !s || !mismatches) return fail("null argument");
+    *mismatches = 0;
+    const SceneTables &T = sc->T;
+    const psdr_triangles &tr = s->tris;
+    const int n = tr.n_triangles;
+    if (n != T.n_tris) return fail("psdr_hip_scene_check_rows: another triangle count than the device scene's");
+    HIPCHK(hipDeviceSynchronize());
+    auto fetch = [&](int off_words, size_t words, std::vector<float> &dst) -> int {
+        dst.resize(4 * words);
+        if (words) HIPCHK(hipMemcpy(dst.data(), (const char *) sc->blob.p + 16 * (size_t) off_words, 16 * words, hipMemcpyDeviceToHost));
+        return 0;
+    };
+    std::vector<float> trav, shade, tan, sec;
+    if (fetch(T.trav_off, 3 * (size_t) n, trav) || fetch(T.shade_off, 6 * (size_t) n, shade)) return 1;
+    if (T.has_tangent && fetch(T.tan_off, 6 * (size_t) n, tan)) return 1;
+    long long bad = 0;
+    auto cmp = [&](const float *dev, float x, float y, float z, float w) { const float h[4] = {x, y, z, w}; for (int k = 0; k < 4; ++k) bad += std::memcmp(dev + k, h + k, 4) != 0 ? 1 : 0; };
+    for (int slot = 0; slot < n; ++slot) {
+        const size_t o = (size_t) sc->order[(size_t) slot];
+        const float *p0 = tr.p0 + 3 * o, *e1 = tr.e1 + 3 * o, *e2 = tr.e2 + 3 * o;
+        const float *t = &trav[12 * (size_t) slot];
+        cmp(t, p0[0], p0[1], p0[2], e1[0]); cmp(t + 4, e1[1], e1[2], e2[0], e2[1]); cmp(t + 8, e2[2], ibits((int32_t) o), 0.f, 0.f);
+        const float *n0 = tr.n0 + 3 * o, *n1 = tr.n1 + 3 * o, *n2 = tr.n2 + 3 * o, *fn = tr.face_normal + 3 * o;
+        const float *w = &shade[24 * (size_t) slot];
+        cmp(w, n0[0], n0[1], n0[2], tr.face_area[o]); cmp(w + 4, n1[0], n1[1], n1[2], ibits(tr.mesh_id[o]));
+        cmp(w + 8, n2[0], n2[1], n2[2], ibits(tr.use_face_normal && tr.use_face_normal[o] ? 1 : 0)); cmp(w + 12, fn[0], fn[1], fn[2], ibits((int32_t) o));
+        if (T.has_tangent && tr.d_p0) {
+            const float *a = tr.d_p0 + 3 * o, *b = tr.d_e1 + 3 * o, *c = tr.d_e2 + 3 * o, *d0 = tr.d_n0 + 3 * o, *d1 = tr.d_n1 + 3 * o, *d2 = tr.d_n2 + 3 * o, *df = tr.d_face_normal + 3 * o;
+            const float *q = &tan[24 * (size_t) slot];
+            cmp(q, a[0], a[1], a[2], b[0]); cmp(q + 4, b[1], b[2], c[0], c[1]); cmp(q + 8, c[2], d0[0], d0[1], d0[2]); cmp(q + 12, d1[0], d1[1], d1[2], d2[0]);
+            cmp(q + 16, d2[1], d2[2], df[0], df[1]); cmp(q + 20, df[2], tr.d_face_area[o], 0.f, 0.f);
+        }
+    }
+    const psdr_sec_edges &se = s->sec_edges;
+    if (se.n_edges > 0 && se.n_edges == sc->E.n) {
+        if (fetch(sc->E.off, 6 * (size_t) se.n_edges, sec)) return 1;
+        const float z3[3] = {0.f, 0.f, 0.f};
+        for (size_t i = 0; i < (size_t) se.n_edges; ++i) {
+            const float *p0 = se.p0 + 3 * i, *e1 = se.e1 + 3 * i, *n0 = se.n0 + 3 * i, *n1 = se.n1 + 3 * i, *p2 = se.p2 + 3 * i;
+            const float *dp0 = se.d_p0 ? se.d_p0 + 3 * i : z3, *de1 = se.d_e1 ? se.d_e1 + 3 * i : z3;
+            const float *q = &sec[24 * i];
+            cmp(q, p0[0], p0[1], p0[2], e1[0]); cmp(q + 4, e1[1], e1[2], n0[0], n0[1]); cmp(q + 8, n0[2], n1[0], n1[1], n1[2]);
+            cmp(q + 12, p2[0], p2[1], p2[2], ibits(se.is_boundary[i] ? 1 : 0)); cmp(q + 16, dp0[0], dp0[1], dp0[2], de1[0]); cmp(q + 20, de1[1], de1[2], 0.f, 0.f);
+        }
+    }
+    *mismatches = bad;
     return 0;
 }
 

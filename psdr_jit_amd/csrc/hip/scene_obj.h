@@ -3,6 +3,7 @@
 // reference does in Scene_OptiX::configure + the jit uploads of Scene::configure, src/scene/scene_optix.cpp:265-332,
 // src/scene/scene.cpp:311-599) and api.hip (the render entry points and their kernels).
 #pragma once
+#include "../common/threads.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdint>
@@ -82,10 +83,13 @@ inline void build_cdf_guide(const float *cmf, int size, float sum, std::vector<i
     int nb = 1;
     while (nb * per_bucket <= size) nb <<= 1;
     guide.resize((size_t) nb + 1);
-    for (int k = 0; k <= nb; ++k) {
-        const float s = ((float) k / (float) nb) * sum;
-        guide[k] = (int) (std::partition_point(cmf, cmf + (size - 1), [s](float c) { return c < s; }) - cmf);
-    }
+    // (32 768 binary searches over 122 885 edges for config 5's secondary-edge table, in every update that moves a vertex: on the host team)
+    psdr::parallel_for((size_t) nb + 1, 2048, [&](size_t kb, size_t ke) {
+        for (size_t k = kb; k < ke; ++k) {
+            const float s = ((float) k / (float) nb) * sum;
+            guide[k] = (int) (std::partition_point(cmf, cmf + (size - 1), [s](float c) { return c < s; }) - cmf);
+        }
+    });
 }
 
 } // namespace psdr
@@ -131,6 +135,9 @@ struct psdr_hip_scene {
     double cost_built = 0.0;                           // SAH cost of the tree when it was built; a refit that exceeds kRebuildFactor x this triggers a build
     std::vector<float> sensor_w2s;                     // world_to_sample of every sensor at the last live-mask build (a mask is rebuilt when it or the triangles changed)
     psdr_update_info last_info{};
+    // geometry on the device (scene_build.hip::geometry_on_device): the topology version and the counts of every mesh at the last topology upload
+    std::vector<uint64_t> geo_versions;
+    std::vector<int> geo_counts;
     bool poisoned = false;                             // a psdr_hip_scene_update failed midway: no rendering until an update has gone through (scene_build.hip)
 
     // The launches of one scene share mutable device scratch - the work-queue ring, the counters, the traversal-stack overflow

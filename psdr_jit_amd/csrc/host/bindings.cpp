@@ -429,6 +429,7 @@ PYBIND11_MODULE(_psdr_core, m) {
         // (triangles, secondary edges) of the configured snapshot: what reverse mode sizes its adjoint buffers with
         .def("_snapshot_counts", [](const Scene &s) { return py::make_tuple((int64_t) s.snap.area.size(), (int64_t) s.snap.n_sec_edges); })
         .def("_hip_handle", [](const Scene &s) { return (uintptr_t) s.m_hip; })
+        .def("_check_device_rows", &Scene::check_device_rows)
         // what the last configure() did to the device copy (psdr_update_info, include/psdr_hip.h)
         .def("_last_update", [](const Scene &s) {
             py::dict d;

@@ -317,6 +317,7 @@ void Mesh::configure() {
         raw_normals_valid = true;
     }
     const DM4 tw = to_world();
+    tw.split(m_tw, m_d_tw);
     vertex_positions.resize(3 * (size_t) m_num_vertices); d_vertex_positions.resize(3 * (size_t) m_num_vertices);
     psdr::parallel_for((size_t) m_num_vertices, 4096, [&](size_t b, size_t e) {
         for (size_t v = b; v < e; ++v) {
@@ -1172,11 +1173,12 @@ Scene::GeometryAdjoint Scene::chain_geometry(int sensor_id, const float *g_tri, 
 }
 
 // assemble the C-ABI snapshot and hand it to the HIP library (replaces Scene_OptiX::configure)
-void Scene::upload() {
+// the configured snapshot as the C ABI's struct (pointers into `snap`, the sensors' edge lists and the meshes)
+void Scene::fill_snapshot(psdr_scene_snapshot &sn) {
     PSDR_ASSERT_MSG(m_host_ready, "configure_host() first");
     Snapshot &S = snap;
     S.sensors.clear();
-    psdr_scene_snapshot sn{};
+    sn = psdr_scene_snapshot{};
     sn.abi_version = PSDR_HIP_ABI_VERSION;
     sn.width = m_opts.width; sn.height = m_opts.height; sn.spp = m_opts.spp; sn.sppe = m_opts.sppe; sn.sppse = m_opts.sppse;
     psdr_triangles &t = sn.tris;
@@ -1212,6 +1214,45 @@ void Scene::upload() {
         S.sensors.push_back(r);
     }
     sn.n_sensors = (int) S.sensors.size(); sn.sensors = S.sensors.data();
+    // what the rows of every mesh are a function of: with it the device computes a moved mesh's triangle and secondary-edge rows itself (psdr_mesh_geometry, include/psdr_hip.h)
+    {
+        const size_t nm = m_meshes.size();
+        if (m_up_geo.size() != nm) { m_up_geo.assign(nm, ~0ull); m_up_tan.assign(nm, ~0ull); }
+        m_geometry.assign(nm, psdr_mesh_geometry{});
+        bool complete = true;
+        for (size_t i = 0; i < nm; ++i) {
+            Mesh *mesh = m_meshes[i];
+            psdr_mesh_geometry &g = m_geometry[i];
+            if (!mesh->vertex_faces_current() || mesh->d_vertex_positions_raw.size() != mesh->vertex_positions_raw.size()) { complete = false; break; }
+            const bool has_edges = m_opts.sppse > 0 && mesh->m_enable_edges;
+            g.n_vertices = mesh->m_num_vertices; g.n_faces = mesh->m_num_faces; g.n_edges = has_edges ? (int) mesh->edges.size() : 0;
+            g.vertices_raw = mesh->vertex_positions_raw.data(); g.d_vertices_raw = mesh->d_vertex_positions_raw.data();
+            std::memcpy(g.to_world, mesh->m_tw, 64); std::memcpy(g.d_to_world, mesh->m_d_tw, 64);
+            g.faces = mesh->face_indices.data();
+            g.vf_begin = mesh->vertex_face_begin().data(); g.vf_item = mesh->vertex_face_item().data();
+            static_assert(sizeof(MeshEdge) == 5 * sizeof(int32_t), "psdr_mesh_geometry.edges: v0 v1 f0 f1 opp");
+            g.edges = has_edges && !mesh->edges.empty() ? reinterpret_cast<const int32_t *>(mesh->edges.data()) : nullptr;
+            g.mesh_id = mesh->m_mesh_id; g.use_face_normals = mesh->m_use_face_normals ? 1 : 0;
+            g.topology_version = (mesh->m_topo_version << 2) | (has_edges ? 2u : 0u) | 1u;
+            g.moved = (m_up_geo[i] != mesh->m_geo_version || m_up_tan[i] != mesh->m_tan_version) ? 1 : 0;
+        }
+        sn.geometry = complete ? m_geometry.data() : nullptr;
+    }
+}
+
+// test aid: words of the device's triangle / secondary-edge rows that differ from the rows the host path would write (psdr_hip_scene_check_rows)
+int64_t Scene::check_device_rows() {
+    PSDR_ASSERT_MSG(m_hip != nullptr && m_configured, "configure() first");
+    psdr_scene_snapshot sn;
+    fill_snapshot(sn);
+    int64_t bad = -1;
+    hip_check(psdr_hip_scene_check_rows(m_hip, &sn, &bad));
+    return bad;
+}
+
+void Scene::upload() {
+    psdr_scene_snapshot sn;
+    fill_snapshot(sn);
     // the device copy: created once, then updated in place - only what changed since the previous upload is rewritten and sent, the tree is kept
     // (refitted on the device when triangles moved); psdr_hip_scene_update, include/psdr_hip.h
     if (m_hip != nullptr && m_always_rebuild) release_device();
@@ -1225,10 +1266,12 @@ void Scene::upload() {
             const std::string why = psdr_hip_last_error();
             release_device();
             m_same = 0;
+            m_up_geo.clear(); m_up_tan.clear();
             throw Exception("libpsdr_hip: " + why);
         }
     }
     m_same = PSDR_SAME_TRIANGLES | PSDR_SAME_TRI_TANGENTS | PSDR_SAME_SEC_EDGES | PSDR_SAME_PRIM_EDGES | PSDR_SAME_ENV_TEXELS | PSDR_SAME_ENV_TANGENT | PSDR_SAME_BITMAPS;
+    for (size_t i = 0; i < m_meshes.size() && i < m_up_geo.size(); ++i) { m_up_geo[i] = m_meshes[i]->m_geo_version; m_up_tan[i] = m_meshes[i]->m_tan_version; }
     m_configured = true;
 }
 

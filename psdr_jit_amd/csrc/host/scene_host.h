@@ -215,6 +215,7 @@ struct Mesh : Object, Transformable {
     uint64_t m_topo_version = 1;               // bumped by load / load_raw (faces, uv indices, vertex count)
     uint64_t m_geo_version = 0, m_tan_version = 0;
     float m_lower[3] = {0, 0, 0}, m_upper[3] = {0, 0, 0};       // box of the world-space vertices
+    float m_tw[16] = {0}, m_d_tw[16] = {0};                     // to_world() of the last configure(), value and tangent (psdr_mesh_geometry: the device computes a moved mesh's rows from it)
 private:
     void build_edges();
 public:
@@ -279,6 +280,8 @@ struct Scene : Object {
     void configure(const std::vector<int> &active_sensor = {});
     void configure_host(const std::vector<int> &active_sensor = {});   // host half (no device needed)
     void upload();                                                      // BVH build + device upload
+    void fill_snapshot(psdr_scene_snapshot &sn);
+    int64_t check_device_rows();
     bool is_ready() const;
     size_t get_num_emitters() const { return m_emitters.size(); }
     // Reverse-mode chain rule of the differentiable part of configure() (Mesh::configure / process_mesh, the secondary-edge rows, the primary-edge projection:
@@ -335,6 +338,8 @@ private:
     struct MeshKey { const Mesh *mesh; uint64_t topo; int nf, bsdf, emitter; bool uv, flat, edges; bool operator==(const MeshKey &o) const { return mesh == o.mesh && topo == o.topo && nf == o.nf && bsdf == o.bsdf && emitter == o.emitter && uv == o.uv && flat == o.flat && edges == o.edges; } };
     std::vector<MeshKey> m_snap_keys;                      // the meshes the snapshot's rows were laid out for
     std::vector<uint64_t> m_seen_geo, m_seen_tan;          // per mesh: the versions its snapshot rows hold
+    std::vector<uint64_t> m_up_geo, m_up_tan;              // per mesh: the versions the device scene holds (psdr_mesh_geometry.moved)
+    std::vector<psdr_mesh_geometry> m_geometry;            // upload(): the per-mesh inputs of the device's row computation
     uint64_t m_layout_version = 0;                         // counts the configure_host() runs that laid the triangle rows out anew (another mesh list, topology or flag)
     uint64_t m_sec_layout = ~0ull;
     uint64_t m_sec_geo = ~0ull, m_sec_tan = ~0ull;         // sum of the mesh versions the secondary-edge arrays were built from

@@ -115,6 +115,49 @@ def test_refit_keeps_the_hits_bit_equal(env, orc, level):
     assert product.rel_l2(img, ref.render_c(max_depth=2, seed=3)) < TOL
 
 
+def test_moved_meshes_get_their_rows_from_the_device(env, orc, monkeypatch):
+    """psdr_mesh_geometry (ABI 16): after a vertex move psdr_hip_scene_update computes the moved meshes' triangle rows (traversal, shading, tangent) and secondary-edge rows ON
+    THE DEVICE from the raw vertices and the composed transform - the reference's Mesh::configure / process_mesh run on the GPU too (src/shape/mesh.cpp:23-62, 317-400) - in the
+    host's own dual-number code compiled for both sides.  The rows must be the host's bits: psdr_hip_scene_check_rows compares every word with what the host path would write;
+    far fewer bytes travel than the rows weigh; and the same update forced through the host path (PSDR_HOST_GEOMETRY) gives the same sections"""
+    torch, psdr, cabi = env
+    spec = scenes.config5_scene(48, 48, 2, 2, 2, level=5, env_res=(64, 32), param="blob_x")
+    sc = product.build_scene(spec)
+    assert sc._check_device_rows() == 0                       # (after the create: the host's rows)
+    mesh = sc.param_map["Mesh[0]"]
+    n_tris = sum(len(m.faces) for m in spec.meshes) + 12
+    dT = np.zeros((4, 4), np.float32); dT[0, 3] = 100.0
+    sent = []
+    for step in range(4):
+        if step % 2 == 0:                                      # a translation with a tangent (the README's parameter) ...
+            t = np.eye(4, dtype=np.float32); t[0, 3] = 3.0 * (step + 1); t[1, 3] = -2.0 * step
+            mesh._set("to_world_left", t, dT)
+        else:                                                  # ... and a deformation of the raw vertices with a tangent of their own
+            v = np.asarray(spec.meshes[0].vertices, np.float32).copy()
+            v[:, 1] *= 1.0 - 0.03 * step
+            dv = np.zeros_like(v); dv[:, 2] = 0.5 * v[:, 0]
+            mesh._set("vertex_positions", v.astype(np.float32), dv)
+        sc.configure([0])
+        info = sc._last_update()
+        assert info["tree"] in ("refitted", "built"), info
+        assert sc._check_device_rows() == 0, step
+        assert _violations(cabi, sc) == 0
+        sent.append(info["bytes_uploaded"])
+    # the rows of this scene weigh 240 B per triangle + 96 B per edge; what travels after the first update (which also carries the topology) is the vertices, the edge CDF, the sensor's edges
+    assert sent[-1] < 0.25 * 240 * n_tris, sent
+    img = psdr.PathTracer(2).renderC(sc, 0, seed=3).cpu().numpy()
+    # the same state through the host path: every row rewritten and sent by the host
+    monkeypatch.setenv("PSDR_HOST_GEOMETRY", "1")
+    v = np.asarray(mesh._get("vertex_positions", False), np.float32).copy()
+    mesh._set("vertex_positions", v, np.zeros_like(v))         # (a tangent change: the rows are written again)
+    sc.configure([0])
+    assert sc._check_device_rows() == 0
+    assert sc._last_update()["bytes_uploaded"] > 96 * n_tris
+    monkeypatch.delenv("PSDR_HOST_GEOMETRY")
+    img_host = psdr.PathTracer(2).renderC(sc, 0, seed=3).cpu().numpy()
+    assert product.rel_l2(img, img_host) < 1e-6
+
+
 def test_a_scrambled_mesh_is_built_again(env, orc):
     """vertices thrown far from where the topology was built for: the refitted tree's SAH cost exceeds 1.4 x the built one and configure() builds a new tree;
     hits stay bit-equal"""
@@ -167,8 +210,15 @@ def test_parameter_changes_keep_the_tree_and_send_little(env, orc):
     mesh._set("to_world_left", np.eye(4, dtype=np.float32), d)
     bs._set("reflectance", np.asarray([0.3, 0.6, 0.2], np.float32), np.zeros(3, np.float32))
     info = reconfigure()
-    # (the tangent rows of the triangles, the secondary-edge rows - 30 720 edges x 7 words - and the primary edges travel: ~5.4 MB; with the value rows it would be 8.4 MB)
-    assert 20480 * 6 * 16 <= info["bytes_uploaded"] < tri_bytes + 30720 * 7 * 16 - 20480 * 9 * 16 + 1200000, info
+    # (rounds 1-5: the tangent rows of the triangles, the secondary-edge rows - 30 720 edges x 7 words - and the primary edges travelled: ~5.4 MB.  Round 6: the device computes the
+    #  moved mesh's rows itself - the raw vertices, the edge CDF and the primary edges travel, and once the topology: ~2 MB, then well under 1 MB)
+    assert info["bytes_uploaded"] < 3000000 and sc._check_device_rows() == 0, info
+    d2 = d.copy(); d2[1, 3] = 0.5
+    mesh._set("to_world_left", np.eye(4, dtype=np.float32), d2)
+    info = reconfigure()
+    assert info["bytes_uploaded"] < 1200000 and sc._check_device_rows() == 0, info
+    mesh._set("to_world_left", np.eye(4, dtype=np.float32), d)
+    reconfigure()
     spec.bsdfs[0].d_reflectance = (0.0, 0.0, 0.0)
     spec.meshes[0].d_to_world_left = d
     ref = orc.OracleScene(spec, [0])

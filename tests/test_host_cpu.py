@@ -33,7 +33,7 @@ def test_cabi_exports_every_declared_symbol(psdr):
     for name in declared:
         assert hasattr(L, name), "libpsdr_hip.so does not export %s" % name
     assert sorted(cabi.SYMBOLS) == declared
-    assert L.psdr_hip_abi_version() == 15
+    assert L.psdr_hip_abi_version() == 16
     # host-side sampler building block is bit-exact with the oracle / golden table
     import json
     with open(os.path.join(ROOT, "tests", "golden", "tea64.json")) as fh:
