@@ -184,6 +184,9 @@ typedef struct psdr_scene_snapshot {
     int32_t n_sensors;  const psdr_sensor_rec *sensors;
     const psdr_envmap_rec *envmap;            /* Scene::m_emitter_env, NULL = none */
     const psdr_mesh_geometry *geometry;       /* [n_meshes] or NULL: lets psdr_hip_scene_update compute moved meshes' rows on the device (BVH scenes; see psdr_mesh_geometry) */
+    int32_t rows_valid;                       /* psdr_hip_scene_update only.  1: the row arrays of `tris` and `sec_edges` hold this state.  0: the caller has not computed the rows of
+                                                 the moved meshes (their sizes, the CDFs and everything else are valid) and relies on `geometry`: the update computes them on the
+                                                 device, or returns PSDR_HIP_NEED_ROWS with the scene unchanged - then call again with the rows */
 } psdr_scene_snapshot;
 
 /* One of Scene::m_samplers[0..2] in closed form: lane i was seeded with
@@ -276,6 +279,7 @@ typedef struct psdr_update_info {
     double sah_cost, sah_cost_built; /* SAH cost of the tree now / when it was built (sum over child boxes of half-area x triangles-or-1, over the root's half-area) */
     double ms_tree, ms_fill, ms_upload, ms_total;   /* host wall clock: tree build / refit, writing the host copy, copies issued, whole call */
 } psdr_update_info;
+#define PSDR_HIP_NEED_ROWS 2          /* psdr_hip_scene_update: snapshot->rows_valid == 0 and this update cannot do without the rows (see psdr_scene_snapshot.rows_valid) */
 int psdr_hip_scene_update(psdr_hip_scene *scene, const psdr_scene_snapshot *snapshot, uint32_t same, psdr_update_info *info);
 /* what the last create / update of this handle did */
 int psdr_hip_scene_last_update(const psdr_hip_scene *scene, psdr_update_info *info);

@@ -441,6 +441,10 @@ static int scene_sync(psdr_hip_scene *sc, const psdr_scene_snapshot *s, unsigned
         if (b.type == 5 && (b.nested_bsdf < 0 || b.nested_bsdf >= s->n_bsdfs || s->bsdfs[b.nested_bsdf].type == 5)) return fail("NormalMap: invalid nested BSDF");
     }
     const bool build = fresh || force_build || n != sc->tree_tris;
+    // rows_valid = 0 (updates only; psdr_scene_snapshot): the caller relies on the device computing the moved meshes' rows.  Whatever needs the rows themselves - a tree to
+    // build, a section that moves, a live-pixel mask to rebuild - answers PSDR_HIP_NEED_ROWS before anything has been changed
+    const bool rows_valid = fresh || s->rows_valid != 0;
+    if (!rows_valid && (build || s->geometry == nullptr || n <= kBruteForceMax)) return PSDR_HIP_NEED_ROWS;
     if (build) same = 0;
     if (!fresh) {
         // the previous calls on this scene read what is about to be overwritten: wait for the last of them (configure() is a synchronisation point in the reference as well)
@@ -520,6 +524,12 @@ static int scene_sync(psdr_hip_scene *sc, const psdr_scene_snapshot *s, unsigned
     T.stack_lds = uses_bvh ? std::min(kStackLds, sc->tree_max_stack) : 0;
     T.stack_depth = uses_bvh ? T.stack_lds + kTravRows : kColdRows;   // BVH: + parked rays, best hits and the pair ring of the traversal (trav4.h); brute force: cold path state (paths.h)
 
+    if (!rows_valid) {
+        const bool layout_kept = sc->blob.p && sc->blob.bytes >= 16 * w && T.trav_off == Told.trav_off && T.shade_off == Told.shade_off && T.tan_off == Told.tan_off && T.map_off == Told.map_off &&
+                                 (has_tan ? 1 : 0) == Told.has_tangent && E.off == Eold.off && E.cdf_off == Eold.cdf_off && E.n == Eold.n && T.env_emitter >= 0 && Told.env_emitter >= 0 &&
+                                 std::getenv("PSDR_HOST_GEOMETRY") == nullptr;
+        if (!layout_kept) { sc->T = Told; sc->E = Eold; return PSDR_HIP_NEED_ROWS; }
+    }
     // ---- the blob: device allocation with head room, pinned host copy
     bool blob_moved = false;
     if (!sc->blob.p || sc->blob.bytes < 16 * w) {
@@ -556,6 +566,7 @@ static int scene_sync(psdr_hip_scene *sc, const psdr_scene_snapshot *s, unsigned
         const bool forced_host = std::getenv("PSDR_HOST_GEOMETRY") != nullptr;         // test knob, read per call: the host writes the rows (what psdr_hip_scene_check_rows compares with)
         if (layout_same && !forced_host && s->geometry != nullptr && (geo || !same_tan || !same_sec)) {
             if (geometry_on_device(sc, s, geo, has_tan && !same_tan, !same_sec, info, dev_geo)) return 1;
+            if (!dev_geo && !rows_valid) { sc->T = Told; sc->E = Eold; return PSDR_HIP_NEED_ROWS; }
         }
     }
     // (the pinned host copy of a section the device wrote is behind the device's; it is only ever sent after the host has rewritten the whole section from the snapshot -
@@ -954,7 +965,10 @@ static int scene_sync(psdr_hip_scene *sc, const psdr_scene_snapshot *s, unsigned
         info.sah_cost = cost;
         info.ms_tree += ms_since(t_refit);
         // the topology no longer fits the geometry: build again (everything that depends on the triangle order is rewritten)
-        if (!(cost <= kRebuildFactor * sc->cost_built)) return scene_sync(sc, s, 0, false, true, info_out);
+        if (!(cost <= kRebuildFactor * sc->cost_built)) {
+            if (!rows_valid) return PSDR_HIP_NEED_ROWS;         // (the rows on the device are this state's, the tables are complete: the caller comes back with its rows and the tree is built then)
+            return scene_sync(sc, s, 0, false, true, info_out);
+        }
     }
 
     // ---- scene class, launch geometry
@@ -1022,6 +1036,7 @@ int psdr_hip_scene_update(psdr_hip_scene *scene, const psdr_scene_snapshot *s, u
     // caller vouches for (its `same` bits are relative to a snapshot the device never fully received) and builds everything again.
     const bool was_poisoned = scene->poisoned;
     const int rc = scene_sync(scene, s, was_poisoned ? 0u : same, false, was_poisoned, info);
+    if (rc == PSDR_HIP_NEED_ROWS) return rc;                  // (nothing was changed, or only rows that are this state's: see psdr_scene_snapshot.rows_valid)
     scene->poisoned = rc != 0;
     if (rc) scene->tree_tris = -1;
     return rc;

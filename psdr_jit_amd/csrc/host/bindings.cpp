@@ -439,8 +439,9 @@ PYBIND11_MODULE(_psdr_core, m) {
             d["ms_host"] = s.m_ms_host; d["ms_tree"] = u.ms_tree; d["ms_fill"] = u.ms_fill; d["ms_upload"] = u.ms_upload; d["ms_total"] = u.ms_total;
             return d; })
         .def_readwrite("_always_rebuild", &Scene::m_always_rebuild)
-        .def("_snapshot", [](const Scene &s) {
+        .def("_snapshot", [](Scene &s) {
             // configured host arrays in the oracle's row formats (tests compare them with the CPU restatement)
+            s.ensure_full_snapshot();                 // (a lean configure leaves the rows to whoever asks)
             const Scene::Snapshot &S = s.snap;
             const size_t n = S.area.size();
             farr tri({(ssize_t) n, (ssize_t) 22}), dtri({(ssize_t) n, (ssize_t) 22});

@@ -13,49 +13,49 @@
 // rows must be the bits the host would have written): under hipcc every function below is __host__ __device__; both compilers run with -ffp-contract=off, every fused
 // multiply-add is an explicit fmaf, and division and square root are correctly rounded on both sides.
 #if defined(__HIPCC__)
-#define PSDR_HD __host__ __device__
+#define PSDR_HNUM_HD __host__ __device__
 #else
-#define PSDR_HD
+#define PSDR_HNUM_HD
 #endif
 
 namespace psdr_host {
 
 struct DF {              // dual float
     float v = 0.f, d = 0.f;
-    PSDR_HD DF() {}
-    PSDR_HD DF(float v_) : v(v_) {}
-    PSDR_HD DF(float v_, float d_) : v(v_), d(d_) {}
+    PSDR_HNUM_HD DF() {}
+    PSDR_HNUM_HD DF(float v_) : v(v_) {}
+    PSDR_HNUM_HD DF(float v_, float d_) : v(v_), d(d_) {}
 };
-PSDR_HD inline DF operator+(DF a, DF b) { return {a.v + b.v, a.d + b.d}; }
-PSDR_HD inline DF operator-(DF a, DF b) { return {a.v - b.v, a.d - b.d}; }
-PSDR_HD inline DF operator-(DF a) { return {-a.v, -a.d}; }
-PSDR_HD inline DF operator*(DF a, DF b) { return {a.v * b.v, a.d * b.v + a.v * b.d}; }
-PSDR_HD inline DF operator/(DF a, DF b) { float q = a.v / b.v; return {q, (a.d - q * b.d) / b.v}; }
-PSDR_HD inline DF dfma(DF a, DF b, DF c) { return {std::fmaf(a.v, b.v, c.v), a.d * b.v + a.v * b.d + c.d}; }
-PSDR_HD inline DF dsqrt(DF a) { float s = std::sqrt(a.v); return {s, a.d / (2.f * s)}; }
-PSDR_HD inline DF drcp(DF a) { return DF(1.f) / a; }
+PSDR_HNUM_HD inline DF operator+(DF a, DF b) { return {a.v + b.v, a.d + b.d}; }
+PSDR_HNUM_HD inline DF operator-(DF a, DF b) { return {a.v - b.v, a.d - b.d}; }
+PSDR_HNUM_HD inline DF operator-(DF a) { return {-a.v, -a.d}; }
+PSDR_HNUM_HD inline DF operator*(DF a, DF b) { return {a.v * b.v, a.d * b.v + a.v * b.d}; }
+PSDR_HNUM_HD inline DF operator/(DF a, DF b) { float q = a.v / b.v; return {q, (a.d - q * b.d) / b.v}; }
+PSDR_HNUM_HD inline DF dfma(DF a, DF b, DF c) { return {std::fmaf(a.v, b.v, c.v), a.d * b.v + a.v * b.d + c.d}; }
+PSDR_HNUM_HD inline DF dsqrt(DF a) { float s = std::sqrt(a.v); return {s, a.d / (2.f * s)}; }
+PSDR_HNUM_HD inline DF drcp(DF a) { return DF(1.f) / a; }
 
 struct D3 { DF x, y, z; };
-PSDR_HD inline D3 operator+(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-PSDR_HD inline D3 operator-(D3 a, D3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-PSDR_HD inline D3 operator*(D3 a, DF s) { return {a.x * s, a.y * s, a.z * s}; }
-PSDR_HD inline D3 operator/(D3 a, DF s) { return {a.x / s, a.y / s, a.z / s}; }
-PSDR_HD inline DF ddot(D3 a, D3 b) { return dfma(a.z, b.z, dfma(a.y, b.y, a.x * b.x)); }
-PSDR_HD inline D3 dcross(D3 a, D3 b) {
+PSDR_HNUM_HD inline D3 operator+(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+PSDR_HNUM_HD inline D3 operator-(D3 a, D3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+PSDR_HNUM_HD inline D3 operator*(D3 a, DF s) { return {a.x * s, a.y * s, a.z * s}; }
+PSDR_HNUM_HD inline D3 operator/(D3 a, DF s) { return {a.x / s, a.y / s, a.z / s}; }
+PSDR_HNUM_HD inline DF ddot(D3 a, D3 b) { return dfma(a.z, b.z, dfma(a.y, b.y, a.x * b.x)); }
+PSDR_HNUM_HD inline D3 dcross(D3 a, D3 b) {
     return {dfma(a.y, b.z, -(a.z * b.y)), dfma(a.z, b.x, -(a.x * b.z)), dfma(a.x, b.y, -(a.y * b.x))};
 }
-PSDR_HD inline DF dnorm(D3 a) { return dsqrt(ddot(a, a)); }
-PSDR_HD inline D3 dnormalize(D3 a) { return a * drcp(dsqrt(ddot(a, a))); }
+PSDR_HNUM_HD inline DF dnorm(D3 a) { return dsqrt(ddot(a, a)); }
+PSDR_HNUM_HD inline D3 dnormalize(D3 a) { return a * drcp(dsqrt(ddot(a, a))); }
 
 struct DM4 {             // row-major 4x4 of duals
     DF m[4][4];
-    PSDR_HD static DM4 identity() { DM4 r; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r.m[i][j] = DF(i == j ? 1.f : 0.f); return r; }
+    PSDR_HNUM_HD static DM4 identity() { DM4 r; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r.m[i][j] = DF(i == j ? 1.f : 0.f); return r; }
     static DM4 from(const std::array<float, 16> &v, const std::array<float, 16> &d) {
         DM4 r; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r.m[i][j] = DF(v[4 * i + j], d[4 * i + j]); return r;
     }
     void split(float *v, float *d) const { for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { v[4 * i + j] = m[i][j].v; d[4 * i + j] = m[i][j].d; } }
 };
-PSDR_HD inline DM4 operator*(const DM4 &a, const DM4 &b) {
+PSDR_HNUM_HD inline DM4 operator*(const DM4 &a, const DM4 &b) {
     DM4 r;
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) {
@@ -65,18 +65,18 @@ PSDR_HD inline DM4 operator*(const DM4 &a, const DM4 &b) {
         }
     return r;
 }
-PSDR_HD inline D3 xform_pos(const DM4 &M, D3 p) {
+PSDR_HNUM_HD inline D3 xform_pos(const DM4 &M, D3 p) {
     DF r[4];
     for (int i = 0; i < 4; ++i) r[i] = dfma(M.m[i][2], p.z, dfma(M.m[i][1], p.y, M.m[i][0] * p.x)) + M.m[i][3];
     return D3{r[0], r[1], r[2]} / r[3];
 }
-PSDR_HD inline D3 xform_dir(const DM4 &M, D3 p) {
+PSDR_HNUM_HD inline D3 xform_dir(const DM4 &M, D3 p) {
     DF r[3];
     for (int i = 0; i < 3; ++i) r[i] = dfma(M.m[i][2], p.z, dfma(M.m[i][1], p.y, M.m[i][0] * p.x));
     return {r[0], r[1], r[2]};
 }
 // closed-form cofactor inverse
-PSDR_HD inline DM4 inverse(const DM4 &A) {
+PSDR_HNUM_HD inline DM4 inverse(const DM4 &A) {
     const DF (*a)[4] = A.m;
     DF s0 = a[0][0] * a[1][1] - a[1][0] * a[0][1], s1 = a[0][0] * a[1][2] - a[1][0] * a[0][2], s2 = a[0][0] * a[1][3] - a[1][0] * a[0][3];
     DF s3 = a[0][1] * a[1][2] - a[1][1] * a[0][2], s4 = a[0][1] * a[1][3] - a[1][1] * a[0][3], s5 = a[0][2] * a[1][3] - a[1][2] * a[0][3];
@@ -103,7 +103,7 @@ PSDR_HD inline DM4 inverse(const DM4 &A) {
     r.m[3][3] = ( a[2][0] * s3 - a[2][1] * s1 + a[2][2] * s0) * id;
     return r;
 }
-PSDR_HD inline float det3(const DM4 &A) {
+PSDR_HNUM_HD inline float det3(const DM4 &A) {
     auto a = [&](int i, int j) { return A.m[i][j].v; };
     return a(0, 0) * (a(1, 1) * a(2, 2) - a(1, 2) * a(2, 1)) - a(0, 1) * (a(1, 0) * a(2, 2) - a(1, 2) * a(2, 0)) + a(0, 2) * (a(1, 0) * a(2, 1) - a(1, 1) * a(2, 0));
 }

@@ -329,10 +329,32 @@ void Mesh::configure() {
     for (int k = 0; k < 3; ++k) { m_lower[k] = std::numeric_limits<float>::max(); m_upper[k] = -std::numeric_limits<float>::max(); }
     for (int v = 0; v < m_num_vertices; ++v)
         for (int k = 0; k < 3; ++k) { m_lower[k] = std::min(m_lower[k], vertex_positions[3 * v + k]); m_upper[k] = std::max(m_upper[k], vertex_positions[3 * v + k]); }
-    process_mesh(world, face_indices, m_num_faces, vf_begin, vf_item, tri, d_tri, nullptr);
+    std::vector<float> areas(m_num_faces);
+    face_p0n.resize(6 * (size_t) m_num_faces);
+    if (m_lean) {
+        // per face: first vertex, unit normal and area as VALUES - the value parts of process_mesh's dual-number formulas, operation for operation (dcross / dnorm of hnum.h)
+        rows_valid = false;
+        const float *P = vertex_positions.data();
+        psdr::parallel_for((size_t) m_num_faces, 4096, [&](size_t b, size_t e) {
+            for (size_t f = b; f < e; ++f) {
+                const float *a = P + 3 * (size_t) face_indices[3 * f], *q1 = P + 3 * (size_t) face_indices[3 * f + 1], *q2 = P + 3 * (size_t) face_indices[3 * f + 2];
+                const float e1[3] = {q1[0] - a[0], q1[1] - a[1], q1[2] - a[2]}, e2[3] = {q2[0] - a[0], q2[1] - a[1], q2[2] - a[2]};
+                const float n[3] = {std::fmaf(e1[1], e2[2], -(e1[2] * e2[1])), std::fmaf(e1[2], e2[0], -(e1[0] * e2[2])), std::fmaf(e1[0], e2[1], -(e1[1] * e2[0]))};
+                const float a2 = std::sqrt(std::fmaf(n[2], n[2], std::fmaf(n[1], n[1], n[0] * n[0])));
+                float *o = &face_p0n[6 * f];
+                o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = n[0] / a2; o[4] = n[1] / a2; o[5] = n[2] / a2;
+                areas[f] = a2 * 0.5f;
+            }
+        });
+    } else {
+        process_mesh(world, face_indices, m_num_faces, vf_begin, vf_item, tri, d_tri, nullptr);
+        rows_valid = true;
+        for (int f = 0; f < m_num_faces; ++f) {
+            areas[f] = tri[22 * (size_t) f + 21];
+            for (int k = 0; k < 3; ++k) { face_p0n[6 * (size_t) f + k] = tri[22 * (size_t) f + k]; face_p0n[6 * (size_t) f + 3 + k] = tri[22 * (size_t) f + 18 + k]; }
+        }
+    }
     if (!same_values) {           // (areas are values: the face distribution follows them)
-        std::vector<float> areas(m_num_faces);
-        for (int f = 0; f < m_num_faces; ++f) areas[f] = tri[22 * (size_t) f + 21];
         m_total_area = sum_f32(areas);
         m_inv_total_area = 1.f / m_total_area;
         face_distrb.init(areas);
@@ -344,6 +366,17 @@ void Mesh::configure() {
     for (int k = 0; k < 3; ++k) { cfg_m[k] = *mv[k]; cfg_dm[k] = *md[k]; }
     cfg_valid = true;
     m_ready = true;
+}
+
+// the TriangleInfo rows a lean configure() left out: the same process_mesh on the same world vertices (stored as floats: the very values)
+void Mesh::ensure_rows() {
+    if (rows_valid) return;
+    std::vector<D3> world((size_t) m_num_vertices);
+    for (size_t v = 0; v < (size_t) m_num_vertices; ++v)
+        world[v] = {DF(vertex_positions[3 * v], d_vertex_positions[3 * v]), DF(vertex_positions[3 * v + 1], d_vertex_positions[3 * v + 1]), DF(vertex_positions[3 * v + 2], d_vertex_positions[3 * v + 2])};
+    if (vf_topo != m_topo_version || vf_begin.size() != (size_t) m_num_vertices + 1) build_vertex_faces();
+    process_mesh(world, face_indices, m_num_faces, vf_begin, vf_item, tri, d_tri, nullptr);
+    rows_valid = true;
 }
 
 std::string Mesh::to_string() const {
@@ -423,10 +456,10 @@ void PerspectiveCamera::configure(const Scene &scene, bool keep_edges) {
           for (size_t i = eb; i < ee; ++i) {
             const MeshEdge &e = mesh->edges[i];
             const bool valid = e.f1 >= 0;
-            const float *t0 = &mesh->tri[22 * (size_t) e.f0];
-            const D3 e0 = dnormalize(cpos - fvec(t0)), n0 = fvec(t0 + 18);
+            const float *t0 = &mesh->face_p0n[6 * (size_t) e.f0];          // (first vertex and unit normal of the face: Mesh::configure keeps them whether or not it wrote the full rows)
+            const D3 e0 = dnormalize(cpos - fvec(t0)), n0 = fvec(t0 + 3);
             D3 e1 = dnormalize(cpos), n1 = {DF(0.f), DF(0.f), DF(0.f)};        // masked gathers return zeros
-            if (valid) { const float *t1 = &mesh->tri[22 * (size_t) e.f1]; e1 = dnormalize(cpos - fvec(t1)); n1 = fvec(t1 + 18); }
+            if (valid) { const float *t1 = &mesh->face_p0n[6 * (size_t) e.f1]; e1 = dnormalize(cpos - fvec(t1)); n1 = fvec(t1 + 3); }
             bool uv_mask = false;
             if (mesh->m_has_uv) {
                 int b[3] = {0, 0, 0}, cut = 0;
@@ -639,7 +672,21 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
     uint32_t same = PSDR_SAME_TRIANGLES | PSDR_SAME_TRI_TANGENTS | PSDR_SAME_SEC_EDGES | PSDR_SAME_PRIM_EDGES | PSDR_SAME_ENV_TEXELS | PSDR_SAME_ENV_TANGENT | PSDR_SAME_BITMAPS;
     // m_upper starts at numeric_limits<float>::min(), the smallest positive float, as in the reference (scene.cpp:357-358)
     for (int k = 0; k < 3; ++k) { m_lower[k] = std::numeric_limits<float>::max(); m_upper[k] = std::numeric_limits<float>::min(); }
-    for (Mesh *mesh : m_meshes) mesh->configure();          // (does nothing for a mesh whose inputs are those of its previous run)
+    // LEAN (round 6): when the device scene exists and computed the moved meshes' rows itself in the last upload (psdr_mesh_geometry), this configure leaves the
+    // per-triangle rows, their snapshot copies and the secondary-edge row arrays for ensure_full_snapshot() - nobody reads them unless the device scene has to be created or
+    // rebuilt, or a test asks - and computes what the host itself consumes: world vertices, face normals and areas, the edge selections and their CDFs.
+    // (environment-lit scenes only: without a map the device rebuilds its live-pixel masks from the rows whenever a triangle moves)
+    bool has_env = false;
+    for (const Emitter *e : m_emitters) has_env = has_env || dynamic_cast<const EnvironmentMap *>(e) != nullptr;
+    {
+        std::vector<MeshKey> keys_now;
+        for (const Mesh *mesh : m_meshes) keys_now.push_back(MeshKey{mesh, mesh->m_topo_version, mesh->m_num_faces, mesh->m_bsdf_id, mesh->m_emitter_id, mesh->m_has_uv, mesh->m_use_face_normals, mesh->m_enable_edges});
+        size_t total_faces = 0;
+        for (const Mesh *mesh : m_meshes) total_faces += (size_t) mesh->m_num_faces;
+        // (scenes of at most 64 triangles are traced by brute force: their device scene always takes the host's rows)
+        m_lean = m_hip != nullptr && !m_always_rebuild && m_device_rows_ok && has_env && total_faces > 64 && keys_now == m_snap_keys && std::getenv("PSDR_HOST_GEOMETRY") == nullptr;
+    }
+    for (Mesh *mesh : m_meshes) { mesh->m_lean = m_lean; mesh->configure(); }          // (does nothing for a mesh whose inputs are those of its previous run)
     auto key_of = [](const Mesh *m) { return MeshKey{m, m->m_topo_version, m->m_num_faces, m->m_bsdf_id, m->m_emitter_id, m->m_has_uv, m->m_use_face_normals, m->m_enable_edges}; };
     // rows [face_offset, face_offset + n_faces) of the triangle arrays for one mesh: the values and / or the tangents
     auto write_rows = [&](const Mesh *mesh, size_t face_offset, bool values, bool tangents) {
@@ -690,16 +737,23 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
         if (!same_layout) {
             resize_rows(total);
             m_seen_geo.assign(m_meshes.size(), ~0ull); m_seen_tan.assign(m_meshes.size(), ~0ull);
+            m_bits_geo.assign(m_meshes.size(), ~0ull); m_bits_tan.assign(m_meshes.size(), ~0ull);
             m_snap_keys = keys;
             ++m_layout_version;
         }
         for (size_t i = 0; i < m_meshes.size(); ++i) {
             const Mesh *mesh = m_meshes[i];
+            // (m_bits_*: the versions the PSDR_SAME_* bits were last derived from; m_seen_*: the versions the snapshot's rows hold - behind after a lean configure)
+            if (m_bits_geo.size() != m_meshes.size()) { m_bits_geo.assign(m_meshes.size(), ~0ull); m_bits_tan.assign(m_meshes.size(), ~0ull); }
+            if (m_bits_geo[i] != mesh->m_geo_version) same &= ~PSDR_SAME_TRIANGLES;
+            if (m_bits_tan[i] != mesh->m_tan_version) same &= ~PSDR_SAME_TRI_TANGENTS;
+            m_bits_geo[i] = mesh->m_geo_version; m_bits_tan[i] = mesh->m_tan_version;
             const bool values = m_seen_geo[i] != mesh->m_geo_version, tangents = m_seen_tan[i] != mesh->m_tan_version;
-            if (values || tangents) write_rows(mesh, (size_t) face_offset, values, tangents);
-            if (values) same &= ~PSDR_SAME_TRIANGLES;
-            if (tangents) same &= ~PSDR_SAME_TRI_TANGENTS;
-            m_seen_geo[i] = mesh->m_geo_version; m_seen_tan[i] = mesh->m_tan_version;
+            if ((values || tangents) && !m_lean) {
+                const_cast<Mesh *>(mesh)->ensure_rows();
+                write_rows(mesh, (size_t) face_offset, values, tangents);
+                m_seen_geo[i] = mesh->m_geo_version; m_seen_tan[i] = mesh->m_tan_version;
+            }
             append_record(mesh);
         }
     }
@@ -768,6 +822,7 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
         write_rows(bound, (size_t) face_offset, true, true);
         append_record(bound);
         m_snap_keys.push_back(key_of(bound)); m_seen_geo.push_back(bound->m_geo_version); m_seen_tan.push_back(bound->m_tan_version);
+        m_bits_geo.push_back(bound->m_geo_version); m_bits_tan.push_back(bound->m_tan_version);
         geo_sum += bound->m_geo_version; tan_sum += bound->m_tan_version;
         ++m_layout_version;
         same &= ~(PSDR_SAME_TRIANGLES | PSDR_SAME_TRI_TANGENTS);
@@ -947,34 +1002,26 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
         std::vector<float> pmf;
         size_t total_edges = 0;
         for (const Mesh *mesh : m_meshes) if (mesh->m_enable_edges) total_edges += mesh->edges.size();
-        for (std::vector<float> *v : {&S.se_p0, &S.se_e1, &S.se_n0, &S.se_n1, &S.se_p2, &S.se_d_p0, &S.se_d_e1}) v->resize(3 * total_edges);
-        S.se_boundary.resize(total_edges); pmf.resize(total_edges);
+        pmf.resize(total_edges);
         size_t base = 0;
-        for (const Mesh *mesh : m_meshes) {
+        for (const Mesh *mesh : m_meshes) {          // the distribution over the edges (~ their lengths): always
             if (!mesh->m_enable_edges) continue;
             const int ne = (int) mesh->edges.size();
-            const float *P = mesh->vertex_positions.data(), *dP = mesh->d_vertex_positions.data();
+            const float *P = mesh->vertex_positions.data();
             psdr::parallel_for((size_t) ne, 4096, [&](size_t eb, size_t ee) {
               for (size_t i = eb; i < ee; ++i) {
                 const MeshEdge &e = mesh->edges[i];
-                const size_t r = base + i;
                 float e1[3];
-                for (int k = 0; k < 3; ++k) {
-                    e1[k] = P[3 * e.v1 + k] - P[3 * e.v0 + k];
-                    S.se_e1[3 * r + k] = e1[k]; S.se_d_e1[3 * r + k] = dP[3 * e.v1 + k] - dP[3 * e.v0 + k];
-                    S.se_p0[3 * r + k] = P[3 * e.v0 + k]; S.se_d_p0[3 * r + k] = dP[3 * e.v0 + k];
-                    S.se_p2[3 * r + k] = P[3 * e.opp + k];
-                    S.se_n0[3 * r + k] = mesh->tri[22 * (size_t) e.f0 + 18 + k];
-                    S.se_n1[3 * r + k] = e.f1 >= 0 ? mesh->tri[22 * (size_t) e.f1 + 18 + k] : 0.f;
-                }
-                S.se_boundary[r] = e.f1 < 0 ? 1 : 0;
-                pmf[r] = std::sqrt(std::fmaf(e1[2], e1[2], std::fmaf(e1[1], e1[1], e1[0] * e1[0])));
+                for (int k = 0; k < 3; ++k) e1[k] = P[3 * e.v1 + k] - P[3 * e.v0 + k];
+                pmf[base + i] = std::sqrt(std::fmaf(e1[2], e1[2], std::fmaf(e1[1], e1[1], e1[0] * e1[0])));
               }
             });
             base += (size_t) ne;
         }
         S.n_sec_edges = (int) pmf.size();
         if (!pmf.empty()) S.sec_edge_distrb.init(pmf);
+        m_sec_rows_stale = true;
+        if (!m_lean) fill_sec_rows();                 // (a lean configure leaves the row arrays to ensure_full_snapshot: the device computes its rows itself)
         if (m_opts.log_level > 0) { std::ostringstream oss; oss << S.n_sec_edges << " secondary edges initialized."; log(oss.str()); }
     }
 
@@ -1022,6 +1069,66 @@ void Scene::configure_host(const std::vector<int> &active_sensor) {
     if (env_cells_rebuilt) same &= ~PSDR_SAME_ENV_TEXELS;
     m_same &= same;              // (several configure_host() calls may pass before the next upload)
     m_host_ready = true;
+}
+
+// SecondaryEdgeInfo rows of the snapshot (mesh.cpp:355-369, scene.cpp:546-571): every edge of every mesh with edges, in mesh order
+void Scene::fill_sec_rows() {
+    Snapshot &S = snap;
+    size_t total_edges = 0;
+    for (const Mesh *mesh : m_meshes) if (mesh->m_enable_edges) total_edges += mesh->edges.size();
+    if (m_opts.sppse <= 0) total_edges = 0;
+    for (std::vector<float> *v : {&S.se_p0, &S.se_e1, &S.se_n0, &S.se_n1, &S.se_p2, &S.se_d_p0, &S.se_d_e1}) v->resize(3 * total_edges);
+    S.se_boundary.resize(total_edges);
+    size_t base = 0;
+    if (total_edges > 0)
+    for (const Mesh *mesh : m_meshes) {
+        if (!mesh->m_enable_edges) continue;
+        const int ne = (int) mesh->edges.size();
+        const float *P = mesh->vertex_positions.data(), *dP = mesh->d_vertex_positions.data();
+        psdr::parallel_for((size_t) ne, 4096, [&](size_t eb, size_t ee) {
+          for (size_t i = eb; i < ee; ++i) {
+            const MeshEdge &e = mesh->edges[i];
+            const size_t r = base + i;
+            for (int k = 0; k < 3; ++k) {
+                S.se_e1[3 * r + k] = P[3 * e.v1 + k] - P[3 * e.v0 + k]; S.se_d_e1[3 * r + k] = dP[3 * e.v1 + k] - dP[3 * e.v0 + k];
+                S.se_p0[3 * r + k] = P[3 * e.v0 + k]; S.se_d_p0[3 * r + k] = dP[3 * e.v0 + k];
+                S.se_p2[3 * r + k] = P[3 * e.opp + k];
+                S.se_n0[3 * r + k] = mesh->face_p0n[6 * (size_t) e.f0 + 3 + k];
+                S.se_n1[3 * r + k] = e.f1 >= 0 ? mesh->face_p0n[6 * (size_t) e.f1 + 3 + k] : 0.f;
+            }
+            S.se_boundary[r] = e.f1 < 0 ? 1 : 0;
+          }
+        });
+        base += (size_t) ne;
+    }
+    m_sec_rows_stale = false;
+}
+
+// what a lean configure_host left out: the TriangleInfo rows of the meshes that changed since the snapshot last held them, and the secondary-edge rows
+void Scene::ensure_full_snapshot() {
+    PSDR_ASSERT_MSG(m_host_ready, "configure_host() first");
+    Snapshot &S = snap;
+    auto put3 = [](std::vector<float> &dst, size_t row, const float *src) { dst[3 * row] = src[0]; dst[3 * row + 1] = src[1]; dst[3 * row + 2] = src[2]; };
+    size_t face_offset = 0;
+    for (size_t i = 0; i < m_meshes.size() && i < m_seen_geo.size(); ++i) {
+        Mesh *mesh = m_meshes[i];
+        const bool values = m_seen_geo[i] != mesh->m_geo_version, tangents = m_seen_tan[i] != mesh->m_tan_version;
+        if (values || tangents) {
+            mesh->ensure_rows();
+            const size_t nf = (size_t) mesh->m_num_faces;
+            psdr::parallel_for(nf, 4096, [&](size_t fb, size_t fe) {
+              for (size_t f = fb; f < fe; ++f) {
+                const size_t row = face_offset + f;
+                const float *t = &mesh->tri[22 * f], *d = &mesh->d_tri[22 * f];
+                if (values) { put3(S.p0, row, t); put3(S.e1, row, t + 3); put3(S.e2, row, t + 6); put3(S.n0, row, t + 9); put3(S.n1, row, t + 12); put3(S.n2, row, t + 15); put3(S.fn, row, t + 18); S.area[row] = t[21]; }
+                if (tangents) { put3(S.d_p0, row, d); put3(S.d_e1, row, d + 3); put3(S.d_e2, row, d + 6); put3(S.d_n0, row, d + 9); put3(S.d_n1, row, d + 12); put3(S.d_n2, row, d + 15); put3(S.d_fn, row, d + 18); S.d_area[row] = d[21]; }
+              }
+            });
+            m_seen_geo[i] = mesh->m_geo_version; m_seen_tan[i] = mesh->m_tan_version;
+        }
+        face_offset += (size_t) mesh->m_num_faces;
+    }
+    if (m_sec_rows_stale) fill_sec_rows();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1174,8 +1281,9 @@ Scene::GeometryAdjoint Scene::chain_geometry(int sensor_id, const float *g_tri, 
 
 // assemble the C-ABI snapshot and hand it to the HIP library (replaces Scene_OptiX::configure)
 // the configured snapshot as the C ABI's struct (pointers into `snap`, the sensors' edge lists and the meshes)
-void Scene::fill_snapshot(psdr_scene_snapshot &sn) {
+void Scene::fill_snapshot(psdr_scene_snapshot &sn, bool full) {
     PSDR_ASSERT_MSG(m_host_ready, "configure_host() first");
+    if (full) ensure_full_snapshot();
     Snapshot &S = snap;
     S.sensors.clear();
     sn = psdr_scene_snapshot{};
@@ -1238,6 +1346,12 @@ void Scene::fill_snapshot(psdr_scene_snapshot &sn) {
         }
         sn.geometry = complete ? m_geometry.data() : nullptr;
     }
+    // rows_valid = 0: the row arrays of psdr_triangles / psdr_sec_edges are behind (a lean configure) - psdr_hip_scene_update either computes the rows on the device or
+    // answers PSDR_HIP_NEED_ROWS without having changed anything
+    bool stale = m_sec_rows_stale && S.n_sec_edges > 0;
+    for (size_t i = 0; i < m_meshes.size() && i < m_seen_geo.size(); ++i) stale = stale || m_seen_geo[i] != m_meshes[i]->m_geo_version || m_seen_tan[i] != m_meshes[i]->m_tan_version;
+    sn.rows_valid = stale ? 0 : 1;
+    if (stale) PSDR_ASSERT_MSG(sn.geometry != nullptr, "lean snapshot without geometry");
 }
 
 // test aid: words of the device's triangle / secondary-edge rows that differ from the rows the host path would write (psdr_hip_scene_check_rows)
@@ -1252,7 +1366,9 @@ int64_t Scene::check_device_rows() {
 
 void Scene::upload() {
     psdr_scene_snapshot sn;
-    fill_snapshot(sn);
+    // a lean configure_host left the rows out: the device is asked first whether it can do without them
+    const bool try_lean = m_lean && m_hip != nullptr && !m_always_rebuild;
+    fill_snapshot(sn, !try_lean);
     // the device copy: created once, then updated in place - only what changed since the previous upload is rewritten and sent, the tree is kept
     // (refitted on the device when triangles moved); psdr_hip_scene_update, include/psdr_hip.h
     if (m_hip != nullptr && m_always_rebuild) release_device();
@@ -1262,16 +1378,22 @@ void Scene::upload() {
     } else {
         // a failed update leaves the device scene half-written (and poisoned, scene_build.hip): the PSDR_SAME_* bits of the NEXT configure() would be relative to a
         // snapshot the device never received, so the handle is dropped and the next upload creates the scene again
-        if (psdr_hip_scene_update(m_hip, &sn, m_same, &m_last_update)) {
+        int rc = psdr_hip_scene_update(m_hip, &sn, m_same, &m_last_update);
+        if (rc == PSDR_HIP_NEED_ROWS) {            // (the device scene is as it was: compute the rows after all and send the complete snapshot)
+            fill_snapshot(sn, true);
+            rc = psdr_hip_scene_update(m_hip, &sn, m_same, &m_last_update);
+        }
+        if (rc) {
             const std::string why = psdr_hip_last_error();
             release_device();
             m_same = 0;
-            m_up_geo.clear(); m_up_tan.clear();
+            m_up_geo.clear(); m_up_tan.clear(); m_device_rows_ok = false;
             throw Exception("libpsdr_hip: " + why);
         }
     }
     m_same = PSDR_SAME_TRIANGLES | PSDR_SAME_TRI_TANGENTS | PSDR_SAME_SEC_EDGES | PSDR_SAME_PRIM_EDGES | PSDR_SAME_ENV_TEXELS | PSDR_SAME_ENV_TANGENT | PSDR_SAME_BITMAPS;
     for (size_t i = 0; i < m_meshes.size() && i < m_up_geo.size(); ++i) { m_up_geo[i] = m_meshes[i]->m_geo_version; m_up_tan[i] = m_meshes[i]->m_tan_version; }
+    m_device_rows_ok = sn.geometry != nullptr;        // (the next configure_host may be lean: the device has the topology or will take it with the next update)
     m_configured = true;
 }
 

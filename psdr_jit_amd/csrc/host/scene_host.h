@@ -208,6 +208,12 @@ struct Mesh : Object, Transformable {
     Distrb face_distrb;
     // per-face TriangleInfo rows (value, tangent), 22 floats each: p0 e1 e2 n0 n1 n2 fn area
     std::vector<float> tri, d_tri;
+    // LEAN configure (round 6): when the device computes this mesh's rows itself (psdr_mesh_geometry) the host only needs, per face, the first vertex and the unit face
+    // normal (primary- and secondary-edge selection) and the area (face distribution) - face_p0n [nf*6], values only, the value parts of the same dual-number formulas -
+    // and leaves tri / d_tri for ensure_rows() to compute when a consumer asks (a device scene to create or rebuild, Scene::_snapshot, psdr_hip_scene_check_rows)
+    bool m_lean = false, rows_valid = false;
+    std::vector<float> face_p0n;
+    void ensure_rows();
     // configure() compares its inputs with the ones of its previous run and does nothing when they are the same (the reference recomputes and
     // re-uploads every mesh in every Scene::configure, src/scene/scene.cpp:346-371).  What it found: m_geo_version counts the runs in which a value
     // input (raw vertices, a to_world factor, the topology) differed, m_tan_version the runs in which a value or a tangent input differed -
@@ -280,7 +286,9 @@ struct Scene : Object {
     void configure(const std::vector<int> &active_sensor = {});
     void configure_host(const std::vector<int> &active_sensor = {});   // host half (no device needed)
     void upload();                                                      // BVH build + device upload
-    void fill_snapshot(psdr_scene_snapshot &sn);
+    void fill_snapshot(psdr_scene_snapshot &sn, bool full = true);
+    void ensure_full_snapshot();                                        // computes what a lean configure_host left out (rows of moved meshes, secondary-edge rows)
+    void fill_sec_rows();
     int64_t check_device_rows();
     bool is_ready() const;
     size_t get_num_emitters() const { return m_emitters.size(); }
@@ -338,7 +346,11 @@ private:
     struct MeshKey { const Mesh *mesh; uint64_t topo; int nf, bsdf, emitter; bool uv, flat, edges; bool operator==(const MeshKey &o) const { return mesh == o.mesh && topo == o.topo && nf == o.nf && bsdf == o.bsdf && emitter == o.emitter && uv == o.uv && flat == o.flat && edges == o.edges; } };
     std::vector<MeshKey> m_snap_keys;                      // the meshes the snapshot's rows were laid out for
     std::vector<uint64_t> m_seen_geo, m_seen_tan;          // per mesh: the versions its snapshot rows hold
+    std::vector<uint64_t> m_bits_geo, m_bits_tan;          // per mesh: the versions the PSDR_SAME_* bits were last derived from
+    bool m_lean = false;                                   // the configure_host in progress / last run was lean (see scene_host.cpp)
     std::vector<uint64_t> m_up_geo, m_up_tan;              // per mesh: the versions the device scene holds (psdr_mesh_geometry.moved)
+    bool m_sec_rows_stale = false;                         // lean configure: the secondary-edge row arrays of the snapshot are behind (their CDF is not)
+    bool m_device_rows_ok = false;                         // the last upload went through with the device computing the moved meshes' rows: the next configure_host may be lean
     std::vector<psdr_mesh_geometry> m_geometry;            // upload(): the per-mesh inputs of the device's row computation
     uint64_t m_layout_version = 0;                         // counts the configure_host() runs that laid the triangle rows out anew (another mesh list, topology or flag)
     uint64_t m_sec_layout = ~0ull;

@@ -156,6 +156,36 @@ def test_moved_meshes_get_their_rows_from_the_device(env, orc, monkeypatch):
     monkeypatch.delenv("PSDR_HOST_GEOMETRY")
     img_host = psdr.PathTracer(2).renderC(sc, 0, seed=3).cpu().numpy()
     assert product.rel_l2(img, img_host) < 1e-6
+    # the lean configures in between left the host's own rows to whoever asks: asked now, they are those of a scene built from scratch in this state, bit for bit
+    m0 = spec.meshes[0]
+    m0.vertices = v; m0.d_vertices = None; m0.path = None
+    t_last = np.eye(4, dtype=np.float32); t_last[0, 3] = 9.0; t_last[1, 3] = -4.0
+    m0.to_world_left = t_last; m0.d_to_world_left = dT
+    fresh = product.build_scene(spec, host_only=True)
+    a, b = sc._snapshot(), fresh._snapshot()
+    for k in ("triangles", "d_triangles", "sec_edges", "d_sec_edges"):
+        assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+
+
+def test_a_lean_configure_falls_back_to_the_rows_when_the_device_needs_them(env, orc):
+    """psdr_scene_snapshot.rows_valid = 0 (what a lean Scene.configure sends once the device computes the rows itself): an update that cannot do without the rows - here a
+    refit whose SAH cost calls for a new tree - answers PSDR_HIP_NEED_ROWS, the host computes the rows after all and the tree is built; hits stay bit-equal"""
+    torch, psdr, cabi = env
+    spec = scenes.config5_scene(32, 32, 1, 1, 1, level=4, env_res=(64, 32))
+    sc = product.build_scene(spec)
+    mesh = sc.param_map["Mesh[0]"]
+    v = np.asarray(spec.meshes[0].vertices, np.float32).copy()
+    mesh._set("vertex_positions", (v * 0.99).astype(np.float32), np.zeros_like(v))       # a first, gentle move: the device path, after which configures are lean
+    sc.configure([0])
+    assert sc._last_update()["tree"] == "refitted" and sc._check_device_rows() == 0
+    rng = np.random.default_rng(1)
+    v2 = (v * rng.uniform(0.2, 1.0, size=(len(v), 1))).astype(np.float32)
+    mesh._set("vertex_positions", v2, np.zeros_like(v2))
+    sc.configure([0])
+    assert sc._last_update()["tree"] == "built", sc._last_update()
+    assert _violations(cabi, sc) == 0 and sc._check_device_rows() == 0
+    spec.meshes[0].vertices = v2
+    _check_hits(torch, cabi, orc, sc, spec, n=8000, brute=2000)
 
 
 def test_a_scrambled_mesh_is_built_again(env, orc):
