@@ -353,7 +353,7 @@ static int geometry_on_device(psdr_hip_scene *sc, const psdr_scene_snapshot *s, 
     auto up = [&](const char *key, const void *src, size_t bytes) -> int {
         DevBuf &b = sc->buf(key);
         if (b.ensure(bytes)) return 1;
-        if (src) { HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, nullptr)); info.bytes_uploaded += (int64_t) bytes; }
+        if (src) { HIPCHK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice)); info.bytes_uploaded += (int64_t) bytes; }         // (synchronous: the sources are locals of this function)
         return 0;
     };
     if (!same_topo) {
